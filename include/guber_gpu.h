@@ -1,0 +1,237 @@
+/*
+ * guber_gpu.h — C ABI of the MI355X rate-limit evaluation engine.
+ *
+ * This is the drop-in boundary for ONE hot path of mailgun/gubernator: everything
+ * below `s.workerPool.GetRateLimit(ctx, r, reqState)` (reference gubernator.go:598),
+ * i.e. workers.go (WorkerPool) + algorithms.go (tokenBucket / leakyBucket) +
+ * lrucache.go / cache.go (Cache, CacheItem).  A Go `GPUWorkerPool` binds these
+ * entry points through cgo (see INTEGRATION.md and go/gpu_worker_pool.go); each
+ * entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; every pointer is caller-owned
+ *    unless the function name says `alloc`.
+ *  - return value: 0 (GUBER_OK) or a negative GUBER_E_* code; never throws.
+ *  - no caller memory is retained after a call returns (cgo pointer rule).
+ *  - `*_dev` variants take DEVICE pointers (HBM-resident SoA) and enqueue on the
+ *    engine stream without synchronising; the plain variants take HOST pointers,
+ *    stage through pinned buffers and return after the results are on the host.
+ *  - responses are positionally aligned with requests (gubernator.proto:51-54).
+ */
+#ifndef GUBER_GPU_H
+#define GUBER_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values = gubernator.proto:56-135) ------------------------------ */
+#define GUBER_ALGO_TOKEN_BUCKET 0u
+#define GUBER_ALGO_LEAKY_BUCKET 1u
+
+#define GUBER_STATUS_UNDER_LIMIT 0u
+#define GUBER_STATUS_OVER_LIMIT 1u
+
+#define GUBER_BEHAVIOR_NO_BATCHING 1u
+#define GUBER_BEHAVIOR_GLOBAL 2u
+#define GUBER_BEHAVIOR_DURATION_IS_GREGORIAN 4u
+#define GUBER_BEHAVIOR_RESET_REMAINING 8u
+#define GUBER_BEHAVIOR_MULTI_REGION 16u
+#define GUBER_BEHAVIOR_DRAIN_OVER_LIMIT 32u
+
+/* Gregorian interval selectors (interval.go:74-81) carried in `duration`. */
+#define GUBER_GREGORIAN_MINUTES 0
+#define GUBER_GREGORIAN_HOURS 1
+#define GUBER_GREGORIAN_DAYS 2
+#define GUBER_GREGORIAN_WEEKS 3
+#define GUBER_GREGORIAN_MONTHS 4
+#define GUBER_GREGORIAN_YEARS 5
+
+/* ---- call-level return codes ------------------------------------------------ */
+#define GUBER_OK 0
+#define GUBER_E_INVALID_ARG (-1)
+#define GUBER_E_NO_DEVICE (-2)     /* HIP runtime / GPU missing: the product path never falls back to CPU */
+#define GUBER_E_HIP (-3)           /* a HIP call failed; guber_last_error() has the text */
+#define GUBER_E_BATCH_TOO_LARGE (-4)
+#define GUBER_E_TABLE_FULL (-5)    /* open-addressed table above its load limit and nothing evictable */
+#define GUBER_E_NOMEM (-6)
+#define GUBER_E_KEY_TOO_LONG (-7)
+#define GUBER_E_NOT_FOUND (-8)
+
+/* ---- per-item error codes (guber_result_t.err) ------------------------------
+ * The reference surfaces these as RateLimitResp.Error strings; guber_item_strerror()
+ * returns the exact reference text. */
+#define GUBER_ITEM_OK 0u
+#define GUBER_ITEM_E_INVALID_ALGORITHM 1u /* workers.go:318  "Invalid rate limit algorithm '%d'" */
+#define GUBER_ITEM_E_GREGORIAN_WEEKS 2u   /* interval.go:93,136 */
+#define GUBER_ITEM_E_GREGORIAN_INVALID 3u /* interval.go:107,147 */
+#define GUBER_ITEM_E_EMPTY_KEY 4u         /* gubernator.go:208-217 (host validation normally catches it) */
+#define GUBER_ITEM_E_RETRY 5u             /* internal: two new keys with one 64-bit hash in one batch; the
+                                             host layer re-submits these items, callers never see it */
+
+typedef struct guber_engine guber_engine_t;
+
+/* Engine configuration.  Replaces Config.{CacheSize,Workers,CacheFactory}
+ * (reference config.go:73-123, workers.go:125-147). */
+typedef struct guber_config {
+    uint32_t struct_size;    /* sizeof(guber_config_t), for ABI growth */
+    int32_t device;          /* HIP device ordinal */
+    uint64_t cache_size;     /* max resident rate limits (Config.CacheSize, default 50_000) */
+    uint64_t table_slots;    /* 0 = derive: next pow2 >= 2*cache_size (load factor <= 0.5) */
+    uint32_t max_batch;      /* largest n accepted by one eval call (0 = 65536) */
+    uint32_t max_key_bytes;  /* longest single key accepted (0 = 1024) */
+    void* stream;            /* optional caller-owned hipStream_t; NULL = engine creates its own */
+    uint32_t flags;          /* reserved, 0 */
+    uint32_t reserved;
+} guber_config_t;
+
+/* One batch of rate-limit checks, structure-of-arrays, all arrays length n.
+ * Field meaning = RateLimitReq (gubernator.proto:137-182).  The key is the
+ * reference's HashKey(): name + "_" + unique_key (client.go:39-41). */
+typedef struct guber_batch {
+    uint32_t n;
+    uint32_t reserved;
+    const uint8_t* key_bytes;   /* concatenated keys */
+    const uint32_t* key_off;    /* n+1 offsets into key_bytes */
+    const int64_t* hits;
+    const int64_t* limit;
+    const int64_t* duration;
+    const int64_t* burst;       /* NULL = all 0 (leaky then defaults burst to limit, algorithms.go:264) */
+    const int64_t* created_at;  /* NULL = all now_ms (gubernator.go:218-220) */
+    const uint8_t* algorithm;   /* 0 token, 1 leaky; anything else -> GUBER_ITEM_E_INVALID_ALGORITHM */
+    const uint32_t* behavior;   /* Behavior bit set */
+    const uint8_t* is_owner;    /* RateLimitReqState.IsOwner; NULL = all 1 */
+    /* Host-precomputed calendar values for DURATION_IS_GREGORIAN items (interval.go:84-148),
+     * NULL when no item carries the bit.  greg_duration < 0 encodes the reference's error:
+     * -GUBER_ITEM_E_GREGORIAN_WEEKS or -GUBER_ITEM_E_GREGORIAN_INVALID. */
+    const int64_t* greg_expire;
+    const int64_t* greg_duration;
+    int64_t now_ms;             /* MillisecondNow() at batch evaluation (lrucache.go:106, cache.go:44) */
+} guber_batch_t;
+
+/* Results, SoA, arrays length n; field meaning = RateLimitResp (gubernator.proto:189-203). */
+typedef struct guber_result {
+    uint8_t* status;
+    int64_t* limit;
+    int64_t* remaining;
+    int64_t* reset_time;
+    uint8_t* err;               /* GUBER_ITEM_* */
+    /* per-batch aggregates the Go shim adds to the reference's prometheus vars
+     * (algorithms.go:165,185,243,391,409,471; lrucache.go:117,121,126,144). Host variants fill
+     * them on return; device variants leave them 0 — read guber_stats() after synchronising. */
+    uint64_t over_limit_count;
+    uint64_t cache_hits;
+    uint64_t cache_misses;
+    uint64_t unexpired_evictions;
+    int64_t cache_size;
+} guber_result_t;
+
+/* A materialised CacheItem (cache.go:29-41) with its TokenBucketItem / LeakyBucketItem
+ * (store.go:29-43) flattened.  Used by AddCacheItem / GetCacheItem / Load / Store. */
+typedef struct guber_item {
+    uint8_t algorithm;   /* CacheItem.Algorithm */
+    uint8_t status;      /* TokenBucketItem.Status (token only) */
+    uint16_t reserved0;
+    uint32_t key_len;
+    const uint8_t* key;  /* CacheItem.Key bytes; for outputs points into the caller's key arena */
+    int64_t limit;
+    int64_t duration;
+    int64_t remaining;        /* token: TokenBucketItem.Remaining */
+    double remaining_f;       /* leaky: LeakyBucketItem.Remaining */
+    int64_t stamp;            /* token: CreatedAt; leaky: UpdatedAt */
+    int64_t burst;            /* leaky only */
+    int64_t expire_at;        /* CacheItem.ExpireAt */
+    int64_t invalid_at;       /* CacheItem.InvalidAt */
+} guber_item_t;
+
+typedef struct guber_stats {
+    uint64_t over_limit_count;
+    uint64_t cache_hits;
+    uint64_t cache_misses;
+    uint64_t unexpired_evictions;
+    int64_t cache_size;       /* LRUCache.Size() (lrucache.go:159) */
+    uint64_t table_slots;
+    uint64_t tags_used;       /* claimed directory entries (live + tombstoned keys) */
+    uint64_t batches;
+    uint64_t retries;         /* GUBER_ITEM_E_RETRY re-submissions */
+} guber_stats_t;
+
+/* ---- lifecycle: NewWorkerPool / WorkerPool.Close (workers.go:125,157) -------- */
+int guber_engine_create(const guber_config_t* cfg, guber_engine_t** out);
+void guber_engine_destroy(guber_engine_t* e);
+
+/* ---- the hot path: WorkerPool.GetRateLimit for a whole batch (workers.go:261-324,
+ *      algorithms.go:37-493).  Host pointers in, host results out. */
+int guber_eval_batch(guber_engine_t* e, const guber_batch_t* batch, guber_result_t* result);
+
+/* Same, every pointer inside batch/result is a DEVICE pointer (the structs themselves live on
+ * the host).  Asynchronous on the engine stream. */
+int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_result_t* result);
+
+/* ---- WorkerPool.AddCacheItem (workers.go:537; callers gubernator.go:452 UpdatePeerGlobals,
+ *      workers.go:329 Load).  Add semantics = LRUCache.Add (lrucache.go:88): replace if present.
+ *      existed[i] (optional) receives Add's return value. */
+int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed);
+
+/* ---- WorkerPool.GetCacheItem (workers.go:583) = LRUCache.GetItem (lrucache.go:111): an expired
+ *      item is removed and reported absent.  *found = 0/1.  out->key is not filled. */
+int guber_get_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len, int64_t now_ms,
+                   guber_item_t* out, int* found);
+
+/* ---- LRUCache.Remove (lrucache.go:131) */
+int guber_remove_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len);
+
+/* ---- LRUCache.Size (lrucache.go:159) */
+int64_t guber_size(guber_engine_t* e);
+
+/* ---- WorkerPool.Store / LRUCache.Each (workers.go:451, lrucache.go:76): dump every resident
+ *      item.  items[0..cap) and key_arena[0..arena_cap) are caller buffers; *n_out gets the item
+ *      count.  Returns GUBER_E_NOMEM if a buffer is too small (then *n_out / *arena_out hold the
+ *      needed sizes). */
+int guber_dump(guber_engine_t* e, guber_item_t* items, uint64_t cap, uint8_t* key_arena,
+               uint64_t arena_cap, uint64_t* n_out, uint64_t* arena_out);
+
+int guber_stats(guber_engine_t* e, guber_stats_t* out);
+int guber_synchronize(guber_engine_t* e);
+
+/* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
+void* guber_alloc_pinned(size_t bytes);
+void guber_free_pinned(void* p);
+
+/* ---- key -> shard routing = ReplicatedConsistentHash (replicated_hash.go:29-119).
+ *      hash_kind 0 = fnv1 (library default, replicated_hash.go:33), 1 = fnv1a (config.go:429). */
+typedef struct guber_ring guber_ring_t;
+int guber_ring_create(const char* const* peer_names, uint32_t n_peers, uint32_t replicas,
+                      int hash_kind, guber_ring_t** out);
+void guber_ring_destroy(guber_ring_t* r);
+/* owner[i] = index into peer_names of the peer owning key i (host arrays). */
+int guber_ring_route(const guber_ring_t* r, const uint8_t* key_bytes, const uint32_t* key_off,
+                     uint32_t n, uint32_t* owner);
+/* Same on DEVICE arrays, enqueued on the engine's stream (router kernel: fnv1-64 + binary search
+ * of the sorted ring staged in LDS). */
+int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_bytes,
+                         const uint32_t* key_off, uint32_t n, uint32_t* owner);
+uint32_t guber_ring_points(const guber_ring_t* r, uint64_t* hashes, uint32_t* owners, uint32_t cap);
+
+/* ---- calendar helpers the host layer uses to fill greg_expire / greg_duration
+ *      (interval.go:84-148), UTC. Return 0 or -GUBER_ITEM_E_GREGORIAN_*. */
+int guber_gregorian_expiration(int64_t now_unix_nano, int64_t d, int64_t* expire_ms);
+int guber_gregorian_duration(int64_t now_unix_nano, int64_t d, int64_t* duration);
+
+/* ---- hashes on the path (third-party in the reference, see oracle/README.md) */
+uint64_t guber_xxhash64(const uint8_t* p, size_t len, uint64_t seed); /* OneOfOne/xxhash, workers.go:154 */
+uint64_t guber_fnv1_64(const uint8_t* p, size_t len);                 /* segmentio/fasthash fnv1 */
+uint64_t guber_fnv1a_64(const uint8_t* p, size_t len);                /* segmentio/fasthash fnv1a */
+
+const char* guber_strerror(int code);
+const char* guber_item_strerror(uint8_t item_err);
+const char* guber_last_error(void);
+const char* guber_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUBER_GPU_H */

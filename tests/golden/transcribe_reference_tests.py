@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.json — the golden vectors the reference's OWN tests hold for the
+rate-limit hot path, transcribed by hand as data tables (the reference is Go and cannot be run
+in this image; see oracle/guber_oracle.c header).  Every scenario cites the reference test
+(file:line in /root/reference) whose table it transcribes.
+
+Scenario format: a frozen clock starting at `start_ms`; each step sends ONE request at the current
+clock and then advances the clock by `advance_ms` (functional_test.go uses clock.Freeze /
+clock.Advance the same way).  `expect` holds what the reference test asserts:
+  status, remaining, limit            exact values
+  reset_nonzero                       assert.True(rl.ResetTime != 0)
+  reset_time                          exact value
+  reset_s_offset                      ResetTime/1000 - now.Unix()  (the leaky tests' formula
+                                      clock.Now().Unix()+(rl.Limit-rl.Remaining)*3 == rl.ResetTime/1000)
+
+Run:  python tests/golden/transcribe_reference_tests.py
+"""
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TOKEN, LEAKY = 0, 1
+UNDER, OVER = 0, 1
+GREGORIAN, RESET_REMAINING, DRAIN = 4, 8, 32
+SECOND, MINUTE = 1000, 60000
+GREG_MINUTES = 0
+START = 1_573_430_430_123  # arbitrary frozen clock, deliberately not on a second boundary
+
+
+def req(name, key, algo, duration, limit, hits, behavior=0, burst=0):
+    return dict(name=name, unique_key=key, algorithm=algo, duration=duration, limit=limit, hits=hits,
+                behavior=behavior, burst=burst)
+
+
+scenarios = []
+
+
+def scenario(name, source, steps, start_ms=START):
+    scenarios.append(dict(name=name, source=source, start_ms=start_ms, steps=steps))
+
+
+# functional_test.go:65-110 TestOverTheLimit
+scenario("TestOverTheLimit", "functional_test.go:65-110", [
+    dict(req=req("test_over_limit", "account:1234", TOKEN, 9 * SECOND, 2, 1),
+         expect=dict(status=s, remaining=r, limit=2, reset_nonzero=True), advance_ms=0)
+    for r, s in [(1, UNDER), (0, UNDER), (0, OVER)]])
+
+# functional_test.go:115-158 TestMultipleAsync (two keys in ONE request batch)
+scenarios.append(dict(name="TestMultipleAsync", source="functional_test.go:115-158", start_ms=START, batch_steps=[
+    dict(reqs=[req("test_multiple_async", "account:9234", TOKEN, 9 * SECOND, 2, 1),
+               req("test_multiple_async", "account:5678", TOKEN, 9 * SECOND, 10, 5)],
+         expect=[dict(status=UNDER, remaining=1, limit=2), dict(status=UNDER, remaining=5, limit=10)],
+         advance_ms=0)]))
+
+# functional_test.go:160-219 TestTokenBucket
+scenario("TestTokenBucket", "functional_test.go:160-219", [
+    dict(req=req("test_token_bucket", "account:1234", TOKEN, 5, 2, 1),
+         expect=dict(status=s, remaining=r, limit=2, reset_nonzero=True), advance_ms=sl)
+    for r, s, sl in [(1, UNDER, 0), (0, UNDER, 100), (1, UNDER, 0)]])
+
+# functional_test.go:221-294 TestTokenBucketGregorian
+scenario("TestTokenBucketGregorian", "functional_test.go:221-294", [
+    dict(req=req("test_token_bucket_greg", "account:12345", TOKEN, GREG_MINUTES, 60, h, behavior=GREGORIAN),
+         expect=dict(status=s, remaining=r, limit=60, reset_nonzero=True), advance_ms=sl)
+    for h, r, s, sl in [(1, 59, UNDER, 0), (1, 58, UNDER, 0), (58, 0, UNDER, 0), (1, 0, OVER, 61 * SECOND),
+                        (0, 60, UNDER, 0)]])
+
+# functional_test.go:296-366 TestTokenBucketNegativeHits
+scenario("TestTokenBucketNegativeHits", "functional_test.go:296-366", [
+    dict(req=req("test_token_bucket_negative", "account:12345", TOKEN, 5, 2, h),
+         expect=dict(status=s, remaining=r, limit=2, reset_nonzero=True), advance_ms=0)
+    for h, r, s in [(-1, 3, UNDER), (-1, 4, UNDER), (4, 0, UNDER), (-1, 1, UNDER)]])
+
+# functional_test.go:368-432 TestDrainOverLimit (both algorithms, separate keys)
+for idx, algo in enumerate([TOKEN, LEAKY]):
+    scenario(f"TestDrainOverLimit/{['TOKEN_BUCKET', 'LEAKY_BUCKET'][idx]}", "functional_test.go:368-432", [
+        dict(req=req("test_drain_over_limit", f"account:1234:{idx}", algo, 30 * SECOND, 10, h, behavior=DRAIN),
+             expect=dict(status=s, remaining=r, limit=10, reset_nonzero=True), advance_ms=0)
+        for h, r, s in [(0, 10, UNDER), (1, 9, UNDER), (100, 0, OVER), (0, 0, UNDER)]])
+
+# functional_test.go:434-475 TestTokenBucketRequestMoreThanAvailable
+scenario("TestTokenBucketRequestMoreThanAvailable", "functional_test.go:434-475", [
+    dict(req=req("test_token_more_than_available", "account:123456", TOKEN, 1000, 2000, h),
+         expect=dict(status=s, remaining=r, limit=2000), advance_ms=0)
+    for s, r, h in [(UNDER, 1000, 1000), (OVER, 1000, 1500), (UNDER, 500, 500), (UNDER, 100, 400), (UNDER, 0, 100),
+                    (OVER, 0, 1)]])
+
+# functional_test.go:477-602 TestLeakyBucket (limit 10 / 30 s => one hit leaks every 3 s)
+scenario("TestLeakyBucket", "functional_test.go:477-602", [
+    dict(req=req("test_leaky_bucket", "account:1234", LEAKY, 30 * SECOND, 10, h),
+         expect=dict(status=s, remaining=r, limit=10, reset_s_offset=(10 - r) * 3), advance_ms=sl)
+    for h, r, s, sl in [(1, 9, UNDER, 1000), (1, 8, UNDER, 1000), (1, 7, UNDER, 1500), (0, 8, UNDER, 3000),
+                        (0, 9, UNDER, 0), (9, 0, UNDER, 0), (1, 0, OVER, 3000), (0, 1, UNDER, 60000),
+                        (0, 10, UNDER, 60000), (10, 0, UNDER, 29000), (9, 0, UNDER, 3000), (1, 0, UNDER, 1000)]])
+
+# functional_test.go:604-709 TestLeakyBucketWithBurst
+scenario("TestLeakyBucketWithBurst", "functional_test.go:604-709", [
+    dict(req=req("test_leaky_bucket_with_burst", "account:1234", LEAKY, 30 * SECOND, 10, h, burst=20),
+         expect=dict(status=s, remaining=r, limit=10, reset_s_offset=(10 - r) * 3), advance_ms=sl)
+    for h, r, s, sl in [(1, 19, UNDER, 1000), (1, 18, UNDER, 1000), (1, 17, UNDER, 1500), (0, 18, UNDER, 3000),
+                        (0, 19, UNDER, 0), (19, 0, UNDER, 0), (1, 0, OVER, 3000), (0, 1, UNDER, 60000),
+                        (0, 20, UNDER, 1000)]])
+
+# functional_test.go:711-779 TestLeakyBucketGregorian (clock 100 ms past a minute boundary, :750-754)
+scenario("TestLeakyBucketGregorian", "functional_test.go:711-779", [
+    dict(req=req("TestLeakyBucketGregorian", "greg-key-01", LEAKY, GREG_MINUTES, 60, h, behavior=GREGORIAN),
+         expect=dict(status=s, remaining=r, limit=60, reset_nonzero=True), advance_ms=sl)
+    for h, r, s, sl in [(1, 59, UNDER, 500), (1, 58, UNDER, 1200), (1, 58, UNDER, 0)]],
+    start_ms=(START // MINUTE) * MINUTE + 100)
+
+# functional_test.go:781-850 TestLeakyBucketNegativeHits
+scenario("TestLeakyBucketNegativeHits", "functional_test.go:781-850", [
+    dict(req=req("test_leaky_bucket_negative", "account:12345", LEAKY, 30 * SECOND, 10, h),
+         expect=dict(status=s, remaining=r, limit=10, reset_s_offset=(10 - r) * 3), advance_ms=0)
+    for h, r, s in [(1, 9, UNDER), (-1, 10, UNDER), (10, 0, UNDER), (-1, 1, UNDER)]])
+
+# functional_test.go:852-894 TestLeakyBucketRequestMoreThanAvailable
+scenario("TestLeakyBucketRequestMoreThanAvailable", "functional_test.go:852-894", [
+    dict(req=req("test_leaky_more_than_available", "account:123456", LEAKY, 1000, 2000, h),
+         expect=dict(status=s, remaining=r, limit=2000), advance_ms=0)
+    for s, r, h in [(UNDER, 1000, 1000), (OVER, 1000, 1500), (UNDER, 500, 500), (UNDER, 100, 400), (UNDER, 0, 100),
+                    (OVER, 0, 1)]])
+
+# functional_test.go:896-957 TestMissingFields.  The two validation errors come from
+# gubernator.go:208-217 (host layer), the first two rows reach the algorithm.
+scenario("TestMissingFields", "functional_test.go:896-957", [
+    dict(req=req("test_missing_fields", "account:1234", TOKEN, 0, 10, 1), expect=dict(status=UNDER, error=""),
+         advance_ms=0),
+    dict(req=req("test_missing_fields", "account:12345", TOKEN, 10000, 0, 1), expect=dict(status=OVER, error=""),
+         advance_ms=0),
+    dict(req=req("", "account:1234", TOKEN, 10000, 5, 1),
+         expect=dict(status=UNDER, error="field 'namespace' cannot be empty"), advance_ms=0),
+    dict(req=req("test_missing_fields", "", TOKEN, 10000, 5, 1),
+         expect=dict(status=UNDER, error="field 'unique_key' cannot be empty"), advance_ms=0)])
+
+# functional_test.go:1343-1436 TestChangeLimit (same key, the algorithm switches after row 5)
+scenario("TestChangeLimit", "functional_test.go:1343-1436", [
+    dict(req=req("test_change_limit", "account:1234", a, 9000, lim, 1),
+         expect=dict(status=UNDER, remaining=r, limit=lim, reset_nonzero=True), advance_ms=0)
+    for a, r, lim in [(TOKEN, 99, 100), (TOKEN, 98, 100), (TOKEN, 7, 10), (TOKEN, 6, 10), (TOKEN, 195, 200),
+                      (LEAKY, 99, 100), (LEAKY, 9, 10), (LEAKY, 8, 10)]])
+
+# functional_test.go:1438-1508 TestResetRemaining
+scenario("TestResetRemaining", "functional_test.go:1438-1508", [
+    dict(req=req("test_reset_remaining", "account:1234", TOKEN, 9000, 100, 1, behavior=b),
+         expect=dict(status=UNDER, remaining=r, limit=100), advance_ms=0)
+    for b, r in [(0, 99), (0, 98), (RESET_REMAINING, 100), (0, 99)]])
+
+# functional_test.go:1535-1576 TestLeakyBucketDivBug (rate 0.5 ms per hit)
+scenario("TestLeakyBucketDivBug", "functional_test.go:1535-1576", [
+    dict(req=req("TestLeakyBucketDivBug", "divbug-key1", LEAKY, 1000, 2000, 1),
+         expect=dict(status=UNDER, remaining=1999, limit=2000, error=""), advance_ms=0),
+    dict(req=req("TestLeakyBucketDivBug", "divbug-key1", LEAKY, 1000, 2000, 100),
+         expect=dict(remaining=1899, limit=2000), advance_ms=0)])
+
+with open(os.path.join(HERE, "functional_vectors.json"), "w") as f:
+    json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 tests by transcribe_reference_tests.py",
+                   scenarios=scenarios), f, indent=1)
+
+# ------------------------------------------------------------------------------------------------
+# store_test.go: pre-loaded items (what Store.Get / Loader.Load hand to the cache) then one request
+# ------------------------------------------------------------------------------------------------
+NOW = START
+store_cases = [
+    # store_test.go:76-125 TestLoader: after one hit the saved item is {Limit 2, Remaining 1, UNDER}
+    dict(name="TestLoader", source="store_test.go:76-125", now_ms=NOW, preload=[],
+         req=req("test_over_limit", "account:1234", TOKEN, SECOND, 2, 1),
+         expect_resp=dict(error=""),
+         expect_item=dict(algorithm=TOKEN, limit=2, remaining=1, status=UNDER), expect_size=1),
+    # store_test.go:266-296 "Found in store after cache miss" (token: createBucketItem :198-205)
+    dict(name="TestStore/Token/FoundInStore", source="store_test.go:266-296", now_ms=NOW,
+         preload=[dict(key="test_over_limit_account:1234", algorithm=TOKEN, limit=10, duration=SECOND,
+                       remaining=10, stamp=NOW, expire_at=NOW + SECOND)],
+         req=req("test_over_limit", "account:1234", TOKEN, SECOND, 10, 1),
+         expect_resp=dict(status=UNDER, limit=10), expect_item=dict(algorithm=TOKEN, limit=10, duration=SECOND)),
+    # same, leaky (createBucketItem :206-211 leaves Remaining 0 and Burst 0)
+    dict(name="TestStore/Leaky/FoundInStore", source="store_test.go:266-296", now_ms=NOW,
+         preload=[dict(key="test_over_limit_account:1234", algorithm=LEAKY, limit=10, duration=SECOND,
+                       remaining_f=0.0, stamp=NOW, burst=0, expire_at=NOW + SECOND)],
+         req=req("test_over_limit", "account:1234", LEAKY, SECOND, 10, 1),
+         expect_resp=dict(status=UNDER, limit=10), expect_item=dict(algorithm=LEAKY, limit=10, duration=SECOND)),
+    # store_test.go:352-436 "Duration changed": ExpireAt == CreatedAt + newDuration
+    dict(name="TestStore/Token/DurationChanged", source="store_test.go:352-436", now_ms=NOW,
+         preload=[dict(key="test_over_limit_account:1234", algorithm=TOKEN, limit=10, duration=5000, remaining=10,
+                       stamp=NOW, expire_at=NOW + 5000)],
+         req=req("test_over_limit", "account:1234", TOKEN, 8000, 10, 1),
+         expect_resp=dict(status=UNDER, limit=10),
+         expect_item=dict(algorithm=TOKEN, limit=10, duration=8000, expire_at_minus_stamp=8000)),
+    # store_test.go:438-529 "Duration changed and immediately expired": renewed
+    dict(name="TestStore/Token/DurationChangedExpired", source="store_test.go:438-529", now_ms=NOW,
+         preload=[dict(key="test_over_limit_account:1234", algorithm=TOKEN, limit=10, duration=500000, remaining=10,
+                       stamp=NOW - 100000, expire_at=NOW - 100000 + 500000)],
+         req=req("test_over_limit", "account:1234", TOKEN, 8000, 10, 1),
+         expect_resp=dict(status=UNDER, limit=10),
+         expect_item=dict(algorithm=TOKEN, limit=10, duration=8000, expire_at_minus_stamp=8000, stamp=NOW)),
+]
+with open(os.path.join(HERE, "store_vectors.json"), "w") as f:
+    json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 store_test.go", cases=store_cases), f, indent=1)
+
+# ------------------------------------------------------------------------------------------------
+# known-answer tests: interval_test.go, replicated_hash_test.go, workers_internal_test.go
+# ------------------------------------------------------------------------------------------------
+def utc_ms(y, mo, d, h=0, mi=0, s=0, ns=0):
+    import calendar
+    return calendar.timegm((y, mo, d, h, mi, s)) * 1000 + ns // 1_000_000
+
+
+def utc_ns(y, mo, d, h=0, mi=0, s=0, ns=0):
+    import calendar
+    return calendar.timegm((y, mo, d, h, mi, s)) * 1_000_000_000 + ns
+
+
+kats = dict(
+    gregorian_expiration=[
+        # interval_test.go:47-59
+        dict(now_ns=utc_ns(2019, 11, 11), d=0, expire=utc_ms(2019, 11, 11, 0, 0, 59, 999000000)),
+        dict(now_ns=utc_ns(2019, 11, 11, 0, 0, 30, 100), d=0, expire=1573430459999),
+        # :61-73
+        dict(now_ns=utc_ns(2019, 11, 11), d=1, expire=utc_ms(2019, 11, 11, 0, 59, 59, 999000000)),
+        dict(now_ns=utc_ns(2019, 11, 11, 0, 20, 1, 2134), d=1, expire=1573433999999),
+        # :75-87
+        dict(now_ns=utc_ns(2019, 11, 11), d=2, expire=utc_ms(2019, 11, 11, 23, 59, 59, 999000000)),
+        dict(now_ns=utc_ns(2019, 11, 11, 12, 10, 9, 2345), d=2, expire=1573516799999),
+        # :89-109
+        dict(now_ns=utc_ns(2019, 11, 1), d=4, expire=utc_ms(2019, 11, 30, 23, 59, 59, 999000000)),
+        dict(now_ns=utc_ns(2019, 11, 11, 22, 2, 23, 0), d=4, expire=1575158399999),
+        dict(now_ns=utc_ns(2019, 1, 1), d=4, expire=utc_ms(2019, 1, 31, 23, 59, 59, 999999999)),
+        # :111-123 (Go normalises second 1231 -> +20m31s)
+        dict(now_ns=utc_ns(2019, 1, 1), d=5, expire=utc_ms(2019, 12, 31, 23, 59, 59, 999000000)),
+        dict(now_ns=utc_ns(2019, 3, 1, 20, 30, 0, 0) + 1231 * 1_000_000_000, d=5, expire=1577836799999),
+    ],
+    gregorian_invalid=dict(now_ns=utc_ns(2019, 1, 1), d=99, expire=0,  # :125-131
+                           error="behavior DURATION_IS_GREGORIAN is set; but `Duration` is not a valid gregorian interval"),
+    # replicated_hash_test.go:56-100: 10 000 keys 192.168.(i>>8).(i&255), 512 replicas
+    ring_distribution=dict(hosts=["a.svc.local", "b.svc.local", "c.svc.local"], replicas=512, n_keys=10000,
+                           fnv1={"a.svc.local": 2948, "b.svc.local": 3592, "c.svc.local": 3460},
+                           fnv1a={"a.svc.local": 3110, "b.svc.local": 3856, "c.svc.local": 3034}),
+    # workers_internal_test.go:37-54: 32 workers
+    worker_index=[dict(workers=32, hash63=0, idx=0), dict(workers=32, hash63=0x3fffffffffffffff, idx=15),
+                  dict(workers=32, hash63=0x4000000000000000, idx=16),
+                  dict(workers=32, hash63=0x7fffffffffffffff, idx=31)],
+)
+with open(os.path.join(HERE, "kat_vectors.json"), "w") as f:
+    json.dump(kats, f, indent=1)
+print("wrote", len(scenarios), "scenarios,", len(store_cases), "store cases")
