@@ -1,0 +1,385 @@
+// guber_algo.h — per-bucket state machine of the rate-limit path, written once and compiled for the
+// gfx950 kernels (hipcc) and, for CPU unit tests of the kernel logic only, for the host (g++).
+//
+// What it computes follows the reference's algorithms.go (mailgun/gubernator v2):
+//   apply()  = one GetRateLimit on one bucket: LRUCache.GetItem expiry check (lrucache.go:111-128,
+//              cache.go:43-57) + tokenBucket / leakyBucket (algorithms.go:37-493) + the algorithm
+//              switch of handleGetRateLimit (workers.go:293-324).
+//   skip()   = k further IDENTICAL requests applied to a bucket, in O(1) for the regimes hot keys
+//              live in (plain subtraction, fixed points, period-2 cycles) and by stepping otherwise.
+//              This is what lets a batch with thousands of hits on one key be evaluated by
+//              independent threads, each reconstructing "the state just before my request".
+// How it is organised (one 64-byte record per bucket, explicit `now`, per-request created_at, dense
+// flags instead of Go interfaces) is this engine's own design.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GB_HD __host__ __device__ __forceinline__
+#else
+#define GB_HD inline
+#endif
+
+namespace guber {
+
+// ---- enums (gubernator.proto:56-135) --------------------------------------------------------
+enum : uint32_t { ALGO_TOKEN = 0, ALGO_LEAKY = 1 };
+enum : uint32_t { ST_UNDER = 0, ST_OVER = 1 };
+enum : uint32_t {
+    BH_NO_BATCHING = 1, BH_GLOBAL = 2, BH_GREGORIAN = 4, BH_RESET_REMAINING = 8, BH_MULTI_REGION = 16,
+    BH_DRAIN_OVER_LIMIT = 32
+};
+enum : uint8_t { IE_OK = 0, IE_INVALID_ALGORITHM = 1, IE_GREG_WEEKS = 2, IE_GREG_INVALID = 3, IE_EMPTY_KEY = 4, IE_RETRY = 5 };
+
+// record kinds: the dynamic type of CacheItem.Value (cache.go:32)
+enum : uint32_t { K_ABSENT = 0, K_TOKEN = 1, K_LEAKY = 2, K_NIL = 3 };
+
+// apply() event flags
+enum : uint32_t { EV_HIT = 1, EV_MISS = 2, EV_OVER = 4 };
+
+// ---- Go integer / float semantics -----------------------------------------------------------
+GB_HD int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+GB_HD int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+GB_HD int64_t wmul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
+// float64 -> int64 as Go on amd64 (CVTTSD2SQ): NaN, +-Inf and out-of-range give INT64_MIN.
+GB_HD int64_t go_f2i(double d) {
+    if (!(d >= -9223372036854775808.0 && d < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t)d;
+}
+GB_HD double bits2f(int64_t b) { union { int64_t i; double d; } u; u.i = b; return u.d; }
+GB_HD int64_t f2bits(double d) { union { int64_t i; double d; } u; u.d = d; return u.i; }
+
+// ---- one bucket: CacheItem + TokenBucketItem | LeakyBucketItem (cache.go:29-41, store.go:29-43)
+struct alignas(16) Rec {
+    int64_t limit;       // Limit
+    int64_t duration;    // Duration
+    int64_t remaining;   // token: Remaining (int64); leaky: Remaining (float64 bits)
+    int64_t stamp;       // token: CreatedAt; leaky: UpdatedAt
+    int64_t burst;       // leaky: Burst
+    int64_t expire_at;   // CacheItem.ExpireAt
+    int64_t invalid_at;  // CacheItem.InvalidAt
+    uint32_t meta;       // kind | status << 8 | CacheItem.Algorithm << 16
+    uint32_t pad;
+};
+static_assert(sizeof(Rec) == 64, "one record = one 64-byte sector");
+
+GB_HD uint32_t rec_kind(const Rec& s) { return s.meta & 0xffu; }
+GB_HD uint32_t rec_status(const Rec& s) { return (s.meta >> 8) & 0xffu; }
+GB_HD uint32_t rec_algo(const Rec& s) { return (s.meta >> 16) & 0xffu; }
+GB_HD uint32_t make_meta(uint32_t kind, uint32_t status, uint32_t algo) { return kind | (status << 8) | (algo << 16); }
+GB_HD void rec_set_status(Rec& s, uint32_t st) { s.meta = (s.meta & ~0xff00u) | (st << 8); }
+GB_HD void rec_clear(Rec& s) {
+    s.limit = s.duration = s.remaining = s.stamp = s.burst = s.expire_at = s.invalid_at = 0;
+    s.meta = 0; s.pad = 0;
+}
+GB_HD bool rec_eq(const Rec& a, const Rec& b) {
+    return a.limit == b.limit && a.duration == b.duration && a.remaining == b.remaining && a.stamp == b.stamp &&
+           a.burst == b.burst && a.expire_at == b.expire_at && a.invalid_at == b.invalid_at && a.meta == b.meta;
+}
+// cache.go:43-57 IsExpired
+GB_HD bool rec_expired(const Rec& s, int64_t now) {
+    return (s.invalid_at != 0 && s.invalid_at < now) || s.expire_at < now;
+}
+
+struct Req {
+    int64_t hits, limit, duration, burst, created_at;
+    int64_t greg_expire, greg_duration;  // host-precomputed interval.go values; greg_duration < 0 = -error
+    uint32_t behavior;
+    uint8_t algorithm, is_owner;
+};
+GB_HD bool req_eq(const Req& a, const Req& b) {
+    return a.hits == b.hits && a.limit == b.limit && a.duration == b.duration && a.burst == b.burst &&
+           a.created_at == b.created_at && a.greg_expire == b.greg_expire && a.greg_duration == b.greg_duration &&
+           a.behavior == b.behavior && a.algorithm == b.algorithm;  // is_owner only feeds a counter
+}
+
+struct Resp {
+    int64_t limit, remaining, reset_time;
+    uint8_t status, err;
+};
+GB_HD void resp_clear(Resp& r) { r.limit = r.remaining = r.reset_time = 0; r.status = 0; r.err = 0; }
+
+// algorithms.go:206-257 tokenBucketNewItem
+GB_HD uint32_t token_new_item(Rec& s, const Req& r, Resp& rl) {
+    uint32_t ev = 0;
+    int64_t expire = wadd(r.created_at, r.duration);
+    int64_t remaining = wsub(r.limit, r.hits);
+    if (r.behavior & BH_GREGORIAN) {
+        if (r.greg_duration < 0) { resp_clear(rl); rl.err = (uint8_t)(-r.greg_duration); return ev; }
+        expire = r.greg_expire;
+    }
+    rl.status = ST_UNDER; rl.limit = r.limit; rl.remaining = remaining; rl.reset_time = expire;
+    if (r.hits > r.limit) {
+        if (r.is_owner) ev |= EV_OVER;
+        rl.status = ST_OVER; rl.remaining = r.limit; remaining = r.limit;
+    }
+    rec_clear(s);
+    s.limit = r.limit; s.duration = r.duration; s.remaining = remaining; s.stamp = r.created_at;
+    s.expire_at = expire; s.meta = make_meta(K_TOKEN, ST_UNDER, ALGO_TOKEN);
+    return ev;
+}
+
+// algorithms.go:437-493 leakyBucketNewItem (`burst` = r.Burst after the :264 defaulting)
+GB_HD uint32_t leaky_new_item(Rec& s, const Req& r, int64_t burst, int64_t now, Resp& rl) {
+    uint32_t ev = 0;
+    int64_t duration = r.duration;
+    double rate = (double)duration / (double)r.limit;
+    if (r.behavior & BH_GREGORIAN) {
+        if (r.greg_duration < 0) { resp_clear(rl); rl.err = (uint8_t)(-r.greg_duration); return ev; }
+        duration = wsub(r.greg_expire, now);
+    }
+    int64_t bh = wsub(burst, r.hits);
+    double remaining = (double)bh;
+    int64_t irate = go_f2i(rate);
+    rl.status = ST_UNDER; rl.limit = r.limit; rl.remaining = bh;
+    rl.reset_time = wadd(r.created_at, wmul(wsub(r.limit, bh), irate));
+    if (r.hits > burst) {
+        if (r.is_owner) ev |= EV_OVER;
+        rl.status = ST_OVER; rl.remaining = 0;
+        rl.reset_time = wadd(r.created_at, wmul(wsub(rl.limit, rl.remaining), irate));
+        remaining = 0.0;
+    }
+    rec_clear(s);
+    s.limit = r.limit; s.duration = duration; s.remaining = f2bits(remaining); s.stamp = r.created_at;
+    s.burst = burst; s.expire_at = wadd(r.created_at, duration);
+    s.meta = make_meta(K_LEAKY, 0, r.algorithm);
+    return ev;
+}
+
+// One GetRateLimit on one bucket.  `s` is the bucket before and after; returns EV_* flags.
+GB_HD uint32_t apply(Rec& s, const Req& r, int64_t now, Resp& rl) {
+    resp_clear(rl);
+    if (r.algorithm > ALGO_LEAKY) { rl.err = IE_INVALID_ALGORITHM; return 0; }  // workers.go:317-321
+    uint32_t ev;
+    bool ok = false;
+    // lrucache.go:111-128 GetItem: an expired item is removed and reported as a miss
+    if (rec_kind(s) != K_ABSENT) {
+        if (rec_expired(s, now)) { rec_clear(s); ev = EV_MISS; }
+        else { ev = EV_HIT; ok = true; }
+    } else ev = EV_MISS;
+    if (ok && rec_kind(s) == K_NIL) ok = false;  // algorithms.go:55-63 / :284-292 "Value is nil"
+
+    if (r.algorithm == ALGO_TOKEN) {
+        if (!ok) return ev | token_new_item(s, r, rl);                       // :202
+        if (r.behavior & BH_RESET_REMAINING) {                               // :78-90
+            rec_clear(s);
+            rl.status = ST_UNDER; rl.limit = r.limit; rl.remaining = r.limit; rl.reset_time = 0;
+            return ev;
+        }
+        if (rec_kind(s) != K_TOKEN) { rec_clear(s); return ev | token_new_item(s, r, rl); }  // :91-103
+        if (s.limit != r.limit) {                                            // :106-113
+            s.remaining = wadd(s.remaining, wsub(r.limit, s.limit));
+            if (s.remaining < 0) s.remaining = 0;
+            s.limit = r.limit;
+        }
+        rl.status = (uint8_t)rec_status(s); rl.limit = r.limit;              // :115-120
+        rl.remaining = s.remaining; rl.reset_time = s.expire_at;
+        if (s.duration != r.duration) {                                      // :123-147
+            int64_t expire = wadd(s.stamp, r.duration);
+            if (r.behavior & BH_GREGORIAN) {
+                if (r.greg_duration < 0) { resp_clear(rl); rl.err = (uint8_t)(-r.greg_duration); return ev; }
+                expire = r.greg_expire;
+            }
+            if (expire <= r.created_at) {                                    // renew; rl.remaining stays stale
+                expire = wadd(r.created_at, r.duration);
+                s.stamp = r.created_at;
+                s.remaining = s.limit;
+            }
+            s.expire_at = expire; s.duration = r.duration; rl.reset_time = expire;
+        }
+        if (r.hits == 0) return ev;                                          // :157-159
+        if (rl.remaining == 0 && r.hits > 0) {                               // :162-170 sticky status
+            if (r.is_owner) ev |= EV_OVER;
+            rl.status = ST_OVER; rec_set_status(s, ST_OVER);
+            return ev;
+        }
+        if (s.remaining == r.hits) { s.remaining = 0; rl.remaining = 0; return ev; }  // :173-178
+        if (r.hits > s.remaining) {                                          // :182-194
+            if (r.is_owner) ev |= EV_OVER;
+            rl.status = ST_OVER;
+            if (r.behavior & BH_DRAIN_OVER_LIMIT) { s.remaining = 0; rl.remaining = 0; }
+            return ev;
+        }
+        s.remaining = wsub(s.remaining, r.hits); rl.remaining = s.remaining;  // :196-198
+        return ev;
+    }
+
+    // ---- leaky bucket, algorithms.go:260-434
+    int64_t burst = r.burst;
+    if (burst == 0) burst = r.limit;                                         // :264-266
+    if (!ok) return ev | leaky_new_item(s, r, burst, now, rl);               // :433
+    if (rec_kind(s) != K_LEAKY) { rec_clear(s); return ev | leaky_new_item(s, r, burst, now, rl); }  // :308-318
+    double rem = bits2f(s.remaining);
+    if (r.behavior & BH_RESET_REMAINING) rem = (double)burst;                // :320-322
+    if (s.burst != burst) {                                                  // :325-330
+        if (burst > go_f2i(rem)) rem = (double)burst;
+        s.burst = burst;
+    }
+    s.limit = r.limit; s.duration = r.duration;                              // :332-333
+    int64_t duration = r.duration;
+    double rate = (double)duration / (double)r.limit;                        // :336
+    if (r.behavior & BH_GREGORIAN) {                                         // :338-354
+        if (r.greg_duration < 0) { s.remaining = f2bits(rem); resp_clear(rl); rl.err = (uint8_t)(-r.greg_duration); return ev; }
+        rate = (double)r.greg_duration / (double)r.limit;
+        duration = wsub(r.greg_expire, now);
+    }
+    if (r.hits != 0) s.expire_at = wadd(r.created_at, duration);             // :356-358 UpdateExpiration
+    int64_t elapsed = wsub(r.created_at, s.stamp);                           // :361-367
+    double leak = (double)elapsed / rate;
+    if (go_f2i(leak) > 0) { rem = rem + leak; s.stamp = r.created_at; }
+    if (go_f2i(rem) > s.burst) rem = (double)s.burst;                        // :369-371
+    int64_t irate = go_f2i(rate);
+    int64_t irem = go_f2i(rem);
+    rl.limit = s.limit; rl.remaining = irem; rl.status = ST_UNDER;           // :373-378
+    rl.reset_time = wadd(r.created_at, wmul(wsub(s.limit, irem), irate));
+    if (irem == 0 && r.hits > 0) {                                           // :389-395
+        if (r.is_owner) ev |= EV_OVER;
+        rl.status = ST_OVER;
+    } else if (irem == r.hits) {                                             // :398-403
+        rem = 0.0; rl.remaining = 0;
+        rl.reset_time = wadd(r.created_at, wmul(wsub(rl.limit, rl.remaining), irate));
+    } else if (r.hits > irem) {                                              // :407-420
+        if (r.is_owner) ev |= EV_OVER;
+        rl.status = ST_OVER;
+        if (r.behavior & BH_DRAIN_OVER_LIMIT) { rem = 0.0; rl.remaining = 0; }
+    } else if (r.hits != 0) {                                                // :423-430
+        rem = rem - (double)r.hits;
+        rl.remaining = go_f2i(rem);
+        rl.reset_time = wadd(r.created_at, wmul(wsub(rl.limit, rl.remaining), irate));
+    }
+    s.remaining = f2bits(rem);
+    return ev;
+}
+
+// True when `after` is `before` with Remaining reduced by exactly r.hits (> 0) and nothing else
+// touched: the "plain subtraction" step of algorithms.go:196-198 / :427-430.
+// The guards make the extrapolation in skip() safe: the bucket is live at `now`, the request does
+// not reset or reconfigure it, so the next step sees the same branch conditions except Remaining.
+GB_HD bool pure_subtract(const Rec& before, const Rec& after, const Req& r, int64_t now) {
+    if (r.hits <= 0 || (r.behavior & BH_RESET_REMAINING)) return false;
+    if (before.limit != after.limit || before.duration != after.duration || before.stamp != after.stamp ||
+        before.burst != after.burst || before.expire_at != after.expire_at || before.invalid_at != after.invalid_at ||
+        before.meta != after.meta)
+        return false;
+    if (rec_expired(after, now) || after.limit != r.limit) return false;
+    uint32_t k = rec_kind(after);
+    if (k == K_TOKEN) {
+        if (r.algorithm != ALGO_TOKEN || after.duration != r.duration) return false;
+        return before.remaining > 0 && after.remaining == before.remaining - r.hits && after.remaining >= 0;
+    }
+    if (k == K_LEAKY) {
+        if (r.algorithm != ALGO_LEAKY || after.burst != (r.burst == 0 ? r.limit : r.burst)) return false;
+        double b = bits2f(before.remaining), a = bits2f(after.remaining);
+        return b >= 0.0 && b < 9007199254740992.0 && a >= 0.0 && a == b - (double)r.hits;
+    }
+    return false;
+}
+
+// Advance `s` by k further applications of the SAME request r (same now), exactly.
+//  * fixed point (apply leaves the bucket unchanged): the remaining steps are identity;
+//  * period-2 cycle (e.g. token RESET_REMAINING alternating remove / create): parity decides;
+//  * an observed plain subtraction is extrapolated: with n = int(Remaining) after the step, the next
+//    (n-1)/hits steps are plain subtractions too (a step is plain iff hits < n); for the leaky
+//    bucket every intermediate float64 is exact because hits is an integer, Remaining < 2^53 and the
+//    magnitude only shrinks, so R - j*hits in one operation equals j successive subtractions bit for bit;
+//  * anything else is stepped one request at a time (always correct, O(k)).
+GB_HD void skip(Rec& s, const Req& r, int64_t now, uint64_t k) {
+    Rec prev2; rec_clear(prev2);
+    bool have_prev2 = false;
+    Resp tmp;
+    while (k > 0) {
+        Rec before = s;
+        apply(s, r, now, tmp);
+        k--;
+        if (rec_eq(s, before)) return;                      // fixed point
+        if (have_prev2 && rec_eq(s, prev2)) {               // period 2: s == state two steps ago
+            if (k & 1) s = before;
+            return;
+        }
+        prev2 = before; have_prev2 = true;
+        if (k > 0 && pure_subtract(before, s, r, now)) {
+            uint32_t kind = rec_kind(s);
+            int64_t n = kind == K_TOKEN ? s.remaining : go_f2i(bits2f(s.remaining));
+            if (n > 0) {
+                uint64_t m = (uint64_t)(n - 1) / (uint64_t)r.hits;
+                uint64_t j = m < k ? m : k;
+                if (j > 0) {
+                    int64_t dec = (int64_t)(j * (uint64_t)r.hits);  // <= n-1, exact
+                    if (kind == K_TOKEN) s.remaining -= dec;
+                    else s.remaining = f2bits(bits2f(s.remaining) - (double)dec);
+                    k -= j;
+                    have_prev2 = false;
+                }
+            }
+        }
+    }
+}
+
+// Response of the request of rank `rank` (0-based) in a run of identical requests applied to the
+// bucket s0; `s_after` is the bucket right after that request (the run's final state when rank is the
+// last).  Every thread of a run calls this independently: no inter-thread dependency, no atomics.
+GB_HD uint32_t eval_uniform_rank(const Rec& s0, const Req& r, int64_t now, uint64_t rank, Resp& out, Rec& s_after) {
+    s_after = s0;
+    if (rank > 0) {
+        Resp tmp;
+        apply(s_after, r, now, tmp);
+        skip(s_after, r, now, rank - 1);
+    }
+    return apply(s_after, r, now, out);
+}
+
+// ---- hashes on the path ----------------------------------------------------------------------
+// XXH64 (published xxHash spec); the reference hashes the key with it to pick a worker shard
+// (workers.go:153-155, OneOfOne/xxhash v1.2.8); here it addresses the HBM bucket directory.
+namespace xxh {
+constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+GB_HD uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+GB_HD uint64_t round1(uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; }
+GB_HD uint64_t merge(uint64_t acc, uint64_t v) { return (acc ^ round1(0, v)) * P1 + P4; }
+GB_HD uint64_t ld64(const uint8_t* p) {
+    uint64_t v; __builtin_memcpy(&v, p, 8); return v;
+}
+GB_HD uint32_t ld32(const uint8_t* p) {
+    uint32_t v; __builtin_memcpy(&v, p, 4); return v;
+}
+}  // namespace xxh
+
+GB_HD uint64_t xxhash64(const uint8_t* p, uint32_t len, uint64_t seed) {
+    using namespace xxh;
+    const uint8_t* end = p + len;
+    uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        const uint8_t* lim = end - 32;
+        do {
+            v1 = round1(v1, ld64(p)); v2 = round1(v2, ld64(p + 8));
+            v3 = round1(v3, ld64(p + 16)); v4 = round1(v4, ld64(p + 24));
+            p += 32;
+        } while (p <= lim);
+        h = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+        h = merge(h, v1); h = merge(h, v2); h = merge(h, v3); h = merge(h, v4);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint64_t)len;
+    while (p + 8 <= end) { h ^= round1(0, ld64(p)); h = rotl(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= end) { h ^= (uint64_t)ld32(p) * P1; h = rotl(h, 23) * P2 + P3; p += 4; }
+    while (p < end) { h ^= (uint64_t)(*p) * P5; h = rotl(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+// FNV-1 / FNV-1a 64 (segmentio/fasthash v1.0.2; replicated_hash.go:33, config.go:429-433)
+GB_HD uint64_t fnv1_64(const uint8_t* p, uint32_t len) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (uint32_t i = 0; i < len; i++) { h *= 0x100000001b3ULL; h ^= p[i]; }
+    return h;
+}
+GB_HD uint64_t fnv1a_64(const uint8_t* p, uint32_t len) {
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (uint32_t i = 0; i < len; i++) { h ^= p[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+
+}  // namespace guber

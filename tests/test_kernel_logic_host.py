@@ -1,0 +1,178 @@
+"""CPU differential tests of the KERNEL LOGIC (gubernator_amd/csrc/guber_algo.h: apply / skip /
+eval_uniform_rank, XXH64, FNV) compiled for the host by tests/hostsim — against the oracle.  These
+de-risk the HIP path on a machine with no GPU; the parity tests proper are the -m gpu ones."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import xxhash
+
+import scenarios
+import streams
+import support
+from support import HostBatch, HostResult, GuberBatch, GuberResult, GuberItem, Oracle
+
+HS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+_lib = None
+
+
+def hostsim_lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(HS_DIR, "libhostsim.so")
+        srcs = [os.path.join(HS_DIR, "hostsim.cpp"), os.path.join(support.ROOT, "gubernator_amd/csrc/guber_algo.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.run(["g++", "-O2", "-g", "-fPIC", "-std=c++17", "-fwrapv", "-ffp-contract=off", "-shared",
+                            "-o", so, srcs[0]], check=True)
+        lib = C.CDLL(so)
+        lib.hs_create.restype = C.c_void_p
+        lib.hs_destroy.argtypes = [C.c_void_p]
+        lib.hs_eval_batch.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int]
+        lib.hs_add_item.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.POINTER(C.c_int)]
+        lib.hs_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
+                                    C.POINTER(C.c_int)]
+        lib.hs_size.restype = C.c_int64
+        lib.hs_size.argtypes = [C.c_void_p]
+        lib.hs_xxhash64.restype = C.c_uint64
+        lib.hs_xxhash64.argtypes = [C.c_char_p, C.c_uint32, C.c_uint64]
+        lib.hs_fnv1_64.restype = C.c_uint64
+        lib.hs_fnv1_64.argtypes = [C.c_char_p, C.c_uint32]
+        lib.hs_fnv1a_64.restype = C.c_uint64
+        lib.hs_fnv1a_64.argtypes = [C.c_char_p, C.c_uint32]
+        _lib = lib
+    return _lib
+
+
+class HostSim:
+    def __init__(self, mode=0):
+        self.lib = hostsim_lib()
+        self.h = self.lib.hs_create()
+        self.mode = mode
+
+    def close(self):
+        if self.h:
+            self.lib.hs_destroy(self.h)
+            self.h = None
+
+    def eval(self, batch):
+        res = HostResult(batch.n)
+        self.lib.hs_eval_batch(self.h, C.byref(batch.c), C.byref(res.c), self.mode)
+        return res
+
+    def add_item(self, item, now_ms=0):
+        ex = C.c_int(0)
+        self.lib.hs_add_item(self.h, C.byref(item), C.byref(ex))
+        return bool(ex.value)
+
+    def get_item(self, key, now_ms):
+        kb = key if isinstance(key, bytes) else key.encode()
+        out, found = GuberItem(), C.c_int(0)
+        self.lib.hs_get_item(self.h, kb, len(kb), now_ms, C.byref(out), C.byref(found))
+        return support.item_dict(out, kb) if found.value else None
+
+    def size(self):
+        return self.lib.hs_size(self.h)
+
+    def each(self):
+        raise NotImplementedError
+
+
+def test_device_hashes_match_independent_implementations():
+    lib = hostsim_lib()
+    olib = support.oracle_lib()
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 100)) + [255, 256, 1000]:
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert lib.hs_xxhash64(b, n, 0) == xxhash.xxh64(b, seed=0).intdigest()
+        assert lib.hs_xxhash64(b, n, 77) == xxhash.xxh64(b, seed=77).intdigest()
+        assert lib.hs_fnv1_64(b, n) == olib.oracle_fnv1_64(b, n)
+        assert lib.hs_fnv1a_64(b, n) == olib.oracle_fnv1a_64(b, n)
+
+
+def test_golden_vectors_through_kernel_logic():
+    assert scenarios.run_functional(lambda: HostSim()) >= 75
+    for case in scenarios.load("store_vectors.json")["cases"]:
+        case.pop("expect_size", None)
+
+    # store vectors (no Each on the host sim)
+    import json
+    n = 0
+    orig = scenarios.load
+
+    def load_no_size(name):
+        d = orig(name)
+        if name == "store_vectors.json":
+            for c in d["cases"]:
+                c.pop("expect_size", None)
+        return d
+    scenarios.load = load_no_size
+    try:
+        n = scenarios.run_store(lambda: HostSim())
+    finally:
+        scenarios.load = orig
+    assert n == 5
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_adversarial_streams_closed_form_vs_oracle(seed):
+    o, h = Oracle(cache_size=1 << 20), HostSim(mode=0)
+    total = 0
+    for bi, b in enumerate(streams.adversarial_batches(seed, 120, 400, greg_fn=support.gregorian)):
+        want, got = o.eval(b), h.eval(b)
+        support.assert_results_equal(got, want, f"seed {seed} batch {bi}")
+        assert got.counters()[:3] == want.counters()[:3], f"counters seed {seed} batch {bi}"
+        assert h.size() == o.size(), f"size seed {seed} batch {bi}"
+        total += b.n
+    assert total > 20000
+
+
+def test_hot_key_uniform_runs_long():
+    """One key hit thousands of times in a batch (the Zipf head): ranks far beyond the bucket's
+    remaining, with and without DRAIN, both algorithms, fractional leaky remainders."""
+    now = streams.NOW0
+    for algo in (0, 1):
+        for beh in (0, 32):
+            for hits, limit in [(1, 100), (3, 100), (7, 1000), (1, 5000), (5, 5)]:
+                o, h = Oracle(cache_size=1 << 16), HostSim(mode=0)
+                for step in range(4):
+                    n = 6000
+                    keys = [b"hot_key"] * n
+                    b = HostBatch(keys, hits, limit, 60_000, now + step * 1700, algorithm=algo, behavior=beh)
+                    support.assert_results_equal(h.eval(b), o.eval(b), f"algo {algo} beh {beh} hits {hits} step {step}")
+
+
+def test_zipf_bench_stream_small():
+    tab = streams.key_table(50_000)
+    z = streams.ZipfSampler(50_000)
+    for algo in (0, 1):
+        o, h = Oracle(cache_size=1 << 20), HostSim(mode=0)
+        for bi in range(6):
+            b = streams.bench_batch(tab, z.draw(8192), streams.NOW0 + bi * 20_000, algorithm=algo)
+            support.assert_results_equal(h.eval(b), o.eval(b), f"algo {algo} batch {bi}")
+
+
+def test_random_uniform_runs_vs_oracle():
+    """Many short scenarios: one key, a random pre-state built by 1-3 random requests, then a run of
+    n identical requests whose rank-wise answers must match the sequential oracle."""
+    rng = np.random.default_rng(99)
+    now = streams.NOW0
+    for trial in range(1500):
+        o, h = Oracle(cache_size=1 << 12), HostSim(mode=0)
+        t = now
+        for phase in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([1, 2, 3, 17, 64, 300]))
+            hits = int(rng.choice([0, 1, 2, 3, 5, 9, -1, 50]))
+            limit = int(rng.choice([0, 1, 7, 10, 100, 250]))
+            duration = int(rng.choice([0, 3, 100, 1000, 60000]))
+            algo = int(rng.choice([0, 1]))
+            beh = int(rng.choice([0, 0, 0, 32, 8, 40]))
+            burst = int(rng.choice([0, 0, 15, 300]))
+            created = t + int(rng.choice([0, 0, -5, 5, -2000]))
+            b = HostBatch([b"solo_key"] * n, hits, limit, duration, t, burst=burst, created_at=created,
+                          algorithm=algo, behavior=beh)
+            support.assert_results_equal(h.eval(b), o.eval(b), f"trial {trial} phase {phase}")
+            assert h.size() == o.size()
+            t += int(rng.choice([0, 1, 2, 40, 150, 1200, 70000]))
+        o.close(); h.close()
