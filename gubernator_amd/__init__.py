@@ -1,0 +1,236 @@
+"""gubernator_amd — MI355X-native rate-limit evaluation engine (drop-in for gubernator's
+WorkerPool.GetRateLimit path).  This package is a thin ctypes binding over the C ABI declared in
+include/guber_gpu.h and implemented by gubernator_amd/libguber_hip.so (hand-written HIP for gfx950).
+
+There is NO CPU fallback: importing works anywhere (so the ABI can be inspected), but creating an
+Engine without the built library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .abi import (GuberBatch, GuberConfig, GuberItem, GuberResult, GuberStats, HostBatch, HostResult,  # noqa: F401
+                  item_dict, make_item)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libguber_hip.so")
+
+# every symbol include/guber_gpu.h declares
+ABI_SYMBOLS = [
+    "guber_engine_create", "guber_engine_destroy", "guber_eval_batch", "guber_eval_batch_dev", "guber_add_items",
+    "guber_get_item", "guber_remove_item", "guber_size", "guber_dump", "guber_stats", "guber_synchronize",
+    "guber_alloc_pinned", "guber_free_pinned", "guber_ring_create", "guber_ring_destroy", "guber_ring_route",
+    "guber_ring_route_dev", "guber_ring_points", "guber_gregorian_expiration", "guber_gregorian_duration",
+    "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
+    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read",
+]
+
+_lib = None
+
+
+class GuberError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"guber error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libguber_hip.so (built by __graft_entry__.build() / gubernator_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GuberError(-2, f"{LIB_PATH} is missing: build it with `make -C gubernator_amd/csrc` "
+                                 "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.guber_engine_create.argtypes = [C.POINTER(GuberConfig), C.POINTER(C.c_void_p)]
+        L.guber_engine_destroy.argtypes = [C.c_void_p]
+        L.guber_engine_destroy.restype = None
+        for name in ("guber_eval_batch", "guber_eval_batch_dev"):
+            getattr(L, name).argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult)]
+        L.guber_add_items.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_uint32, C.c_void_p]
+        L.guber_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
+                                     C.POINTER(C.c_int)]
+        L.guber_remove_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.guber_size.restype = C.c_int64
+        L.guber_size.argtypes = [C.c_void_p]
+        L.guber_dump.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_uint64, C.c_void_p, C.c_uint64,
+                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
+        L.guber_synchronize.argtypes = [C.c_void_p]
+        L.guber_profile_enable.argtypes = [C.c_void_p, C.c_int]
+        L.guber_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.guber_alloc_pinned.restype = C.c_void_p
+        L.guber_alloc_pinned.argtypes = [C.c_size_t]
+        L.guber_free_pinned.argtypes = [C.c_void_p]
+        L.guber_free_pinned.restype = None
+        L.guber_ring_create.argtypes = [C.POINTER(C.c_char_p), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
+        L.guber_ring_destroy.argtypes = [C.c_void_p]
+        L.guber_ring_destroy.restype = None
+        L.guber_ring_route.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.guber_ring_route_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.guber_ring_points.restype = C.c_uint32
+        L.guber_ring_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.guber_gregorian_expiration.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+        L.guber_gregorian_duration.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_int64)]
+        L.guber_xxhash64.restype = C.c_uint64
+        L.guber_xxhash64.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64]
+        L.guber_fnv1_64.restype = C.c_uint64
+        L.guber_fnv1_64.argtypes = [C.c_char_p, C.c_size_t]
+        L.guber_fnv1a_64.restype = C.c_uint64
+        L.guber_fnv1a_64.argtypes = [C.c_char_p, C.c_size_t]
+        for name in ("guber_strerror", "guber_item_strerror", "guber_last_error", "guber_version"):
+            getattr(L, name).restype = C.c_char_p
+        L.guber_strerror.argtypes = [C.c_int]
+        L.guber_item_strerror.argtypes = [C.c_uint8]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        L = lib()
+        raise GuberError(rc, f"{L.guber_strerror(rc).decode()} ({L.guber_last_error().decode()})")
+
+
+def gregorian(now_ms, d):
+    """(greg_expire, greg_duration) for a DURATION_IS_GREGORIAN request (interval.go:84-148);
+    greg_duration < 0 carries the reference's error."""
+    L = lib()
+    e, g = C.c_int64(0), C.c_int64(0)
+    rc = L.guber_gregorian_expiration(now_ms * 1_000_000, d, C.byref(e))
+    rc2 = L.guber_gregorian_duration(now_ms * 1_000_000, d, C.byref(g))
+    if rc != 0 or rc2 != 0:
+        return 0, rc if rc != 0 else rc2
+    return e.value, g.value
+
+
+class Ring:
+    """ReplicatedConsistentHash (replicated_hash.go): which peer / GPU owns a key."""
+
+    def __init__(self, peers, replicas=512, hash_kind="fnv1"):
+        self.peers = list(peers)
+        arr = (C.c_char_p * len(self.peers))(*[p.encode() for p in self.peers])
+        self.h = C.c_void_p()
+        _check(lib().guber_ring_create(arr, len(self.peers), replicas, 1 if hash_kind == "fnv1a" else 0,
+                                       C.byref(self.h)))
+
+    def route(self, keys):
+        if isinstance(keys, tuple):
+            kb, ko = keys
+        else:
+            hb = HostBatch(keys, 0, 0, 0, 0)
+            kb, ko = hb.key_bytes, hb.key_off
+        n = len(ko) - 1
+        owner = np.zeros(max(n, 1), np.uint32)
+        _check(lib().guber_ring_route(self.h, kb.ctypes.data, ko.ctypes.data, n, owner.ctypes.data))
+        return owner[:n]
+
+    def points(self):
+        n = lib().guber_ring_points(self.h, None, None, 0)
+        hh, oo = np.zeros(n, np.uint64), np.zeros(n, np.uint32)
+        lib().guber_ring_points(self.h, hh.ctypes.data, oo.ctypes.data, n)
+        return hh, oo
+
+    def close(self):
+        if self.h:
+            lib().guber_ring_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One GPU-resident bucket table + the batched evaluation kernels (C ABI guber_engine_*)."""
+
+    def __init__(self, cache_size=50_000, device=0, max_batch=65536, table_slots=0, max_key_bytes=0, stream=None,
+                 flags=0):
+        cfg = GuberConfig(C.sizeof(GuberConfig), device, cache_size, table_slots, max_batch, max_key_bytes,
+                          stream, flags, 0)
+        self.h = C.c_void_p()
+        _check(lib().guber_engine_create(C.byref(cfg), C.byref(self.h)))
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().guber_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- hot path -------------------------------------------------------------------------------
+    def eval(self, batch):
+        """HostBatch -> HostResult through guber_eval_batch (host pointers, synchronous)."""
+        res = HostResult(batch.n)
+        _check(lib().guber_eval_batch(self.h, C.byref(batch.c), C.byref(res.c)))
+        return res
+
+    def eval_dev(self, batch_struct, result_struct):
+        """GuberBatch / GuberResult whose pointers are DEVICE pointers; asynchronous."""
+        _check(lib().guber_eval_batch_dev(self.h, C.byref(batch_struct), C.byref(result_struct)))
+
+    # -- cache operations -----------------------------------------------------------------------
+    def add_item(self, item, now_ms=0):
+        ex = (C.c_uint8 * 1)()
+        _check(lib().guber_add_items(self.h, C.byref(item), 1, ex))
+        return bool(ex[0])
+
+    def add_items(self, items):
+        arr = (GuberItem * len(items))(*items)
+        ex = (C.c_uint8 * max(len(items), 1))()
+        _check(lib().guber_add_items(self.h, arr, len(items), ex))
+        return [bool(x) for x in ex[:len(items)]]
+
+    def get_item(self, key, now_ms):
+        kb = key if isinstance(key, bytes) else key.encode()
+        out, found = GuberItem(), C.c_int(0)
+        _check(lib().guber_get_item(self.h, kb, len(kb), now_ms, C.byref(out), C.byref(found)))
+        return item_dict(out, kb) if found.value else None
+
+    def remove_item(self, key):
+        kb = key if isinstance(key, bytes) else key.encode()
+        _check(lib().guber_remove_item(self.h, kb, len(kb)))
+
+    def size(self):
+        return lib().guber_size(self.h)
+
+    def each(self):
+        n, a = C.c_uint64(0), C.c_uint64(0)
+        rc = lib().guber_dump(self.h, None, 0, None, 0, C.byref(n), C.byref(a))
+        if rc not in (0, -6):
+            _check(rc)
+        cap, acap = n.value + 16, a.value + 1024
+        items = (GuberItem * cap)()
+        arena = C.create_string_buffer(acap)
+        _check(lib().guber_dump(self.h, items, cap, arena, acap, C.byref(n), C.byref(a)))
+        return [item_dict(items[i]) for i in range(n.value)]
+
+    def stats(self):
+        s = GuberStats()
+        _check(lib().guber_stats(self.h, C.byref(s)))
+        return {f[0]: getattr(s, f[0]) for f in GuberStats._fields_}
+
+    def profile(self, enable):
+        _check(lib().guber_profile_enable(self.h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel name: (launches, total_ms)} since the last read."""
+        arr = (abi.GuberKernelTime * 16)()
+        n = C.c_uint32(0)
+        _check(lib().guber_profile_read(self.h, arr, 16, C.byref(n)))
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+
+    def synchronize(self):
+        _check(lib().guber_synchronize(self.h))
+
+    def route_dev(self, ring, key_bytes_ptr, key_off_ptr, n, owner_ptr):
+        _check(lib().guber_ring_route_dev(self.h, ring.h, key_bytes_ptr, key_off_ptr, n, owner_ptr))

@@ -1,0 +1,630 @@
+// guber_engine.hip — host side of the MI355X rate-limit engine and the C ABI of include/guber_gpu.h.
+// It owns the HBM-resident table, sequences the kernels of guber_kernels.h on one HIP stream and
+// stages host batches through pinned memory.  It is the replacement for the reference's WorkerPool
+// (workers.go:125-626): same operations, one call per batch instead of one channel hop per request.
+// There is no CPU fallback: without a HIP device every entry point fails with GUBER_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/guber_gpu.h"
+#include "guber_host.h"
+#include "guber_kernels.h"
+
+using namespace guber;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return fail(GUBER_E_HIP, #call, _e);          \
+    } while (0)
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(n, (size_t)16);
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(GUBER_E_NOMEM, "hipMalloc", e);
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+template <typename T>
+struct PinBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(n, (size_t)16);
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return fail(GUBER_E_NOMEM, "hipHostMalloc", e);
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct guber_engine {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    uint64_t slots = 0, cache_size = 0;
+    uint32_t max_batch = 0, max_key = 0;
+    Table T{};
+    Work W{};
+    // table + work storage
+    DevBuf<DirEntry> dir; DevBuf<KeyCell> cells; DevBuf<Rec> recs; DevBuf<uint8_t> arena; DevBuf<DevCounters> ctr;
+    DevBuf<uint32_t> w_u32;    // all u32 work arrays carved from one allocation
+    DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_scratch;  // n_dense + hist (memset per batch)
+    // staging for the host-pointer entry points
+    DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
+    DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
+    PinBuf<uint8_t> h_stage;   // one pinned arena for inputs and outputs
+    PinBuf<DevCounters> h_ctr;
+    DevCounters last_ctr{};
+    uint32_t epoch = 0;
+    uint64_t batches = 0;
+    uint64_t tags_upper = 0;   // host-side upper bound of ctr.tags_used
+    std::mutex mu;
+    // optional per-kernel timing (guber_profile_*)
+    bool profiling = false;
+    struct Span { int kernel; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    double prof_ms[8] = {0}; uint64_t prof_n[8] = {0};
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
+        hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); return ev;
+    }
+    void span_begin(int k) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); } }
+    void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, stream); }
+
+    int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+};
+
+enum { KT_MEMSET = 0, KT_RESOLVE, KT_SCAN, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
+static const char* const kKernelNames[KT_COUNT] = {"memset_scratch", "k_resolve", "k_scan", "k_scatter(first)",
+                                                   "k_scatter", "k_heads", "k_eval"};
+
+static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+
+static int engine_refresh_counters(guber_engine* e) {
+    HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->last_ctr = *e->h_ctr.p;
+    e->tags_upper = e->last_ctr.tags_used;
+    return 0;
+}
+
+extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** out) {
+    if (!cfg || !out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GUBER_E_NO_DEVICE, "no HIP device: the engine has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(GUBER_E_INVALID_ARG, "device ordinal out of range");
+    guber_engine* e = new guber_engine();
+    e->device = cfg->device;
+    if (hipSetDevice(e->device) != hipSuccess) { delete e; return fail(GUBER_E_HIP, "hipSetDevice"); }
+    e->cache_size = cfg->cache_size ? cfg->cache_size : 50000;  // workers.go:126
+    e->slots = cfg->table_slots ? next_pow2(cfg->table_slots) : next_pow2(std::max<uint64_t>(2 * e->cache_size, 1024));
+    if (e->slots > (1ull << 32)) { delete e; return fail(GUBER_E_INVALID_ARG, "table_slots above 2^32"); }
+    e->max_batch = cfg->max_batch ? cfg->max_batch : 65536;
+    if (e->max_batch > (1u << 24)) { delete e; return fail(GUBER_E_INVALID_ARG, "max_batch above 2^24"); }
+    e->max_key = cfg->max_key_bytes ? cfg->max_key_bytes : 1024;
+    if (e->max_key > 65000) e->max_key = 65000;
+    if (cfg->stream) { e->stream = (hipStream_t)cfg->stream; e->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return fail(GUBER_E_HIP, "hipStreamCreate"); }
+        e->own_stream = true;
+    }
+    int rc = 0;
+    const uint64_t arena_cap = std::max<uint64_t>(e->slots * 16, 1 << 20);   // long-key overflow arena
+    rc |= e->dir.ensure(e->slots); rc |= e->cells.ensure(e->slots); rc |= e->recs.ensure(e->slots);
+    rc |= e->arena.ensure(arena_cap + 64); rc |= e->ctr.ensure(1); rc |= e->h_ctr.ensure(1);
+    const uint32_t M = e->max_batch;
+    const uint32_t tiles = (M + TILE - 1) / TILE;
+    rc |= e->w_u32.ensure((size_t)M * 14);
+    rc |= e->w_rflags.ensure(M); rc |= e->w_snap.ensure(M);
+    rc |= e->w_scratch.ensure(16 + (size_t)MAX_PASSES * RADIX * tiles);
+    if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
+    hipError_t he = hipSuccess;
+    if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->recs.p, 0, e->slots * sizeof(Rec), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
+        guber_engine_destroy(e);
+        return fail(GUBER_E_HIP, "table initialisation", he);
+    }
+    e->T.dir = e->dir.p; e->T.cells = e->cells.p; e->T.recs = e->recs.p; e->T.arena = e->arena.p;
+    e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p;
+    e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 16); e->T.max_key = e->max_key;
+    e->T.hash_mask = (cfg->flags & GUBER_FLAG_TEST_WEAK_HASH) ? 0x1f80ull : ~0ull;   // 6 significant bits
+    uint32_t* u = e->w_u32.p;
+    uint32_t** fields[] = {&e->W.slot, &e->W.did, &e->W.keyA, &e->W.valA, &e->W.keyB, &e->W.valB, &e->W.pos,
+                           &e->W.order, &e->W.sdid, &e->W.seg_first, &e->W.seg_last, &e->W.seg_flags, &e->W.seg_rep,
+                           &e->W.seg_slot};
+    for (auto f : fields) { *f = u; u += M; }
+    e->W.rflags = e->w_rflags.p; e->W.snap = e->w_snap.p;
+    e->W.n_dense = e->w_scratch.p; e->W.hist = e->w_scratch.p + 16;
+    e->W.tiles_cap = tiles; e->W.epoch = 0;
+    *out = e;
+    return GUBER_OK;
+}
+
+extern "C" void guber_engine_destroy(guber_engine_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    e->dir.release(); e->cells.release(); e->recs.release(); e->arena.release(); e->ctr.release();
+    e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_scratch.release();
+    e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
+    e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+// Enqueue the kernel sequence for one batch whose arrays are all in HBM.
+static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R) {
+    const uint32_t n = B.n;
+    if (n == 0) return 0;
+    if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
+    // load guard: every request may claim a new directory entry
+    const uint64_t limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
+    if (e->tags_upper + n > limit) {
+        int rc = engine_refresh_counters(e);
+        if (rc) return rc;
+        if (e->tags_upper + n > limit) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
+    }
+    e->tags_upper += n;
+    if (++e->epoch >= 0x7fffffffu) {   // 31-bit epoch wrapped: drop all dense-id claims
+        hipLaunchKernelGGL(k_clear_claims, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots);
+        e->epoch = 1;
+    }
+    const uint32_t tiles = (n + TILE - 1) / TILE;
+    Work W = e->W;
+    W.epoch = e->epoch;
+    W.tiles_cap = tiles;
+    int passes = 1;
+    while (passes < MAX_PASSES && (1ull << (RADIX_BITS * passes)) < n) passes++;
+    e->span_begin(KT_MEMSET);
+    HIPCHK(hipMemsetAsync(e->w_scratch.p, 0, (16 + (size_t)MAX_PASSES * RADIX * tiles) * sizeof(uint32_t), e->stream));
+    e->span_end();
+    e->span_begin(KT_RESOLVE);
+    hipLaunchKernelGGL(k_resolve, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B, W);
+    e->span_end();
+    const uint32_t* kin = nullptr; const uint32_t* vin = nullptr;
+    uint32_t* kout = W.keyA; uint32_t* vout = W.valA;
+    for (int p = 0; p < passes; ++p) {
+        e->span_begin(KT_SCAN);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, e->stream, W.hist + (size_t)p * RADIX * tiles, (uint32_t)(RADIX * tiles));
+        e->span_end();
+        e->span_begin(p == 0 ? KT_SCATTER0 : KT_SCATTER);
+        hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B, W, p, p == 0 ? 1 : 0,
+                           p == passes - 1 ? 1 : 0, kin, vin, kout, vout);
+        e->span_end();
+        kin = kout; vin = vout;
+        kout = (kout == W.keyA) ? W.keyB : W.keyA; vout = (vout == W.valA) ? W.valB : W.valA;
+    }
+    e->span_begin(KT_HEADS);
+    hipLaunchKernelGGL(k_heads, dim3((n + 255) / 256), dim3(256), 0, e->stream, W, n);
+    e->span_end();
+    e->span_begin(KT_EVAL);
+    hipLaunchKernelGGL(k_eval, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B, R, W);
+    e->span_end();
+    HIPCHK(hipGetLastError());
+    e->batches++;
+    return 0;
+}
+
+static int check_batch_args(const guber_batch_t* b, const guber_result_t* r) {
+    if (!b || !r) return fail(GUBER_E_INVALID_ARG, "null batch/result");
+    if (b->n == 0) return 0;
+    if (!b->key_bytes || !b->key_off || !b->hits || !b->limit || !b->duration)
+        return fail(GUBER_E_INVALID_ARG, "batch is missing a mandatory array");
+    if (!r->status || !r->limit || !r->remaining || !r->reset_time || !r->err)
+        return fail(GUBER_E_INVALID_ARG, "result is missing an array");
+    return 0;
+}
+
+extern "C" int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    int rc = check_batch_args(b, r);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    BatchView B{b->n, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
+    ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
+    r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+    return launch_batch(e, B, R);
+}
+
+// Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of
+// the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
+static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_t* r, const uint32_t* idx, uint32_t n) {
+    const bool has_burst = b->burst, has_created = b->created_at, has_greg = b->greg_expire && b->greg_duration;
+    // key bytes of the (sub)batch
+    size_t kbytes = 0;
+    for (uint32_t j = 0; j < n; ++j) { uint32_t i = idx ? idx[j] : j; kbytes += b->key_off[i + 1] - b->key_off[i]; }
+    if (kbytes > 0xfffffff0ull) return fail(GUBER_E_BATCH_TOO_LARGE, "key bytes exceed 4 GiB");
+    const size_t n64 = (size_t)n * 7;   // hits limit duration burst created greg_expire greg_duration
+    const size_t stage_bytes = (kbytes + 16) + (size_t)(n + 1) * 4 + n64 * 8 + (size_t)n * 4 + (size_t)n * 2 + 64 +
+                               (size_t)n * (3 * 8 + 2);
+    int rc = 0;
+    rc |= e->h_stage.ensure(stage_bytes + 256);
+    rc |= e->d_keys.ensure(kbytes + 16); rc |= e->d_off.ensure(n + 1); rc |= e->d_i64.ensure(n64);
+    rc |= e->d_beh.ensure(n); rc |= e->d_u8.ensure((size_t)n * 2);
+    rc |= e->d_out64.ensure((size_t)n * 3); rc |= e->d_out8.ensure((size_t)n * 2);
+    if (rc) return GUBER_E_NOMEM;
+    // carve the pinned arena (8-byte aligned pieces first)
+    uint8_t* base = e->h_stage.p;
+    int64_t* s64 = (int64_t*)base; base += n64 * 8;
+    int64_t* o64 = (int64_t*)base; base += (size_t)n * 3 * 8;
+    uint32_t* soff = (uint32_t*)base; base += (size_t)(n + 1) * 4;
+    uint32_t* sbeh = (uint32_t*)base; base += (size_t)n * 4;
+    uint8_t* su8 = base; base += (size_t)n * 2;
+    uint8_t* o8 = base; base += (size_t)n * 2;
+    uint8_t* skeys = base;
+    uint32_t off = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t i = idx ? idx[j] : j;
+        const uint32_t len = b->key_off[i + 1] - b->key_off[i];
+        memcpy(skeys + off, b->key_bytes + b->key_off[i], len);
+        soff[j] = off; off += len;
+        s64[j] = b->hits[i]; s64[n + j] = b->limit[i]; s64[2 * (size_t)n + j] = b->duration[i];
+        s64[3 * (size_t)n + j] = has_burst ? b->burst[i] : 0;
+        s64[4 * (size_t)n + j] = has_created ? b->created_at[i] : b->now_ms;
+        s64[5 * (size_t)n + j] = has_greg ? b->greg_expire[i] : 0;
+        s64[6 * (size_t)n + j] = has_greg ? b->greg_duration[i] : 0;
+        sbeh[j] = b->behavior ? b->behavior[i] : 0;
+        su8[j] = b->algorithm ? b->algorithm[i] : 0;
+        su8[n + j] = b->is_owner ? b->is_owner[i] : 1;
+    }
+    soff[n] = off;
+    memset(skeys + off, 0, 16);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(e->d_keys.p, skeys, kbytes + 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_off.p, soff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_i64.p, s64, n64 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_beh.p, sbeh, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_u8.p, su8, (size_t)n * 2, hipMemcpyHostToDevice, st));
+    int64_t* d64 = e->d_i64.p;
+    BatchView B{n, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
+                e->d_u8.p, e->d_beh.p, e->d_u8.p + n, d64 + 5 * (size_t)n, d64 + 6 * (size_t)n, b->now_ms};
+    ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
+    rc = launch_batch(e, B, R);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(o64, e->d_out64.p, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(o8, e->d_out8.p, (size_t)n * 2, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t j = 0; j < n; ++j) {
+        const uint32_t i = idx ? idx[j] : j;
+        r->status[i] = o8[j]; r->err[i] = o8[n + j];
+        r->limit[i] = o64[j]; r->remaining[i] = o64[n + j]; r->reset_time[i] = o64[2 * (size_t)n + j];
+    }
+    return 0;
+}
+
+extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    int rc = check_batch_args(b, r);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    const DevCounters before = e->last_ctr;
+    r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0;
+    if (b->n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
+    if (b->n) {
+        rc = eval_host_once(e, b, r, nullptr, b->n);
+        if (rc) return rc;
+        // two new keys sharing one 64-bit hash inside one batch: re-submit the affected items; on the
+        // second pass the first key is resident and the other one probes past it.
+        for (int round = 0; round < 64; ++round) {
+            std::vector<uint32_t> again;
+            for (uint32_t i = 0; i < b->n; ++i) if (r->err[i] == GUBER_ITEM_E_RETRY) again.push_back(i);
+            if (again.empty()) break;
+            rc = eval_host_once(e, b, r, again.data(), (uint32_t)again.size());
+            if (rc) return rc;
+        }
+        e->last_ctr = *e->h_ctr.p;
+        e->tags_upper = e->last_ctr.tags_used;
+    }
+    r->over_limit_count = e->last_ctr.over - before.over;
+    r->cache_hits = e->last_ctr.hits - before.hits;
+    r->cache_misses = e->last_ctr.misses - before.misses;
+    r->unexpired_evictions = e->last_ctr.evictions - before.evictions;
+    r->cache_size = e->last_ctr.size;
+    return GUBER_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static Rec rec_from_item(const guber_item_t& in) {
+    Rec s; rec_clear(s);
+    s.limit = in.limit; s.duration = in.duration; s.stamp = in.stamp; s.burst = in.burst;
+    s.expire_at = in.expire_at; s.invalid_at = in.invalid_at;
+    if (in.algorithm == GUBER_ALGO_TOKEN_BUCKET) { s.remaining = in.remaining; s.meta = make_meta(K_TOKEN, in.status, ALGO_TOKEN); }
+    else if (in.algorithm == GUBER_ALGO_LEAKY_BUCKET) { s.remaining = f2bits(in.remaining_f); s.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY); }
+    else s.meta = make_meta(K_NIL, 0, in.algorithm);   // gubernator.go:435-455: no Value for other algorithms
+    return s;
+}
+static void item_from_rec(const Rec& s, guber_item_t* out) {
+    memset(out, 0, sizeof(*out));
+    out->limit = s.limit; out->duration = s.duration; out->stamp = s.stamp; out->burst = s.burst;
+    out->expire_at = s.expire_at; out->invalid_at = s.invalid_at;
+    if (rec_kind(s) == K_TOKEN) { out->algorithm = GUBER_ALGO_TOKEN_BUCKET; out->status = (uint8_t)rec_status(s); out->remaining = s.remaining; }
+    else if (rec_kind(s) == K_LEAKY) { out->algorithm = GUBER_ALGO_LEAKY_BUCKET; out->remaining_f = bits2f(s.remaining); }
+    else {   // CacheItem without a Value: only the CacheItem fields exist
+        out->algorithm = (uint8_t)rec_algo(s);
+        out->limit = out->duration = out->stamp = out->burst = 0;
+    }
+}
+
+static int add_items_once(guber_engine* e, const guber_item_t* items, const std::vector<uint32_t>& sel, uint8_t* res_out) {
+    const uint32_t n = (uint32_t)sel.size();
+    size_t kbytes = 0;
+    for (uint32_t j : sel) kbytes += items[j].key_len;
+    std::vector<ItemIn> host(n);
+    std::vector<uint8_t> keys(kbytes + 16, 0);
+    size_t off = 0;
+    for (uint32_t j = 0; j < n; ++j) {
+        const guber_item_t& it = items[sel[j]];
+        host[j].rec = rec_from_item(it);
+        host[j].key_off = (uint32_t)off; host[j].key_len = it.key_len;
+        if (it.key_len) memcpy(keys.data() + off, it.key, it.key_len);
+        off += it.key_len;
+    }
+    DevBuf<ItemIn> d_items; DevBuf<uint8_t> d_keys, d_flags, d_res; DevBuf<uint32_t> d_slots;
+    int rc = 0;
+    rc |= d_items.ensure(n); rc |= d_keys.ensure(keys.size()); rc |= d_flags.ensure(n); rc |= d_res.ensure(n); rc |= d_slots.ensure(n);
+    auto cleanup = [&]() { d_items.release(); d_keys.release(); d_flags.release(); d_res.release(); d_slots.release(); };
+    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    hipStream_t st = e->stream;
+    hipError_t he;
+    if ((he = hipMemcpyAsync(d_items.p, host.data(), n * sizeof(ItemIn), hipMemcpyHostToDevice, st)) != hipSuccess ||
+        (he = hipMemcpyAsync(d_keys.p, keys.data(), keys.size(), hipMemcpyHostToDevice, st)) != hipSuccess) {
+        cleanup(); return fail(GUBER_E_HIP, "add_items H2D", he);
+    }
+    hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p);
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p);
+    std::vector<uint8_t> res(n);
+    if ((he = hipMemcpyAsync(res.data(), d_res.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (he = hipStreamSynchronize(st)) != hipSuccess) {
+        cleanup(); return fail(GUBER_E_HIP, "add_items D2H", he);
+    }
+    cleanup();
+    for (uint32_t j = 0; j < n; ++j) res_out[sel[j]] = res[j];
+    return 0;
+}
+
+extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
+    if (!e || (!items && n)) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (n == 0) return GUBER_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!items[i].key || items[i].key_len == 0) return fail(GUBER_E_INVALID_ARG, "item without a key");
+        if (items[i].key_len > e->max_key) return fail(GUBER_E_KEY_TOO_LONG, "item key longer than max_key_bytes");
+    }
+    if (e->tags_upper + n > e->slots - e->slots / 8) {
+        int rc = engine_refresh_counters(e);
+        if (rc) return rc;
+        if (e->tags_upper + n > e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
+    }
+    e->tags_upper += n;
+    // LRUCache.Add is applied item by item (workers.go:566-581): with duplicates of a key in one call
+    // the LAST one must win and the later ones report existed = 1.  Waves of distinct keys keep that.
+    std::vector<uint8_t> res(n, 0);
+    std::vector<uint32_t> pending(n);
+    for (uint32_t i = 0; i < n; ++i) pending[i] = i;
+    int guard = 0;
+    while (!pending.empty()) {
+        if (++guard > 64) return fail(GUBER_E_HIP, "add_items did not converge");
+        std::unordered_map<std::string, int> seen;
+        std::vector<uint32_t> wave, later;
+        for (uint32_t i : pending) {
+            std::string k((const char*)items[i].key, items[i].key_len);
+            if (seen.emplace(std::move(k), 1).second) wave.push_back(i); else later.push_back(i);
+        }
+        int rc = add_items_once(e, items, wave, res.data());
+        if (rc) return rc;
+        std::vector<uint32_t> next;
+        for (uint32_t i : wave) {
+            if (res[i] == 0xFF) next.push_back(i);            // in-call hash collision: resubmit
+            else if (res[i] == 0xFE) return fail(GUBER_E_TABLE_FULL, "no directory entry for item");
+        }
+        // keep original relative order for the next wave
+        next.insert(next.end(), later.begin(), later.end());
+        std::sort(next.begin(), next.end());
+        pending.swap(next);
+    }
+    if (existed) for (uint32_t i = 0; i < n; ++i) existed[i] = res[i];
+    return GUBER_OK;
+}
+
+static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, int mode, guber_item_t* out, int* found) {
+    if (!e || !key || !found) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    *found = 0;
+    if (key_len == 0 || key_len > e->max_key) return GUBER_OK;
+    DevBuf<uint8_t> d_key; DevBuf<Rec> d_rec; DevBuf<int> d_found;
+    int rc = d_key.ensure(key_len + 16) | d_rec.ensure(1) | d_found.ensure(1);
+    auto cleanup = [&]() { d_key.release(); d_rec.release(); d_found.release(); };
+    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    std::vector<uint8_t> kb(key_len + 16, 0);
+    memcpy(kb.data(), key, key_len);
+    Rec hrec; int hfound = 0;
+    hipStream_t st = e->stream;
+    hipError_t he;
+    if ((he = hipMemcpyAsync(d_key.p, kb.data(), kb.size(), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup H2D", he); }
+    hipLaunchKernelGGL(k_item_lookup, dim3(1), dim3(64), 0, st, e->T, d_key.p, key_len, now_ms, mode, d_rec.p, d_found.p);
+    if ((he = hipMemcpyAsync(&hfound, d_found.p, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (he = hipMemcpyAsync(&hrec, d_rec.p, sizeof(Rec), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (he = hipStreamSynchronize(st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup D2H", he); }
+    cleanup();
+    *found = hfound;
+    if (hfound && out) { item_from_rec(hrec, out); out->key = nullptr; out->key_len = key_len; }
+    return GUBER_OK;
+}
+
+extern "C" int guber_get_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, guber_item_t* out, int* found) {
+    return item_lookup(e, key, key_len, now_ms, 0, out, found);
+}
+extern "C" int guber_remove_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len) {
+    int found = 0;
+    return item_lookup(e, key, key_len, 0, 1, nullptr, &found);
+}
+
+extern "C" int guber_stats(guber_engine_t* e, guber_stats_t* out) {
+    if (!e || !out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    int rc = engine_refresh_counters(e);
+    if (rc) return rc;
+    const DevCounters& c = e->last_ctr;
+    out->over_limit_count = c.over; out->cache_hits = c.hits; out->cache_misses = c.misses;
+    out->unexpired_evictions = c.evictions; out->cache_size = c.size; out->table_slots = e->slots;
+    out->tags_used = c.tags_used; out->batches = e->batches; out->retries = c.retries;
+    return GUBER_OK;
+}
+extern "C" int64_t guber_size(guber_engine_t* e) {
+    guber_stats_t s;
+    if (guber_stats(e, &s) != GUBER_OK) return -1;
+    return s.cache_size;
+}
+extern "C" int guber_synchronize(guber_engine_t* e) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GUBER_OK;
+}
+
+extern "C" int guber_dump(guber_engine_t* e, guber_item_t* items, uint64_t cap, uint8_t* key_arena, uint64_t arena_cap,
+                          uint64_t* n_out, uint64_t* arena_out) {
+    if (!e || !n_out || !arena_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    int rc = engine_refresh_counters(e);
+    if (rc) return rc;
+    const uint64_t resident = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
+    DevBuf<Rec> d_recs; DevBuf<KeyCell> d_cells; DevBuf<unsigned long long> d_count;
+    rc = d_recs.ensure(resident + 1) | d_cells.ensure(resident + 1) | d_count.ensure(1);
+    auto cleanup = [&]() { d_recs.release(); d_cells.release(); d_count.release(); };
+    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    hipStream_t st = e->stream;
+    hipError_t he;
+    unsigned long long count = 0;
+    std::vector<Rec> recs(resident + 1);
+    std::vector<KeyCell> cells(resident + 1);
+    if ((he = hipMemsetAsync(d_count.p, 0, sizeof(unsigned long long), st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "dump", he); }
+    hipLaunchKernelGGL(k_dump, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, st, e->T, e->slots, d_recs.p, d_cells.p, resident + 1, d_count.p);
+    if ((he = hipMemcpyAsync(&count, d_count.p, sizeof(count), hipMemcpyDeviceToHost, st)) != hipSuccess ||
+        (he = hipStreamSynchronize(st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "dump", he); }
+    if (count > resident + 1) count = resident + 1;
+    if ((he = hipMemcpy(recs.data(), d_recs.p, count * sizeof(Rec), hipMemcpyDeviceToHost)) != hipSuccess ||
+        (he = hipMemcpy(cells.data(), d_cells.p, count * sizeof(KeyCell), hipMemcpyDeviceToHost)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "dump D2H", he); }
+    cleanup();
+    uint64_t need_arena = 0;
+    for (uint64_t i = 0; i < count; ++i) need_arena += (uint32_t)(cells[i].w[7] >> 48);
+    *n_out = count; *arena_out = need_arena;
+    if (count > cap || need_arena > arena_cap || (!items && count) || (!key_arena && need_arena)) return fail(GUBER_E_NOMEM, "dump buffers too small");
+    uint64_t aoff = 0;
+    for (uint64_t i = 0; i < count; ++i) {
+        item_from_rec(recs[i], &items[i]);
+        const uint32_t len = (uint32_t)(cells[i].w[7] >> 48);
+        uint8_t* dst = key_arena + aoff;
+        if (len <= INLINE_KEY) memcpy(dst, cells[i].w, len);
+        else if ((he = hipMemcpy(dst, e->arena.p + cells[i].w[0], len, hipMemcpyDeviceToHost)) != hipSuccess) return fail(GUBER_E_HIP, "dump long key", he);
+        items[i].key = dst; items[i].key_len = len;
+        aoff += len;
+    }
+    return GUBER_OK;
+}
+
+extern "C" void* guber_alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void guber_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
+
+// ---- device routing on the consistent-hash ring ------------------------------------------------
+extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_bytes,
+                                    const uint32_t* key_off, uint32_t n, uint32_t* owner) {
+    if (!e || !r || (n && (!key_bytes || !key_off || !owner))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (n == 0) return GUBER_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    const uint32_t npts = guber_ring_points(r, nullptr, nullptr, 0);
+    if (npts == 0) return fail(GUBER_E_INVALID_ARG, "empty ring");
+    if ((size_t)npts * 8 > 150 * 1024) return fail(GUBER_E_INVALID_ARG, "ring does not fit in LDS");
+    std::vector<uint64_t> hh(npts); std::vector<uint32_t> oo(npts);
+    guber_ring_points(r, hh.data(), oo.data(), npts);
+    DevBuf<uint64_t> d_h; DevBuf<uint32_t> d_o;
+    int rc = d_h.ensure(npts) | d_o.ensure(npts);
+    auto cleanup = [&]() { d_h.release(); d_o.release(); };
+    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    hipError_t he;
+    if ((he = hipMemcpyAsync(d_h.p, hh.data(), npts * 8, hipMemcpyHostToDevice, e->stream)) != hipSuccess ||
+        (he = hipMemcpyAsync(d_o.p, oo.data(), npts * 4, hipMemcpyHostToDevice, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "ring H2D", he); }
+    hipLaunchKernelGGL(k_route, dim3((n + 255) / 256), dim3(256), (size_t)npts * 8, e->stream, key_bytes, key_off, n,
+                       d_h.p, d_o.p, npts, guber_ring_kind(r), owner);
+    he = hipStreamSynchronize(e->stream);
+    cleanup();
+    if (he != hipSuccess) return fail(GUBER_E_HIP, "k_route", he);
+    return GUBER_OK;
+}
+
+extern "C" int guber_profile_enable(guber_engine_t* e, int enable) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->profiling = enable != 0;
+    return GUBER_OK;
+}
+extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out) {
+    if (!e || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (auto& s : e->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { e->prof_ms[s.kernel] += ms; e->prof_n[s.kernel]++; }
+        e->event_pool.push_back(s.a); e->event_pool.push_back(s.b);
+    }
+    e->spans.clear();
+    *n_out = KT_COUNT;
+    for (uint32_t k = 0; k < KT_COUNT && k < cap && out; ++k) {
+        memset(&out[k], 0, sizeof(out[k]));
+        snprintf(out[k].name, sizeof(out[k].name), "%s", kKernelNames[k]);
+        out[k].launches = e->prof_n[k]; out[k].total_ms = e->prof_ms[k];
+    }
+    if (out) for (int k = 0; k < KT_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
+    return GUBER_OK;
+}
+
+extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }

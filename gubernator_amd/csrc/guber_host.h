@@ -1,0 +1,8 @@
+// guber_host.h — host-only pieces of the engine: the consistent-hash ring, calendar helpers, error
+// strings.  Internal accessors used by guber_engine.hip live here next to the public C ABI.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/guber_gpu.h"
+
+extern "C" int guber_ring_kind(const guber_ring_t* r);   // 0 fnv1, 1 fnv1a

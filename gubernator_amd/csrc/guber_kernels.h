@@ -1,0 +1,522 @@
+// guber_kernels.h — device-side data layout and the gfx950 kernels of the batched rate-limit path.
+//
+// HBM layout (one engine = one GPU = one shard of the key space):
+//   dir[slots]    16 B  {tag = XXH64(key) (0 = empty), meta = READY | epoch | dense id}   probe target
+//   cells[slots]  64 B  key bytes (<= 62 inline, longer keys live in the arena) + u16 length
+//   recs[slots]   64 B  guber::Rec — the bucket (CacheItem + Token/LeakyBucketItem), one sector
+// `slots` is a power of two >= 2 x cache_size; linear probing; tags are write-once (a removed bucket
+// keeps its tag and key, its record becomes K_ABSENT) so probing never needs tombstone handling.
+//
+// One batch (n requests, any number of duplicates of a key, reference order semantics
+// gubernator.go:203 + workers.go:190-258) is evaluated by a fixed sequence of launches on one stream:
+//   k_resolve      hash each key, find-or-insert its directory entry, give every distinct key of
+//                  the batch a dense id (first toucher claims it with one 64-bit CAS), per-tile digit
+//                  histogram for the sort
+//   k_scan         exclusive scan of the (digit, tile) histogram
+//   k_scatter x P  stable LSD radix passes on the dense id (P = ceil(log256 n)); the first pass also
+//                  verifies in-batch inserts, publishes READY, snapshots each touched bucket into a
+//                  dense array and flags segments whose requests are not all identical
+//   k_heads        segment (= same key) boundaries in the sorted order
+//   k_eval         every request computes ITS OWN response from (snapshot, rank in segment) with
+//                  guber::eval_uniform_rank — no atomics on bucket state, no serial chain for hot
+//                  keys; the last request of a segment writes the bucket back.  Heterogeneous
+//                  segments are walked in request order by their first request's thread.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "guber_algo.h"
+
+namespace guber {
+
+constexpr int TILE = 1024;              // requests per workgroup in resolve / scatter (16 waves)
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int MAX_PASSES = 3;           // dense ids < 2^24
+
+struct DirEntry { unsigned long long tag; unsigned long long meta; };
+struct alignas(64) KeyCell { uint64_t w[8]; };
+constexpr uint32_t INLINE_KEY = 62;
+constexpr unsigned long long META_READY = 1ull << 63;
+
+struct DevCounters {
+    unsigned long long over, hits, misses, evictions;
+    long long size;
+    unsigned long long tags_used, arena_head, retries;
+};
+
+struct Table {
+    DirEntry* dir; KeyCell* cells; Rec* recs; uint8_t* arena;
+    uint64_t mask; uint64_t arena_cap; DevCounters* ctr;
+    uint32_t max_probe; uint32_t max_key;
+    uint64_t hash_mask;   // ~0; tests narrow it to force 64-bit-hash collisions through the verify / retry path
+};
+
+struct BatchView {
+    uint32_t n;
+    const uint8_t* key_bytes; const uint32_t* key_off;
+    const int64_t *hits, *limit, *duration, *burst, *created_at;
+    const uint8_t* algorithm; const uint32_t* behavior; const uint8_t* is_owner;
+    const int64_t *greg_expire, *greg_duration;
+    int64_t now_ms;
+};
+struct ResultView { uint8_t* status; int64_t *limit, *remaining, *reset_time; uint8_t* err; };
+
+// request flags written by k_resolve
+enum : uint8_t { RF_INSERTED = 1, RF_NEED_VERIFY = 2, RF_ERR = 4 };
+// segment flags
+enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits 8..15 */ };
+
+struct Work {
+    uint32_t *slot, *did; uint8_t* rflags;
+    uint32_t *keyA, *valA, *keyB, *valB;
+    uint32_t *pos, *order, *sdid;
+    uint32_t *seg_first, *seg_last, *seg_flags, *seg_rep, *seg_slot;
+    Rec* snap;
+    uint32_t* hist;        // [MAX_PASSES][RADIX][tiles_cap]
+    uint32_t* n_dense;     // per-batch dense id allocator
+    uint32_t tiles_cap;
+    uint32_t epoch;        // 1 .. 2^31-1
+};
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_key_word(const uint8_t* p) {
+    uint64_t v; __builtin_memcpy(&v, p, 8); return v;
+}
+__device__ __forceinline__ uint64_t tail_mask(uint32_t nbytes) {  // nbytes in 1..8
+    return nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1ull);
+}
+
+__device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
+    Req r;
+    r.hits = B.hits[i]; r.limit = B.limit[i]; r.duration = B.duration[i];
+    r.burst = B.burst ? B.burst[i] : 0;
+    r.created_at = B.created_at ? B.created_at[i] : B.now_ms;
+    r.greg_expire = B.greg_expire ? B.greg_expire[i] : 0;
+    r.greg_duration = B.greg_duration ? B.greg_duration[i] : 0;
+    r.behavior = B.behavior ? B.behavior[i] : 0;
+    r.algorithm = B.algorithm ? B.algorithm[i] : 0;
+    r.is_owner = B.is_owner ? B.is_owner[i] : 1;
+    return r;
+}
+__device__ __forceinline__ void store_resp(const ResultView& R, uint32_t i, const Resp& o) {
+    R.status[i] = o.status; R.limit[i] = o.limit; R.remaining[i] = o.remaining;
+    R.reset_time[i] = o.reset_time; R.err[i] = o.err;
+}
+__device__ __forceinline__ void store_err(const ResultView& R, uint32_t i, uint8_t code) {
+    R.status[i] = 0; R.limit[i] = 0; R.remaining[i] = 0; R.reset_time[i] = 0; R.err[i] = code;
+}
+
+// exact key comparison against the key stored for `slot`
+__device__ __forceinline__ bool key_equal(const Table& T, uint64_t slot, const uint8_t* key, uint32_t len) {
+    const KeyCell* c = &T.cells[slot];
+    uint64_t w7 = c->w[7];
+    if ((uint32_t)(w7 >> 48) != len) return false;
+    const uint8_t* stored = nullptr;
+    if (len > INLINE_KEY) stored = T.arena + c->w[0];
+    uint32_t nw = (len + 7) >> 3;
+    for (uint32_t w = 0; w < nw; ++w) {
+        uint64_t kv = ld_key_word(key + 8 * w);
+        uint64_t cv;
+        if (stored) cv = ld_key_word(stored + 8 * w);   // arena allocations are 8-byte padded
+        else { cv = c->w[w]; if (w == 7) cv &= 0x0000ffffffffffffull; }
+        if (w == nw - 1) { uint64_t m = tail_mask(len - 8 * w); kv &= m; cv &= m; }
+        if (kv != cv) return false;
+    }
+    return true;
+}
+
+// store the key of a freshly claimed slot; false = key arena exhausted
+__device__ __forceinline__ bool key_store(const Table& T, uint64_t slot, const uint8_t* key, uint32_t len) {
+    KeyCell* c = &T.cells[slot];
+    uint64_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = 0;
+    if (len <= INLINE_KEY) {
+        uint32_t nw = (len + 7) >> 3;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i) {
+            if (i < nw) {
+                uint64_t kv = ld_key_word(key + 8 * i);
+                if (i == nw - 1) kv &= tail_mask(len - 8 * i);
+                w[i] = kv;
+            }
+        }
+    } else {
+        uint64_t need = ((uint64_t)len + 7) & ~7ull;
+        uint64_t off = atomicAdd(&T.ctr->arena_head, (unsigned long long)need);
+        if (off + need > T.arena_cap) {   // poison the cell: length 0xFFFF never equals a legal key length
+#pragma unroll
+            for (int i = 0; i < 7; ++i) c->w[i] = 0;
+            c->w[7] = 0xffffull << 48;
+            return false;
+        }
+        for (uint64_t b = 0; b < need; b += 8) {
+            uint64_t kv = ld_key_word(key + b);
+            if (b + 8 > len) kv &= tail_mask(len - (uint32_t)b);
+            *(uint64_t*)(T.arena + off + b) = kv;
+        }
+        w[0] = off;
+    }
+    w[7] = (w[7] & 0x0000ffffffffffffull) | ((uint64_t)len << 48);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) c->w[i] = w[i];
+    return true;
+}
+
+enum : uint32_t { PR_FOUND = 1, PR_INSERTED = 2, PR_NEED_VERIFY = 4, PR_FULL = 8, PR_MISSING = 16 };
+
+// Find the directory entry of `key`, inserting it when absent (insert = true).
+//  - tags are write-once, so a stale "empty" read is resolved by the CAS;
+//  - an entry without META_READY was inserted during THIS launch by another thread whose key bytes
+//    may not be visible yet: the match is tentative (PR_NEED_VERIFY) and checked in the next launch.
+__device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, uint32_t len, uint64_t h,
+                                          bool insert, uint32_t& slot_out) {
+    h &= T.hash_mask;
+    unsigned long long tag = h ? h : 1ull;
+    uint64_t pos = (h >> 7) & T.mask;
+    for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
+        unsigned long long t = ld_agent(&T.dir[pos].tag);
+        if (t == 0ull) {
+            if (!insert) { slot_out = 0; return PR_MISSING; }
+            unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
+            if (old == 0ull) {
+                slot_out = (uint32_t)pos;
+                atomicAdd(&T.ctr->tags_used, 1ull);
+                if (!key_store(T, pos, key, len)) return PR_FULL | PR_INSERTED;
+                return PR_INSERTED;
+            }
+            t = old;
+        }
+        if (t == tag) {
+            unsigned long long m = ld_agent(&T.dir[pos].meta);
+            if (m & META_READY) {
+                if (key_equal(T, pos, key, len)) { slot_out = (uint32_t)pos; return PR_FOUND; }
+            } else {
+                slot_out = (uint32_t)pos;
+                return PR_NEED_VERIFY;
+            }
+        }
+    }
+    slot_out = 0;
+    return PR_FULL;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void count_events(DevCounters* ctr, uint32_t over, uint32_t hit, uint32_t miss) {
+    over = wave_sum(over); hit = wave_sum(hit); miss = wave_sum(miss);
+    if ((threadIdx.x & 63) == 0) {
+        if (over) atomicAdd(&ctr->over, (unsigned long long)over);
+        if (hit) atomicAdd(&ctr->hits, (unsigned long long)hit);
+        if (miss) atomicAdd(&ctr->misses, (unsigned long long)miss);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resolve: one thread per request.
+__global__ __launch_bounds__(TILE) void k_resolve(Table T, BatchView B, Work W) {
+    __shared__ uint32_t lhist[RADIX];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint32_t i = tile * TILE + tid;
+    if (tid < RADIX) lhist[tid] = 0;
+    __syncthreads();
+    if (i < B.n) {
+        const uint32_t off = B.key_off[i];
+        const uint32_t len = B.key_off[i + 1] - off;
+        const uint8_t* key = B.key_bytes + off;
+        uint32_t slot = 0, d;
+        uint8_t rf = 0;
+        uint32_t errcode = 0;
+        if (len == 0) errcode = IE_EMPTY_KEY;
+        else if (len > T.max_key) errcode = 7;  // GUBER_ITEM_E_KEY_TOO_LONG
+        uint32_t pr = 0;
+        if (!errcode) {
+            uint64_t h = xxhash64(key, len, 0);
+            pr = probe(T, key, len, h, true, slot);
+            if (pr & PR_FULL) errcode = 6;      // GUBER_ITEM_E_TABLE_FULL
+        }
+        if (errcode) {
+            d = atomicAdd(W.n_dense, 1u);       // a solo segment that only carries the error
+            W.seg_flags[d] = SEG_ERR | (errcode << 8);
+            W.seg_rep[d] = i; W.seg_slot[d] = 0;
+            rf = RF_ERR | ((pr & PR_INSERTED) ? RF_INSERTED : 0);
+        } else {
+            if (pr & PR_INSERTED) rf |= RF_INSERTED;
+            if (pr & PR_NEED_VERIFY) rf |= RF_NEED_VERIFY;
+            // dense id of this key within the batch: first toucher claims it
+            unsigned long long* mp = &T.dir[slot].meta;
+            unsigned long long m = ld_agent(mp);
+            uint32_t mine = 0xffffffffu;
+            for (;;) {
+                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
+                if (mine == 0xffffffffu) mine = atomicAdd(W.n_dense, 1u);
+                unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | mine;
+                unsigned long long old = atomicCAS(mp, m, want);
+                if (old == m) {
+                    d = mine;
+                    W.seg_flags[d] = 0; W.seg_rep[d] = i; W.seg_slot[d] = slot;
+                    break;
+                }
+                m = old;
+            }
+        }
+        W.slot[i] = slot; W.did[i] = d; W.rflags[i] = rf;
+        atomicAdd(&lhist[d & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid < RADIX) W.hist[(size_t)tid * W.tiles_cap + tile] = lhist[tid];
+}
+
+// k_scan: in-place exclusive scan of `count` u32 by one workgroup.
+__global__ __launch_bounds__(1024) void k_scan(uint32_t* a, uint32_t count) {
+    __shared__ uint32_t sums[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = (count + 1023u) / 1024u;
+    const uint32_t lo = tid * chunk;
+    const uint32_t hi = lo + chunk < count ? lo + chunk : count;
+    uint32_t local = 0;
+    for (uint32_t j = lo; j < hi; ++j) local += a[j];
+    sums[tid] = local;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        uint32_t v = tid >= o ? sums[tid - o] : 0;
+        __syncthreads();
+        sums[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sums[tid] - local;
+    for (uint32_t j = lo; j < hi; ++j) { uint32_t t = a[j]; a[j] = run; run += t; }
+}
+
+// k_scatter: one stable LSD radix pass (8-bit digit `pass`) over (key = dense id, val = request idx).
+// hist points at this pass's scanned [RADIX][tiles_cap] table; when there is a next pass its
+// histogram is accumulated here for the tiles the elements land in.
+__global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, int pass, int first, int last,
+                                                  const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
+                                                  uint32_t* vout) {
+    __shared__ uint32_t whist[TILE / 64][RADIX];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = tile * TILE + tid;
+    const bool valid = g < B.n;
+    for (uint32_t j = tid; j < (TILE / 64) * RADIX; j += TILE) (&whist[0][0])[j] = 0;
+    __syncthreads();
+    uint32_t key = 0, val = 0;
+    if (valid) { key = first ? W.did[g] : kin[g]; val = first ? g : vin[g]; }
+    const uint32_t digit = (key >> (RADIX_BITS * pass)) & (RADIX - 1);
+
+    if (first && valid) {
+        // deferred work of the resolve stage, in request order (needs every k_resolve write)
+        const uint8_t rf = W.rflags[g];
+        const uint32_t d = key;
+        if (!(rf & RF_ERR)) {
+            const uint32_t slot = W.slot[g];
+            if (rf & RF_NEED_VERIFY) {
+                const uint32_t off = B.key_off[g];
+                if (!key_equal(T, slot, B.key_bytes + off, B.key_off[g + 1] - off)) atomicOr(&W.seg_flags[d], SEG_RETRY);
+            }
+            if (rf & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
+            const uint32_t rep = W.seg_rep[d];
+            if (rep == g) {
+                W.snap[d] = T.recs[slot];
+            } else {
+                Req a = load_req(B, g), b = load_req(B, rep);
+                if (!req_eq(a, b)) atomicOr(&W.seg_flags[d], SEG_NONUNIFORM);
+            }
+        } else if (rf & RF_INSERTED) {
+            atomicOr(&T.dir[W.slot[g]].meta, META_READY);
+        }
+    }
+
+    // lanes of this wave holding the same digit
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    const uint32_t rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank_in_wave == 0) whist[wave][digit] = __popcll(peers);
+    __syncthreads();
+    if (tid < RADIX) {
+        uint32_t run = W.hist[((size_t)pass * RADIX + tid) * W.tiles_cap + tile];
+#pragma unroll
+        for (int w = 0; w < TILE / 64; ++w) { uint32_t c = whist[w][tid]; whist[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+    if (valid) {
+        const uint32_t dst = whist[wave][digit] + rank_in_wave;
+        if (last) {
+            W.sdid[dst] = key; W.order[dst] = val; W.pos[val] = dst;
+        } else {
+            kout[dst] = key; vout[dst] = val;
+            const uint32_t nd = (key >> (RADIX_BITS * (pass + 1))) & (RADIX - 1);
+            atomicAdd(&W.hist[((size_t)(pass + 1) * RADIX + nd) * W.tiles_cap + (dst / TILE)], 1u);
+        }
+    }
+}
+
+// k_heads: segment boundaries in sorted order.
+__global__ __launch_bounds__(256) void k_heads(Work W, uint32_t n) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t d = W.sdid[p];
+    if (p == 0 || W.sdid[p - 1] != d) W.seg_first[d] = p;
+    if (p == n - 1 || W.sdid[p + 1] != d) W.seg_last[d] = p;
+}
+
+// k_eval: one thread per request, request order (coalesced inputs and outputs).
+__global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R, Work W) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c_over = 0, c_hit = 0, c_miss = 0;
+    if (i < B.n) {
+        const uint32_t d = W.did[i];
+        const uint32_t sf = W.seg_flags[d];
+        if (sf & SEG_ERR) {
+            store_err(R, i, (uint8_t)(sf >> 8));
+        } else if (sf & SEG_RETRY) {
+            store_err(R, i, IE_RETRY);
+            atomicAdd(&T.ctr->retries, 1ull);
+        } else {
+            const uint32_t first = W.seg_first[d], last = W.seg_last[d];
+            const uint32_t rank = W.pos[i] - first;
+            const uint32_t slot = W.seg_slot[d];
+            if (!(sf & SEG_NONUNIFORM)) {
+                const Req r = load_req(B, i);
+                const Rec s0 = W.snap[d];
+                Rec after; Resp out;
+                const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
+                store_resp(R, i, out);
+                c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+                if (rank == last - first) {
+                    T.recs[slot] = after;
+                    const int delta = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                    if (delta) atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)delta);
+                }
+            } else if (rank == 0) {
+                // requests to this key differ: apply them one by one in request order
+                const Rec s0 = W.snap[d];
+                Rec s = s0;
+                for (uint32_t q = first; q <= last; ++q) {
+                    const uint32_t j = W.order[q];
+                    const Req rj = load_req(B, j);
+                    Resp out;
+                    const uint32_t ev = apply(s, rj, B.now_ms, out);
+                    store_resp(R, j, out);
+                    c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                }
+                T.recs[slot] = s;
+                const int delta = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                if (delta) atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)delta);
+            }
+        }
+    }
+    count_events(T.ctr, c_over, c_hit, c_miss);
+}
+
+// ---------------------------------------------------------------------------------------------
+// maintenance kernels: AddCacheItem / GetCacheItem / Remove / Each
+struct ItemIn {   // device image of guber_item_t with the key referenced by offset
+    Rec rec; uint32_t key_off, key_len;
+};
+
+// phase A: find-or-insert the directory entry (flags as in k_resolve)
+__global__ __launch_bounds__(256) void k_items_probe(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
+                                                     uint32_t* slots, uint8_t* flags) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* key = keys + items[i].key_off;
+    const uint32_t len = items[i].key_len;
+    uint32_t slot = 0; uint8_t f = 0;
+    if (len == 0 || len > T.max_key) f = RF_ERR;
+    else {
+        uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
+        if (pr & PR_FULL) f = RF_ERR;
+        if (pr & PR_INSERTED) f |= RF_INSERTED;
+        if (pr & PR_NEED_VERIFY) f |= RF_NEED_VERIFY;
+    }
+    slots[i] = slot; flags[i] = f;
+}
+// phase B: verify tentative matches, publish READY, LRUCache.Add (lrucache.go:88-103): replace the
+// value when the key is resident (existed = 1), insert otherwise.  result: 0/1 existed, 0xFF retry, 0xFE error
+__global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
+                                                      const uint32_t* slots, const uint8_t* flags, uint8_t* result) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t f = flags[i];
+    const uint32_t slot = slots[i];
+    if (f & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
+    if (f & RF_ERR) { result[i] = 0xFE; return; }
+    if ((f & RF_NEED_VERIFY) && !key_equal(T, slot, keys + items[i].key_off, items[i].key_len)) { result[i] = 0xFF; return; }
+    const bool existed = rec_kind(T.recs[slot]) != K_ABSENT;
+    T.recs[slot] = items[i].rec;
+    if (!existed) atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
+    result[i] = existed ? 1 : 0;
+}
+
+// LRUCache.GetItem (lrucache.go:111-128) / Remove (:131-135) for one key. mode 0 = get, 1 = remove
+__global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *found = 0;
+    uint32_t slot;
+    if (len == 0 || len > T.max_key) return;
+    uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), false, slot);
+    Rec s; rec_clear(s);
+    if (pr & PR_FOUND) s = T.recs[slot];
+    if (rec_kind(s) == K_ABSENT) { if (mode == 0) atomicAdd(&T.ctr->misses, 1ull); return; }
+    if (mode == 1 || rec_expired(s, now)) {
+        Rec z; rec_clear(z);
+        T.recs[slot] = z;
+        atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)-1);
+        if (mode == 0) atomicAdd(&T.ctr->misses, 1ull);
+        return;
+    }
+    if (mode == 0) atomicAdd(&T.ctr->hits, 1ull);
+    *out = s; *found = 1;
+}
+
+// LRUCache.Each (lrucache.go:76-85): compact every resident bucket (+ its key cell) into out arrays
+__global__ __launch_bounds__(256) void k_dump(Table T, uint64_t slots, Rec* out_recs, KeyCell* out_cells, uint64_t cap,
+                                              unsigned long long* count) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    if (T.dir[s].tag == 0ull) return;
+    Rec r = T.recs[s];
+    if (rec_kind(r) == K_ABSENT) return;
+    unsigned long long idx = atomicAdd(count, 1ull);
+    if (idx < cap) { out_recs[idx] = r; out_cells[idx] = T.cells[s]; }
+}
+
+// wrap of the 31-bit batch epoch: forget every dense-id claim
+__global__ __launch_bounds__(256) void k_clear_claims(Table T, uint64_t slots) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < slots) T.dir[s].meta &= META_READY;
+}
+
+// ReplicatedConsistentHash.Get (replicated_hash.go:104-119): owner of each key on a sorted ring.
+__global__ __launch_bounds__(256) void k_route(const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
+                                               const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
+                                               int kind, uint32_t* owner) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* lh = (uint64_t*)smem;
+    for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* k = key_bytes + key_off[i];
+    const uint32_t len = key_off[i + 1] - key_off[i];
+    const uint64_t h = kind == 1 ? fnv1a_64(k, len) : fnv1_64(k, len);
+    uint32_t lo = 0, hi = npts;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (lh[mid] >= h) hi = mid; else lo = mid + 1; }
+    if (lo == npts) lo = 0;
+    owner[i] = ring_owner[lo];
+}
+
+}  // namespace guber

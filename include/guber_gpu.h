@@ -71,8 +71,14 @@ extern "C" {
 #define GUBER_ITEM_E_EMPTY_KEY 4u         /* gubernator.go:208-217 (host validation normally catches it) */
 #define GUBER_ITEM_E_RETRY 5u             /* internal: two new keys with one 64-bit hash in one batch; the
                                              host layer re-submits these items, callers never see it */
+#define GUBER_ITEM_E_TABLE_FULL 6u        /* no free directory entry / key arena exhausted */
+#define GUBER_ITEM_E_KEY_TOO_LONG 7u      /* key longer than guber_config_t.max_key_bytes */
 
 typedef struct guber_engine guber_engine_t;
+
+/* guber_config_t.flags */
+#define GUBER_FLAG_TEST_WEAK_HASH 1u /* tests only: keep 6 bits of the key hash so distinct keys collide and
+                                        the exact-key verification / retry path is exercised */
 
 /* Engine configuration.  Replaces Config.{CacheSize,Workers,CacheFactory}
  * (reference config.go:73-123, workers.go:125-147). */
@@ -84,7 +90,7 @@ typedef struct guber_config {
     uint32_t max_batch;      /* largest n accepted by one eval call (0 = 65536) */
     uint32_t max_key_bytes;  /* longest single key accepted (0 = 1024) */
     void* stream;            /* optional caller-owned hipStream_t; NULL = engine creates its own */
-    uint32_t flags;          /* reserved, 0 */
+    uint32_t flags;          /* GUBER_FLAG_* */
     uint32_t reserved;
 } guber_config_t;
 
@@ -94,7 +100,8 @@ typedef struct guber_config {
 typedef struct guber_batch {
     uint32_t n;
     uint32_t reserved;
-    const uint8_t* key_bytes;   /* concatenated keys */
+    const uint8_t* key_bytes;   /* concatenated keys; the buffer must stay readable for 8 bytes past the
+                                   last key (the kernels load keys as 8-byte words) */
     const uint32_t* key_off;    /* n+1 offsets into key_bytes */
     const int64_t* hits;
     const int64_t* limit;
@@ -196,6 +203,18 @@ int guber_dump(guber_engine_t* e, guber_item_t* items, uint64_t cap, uint8_t* ke
 
 int guber_stats(guber_engine_t* e, guber_stats_t* out);
 int guber_synchronize(guber_engine_t* e);
+
+/* ---- per-kernel timing for the roofline report (replaces the reference's prometheus
+ *      metricFuncTimeDuration timers, algorithms.go:38, workers.go:294).  While enabled every launch of
+ *      the batch sequence is bracketed by HIP events on the engine stream; guber_profile_read()
+ *      synchronises and returns, per kernel, the launch count and the summed duration. */
+typedef struct guber_kernel_time {
+    char name[32];
+    uint64_t launches;
+    double total_ms;
+} guber_kernel_time_t;
+int guber_profile_enable(guber_engine_t* e, int enable);
+int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out);
 
 /* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
 void* guber_alloc_pinned(size_t bytes);

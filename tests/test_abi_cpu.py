@@ -1,0 +1,103 @@
+"""CPU-side checks of the PRODUCT library (no GPU needed, no compute kernels launched): it loads,
+exports every symbol include/guber_gpu.h declares, fails loudly without a device, and its host-only
+functions (consistent-hash ring, calendar helpers, hashes, error strings) match the reference's
+known answers."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import xxhash
+
+import gubernator_amd as ga
+import scenarios
+import support
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(ga.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ga.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(support.ROOT, "include", "guber_gpu.h")).read()
+    declared = set(re.findall(r"\b(guber_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(ga.ABI_SYMBOLS), declared ^ set(ga.ABI_SYMBOLS)
+    for name in ga.ABI_SYMBOLS:
+        assert hasattr(L, name), name
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(ga.GuberConfig) == 48
+    assert C.sizeof(ga.GuberBatch) == 8 + 12 * 8 + 8
+    assert C.sizeof(ga.GuberResult) == 5 * 8 + 5 * 8
+    assert C.sizeof(ga.GuberItem) == 80
+    assert C.sizeof(ga.GuberStats) == 72
+
+
+def test_no_silent_cpu_fallback(L):
+    """Without a GPU the product path must fail loudly, never evaluate on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ga.GuberError) as ei:
+        ga.Engine(cache_size=1000)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+
+
+def test_product_path_does_not_reference_oracle():
+    for root, _, files in os.walk(os.path.join(support.ROOT, "gubernator_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "oracle" not in txt.lower().replace("no cpu", ""), os.path.join(root, f)
+
+
+def test_ring_distribution_kat(L):
+    k = scenarios.load("kat_vectors.json")["ring_distribution"]
+    keys = [f"192.168.{(i >> 8) & 255}.{i & 255}" for i in range(k["n_keys"])]
+    for kind in ("fnv1", "fnv1a"):
+        ring = ga.Ring(k["hosts"], k["replicas"], kind)
+        owner = ring.route(keys)
+        dist = {h: int((owner == i).sum()) for i, h in enumerate(k["hosts"])}
+        assert dist == k[kind], (kind, dist)
+        hh, _ = ring.points()
+        assert len(hh) == 3 * 512 and (np.diff(hh.astype(np.float64)) >= 0).all()
+
+
+def test_gregorian_kats(L):
+    k = scenarios.load("kat_vectors.json")
+    out = C.c_int64(0)
+    for v in k["gregorian_expiration"]:
+        assert L.guber_gregorian_expiration(v["now_ns"], v["d"], C.byref(out)) == 0
+        assert out.value == v["expire"], v
+    inv = k["gregorian_invalid"]
+    assert L.guber_gregorian_expiration(inv["now_ns"], inv["d"], C.byref(out)) == -3 and out.value == 0
+    assert L.guber_item_strerror(3).decode() == inv["error"]
+    assert L.guber_gregorian_duration(inv["now_ns"], 3, C.byref(out)) == -2
+    # product helpers agree with the oracle's on a sweep of instants and selectors
+    ol = support.oracle_lib()
+    o2 = C.c_int64(0)
+    rng = np.random.default_rng(8)
+    for _ in range(2000):
+        ns = int(rng.integers(0, 4_000_000_000)) * 1_000_000_000 + int(rng.integers(0, 10 ** 9))
+        d = int(rng.integers(0, 7))
+        assert L.guber_gregorian_expiration(ns, d, C.byref(out)) == ol.oracle_gregorian_expiration(ns, d, C.byref(o2))
+        assert out.value == o2.value
+        assert L.guber_gregorian_duration(ns, d, C.byref(out)) == ol.oracle_gregorian_duration(ns, d, C.byref(o2))
+        assert out.value == o2.value
+
+
+def test_hashes(L):
+    rng = np.random.default_rng(4)
+    for n in list(range(0, 80)) + [200, 1000]:
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert L.guber_xxhash64(b, n, 0) == xxhash.xxh64(b, seed=0).intdigest()
+    assert L.guber_fnv1_64(b"foobar", 6) == 0x340d8765a4dda9c2
+    assert L.guber_fnv1a_64(b"foobar", 6) == 0x85944171f73967e8
+    assert b"Invalid rate limit algorithm" in L.guber_item_strerror(1)
+    assert L.guber_strerror(-2).startswith(b"no HIP device")

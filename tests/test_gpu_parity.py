@@ -1,0 +1,176 @@
+"""Parity tests proper: the HIP path, called through the C ABI (include/guber_gpu.h), against the
+CPU oracle on the same seeded inputs — bit-exact on status / limit / remaining / reset_time / err,
+for token AND leaky buckets (the leaky float64 math is IEEE division, add, subtract and conversions
+only, so the tolerance is 0)."""
+import numpy as np
+import pytest
+
+import gubernator_amd as ga
+import scenarios
+import streams
+import support
+from support import HostBatch, Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def engine(**kw):
+    kw.setdefault("cache_size", 1 << 16)
+    kw.setdefault("max_batch", 65536)
+    return ga.Engine(**kw)
+
+
+def test_golden_functional_vectors():
+    assert scenarios.run_functional(lambda: engine(cache_size=4096, max_batch=1024)) >= 75
+
+
+def test_golden_store_vectors():
+    assert scenarios.run_store(lambda: engine(cache_size=4096, max_batch=1024)) == 5
+
+
+def test_get_peer_rate_limits_order_stable():
+    # functional_test.go:1638-1686
+    now = streams.NOW0
+    for n in [1, 2, 5, 10, 100, 1000]:
+        e = engine(cache_size=4096, max_batch=1024)
+        keys = [f"TestGetPeerRateLimits_k{n}_{i:05d}" for i in range(n)]
+        res = e.eval(HostBatch(keys, 0, [1000 + i for i in range(n)], 1000, now))
+        assert res.limit[:n].tolist() == [1000 + i for i in range(n)]
+        assert (res.err[:n] == 0).all()
+        e.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_streams(seed):
+    o, e = Oracle(cache_size=1 << 20), engine()
+    for bi, b in enumerate(streams.adversarial_batches(seed, 60, 3000, greg_fn=support.gregorian)):
+        want, got = o.eval(b), e.eval(b)
+        support.assert_results_equal(got, want, f"seed {seed} batch {bi}")
+        assert got.counters() == want.counters(), f"counters seed {seed} batch {bi}: {got.counters()} {want.counters()}"
+    e.close()
+
+
+def test_hot_key_runs():
+    now = streams.NOW0
+    for algo in (0, 1):
+        for beh in (0, 32):
+            for hits, limit in [(1, 100), (3, 100), (1, 5000), (5, 5)]:
+                o, e = Oracle(cache_size=1 << 16), engine(cache_size=1024, max_batch=8192)
+                for step in range(3):
+                    b = HostBatch([b"hot_key"] * 6000, hits, limit, 60_000, now + step * 1700, algorithm=algo, behavior=beh)
+                    support.assert_results_equal(e.eval(b), o.eval(b), f"algo {algo} beh {beh} hits {hits} step {step}")
+                e.close()
+
+
+def test_edge_cases_empty_ragged_long_keys():
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, max_key_bytes=300)
+    now = streams.NOW0
+    # empty batch
+    res = e.eval(HostBatch([], [], [], [], now))
+    assert res.n == 0
+    # ragged key lengths 1..300 (inline <= 62 bytes, arena beyond), duplicates of long keys
+    keys = [(b"k" * L) for L in range(1, 301)] + [b"k" * 100, b"k" * 299, b"q" * 63, b"q" * 62]
+    b = HostBatch(keys, 1, 3, 10_000, now)
+    support.assert_results_equal(e.eval(b), o.eval(b), "ragged")
+    support.assert_results_equal(e.eval(b), o.eval(b), "ragged again")
+    # keys that differ only in the last byte / only in length
+    keys = [b"same_prefix_" + bytes([65 + i]) for i in range(26)] + [b"same_prefix_", b"same_prefix_A\0"]
+    b = HostBatch(keys * 3, 1, 2, 10_000, now)
+    support.assert_results_equal(e.eval(b), o.eval(b), "near keys")
+    # empty key and over-long key are per-item errors, everything else in the batch is unaffected
+    b = HostBatch([b"ok_1", b"", b"z" * 301, b"ok_1"], 1, 5, 1000, now)
+    r = e.eval(b)
+    assert r.err[:4].tolist() == [0, 4, 7, 0] and r.remaining[:4].tolist() == [4, 0, 0, 3]
+    assert e.size() == o.size() + 1
+    e.close()
+
+
+def test_hash_collisions_are_resolved_exactly():
+    """GUBER_FLAG_TEST_WEAK_HASH keeps 6 bits of the key hash: hundreds of distinct keys share a
+    tag, so the exact key verification, probing past a collision and the in-batch retry path all run."""
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, flags=1)
+    rng = np.random.default_rng(5)
+    now = streams.NOW0
+    for step in range(6):
+        ids = rng.integers(0, 400, 2500)
+        keys = [f"coll_{int(i)}" for i in ids]
+        b = HostBatch(keys, 1, 7, 2_000, now + step * 900, algorithm=(ids % 2).astype(np.uint8))
+        support.assert_results_equal(e.eval(b), o.eval(b), f"collisions step {step}")
+    assert e.size() == o.size()
+    assert e.stats()["retries"] > 0
+    e.close()
+
+
+def test_cache_operations_add_get_remove_each():
+    # workers.go:537-626 AddCacheItem / GetCacheItem, lrucache.go:76-171
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=1024)
+    now = streams.NOW0
+    items = [support.make_item(f"it_{i}", i % 2, limit=10 + i, duration=1000, remaining=5, remaining_f=2.5,
+                               stamp=now - 10, burst=10 + i, expire_at=now + 1000 * (i % 3), status=i % 2)
+             for i in range(50)]
+    items.append(support.make_item("it_3", 0, limit=99, duration=7, remaining=1, stamp=now, expire_at=now + 5))
+    items.append(support.make_item("nilval", 9, limit=1, expire_at=now + 50))   # unknown algorithm: nil Value
+    want_ex = [o.add_item(it, now) for it in items]
+    assert e.add_items(items) == want_ex
+    assert e.size() == o.size() == 51
+    for k in ["it_0", "it_3", "it_7", "missing", "nilval"]:
+        assert e.get_item(k, now + 1) == o.get_item(k, now + 1), k
+    # expired on access -> removed (lrucache.go:115-119)
+    assert e.get_item("it_0", now + 1) is None and o.get_item("it_0", now + 1) is None
+    assert e.size() == o.size()
+    e.remove_item("it_7"); o.remove_item("it_7")
+    assert e.get_item("it_7", now) is None and e.size() == o.size()
+    key = lambda d: d["key"]
+    assert sorted(e.each(), key=key) == sorted(o.each(), key=key)
+    # evaluation continues from the injected state (UpdatePeerGlobals path, gubernator.go:425-459)
+    b = HostBatch(["it_1", "it_2", "it_3", "nilval", "it_4"], 1, [11, 12, 99, 1, 14], 1000, now, algorithm=[1, 0, 0, 0, 0])
+    got, want = e.eval(b), o.eval(b)
+    support.assert_results_equal(got, want, "after add")
+    assert got.counters() == want.counters()
+    e.close()
+
+
+def test_zipf_bench_stream_midsize():
+    """The BASELINE stream shape (Zipf 1.1, hits 1, limit 100, 60 s) at 200k keys / 16384 batch."""
+    tab = streams.key_table(200_000)
+    for algo in (0, 1):
+        z = streams.ZipfSampler(200_000)
+        o, e = Oracle(cache_size=1 << 21), engine(cache_size=400_000, max_batch=16384)
+        for bi in range(10):
+            b = streams.bench_batch(tab, z.draw(16384), streams.NOW0 + bi * 9_000, algorithm=algo)
+            got, want = e.eval(b), o.eval(b)
+            support.assert_results_equal(got, want, f"algo {algo} batch {bi}")
+            assert got.counters() == want.counters()
+        e.close()
+
+
+def test_full_size_10m_keys_batch_65536():
+    """BASELINE config 2/3 at full size: 10M resident keys, Zipf-1.1 batches of 65536, element-wise
+    against the oracle, plus size-independent properties of the token bucket."""
+    K, B = 10_000_000, 65536
+    tab = streams.key_table(K)
+    z = streams.ZipfSampler(K)
+    o, e = Oracle(cache_size=2 * K), engine(cache_size=K, max_batch=B)
+    now = streams.NOW0
+    # residency: one insert pass (hits 0 creates every bucket without consuming)
+    for lo in range(0, K, B):
+        ids = np.arange(lo, min(lo + B, K))
+        b = streams.bench_batch(tab, ids, now, hits=0)
+        o.eval(b); e.eval(b)
+    assert e.size() == o.size() == K
+    for algo in (0, 1):
+        for bi in range(3):
+            ids = z.draw(B)
+            b = streams.bench_batch(tab, ids, now + 1 + bi, algorithm=algo)
+            got, want = e.eval(b), o.eval(b)
+            support.assert_results_equal(got, want, f"algo {algo} batch {bi}")
+            if algo == 0:
+                # per key: remaining strictly decreases by 1 per admitted request, in request order
+                order = np.argsort(ids, kind="stable")
+                sid, rem, st = ids[order], got.remaining[:B][order], got.status[:B][order]
+                same = sid[1:] == sid[:-1]
+                under = (st[1:] == 0) & (st[:-1] == 0) & same
+                assert (rem[:-1][under] - rem[1:][under] == 1).all()
+                assert (rem[st == 1] == 0).all() and (got.limit[:B] == 100).all()
+    assert e.size() == o.size()
+    e.close()
