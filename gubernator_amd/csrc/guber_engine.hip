@@ -192,12 +192,14 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     const uint32_t n = B.n;
     if (n == 0) return 0;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
-    // load guard: every request may claim a new directory entry
+    // load guard.  tags_upper is a host-side upper bound (every request might claim a new directory
+    // entry); only when it crosses the limit is the real count read back.  A batch that would overflow
+    // anyway gets per-item GUBER_ITEM_E_TABLE_FULL from the bounded probe.
     const uint64_t limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
     if (e->tags_upper + n > limit) {
         int rc = engine_refresh_counters(e);
         if (rc) return rc;
-        if (e->tags_upper + n > limit) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
+        if (e->tags_upper >= limit) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
     e->tags_upper += n;
     if (++e->epoch >= 0x7fffffffu) {   // 31-bit epoch wrapped: drop all dense-id claims
@@ -367,7 +369,7 @@ static Rec rec_from_item(const guber_item_t& in) {
     Rec s; rec_clear(s);
     s.limit = in.limit; s.duration = in.duration; s.stamp = in.stamp; s.burst = in.burst;
     s.expire_at = in.expire_at; s.invalid_at = in.invalid_at;
-    if (in.algorithm == GUBER_ALGO_TOKEN_BUCKET) { s.remaining = in.remaining; s.meta = make_meta(K_TOKEN, in.status, ALGO_TOKEN); }
+    if (in.algorithm == GUBER_ALGO_TOKEN_BUCKET) { s.remaining = in.remaining; s.burst = 0; s.meta = make_meta(K_TOKEN, in.status, ALGO_TOKEN); }
     else if (in.algorithm == GUBER_ALGO_LEAKY_BUCKET) { s.remaining = f2bits(in.remaining_f); s.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY); }
     else s.meta = make_meta(K_NIL, 0, in.algorithm);   // gubernator.go:435-455: no Value for other algorithms
     return s;
@@ -376,7 +378,7 @@ static void item_from_rec(const Rec& s, guber_item_t* out) {
     memset(out, 0, sizeof(*out));
     out->limit = s.limit; out->duration = s.duration; out->stamp = s.stamp; out->burst = s.burst;
     out->expire_at = s.expire_at; out->invalid_at = s.invalid_at;
-    if (rec_kind(s) == K_TOKEN) { out->algorithm = GUBER_ALGO_TOKEN_BUCKET; out->status = (uint8_t)rec_status(s); out->remaining = s.remaining; }
+    if (rec_kind(s) == K_TOKEN) { out->algorithm = GUBER_ALGO_TOKEN_BUCKET; out->status = (uint8_t)rec_status(s); out->remaining = s.remaining; out->burst = 0; }
     else if (rec_kind(s) == K_LEAKY) { out->algorithm = GUBER_ALGO_LEAKY_BUCKET; out->remaining_f = bits2f(s.remaining); }
     else {   // CacheItem without a Value: only the CacheItem fields exist
         out->algorithm = (uint8_t)rec_algo(s);
@@ -433,7 +435,7 @@ extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uin
     if (e->tags_upper + n > e->slots - e->slots / 8) {
         int rc = engine_refresh_counters(e);
         if (rc) return rc;
-        if (e->tags_upper + n > e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
+        if (e->tags_upper >= e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
     e->tags_upper += n;
     // LRUCache.Add is applied item by item (workers.go:566-581): with duplicates of a key in one call
