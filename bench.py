@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py — rate-limit decisions/sec of the MI355X engine on BASELINE.json's workload.
+
+One "step" = one GetRateLimits batch of 65536 checks evaluated by the HIP path
+(guber_eval_batch_dev: k_resolve -> radix passes -> k_heads -> k_eval) with every input array
+already resident in HBM.  Workload (BASELINE.json configs[1]): 10M resident
+keys per GPU, Zipf(1.1) key popularity (stream seed 1234, permutation seed 99), TOKEN_BUCKET, hits 1,
+limit 100, duration 60 s, now_ms advancing 1 ms per batch.  `--algo leaky` switches to configs[2].
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by
+the reference's replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1),
+every rank evaluates batches over the keys it owns — no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
+BYTES_PER_DECISION = {"token": 149, "leaky": 173}   # SURVEY.md section 8d, 16-byte keys
+# split of the algorithmic bytes over the two kernels that touch request / table / response data
+# (DESIGN.md section "Algorithmic bytes"): k_resolve reads key_off 4 + key 16 + directory tag 8.
+KERNEL_BYTES = {"token": {"k_resolve": 28, "k_eval": 121}, "leaky": {"k_resolve": 28, "k_eval": 145}}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--keys", type=int, default=10_000_000, help="resident keys per GPU")
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--algo", choices=["token", "leaky"], default="token")
+    ap.add_argument("--dist", choices=["zipf", "uniform"], default="zipf")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batches", type=int, default=48)
+    ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
+    ap.add_argument("--profile-steps", type=int, default=32)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import gubernator_amd as ga
+    import streams
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, B = args.keys, args.batch
+    algo_id = 0 if args.algo == "token" else 1
+    stream = torch.cuda.Stream(device=dev)
+    eng = ga.Engine(cache_size=K + K // 4, device=local_rank, max_batch=B, stream=stream.cuda_stream)
+
+    # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
+    total_keys = K * world
+    table = streams.key_table(total_keys)
+    if world > 1:
+        ring = ga.Ring([f"gpu{i}" for i in range(world)], 512, "fnv1")
+        owned = []
+        chunk = 4_000_000
+        for lo in range(0, total_keys, chunk):
+            ids = np.arange(lo, min(lo + chunk, total_keys))
+            kb, ko = streams.keys_for_ids(table, ids)
+            d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
+            d_owner = torch.empty(len(ids), dtype=torch.int32, device=dev)
+            eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ids), d_owner.data_ptr())
+            owned.append(ids[(d_owner.cpu().numpy() == rank)])
+        my_ids = np.concatenate(owned)
+    else:
+        my_ids = np.arange(total_keys)
+    nk = len(my_ids)
+
+    # ---- device-resident batches ------------------------------------------------------------
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    class DevBatch:
+        def __init__(self, ids, now_ms, hits=1):
+            kb, ko = streams.keys_for_ids(table, ids)
+            n = len(ids)
+            self.n = n
+            self.t = [to_dev(kb), to_dev(ko.view(np.int32)),
+                      torch.full((n,), hits, dtype=torch.int64, device=dev),
+                      torch.full((n,), 100, dtype=torch.int64, device=dev),
+                      torch.full((n,), 60_000, dtype=torch.int64, device=dev),
+                      torch.full((n,), algo_id, dtype=torch.uint8, device=dev),
+                      torch.zeros((n,), dtype=torch.int32, device=dev)]
+            p = [x.data_ptr() for x in self.t]
+            self.c = ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], None, None, None,
+                                   int(now_ms))
+
+    class DevResult:
+        def __init__(self, n):
+            self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.err = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.limit = torch.empty(n, dtype=torch.int64, device=dev)
+            self.remaining = torch.empty(n, dtype=torch.int64, device=dev)
+            self.reset_time = torch.empty(n, dtype=torch.int64, device=dev)
+            self.c = ga.GuberResult(self.status.data_ptr(), self.limit.data_ptr(), self.remaining.data_ptr(),
+                                    self.reset_time.data_ptr(), self.err.data_ptr(), 0, 0, 0, 0, 0)
+
+        def host(self):
+            h = ga.HostResult(len(self.status))
+            for name in ("status", "limit", "remaining", "reset_time", "err"):
+                getattr(h, name)[:] = getattr(self, name).cpu().numpy()
+            return h
+
+    NOW0 = streams.NOW0
+    # residency: every owned key gets a bucket before anything is timed (hits 0 = create, consume nothing)
+    with torch.cuda.stream(stream):
+        scratch = DevResult(B)
+        for lo in range(0, nk, B):
+            db = DevBatch(my_ids[lo:lo + B], NOW0, hits=0)
+            eng.eval_dev(db.c, scratch.c)
+            eng.synchronize()
+    resident = eng.size()
+
+    if args.dist == "zipf":
+        sampler = streams.ZipfSampler(nk, s=1.1, seed=1234 + rank, perm_seed=99)
+        draw = lambda n: my_ids[sampler.draw(n)]
+    else:
+        rng = np.random.default_rng(1234 + rank)
+        draw = lambda n: my_ids[rng.permutation(nk)[:n]] if n <= nk else my_ids[rng.integers(0, nk, n)]
+
+    total_steps = args.warmup + args.steps
+    host_ids = [draw(B) for _ in range(total_steps)]
+    batches = [DevBatch(host_ids[s], NOW0 + 1 + s) for s in range(total_steps)]
+    KEEP = min(8, total_steps)           # results of the first KEEP steps are kept for the parity gate
+    kept = [DevResult(B) for _ in range(KEEP)]
+
+    def run(s):
+        eng.eval_dev(batches[s].c, (kept[s] if s < KEEP else scratch).c)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    with torch.cuda.stream(stream):
+        for s in range(args.warmup):
+            run(s)
+        torch.cuda.synchronize(dev)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for s in range(args.warmup, total_steps):
+            run(s)
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        barrier()
+    wall = t1 - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    decisions = args.steps * B * world
+    value = decisions / wall
+
+    # ---- per-kernel durations (HIP events on the engine stream), same inputs ---------------------
+    roofline = None
+    kernel_ms = {}
+    if rank == 0 and args.profile_steps > 0:
+        eng.profile(True)
+        eng.profile_read()
+        with torch.cuda.stream(stream):
+            for j in range(args.profile_steps):
+                eng.eval_dev(batches[args.warmup + (j % args.steps)].c, scratch.c)
+        prof = eng.profile_read()
+        eng.profile(False)
+        kernel_ms = {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
+        cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo]}
+        dom = max(cand, key=cand.get)
+        dom_bytes = KERNEL_BYTES[args.algo][dom] * B
+        achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.algo, {}).get(dom)
+            except Exception:
+                traffic = None
+        step_ms_events = ev_ms / args.steps
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": dom_bytes,
+                    "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items()},
+                    "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
+                                 "ms_per_batch_events": round(step_ms_events, 5),
+                                 "achieved": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9, 2),
+                                 "frac": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}}
+
+    # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import support
+        threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+        orc = support.Oracle(cache_size=4 * K, workers=threads)
+        for lo in range(0, nk, 1 << 18):
+            orc.eval(streams.bench_batch(table, my_ids[lo:lo + (1 << 18)], NOW0, hits=0, algorithm=algo_id), threads=threads)
+        nb = min(args.cpu_batches, total_steps)
+        hb = [streams.bench_batch(table, host_ids[s], NOW0 + 1 + s, algorithm=algo_id) for s in range(nb)]
+        # parity gate: the GPU's answers for the first KEEP batches of this very stream
+        ok = True
+        c0 = time.perf_counter()
+        outs = [orc.eval(hb[s], threads=threads) for s in range(nb)]
+        c1 = time.perf_counter()
+        for s in range(KEEP):
+            try:
+                support.assert_results_equal(kept[s].host(), outs[s], f"bench batch {s}")
+            except AssertionError as ex:
+                ok = False
+                print("PARITY FAILURE:", ex, file=sys.stderr)
+        parity = "bit-exact vs oracle on the first %d batches" % KEEP if ok else "FAILED"
+        mt = nb * B / (c1 - c0)
+        # single-thread leg on a fresh, smaller sample of the same stream
+        nb1 = max(4, nb // 4)
+        c0 = time.perf_counter()
+        for s in range(nb1):
+            orc.eval(hb[s])
+        c1 = time.perf_counter()
+        st = nb1 * B / (c1 - c0)
+        cpu = {"value": round(mt, 1), "unit": "decisions/s", "cores": threads, "kind": "port",
+               "sample": f"{nb} batches of {B} from the same stream, {K} resident keys, oracle in the reference's "
+                         f"worker-sharded design ({threads} workers/threads); single thread: {round(st, 1)} decisions/s "
+                         f"over {nb1} batches",
+               "single_thread_value": round(st, 1)}
+        if not ok:
+            raise SystemExit("parity gate failed: refusing to report a number")
+
+    if rank == 0:
+        out = {
+            "metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)",
+            "value": round(value, 1), "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
+            "config": {"workload": f"{K} resident keys per GPU, {args.dist} key popularity"
+                                   + (" s=1.1" if args.dist == "zipf" else "") +
+                                   f", batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, "
+                                   f"{world}xMI355X" + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else ""),
+                       "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
+                       "host_cores": os.cpu_count()},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,7 +76,8 @@ struct guber_engine {
     // table + work storage
     DevBuf<DirEntry> dir; DevBuf<KeyCell> cells; DevBuf<Rec> recs; DevBuf<uint8_t> arena; DevBuf<DevCounters> ctr;
     DevBuf<uint32_t> w_u32;    // all u32 work arrays carved from one allocation
-    DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_scratch;  // n_dense + hist (memset per batch)
+    DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
+    PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -104,17 +105,32 @@ struct guber_engine {
     int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
-enum { KT_MEMSET = 0, KT_RESOLVE, KT_SCAN, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
-static const char* const kKernelNames[KT_COUNT] = {"memset_scratch", "k_resolve", "k_scan", "k_scatter(first)",
-                                                   "k_scatter", "k_heads", "k_eval"};
+enum { KT_RESOLVE = 0, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
+static const char* const kKernelNames[KT_COUNT] = {"k_resolve", "k_hist", "k_scatter(first)", "k_scatter", "k_heads",
+                                                   "k_eval"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
-static int engine_refresh_counters(guber_engine* e) {
+// fold the per-workgroup event counters into a DevCounters image (host side)
+static void fold_counters(guber_engine* e) {
+    DevCounters c = *e->h_ctr.p;
+    for (uint32_t b = 0; b < e->n_bctr; ++b) {
+        const BlockCounters& bc = e->h_bctr.p[b];
+        c.over += bc.over; c.hits += bc.hits; c.misses += bc.misses; c.size += bc.size_delta;
+    }
+    e->last_ctr = c;
+    e->tags_upper = c.tags_used;
+}
+static int enqueue_counter_readback(guber_engine* e) {
     HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_bctr.p, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
+    return 0;
+}
+static int engine_refresh_counters(guber_engine* e) {
+    int rc = enqueue_counter_readback(e);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->last_ctr = *e->h_ctr.p;
-    e->tags_upper = e->last_ctr.tags_used;
+    fold_counters(e);
     return 0;
 }
 
@@ -148,19 +164,22 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     const uint32_t tiles = (M + TILE - 1) / TILE;
     rc |= e->w_u32.ensure((size_t)M * 14);
     rc |= e->w_rflags.ensure(M); rc |= e->w_snap.ensure(M);
-    rc |= e->w_scratch.ensure(16 + (size_t)MAX_PASSES * RADIX * tiles);
+    rc |= e->w_hist.ensure((size_t)MAX_PASSES * RADIX * tiles);
+    e->n_bctr = (M + 255) / 256;
+    rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
     hipError_t he = hipSuccess;
     if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->recs.p, 0, e->slots * sizeof(Rec), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->bctr.p, 0, e->n_bctr * sizeof(BlockCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
         guber_engine_destroy(e);
         return fail(GUBER_E_HIP, "table initialisation", he);
     }
     e->T.dir = e->dir.p; e->T.cells = e->cells.p; e->T.recs = e->recs.p; e->T.arena = e->arena.p;
-    e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p;
+    e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p; e->T.bctr = e->bctr.p;
     e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 16); e->T.max_key = e->max_key;
     e->T.hash_mask = (cfg->flags & GUBER_FLAG_TEST_WEAK_HASH) ? 0x1f80ull : ~0ull;   // 6 significant bits
     uint32_t* u = e->w_u32.p;
@@ -169,8 +188,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
                            &e->W.seg_slot};
     for (auto f : fields) { *f = u; u += M; }
     e->W.rflags = e->w_rflags.p; e->W.snap = e->w_snap.p;
-    e->W.n_dense = e->w_scratch.p; e->W.hist = e->w_scratch.p + 16;
-    e->W.tiles_cap = tiles; e->W.epoch = 0;
+    e->W.hist = e->w_hist.p;
+    e->W.tiles = tiles; e->W.epoch = 0;
     *out = e;
     return GUBER_OK;
 }
@@ -180,7 +199,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     e->dir.release(); e->cells.release(); e->recs.release(); e->arena.release(); e->ctr.release();
-    e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_scratch.release();
+    e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
+    e->bctr.release(); e->h_bctr.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -209,21 +229,20 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     const uint32_t tiles = (n + TILE - 1) / TILE;
     Work W = e->W;
     W.epoch = e->epoch;
-    W.tiles_cap = tiles;
+    W.tiles = tiles;
     int passes = 1;
     while (passes < MAX_PASSES && (1ull << (RADIX_BITS * passes)) < n) passes++;
-    e->span_begin(KT_MEMSET);
-    HIPCHK(hipMemsetAsync(e->w_scratch.p, 0, (16 + (size_t)MAX_PASSES * RADIX * tiles) * sizeof(uint32_t), e->stream));
-    e->span_end();
     e->span_begin(KT_RESOLVE);
     hipLaunchKernelGGL(k_resolve, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B, W);
     e->span_end();
     const uint32_t* kin = nullptr; const uint32_t* vin = nullptr;
     uint32_t* kout = W.keyA; uint32_t* vout = W.valA;
     for (int p = 0; p < passes; ++p) {
-        e->span_begin(KT_SCAN);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, e->stream, W.hist + (size_t)p * RADIX * tiles, (uint32_t)(RADIX * tiles));
-        e->span_end();
+        if (p > 0) {
+            e->span_begin(KT_HIST);
+            hipLaunchKernelGGL(k_hist, dim3(tiles), dim3(TILE), 0, e->stream, W, n, p, kin);
+            e->span_end();
+        }
         e->span_begin(p == 0 ? KT_SCATTER0 : KT_SCATTER);
         hipLaunchKernelGGL(k_scatter, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B, W, p, p == 0 ? 1 : 0,
                            p == passes - 1 ? 1 : 0, kin, vin, kout, vout);
@@ -322,7 +341,8 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(o64, e->d_out64.p, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(o8, e->d_out8.p, (size_t)n * 2, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, st));
+    rc = enqueue_counter_readback(e);
+    if (rc) return rc;
     HIPCHK(hipStreamSynchronize(st));
     for (uint32_t j = 0; j < n; ++j) {
         const uint32_t i = idx ? idx[j] : j;
@@ -353,8 +373,7 @@ extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber
             rc = eval_host_once(e, b, r, again.data(), (uint32_t)again.size());
             if (rc) return rc;
         }
-        e->last_ctr = *e->h_ctr.p;
-        e->tags_upper = e->last_ctr.tags_used;
+        fold_counters(e);
     }
     r->over_limit_count = e->last_ctr.over - before.over;
     r->cache_hits = e->last_ctr.hits - before.hits;

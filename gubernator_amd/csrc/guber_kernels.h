@@ -10,12 +10,13 @@
 // One batch (n requests, any number of duplicates of a key, reference order semantics
 // gubernator.go:203 + workers.go:190-258) is evaluated by a fixed sequence of launches on one stream:
 //   k_resolve      hash each key, find-or-insert its directory entry, give every distinct key of
-//                  the batch a dense id (first toucher claims it with one 64-bit CAS), per-tile digit
-//                  histogram for the sort
-//   k_scan         exclusive scan of the (digit, tile) histogram
-//   k_scatter x P  stable LSD radix passes on the dense id (P = ceil(log256 n)); the first pass also
-//                  verifies in-batch inserts, publishes READY, snapshots each touched bucket into a
-//                  dense array and flags segments whose requests are not all identical
+//                  the batch a segment id (= request index of the first toucher, claimed with one
+//                  64-bit CAS on the entry's meta word), per-tile digit histogram for the sort
+//   k_scatter x P  stable LSD radix passes on the segment id (P = ceil(log256 n)); every workgroup
+//                  derives its digit bases from the raw per-tile histograms itself (no scan launch);
+//                  the first pass also verifies in-batch inserts, publishes READY, snapshots each
+//                  touched bucket into a dense array and flags segments whose requests differ
+//   k_hist         per-tile digit histogram of the next pass (only between passes)
 //   k_heads        segment (= same key) boundaries in the sorted order
 //   k_eval         every request computes ITS OWN response from (snapshot, rank in segment) with
 //                  guber::eval_uniform_rank — no atomics on bucket state, no serial chain for hot
@@ -40,14 +41,17 @@ constexpr uint32_t INLINE_KEY = 62;
 constexpr unsigned long long META_READY = 1ull << 63;
 
 struct DevCounters {
-    unsigned long long over, hits, misses, evictions;
+    unsigned long long over, hits, misses, evictions;   // over/hits/misses: see BlockCounters
     long long size;
     unsigned long long tags_used, arena_head, retries;
 };
+// Event counters are accumulated per workgroup slot (plain read-modify-write by one thread; launches
+// on one stream are ordered) instead of hammering three global words with atomics; readers sum them.
+struct BlockCounters { unsigned long long over, hits, misses; long long size_delta; };
 
 struct Table {
     DirEntry* dir; KeyCell* cells; Rec* recs; uint8_t* arena;
-    uint64_t mask; uint64_t arena_cap; DevCounters* ctr;
+    uint64_t mask; uint64_t arena_cap; DevCounters* ctr; BlockCounters* bctr;
     uint32_t max_probe; uint32_t max_key;
     uint64_t hash_mask;   // ~0; tests narrow it to force 64-bit-hash collisions through the verify / retry path
 };
@@ -73,9 +77,8 @@ struct Work {
     uint32_t *pos, *order, *sdid;
     uint32_t *seg_first, *seg_last, *seg_flags, *seg_rep, *seg_slot;
     Rec* snap;
-    uint32_t* hist;        // [MAX_PASSES][RADIX][tiles_cap]
-    uint32_t* n_dense;     // per-batch dense id allocator
-    uint32_t tiles_cap;
+    uint32_t* hist;        // [MAX_PASSES][tiles][RADIX], raw per-tile digit counts
+    uint32_t tiles;        // tiles of this batch
     uint32_t epoch;        // 1 .. 2^31-1
 };
 
@@ -185,7 +188,6 @@ __device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, ui
             unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
             if (old == 0ull) {
                 slot_out = (uint32_t)pos;
-                atomicAdd(&T.ctr->tags_used, 1ull);
                 if (!key_store(T, pos, key, len)) return PR_FULL | PR_INSERTED;
                 return PR_INSERTED;
             }
@@ -205,33 +207,51 @@ __device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, ui
     return PR_FULL;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+__device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ void count_events(DevCounters* ctr, uint32_t over, uint32_t hit, uint32_t miss) {
-    over = wave_sum(over); hit = wave_sum(hit); miss = wave_sum(miss);
-    if ((threadIdx.x & 63) == 0) {
-        if (over) atomicAdd(&ctr->over, (unsigned long long)over);
-        if (hit) atomicAdd(&ctr->hits, (unsigned long long)hit);
-        if (miss) atomicAdd(&ctr->misses, (unsigned long long)miss);
+// Sum v over the workgroup (<= 16 waves); result valid in thread 0.  `red` = 16 ints of LDS.
+__device__ __forceinline__ int block_sum(int v, int* red) {
+    v = wave_sum(v);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    int t = 0;
+    if (threadIdx.x == 0) for (uint32_t w = 0; w < nw; ++w) t += red[w];
+    return t;
+}
+// lanes of this wave that hold the same 8-bit digit as the caller (among `valid` lanes)
+__device__ __forceinline__ unsigned long long digit_peers(uint32_t digit, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RADIX_BITS; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
     }
+    return peers;
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_resolve: one thread per request.
 __global__ __launch_bounds__(TILE) void k_resolve(Table T, BatchView B, Work W) {
     __shared__ uint32_t lhist[RADIX];
+    __shared__ int red[TILE / 64];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
     const uint32_t i = tile * TILE + tid;
+    const bool valid = i < B.n;
     if (tid < RADIX) lhist[tid] = 0;
     __syncthreads();
-    if (i < B.n) {
+    uint32_t d = 0;
+    int inserted = 0;
+    if (valid) {
         const uint32_t off = B.key_off[i];
         const uint32_t len = B.key_off[i + 1] - off;
         const uint8_t* key = B.key_bytes + off;
-        uint32_t slot = 0, d;
+        uint32_t slot = 0;
         uint8_t rf = 0;
         uint32_t errcode = 0;
         if (len == 0) errcode = IE_EMPTY_KEY;
@@ -242,25 +262,24 @@ __global__ __launch_bounds__(TILE) void k_resolve(Table T, BatchView B, Work W) 
             pr = probe(T, key, len, h, true, slot);
             if (pr & PR_FULL) errcode = 6;      // GUBER_ITEM_E_TABLE_FULL
         }
+        inserted = (pr & PR_INSERTED) ? 1 : 0;
         if (errcode) {
-            d = atomicAdd(W.n_dense, 1u);       // a solo segment that only carries the error
+            d = i;                              // a solo segment that only carries the error
             W.seg_flags[d] = SEG_ERR | (errcode << 8);
             W.seg_rep[d] = i; W.seg_slot[d] = 0;
-            rf = RF_ERR | ((pr & PR_INSERTED) ? RF_INSERTED : 0);
+            rf = RF_ERR | (inserted ? RF_INSERTED : 0);
         } else {
-            if (pr & PR_INSERTED) rf |= RF_INSERTED;
+            if (inserted) rf |= RF_INSERTED;
             if (pr & PR_NEED_VERIFY) rf |= RF_NEED_VERIFY;
-            // dense id of this key within the batch: first toucher claims it
+            // segment id of this key within the batch = request index of the first toucher
             unsigned long long* mp = &T.dir[slot].meta;
             unsigned long long m = ld_agent(mp);
-            uint32_t mine = 0xffffffffu;
             for (;;) {
                 if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
-                if (mine == 0xffffffffu) mine = atomicAdd(W.n_dense, 1u);
-                unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | mine;
-                unsigned long long old = atomicCAS(mp, m, want);
+                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | i;
+                const unsigned long long old = atomicCAS(mp, m, want);
                 if (old == m) {
-                    d = mine;
+                    d = i;
                     W.seg_flags[d] = 0; W.seg_rep[d] = i; W.seg_slot[d] = slot;
                     break;
                 }
@@ -268,45 +287,64 @@ __global__ __launch_bounds__(TILE) void k_resolve(Table T, BatchView B, Work W) 
             }
         }
         W.slot[i] = slot; W.did[i] = d; W.rflags[i] = rf;
-        atomicAdd(&lhist[d & (RADIX - 1)], 1u);
     }
-    __syncthreads();
-    if (tid < RADIX) W.hist[(size_t)tid * W.tiles_cap + tile] = lhist[tid];
+    // per-tile histogram of the first digit: one LDS add per distinct digit per wave
+    const uint32_t digit = d & (RADIX - 1);
+    const unsigned long long peers = digit_peers(digit, valid);
+    if (valid && (peers & ((1ull << (tid & 63)) - 1ull)) == 0) atomicAdd(&lhist[digit], (uint32_t)__popcll(peers));
+    const int ins = block_sum(inserted, red);   // contains the barriers that publish lhist
+    if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+    if (tid < RADIX) W.hist[(size_t)tile * RADIX + tid] = lhist[tid];
 }
 
-// k_scan: in-place exclusive scan of `count` u32 by one workgroup.
-__global__ __launch_bounds__(1024) void k_scan(uint32_t* a, uint32_t count) {
-    __shared__ uint32_t sums[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t chunk = (count + 1023u) / 1024u;
-    const uint32_t lo = tid * chunk;
-    const uint32_t hi = lo + chunk < count ? lo + chunk : count;
-    uint32_t local = 0;
-    for (uint32_t j = lo; j < hi; ++j) local += a[j];
-    sums[tid] = local;
+// k_hist: per-tile digit histogram of pass `pass` over the keys produced by the previous pass.
+__global__ __launch_bounds__(TILE) void k_hist(Work W, uint32_t n, int pass, const uint32_t* kin) {
+    __shared__ uint32_t lhist[RADIX];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint32_t g = tile * TILE + tid;
+    const bool valid = g < n;
+    if (tid < RADIX) lhist[tid] = 0;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
-        uint32_t v = tid >= o ? sums[tid - o] : 0;
-        __syncthreads();
-        sums[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = sums[tid] - local;
-    for (uint32_t j = lo; j < hi; ++j) { uint32_t t = a[j]; a[j] = run; run += t; }
+    const uint32_t digit = valid ? ((kin[g] >> (RADIX_BITS * pass)) & (RADIX - 1)) : 0;
+    const unsigned long long peers = digit_peers(digit, valid);
+    if (valid && (peers & ((1ull << (tid & 63)) - 1ull)) == 0) atomicAdd(&lhist[digit], (uint32_t)__popcll(peers));
+    __syncthreads();
+    if (tid < RADIX) W.hist[((size_t)pass * W.tiles + tile) * RADIX + tid] = lhist[tid];
 }
 
-// k_scatter: one stable LSD radix pass (8-bit digit `pass`) over (key = dense id, val = request idx).
-// hist points at this pass's scanned [RADIX][tiles_cap] table; when there is a next pass its
-// histogram is accumulated here for the tiles the elements land in.
+// k_scatter: one stable LSD radix pass (8-bit digit `pass`) over (key = segment id, val = request idx).
 __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, int pass, int first, int last,
                                                   const uint32_t* kin, const uint32_t* vin, uint32_t* kout,
                                                   uint32_t* vout) {
     __shared__ uint32_t whist[TILE / 64][RADIX];
+    __shared__ uint32_t dscan[RADIX];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * TILE + tid;
     const bool valid = g < B.n;
     for (uint32_t j = tid; j < (TILE / 64) * RADIX; j += TILE) (&whist[0][0])[j] = 0;
+
+    // digit bases from the raw per-tile histograms: all elements of smaller digits, plus this digit's
+    // elements in earlier tiles.  Thread t < 256 owns digit t; the column reads are coalesced.
+    uint32_t before = 0, total = 0;
+    if (tid < RADIX) {
+        const uint32_t* col = W.hist + (size_t)pass * W.tiles * RADIX + tid;
+        for (uint32_t t = 0; t < W.tiles; ++t) {
+            const uint32_t v = col[(size_t)t * RADIX];
+            total += v;
+            if (t < tile) before += v;
+        }
+        dscan[tid] = total;
+    }
     __syncthreads();
+    for (uint32_t o = 1; o < RADIX; o <<= 1) {          // inclusive scan of the 256 digit totals
+        uint32_t v = 0;
+        if (tid < RADIX && tid >= o) v = dscan[tid - o];
+        __syncthreads();
+        if (tid < RADIX) dscan[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t my_base = tid < RADIX ? dscan[tid] - total + before : 0;
+
     uint32_t key = 0, val = 0;
     if (valid) { key = first ? W.did[g] : kin[g]; val = first ? g : vin[g]; }
     const uint32_t digit = (key >> (RADIX_BITS * pass)) & (RADIX - 1);
@@ -322,11 +360,10 @@ __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, 
                 if (!key_equal(T, slot, B.key_bytes + off, B.key_off[g + 1] - off)) atomicOr(&W.seg_flags[d], SEG_RETRY);
             }
             if (rf & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
-            const uint32_t rep = W.seg_rep[d];
-            if (rep == g) {
+            if (d == g) {
                 W.snap[d] = T.recs[slot];
             } else {
-                Req a = load_req(B, g), b = load_req(B, rep);
+                Req a = load_req(B, g), b = load_req(B, d);
                 if (!req_eq(a, b)) atomicOr(&W.seg_flags[d], SEG_NONUNIFORM);
             }
         } else if (rf & RF_INSERTED) {
@@ -334,32 +371,20 @@ __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, 
         }
     }
 
-    // lanes of this wave holding the same digit
-    unsigned long long peers = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < RADIX_BITS; ++b) {
-        const bool bit = (digit >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        peers &= bit ? bal : ~bal;
-    }
+    const unsigned long long peers = digit_peers(digit, valid);
     const uint32_t rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
     if (valid && rank_in_wave == 0) whist[wave][digit] = __popcll(peers);
     __syncthreads();
     if (tid < RADIX) {
-        uint32_t run = W.hist[((size_t)pass * RADIX + tid) * W.tiles_cap + tile];
+        uint32_t run = my_base;
 #pragma unroll
         for (int w = 0; w < TILE / 64; ++w) { uint32_t c = whist[w][tid]; whist[w][tid] = run; run += c; }
     }
     __syncthreads();
     if (valid) {
         const uint32_t dst = whist[wave][digit] + rank_in_wave;
-        if (last) {
-            W.sdid[dst] = key; W.order[dst] = val; W.pos[val] = dst;
-        } else {
-            kout[dst] = key; vout[dst] = val;
-            const uint32_t nd = (key >> (RADIX_BITS * (pass + 1))) & (RADIX - 1);
-            atomicAdd(&W.hist[((size_t)(pass + 1) * RADIX + nd) * W.tiles_cap + (dst / TILE)], 1u);
-        }
+        if (last) { W.sdid[dst] = key; W.order[dst] = val; W.pos[val] = dst; }
+        else { kout[dst] = key; vout[dst] = val; }
     }
 }
 
@@ -374,8 +399,9 @@ __global__ __launch_bounds__(256) void k_heads(Work W, uint32_t n) {
 
 // k_eval: one thread per request, request order (coalesced inputs and outputs).
 __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R, Work W) {
+    __shared__ int red[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t c_over = 0, c_hit = 0, c_miss = 0;
+    int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (i < B.n) {
         const uint32_t d = W.did[i];
         const uint32_t sf = W.seg_flags[d];
@@ -397,8 +423,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == last - first) {
                     T.recs[slot] = after;
-                    const int delta = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
-                    if (delta) atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)delta);
+                    c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 }
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order
@@ -413,12 +438,17 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
                 T.recs[slot] = s;
-                const int delta = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
-                if (delta) atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)delta);
+                c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
             }
         }
     }
-    count_events(T.ctr, c_over, c_hit, c_miss);
+    const int t_over = block_sum(c_over, red), t_hit = block_sum(c_hit, red), t_miss = block_sum(c_miss, red),
+              t_size = block_sum(c_size, red);
+    if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
+        BlockCounters* bc = &T.bctr[blockIdx.x];
+        bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
+        bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -439,7 +469,7 @@ __global__ __launch_bounds__(256) void k_items_probe(Table T, const ItemIn* item
     else {
         uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
         if (pr & PR_FULL) f = RF_ERR;
-        if (pr & PR_INSERTED) f |= RF_INSERTED;
+        if (pr & PR_INSERTED) { f |= RF_INSERTED; atomicAdd(&T.ctr->tags_used, 1ull); }
         if (pr & PR_NEED_VERIFY) f |= RF_NEED_VERIFY;
     }
     slots[i] = slot; flags[i] = f;
