@@ -28,9 +28,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_DECISION = {"token": 149, "leaky": 173}   # SURVEY.md section 8d, 16-byte keys
-# split of the algorithmic bytes over the two kernels that touch request / table / response data
-# (DESIGN.md section "Algorithmic bytes"): k_resolve reads key_off 4 + key 16 + directory tag 8.
-KERNEL_BYTES = {"token": {"k_resolve": 28, "k_eval": 121}, "leaky": {"k_resolve": 28, "k_eval": 145}}
+# split of the algorithmic bytes over the kernels that touch request / table / response data (DESIGN.md
+# "Algorithmic bytes"): k_front reads key_off 4 + key 16 + table 56 (token) / 64 (leaky); k_eval2 reads
+# the request fields 32 / 40, writes table 16 / 24 and the response 25.
+KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_resolve": 28, "k_eval": 121},
+                "leaky": {"k_front": 84, "k_eval2": 89, "k_resolve": 28, "k_eval": 145}}
 
 
 def parse():
@@ -194,7 +196,7 @@ def main():
         prof = eng.profile_read()
         eng.profile(False)
         kernel_ms = {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
-        cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo]}
+        cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo] and v > 0}
         dom = max(cand, key=cand.get)
         dom_bytes = KERNEL_BYTES[args.algo][dom] * B
         achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9

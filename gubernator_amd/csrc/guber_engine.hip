@@ -78,6 +78,12 @@ struct guber_engine {
     DevBuf<uint32_t> w_u32;    // all u32 work arrays carved from one allocation
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
+    // tile-bitmap grouping path (batches <= 65536)
+    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_tilecnt, w_tilestart, w_lrank;
+    DevBuf<uint32_t> w_torder;
+    uint32_t fast_cap = 0;      // entries of the arrays above
+    uint32_t fast_batches = 0, fast_prev_n = 0;
+    bool force_radix = false;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -93,7 +99,7 @@ struct guber_engine {
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[8] = {0}; uint64_t prof_n[8] = {0};
+    double prof_ms[16] = {0}; uint64_t prof_n[16] = {0};
 
     hipEvent_t get_event() {
         if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
@@ -105,9 +111,9 @@ struct guber_engine {
     int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
-enum { KT_RESOLVE = 0, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
-static const char* const kKernelNames[KT_COUNT] = {"k_resolve", "k_hist", "k_scatter(first)", "k_scatter", "k_heads",
-                                                   "k_eval"};
+enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
+static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
+                                                   "k_scatter", "k_heads", "k_eval"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -165,6 +171,11 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_u32.ensure((size_t)M * 14);
     rc |= e->w_rflags.ensure(M); rc |= e->w_snap.ensure(M);
     rc |= e->w_hist.ensure((size_t)MAX_PASSES * RADIX * tiles);
+    e->fast_cap = std::min<uint32_t>(M, 64 * TILE);
+    e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
+    rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
+    rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * 64); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * 64);
+    rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     e->n_bctr = (M + 255) / 256;
     rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
@@ -173,6 +184,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->recs.p, 0, e->slots * sizeof(Rec), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->bctr.p, 0, e->n_bctr * sizeof(BlockCounters), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * 8, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_flags2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
         guber_engine_destroy(e);
@@ -190,6 +203,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.rflags = e->w_rflags.p; e->W.snap = e->w_snap.p;
     e->W.hist = e->w_hist.p;
     e->W.tiles = tiles; e->W.epoch = 0;
+    e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
+    e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
+    e->W.parity = 0; e->W.clear_n = 0;
     *out = e;
     return GUBER_OK;
 }
@@ -201,6 +217,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->dir.release(); e->cells.release(); e->recs.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
+    e->w_tilemask.release(); e->w_flags2.release(); e->w_tilecnt.release(); e->w_tilestart.release();
+    e->w_lrank.release(); e->w_torder.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -230,6 +248,24 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     Work W = e->W;
     W.epoch = e->epoch;
     W.tiles = tiles;
+    if (n <= e->fast_cap && !e->force_radix) {
+        // two launches: resolve + in-tile grouping, then evaluation
+        BatchView B2 = B;
+        B2.n_cap = e->fast_cap;
+        W.parity = e->fast_batches & 1u;
+        W.clear_n = e->fast_prev_n;
+        e->span_begin(KT_FRONT);
+        hipLaunchKernelGGL(k_front, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B2, W);
+        e->span_end();
+        e->span_begin(KT_EVAL2);
+        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
+        e->span_end();
+        HIPCHK(hipGetLastError());
+        e->fast_batches++;
+        e->fast_prev_n = n;
+        e->batches++;
+        return 0;
+    }
     int passes = 1;
     while (passes < MAX_PASSES && (1ull << (RADIX_BITS * passes)) < n) passes++;
     e->span_begin(KT_RESOLVE);
@@ -277,7 +313,7 @@ extern "C" int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* b, g
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    BatchView B{b->n, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+    BatchView B{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
                 b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
     ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
     r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
@@ -334,7 +370,7 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     HIPCHK(hipMemcpyAsync(e->d_beh.p, sbeh, (size_t)n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(e->d_u8.p, su8, (size_t)n * 2, hipMemcpyHostToDevice, st));
     int64_t* d64 = e->d_i64.p;
-    BatchView B{n, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
+    BatchView B{n, 0, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
                 e->d_u8.p, e->d_beh.p, e->d_u8.p + n, d64 + 5 * (size_t)n, d64 + 6 * (size_t)n, b->now_ms};
     ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
     rc = launch_batch(e, B, R);

@@ -58,6 +58,7 @@ struct Table {
 
 struct BatchView {
     uint32_t n;
+    uint32_t n_cap;   // engine max_batch: stride of the per-batch double-buffered work arrays
     const uint8_t* key_bytes; const uint32_t* key_off;
     const int64_t *hits, *limit, *duration, *burst, *created_at;
     const uint8_t* algorithm; const uint32_t* behavior; const uint8_t* is_owner;
@@ -80,6 +81,18 @@ struct Work {
     uint32_t* hist;        // [MAX_PASSES][tiles][RADIX], raw per-tile digit counts
     uint32_t tiles;        // tiles of this batch
     uint32_t epoch;        // 1 .. 2^31-1
+    // tile-bitmap grouping (batches of <= 64 tiles): per segment a bitmap of the tiles holding its
+    // requests and, per (segment, tile), the group's size and start inside the tile's sorted order.
+    // seg_flags / seg_tilemask are double-buffered by batch parity: a batch's eval kernel clears the
+    // other copy for the next batch, so no memset launch is needed.
+    unsigned long long* seg_tilemask;   // [2][max_batch]
+    uint32_t* seg_flags2;               // [2][max_batch]
+    uint16_t* tilecnt;                  // [max_batch][64]
+    uint16_t* tilestart;                // [max_batch][64]
+    uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
+    uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
+    uint32_t parity;                    // batch & 1
+    uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -436,6 +449,259 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     const uint32_t ev = apply(s, rj, B.now_ms, out);
                     store_resp(R, j, out);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                }
+                T.recs[slot] = s;
+                c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+            }
+        }
+    }
+    const int t_over = block_sum(c_over, red), t_hit = block_sum(c_hit, red), t_miss = block_sum(c_miss, red),
+              t_size = block_sum(c_size, red);
+    if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
+        BlockCounters* bc = &T.bctr[blockIdx.x];
+        bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
+        bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pipeline for batches of <= 64 tiles (65536 requests): TWO launches.
+//
+// k_front: resolve (as k_resolve) and, in the same workgroup, group the tile's 1024 requests by
+// segment id with a stable 2-pass LDS radix sort; publish per (segment, tile) group size / start and
+// set the tile's bit in the segment's bitmap.  Nothing here depends on another workgroup:
+//  - a match on a directory entry that is not READY (inserted during this launch) is verified by
+//    comparing key bytes with the CLAIMER's request key (input data, always readable) instead of the
+//    stored key, whose writer may still be in flight; the inserter performs the same comparison, so
+//    every member of a segment provably has the key that ends up stored.
+__device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, uint32_t b) {
+    const uint32_t oa = B.key_off[a], ob = B.key_off[b];
+    const uint32_t la = B.key_off[a + 1] - oa, lb = B.key_off[b + 1] - ob;
+    if (la != lb) return false;
+    const uint8_t* pa = B.key_bytes + oa; const uint8_t* pb = B.key_bytes + ob;
+    const uint32_t nw = (la + 7) >> 3;
+    for (uint32_t w = 0; w < nw; ++w) {
+        uint64_t x = ld_key_word(pa + 8 * w), y = ld_key_word(pb + 8 * w);
+        if (w == nw - 1) { const uint64_t m = tail_mask(la - 8 * w); x &= m; y &= m; }
+        if (x != y) return false;
+    }
+    return true;
+}
+
+// one stable LDS radix pass over (key, val) pairs of a tile; returns the element's new position
+__device__ __forceinline__ uint32_t tile_radix_pass(uint32_t key, bool valid, int shift, uint32_t (*whist)[RADIX],
+                                                    uint32_t* dscan) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t j = tid; j < (TILE / 64) * RADIX; j += TILE) (&whist[0][0])[j] = 0;
+    __syncthreads();
+    const uint32_t digit = (key >> shift) & (RADIX - 1);
+    const unsigned long long peers = digit_peers(digit, valid);
+    const uint32_t rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
+    if (valid && rank_in_wave == 0) whist[wave][digit] = __popcll(peers);
+    __syncthreads();
+    uint32_t total = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < TILE / 64; ++w) { const uint32_t c = whist[w][tid]; whist[w][tid] = total; total += c; }
+        dscan[tid] = total;
+    }
+    __syncthreads();
+    for (uint32_t o = 1; o < RADIX; o <<= 1) {
+        uint32_t v = 0;
+        if (tid < RADIX && tid >= o) v = dscan[tid - o];
+        __syncthreads();
+        if (tid < RADIX) dscan[tid] += v;
+        __syncthreads();
+    }
+    uint32_t dst = 0;
+    if (valid) dst = (digit ? dscan[digit - 1] : 0) + whist[wave][digit] + rank_in_wave;
+    __syncthreads();
+    return dst;
+}
+
+__global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
+    __shared__ uint32_t whist[TILE / 64][RADIX];
+    __shared__ uint32_t dscan[RADIX];
+    __shared__ uint32_t skey[2][TILE];
+    __shared__ uint16_t sval[2][TILE];
+    __shared__ int red[TILE / 64];
+    __shared__ uint32_t wagg[2][TILE / 64];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = tile * TILE + tid;
+    const bool valid = g < B.n;
+    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
+    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap;
+
+    // ---- phase A: resolve + claim (per request) -------------------------------------------------
+    uint32_t d = 0;
+    int inserted = 0;
+    if (valid) {
+        const uint32_t off = B.key_off[g];
+        const uint32_t len = B.key_off[g + 1] - off;
+        const uint8_t* key = B.key_bytes + off;
+        uint32_t slot = 0;
+        uint8_t rf = 0;
+        uint32_t errcode = 0;
+        if (len == 0) errcode = IE_EMPTY_KEY;
+        else if (len > T.max_key) errcode = 7;
+        uint32_t pr = 0;
+        if (!errcode) {
+            pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
+            if (pr & PR_FULL) errcode = 6;
+        }
+        inserted = (pr & PR_INSERTED) ? 1 : 0;
+        if (errcode) {
+            d = g;
+            atomicOr(&seg_flags[d], SEG_ERR | (errcode << 8));
+            rf = RF_ERR | (inserted ? RF_INSERTED : 0);
+        } else {
+            if (inserted) rf |= RF_INSERTED;
+            unsigned long long* mp = &T.dir[slot].meta;
+            unsigned long long m = ld_agent(mp);
+            for (;;) {
+                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
+                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
+                const unsigned long long old = atomicCAS(mp, m, want);
+                if (old == m) { d = g; W.seg_slot[d] = slot; break; }
+                m = old;
+            }
+            if (d == g) {
+                W.snap[d] = T.recs[slot];                      // claimer snapshots the bucket
+            } else {
+                // entry created during this launch: prove key equality against the claimer's request
+                if ((pr & (PR_NEED_VERIFY | PR_INSERTED)) && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
+                const Req a = load_req(B, g), b = load_req(B, d);
+                if (!req_eq(a, b)) atomicOr(&seg_flags[d], SEG_NONUNIFORM);
+            }
+        }
+        W.did[g] = d; W.rflags[g] = rf;
+        if (inserted) W.slot[g] = slot;
+    }
+    const int ins = block_sum(inserted, red);
+    if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+
+    // ---- phase B: stable sort of the tile by segment id (16 bits), two LDS radix passes ----------
+    uint32_t p1 = tile_radix_pass(d, valid, 0, whist, dscan);
+    if (valid) { skey[0][p1] = d; sval[0][p1] = (uint16_t)tid; }
+    __syncthreads();
+    const uint32_t nvalid = (B.n - tile * TILE) < (uint32_t)TILE ? (B.n - tile * TILE) : (uint32_t)TILE;
+    const bool v2 = tid < nvalid;
+    const uint32_t k1 = v2 ? skey[0][tid] : 0;
+    const uint16_t l1 = v2 ? sval[0][tid] : 0;
+    uint32_t p2 = tile_radix_pass(k1, v2, RADIX_BITS, whist, dscan);
+    if (v2) { skey[1][p2] = k1; sval[1][p2] = l1; }
+    __syncthreads();
+
+    // ---- phase C: groups in sorted order: first / last position of my segment inside the tile -----
+    const uint32_t p = tid;
+    const uint32_t myk = v2 ? skey[1][p] : 0xffffffffu;
+    const bool head = v2 && (p == 0 || skey[1][p - 1] != myk);
+    const bool tail = v2 && (p == nvalid - 1 || skey[1][p + 1] != myk);
+    uint32_t firstp = head ? p : 0;                         // inclusive max-scan over positions
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(firstp, o, 64); if (lane >= (uint32_t)o) firstp = firstp > v ? firstp : v; }
+    uint32_t lastp = tail ? p : 0xffffffffu;                // inclusive min-scan from the right
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_down(lastp, o, 64); if (lane + o < 64) lastp = lastp < v ? lastp : v; }
+    if (lane == 63) wagg[0][wave] = firstp;
+    if (lane == 0) wagg[1][wave] = lastp;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; ++w) { const uint32_t v = wagg[0][w]; firstp = firstp > v ? firstp : v; }
+    for (uint32_t w = wave + 1; w < TILE / 64; ++w) { const uint32_t v = wagg[1][w]; lastp = lastp < v ? lastp : v; }
+    if (v2) {
+        const uint32_t req = tile * TILE + sval[1][p];
+        W.torder[tile * TILE + p] = req;
+        W.lrank[req] = (uint16_t)(p - firstp);
+        if (head) {
+            W.tilecnt[(size_t)myk * 64 + tile] = (uint16_t)(lastp - firstp + 1);
+            W.tilestart[(size_t)myk * 64 + tile] = (uint16_t)firstp;
+            atomicOr(&seg_mask[myk], 1ull << tile);
+        }
+    }
+}
+
+// k_eval2: one thread per request in request order.  rank = requests of my segment in earlier tiles
+// (bitmap + one 128-byte row of per-tile counts) + rank inside my tile.
+__global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
+    __shared__ int red[4];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
+    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap;
+    // clear the other copy for the next batch
+    {
+        uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
+        unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap;
+        for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) { of[j] = 0; om[j] = 0ull; }
+    }
+    int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
+    if (i < B.n) {
+        const uint32_t d = W.did[i];
+        const uint32_t sf = seg_flags[d];
+        const uint8_t rf = W.rflags[i];
+        if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);   // publish this batch's inserts
+        if (sf & SEG_ERR) {
+            store_err(R, i, (uint8_t)(sf >> 8));
+        } else if (sf & SEG_RETRY) {
+            store_err(R, i, IE_RETRY);
+            atomicAdd(&T.ctr->retries, 1ull);
+        } else {
+            const unsigned long long mask = seg_mask[d];
+            const uint32_t t = i / TILE;
+            const uint16_t* row = W.tilecnt + (size_t)d * 64;
+            uint32_t base = 0, total;
+            if ((mask & (mask - 1ull)) == 0ull) {
+                total = row[t];                                   // the segment lives in my tile only
+            } else {
+                total = 0;
+                const uint4* r4 = (const uint4*)row;              // 64 x u16 = 8 x 16 bytes, one round trip
+                uint4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = r4[q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t tlo = q * 8 + e * 2, thi = tlo + 1;
+                        const uint32_t clo = (mask >> tlo) & 1ull ? (w4[e] & 0xffffu) : 0u;
+                        const uint32_t chi = (mask >> thi) & 1ull ? (w4[e] >> 16) : 0u;
+                        total += clo + chi;
+                        base += (tlo < t ? clo : 0u) + (thi < t ? chi : 0u);
+                    }
+                }
+            }
+            const uint32_t rank = base + W.lrank[i];
+            const uint32_t slot = W.seg_slot[d];
+            if (!(sf & SEG_NONUNIFORM)) {
+                const Req r = load_req(B, i);
+                const Rec s0 = W.snap[d];
+                Rec after; Resp out;
+                const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
+                store_resp(R, i, out);
+                c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+                if (rank == total - 1) {
+                    T.recs[slot] = after;
+                    c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                }
+            } else if (rank == 0) {
+                // requests to this key differ: apply them one by one in request order (tiles in order,
+                // members of a tile in their sorted = request order)
+                const Rec s0 = W.snap[d];
+                Rec s = s0;
+                unsigned long long mm = mask;
+                while (mm) {
+                    const uint32_t tt = __ffsll((unsigned long long)mm) - 1;
+                    mm &= mm - 1ull;
+                    const uint32_t start = tt * TILE + W.tilestart[(size_t)d * 64 + tt];
+                    const uint32_t cnt = row[tt];
+                    for (uint32_t q = start; q < start + cnt; ++q) {
+                        const uint32_t j = W.torder[q];
+                        const Req rj = load_req(B, j);
+                        Resp out;
+                        const uint32_t ev = apply(s, rj, B.now_ms, out);
+                        store_resp(R, j, out);
+                        c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                    }
                 }
                 T.recs[slot] = s;
                 c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);

@@ -40,9 +40,11 @@ def test_get_peer_rate_limits_order_stable():
         e.close()
 
 
+# flags 0 = two-launch tile-bitmap pipeline (batches <= 65536); 2 = force the large-batch radix pipeline
+@pytest.mark.parametrize("flags", [0, 2])
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_adversarial_streams(seed):
-    o, e = Oracle(cache_size=1 << 20), engine()
+def test_adversarial_streams(seed, flags):
+    o, e = Oracle(cache_size=1 << 20), engine(flags=flags)
     for bi, b in enumerate(streams.adversarial_batches(seed, 60, 3000, greg_fn=support.gregorian)):
         want, got = o.eval(b), e.eval(b)
         support.assert_results_equal(got, want, f"seed {seed} batch {bi}")
@@ -50,20 +52,22 @@ def test_adversarial_streams(seed):
     e.close()
 
 
-def test_hot_key_runs():
+@pytest.mark.parametrize("flags", [0, 2])
+def test_hot_key_runs(flags):
     now = streams.NOW0
     for algo in (0, 1):
         for beh in (0, 32):
             for hits, limit in [(1, 100), (3, 100), (1, 5000), (5, 5)]:
-                o, e = Oracle(cache_size=1 << 16), engine(cache_size=1024, max_batch=8192)
+                o, e = Oracle(cache_size=1 << 16), engine(cache_size=1024, max_batch=8192, flags=flags)
                 for step in range(3):
                     b = HostBatch([b"hot_key"] * 6000, hits, limit, 60_000, now + step * 1700, algorithm=algo, behavior=beh)
                     support.assert_results_equal(e.eval(b), o.eval(b), f"algo {algo} beh {beh} hits {hits} step {step}")
                 e.close()
 
 
-def test_edge_cases_empty_ragged_long_keys():
-    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, max_key_bytes=300)
+@pytest.mark.parametrize("flags", [0, 2])
+def test_edge_cases_empty_ragged_long_keys(flags):
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, max_key_bytes=300, flags=flags)
     now = streams.NOW0
     # empty batch
     res = e.eval(HostBatch([], [], [], [], now))
@@ -85,10 +89,11 @@ def test_edge_cases_empty_ragged_long_keys():
     e.close()
 
 
-def test_hash_collisions_are_resolved_exactly():
+@pytest.mark.parametrize("flags", [1, 3])
+def test_hash_collisions_are_resolved_exactly(flags):
     """GUBER_FLAG_TEST_WEAK_HASH keeps 6 bits of the key hash: hundreds of distinct keys share a
     tag, so the exact key verification, probing past a collision and the in-batch retry path all run."""
-    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, flags=1)
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, flags=flags)
     rng = np.random.default_rng(5)
     now = streams.NOW0
     for step in range(6):
@@ -130,12 +135,13 @@ def test_cache_operations_add_get_remove_each():
     e.close()
 
 
-def test_zipf_bench_stream_midsize():
+@pytest.mark.parametrize("flags", [0, 2])
+def test_zipf_bench_stream_midsize(flags):
     """The BASELINE stream shape (Zipf 1.1, hits 1, limit 100, 60 s) at 200k keys / 16384 batch."""
     tab = streams.key_table(200_000)
     for algo in (0, 1):
         z = streams.ZipfSampler(200_000)
-        o, e = Oracle(cache_size=1 << 21), engine(cache_size=400_000, max_batch=16384)
+        o, e = Oracle(cache_size=1 << 21), engine(cache_size=400_000, max_batch=16384, flags=flags)
         for bi in range(10):
             b = streams.bench_batch(tab, z.draw(16384), streams.NOW0 + bi * 9_000, algorithm=algo)
             got, want = e.eval(b), o.eval(b)
@@ -173,4 +179,18 @@ def test_full_size_10m_keys_batch_65536():
                 assert (rem[:-1][under] - rem[1:][under] == 1).all()
                 assert (rem[st == 1] == 0).all() and (got.limit[:B] == 100).all()
     assert e.size() == o.size()
+    e.close()
+
+
+def test_large_batch_uses_radix_pipeline():
+    """Batches above 65536 requests take the global radix-sort kernel sequence (3 digit passes)."""
+    K, B = 300_000, 200_000
+    tab = streams.key_table(K)
+    z = streams.ZipfSampler(K, seed=7)
+    o, e = Oracle(cache_size=1 << 21), engine(cache_size=2 * K, max_batch=B)
+    for bi in range(3):
+        b = streams.bench_batch(tab, z.draw(B), streams.NOW0 + bi * 25_000, algorithm=bi % 2)
+        got, want = e.eval(b), o.eval(b)
+        support.assert_results_equal(got, want, f"large batch {bi}")
+        assert got.counters() == want.counters()
     e.close()
