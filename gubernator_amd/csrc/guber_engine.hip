@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -74,7 +75,7 @@ struct guber_engine {
     Table T{};
     Work W{};
     // table + work storage
-    DevBuf<DirEntry> dir; DevBuf<KeyCell> cells; DevBuf<Rec> recs; DevBuf<uint8_t> arena; DevBuf<DevCounters> ctr;
+    DevBuf<DirEntry> dir; DevBuf<Bucket> buckets; DevBuf<uint8_t> arena; DevBuf<DevCounters> ctr;
     DevBuf<uint32_t> w_u32;    // all u32 work arrays carved from one allocation
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
@@ -84,6 +85,8 @@ struct guber_engine {
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
+    bool careful = false;       // retry rounds run without speculative claims
+    DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -164,7 +167,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     }
     int rc = 0;
     const uint64_t arena_cap = std::max<uint64_t>(e->slots * 16, 1 << 20);   // long-key overflow arena
-    rc |= e->dir.ensure(e->slots); rc |= e->cells.ensure(e->slots); rc |= e->recs.ensure(e->slots);
+    rc |= e->dir.ensure(e->slots); rc |= e->buckets.ensure(e->slots);
     rc |= e->arena.ensure(arena_cap + 64); rc |= e->ctr.ensure(1); rc |= e->h_ctr.ensure(1);
     const uint32_t M = e->max_batch;
     const uint32_t tiles = (M + TILE - 1) / TILE;
@@ -181,7 +184,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
     hipError_t he = hipSuccess;
     if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
-        (he = hipMemsetAsync(e->recs.p, 0, e->slots * sizeof(Rec), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->buckets.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->bctr.p, 0, e->n_bctr * sizeof(BlockCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * 8, e->stream)) != hipSuccess ||
@@ -191,7 +194,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         guber_engine_destroy(e);
         return fail(GUBER_E_HIP, "table initialisation", he);
     }
-    e->T.dir = e->dir.p; e->T.cells = e->cells.p; e->T.recs = e->recs.p; e->T.arena = e->arena.p;
+    e->T.dir = e->dir.p; e->T.buckets = e->buckets.p; e->T.arena = e->arena.p;
     e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p; e->T.bctr = e->bctr.p;
     e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 16); e->T.max_key = e->max_key;
     e->T.hash_mask = (cfg->flags & GUBER_FLAG_TEST_WEAK_HASH) ? 0x1f80ull : ~0ull;   // 6 significant bits
@@ -205,7 +208,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.tiles = tiles; e->W.epoch = 0;
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
     e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
-    e->W.parity = 0; e->W.clear_n = 0;
+    e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
+    if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)tiles * 8) == 0) e->W.dbg = e->dbg.p; }
     *out = e;
     return GUBER_OK;
 }
@@ -214,7 +218,14 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    e->dir.release(); e->cells.release(); e->recs.release(); e->arena.release(); e->ctr.release();
+    if (e->dbg_n) {   // wall_clock64 ticks at 100 MHz
+        const double per = 1.0 / (double)e->dbg_n * 0.01;
+        fprintf(stderr, "[guber phase timing] k_front per tile: resolve %.2f us, sort %.2f us, group %.2f us; kernel span %.2f us\n",
+                e->dbg_sum[0] * per, e->dbg_sum[1] * per, e->dbg_sum[2] * per,
+                e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 64.0));
+    }
+    e->dbg.release();
+    e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_flags2.release(); e->w_tilecnt.release(); e->w_tilestart.release();
@@ -252,11 +263,25 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         // two launches: resolve + in-tile grouping, then evaluation
         BatchView B2 = B;
         B2.n_cap = e->fast_cap;
+        W.careful = e->careful ? 1u : 0u;
         W.parity = e->fast_batches & 1u;
         W.clear_n = e->fast_prev_n;
+        W.dbg = e->dbg.p;
         e->span_begin(KT_FRONT);
         hipLaunchKernelGGL(k_front, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B2, W);
         e->span_end();
+        if (e->dbg.p && e->fast_batches > 200 && e->fast_batches % 8 == 0) {   // debug only: sync + fold stamps
+            std::vector<unsigned long long> h(tiles * 8);
+            (void)hipMemcpyAsync(h.data(), e->dbg.p, h.size() * 8, hipMemcpyDeviceToHost, e->stream);
+            (void)hipStreamSynchronize(e->stream);
+            unsigned long long t0 = ~0ull, t3 = 0;
+            for (uint32_t t = 0; t < tiles; ++t) {
+                for (int k = 0; k < 3; ++k) e->dbg_sum[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + k]);
+                t0 = std::min(t0, h[t * 8]); t3 = std::max(t3, h[t * 8 + 3]);
+            }
+            e->dbg_sum[3] += (double)(t3 - t0);
+            e->dbg_n += tiles;
+        }
         e->span_begin(KT_EVAL2);
         hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
         e->span_end();
@@ -406,7 +431,9 @@ extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber
             std::vector<uint32_t> again;
             for (uint32_t i = 0; i < b->n; ++i) if (r->err[i] == GUBER_ITEM_E_RETRY) again.push_back(i);
             if (again.empty()) break;
+            e->careful = true;
             rc = eval_host_once(e, b, r, again.data(), (uint32_t)again.size());
+            e->careful = false;
             if (rc) return rc;
         }
         fold_counters(e);

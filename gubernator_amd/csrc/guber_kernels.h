@@ -1,9 +1,10 @@
 // guber_kernels.h — device-side data layout and the gfx950 kernels of the batched rate-limit path.
 //
 // HBM layout (one engine = one GPU = one shard of the key space):
-//   dir[slots]    16 B  {tag = XXH64(key) (0 = empty), meta = READY | epoch | dense id}   probe target
-//   cells[slots]  64 B  key bytes (<= 62 inline, longer keys live in the arena) + u16 length
-//   recs[slots]   64 B  guber::Rec — the bucket (CacheItem + Token/LeakyBucketItem), one sector
+//   dir[slots]      16 B  {tag = XXH64(key) (0 = empty), meta = READY | epoch | segment id}  probe target
+//   buckets[slots] 128 B  key cell (key bytes <= 62 inline, longer keys in the arena, u16 length) +
+//                         guber::Rec (CacheItem + Token/LeakyBucketItem): two adjacent 64-byte sectors,
+//                         fetched together in one round trip
 // `slots` is a power of two >= 2 x cache_size; linear probing; tags are write-once (a removed bucket
 // keeps its tag and key, its record becomes K_ABSENT) so probing never needs tombstone handling.
 //
@@ -37,6 +38,7 @@ constexpr int MAX_PASSES = 3;           // dense ids < 2^24
 
 struct DirEntry { unsigned long long tag; unsigned long long meta; };
 struct alignas(64) KeyCell { uint64_t w[8]; };
+struct alignas(128) Bucket { KeyCell cell; Rec rec; };
 constexpr uint32_t INLINE_KEY = 62;
 constexpr unsigned long long META_READY = 1ull << 63;
 
@@ -50,7 +52,7 @@ struct DevCounters {
 struct BlockCounters { unsigned long long over, hits, misses; long long size_delta; };
 
 struct Table {
-    DirEntry* dir; KeyCell* cells; Rec* recs; uint8_t* arena;
+    DirEntry* dir; Bucket* buckets; uint8_t* arena;
     uint64_t mask; uint64_t arena_cap; DevCounters* ctr; BlockCounters* bctr;
     uint32_t max_probe; uint32_t max_key;
     uint64_t hash_mask;   // ~0; tests narrow it to force 64-bit-hash collisions through the verify / retry path
@@ -91,6 +93,8 @@ struct Work {
     uint16_t* tilestart;                // [max_batch][64]
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
+    unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
+    uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
 };
@@ -128,7 +132,7 @@ __device__ __forceinline__ void store_err(const ResultView& R, uint32_t i, uint8
 
 // exact key comparison against the key stored for `slot`
 __device__ __forceinline__ bool key_equal(const Table& T, uint64_t slot, const uint8_t* key, uint32_t len) {
-    const KeyCell* c = &T.cells[slot];
+    const KeyCell* c = &T.buckets[slot].cell;
     uint64_t w7 = c->w[7];
     if ((uint32_t)(w7 >> 48) != len) return false;
     const uint8_t* stored = nullptr;
@@ -147,7 +151,7 @@ __device__ __forceinline__ bool key_equal(const Table& T, uint64_t slot, const u
 
 // store the key of a freshly claimed slot; false = key arena exhausted
 __device__ __forceinline__ bool key_store(const Table& T, uint64_t slot, const uint8_t* key, uint32_t len) {
-    KeyCell* c = &T.cells[slot];
+    KeyCell* c = &T.buckets[slot].cell;
     uint64_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = 0;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, 
             }
             if (rf & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
             if (d == g) {
-                W.snap[d] = T.recs[slot];
+                W.snap[d] = T.buckets[slot].rec;
             } else {
                 Req a = load_req(B, g), b = load_req(B, d);
                 if (!req_eq(a, b)) atomicOr(&W.seg_flags[d], SEG_NONUNIFORM);
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 store_resp(R, i, out);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == last - first) {
-                    T.recs[slot] = after;
+                    T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 }
             } else if (rank == 0) {
@@ -450,7 +454,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     store_resp(R, j, out);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
-                T.recs[slot] = s;
+                T.buckets[slot].rec = s;
                 c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
             }
         }
@@ -532,7 +536,13 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap;
 
+#define GB_STAMP(k) do { if (W.dbg && tid == 0) W.dbg[tile * 8 + (k)] = wall_clock64(); } while (0)
+    GB_STAMP(0);
     // ---- phase A: resolve + claim (per request) -------------------------------------------------
+    // Dependent round trips for a resident key: key_off -> key bytes -> directory entry (16 B) ->
+    // {bucket (128 B) || claim CAS} -> stores.  The claim is issued BEFORE the stored key has been
+    // compared (speculation): a 64-bit-hash collision then shows up as a failed comparison and the
+    // whole segment is answered GUBER_ITEM_E_RETRY and re-run in careful mode.
     uint32_t d = 0;
     int inserted = 0;
     if (valid) {
@@ -542,43 +552,140 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
         uint32_t slot = 0;
         uint8_t rf = 0;
         uint32_t errcode = 0;
+        bool fresh = false, claimed = false, have_d = false;
+        Rec rec; rec_clear(rec);
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
-        uint32_t pr = 0;
         if (!errcode) {
-            pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
-            if (pr & PR_FULL) errcode = 6;
+            uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
+            const unsigned long long tag = h ? h : 1ull;
+            uint64_t pos = (h >> 7) & T.mask;
+            bool done = false;
+            for (uint32_t step = 0; step < T.max_probe && !done; ++step, pos = (pos + 1) & T.mask) {
+                const ulonglong2 e = *(const ulonglong2*)&T.dir[pos];          // tag + meta in one load
+                unsigned long long t = e.x, m = e.y;
+                if (t == 0ull) {
+                    const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
+                    if (old == 0ull) {
+                        slot = (uint32_t)pos; inserted = 1; fresh = true; done = true;
+                        if (!key_store(T, pos, key, len)) errcode = 6;
+                        rec = T.buckets[pos].rec;                              // zero unless a removed bucket is reused
+                        m = 0ull;
+                        if (!errcode) { have_d = true; }
+                        // claim below
+                        if (!errcode) {
+                            unsigned long long* mp = &T.dir[pos].meta;
+                            for (;;) {
+                                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
+                                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
+                                const unsigned long long o2 = atomicCAS(mp, m, want);
+                                if (o2 == m) { d = g; claimed = true; break; }
+                                m = o2;
+                            }
+                        }
+                        break;
+                    }
+                    t = old;
+                    m = 0ull;   // meta of an entry claimed a moment ago: re-read through the CAS below
+                }
+                if (t != tag) continue;
+                unsigned long long* mp = &T.dir[pos].meta;
+                if (!(m & META_READY) && t == tag && e.x == 0ull) m = ld_agent(mp);
+                if (m & META_READY) {
+                    // resident entry: fetch key cell + record, claim, then compare
+                    const Bucket* bk = &T.buckets[pos];
+                    const uint4* cw = (const uint4*)&bk->cell;
+                    const uint4 c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3];
+                    rec = bk->rec;
+                    uint32_t dd = 0; bool cl = false;
+                    if (!W.careful) {
+                        for (;;) {
+                            if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { dd = (uint32_t)m; break; }
+                            const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
+                            const unsigned long long o2 = atomicCAS(mp, m, want);
+                            if (o2 == m) { dd = g; cl = true; break; }
+                            m = o2;
+                        }
+                    }
+                    // compare the stored key with mine
+                    const uint64_t cell[8] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z,
+                                              ((uint64_t)c1.y << 32) | c1.x, ((uint64_t)c1.w << 32) | c1.z,
+                                              ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z,
+                                              ((uint64_t)c3.y << 32) | c3.x, ((uint64_t)c3.w << 32) | c3.z};
+                    bool eq = (uint32_t)(cell[7] >> 48) == len;
+                    if (eq) {
+                        if (len <= INLINE_KEY) {
+                            const uint32_t nw = (len + 7) >> 3;
+#pragma unroll
+                            for (uint32_t w = 0; w < 8; ++w) {
+                                if (w < nw) {
+                                    uint64_t kv = ld_key_word(key + 8 * w), cv = cell[w];
+                                    if (w == 7) cv &= 0x0000ffffffffffffull;
+                                    if (w == nw - 1) { const uint64_t mk = tail_mask(len - 8 * w); kv &= mk; cv &= mk; }
+                                    eq = eq && (kv == cv);
+                                }
+                            }
+                        } else {
+                            eq = key_equal(T, pos, key, len);
+                        }
+                    }
+                    if (eq) {
+                        slot = (uint32_t)pos; done = true; have_d = true;
+                        if (W.careful) {
+                            for (;;) {
+                                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { dd = (uint32_t)m; break; }
+                                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
+                                const unsigned long long o2 = atomicCAS(mp, m, want);
+                                if (o2 == m) { dd = g; cl = true; break; }
+                                m = o2;
+                            }
+                        }
+                        d = dd; claimed = cl;
+                    } else if (!W.careful) {
+                        // speculation failed: I am a member of a foreign segment -> retry everybody in it
+                        slot = (uint32_t)pos; done = true; have_d = true;
+                        d = dd; claimed = cl;
+                        atomicOr(&seg_flags[d], SEG_RETRY);
+                    }
+                    // careful mode + mismatch: keep probing
+                } else {
+                    // entry inserted during this launch by another thread: tentative member
+                    slot = (uint32_t)pos; done = true; fresh = true; have_d = true;
+                    rec = T.buckets[pos].rec;
+                    for (;;) {
+                        if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
+                        const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
+                        const unsigned long long o2 = atomicCAS(mp, m, want);
+                        if (o2 == m) { d = g; claimed = true; break; }
+                        m = o2;
+                    }
+                }
+            }
+            if (!done && !errcode) errcode = 6;     // probe bound exceeded: table full
         }
-        inserted = (pr & PR_INSERTED) ? 1 : 0;
         if (errcode) {
             d = g;
             atomicOr(&seg_flags[d], SEG_ERR | (errcode << 8));
             rf = RF_ERR | (inserted ? RF_INSERTED : 0);
         } else {
             if (inserted) rf |= RF_INSERTED;
-            unsigned long long* mp = &T.dir[slot].meta;
-            unsigned long long m = ld_agent(mp);
-            for (;;) {
-                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
-                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
-                const unsigned long long old = atomicCAS(mp, m, want);
-                if (old == m) { d = g; W.seg_slot[d] = slot; break; }
-                m = old;
-            }
-            if (d == g) {
-                W.snap[d] = T.recs[slot];                      // claimer snapshots the bucket
+            if (claimed) {
+                W.seg_slot[d] = slot;
+                W.snap[d] = rec;                               // claimer snapshots the bucket
             } else {
                 // entry created during this launch: prove key equality against the claimer's request
-                if ((pr & (PR_NEED_VERIFY | PR_INSERTED)) && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
+                if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
                 const Req a = load_req(B, g), b = load_req(B, d);
                 if (!req_eq(a, b)) atomicOr(&seg_flags[d], SEG_NONUNIFORM);
             }
         }
+        (void)have_d;
         W.did[g] = d; W.rflags[g] = rf;
         if (inserted) W.slot[g] = slot;
     }
     const int ins = block_sum(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+    GB_STAMP(1);
 
     // ---- phase B: stable sort of the tile by segment id (16 bits), two LDS radix passes ----------
     uint32_t p1 = tile_radix_pass(d, valid, 0, whist, dscan);
@@ -592,6 +699,7 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
     if (v2) { skey[1][p2] = k1; sval[1][p2] = l1; }
     __syncthreads();
 
+    GB_STAMP(2);
     // ---- phase C: groups in sorted order: first / last position of my segment inside the tile -----
     const uint32_t p = tid;
     const uint32_t myk = v2 ? skey[1][p] : 0xffffffffu;
@@ -618,6 +726,9 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
             atomicOr(&seg_mask[myk], 1ull << tile);
         }
     }
+    __syncthreads();
+    GB_STAMP(3);
+#undef GB_STAMP
 }
 
 // k_eval2: one thread per request in request order.  rank = requests of my segment in earlier tiles
@@ -680,7 +791,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                 store_resp(R, i, out);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == total - 1) {
-                    T.recs[slot] = after;
+                    T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 }
             } else if (rank == 0) {
@@ -703,7 +814,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                         c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                     }
                 }
-                T.recs[slot] = s;
+                T.buckets[slot].rec = s;
                 c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
             }
         }
@@ -751,8 +862,8 @@ __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* ite
     if (f & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
     if (f & RF_ERR) { result[i] = 0xFE; return; }
     if ((f & RF_NEED_VERIFY) && !key_equal(T, slot, keys + items[i].key_off, items[i].key_len)) { result[i] = 0xFF; return; }
-    const bool existed = rec_kind(T.recs[slot]) != K_ABSENT;
-    T.recs[slot] = items[i].rec;
+    const bool existed = rec_kind(T.buckets[slot].rec) != K_ABSENT;
+    T.buckets[slot].rec = items[i].rec;
     if (!existed) atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
     result[i] = existed ? 1 : 0;
 }
@@ -765,11 +876,11 @@ __global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t
     if (len == 0 || len > T.max_key) return;
     uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), false, slot);
     Rec s; rec_clear(s);
-    if (pr & PR_FOUND) s = T.recs[slot];
+    if (pr & PR_FOUND) s = T.buckets[slot].rec;
     if (rec_kind(s) == K_ABSENT) { if (mode == 0) atomicAdd(&T.ctr->misses, 1ull); return; }
     if (mode == 1 || rec_expired(s, now)) {
         Rec z; rec_clear(z);
-        T.recs[slot] = z;
+        T.buckets[slot].rec = z;
         atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)-1);
         if (mode == 0) atomicAdd(&T.ctr->misses, 1ull);
         return;
@@ -784,10 +895,10 @@ __global__ __launch_bounds__(256) void k_dump(Table T, uint64_t slots, Rec* out_
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= slots) return;
     if (T.dir[s].tag == 0ull) return;
-    Rec r = T.recs[s];
+    Rec r = T.buckets[s].rec;
     if (rec_kind(r) == K_ABSENT) return;
     unsigned long long idx = atomicAdd(count, 1ull);
-    if (idx < cap) { out_recs[idx] = r; out_cells[idx] = T.cells[s]; }
+    if (idx < cap) { out_recs[idx] = r; out_cells[idx] = T.buckets[s].cell; }
 }
 
 // wrap of the 31-bit batch epoch: forget every dense-id claim
