@@ -174,10 +174,10 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_u32.ensure((size_t)M * 14);
     rc |= e->w_rflags.ensure(M); rc |= e->w_snap.ensure(M);
     rc |= e->w_hist.ensure((size_t)MAX_PASSES * RADIX * tiles);
-    e->fast_cap = std::min<uint32_t>(M, 64 * TILE);
+    e->fast_cap = std::min<uint32_t>(M, FT * FT_MAX_TILES);
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
-    rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
-    rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * 64); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * 64);
+    rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
+    rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     e->n_bctr = (M + 255) / 256;
     rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
@@ -187,7 +187,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->buckets.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->bctr.p, 0, e->n_bctr * sizeof(BlockCounters), e->stream)) != hipSuccess ||
-        (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * 8, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_flags2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
@@ -209,7 +209,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
     e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
     e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
-    if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)tiles * 8) == 0) e->W.dbg = e->dbg.p; }
+    if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)FT_MAX_TILES * 8) == 0) e->W.dbg = e->dbg.p; }
     *out = e;
     return GUBER_OK;
 }
@@ -222,7 +222,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
         const double per = 1.0 / (double)e->dbg_n * 0.01;
         fprintf(stderr, "[guber phase timing] k_front per tile: resolve %.2f us, sort %.2f us, group %.2f us; kernel span %.2f us\n",
                 e->dbg_sum[0] * per, e->dbg_sum[1] * per, e->dbg_sum[2] * per,
-                e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 64.0));
+                e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 256.0));
     }
     e->dbg.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
@@ -263,24 +263,25 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         // two launches: resolve + in-tile grouping, then evaluation
         BatchView B2 = B;
         B2.n_cap = e->fast_cap;
+        const uint32_t ftiles = (n + FT - 1) / FT;
         W.careful = e->careful ? 1u : 0u;
         W.parity = e->fast_batches & 1u;
         W.clear_n = e->fast_prev_n;
         W.dbg = e->dbg.p;
         e->span_begin(KT_FRONT);
-        hipLaunchKernelGGL(k_front, dim3(tiles), dim3(TILE), 0, e->stream, e->T, B2, W);
+        hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
         if (e->dbg.p && e->fast_batches > 200 && e->fast_batches % 8 == 0) {   // debug only: sync + fold stamps
-            std::vector<unsigned long long> h(tiles * 8);
+            std::vector<unsigned long long> h(ftiles * 8);
             (void)hipMemcpyAsync(h.data(), e->dbg.p, h.size() * 8, hipMemcpyDeviceToHost, e->stream);
             (void)hipStreamSynchronize(e->stream);
             unsigned long long t0 = ~0ull, t3 = 0;
-            for (uint32_t t = 0; t < tiles; ++t) {
+            for (uint32_t t = 0; t < ftiles; ++t) {
                 for (int k = 0; k < 3; ++k) e->dbg_sum[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + k]);
                 t0 = std::min(t0, h[t * 8]); t3 = std::max(t3, h[t * 8 + 3]);
             }
             e->dbg_sum[3] += (double)(t3 - t0);
-            e->dbg_n += tiles;
+            e->dbg_n += ftiles;
         }
         e->span_begin(KT_EVAL2);
         hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);

@@ -83,14 +83,14 @@ struct Work {
     uint32_t* hist;        // [MAX_PASSES][tiles][RADIX], raw per-tile digit counts
     uint32_t tiles;        // tiles of this batch
     uint32_t epoch;        // 1 .. 2^31-1
-    // tile-bitmap grouping (batches of <= 64 tiles): per segment a bitmap of the tiles holding its
+    // tile-bitmap grouping (batches of <= FT_MAX_TILES tiles of FT requests): per segment a bitmap of the tiles holding its
     // requests and, per (segment, tile), the group's size and start inside the tile's sorted order.
     // seg_flags / seg_tilemask are double-buffered by batch parity: a batch's eval kernel clears the
     // other copy for the next batch, so no memset launch is needed.
-    unsigned long long* seg_tilemask;   // [2][max_batch]
-    uint32_t* seg_flags2;               // [2][max_batch]
-    uint16_t* tilecnt;                  // [max_batch][64]
-    uint16_t* tilestart;                // [max_batch][64]
+    unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]
+    uint32_t* seg_flags2;               // [2][cap]
+    uint16_t* tilecnt;                  // [cap][FT_MAX_TILES]
+    uint16_t* tilestart;                // [cap][FT_MAX_TILES]
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
     unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
@@ -469,15 +469,29 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pipeline for batches of <= 64 tiles (65536 requests): TWO launches.
+// Pipeline for batches of <= FT_MAX_TILES tiles of FT requests (65536 requests): TWO launches.
 //
-// k_front: resolve (as k_resolve) and, in the same workgroup, group the tile's 1024 requests by
-// segment id with a stable 2-pass LDS radix sort; publish per (segment, tile) group size / start and
-// set the tile's bit in the segment's bitmap.  Nothing here depends on another workgroup:
-//  - a match on a directory entry that is not READY (inserted during this launch) is verified by
-//    comparing key bytes with the CLAIMER's request key (input data, always readable) instead of the
-//    stored key, whose writer may still be in flight; the inserter performs the same comparison, so
-//    every member of a segment provably has the key that ends up stored.
+// Measured on MI355X (tools/microbench.hip): the random-access part (16 B directory entry, 128 B
+// bucket, claim CAS for 65536 requests) takes ~5 us with 256-thread workgroups spread over all 256 CUs
+// and ~15 us with 1024-thread workgroups on 64 CUs (per-CU L1 request rate), and atomics on ONE address
+// serialise at ~12 ns each.  Hence: 256-request tiles, sc1 (L1-bypassing) directory loads so that only
+// the first toucher of a key issues a CAS, and no per-key atomics other than one bitmap OR per
+// (key, tile) group.
+//
+// k_front (one workgroup = one tile of FT requests):
+//   A  resolve: key -> directory entry -> {bucket fetch || speculative claim CAS} -> verify.
+//      Segment id of a key = request index of its first toucher.  A match on an entry that is not
+//      READY (inserted during this launch) is verified against the CLAIMER's request key (input data)
+//      instead of the stored key, whose writer may still be in flight; the inserter performs the same
+//      comparison, so every member of a segment provably has the key that ends up stored.
+//   B  group the tile by segment id: an all-pairs count in LDS (FT = 256 keys) gives every request its
+//      sorted position, its rank inside its (segment, tile) group and the group size directly.
+//   C  group heads publish size / start for (segment, tile) and set the tile bit in the segment bitmap.
+// k_eval2 (request order): rank = members in earlier tiles (bitmap + per-tile counts) + rank in tile.
+constexpr int FT = 256;                 // requests per tile in the two-launch pipeline
+constexpr int FT_MAX_TILES = 256;       // bitmap bits per segment
+constexpr int FT_WORDS = FT_MAX_TILES / 64;
+
 __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, uint32_t b) {
     const uint32_t oa = B.key_off[a], ob = B.key_off[b];
     const uint32_t la = B.key_off[a + 1] - oa, lb = B.key_off[b + 1] - ob;
@@ -492,58 +506,31 @@ __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, ui
     return true;
 }
 
-// one stable LDS radix pass over (key, val) pairs of a tile; returns the element's new position
-__device__ __forceinline__ uint32_t tile_radix_pass(uint32_t key, bool valid, int shift, uint32_t (*whist)[RADIX],
-                                                    uint32_t* dscan) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t j = tid; j < (TILE / 64) * RADIX; j += TILE) (&whist[0][0])[j] = 0;
-    __syncthreads();
-    const uint32_t digit = (key >> shift) & (RADIX - 1);
-    const unsigned long long peers = digit_peers(digit, valid);
-    const uint32_t rank_in_wave = __popcll(peers & ((1ull << lane) - 1ull));
-    if (valid && rank_in_wave == 0) whist[wave][digit] = __popcll(peers);
-    __syncthreads();
-    uint32_t total = 0;
-    if (tid < RADIX) {
-#pragma unroll
-        for (int w = 0; w < TILE / 64; ++w) { const uint32_t c = whist[w][tid]; whist[w][tid] = total; total += c; }
-        dscan[tid] = total;
+// claim the segment id of a directory entry for this batch; m = last known meta value
+__device__ __forceinline__ uint32_t claim_segment(unsigned long long* mp, unsigned long long m, uint32_t epoch, uint32_t g,
+                                                 bool& claimed) {
+    for (;;) {
+        if ((uint32_t)((m >> 32) & 0x7fffffffu) == epoch) return (uint32_t)m;
+        const unsigned long long want = (m & META_READY) | ((unsigned long long)epoch << 32) | g;
+        const unsigned long long old = atomicCAS(mp, m, want);
+        if (old == m) { claimed = true; return g; }
+        m = old;
     }
-    __syncthreads();
-    for (uint32_t o = 1; o < RADIX; o <<= 1) {
-        uint32_t v = 0;
-        if (tid < RADIX && tid >= o) v = dscan[tid - o];
-        __syncthreads();
-        if (tid < RADIX) dscan[tid] += v;
-        __syncthreads();
-    }
-    uint32_t dst = 0;
-    if (valid) dst = (digit ? dscan[digit - 1] : 0) + whist[wave][digit] + rank_in_wave;
-    __syncthreads();
-    return dst;
 }
 
-__global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
-    __shared__ uint32_t whist[TILE / 64][RADIX];
-    __shared__ uint32_t dscan[RADIX];
-    __shared__ uint32_t skey[2][TILE];
-    __shared__ uint16_t sval[2][TILE];
-    __shared__ int red[TILE / 64];
-    __shared__ uint32_t wagg[2][TILE / 64];
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t g = tile * TILE + tid;
+__global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
+    __shared__ uint32_t skey[FT];
+    __shared__ int red[FT / 64];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
-    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap;
-
+    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
 #define GB_STAMP(k) do { if (W.dbg && tid == 0) W.dbg[tile * 8 + (k)] = wall_clock64(); } while (0)
     GB_STAMP(0);
-    // ---- phase A: resolve + claim (per request) -------------------------------------------------
-    // Dependent round trips for a resident key: key_off -> key bytes -> directory entry (16 B) ->
-    // {bucket (128 B) || claim CAS} -> stores.  The claim is issued BEFORE the stored key has been
-    // compared (speculation): a 64-bit-hash collision then shows up as a failed comparison and the
-    // whole segment is answered GUBER_ITEM_E_RETRY and re-run in careful mode.
-    uint32_t d = 0;
+
+    // ---- phase A --------------------------------------------------------------------------------
+    uint32_t d = 0xffffffffu;
     int inserted = 0;
     if (valid) {
         const uint32_t off = B.key_off[g];
@@ -552,62 +539,40 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
         uint32_t slot = 0;
         uint8_t rf = 0;
         uint32_t errcode = 0;
-        bool fresh = false, claimed = false, have_d = false;
+        bool fresh = false, claimed = false;
         Rec rec; rec_clear(rec);
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
         if (!errcode) {
-            uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
+            const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
             const unsigned long long tag = h ? h : 1ull;
             uint64_t pos = (h >> 7) & T.mask;
             bool done = false;
             for (uint32_t step = 0; step < T.max_probe && !done; ++step, pos = (pos + 1) & T.mask) {
-                const ulonglong2 e = *(const ulonglong2*)&T.dir[pos];          // tag + meta in one load
-                unsigned long long t = e.x, m = e.y;
+                unsigned long long* mp = &T.dir[pos].meta;
+                unsigned long long t = ld_agent(&T.dir[pos].tag);   // both sc1 loads issue back to back:
+                unsigned long long m = ld_agent(mp);                // one round trip, never a stale L1 line
                 if (t == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
-                    if (old == 0ull) {
+                    if (old == 0ull) {                               // new key: this thread inserts it
                         slot = (uint32_t)pos; inserted = 1; fresh = true; done = true;
-                        if (!key_store(T, pos, key, len)) errcode = 6;
-                        rec = T.buckets[pos].rec;                              // zero unless a removed bucket is reused
-                        m = 0ull;
-                        if (!errcode) { have_d = true; }
-                        // claim below
-                        if (!errcode) {
-                            unsigned long long* mp = &T.dir[pos].meta;
-                            for (;;) {
-                                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
-                                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
-                                const unsigned long long o2 = atomicCAS(mp, m, want);
-                                if (o2 == m) { d = g; claimed = true; break; }
-                                m = o2;
-                            }
-                        }
+                        if (!key_store(T, pos, key, len)) { errcode = 6; break; }
+                        rec = T.buckets[pos].rec;                    // zero for a never-used bucket
+                        d = claim_segment(mp, 0ull, W.epoch, g, claimed);
                         break;
                     }
                     t = old;
-                    m = 0ull;   // meta of an entry claimed a moment ago: re-read through the CAS below
+                    m = ld_agent(mp);
                 }
                 if (t != tag) continue;
-                unsigned long long* mp = &T.dir[pos].meta;
-                if (!(m & META_READY) && t == tag && e.x == 0ull) m = ld_agent(mp);
                 if (m & META_READY) {
-                    // resident entry: fetch key cell + record, claim, then compare
+                    // resident entry: fetch key cell + record, claim, then compare the key
                     const Bucket* bk = &T.buckets[pos];
                     const uint4* cw = (const uint4*)&bk->cell;
                     const uint4 c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3];
                     rec = bk->rec;
                     uint32_t dd = 0; bool cl = false;
-                    if (!W.careful) {
-                        for (;;) {
-                            if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { dd = (uint32_t)m; break; }
-                            const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
-                            const unsigned long long o2 = atomicCAS(mp, m, want);
-                            if (o2 == m) { dd = g; cl = true; break; }
-                            m = o2;
-                        }
-                    }
-                    // compare the stored key with mine
+                    if (!W.careful) dd = claim_segment(mp, m, W.epoch, g, cl);
                     const uint64_t cell[8] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z,
                                               ((uint64_t)c1.y << 32) | c1.x, ((uint64_t)c1.w << 32) | c1.z,
                                               ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z,
@@ -630,35 +595,21 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
                         }
                     }
                     if (eq) {
-                        slot = (uint32_t)pos; done = true; have_d = true;
-                        if (W.careful) {
-                            for (;;) {
-                                if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { dd = (uint32_t)m; break; }
-                                const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
-                                const unsigned long long o2 = atomicCAS(mp, m, want);
-                                if (o2 == m) { dd = g; cl = true; break; }
-                                m = o2;
-                            }
-                        }
+                        slot = (uint32_t)pos; done = true;
+                        if (W.careful) dd = claim_segment(mp, m, W.epoch, g, cl);
                         d = dd; claimed = cl;
                     } else if (!W.careful) {
-                        // speculation failed: I am a member of a foreign segment -> retry everybody in it
-                        slot = (uint32_t)pos; done = true; have_d = true;
+                        // speculation failed (64-bit hash collision with a resident key): I joined a
+                        // foreign segment -> everybody in it is answered RETRY and re-run carefully
+                        slot = (uint32_t)pos; done = true;
                         d = dd; claimed = cl;
                         atomicOr(&seg_flags[d], SEG_RETRY);
                     }
-                    // careful mode + mismatch: keep probing
                 } else {
                     // entry inserted during this launch by another thread: tentative member
-                    slot = (uint32_t)pos; done = true; fresh = true; have_d = true;
+                    slot = (uint32_t)pos; done = true; fresh = true;
                     rec = T.buckets[pos].rec;
-                    for (;;) {
-                        if ((uint32_t)((m >> 32) & 0x7fffffffu) == W.epoch) { d = (uint32_t)m; break; }
-                        const unsigned long long want = (m & META_READY) | ((unsigned long long)W.epoch << 32) | g;
-                        const unsigned long long o2 = atomicCAS(mp, m, want);
-                        if (o2 == m) { d = g; claimed = true; break; }
-                        m = o2;
-                    }
+                    d = claim_segment(mp, m, W.epoch, g, claimed);
                 }
             }
             if (!done && !errcode) errcode = 6;     // probe bound exceeded: table full
@@ -673,76 +624,65 @@ __global__ __launch_bounds__(TILE) void k_front(Table T, BatchView B, Work W) {
                 W.seg_slot[d] = slot;
                 W.snap[d] = rec;                               // claimer snapshots the bucket
             } else {
-                // entry created during this launch: prove key equality against the claimer's request
                 if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
                 const Req a = load_req(B, g), b = load_req(B, d);
                 if (!req_eq(a, b)) atomicOr(&seg_flags[d], SEG_NONUNIFORM);
             }
         }
-        (void)have_d;
         W.did[g] = d; W.rflags[g] = rf;
         if (inserted) W.slot[g] = slot;
     }
-    const int ins = block_sum(inserted, red);
+    skey[tid] = d;                                             // 0xffffffff for lanes past the batch end
+    const int ins = block_sum(inserted, red);                  // (barriers inside publish skey)
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
     GB_STAMP(1);
 
-    // ---- phase B: stable sort of the tile by segment id (16 bits), two LDS radix passes ----------
-    uint32_t p1 = tile_radix_pass(d, valid, 0, whist, dscan);
-    if (valid) { skey[0][p1] = d; sval[0][p1] = (uint16_t)tid; }
-    __syncthreads();
-    const uint32_t nvalid = (B.n - tile * TILE) < (uint32_t)TILE ? (B.n - tile * TILE) : (uint32_t)TILE;
-    const bool v2 = tid < nvalid;
-    const uint32_t k1 = v2 ? skey[0][tid] : 0;
-    const uint16_t l1 = v2 ? sval[0][tid] : 0;
-    uint32_t p2 = tile_radix_pass(k1, v2, RADIX_BITS, whist, dscan);
-    if (v2) { skey[1][p2] = k1; sval[1][p2] = l1; }
-    __syncthreads();
-
-    GB_STAMP(2);
-    // ---- phase C: groups in sorted order: first / last position of my segment inside the tile -----
-    const uint32_t p = tid;
-    const uint32_t myk = v2 ? skey[1][p] : 0xffffffffu;
-    const bool head = v2 && (p == 0 || skey[1][p - 1] != myk);
-    const bool tail = v2 && (p == nvalid - 1 || skey[1][p + 1] != myk);
-    uint32_t firstp = head ? p : 0;                         // inclusive max-scan over positions
+    // ---- phase B: all-pairs grouping of the tile's FT segment ids -----------------------------------
+    uint32_t lt = 0, eq_before = 0, eq_total = 0;
+    {
+        const uint4* k4 = (const uint4*)skey;
+#pragma unroll 4
+        for (uint32_t q = 0; q < FT / 4; ++q) {
+            const uint4 kk = k4[q];                            // same address in every lane: LDS broadcast
+            const uint32_t ks[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(firstp, o, 64); if (lane >= (uint32_t)o) firstp = firstp > v ? firstp : v; }
-    uint32_t lastp = tail ? p : 0xffffffffu;                // inclusive min-scan from the right
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_down(lastp, o, 64); if (lane + o < 64) lastp = lastp < v ? lastp : v; }
-    if (lane == 63) wagg[0][wave] = firstp;
-    if (lane == 0) wagg[1][wave] = lastp;
-    __syncthreads();
-    for (uint32_t w = 0; w < wave; ++w) { const uint32_t v = wagg[0][w]; firstp = firstp > v ? firstp : v; }
-    for (uint32_t w = wave + 1; w < TILE / 64; ++w) { const uint32_t v = wagg[1][w]; lastp = lastp < v ? lastp : v; }
-    if (v2) {
-        const uint32_t req = tile * TILE + sval[1][p];
-        W.torder[tile * TILE + p] = req;
-        W.lrank[req] = (uint16_t)(p - firstp);
-        if (head) {
-            W.tilecnt[(size_t)myk * 64 + tile] = (uint16_t)(lastp - firstp + 1);
-            W.tilestart[(size_t)myk * 64 + tile] = (uint16_t)firstp;
-            atomicOr(&seg_mask[myk], 1ull << tile);
+            for (uint32_t e = 0; e < 4; ++e) {
+                const uint32_t j = q * 4 + e;
+                lt += ks[e] < d ? 1u : 0u;
+                const uint32_t same = ks[e] == d ? 1u : 0u;
+                eq_total += same;
+                eq_before += (same && j < tid) ? 1u : 0u;
+            }
         }
     }
-    __syncthreads();
+    GB_STAMP(2);
+    // ---- phase C: publish groups -------------------------------------------------------------------
+    if (valid) {
+        W.torder[tile * FT + lt + eq_before] = g;
+        W.lrank[g] = (uint16_t)eq_before;
+        if (eq_before == 0) {
+            W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
+            W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)lt;
+            atomicOr(&seg_mask[(size_t)d * FT_WORDS + (tile >> 6)], 1ull << (tile & 63));
+        }
+    }
     GB_STAMP(3);
 #undef GB_STAMP
 }
 
-// k_eval2: one thread per request in request order.  rank = requests of my segment in earlier tiles
-// (bitmap + one 128-byte row of per-tile counts) + rank inside my tile.
 __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
     __shared__ int red[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
-    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap;
-    // clear the other copy for the next batch
-    {
+    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
+    {   // clear the other copy for the next batch
         uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
-        unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap;
-        for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) { of[j] = 0; om[j] = 0ull; }
+        unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
+        for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
+            of[j] = 0;
+#pragma unroll
+            for (int w = 0; w < FT_WORDS; ++w) om[(size_t)j * FT_WORDS + w] = 0ull;
+        }
     }
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (i < B.n) {
@@ -756,26 +696,37 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
-            const unsigned long long mask = seg_mask[d];
-            const uint32_t t = i / TILE;
-            const uint16_t* row = W.tilecnt + (size_t)d * 64;
-            uint32_t base = 0, total;
-            if ((mask & (mask - 1ull)) == 0ull) {
+            const uint32_t t = i / FT;
+            const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
+            unsigned long long mask[FT_WORDS];
+            uint32_t ntiles = 0;
+#pragma unroll
+            for (int w = 0; w < FT_WORDS; ++w) { mask[w] = seg_mask[(size_t)d * FT_WORDS + w]; ntiles += __popcll(mask[w]); }
+            uint32_t base = 0, total = 0;
+            if (ntiles == 1) {
                 total = row[t];                                   // the segment lives in my tile only
+            } else if (ntiles <= 12) {
+#pragma unroll
+                for (int w = 0; w < FT_WORDS; ++w) {
+                    unsigned long long mm = mask[w];
+                    while (mm) {
+                        const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+                        mm &= mm - 1ull;
+                        const uint32_t c = row[tt];
+                        total += c; base += tt < t ? c : 0u;
+                    }
+                }
             } else {
-                total = 0;
-                const uint4* r4 = (const uint4*)row;              // 64 x u16 = 8 x 16 bytes, one round trip
-                uint4 v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = r4[q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                const uint4* r4 = (const uint4*)row;              // 256 x u16: stream the whole row
+                for (uint32_t q = 0; q < FT_MAX_TILES / 8; ++q) {
+                    const uint4 v = r4[q];
+                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                    const unsigned long long mw = mask[q >> 3] >> ((q & 7) * 8);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const uint32_t tlo = q * 8 + e * 2, thi = tlo + 1;
-                        const uint32_t clo = (mask >> tlo) & 1ull ? (w4[e] & 0xffffu) : 0u;
-                        const uint32_t chi = (mask >> thi) & 1ull ? (w4[e] >> 16) : 0u;
+                        const uint32_t clo = (mw >> (e * 2)) & 1ull ? (w4[e] & 0xffffu) : 0u;
+                        const uint32_t chi = (mw >> (e * 2 + 1)) & 1ull ? (w4[e] >> 16) : 0u;
                         total += clo + chi;
                         base += (tlo < t ? clo : 0u) + (thi < t ? chi : 0u);
                     }
@@ -799,19 +750,21 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                 // members of a tile in their sorted = request order)
                 const Rec s0 = W.snap[d];
                 Rec s = s0;
-                unsigned long long mm = mask;
-                while (mm) {
-                    const uint32_t tt = __ffsll((unsigned long long)mm) - 1;
-                    mm &= mm - 1ull;
-                    const uint32_t start = tt * TILE + W.tilestart[(size_t)d * 64 + tt];
-                    const uint32_t cnt = row[tt];
-                    for (uint32_t q = start; q < start + cnt; ++q) {
-                        const uint32_t j = W.torder[q];
-                        const Req rj = load_req(B, j);
-                        Resp out;
-                        const uint32_t ev = apply(s, rj, B.now_ms, out);
-                        store_resp(R, j, out);
-                        c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                for (int w = 0; w < FT_WORDS; ++w) {
+                    unsigned long long mm = mask[w];
+                    while (mm) {
+                        const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+                        mm &= mm - 1ull;
+                        const uint32_t start = tt * FT + W.tilestart[(size_t)d * FT_MAX_TILES + tt];
+                        const uint32_t cnt = row[tt];
+                        for (uint32_t q = start; q < start + cnt; ++q) {
+                            const uint32_t j = W.torder[q];
+                            const Req rj = load_req(B, j);
+                            Resp out;
+                            const uint32_t ev = apply(s, rj, B.now_ms, out);
+                            store_resp(R, j, out);
+                            c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                        }
                     }
                 }
                 T.buckets[slot].rec = s;
