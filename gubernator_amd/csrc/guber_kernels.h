@@ -518,8 +518,24 @@ __device__ __forceinline__ uint32_t claim_segment(unsigned long long* mp, unsign
     }
 }
 
+// careful (retry-round) resolution of one request: verify the stored key BEFORE claiming.
+__device__ __forceinline__ uint32_t resolve_careful(const Table& T, const Work& W, const uint8_t* key, uint32_t len,
+                                                    uint32_t g, uint32_t& slot, uint32_t& d, bool& claimed, bool& fresh,
+                                                    int& inserted, Rec& rec) {
+    uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
+    if (pr & PR_FULL) { inserted = (pr & PR_INSERTED) ? 1 : 0; return 6; }
+    inserted = (pr & PR_INSERTED) ? 1 : 0;
+    fresh = (pr & (PR_INSERTED | PR_NEED_VERIFY)) != 0;
+    unsigned long long* mp = &T.dir[slot].meta;
+    d = claim_segment(mp, ld_agent(mp), W.epoch, g, claimed);
+    rec = T.buckets[slot].rec;
+    return 0;
+}
+
 __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
-    __shared__ uint32_t skey[FT];
+    __shared__ uint32_t skey[FT];       // stage 2: candidate slot per thread; phase B: segment id per thread
+    __shared__ uint32_t sd[FT];         // stage 2: segment id obtained by each leader
+    __shared__ uint32_t ltab[2 * FT];   // stage 2: slot-hash -> some thread holding that slot
     __shared__ int red[FT / 64];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
     const uint32_t g = tile * FT + tid;
@@ -529,90 +545,93 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
 #define GB_STAMP(k) do { if (W.dbg && tid == 0) W.dbg[tile * 8 + (k)] = wall_clock64(); } while (0)
     GB_STAMP(0);
 
-    // ---- phase A --------------------------------------------------------------------------------
-    uint32_t d = 0xffffffffu;
+    // ---- phase A, stage 1: find (or insert) the directory entry; start fetching its bucket -----------
+    uint32_t d = 0xffffffffu, slot = 0, errcode = 0, len = 0;
     int inserted = 0;
+    bool fresh = false, claimed = false, cand = false, ready = false;
+    unsigned long long meta = 0ull;
+    const uint8_t* key = nullptr;
+    Rec rec; rec_clear(rec);
+    uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     if (valid) {
         const uint32_t off = B.key_off[g];
-        const uint32_t len = B.key_off[g + 1] - off;
-        const uint8_t* key = B.key_bytes + off;
-        uint32_t slot = 0;
-        uint8_t rf = 0;
-        uint32_t errcode = 0;
-        bool fresh = false, claimed = false;
-        Rec rec; rec_clear(rec);
+        len = B.key_off[g + 1] - off;
+        key = B.key_bytes + off;
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
-        if (!errcode) {
+        if (!errcode && W.careful) {
+            errcode = resolve_careful(T, W, key, len, g, slot, d, claimed, fresh, inserted, rec);
+        } else if (!errcode) {
             const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
             const unsigned long long tag = h ? h : 1ull;
             uint64_t pos = (h >> 7) & T.mask;
-            bool done = false;
-            for (uint32_t step = 0; step < T.max_probe && !done; ++step, pos = (pos + 1) & T.mask) {
-                unsigned long long* mp = &T.dir[pos].meta;
-                unsigned long long t = ld_agent(&T.dir[pos].tag);   // both sc1 loads issue back to back:
-                unsigned long long m = ld_agent(mp);                // one round trip, never a stale L1 line
+            for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
+                unsigned long long t = ld_agent(&T.dir[pos].tag);   // two sc1 loads, one round trip,
+                unsigned long long m = ld_agent(&T.dir[pos].meta);  // never a stale L1 line
                 if (t == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
                     if (old == 0ull) {                               // new key: this thread inserts it
-                        slot = (uint32_t)pos; inserted = 1; fresh = true; done = true;
-                        if (!key_store(T, pos, key, len)) { errcode = 6; break; }
-                        rec = T.buckets[pos].rec;                    // zero for a never-used bucket
-                        d = claim_segment(mp, 0ull, W.epoch, g, claimed);
+                        slot = (uint32_t)pos; inserted = 1; fresh = true; cand = true; meta = 0ull;
+                        if (!key_store(T, pos, key, len)) { errcode = 6; cand = false; }
                         break;
                     }
                     t = old;
-                    m = ld_agent(mp);
+                    m = ld_agent(&T.dir[pos].meta);
                 }
-                if (t != tag) continue;
-                if (m & META_READY) {
-                    // resident entry: fetch key cell + record, claim, then compare the key
-                    const Bucket* bk = &T.buckets[pos];
-                    const uint4* cw = (const uint4*)&bk->cell;
-                    const uint4 c0 = cw[0], c1 = cw[1], c2 = cw[2], c3 = cw[3];
-                    rec = bk->rec;
-                    uint32_t dd = 0; bool cl = false;
-                    if (!W.careful) dd = claim_segment(mp, m, W.epoch, g, cl);
-                    const uint64_t cell[8] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z,
-                                              ((uint64_t)c1.y << 32) | c1.x, ((uint64_t)c1.w << 32) | c1.z,
-                                              ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z,
-                                              ((uint64_t)c3.y << 32) | c3.x, ((uint64_t)c3.w << 32) | c3.z};
-                    bool eq = (uint32_t)(cell[7] >> 48) == len;
-                    if (eq) {
-                        if (len <= INLINE_KEY) {
-                            const uint32_t nw = (len + 7) >> 3;
+                if (t == tag) { slot = (uint32_t)pos; cand = true; meta = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
+            }
+            if (!cand && !errcode) errcode = 6;                      // probe bound exceeded: table full
+            if (cand) {
+                const Bucket* bk = &T.buckets[slot];
+                if (ready) { const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3]; }
+                rec = bk->rec;                                       // (zero for a bucket never used)
+            }
+        }
+    }
+    // ---- stage 2: one claim per (workgroup, slot).  Threads holding the same slot elect a leader
+    // through an LDS table; only leaders touch the entry's meta word (atomics on one address serialise
+    // at ~12 ns each, and a hot key shows up thousands of times in a batch).
+    const bool fast = cand && !W.careful;
+    const uint32_t hidx = (slot * 0x9E3779B1u) >> 23;                // 9 bits
+    skey[tid] = fast ? slot : 0xffffffffu;
+    if (fast) ltab[hidx] = tid;
+    __syncthreads();
+    uint32_t lead = tid;
+    if (fast) { const uint32_t l = ltab[hidx]; if (skey[l] == slot) lead = l; }
+    if (fast && lead == tid) { d = claim_segment(&T.dir[slot].meta, meta, W.epoch, g, claimed); sd[tid] = d; }
+    __syncthreads();
+    if (fast && lead != tid) d = sd[lead];
+    __syncthreads();
+
+    // ---- stage 3: verify, flag, snapshot -----------------------------------------------------------
+    if (valid) {
+        uint8_t rf = 0;
+        if (!errcode && fast && ready) {
+            const uint64_t cell[8] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z,
+                                      ((uint64_t)c1.y << 32) | c1.x, ((uint64_t)c1.w << 32) | c1.z,
+                                      ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z,
+                                      ((uint64_t)c3.y << 32) | c3.x, ((uint64_t)c3.w << 32) | c3.z};
+            bool eq = (uint32_t)(cell[7] >> 48) == len;
+            if (eq) {
+                if (len <= INLINE_KEY) {
+                    const uint32_t nw = (len + 7) >> 3;
 #pragma unroll
-                            for (uint32_t w = 0; w < 8; ++w) {
-                                if (w < nw) {
-                                    uint64_t kv = ld_key_word(key + 8 * w), cv = cell[w];
-                                    if (w == 7) cv &= 0x0000ffffffffffffull;
-                                    if (w == nw - 1) { const uint64_t mk = tail_mask(len - 8 * w); kv &= mk; cv &= mk; }
-                                    eq = eq && (kv == cv);
-                                }
-                            }
-                        } else {
-                            eq = key_equal(T, pos, key, len);
+                    for (uint32_t w = 0; w < 8; ++w) {
+                        if (w < nw) {
+                            uint64_t kv = ld_key_word(key + 8 * w), cv = cell[w];
+                            if (w == 7) cv &= 0x0000ffffffffffffull;
+                            if (w == nw - 1) { const uint64_t mk = tail_mask(len - 8 * w); kv &= mk; cv &= mk; }
+                            eq = eq && (kv == cv);
                         }
                     }
-                    if (eq) {
-                        slot = (uint32_t)pos; done = true;
-                        if (W.careful) dd = claim_segment(mp, m, W.epoch, g, cl);
-                        d = dd; claimed = cl;
-                    } else if (!W.careful) {
-                        // speculation failed (64-bit hash collision with a resident key): I joined a
-                        // foreign segment -> everybody in it is answered RETRY and re-run carefully
-                        slot = (uint32_t)pos; done = true;
-                        d = dd; claimed = cl;
-                        atomicOr(&seg_flags[d], SEG_RETRY);
-                    }
                 } else {
-                    // entry inserted during this launch by another thread: tentative member
-                    slot = (uint32_t)pos; done = true; fresh = true;
-                    rec = T.buckets[pos].rec;
-                    d = claim_segment(mp, m, W.epoch, g, claimed);
+                    eq = key_equal(T, slot, key, len);
                 }
             }
-            if (!done && !errcode) errcode = 6;     // probe bound exceeded: table full
+            // the claim was issued before this comparison (speculation).  A mismatch = a 64-bit hash
+            // collision with a resident key: I joined a foreign segment, so everybody in it is answered
+            // RETRY and re-run in careful mode.
+            if (!eq) atomicOr(&seg_flags[d], SEG_RETRY);
         }
         if (errcode) {
             d = g;
@@ -624,6 +643,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 W.seg_slot[d] = slot;
                 W.snap[d] = rec;                               // claimer snapshots the bucket
             } else {
+                // entry created during this launch: prove key equality against the claimer's request
                 if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
                 const Req a = load_req(B, g), b = load_req(B, d);
                 if (!req_eq(a, b)) atomicOr(&seg_flags[d], SEG_NONUNIFORM);
@@ -638,7 +658,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     GB_STAMP(1);
 
     // ---- phase B: all-pairs grouping of the tile's FT segment ids -----------------------------------
-    uint32_t lt = 0, eq_before = 0, eq_total = 0;
+    uint32_t lt = 0, eq_before = 0, eq_total = 0, head_tid = tid;
     {
         const uint4* k4 = (const uint4*)skey;
 #pragma unroll 4
@@ -649,9 +669,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             for (uint32_t e = 0; e < 4; ++e) {
                 const uint32_t j = q * 4 + e;
                 lt += ks[e] < d ? 1u : 0u;
-                const uint32_t same = ks[e] == d ? 1u : 0u;
-                eq_total += same;
+                const bool same = ks[e] == d;
+                eq_total += same ? 1u : 0u;
                 eq_before += (same && j < tid) ? 1u : 0u;
+                head_tid = (same && j < head_tid) ? j : head_tid;
             }
         }
     }
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     // ---- phase C: publish groups -------------------------------------------------------------------
     if (valid) {
         W.torder[tile * FT + lt + eq_before] = g;
-        W.lrank[g] = (uint16_t)eq_before;
+        W.lrank[g] = (uint16_t)(eq_before | (head_tid << 8));   // rank in group | tid of the group's head
         if (eq_before == 0) {
             W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
             W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)lt;
@@ -684,6 +705,52 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             for (int w = 0; w < FT_WORDS; ++w) om[(size_t)j * FT_WORDS + w] = 0ull;
         }
     }
+    // pre-pass: the head of every (segment, tile) group computes the group's base = members of the
+    // segment in earlier tiles, and the segment's total, from the bitmap and the per-tile counts; the
+    // other members pick both up from LDS (eval workgroup == tile, FT == 256).
+    __shared__ uint32_t sbase[FT], stotal[FT];
+    const uint32_t lr = i < B.n ? W.lrank[i] : 0u;
+    unsigned long long mask[FT_WORDS] = {0ull, 0ull, 0ull, 0ull};
+    if (i < B.n && (lr & 0xffu) == 0u) {
+        const uint32_t d = W.did[i];
+        const uint32_t t = i / FT;
+        const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
+        uint32_t ntiles = 0;
+#pragma unroll
+        for (int w = 0; w < FT_WORDS; ++w) { mask[w] = seg_mask[(size_t)d * FT_WORDS + w]; ntiles += __popcll(mask[w]); }
+        uint32_t base = 0, total = 0;
+        if (ntiles <= 1) {
+            total = row[t];                                   // the segment lives in my tile only
+        } else if (ntiles <= 12) {
+#pragma unroll
+            for (int w = 0; w < FT_WORDS; ++w) {
+                unsigned long long mm = mask[w];
+                while (mm) {
+                    const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
+                    mm &= mm - 1ull;
+                    const uint32_t c = row[tt];
+                    total += c; base += tt < t ? c : 0u;
+                }
+            }
+        } else {
+            const uint4* r4 = (const uint4*)row;              // 256 x u16: stream the whole row
+            for (uint32_t q = 0; q < FT_MAX_TILES / 8; ++q) {
+                const uint4 v = r4[q];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                const unsigned long long mw = mask[q >> 3] >> ((q & 7) * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t tlo = q * 8 + e * 2, thi = tlo + 1;
+                    const uint32_t clo = (mw >> (e * 2)) & 1ull ? (w4[e] & 0xffffu) : 0u;
+                    const uint32_t chi = (mw >> (e * 2 + 1)) & 1ull ? (w4[e] >> 16) : 0u;
+                    total += clo + chi;
+                    base += (tlo < t ? clo : 0u) + (thi < t ? chi : 0u);
+                }
+            }
+        }
+        sbase[threadIdx.x] = base; stotal[threadIdx.x] = total;
+    }
+    __syncthreads();
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (i < B.n) {
         const uint32_t d = W.did[i];
@@ -698,41 +765,8 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
         } else {
             const uint32_t t = i / FT;
             const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
-            unsigned long long mask[FT_WORDS];
-            uint32_t ntiles = 0;
-#pragma unroll
-            for (int w = 0; w < FT_WORDS; ++w) { mask[w] = seg_mask[(size_t)d * FT_WORDS + w]; ntiles += __popcll(mask[w]); }
-            uint32_t base = 0, total = 0;
-            if (ntiles == 1) {
-                total = row[t];                                   // the segment lives in my tile only
-            } else if (ntiles <= 12) {
-#pragma unroll
-                for (int w = 0; w < FT_WORDS; ++w) {
-                    unsigned long long mm = mask[w];
-                    while (mm) {
-                        const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
-                        mm &= mm - 1ull;
-                        const uint32_t c = row[tt];
-                        total += c; base += tt < t ? c : 0u;
-                    }
-                }
-            } else {
-                const uint4* r4 = (const uint4*)row;              // 256 x u16: stream the whole row
-                for (uint32_t q = 0; q < FT_MAX_TILES / 8; ++q) {
-                    const uint4 v = r4[q];
-                    const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-                    const unsigned long long mw = mask[q >> 3] >> ((q & 7) * 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t tlo = q * 8 + e * 2, thi = tlo + 1;
-                        const uint32_t clo = (mw >> (e * 2)) & 1ull ? (w4[e] & 0xffffu) : 0u;
-                        const uint32_t chi = (mw >> (e * 2 + 1)) & 1ull ? (w4[e] >> 16) : 0u;
-                        total += clo + chi;
-                        base += (tlo < t ? clo : 0u) + (thi < t ? chi : 0u);
-                    }
-                }
-            }
-            const uint32_t rank = base + W.lrank[i];
+            uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
+            const uint32_t rank = base + (lr & 0xffu);
             const uint32_t slot = W.seg_slot[d];
             if (!(sf & SEG_NONUNIFORM)) {
                 const Req r = load_req(B, i);
@@ -751,7 +785,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                 const Rec s0 = W.snap[d];
                 Rec s = s0;
                 for (int w = 0; w < FT_WORDS; ++w) {
-                    unsigned long long mm = mask[w];
+                    unsigned long long mm = seg_mask[(size_t)d * FT_WORDS + w];
                     while (mm) {
                         const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
                         mm &= mm - 1ull;
