@@ -86,6 +86,7 @@ struct guber_engine {
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
     bool careful = false;       // retry rounds run without speculative claims
+    bool always_careful = false;
     DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
@@ -176,6 +177,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_hist.ensure((size_t)MAX_PASSES * RADIX * tiles);
     e->fast_cap = std::min<uint32_t>(M, FT * FT_MAX_TILES);
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
+    e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
     rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
@@ -264,7 +266,7 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         BatchView B2 = B;
         B2.n_cap = e->fast_cap;
         const uint32_t ftiles = (n + FT - 1) / FT;
-        W.careful = e->careful ? 1u : 0u;
+        W.careful = (e->careful || e->always_careful) ? 1u : 0u;
         W.parity = e->fast_batches & 1u;
         W.clear_n = e->fast_prev_n;
         W.dbg = e->dbg.p;
@@ -713,3 +715,20 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
 }
 
 extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }
+
+// debug only (not part of the ABI): copy a per-request work array of the last batch to the host.
+// which: 0 did, 1 slot, 2 rflags(u8 widened), 3 lrank(u16 widened), 4 seg_slot, 5 seg_flags(cur parity)
+extern "C" int gbdbg_read_work(guber_engine_t* e, int which, uint32_t* out, uint32_t n) {
+    if (!e || !out) return -1;
+    (void)hipStreamSynchronize(e->stream);
+    std::vector<uint8_t> b8(n); std::vector<uint16_t> b16(n);
+    switch (which) {
+    case 0: return hipMemcpy(out, e->W.did, n * 4, hipMemcpyDeviceToHost);
+    case 1: return hipMemcpy(out, e->W.slot, n * 4, hipMemcpyDeviceToHost);
+    case 2: { int r = hipMemcpy(b8.data(), e->W.rflags, n, hipMemcpyDeviceToHost); for (uint32_t i = 0; i < n; ++i) out[i] = b8[i]; return r; }
+    case 3: { int r = hipMemcpy(b16.data(), e->W.lrank, n * 2, hipMemcpyDeviceToHost); for (uint32_t i = 0; i < n; ++i) out[i] = b16[i]; return r; }
+    case 4: return hipMemcpy(out, e->W.seg_slot, n * 4, hipMemcpyDeviceToHost);
+    case 5: return hipMemcpy(out, e->W.seg_flags2 + (size_t)((e->fast_batches - 1) & 1u) * e->fast_cap, n * 4, hipMemcpyDeviceToHost);
+    }
+    return -1;
+}

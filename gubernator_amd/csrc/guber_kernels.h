@@ -518,20 +518,6 @@ __device__ __forceinline__ uint32_t claim_segment(unsigned long long* mp, unsign
     }
 }
 
-// careful (retry-round) resolution of one request: verify the stored key BEFORE claiming.
-__device__ __forceinline__ uint32_t resolve_careful(const Table& T, const Work& W, const uint8_t* key, uint32_t len,
-                                                    uint32_t g, uint32_t& slot, uint32_t& d, bool& claimed, bool& fresh,
-                                                    int& inserted, Rec& rec) {
-    uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
-    if (pr & PR_FULL) { inserted = (pr & PR_INSERTED) ? 1 : 0; return 6; }
-    inserted = (pr & PR_INSERTED) ? 1 : 0;
-    fresh = (pr & (PR_INSERTED | PR_NEED_VERIFY)) != 0;
-    unsigned long long* mp = &T.dir[slot].meta;
-    d = claim_segment(mp, ld_agent(mp), W.epoch, g, claimed);
-    rec = T.buckets[slot].rec;
-    return 0;
-}
-
 __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ uint32_t skey[FT];       // stage 2: candidate slot per thread; phase B: segment id per thread
     __shared__ uint32_t sd[FT];         // stage 2: segment id obtained by each leader
@@ -560,7 +546,20 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
         if (!errcode && W.careful) {
-            errcode = resolve_careful(T, W, key, len, g, slot, d, claimed, fresh, inserted, rec);
+            // retry round: verify the stored key BEFORE claiming (no speculation, no dedup)
+            uint32_t cslot = 0;
+            const uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, cslot);
+            slot = cslot;
+            inserted = (pr & PR_INSERTED) ? 1 : 0;
+            if (pr & PR_FULL) errcode = 6;
+            else {
+                fresh = (pr & (PR_INSERTED | PR_NEED_VERIFY)) != 0;
+                unsigned long long* mp = &T.dir[cslot].meta;
+                bool cl = false;
+                d = claim_segment(mp, ld_agent(mp), W.epoch, g, cl);
+                claimed = cl;
+                rec = T.buckets[cslot].rec;
+            }
         } else if (!errcode) {
             const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
             const unsigned long long tag = h ? h : 1ull;

@@ -77,6 +77,7 @@ extern "C" {
 typedef struct guber_engine guber_engine_t;
 
 /* guber_config_t.flags */
+#define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
                                           sort) kernel sequence as well */
 #define GUBER_FLAG_TEST_WEAK_HASH 1u /* tests only: keep 6 bits of the key hash so distinct keys collide and
