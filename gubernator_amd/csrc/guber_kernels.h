@@ -91,6 +91,7 @@ struct Work {
     uint32_t* seg_flags2;               // [2][cap]
     uint16_t* tilecnt;                  // [cap][FT_MAX_TILES]
     uint16_t* tilestart;                // [cap][FT_MAX_TILES]
+    uint32_t* wordcnt;                  // [2][cap][FT_WORDS] members of a segment per 64-tile word (double-buffered)
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
     unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
@@ -657,23 +658,31 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     GB_STAMP(1);
 
     // ---- phase B: all-pairs grouping of the tile's FT segment ids -----------------------------------
+    // (one wave per SIMD here, so four independent accumulator sets hide the VALU dependency latency)
     uint32_t lt = 0, eq_before = 0, eq_total = 0, head_tid = tid;
     {
         const uint4* k4 = (const uint4*)skey;
-#pragma unroll 4
+        uint32_t lt4[4] = {0, 0, 0, 0}, eb4[4] = {0, 0, 0, 0}, et4[4] = {0, 0, 0, 0}, hd4[4] = {tid, tid, tid, tid};
+#pragma unroll 8
         for (uint32_t q = 0; q < FT / 4; ++q) {
             const uint4 kk = k4[q];                            // same address in every lane: LDS broadcast
             const uint32_t ks[4] = {kk.x, kk.y, kk.z, kk.w};
 #pragma unroll
             for (uint32_t e = 0; e < 4; ++e) {
                 const uint32_t j = q * 4 + e;
-                lt += ks[e] < d ? 1u : 0u;
                 const bool same = ks[e] == d;
-                eq_total += same ? 1u : 0u;
-                eq_before += (same && j < tid) ? 1u : 0u;
-                head_tid = (same && j < head_tid) ? j : head_tid;
+                const bool before = j < tid;
+                lt4[e] += ks[e] < d ? 1u : 0u;
+                et4[e] += same ? 1u : 0u;
+                eb4[e] += (same && before) ? 1u : 0u;
+                hd4[e] = (same && j < hd4[e]) ? j : hd4[e];
             }
         }
+        lt = lt4[0] + lt4[1] + lt4[2] + lt4[3];
+        eq_total = et4[0] + et4[1] + et4[2] + et4[3];
+        eq_before = eb4[0] + eb4[1] + eb4[2] + eb4[3];
+        const uint32_t h01 = hd4[0] < hd4[1] ? hd4[0] : hd4[1], h23 = hd4[2] < hd4[3] ? hd4[2] : hd4[3];
+        head_tid = h01 < h23 ? h01 : h23;
     }
     GB_STAMP(2);
     // ---- phase C: publish groups -------------------------------------------------------------------
@@ -684,6 +693,8 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
             W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)lt;
             atomicOr(&seg_mask[(size_t)d * FT_WORDS + (tile >> 6)], 1ull << (tile & 63));
+            // members per 64-tile word: lets a group head in k_eval2 sum earlier words in O(1)
+            atomicAdd(&W.wordcnt[((size_t)W.parity * B.n_cap + d) * FT_WORDS + (tile >> 6)], eq_total);
         }
     }
     GB_STAMP(3);
@@ -698,10 +709,11 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     {   // clear the other copy for the next batch
         uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
         unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
+        uint32_t* ow = W.wordcnt + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
         for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
             of[j] = 0;
 #pragma unroll
-            for (int w = 0; w < FT_WORDS; ++w) om[(size_t)j * FT_WORDS + w] = 0ull;
+            for (int w = 0; w < FT_WORDS; ++w) { om[(size_t)j * FT_WORDS + w] = 0ull; ow[(size_t)j * FT_WORDS + w] = 0u; }
         }
     }
     // pre-pass: the head of every (segment, tile) group computes the group's base = members of the
@@ -720,30 +732,30 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
         uint32_t base = 0, total = 0;
         if (ntiles <= 1) {
             total = row[t];                                   // the segment lives in my tile only
-        } else if (ntiles <= 12) {
-#pragma unroll
-            for (int w = 0; w < FT_WORDS; ++w) {
-                unsigned long long mm = mask[w];
-                while (mm) {
-                    const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
-                    mm &= mm - 1ull;
-                    const uint32_t c = row[tt];
-                    total += c; base += tt < t ? c : 0u;
-                }
-            }
         } else {
-            const uint4* r4 = (const uint4*)row;              // 256 x u16: stream the whole row
-            for (uint32_t q = 0; q < FT_MAX_TILES / 8; ++q) {
-                const uint4 v = r4[q];
-                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-                const unsigned long long mw = mask[q >> 3] >> ((q & 7) * 8);
+            // earlier 64-tile words from the per-word subtotals, my own word from its 64 per-tile counts
+            // (128 bytes fetched in one round trip, masked by the bitmap)
+            const uint32_t mw = t >> 6, mb = t & 63;
+            const uint4 wc = *(const uint4*)(W.wordcnt + ((size_t)W.parity * B.n_cap + d) * FT_WORDS);
+            const uint32_t wcs[4] = {wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t tlo = q * 8 + e * 2, thi = tlo + 1;
-                    const uint32_t clo = (mw >> (e * 2)) & 1ull ? (w4[e] & 0xffffu) : 0u;
-                    const uint32_t chi = (mw >> (e * 2 + 1)) & 1ull ? (w4[e] >> 16) : 0u;
-                    total += clo + chi;
-                    base += (tlo < t ? clo : 0u) + (thi < t ? chi : 0u);
+            for (uint32_t w = 0; w < FT_WORDS; ++w) { total += wcs[w]; base += w < mw ? wcs[w] : 0u; }
+            const unsigned long long mymask = mw == 0 ? mask[0] : mw == 1 ? mask[1] : mw == 2 ? mask[2] : mask[3];
+            const unsigned long long below = mymask & ((1ull << mb) - 1ull);
+            if (below) {
+                const uint4* r4 = (const uint4*)(row + mw * 64);
+                uint4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = r4[q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t blo = q * 8 + e * 2, bhi = blo + 1;
+                        base += ((below >> blo) & 1ull) ? (w4[e] & 0xffffu) : 0u;
+                        base += ((below >> bhi) & 1ull) ? (w4[e] >> 16) : 0u;
+                    }
                 }
             }
         }
