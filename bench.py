@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=48)
     ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=32)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="debug: all ranks share GPU 0 (single-GPU box; use with --backend gloo)")
     return ap.parse_args()
 
 
@@ -66,11 +69,17 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = dev if args.backend == "nccl" else None
 
     K, B = args.keys, args.batch
     algo_id = 0 if args.algo == "token" else 1
@@ -80,20 +89,15 @@ def main():
     # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
     total_keys = K * world
     table = streams.key_table(total_keys)
-    if world > 1:
-        ring = ga.Ring([f"gpu{i}" for i in range(world)], 512, "fnv1")
-        owned = []
-        chunk = 4_000_000
-        for lo in range(0, total_keys, chunk):
-            ids = np.arange(lo, min(lo + chunk, total_keys))
-            kb, ko = streams.keys_for_ids(table, ids)
-            d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
-            d_owner = torch.empty(len(ids), dtype=torch.int32, device=dev)
-            eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ids), d_owner.data_ptr())
-            owned.append(ids[(d_owner.cpu().numpy() == rank)])
-        my_ids = np.concatenate(owned)
-    else:
-        my_ids = np.arange(total_keys)
+    from gubernator_amd import shard
+
+    def route_on_device(ring, kb, ko):       # ReplicatedConsistentHash.Get for a chunk of keys (k_route)
+        d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
+        d_owner = torch.empty(len(ko) - 1, dtype=torch.int32, device=dev)
+        eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ko) - 1, d_owner.data_ptr())
+        return d_owner.cpu().numpy()
+
+    my_ids = shard.owned_key_ids(table, world, rank, route=route_on_device, chunk=4_000_000)
     nk = len(my_ids)
 
     # ---- device-resident batches ------------------------------------------------------------
@@ -177,10 +181,7 @@ def main():
         barrier()
     wall = t1 - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    wall = shard.max_over_ranks(wall, device=red_dev)
     decisions = args.steps * B * world
     value = decisions / wall
 

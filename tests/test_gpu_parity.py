@@ -194,3 +194,31 @@ def test_large_batch_uses_radix_pipeline():
         support.assert_results_equal(got, want, f"large batch {bi}")
         assert got.counters() == want.counters()
     e.close()
+
+
+def test_device_router_matches_host_ring():
+    """k_route (ring staged in LDS, fnv1/fnv1a + binary search) == guber_ring_route == the reference's
+    ReplicatedConsistentHash.Get (replicated_hash.go:104-119), incl. the known-answer distribution."""
+    import torch
+    k = scenarios.load("kat_vectors.json")["ring_distribution"]
+    e = engine(cache_size=1024, max_batch=1024)
+    keys = [f"192.168.{(i >> 8) & 255}.{i & 255}" for i in range(k["n_keys"])]
+    hb = HostBatch(keys, 0, 0, 0, 0)
+    dev = torch.device("cuda", 0)
+    d_kb = torch.from_numpy(hb.key_bytes).to(dev)
+    d_ko = torch.from_numpy(hb.key_off.view(np.int32)).to(dev)
+    for kind in ("fnv1", "fnv1a"):
+        ring = ga.Ring(k["hosts"], k["replicas"], kind)
+        d_owner = torch.empty(len(keys), dtype=torch.int32, device=dev)
+        e.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(keys), d_owner.data_ptr())
+        owner = d_owner.cpu().numpy()
+        assert np.array_equal(owner, ring.route(keys).astype(np.int32))
+        assert {h: int((owner == i).sum()) for i, h in enumerate(k["hosts"])} == k[kind]
+    ring8 = ga.Ring([f"gpu{i}" for i in range(8)], 512, "fnv1")
+    tab = streams.key_table(100_000)
+    kb, ko = streams.keys_for_ids(tab, np.arange(100_000))
+    d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
+    d_owner = torch.empty(100_000, dtype=torch.int32, device=dev)
+    e.route_dev(ring8, d_kb.data_ptr(), d_ko.data_ptr(), 100_000, d_owner.data_ptr())
+    assert np.array_equal(d_owner.cpu().numpy(), ring8.route((kb, ko)).astype(np.int32))
+    e.close()
