@@ -24,8 +24,10 @@ ABI_SYMBOLS = [
     "guber_alloc_pinned", "guber_free_pinned", "guber_ring_create", "guber_ring_destroy", "guber_ring_route",
     "guber_ring_route_dev", "guber_ring_points", "guber_gregorian_expiration", "guber_gregorian_duration",
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
-    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read",
+    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
 ]
+
+FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
 
 _lib = None
 
@@ -59,6 +61,7 @@ def lib():
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
+        L.guber_global_take.argtypes = [C.c_void_p, C.POINTER(abi.GuberGlobalRows)]
         L.guber_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.guber_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_alloc_pinned.restype = C.c_void_p
@@ -218,6 +221,26 @@ class Engine:
         s = GuberStats()
         _check(lib().guber_stats(self.h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in GuberStats._fields_}
+
+    def global_take(self):
+        """Pending GLOBAL rows since the last call (guber_global_take) as a list of dicts."""
+        rows = abi.GuberGlobalRows()
+        _check(lib().guber_global_take(self.h, C.byref(rows)))
+        n = rows.n
+        if n == 0:
+            return []
+        def arr(ptr, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,)).copy()
+        klen = arr(rows.key_len, C.c_uint32)
+        kb = np.ctypeslib.as_array(C.cast(rows.key_bytes, C.POINTER(C.c_uint8)), shape=(n * rows.key_stride,)).copy()
+        cols = {name: arr(getattr(rows, name), dt) for name, dt in
+                [("hits", C.c_int64), ("limit", C.c_int64), ("duration", C.c_int64), ("burst", C.c_int64),
+                 ("created_at", C.c_int64), ("behavior", C.c_uint32), ("algorithm", C.c_uint8), ("role", C.c_uint8)]}
+        out = []
+        for i in range(n):
+            k = kb[i * rows.key_stride: i * rows.key_stride + int(klen[i])].tobytes()
+            out.append(dict(key=k, **{c: int(v[i]) for c, v in cols.items()}))
+        return out
 
     def profile(self, enable):
         _check(lib().guber_profile_enable(self.h, 1 if enable else 0))

@@ -48,6 +48,12 @@ class GuberStats(C.Structure):
                 ("tags_used", C.c_uint64), ("batches", C.c_uint64), ("retries", C.c_uint64)]
 
 
+class GuberGlobalRows(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("key_stride", C.c_uint32), ("key_bytes", C.c_void_p), ("key_len", C.c_void_p),
+                ("hits", C.c_void_p), ("limit", C.c_void_p), ("duration", C.c_void_p), ("burst", C.c_void_p),
+                ("created_at", C.c_void_p), ("behavior", C.c_void_p), ("algorithm", C.c_void_p), ("role", C.c_void_p)]
+
+
 class GuberKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
 

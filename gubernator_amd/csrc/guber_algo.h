@@ -91,7 +91,7 @@ struct Req {
 GB_HD bool req_eq(const Req& a, const Req& b) {
     return a.hits == b.hits && a.limit == b.limit && a.duration == b.duration && a.burst == b.burst &&
            a.created_at == b.created_at && a.greg_expire == b.greg_expire && a.greg_duration == b.greg_duration &&
-           a.behavior == b.behavior && a.algorithm == b.algorithm;  // is_owner only feeds a counter
+           a.behavior == b.behavior && a.algorithm == b.algorithm && a.is_owner == b.is_owner;
 }
 
 struct Resp {

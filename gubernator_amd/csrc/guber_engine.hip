@@ -88,6 +88,8 @@ struct guber_engine {
     bool careful = false;       // retry rounds run without speculative claims
     bool always_careful = false;
     DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
+    // GLOBAL pending queues
+    DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -182,6 +184,11 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     rc |= e->w_wordcnt.ensure((size_t)2 * e->fast_cap * FT_WORDS);
+    uint32_t gdirty_cap = 0;
+    if (cfg->flags & GUBER_FLAG_GLOBAL) {
+        gdirty_cap = (uint32_t)std::min<uint64_t>(e->slots, 1u << 24);
+        rc |= e->gpend.ensure(e->slots); rc |= e->gdirty.ensure(gdirty_cap);
+    }
     e->n_bctr = (M + 255) / 256;
     rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
@@ -194,10 +201,12 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_flags2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_wordcnt.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
+        (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
         guber_engine_destroy(e);
         return fail(GUBER_E_HIP, "table initialisation", he);
     }
+    e->T.gpend = e->gpend.p; e->T.gdirty = e->gdirty.p; e->T.gdirty_cap = gdirty_cap;
     e->T.dir = e->dir.p; e->T.buckets = e->buckets.p; e->T.arena = e->arena.p;
     e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p; e->T.bctr = e->bctr.p;
     e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 16); e->T.max_key = e->max_key;
@@ -229,7 +238,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
                 e->dbg_sum[0] * per, e->dbg_sum[1] * per, e->dbg_sum[2] * per,
                 e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 256.0));
     }
-    e->dbg.release();
+    e->dbg.release(); e->gpend.release(); e->gdirty.release(); e->d_take.release(); e->h_take.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
@@ -687,6 +696,40 @@ extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, co
     he = hipStreamSynchronize(e->stream);
     cleanup();
     if (he != hipSuccess) return fail(GUBER_E_HIP, "k_route", he);
+    return GUBER_OK;
+}
+
+extern "C" int guber_global_take(guber_engine_t* e, guber_global_rows_t* out) {
+    if (!e || !out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    memset(out, 0, sizeof(*out));
+    if (!e->T.gpend) return fail(GUBER_E_INVALID_ARG, "engine created without GUBER_FLAG_GLOBAL");
+    DevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (c.gdirty_overflow) return fail(GUBER_E_NOMEM, "GLOBAL dirty list overflowed");
+    const uint32_t n = c.gdirty_n;
+    const uint32_t stride = (e->max_key + 7u) & ~7u;
+    out->key_stride = stride;
+    if (n == 0) return GUBER_OK;
+    // one device + one pinned arena: keys | 5 x i64 | key_len u32 | behavior u32 | algorithm u8 | role u8
+    const size_t o_keys = 0, o_i64 = (size_t)n * stride, o_len = o_i64 + (size_t)n * 40, o_beh = o_len + (size_t)n * 4,
+                 o_alg = o_beh + (size_t)n * 4, o_role = o_alg + n, total = o_role + n + 64;
+    int rc = e->d_take.ensure(total) | e->h_take.ensure(total);
+    if (rc) return GUBER_E_NOMEM;
+    uint8_t* d = e->d_take.p;
+    GTakeOut O{d + o_keys, (uint32_t*)(d + o_len), (int64_t*)(d + o_i64), (int64_t*)(d + o_i64) + n, (int64_t*)(d + o_i64) + 2 * (size_t)n,
+               (int64_t*)(d + o_i64) + 3 * (size_t)n, (int64_t*)(d + o_i64) + 4 * (size_t)n, (uint32_t*)(d + o_beh), d + o_alg, d + o_role, stride};
+    hipLaunchKernelGGL(k_global_take, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, n, O);
+    HIPCHK(hipMemsetAsync(&e->ctr.p->gdirty_n, 0, sizeof(unsigned int), e->stream));
+    HIPCHK(hipMemcpyAsync(e->h_take.p, d, total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const uint8_t* h = e->h_take.p;
+    out->n = n; out->key_bytes = h + o_keys; out->key_len = (const uint32_t*)(h + o_len);
+    out->hits = (const int64_t*)(h + o_i64); out->limit = out->hits + n; out->duration = out->hits + 2 * (size_t)n;
+    out->burst = out->hits + 3 * (size_t)n; out->created_at = out->hits + 4 * (size_t)n;
+    out->behavior = (const uint32_t*)(h + o_beh); out->algorithm = h + o_alg; out->role = h + o_role;
     return GUBER_OK;
 }
 

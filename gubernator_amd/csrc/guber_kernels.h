@@ -46,12 +46,31 @@ struct DevCounters {
     unsigned long long over, hits, misses, evictions;   // over/hits/misses: see BlockCounters
     long long size;
     unsigned long long tags_used, arena_head, retries;
+    unsigned int gdirty_n, gdirty_overflow;
 };
 // Event counters are accumulated per workgroup slot (plain read-modify-write by one thread; launches
 // on one stream are ordered) instead of hammering three global words with atomics; readers sum them.
 struct BlockCounters { unsigned long long over, hits, misses; long long size_delta; };
 
+// Pending GLOBAL work of one bucket (the reference's globalManager queues, global.go:74-140, kept per
+// bucket instead of in host maps): on a non-owner the hits of the interval are summed and the FIRST
+// queued request is the template (global.go:100-111); on the owner the LAST request is the template of
+// the broadcast (global.go:200).
+struct alignas(64) GPend {
+    int64_t hits;          // non-owner: summed Hits of the interval
+    int64_t limit, duration, burst, created_at;
+    uint32_t behavior;
+    uint8_t algorithm;
+    uint8_t queued;        // 0 = nothing pending, 1 = hits for the owner, 2 = owner update to broadcast
+    uint16_t pad;
+    uint64_t pad2[2];
+};
+static_assert(sizeof(GPend) == 64, "one pending record per 64-byte sector");
+
 struct Table {
+    GPend* gpend;          // null unless the engine was created with GUBER_FLAG_GLOBAL
+    uint32_t* gdirty;      // slots with a pending record
+    uint32_t gdirty_cap;
     DirEntry* dir; Bucket* buckets; uint8_t* arena;
     uint64_t mask; uint64_t arena_cap; DevCounters* ctr; BlockCounters* bctr;
     uint32_t max_probe; uint32_t max_key;
@@ -241,6 +260,33 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
     if (threadIdx.x == 0) for (uint32_t w = 0; w < nw; ++w) t += red[w];
     return t;
 }
+// Queue GLOBAL work for a bucket after a segment of n successful identical requests `r` (or, from the
+// serial walk, one request at a time with n = 1).  Called by ONE thread per bucket per batch.
+//   non-owner request (V1Instance.getGlobalRateLimit -> QueueHit, gubernator.go:395-421, global.go:74-78)
+//   owner request     (getLocalRateLimit -> QueueUpdate, gubernator.go:604-606, global.go:80-84)
+__device__ __forceinline__ void queue_global(const Table& T, uint32_t slot, const Req& r, uint64_t n) {
+    if (!T.gpend || !(r.behavior & BH_GLOBAL) || r.hits == 0 || n == 0) return;
+    GPend p = T.gpend[slot];
+    const bool was_queued = p.queued != 0;
+    if (r.is_owner) {
+        p.queued = 2; p.hits = 0;
+        p.limit = r.limit; p.duration = r.duration; p.burst = r.burst; p.created_at = r.created_at;
+        p.behavior = r.behavior; p.algorithm = r.algorithm;                      // last request wins
+    } else if (p.queued == 1) {
+        p.hits = wadd(p.hits, wmul(r.hits, (int64_t)n));                        // hits[key].Hits += r.Hits
+        p.behavior |= (r.behavior & BH_RESET_REMAINING);                        // global.go:105-107
+    } else {
+        p.queued = 1; p.hits = wmul(r.hits, (int64_t)n);
+        p.limit = r.limit; p.duration = r.duration; p.burst = r.burst; p.created_at = r.created_at;
+        p.behavior = r.behavior; p.algorithm = r.algorithm;                      // first request is the template
+    }
+    T.gpend[slot] = p;
+    if (!was_queued) {
+        const uint32_t k = atomicAdd(&T.ctr->gdirty_n, 1u);
+        if (k < T.gdirty_cap) T.gdirty[k] = slot; else atomicAdd(&T.ctr->gdirty_overflow, 1u);
+    }
+}
+
 // lanes of this wave that hold the same 8-bit digit as the caller (among `valid` lanes)
 __device__ __forceinline__ unsigned long long digit_peers(uint32_t digit, bool valid) {
     unsigned long long peers = __ballot(valid);
@@ -442,6 +488,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 if (rank == last - first) {
                     T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                    if (out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
                 }
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order
@@ -453,6 +500,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     Resp out;
                     const uint32_t ev = apply(s, rj, B.now_ms, out);
                     store_resp(R, j, out);
+                    if (out.err == 0) queue_global(T, slot, rj, 1);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
                 T.buckets[slot].rec = s;
@@ -789,6 +837,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                 if (rank == total - 1) {
                     T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                    if (out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
                 }
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order (tiles in order,
@@ -808,6 +857,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                             Resp out;
                             const uint32_t ev = apply(s, rj, B.now_ms, out);
                             store_resp(R, j, out);
+                            if (out.err == 0) queue_global(T, slot, rj, 1);
                             c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                         }
                     }
@@ -897,6 +947,31 @@ __global__ __launch_bounds__(256) void k_dump(Table T, uint64_t slots, Rec* out_
     if (rec_kind(r) == K_ABSENT) return;
     unsigned long long idx = atomicAdd(count, 1ull);
     if (idx < cap) { out_recs[idx] = r; out_cells[idx] = T.buckets[s].cell; }
+}
+
+// globalManager flush (global.go:114-139 / 200-215): turn every pending record into one request row
+// (key bytes from the bucket's key cell, summed hits / template fields) and clear it.
+struct GTakeOut {
+    uint8_t* key_bytes; uint32_t* key_len;      // key i occupies key_bytes[i*stride .. +key_len[i])
+    int64_t *hits, *limit, *duration, *burst, *created_at;
+    uint32_t* behavior; uint8_t* algorithm; uint8_t* role;   // role 1 = hits for the owner, 2 = owner update
+    uint32_t stride;
+};
+__global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, GTakeOut O) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t slot = T.gdirty[i];
+    GPend p = T.gpend[slot];
+    const KeyCell* c = &T.buckets[slot].cell;
+    const uint32_t len = (uint32_t)(c->w[7] >> 48);
+    const uint8_t* src = len <= INLINE_KEY ? (const uint8_t*)c->w : T.arena + c->w[0];
+    uint8_t* dst = O.key_bytes + (size_t)i * O.stride;
+    for (uint32_t b = 0; b < len && b < O.stride; ++b) dst[b] = src[b];
+    O.key_len[i] = len;
+    O.hits[i] = p.hits; O.limit[i] = p.limit; O.duration[i] = p.duration; O.burst[i] = p.burst;
+    O.created_at[i] = p.created_at; O.behavior[i] = p.behavior; O.algorithm[i] = p.algorithm; O.role[i] = p.queued;
+    GPend z; __builtin_memset(&z, 0, sizeof(z));
+    T.gpend[slot] = z;
 }
 
 // wrap of the 31-bit batch epoch: forget every dense-id claim

@@ -77,6 +77,7 @@ extern "C" {
 typedef struct guber_engine guber_engine_t;
 
 /* guber_config_t.flags */
+#define GUBER_FLAG_GLOBAL 8u          /* keep per-bucket pending GLOBAL hits / updates (guber_global_take) */
 #define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
                                           sort) kernel sequence as well */
@@ -218,6 +219,29 @@ typedef struct guber_kernel_time {
 } guber_kernel_time_t;
 int guber_profile_enable(guber_engine_t* e, int enable);
 int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out);
+
+/* ---- GLOBAL behaviour (global.go): the engine accumulates, per bucket, what the reference's
+ *      globalManager keeps in its hitsQueue / broadcastQueue maps.  A request carrying
+ *      GUBER_BEHAVIOR_GLOBAL with hits != 0 and no error is queued when it is evaluated:
+ *        is_owner = 0  -> hits are summed per key; template = FIRST queued request; RESET_REMAINING is
+ *                         OR-ed in (global.go:100-111)                                  role 1
+ *        is_owner = 1  -> the key is marked for broadcast; template = LAST request (global.go:200)  role 2
+ *      guber_global_take() returns one row per pending key and clears the queues (the flush of
+ *      runAsyncHits / runBroadcasts, global.go:114-139, 217-232).  Buffers belong to the engine and stay
+ *      valid until the next call.  The caller ships role-1 rows to the owning GPU (evaluate with is_owner
+ *      = 1 and DRAIN_OVER_LIMIT, gubernator.go:510-512) and, for role-2 rows, re-reads the state with hits
+ *      = 0 and installs it on the other GPUs with guber_add_items (gubernator.go:425-459). */
+typedef struct guber_global_rows {
+    uint32_t n;
+    uint32_t key_stride;        /* key i = key_bytes[i*key_stride .. + key_len[i]) */
+    const uint8_t* key_bytes;
+    const uint32_t* key_len;
+    const int64_t *hits, *limit, *duration, *burst, *created_at;
+    const uint32_t* behavior;
+    const uint8_t* algorithm;
+    const uint8_t* role;
+} guber_global_rows_t;
+int guber_global_take(guber_engine_t* e, guber_global_rows_t* out);
 
 /* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
 void* guber_alloc_pinned(size_t bytes);

@@ -222,3 +222,32 @@ def test_device_router_matches_host_ring():
     e.route_dev(ring8, d_kb.data_ptr(), d_ko.data_ptr(), 100_000, d_owner.data_ptr())
     assert np.array_equal(d_owner.cpu().numpy(), ring8.route((kb, ko)).astype(np.int32))
     e.close()
+
+
+def test_global_behaviour_engines_vs_model():
+    """BASELINE config 5 semantics: N logical GPUs (N engines on this device) with device-side GLOBAL
+    queues (guber_global_take) and the product orchestrator, against the global.go model; also the
+    GLOBAL vectors of the reference's functional tests."""
+    import test_global as tg
+    from global_model import GlobalModel
+    from gubernator_amd import global_sync
+    n = 4
+    ring = ga.Ring([f"gpu{i}" for i in range(6)])
+    mk = lambda: engine(cache_size=4096, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL)
+    cluster = global_sync.LocalCluster([mk() for _ in range(6)], ring)
+    assert tg.run_vectors(lambda r, q, now: tg.cluster_request(cluster, r, q, now), cluster.sync, ring, 6) >= 40
+    for seed in (1, 2, 3):
+        ring4 = ga.Ring([f"gpu{i}" for i in range(n)])
+        cl = global_sync.LocalCluster([mk() for _ in range(n)], ring4)
+        model = GlobalModel(n, lambda k: int(ring4.route([k])[0]))
+        tg.run_random(lambda r, b, now: cl.ranks[r].evaluate(b["keys"], b["hits"], b["limit"], b["duration"], now,
+                                                             algorithm=b["algorithm"], behavior=b["behavior"], burst=0,
+                                                             created_at=now),
+                      cl.sync, model, n, seed, steps=200)
+        # replicas converge: after a final sync every peer reports the same remaining for every key
+        cl.sync(tg.NOW + 10_000); model.sync(tg.NOW + 10_000)
+        for k in range(40):
+            key = f"glob_{k}".encode()
+            vals = {r: (cl.ranks[r].node.get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+            want = {r: (model.oracles[r].get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+            assert vals == want, (seed, key, vals, want)
