@@ -572,6 +572,9 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ uint32_t sd[FT];         // stage 2: segment id obtained by each leader
     __shared__ uint32_t ltab[2 * FT];   // stage 2: slot-hash -> some thread holding that slot
     __shared__ int red[FT / 64];
+    constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
+    __shared__ uint32_t gkey[GT], gstart[GT], galloc;
+    __shared__ unsigned long long gbits[FT / 64][GT];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
@@ -700,46 +703,58 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         W.did[g] = d; W.rflags[g] = rf;
         if (inserted) W.slot[g] = slot;
     }
-    skey[tid] = d;                                             // 0xffffffff for lanes past the batch end
-    const int ins = block_sum(inserted, red);                  // (barriers inside publish skey)
+    const int ins = block_sum(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
     GB_STAMP(1);
 
-    // ---- phase B: all-pairs grouping of the tile's FT segment ids -----------------------------------
-    // (one wave per SIMD here, so four independent accumulator sets hide the VALU dependency latency)
-    uint32_t lt = 0, eq_before = 0, eq_total = 0, head_tid = tid;
-    {
-        const uint4* k4 = (const uint4*)skey;
-        uint32_t lt4[4] = {0, 0, 0, 0}, eb4[4] = {0, 0, 0, 0}, et4[4] = {0, 0, 0, 0}, hd4[4] = {tid, tid, tid, tid};
-#pragma unroll 8
-        for (uint32_t q = 0; q < FT / 4; ++q) {
-            const uint4 kk = k4[q];                            // same address in every lane: LDS broadcast
-            const uint32_t ks[4] = {kk.x, kk.y, kk.z, kk.w};
+    // ---- phase B: group the tile's FT segment ids through an LDS hash table ------------------------
+    // Every distinct id gets one table entry (open addressing, CAS on the key); each wave ORs its lane
+    // into the entry's per-wave 64-bit member bitmap.  A request's rank inside its (segment, tile) group,
+    // the group size and the group's first thread then come from four popcounts — O(1) per request
+    // instead of comparing against all 256 ids.
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    for (uint32_t j = tid; j < GT; j += FT) {
+        gkey[j] = 0xffffffffu;
 #pragma unroll
-            for (uint32_t e = 0; e < 4; ++e) {
-                const uint32_t j = q * 4 + e;
-                const bool same = ks[e] == d;
-                const bool before = j < tid;
-                lt4[e] += ks[e] < d ? 1u : 0u;
-                et4[e] += same ? 1u : 0u;
-                eb4[e] += (same && before) ? 1u : 0u;
-                hd4[e] = (same && j < hd4[e]) ? j : hd4[e];
-            }
-        }
-        lt = lt4[0] + lt4[1] + lt4[2] + lt4[3];
-        eq_total = et4[0] + et4[1] + et4[2] + et4[3];
-        eq_before = eb4[0] + eb4[1] + eb4[2] + eb4[3];
-        const uint32_t h01 = hd4[0] < hd4[1] ? hd4[0] : hd4[1], h23 = hd4[2] < hd4[3] ? hd4[2] : hd4[3];
-        head_tid = h01 < h23 ? h01 : h23;
+        for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
     }
+    if (tid == 0) galloc = 0;
+    __syncthreads();
+    uint32_t gh = 0;
+    if (valid) {
+        gh = (d * 0x9E3779B1u) >> (32 - GT_BITS);
+        for (;;) {
+            const uint32_t old = atomicCAS(&gkey[gh], 0xffffffffu, d);
+            if (old == 0xffffffffu || old == d) break;
+            gh = (gh + 1) & (GT - 1);
+        }
+        atomicOr(&gbits[wave][gh], 1ull << lane);
+    }
+    __syncthreads();
+    uint32_t eq_before = 0, eq_total = 0, head_tid = tid;
+    if (valid) {
+        bool found_head = false;
+#pragma unroll
+        for (uint32_t w = 0; w < FT / 64; ++w) {
+            const unsigned long long bw = gbits[w][gh];
+            const uint32_t c = __popcll(bw);
+            eq_total += c;
+            if (w < wave) eq_before += c;
+            else if (w == wave) eq_before += __popcll(bw & ((1ull << lane) - 1ull));
+            if (!found_head && bw) { head_tid = w * 64 + (uint32_t)__ffsll((unsigned long long)bw) - 1; found_head = true; }
+        }
+        if (eq_before == 0) gstart[gh] = atomicAdd(&galloc, eq_total);   // contiguous range for the group
+    }
+    __syncthreads();
     GB_STAMP(2);
     // ---- phase C: publish groups -------------------------------------------------------------------
     if (valid) {
-        W.torder[tile * FT + lt + eq_before] = g;
+        const uint32_t start = gstart[gh];
+        W.torder[tile * FT + start + eq_before] = g;
         W.lrank[g] = (uint16_t)(eq_before | (head_tid << 8));   // rank in group | tid of the group's head
         if (eq_before == 0) {
             W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
-            W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)lt;
+            W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)start;
             atomicOr(&seg_mask[(size_t)d * FT_WORDS + (tile >> 6)], 1ull << (tile & 63));
             // members per 64-tile word: lets a group head in k_eval2 sum earlier words in O(1)
             atomicAdd(&W.wordcnt[((size_t)W.parity * B.n_cap + d) * FT_WORDS + (tile >> 6)], eq_total);
