@@ -25,6 +25,8 @@ ABI_SYMBOLS = [
     "guber_ring_route_dev", "guber_ring_points", "guber_gregorian_expiration", "guber_gregorian_duration",
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
+    "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
+    "guber_pool_get_rate_limits",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
@@ -62,6 +64,16 @@ def lib():
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
         L.guber_global_take.argtypes = [C.c_void_p, C.POINTER(abi.GuberGlobalRows)]
+        L.guber_pool_create.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_pool_destroy.argtypes = [C.c_void_p]
+        L.guber_pool_destroy.restype = None
+        L.guber_pool_set_clock.argtypes = [C.c_void_p, C.c_int64]
+        L.guber_pool_set_clock.restype = None
+        L.guber_pool_engine.argtypes = [C.c_void_p]
+        L.guber_pool_engine.restype = C.c_void_p
+        L.guber_pool_batches.argtypes = [C.c_void_p]
+        L.guber_pool_batches.restype = C.c_uint64
+        L.guber_pool_get_rate_limits.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 11 + [C.POINTER(GuberResult), C.c_void_p, C.c_uint32]
         L.guber_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.guber_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_alloc_pinned.restype = C.c_void_p
@@ -257,3 +269,61 @@ class Engine:
 
     def route_dev(self, ring, key_bytes_ptr, key_off_ptr, n, owner_ptr):
         _check(lib().guber_ring_route_dev(self.h, ring.h, key_bytes_ptr, key_off_ptr, n, owner_ptr))
+
+
+class V1Instance:
+    """The C++ host layer (csrc/worker_pool.h): V1Instance.GetRateLimits over a micro-batching
+    GPUWorkerPool.  Thread-safe; requests are dicts with the RateLimitReq field names."""
+    ERR_STRIDE = 200
+
+    def __init__(self, cache_size=50_000, device=0, batch_limit=1000, batch_wait_us=500, flags=0):
+        cfg = GuberConfig(C.sizeof(GuberConfig), device, cache_size, 0, max(batch_limit, 1024), 0, None, flags, 0)
+        self.h = C.c_void_p()
+        _check(lib().guber_pool_create(C.byref(cfg), batch_limit, batch_wait_us, C.byref(self.h)))
+
+    def set_clock(self, now_ms):
+        lib().guber_pool_set_clock(self.h, now_ms)
+
+    def batches(self):
+        return lib().guber_pool_batches(self.h)
+
+    def GetRateLimits(self, reqs):
+        """-> list of dicts {status, limit, remaining, reset_time, error}; raises GuberError for the
+        RPC-level OutOfRange error (more than 1000 requests)."""
+        n = len(reqs)
+        def strs(field):
+            bs = [r.get(field, "").encode() for r in reqs]
+            off = np.zeros(n + 1, np.uint32)
+            if n:
+                off[1:] = np.cumsum([len(b) for b in bs])
+            return np.frombuffer(b"".join(bs) + b"\0", np.uint8).copy(), off
+        nb, no = strs("name")
+        kb, ko = strs("unique_key")
+        col = lambda f, dt: np.array([r.get(f, 0) for r in reqs], dtype=dt) if n else np.zeros(1, dt)
+        hits, limit, duration, burst, created = (col(f, np.int64) for f in ("hits", "limit", "duration", "burst", "created_at"))
+        algo, beh = col("algorithm", np.int32), col("behavior", np.uint32)
+        res = HostResult(n)
+        txt = C.create_string_buffer(max(n, 1) * self.ERR_STRIDE)
+        rc = lib().guber_pool_get_rate_limits(self.h, n, nb.ctypes.data, no.ctypes.data, kb.ctypes.data, ko.ctypes.data,
+                                              hits.ctypes.data, limit.ctypes.data, duration.ctypes.data, burst.ctypes.data,
+                                              created.ctypes.data, algo.ctypes.data, beh.ctypes.data, C.byref(res.c), txt,
+                                              self.ERR_STRIDE)
+        if rc != 0:
+            raise GuberError(rc, txt.raw[:self.ERR_STRIDE].split(b"\0")[0].decode())
+        out = []
+        for i in range(n):
+            err = txt.raw[i * self.ERR_STRIDE:(i + 1) * self.ERR_STRIDE].split(b"\0")[0].decode()
+            out.append(dict(status=int(res.status[i]), limit=int(res.limit[i]), remaining=int(res.remaining[i]),
+                            reset_time=int(res.reset_time[i]), error=err))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().guber_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

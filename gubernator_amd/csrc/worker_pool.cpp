@@ -1,0 +1,225 @@
+// worker_pool.cpp — see worker_pool.h.
+#include "worker_pool.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+namespace gubernator {
+
+GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us)
+    : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
+    guber_config_t c = cfg;
+    if (c.max_batch < batch_limit_) c.max_batch = batch_limit_;
+    create_rc_ = guber_engine_create(&c, &engine_);
+    if (create_rc_ != GUBER_OK) { engine_ = nullptr; return; }
+    thread_ = std::thread([this] { run(); });
+}
+
+GPUWorkerPool::~GPUWorkerPool() { Close(); }
+
+void GPUWorkerPool::Close() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (closing_) return;
+        closing_ = true;
+    }
+    cv_.notify_all();
+    if (thread_.joinable()) thread_.join();
+    if (engine_) { guber_engine_destroy(engine_); engine_ = nullptr; }
+}
+
+int64_t GPUWorkerPool::NowMs() const {
+    if (frozen_ms_) return frozen_ms_;
+    using namespace std::chrono;
+    return duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();   // MillisecondNow, lrucache.go:106
+}
+
+bool GPUWorkerPool::GetRateLimit(const RateLimitReq& r, RateLimitReqState st, RateLimitResp* resp) {
+    std::vector<const RateLimitReq*> reqs{&r};
+    std::vector<RateLimitReqState> sts{st};
+    std::vector<RateLimitResp*> out{resp};
+    GetRateLimitMany(reqs, sts, out);
+    return resp->error.empty();
+}
+
+void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
+                                     std::vector<RateLimitResp*>& out) {
+    if (reqs.empty()) return;
+    Call call;
+    call.remaining = reqs.size();
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (closing_ || !engine_) {
+            for (auto* r : out) r->error = "worker pool is closed";
+            return;
+        }
+        for (size_t i = 0; i < reqs.size(); ++i) queue_.push_back({reqs[i], st[i], out[i], &call});
+    }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> lk(call.mu);
+    call.cv.wait(lk, [&] { return call.remaining == 0; });
+}
+
+void GPUWorkerPool::run() {
+    std::vector<Pending> batch;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return closing_ || !queue_.empty(); });
+            if (queue_.empty() && closing_) return;
+            // flush at batch_limit or batch_wait after the first queued item (peer_client.go:284-337)
+            if (queue_.size() < batch_limit_ && !closing_)
+                cv_.wait_for(lk, std::chrono::microseconds(batch_wait_us_), [&] { return closing_ || queue_.size() >= batch_limit_; });
+            const size_t take = std::min<size_t>(queue_.size(), batch_limit_);
+            batch.assign(queue_.begin(), queue_.begin() + take);
+            queue_.erase(queue_.begin(), queue_.begin() + take);
+        }
+        flush(batch);
+        batch.clear();
+    }
+}
+
+void GPUWorkerPool::flush(std::vector<Pending>& batch) {
+    const uint32_t n = (uint32_t)batch.size();
+    const int64_t now = NowMs();
+    std::vector<uint8_t> keys; std::vector<uint32_t> off(n + 1), beh(n);
+    std::vector<int64_t> hits(n), limit(n), duration(n), burst(n), created(n), gexp(n, 0), gdur(n, 0);
+    std::vector<uint8_t> algo(n), owner(n), status(n), err(n);
+    std::vector<int64_t> rlimit(n), rremaining(n), rreset(n);
+    bool any_greg = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const RateLimitReq& r = *batch[i].req;
+        const std::string k = r.HashKey();
+        off[i] = (uint32_t)keys.size();
+        keys.insert(keys.end(), k.begin(), k.end());
+        hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
+        created[i] = r.created_at ? r.created_at : now;
+        algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
+        beh[i] = r.behavior; owner[i] = batch[i].st.is_owner ? 1 : 0;
+        if (r.behavior & GUBER_BEHAVIOR_DURATION_IS_GREGORIAN) {      // interval.go:84-148 with clock.Now()
+            any_greg = true;
+            int64_t e = 0, d = 0;
+            int rc = guber_gregorian_expiration(now * 1000000, r.duration, &e);
+            if (rc == 0) rc = guber_gregorian_duration(now * 1000000, r.duration, &d);
+            gexp[i] = e; gdur[i] = rc ? rc : d;
+        }
+    }
+    off[n] = (uint32_t)keys.size();
+    keys.resize(keys.size() + 16, 0);
+    guber_batch_t b{}; guber_result_t res{};
+    b.n = n; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = limit.data();
+    b.duration = duration.data(); b.burst = burst.data(); b.created_at = created.data(); b.algorithm = algo.data();
+    b.behavior = beh.data(); b.is_owner = owner.data(); b.now_ms = now;
+    if (any_greg) { b.greg_expire = gexp.data(); b.greg_duration = gdur.data(); }
+    res.status = status.data(); res.limit = rlimit.data(); res.remaining = rremaining.data(); res.reset_time = rreset.data();
+    res.err = err.data();
+    const int rc = guber_eval_batch(engine_, &b, &res);
+    flushed_++;
+    for (uint32_t i = 0; i < n; ++i) {
+        RateLimitResp& o = *batch[i].resp;
+        o = RateLimitResp{};
+        if (rc != GUBER_OK) {
+            o.error = std::string("gpu engine: ") + guber_strerror(rc);
+        } else if (err[i] != 0) {
+            char buf[256];
+            if (err[i] == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, sizeof buf, guber_item_strerror(err[i]), batch[i].req->algorithm);
+            else snprintf(buf, sizeof buf, "%s", guber_item_strerror(err[i]));
+            o.error = buf;                                           // nil response + error (workers.go:317-321)
+        } else {
+            o.status = status[i]; o.limit = rlimit[i]; o.remaining = rremaining[i]; o.reset_time = rreset[i];
+        }
+        Call* c = batch[i].call;
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->mu); last = --c->remaining == 0; }
+        if (last) c->cv.notify_all();
+    }
+}
+
+int GPUWorkerPool::AddCacheItem(const guber_item_t& item) { return guber_add_items(engine_, &item, 1, nullptr); }
+int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool* found) {
+    int f = 0;
+    const int rc = guber_get_item(engine_, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
+    *found = f != 0;
+    return rc;
+}
+int64_t GPUWorkerPool::Size() { return guber_size(engine_); }
+
+bool V1Instance::GetRateLimits(std::vector<RateLimitReq>& reqs, std::vector<RateLimitResp>* resps, std::string* rpc_error) {
+    if (reqs.size() > kMaxBatchSize) {                                // gubernator.go:189-193
+        char buf[128];
+        snprintf(buf, sizeof buf, "Requests.RateLimits list too large; max size is '%u'", kMaxBatchSize);
+        *rpc_error = buf;
+        return false;
+    }
+    const int64_t created_at = pool_->NowMs();                        // :195
+    resps->assign(reqs.size(), RateLimitResp{});
+    std::vector<const RateLimitReq*> send; std::vector<RateLimitReqState> st; std::vector<RateLimitResp*> out;
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        RateLimitReq& r = reqs[i];
+        if (r.unique_key.empty()) { (*resps)[i].error = "field 'unique_key' cannot be empty"; continue; }   // :208-212
+        if (r.name.empty()) { (*resps)[i].error = "field 'namespace' cannot be empty"; continue; }          // :213-217
+        if (r.created_at == 0) r.created_at = created_at;                                                    // :218-220
+        send.push_back(&r); st.push_back(RateLimitReqState{true}); out.push_back(&(*resps)[i]);
+    }
+    pool_->GetRateLimitMany(send, st, out);
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        RateLimitResp& o = (*resps)[i];
+        if (!o.error.empty() && o.error.rfind("field '", 0) != 0) {
+            // gubernator.go:250-255: errors of the local path are wrapped with the key
+            o.error = "Error while apply rate limit for '" + reqs[i].HashKey() + "': " + o.error;
+        }
+    }
+    return true;
+}
+
+}  // namespace gubernator
+
+// ---- C entry points for bindings / tests ------------------------------------------------------------
+using namespace gubernator;
+struct guber_pool { GPUWorkerPool* pool; V1Instance* inst; };
+
+extern "C" int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out) {
+    if (!cfg || !out) return GUBER_E_INVALID_ARG;
+    GPUWorkerPool* p = new GPUWorkerPool(*cfg, batch_limit, batch_wait_us);
+    if (!p->ok()) { const int rc = p->create_error(); delete p; return rc; }
+    *out = new guber_pool{p, new V1Instance(p)};
+    return GUBER_OK;
+}
+extern "C" void guber_pool_destroy(guber_pool_t* p) {
+    if (!p) return;
+    p->pool->Close();
+    delete p->inst; delete p->pool; delete p;
+}
+extern "C" void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms) { if (p) p->pool->SetClockMs(now_ms); }
+extern "C" guber_engine_t* guber_pool_engine(guber_pool_t* p) { return p ? p->pool->engine() : nullptr; }
+extern "C" uint64_t guber_pool_batches(guber_pool_t* p) { return p ? p->pool->batches_flushed() : 0; }
+
+extern "C" int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off,
+                                          const uint8_t* ukey_bytes, const uint32_t* ukey_off, const int64_t* hits,
+                                          const int64_t* limit, const int64_t* duration, const int64_t* burst,
+                                          const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
+                                          guber_result_t* out, char* err_text, uint32_t err_stride) {
+    if (!p || !out) return GUBER_E_INVALID_ARG;
+    std::vector<RateLimitReq> reqs(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        RateLimitReq& r = reqs[i];
+        r.name.assign((const char*)name_bytes + name_off[i], name_off[i + 1] - name_off[i]);
+        r.unique_key.assign((const char*)ukey_bytes + ukey_off[i], ukey_off[i + 1] - ukey_off[i]);
+        r.hits = hits[i]; r.limit = limit[i]; r.duration = duration[i]; r.burst = burst ? burst[i] : 0;
+        r.created_at = created_at ? created_at[i] : 0; r.algorithm = algorithm ? algorithm[i] : 0;
+        r.behavior = behavior ? behavior[i] : 0;
+    }
+    std::vector<RateLimitResp> resps;
+    std::string rpc_error;
+    if (!p->inst->GetRateLimits(reqs, &resps, &rpc_error)) {
+        if (err_text && err_stride) snprintf(err_text, err_stride, "%s", rpc_error.c_str());
+        return GUBER_E_BATCH_TOO_LARGE;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        out->status[i] = (uint8_t)resps[i].status; out->limit[i] = resps[i].limit; out->remaining[i] = resps[i].remaining;
+        out->reset_time[i] = resps[i].reset_time; out->err[i] = resps[i].error.empty() ? 0 : 1;
+        if (err_text && err_stride) snprintf(err_text + (size_t)i * err_stride, err_stride, "%s", resps[i].error.c_str());
+    }
+    return GUBER_OK;
+}

@@ -243,6 +243,25 @@ typedef struct guber_global_rows {
 } guber_global_rows_t;
 int guber_global_take(guber_engine_t* e, guber_global_rows_t* out);
 
+/* ---- C++ host layer (gubernator_amd/csrc/worker_pool.h): GPUWorkerPool (micro-batching WorkerPool,
+ *      workers.go:54-626 + peer_client.go:284-337 flush policy) and the V1Instance.GetRateLimits slice
+ *      (gubernator.go:183-306: 1000-item cap, empty-field errors, CreatedAt default).  Exported for
+ *      bindings and tests; thread-safe: any number of threads may call guber_pool_get_rate_limits. */
+typedef struct guber_pool guber_pool_t;
+int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out);
+void guber_pool_destroy(guber_pool_t* p);
+void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms);   /* clock.Freeze of the reference tests; 0 = wall clock */
+guber_engine_t* guber_pool_engine(guber_pool_t* p);
+uint64_t guber_pool_batches(guber_pool_t* p);
+/* names / unique keys as SoA strings; created_at[i] = 0 means unset; err_text (optional) receives the
+ * reference's per-item error strings, err_stride bytes each (RPC-level error text in the first slot
+ * when GUBER_E_BATCH_TOO_LARGE is returned). */
+int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off,
+                               const uint8_t* ukey_bytes, const uint32_t* ukey_off, const int64_t* hits,
+                               const int64_t* limit, const int64_t* duration, const int64_t* burst,
+                               const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
+                               guber_result_t* out, char* err_text, uint32_t err_stride);
+
 /* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
 void* guber_alloc_pinned(size_t bytes);
 void guber_free_pinned(void* p);

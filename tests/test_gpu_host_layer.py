@@ -1,0 +1,95 @@
+"""The C++ host layer (GPUWorkerPool + V1Instance.GetRateLimits, csrc/worker_pool.h) driven the way the
+reference's functional tests drive a daemon: a frozen clock, one GetRateLimits call per step."""
+import threading
+
+import numpy as np
+import pytest
+
+import gubernator_amd as ga
+import scenarios
+import support
+
+pytestmark = pytest.mark.gpu
+
+
+def test_functional_vectors_through_v1instance():
+    """functional_test.go tables replayed through V1Instance.GetRateLimits (frozen clock = clock.Freeze)."""
+    n = 0
+    for sc in scenarios.load("functional_vectors.json")["scenarios"]:
+        inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=50)
+        now = sc["start_ms"]
+        for si, step in enumerate(sc.get("steps", [])):
+            inst.set_clock(now)
+            r = inst.GetRateLimits([step["req"]])[0]
+            exp = step["expect"]
+            where = f"{sc['name']} step {si}"
+            if "error" in exp:
+                assert r["error"] == exp["error"], where          # TestMissingFields strings (gubernator.go:208-217)
+            if exp.get("error"):
+                n += 1
+                now += step["advance_ms"]
+                continue
+            assert r["error"] == "", where
+            scenarios.check_expect(exp, (r["status"], r["limit"], r["remaining"], r["reset_time"], 0), now, where)
+            n += 1
+            now += step["advance_ms"]
+        for step in sc.get("batch_steps", []):
+            inst.set_clock(now)
+            out = inst.GetRateLimits(step["reqs"])
+            for j, exp in enumerate(step["expect"]):
+                scenarios.check_expect(exp, (out[j]["status"], out[j]["limit"], out[j]["remaining"], out[j]["reset_time"], 0), now, sc["name"])
+                n += 1
+        inst.close()
+    assert n >= 80
+
+
+def test_request_list_too_large_and_error_texts():
+    inst = ga.V1Instance(cache_size=4096)
+    reqs = [dict(name="big", unique_key=f"k{i}", hits=1, limit=5, duration=1000) for i in range(1001)]
+    with pytest.raises(ga.GuberError) as ei:                       # gubernator.go:189-193 codes.OutOfRange
+        inst.GetRateLimits(reqs)
+    assert "Requests.RateLimits list too large; max size is '1000'" in str(ei.value)
+    out = inst.GetRateLimits(reqs[:1000])                           # exactly 1000 is accepted, order kept
+    assert [o["remaining"] for o in out] == [4] * 1000
+    bad = inst.GetRateLimits([dict(name="x", unique_key="y", hits=1, limit=5, duration=1000, algorithm=7),
+                              dict(name="x", unique_key="g", hits=1, limit=5, duration=99, behavior=4),
+                              dict(name="x", unique_key="w", hits=1, limit=5, duration=3, behavior=4)])
+    assert bad[0]["error"] == "Error while apply rate limit for 'x_y': Invalid rate limit algorithm '7'"   # workers.go:318
+    assert bad[1]["error"].endswith("behavior DURATION_IS_GREGORIAN is set; but `Duration` is not a valid gregorian interval")
+    assert bad[2]["error"].endswith("`Duration = GregorianWeeks` not yet supported; consider making a PR!`")
+    inst.close()
+
+
+def test_peer_order_stability_batch_sizes():
+    # functional_test.go:1638-1686: responses in request order for batch sizes 1..1000
+    inst = ga.V1Instance(cache_size=8192)
+    for n in [1, 2, 5, 10, 100, 1000]:
+        reqs = [dict(name="TestGetPeerRateLimits", unique_key=f"{n}_{i}", hits=0, limit=1000 + i, duration=1000) for i in range(n)]
+        assert [o["limit"] for o in inst.GetRateLimits(reqs)] == [1000 + i for i in range(n)]
+    inst.close()
+
+
+def test_concurrent_callers_are_batched_and_consistent():
+    """Many goroutine-like callers on one key set (benchmark_test.go "Thundering herd" shape): every hit is
+    accounted exactly once — admitted hits == limit per key — and callers share device batches."""
+    inst = ga.V1Instance(cache_size=8192, batch_limit=512, batch_wait_us=300)
+    inst.set_clock(1_700_000_000_000)
+    keys, limit, threads, per_thread = 20, 50, 16, 25
+    admitted = np.zeros(keys, np.int64)
+    lock = threading.Lock()
+
+    def worker(t):
+        local = np.zeros(keys, np.int64)
+        for j in range(per_thread):
+            reqs = [dict(name="herd", unique_key=f"k{k}", hits=1, limit=limit, duration=600_000) for k in range(keys)]
+            for k, o in enumerate(inst.GetRateLimits(reqs)):
+                assert o["error"] == ""
+                local[k] += 1 if o["status"] == 0 else 0
+        with lock:
+            admitted[:] += local
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert (admitted == limit).all(), admitted                     # 16*25 = 400 hits per key, limit 50
+    assert inst.batches() < threads * per_thread                    # callers were coalesced into shared batches
+    inst.close()
