@@ -94,6 +94,20 @@ GB_HD bool req_eq(const Req& a, const Req& b) {
            a.behavior == b.behavior && a.algorithm == b.algorithm && a.is_owner == b.is_owner;
 }
 
+// Requests that differ ONLY in created_at (RPCs of one device batch stamped a millisecond apart).
+GB_HD bool req_eq_but_created(const Req& a, const Req& b) {
+    return a.hits == b.hits && a.limit == b.limit && a.duration == b.duration && a.burst == b.burst &&
+           a.greg_expire == b.greg_expire && a.greg_duration == b.greg_duration &&
+           a.behavior == b.behavior && a.algorithm == b.algorithm && a.is_owner == b.is_owner;
+}
+// tokenBucket reads r.CreatedAt only when it creates an item (algorithms.go:207) or when the duration
+// changed (algorithms.go:135): for a live token bucket with the same duration and no RESET_REMAINING a
+// run of requests that differ only in created_at behaves exactly like a run of identical requests.
+GB_HD bool created_at_irrelevant(const Rec& s0, const Req& r, int64_t now) {
+    return r.algorithm == ALGO_TOKEN && rec_kind(s0) == K_TOKEN && !rec_expired(s0, now) &&
+           !(r.behavior & BH_RESET_REMAINING) && s0.duration == r.duration;
+}
+
 struct Resp {
     int64_t limit, remaining, reset_time;
     uint8_t status, err;

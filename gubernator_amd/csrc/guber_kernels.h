@@ -91,7 +91,7 @@ struct ResultView { uint8_t* status; int64_t *limit, *remaining, *reset_time; ui
 // request flags written by k_resolve
 enum : uint8_t { RF_INSERTED = 1, RF_NEED_VERIFY = 2, RF_ERR = 4 };
 // segment flags
-enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits 8..15 */ };
+enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits 8..15 */, SEG_CREATED_DIFFERS = 8 };
 
 struct Work {
     uint32_t *slot, *did; uint8_t* rflags;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, 
                 W.snap[d] = T.buckets[slot].rec;
             } else {
                 Req a = load_req(B, g), b = load_req(B, d);
-                if (!req_eq(a, b)) atomicOr(&W.seg_flags[d], SEG_NONUNIFORM);
+                if (!req_eq(a, b)) atomicOr(&W.seg_flags[d], req_eq_but_created(a, b) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM);
             }
         } else if (rf & RF_INSERTED) {
             atomicOr(&T.dir[W.slot[g]].meta, META_READY);
@@ -478,9 +478,13 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
             const uint32_t first = W.seg_first[d], last = W.seg_last[d];
             const uint32_t rank = W.pos[i] - first;
             const uint32_t slot = W.seg_slot[d];
-            if (!(sf & SEG_NONUNIFORM)) {
-                const Req r = load_req(B, i);
-                const Rec s0 = W.snap[d];
+            const Req r = load_req(B, i);
+            const Rec s0 = W.snap[d];
+            // requests differing only in created_at still take the parallel path when created_at is never read
+            const bool parallel = !(sf & SEG_NONUNIFORM) &&
+                                  (!(sf & SEG_CREATED_DIFFERS) ||
+                                   (created_at_irrelevant(s0, r, B.now_ms) && !(T.gpend && (r.behavior & BH_GLOBAL))));
+            if (parallel) {
                 Rec after; Resp out;
                 const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
                 store_resp(R, i, out);
@@ -492,7 +496,6 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 }
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order
-                const Rec s0 = W.snap[d];
                 Rec s = s0;
                 for (uint32_t q = first; q <= last; ++q) {
                     const uint32_t j = W.order[q];
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 // entry created during this launch: prove key equality against the claimer's request
                 if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
                 const Req a = load_req(B, g), b = load_req(B, d);
-                if (!req_eq(a, b)) atomicOr(&seg_flags[d], SEG_NONUNIFORM);
+                if (!req_eq(a, b)) atomicOr(&seg_flags[d], req_eq_but_created(a, b) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM);
             }
         }
         W.did[g] = d; W.rflags[g] = rf;
@@ -842,9 +845,13 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
             const uint32_t slot = W.seg_slot[d];
-            if (!(sf & SEG_NONUNIFORM)) {
-                const Req r = load_req(B, i);
-                const Rec s0 = W.snap[d];
+            const Req r = load_req(B, i);
+            const Rec s0 = W.snap[d];
+            // requests differing only in created_at still take the parallel path when created_at is never read
+            const bool parallel = !(sf & SEG_NONUNIFORM) &&
+                                  (!(sf & SEG_CREATED_DIFFERS) ||
+                                   (created_at_irrelevant(s0, r, B.now_ms) && !(T.gpend && (r.behavior & BH_GLOBAL))));
+            if (parallel) {
                 Rec after; Resp out;
                 const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
                 store_resp(R, i, out);
@@ -857,7 +864,6 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order (tiles in order,
                 // members of a tile in their sorted = request order)
-                const Rec s0 = W.snap[d];
                 Rec s = s0;
                 for (int w = 0; w < FT_WORDS; ++w) {
                     unsigned long long mm = seg_mask[(size_t)d * FT_WORDS + w];

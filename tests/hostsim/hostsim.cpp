@@ -57,8 +57,12 @@ int hs_eval_batch(void* hp, const guber_batch_t* b, guber_result_t* res, int mod
         auto it = h->table.find(k);
         if (it != h->table.end()) s0 = it->second;
         Req r0 = load_req(b, idx[0]);
-        bool uniform = true;
-        for (size_t j = 1; j < idx.size(); j++) if (!req_eq(load_req(b, idx[j]), r0)) { uniform = false; break; }
+        bool uniform = true, created_only = true;
+        for (size_t j = 1; j < idx.size(); j++) {
+            Req rj = load_req(b, idx[j]);
+            if (!req_eq(rj, r0)) { uniform = false; if (!req_eq_but_created(rj, r0)) { created_only = false; break; } }
+        }
+        if (!uniform && created_only && created_at_irrelevant(s0, r0, b->now_ms)) uniform = true;
         Rec fin = s0;
         if (uniform && mode == 0) {
             for (size_t j = 0; j < idx.size(); j++) {

@@ -251,3 +251,31 @@ def test_global_behaviour_engines_vs_model():
             vals = {r: (cl.ranks[r].node.get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
             want = {r: (model.oracles[r].get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
             assert vals == want, (seed, key, vals, want)
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_created_at_only_variation_on_hot_keys(flags):
+    rng = np.random.default_rng(17)
+    now = streams.NOW0
+    for algo in (0, 1):
+        o, e = Oracle(cache_size=1 << 12), engine(cache_size=1024, max_batch=4096, flags=flags)
+        for step in range(6):
+            n = 3000
+            keys = [b"hotk"] * 2500 + [f"cold{i}".encode() for i in range(500)]
+            created = now + step * 400 + np.sort(rng.integers(0, 3, n))
+            beh = 8 if step == 4 else 0
+            dur = 60_000 if step != 3 else 30_000
+            b = HostBatch(keys, 1, 5000, dur, now + step * 400 + 2, created_at=created, algorithm=algo, behavior=beh)
+            support.assert_results_equal(e.eval(b), o.eval(b), f"algo {algo} step {step}")
+        e.close()
+
+
+def test_config0_batch_of_one_1k_keys():
+    """BASELINE configs[0] (benchmark_test.go:63-84 shape): TOKEN_BUCKET, batch = 1, limit 10, 5 s, hits 1,
+    1000 keys cycled through the C ABI one request per call."""
+    o, e = Oracle(cache_size=1 << 12), engine(cache_size=4096, max_batch=1024)
+    now = streams.NOW0
+    for i in range(3000):
+        b = HostBatch([f"bench_{i % 1000:04d}"], 1, 10, 5000, now + i)
+        assert e.eval(b).rows() == o.eval(b).rows(), i
+    e.close()

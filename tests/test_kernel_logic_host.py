@@ -176,3 +176,20 @@ def test_random_uniform_runs_vs_oracle():
             assert h.size() == o.size()
             t += int(rng.choice([0, 1, 2, 40, 150, 1200, 70000]))
         o.close(); h.close()
+
+
+def test_created_at_only_variation_on_hot_token_keys():
+    """Requests of one key that differ only in created_at (RPCs stamped a ms apart): parallel path for live
+    token buckets, serial otherwise — answers must equal the oracle in every case."""
+    rng = np.random.default_rng(17)
+    now = streams.NOW0
+    for algo in (0, 1):
+        o, h = Oracle(cache_size=1 << 12), HostSim(mode=0)
+        for step in range(6):
+            n = 900
+            keys = [b"hotk"] * n
+            created = now + step * 400 + np.sort(rng.integers(0, 3, n))
+            beh = 8 if step == 4 else 0
+            dur = 60_000 if step != 3 else 30_000        # step 3 changes the duration -> created_at matters
+            b = HostBatch(keys, 1, 5000, dur, now + step * 400 + 2, created_at=created, algorithm=algo, behavior=beh)
+            support.assert_results_equal(h.eval(b), o.eval(b), f"algo {algo} step {step}")
