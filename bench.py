@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=48)
     ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=32)
+    ap.add_argument("--global-sync", type=int, default=0, metavar="K",
+                    help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
+                         "and every K steps the ranks exchange pending hits / broadcast owner state (0 = off)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: all ranks share GPU 0 (single-GPU box; use with --backend gloo)")
@@ -84,10 +87,12 @@ def main():
     K, B = args.keys, args.batch
     algo_id = 0 if args.algo == "token" else 1
     stream = torch.cuda.Stream(device=dev)
-    eng = ga.Engine(cache_size=K + K // 4, device=local_rank, max_batch=B, stream=stream.cuda_stream)
+    GSYNC = args.global_sync
+    eng = ga.Engine(cache_size=K + K // 4, device=local_rank, max_batch=B, stream=stream.cuda_stream,
+                    max_key_bytes=64 if GSYNC else 0, flags=ga.FLAG_GLOBAL if GSYNC else 0)
 
     # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
-    total_keys = K * world
+    total_keys = K if GSYNC else K * world      # GLOBAL: one key space, replicated on every GPU
     table = streams.key_table(total_keys)
     from gubernator_amd import shard
 
@@ -97,7 +102,11 @@ def main():
         eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ko) - 1, d_owner.data_ptr())
         return d_owner.cpu().numpy()
 
-    my_ids = shard.owned_key_ids(table, world, rank, route=route_on_device, chunk=4_000_000)
+    if GSYNC:
+        my_ids = np.arange(total_keys)          # every rank holds (a replica of) every key
+        ring = ga.Ring(shard.peer_names(world), 512, "fnv1")
+    else:
+        my_ids = shard.owned_key_ids(table, world, rank, route=route_on_device, chunk=4_000_000)
     nk = len(my_ids)
 
     # ---- device-resident batches ------------------------------------------------------------
@@ -114,9 +123,15 @@ def main():
                       torch.full((n,), 100, dtype=torch.int64, device=dev),
                       torch.full((n,), 60_000, dtype=torch.int64, device=dev),
                       torch.full((n,), algo_id, dtype=torch.uint8, device=dev),
-                      torch.zeros((n,), dtype=torch.int32, device=dev)]
+                      torch.full((n,), 2 if GSYNC else 0, dtype=torch.int32, device=dev)]
             p = [x.data_ptr() for x in self.t]
-            self.c = ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], None, None, None,
+            owner_ptr = None
+            if GSYNC and world > 1:                 # is_owner[i] = (ring owner of key i == this rank), on device
+                d_owner = torch.empty(n, dtype=torch.int32, device=dev)
+                eng.route_dev(ring, p[0], p[1], n, d_owner.data_ptr())
+                self.t.append((d_owner == rank).to(torch.uint8))
+                owner_ptr = self.t[-1].data_ptr()
+            self.c = ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], owner_ptr, None, None,
                                    int(now_ms))
 
     class DevResult:
@@ -158,8 +173,21 @@ def main():
     KEEP = min(8, total_steps)           # results of the first KEEP steps are kept for the parity gate
     kept = [DevResult(B) for _ in range(KEEP)]
 
+    gsync = None
+    if GSYNC:
+        from gubernator_amd import global_sync
+        eng.max_batch = B
+        transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
+        gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
+    sync_stats = []
+
     def run(s):
         eng.eval_dev(batches[s].c, (kept[s] if s < KEEP else scratch).c)
+        if gsync is not None and (s + 1) % GSYNC == 0:
+            t_s = time.perf_counter()
+            st = gsync.sync(NOW0 + 1 + s)
+            st["ms"] = (time.perf_counter() - t_s) * 1e3
+            sync_stats.append(st)
 
     def barrier():
         if world > 1:
@@ -221,7 +249,7 @@ def main():
     # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not GSYNC:
         import support
         threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
         orc = support.Oracle(cache_size=4 * K, workers=threads)
@@ -272,6 +300,14 @@ def main():
                        "host_cores": os.cpu_count()},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
+        if GSYNC:
+            timed = sync_stats[args.warmup // GSYNC:] or sync_stats
+            out["config"]["workload"] += f", GLOBAL behaviour, sync every {GSYNC} batches"
+            out["global_sync"] = {"every_batches": GSYNC, "syncs": len(sync_stats),
+                                  "avg_ms": round(sum(x["ms"] for x in timed) / max(len(timed), 1), 3),
+                                  "avg_rows_broadcast": int(sum(x["broadcast"] for x in timed) / max(len(timed), 1)),
+                                  "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
+                                  "bytes_moved_rank0": gsync.bytes_moved}
         print(json.dumps(out))
     eng.close()
     if world > 1:

@@ -63,7 +63,7 @@ def lib():
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
-        L.guber_global_take.argtypes = [C.c_void_p, C.POINTER(abi.GuberGlobalRows)]
+        L.guber_global_take.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.GuberGlobalRows)]
         L.guber_pool_create.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.guber_pool_destroy.argtypes = [C.c_void_p]
         L.guber_pool_destroy.restype = None
@@ -234,25 +234,27 @@ class Engine:
         _check(lib().guber_stats(self.h, C.byref(s)))
         return {f[0]: getattr(s, f[0]) for f in GuberStats._fields_}
 
-    def global_take(self):
-        """Pending GLOBAL rows since the last call (guber_global_take) as a list of dicts."""
+    def global_take(self, role_mask=6):
+        """Pending GLOBAL rows of the requested roles (bit 1 = hits for the owner, bit 2 = owner updates) as
+        a global_sync.Rows (structure of numpy arrays); those queues are cleared."""
+        from .global_sync import Rows
         rows = abi.GuberGlobalRows()
-        _check(lib().guber_global_take(self.h, C.byref(rows)))
+        _check(lib().guber_global_take(self.h, role_mask, C.byref(rows)))
         n = rows.n
         if n == 0:
-            return []
+            return Rows.empty(rows.key_stride or 8)
         def arr(ptr, dt):
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,)).copy()
-        klen = arr(rows.key_len, C.c_uint32)
-        kb = np.ctypeslib.as_array(C.cast(rows.key_bytes, C.POINTER(C.c_uint8)), shape=(n * rows.key_stride,)).copy()
-        cols = {name: arr(getattr(rows, name), dt) for name, dt in
-                [("hits", C.c_int64), ("limit", C.c_int64), ("duration", C.c_int64), ("burst", C.c_int64),
-                 ("created_at", C.c_int64), ("behavior", C.c_uint32), ("algorithm", C.c_uint8), ("role", C.c_uint8)]}
-        out = []
-        for i in range(n):
-            k = kb[i * rows.key_stride: i * rows.key_stride + int(klen[i])].tobytes()
-            out.append(dict(key=k, **{c: int(v[i]) for c, v in cols.items()}))
-        return out
+        km = np.ctypeslib.as_array(C.cast(rows.key_bytes, C.POINTER(C.c_uint8)), shape=(n, rows.key_stride)).copy()
+        return Rows(km, arr(rows.key_len, C.c_uint32), arr(rows.hits, C.c_int64), arr(rows.limit, C.c_int64),
+                    arr(rows.duration, C.c_int64), arr(rows.burst, C.c_int64), arr(rows.created_at, C.c_int64),
+                    arr(rows.behavior, C.c_uint32), arr(rows.algorithm, C.c_uint8), arr(rows.role, C.c_uint8))
+
+    def add_items_struct(self, items, keepalive=None):
+        """guber_add_items on a numpy structured array laid out as guber_item_t (global_sync.ITEM_DTYPE)."""
+        n = len(items)
+        if n:
+            _check(lib().guber_add_items(self.h, C.cast(items.ctypes.data, C.POINTER(GuberItem)), n, None))
 
     def profile(self, enable):
         _check(lib().guber_profile_enable(self.h, 1 if enable else 0))

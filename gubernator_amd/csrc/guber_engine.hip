@@ -89,7 +89,7 @@ struct guber_engine {
     bool always_careful = false;
     DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
     // GLOBAL pending queues
-    DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
+    DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -187,7 +187,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     uint32_t gdirty_cap = 0;
     if (cfg->flags & GUBER_FLAG_GLOBAL) {
         gdirty_cap = (uint32_t)std::min<uint64_t>(e->slots, 1u << 24);
-        rc |= e->gpend.ensure(e->slots); rc |= e->gdirty.ensure(gdirty_cap);
+        rc |= e->gpend.ensure(e->slots); rc |= e->gdirty.ensure(gdirty_cap); rc |= e->gdirty2.ensure(gdirty_cap);
+        rc |= e->gtake_ctr.ensure(4);
     }
     e->n_bctr = (M + 255) / 256;
     rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
@@ -238,7 +239,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
                 e->dbg_sum[0] * per, e->dbg_sum[1] * per, e->dbg_sum[2] * per,
                 e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 256.0));
     }
-    e->dbg.release(); e->gpend.release(); e->gdirty.release(); e->d_take.release(); e->h_take.release();
+    e->dbg.release(); e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
+    e->d_take.release(); e->h_take.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
@@ -699,7 +701,7 @@ extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, co
     return GUBER_OK;
 }
 
-extern "C" int guber_global_take(guber_engine_t* e, guber_global_rows_t* out) {
+extern "C" int guber_global_take(guber_engine_t* e, uint32_t role_mask, guber_global_rows_t* out) {
     if (!e || !out) return fail(GUBER_E_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
@@ -721,12 +723,21 @@ extern "C" int guber_global_take(guber_engine_t* e, guber_global_rows_t* out) {
     uint8_t* d = e->d_take.p;
     GTakeOut O{d + o_keys, (uint32_t*)(d + o_len), (int64_t*)(d + o_i64), (int64_t*)(d + o_i64) + n, (int64_t*)(d + o_i64) + 2 * (size_t)n,
                (int64_t*)(d + o_i64) + 3 * (size_t)n, (int64_t*)(d + o_i64) + 4 * (size_t)n, (uint32_t*)(d + o_beh), d + o_alg, d + o_role, stride};
-    hipLaunchKernelGGL(k_global_take, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, n, O);
-    HIPCHK(hipMemsetAsync(&e->ctr.p->gdirty_n, 0, sizeof(unsigned int), e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_take.p, d, total, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemsetAsync(e->gtake_ctr.p, 0, 4 * sizeof(uint32_t), e->stream));
+    hipLaunchKernelGGL(k_global_take, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, n, role_mask, e->gdirty2.p,
+                       (unsigned int*)e->gtake_ctr.p, O);
+    unsigned int cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, e->gtake_ctr.p, sizeof(cnt), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    // rows that were not asked for stay queued: the kept list becomes the dirty list
+    std::swap(e->gdirty.p, e->gdirty2.p);
+    e->T.gdirty = e->gdirty.p;
+    HIPCHK(hipMemcpyAsync(&e->ctr.p->gdirty_n, &cnt[1], sizeof(unsigned int), hipMemcpyHostToDevice, e->stream));
+    const uint32_t m = cnt[0];
+    if (m) HIPCHK(hipMemcpyAsync(e->h_take.p, d, total, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     const uint8_t* h = e->h_take.p;
-    out->n = n; out->key_bytes = h + o_keys; out->key_len = (const uint32_t*)(h + o_len);
+    out->n = m; out->key_bytes = h + o_keys; out->key_len = (const uint32_t*)(h + o_len);
     out->hits = (const int64_t*)(h + o_i64); out->limit = out->hits + n; out->duration = out->hits + 2 * (size_t)n;
     out->burst = out->hits + 3 * (size_t)n; out->created_at = out->hits + 4 * (size_t)n;
     out->behavior = (const uint32_t*)(h + o_beh); out->algorithm = h + o_alg; out->role = h + o_role;

@@ -978,16 +978,22 @@ struct GTakeOut {
     uint32_t* behavior; uint8_t* algorithm; uint8_t* role;   // role 1 = hits for the owner, 2 = owner update
     uint32_t stride;
 };
-__global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, GTakeOut O) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t slot = T.gdirty[i];
+__global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, uint32_t role_mask, uint32_t* keep_list,
+                                                     unsigned int* counters /* [0] rows out, [1] kept */, GTakeOut O) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t slot = T.gdirty[j];
     GPend p = T.gpend[slot];
+    if (!((role_mask >> p.queued) & 1u)) {            // not asked for: stays pending
+        keep_list[atomicAdd(&counters[1], 1u)] = slot;
+        return;
+    }
+    const uint32_t i = atomicAdd(&counters[0], 1u);
     const KeyCell* c = &T.buckets[slot].cell;
     const uint32_t len = (uint32_t)(c->w[7] >> 48);
     const uint8_t* src = len <= INLINE_KEY ? (const uint8_t*)c->w : T.arena + c->w[0];
     uint8_t* dst = O.key_bytes + (size_t)i * O.stride;
-    for (uint32_t b = 0; b < len && b < O.stride; ++b) dst[b] = src[b];
+    for (uint32_t b = 0; b < O.stride; ++b) dst[b] = b < len ? src[b] : 0;
     O.key_len[i] = len;
     O.hits[i] = p.hits; O.limit[i] = p.limit; O.duration[i] = p.duration; O.burst[i] = p.burst;
     O.created_at[i] = p.created_at; O.behavior[i] = p.behavior; O.algorithm[i] = p.algorithm; O.role[i] = p.queued;

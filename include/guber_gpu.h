@@ -226,7 +226,7 @@ int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap
  *        is_owner = 0  -> hits are summed per key; template = FIRST queued request; RESET_REMAINING is
  *                         OR-ed in (global.go:100-111)                                  role 1
  *        is_owner = 1  -> the key is marked for broadcast; template = LAST request (global.go:200)  role 2
- *      guber_global_take() returns one row per pending key and clears the queues (the flush of
+ *      guber_global_take() returns one row per pending key of the requested roles and clears those queues (the flush of
  *      runAsyncHits / runBroadcasts, global.go:114-139, 217-232).  Buffers belong to the engine and stay
  *      valid until the next call.  The caller ships role-1 rows to the owning GPU (evaluate with is_owner
  *      = 1 and DRAIN_OVER_LIMIT, gubernator.go:510-512) and, for role-2 rows, re-reads the state with hits
@@ -241,7 +241,8 @@ typedef struct guber_global_rows {
     const uint8_t* algorithm;
     const uint8_t* role;
 } guber_global_rows_t;
-int guber_global_take(guber_engine_t* e, guber_global_rows_t* out);
+int guber_global_take(guber_engine_t* e, uint32_t role_mask /* bit 1: hits rows, bit 2: update rows */,
+                      guber_global_rows_t* out);
 
 /* ---- C++ host layer (gubernator_amd/csrc/worker_pool.h): GPUWorkerPool (micro-batching WorkerPool,
  *      workers.go:54-626 + peer_client.go:284-337 flush policy) and the V1Instance.GetRateLimits slice

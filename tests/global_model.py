@@ -113,14 +113,21 @@ class OracleNode:
                 self.pending[key] = dict(tmpl, role=1)
         return res
 
-    def add_items(self, items):
-        for it in items:
-            self.o.add_item(it, 0)
+    def add_items_struct(self, items, keepalive=None):
+        import ctypes as C
+        for i in range(len(items)):
+            r = items[i]
+            key = C.string_at(int(r["key"]), int(r["key_len"]))
+            self.o.add_item(support.make_item(key, int(r["algorithm"]), limit=int(r["limit"]), duration=int(r["duration"]),
+                                              remaining=int(r["remaining"]), remaining_f=float(r["remaining_f"]),
+                                              stamp=int(r["stamp"]), burst=int(r["burst"]), expire_at=int(r["expire_at"]),
+                                              status=int(r["status"])), 0)
 
-    def global_take(self):
-        rows = list(self.pending.values())
-        self.pending = {}
-        return rows
+    def global_take(self, role_mask=6):
+        from gubernator_amd.global_sync import Rows
+        take = [k for k, r in self.pending.items() if (role_mask >> r["role"]) & 1]
+        rows = [self.pending.pop(k) for k in take]
+        return Rows.from_dicts(rows) if rows else Rows.empty()
 
     def get_item(self, key, now_ms):
         return self.o.get_item(key, now_ms)
