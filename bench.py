@@ -29,10 +29,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_DECISION = {"token": 149, "leaky": 173}   # SURVEY.md section 8d, 16-byte keys
 # split of the algorithmic bytes over the kernels that touch request / table / response data (DESIGN.md
-# "Algorithmic bytes"): k_front reads key_off 4 + key 16 + directory tag 8; k_snap reads the bucket state
-# 48 (token) / 56 (leaky); k_eval2 reads the request fields 32 / 40, writes table 16 / 24 and the response 25.
-KERNEL_BYTES = {"token": {"k_front": 28, "k_snap": 48, "k_eval2": 73, "k_resolve": 28, "k_eval": 121},
-                "leaky": {"k_front": 28, "k_snap": 56, "k_eval2": 89, "k_resolve": 28, "k_eval": 145}}
+# "Algorithmic bytes"): k_front reads key_off 4 + key 16 + table 56 (token) / 64 (leaky); k_eval2 reads
+# the request fields 32 / 40, writes table 16 / 24 and the response 25.
+KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_resolve": 28, "k_eval": 121},
+                "leaky": {"k_front": 84, "k_eval2": 89, "k_resolve": 28, "k_eval": 145}}
 
 
 def parse():

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "guber_pool_get_rate_limits",
 ]
 
-FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_TEST_SERIAL = 1, 2, 4, 8, 16
+FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
 
 _lib = None
 

@@ -80,20 +80,11 @@ struct guber_engine {
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // tile-bitmap grouping path (batches <= 65536)
-    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2, w_wordcnt;
+    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_tilecnt, w_tilestart, w_lrank;
+    DevBuf<uint32_t> w_torder, w_wordcnt;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
-    // software pipeline: k_front / k_snap of batch b+1 run on `front_stream` while k_eval2 of batch b runs on
-    // `stream`; every per-batch work array exists twice (index = batch parity)
-    hipStream_t front_stream = nullptr;
-    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_eval[2] = {nullptr, nullptr}, ev_sync = nullptr;
-    bool eval_recorded[2] = {false, false};
-    bool front_must_wait_main = false;   // set by anything that used `stream` outside the pipeline
-    Work Wp[2];
-    DevBuf<uint32_t> p_u32[2]; DevBuf<uint8_t> p_rflags[2]; DevBuf<Rec> p_snap[2];
-    DevBuf<uint16_t> p_tilecnt[2], p_tilestart[2], p_lrank[2];
     bool force_radix = false;
-    bool serial_pipeline = false;   // GUBER_FLAG_TEST_SERIAL: all three kernels on one stream (no overlap)
     bool careful = false;       // retry rounds run without speculative claims
     bool always_careful = false;
     DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
@@ -120,25 +111,17 @@ struct guber_engine {
         if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
         hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); return ev;
     }
-    // per-kernel timing serialises the pipeline onto `stream` (see launch_batch: profiling => serial)
     void span_begin(int k) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); } }
     void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, stream); }
 
     int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
-enum { KT_FRONT = 0, KT_SNAP, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
-static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_snap", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
+enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
+static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
                                                    "k_scatter", "k_heads", "k_eval"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
-
-// Everything except the pipelined batch path runs on `stream` only: drain the front stream first and make the
-// next pipelined batch wait for whatever was enqueued on `stream`.
-static void quiesce(guber_engine* e) {
-    if (e->front_stream) (void)hipStreamSynchronize(e->front_stream);
-    e->front_must_wait_main = true;
-}
 
 // fold the per-workgroup event counters into a DevCounters image (host side)
 static void fold_counters(guber_engine* e) {
@@ -156,7 +139,6 @@ static int enqueue_counter_readback(guber_engine* e) {
     return 0;
 }
 static int engine_refresh_counters(guber_engine* e) {
-    quiesce(e);
     int rc = enqueue_counter_readback(e);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -198,15 +180,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->fast_cap = std::min<uint32_t>(M, FT * FT_MAX_TILES);
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
-    e->serial_pipeline = (cfg->flags & GUBER_FLAG_TEST_SERIAL) != 0 || getenv("GUBER_SERIAL_PIPELINE") != nullptr;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
-    for (int q = 0; q < 2; ++q) {
-        rc |= e->p_u32[q].ensure((size_t)e->fast_cap * 4);          // did, slot, seg_slot, torder
-        rc |= e->p_rflags[q].ensure(e->fast_cap); rc |= e->p_snap[q].ensure(e->fast_cap);
-        rc |= e->p_tilecnt[q].ensure((size_t)e->fast_cap * FT_MAX_TILES);
-        rc |= e->p_tilestart[q].ensure((size_t)e->fast_cap * FT_MAX_TILES);
-        rc |= e->p_lrank[q].ensure(e->fast_cap);
-    }
+    rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
+    rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     rc |= e->w_wordcnt.ensure((size_t)2 * e->fast_cap * FT_WORDS);
     uint32_t gdirty_cap = 0;
     if (cfg->flags & GUBER_FLAG_GLOBAL) {
@@ -244,22 +220,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.rflags = e->w_rflags.p; e->W.snap = e->w_snap.p;
     e->W.hist = e->w_hist.p;
     e->W.tiles = tiles; e->W.epoch = 0;
-    e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.wordcnt = e->w_wordcnt.p;
-    for (int q = 0; q < 2; ++q) {
-        Work& w = e->Wp[q];
-        w = e->W;
-        uint32_t* u = e->p_u32[q].p;
-        w.did = u; w.slot = u + e->fast_cap; w.seg_slot = u + 2 * (size_t)e->fast_cap; w.torder = u + 3 * (size_t)e->fast_cap;
-        w.rflags = e->p_rflags[q].p; w.snap = e->p_snap[q].p; w.tilecnt = e->p_tilecnt[q].p;
-        w.tilestart = e->p_tilestart[q].p; w.lrank = e->p_lrank[q].p;
-        w.parity = (uint32_t)q;
-    }
-    if (hipStreamCreateWithFlags(&e->front_stream, hipStreamNonBlocking) != hipSuccess) { guber_engine_destroy(e); return fail(GUBER_E_HIP, "hipStreamCreate"); }
-    for (int q = 0; q < 2; ++q) {
-        (void)hipEventCreateWithFlags(&e->ev_snap[q], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&e->ev_eval[q], hipEventDisableTiming);
-    }
-    (void)hipEventCreateWithFlags(&e->ev_sync, hipEventDisableTiming);
+    e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
+    e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
+    e->W.wordcnt = e->w_wordcnt.p;
     e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
     if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)FT_MAX_TILES * 8) == 0) e->W.dbg = e->dbg.p; }
     *out = e;
@@ -269,7 +232,6 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
 extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->front_stream) (void)hipStreamSynchronize(e->front_stream);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->dbg_n) {   // wall_clock64 ticks at 100 MHz
         const double per = 1.0 / (double)e->dbg_n * 0.01;
@@ -282,16 +244,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
-    e->w_tilemask.release(); e->w_flags2.release();
-    e->w_wordcnt.release();
-    for (int q = 0; q < 2; ++q) {
-        e->p_u32[q].release(); e->p_rflags[q].release(); e->p_snap[q].release(); e->p_tilecnt[q].release();
-        e->p_tilestart[q].release(); e->p_lrank[q].release();
-        if (e->ev_snap[q]) (void)hipEventDestroy(e->ev_snap[q]);
-        if (e->ev_eval[q]) (void)hipEventDestroy(e->ev_eval[q]);
-    }
-    if (e->ev_sync) (void)hipEventDestroy(e->ev_sync);
-    if (e->front_stream) { (void)hipStreamSynchronize(e->front_stream); (void)hipStreamDestroy(e->front_stream); }
+    e->w_tilemask.release(); e->w_flags2.release(); e->w_tilecnt.release(); e->w_tilestart.release();
+    e->w_lrank.release(); e->w_torder.release(); e->w_wordcnt.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -322,49 +276,38 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     W.epoch = e->epoch;
     W.tiles = tiles;
     if (n <= e->fast_cap && !e->force_radix) {
-        // three launches, software-pipelined over two streams:
-        //   front_stream: k_front(b) -> [wait eval(b-1)] -> k_snap(b) -> k_front(b+1) -> ...
-        //   stream      : [wait snap(b)] -> k_eval2(b) -> ...
-        // so the key resolution of batch b+1 overlaps the evaluation of batch b.  Device inputs must be complete
-        // when the call is made (the host-pointer entry point and management calls set front_must_wait_main).
-        const uint32_t q = e->fast_batches & 1u;
-        Work Wq = e->Wp[q];
-        Wq.epoch = e->epoch; Wq.tiles = tiles;
+        // two launches: resolve + in-tile grouping, then evaluation
         BatchView B2 = B;
         B2.n_cap = e->fast_cap;
         const uint32_t ftiles = (n + FT - 1) / FT;
-        Wq.careful = (e->careful || e->always_careful) ? 1u : 0u;
-        Wq.parity = q;
-        Wq.clear_n = e->fast_prev_n;
-        Wq.dbg = e->dbg.p;
-        hipStream_t fs = (e->serial_pipeline || e->profiling) ? e->stream : e->front_stream;
-        if (e->front_must_wait_main && fs != e->stream) {
-            HIPCHK(hipEventRecord(e->ev_sync, e->stream));
-            HIPCHK(hipStreamWaitEvent(fs, e->ev_sync, 0));
-        }
-        e->front_must_wait_main = false;
+        W.careful = (e->careful || e->always_careful) ? 1u : 0u;
+        W.parity = e->fast_batches & 1u;
+        W.clear_n = e->fast_prev_n;
+        W.dbg = e->dbg.p;
         e->span_begin(KT_FRONT);
-        hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, fs, e->T, B2, Wq);
+        hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
-        if (fs != e->stream && e->eval_recorded[q ^ 1u]) HIPCHK(hipStreamWaitEvent(fs, e->ev_eval[q ^ 1u], 0));
-        e->span_begin(KT_SNAP);
-        hipLaunchKernelGGL(k_snap, dim3((std::max(n, Wq.clear_n) + 255) / 256), dim3(256), 0, fs, e->T, B2, Wq);
-        e->span_end();
-        if (fs != e->stream) {
-            HIPCHK(hipEventRecord(e->ev_snap[q], fs));
-            HIPCHK(hipStreamWaitEvent(e->stream, e->ev_snap[q], 0));
+        if (e->dbg.p && e->fast_batches > 200 && e->fast_batches % 8 == 0) {   // debug only: sync + fold stamps
+            std::vector<unsigned long long> h(ftiles * 8);
+            (void)hipMemcpyAsync(h.data(), e->dbg.p, h.size() * 8, hipMemcpyDeviceToHost, e->stream);
+            (void)hipStreamSynchronize(e->stream);
+            unsigned long long t0 = ~0ull, t3 = 0;
+            for (uint32_t t = 0; t < ftiles; ++t) {
+                for (int k = 0; k < 3; ++k) e->dbg_sum[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + k]);
+                t0 = std::min(t0, h[t * 8]); t3 = std::max(t3, h[t * 8 + 3]);
+            }
+            e->dbg_sum[3] += (double)(t3 - t0);
+            e->dbg_n += ftiles;
         }
         e->span_begin(KT_EVAL2);
-        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, Wq);
+        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
         e->span_end();
-        if (fs != e->stream) { HIPCHK(hipEventRecord(e->ev_eval[q], e->stream)); e->eval_recorded[q] = true; }
         HIPCHK(hipGetLastError());
         e->fast_batches++;
         e->fast_prev_n = n;
         e->batches++;
         return 0;
     }
-    quiesce(e);
     int passes = 1;
     while (passes < MAX_PASSES && (1ull << (RADIX_BITS * passes)) < n) passes++;
     e->span_begin(KT_RESOLVE);
@@ -422,7 +365,6 @@ extern "C" int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* b, g
 // Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of
 // the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
 static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_t* r, const uint32_t* idx, uint32_t n) {
-    quiesce(e);   // inputs are staged on `stream`: the front stream must wait for the copies
     const bool has_burst = b->burst, has_created = b->created_at, has_greg = b->greg_expire && b->greg_duration;
     // key bytes of the (sub)batch
     size_t kbytes = 0;
@@ -544,7 +486,6 @@ static void item_from_rec(const Rec& s, guber_item_t* out) {
 }
 
 static int add_items_once(guber_engine* e, const guber_item_t* items, const std::vector<uint32_t>& sel, uint8_t* res_out) {
-    quiesce(e);
     const uint32_t n = (uint32_t)sel.size();
     size_t kbytes = 0;
     for (uint32_t j : sel) kbytes += items[j].key_len;
@@ -632,7 +573,6 @@ static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, in
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     *found = 0;
     if (key_len == 0 || key_len > e->max_key) return GUBER_OK;
-    quiesce(e);
     DevBuf<uint8_t> d_key; DevBuf<Rec> d_rec; DevBuf<int> d_found;
     int rc = d_key.ensure(key_len + 16) | d_rec.ensure(1) | d_found.ensure(1);
     auto cleanup = [&]() { d_key.release(); d_rec.release(); d_found.release(); };
@@ -681,7 +621,6 @@ extern "C" int64_t guber_size(guber_engine_t* e) {
 extern "C" int guber_synchronize(guber_engine_t* e) {
     if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    if (e->front_stream) HIPCHK(hipStreamSynchronize(e->front_stream));
     HIPCHK(hipStreamSynchronize(e->stream));
     return GUBER_OK;
 }
@@ -744,7 +683,6 @@ extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, co
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     const uint32_t npts = guber_ring_points(r, nullptr, nullptr, 0);
     if (npts == 0) return fail(GUBER_E_INVALID_ARG, "empty ring");
-    quiesce(e);
     if ((size_t)npts * 8 > 150 * 1024) return fail(GUBER_E_INVALID_ARG, "ring does not fit in LDS");
     std::vector<uint64_t> hh(npts); std::vector<uint32_t> oo(npts);
     guber_ring_points(r, hh.data(), oo.data(), npts);
@@ -769,7 +707,6 @@ extern "C" int guber_global_take(guber_engine_t* e, uint32_t role_mask, guber_gl
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     memset(out, 0, sizeof(*out));
     if (!e->T.gpend) return fail(GUBER_E_INVALID_ARG, "engine created without GUBER_FLAG_GLOBAL");
-    quiesce(e);
     DevCounters c;
     HIPCHK(hipMemcpyAsync(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -817,7 +754,6 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
     if (!e || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    quiesce(e);
     HIPCHK(hipStreamSynchronize(e->stream));
     for (auto& s : e->spans) {
         float ms = 0.f;

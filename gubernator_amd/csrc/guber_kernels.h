@@ -592,6 +592,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     bool fresh = false, claimed = false, cand = false, ready = false;
     unsigned long long meta = 0ull;
     const uint8_t* key = nullptr;
+    Rec rec; rec_clear(rec);
     uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     if (valid) {
         const uint32_t off = B.key_off[g];
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 bool cl = false;
                 d = claim_segment(mp, ld_agent(mp), W.epoch, g, cl);
                 claimed = cl;
+                rec = T.buckets[cslot].rec;
             }
         } else if (!errcode) {
             const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
@@ -633,9 +635,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 if (t == tag) { slot = (uint32_t)pos; cand = true; meta = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
             }
             if (!cand && !errcode) errcode = 6;                      // probe bound exceeded: table full
-            if (cand && ready) {                                     // start fetching the stored key
-                const uint4* cw = (const uint4*)&T.buckets[slot].cell;
-                c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
+            if (cand) {
+                const Bucket* bk = &T.buckets[slot];
+                if (ready) { const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3]; }
+                rec = bk->rec;                                       // (zero for a bucket never used)
             }
         }
     }
@@ -691,7 +694,8 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         } else {
             if (inserted) rf |= RF_INSERTED;
             if (claimed) {
-                W.seg_slot[d] = slot;                          // (k_snap copies the bucket record next)
+                W.seg_slot[d] = slot;
+                W.snap[d] = rec;                               // claimer snapshots the bucket
             } else {
                 // entry created during this launch: prove key equality against the claimer's request
                 if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
@@ -763,15 +767,12 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
 #undef GB_STAMP
 }
 
-// k_snap: between k_front and k_eval2.  It is the only kernel of the pipeline that must wait for the
-// PREVIOUS batch's evaluation (it reads bucket records), which lets k_front(b+1) overlap k_eval2(b):
-//   * every segment's claimer copies its bucket record into the dense snapshot array;
-//   * this batch's inserts become READY (their key cells are complete once k_front has finished);
-//   * the double-buffered segment flags / bitmaps / subtotals of the OTHER parity (consumed by the
-//     previous batch's k_eval2) are cleared for the next batch.
-__global__ __launch_bounds__(256) void k_snap(Table T, BatchView B, Work W) {
+__global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
+    __shared__ int red[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    {
+    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
+    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
+    {   // clear the other copy for the next batch
         uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
         unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
         uint32_t* ow = W.wordcnt + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
@@ -781,17 +782,6 @@ __global__ __launch_bounds__(256) void k_snap(Table T, BatchView B, Work W) {
             for (int w = 0; w < FT_WORDS; ++w) { om[(size_t)j * FT_WORDS + w] = 0ull; ow[(size_t)j * FT_WORDS + w] = 0u; }
         }
     }
-    if (i >= B.n) return;
-    const uint8_t rf = W.rflags[i];
-    if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);
-    if (!(rf & RF_ERR) && W.did[i] == i) W.snap[i] = T.buckets[W.seg_slot[i]].rec;
-}
-
-__global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
-    __shared__ int red[4];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
-    unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
     // pre-pass: the head of every (segment, tile) group computes the group's base = members of the
     // segment in earlier tiles, and the segment's total, from the bitmap and the per-tile counts; the
     // other members pick both up from LDS (eval workgroup == tile, FT == 256).
@@ -842,12 +832,15 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     if (i < B.n) {
         const uint32_t d = W.did[i];
         const uint32_t sf = seg_flags[d];
+        const uint8_t rf = W.rflags[i];
+        if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);   // publish this batch's inserts
         if (sf & SEG_ERR) {
             store_err(R, i, (uint8_t)(sf >> 8));
         } else if (sf & SEG_RETRY) {
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
+            const uint32_t t = i / FT;
             const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
             uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);

@@ -13,11 +13,8 @@
  *    unless the function name says `alloc`.
  *  - return value: 0 (GUBER_OK) or a negative GUBER_E_* code; never throws.
  *  - no caller memory is retained after a call returns (cgo pointer rule).
- *  - `*_dev` variants take DEVICE pointers (HBM-resident SoA) and enqueue without
- *    synchronising: results are complete on the engine stream; the input arrays must
- *    already be complete when the call is made and stay untouched until the results
- *    are (consecutive batches are software-pipelined over two internal streams).
- *    The plain variants take HOST pointers,
+ *  - `*_dev` variants take DEVICE pointers (HBM-resident SoA) and enqueue on the
+ *    engine stream without synchronising; the plain variants take HOST pointers,
  *    stage through pinned buffers and return after the results are on the host.
  *  - responses are positionally aligned with requests (gubernator.proto:51-54).
  */
@@ -80,7 +77,6 @@ extern "C" {
 typedef struct guber_engine guber_engine_t;
 
 /* guber_config_t.flags */
-#define GUBER_FLAG_TEST_SERIAL 16u   /* tests only: run the batch pipeline on one stream (no front/eval overlap) */
 #define GUBER_FLAG_GLOBAL 8u          /* keep per-bucket pending GLOBAL hits / updates (guber_global_take) */
 #define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
