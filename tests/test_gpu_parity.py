@@ -279,3 +279,42 @@ def test_config0_batch_of_one_1k_keys():
         b = HostBatch([f"bench_{i % 1000:04d}"], 1, 10, 5000, now + i)
         assert e.eval(b).rows() == o.eval(b).rows(), i
     e.close()
+
+
+def test_back_to_back_device_batches_match_oracle():
+    """Many dependent device-resident batches (guber_eval_batch_dev) enqueued back to back without any host
+    synchronisation in between, on overlapping key sets, checked batch by batch against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    K, B, steps = 3000, 4096, 40
+    tab = streams.key_table(K)
+    z = streams.ZipfSampler(K, seed=5)
+    stream = torch.cuda.Stream(device=dev)
+    e = ga.Engine(cache_size=4 * K, max_batch=B, stream=stream.cuda_stream)
+    o = Oracle(cache_size=1 << 16)
+    hbs, dbs, outs = [], [], []
+    for s in range(steps):
+        hb = streams.bench_batch(tab, z.draw(B), streams.NOW0 + s * 900, algorithm=s % 2, limit=40, duration=5000)
+        t = [torch.from_numpy(hb.key_bytes).to(dev), torch.from_numpy(hb.key_off.view(np.int32)).to(dev),
+             torch.from_numpy(hb.hits).to(dev), torch.from_numpy(hb.limit).to(dev), torch.from_numpy(hb.duration).to(dev),
+             torch.from_numpy(hb.algorithm).to(dev), torch.from_numpy(hb.behavior.view(np.int32)).to(dev)]
+        p = [x.data_ptr() for x in t]
+        r = dict(status=torch.empty(B, dtype=torch.uint8, device=dev), err=torch.empty(B, dtype=torch.uint8, device=dev),
+                 limit=torch.empty(B, dtype=torch.int64, device=dev), remaining=torch.empty(B, dtype=torch.int64, device=dev),
+                 reset_time=torch.empty(B, dtype=torch.int64, device=dev))
+        hbs.append(hb); dbs.append((t, ga.GuberBatch(B, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], None, None, None, hb.now_ms)))
+        outs.append((r, ga.GuberResult(r["status"].data_ptr(), r["limit"].data_ptr(), r["remaining"].data_ptr(),
+                                       r["reset_time"].data_ptr(), r["err"].data_ptr(), 0, 0, 0, 0, 0)))
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(stream):
+        for s in range(steps):
+            e.eval_dev(dbs[s][1], outs[s][1])
+    e.synchronize()
+    for s in range(steps):
+        want = o.eval(hbs[s])
+        got = ga.HostResult(B)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = outs[s][0][name].cpu().numpy()
+        support.assert_results_equal(got, want, f"step {s}")
+    assert e.size() == o.size()
+    e.close()
