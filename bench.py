@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=48)
     ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=32)
+    ap.add_argument("--shards", type=int, default=1, metavar="S",
+                    help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
+                         "engines with their own tables and streams; step s evaluates a batch of shard s %% S")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
                     help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
                          "and every K steps the ranks exchange pending hits / broadcast owner state (0 = off)")
@@ -88,8 +91,13 @@ def main():
     algo_id = 0 if args.algo == "token" else 1
     stream = torch.cuda.Stream(device=dev)
     GSYNC = args.global_sync
-    eng = ga.Engine(cache_size=K + K // 4, device=local_rank, max_batch=B, stream=stream.cuda_stream,
-                    max_key_bytes=64 if GSYNC else 0, flags=ga.FLAG_GLOBAL if GSYNC else 0)
+    S = max(1, args.shards)
+    if GSYNC and S > 1:
+        raise SystemExit("--global-sync runs with one shard per GPU")
+    sstreams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
+    engines = [ga.Engine(cache_size=(K + K // 4) // S + 1024, device=local_rank, max_batch=B, stream=sstreams[j].cuda_stream,
+                         max_key_bytes=64 if GSYNC else 0, flags=ga.FLAG_GLOBAL if GSYNC else 0) for j in range(S)]
+    eng = engines[0]
 
     # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
     total_keys = K if GSYNC else K * world      # GLOBAL: one key space, replicated on every GPU
@@ -108,6 +116,14 @@ def main():
     else:
         my_ids = shard.owned_key_ids(table, world, rank, route=route_on_device, chunk=4_000_000)
     nk = len(my_ids)
+    # logical shards inside this GPU: the rank's keys are split once more by the same kind of ring
+    if S > 1:
+        sring = ga.Ring([f"gpu{rank}-shard{j}" for j in range(S)], 512, "fnv1")
+        sown = np.concatenate([route_on_device(sring, *streams.keys_for_ids(table, my_ids[lo:lo + 4_000_000]))
+                               for lo in range(0, nk, 4_000_000)])
+        shard_ids = [my_ids[sown == j] for j in range(S)]
+    else:
+        shard_ids = [my_ids]
 
     # ---- device-resident batches ------------------------------------------------------------
     def to_dev(a):
@@ -152,23 +168,28 @@ def main():
 
     NOW0 = streams.NOW0
     # residency: every owned key gets a bucket before anything is timed (hits 0 = create, consume nothing)
-    with torch.cuda.stream(stream):
-        scratch = DevResult(B)
-        for lo in range(0, nk, B):
-            db = DevBatch(my_ids[lo:lo + B], NOW0, hits=0)
-            eng.eval_dev(db.c, scratch.c)
-            eng.synchronize()
-    resident = eng.size()
+    scratches = [DevResult(B) for _ in range(S)]
+    scratch = scratches[0]
+    for j in range(S):
+        with torch.cuda.stream(sstreams[j]):
+            for lo in range(0, len(shard_ids[j]), B):
+                db = DevBatch(shard_ids[j][lo:lo + B], NOW0, hits=0)
+                engines[j].eval_dev(db.c, scratches[j].c)
+                engines[j].synchronize()
+    resident = sum(e_.size() for e_ in engines)
 
-    if args.dist == "zipf":
-        sampler = streams.ZipfSampler(nk, s=1.1, seed=1234 + rank, perm_seed=99)
-        draw = lambda n: my_ids[sampler.draw(n)]
-    else:
-        rng = np.random.default_rng(1234 + rank)
-        draw = lambda n: my_ids[rng.permutation(nk)[:n]] if n <= nk else my_ids[rng.integers(0, nk, n)]
+    draws = []
+    for j in range(S):
+        ids_j = shard_ids[j]
+        if args.dist == "zipf":
+            smp = streams.ZipfSampler(len(ids_j), s=1.1, seed=1234 + rank * 64 + j, perm_seed=99)
+            draws.append(lambda n, smp=smp, ids_j=ids_j: ids_j[smp.draw(n)])
+        else:
+            rg = np.random.default_rng(1234 + rank * 64 + j)
+            draws.append(lambda n, rg=rg, ids_j=ids_j: ids_j[rg.permutation(len(ids_j))[:n]] if n <= len(ids_j) else ids_j[rg.integers(0, len(ids_j), n)])
 
     total_steps = args.warmup + args.steps
-    host_ids = [draw(B) for _ in range(total_steps)]
+    host_ids = [draws[s % S](B) for s in range(total_steps)]
     batches = [DevBatch(host_ids[s], NOW0 + 1 + s) for s in range(total_steps)]
     KEEP = min(8, total_steps)           # results of the first KEEP steps are kept for the parity gate
     kept = [DevResult(B) for _ in range(KEEP)]
@@ -182,7 +203,7 @@ def main():
     sync_stats = []
 
     def run(s):
-        eng.eval_dev(batches[s].c, (kept[s] if s < KEEP else scratch).c)
+        engines[s % S].eval_dev(batches[s].c, (kept[s] if s < KEEP else scratches[s % S]).c)
         if gsync is not None and (s + 1) % GSYNC == 0:
             t_s = time.perf_counter()
             st = gsync.sync(NOW0 + 1 + s)
@@ -217,11 +238,12 @@ def main():
     roofline = None
     kernel_ms = {}
     if rank == 0 and args.profile_steps > 0:
+        shard0_steps = [s_ for s_ in range(args.warmup, total_steps) if s_ % S == 0]
         eng.profile(True)
         eng.profile_read()
         with torch.cuda.stream(stream):
             for j in range(args.profile_steps):
-                eng.eval_dev(batches[args.warmup + (j % args.steps)].c, scratch.c)
+                eng.eval_dev(batches[shard0_steps[j % len(shard0_steps)]].c, scratch.c)
         prof = eng.profile_read()
         eng.profile(False)
         kernel_ms = {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
@@ -297,6 +319,7 @@ def main():
                                    f", batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, "
                                    f"{world}xMI355X" + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else ""),
                        "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
+                       "logical_shards_per_gpu": S,
                        "host_cores": os.cpu_count()},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         }
@@ -309,7 +332,8 @@ def main():
                                   "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
                                   "bytes_moved_rank0": gsync.bytes_moved}
         print(json.dumps(out))
-    eng.close()
+    for e_ in engines:
+        e_.close()
     if world > 1:
         dist.destroy_process_group()
 
