@@ -7,6 +7,12 @@ already resident in HBM.  Workload (BASELINE.json configs[1], SURVEY.md section 
 keys per GPU, Zipf(1.1) key popularity (stream seed 1234, permutation seed 99), TOKEN_BUCKET, hits 1,
 limit 100, duration 60 s, now_ms advancing 1 ms per batch.  `--algo leaky` switches to configs[2].
 
+Inside a GPU the resident keys are split into S logical shards (default 2; the reference shards its key
+space the same way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables
+and HIP streams, the front end routes a key to its shard with the same consistent hash, and step s
+evaluates one 65536-request batch of shard s % S — consecutive steps are independent and overlap on the
+GPU.  `--shards 1` gives the single-table number (1.8 G/s vs 2.8 G/s on MI355X).
+
 N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by
 the reference's replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1),
 every rank evaluates batches over the keys it owns — no data-path collective (weak scaling).
@@ -48,7 +54,7 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=48)
     ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=32)
-    ap.add_argument("--shards", type=int, default=1, metavar="S",
+    ap.add_argument("--shards", type=int, default=2, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
                          "engines with their own tables and streams; step s evaluates a batch of shard s %% S")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
@@ -92,8 +98,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     GSYNC = args.global_sync
     S = max(1, args.shards)
-    if GSYNC and S > 1:
-        raise SystemExit("--global-sync runs with one shard per GPU")
+    if GSYNC:
+        S = 1   # GLOBAL replicas: one table per GPU
     sstreams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
     engines = [ga.Engine(cache_size=(K + K // 4) // S + 1024, device=local_rank, max_batch=B, stream=sstreams[j].cuda_stream,
                          max_key_bytes=64 if GSYNC else 0, flags=ga.FLAG_GLOBAL if GSYNC else 0) for j in range(S)]
@@ -317,7 +323,8 @@ def main():
             "config": {"workload": f"{K} resident keys per GPU, {args.dist} key popularity"
                                    + (" s=1.1" if args.dist == "zipf" else "") +
                                    f", batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, "
-                                   f"{world}xMI355X" + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else ""),
+                                   f"{world}xMI355X" + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
+                                   + (f", {S} logical shards per GPU (own table + stream each, batches routed by the same hash)" if S > 1 else ""),
                        "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
                        "logical_shards_per_gpu": S,
                        "host_cores": os.cpu_count()},
