@@ -220,22 +220,41 @@ def main():
         if world > 1:
             dist.barrier()
 
-    with torch.cuda.stream(stream):
-        for s in range(args.warmup):
-            run(s)
-        torch.cuda.synchronize(dev)
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record(stream)
-        for s in range(args.warmup, total_steps):
-            run(s)
-        ev1.record(stream)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        barrier()
+    import threading
+
+    def run_range(lo, hi, j):
+        # steps of shard j in [lo, hi): one driver thread per shard, as one batcher goroutine per shard would
+        for s_ in range(lo, hi):
+            if s_ % S == j:
+                run(s_)
+
+    def run_steps(lo, hi):
+        if S == 1 or gsync is not None:
+            for s_ in range(lo, hi):
+                run(s_)
+            return
+        ts = [threading.Thread(target=run_range, args=(lo, hi, j)) for j in range(S)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    run_steps(0, args.warmup)
+    torch.cuda.synchronize(dev)
+    barrier()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    t0 = time.perf_counter()
+    for j in range(S):
+        ev0[j].record(sstreams[j])
+    run_steps(args.warmup, total_steps)
+    for j in range(S):
+        ev1[j].record(sstreams[j])
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    barrier()
     wall = t1 - t0
-    ev_ms = ev0.elapsed_time(ev1)
+    ev_ms = max(ev0[j].elapsed_time(ev1[j]) for j in range(S))
     wall = shard.max_over_ranks(wall, device=red_dev)
     decisions = args.steps * B * world
     value = decisions / wall
