@@ -620,8 +620,12 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             const unsigned long long tag = h ? h : 1ull;
             uint64_t pos = (h >> 7) & T.mask;
             for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
-                unsigned long long t = ld_agent(&T.dir[pos].tag);   // two sc1 loads, one round trip,
-                unsigned long long m = ld_agent(&T.dir[pos].meta);  // never a stale L1 line
+                // plain 16-byte load: L1 may serve a line that is stale within this launch, which is safe here —
+                // a stale "empty" tag is corrected by the insert CAS, a stale meta by the claim CAS (only one
+                // leader per workgroup and key claims), READY never changes during k_front — and it keeps the
+                // thousands of re-reads of a hot key's entry out of L2 / the memory-side atomics' way.
+                const ulonglong2 de = *(const ulonglong2*)&T.dir[pos];
+                unsigned long long t = de.x, m = de.y;
                 if (t == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
                     if (old == 0ull) {                               // new key: this thread inserts it
