@@ -81,7 +81,7 @@ struct guber_engine {
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_tilecnt, w_tilestart, w_lrank;
-    DevBuf<uint32_t> w_torder, w_wordcnt;
+    DevBuf<uint32_t> w_torder, w_did2;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -183,7 +183,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
     rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
-    rc |= e->w_wordcnt.ensure((size_t)2 * e->fast_cap * FT_WORDS);
+    rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     uint32_t gdirty_cap = 0;
     if (cfg->flags & GUBER_FLAG_GLOBAL) {
         gdirty_cap = (uint32_t)std::min<uint64_t>(e->slots, 1u << 24);
@@ -200,7 +200,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->bctr.p, 0, e->n_bctr * sizeof(BlockCounters), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_flags2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
-        (he = hipMemsetAsync(e->w_wordcnt.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 4, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
@@ -222,7 +222,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.tiles = tiles; e->W.epoch = 0;
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
     e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
-    e->W.wordcnt = e->w_wordcnt.p;
+
     e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
     if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)FT_MAX_TILES * 8) == 0) e->W.dbg = e->dbg.p; }
     *out = e;
@@ -245,7 +245,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_flags2.release(); e->w_tilecnt.release(); e->w_tilestart.release();
-    e->w_lrank.release(); e->w_torder.release(); e->w_wordcnt.release();
+    e->w_lrank.release(); e->w_torder.release(); e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -282,6 +282,8 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         const uint32_t ftiles = (n + FT - 1) / FT;
         W.careful = (e->careful || e->always_careful) ? 1u : 0u;
         W.parity = e->fast_batches & 1u;
+        W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
+        W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;
         W.clear_n = e->fast_prev_n;
         W.dbg = e->dbg.p;
         e->span_begin(KT_FRONT);

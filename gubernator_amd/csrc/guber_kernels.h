@@ -106,11 +106,11 @@ struct Work {
     // requests and, per (segment, tile), the group's size and start inside the tile's sorted order.
     // seg_flags / seg_tilemask are double-buffered by batch parity: a batch's eval kernel clears the
     // other copy for the next batch, so no memset launch is needed.
-    unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]
+    unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
+    uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
     uint32_t* seg_flags2;               // [2][cap]
     uint16_t* tilecnt;                  // [cap][FT_MAX_TILES]
     uint16_t* tilestart;                // [cap][FT_MAX_TILES]
-    uint32_t* wordcnt;                  // [2][cap][FT_WORDS] members of a segment per 64-tile word (double-buffered)
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
     unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
 // k_eval2 (request order): rank = members in earlier tiles (bitmap + per-tile counts) + rank in tile.
 constexpr int FT = 256;                 // requests per tile in the two-launch pipeline
 constexpr int FT_MAX_TILES = 256;       // bitmap bits per segment
-constexpr int FT_WORDS = FT_MAX_TILES / 64;
+constexpr int FT_WORDS = FT_MAX_TILES / 32;   // per segment: 8 x u64, each = members << 32 | bitmap of 32 tiles
 
 __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, uint32_t b) {
     const uint32_t oa = B.key_off[a], ob = B.key_off[b];
@@ -762,9 +762,9 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         if (eq_before == 0) {
             W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
             W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)start;
-            atomicOr(&seg_mask[(size_t)d * FT_WORDS + (tile >> 6)], 1ull << (tile & 63));
-            // members per 64-tile word: lets a group head in k_eval2 sum earlier words in O(1)
-            atomicAdd(&W.wordcnt[((size_t)W.parity * B.n_cap + d) * FT_WORDS + (tile >> 6)], eq_total);
+            // ONE atomic per (segment, tile) group: set the tile's bit and add the group size (bits are set once
+            // each, so the add never carries into the count)
+            atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
         }
     }
     GB_STAMP(3);
@@ -776,14 +776,16 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
-    {   // clear the other copy for the next batch
+    {   // clear, for the next batch, the entries of the other copy that the previous batch used
         uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
-        unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
-        uint32_t* ow = W.wordcnt + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
+        uint4* om = (uint4*)(W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS);
+        const uint4 z = {0, 0, 0, 0};
         for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
-            of[j] = 0;
+            if (W.did_prev[j] == j) {
+                of[j] = 0;
 #pragma unroll
-            for (int w = 0; w < FT_WORDS; ++w) { om[(size_t)j * FT_WORDS + w] = 0ull; ow[(size_t)j * FT_WORDS + w] = 0u; }
+                for (int q = 0; q < FT_WORDS / 2; ++q) om[(size_t)j * (FT_WORDS / 2) + q] = z;
+            }
         }
     }
     // pre-pass: the head of every (segment, tile) group computes the group's base = members of the
@@ -791,41 +793,39 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     // other members pick both up from LDS (eval workgroup == tile, FT == 256).
     __shared__ uint32_t sbase[FT], stotal[FT];
     const uint32_t lr = i < B.n ? W.lrank[i] : 0u;
-    unsigned long long mask[FT_WORDS] = {0ull, 0ull, 0ull, 0ull};
     if (i < B.n && (lr & 0xffu) == 0u) {
         const uint32_t d = W.did[i];
         const uint32_t t = i / FT;
-        const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
-        uint32_t ntiles = 0;
+        const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip
+        unsigned long long sw[FT_WORDS];
 #pragma unroll
-        for (int w = 0; w < FT_WORDS; ++w) { mask[w] = seg_mask[(size_t)d * FT_WORDS + w]; ntiles += __popcll(mask[w]); }
-        uint32_t base = 0, total = 0;
-        if (ntiles <= 1) {
-            total = row[t];                                   // the segment lives in my tile only
-        } else {
-            // earlier 64-tile words from the per-word subtotals, my own word from its 64 per-tile counts
-            // (128 bytes fetched in one round trip, masked by the bitmap)
-            const uint32_t mw = t >> 6, mb = t & 63;
-            const uint4 wc = *(const uint4*)(W.wordcnt + ((size_t)W.parity * B.n_cap + d) * FT_WORDS);
-            const uint32_t wcs[4] = {wc.x, wc.y, wc.z, wc.w};
+        for (int q = 0; q < FT_WORDS / 2; ++q) {
+            const uint4 v = wp[q];
+            sw[2 * q] = ((unsigned long long)v.y << 32) | v.x; sw[2 * q + 1] = ((unsigned long long)v.w << 32) | v.z;
+        }
+        const uint32_t mw = t >> 5, mb = t & 31;
+        uint32_t base = 0, total = 0, below = 0;
 #pragma unroll
-            for (uint32_t w = 0; w < FT_WORDS; ++w) { total += wcs[w]; base += w < mw ? wcs[w] : 0u; }
-            const unsigned long long mymask = mw == 0 ? mask[0] : mw == 1 ? mask[1] : mw == 2 ? mask[2] : mask[3];
-            const unsigned long long below = mymask & ((1ull << mb) - 1ull);
-            if (below) {
-                const uint4* r4 = (const uint4*)(row + mw * 64);
-                uint4 v[8];
+        for (uint32_t w = 0; w < FT_WORDS; ++w) {
+            const uint32_t c = (uint32_t)(sw[w] >> 32);
+            total += c;
+            base += w < mw ? c : 0u;
+            if (w == mw) below = (uint32_t)sw[w] & ((1u << mb) - 1u);
+        }
+        if (below) {
+            // members in earlier tiles of my own 32-tile word: their per-tile counts, 64 bytes, masked by the bitmap
+            const uint4* r4 = (const uint4*)(W.tilecnt + (size_t)d * FT_MAX_TILES + mw * 32);
+            uint4 v[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = r4[q];
+            for (int q = 0; q < 4; ++q) v[q] = r4[q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t blo = q * 8 + e * 2, bhi = blo + 1;
-                        base += ((below >> blo) & 1ull) ? (w4[e] & 0xffffu) : 0u;
-                        base += ((below >> bhi) & 1ull) ? (w4[e] >> 16) : 0u;
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t blo = q * 8 + e * 2, bhi = blo + 1;
+                    base += ((below >> blo) & 1u) ? (w4[e] & 0xffffu) : 0u;
+                    base += ((below >> bhi) & 1u) ? (w4[e] >> 16) : 0u;
                 }
             }
         }
@@ -844,9 +844,8 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
-            const uint32_t t = i / FT;
             const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
-            uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
+            const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
             const uint32_t slot = W.seg_slot[d];
             const Req r = load_req(B, i);
@@ -870,10 +869,10 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                 // members of a tile in their sorted = request order)
                 Rec s = s0;
                 for (int w = 0; w < FT_WORDS; ++w) {
-                    unsigned long long mm = seg_mask[(size_t)d * FT_WORDS + w];
+                    uint32_t mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + w];
                     while (mm) {
-                        const uint32_t tt = w * 64 + (uint32_t)__ffsll((unsigned long long)mm) - 1;
-                        mm &= mm - 1ull;
+                        const uint32_t tt = w * 32 + (uint32_t)__ffs((int)mm) - 1;
+                        mm &= mm - 1u;
                         const uint32_t start = tt * FT + W.tilestart[(size_t)d * FT_MAX_TILES + tt];
                         const uint32_t cnt = row[tt];
                         for (uint32_t q = start; q < start + cnt; ++q) {
