@@ -7,11 +7,11 @@ already resident in HBM.  Workload (BASELINE.json configs[1], SURVEY.md section 
 keys per GPU, Zipf(1.1) key popularity (stream seed 1234, permutation seed 99), TOKEN_BUCKET, hits 1,
 limit 100, duration 60 s, now_ms advancing 1 ms per batch.  `--algo leaky` switches to configs[2].
 
-Inside a GPU the resident keys are split into S logical shards (default 2; the reference shards its key
+Inside a GPU the resident keys are split into S logical shards (default 4; the reference shards its key
 space the same way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables
 and HIP streams, the front end routes a key to its shard with the same consistent hash, and step s
 evaluates one 65536-request batch of shard s % S — consecutive steps are independent and overlap on the
-GPU.  `--shards 1` gives the single-table number (1.8 G/s vs 2.8 G/s on MI355X).
+GPU.  `--shards 1` gives the single-table number (2.1 G/s vs 3.5 G/s on MI355X).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by
 the reference's replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1),
@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=48)
     ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
     ap.add_argument("--profile-steps", type=int, default=32)
-    ap.add_argument("--shards", type=int, default=2, metavar="S",
+    ap.add_argument("--shards", type=int, default=4, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
                          "engines with their own tables and streams; step s evaluates a batch of shard s %% S")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",

@@ -80,7 +80,7 @@ struct guber_engine {
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // tile-bitmap grouping path (batches <= 65536)
-    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_tilecnt, w_tilestart, w_lrank;
+    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_lrank; DevBuf<uint32_t> w_tilerow;
     DevBuf<uint32_t> w_torder, w_did2;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
@@ -181,7 +181,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
-    rc |= e->w_tilecnt.ensure((size_t)e->fast_cap * FT_MAX_TILES); rc |= e->w_tilestart.ensure((size_t)e->fast_cap * FT_MAX_TILES);
+    rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     uint32_t gdirty_cap = 0;
@@ -220,8 +220,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.rflags = e->w_rflags.p; e->W.snap = e->w_snap.p;
     e->W.hist = e->w_hist.p;
     e->W.tiles = tiles; e->W.epoch = 0;
-    e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilecnt = e->w_tilecnt.p;
-    e->W.tilestart = e->w_tilestart.p; e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
+    e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilerow = e->w_tilerow.p;
+    e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
 
     e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
     if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)FT_MAX_TILES * 8) == 0) e->W.dbg = e->dbg.p; }
@@ -244,7 +244,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
-    e->w_tilemask.release(); e->w_flags2.release(); e->w_tilecnt.release(); e->w_tilestart.release();
+    e->w_tilemask.release(); e->w_flags2.release(); e->w_tilerow.release();
     e->w_lrank.release(); e->w_torder.release(); e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();

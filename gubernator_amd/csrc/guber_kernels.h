@@ -109,8 +109,7 @@ struct Work {
     unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
     uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
     uint32_t* seg_flags2;               // [2][cap]
-    uint16_t* tilecnt;                  // [cap][FT_MAX_TILES]
-    uint16_t* tilestart;                // [cap][FT_MAX_TILES]
+    uint32_t* tilerow;                  // [cap][FT_MAX_TILES]: start inside the tile << 16 | members, per (segment, tile)
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
     unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
@@ -698,7 +697,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         } else {
             if (inserted) rf |= RF_INSERTED;
             if (claimed) {
-                W.seg_slot[d] = slot;
+                rec.pad = slot;                                // the segment's slot rides in the snapshot's spare word
                 W.snap[d] = rec;                               // claimer snapshots the bucket
             } else {
                 // entry created during this launch: prove key equality against the claimer's request
@@ -760,8 +759,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         W.torder[tile * FT + start + eq_before] = g;
         W.lrank[g] = (uint16_t)(eq_before | (head_tid << 8));   // rank in group | tid of the group's head
         if (eq_before == 0) {
-            W.tilecnt[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
-            W.tilestart[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)start;
+            W.tilerow[(size_t)d * FT_MAX_TILES + tile] = (start << 16) | eq_total;   // group start | size
             // ONE atomic per (segment, tile) group: set the tile's bit and add the group size (bits are set once
             // each, so the add never carries into the count)
             atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
@@ -814,19 +812,15 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
         }
         if (below) {
             // members in earlier tiles of my own 32-tile word: their per-tile counts, 64 bytes, masked by the bitmap
-            const uint4* r4 = (const uint4*)(W.tilecnt + (size_t)d * FT_MAX_TILES + mw * 32);
-            uint4 v[4];
+            const uint4* r4 = (const uint4*)(W.tilerow + (size_t)d * FT_MAX_TILES + mw * 32);
+            uint4 v[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = r4[q];
+            for (int q = 0; q < 8; ++q) v[q] = r4[q];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < 8; ++q) {
                 const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t blo = q * 8 + e * 2, bhi = blo + 1;
-                    base += ((below >> blo) & 1u) ? (w4[e] & 0xffffu) : 0u;
-                    base += ((below >> bhi) & 1u) ? (w4[e] >> 16) : 0u;
-                }
+                for (int e = 0; e < 4; ++e) base += ((below >> (q * 4 + e)) & 1u) ? (w4[e] & 0xffffu) : 0u;
             }
         }
         sbase[threadIdx.x] = base; stotal[threadIdx.x] = total;
@@ -844,12 +838,13 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
-            const uint16_t* row = W.tilecnt + (size_t)d * FT_MAX_TILES;
+            const uint32_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
             const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
-            const uint32_t slot = W.seg_slot[d];
             const Req r = load_req(B, i);
-            const Rec s0 = W.snap[d];
+            Rec s0 = W.snap[d];
+            const uint32_t slot = s0.pad;
+            s0.pad = 0;
             // requests differing only in created_at still take the parallel path when created_at is never read
             const bool parallel = !(sf & SEG_NONUNIFORM) &&
                                   (!(sf & SEG_CREATED_DIFFERS) ||
@@ -873,8 +868,8 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
                     while (mm) {
                         const uint32_t tt = w * 32 + (uint32_t)__ffs((int)mm) - 1;
                         mm &= mm - 1u;
-                        const uint32_t start = tt * FT + W.tilestart[(size_t)d * FT_MAX_TILES + tt];
-                        const uint32_t cnt = row[tt];
+                        const uint32_t start = tt * FT + (row[tt] >> 16);
+                        const uint32_t cnt = row[tt] & 0xffffu;
                         for (uint32_t q = start; q < start + cnt; ++q) {
                             const uint32_t j = W.torder[q];
                             const Req rj = load_req(B, j);
