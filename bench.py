@@ -293,6 +293,23 @@ def main():
                                  "achieved": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9, 2),
                                  "frac": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}}
 
+    # ---- single-batch latency: submit -> complete, one batch in flight (BASELINE metric: p99 batch latency) ----
+    latency = None
+    if rank == 0 and not GSYNC:
+        lat = []
+        shard0 = [s_ for s_ in range(args.warmup, total_steps) if s_ % S == 0]
+        with torch.cuda.stream(stream):
+            for j in range(min(200, 4 * len(shard0))):
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                eng.eval_dev(batches[shard0[j % len(shard0)]].c, scratch.c)
+                b_.record(stream)
+                b_.synchronize()
+                lat.append(a.elapsed_time(b_) * 1e3)
+        lat.sort()
+        latency = {"unit": "us", "p50": round(lat[len(lat) // 2], 2), "p99": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 2),
+                   "min": round(lat[0], 2), "n": len(lat), "what": "one 65536-request batch, HIP events around guber_eval_batch_dev, nothing else in flight"}
+
     # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
     cpu = None
     parity = None
@@ -347,7 +364,7 @@ def main():
                        "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
                        "logical_shards_per_gpu": S,
                        "host_cores": os.cpu_count()},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
         }
         if GSYNC:
             timed = sync_stats[args.warmup // GSYNC:] or sync_stats

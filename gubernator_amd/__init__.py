@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
-    "guber_pool_get_rate_limits",
+    "guber_pool_get_rate_limits", "guber_compact",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
@@ -63,6 +63,7 @@ def lib():
                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
+        L.guber_compact.argtypes = [C.c_void_p, C.c_int64]
         L.guber_global_take.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.GuberGlobalRows)]
         L.guber_pool_create.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.guber_pool_destroy.argtypes = [C.c_void_p]
@@ -265,6 +266,9 @@ class Engine:
         n = C.c_uint32(0)
         _check(lib().guber_profile_read(self.h, arr, 16, C.byref(n)))
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+
+    def compact(self, now_ms):
+        _check(lib().guber_compact(self.h, now_ms))
 
     def synchronize(self):
         _check(lib().guber_synchronize(self.h))

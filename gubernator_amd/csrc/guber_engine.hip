@@ -99,6 +99,7 @@ struct guber_engine {
     uint32_t epoch = 0;
     uint64_t batches = 0;
     uint64_t tags_upper = 0;   // host-side upper bound of ctr.tags_used
+    uint64_t compactions = 0;
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
     bool profiling = false;
@@ -122,6 +123,8 @@ static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_reso
                                                    "k_scatter", "k_heads", "k_eval"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+
+static void quiesce_all(guber_engine* e) { (void)hipStreamSynchronize(e->stream); }
 
 // fold the per-workgroup event counters into a DevCounters image (host side)
 static void fold_counters(guber_engine* e) {
@@ -253,6 +256,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
 }
 
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
+static int compact_table(guber_engine* e, int64_t now_ms);
 static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R) {
     const uint32_t n = B.n;
     if (n == 0) return 0;
@@ -264,6 +268,11 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     if (e->tags_upper + n > limit) {
         int rc = engine_refresh_counters(e);
         if (rc) return rc;
+        if (e->tags_upper >= limit && !e->T.gpend) {
+            // drop expired / removed buckets before giving up (the reference's cache would have evicted them)
+            rc = compact_table(e, B.now_ms);
+            if (rc) return rc;
+        }
         if (e->tags_upper >= limit) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
     e->tags_upper += n;
@@ -612,7 +621,7 @@ extern "C" int guber_stats(guber_engine_t* e, guber_stats_t* out) {
     const DevCounters& c = e->last_ctr;
     out->over_limit_count = c.over; out->cache_hits = c.hits; out->cache_misses = c.misses;
     out->unexpired_evictions = c.evictions; out->cache_size = c.size; out->table_slots = e->slots;
-    out->tags_used = c.tags_used; out->batches = e->batches; out->retries = c.retries;
+    out->tags_used = c.tags_used; out->batches = e->batches; out->retries = c.retries; out->compactions = e->compactions;
     return GUBER_OK;
 }
 extern "C" int64_t guber_size(guber_engine_t* e) {
@@ -744,6 +753,58 @@ extern "C" int guber_global_take(guber_engine_t* e, uint32_t role_mask, guber_gl
     out->burst = out->hits + 3 * (size_t)n; out->created_at = out->hits + 4 * (size_t)n;
     out->behavior = (const uint32_t*)(h + o_beh); out->algorithm = h + o_alg; out->role = h + o_role;
     return GUBER_OK;
+}
+
+// Rebuild the table keeping only live buckets.  Called explicitly (guber_compact) or automatically by
+// launch_batch when the directory is above its load limit.
+static int compact_table(guber_engine* e, int64_t now_ms) {
+    quiesce_all(e);
+    DevBuf<DirEntry> ndir; DevBuf<Bucket> nb; DevBuf<unsigned long long> kept;
+    int rc = ndir.ensure(e->slots) | nb.ensure(e->slots) | kept.ensure(1);
+    if (rc) { ndir.release(); nb.release(); kept.release(); return GUBER_E_NOMEM; }
+    hipError_t he;
+    if ((he = hipMemsetAsync(ndir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(nb.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(kept.p, 0, sizeof(unsigned long long), e->stream)) != hipSuccess) {
+        ndir.release(); nb.release(); kept.release();
+        return fail(GUBER_E_HIP, "compaction", he);
+    }
+    Table N = e->T;
+    N.dir = ndir.p; N.buckets = nb.p;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots, N, now_ms, kept.p);
+    unsigned long long k = 0;
+    if ((he = hipMemcpyAsync(&k, kept.p, sizeof(k), hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
+        ndir.release(); nb.release(); kept.release();
+        return fail(GUBER_E_HIP, "compaction", he);
+    }
+    kept.release();
+    // size = live buckets, tags_used = kept entries; pending GLOBAL records are per slot and cannot be carried over
+    DevCounters c;
+    HIPCHK(hipMemcpy(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    long long bsize = 0;
+    std::vector<BlockCounters> bc(e->n_bctr);
+    HIPCHK(hipMemcpy(bc.data(), e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost));
+    for (auto& x : bc) { bsize += x.size_delta; x.size_delta = 0; }
+    (void)bsize;
+    c.size = (long long)k; c.tags_used = k;
+    HIPCHK(hipMemcpy(e->ctr.p, &c, sizeof(c), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->bctr.p, bc.data(), e->n_bctr * sizeof(BlockCounters), hipMemcpyHostToDevice));
+    std::swap(e->dir.p, ndir.p); std::swap(e->buckets.p, nb.p);
+    std::swap(e->dir.cap, ndir.cap); std::swap(e->buckets.cap, nb.cap);
+    ndir.release(); nb.release();
+    e->T.dir = e->dir.p; e->T.buckets = e->buckets.p;
+    e->tags_upper = k;
+    e->compactions++;
+    return 0;
+}
+
+extern "C" int guber_compact(guber_engine_t* e, int64_t now_ms) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (e->T.gpend) return fail(GUBER_E_INVALID_ARG, "compaction with pending GLOBAL queues: call guber_global_take first");
+    return compact_table(e, now_ms);
 }
 
 extern "C" int guber_profile_enable(guber_engine_t* e, int enable) {

@@ -999,6 +999,29 @@ __global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, uint32
     T.gpend[slot] = z;
 }
 
+// Table compaction: re-insert every LIVE bucket (present and not expired at `now`) of the old table into a
+// fresh one.  Expired buckets are indistinguishable from absent ones for the algorithm (lrucache.go:115-119
+// removes them on access), removed buckets (K_ABSENT) only kept their tag for probing; both are dropped, which
+// frees their directory entries — the stand-in for the reference's bounded LRU (lrucache.go:98-100,138-149).
+__global__ __launch_bounds__(256) void k_compact(Table Old, uint64_t old_slots, Table New, int64_t now,
+                                                 unsigned long long* kept) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= old_slots) return;
+    const unsigned long long tag = Old.dir[s].tag;
+    if (tag == 0ull) return;
+    const Bucket b = Old.buckets[s];
+    if (rec_kind(b.rec) == K_ABSENT || rec_expired(b.rec, now)) return;
+    uint64_t pos = ((tag == 1ull ? 0ull : tag) >> 7) & New.mask;     // same home position rule as probe()
+    for (uint64_t step = 0; step <= New.mask; ++step, pos = (pos + 1) & New.mask) {
+        if (atomicCAS(&New.dir[pos].tag, 0ull, tag) == 0ull) {
+            New.dir[pos].meta = META_READY;
+            New.buckets[pos] = b;                                     // long keys keep their arena offset
+            atomicAdd(kept, 1ull);
+            return;
+        }
+    }
+}
+
 // wrap of the 31-bit batch epoch: forget every dense-id claim
 __global__ __launch_bounds__(256) void k_clear_claims(Table T, uint64_t slots) {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;

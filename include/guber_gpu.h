@@ -168,6 +168,7 @@ typedef struct guber_stats {
     uint64_t tags_used;       /* claimed directory entries (live + tombstoned keys) */
     uint64_t batches;
     uint64_t retries;         /* GUBER_ITEM_E_RETRY re-submissions */
+    uint64_t compactions;     /* table rebuilds (guber_compact or automatic) */
 } guber_stats_t;
 
 /* ---- lifecycle: NewWorkerPool / WorkerPool.Close (workers.go:125,157) -------- */
@@ -204,6 +205,13 @@ int64_t guber_size(guber_engine_t* e);
  *      needed sizes). */
 int guber_dump(guber_engine_t* e, guber_item_t* items, uint64_t cap, uint8_t* key_arena,
                uint64_t arena_cap, uint64_t* n_out, uint64_t* arena_out);
+
+/* ---- bounded cache: the reference keeps at most CacheSize items and evicts the least recently used
+ *      (lrucache.go:98-100,138-149).  The HBM table instead drops every bucket that is expired at now_ms
+ *      or was removed, by rebuilding itself (also done automatically when the directory passes 7/8 full).
+ *      Unexpired buckets are never evicted: if the live set itself outgrows the table, new keys get
+ *      GUBER_ITEM_E_TABLE_FULL (documented divergence). */
+int guber_compact(guber_engine_t* e, int64_t now_ms);
 
 int guber_stats(guber_engine_t* e, guber_stats_t* out);
 int guber_synchronize(guber_engine_t* e);

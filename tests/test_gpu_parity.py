@@ -318,3 +318,23 @@ def test_back_to_back_device_batches_match_oracle():
         support.assert_results_equal(got, want, f"step {s}")
     assert e.size() == o.size()
     e.close()
+
+
+def test_compaction_keeps_churning_key_sets_going():
+    """A key population that keeps changing: the directory would fill with expired / removed buckets; the
+    table rebuilds itself (guber_compact, also automatic) and results stay identical to the oracle."""
+    o, e = Oracle(cache_size=1 << 20), engine(cache_size=2048, max_batch=1024)     # 4096 slots, limit 3584 tags
+    now = streams.NOW0
+    for step in range(40):
+        keys = [f"churn_{step}_{i}" for i in range(400)] + [f"steady_{i}" for i in range(100)]
+        b = HostBatch(keys, 1, 5, [20] * 400 + [600_000] * 100, now, algorithm=[step % 2] * 400 + [0] * 100)
+        support.assert_results_equal(e.eval(b), o.eval(b), f"churn step {step}")
+        now += 1000
+    st = e.stats()
+    assert st["compactions"] >= 3 and st["tags_used"] <= 3584
+    e.compact(now)                                        # explicit: only the 100 steady buckets are live
+    assert e.size() == 100 and e.stats()["tags_used"] == 100
+    b = HostBatch([f"steady_{i}" for i in range(100)], 1, 5, 600_000, now)
+    support.assert_results_equal(e.eval(b), o.eval(b), "after compaction")
+    assert sorted(d["key"] for d in e.each()) == sorted(f"steady_{i}".encode() for i in range(100))
+    e.close()
