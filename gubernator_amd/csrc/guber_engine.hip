@@ -87,7 +87,6 @@ struct guber_engine {
     bool force_radix = false;
     bool careful = false;       // retry rounds run without speculative claims
     bool always_careful = false;
-    DevBuf<unsigned long long> dbg; double dbg_sum[4] = {0}; uint64_t dbg_n = 0;
     // GLOBAL pending queues
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
@@ -226,8 +225,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilerow = e->w_tilerow.p;
     e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
 
-    e->W.parity = 0; e->W.clear_n = 0; e->W.dbg = nullptr;
-    if (getenv("GUBER_PHASE_TIMING")) { if (e->dbg.ensure((size_t)FT_MAX_TILES * 8) == 0) e->W.dbg = e->dbg.p; }
+    e->W.parity = 0; e->W.clear_n = 0;
     *out = e;
     return GUBER_OK;
 }
@@ -236,13 +234,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->dbg_n) {   // wall_clock64 ticks at 100 MHz
-        const double per = 1.0 / (double)e->dbg_n * 0.01;
-        fprintf(stderr, "[guber phase timing] k_front per tile: resolve %.2f us, sort %.2f us, group %.2f us; kernel span %.2f us\n",
-                e->dbg_sum[0] * per, e->dbg_sum[1] * per, e->dbg_sum[2] * per,
-                e->dbg_sum[3] * 0.01 / ((double)e->dbg_n / 256.0));
-    }
-    e->dbg.release(); e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
+    e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
     e->d_take.release(); e->h_take.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
@@ -294,22 +286,9 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
         W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;
         W.clear_n = e->fast_prev_n;
-        W.dbg = e->dbg.p;
         e->span_begin(KT_FRONT);
         hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
-        if (e->dbg.p && e->fast_batches > 200 && e->fast_batches % 8 == 0) {   // debug only: sync + fold stamps
-            std::vector<unsigned long long> h(ftiles * 8);
-            (void)hipMemcpyAsync(h.data(), e->dbg.p, h.size() * 8, hipMemcpyDeviceToHost, e->stream);
-            (void)hipStreamSynchronize(e->stream);
-            unsigned long long t0 = ~0ull, t3 = 0;
-            for (uint32_t t = 0; t < ftiles; ++t) {
-                for (int k = 0; k < 3; ++k) e->dbg_sum[k] += (double)(h[t * 8 + k + 1] - h[t * 8 + k]);
-                t0 = std::min(t0, h[t * 8]); t3 = std::max(t3, h[t * 8 + 3]);
-            }
-            e->dbg_sum[3] += (double)(t3 - t0);
-            e->dbg_n += ftiles;
-        }
         e->span_begin(KT_EVAL2);
         hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
         e->span_end();
@@ -835,20 +814,3 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
 }
 
 extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }
-
-// debug only (not part of the ABI): copy a per-request work array of the last batch to the host.
-// which: 0 did, 1 slot, 2 rflags(u8 widened), 3 lrank(u16 widened), 4 seg_slot, 5 seg_flags(cur parity)
-extern "C" int gbdbg_read_work(guber_engine_t* e, int which, uint32_t* out, uint32_t n) {
-    if (!e || !out) return -1;
-    (void)hipStreamSynchronize(e->stream);
-    std::vector<uint8_t> b8(n); std::vector<uint16_t> b16(n);
-    switch (which) {
-    case 0: return hipMemcpy(out, e->W.did, n * 4, hipMemcpyDeviceToHost);
-    case 1: return hipMemcpy(out, e->W.slot, n * 4, hipMemcpyDeviceToHost);
-    case 2: { int r = hipMemcpy(b8.data(), e->W.rflags, n, hipMemcpyDeviceToHost); for (uint32_t i = 0; i < n; ++i) out[i] = b8[i]; return r; }
-    case 3: { int r = hipMemcpy(b16.data(), e->W.lrank, n * 2, hipMemcpyDeviceToHost); for (uint32_t i = 0; i < n; ++i) out[i] = b16[i]; return r; }
-    case 4: return hipMemcpy(out, e->W.seg_slot, n * 4, hipMemcpyDeviceToHost);
-    case 5: return hipMemcpy(out, e->W.seg_flags2 + (size_t)((e->fast_batches - 1) & 1u) * e->fast_cap, n * 4, hipMemcpyDeviceToHost);
-    }
-    return -1;
-}

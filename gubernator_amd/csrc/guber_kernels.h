@@ -112,7 +112,6 @@ struct Work {
     uint32_t* tilerow;                  // [cap][FT_MAX_TILES]: start inside the tile << 16 | members, per (segment, tile)
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
     uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
-    unsigned long long* dbg;            // optional [tiles][8] phase timestamps (GUBER_PHASE_TIMING=1)
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
@@ -582,8 +581,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     const bool valid = g < B.n;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
-#define GB_STAMP(k) do { if (W.dbg && tid == 0) W.dbg[tile * 8 + (k)] = wall_clock64(); } while (0)
-    GB_STAMP(0);
 
     // ---- phase A, stage 1: find (or insert) the directory entry; start fetching its bucket -----------
     uint32_t d = 0xffffffffu, slot = 0, errcode = 0, len = 0;
@@ -711,7 +708,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     }
     const int ins = block_sum(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
-    GB_STAMP(1);
 
     // ---- phase B: group the tile's FT segment ids through an LDS hash table ------------------------
     // Every distinct id gets one table entry (open addressing, CAS on the key); each wave ORs its lane
@@ -752,7 +748,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         if (eq_before == 0) gstart[gh] = atomicAdd(&galloc, eq_total);   // contiguous range for the group
     }
     __syncthreads();
-    GB_STAMP(2);
     // ---- phase C: publish groups -------------------------------------------------------------------
     if (valid) {
         const uint32_t start = gstart[gh];
@@ -765,8 +760,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
         }
     }
-    GB_STAMP(3);
-#undef GB_STAMP
 }
 
 __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
