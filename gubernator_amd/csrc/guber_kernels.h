@@ -615,6 +615,14 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
             const unsigned long long tag = h ? h : 1ull;
             uint64_t pos = (h >> 7) & T.mask;
+            // speculation: the key's bucket is at its home position for most resident keys (load <= 0.5), so the
+            // home bucket is requested together with the home directory entry — one round trip instead of two
+            const uint32_t home = (uint32_t)pos;
+            {
+                const Bucket* hb = &T.buckets[home];
+                const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
+                rec = hb->rec;
+            }
             for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
                 // plain 16-byte load: L1 may serve a line that is stale within this launch, which is safe here —
                 // a stale "empty" tag is corrected by the insert CAS, a stale meta by the claim CAS (only one
@@ -635,7 +643,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 if (t == tag) { slot = (uint32_t)pos; cand = true; meta = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
             }
             if (!cand && !errcode) errcode = 6;                      // probe bound exceeded: table full
-            if (cand) {
+            if (cand && slot != home) {
                 const Bucket* bk = &T.buckets[slot];
                 if (ready) { const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3]; }
                 rec = bk->rec;                                       // (zero for a bucket never used)
@@ -783,9 +791,14 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     // segment in earlier tiles, and the segment's total, from the bitmap and the per-tile counts; the
     // other members pick both up from LDS (eval workgroup == tile, FT == 256).
     __shared__ uint32_t sbase[FT], stotal[FT];
-    const uint32_t lr = i < B.n ? W.lrank[i] : 0u;
-    if (i < B.n && (lr & 0xffu) == 0u) {
-        const uint32_t d = W.did[i];
+    const bool live = i < B.n;
+    const uint32_t lr = live ? W.lrank[i] : 0u;
+    const uint32_t d = live ? W.did[i] : 0u;
+    // everything that depends only on (i, d) is requested now, so that these loads are in flight together
+    // with the heads' bitmap loads below instead of after the barrier
+    uint32_t sf = 0; uint8_t rf = 0; Req r; Rec s0;
+    if (live) { sf = seg_flags[d]; rf = W.rflags[i]; r = load_req(B, i); s0 = W.snap[d]; }
+    if (live && (lr & 0xffu) == 0u) {
         const uint32_t t = i / FT;
         const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip
         unsigned long long sw[FT_WORDS];
@@ -820,10 +833,7 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
     }
     __syncthreads();
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
-    if (i < B.n) {
-        const uint32_t d = W.did[i];
-        const uint32_t sf = seg_flags[d];
-        const uint8_t rf = W.rflags[i];
+    if (live) {
         if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);   // publish this batch's inserts
         if (sf & SEG_ERR) {
             store_err(R, i, (uint8_t)(sf >> 8));
@@ -834,8 +844,6 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             const uint32_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
             const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
-            const Req r = load_req(B, i);
-            Rec s0 = W.snap[d];
             const uint32_t slot = s0.pad;
             s0.pad = 0;
             // requests differing only in created_at still take the parallel path when created_at is never read

@@ -4,7 +4,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 128 --warmup 16 --no-cpu-baseline --profile-steps 0"
+# the default bench command (256 timed steps on 4 logical shards, then the 32-step profiling leg and the
+# 200-batch latency leg, both one batch at a time), minus the CPU leg
+ARGS="--no-cpu-baseline"
 for algo in token leaky; do
   rm -rf $R/gpurun_out/prof_$algo
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$algo -o $algo -- python $R/bench.py $ARGS --algo $algo > $R/gpurun_out/prof_$algo.log 2>&1; echo "stats $algo rc=$?"

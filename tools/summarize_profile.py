@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 outputs (gpurun_out/prof_<algo>/, gpurun_out/pmc_<CTR>/) into the committed
-profiles/: per-kernel duration statistics over the TIMED steps only (the residency pass of bench.py is
-excluded by taking the last N dispatches of each kernel), and HBM traffic per launch from the PMC
-passes.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
+profiles/: per-kernel duration statistics (a) over the last N_ISO dispatches = bench.py's profiling + latency
+legs, one batch in flight, the condition roofline.kernel_avg_us is measured under, and (b) over the N_TIMED
+dispatches before them = the timed region, where the logical shards' kernels overlap on the GPU; and HBM
+traffic per launch from the PMC passes.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
 (MI355X_MICROARCH.md, HBM section), so the corrected read volume is 2 x FETCH_SIZE (upper bound for our
 mix of 16-byte and 128-byte random reads; the raw figure is kept next to it).
-usage: summarize_profile.py <tag> <timed_steps_stats> <timed_steps_pmc>"""
+usage: summarize_profile.py <tag> <n_iso> <n_pmc> [n_timed]"""
 import csv, json, os, sys, collections, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, n_stats, n_pmc = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+n_timed = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 out = {"tag": tag, "kernels": {}, "traffic": {}}
 lines = [f"# rocprofv3 summary {tag} (bench.py, 10M keys, Zipf-1.1, batch 65536, 1xMI355X)", ""]
 for algo in ("token", "leaky"):
@@ -20,7 +22,7 @@ for algo in ("token", "leaky"):
         name = row["Kernel_Name"].split("(")[0]
         if "guber::" in name:
             per[name].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    lines += [f"## {algo}: kernel durations over the last {n_stats} dispatches (timed steps)", "",
+    lines += [f"## {algo}: kernel durations over the last {n_stats} dispatches (one batch in flight)", "",
               "| kernel | launches | avg us | min us | p50 us | max us |", "|---|---|---|---|---|---|"]
     out["kernels"][algo] = {}
     for name, d in per.items():
@@ -29,6 +31,18 @@ for algo in ("token", "leaky"):
         out["kernels"][algo][name.replace("guber::", "")] = st
         lines.append(f"| {name} | {st['launches']} | {st['avg_us']:.2f} | {st['min_us']:.2f} | {st['p50_us']:.2f} | {st['max_us']:.2f} |")
     lines.append("")
+    if n_timed:
+        lines += [f"## {algo}: the {n_timed} dispatches before those (timed region, logical shards overlapping)", "",
+                  "| kernel | launches | avg us | min us | p50 us | max us |", "|---|---|---|---|---|---|"]
+        out["kernels"][algo + "_timed_region"] = {}
+        for name, d in per.items():
+            d = d[-(n_stats + n_timed):-n_stats]
+            if not d:
+                continue
+            st = dict(launches=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, p50_us=statistics.median(d) / 1e3, max_us=max(d) / 1e3)
+            out["kernels"][algo + "_timed_region"][name.replace("guber::", "")] = st
+            lines.append(f"| {name} | {st['launches']} | {st['avg_us']:.2f} | {st['min_us']:.2f} | {st['p50_us']:.2f} | {st['max_us']:.2f} |")
+        lines.append("")
 pm = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     path = os.path.join(ROOT, "gpurun_out", f"pmc_{ctr}", "pmc_counter_collection.csv")
