@@ -15,7 +15,8 @@ from .abi import (GuberBatch, GuberConfig, GuberItem, GuberResult, GuberStats, H
                   item_dict, make_item)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libguber_hip.so")
+# GUBER_HIP_LIB selects another build of the same library (the phase-timing measurement build, `make timing`)
+LIB_PATH = os.environ.get("GUBER_HIP_LIB") or os.path.join(_HERE, "libguber_hip.so")
 
 # every symbol include/guber_gpu.h declares
 ABI_SYMBOLS = [

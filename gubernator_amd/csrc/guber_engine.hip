@@ -88,6 +88,9 @@ struct guber_engine {
     bool careful = false;       // retry rounds run without speculative claims
     bool always_careful = false;
     // GLOBAL pending queues
+#ifdef GUBER_PHASE_TIMING
+    DevBuf<unsigned long long> dbg; double dbg_avg[2][8] = {{0}}, dbg_max[2][8] = {{0}}; uint64_t dbg_n = 0;
+#endif
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
@@ -226,6 +229,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
 
     e->W.parity = 0; e->W.clear_n = 0;
+#ifdef GUBER_PHASE_TIMING
+    (void)e->dbg.ensure(4096);
+#endif
     *out = e;
     return GUBER_OK;
 }
@@ -234,6 +240,19 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+#ifdef GUBER_PHASE_TIMING
+    if (e->dbg_n) {
+        static const char* names[2][8] = {{"entry", "stage 1 done (probe)", "claims done", "verify+snapshot done", "grouping done", "end", "key_off loaded", "key hashed"},
+                                          {"entry", "loads issued+prepass", "after barrier", "eval done", "end", "", "", ""}};
+        for (int kern = 0; kern < 2; ++kern) {
+            fprintf(stderr, "[phase timing] %s over %llu full batches (us since the first workgroup's entry: avg over workgroups / last workgroup)\n",
+                    kern ? "k_eval2" : "k_front", (unsigned long long)e->dbg_n);
+            for (int k = 0; k < (kern ? 5 : 8); ++k)
+                fprintf(stderr, "    %-24s %7.2f / %7.2f\n", names[kern][k], e->dbg_avg[kern][k] / e->dbg_n, e->dbg_max[kern][k] / e->dbg_n);
+        }
+    }
+    e->dbg.release();
+#endif
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
     e->d_take.release(); e->h_take.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
@@ -286,6 +305,9 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
         W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;
         W.clear_n = e->fast_prev_n;
+#ifdef GUBER_PHASE_TIMING
+        W.dbg = e->dbg.p;
+#endif
         e->span_begin(KT_FRONT);
         hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
@@ -293,6 +315,25 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
         e->span_end();
         HIPCHK(hipGetLastError());
+#ifdef GUBER_PHASE_TIMING
+        if (n == e->fast_cap) {   // fold the stamps of full batches: avg and max over workgroups, relative to the first workgroup's entry
+            static unsigned long long hb[4096];
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipMemcpy(hb, e->dbg.p, sizeof(hb), hipMemcpyDeviceToHost);
+            for (int kern = 0; kern < 2; ++kern) {
+                const int ns = kern ? 5 : 8;
+                const unsigned long long* b = hb + kern * 2048;
+                unsigned long long t0 = ~0ull;
+                for (uint32_t t = 0; t < ftiles; ++t) t0 = b[t * 8] < t0 ? b[t * 8] : t0;
+                for (int k = 0; k < ns; ++k) {
+                    double sum = 0, mx = 0;
+                    for (uint32_t t = 0; t < ftiles; ++t) { const double v = (double)(b[t * 8 + k] - t0) * 0.01; sum += v; mx = v > mx ? v : mx; }
+                    e->dbg_avg[kern][k] += sum / ftiles; e->dbg_max[kern][k] += mx;
+                }
+            }
+            e->dbg_n++;
+        }
+#endif
         e->fast_batches++;
         e->fast_prev_n = n;
         e->batches++;

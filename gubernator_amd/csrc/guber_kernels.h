@@ -93,7 +93,19 @@ enum : uint8_t { RF_INSERTED = 1, RF_NEED_VERIFY = 2, RF_ERR = 4 };
 // segment flags
 enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits 8..15 */, SEG_CREATED_DIFFERS = 8 };
 
+#ifdef GUBER_PHASE_TIMING   // measurement build only (make timing): per-workgroup phase timestamps
+#define GB_STAMP(k) do { if (threadIdx.x == 0) W.dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define GB_STAMP2(k) do { if (threadIdx.x == 0) W.dbg[2048 + blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define GB_STAMPW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GB_STAMP(k); } while (0)
+#else
+#define GB_STAMP(k) do {} while (0)
+#define GB_STAMP2(k) do {} while (0)
+#define GB_STAMPW(k) do {} while (0)
+#endif
 struct Work {
+#ifdef GUBER_PHASE_TIMING
+    unsigned long long* dbg;
+#endif
     uint32_t *slot, *did; uint8_t* rflags;
     uint32_t *keyA, *valA, *keyB, *valB;
     uint32_t *pos, *order, *sdid;
@@ -246,6 +258,24 @@ __device__ __forceinline__ int wave_sum(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
+// load, store and atomic of the wave (s_waitcnt vmcnt(0)); k_front / k_eval2 exchange data between threads
+// through LDS only, so their global traffic may stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ int block_sum_lds(int v, int* red) {   // block_sum with LDS-only barriers
+    v = wave_sum(v);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    lds_barrier();
+    if (lane == 0) red[wave] = v;
+    lds_barrier();
+    int t = 0;
+    if (threadIdx.x == 0) for (uint32_t w = 0; w < nw; ++w) t += red[w];
+    return t;
 }
 // Sum v over the workgroup (<= 16 waves); result valid in thread 0.  `red` = 16 ints of LDS.
 __device__ __forceinline__ int block_sum(int v, int* red) {
@@ -509,6 +539,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
             }
         }
     }
+    GB_STAMP2(3);
     const int t_over = block_sum(c_over, red), t_hit = block_sum(c_hit, red), t_miss = block_sum(c_miss, red),
               t_size = block_sum(c_size, red);
     if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
@@ -516,6 +547,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
         bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
         bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
     }
+    GB_STAMP2(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -582,6 +614,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
 
+    GB_STAMP(0);
     // ---- phase A, stage 1: find (or insert) the directory entry; start fetching its bucket -----------
     uint32_t d = 0xffffffffu, slot = 0, errcode = 0, len = 0;
     int inserted = 0;
@@ -596,6 +629,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         key = B.key_bytes + off;
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
+        GB_STAMPW(6);
         if (!errcode && W.careful) {
             // retry round: verify the stored key BEFORE claiming (no speculation, no dedup)
             uint32_t cslot = 0;
@@ -615,20 +649,23 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
             const unsigned long long tag = h ? h : 1ull;
             uint64_t pos = (h >> 7) & T.mask;
+            GB_STAMPW(7);
             // speculation: the key's bucket is at its home position for most resident keys (load <= 0.5), so the
-            // home bucket is requested together with the home directory entry — one round trip instead of two
+            // home bucket is requested together with the home directory entry — one round trip instead of two.
+            // Plain loads: L1 may serve a line that is stale within this launch, which is safe here — a stale
+            // "empty" tag is corrected by the insert CAS, a stale meta by the claim CAS (only one leader per
+            // workgroup and key claims), READY never changes during k_front — and it keeps the thousands of
+            // re-reads of a hot key's entry out of L2 / the memory-side atomics' way.
             const uint32_t home = (uint32_t)pos;
+            const ulonglong2 de0 = *(const ulonglong2*)&T.dir[home];
             {
                 const Bucket* hb = &T.buckets[home];
                 const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
                 rec = hb->rec;
             }
             for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
-                // plain 16-byte load: L1 may serve a line that is stale within this launch, which is safe here —
-                // a stale "empty" tag is corrected by the insert CAS, a stale meta by the claim CAS (only one
-                // leader per workgroup and key claims), READY never changes during k_front — and it keeps the
-                // thousands of re-reads of a hot key's entry out of L2 / the memory-side atomics' way.
-                const ulonglong2 de = *(const ulonglong2*)&T.dir[pos];
+                ulonglong2 de = de0;
+                if (step) de = *(const ulonglong2*)&T.dir[pos];
                 unsigned long long t = de.x, m = de.y;
                 if (t == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
@@ -653,17 +690,19 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     // ---- stage 2: one claim per (workgroup, slot).  Threads holding the same slot elect a leader
     // through an LDS table; only leaders touch the entry's meta word (atomics on one address serialise
     // at ~12 ns each, and a hot key shows up thousands of times in a batch).
+    GB_STAMP(1);
     const bool fast = cand && !W.careful;
     const uint32_t hidx = (slot * 0x9E3779B1u) >> 23;                // 9 bits
     skey[tid] = fast ? slot : 0xffffffffu;
     if (fast) ltab[hidx] = tid;
-    __syncthreads();
+    lds_barrier();
     uint32_t lead = tid;
     if (fast) { const uint32_t l = ltab[hidx]; if (skey[l] == slot) lead = l; }
     if (fast && lead == tid) { d = claim_segment(&T.dir[slot].meta, meta, W.epoch, g, claimed); sd[tid] = d; }
-    __syncthreads();
+    lds_barrier();
     if (fast && lead != tid) d = sd[lead];
-    __syncthreads();
+    lds_barrier();
+    GB_STAMP(2);
 
     // ---- stage 3: verify, flag, snapshot -----------------------------------------------------------
     if (valid) {
@@ -714,8 +753,9 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         W.did[g] = d; W.rflags[g] = rf;
         if (inserted) W.slot[g] = slot;
     }
-    const int ins = block_sum(inserted, red);
+    const int ins = block_sum_lds(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+    GB_STAMP(3);
 
     // ---- phase B: group the tile's FT segment ids through an LDS hash table ------------------------
     // Every distinct id gets one table entry (open addressing, CAS on the key); each wave ORs its lane
@@ -729,7 +769,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
     }
     if (tid == 0) galloc = 0;
-    __syncthreads();
+    lds_barrier();
     uint32_t gh = 0;
     if (valid) {
         gh = (d * 0x9E3779B1u) >> (32 - GT_BITS);
@@ -740,7 +780,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         }
         atomicOr(&gbits[wave][gh], 1ull << lane);
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t eq_before = 0, eq_total = 0, head_tid = tid;
     if (valid) {
         bool found_head = false;
@@ -755,7 +795,8 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         }
         if (eq_before == 0) gstart[gh] = atomicAdd(&galloc, eq_total);   // contiguous range for the group
     }
-    __syncthreads();
+    lds_barrier();
+    GB_STAMP(4);
     // ---- phase C: publish groups -------------------------------------------------------------------
     if (valid) {
         const uint32_t start = gstart[gh];
@@ -768,13 +809,18 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
         }
     }
+    GB_STAMP(5);
 }
 
-__global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
+#ifndef GUBER_EVAL2_BLOCKS
+#define GUBER_EVAL2_BLOCKS 1
+#endif
+__global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
     __shared__ int red[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
+    GB_STAMP2(0);
     {   // clear, for the next batch, the entries of the other copy that the previous batch used
         uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
         uint4* om = (uint4*)(W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS);
@@ -831,7 +877,9 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
         }
         sbase[threadIdx.x] = base; stotal[threadIdx.x] = total;
     }
-    __syncthreads();
+    GB_STAMP2(1);
+    lds_barrier();
+    GB_STAMP2(2);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (live) {
         if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);   // publish this batch's inserts
@@ -887,8 +935,8 @@ __global__ __launch_bounds__(256) void k_eval2(Table T, BatchView B, ResultView 
             }
         }
     }
-    const int t_over = block_sum(c_over, red), t_hit = block_sum(c_hit, red), t_miss = block_sum(c_miss, red),
-              t_size = block_sum(c_size, red);
+    const int t_over = block_sum_lds(c_over, red), t_hit = block_sum_lds(c_hit, red), t_miss = block_sum_lds(c_miss, red),
+              t_size = block_sum_lds(c_size, red);
     if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
         BlockCounters* bc = &T.bctr[blockIdx.x];
         bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;

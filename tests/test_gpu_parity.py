@@ -72,8 +72,10 @@ def test_edge_cases_empty_ragged_long_keys(flags):
     # empty batch
     res = e.eval(HostBatch([], [], [], [], now))
     assert res.n == 0
-    # ragged key lengths 1..300 (inline <= 62 bytes, arena beyond), duplicates of long keys
-    keys = [(b"k" * L) for L in range(1, 301)] + [b"k" * 100, b"k" * 299, b"q" * 63, b"q" * 62]
+    # ragged key lengths 1..300 (inline <= 62 bytes, arena beyond), duplicates of long keys, keys that
+    # differ only in the last inline word / byte
+    keys = [(b"k" * L) for L in range(1, 301)] + [b"k" * 100, b"k" * 299, b"q" * 63, b"q" * 62,
+                                                 b"q" * 45, b"q" * 46, b"q" * 47, b"q" * 48, b"q" * 45 + b"r", b"q" * 40 + b"r" + b"q" * 5]
     b = HostBatch(keys, 1, 3, 10_000, now)
     support.assert_results_equal(e.eval(b), o.eval(b), "ragged")
     support.assert_results_equal(e.eval(b), o.eval(b), "ragged again")
