@@ -208,6 +208,9 @@ extern "C" const char* guber_strerror(int code) {
     case GUBER_E_NOMEM: return "out of memory / buffer too small";
     case GUBER_E_KEY_TOO_LONG: return "key too long";
     case GUBER_E_NOT_FOUND: return "not found";
+    case -20: return "malformed protobuf payload";                                     // GUBER_E_WIRE_MALFORMED
+    case -21: return "Requests.RateLimits list too large; max size is '1000'";         // GUBER_E_WIRE_TOO_LARGE, gubernator.go:191
+    case -22: return "wire batch full";                                                // GUBER_E_WIRE_FULL
     }
     return "unknown error";
 }

@@ -1,0 +1,334 @@
+// wire.cpp — protobuf wire format <-> SoA batch transcoder (include/guber_wire.h).  Host code, no device work
+// except guber_wire_eval (which is guber_eval_batch on the batch's own arrays).
+//
+// Reference behaviour restated here (not its code — the reference uses generated protobuf-go structs):
+//   gubernator.proto:137-203, peers.proto:36-49   message layouts
+//   gubernator.go:189-220                          batch cap, per-item validation, CreatedAt default
+//   client.go:39-41                                key = name + "_" + unique_key
+//   gubernator.go:250-255, workers.go:317-321      error texts of the evaluation
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/guber_wire.h"
+
+namespace {
+
+struct Span { const uint8_t* p = nullptr; uint32_t n = 0; };
+struct ReqFields {
+    Span name, unique_key;
+    int64_t hits = 0, limit = 0, duration = 0, burst = 0, created_at = 0;
+    int64_t algorithm = 0, behavior = 0;
+};
+
+inline bool get_varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
+    uint64_t r = 0;
+    for (int shift = 0; shift < 70; shift += 7) {
+        if (p >= end) return false;
+        const uint8_t b = *p++;
+        if (shift == 63 && (b & 0xfe)) return false;            // more than 64 bits
+        r |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) { v = r; return true; }
+    }
+    return false;                                              // longer than 10 bytes
+}
+inline bool skip_field(const uint8_t*& p, const uint8_t* end, uint32_t wt) {
+    uint64_t v;
+    switch (wt) {
+    case 0: return get_varint(p, end, v);
+    case 1: if (end - p < 8) return false; p += 8; return true;
+    case 2: if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return false; p += v; return true;
+    case 5: if (end - p < 4) return false; p += 4; return true;
+    default: return false;                                     // groups (3/4) do not occur in these messages
+    }
+}
+// proto3 string fields must be valid UTF-8 (the Go runtime rejects the message otherwise)
+bool valid_utf8(const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n) {
+        if (i + 8 <= n) {                                        // ASCII fast path, 8 bytes at a time
+            uint64_t w;
+            memcpy(&w, s + i, 8);
+            if (!(w & 0x8080808080808080ull)) { i += 8; continue; }
+        }
+        const uint8_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        uint32_t need, cp;
+        if ((c & 0xe0) == 0xc0) { need = 1; cp = c & 0x1f; }
+        else if ((c & 0xf0) == 0xe0) { need = 2; cp = c & 0x0f; }
+        else if ((c & 0xf8) == 0xf0) { need = 3; cp = c & 0x07; }
+        else return false;
+        if (i + need >= n) return false;                        // truncated sequence
+        for (uint32_t k = 1; k <= need; ++k) {
+            const uint8_t cc = s[i + k];
+            if ((cc & 0xc0) != 0x80) return false;
+            cp = (cp << 6) | (cc & 0x3f);
+        }
+        if ((need == 1 && cp < 0x80) || (need == 2 && cp < 0x800) || (need == 3 && cp < 0x10000)) return false;   // overlong
+        if (cp > 0x10ffff || (cp >= 0xd800 && cp <= 0xdfff)) return false;
+        i += need + 1;
+    }
+    return true;
+}
+bool parse_req(const uint8_t* p, const uint8_t* end, ReqFields& f) {
+    while (p < end) {
+        uint64_t tag, v;
+        if (!get_varint(p, end, tag)) return false;
+        const uint32_t wt = (uint32_t)(tag & 7);
+        const uint64_t field = tag >> 3;
+        if (field == 0) return false;
+        if ((field == 1 || field == 2) && wt == 2) {
+            if (!get_varint(p, end, v) || (uint64_t)(end - p) < v || v > 0xffffffffull) return false;
+            if (!valid_utf8(p, (uint32_t)v)) return false;
+            Span& s = field == 1 ? f.name : f.unique_key;
+            s.p = p; s.n = (uint32_t)v;
+            p += v;
+        } else if (wt == 0 && (field == 3 || field == 4 || field == 5 || field == 6 || field == 7 || field == 8 || field == 10)) {
+            if (!get_varint(p, end, v)) return false;
+            switch (field) {
+            case 3: f.hits = (int64_t)v; break;
+            case 4: f.limit = (int64_t)v; break;
+            case 5: f.duration = (int64_t)v; break;
+            case 6: f.algorithm = (int64_t)(int32_t)v; break;      // enums are int32 on the wire (sign-extended varint)
+            case 7: f.behavior = (int64_t)(int32_t)v; break;
+            case 8: f.burst = (int64_t)v; break;
+            case 10: f.created_at = (int64_t)v; break;
+            }
+        } else if (!skip_field(p, end, wt)) {
+            return false;
+        }
+    }
+    return true;
+}
+
+inline size_t varint_size(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+inline uint8_t* put_varint(uint8_t* p, uint64_t v) {
+    while (v >= 0x80) { *p++ = (uint8_t)(v | 0x80); v >>= 7; }
+    *p++ = (uint8_t)v;
+    return p;
+}
+
+}  // namespace
+
+struct guber_wire_batch {
+    uint32_t cap_items = 0, cap_keys = 0, flags = 0, n = 0, key_used = 0;
+    int64_t now_ms = 0;
+    bool any_greg = false;
+    void* block = nullptr;                // one allocation for every array
+    uint8_t* key_bytes = nullptr; uint32_t* key_off = nullptr;
+    int64_t *hits = nullptr, *limit = nullptr, *duration = nullptr, *burst = nullptr, *created_at = nullptr;
+    int64_t *greg_expire = nullptr, *greg_duration = nullptr;
+    uint32_t* behavior = nullptr; int32_t* algo_raw = nullptr;
+    uint8_t *algorithm = nullptr, *is_owner = nullptr, *pre_err = nullptr;
+    int64_t *r_limit = nullptr, *r_remaining = nullptr, *r_reset = nullptr;
+    uint8_t *r_status = nullptr, *r_err = nullptr;
+    guber_batch_t view{};
+    guber_result_t res{};
+    std::vector<ReqFields> scratch;       // items of the payload being decoded
+};
+
+extern "C" int guber_wire_batch_create(uint32_t max_items, uint32_t max_key_bytes, uint32_t flags, guber_wire_batch_t** out) {
+    if (!out || max_items == 0 || max_key_bytes == 0) return GUBER_E_INVALID_ARG;
+    *out = nullptr;
+    guber_wire_batch* b = new (std::nothrow) guber_wire_batch();
+    if (!b) return GUBER_E_NOMEM;
+    b->cap_items = max_items; b->cap_keys = max_key_bytes; b->flags = flags;
+    const size_t M = max_items;
+    // layout: 10 x int64[M] | u32 key_off[M+1], behavior[M] | i32 algo_raw[M] | 5 x u8[M] | key bytes (+16 readable past the end)
+    const size_t bytes = 10 * 8 * M + 4 * (M + 1) + 4 * M + 4 * M + 5 * M + 64 + (size_t)max_key_bytes + 16;
+    b->block = (flags & GUBER_WIRE_PINNED) ? guber_alloc_pinned(bytes) : calloc(1, bytes);
+    if (!b->block) { delete b; return (flags & GUBER_WIRE_PINNED) ? GUBER_E_NO_DEVICE : GUBER_E_NOMEM; }
+    memset(b->block, 0, bytes);
+    uint8_t* p = (uint8_t*)b->block;
+    int64_t** i64s[] = {&b->hits, &b->limit, &b->duration, &b->burst, &b->created_at, &b->greg_expire, &b->greg_duration,
+                        &b->r_limit, &b->r_remaining, &b->r_reset};
+    for (auto f : i64s) { *f = (int64_t*)p; p += 8 * M; }
+    b->key_off = (uint32_t*)p; p += 4 * (M + 1);
+    b->behavior = (uint32_t*)p; p += 4 * M;
+    b->algo_raw = (int32_t*)p; p += 4 * M;
+    uint8_t** u8s[] = {&b->algorithm, &b->is_owner, &b->pre_err, &b->r_status, &b->r_err};
+    for (auto f : u8s) { *f = p; p += M; }
+    p = (uint8_t*)(((uintptr_t)p + 63) & ~(uintptr_t)63);
+    b->key_bytes = p;
+    try { b->scratch.reserve(1024); } catch (...) { guber_wire_batch_destroy(b); return GUBER_E_NOMEM; }
+    guber_wire_batch_reset(b, 0);
+    *out = b;
+    return GUBER_OK;
+}
+
+extern "C" void guber_wire_batch_destroy(guber_wire_batch_t* b) {
+    if (!b) return;
+    if (b->block) { if (b->flags & GUBER_WIRE_PINNED) guber_free_pinned(b->block); else free(b->block); }
+    delete b;
+}
+
+extern "C" void guber_wire_batch_reset(guber_wire_batch_t* b, int64_t now_ms) {
+    if (!b) return;
+    b->n = 0; b->key_used = 0; b->now_ms = now_ms; b->any_greg = false;
+    b->key_off[0] = 0;
+}
+
+extern "C" uint32_t guber_wire_batch_size(const guber_wire_batch_t* b) { return b ? b->n : 0; }
+
+extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* msg, size_t len, uint32_t max_per_rpc,
+                                          uint8_t is_owner, uint32_t* first, uint32_t* count) {
+    if (!b || (!msg && len) || !first || !count) return GUBER_E_INVALID_ARG;
+    *first = b->n; *count = 0;
+    // pass 1: parse every item (spans point into msg), nothing is appended before the payload is known to be
+    // well-formed and to fit
+    std::vector<ReqFields>& items = b->scratch;
+    items.clear();
+    const uint8_t* p = msg; const uint8_t* end = msg + len;
+    uint64_t key_bytes = 0;
+    try {
+        while (p < end) {
+            uint64_t tag, v;
+            if (!get_varint(p, end, tag)) return GUBER_E_WIRE_MALFORMED;
+            const uint32_t wt = (uint32_t)(tag & 7);
+            if ((tag >> 3) == 0) return GUBER_E_WIRE_MALFORMED;
+            if ((tag >> 3) == 1 && wt == 2) {
+                if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return GUBER_E_WIRE_MALFORMED;
+                ReqFields f;
+                if (!parse_req(p, p + v, f)) return GUBER_E_WIRE_MALFORMED;
+                p += v;
+                if (f.unique_key.n && f.name.n) key_bytes += (uint64_t)f.name.n + 1 + f.unique_key.n;
+                items.push_back(f);
+            } else if (!skip_field(p, end, wt)) {
+                return GUBER_E_WIRE_MALFORMED;
+            }
+        }
+    } catch (...) { return GUBER_E_NOMEM; }
+    if (max_per_rpc && items.size() > max_per_rpc) { *count = (uint32_t)items.size(); return GUBER_E_WIRE_TOO_LARGE; }
+    if (items.size() > b->cap_items - b->n || key_bytes > (uint64_t)(b->cap_keys - b->key_used)) return GUBER_E_WIRE_FULL;
+    // pass 2: append
+    uint32_t i = b->n;
+    for (const ReqFields& f : items) {
+        uint8_t pre = GUBER_WIRE_PRE_OK;
+        if (f.unique_key.n == 0) pre = GUBER_WIRE_PRE_EMPTY_UNIQUE_KEY;          // gubernator.go:208-212
+        else if (f.name.n == 0) pre = GUBER_WIRE_PRE_EMPTY_NAME;                 // gubernator.go:213-217
+        b->pre_err[i] = pre;
+        if (pre == GUBER_WIRE_PRE_OK) {                                          // client.go:39-41
+            uint8_t* k = b->key_bytes + b->key_used;
+            memcpy(k, f.name.p, f.name.n); k[f.name.n] = '_'; memcpy(k + f.name.n + 1, f.unique_key.p, f.unique_key.n);
+            b->key_used += f.name.n + 1 + f.unique_key.n;
+        }
+        b->key_off[i + 1] = b->key_used;
+        b->hits[i] = f.hits; b->limit[i] = f.limit; b->duration[i] = f.duration; b->burst[i] = f.burst;
+        b->created_at[i] = f.created_at ? f.created_at : b->now_ms;              // gubernator.go:218-220
+        b->algo_raw[i] = (int32_t)f.algorithm;
+        b->algorithm[i] = (f.algorithm == 0 || f.algorithm == 1) ? (uint8_t)f.algorithm : 255;
+        b->behavior[i] = (uint32_t)f.behavior;
+        b->is_owner[i] = is_owner ? 1 : 0;
+        b->greg_expire[i] = 0; b->greg_duration[i] = 0;
+        if (pre == GUBER_WIRE_PRE_OK && (b->behavior[i] & GUBER_BEHAVIOR_DURATION_IS_GREGORIAN)) {   // interval.go:84-148 at clock.Now()
+            b->any_greg = true;
+            int64_t e = 0, d = 0;
+            int rc = guber_gregorian_expiration(b->now_ms * 1000000, f.duration, &e);
+            if (rc == 0) rc = guber_gregorian_duration(b->now_ms * 1000000, f.duration, &d);
+            b->greg_expire[i] = e; b->greg_duration[i] = rc ? rc : d;
+        }
+        ++i;
+    }
+    *count = (uint32_t)items.size();
+    b->n = i;
+    memset(b->key_bytes + b->key_used, 0, 16);
+    return GUBER_OK;
+}
+
+extern "C" const guber_batch_t* guber_wire_batch_view(guber_wire_batch_t* b) {
+    if (!b) return nullptr;
+    guber_batch_t& v = b->view;
+    v = guber_batch_t{};
+    v.n = b->n; v.key_bytes = b->key_bytes; v.key_off = b->key_off; v.hits = b->hits; v.limit = b->limit;
+    v.duration = b->duration; v.burst = b->burst; v.created_at = b->created_at; v.algorithm = b->algorithm;
+    v.behavior = b->behavior; v.is_owner = b->is_owner; v.now_ms = b->now_ms;
+    if (b->any_greg) { v.greg_expire = b->greg_expire; v.greg_duration = b->greg_duration; }
+    return &v;
+}
+
+extern "C" guber_result_t* guber_wire_batch_result(guber_wire_batch_t* b) {
+    if (!b) return nullptr;
+    guber_result_t& r = b->res;
+    r.status = b->r_status; r.limit = b->r_limit; r.remaining = b->r_remaining; r.reset_time = b->r_reset; r.err = b->r_err;
+    return &r;
+}
+
+extern "C" const uint8_t* guber_wire_batch_pre_errors(const guber_wire_batch_t* b) { return b ? b->pre_err : nullptr; }
+
+extern "C" int guber_wire_eval(guber_engine_t* e, guber_wire_batch_t* b) {
+    if (!e || !b) return GUBER_E_INVALID_ARG;
+    return guber_eval_batch(e, guber_wire_batch_view(b), guber_wire_batch_result(b));
+}
+
+namespace {
+// error text of item i ("" = none)
+std::string item_error(const guber_wire_batch* b, uint32_t i, int wrap) {
+    if (b->pre_err[i] == GUBER_WIRE_PRE_EMPTY_UNIQUE_KEY) return "field 'unique_key' cannot be empty";
+    if (b->pre_err[i] == GUBER_WIRE_PRE_EMPTY_NAME) return "field 'namespace' cannot be empty";
+    const uint8_t code = b->r_err[i];
+    if (code == GUBER_ITEM_OK) return std::string();
+    char buf[256];
+    if (code == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, sizeof buf, guber_item_strerror(code), (int)b->algo_raw[i]);   // workers.go:318
+    else snprintf(buf, sizeof buf, "%s", guber_item_strerror(code));
+    if (!wrap) return buf;
+    std::string s = "Error while apply rate limit for '";                                                                     // gubernator.go:250-255
+    s.append((const char*)b->key_bytes + b->key_off[i], b->key_off[i + 1] - b->key_off[i]);
+    s += "': "; s += buf;
+    return s;
+}
+struct RespFields { uint64_t status, limit, remaining, reset; };
+inline size_t resp_body_size(const RespFields& f, size_t err_len) {
+    size_t n = 0;
+    if (f.status) n += 1 + varint_size(f.status);
+    if (f.limit) n += 1 + varint_size(f.limit);
+    if (f.remaining) n += 1 + varint_size(f.remaining);
+    if (f.reset) n += 1 + varint_size(f.reset);
+    if (err_len) n += 1 + varint_size(err_len) + err_len;
+    return n;
+}
+inline RespFields resp_fields(const guber_wire_batch* b, uint32_t i, bool has_error) {
+    if (has_error) return RespFields{0, 0, 0, 0};              // the reference answers {Error: ...} only
+    return RespFields{(uint64_t)b->r_status[i], (uint64_t)b->r_limit[i], (uint64_t)b->r_remaining[i], (uint64_t)b->r_reset[i]};
+}
+}  // namespace
+
+extern "C" size_t guber_wire_encode_bound(const guber_wire_batch_t* b, uint32_t first, uint32_t count) {
+    if (!b || first > b->n || count > b->n - first) return 0;
+    // tag + length (<= 3) + 4 varint fields (<= 11 each) + error field: wrapper text + key + message (<= 256)
+    size_t bound = 0;
+    for (uint32_t i = first; i < first + count; ++i) bound += 4 + 44 + 3 + 40 + 256 + (b->key_off[i + 1] - b->key_off[i]);
+    return bound;
+}
+
+extern "C" int guber_wire_encode_responses(const guber_wire_batch_t* b, uint32_t first, uint32_t count, int wrap_errors,
+                                           uint8_t* out, size_t cap, size_t* len) {
+    if (!b || !len || (!out && cap) || first > b->n || count > b->n - first) return GUBER_E_INVALID_ARG;
+    size_t used = 0;
+    bool overflow = false;
+    for (uint32_t i = first; i < first + count; ++i) {
+        std::string err;
+        if (b->pre_err[i] != GUBER_WIRE_PRE_OK || b->r_err[i] != GUBER_ITEM_OK) err = item_error(b, i, wrap_errors);
+        const RespFields f = resp_fields(b, i, !err.empty());
+        const size_t body = resp_body_size(f, err.size());
+        const size_t total = 1 + varint_size(body) + body;
+        if (!overflow && used + total <= cap) {
+            uint8_t* p = out + used;
+            *p++ = 0x0a;                                        // field 1, LEN
+            p = put_varint(p, body);
+            if (f.status) { *p++ = 0x08; p = put_varint(p, f.status); }
+            if (f.limit) { *p++ = 0x10; p = put_varint(p, f.limit); }
+            if (f.remaining) { *p++ = 0x18; p = put_varint(p, f.remaining); }
+            if (f.reset) { *p++ = 0x20; p = put_varint(p, f.reset); }
+            if (!err.empty()) { *p++ = 0x2a; p = put_varint(p, err.size()); memcpy(p, err.data(), err.size()); p += err.size(); }
+        } else {
+            overflow = true;
+        }
+        used += total;
+    }
+    *len = used;
+    return overflow ? GUBER_E_NOMEM : GUBER_OK;
+}

@@ -1,0 +1,122 @@
+"""ctypes binding of include/guber_wire.h: serialized GetRateLimitsReq / GetPeerRateLimitsReq payloads ->
+one SoA device batch -> serialized responses (the step immediately before / after the hot path,
+gubernator.proto:137-203, gubernator.go:189-220)."""
+import ctypes as C
+
+import numpy as np
+
+from . import GuberError, lib
+from .abi import GuberBatch, GuberResult
+
+E_WIRE_MALFORMED, E_WIRE_TOO_LARGE, E_WIRE_FULL = -20, -21, -22
+WIRE_SYMBOLS = [
+    "guber_wire_batch_create", "guber_wire_batch_destroy", "guber_wire_batch_reset", "guber_wire_batch_size",
+    "guber_wire_decode_requests", "guber_wire_batch_view", "guber_wire_batch_result", "guber_wire_batch_pre_errors",
+    "guber_wire_eval", "guber_wire_encode_bound", "guber_wire_encode_responses",
+]
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = lib()
+    if not _bound:
+        L.guber_wire_batch_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_wire_batch_destroy.argtypes = [C.c_void_p]
+        L.guber_wire_batch_destroy.restype = None
+        L.guber_wire_batch_reset.argtypes = [C.c_void_p, C.c_int64]
+        L.guber_wire_batch_reset.restype = None
+        L.guber_wire_batch_size.argtypes = [C.c_void_p]
+        L.guber_wire_batch_size.restype = C.c_uint32
+        L.guber_wire_decode_requests.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, C.c_uint8,
+                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.guber_wire_batch_view.argtypes = [C.c_void_p]
+        L.guber_wire_batch_view.restype = C.POINTER(GuberBatch)
+        L.guber_wire_batch_result.argtypes = [C.c_void_p]
+        L.guber_wire_batch_result.restype = C.POINTER(GuberResult)
+        L.guber_wire_batch_pre_errors.argtypes = [C.c_void_p]
+        L.guber_wire_batch_pre_errors.restype = C.POINTER(C.c_uint8)
+        L.guber_wire_eval.argtypes = [C.c_void_p, C.c_void_p]
+        L.guber_wire_encode_bound.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.guber_wire_encode_bound.restype = C.c_size_t
+        L.guber_wire_encode_responses.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
+                                                  C.POINTER(C.c_size_t)]
+        _bound = True
+    return L
+
+
+class WireBatch:
+    """One device batch under construction from any number of RPC payloads."""
+
+    def __init__(self, max_items=65536, max_key_bytes=4 << 20, pinned=False):
+        self.L = _lib()
+        self.h = C.c_void_p()
+        rc = self.L.guber_wire_batch_create(max_items, max_key_bytes, 1 if pinned else 0, C.byref(self.h))
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+
+    def close(self):
+        if self.h:
+            self.L.guber_wire_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, now_ms):
+        self.L.guber_wire_batch_reset(self.h, now_ms)
+
+    def __len__(self):
+        return self.L.guber_wire_batch_size(self.h)
+
+    def decode(self, payload: bytes, max_per_rpc=0, is_owner=True):
+        """Append one serialized request message; returns (first, count).  Raises GuberError with the code
+        E_WIRE_MALFORMED / E_WIRE_TOO_LARGE / E_WIRE_FULL (nothing appended)."""
+        first, count = C.c_uint32(), C.c_uint32()
+        rc = self.L.guber_wire_decode_requests(self.h, payload, len(payload), max_per_rpc, 1 if is_owner else 0,
+                                               C.byref(first), C.byref(count))
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+        return first.value, count.value
+
+    def view(self):
+        return self.L.guber_wire_batch_view(self.h).contents
+
+    def result(self):
+        return self.L.guber_wire_batch_result(self.h).contents
+
+    def pre_errors(self):
+        n = len(self)
+        return np.ctypeslib.as_array(self.L.guber_wire_batch_pre_errors(self.h), shape=(n,)).copy() if n else np.zeros(0, np.uint8)
+
+    def arrays(self):
+        """numpy copies of the SoA (tests / debugging)."""
+        v, n = self.view(), len(self)
+        def arr(ptr, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,)).copy() if n and ptr else None
+        off = np.ctypeslib.as_array(C.cast(v.key_off, C.POINTER(C.c_uint32)), shape=(n + 1,)).copy()
+        kb = C.string_at(v.key_bytes, int(off[-1])) if n else b""
+        return dict(n=n, now_ms=v.now_ms, keys=[kb[off[i]:off[i + 1]] for i in range(n)],
+                    hits=arr(v.hits, C.c_int64), limit=arr(v.limit, C.c_int64), duration=arr(v.duration, C.c_int64),
+                    burst=arr(v.burst, C.c_int64), created_at=arr(v.created_at, C.c_int64),
+                    algorithm=arr(v.algorithm, C.c_uint8), behavior=arr(v.behavior, C.c_uint32),
+                    is_owner=arr(v.is_owner, C.c_uint8), greg_expire=arr(v.greg_expire, C.c_int64),
+                    greg_duration=arr(v.greg_duration, C.c_int64))
+
+    def eval(self, engine):
+        """guber_eval_batch on the batch's own arrays (needs the GPU engine)."""
+        rc = self.L.guber_wire_eval(engine.h, self.h)
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+
+    def encode(self, first, count, wrap_errors=True):
+        cap = self.L.guber_wire_encode_bound(self.h, first, count)
+        buf = (C.c_uint8 * max(cap, 1))()
+        n = C.c_size_t()
+        rc = self.L.guber_wire_encode_responses(self.h, first, count, 1 if wrap_errors else 0, buf, cap, C.byref(n))
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+        return bytes(buf[:n.value])

@@ -1,0 +1,89 @@
+/* guber_wire.h — wire-format front end of the batched rate-limit path (C ABI, host code).
+ *
+ * What it replaces in the reference: the protobuf unmarshalling of `GetRateLimitsReq` /
+ * `GetPeerRateLimitsReq` into one heap-allocated `*RateLimitReq` per item (generated code of
+ * gubernator.proto:137-182 / peers.proto:36-44) followed by the per-item validation of
+ * `V1Instance.GetRateLimits` (gubernator.go:189-220), and the marshalling of `GetRateLimitsResp` /
+ * `GetPeerRateLimitsResp` (gubernator.proto:189-203, peers.proto:46-49).  Here the serialized RPC payload
+ * is transcoded straight into the SoA batch `guber_eval_batch` consumes (include/guber_gpu.h) — no per-item
+ * allocation — and the SoA results straight back into the serialized response.  Several RPC payloads can
+ * be appended to ONE device batch, which lifts the reference's 1000-items-per-RPC cap (gubernator.go:40,189)
+ * and 1 MiB receive limit (daemon.go:122) from the device batch size.
+ *
+ * Wire facts relied upon (proto3): both request messages are `repeated RateLimitReq = 1`, both response
+ * messages are `repeated RateLimitResp = 1`, so one decoder / encoder serves the client and the peer RPC.
+ *   RateLimitReq : name 1 (LEN), unique_key 2 (LEN), hits 3, limit 4, duration 5 (int64 varint),
+ *                  algorithm 6, behavior 7 (enum varint), burst 8 (int64 varint),
+ *                  metadata 9 (map entry, skipped: tracing propagation only), created_at 10 (optional int64)
+ *   RateLimitResp: status 1 (enum), limit 2, remaining 3, reset_time 4 (int64), error 5 (string),
+ *                  metadata 6 (never set on this path)
+ * Unknown fields are skipped by wire type, the last occurrence of a singular field wins, zero-valued
+ * response fields are omitted and fields are written in field-number order — the bytes equal what the
+ * protobuf runtimes produce for the same message.
+ *
+ * Conventions: as guber_gpu.h (0 or negative code, never throws, caller-owned buffers, no pointer kept).
+ */
+#ifndef GUBER_WIRE_H
+#define GUBER_WIRE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "guber_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GUBER_E_WIRE_MALFORMED (-20)   /* truncated / invalid protobuf; nothing was appended */
+#define GUBER_E_WIRE_TOO_LARGE (-21)   /* more than max_per_rpc items: gubernator.go:189-193 (codes.OutOfRange) */
+#define GUBER_E_WIRE_FULL (-22)        /* the batch has no room for this payload; nothing was appended: flush, reset, retry */
+
+#define GUBER_WIRE_PINNED 1u           /* allocate the SoA with guber_alloc_pinned (needs a HIP device) */
+
+/* per-item validation outcome of gubernator.go:207-217, kept next to the SoA */
+#define GUBER_WIRE_PRE_OK 0
+#define GUBER_WIRE_PRE_EMPTY_UNIQUE_KEY 1   /* "field 'unique_key' cannot be empty" */
+#define GUBER_WIRE_PRE_EMPTY_NAME 2         /* "field 'namespace' cannot be empty" */
+
+typedef struct guber_wire_batch guber_wire_batch_t;
+
+/* A growable-up-to-capacity SoA batch plus the result arrays of its evaluation. */
+int guber_wire_batch_create(uint32_t max_items, uint32_t max_key_bytes, uint32_t flags, guber_wire_batch_t** out);
+void guber_wire_batch_destroy(guber_wire_batch_t* b);
+/* Empty the batch and set the clock of the next evaluation: MillisecondNow() for expiry (lrucache.go:106)
+ * and the CreatedAt default of items that carry none (gubernator.go:218-220). */
+void guber_wire_batch_reset(guber_wire_batch_t* b, int64_t now_ms);
+uint32_t guber_wire_batch_size(const guber_wire_batch_t* b);
+
+/* Append every RateLimitReq of one serialized GetRateLimitsReq / GetPeerRateLimitsReq.
+ *   max_per_rpc  0 = no cap; the reference passes 1000 (gubernator.go:40) -> GUBER_E_WIRE_TOO_LARGE
+ *   is_owner     RateLimitReqState.IsOwner of these items (gubernator.go:246, 489)
+ *   *first,*count  the slice [first, first+count) of the batch this payload occupies (responses are
+ *                  positionally aligned, gubernator.proto:51-54)
+ * Items failing the reference's validation keep their position with an empty key; they are answered with
+ * the reference's error text by guber_wire_encode_responses and never reach a bucket. */
+int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* msg, size_t len, uint32_t max_per_rpc,
+                               uint8_t is_owner, uint32_t* first, uint32_t* count);
+
+/* The SoA view to hand to guber_eval_batch (valid until the next reset / decode), the result arrays an
+ * evaluation fills, and the per-item validation codes. */
+const guber_batch_t* guber_wire_batch_view(guber_wire_batch_t* b);
+guber_result_t* guber_wire_batch_result(guber_wire_batch_t* b);
+const uint8_t* guber_wire_batch_pre_errors(const guber_wire_batch_t* b);
+
+/* guber_eval_batch(e, view, result) on the batch's own arrays. */
+int guber_wire_eval(guber_engine_t* e, guber_wire_batch_t* b);
+
+/* Serialize the responses of the slice [first, first+count) as GetRateLimitsResp (= GetPeerRateLimitsResp).
+ *   wrap_errors  1 = local path: errors of the evaluation are wrapped as
+ *                "Error while apply rate limit for '<key>': <text>" (gubernator.go:250-255); 0 = peer path
+ * Returns GUBER_E_NOMEM when cap is too small; *len then holds the size needed. */
+size_t guber_wire_encode_bound(const guber_wire_batch_t* b, uint32_t first, uint32_t count);
+int guber_wire_encode_responses(const guber_wire_batch_t* b, uint32_t first, uint32_t count, int wrap_errors,
+                                uint8_t* out, size_t cap, size_t* len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

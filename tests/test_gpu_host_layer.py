@@ -93,3 +93,56 @@ def test_concurrent_callers_are_batched_and_consistent():
     assert (admitted == limit).all(), admitted                     # 16*25 = 400 hits per key, limit 50
     assert inst.batches() < threads * per_thread                    # callers were coalesced into shared batches
     inst.close()
+
+
+def test_golden_functional_scenarios_through_the_wire_on_the_gpu():
+    """serialized GetRateLimitsReq -> guber_wire_decode_requests -> guber_wire_eval (HIP engine) ->
+    guber_wire_encode_responses -> parsed by the python protobuf runtime -> the reference's expectations."""
+    import wire_replay
+    from gubernator_amd import wire as gw
+
+    def make_eval():
+        e = ga.Engine(cache_size=4096, max_batch=2048)
+        return (lambda wb: wb.eval(e)), e.close
+    assert wire_replay.run_functional_wire(lambda: gw.WireBatch(2048, 1 << 16, pinned=True), make_eval) >= 80
+
+
+def test_aggregated_rpc_payloads_match_the_oracle_on_the_gpu():
+    """70 RPC payloads of up to 1000 items (the reference's per-RPC cap) aggregated into ONE device batch; every
+    RPC's response slice must equal what the oracle answers for the same aggregated batch."""
+    import ctypes as C
+    import wire_replay
+    from gubernator_amd import wire as gw
+    import support
+    from pb_schema import PB
+    rng = np.random.default_rng(21)
+    now = 1_700_000_000_000
+    e = ga.Engine(cache_size=1 << 16, max_batch=65536)
+    o = support.Oracle(cache_size=1 << 17)
+    gpu, cpu = gw.WireBatch(65536, 4 << 20, pinned=True), gw.WireBatch(65536, 4 << 20)
+    for rounds in range(3):
+        gpu.reset(now); cpu.reset(now)
+        slices = []
+        for rpc in range(70):
+            n = int(rng.integers(1, 1001))
+            reqs = [dict(name="agg", unique_key="k%d" % int(rng.zipf(1.3)) if rng.random() > 0.01 else "", hits=int(rng.integers(0, 3)),
+                         limit=50, duration=int(rng.choice([1, 60_000])), algorithm=int(rng.integers(0, 3) % 3 if rng.random() < 0.02 else rng.integers(0, 2)),
+                         behavior=int(rng.choice([0, 0, 0, 8, 32])), burst=0) for _ in range(n)]
+            p = wire_replay.pb_request(reqs)
+            try:
+                s = gpu.decode(p, max_per_rpc=1000)
+            except ga.GuberError as ex:
+                assert ex.code == gw.E_WIRE_FULL
+                break
+            assert cpu.decode(p, max_per_rpc=1000) == s
+            slices.append(s)
+        gpu.eval(e)
+        o.lib.oracle_eval_batch(o.h, C.byref(cpu.view()), C.byref(cpu.result()))
+        for first, count in slices:
+            a, b = gpu.encode(first, count), cpu.encode(first, count)
+            assert a == b, (rounds, first, count)
+            m = PB["GetRateLimitsResp"]()
+            m.ParseFromString(a)
+            assert len(m.responses) == count
+        now += 7
+    e.close()

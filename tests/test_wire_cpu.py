@@ -1,0 +1,235 @@
+"""CPU tests of the wire front end (include/guber_wire.h, gubernator_amd/csrc/wire.cpp): the transcoder is
+checked against the python protobuf runtime on the reference's message schema (tests/pb_schema.py), and the
+golden functional scenarios are replayed through it with the oracle as evaluator."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import support
+from pb_schema import PB
+import wire_replay
+import gubernator_amd as ga
+from gubernator_amd import wire as gw
+
+NOW = 1_700_000_000_000
+
+
+def rand_reqs(rng, n, bad=True):
+    out = []
+    for i in range(n):
+        kind = rng.integers(0, 12)
+        name = "ns_%d" % rng.integers(0, 5) if not (bad and kind == 0) else ""
+        uk = ("acct:%d" % rng.integers(0, 1000)) if not (bad and kind == 1) else ""
+        if kind == 2:
+            name, uk = "ünï_" + "x" * int(rng.integers(0, 70)), "ключ/🔑" + str(i)
+        r = dict(name=name, unique_key=uk,
+                 hits=int(rng.choice([0, 1, 1, 1, -1, 5, 2**62, -2**63, 2**63 - 1])),
+                 limit=int(rng.choice([0, 1, 10, 100, -3, 2**40])),
+                 duration=int(rng.choice([0, 1, 5, 1000, 60000, -1, 2**50])),
+                 algorithm=int(rng.choice([0, 0, 1, 1, 7, -2])) if bad else int(rng.integers(0, 2)),
+                 behavior=int(rng.choice([0, 0, 2, 8, 32, 34, 1 | 16])),
+                 burst=int(rng.choice([0, 0, 20, -1])),
+                 created_at=int(rng.choice([0, 0, NOW - 5, 12345])))
+        out.append(r)
+    return out
+
+
+def expected_key(r):
+    return (r["name"] + "_" + r["unique_key"]).encode() if r["name"] and r["unique_key"] else b""
+
+
+def check_decoded(arr, base, reqs, now, is_owner=1):
+    for j, r in enumerate(reqs):
+        i = base + j
+        assert arr["keys"][i] == expected_key(r), (i, r)
+        assert arr["hits"][i] == r["hits"] and arr["limit"][i] == r["limit"] and arr["duration"][i] == r["duration"]
+        assert arr["burst"][i] == r["burst"]
+        assert arr["created_at"][i] == (r["created_at"] or now)             # gubernator.go:218-220
+        assert arr["algorithm"][i] == (r["algorithm"] if r["algorithm"] in (0, 1) else 255)
+        assert arr["behavior"][i] == r["behavior"]
+        assert arr["is_owner"][i] == is_owner
+
+
+def test_wire_symbols_exported_and_declared():
+    hdr = open(os.path.join(support.ROOT, "include", "guber_wire.h")).read()
+    declared = set(re.findall(r"\b(guber_wire_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(gw.WIRE_SYMBOLS), declared ^ set(gw.WIRE_SYMBOLS)
+    L = ga.lib()
+    for s in gw.WIRE_SYMBOLS:
+        assert hasattr(L, s), s
+
+
+def test_decode_matches_protobuf_runtime_and_aggregates_payloads():
+    rng = np.random.default_rng(11)
+    wb = gw.WireBatch(max_items=4096, max_key_bytes=1 << 18)
+    wb.reset(NOW)
+    all_reqs, slices = [], []
+    for rpc in range(12):
+        reqs = rand_reqs(rng, int(rng.integers(0, 200)))
+        payload = wire_replay.pb_request(reqs, peer=bool(rpc & 1))
+        # map entries (metadata, field 9) and unknown fields are skipped
+        m = PB["GetRateLimitsReq"]()
+        m.ParseFromString(payload)
+        for q in m.requests[:3]:
+            q.metadata["traceparent"] = "00-abc-def-01"
+        payload = m.SerializeToString() + bytes([0x78, 0x05]) + bytes([0x82, 0x01, 0x02, 0x41, 0x42])   # fields 15 (varint), 16 (LEN)
+        first, count = wb.decode(payload, is_owner=not (rpc & 1))
+        assert (first, count) == (len(all_reqs), len(reqs))
+        slices.append((first, reqs, 0 if rpc & 1 else 1))
+        all_reqs += reqs
+    assert len(wb) == len(all_reqs)
+    arr = wb.arrays()
+    for first, reqs, own in slices:
+        check_decoded(arr, first, reqs, NOW, own)
+    pre = wb.pre_errors()
+    want = [1 if not r["unique_key"] else 2 if not r["name"] else 0 for r in all_reqs]
+    assert pre.tolist() == want
+    v = wb.view()
+    assert v.n == len(all_reqs) and v.now_ms == NOW
+    wb.close()
+
+
+def test_last_value_wins_and_field_order_is_free():
+    a = PB["RateLimitReq"](name="old", unique_key="k", hits=1, limit=2)
+    b = PB["RateLimitReq"](name="new", hits=7, duration=9)
+    body = a.SerializeToString() + b.SerializeToString()         # concatenation = merge: later singular fields win
+    payload = bytes([0x0a, len(body)]) + body
+    ref = PB["GetRateLimitsReq"]()
+    ref.ParseFromString(payload)
+    assert (ref.requests[0].name, ref.requests[0].hits, ref.requests[0].limit) == ("new", 7, 2)
+    wb = gw.WireBatch(16, 1024)
+    wb.reset(NOW)
+    assert wb.decode(payload) == (0, 1)
+    arr = wb.arrays()
+    assert arr["keys"][0] == b"new_k" and arr["hits"][0] == 7 and arr["limit"][0] == 2 and arr["duration"][0] == 9
+    wb.close()
+
+
+def test_malformed_capacity_and_rpc_cap_append_nothing():
+    rng = np.random.default_rng(3)
+    reqs = rand_reqs(rng, 40, bad=False)
+    payload = wire_replay.pb_request(reqs)
+    wb = gw.WireBatch(max_items=64, max_key_bytes=4096)
+    wb.reset(NOW)
+    assert wb.decode(payload) == (0, 40)
+    # every strict prefix is either a shorter valid message (cut at a record boundary) or malformed; a failed decode appends nothing
+    ok = bad = 0
+    for cut in range(len(payload)):
+        wb.reset(NOW)
+        wb.decode(payload[:0])
+        try:
+            first, count = wb.decode(payload[:cut])
+            ref = PB["GetRateLimitsReq"]()
+            ref.ParseFromString(payload[:cut])
+            assert count == len(ref.requests) == len(wb)
+            ok += 1
+        except ga.GuberError as e:
+            assert e.code == gw.E_WIRE_MALFORMED
+            assert len(wb) == 0
+            with pytest.raises(Exception):
+                PB["GetRateLimitsReq"]().ParseFromString(payload[:cut])
+            bad += 1
+    assert ok >= 40 and bad > 100
+    # invalid UTF-8 in a string field, over-long varint, zero field number
+    for raw in (bytes([0x0a, 0x04, 0x0a, 0x02, 0xc3, 0x28]), bytes([0x0a, 0x0c, 0x18] + [0xff] * 10 + [0x01]), bytes([0x00, 0x00])):
+        before = len(wb)
+        with pytest.raises(ga.GuberError) as ei:
+            wb.decode(raw)
+        assert ei.value.code == gw.E_WIRE_MALFORMED and len(wb) == before
+    # capacity: items, then key bytes
+    wb.reset(NOW)
+    wb.decode(payload)
+    with pytest.raises(ga.GuberError) as ei:
+        wb.decode(payload)
+    assert ei.value.code == gw.E_WIRE_FULL and len(wb) == 40
+    small = gw.WireBatch(max_items=64, max_key_bytes=100)
+    small.reset(NOW)
+    with pytest.raises(ga.GuberError) as ei:
+        small.decode(payload)
+    assert ei.value.code == gw.E_WIRE_FULL and len(small) == 0
+    # the reference's per-RPC cap (gubernator.go:189-193)
+    big = wire_replay.pb_request(rand_reqs(rng, 1001, bad=False))
+    cap = gw.WireBatch(4096, 1 << 18)
+    cap.reset(NOW)
+    with pytest.raises(ga.GuberError) as ei:
+        cap.decode(big, max_per_rpc=1000)
+    assert ei.value.code == gw.E_WIRE_TOO_LARGE and len(cap) == 0
+    assert "max size is '1000'" in str(ei.value)
+    assert cap.decode(big, max_per_rpc=0) == (0, 1001)
+    for w in (wb, small, cap):
+        w.close()
+
+
+def test_encode_is_byte_identical_to_protobuf_runtime():
+    rng = np.random.default_rng(5)
+    reqs = rand_reqs(rng, 300)
+    wb = gw.WireBatch(1024, 1 << 16)
+    wb.reset(NOW)
+    wb.decode(wire_replay.pb_request(reqs))
+    n = len(wb)
+    res = wb.result()
+    def arr(ptr, dt):
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,))
+    status, limit, remaining, reset, err = (arr(res.status, C.c_uint8), arr(res.limit, C.c_int64), arr(res.remaining, C.c_int64),
+                                             arr(res.reset_time, C.c_int64), arr(res.err, C.c_uint8))
+    status[:] = rng.integers(0, 2, n)
+    limit[:] = rng.choice([0, 1, 100, -5, 2**62, -2**63], n)
+    remaining[:] = rng.choice([0, 0, 7, -1, 2**63 - 1], n)
+    reset[:] = rng.choice([0, NOW + 60000, -9], n)
+    err[:] = 0
+    pre = wb.pre_errors()
+    for i, r in enumerate(reqs):
+        if pre[i] == 0 and r["algorithm"] not in (0, 1):
+            err[i] = 1                                            # GUBER_ITEM_E_INVALID_ALGORITHM, as the engine reports it
+    for wrap in (1, 0):
+        want = PB["GetRateLimitsResp"]()
+        for i, r in enumerate(reqs):
+            o = want.responses.add()
+            if pre[i] == 1:
+                o.error = "field 'unique_key' cannot be empty"
+            elif pre[i] == 2:
+                o.error = "field 'namespace' cannot be empty"
+            elif err[i]:
+                msg = "Invalid rate limit algorithm '%d'" % r["algorithm"]              # workers.go:318
+                o.error = ("Error while apply rate limit for '%s_%s': %s" % (r["name"], r["unique_key"], msg)) if wrap else msg
+            else:
+                o.status, o.limit, o.remaining, o.reset_time = int(status[i]), int(limit[i]), int(remaining[i]), int(reset[i])
+        got = wb.encode(0, n, wrap_errors=bool(wrap))
+        assert got == want.SerializeToString(deterministic=True)
+        # a slice in the middle (one RPC's share of an aggregated batch), parsed as the peer response message
+        sl = wb.encode(17, 40, wrap_errors=bool(wrap))
+        peer = PB["GetPeerRateLimitsResp"]()
+        peer.ParseFromString(sl)
+        assert [x.SerializeToString(deterministic=True) for x in peer.rate_limits] == \
+               [x.SerializeToString(deterministic=True) for x in want.responses[17:57]]
+    # too small an output buffer: GUBER_E_NOMEM and the size needed
+    L = ga.lib()
+    need = C.c_size_t()
+    buf = (C.c_uint8 * 8)()
+    assert L.guber_wire_encode_responses(wb.h, 0, n, 0, buf, 8, C.byref(need)) == -6 and need.value == len(got)
+    wb.close()
+
+
+def test_gregorian_items_get_host_precomputed_calendar_values():
+    wb = gw.WireBatch(16, 1024)
+    wb.reset(NOW)
+    reqs = [dict(name="g", unique_key="k%d" % d, hits=1, limit=10, duration=d, algorithm=0, behavior=4, burst=0) for d in (0, 1, 2, 4, 5, 3, 99)]
+    wb.decode(wire_replay.pb_request(reqs))
+    arr = wb.arrays()
+    for i, r in enumerate(reqs):
+        e, d = support.gregorian(NOW, r["duration"])
+        assert (arr["greg_expire"][i], arr["greg_duration"][i]) == (e, d), r
+    wb.close()
+
+
+def test_golden_functional_scenarios_through_the_wire_with_the_oracle():
+    def make_eval():
+        o = support.Oracle(cache_size=1 << 16)
+        def evaluate(wb):
+            o.lib.oracle_eval_batch(o.h, C.byref(wb.view()), C.byref(wb.result()))
+        return evaluate, (lambda: None)
+    n = wire_replay.run_functional_wire(lambda: gw.WireBatch(2048, 1 << 16), make_eval)
+    assert n >= 80
