@@ -36,7 +36,11 @@ enum : uint8_t { IE_OK = 0, IE_INVALID_ALGORITHM = 1, IE_GREG_WEEKS = 2, IE_GREG
 enum : uint32_t { K_ABSENT = 0, K_TOKEN = 1, K_LEAKY = 2, K_NIL = 3 };
 
 // apply() event flags
-enum : uint32_t { EV_HIT = 1, EV_MISS = 2, EV_OVER = 4 };
+// EV_ONCHANGE / EV_REMOVE: the persistent Store's callbacks that the reference would issue for this request
+// (store.go:49-65): Store.OnChange(r, item) with the item as it is AFTER the request — deferred at
+// algorithms.go:149-153 / :382-386 for a found item, direct at :252-254 / :488-490 for a new one, owner only —
+// and Store.Remove(key) at :79-84 (token RESET_REMAINING), :96-100 / :311-315 (algorithm switched).
+enum : uint32_t { EV_HIT = 1, EV_MISS = 2, EV_OVER = 4, EV_ONCHANGE = 8, EV_REMOVE = 16 };
 
 // ---- Go integer / float semantics -----------------------------------------------------------
 GB_HD int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -174,14 +178,20 @@ GB_HD uint32_t apply(Rec& s, const Req& r, int64_t now, Resp& rl) {
     } else ev = EV_MISS;
     if (ok && rec_kind(s) == K_NIL) ok = false;  // algorithms.go:55-63 / :284-292 "Value is nil"
 
+    // Store.OnChange after a NewItem (:252-254, :488-490): owner only, not on the Gregorian error return
+    const uint32_t chg = r.is_owner ? EV_ONCHANGE : 0u;
     if (r.algorithm == ALGO_TOKEN) {
-        if (!ok) return ev | token_new_item(s, r, rl);                       // :202
+        if (!ok) { ev |= token_new_item(s, r, rl); return rl.err ? ev : ev | chg; }          // :202
         if (r.behavior & BH_RESET_REMAINING) {                               // :78-90
             rec_clear(s);
             rl.status = ST_UNDER; rl.limit = r.limit; rl.remaining = r.limit; rl.reset_time = 0;
-            return ev;
+            return ev | EV_REMOVE;
         }
-        if (rec_kind(s) != K_TOKEN) { rec_clear(s); return ev | token_new_item(s, r, rl); }  // :91-103
+        if (rec_kind(s) != K_TOKEN) {                                        // :91-103
+            rec_clear(s);
+            ev |= EV_REMOVE | token_new_item(s, r, rl);
+            return rl.err ? ev : ev | chg;
+        }
         if (s.limit != r.limit) {                                            // :106-113
             s.remaining = wadd(s.remaining, wsub(r.limit, s.limit));
             if (s.remaining < 0) s.remaining = 0;
@@ -202,6 +212,7 @@ GB_HD uint32_t apply(Rec& s, const Req& r, int64_t now, Resp& rl) {
             }
             s.expire_at = expire; s.duration = r.duration; rl.reset_time = expire;
         }
+        ev |= chg;                                                           // :149-153 deferred OnChange: every return below
         if (r.hits == 0) return ev;                                          // :157-159
         if (rl.remaining == 0 && r.hits > 0) {                               // :162-170 sticky status
             if (r.is_owner) ev |= EV_OVER;
@@ -222,8 +233,12 @@ GB_HD uint32_t apply(Rec& s, const Req& r, int64_t now, Resp& rl) {
     // ---- leaky bucket, algorithms.go:260-434
     int64_t burst = r.burst;
     if (burst == 0) burst = r.limit;                                         // :264-266
-    if (!ok) return ev | leaky_new_item(s, r, burst, now, rl);               // :433
-    if (rec_kind(s) != K_LEAKY) { rec_clear(s); return ev | leaky_new_item(s, r, burst, now, rl); }  // :308-318
+    if (!ok) { ev |= leaky_new_item(s, r, burst, now, rl); return rl.err ? ev : ev | chg; }   // :433
+    if (rec_kind(s) != K_LEAKY) {                                            // :308-318
+        rec_clear(s);
+        ev |= EV_REMOVE | leaky_new_item(s, r, burst, now, rl);
+        return rl.err ? ev : ev | chg;
+    }
     double rem = bits2f(s.remaining);
     if (r.behavior & BH_RESET_REMAINING) rem = (double)burst;                // :320-322
     if (s.burst != burst) {                                                  // :325-330
@@ -238,6 +253,7 @@ GB_HD uint32_t apply(Rec& s, const Req& r, int64_t now, Resp& rl) {
         rate = (double)r.greg_duration / (double)r.limit;
         duration = wsub(r.greg_expire, now);
     }
+    ev |= chg;                                                               // :382-386 deferred OnChange (the returns above it are errors)
     if (r.hits != 0) s.expire_at = wadd(r.created_at, duration);             // :356-358 UpdateExpiration
     int64_t elapsed = wsub(r.created_at, s.stamp);                           // :361-367
     double leak = (double)elapsed / rate;

@@ -174,6 +174,8 @@ typedef struct lru {
 struct oracle {
     lru_t* workers; uint32_t nworkers; uint64_t ring_step;
     uint64_t over_limit, hits, misses, unexpired_evictions;
+    /* Config.Store (store.go:49-65) for oracle_eval_batch_store; NULL = no store (the `s != nil` tests) */
+    const oracle_store_t* store; uint32_t cur_req;
 };
 
 static void lru_init(lru_t* c, int64_t cache_size) {
@@ -288,6 +290,29 @@ typedef struct { uint8_t status; int64_t limit, remaining, reset_time; uint8_t e
 
 static int greg_error(const req_t* r) { return r->greg_duration < 0 ? (int)(-r->greg_duration) : 0; }
 
+static void item_from_abi(const guber_item_t* in, citem_t* it);
+static void item_to_abi(const citem_t* it, guber_item_t* out);
+/* `s.OnChange(ctx, r, item)`: the store sees the item as it is when the call is made */
+static void store_on_change(oracle_t* o, const req_t* r, const citem_t* item) {
+    if (!o->store || !r->is_owner || !o->store->on_change) return;
+    guber_item_t out; item_to_abi(item, &out);
+    out.key = (const uint8_t*)r->key; out.key_len = r->klen;
+    o->store->on_change(o->store->user, o->cur_req, &out);
+}
+static void store_remove(oracle_t* o, const req_t* r) {
+    if (o->store && o->store->remove) o->store->remove(o->store->user, o->cur_req, (const uint8_t*)r->key, r->klen);
+}
+/* algorithms.go:45-51 / :274-280: on a cache miss ask the store; a returned item is added to the cache */
+static citem_t* store_get(oracle_t* o, lru_t* c, const req_t* r, int64_t now) {
+    if (!o->store || !o->store->get) return NULL;
+    guber_item_t in; memset(&in, 0, sizeof(in));
+    if (!o->store->get(o->store->user, o->cur_req, &in)) return NULL;
+    citem_t it; item_from_abi(&in, &it);
+    citem_t* e = NULL;
+    lru_add(o, c, &it, r->key, r->klen, r->h, now, &e);
+    return e;
+}
+
 /* algorithms.go:206-257 tokenBucketNewItem */
 static int token_bucket_new_item(oracle_t* o, lru_t* c, const req_t* r, int64_t now, resp_t* rl) {
     int64_t created_at = r->created_at;
@@ -310,24 +335,29 @@ static int token_bucket_new_item(oracle_t* o, lru_t* c, const req_t* r, int64_t 
         rl->remaining = r->limit;
         it.t_remaining = r->limit;
     }
-    lru_add(o, c, &it, r->key, r->klen, r->h, now, NULL);            /* :250 */
+    citem_t* added = NULL;
+    lru_add(o, c, &it, r->key, r->klen, r->h, now, &added);          /* :250 */
+    store_on_change(o, r, added);                                   /* :252-254 */
     return 0;
 }
 
-/* algorithms.go:37-203 tokenBucket (Store == nil: the persistent-store callbacks stay on the host) */
+/* algorithms.go:37-203 tokenBucket (o->store == NULL is the reference's `s == nil`) */
 static int token_bucket(oracle_t* o, lru_t* c, const req_t* r, int64_t now, resp_t* rl) {
     citem_t* item = lru_get_item(o, c, r->key, r->klen, r->h, now); /* :43 */
     int ok = item != NULL;
+    if (!ok && (item = store_get(o, c, r, now)) != NULL) ok = 1;    /* :45-51 */
     if (ok && item->vkind == VK_NIL) ok = 0;                        /* :55-63 Value is nil */
     if (ok) {
         if (HAS(r->behavior, GUBER_BEHAVIOR_RESET_REMAINING)) {     /* :78-90 */
             lru_remove(c, r->key, r->klen, r->h);
+            store_remove(o, r);                                     /* :81-83 */
             rl->status = GUBER_STATUS_UNDER_LIMIT; rl->limit = r->limit;
             rl->remaining = r->limit; rl->reset_time = 0;
             return 0;
         }
         if (item->vkind != VK_TOKEN) {                              /* :91-103 switched algorithms */
             lru_remove(c, r->key, r->klen, r->h);
+            store_remove(o, r);                                     /* :98-100 */
             return token_bucket_new_item(o, c, r, now, rl);
         }
         citem_t* t = item;
@@ -355,25 +385,29 @@ static int token_bucket(oracle_t* o, lru_t* c, const req_t* r, int64_t now, resp
             t->t_duration = r->duration;
             rl->reset_time = expire;
         }
-        if (r->hits == 0) return 0;                                 /* :157-159 */
+        /* :149-153 `defer s.OnChange(ctx, r, item)`: runs at every return below */
+        if (r->hits == 0) goto found_done;                                 /* :157-159 */
         if (rl->remaining == 0 && r->hits > 0) {                    /* :162-170 */
             if (r->is_owner) o->over_limit++;
             rl->status = GUBER_STATUS_OVER_LIMIT;
             t->t_status = rl->status;
-            return 0;
+            goto found_done;
         }
         if (t->t_remaining == r->hits) {                            /* :173-178 */
             t->t_remaining = 0; rl->remaining = 0;
-            return 0;
+            goto found_done;
         }
         if (r->hits > t->t_remaining) {                             /* :182-194 */
             if (r->is_owner) o->over_limit++;
             rl->status = GUBER_STATUS_OVER_LIMIT;
             if (HAS(r->behavior, GUBER_BEHAVIOR_DRAIN_OVER_LIMIT)) { t->t_remaining = 0; rl->remaining = 0; }
-            return 0;
+            goto found_done;
         }
         t->t_remaining -= r->hits;                                  /* :196-198 */
         rl->remaining = t->t_remaining;
+        goto found_done;
+    found_done:
+        store_on_change(o, r, item);
         return 0;
     }
     return token_bucket_new_item(o, c, r, now, rl);                 /* :202 */
@@ -405,7 +439,9 @@ static int leaky_bucket_new_item(oracle_t* o, lru_t* c, const req_t* r, int64_t 
     }
     it.expire_at = created_at + duration;                           /* :479-484 */
     it.algorithm = (int32_t)r->algorithm;
-    lru_add(o, c, &it, r->key, r->klen, r->h, now, NULL);            /* :486 */
+    citem_t* added = NULL;
+    lru_add(o, c, &it, r->key, r->klen, r->h, now, &added);          /* :486 */
+    store_on_change(o, r, added);                                   /* :488-490 */
     return 0;
 }
 
@@ -416,10 +452,12 @@ static int leaky_bucket(oracle_t* o, lru_t* c, const req_t* r, int64_t now, resp
     int64_t created_at = r->created_at;
     citem_t* item = lru_get_item(o, c, r->key, r->klen, r->h, now); /* :272 */
     int ok = item != NULL;
+    if (!ok && (item = store_get(o, c, r, now)) != NULL) ok = 1;    /* :274-280 */
     if (ok && item->vkind == VK_NIL) ok = 0;                        /* :284-292 */
     if (ok) {
         if (item->vkind != VK_LEAKY) {                              /* :308-318 */
             lru_remove(c, r->key, r->klen, r->h);
+            store_remove(o, r);                                     /* :313-315 */
             return leaky_bucket_new_item(o, c, r, burst, now, rl);
         }
         citem_t* b = item;
@@ -445,27 +483,31 @@ static int leaky_bucket(oracle_t* o, lru_t* c, const req_t* r, int64_t now, resp
         rl->limit = b->l_limit; rl->remaining = go_f2i(b->l_remaining);             /* :373-378 */
         rl->status = GUBER_STATUS_UNDER_LIMIT;
         rl->reset_time = created_at + (b->l_limit - go_f2i(b->l_remaining)) * go_f2i(rate);
+        /* :382-386 `defer s.OnChange(ctx, r, item)`: runs at every return below */
         if (go_f2i(b->l_remaining) == 0 && r->hits > 0) {           /* :389-395 */
             if (r->is_owner) o->over_limit++;
             rl->status = GUBER_STATUS_OVER_LIMIT;
-            return 0;
+            goto found_done;
         }
         if (go_f2i(b->l_remaining) == r->hits) {                    /* :398-403 */
             b->l_remaining = 0;
             rl->remaining = go_f2i(b->l_remaining);
             rl->reset_time = created_at + (rl->limit - rl->remaining) * go_f2i(rate);
-            return 0;
+            goto found_done;
         }
         if (r->hits > go_f2i(b->l_remaining)) {                     /* :407-420 */
             if (r->is_owner) o->over_limit++;
             rl->status = GUBER_STATUS_OVER_LIMIT;
             if (HAS(r->behavior, GUBER_BEHAVIOR_DRAIN_OVER_LIMIT)) { b->l_remaining = 0; rl->remaining = 0; }
-            return 0;
+            goto found_done;
         }
-        if (r->hits == 0) return 0;                                 /* :423-425 */
+        if (r->hits == 0) goto found_done;                                 /* :423-425 */
         b->l_remaining -= (double)r->hits;                          /* :427-430 */
         rl->remaining = go_f2i(b->l_remaining);
         rl->reset_time = created_at + (rl->limit - rl->remaining) * go_f2i(rate);
+        goto found_done;
+    found_done:
+        store_on_change(o, r, item);
         return 0;
     }
     return leaky_bucket_new_item(o, c, r, burst, now, rl);          /* :433 */
@@ -540,6 +582,26 @@ int oracle_eval_batch(oracle_t* o, const guber_batch_t* b, guber_result_t* res) 
         handle_get_rate_limit(o, &o->workers[worker_index(o, r.h)], &r, b->now_ms, &rl);
         store_resp(res, i, &rl);
     }
+    res->over_limit_count = o->over_limit - ol0; res->cache_hits = o->hits - h0;
+    res->cache_misses = o->misses - m0; res->unexpired_evictions = o->unexpired_evictions - ev0;
+    res->cache_size = oracle_size(o);
+    return 0;
+}
+
+/* The same loop with Config.Store set (store.go:49-65): Get on a cache miss, OnChange after an evaluated
+ * request when the node owns the key, Remove when an item is dropped because of RESET_REMAINING (token) or an
+ * algorithm switch.  The callbacks receive the index of the request that caused them. */
+int oracle_eval_batch_store(oracle_t* o, const guber_batch_t* b, guber_result_t* res, const oracle_store_t* st) {
+    o->store = st;
+    uint64_t ol0 = o->over_limit, h0 = o->hits, m0 = o->misses, ev0 = o->unexpired_evictions;
+    for (uint32_t i = 0; i < b->n; i++) {
+        req_t r; resp_t rl;
+        load_req(b, i, &r);
+        o->cur_req = i;
+        handle_get_rate_limit(o, &o->workers[worker_index(o, r.h)], &r, b->now_ms, &rl);
+        store_resp(res, i, &rl);
+    }
+    o->store = NULL;
     res->over_limit_count = o->over_limit - ol0; res->cache_hits = o->hits - h0;
     res->cache_misses = o->misses - m0; res->unexpired_evictions = o->unexpired_evictions - ev0;
     res->cache_size = oracle_size(o);

@@ -15,9 +15,18 @@ extern "C" {
 typedef struct oracle oracle_t;
 typedef struct oracle_ring oracle_ring_t;
 
+/* Config.Store (store.go:49-65) as C callbacks; `req` = index in the batch of the request being applied */
+typedef struct oracle_store {
+    int (*get)(void* user, uint32_t req, guber_item_t* out);                         /* 1 = found: *out filled (key ignored) */
+    void (*on_change)(void* user, uint32_t req, const guber_item_t* item);
+    void (*remove)(void* user, uint32_t req, const uint8_t* key, uint32_t key_len);
+    void* user;
+} oracle_store_t;
+
 oracle_t* oracle_create(uint64_t cache_size, uint32_t workers);
 void oracle_destroy(oracle_t* o);
 int oracle_eval_batch(oracle_t* o, const guber_batch_t* b, guber_result_t* res);
+int oracle_eval_batch_store(oracle_t* o, const guber_batch_t* b, guber_result_t* res, const oracle_store_t* st);
 int oracle_eval_batch_mt(oracle_t* o, const guber_batch_t* b, guber_result_t* res, int threads);
 int oracle_add_item(oracle_t* o, const guber_item_t* in, int64_t now_ms, int* existed);
 int oracle_get_item(oracle_t* o, const uint8_t* key, uint32_t klen, int64_t now_ms, guber_item_t* out, int* found);

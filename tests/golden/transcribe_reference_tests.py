@@ -198,6 +198,48 @@ with open(os.path.join(HERE, "store_vectors.json"), "w") as f:
     json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 store_test.go", cases=store_cases), f, indent=1)
 
 # ------------------------------------------------------------------------------------------------
+# store_test.go:127-529 TestStore with its MockStore2: WHICH Store callbacks the path issues, in which order,
+# and what the OnChange item must look like (matchItem :160-193).  `get` is what the mocked Store.Get returns
+# (None = (nil, false)); `calls` is the exact expected call sequence for the step (mock .Once() each).
+# ------------------------------------------------------------------------------------------------
+KEY = "test_over_limit_account:1234"
+store_event_cases = []
+for ALG, ANAME in ((TOKEN, "Token bucket"), (LEAKY, "Leaky bucket")):
+    R = req("test_over_limit", "account:1234", ALG, SECOND, 10, 1)
+    match = dict(algorithm=ALG, key=KEY, limit=10, duration=SECOND)               # matchItem
+    # createBucketItem :195-218
+    bucket = (dict(key=KEY, algorithm=TOKEN, limit=10, duration=SECOND, remaining=10, stamp=NOW, expire_at=NOW + SECOND) if ALG == TOKEN
+              else dict(key=KEY, algorithm=LEAKY, limit=10, duration=SECOND, remaining_f=0.0, stamp=NOW, burst=0, expire_at=NOW + SECOND))
+    store_event_cases += [
+        dict(name=f"TestStore/{ANAME}/First rate check pulls from store", source="store_test.go:236-277", now_ms=NOW, steps=[
+            dict(req=R, get=None, calls=["get", "on_change"], expect_resp=dict(status=UNDER, limit=10), expect_item=match),
+            # :262-276 "Second rate check pulls from cache"
+            dict(req=R, get=None, calls=["on_change"], expect_resp=dict(status=UNDER, limit=10), expect_item=match)]),
+        dict(name=f"TestStore/{ANAME}/Found in store after cache miss", source="store_test.go:279-314", now_ms=NOW, steps=[
+            dict(req=R, get=bucket, calls=["get", "on_change"], expect_resp=dict(status=UNDER, limit=10), expect_item=match)]),
+        # :316-350 the stored CacheItem carries a Value of a foreign type (`&struct{}{}`): the type assertion fails ->
+        # Remove, then a new item.  A foreign Value is represented here by an item of the OTHER algorithm.
+        dict(name=f"TestStore/{ANAME}/Algorithm changed", source="store_test.go:316-350", now_ms=NOW, steps=[
+            dict(req=R, get=dict(bucket, algorithm=LEAKY if ALG == TOKEN else TOKEN, remaining=10, remaining_f=10.0, burst=10),
+                 calls=["get", "remove", "on_change"], expect_resp=dict(status=UNDER, limit=10), expect_item=match)]),
+    ]
+# :352-436 "Duration changed" (token only): OnChange item has ExpireAt == CreatedAt + newDuration
+store_event_cases.append(dict(name="TestStore/Token bucket/Duration changed", source="store_test.go:352-436", now_ms=NOW, steps=[
+    dict(req=req("test_over_limit", "account:1234", TOKEN, 8000, 10, 1),
+         get=dict(key=KEY, algorithm=TOKEN, limit=10, duration=5000, remaining=10, stamp=NOW, expire_at=NOW + 5000),
+         calls=["get", "on_change"], expect_resp=dict(status=UNDER, limit=10),
+         expect_item=dict(algorithm=TOKEN, key=KEY, limit=10, duration=8000, expire_at_minus_stamp=8000))]))
+# :438-529 "Duration changed and immediately expired": the stored item is older than the new duration -> renewed
+store_event_cases.append(dict(name="TestStore/Token bucket/Duration changed and immediately expired", source="store_test.go:438-529", now_ms=NOW, steps=[
+    dict(req=req("test_over_limit", "account:1234", TOKEN, 8000, 10, 1),
+         get=dict(key=KEY, algorithm=TOKEN, limit=10, duration=500000, remaining=10, stamp=NOW - 100000, expire_at=NOW - 100000 + 500000),
+         calls=["get", "on_change"], expect_resp=dict(status=UNDER, limit=10),
+         expect_item=dict(algorithm=TOKEN, key=KEY, limit=10, duration=8000, expire_at_minus_stamp=8000, stamp=NOW))]))
+with open(os.path.join(HERE, "store_events_vectors.json"), "w") as f:
+    json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 store_test.go TestStore (MockStore2 expectations)",
+                   cases=store_event_cases), f, indent=1)
+
+# ------------------------------------------------------------------------------------------------
 # known-answer tests: interval_test.go, replicated_hash_test.go, workers_internal_test.go
 # ------------------------------------------------------------------------------------------------
 def utc_ms(y, mo, d, h=0, mi=0, s=0, ns=0):

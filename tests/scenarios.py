@@ -118,3 +118,34 @@ def run_store(make_backend):
         if hasattr(be, "close"):
             be.close()
     return n
+
+
+def run_store_events(make_backend):
+    """tests/golden/store_events_vectors.json (store_test.go TestStore): the backend's
+    eval_store(batch, store) must issue exactly the Store calls the reference's mock expects, in order, and the
+    OnChange item must satisfy the test's matchItem."""
+    n = 0
+    for case in load("store_events_vectors.json")["cases"]:
+        be = make_backend()
+        now = case["now_ms"]
+        for si, step in enumerate(case["steps"]):
+            where = f"{case['name']} step {si} ({case['source']})"
+            key = step["req"]["name"] + "_" + step["req"]["unique_key"]
+            store = support.MockStore({key: step["get"]} if step["get"] else {})
+            res = be.eval_store(batch_of([step["req"]], now), store)
+            check_expect(step["expect_resp"], res.rows()[0], now, where)
+            assert store.kinds() == step["calls"], f"{where}: {store.kinds()}"
+            for c in store.calls:
+                assert c[1] == 0 and c[2] == key, where
+            item = [c for c in store.calls if c[0] == "on_change"][-1][3]
+            exp = step["expect_item"]
+            for f in ("algorithm", "limit", "duration", "stamp"):
+                if f in exp:
+                    assert item[f] == exp[f], f"{where}: item.{f} = {item[f]}"
+            assert item["key"] == exp["key"], where
+            if "expire_at_minus_stamp" in exp:
+                assert item["expire_at"] - item["stamp"] == exp["expire_at_minus_stamp"], where
+            n += 1
+        if hasattr(be, "close"):
+            be.close()
+    return n

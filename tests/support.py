@@ -28,6 +28,57 @@ from gubernator_amd.abi import (GuberConfig, GuberBatch, GuberResult, GuberItem,
 
 
 # ------------------------------------------------------------------------------------------------
+# Store (store.go:49-65) test double: the reference's MockStore2 (store_test.go) in python
+# ------------------------------------------------------------------------------------------------
+class MockStore:
+    """Records every call in order; `items` (key -> item dict) is what Get returns, like the mock's
+    `.Return(storedItem, true)`.  on_change also keeps the last item per key (a write-through store)."""
+
+    def __init__(self, items=None, write_through=False):
+        self.items = dict(items or {})
+        self.calls = []
+        self.write_through = write_through
+
+    def get(self, req_index, key):
+        self.calls.append(("get", req_index, key))
+        return self.items.get(key)
+
+    def on_change(self, req_index, key, item):
+        self.calls.append(("on_change", req_index, key, item))
+        if self.write_through:
+            self.items[key] = dict(item, key=key)
+
+    def remove(self, req_index, key):
+        self.calls.append(("remove", req_index, key))
+        if self.write_through:
+            self.items.pop(key, None)
+
+    def kinds(self):
+        return [c[0] for c in self.calls]
+
+
+_GET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(GuberItem))
+_CHG_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(GuberItem))
+_REM_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32)
+
+
+class OracleStore(C.Structure):
+    _fields_ = [("get", _GET_CB), ("on_change", _CHG_CB), ("remove", _REM_CB), ("user", C.c_void_p)]
+
+
+def fill_item(out, d):
+    """item dict -> *GuberItem (key left to the callee)"""
+    out.algorithm = d["algorithm"]; out.status = d.get("status", 0); out.limit = d.get("limit", 0)
+    out.duration = d.get("duration", 0); out.remaining = d.get("remaining", 0); out.remaining_f = d.get("remaining_f", 0.0)
+    out.stamp = d.get("stamp", 0); out.burst = d.get("burst", 0); out.expire_at = d.get("expire_at", 0)
+    out.invalid_at = d.get("invalid_at", 0)
+
+
+def batch_key(batch, i):
+    return bytes(batch.key_bytes[batch.key_off[i]:batch.key_off[i + 1]]).decode()
+
+
+# ------------------------------------------------------------------------------------------------
 # Oracle
 # ------------------------------------------------------------------------------------------------
 _ORACLE = None
@@ -50,6 +101,7 @@ def oracle_lib():
         lib.oracle_destroy.argtypes = [C.c_void_p]
         lib.oracle_eval_batch.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult)]
         lib.oracle_eval_batch_mt.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int]
+        lib.oracle_eval_batch_store.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.POINTER(OracleStore)]
         lib.oracle_add_item.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_int64, C.POINTER(C.c_int)]
         lib.oracle_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
                                         C.POINTER(C.c_int)]
@@ -100,6 +152,27 @@ class Oracle:
             self.lib.oracle_eval_batch_mt(self.h, C.byref(batch.c), C.byref(res.c), threads)
         else:
             self.lib.oracle_eval_batch(self.h, C.byref(batch.c), C.byref(res.c))
+        return res
+
+    def eval_store(self, batch, store):
+        """The batch with Config.Store = `store` (a MockStore-like object), the reference's way: Get on a miss,
+        OnChange / Remove from inside the algorithms."""
+        res = HostResult(batch.n)
+
+        def get(_u, i, out):
+            d = store.get(i, batch_key(batch, i))
+            if d is None:
+                return 0
+            fill_item(out.contents, d)
+            return 1
+
+        def chg(_u, i, item):
+            store.on_change(i, batch_key(batch, i), item_dict(item.contents, key=batch_key(batch, i)))
+
+        def rem(_u, i, key, klen):
+            store.remove(i, C.string_at(key, klen).decode())
+        cbs = OracleStore(_GET_CB(get), _CHG_CB(chg), _REM_CB(rem), None)
+        self.lib.oracle_eval_batch_store(self.h, C.byref(batch.c), C.byref(res.c), C.byref(cbs))
         return res
 
     def add_item(self, item, now_ms=0):

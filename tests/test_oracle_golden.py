@@ -134,3 +134,8 @@ def test_mt_matches_sequential():
         hb = HostBatch(keys, rng.integers(0, 4, 5000), 20, 50, now + step * 30,
                        algorithm=(ids % 2).astype(np.uint8))
         support.assert_results_equal(a.eval(hb, threads=4), b.eval(hb), f"step {step}")
+
+
+def test_store_callbacks_follow_teststore():
+    """store_test.go TestStore: Get on a miss, OnChange after the request, Remove on a foreign Value."""
+    assert scenarios.run_store_events(lambda: Oracle(cache_size=1 << 12)) == 10
