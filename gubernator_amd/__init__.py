@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
-    "guber_pool_get_rate_limits", "guber_compact",
+    "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
+    "guber_pool_set_store",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
@@ -65,10 +66,14 @@ def lib():
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
         L.guber_compact.argtypes = [C.c_void_p, C.c_int64]
+        L.guber_probe_missing.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.c_void_p]
+        L.guber_eval_batch_store.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.POINTER(abi.GuberStoreEvents)]
         L.guber_global_take.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.GuberGlobalRows)]
         L.guber_pool_create.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.guber_pool_destroy.argtypes = [C.c_void_p]
         L.guber_pool_destroy.restype = None
+        L.guber_pool_set_store.argtypes = [C.c_void_p, C.c_void_p]
+        L.guber_pool_set_store.restype = None
         L.guber_pool_set_clock.argtypes = [C.c_void_p, C.c_int64]
         L.guber_pool_set_clock.restype = None
         L.guber_pool_engine.argtypes = [C.c_void_p]
@@ -191,6 +196,46 @@ class Engine:
         _check(lib().guber_eval_batch(self.h, C.byref(batch.c), C.byref(res.c)))
         return res
 
+    def probe_missing(self, batch):
+        """missing[i] = 1: the key of request i is not resident at batch.now_ms (Store.Get is due, algorithms.go:45-51)."""
+        out = np.zeros(max(batch.n, 1), np.uint8)
+        _check(lib().guber_probe_missing(self.h, C.byref(batch.c), out.ctypes.data))
+        return out[:batch.n]
+
+    def eval_store_raw(self, batch):
+        """guber_eval_batch_store: (HostResult, flags uint8[n], items GuberItem[n])."""
+        res = HostResult(batch.n)
+        flags = np.zeros(max(batch.n, 1), np.uint8)
+        items = (GuberItem * max(batch.n, 1))()
+        ev = abi.GuberStoreEvents(flags.ctypes.data, C.cast(items, C.c_void_p))
+        _check(lib().guber_eval_batch_store(self.h, C.byref(batch.c), C.byref(res.c), C.byref(ev)))
+        return res, flags[:batch.n], items
+
+    def eval_store(self, batch, store):
+        """One batch with a persistent Store configured, the way the Go shim drives it (include/guber_gpu.h,
+        Config.Store section): Store.Get for the first request of every non-resident key -> guber_add_items ->
+        guber_eval_batch_store -> Remove / OnChange callbacks in request order.
+        `store` has get(req_index, key) -> item dict | None, on_change(req_index, key, item dict), remove(req_index, key)."""
+        keys = [bytes(batch.key_bytes[batch.key_off[i]:batch.key_off[i + 1]]).decode() for i in range(batch.n)]
+        asked = set()
+        for i in np.nonzero(self.probe_missing(batch))[0].tolist():
+            if keys[i] in asked or not keys[i]:
+                continue
+            asked.add(keys[i])
+            d = store.get(i, keys[i])
+            if d is not None:
+                self.add_item(make_item(keys[i], d["algorithm"], limit=d.get("limit", 0), duration=d.get("duration", 0),
+                                        remaining=d.get("remaining", 0), remaining_f=d.get("remaining_f", 0.0),
+                                        stamp=d.get("stamp", 0), burst=d.get("burst", 0), expire_at=d.get("expire_at", 0),
+                                        invalid_at=d.get("invalid_at", 0), status=d.get("status", 0)), batch.now_ms)
+        res, flags, items = self.eval_store_raw(batch)
+        for i in range(batch.n):
+            if flags[i] & 2:
+                store.remove(i, keys[i])
+            if flags[i] & 1:
+                store.on_change(i, keys[i], item_dict(items[i], key=keys[i]))
+        return res
+
     def eval_dev(self, batch_struct, result_struct):
         """GuberBatch / GuberResult whose pointers are DEVICE pointers; asynchronous."""
         _check(lib().guber_eval_batch_dev(self.h, C.byref(batch_struct), C.byref(result_struct)))
@@ -293,6 +338,42 @@ class V1Instance:
 
     def batches(self):
         return lib().guber_pool_batches(self.h)
+
+    def set_store(self, store):
+        """Config.Store (store.go:49-65).  `store` has get(req, key) -> item dict | None, on_change(req, key, item dict),
+        remove(req, key), where req is a dict of the request fields the reference hands to the Store (None for remove)."""
+        L = lib()
+        if store is None:
+            L.guber_pool_set_store(self.h, None)
+            self._store_cbs = None
+            return
+
+        def reqd(q):
+            q = q.contents
+            key = C.string_at(q.key, q.key_len).decode()
+            return key, dict(name=key[:q.name_len], unique_key=key[q.name_len + 1:], hits=q.hits, limit=q.limit, duration=q.duration,
+                             burst=q.burst, created_at=q.created_at, algorithm=q.algorithm, behavior=q.behavior)
+
+        def get(_u, q, out):
+            key, r = reqd(q)
+            d = store.get(r, key)
+            if d is None:
+                return 0
+            o = out.contents
+            o.algorithm = d["algorithm"]; o.status = d.get("status", 0); o.limit = d.get("limit", 0); o.duration = d.get("duration", 0)
+            o.remaining = d.get("remaining", 0); o.remaining_f = d.get("remaining_f", 0.0); o.stamp = d.get("stamp", 0)
+            o.burst = d.get("burst", 0); o.expire_at = d.get("expire_at", 0); o.invalid_at = d.get("invalid_at", 0)
+            return 1
+
+        def chg(_u, q, item):
+            key, r = reqd(q)
+            store.on_change(r, key, item_dict(item.contents, key=key))
+
+        def rem(_u, key, klen):
+            store.remove(None, C.string_at(key, klen).decode())
+        cbs = abi.GuberStoreCallbacks(abi.STORE_GET_CB(get), abi.STORE_CHG_CB(chg), abi.STORE_REM_CB(rem), None)
+        self._store_cbs = cbs
+        L.guber_pool_set_store(self.h, C.byref(cbs))
 
     def GetRateLimits(self, reqs):
         """-> list of dicts {status, limit, remaining, reset_time, error}; raises GuberError for the

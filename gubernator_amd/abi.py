@@ -63,6 +63,25 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+class GuberStoreEvents(C.Structure):
+    _fields_ = [("flags", C.c_void_p), ("items", C.c_void_p)]
+
+
+class GuberStoreReq(C.Structure):
+    _fields_ = [("key", C.c_void_p), ("key_len", C.c_uint32), ("name_len", C.c_uint32), ("hits", C.c_int64), ("limit", C.c_int64),
+                ("duration", C.c_int64), ("burst", C.c_int64), ("created_at", C.c_int64), ("algorithm", C.c_int32),
+                ("behavior", C.c_uint32)]
+
+
+STORE_GET_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(GuberStoreReq), C.POINTER(GuberItem))
+STORE_CHG_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(GuberStoreReq), C.POINTER(GuberItem))
+STORE_REM_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint32)
+
+
+class GuberStoreCallbacks(C.Structure):
+    _fields_ = [("get", STORE_GET_CB), ("on_change", STORE_CHG_CB), ("remove", STORE_REM_CB), ("user", C.c_void_p)]
+
+
 class HostBatch:
     """SoA batch in numpy arrays + the ctypes struct pointing at them."""
 

@@ -91,6 +91,7 @@ struct guber_engine {
 #ifdef GUBER_PHASE_TIMING
     DevBuf<unsigned long long> dbg; double dbg_avg[2][8] = {{0}}, dbg_max[2][8] = {{0}}; uint64_t dbg_n = 0;
 #endif
+    DevBuf<uint8_t> d_sflags; DevBuf<Rec> d_safter;   // Store side channel (guber_eval_batch_store), allocated on first use
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
@@ -228,7 +229,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilerow = e->w_tilerow.p;
     e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
 
-    e->W.parity = 0; e->W.clear_n = 0;
+    e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -253,6 +254,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     }
     e->dbg.release();
 #endif
+    e->d_sflags.release(); e->d_safter.release();
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
     e->d_take.release(); e->h_take.release();
     e->dir.release(); e->buckets.release(); e->arena.release(); e->ctr.release();
@@ -395,7 +397,9 @@ extern "C" int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* b, g
 
 // Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of
 // the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
-static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_t* r, const uint32_t* idx, uint32_t n) {
+static void item_from_rec(const Rec& s, guber_item_t* out);
+static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_t* r, const uint32_t* idx, uint32_t n,
+                          guber_store_events_t* sev = nullptr) {
     const bool has_burst = b->burst, has_created = b->created_at, has_greg = b->greg_expire && b->greg_duration;
     // key bytes of the (sub)batch
     size_t kbytes = 0;
@@ -446,8 +450,20 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     BatchView B{n, 0, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
                 e->d_u8.p, e->d_beh.p, e->d_u8.p + n, d64 + 5 * (size_t)n, d64 + 6 * (size_t)n, b->now_ms};
     ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
+    std::vector<uint8_t> h_sflags; std::vector<Rec> h_safter;
+    if (sev) {
+        if (e->d_sflags.ensure(n) || e->d_safter.ensure(n)) return GUBER_E_NOMEM;
+        HIPCHK(hipMemsetAsync(e->d_sflags.p, 0, n, st));
+        e->W.store_flags = e->d_sflags.p; e->W.store_after = e->d_safter.p;
+    }
     rc = launch_batch(e, B, R);
+    e->W.store_flags = nullptr; e->W.store_after = nullptr;
     if (rc) return rc;
+    if (sev) {
+        try { h_sflags.resize(n); h_safter.resize(n); } catch (...) { return GUBER_E_NOMEM; }
+        HIPCHK(hipMemcpyAsync(h_sflags.data(), e->d_sflags.p, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_safter.data(), e->d_safter.p, (size_t)n * sizeof(Rec), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipMemcpyAsync(o64, e->d_out64.p, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(o8, e->d_out8.p, (size_t)n * 2, hipMemcpyDeviceToHost, st));
     rc = enqueue_counter_readback(e);
@@ -457,21 +473,31 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
         const uint32_t i = idx ? idx[j] : j;
         r->status[i] = o8[j]; r->err[i] = o8[n + j];
         r->limit[i] = o64[j]; r->remaining[i] = o64[n + j]; r->reset_time[i] = o64[2 * (size_t)n + j];
+        if (sev && o8[n + j] != GUBER_ITEM_E_RETRY) {
+            sev->flags[i] = h_sflags[j];
+            if (h_sflags[j] & GUBER_STORE_ONCHANGE) {
+                item_from_rec(h_safter[j], &sev->items[i]);
+                sev->items[i].key = b->key_bytes + b->key_off[i];
+                sev->items[i].key_len = b->key_off[i + 1] - b->key_off[i];
+            }
+        }
     }
     return 0;
 }
 
-extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) {
+static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* sev) {
     if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
     int rc = check_batch_args(b, r);
     if (rc) return rc;
+    if (sev && b->n && (!sev->flags || !sev->items)) return fail(GUBER_E_INVALID_ARG, "null store event arrays");
+    if (sev && b->n) memset(sev->flags, 0, b->n);
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     const DevCounters before = e->last_ctr;
     r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0;
     if (b->n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
     if (b->n) {
-        rc = eval_host_once(e, b, r, nullptr, b->n);
+        rc = eval_host_once(e, b, r, nullptr, b->n, sev);
         if (rc) return rc;
         // two new keys sharing one 64-bit hash inside one batch: re-submit the affected items; on the
         // second pass the first key is resident and the other one probes past it.
@@ -480,7 +506,7 @@ extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber
             for (uint32_t i = 0; i < b->n; ++i) if (r->err[i] == GUBER_ITEM_E_RETRY) again.push_back(i);
             if (again.empty()) break;
             e->careful = true;
-            rc = eval_host_once(e, b, r, again.data(), (uint32_t)again.size());
+            rc = eval_host_once(e, b, r, again.data(), (uint32_t)again.size(), sev);
             e->careful = false;
             if (rc) return rc;
         }
@@ -491,6 +517,42 @@ extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber
     r->cache_misses = e->last_ctr.misses - before.misses;
     r->unexpired_evictions = e->last_ctr.evictions - before.evictions;
     r->cache_size = e->last_ctr.size;
+    return GUBER_OK;
+}
+extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) { return eval_batch_host(e, b, r, nullptr); }
+extern "C" int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* ev) {
+    if (!ev) return fail(GUBER_E_INVALID_ARG, "null store events");
+    return eval_batch_host(e, b, r, ev);
+}
+
+// Store.Get is due for a request whose key is not resident when the request is applied (algorithms.go:45-51,
+// :274-280): report the keys that are absent or expired at now_ms BEFORE the batch, so that the host can ask
+// the Store and hand what it finds to guber_add_items first.
+extern "C" int guber_probe_missing(guber_engine_t* e, const guber_batch_t* b, uint8_t* missing) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    if (!b || (b->n && (!b->key_bytes || !b->key_off || !missing))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (b->n == 0) return GUBER_OK;
+    if (b->n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    const uint32_t n = b->n;
+    const size_t kbytes = b->key_off[n] - b->key_off[0];
+    if (e->d_keys.ensure(kbytes + 16) || e->d_off.ensure(n + 1) || e->d_out8.ensure((size_t)n * 2) || e->h_stage.ensure(kbytes + 16 + (size_t)(n + 1) * 4 + n + 64))
+        return GUBER_E_NOMEM;
+    uint32_t* soff = (uint32_t*)e->h_stage.p;
+    uint8_t* skeys = e->h_stage.p + (size_t)(n + 1) * 4;
+    uint8_t* sout = skeys + ((kbytes + 16 + 7) & ~(size_t)7);
+    for (uint32_t i = 0; i <= n; ++i) soff[i] = b->key_off[i] - b->key_off[0];
+    memcpy(skeys, b->key_bytes + b->key_off[0], kbytes);
+    memset(skeys + kbytes, 0, 16);
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(e->d_keys.p, skeys, kbytes + 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_off.p, soff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_probe_missing, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_keys.p, e->d_off.p, n, b->now_ms, e->d_out8.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(sout, e->d_out8.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(missing, sout, n);
     return GUBER_OK;
 }
 

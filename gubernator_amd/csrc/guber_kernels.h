@@ -103,6 +103,9 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMPW(k) do {} while (0)
 #endif
 struct Work {
+    // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
+    // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
+    uint8_t* store_flags; Rec* store_after;
 #ifdef GUBER_PHASE_TIMING
     unsigned long long* dbg;
 #endif
@@ -155,6 +158,11 @@ __device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
 __device__ __forceinline__ void store_resp(const ResultView& R, uint32_t i, const Resp& o) {
     R.status[i] = o.status; R.limit[i] = o.limit; R.remaining[i] = o.remaining;
     R.reset_time[i] = o.reset_time; R.err[i] = o.err;
+}
+__device__ __forceinline__ void store_events(const Work& W, uint32_t i, uint32_t ev, const Rec& after) {
+    if (!W.store_flags) return;
+    W.store_flags[i] = (uint8_t)((ev >> 3) & 3u);
+    if (ev & EV_ONCHANGE) W.store_after[i] = after;
 }
 __device__ __forceinline__ void store_err(const ResultView& R, uint32_t i, uint8_t code) {
     R.status[i] = 0; R.limit[i] = 0; R.remaining[i] = 0; R.reset_time[i] = 0; R.err[i] = code;
@@ -516,6 +524,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 Rec after; Resp out;
                 const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
                 store_resp(R, i, out);
+                store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == last - first) {
                     T.buckets[slot].rec = after;
@@ -531,6 +540,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     Resp out;
                     const uint32_t ev = apply(s, rj, B.now_ms, out);
                     store_resp(R, j, out);
+                    store_events(W, j, ev, s);
                     if (out.err == 0) queue_global(T, slot, rj, 1);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
@@ -539,7 +549,6 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
             }
         }
     }
-    GB_STAMP2(3);
     const int t_over = block_sum(c_over, red), t_hit = block_sum(c_hit, red), t_miss = block_sum(c_miss, red),
               t_size = block_sum(c_size, red);
     if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
@@ -547,7 +556,6 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
         bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
         bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
     }
-    GB_STAMP2(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -902,6 +910,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
                 Rec after; Resp out;
                 const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
                 store_resp(R, i, out);
+                store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == total - 1) {
                     T.buckets[slot].rec = after;
@@ -925,6 +934,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
                             Resp out;
                             const uint32_t ev = apply(s, rj, B.now_ms, out);
                             store_resp(R, j, out);
+                            store_events(W, j, ev, s);
                             if (out.err == 0) queue_global(T, slot, rj, 1);
                             c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                         }
@@ -935,6 +945,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
             }
         }
     }
+    GB_STAMP2(3);
     const int t_over = block_sum_lds(c_over, red), t_hit = block_sum_lds(c_hit, red), t_miss = block_sum_lds(c_miss, red),
               t_size = block_sum_lds(c_size, red);
     if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
@@ -942,6 +953,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
         bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
         bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
     }
+    GB_STAMP2(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1003,6 +1015,25 @@ __global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t
     }
     if (mode == 0) atomicAdd(&T.ctr->hits, 1ull);
     *out = s; *found = 1;
+}
+
+// Read-only residency test per request key: 1 = absent or expired at `now` (what LRUCache.GetItem would report as
+// a miss, lrucache.go:111-128) — the keys a configured Store has to be asked for (algorithms.go:45-51).
+__global__ __launch_bounds__(256) void k_probe_missing(Table T, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
+                                                       int64_t now, uint8_t* missing) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+    uint8_t m = 1;
+    if (len != 0 && len <= T.max_key) {
+        uint32_t slot = 0;
+        const uint32_t pr = probe(T, key_bytes + off, len, xxhash64(key_bytes + off, len, 0), false, slot);
+        if (pr & PR_FOUND) {
+            const Rec s = T.buckets[slot].rec;
+            m = (rec_kind(s) == K_ABSENT || rec_expired(s, now)) ? 1 : 0;
+        }
+    }
+    missing[i] = m;
 }
 
 // LRUCache.Each (lrucache.go:76-85): compact every resident bucket (+ its key cell) into out arrays

@@ -1,6 +1,7 @@
 // worker_pool.cpp — see worker_pool.h.
 #include "worker_pool.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -114,7 +115,48 @@ void GPUWorkerPool::flush(std::vector<Pending>& batch) {
     if (any_greg) { b.greg_expire = gexp.data(); b.greg_duration = gdur.data(); }
     res.status = status.data(); res.limit = rlimit.data(); res.remaining = rremaining.data(); res.reset_time = rreset.data();
     res.err = err.data();
-    const int rc = guber_eval_batch(engine_, &b, &res);
+    // Config.Store (store.go:49-65): ask the store for keys that are not resident BEFORE the batch
+    // (algorithms.go:45-51 `s.Get` on a cache miss, then `c.Add(item)`), evaluate, then issue the Remove / OnChange
+    // calls the reference makes from inside the algorithms, in request order.
+    std::vector<uint8_t> sflags; std::vector<guber_item_t> sitems;
+    guber_store_events_t sev{nullptr, nullptr};
+    auto store_req = [&](uint32_t i) {
+        const RateLimitReq& r = *batch[i].req;
+        guber_store_req_t q{};
+        q.key = keys.data() + off[i]; q.key_len = off[i + 1] - off[i]; q.name_len = (uint32_t)r.name.size();
+        q.hits = r.hits; q.limit = r.limit; q.duration = r.duration; q.burst = r.burst; q.created_at = created[i];
+        q.algorithm = r.algorithm; q.behavior = r.behavior;
+        return q;
+    };
+    int rc = GUBER_OK;
+    if (has_store_) {
+        std::vector<uint8_t> missing(n, 0);
+        rc = guber_probe_missing(engine_, &b, missing.data());
+        if (rc == GUBER_OK && store_.get) {
+            std::vector<std::string> asked;
+            for (uint32_t i = 0; i < n && rc == GUBER_OK; ++i) {
+                if (!missing[i] || off[i + 1] == off[i]) continue;
+                std::string k((const char*)keys.data() + off[i], off[i + 1] - off[i]);
+                if (std::find(asked.begin(), asked.end(), k) != asked.end()) continue;
+                asked.push_back(k);
+                guber_item_t it{};
+                const guber_store_req_t q = store_req(i);
+                if (store_.get(store_.user, &q, &it)) {
+                    it.key = (const uint8_t*)k.data(); it.key_len = (uint32_t)k.size();
+                    rc = guber_add_items(engine_, &it, 1, nullptr);
+                }
+            }
+        }
+        sflags.assign(n, 0); sitems.resize(n);
+        sev.flags = sflags.data(); sev.items = sitems.data();
+    }
+    if (rc == GUBER_OK) rc = has_store_ ? guber_eval_batch_store(engine_, &b, &res, &sev) : guber_eval_batch(engine_, &b, &res);
+    if (rc == GUBER_OK && has_store_) {
+        for (uint32_t i = 0; i < n; ++i) {
+            if ((sflags[i] & GUBER_STORE_REMOVE) && store_.remove) store_.remove(store_.user, keys.data() + off[i], off[i + 1] - off[i]);
+            if ((sflags[i] & GUBER_STORE_ONCHANGE) && store_.on_change) { const guber_store_req_t q = store_req(i); store_.on_change(store_.user, &q, &sitems[i]); }
+        }
+    }
     flushed_++;
     for (uint32_t i = 0; i < n; ++i) {
         RateLimitResp& o = *batch[i].resp;
@@ -191,6 +233,7 @@ extern "C" void guber_pool_destroy(guber_pool_t* p) {
     p->pool->Close();
     delete p->inst; delete p->pool; delete p;
 }
+extern "C" void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb) { if (p) p->pool->SetStore(cb); }
 extern "C" void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms) { if (p) p->pool->SetClockMs(now_ms); }
 extern "C" guber_engine_t* guber_pool_engine(guber_pool_t* p) { return p ? p->pool->engine() : nullptr; }
 extern "C" uint64_t guber_pool_batches(guber_pool_t* p) { return p ? p->pool->batches_flushed() : 0; }

@@ -52,6 +52,8 @@ class GPUWorkerPool {
     int64_t Size();
     void Close();                                                                // workers.go:157
     // clock.Freeze / clock.Advance of the reference's tests: 0 = wall clock
+    // Config.Store (config.go:99, store.go:49-65): call before the first request; nullptr = none
+    void SetStore(const guber_store_callbacks_t* cb) { has_store_ = cb != nullptr; if (cb) store_ = *cb; }
     void SetClockMs(int64_t now_ms) { frozen_ms_ = now_ms; }
     int64_t NowMs() const;
     guber_engine_t* engine() { return engine_; }
@@ -73,6 +75,8 @@ class GPUWorkerPool {
     std::thread thread_;
     volatile int64_t frozen_ms_ = 0;
     uint64_t flushed_ = 0;
+    bool has_store_ = false;
+    guber_store_callbacks_t store_{};
 };
 
 class V1Instance {

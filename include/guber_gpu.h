@@ -206,6 +206,30 @@ int64_t guber_size(guber_engine_t* e);
 int guber_dump(guber_engine_t* e, guber_item_t* items, uint64_t cap, uint8_t* key_arena,
                uint64_t arena_cap, uint64_t* n_out, uint64_t* arena_out);
 
+/* ---- Config.Store (store.go:49-65), the persistent write-through store.  The reference calls, from inside
+ *      the algorithms: Store.Get on a cache miss (algorithms.go:45-51, :274-280), Store.OnChange(r, item) after
+ *      a request was applied when the node owns the key — `item` = the CacheItem as it is AFTER that request
+ *      (deferred at :149-153 / :382-386, direct at :252-254 / :488-490) — and Store.Remove(key) when an item is
+ *      dropped for RESET_REMAINING (token, :79-84) or because the algorithm changed (:96-100, :311-315).
+ *      These are user Go code, so they stay on the host; the engine tells the host WHICH calls are due:
+ *        1. guber_probe_missing  -> missing[i] = 1: the key of request i is not resident (absent or expired
+ *           at now_ms).  The host asks Store.Get for the first request of each such key and hands what it
+ *           finds to guber_add_items (= `c.Add(item)`, algorithms.go:49).
+ *        2. guber_eval_batch_store = guber_eval_batch + per request i: flags[i] (GUBER_STORE_*) and, when
+ *           GUBER_STORE_ONCHANGE is set, items[i] = the item right after request i (exact also for requests
+ *           in the middle of a run on one key; items[i].key points into the batch's key_bytes).
+ *           The host then issues, in request order: Remove (if flagged), then OnChange (if flagged).
+ *      Divergence: an item the Store returns that is already expired at now_ms is treated as absent (the
+ *      reference would use it without re-checking IsExpired). */
+#define GUBER_STORE_ONCHANGE 1
+#define GUBER_STORE_REMOVE 2
+typedef struct guber_store_events {
+    uint8_t* flags;          /* n */
+    guber_item_t* items;     /* n */
+} guber_store_events_t;
+int guber_probe_missing(guber_engine_t* e, const guber_batch_t* b, uint8_t* missing);
+int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* ev);
+
 /* ---- bounded cache: the reference keeps at most CacheSize items and evicts the least recently used
  *      (lrucache.go:98-100,138-149).  The HBM table instead drops every bucket that is expired at now_ms
  *      or was removed, by rebuilding itself (also done automatically when the directory passes 7/8 full).
@@ -259,7 +283,22 @@ int guber_global_take(guber_engine_t* e, uint32_t role_mask /* bit 1: hits rows,
 typedef struct guber_pool guber_pool_t;
 int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out);
 void guber_pool_destroy(guber_pool_t* p);
-void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms);   /* clock.Freeze of the reference tests; 0 = wall clock */
+void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms);
+/* Config.Store for the pool: the batcher drives guber_probe_missing / guber_add_items / guber_eval_batch_store and
+ * calls back in the reference's order.  The request view carries what the reference hands to Store.Get /
+ * Store.OnChange (`r *RateLimitReq`): key = name + "_" + unique_key, name = key[0..name_len). */
+typedef struct guber_store_req {
+    const uint8_t* key; uint32_t key_len; uint32_t name_len;
+    int64_t hits, limit, duration, burst, created_at;
+    int32_t algorithm; uint32_t behavior;
+} guber_store_req_t;
+typedef struct guber_store_callbacks {
+    int (*get)(void* user, const guber_store_req_t* r, guber_item_t* out);            /* 1 = found, *out filled (key ignored) */
+    void (*on_change)(void* user, const guber_store_req_t* r, const guber_item_t* item);
+    void (*remove)(void* user, const uint8_t* key, uint32_t key_len);
+    void* user;
+} guber_store_callbacks_t;
+void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb);      /* before the first request; NULL = none */   /* clock.Freeze of the reference tests; 0 = wall clock */
 guber_engine_t* guber_pool_engine(guber_pool_t* p);
 uint64_t guber_pool_batches(guber_pool_t* p);
 /* names / unique keys as SoA strings; created_at[i] = 0 means unset; err_text (optional) receives the

@@ -41,7 +41,13 @@ class MockStore:
 
     def get(self, req_index, key):
         self.calls.append(("get", req_index, key))
-        return self.items.get(key)
+        d = self.items.get(key)
+        # "It's up to the store to expire old rate limit items" (store.go:52-53): a write-through store drops them
+        now = getattr(self, "now", None)
+        if d is not None and self.write_through and now is not None and \
+                (d.get("expire_at", 0) < now or (d.get("invalid_at", 0) and d["invalid_at"] < now)):
+            return None
+        return d
 
     def on_change(self, req_index, key, item):
         self.calls.append(("on_change", req_index, key, item))

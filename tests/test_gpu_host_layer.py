@@ -146,3 +146,37 @@ def test_aggregated_rpc_payloads_match_the_oracle_on_the_gpu():
             assert len(m.responses) == count
         now += 7
     e.close()
+
+
+def test_store_callbacks_through_the_pool_teststore():
+    """store_test.go TestStore through the C++ pool: Config.Store as C callbacks (guber_pool_set_store); the batcher
+    must call Get on the miss, Remove for a foreign Value, OnChange with the item after the request."""
+    import scenarios
+    import support
+
+    class PoolBackend:
+        def __init__(self):
+            self.inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+
+        def eval_store(self, batch, store):
+            # adapter: MockStore speaks (req_index, key); the pool hands (req dict, key)
+            class A:
+                def get(_s, r, key): return store.get(0, key)
+                def on_change(_s, r, key, item): store.on_change(0, key, item)
+                def remove(_s, r, key): store.remove(0, key)
+            self.inst.set_clock(batch.now_ms)
+            self.inst.set_store(A())
+            keys = [support.batch_key(batch, i) for i in range(batch.n)]
+            reqs = [dict(name=k.split("_account")[0], unique_key="account" + k.split("_account")[1], hits=int(batch.hits[i]),
+                         limit=int(batch.limit[i]), duration=int(batch.duration[i]), algorithm=int(batch.algorithm[i]),
+                         behavior=int(batch.behavior[i]), burst=int(batch.burst[i])) for i, k in enumerate(keys)]
+            out = self.inst.GetRateLimits(reqs)
+            res = support.HostResult(batch.n)
+            for i, o in enumerate(out):
+                assert o["error"] == ""
+                res.status[i], res.limit[i], res.remaining[i], res.reset_time[i], res.err[i] = o["status"], o["limit"], o["remaining"], o["reset_time"], 0
+            return res
+
+        def close(self):
+            self.inst.close()
+    assert scenarios.run_store_events(PoolBackend) == 10

@@ -340,3 +340,49 @@ def test_compaction_keeps_churning_key_sets_going():
     support.assert_results_equal(e.eval(b), o.eval(b), "after compaction")
     assert sorted(d["key"] for d in e.each()) == sorted(f"steady_{i}".encode() for i in range(100))
     e.close()
+
+
+def test_store_events_golden_teststore():
+    """store_test.go TestStore on the engine: guber_probe_missing -> Store.Get -> guber_add_items ->
+    guber_eval_batch_store -> Remove / OnChange, the call sequence and the OnChange item of the reference's mock."""
+    assert scenarios.run_store_events(lambda: engine(cache_size=4096, max_batch=1024)) == 10
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_store_events_match_the_oracle_on_random_batches(flags):
+    """Every request's Store callbacks (which, in which order, and the CacheItem handed to OnChange — the state right
+    after THAT request, also in the middle of a run on a hot key) equal the reference restatement's."""
+    rng = np.random.default_rng(77 + flags)
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=1 << 14, max_batch=8192, flags=flags)
+    so, se = support.MockStore(write_through=True), support.MockStore(write_through=True)
+    now = streams.NOW0
+    for step in range(12):
+        n = int(rng.integers(1, 3000))
+        kid = rng.zipf(1.3, n) % 400
+        # per key one request shape per batch half, so that hot keys form long uniform runs as well as mixed ones
+        shape = rng.integers(0, 6, 400)
+        mixed = rng.random(n) < 0.15
+        algo = np.where(mixed, rng.integers(0, 2, n), shape[kid] & 1).astype(np.uint8)
+        beh = np.where(mixed, rng.choice([0, 8, 32, 0, 0], n), np.where(shape[kid] == 5, 32, 0)).astype(np.uint32)
+        hits = np.where(mixed, rng.integers(0, 4, n), 1).astype(np.int64)
+        owner = np.where(rng.random(n) < 0.1, 0, 1).astype(np.uint8) if step % 3 == 2 else np.ones(n, np.uint8)
+        keys = [b"st_k%d" % k for k in kid]
+        b = HostBatch(keys, hits, 20 + (kid % 7), np.where(kid % 11 == 0, 3, 60_000), now, algorithm=algo, behavior=beh, is_owner=owner,
+                      burst=np.zeros(n, np.int64), created_at=np.full(n, now))
+        for st in (so, se):
+            st.calls.clear()
+            st.now = now
+        ro, re_ = o.eval_store(b, so), e.eval_store(b, se)
+        support.assert_results_equal(re_, ro, f"store batch {step}")
+        pick = lambda st, kinds: [c for c in st.calls if c[0] in kinds]
+        assert pick(se, ("on_change", "remove")) == pick(so, ("on_change", "remove")), f"batch {step}"
+        # Store.Get: the engine asks once per non-resident key, before the batch; the reference asks again when a key is
+        # requested after an in-batch token RESET_REMAINING dropped it (documented divergence, the answer cannot differ
+        # for a store that honours Remove)
+        first_req = {}
+        for i, k in enumerate(keys):
+            first_req.setdefault(k.decode(), i)
+        want = [c for c in pick(so, ("get",)) if first_req[c[2]] == c[1]]
+        assert sorted(pick(se, ("get",))) == sorted(want), f"batch {step}"
+        now += int(rng.choice([1, 2, 5, 4000]))
+    e.close()
