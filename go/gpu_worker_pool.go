@@ -63,6 +63,9 @@ type GPUWorkerPool struct {
 	behavior                                *C.uint32_t
 	status, errCode                         *C.uint8_t
 	rLimit, rRemaining, rReset              *C.int64_t
+	// Config.Store side channel (only allocated when conf.Store != nil)
+	missing, storeFlags *C.uint8_t
+	storeItems          *C.guber_item_t
 }
 
 func NewGPUWorkerPool(conf *Config, device int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
@@ -81,6 +84,10 @@ func NewGPUWorkerPool(conf *Config, device int, batchLimit int, batchWait time.D
 	p.algorithm, p.isOwner = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
 	p.status, p.errCode = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
 	p.behavior = (*C.uint32_t)(C.guber_alloc_pinned(n * 4))
+	if conf.Store != nil {
+		p.missing, p.storeFlags = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
+		p.storeItems = (*C.guber_item_t)(C.guber_alloc_pinned(n * C.sizeof_guber_item_t))
+	}
 	go p.run(batchLimit, batchWait)
 	return p, nil
 }
@@ -170,7 +177,12 @@ func (p *GPUWorkerPool) flush(batch []gpuRequest) {
 		duration: p.duration, burst: p.burst, created_at: p.createdAt, algorithm: p.algorithm, behavior: p.behavior,
 		is_owner: p.isOwner, greg_expire: p.gregExpire, greg_duration: p.gregDuration, now_ms: C.int64_t(nowMs)}
 	res := C.guber_result_t{status: p.status, limit: p.rLimit, remaining: p.rRemaining, reset_time: p.rReset, err: p.errCode}
-	rc := C.guber_eval_batch(p.engine, &b, &res)
+	var rc C.int
+	if p.conf.Store == nil {
+		rc = C.guber_eval_batch(p.engine, &b, &res)
+	} else {
+		rc = p.evalWithStore(batch, &b, &res)
+	}
 	// prometheus: the engine returns the per-batch aggregates of the reference's counters
 	metricOverLimitCounter.Add(float64(res.over_limit_count))             // algorithms.go:165,185,243,391,409,471
 	metricCacheAccess.WithLabelValues("hit").Add(float64(res.cache_hits)) // lrucache.go:117,121,126
@@ -192,6 +204,50 @@ func (p *GPUWorkerPool) flush(batch []gpuRequest) {
 		g.resp <- gpuResponse{&RateLimitResp{Status: Status(*at8(p.status, i)), Limit: int64(*at64(p.rLimit, i)),
 			Remaining: int64(*at64(p.rRemaining, i)), ResetTime: int64(*at64(p.rReset, i))}, nil}
 	}
+}
+
+// evalWithStore is the Config.Store path (store.go:49-65).  The reference calls the store from inside the
+// algorithms; here the engine reports which calls are due and this function makes them, in the same order:
+//   Store.Get      for the first request of every key that is not resident before the batch (algorithms.go:45-51)
+//   Store.Remove   token RESET_REMAINING / algorithm switched                                 (:79-84, :96-100, :311-315)
+//   Store.OnChange with the CacheItem as it is right after THAT request, owner only           (:149-153, :252-254, ...)
+func (p *GPUWorkerPool) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, res *C.guber_result_t) C.int {
+	ctx := context.Background()
+	if rc := C.guber_probe_missing(p.engine, b, p.missing); rc != C.GUBER_OK {
+		return rc
+	}
+	asked := map[string]struct{}{}
+	for i, g := range batch {
+		if *at8(p.missing, i) == 0 {
+			continue
+		}
+		key := g.req.HashKey()
+		if _, dup := asked[key]; dup {
+			continue
+		}
+		asked[key] = struct{}{}
+		if item, ok := p.conf.Store.Get(ctx, g.req); ok {
+			if err := p.AddCacheItem(ctx, key, item); err != nil {
+				return C.GUBER_E_HIP
+			}
+		}
+	}
+	ev := C.guber_store_events_t{flags: p.storeFlags, items: p.storeItems}
+	rc := C.guber_eval_batch_store(p.engine, b, res, &ev)
+	if rc != C.GUBER_OK {
+		return rc
+	}
+	for i, g := range batch {
+		f := *at8(p.storeFlags, i)
+		if f&C.GUBER_STORE_REMOVE != 0 {
+			p.conf.Store.Remove(ctx, g.req.HashKey())
+		}
+		if f&C.GUBER_STORE_ONCHANGE != 0 {
+			ci := (*C.guber_item_t)(unsafe.Add(unsafe.Pointer(p.storeItems), i*C.sizeof_guber_item_t))
+			p.conf.Store.OnChange(ctx, g.req, fromCItem(g.req.HashKey(), ci))
+		}
+	}
+	return C.GUBER_OK
 }
 
 // AddCacheItem = LRUCache.Add through the engine (UpdatePeerGlobals, gubernator.go:425-459).
