@@ -112,6 +112,24 @@ GB_HD bool created_at_irrelevant(const Rec& s0, const Req& r, int64_t now) {
            !(r.behavior & BH_RESET_REMAINING) && s0.duration == r.duration;
 }
 
+// leakyBucket reads r.CreatedAt in three places: the leak since UpdatedAt (algorithms.go:361-367), UpdateExpiration
+// (:356-358) and the response's ResetTime.  For a LIVE leaky bucket and a request that neither resets nor uses the
+// calendar, a request whose created_at lies less than one token interval after UpdatedAt leaks nothing
+// (`int64(leak) > 0` is false), so Remaining / UpdatedAt evolve exactly as for any other such created_at; the
+// expiration is "the last hit wins" (each request writes created_at + duration itself) and ResetTime is computed
+// from the request's own created_at.  If every request of a run on one key is harmless in this sense, the run
+// behaves like a run of identical requests as far as the bucket is concerned, and each request can evaluate
+// itself with its own created_at.  The second guard keeps UpdateExpiration from making the bucket look expired to
+// the requests that follow in the same batch.
+GB_HD bool leaky_created_harmless(const Rec& s0, const Req& r, int64_t now) {
+    if (r.algorithm != ALGO_LEAKY || rec_kind(s0) != K_LEAKY || rec_expired(s0, now)) return false;
+    if ((r.behavior & (BH_RESET_REMAINING | BH_GREGORIAN)) || r.limit <= 0 || r.duration <= 0) return false;
+    const double rate = (double)r.duration / (double)r.limit;
+    const double leak = (double)wsub(r.created_at, s0.stamp) / rate;
+    if (go_f2i(leak) > 0) return false;
+    return wadd(r.created_at, r.duration) >= now;
+}
+
 struct Resp {
     int64_t limit, remaining, reset_time;
     uint8_t status, err;

@@ -755,7 +755,14 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 // entry created during this launch: prove key equality against the claimer's request
                 if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
                 const Req a = load_req(B, g), b = load_req(B, d);
-                if (!req_eq(a, b)) atomicOr(&seg_flags[d], req_eq_but_created(a, b) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM);
+                if (!req_eq(a, b)) {
+                    // created_at-only differences keep the parallel path when created_at cannot matter: decided in
+                    // k_eval2 for token buckets; a leaky request must leak nothing (checked here against the bucket
+                    // as it is before the batch; the claimer's own created_at is checked in k_eval2)
+                    bool soft = req_eq_but_created(a, b);
+                    if (soft && a.algorithm == ALGO_LEAKY) soft = leaky_created_harmless(rec, a, B.now_ms);
+                    atomicOr(&seg_flags[d], soft ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM);
+                }
             }
         }
         W.did[g] = d; W.rflags[g] = rf;
@@ -902,10 +909,20 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
             const uint32_t rank = base + (lr & 0xffu);
             const uint32_t slot = s0.pad;
             s0.pad = 0;
-            // requests differing only in created_at still take the parallel path when created_at is never read
-            const bool parallel = !(sf & SEG_NONUNIFORM) &&
-                                  (!(sf & SEG_CREATED_DIFFERS) ||
-                                   (created_at_irrelevant(s0, r, B.now_ms) && !(T.gpend && (r.behavior & BH_GLOBAL))));
+            // requests differing only in created_at still take the parallel path when created_at cannot matter: live
+            // token bucket (never read), or live leaky bucket where no request of the run leaks (the other members
+            // were checked in k_front; the claimer's created_at is checked here, identically by every member)
+            bool parallel = !(sf & SEG_NONUNIFORM);
+            if (parallel && (sf & SEG_CREATED_DIFFERS)) {
+                parallel = !(T.gpend && (r.behavior & BH_GLOBAL));
+                if (parallel && r.algorithm == ALGO_LEAKY) {
+                    Req rc = r;
+                    rc.created_at = B.created_at ? B.created_at[d] : B.now_ms;
+                    parallel = leaky_created_harmless(s0, rc, B.now_ms) && leaky_created_harmless(s0, r, B.now_ms);
+                } else if (parallel) {
+                    parallel = created_at_irrelevant(s0, r, B.now_ms);
+                }
+            }
             if (parallel) {
                 Rec after; Resp out;
                 const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);

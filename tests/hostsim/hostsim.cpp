@@ -17,6 +17,7 @@ struct HostSim {
     std::unordered_map<std::string, Rec> table;
     uint64_t over = 0, hits = 0, misses = 0;
     int64_t size = 0;
+    uint64_t par_segs = 0, ser_segs = 0;
 };
 
 static Req load_req(const guber_batch_t* b, uint32_t i) {
@@ -38,6 +39,8 @@ static void store(guber_result_t* res, uint32_t i, const Resp& rl) {
 
 extern "C" {
 void* hs_create() { return new HostSim(); }
+// multi-request segments evaluated on the parallel (closed-form) path / walked serially
+void hs_path_counts(void* h, uint64_t* out) { out[0] = ((HostSim*)h)->par_segs; out[1] = ((HostSim*)h)->ser_segs; }
 void hs_destroy(void* h) { delete (HostSim*)h; }
 
 // mode 0: pipeline emulation (uniform -> per-rank closed form, else serial); mode 1: force serial
@@ -62,8 +65,16 @@ int hs_eval_batch(void* hp, const guber_batch_t* b, guber_result_t* res, int mod
             Req rj = load_req(b, idx[j]);
             if (!req_eq(rj, r0)) { uniform = false; if (!req_eq_but_created(rj, r0)) { created_only = false; break; } }
         }
-        if (!uniform && created_only && created_at_irrelevant(s0, r0, b->now_ms)) uniform = true;
+        if (!uniform && created_only) {
+            if (created_at_irrelevant(s0, r0, b->now_ms)) uniform = true;          // live token bucket
+            else if (r0.algorithm == ALGO_LEAKY && !(r0.behavior & BH_GLOBAL)) {   // live leaky bucket, nobody leaks
+                bool ok = true;
+                for (size_t j = 0; j < idx.size() && ok; j++) ok = leaky_created_harmless(s0, load_req(b, idx[j]), b->now_ms);
+                uniform = ok;
+            }
+        }
         Rec fin = s0;
+        if (idx.size() > 1) { if (uniform && mode == 0) h->par_segs++; else h->ser_segs++; }
         if (uniform && mode == 0) {
             for (size_t j = 0; j < idx.size(); j++) {
                 Req r = load_req(b, idx[j]);

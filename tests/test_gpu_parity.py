@@ -386,3 +386,34 @@ def test_store_events_match_the_oracle_on_random_batches(flags):
         assert sorted(pick(se, ("get",))) == sorted(want), f"batch {step}"
         now += int(rng.choice([1, 2, 5, 4000]))
     e.close()
+
+
+@pytest.mark.parametrize("flags", [0, 2])
+def test_created_at_only_variation_on_hot_leaky_keys(flags):
+    """Hot LEAKY keys whose requests carry slightly different created_at (aggregated RPC payloads): parallel path
+    while no request leaks (leaky_created_harmless), serial otherwise; bit-exact either way."""
+    rng = np.random.default_rng(23 + flags)
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=1 << 14, max_batch=16384, flags=flags)
+    t = streams.NOW0
+    for step in range(16):
+        n = int(rng.integers(2000, 12000))
+        kid = rng.zipf(1.2, n) % 50
+        dur = np.where(kid % 5 == 0, 3, 60_000)
+        kind = step % 8
+        slice_of = np.arange(n) // 1000                                      # one RPC payload = 1000 items
+        created = t - 2 + slice_of % 4                                       # harmless: RPCs stamped 0..3 ms apart
+        if kind == 2:
+            created = created + np.where(rng.random(n) < 0.001, 700, 0)      # a few members leak
+        elif kind == 3:
+            created = np.where(rng.random(n) < 0.001, t - 700_000, created)  # far in the past
+        elif kind == 4:
+            created = t + rng.integers(-2000, 2000, n)
+        elif kind == 5:
+            created[np.unique(kid, return_index=True)[1]] += 200_000         # the first toucher of every key is the odd one
+        hits = np.where(kind == 6, 0, 1)
+        b = HostBatch([b"hl_%d" % k for k in kid], hits, 100 + kid % 3, dur, t, created_at=created,
+                      algorithm=np.where(kid % 7 == 3, 0, 1).astype(np.uint8), behavior=np.where(step == 9, 32, 0).astype(np.uint32))
+        support.assert_results_equal(e.eval(b), o.eval(b), f"step {step} kind {kind}")
+        assert e.size() == o.size()
+        t += int(rng.choice([1, 3, 50, 30_001, 120_000]))
+    e.close()

@@ -29,6 +29,8 @@ def hostsim_lib():
         lib = C.CDLL(so)
         lib.hs_create.restype = C.c_void_p
         lib.hs_destroy.argtypes = [C.c_void_p]
+        lib.hs_path_counts.argtypes = [C.c_void_p, C.c_void_p]
+        lib.hs_path_counts.restype = None
         lib.hs_eval_batch.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int]
         lib.hs_add_item.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.POINTER(C.c_int)]
         lib.hs_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
@@ -60,6 +62,12 @@ class HostSim:
         res = HostResult(batch.n)
         self.lib.hs_eval_batch(self.h, C.byref(batch.c), C.byref(res.c), self.mode)
         return res
+
+    def path_counts(self):
+        """(multi-request segments on the parallel closed-form path, walked serially)"""
+        out = (C.c_uint64 * 2)()
+        self.lib.hs_path_counts(self.h, out)
+        return out[0], out[1]
 
     def add_item(self, item, now_ms=0):
         ex = C.c_int(0)
@@ -193,3 +201,41 @@ def test_created_at_only_variation_on_hot_token_keys():
             dur = 60_000 if step != 3 else 30_000        # step 3 changes the duration -> created_at matters
             b = HostBatch(keys, 1, 5000, dur, now + step * 400 + 2, created_at=created, algorithm=algo, behavior=beh)
             support.assert_results_equal(h.eval(b), o.eval(b), f"algo {algo} step {step}")
+
+
+def test_created_at_only_variation_on_hot_leaky_keys():
+    """Aggregated RPC payloads stamp a hot LEAKY key's requests a few ms apart.  The run stays on the parallel path
+    only while no request leaks and none pulls the expiration before the batch clock (leaky_created_harmless);
+    every mix — harmless, one leaking member in the middle, created_at far in the past / future, tiny durations,
+    fresh and expired buckets — must equal the oracle bit for bit."""
+    rng = np.random.default_rng(23)
+    now = streams.NOW0
+    cases, paths = 0, []
+    for dur, limit in ((60_000, 100), (1000, 100_000), (3, 10), (60_000, 7)):
+        o, h = Oracle(cache_size=1 << 12), HostSim(mode=0)
+        t = now
+        for step in range(14):
+            n = int(rng.integers(2, 700))
+            kind = step % 7
+            base = t - int(rng.integers(0, 3))
+            created = base + np.sort(rng.integers(0, 4, n))                 # harmless: within a few ms
+            if kind == 2:
+                created[n // 2] += int(rng.choice([dur, 10 * dur, 700, 5]))     # one member leaks (or not, by rate)
+            elif kind == 3:
+                created[rng.integers(0, n)] = t - 10 * dur - 5                   # far in the past: expiry guard
+            elif kind == 4:
+                created = t + rng.integers(-2000, 2000, n)                       # unsorted, wide
+            elif kind == 5:
+                created[0] += 3 * dur                                            # the claimer itself is the odd one
+            hits = 1 if kind != 6 else 0
+            b = HostBatch([b"hot_leaky"] * n, hits, limit, dur, t, created_at=created, algorithm=1,
+                          behavior=32 if step == 9 else 0)
+            support.assert_results_equal(h.eval(b), o.eval(b), f"dur {dur} limit {limit} step {step} kind {kind}")
+            assert h.size() == o.size()
+            t += int(rng.choice([1, 3, 50, dur // 2 + 1, 2 * dur]))
+            cases += 1
+        par, ser = h.path_counts()
+        paths.append((par, ser))
+        o.close(); h.close()
+    assert cases == 56
+    assert sum(p for p, _ in paths) >= 12 and sum(s_ for _, s_ in paths) >= 12, paths   # both paths exercised
