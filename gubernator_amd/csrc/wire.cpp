@@ -36,14 +36,28 @@ inline bool get_varint(const uint8_t*& p, const uint8_t* end, uint64_t& v) {
     }
     return false;                                              // longer than 10 bytes
 }
-inline bool skip_field(const uint8_t*& p, const uint8_t* end, uint32_t wt) {
+// Skip one unknown field whose tag (field number `field`, wire type `wt`) has just been read.  Groups (wire
+// types 3 / 4, proto2 leftovers) are skipped the way the protobuf runtimes do: everything up to the matching
+// END_GROUP tag of the same field number, nested groups included.
+inline bool skip_field(const uint8_t*& p, const uint8_t* end, uint32_t wt, uint64_t field, int depth = 0) {
     uint64_t v;
     switch (wt) {
     case 0: return get_varint(p, end, v);
     case 1: if (end - p < 8) return false; p += 8; return true;
     case 2: if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return false; p += v; return true;
     case 5: if (end - p < 4) return false; p += 4; return true;
-    default: return false;                                     // groups (3/4) do not occur in these messages
+    case 3:
+        if (depth > 64) return false;
+        for (;;) {
+            uint64_t tag;
+            if (!get_varint(p, end, tag)) return false;
+            const uint32_t w2 = (uint32_t)(tag & 7);
+            const uint64_t f2 = tag >> 3;
+            if (f2 == 0 || f2 > 0x1fffffffull) return false;
+            if (w2 == 4) return f2 == field;                    // END_GROUP must close THIS group
+            if (!skip_field(p, end, w2, f2, depth + 1)) return false;
+        }
+    default: return false;                                     // stray END_GROUP, wire types 6 / 7
     }
 }
 // proto3 string fields must be valid UTF-8 (the Go runtime rejects the message otherwise)
@@ -80,7 +94,7 @@ bool parse_req(const uint8_t* p, const uint8_t* end, ReqFields& f) {
         if (!get_varint(p, end, tag)) return false;
         const uint32_t wt = (uint32_t)(tag & 7);
         const uint64_t field = tag >> 3;
-        if (field == 0) return false;
+        if (field == 0 || field > 0x1fffffffull) return false;
         if ((field == 1 || field == 2) && wt == 2) {
             if (!get_varint(p, end, v) || (uint64_t)(end - p) < v || v > 0xffffffffull) return false;
             if (!valid_utf8(p, (uint32_t)v)) return false;
@@ -98,7 +112,26 @@ bool parse_req(const uint8_t* p, const uint8_t* end, ReqFields& f) {
             case 8: f.burst = (int64_t)v; break;
             case 10: f.created_at = (int64_t)v; break;
             }
-        } else if (!skip_field(p, end, wt)) {
+        } else if (field == 9 && wt == 2) {
+            // metadata map entry (string key = 1, string value = 2): not used on the path, but a malformed entry makes
+            // the runtimes reject the whole message, so its structure and UTF-8 are checked
+            if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return false;
+            const uint8_t* q = p; const uint8_t* qe = p + v;
+            while (q < qe) {
+                uint64_t t2, l2;
+                if (!get_varint(q, qe, t2)) return false;
+                const uint32_t w2 = (uint32_t)(t2 & 7);
+                const uint64_t f2 = t2 >> 3;
+                if (f2 == 0 || f2 > 0x1fffffffull) return false;
+                if ((f2 == 1 || f2 == 2) && w2 == 2) {
+                    if (!get_varint(q, qe, l2) || (uint64_t)(qe - q) < l2 || l2 > 0xffffffffull || !valid_utf8(q, (uint32_t)l2)) return false;
+                    q += l2;
+                } else if (!skip_field(q, qe, w2, f2)) {
+                    return false;
+                }
+            }
+            p = qe;
+        } else if (!skip_field(p, end, wt, field)) {
             return false;
         }
     }
@@ -189,7 +222,7 @@ extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* 
             uint64_t tag, v;
             if (!get_varint(p, end, tag)) return GUBER_E_WIRE_MALFORMED;
             const uint32_t wt = (uint32_t)(tag & 7);
-            if ((tag >> 3) == 0) return GUBER_E_WIRE_MALFORMED;
+            if ((tag >> 3) == 0 || (tag >> 3) > 0x1fffffffull) return GUBER_E_WIRE_MALFORMED;
             if ((tag >> 3) == 1 && wt == 2) {
                 if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return GUBER_E_WIRE_MALFORMED;
                 ReqFields f;
@@ -197,7 +230,7 @@ extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* 
                 p += v;
                 if (f.unique_key.n && f.name.n) key_bytes += (uint64_t)f.name.n + 1 + f.unique_key.n;
                 items.push_back(f);
-            } else if (!skip_field(p, end, wt)) {
+            } else if (!skip_field(p, end, wt, tag >> 3)) {
                 return GUBER_E_WIRE_MALFORMED;
             }
         }

@@ -233,3 +233,121 @@ def test_golden_functional_scenarios_through_the_wire_with_the_oracle():
         return evaluate, (lambda: None)
     n = wire_replay.run_functional_wire(lambda: gw.WireBatch(2048, 1 << 16), make_eval)
     assert n >= 80
+
+
+def _decode_or_none(wb, payload):
+    wb.reset(NOW)
+    try:
+        first, count = wb.decode(payload)
+    except ga.GuberError as e:
+        assert e.code == gw.E_WIRE_MALFORMED, e
+        assert len(wb) == 0
+        return None
+    return wb.arrays()
+
+
+def _reference_view(payload):
+    m = PB["GetRateLimitsReq"]()
+    try:
+        m.ParseFromString(payload)
+    except Exception:
+        return None
+    return m
+
+
+def _has_overflowing_varint(buf, depth=0, known_nested=(1,)):
+    """True when some varint of the message occupies 10 bytes with a last byte >= 2 (more than 64 bits).  The
+    reference's runtime (google.golang.org/protobuf v1.32.0, go.mod:32: protowire.ConsumeVarint) rejects such
+    input as overflow — and so does the transcoder — while the python runtime truncates silently.  Only called on
+    payloads the python runtime accepted, so the structure is known to be walkable."""
+    pos = 0
+
+    def varint():
+        nonlocal pos
+        n = 0
+        while True:
+            c = buf[pos]; pos += 1; n += 1
+            if not c & 0x80:
+                return n == 10 and c >= 2
+    while pos < len(buf):
+        start = pos
+        if varint():
+            return True
+        tag = 0
+        for k, c in enumerate(buf[start:pos]):
+            tag |= (c & 0x7f) << (7 * k)
+        wt, field = tag & 7, tag >> 3
+        if wt == 0:
+            if varint():
+                return True
+        elif wt == 1:
+            pos += 8
+        elif wt == 5:
+            pos += 4
+        elif wt == 2:
+            s0 = pos
+            if varint():
+                return True
+            ln = 0
+            for k, c in enumerate(buf[s0:pos]):
+                ln |= (c & 0x7f) << (7 * k)
+            body = buf[pos:pos + ln]
+            pos += ln
+            # nested messages the schema knows: requests (1) at the top, metadata entries (9) inside a request
+            if (depth == 0 and field == 1) or (depth == 1 and field == 9):
+                if _has_overflowing_varint(body, depth + 1):
+                    return True
+        # groups: the fuzz corpus only has them at the top level with plain varint content; tags were checked above
+    return False
+
+
+def test_fuzzed_payloads_agree_with_the_protobuf_runtime():
+    """Mutated payloads (bit flips, byte inserts / deletes, truncation, spliced garbage, unknown groups): the
+    transcoder must accept exactly what the python protobuf runtime accepts, decode it to the same values, and
+    never touch memory it should not (the batch is sized tightly)."""
+    rng = np.random.default_rng(101)
+    wb = gw.WireBatch(max_items=256, max_key_bytes=1 << 15)
+    base = [wire_replay.pb_request(rand_reqs(rng, int(rng.integers(1, 12)))) for _ in range(40)]
+    # unknown group field 20 wrapping a varint field and a nested group 21, then a normal record
+    grp = bytes([0xa3, 0x01, 0x08, 0x05, 0xab, 0x01, 0xac, 0x01, 0xa4, 0x01])
+    base.append(grp + base[0])
+    base.append(base[1] + bytes([0xa3, 0x01, 0x08]))            # unterminated group
+    base.append(bytes([0xa4, 0x01]) + base[2])                   # stray END_GROUP
+    accepted = rejected = overflow = 0
+    for it in range(6000):
+        p = bytearray(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 4))):
+            if not p:
+                break
+            op = rng.integers(0, 5)
+            i = int(rng.integers(0, len(p)))
+            if op == 0:
+                p[i] ^= 1 << int(rng.integers(0, 8))
+            elif op == 1:
+                p.insert(i, int(rng.integers(0, 256)))
+            elif op == 2:
+                del p[i]
+            elif op == 3:
+                del p[i:]
+            else:
+                p[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+        p = bytes(p)
+        got, ref = _decode_or_none(wb, p), _reference_view(p)
+        if got is None and ref is not None and _has_overflowing_varint(p):
+            overflow += 1                                        # Go and the transcoder reject, python truncates
+            continue
+        assert (got is None) == (ref is None), (it, p.hex())
+        if ref is None:
+            rejected += 1
+            continue
+        accepted += 1
+        assert got["n"] == len(ref.requests), (it, p.hex())
+        for i, q in enumerate(ref.requests):
+            want_key = (q.name + "_" + q.unique_key).encode() if q.name and q.unique_key else b""
+            assert got["keys"][i] == want_key, (it, p.hex())
+            assert (got["hits"][i], got["limit"][i], got["duration"][i], got["burst"][i]) == (q.hits, q.limit, q.duration, q.burst), (it, p.hex())
+            assert got["created_at"][i] == (q.created_at or NOW)
+            assert got["behavior"][i] == q.behavior & 0xffffffff
+            assert got["algorithm"][i] == (q.algorithm if q.algorithm in (0, 1) else 255)
+    assert accepted > 1500 and rejected > 1500 and overflow < 60, (accepted, rejected, overflow)
+    wb.close()
