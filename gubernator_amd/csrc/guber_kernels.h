@@ -9,7 +9,19 @@
 // keeps its tag and key, its record becomes K_ABSENT) so probing never needs tombstone handling.
 //
 // One batch (n requests, any number of duplicates of a key, reference order semantics
-// gubernator.go:203 + workers.go:190-258) is evaluated by a fixed sequence of launches on one stream:
+// gubernator.go:203 + workers.go:190-258) is evaluated by a fixed sequence of launches on one stream.
+//
+// n <= 65 536 (the headline configuration) — TWO launches, described in detail above k_front:
+//   k_front        one workgroup per tile of 256 requests: hash, find-or-insert the directory entry (home bucket
+//                  fetched speculatively in the same round trip), one claim CAS per (workgroup, key) after an LDS
+//                  leader election, key verification, bucket snapshot, grouping of the tile by segment id
+//                  through an LDS hash table, one packed atomic per (key, tile) group
+//   k_eval2        rank of every request inside its key's segment from the tile bitmap + per-tile counts, then
+//                  every request computes ITS OWN response from (snapshot, rank) with guber::eval_uniform_rank —
+//                  no atomics on bucket state, no serial chain for hot keys; the last request of a segment
+//                  writes the bucket back.  Heterogeneous segments are walked in request order by one thread.
+//
+// n > 65 536 — a global stable radix sort of the requests by segment id:
 //   k_resolve      hash each key, find-or-insert its directory entry, give every distinct key of
 //                  the batch a segment id (= request index of the first toucher, claimed with one
 //                  64-bit CAS on the entry's meta word), per-tile digit histogram for the sort
@@ -19,10 +31,7 @@
 //                  touched bucket into a dense array and flags segments whose requests differ
 //   k_hist         per-tile digit histogram of the next pass (only between passes)
 //   k_heads        segment (= same key) boundaries in the sorted order
-//   k_eval         every request computes ITS OWN response from (snapshot, rank in segment) with
-//                  guber::eval_uniform_rank — no atomics on bucket state, no serial chain for hot
-//                  keys; the last request of a segment writes the bucket back.  Heterogeneous
-//                  segments are walked in request order by their first request's thread.
+//   k_eval         as k_eval2, with the rank taken from the sorted position
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -561,22 +570,22 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
 // ---------------------------------------------------------------------------------------------
 // Pipeline for batches of <= FT_MAX_TILES tiles of FT requests (65536 requests): TWO launches.
 //
-// Measured on MI355X (tools/microbench.hip): the random-access part (16 B directory entry, 128 B
-// bucket, claim CAS for 65536 requests) takes ~5 us with 256-thread workgroups spread over all 256 CUs
-// and ~15 us with 1024-thread workgroups on 64 CUs (per-CU L1 request rate), and atomics on ONE address
-// serialise at ~12 ns each.  Hence: 256-request tiles, sc1 (L1-bypassing) directory loads so that only
-// the first toucher of a key issues a CAS, and no per-key atomics other than one bitmap OR per
-// (key, tile) group.
+// Measured on MI355X (tools/microbench.hip, profiles/): the random-access part (16 B directory entry, 128 B
+// bucket, claim CAS for 65536 requests) takes ~5 us with 256-thread workgroups spread over all 256 CUs and
+// ~15 us with 1024-thread workgroups on 64 CUs (per-CU L1 request rate), and atomics on ONE address serialise
+// at ~12 ns each.  Hence: 256-request tiles, one claim CAS per (workgroup, key) — the threads of a workgroup
+// that hold the same key elect a leader through LDS — plain (L1-cacheable) directory loads, and no per-key
+// atomics other than one packed add per (key, tile) group.
 //
 // k_front (one workgroup = one tile of FT requests):
-//   A  resolve: key -> directory entry -> {bucket fetch || speculative claim CAS} -> verify.
+//   A  resolve: key -> directory entry || home bucket (one round trip) -> claim CAS by the leader -> verify.
 //      Segment id of a key = request index of its first toucher.  A match on an entry that is not
 //      READY (inserted during this launch) is verified against the CLAIMER's request key (input data)
 //      instead of the stored key, whose writer may still be in flight; the inserter performs the same
 //      comparison, so every member of a segment provably has the key that ends up stored.
-//   B  group the tile by segment id: an all-pairs count in LDS (FT = 256 keys) gives every request its
-//      sorted position, its rank inside its (segment, tile) group and the group size directly.
-//   C  group heads publish size / start for (segment, tile) and set the tile bit in the segment bitmap.
+//   B  group the tile by segment id through an LDS hash table with per-wave member bitmaps: a request's sorted
+//      position, its rank inside its (segment, tile) group and the group size come from four popcounts.
+//   C  group heads publish size / start for (segment, tile) and add (size << 32 | tile bit) to the segment's word.
 // k_eval2 (request order): rank = members in earlier tiles (bitmap + per-tile counts) + rank in tile.
 constexpr int FT = 256;                 // requests per tile in the two-launch pipeline
 constexpr int FT_MAX_TILES = 256;       // bitmap bits per segment
