@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--shards", type=int, default=4, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
                          "engines with their own tables and streams; step s evaluates a batch of shard s %% S")
+    ap.add_argument("--global-host", action="store_true", help="with --global-sync: use the host-staged exchange (global_sync.py)")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
                     help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
                          "and every K steps the ranks exchange pending hits / broadcast owner state (0 = off)")
@@ -202,17 +203,28 @@ def main():
 
     gsync = None
     if GSYNC:
-        from gubernator_amd import global_sync
         eng.max_batch = B
-        transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
-        gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
+        if args.global_host:      # host-staged exchange (numpy rows, pickled all_gather): kept for comparison
+            from gubernator_amd import global_sync
+            transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
+            gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
+        else:                     # rows stay in HBM: take_dev -> route -> RCCL all_to_all / all_gather -> eval_dev / add_items_dev
+            from gubernator_amd import global_sync_dev
+            if world > 1:
+                transport = global_sync_dev.TorchTransportDev(dev)
+            else:
+                transport = type("T", (), {"exchange_rows": staticmethod(lambda send, counts: send),
+                                           "gather_rows": staticmethod(lambda rows: [rows])})()
+            gsync = global_sync_dev.GlobalSyncDev(eng, rank, world, ring, transport, dev, key_stride=64)
     sync_stats = []
 
     def run(s):
         engines[s % S].eval_dev(batches[s].c, (kept[s] if s < KEEP else scratches[s % S]).c)
         if gsync is not None and (s + 1) % GSYNC == 0:
             t_s = time.perf_counter()
-            st = gsync.sync(NOW0 + 1 + s)
+            with torch.cuda.stream(stream):          # the engine's stream: torch ops of the exchange and engine kernels stay ordered
+                st = gsync.sync(NOW0 + 1 + s)
+                stream.synchronize()
             st["ms"] = (time.perf_counter() - t_s) * 1e3
             sync_stats.append(st)
 
@@ -373,7 +385,8 @@ def main():
                                   "avg_ms": round(sum(x["ms"] for x in timed) / max(len(timed), 1), 3),
                                   "avg_rows_broadcast": int(sum(x["broadcast"] for x in timed) / max(len(timed), 1)),
                                   "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
-                                  "bytes_moved_rank0": gsync.bytes_moved}
+                                  "bytes_moved_rank0": gsync.bytes_moved,
+                                  "exchange": "host-staged" if args.global_host else "device-resident (RCCL on HBM rows)"}
         print(json.dumps(out))
     for e_ in engines:
         e_.close()

@@ -91,6 +91,8 @@ struct guber_engine {
 #ifdef GUBER_PHASE_TIMING
     DevBuf<unsigned long long> dbg; double dbg_avg[2][8] = {{0}}, dbg_max[2][8] = {{0}}; uint64_t dbg_n = 0;
 #endif
+    DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; const guber_ring_t* ring_cached = nullptr; uint32_t ring_npts = 0;   // ring image for the *_dev routers
+    DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags;   // guber_add_items_dev scratch
     DevBuf<uint8_t> d_sflags; DevBuf<Rec> d_safter;   // Store side channel (guber_eval_batch_store), allocated on first use
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
@@ -254,6 +256,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     }
     e->dbg.release();
 #endif
+    e->d_ring_h.release(); e->d_ring_o.release(); e->d_items.release(); e->d_islots.release(); e->d_iflags.release();
     e->d_sflags.release(); e->d_safter.release();
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
     e->d_take.release(); e->h_take.release();
@@ -791,6 +794,114 @@ extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, co
     he = hipStreamSynchronize(e->stream);
     cleanup();
     if (he != hipSuccess) return fail(GUBER_E_HIP, "k_route", he);
+    return GUBER_OK;
+}
+
+// ring image on the device, uploaded once per (engine, ring)
+static int ensure_ring_on_device(guber_engine* e, const guber_ring_t* r) {
+    if (e->ring_cached == r && e->ring_npts) return 0;
+    const uint32_t npts = guber_ring_points(r, nullptr, nullptr, 0);
+    if (npts == 0) return fail(GUBER_E_INVALID_ARG, "empty ring");
+    if ((size_t)npts * 8 > 150 * 1024) return fail(GUBER_E_INVALID_ARG, "ring does not fit in LDS");
+    std::vector<uint64_t> hh(npts); std::vector<uint32_t> oo(npts);
+    guber_ring_points(r, hh.data(), oo.data(), npts);
+    if (e->d_ring_h.ensure(npts) || e->d_ring_o.ensure(npts)) return GUBER_E_NOMEM;
+    HIPCHK(hipMemcpyAsync(e->d_ring_h.p, hh.data(), npts * 8, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->d_ring_o.p, oo.data(), npts * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    e->ring_cached = r; e->ring_npts = npts;
+    return 0;
+}
+
+extern "C" int guber_ring_route_rows_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_rows, uint32_t stride,
+                                         const uint32_t* key_len, uint32_t n, uint32_t* owner) {
+    if (!e || !r || (n && (!key_rows || !key_len || !owner))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (n == 0) return GUBER_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    int rc = ensure_ring_on_device(e, r);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_route_rows, dim3((n + 255) / 256), dim3(256), (size_t)e->ring_npts * 8, e->stream, key_rows, stride, key_len, n,
+                       e->d_ring_h.p, e->d_ring_o.p, e->ring_npts, guber_ring_kind(r), owner);
+    HIPCHK(hipGetLastError());
+    return GUBER_OK;
+}
+
+extern "C" int guber_global_pending(guber_engine_t* e, uint32_t* n_out) {
+    if (!e || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    *n_out = 0;
+    if (!e->T.gpend) return fail(GUBER_E_INVALID_ARG, "engine created without GUBER_FLAG_GLOBAL");
+    DevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (c.gdirty_overflow) return fail(GUBER_E_NOMEM, "GLOBAL dirty list overflowed");
+    *n_out = c.gdirty_n;
+    return GUBER_OK;
+}
+
+// guber_global_take with the rows left in HBM, in caller-provided device arrays (cap rows each, key rows of
+// out->key_stride bytes).  The rows feed guber_ring_route_rows_dev, an RCCL exchange and guber_eval_batch_dev /
+// guber_add_items_dev without touching the host.
+extern "C" int guber_global_take_dev(guber_engine_t* e, uint32_t role_mask, const guber_global_rows_dev_t* out, uint32_t* n_out) {
+    if (!e || !out || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    *n_out = 0;
+    if (!e->T.gpend) return fail(GUBER_E_INVALID_ARG, "engine created without GUBER_FLAG_GLOBAL");
+    DevCounters c;
+    HIPCHK(hipMemcpyAsync(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (c.gdirty_overflow) return fail(GUBER_E_NOMEM, "GLOBAL dirty list overflowed");
+    const uint32_t n = c.gdirty_n;
+    if (n == 0) return GUBER_OK;
+    if (n > out->cap) { *n_out = n; return fail(GUBER_E_NOMEM, "row arrays too small"); }
+    if (out->key_stride < e->max_key || !out->key_bytes || !out->key_len || !out->hits || !out->limit || !out->duration || !out->burst ||
+        !out->created_at || !out->behavior || !out->algorithm || !out->role)
+        return fail(GUBER_E_INVALID_ARG, "row arrays missing or key_stride < max_key_bytes");
+    GTakeOut O{out->key_bytes, out->key_len, out->hits, out->limit, out->duration, out->burst, out->created_at, out->behavior,
+               out->algorithm, out->role, out->key_stride};
+    HIPCHK(hipMemsetAsync(e->gtake_ctr.p, 0, 4 * sizeof(uint32_t), e->stream));
+    hipLaunchKernelGGL(k_global_take, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, n, role_mask, e->gdirty2.p,
+                       (unsigned int*)e->gtake_ctr.p, O);
+    unsigned int cnt[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(cnt, e->gtake_ctr.p, sizeof(cnt), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    std::swap(e->gdirty.p, e->gdirty2.p);
+    e->T.gdirty = e->gdirty.p;
+    HIPCHK(hipMemcpyAsync(&e->ctr.p->gdirty_n, &cnt[1], sizeof(unsigned int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *n_out = cnt[0];
+    return GUBER_OK;
+}
+
+// LRUCache.Add for device-resident item columns (keys must be distinct within one call: the receiver side of
+// UpdatePeerGlobals, where every key comes from exactly one owner).  result[i] (device): 0 / 1 = existed,
+// 0xFF = resubmit (in-call 64-bit hash collision or duplicate key), 0xFE = no directory entry.
+extern "C" int guber_add_items_dev(guber_engine_t* e, const guber_items_dev_t* it, uint8_t* result) {
+    if (!e || !it) return fail(GUBER_E_INVALID_ARG, "null argument");
+    const uint32_t n = it->n;
+    if (n == 0) return GUBER_OK;
+    if (!result || !it->key_bytes || !it->key_off || !it->algorithm || !it->limit || !it->duration || !it->remaining || !it->remaining_f ||
+        !it->stamp || !it->expire_at)
+        return fail(GUBER_E_INVALID_ARG, "item column missing");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (e->tags_upper + n > e->slots - e->slots / 8) {
+        int rc = engine_refresh_counters(e);
+        if (rc) return rc;
+        if (e->tags_upper >= e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
+    }
+    e->tags_upper += n;
+    if (e->d_items.ensure(n) || e->d_islots.ensure(n) || e->d_iflags.ensure(n)) return GUBER_E_NOMEM;
+    ItemsSoA S{it->key_off, it->algorithm, it->status, it->limit, it->duration, it->remaining, it->remaining_f, it->stamp, it->burst,
+               it->expire_at, it->invalid_at};
+    hipStream_t st = e->stream;
+    hipLaunchKernelGGL(k_items_from_soa, dim3((n + 255) / 256), dim3(256), 0, st, S, n, e->d_items.p);
+    hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p);
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p, result);
+    HIPCHK(hipGetLastError());
     return GUBER_OK;
 }
 

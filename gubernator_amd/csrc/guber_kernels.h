@@ -1153,4 +1153,44 @@ __global__ __launch_bounds__(256) void k_route(const uint8_t* key_bytes, const u
     owner[i] = ring_owner[lo];
 }
 
+// the same for keys stored as rows of a [n][stride] matrix with explicit lengths (guber_global_take_dev rows)
+__global__ __launch_bounds__(256) void k_route_rows(const uint8_t* key_rows, uint32_t stride, const uint32_t* key_len, uint32_t n,
+                                                    const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
+                                                    int kind, uint32_t* owner) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* lh = (uint64_t*)smem;
+    for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* k = key_rows + (size_t)i * stride;
+    const uint32_t len = key_len[i];
+    const uint64_t h = kind == 1 ? fnv1a_64(k, len) : fnv1_64(k, len);
+    uint32_t lo = 0, hi = npts;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (lh[mid] >= h) hi = mid; else lo = mid + 1; }
+    if (lo == npts) lo = 0;
+    owner[i] = ring_owner[lo];
+}
+
+// guber_add_items_dev: build the ItemIn image (bucket record + key reference) of device-resident item columns —
+// the device twin of rec_from_item() in guber_engine.hip (UpdatePeerGlobals / Loader items, gubernator.go:425-459)
+struct ItemsSoA {
+    const uint32_t* key_off; const uint8_t *algorithm, *status;
+    const int64_t *limit, *duration, *remaining; const double* remaining_f;
+    const int64_t *stamp, *burst, *expire_at, *invalid_at;
+};
+__global__ __launch_bounds__(256) void k_items_from_soa(ItemsSoA S, uint32_t n, ItemIn* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Rec s; rec_clear(s);
+    const uint8_t algo = S.algorithm[i];
+    s.limit = S.limit[i]; s.duration = S.duration[i]; s.stamp = S.stamp[i]; s.burst = S.burst ? S.burst[i] : 0;
+    s.expire_at = S.expire_at[i]; s.invalid_at = S.invalid_at ? S.invalid_at[i] : 0;
+    if (algo == ALGO_TOKEN) { s.remaining = S.remaining[i]; s.burst = 0; s.meta = make_meta(K_TOKEN, S.status ? S.status[i] : 0, ALGO_TOKEN); }
+    else if (algo == ALGO_LEAKY) { s.remaining = f2bits(S.remaining_f[i]); s.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY); }
+    else s.meta = make_meta(K_NIL, 0, algo);
+    ItemIn o; o.rec = s; o.key_off = S.key_off[i]; o.key_len = S.key_off[i + 1] - S.key_off[i];
+    out[i] = o;
+}
+
 }  // namespace guber

@@ -329,6 +329,35 @@ int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t
                          const uint32_t* key_off, uint32_t n, uint32_t* owner);
 uint32_t guber_ring_points(const guber_ring_t* r, uint64_t* hashes, uint32_t* owners, uint32_t cap);
 
+/* ---- the same queues without leaving HBM (the GLOBAL exchange of one node runs GPU -> RCCL/xGMI -> GPU):
+ *      guber_global_pending     upper bound of the rows a take can return (size the arrays with it)
+ *      guber_global_take_dev    rows into caller-provided DEVICE arrays: key i = key_bytes[i*key_stride ..+key_len[i]),
+ *                               key_stride >= max_key_bytes; *n_out rows written (GUBER_E_NOMEM + *n_out = rows needed
+ *                               when cap is too small)
+ *      guber_ring_route_rows_dev  owning peer of every row key (replicated_hash.go:104-119), asynchronous on the engine stream
+ *      guber_add_items_dev      LRUCache.Add (lrucache.go:88-103) of device-resident item columns — the receiving side of
+ *                               UpdatePeerGlobals (gubernator.go:425-459); keys must be distinct within a call;
+ *                               result[i] (device) = 0 / 1 existed, 0xFF resubmit, 0xFE no directory entry; asynchronous */
+typedef struct guber_global_rows_dev {
+    uint32_t cap; uint32_t key_stride;
+    uint8_t* key_bytes; uint32_t* key_len;
+    int64_t *hits, *limit, *duration, *burst, *created_at;
+    uint32_t* behavior; uint8_t* algorithm; uint8_t* role;
+} guber_global_rows_dev_t;
+typedef struct guber_items_dev {
+    uint32_t n; uint32_t reserved;
+    const uint8_t* key_bytes;    /* packed keys, readable 8 bytes past the end */
+    const uint32_t* key_off;     /* n + 1 */
+    const uint8_t* algorithm; const uint8_t* status;          /* status may be NULL (all UNDER_LIMIT) */
+    const int64_t *limit, *duration, *remaining; const double* remaining_f;
+    const int64_t *stamp, *burst, *expire_at, *invalid_at;    /* burst / invalid_at may be NULL (all 0) */
+} guber_items_dev_t;
+int guber_global_pending(guber_engine_t* e, uint32_t* n_out);
+int guber_global_take_dev(guber_engine_t* e, uint32_t role_mask, const guber_global_rows_dev_t* out, uint32_t* n_out);
+int guber_ring_route_rows_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_rows, uint32_t key_stride,
+                              const uint32_t* key_len, uint32_t n, uint32_t* owner);
+int guber_add_items_dev(guber_engine_t* e, const guber_items_dev_t* items, uint8_t* result);
+
 /* ---- calendar helpers the host layer uses to fill greg_expire / greg_duration
  *      (interval.go:84-148), UTC. Return 0 or -GUBER_ITEM_E_GREGORIAN_*. */
 int guber_gregorian_expiration(int64_t now_unix_nano, int64_t d, int64_t* expire_ms);

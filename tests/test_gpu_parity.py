@@ -417,3 +417,49 @@ def test_created_at_only_variation_on_hot_leaky_keys(flags):
         assert e.size() == o.size()
         t += int(rng.choice([1, 3, 50, 30_001, 120_000]))
     e.close()
+
+
+def test_global_behaviour_device_resident_exchange_vs_model():
+    """The same GLOBAL semantics with the exchange running on device arrays (guber_global_take_dev ->
+    guber_ring_route_rows_dev -> row exchange -> guber_eval_batch_dev -> guber_add_items_dev): logical ranks on one
+    device against the global.go model, the reference's GLOBAL vectors, and a 1-rank RCCL process group."""
+    import torch
+    import test_global as tg
+    from global_model import GlobalModel
+    from gubernator_amd import global_sync_dev as gsd
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        mk = lambda: ga.Engine(cache_size=4096, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL, stream=s.cuda_stream)
+        ring = ga.Ring([f"gpu{i}" for i in range(6)])
+        cluster = gsd.LocalClusterDev([mk() for _ in range(6)], ring, "cuda:0")
+        assert tg.run_vectors(lambda r, q, now: tg.cluster_request(cluster, r, q, now), cluster.sync, ring, 6) >= 40
+        n = 4
+        for seed in (1, 2):
+            ring4 = ga.Ring([f"gpu{i}" for i in range(n)])
+            cl = gsd.LocalClusterDev([mk() for _ in range(n)], ring4, "cuda:0")
+            model = GlobalModel(n, lambda k: int(ring4.route([k])[0]))
+            tg.run_random(lambda r, b, now: cl.ranks[r].evaluate(b["keys"], b["hits"], b["limit"], b["duration"], now,
+                                                                 algorithm=b["algorithm"], behavior=b["behavior"], burst=0,
+                                                                 created_at=now),
+                          cl.sync, model, n, seed, steps=200)
+            cl.sync(tg.NOW + 10_000); model.sync(tg.NOW + 10_000)
+            for k in range(40):
+                key = f"glob_{k}".encode()
+                vals = {r: (cl.ranks[r].node.get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+                want = {r: (model.oracles[r].get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+                assert vals == want, (seed, key, vals, want)
+            assert sum(r.fallbacks for r in cl.ranks) == 0
+        # the collectives themselves: one rank, RCCL backend (all_to_all_single / all_gather_into_tensor on device tensors)
+        import torch.distributed as dist
+        import socket
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        try:
+            ring1 = ga.Ring(["gpu0"])
+            g = gsd.GlobalSyncDev(mk(), 0, 1, ring1, gsd.TorchTransportDev("cuda:0"), "cuda:0")
+            model = GlobalModel(1, lambda k: 0)
+            tg.run_random(lambda r, b, now: g.evaluate(b["keys"], b["hits"], b["limit"], b["duration"], now, algorithm=b["algorithm"],
+                                                       behavior=b["behavior"], burst=0, created_at=now),
+                          lambda now: [g.sync(now)], model, 1, 5, steps=60)
+        finally:
+            dist.destroy_process_group()
