@@ -152,3 +152,37 @@ def test_global_sync_over_gloo_two_ranks(tmp_path):
     port = _free_port()
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(2))
+
+
+def _gloo_transport_worker(rank, world, port, out_dir):
+    """The row collectives of the device-resident exchange (global_sync_dev.TorchTransportDev): all_to_all_single with
+    variable splits and a padded all_gather_into_tensor, here over gloo on CPU tensors (RCCL on the GPU)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    from gubernator_amd import global_sync_dev as gsd
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = gsd.TorchTransportDev("cpu")
+    rb = 12
+    for it in range(6):
+        rng = np.random.default_rng(100 + it)                         # same stream on every rank
+        counts = rng.integers(0, 5, (world, world))                   # counts[src][dst]
+        rows = {src: rng.integers(0, 256, (int(counts[src].sum()), rb), dtype=np.uint8) for src in range(world)}
+        recv = t.exchange_rows(torch.from_numpy(rows[rank].copy()), [int(c) for c in counts[rank]])
+        want = np.concatenate([rows[src][int(counts[src][:rank].sum()):int(counts[src][:rank + 1].sum())] for src in range(world)])
+        assert np.array_equal(recv.numpy(), want), (rank, it)
+        ns = rng.integers(0, 4, world)
+        items = {src: rng.integers(0, 256, (int(ns[src]), rb), dtype=np.uint8) for src in range(world)}
+        got = t.gather_rows(torch.from_numpy(items[rank].copy()))
+        assert len(got) == world and all(np.array_equal(got[src].numpy(), items[src]) for src in range(world)), (rank, it)
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_device_exchange_collectives_over_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_gloo_transport_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
