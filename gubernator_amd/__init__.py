@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_pool_set_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_pool_set_store", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL = 1, 2, 4, 8
@@ -338,6 +338,23 @@ class V1Instance:
 
     def batches(self):
         return lib().guber_pool_batches(self.h)
+
+    def load(self, items):
+        """WorkerPool.Load: items = list of GuberItem (make_item)."""
+        arr = (GuberItem * max(len(items), 1))(*items)
+        L = lib()
+        L.guber_pool_load.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_uint32]
+        _check(L.guber_pool_load(self.h, arr, len(items)))
+
+    def store(self):
+        """WorkerPool.Store: every resident item as a dict (what Loader.Save receives)."""
+        out = []
+        cb_t = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(GuberItem))
+        cb = cb_t(lambda _u, it: out.append(item_dict(it.contents)))
+        L = lib()
+        L.guber_pool_store.argtypes = [C.c_void_p, cb_t, C.c_void_p]
+        _check(L.guber_pool_store(self.h, cb, None))
+        return out
 
     def set_store(self, store):
         """Config.Store (store.go:49-65).  `store` has get(req, key) -> item dict | None, on_change(req, key, item dict),

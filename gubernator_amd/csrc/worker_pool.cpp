@@ -185,6 +185,24 @@ int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool*
     *found = f != 0;
     return rc;
 }
+int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n) {
+    for (uint32_t lo = 0; lo < n; lo += 65536) {          // chunks bound the staging buffers
+        const int rc = guber_add_items(engine_, items + lo, std::min<uint32_t>(65536, n - lo), nullptr);
+        if (rc != GUBER_OK) return rc;
+    }
+    return GUBER_OK;
+}
+int GPUWorkerPool::Store(const std::function<void(const guber_item_t&)>& save) {
+    uint64_t n = 0, arena = 0;
+    int rc = guber_dump(engine_, nullptr, 0, nullptr, 0, &n, &arena);           // sizes first
+    if (rc != GUBER_OK && rc != GUBER_E_NOMEM) return rc;
+    std::vector<guber_item_t> items(n + 1024);
+    std::vector<uint8_t> keys(arena + 64 * 1024);
+    rc = guber_dump(engine_, items.data(), items.size(), keys.data(), keys.size(), &n, &arena);
+    if (rc != GUBER_OK) return rc;
+    for (uint64_t i = 0; i < n; ++i) save(items[i]);
+    return GUBER_OK;
+}
 int64_t GPUWorkerPool::Size() { return guber_size(engine_); }
 
 bool V1Instance::GetRateLimits(std::vector<RateLimitReq>& reqs, std::vector<RateLimitResp>* resps, std::string* rpc_error) {
@@ -232,6 +250,11 @@ extern "C" void guber_pool_destroy(guber_pool_t* p) {
     if (!p) return;
     p->pool->Close();
     delete p->inst; delete p->pool; delete p;
+}
+extern "C" int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n) { return p ? p->pool->Load(items, n) : GUBER_E_INVALID_ARG; }
+extern "C" int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user) {
+    if (!p || !save) return GUBER_E_INVALID_ARG;
+    return p->pool->Store([&](const guber_item_t& it) { save(user, &it); });
 }
 extern "C" void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb) { if (p) p->pool->SetStore(cb); }
 extern "C" void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms) { if (p) p->pool->SetClockMs(now_ms); }

@@ -49,6 +49,10 @@ class GPUWorkerPool {
                           std::vector<RateLimitResp*>& out);
     int AddCacheItem(const guber_item_t& item);                                  // workers.go:537
     int GetCacheItem(const std::string& key, guber_item_t* out, bool* found);    // workers.go:583
+    // WorkerPool.Load (workers.go:329-449): hand every item of a Loader to the cache; WorkerPool.Store (workers.go:451-534):
+    // visit every resident item (what Loader.Save receives).  Bulk paths: guber_add_items / guber_dump.
+    int Load(const guber_item_t* items, uint32_t n);
+    int Store(const std::function<void(const guber_item_t&)>& save);
     int64_t Size();
     void Close();                                                                // workers.go:157
     // clock.Freeze / clock.Advance of the reference's tests: 0 = wall clock

@@ -298,7 +298,11 @@ typedef struct guber_store_callbacks {
     void (*remove)(void* user, const uint8_t* key, uint32_t key_len);
     void* user;
 } guber_store_callbacks_t;
-void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb);      /* before the first request; NULL = none */   /* clock.Freeze of the reference tests; 0 = wall clock */
+void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb);
+/* WorkerPool.Load / WorkerPool.Store (workers.go:329-449, 451-534): the Loader's items into the cache at start-up; every
+ * resident item to Loader.Save at shutdown (`save` is called once per item; item->key is valid during the call). */
+int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n);
+int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user);      /* before the first request; NULL = none */   /* clock.Freeze of the reference tests; 0 = wall clock */
 guber_engine_t* guber_pool_engine(guber_pool_t* p);
 uint64_t guber_pool_batches(guber_pool_t* p);
 /* names / unique keys as SoA strings; created_at[i] = 0 means unset; err_text (optional) receives the

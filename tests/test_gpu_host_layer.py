@@ -180,3 +180,23 @@ def test_store_callbacks_through_the_pool_teststore():
         def close(self):
             self.inst.close()
     assert scenarios.run_store_events(PoolBackend) == 10
+
+
+def test_loader_round_trip_through_the_pool():
+    """store_test.go:76-125 TestLoader: items handed over by Loader.Load are served from the cache, and Loader.Save at
+    shutdown receives every resident item with its current state ({Limit 2, Remaining 1, UNDER} after one hit)."""
+    now = 1_700_000_000_000
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+    inst.set_clock(now)
+    inst.load([ga.make_item(f"loaded_k{i}", 0, limit=10, duration=60_000, remaining=10 - i % 5, stamp=now - 5, expire_at=now + 59_995)
+               for i in range(300)])
+    out = inst.GetRateLimits([dict(name="test_over_limit", unique_key="account:1234", hits=1, limit=2, duration=1000),
+                              dict(name="loaded", unique_key="k3", hits=1, limit=10, duration=60_000)])
+    assert (out[0]["status"], out[0]["remaining"]) == (0, 1)
+    assert (out[1]["status"], out[1]["remaining"]) == (0, 10 - 3 - 1)                   # continued from the loaded state
+    saved = {d["key"]: d for d in inst.store()}
+    assert len(saved) == 301
+    it = saved[b"test_over_limit_account:1234"]
+    assert (it["algorithm"], it["limit"], it["remaining"], it["status"]) == (0, 2, 1, 0)
+    assert saved[b"loaded_k3"]["remaining"] == 6 and saved[b"loaded_k7"]["remaining"] == 10 - 7 % 5
+    inst.close()
