@@ -296,10 +296,26 @@ def main():
             except Exception:
                 traffic = None
         step_ms_events = ev_ms / args.steps
+        # measured ceilings of this GPU (tools/hbm_peak.hip -> profiles/hbm_peak.json) and the HBM traffic of one batch
+        # from the PMC passes (profiles/roofline_traffic.json): how close the pipeline runs to what random access allows
+        measured = None
+        try:
+            hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
+            tr = json.load(open(tpath)).get(args.algo, {})
+            per_batch = sum(tr.get(k, 0) for k in KERNEL_BYTES[args.algo])
+            if per_batch:
+                gbps = per_batch / (step_ms_events * 1e-3) / 1e9
+                measured = {"stream_read_GBps": hp["stream_read_GBps"], "random_gather_GBps": hp["random_gather_128B_GBps"],
+                            "hbm_traffic_bytes_per_batch": per_batch, "hbm_traffic_GBps": round(gbps, 1),
+                            "frac_of_stream_read": round(gbps / hp["stream_read_GBps"], 4),
+                            "frac_of_random_gather": round(gbps / hp["random_gather_128B_GBps"], 4)}
+        except Exception:
+            measured = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                     "algorithmic_bytes_per_launch": dom_bytes,
                     "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items()},
+                    "measured_ceilings": measured,
                     "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
                                  "ms_per_batch_events": round(step_ms_events, 5),
                                  "achieved": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9, 2),
