@@ -301,14 +301,16 @@ def main():
         measured = None
         try:
             hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
-            tr = json.load(open(tpath)).get(args.algo, {})
-            per_batch = sum(tr.get(k, 0) for k in KERNEL_BYTES[args.algo])
-            if per_batch:
-                gbps = per_batch / (step_ms_events * 1e-3) / 1e9
+            tj = json.load(open(tpath))
+            cor = sum(tj.get(args.algo, {}).get(k, 0) for k in KERNEL_BYTES[args.algo])
+            raw = sum(tj.get(args.algo + "_raw", {}).get(k, 0) for k in KERNEL_BYTES[args.algo])
+            if cor and raw:
+                g_raw, g_cor = (x / (step_ms_events * 1e-3) / 1e9 for x in (raw, cor))
                 measured = {"stream_read_GBps": hp["stream_read_GBps"], "random_gather_GBps": hp["random_gather_128B_GBps"],
-                            "hbm_traffic_bytes_per_batch": per_batch, "hbm_traffic_GBps": round(gbps, 1),
-                            "frac_of_stream_read": round(gbps / hp["stream_read_GBps"], 4),
-                            "frac_of_random_gather": round(gbps / hp["random_gather_128B_GBps"], 4)}
+                            "hbm_traffic_bytes_per_batch": {"raw": raw, "corrected": cor},
+                            "hbm_traffic_GBps": {"raw": round(g_raw, 1), "corrected": round(g_cor, 1)},
+                            "frac_of_random_gather": {"raw": round(g_raw / hp["random_gather_128B_GBps"], 4),
+                                                      "corrected": round(g_cor / hp["random_gather_128B_GBps"], 4)}}
         except Exception:
             measured = None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,

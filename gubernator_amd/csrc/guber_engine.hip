@@ -93,6 +93,7 @@ struct guber_engine {
 #endif
     DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; const guber_ring_t* ring_cached = nullptr; uint32_t ring_npts = 0;   // ring image for the *_dev routers
     DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags;   // guber_add_items_dev scratch
+    DevBuf<unsigned long long> w_claims; uint32_t claims_cells = 0; uint32_t fast_epoch16 = 0;   // k_front's per-batch claim table
     DevBuf<uint8_t> d_sflags; DevBuf<Rec> d_safter;   // Store side channel (guber_eval_batch_store), allocated on first use
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
     // staging for the host-pointer entry points
@@ -192,6 +193,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
+    e->claims_cells = 1024;
+    while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
+    rc |= e->w_claims.ensure(e->claims_cells);
     uint32_t gdirty_cap = 0;
     if (cfg->flags & GUBER_FLAG_GLOBAL) {
         gdirty_cap = (uint32_t)std::min<uint64_t>(e->slots, 1u << 24);
@@ -209,6 +213,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_flags2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
@@ -232,6 +237,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
 
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
+    e->W.claims = (cfg->flags & GUBER_FLAG_DIR_CLAIMS) ? nullptr : e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -257,6 +263,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->dbg.release();
 #endif
     e->d_ring_h.release(); e->d_ring_o.release(); e->d_items.release(); e->d_islots.release(); e->d_iflags.release();
+    e->w_claims.release();
     e->d_sflags.release(); e->d_safter.release();
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
     e->d_take.release(); e->h_take.release();
@@ -306,6 +313,11 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         B2.n_cap = e->fast_cap;
         const uint32_t ftiles = (n + FT - 1) / FT;
         W.careful = (e->careful || e->always_careful) ? 1u : 0u;
+        if (++e->fast_epoch16 > 0xffffu) {   // 16-bit claim epoch wrapped: forget every cell
+            HIPCHK(hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream));
+            e->fast_epoch16 = 1;
+        }
+        W.epoch16 = e->fast_epoch16;
         W.parity = e->fast_batches & 1u;
         W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
         W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;

@@ -115,6 +115,11 @@ struct Work {
     // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
     uint8_t* store_flags; Rec* store_after;
+    // per-batch segment claims of the two-launch pipeline: an insert-only hash table slot -> first toucher, 2 x fast_cap
+    // cells of (epoch16 << 48 | slot << 16 | request index), small enough to live in L2 / Infinity Cache, so that the
+    // HBM table is not written by k_front at all in steady state (a claim in the directory's meta word would dirty one
+    // directory sector per distinct key and batch).  null = claim in the directory entry instead (GUBER_FLAG_DIR_CLAIMS).
+    unsigned long long* claims; uint32_t cmask; uint32_t epoch16;
 #ifdef GUBER_PHASE_TIMING
     unsigned long long* dbg;
 #endif
@@ -617,6 +622,32 @@ __device__ __forceinline__ uint32_t claim_segment(unsigned long long* mp, unsign
     }
 }
 
+// claim the segment id of bucket `slot` for this batch in the claims table (see Work::claims).  Insert-only open
+// addressing: cells of older epochs count as empty; everybody scans from the same home cell in the same order, so a
+// slot is inserted at most once and later arrivers find it.
+__device__ __forceinline__ uint32_t claim_cell(uint32_t slot, uint32_t cmask) { return ((slot * 0x9E3779B1u) >> 11) & cmask; }
+__device__ __forceinline__ uint32_t claim_slot(unsigned long long* claims, uint32_t cmask, uint32_t slot, uint32_t e16,
+                                               uint32_t g, bool& claimed) {
+    uint32_t h = claim_cell(slot, cmask);
+    const unsigned long long want = ((unsigned long long)e16 << 48) | ((unsigned long long)slot << 16) | g;
+    for (;;) {
+        // a fresh (L1-bypassing) look first: for a hot key all but the first workgroup find the cell taken and issue no
+        // CAS at all — requesting the cell early with the directory entry and CAS-ing on that value was measured and lost
+        // (failed CASes on the hot cells; profiles/r01_claims_ab.txt)
+        unsigned long long cur = ld_agent(&claims[h]);
+        for (;;) {
+            if ((uint32_t)(cur >> 48) == e16) {
+                if ((uint32_t)(cur >> 16) == slot) return (uint32_t)(cur & 0xffffull);
+                break;                                          // another bucket's cell: next
+            }
+            const unsigned long long old = atomicCAS(&claims[h], cur, want);
+            if (old == cur) { claimed = true; return g; }
+            cur = old;                                          // lost the race for this cell: look at the winner
+        }
+        h = (h + 1) & cmask;
+    }
+}
+
 __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ uint32_t skey[FT];       // stage 2: candidate slot per thread; phase B: segment id per thread
     __shared__ uint32_t sd[FT];         // stage 2: segment id obtained by each leader
@@ -636,10 +667,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     uint32_t d = 0xffffffffu, slot = 0, errcode = 0, len = 0;
     int inserted = 0;
     bool fresh = false, claimed = false, cand = false, ready = false;
-    unsigned long long meta = 0ull;
     const uint8_t* key = nullptr;
     Rec rec; rec_clear(rec);
     uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    unsigned long long meta0 = 0ull;
     if (valid) {
         const uint32_t off = B.key_off[g];
         len = B.key_off[g + 1] - off;
@@ -656,9 +687,9 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             if (pr & PR_FULL) errcode = 6;
             else {
                 fresh = (pr & (PR_INSERTED | PR_NEED_VERIFY)) != 0;
-                unsigned long long* mp = &T.dir[cslot].meta;
                 bool cl = false;
-                d = claim_segment(mp, ld_agent(mp), W.epoch, g, cl);
+                if (W.claims) d = claim_slot(W.claims, W.cmask, cslot, W.epoch16, g, cl);
+                else { unsigned long long* mp = &T.dir[cslot].meta; d = claim_segment(mp, ld_agent(mp), W.epoch, g, cl); }
                 claimed = cl;
                 rec = T.buckets[cslot].rec;
             }
@@ -687,14 +718,14 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 if (t == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
                     if (old == 0ull) {                               // new key: this thread inserts it
-                        slot = (uint32_t)pos; inserted = 1; fresh = true; cand = true; meta = 0ull;
+                        slot = (uint32_t)pos; inserted = 1; fresh = true; cand = true;
                         if (!key_store(T, pos, key, len)) { errcode = 6; cand = false; }
                         break;
                     }
                     t = old;
                     m = ld_agent(&T.dir[pos].meta);
                 }
-                if (t == tag) { slot = (uint32_t)pos; cand = true; meta = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
+                if (t == tag) { slot = (uint32_t)pos; cand = true; meta0 = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
             }
             if (!cand && !errcode) errcode = 6;                      // probe bound exceeded: table full
             if (cand && slot != home) {
@@ -715,7 +746,11 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     lds_barrier();
     uint32_t lead = tid;
     if (fast) { const uint32_t l = ltab[hidx]; if (skey[l] == slot) lead = l; }
-    if (fast && lead == tid) { d = claim_segment(&T.dir[slot].meta, meta, W.epoch, g, claimed); sd[tid] = d; }
+    if (fast && lead == tid) {
+        d = W.claims ? claim_slot(W.claims, W.cmask, slot, W.epoch16, g, claimed)
+                     : claim_segment(&T.dir[slot].meta, meta0, W.epoch, g, claimed);   // GUBER_FLAG_DIR_CLAIMS
+        sd[tid] = d;
+    }
     lds_barrier();
     if (fast && lead != tid) d = sd[lead];
     lds_barrier();

@@ -40,8 +40,9 @@ def test_get_peer_rate_limits_order_stable():
         e.close()
 
 
-# flags 0 = two-launch tile-bitmap pipeline (batches <= 65536); 2 = force the large-batch radix pipeline
-@pytest.mark.parametrize("flags", [0, 2])
+# flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 16 = the same with
+# claims in the directory entries (GUBER_FLAG_DIR_CLAIMS); 2 = force the large-batch radix pipeline
+@pytest.mark.parametrize("flags", [0, 2, 16])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_adversarial_streams(seed, flags):
     o, e = Oracle(cache_size=1 << 20), engine(flags=flags)
@@ -52,7 +53,7 @@ def test_adversarial_streams(seed, flags):
     e.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 16])
 def test_hot_key_runs(flags):
     now = streams.NOW0
     for algo in (0, 1):
@@ -91,7 +92,7 @@ def test_edge_cases_empty_ragged_long_keys(flags):
     e.close()
 
 
-@pytest.mark.parametrize("flags", [1, 3])
+@pytest.mark.parametrize("flags", [1, 3, 17])
 def test_hash_collisions_are_resolved_exactly(flags):
     """GUBER_FLAG_TEST_WEAK_HASH keeps 6 bits of the key hash: hundreds of distinct keys share a
     tag, so the exact key verification, probing past a collision and the in-batch retry path all run."""
@@ -463,3 +464,21 @@ def test_global_behaviour_device_resident_exchange_vs_model():
                           lambda now: [g.sync(now)], model, 1, 5, steps=60)
         finally:
             dist.destroy_process_group()
+
+
+def test_claim_table_epoch_wraps():
+    """The claim table's cells are tagged with a 16-bit batch epoch; after 65 535 batches the table is wiped and the
+    epoch restarts.  66 500 small batches (duplicates inside each) straddle the wrap and must stay bit-exact."""
+    o, e = Oracle(cache_size=1 << 12), engine(cache_size=1024, max_batch=1024)
+    rng = np.random.default_rng(9)
+    now = streams.NOW0
+    keys = [b"wrap_%d" % i for i in range(40)]
+    for i in range(66_500):
+        n = 3 if i % 1000 else 200
+        ks = [keys[j] for j in rng.integers(0, 40, n)]
+        b = HostBatch(ks, 1, 1_000_000, 3_600_000, now + i // 10)
+        if i % 1000 == 0 or i > 65_400:
+            support.assert_results_equal(e.eval(b), o.eval(b), f"batch {i}")
+        else:
+            e.eval(b); o.eval(b)
+    e.close()

@@ -58,14 +58,17 @@ if pm:
     lines += [f"## token: HBM traffic per launch (PMC, separate passes, last {n_pmc} dispatches)", "",
               "| kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | raw bytes | corrected bytes (2xFETCH+WRITE) | algorithmic bytes |", "|---|---|---|---|---|---|"]
     alg = {"k_front": 76 * 65536, "k_eval2": 73 * 65536}
-    tr = {}
+    tr, tr_raw = {}, {}
     for k in sorted(set(pm.get("FETCH_SIZE", {})) | set(pm.get("WRITE_SIZE", {}))):
         f, w = pm.get("FETCH_SIZE", {}).get(k, 0.0), pm.get("WRITE_SIZE", {}).get(k, 0.0)
         raw, cor = (f + w) * 1024, (2 * f + w) * 1024
         tr[k] = int(cor)
+        tr_raw[k] = int(raw)
         lines.append(f"| {k} | {f:.1f} | {w:.1f} | {raw:.0f} | {cor:.0f} | {alg.get(k, '')} |")
         out["traffic"][k] = dict(fetch_kib=f, write_kib=w, raw_bytes=raw, corrected_bytes=cor)
-    json.dump({"token": tr, "note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction"},
+    json.dump({"token": tr, "token_raw": tr_raw,
+               "note": "bytes per launch: token = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, an upper bound for 64-byte requests), "
+                       "token_raw = (FETCH_SIZE + WRITE_SIZE)*1024"},
               open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
 open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(lines) + "\n")
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_summary.json"), "w"), indent=1)
