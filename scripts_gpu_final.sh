@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.txt 2>&1; tail -3 gpurun_out/pytest_gpu.txt
 timeout 600 python bench.py > gpurun_out/bench_token.json 2> gpurun_out/bench_token.err; echo "token rc=$?"; cat gpurun_out/bench_token.json
 timeout 300 python bench.py --algo leaky --no-cpu-baseline > gpurun_out/bench_leaky.json 2>/dev/null; echo "leaky rc=$?"; cat gpurun_out/bench_leaky.json
 timeout 300 python bench.py --dist uniform --no-cpu-baseline > gpurun_out/bench_uniform.json 2>/dev/null; echo "uniform rc=$?"; cat gpurun_out/bench_uniform.json
