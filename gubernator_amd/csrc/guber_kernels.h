@@ -245,35 +245,39 @@ enum : uint32_t { PR_FOUND = 1, PR_INSERTED = 2, PR_NEED_VERIFY = 4, PR_FULL = 8
 //  - tags are write-once, so a stale "empty" read is resolved by the CAS;
 //  - an entry without META_READY was inserted during THIS launch by another thread whose key bytes
 //    may not be visible yet: the match is tentative (PR_NEED_VERIFY) and checked in the next launch.
-__device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, uint32_t len, uint64_t h,
-                                          bool insert, uint32_t& slot_out) {
+// The result packs the PR_* flags (low 32 bits) and the slot (high 32 bits): a by-reference out-parameter was
+// observed to come back as 0 from the inlined function with this compiler (ROCm 7.0.2 hipcc, gfx950) after an
+// unrelated layout change, so the slot travels in the return value.
+__device__ __forceinline__ uint64_t probe_packed(const Table& T, const uint8_t* key, uint32_t len, uint64_t h, bool insert) {
     h &= T.hash_mask;
     unsigned long long tag = h ? h : 1ull;
     uint64_t pos = (h >> 7) & T.mask;
     for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
         unsigned long long t = ld_agent(&T.dir[pos].tag);
         if (t == 0ull) {
-            if (!insert) { slot_out = 0; return PR_MISSING; }
+            if (!insert) return PR_MISSING;
             unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
             if (old == 0ull) {
-                slot_out = (uint32_t)pos;
-                if (!key_store(T, pos, key, len)) return PR_FULL | PR_INSERTED;
-                return PR_INSERTED;
+                if (!key_store(T, pos, key, len)) return (pos << 32) | PR_FULL | PR_INSERTED;
+                return (pos << 32) | PR_INSERTED;
             }
             t = old;
         }
         if (t == tag) {
             unsigned long long m = ld_agent(&T.dir[pos].meta);
             if (m & META_READY) {
-                if (key_equal(T, pos, key, len)) { slot_out = (uint32_t)pos; return PR_FOUND; }
+                if (key_equal(T, pos, key, len)) return (pos << 32) | PR_FOUND;
             } else {
-                slot_out = (uint32_t)pos;
-                return PR_NEED_VERIFY;
+                return (pos << 32) | PR_NEED_VERIFY;
             }
         }
     }
-    slot_out = 0;
     return PR_FULL;
+}
+__device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, uint32_t len, uint64_t h, bool insert, uint32_t& slot_out) {
+    const uint64_t r = probe_packed(T, key, len, h, insert);
+    slot_out = (uint32_t)(r >> 32);
+    return (uint32_t)r;
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
