@@ -81,7 +81,7 @@ struct guber_engine {
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_lrank; DevBuf<uint32_t> w_tilerow;
-    DevBuf<uint32_t> w_torder, w_did2;
+    DevBuf<uint32_t> w_did2;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -191,7 +191,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
-    rc |= e->w_lrank.ensure(e->fast_cap); rc |= e->w_torder.ensure(e->fast_cap);
+    rc |= e->w_lrank.ensure(e->fast_cap);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
@@ -234,7 +234,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.hist = e->w_hist.p;
     e->W.tiles = tiles; e->W.epoch = 0;
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilerow = e->w_tilerow.p;
-    e->W.lrank = e->w_lrank.p; e->W.torder = e->w_torder.p;
+    e->W.lrank = e->w_lrank.p;
 
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = (cfg->flags & GUBER_FLAG_DIR_CLAIMS) ? nullptr : e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
@@ -271,7 +271,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_flags2.release(); e->w_tilerow.release();
-    e->w_lrank.release(); e->w_torder.release(); e->w_did2.release();
+    e->w_lrank.release(); e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);

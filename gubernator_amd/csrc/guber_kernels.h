@@ -138,9 +138,8 @@ struct Work {
     unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
     uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
     uint32_t* seg_flags2;               // [2][cap]
-    uint32_t* tilerow;                  // [cap][FT_MAX_TILES]: start inside the tile << 16 | members, per (segment, tile)
+    uint32_t* tilerow;                  // [cap][FT_MAX_TILES]: members per (segment, tile) — written only for keys that span several tiles of a word
     uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
-    uint32_t* torder;                   // [max_batch] request index at each tile-sorted position
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
@@ -658,7 +657,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ uint32_t ltab[2 * FT];   // stage 2: slot-hash -> some thread holding that slot
     __shared__ int red[FT / 64];
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
-    __shared__ uint32_t gkey[GT], gstart[GT], galloc;
+    __shared__ uint32_t gkey[GT];
     __shared__ unsigned long long gbits[FT / 64][GT];
     const uint32_t tid = threadIdx.x, tile = blockIdx.x;
     const uint32_t g = tile * FT + tid;
@@ -831,7 +830,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
 #pragma unroll
         for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
     }
-    if (tid == 0) galloc = 0;
     lds_barrier();
     uint32_t gh = 0;
     if (valid) {
@@ -856,20 +854,26 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             else if (w == wave) eq_before += __popcll(bw & ((1ull << lane) - 1ull));
             if (!found_head && bw) { head_tid = w * 64 + (uint32_t)__ffsll((unsigned long long)bw) - 1; found_head = true; }
         }
-        if (eq_before == 0) gstart[gh] = atomicAdd(&galloc, eq_total);   // contiguous range for the group
     }
-    lds_barrier();
     GB_STAMP(4);
     // ---- phase C: publish groups -------------------------------------------------------------------
     if (valid) {
-        const uint32_t start = gstart[gh];
-        W.torder[tile * FT + start + eq_before] = g;
         W.lrank[g] = (uint16_t)(eq_before | (head_tid << 8));   // rank in group | tid of the group's head
         if (eq_before == 0) {
-            W.tilerow[(size_t)d * FT_MAX_TILES + tile] = (start << 16) | eq_total;   // group start | size
             // ONE atomic per (segment, tile) group: set the tile's bit and add the group size (bits are set once
-            // each, so the add never carries into the count)
-            atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
+            // each, so the add never carries into the count).  Its return value tells whether other tiles of this
+            // 32-tile word already hold the key — only then are per-tile counts needed (k_eval2 ranks a request by
+            // the members in earlier tiles), so the scattered count is written only for keys spanning several tiles:
+            // every arriver but the first writes its own, and the second also writes the first's (= the word's
+            // count so far, the first having been alone).
+            const unsigned long long old = atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)],
+                                                     ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
+            const uint32_t ob = (uint32_t)old;
+            if (ob) {
+                uint32_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
+                row[tile] = eq_total;
+                if ((ob & (ob - 1u)) == 0u) row[(tile & ~31u) + (uint32_t)__ffs((int)ob) - 1u] = (uint32_t)(old >> 32);
+            }
         }
     }
     GB_STAMP(5);
@@ -952,7 +956,6 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
-            const uint32_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
             const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
             const uint32_t slot = s0.pad;
@@ -983,18 +986,22 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
                     if (out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
                 }
             } else if (rank == 0) {
-                // requests to this key differ: apply them one by one in request order (tiles in order,
-                // members of a tile in their sorted = request order)
+                // requests to this key differ: apply them one by one in request order — tiles in order (bitmap), and
+                // inside a tile the requests whose segment id is d, found by scanning the tile's 256 ids
                 Rec s = s0;
                 for (int w = 0; w < FT_WORDS; ++w) {
                     uint32_t mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + w];
                     while (mm) {
                         const uint32_t tt = w * 32 + (uint32_t)__ffs((int)mm) - 1;
                         mm &= mm - 1u;
-                        const uint32_t start = tt * FT + (row[tt] >> 16);
-                        const uint32_t cnt = row[tt] & 0xffffu;
-                        for (uint32_t q = start; q < start + cnt; ++q) {
-                            const uint32_t j = W.torder[q];
+                        const uint4* ids = (const uint4*)(W.did + (size_t)tt * FT);
+                        for (uint32_t q4 = 0; q4 < FT / 4 && tt * FT + q4 * 4 < B.n; ++q4) {
+                          const uint4 v = ids[q4];
+                          const uint32_t four[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                          for (uint32_t e4 = 0; e4 < 4; ++e4) {
+                            const uint32_t j = tt * FT + q4 * 4 + e4;
+                            if (four[e4] != d || j >= B.n) continue;
                             const Req rj = load_req(B, j);
                             Resp out;
                             const uint32_t ev = apply(s, rj, B.now_ms, out);
@@ -1002,6 +1009,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
                             store_events(W, j, ev, s);
                             if (out.err == 0) queue_global(T, slot, rj, 1);
                             c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
+                          }
                         }
                     }
                 }
