@@ -1,0 +1,219 @@
+// guber_kernels_ops.h — everything that is not batch evaluation: cache operations (AddCacheItem / GetCacheItem / Remove /
+// Each), Store residency probe, GLOBAL queue flush, table compaction, consistent-hash routers, device item columns.
+#pragma once
+#include "guber_table.h"
+
+namespace guber {
+
+// ---------------------------------------------------------------------------------------------
+// maintenance kernels: AddCacheItem / GetCacheItem / Remove / Each
+struct ItemIn {   // device image of guber_item_t with the key referenced by offset
+    Rec rec; uint32_t key_off, key_len;
+};
+
+// phase A: find-or-insert the directory entry (flags as in k_resolve)
+__global__ __launch_bounds__(256) void k_items_probe(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
+                                                     uint32_t* slots, uint8_t* flags) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* key = keys + items[i].key_off;
+    const uint32_t len = items[i].key_len;
+    uint32_t slot = 0; uint8_t f = 0;
+    if (len == 0 || len > T.max_key) f = RF_ERR;
+    else {
+        uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, slot);
+        if (pr & PR_FULL) f = RF_ERR;
+        if (pr & PR_INSERTED) { f |= RF_INSERTED; atomicAdd(&T.ctr->tags_used, 1ull); }
+        if (pr & PR_NEED_VERIFY) f |= RF_NEED_VERIFY;
+    }
+    slots[i] = slot; flags[i] = f;
+}
+// phase B: verify tentative matches, publish READY, LRUCache.Add (lrucache.go:88-103): replace the
+// value when the key is resident (existed = 1), insert otherwise.  result: 0/1 existed, 0xFF retry, 0xFE error
+__global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
+                                                      const uint32_t* slots, const uint8_t* flags, uint8_t* result) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t f = flags[i];
+    const uint32_t slot = slots[i];
+    if (f & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
+    if (f & RF_ERR) { result[i] = 0xFE; return; }
+    if ((f & RF_NEED_VERIFY) && !key_equal(T, slot, keys + items[i].key_off, items[i].key_len)) { result[i] = 0xFF; return; }
+    const bool existed = rec_kind(T.buckets[slot].rec) != K_ABSENT;
+    T.buckets[slot].rec = items[i].rec;
+    if (!existed) atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
+    result[i] = existed ? 1 : 0;
+}
+
+// LRUCache.GetItem (lrucache.go:111-128) / Remove (:131-135) for one key. mode 0 = get, 1 = remove
+__global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    *found = 0;
+    uint32_t slot;
+    if (len == 0 || len > T.max_key) return;
+    uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), false, slot);
+    Rec s; rec_clear(s);
+    if (pr & PR_FOUND) s = T.buckets[slot].rec;
+    if (rec_kind(s) == K_ABSENT) { if (mode == 0) atomicAdd(&T.ctr->misses, 1ull); return; }
+    if (mode == 1 || rec_expired(s, now)) {
+        Rec z; rec_clear(z);
+        T.buckets[slot].rec = z;
+        atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)-1);
+        if (mode == 0) atomicAdd(&T.ctr->misses, 1ull);
+        return;
+    }
+    if (mode == 0) atomicAdd(&T.ctr->hits, 1ull);
+    *out = s; *found = 1;
+}
+
+// Read-only residency test per request key: 1 = absent or expired at `now` (what LRUCache.GetItem would report as
+// a miss, lrucache.go:111-128) — the keys a configured Store has to be asked for (algorithms.go:45-51).
+__global__ __launch_bounds__(256) void k_probe_missing(Table T, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
+                                                       int64_t now, uint8_t* missing) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+    uint8_t m = 1;
+    if (len != 0 && len <= T.max_key) {
+        uint32_t slot = 0;
+        const uint32_t pr = probe(T, key_bytes + off, len, xxhash64(key_bytes + off, len, 0), false, slot);
+        if (pr & PR_FOUND) {
+            const Rec s = T.buckets[slot].rec;
+            m = (rec_kind(s) == K_ABSENT || rec_expired(s, now)) ? 1 : 0;
+        }
+    }
+    missing[i] = m;
+}
+
+// LRUCache.Each (lrucache.go:76-85): compact every resident bucket (+ its key cell) into out arrays
+__global__ __launch_bounds__(256) void k_dump(Table T, uint64_t slots, Rec* out_recs, KeyCell* out_cells, uint64_t cap,
+                                              unsigned long long* count) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= slots) return;
+    if (T.dir[s].tag == 0ull) return;
+    Rec r = T.buckets[s].rec;
+    if (rec_kind(r) == K_ABSENT) return;
+    unsigned long long idx = atomicAdd(count, 1ull);
+    if (idx < cap) { out_recs[idx] = r; out_cells[idx] = T.buckets[s].cell; }
+}
+
+// globalManager flush (global.go:114-139 / 200-215): turn every pending record into one request row
+// (key bytes from the bucket's key cell, summed hits / template fields) and clear it.
+struct GTakeOut {
+    uint8_t* key_bytes; uint32_t* key_len;      // key i occupies key_bytes[i*stride .. +key_len[i])
+    int64_t *hits, *limit, *duration, *burst, *created_at;
+    uint32_t* behavior; uint8_t* algorithm; uint8_t* role;   // role 1 = hits for the owner, 2 = owner update
+    uint32_t stride;
+};
+__global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, uint32_t role_mask, uint32_t* keep_list,
+                                                     unsigned int* counters /* [0] rows out, [1] kept */, GTakeOut O) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t slot = T.gdirty[j];
+    GPend p = T.gpend[slot];
+    if (!((role_mask >> p.queued) & 1u)) {            // not asked for: stays pending
+        keep_list[atomicAdd(&counters[1], 1u)] = slot;
+        return;
+    }
+    const uint32_t i = atomicAdd(&counters[0], 1u);
+    const KeyCell* c = &T.buckets[slot].cell;
+    const uint32_t len = (uint32_t)(c->w[7] >> 48);
+    const uint8_t* src = len <= INLINE_KEY ? (const uint8_t*)c->w : T.arena + c->w[0];
+    uint8_t* dst = O.key_bytes + (size_t)i * O.stride;
+    for (uint32_t b = 0; b < O.stride; ++b) dst[b] = b < len ? src[b] : 0;
+    O.key_len[i] = len;
+    O.hits[i] = p.hits; O.limit[i] = p.limit; O.duration[i] = p.duration; O.burst[i] = p.burst;
+    O.created_at[i] = p.created_at; O.behavior[i] = p.behavior; O.algorithm[i] = p.algorithm; O.role[i] = p.queued;
+    GPend z; __builtin_memset(&z, 0, sizeof(z));
+    T.gpend[slot] = z;
+}
+
+// Table compaction: re-insert every LIVE bucket (present and not expired at `now`) of the old table into a
+// fresh one.  Expired buckets are indistinguishable from absent ones for the algorithm (lrucache.go:115-119
+// removes them on access), removed buckets (K_ABSENT) only kept their tag for probing; both are dropped, which
+// frees their directory entries — the stand-in for the reference's bounded LRU (lrucache.go:98-100,138-149).
+__global__ __launch_bounds__(256) void k_compact(Table Old, uint64_t old_slots, Table New, int64_t now,
+                                                 unsigned long long* kept) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= old_slots) return;
+    const unsigned long long tag = Old.dir[s].tag;
+    if (tag == 0ull) return;
+    const Bucket b = Old.buckets[s];
+    if (rec_kind(b.rec) == K_ABSENT || rec_expired(b.rec, now)) return;
+    uint64_t pos = ((tag == 1ull ? 0ull : tag) >> 7) & New.mask;     // same home position rule as probe()
+    for (uint64_t step = 0; step <= New.mask; ++step, pos = (pos + 1) & New.mask) {
+        if (atomicCAS(&New.dir[pos].tag, 0ull, tag) == 0ull) {
+            New.dir[pos].meta = META_READY;
+            New.buckets[pos] = b;                                     // long keys keep their arena offset
+            atomicAdd(kept, 1ull);
+            return;
+        }
+    }
+}
+
+// wrap of the 31-bit batch epoch: forget every dense-id claim
+__global__ __launch_bounds__(256) void k_clear_claims(Table T, uint64_t slots) {
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < slots) T.dir[s].meta &= META_READY;
+}
+
+// ReplicatedConsistentHash.Get (replicated_hash.go:104-119): owner of each key on a sorted ring.
+__global__ __launch_bounds__(256) void k_route(const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
+                                               const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
+                                               int kind, uint32_t* owner) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* lh = (uint64_t*)smem;
+    for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* k = key_bytes + key_off[i];
+    const uint32_t len = key_off[i + 1] - key_off[i];
+    const uint64_t h = kind == 1 ? fnv1a_64(k, len) : fnv1_64(k, len);
+    uint32_t lo = 0, hi = npts;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (lh[mid] >= h) hi = mid; else lo = mid + 1; }
+    if (lo == npts) lo = 0;
+    owner[i] = ring_owner[lo];
+}
+
+// the same for keys stored as rows of a [n][stride] matrix with explicit lengths (guber_global_take_dev rows)
+__global__ __launch_bounds__(256) void k_route_rows(const uint8_t* key_rows, uint32_t stride, const uint32_t* key_len, uint32_t n,
+                                                    const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
+                                                    int kind, uint32_t* owner) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* lh = (uint64_t*)smem;
+    for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* k = key_rows + (size_t)i * stride;
+    const uint32_t len = key_len[i];
+    const uint64_t h = kind == 1 ? fnv1a_64(k, len) : fnv1_64(k, len);
+    uint32_t lo = 0, hi = npts;
+    while (lo < hi) { uint32_t mid = lo + ((hi - lo) >> 1); if (lh[mid] >= h) hi = mid; else lo = mid + 1; }
+    if (lo == npts) lo = 0;
+    owner[i] = ring_owner[lo];
+}
+
+// guber_add_items_dev: build the ItemIn image (bucket record + key reference) of device-resident item columns —
+// the device twin of rec_from_item() in guber_engine.hip (UpdatePeerGlobals / Loader items, gubernator.go:425-459)
+struct ItemsSoA {
+    const uint32_t* key_off; const uint8_t *algorithm, *status;
+    const int64_t *limit, *duration, *remaining; const double* remaining_f;
+    const int64_t *stamp, *burst, *expire_at, *invalid_at;
+};
+__global__ __launch_bounds__(256) void k_items_from_soa(ItemsSoA S, uint32_t n, ItemIn* out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Rec s; rec_clear(s);
+    const uint8_t algo = S.algorithm[i];
+    s.limit = S.limit[i]; s.duration = S.duration[i]; s.stamp = S.stamp[i]; s.burst = S.burst ? S.burst[i] : 0;
+    s.expire_at = S.expire_at[i]; s.invalid_at = S.invalid_at ? S.invalid_at[i] : 0;
+    if (algo == ALGO_TOKEN) { s.remaining = S.remaining[i]; s.burst = 0; s.meta = make_meta(K_TOKEN, S.status ? S.status[i] : 0, ALGO_TOKEN); }
+    else if (algo == ALGO_LEAKY) { s.remaining = f2bits(S.remaining_f[i]); s.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY); }
+    else s.meta = make_meta(K_NIL, 0, algo);
+    ItemIn o; o.rec = s; o.key_off = S.key_off[i]; o.key_len = S.key_off[i + 1] - S.key_off[i];
+    out[i] = o;
+}
+
+}  // namespace guber
