@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_pool_set_store", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS = 1, 2, 4, 8, 16
@@ -328,10 +328,12 @@ class V1Instance:
     GPUWorkerPool.  Thread-safe; requests are dicts with the RateLimitReq field names."""
     ERR_STRIDE = 200
 
-    def __init__(self, cache_size=50_000, device=0, batch_limit=1000, batch_wait_us=500, flags=0):
+    def __init__(self, cache_size=50_000, device=0, batch_limit=1000, batch_wait_us=500, flags=0, shards=1):
         cfg = GuberConfig(C.sizeof(GuberConfig), device, cache_size, 0, max(batch_limit, 1024), 0, None, flags, 0)
         self.h = C.c_void_p()
-        _check(lib().guber_pool_create(C.byref(cfg), batch_limit, batch_wait_us, C.byref(self.h)))
+        L = lib()
+        L.guber_pool_create_sharded.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        _check(L.guber_pool_create_sharded(C.byref(cfg), shards, batch_limit, batch_wait_us, C.byref(self.h)))
 
     def set_clock(self, now_ms):
         lib().guber_pool_set_clock(self.h, now_ms)

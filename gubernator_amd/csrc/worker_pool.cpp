@@ -8,26 +8,52 @@
 
 namespace gubernator {
 
-GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us)
+GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards)
     : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
+    if (shards == 0) shards = 1;
+    ring_step_ = (1ull << 63) / shards;                              // workers.go:132 hashRingStep
     guber_config_t c = cfg;
     if (c.max_batch < batch_limit_) c.max_batch = batch_limit_;
-    create_rc_ = guber_engine_create(&c, &engine_);
-    if (create_rc_ != GUBER_OK) { engine_ = nullptr; return; }
-    thread_ = std::thread([this] { run(); });
+    if (shards > 1) c.cache_size = c.cache_size / shards + 1;        // workers.go:132 `CacheSize / Workers` per worker
+    for (uint32_t i = 0; i < shards; ++i) {
+        std::unique_ptr<Shard> sh(new Shard());
+        create_rc_ = guber_engine_create(&c, &sh->engine);
+        if (create_rc_ != GUBER_OK) { sh->engine = nullptr; break; }
+        shards_.push_back(std::move(sh));
+    }
+    if (create_rc_ != GUBER_OK) {
+        for (auto& sh : shards_) guber_engine_destroy(sh->engine);
+        shards_.clear();
+        return;
+    }
+    for (auto& sh : shards_) { Shard* p = sh.get(); p->thread = std::thread([this, p] { run(*p); }); }
 }
 
 GPUWorkerPool::~GPUWorkerPool() { Close(); }
 
 void GPUWorkerPool::Close() {
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (closing_) return;
-        closing_ = true;
+    if (closed_) return;
+    closed_ = true;
+    for (auto& sh : shards_) {
+        { std::lock_guard<std::mutex> lk(sh->mu); sh->closing = true; }
+        sh->cv.notify_all();
     }
-    cv_.notify_all();
-    if (thread_.joinable()) thread_.join();
-    if (engine_) { guber_engine_destroy(engine_); engine_ = nullptr; }
+    for (auto& sh : shards_) {
+        if (sh->thread.joinable()) sh->thread.join();
+        if (sh->engine) { guber_engine_destroy(sh->engine); sh->engine = nullptr; }
+    }
+}
+
+uint32_t GPUWorkerPool::ShardOf(const std::string& key) const {
+    if (shards_.size() <= 1) return 0;
+    const uint64_t h63 = guber_xxhash64((const uint8_t*)key.data(), key.size(), 0) >> 1;   // workers.go:153-155 ComputeHash63
+    const uint64_t idx = h63 / ring_step_;                                                  // workers.go:180-184 getWorker
+    return (uint32_t)std::min<uint64_t>(idx, shards_.size() - 1);
+}
+uint64_t GPUWorkerPool::batches_flushed() const {
+    uint64_t n = 0;
+    for (auto& sh : shards_) n += sh->flushed;
+    return n;
 }
 
 int64_t GPUWorkerPool::NowMs() const {
@@ -47,41 +73,47 @@ bool GPUWorkerPool::GetRateLimit(const RateLimitReq& r, RateLimitReqState st, Ra
 void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
                                      std::vector<RateLimitResp*>& out) {
     if (reqs.empty()) return;
+    if (closed_ || shards_.empty()) {
+        for (auto* r : out) r->error = "worker pool is closed";
+        return;
+    }
     Call call;
     call.remaining = reqs.size();
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (closing_ || !engine_) {
-            for (auto* r : out) r->error = "worker pool is closed";
-            return;
-        }
-        for (size_t i = 0; i < reqs.size(); ++i) queue_.push_back({reqs[i], st[i], out[i], &call});
+    // every request goes to the queue of its key's shard (workers.go:261-291); requests of one key keep their order
+    std::vector<std::vector<Pending>> per(shards_.size());
+    for (size_t i = 0; i < reqs.size(); ++i)
+        per[shards_.size() > 1 ? ShardOf(reqs[i]->HashKey()) : 0].push_back({reqs[i], st[i], out[i], &call});
+    for (size_t j = 0; j < per.size(); ++j) {
+        if (per[j].empty()) continue;
+        Shard& sh = *shards_[j];
+        { std::lock_guard<std::mutex> lk(sh.mu); sh.queue.insert(sh.queue.end(), per[j].begin(), per[j].end()); }
+        sh.cv.notify_all();
     }
-    cv_.notify_all();
     std::unique_lock<std::mutex> lk(call.mu);
     call.cv.wait(lk, [&] { return call.remaining == 0; });
 }
 
-void GPUWorkerPool::run() {
+void GPUWorkerPool::run(Shard& sh) {
     std::vector<Pending> batch;
     for (;;) {
         {
-            std::unique_lock<std::mutex> lk(mu_);
-            cv_.wait(lk, [&] { return closing_ || !queue_.empty(); });
-            if (queue_.empty() && closing_) return;
+            std::unique_lock<std::mutex> lk(sh.mu);
+            sh.cv.wait(lk, [&] { return sh.closing || !sh.queue.empty(); });
+            if (sh.queue.empty() && sh.closing) return;
             // flush at batch_limit or batch_wait after the first queued item (peer_client.go:284-337)
-            if (queue_.size() < batch_limit_ && !closing_)
-                cv_.wait_for(lk, std::chrono::microseconds(batch_wait_us_), [&] { return closing_ || queue_.size() >= batch_limit_; });
-            const size_t take = std::min<size_t>(queue_.size(), batch_limit_);
-            batch.assign(queue_.begin(), queue_.begin() + take);
-            queue_.erase(queue_.begin(), queue_.begin() + take);
+            if (sh.queue.size() < batch_limit_ && !sh.closing)
+                sh.cv.wait_for(lk, std::chrono::microseconds(batch_wait_us_), [&] { return sh.closing || sh.queue.size() >= batch_limit_; });
+            const size_t take = std::min<size_t>(sh.queue.size(), batch_limit_);
+            batch.assign(sh.queue.begin(), sh.queue.begin() + take);
+            sh.queue.erase(sh.queue.begin(), sh.queue.begin() + take);
         }
-        flush(batch);
+        flush(sh, batch);
         batch.clear();
     }
 }
 
-void GPUWorkerPool::flush(std::vector<Pending>& batch) {
+void GPUWorkerPool::flush(Shard& sh, std::vector<Pending>& batch) {
+    guber_engine_t* const engine_ = sh.engine;
     const uint32_t n = (uint32_t)batch.size();
     const int64_t now = NowMs();
     std::vector<uint8_t> keys; std::vector<uint32_t> off(n + 1), beh(n);
@@ -157,7 +189,7 @@ void GPUWorkerPool::flush(std::vector<Pending>& batch) {
             if ((sflags[i] & GUBER_STORE_ONCHANGE) && store_.on_change) { const guber_store_req_t q = store_req(i); store_.on_change(store_.user, &q, &sitems[i]); }
         }
     }
-    flushed_++;
+    sh.flushed++;
     for (uint32_t i = 0; i < n; ++i) {
         RateLimitResp& o = *batch[i].resp;
         o = RateLimitResp{};
@@ -178,32 +210,46 @@ void GPUWorkerPool::flush(std::vector<Pending>& batch) {
     }
 }
 
-int GPUWorkerPool::AddCacheItem(const guber_item_t& item) { return guber_add_items(engine_, &item, 1, nullptr); }
+int GPUWorkerPool::AddCacheItem(const guber_item_t& item) {
+    if (shards_.empty()) return GUBER_E_INVALID_ARG;
+    return guber_add_items(shards_[ShardOf(std::string((const char*)item.key, item.key_len))]->engine, &item, 1, nullptr);
+}
 int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool* found) {
     int f = 0;
-    const int rc = guber_get_item(engine_, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
+    if (shards_.empty()) return GUBER_E_INVALID_ARG;
+    const int rc = guber_get_item(shards_[ShardOf(key)]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
     *found = f != 0;
     return rc;
 }
 int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n) {
-    for (uint32_t lo = 0; lo < n; lo += 65536) {          // chunks bound the staging buffers
-        const int rc = guber_add_items(engine_, items + lo, std::min<uint32_t>(65536, n - lo), nullptr);
-        if (rc != GUBER_OK) return rc;
-    }
+    // workers.go:329-449: every item goes to the worker that owns its key; chunks bound the staging buffers
+    std::vector<std::vector<guber_item_t>> per(shards_.size());
+    for (uint32_t i = 0; i < n; ++i) per[ShardOf(std::string((const char*)items[i].key, items[i].key_len))].push_back(items[i]);
+    for (size_t j = 0; j < per.size(); ++j)
+        for (size_t lo = 0; lo < per[j].size(); lo += 65536) {
+            const int rc = guber_add_items(shards_[j]->engine, per[j].data() + lo, (uint32_t)std::min<size_t>(65536, per[j].size() - lo), nullptr);
+            if (rc != GUBER_OK) return rc;
+        }
     return GUBER_OK;
 }
 int GPUWorkerPool::Store(const std::function<void(const guber_item_t&)>& save) {
-    uint64_t n = 0, arena = 0;
-    int rc = guber_dump(engine_, nullptr, 0, nullptr, 0, &n, &arena);           // sizes first
-    if (rc != GUBER_OK && rc != GUBER_E_NOMEM) return rc;
-    std::vector<guber_item_t> items(n + 1024);
-    std::vector<uint8_t> keys(arena + 64 * 1024);
-    rc = guber_dump(engine_, items.data(), items.size(), keys.data(), keys.size(), &n, &arena);
-    if (rc != GUBER_OK) return rc;
-    for (uint64_t i = 0; i < n; ++i) save(items[i]);
+    for (auto& sh : shards_) {                                                        // workers.go:451-534: every worker in turn
+        uint64_t n = 0, arena = 0;
+        int rc = guber_dump(sh->engine, nullptr, 0, nullptr, 0, &n, &arena);          // sizes first
+        if (rc != GUBER_OK && rc != GUBER_E_NOMEM) return rc;
+        std::vector<guber_item_t> items(n + 1024);
+        std::vector<uint8_t> keys(arena + 64 * 1024);
+        rc = guber_dump(sh->engine, items.data(), items.size(), keys.data(), keys.size(), &n, &arena);
+        if (rc != GUBER_OK) return rc;
+        for (uint64_t i = 0; i < n; ++i) save(items[i]);
+    }
     return GUBER_OK;
 }
-int64_t GPUWorkerPool::Size() { return guber_size(engine_); }
+int64_t GPUWorkerPool::Size() {
+    int64_t n = 0;
+    for (auto& sh : shards_) n += guber_size(sh->engine);
+    return n;
+}
 
 bool V1Instance::GetRateLimits(std::vector<RateLimitReq>& reqs, std::vector<RateLimitResp>* resps, std::string* rpc_error) {
     if (reqs.size() > kMaxBatchSize) {                                // gubernator.go:189-193
@@ -240,8 +286,12 @@ using namespace gubernator;
 struct guber_pool { GPUWorkerPool* pool; V1Instance* inst; };
 
 extern "C" int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out) {
+    return guber_pool_create_sharded(cfg, 1, batch_limit, batch_wait_us, out);
+}
+extern "C" int guber_pool_create_sharded(const guber_config_t* cfg, uint32_t shards, uint32_t batch_limit, uint32_t batch_wait_us,
+                                         guber_pool_t** out) {
     if (!cfg || !out) return GUBER_E_INVALID_ARG;
-    GPUWorkerPool* p = new GPUWorkerPool(*cfg, batch_limit, batch_wait_us);
+    GPUWorkerPool* p = new GPUWorkerPool(*cfg, batch_limit, batch_wait_us, shards);
     if (!p->ok()) { const int rc = p->create_error(); delete p; return rc; }
     *out = new guber_pool{p, new V1Instance(p)};
     return GUBER_OK;
@@ -250,6 +300,9 @@ extern "C" void guber_pool_destroy(guber_pool_t* p) {
     if (!p) return;
     p->pool->Close();
     delete p->inst; delete p->pool; delete p;
+}
+extern "C" uint32_t guber_pool_shard_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len) {
+    return p ? p->pool->ShardOf(std::string((const char*)key, key_len)) : 0;
 }
 extern "C" int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n) { return p ? p->pool->Load(items, n) : GUBER_E_INVALID_ARG; }
 extern "C" int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user) {

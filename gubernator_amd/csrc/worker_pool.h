@@ -8,6 +8,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -36,9 +37,13 @@ constexpr uint32_t kMaxBatchSize = 1000;              // gubernator.go:40
 
 class GPUWorkerPool {
  public:
-    GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us);
+    // `shards` = Config.Workers of the reference (config.go:110, workers.go:125-151): the key space is split by
+    // hash range into that many independent caches, here one HBM table + HIP stream + batcher thread each, so that
+    // batches of different shards overlap on the GPU (4 saturate an MI355X).  cfg.cache_size is per pool, as in the
+    // reference (each shard gets cache_size / shards, workers.go:132).
+    GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards = 1);
     ~GPUWorkerPool();
-    bool ok() const { return engine_ != nullptr; }
+    bool ok() const { return !shards_.empty() && create_rc_ == 0; }
     int create_error() const { return create_rc_; }
 
     // WorkerPool.GetRateLimit (workers.go:261): blocks until the request's batch has been evaluated.
@@ -60,25 +65,33 @@ class GPUWorkerPool {
     void SetStore(const guber_store_callbacks_t* cb) { has_store_ = cb != nullptr; if (cb) store_ = *cb; }
     void SetClockMs(int64_t now_ms) { frozen_ms_ = now_ms; }
     int64_t NowMs() const;
-    guber_engine_t* engine() { return engine_; }
-    uint64_t batches_flushed() const { return flushed_; }
+    guber_engine_t* engine(uint32_t shard = 0) { return shard < shards_.size() ? shards_[shard]->engine : nullptr; }
+    uint32_t shards() const { return (uint32_t)shards_.size(); }
+    // WorkerPool.getWorker (workers.go:180-184): shard = (XXH64(key) >> 1) / (2^63 / shards)
+    uint32_t ShardOf(const std::string& key) const;
+    uint64_t batches_flushed() const;
 
  private:
     struct Call { std::mutex mu; std::condition_variable cv; size_t remaining = 0; };
     struct Pending { const RateLimitReq* req; RateLimitReqState st; RateLimitResp* resp; Call* call; };
-    void run();
-    void flush(std::vector<Pending>& batch);
+    struct Shard {              // one "worker" of the reference: its own cache (engine), queue and goroutine (thread)
+        guber_engine_t* engine = nullptr;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::vector<Pending> queue;
+        bool closing = false;
+        std::thread thread;
+        uint64_t flushed = 0;
+    };
+    void run(Shard& sh);
+    void flush(Shard& sh, std::vector<Pending>& batch);
 
-    guber_engine_t* engine_ = nullptr;
+    std::vector<std::unique_ptr<Shard>> shards_;
+    uint64_t ring_step_ = 0;
     int create_rc_ = 0;
     uint32_t batch_limit_, batch_wait_us_;
-    std::mutex mu_;
-    std::condition_variable cv_;
-    std::vector<Pending> queue_;
-    bool closing_ = false;
-    std::thread thread_;
+    bool closed_ = false;
     volatile int64_t frozen_ms_ = 0;
-    uint64_t flushed_ = 0;
     bool has_store_ = false;
     guber_store_callbacks_t store_{};
 };

@@ -286,6 +286,10 @@ int guber_global_take(guber_engine_t* e, uint32_t role_mask /* bit 1: hits rows,
  *      bindings and tests; thread-safe: any number of threads may call guber_pool_get_rate_limits. */
 typedef struct guber_pool guber_pool_t;
 int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out);
+/* `shards` = Config.Workers (config.go:110): the key space split by XXH64 range (workers.go:153-155,180-184) over that many
+ * engines + batcher threads inside one GPU, so that batches of different shards overlap; cfg->cache_size is the pool total. */
+int guber_pool_create_sharded(const guber_config_t* cfg, uint32_t shards, uint32_t batch_limit, uint32_t batch_wait_us,
+                              guber_pool_t** out);
 void guber_pool_destroy(guber_pool_t* p);
 void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms);
 /* Config.Store for the pool: the batcher drives guber_probe_missing / guber_add_items / guber_eval_batch_store and
@@ -305,6 +309,7 @@ typedef struct guber_store_callbacks {
 void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb);
 /* WorkerPool.Load / WorkerPool.Store (workers.go:329-449, 451-534): the Loader's items into the cache at start-up; every
  * resident item to Loader.Save at shutdown (`save` is called once per item; item->key is valid during the call). */
+uint32_t guber_pool_shard_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len);   /* WorkerPool.getWorker, workers.go:180-184 */
 int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n);
 int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user);      /* before the first request; NULL = none */   /* clock.Freeze of the reference tests; 0 = wall clock */
 guber_engine_t* guber_pool_engine(guber_pool_t* p);

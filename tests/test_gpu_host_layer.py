@@ -12,11 +12,12 @@ import support
 pytestmark = pytest.mark.gpu
 
 
-def test_functional_vectors_through_v1instance():
+@pytest.mark.parametrize("shards", [1, 4])
+def test_functional_vectors_through_v1instance(shards):
     """functional_test.go tables replayed through V1Instance.GetRateLimits (frozen clock = clock.Freeze)."""
     n = 0
     for sc in scenarios.load("functional_vectors.json")["scenarios"]:
-        inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=50)
+        inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=50, shards=shards)
         now = sc["start_ms"]
         for si, step in enumerate(sc.get("steps", [])):
             inst.set_clock(now)
@@ -69,10 +70,11 @@ def test_peer_order_stability_batch_sizes():
     inst.close()
 
 
-def test_concurrent_callers_are_batched_and_consistent():
+@pytest.mark.parametrize("shards", [1, 4])
+def test_concurrent_callers_are_batched_and_consistent(shards):
     """Many goroutine-like callers on one key set (benchmark_test.go "Thundering herd" shape): every hit is
     accounted exactly once — admitted hits == limit per key — and callers share device batches."""
-    inst = ga.V1Instance(cache_size=8192, batch_limit=512, batch_wait_us=300)
+    inst = ga.V1Instance(cache_size=8192, batch_limit=512, batch_wait_us=300, shards=shards)
     inst.set_clock(1_700_000_000_000)
     keys, limit, threads, per_thread = 20, 50, 16, 25
     admitted = np.zeros(keys, np.int64)
@@ -91,7 +93,7 @@ def test_concurrent_callers_are_batched_and_consistent():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert (admitted == limit).all(), admitted                     # 16*25 = 400 hits per key, limit 50
-    assert inst.batches() < threads * per_thread                    # callers were coalesced into shared batches
+    assert inst.batches() < threads * per_thread * shards           # callers were coalesced into shared batches
     inst.close()
 
 
@@ -182,11 +184,12 @@ def test_store_callbacks_through_the_pool_teststore():
     assert scenarios.run_store_events(PoolBackend) == 10
 
 
-def test_loader_round_trip_through_the_pool():
+@pytest.mark.parametrize("shards", [1, 3])
+def test_loader_round_trip_through_the_pool(shards):
     """store_test.go:76-125 TestLoader: items handed over by Loader.Load are served from the cache, and Loader.Save at
     shutdown receives every resident item with its current state ({Limit 2, Remaining 1, UNDER} after one hit)."""
     now = 1_700_000_000_000
-    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200, shards=shards)
     inst.set_clock(now)
     inst.load([ga.make_item(f"loaded_k{i}", 0, limit=10, duration=60_000, remaining=10 - i % 5, stamp=now - 5, expire_at=now + 59_995)
                for i in range(300)])
@@ -199,4 +202,28 @@ def test_loader_round_trip_through_the_pool():
     it = saved[b"test_over_limit_account:1234"]
     assert (it["algorithm"], it["limit"], it["remaining"], it["status"]) == (0, 2, 1, 0)
     assert saved[b"loaded_k3"]["remaining"] == 6 and saved[b"loaded_k7"]["remaining"] == 10 - 7 % 5
+    inst.close()
+
+
+def test_pool_shards_follow_the_reference_worker_rule():
+    """WorkerPool.getWorker (workers.go:153-155,180-184; workers_internal_test.go:51-54): shard = XXH64(key) >> 1 divided by
+    2^63 / workers — the pool's key -> shard map must be exactly that, and every key must live in exactly one shard."""
+    import ctypes as C
+    import xxhash
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=100, shards=5)
+    L = ga.lib()
+    L.guber_pool_shard_of.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+    L.guber_pool_shard_of.restype = C.c_uint32
+    o = support.oracle_lib()
+    seen = set()
+    for i in range(2000):
+        k = b"shardkey_%d" % i
+        want = o.oracle_worker_index_for_hash63(5, xxhash.xxh64(k, seed=0).intdigest() >> 1)
+        assert L.guber_pool_shard_of(inst.h, k, len(k)) == want
+        seen.add(want)
+    assert seen == {0, 1, 2, 3, 4}
+    inst.set_clock(1_700_000_000_000)
+    out = inst.GetRateLimits([dict(name="shardkey", unique_key=str(i), hits=1, limit=3, duration=60_000) for i in range(500)] * 2)
+    assert [o_["remaining"] for o_ in out[:500]] == [2] * 500 and [o_["remaining"] for o_ in out[500:]] == [1] * 500
+    assert len(inst.store()) == 500
     inst.close()
