@@ -10,9 +10,9 @@
 //	GetCacheItem(ctx, key) (*CacheItem, bool, error)                               workers.go:583
 //	Load(ctx) error / Store(ctx) error / Close() error                             gubernator.go:143,161,169
 //
-// Requests from any number of gRPC goroutines are collected by one batcher goroutine (same policy as
-// peer_client.go:284-337: flush at BatchLimit items or after BatchWait) into C-owned pinned SoA buffers
-// and evaluated with ONE guber_eval_batch call.
+// Requests from any number of gRPC goroutines are routed to their key's shard (the reference's worker rule) and
+// collected there by one batcher goroutine (same policy as peer_client.go:284-337: flush at BatchLimit items or
+// after BatchWait) into C-owned pinned SoA buffers and evaluated with ONE guber_eval_batch call.
 
 //go:build gpu
 
@@ -47,8 +47,19 @@ type gpuResponse struct {
 	err error
 }
 
-// GPUWorkerPool satisfies the call surface of *WorkerPool.
+// GPUWorkerPool satisfies the call surface of *WorkerPool.  Like WorkerPool it splits the key space over
+// conf.Workers shards by hash range (workers.go:125-151,180-184); a shard here is one engine (HBM table + HIP
+// stream) with its own batcher goroutine, so that batches of different shards overlap on the GPU — 4 saturate an
+// MI355X (bench.py --shards).
 type GPUWorkerPool struct {
+	conf         *Config
+	hasher       workerHasher // workers.go:70-72
+	hashRingStep uint64       // workers.go:132
+	shards       []*gpuShard
+}
+
+// gpuShard = one "worker" of the reference: single writer of its own cache.
+type gpuShard struct {
 	conf   *Config
 	engine *C.guber_engine_t
 	queue  chan gpuRequest
@@ -69,9 +80,93 @@ type GPUWorkerPool struct {
 }
 
 func NewGPUWorkerPool(conf *Config, device int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
+	workers := conf.Workers // config.go:110; default = NumCPU, GUBER_GPU_SHARDS overrides it for the GPU pool (4 is enough)
+	if workers <= 0 {
+		workers = 1
+	}
+	p := &GPUWorkerPool{conf: conf, hasher: &hasher{}, hashRingStep: uint64(1<<63) / uint64(workers)} // workers.go:80,132
+	for i := 0; i < workers; i++ {
+		sh, err := newGPUShard(conf, device, conf.CacheSize/workers+1, batchLimit, batchWait) // workers.go:132
+		if err != nil {
+			_ = p.Close()
+			return nil, err
+		}
+		p.shards = append(p.shards, sh)
+	}
+	return p, nil
+}
+
+// shardOf = WorkerPool.getWorker (workers.go:180-184)
+func (p *GPUWorkerPool) shardOf(key string) *gpuShard {
+	return p.shards[p.hasher.ComputeHash63(key)/p.hashRingStep]
+}
+
+func (p *GPUWorkerPool) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimitReqState) (*RateLimitResp, error) {
+	return p.shardOf(r.HashKey()).GetRateLimit(ctx, r, s)
+}
+func (p *GPUWorkerPool) AddCacheItem(ctx context.Context, key string, item *CacheItem) error {
+	return p.shardOf(key).AddCacheItem(ctx, key, item)
+}
+func (p *GPUWorkerPool) GetCacheItem(ctx context.Context, key string) (*CacheItem, bool, error) {
+	return p.shardOf(key).GetCacheItem(ctx, key)
+}
+
+// Load drains Loader.Load() into the shards in bulk (workers.go:329-413).
+func (p *GPUWorkerPool) Load(ctx context.Context) error {
+	ch, err := p.conf.Loader.Load()
+	if err != nil {
+		return errors.Wrap(err, "Error in loader.Load")
+	}
+	pending := make(map[*gpuShard][]C.guber_item_t, len(p.shards))
+	for item := range ch {
+		sh := p.shardOf(item.Key)
+		pending[sh] = append(pending[sh], toCItem(item.Key, item))
+		if len(pending[sh]) >= 4096 {
+			if err := sh.addItems(pending[sh]); err != nil {
+				return err
+			}
+			pending[sh] = pending[sh][:0]
+		}
+	}
+	for sh, items := range pending {
+		if err := sh.addItems(items); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
+// Store hands every resident item of every shard to Loader.Save (workers.go:451-534).
+func (p *GPUWorkerPool) Store(ctx context.Context) error {
+	out := make(chan *CacheItem, 500)
+	errc := make(chan error, 1)
+	go func() {
+		defer close(out)
+		for _, sh := range p.shards {
+			if err := sh.dump(out); err != nil {
+				errc <- err
+				return
+			}
+		}
+		errc <- nil
+	}()
+	if err := p.conf.Loader.Save(out); err != nil {
+		return errors.Wrap(err, "Error in loader.Save")
+	}
+	return <-errc
+}
+
+func (p *GPUWorkerPool) Close() error {
+	for _, sh := range p.shards {
+		_ = sh.Close()
+	}
+	return nil
+}
+
+func newGPUShard(conf *Config, device int, cacheSize int, batchLimit int, batchWait time.Duration) (*gpuShard, error) {
 	cfg := C.guber_config_t{struct_size: C.uint32_t(unsafe.Sizeof(C.guber_config_t{})), device: C.int32_t(device),
-		cache_size: C.uint64_t(conf.CacheSize), max_batch: C.uint32_t(batchLimit)}
-	p := &GPUWorkerPool{conf: conf, queue: make(chan gpuRequest, batchLimit), done: make(chan struct{}), cap: batchLimit}
+		cache_size: C.uint64_t(cacheSize), max_batch: C.uint32_t(batchLimit)}
+	p := &gpuShard{conf: conf, queue: make(chan gpuRequest, batchLimit), done: make(chan struct{}), cap: batchLimit}
 	if rc := C.guber_engine_create(&cfg, &p.engine); rc != C.GUBER_OK {
 		return nil, fmt.Errorf("guber_engine_create: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
 	}
@@ -94,7 +189,7 @@ func NewGPUWorkerPool(conf *Config, device int, batchLimit int, batchWait time.D
 
 // GetRateLimit enqueues the request and waits for its batch (workers.go:261-291 semantics: ctx honoured
 // at both waits).
-func (p *GPUWorkerPool) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimitReqState) (*RateLimitResp, error) {
+func (p *gpuShard) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimitReqState) (*RateLimitResp, error) {
 	g := gpuRequest{req: r, state: s, resp: make(chan gpuResponse, 1)}
 	select {
 	case p.queue <- g:
@@ -109,7 +204,7 @@ func (p *GPUWorkerPool) GetRateLimit(ctx context.Context, r *RateLimitReq, s Rat
 	}
 }
 
-func (p *GPUWorkerPool) run(limit int, wait time.Duration) {
+func (p *gpuShard) run(limit int, wait time.Duration) {
 	runtime.LockOSThread() // one OS thread owns the HIP context
 	pending := make([]gpuRequest, 0, limit)
 	timer := time.NewTimer(wait)
@@ -138,7 +233,7 @@ func (p *GPUWorkerPool) run(limit int, wait time.Duration) {
 func at64(p *C.int64_t, i int) *C.int64_t { return (*C.int64_t)(unsafe.Add(unsafe.Pointer(p), i*8)) }
 func at8(p *C.uint8_t, i int) *C.uint8_t   { return (*C.uint8_t)(unsafe.Add(unsafe.Pointer(p), i)) }
 
-func (p *GPUWorkerPool) flush(batch []gpuRequest) {
+func (p *gpuShard) flush(batch []gpuRequest) {
 	now := clock.Now()
 	nowMs := now.UnixNano() / 1000000
 	off := 0
@@ -211,7 +306,7 @@ func (p *GPUWorkerPool) flush(batch []gpuRequest) {
 //   Store.Get      for the first request of every key that is not resident before the batch (algorithms.go:45-51)
 //   Store.Remove   token RESET_REMAINING / algorithm switched                                 (:79-84, :96-100, :311-315)
 //   Store.OnChange with the CacheItem as it is right after THAT request, owner only           (:149-153, :252-254, ...)
-func (p *GPUWorkerPool) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, res *C.guber_result_t) C.int {
+func (p *gpuShard) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, res *C.guber_result_t) C.int {
 	ctx := context.Background()
 	if rc := C.guber_probe_missing(p.engine, b, p.missing); rc != C.GUBER_OK {
 		return rc
@@ -251,7 +346,7 @@ func (p *GPUWorkerPool) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, re
 }
 
 // AddCacheItem = LRUCache.Add through the engine (UpdatePeerGlobals, gubernator.go:425-459).
-func (p *GPUWorkerPool) AddCacheItem(ctx context.Context, key string, item *CacheItem) error {
+func (p *gpuShard) AddCacheItem(ctx context.Context, key string, item *CacheItem) error {
 	ci := toCItem(key, item)
 	defer C.free(unsafe.Pointer(ci.key))
 	if rc := C.guber_add_items(p.engine, &ci, 1, nil); rc != C.GUBER_OK {
@@ -261,7 +356,7 @@ func (p *GPUWorkerPool) AddCacheItem(ctx context.Context, key string, item *Cach
 }
 
 // GetCacheItem = LRUCache.GetItem (expired items are removed and reported absent).
-func (p *GPUWorkerPool) GetCacheItem(ctx context.Context, key string) (*CacheItem, bool, error) {
+func (p *gpuShard) GetCacheItem(ctx context.Context, key string) (*CacheItem, bool, error) {
 	ck := C.CString(key)
 	defer C.free(unsafe.Pointer(ck))
 	var out C.guber_item_t
@@ -275,40 +370,23 @@ func (p *GPUWorkerPool) GetCacheItem(ctx context.Context, key string) (*CacheIte
 	return fromCItem(key, &out), true, nil
 }
 
-// Load drains Loader.Load() into the engine in bulk (workers.go:329-413).
-func (p *GPUWorkerPool) Load(ctx context.Context) error {
-	ch, err := p.conf.Loader.Load()
-	if err != nil {
-		return errors.Wrap(err, "Error in loader.Load")
-	}
-	items := make([]C.guber_item_t, 0, 4096)
-	flush := func() error {
-		if len(items) == 0 {
-			return nil
-		}
-		rc := C.guber_add_items(p.engine, &items[0], C.uint32_t(len(items)), nil)
-		for i := range items {
-			C.free(unsafe.Pointer(items[i].key))
-		}
-		items = items[:0]
-		if rc != C.GUBER_OK {
-			return errors.Errorf("guber_add_items: %s", C.GoString(C.guber_strerror(rc)))
-		}
+// addItems = LRUCache.Add for a chunk of loaded items; frees the C key copies made by toCItem.
+func (p *gpuShard) addItems(items []C.guber_item_t) error {
+	if len(items) == 0 {
 		return nil
 	}
-	for item := range ch {
-		items = append(items, toCItem(item.Key, item))
-		if len(items) == cap(items) {
-			if err := flush(); err != nil {
-				return err
-			}
-		}
+	rc := C.guber_add_items(p.engine, &items[0], C.uint32_t(len(items)), nil)
+	for i := range items {
+		C.free(unsafe.Pointer(items[i].key))
 	}
-	return flush()
+	if rc != C.GUBER_OK {
+		return errors.Errorf("guber_add_items: %s", C.GoString(C.guber_strerror(rc)))
+	}
+	return nil
 }
 
-// Store dumps every resident item to Loader.Save (workers.go:451-534, lrucache.go:76-85).
-func (p *GPUWorkerPool) Store(ctx context.Context) error {
+// dump sends every resident item of this shard to `out` (lrucache.go:76-85 Each).
+func (p *gpuShard) dump(out chan<- *CacheItem) error {
 	var n, arena C.uint64_t
 	C.guber_dump(p.engine, nil, 0, nil, 0, &n, &arena) // sizes
 	items := make([]C.guber_item_t, int(n)+16)
@@ -317,17 +395,13 @@ func (p *GPUWorkerPool) Store(ctx context.Context) error {
 	if rc := C.guber_dump(p.engine, &items[0], C.uint64_t(len(items)), (*C.uint8_t)(keys), arena+1024, &n, &arena); rc != C.GUBER_OK {
 		return errors.Errorf("guber_dump: %s", C.GoString(C.guber_strerror(rc)))
 	}
-	out := make(chan *CacheItem, 500)
-	go func() {
-		for i := 0; i < int(n); i++ {
-			out <- fromCItem(C.GoStringN((*C.char)(unsafe.Pointer(items[i].key)), C.int(items[i].key_len)), &items[i])
-		}
-		close(out)
-	}()
-	return p.conf.Loader.Save(out)
+	for i := 0; i < int(n); i++ {
+		out <- fromCItem(C.GoStringN((*C.char)(unsafe.Pointer(items[i].key)), C.int(items[i].key_len)), &items[i])
+	}
+	return nil
 }
 
-func (p *GPUWorkerPool) Close() error {
+func (p *gpuShard) Close() error {
 	close(p.done)
 	C.guber_engine_destroy(p.engine)
 	return nil
