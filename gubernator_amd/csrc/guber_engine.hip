@@ -91,8 +91,9 @@ struct guber_engine {
 #ifdef GUBER_PHASE_TIMING
     DevBuf<unsigned long long> dbg; double dbg_avg[2][8] = {{0}}, dbg_max[2][8] = {{0}}; uint64_t dbg_n = 0;
 #endif
-    DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; const guber_ring_t* ring_cached = nullptr; uint32_t ring_npts = 0;   // ring image for the *_dev routers
-    DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags;   // guber_add_items_dev scratch
+    DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; uint64_t ring_cached_id = 0; uint32_t ring_npts = 0;   // ring image for the *_dev routers
+    DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags, d_ikeys, d_ires;   // guber_add_items[_dev] scratch (persistent)
+    DevBuf<uint8_t> d_lkey; DevBuf<Rec> d_lrec; DevBuf<int> d_lfound;                 // guber_get_item / guber_remove_item scratch
     DevBuf<unsigned long long> w_claims; uint32_t claims_cells = 0; uint32_t fast_epoch16 = 0;   // k_front's per-batch claim table
     DevBuf<uint8_t> d_sflags; DevBuf<Rec> d_safter;   // Store side channel (guber_eval_batch_store), allocated on first use
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
@@ -262,7 +263,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     }
     e->dbg.release();
 #endif
-    e->d_ring_h.release(); e->d_ring_o.release(); e->d_items.release(); e->d_islots.release(); e->d_iflags.release();
+    e->d_ring_h.release(); e->d_ring_o.release(); e->d_items.release(); e->d_islots.release(); e->d_iflags.release(); e->d_ikeys.release(); e->d_ires.release();
+    e->d_lkey.release(); e->d_lrec.release(); e->d_lfound.release();
     e->w_claims.release();
     e->d_sflags.release(); e->d_safter.release();
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
@@ -607,11 +609,13 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
         if (it.key_len) memcpy(keys.data() + off, it.key, it.key_len);
         off += it.key_len;
     }
-    DevBuf<ItemIn> d_items; DevBuf<uint8_t> d_keys, d_flags, d_res; DevBuf<uint32_t> d_slots;
+    // engine-owned scratch (grown on demand, kept): no allocation on the AddCacheItem / UpdatePeerGlobals path
+    DevBuf<ItemIn>& d_items = e->d_items; DevBuf<uint8_t>&d_keys = e->d_ikeys, &d_flags = e->d_iflags, &d_res = e->d_ires;
+    DevBuf<uint32_t>& d_slots = e->d_islots;
     int rc = 0;
     rc |= d_items.ensure(n); rc |= d_keys.ensure(keys.size()); rc |= d_flags.ensure(n); rc |= d_res.ensure(n); rc |= d_slots.ensure(n);
-    auto cleanup = [&]() { d_items.release(); d_keys.release(); d_flags.release(); d_res.release(); d_slots.release(); };
-    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    auto cleanup = [&]() {};
+    if (rc) return GUBER_E_NOMEM;
     hipStream_t st = e->stream;
     hipError_t he;
     if ((he = hipMemcpyAsync(d_items.p, host.data(), n * sizeof(ItemIn), hipMemcpyHostToDevice, st)) != hipSuccess ||
@@ -681,10 +685,10 @@ static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, in
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     *found = 0;
     if (key_len == 0 || key_len > e->max_key) return GUBER_OK;
-    DevBuf<uint8_t> d_key; DevBuf<Rec> d_rec; DevBuf<int> d_found;
+    DevBuf<uint8_t>& d_key = e->d_lkey; DevBuf<Rec>& d_rec = e->d_lrec; DevBuf<int>& d_found = e->d_lfound;   // engine-owned scratch
     int rc = d_key.ensure(key_len + 16) | d_rec.ensure(1) | d_found.ensure(1);
-    auto cleanup = [&]() { d_key.release(); d_rec.release(); d_found.release(); };
-    if (rc) { cleanup(); return GUBER_E_NOMEM; }
+    auto cleanup = [&]() {};
+    if (rc) return GUBER_E_NOMEM;
     std::vector<uint8_t> kb(key_len + 16, 0);
     memcpy(kb.data(), key, key_len);
     Rec hrec; int hfound = 0;
@@ -783,35 +787,9 @@ extern "C" void* guber_alloc_pinned(size_t bytes) {
 extern "C" void guber_free_pinned(void* p) { if (p) (void)hipHostFree(p); }
 
 // ---- device routing on the consistent-hash ring ------------------------------------------------
-extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_bytes,
-                                    const uint32_t* key_off, uint32_t n, uint32_t* owner) {
-    if (!e || !r || (n && (!key_bytes || !key_off || !owner))) return fail(GUBER_E_INVALID_ARG, "null argument");
-    if (n == 0) return GUBER_OK;
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    const uint32_t npts = guber_ring_points(r, nullptr, nullptr, 0);
-    if (npts == 0) return fail(GUBER_E_INVALID_ARG, "empty ring");
-    if ((size_t)npts * 8 > 150 * 1024) return fail(GUBER_E_INVALID_ARG, "ring does not fit in LDS");
-    std::vector<uint64_t> hh(npts); std::vector<uint32_t> oo(npts);
-    guber_ring_points(r, hh.data(), oo.data(), npts);
-    DevBuf<uint64_t> d_h; DevBuf<uint32_t> d_o;
-    int rc = d_h.ensure(npts) | d_o.ensure(npts);
-    auto cleanup = [&]() { d_h.release(); d_o.release(); };
-    if (rc) { cleanup(); return GUBER_E_NOMEM; }
-    hipError_t he;
-    if ((he = hipMemcpyAsync(d_h.p, hh.data(), npts * 8, hipMemcpyHostToDevice, e->stream)) != hipSuccess ||
-        (he = hipMemcpyAsync(d_o.p, oo.data(), npts * 4, hipMemcpyHostToDevice, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "ring H2D", he); }
-    hipLaunchKernelGGL(k_route, dim3((n + 255) / 256), dim3(256), (size_t)npts * 8, e->stream, key_bytes, key_off, n,
-                       d_h.p, d_o.p, npts, guber_ring_kind(r), owner);
-    he = hipStreamSynchronize(e->stream);
-    cleanup();
-    if (he != hipSuccess) return fail(GUBER_E_HIP, "k_route", he);
-    return GUBER_OK;
-}
-
 // ring image on the device, uploaded once per (engine, ring)
 static int ensure_ring_on_device(guber_engine* e, const guber_ring_t* r) {
-    if (e->ring_cached == r && e->ring_npts) return 0;
+    if (e->ring_cached_id == guber_ring_id(r) && e->ring_npts) return 0;
     const uint32_t npts = guber_ring_points(r, nullptr, nullptr, 0);
     if (npts == 0) return fail(GUBER_E_INVALID_ARG, "empty ring");
     if ((size_t)npts * 8 > 150 * 1024) return fail(GUBER_E_INVALID_ARG, "ring does not fit in LDS");
@@ -821,8 +799,23 @@ static int ensure_ring_on_device(guber_engine* e, const guber_ring_t* r) {
     HIPCHK(hipMemcpyAsync(e->d_ring_h.p, hh.data(), npts * 8, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipMemcpyAsync(e->d_ring_o.p, oo.data(), npts * 4, hipMemcpyHostToDevice, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
-    e->ring_cached = r; e->ring_npts = npts;
+    e->ring_cached_id = guber_ring_id(r); e->ring_npts = npts;
     return 0;
+}
+
+extern "C" int guber_ring_route_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_bytes,
+                                    const uint32_t* key_off, uint32_t n, uint32_t* owner) {
+    if (!e || !r || (n && (!key_bytes || !key_off || !owner))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (n == 0) return GUBER_OK;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    int rc = ensure_ring_on_device(e, r);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_route, dim3((n + 255) / 256), dim3(256), (size_t)e->ring_npts * 8, e->stream, key_bytes, key_off, n,
+                       e->d_ring_h.p, e->d_ring_o.p, e->ring_npts, guber_ring_kind(r), owner);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return GUBER_OK;
 }
 
 extern "C" int guber_ring_route_rows_dev(guber_engine_t* e, const guber_ring_t* r, const uint8_t* key_rows, uint32_t stride,

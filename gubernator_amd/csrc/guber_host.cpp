@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "guber_algo.h"
@@ -96,6 +97,7 @@ struct guber_ring {
     std::vector<uint64_t> hash;
     std::vector<uint32_t> owner;
     int kind = 0;
+    uint64_t id = 0;   // unique per created ring: engines cache the device image by id, not by (reusable) address
 };
 
 extern "C" int guber_ring_create(const char* const* peer_names, uint32_t n_peers, uint32_t replicas, int hash_kind,
@@ -115,7 +117,9 @@ extern "C" int guber_ring_create(const char* const* peer_names, uint32_t n_peers
         }
     }
     std::sort(pts.begin(), pts.end(), [](const Pt& a, const Pt& b) { return a.h != b.h ? a.h < b.h : a.seq < b.seq; });  // :90
+    static std::atomic<uint64_t> next_ring_id{1};
     guber_ring* r = new guber_ring();
+    r->id = next_ring_id.fetch_add(1);
     r->kind = hash_kind;
     for (const Pt& p : pts) { r->hash.push_back(p.h); r->owner.push_back(p.o); }
     *out = r;
@@ -123,6 +127,7 @@ extern "C" int guber_ring_create(const char* const* peer_names, uint32_t n_peers
 }
 extern "C" void guber_ring_destroy(guber_ring_t* r) { delete r; }
 extern "C" int guber_ring_kind(const guber_ring_t* r) { return r ? r->kind : 0; }
+extern "C" uint64_t guber_ring_id(const guber_ring_t* r) { return r ? r->id : 0; }
 extern "C" uint32_t guber_ring_points(const guber_ring_t* r, uint64_t* hashes, uint32_t* owners, uint32_t cap) {
     if (!r) return 0;
     const uint32_t n = (uint32_t)r->hash.size();

@@ -6,3 +6,4 @@
 #include "../../include/guber_gpu.h"
 
 extern "C" int guber_ring_kind(const guber_ring_t* r);   // 0 fnv1, 1 fnv1a
+extern "C" uint64_t guber_ring_id(const guber_ring_t* r);   // unique per guber_ring_create
