@@ -91,18 +91,22 @@ bool valid_utf8(const uint8_t* s, uint32_t n) {
 bool parse_req(const uint8_t* p, const uint8_t* end, ReqFields& f) {
     while (p < end) {
         uint64_t tag, v;
-        if (!get_varint(p, end, tag)) return false;
+        if (*p < 0x80) tag = *p++;                                  // one-byte tag: every field of these messages
+        else if (!get_varint(p, end, tag)) return false;
         const uint32_t wt = (uint32_t)(tag & 7);
         const uint64_t field = tag >> 3;
         if (field == 0 || field > 0x1fffffffull) return false;
         if ((field == 1 || field == 2) && wt == 2) {
-            if (!get_varint(p, end, v) || (uint64_t)(end - p) < v || v > 0xffffffffull) return false;
+            if (p < end && *p < 0x80) v = *p++;
+            else if (!get_varint(p, end, v)) return false;
+            if ((uint64_t)(end - p) < v || v > 0xffffffffull) return false;
             if (!valid_utf8(p, (uint32_t)v)) return false;
             Span& s = field == 1 ? f.name : f.unique_key;
             s.p = p; s.n = (uint32_t)v;
             p += v;
         } else if (wt == 0 && (field == 3 || field == 4 || field == 5 || field == 6 || field == 7 || field == 8 || field == 10)) {
-            if (!get_varint(p, end, v)) return false;
+            if (p < end && *p < 0x80) v = *p++;
+            else if (!get_varint(p, end, v)) return false;
             switch (field) {
             case 3: f.hits = (int64_t)v; break;
             case 4: f.limit = (int64_t)v; break;
@@ -161,7 +165,6 @@ struct guber_wire_batch {
     uint8_t *r_status = nullptr, *r_err = nullptr;
     guber_batch_t view{};
     guber_result_t res{};
-    std::vector<ReqFields> scratch;       // items of the payload being decoded
 };
 
 extern "C" int guber_wire_batch_create(uint32_t max_items, uint32_t max_key_bytes, uint32_t flags, guber_wire_batch_t** out) {
@@ -187,7 +190,6 @@ extern "C" int guber_wire_batch_create(uint32_t max_items, uint32_t max_key_byte
     for (auto f : u8s) { *f = p; p += M; }
     p = (uint8_t*)(((uintptr_t)p + 63) & ~(uintptr_t)63);
     b->key_bytes = p;
-    try { b->scratch.reserve(1024); } catch (...) { guber_wire_batch_destroy(b); return GUBER_E_NOMEM; }
     guber_wire_batch_reset(b, 0);
     *out = b;
     return GUBER_OK;
@@ -211,45 +213,42 @@ extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* 
                                           uint8_t is_owner, uint32_t* first, uint32_t* count) {
     if (!b || (!msg && len) || !first || !count) return GUBER_E_INVALID_ARG;
     *first = b->n; *count = 0;
-    // pass 1: parse every item (spans point into msg), nothing is appended before the payload is known to be
-    // well-formed and to fit
-    std::vector<ReqFields>& items = b->scratch;
-    items.clear();
+    // One pass over the payload, writing straight into the SoA at [n0, ...): the batch's item / key counters are only
+    // advanced at the very end, so a malformed, over-long or non-fitting payload leaves the batch exactly as it was
+    // (whatever was written beyond the counters is overwritten by the next successful decode).
+    const uint32_t n0 = b->n, k0 = b->key_used;
+    uint32_t i = n0, kused = k0;
+    bool full = false, any_greg = b->any_greg;
     const uint8_t* p = msg; const uint8_t* end = msg + len;
-    uint64_t key_bytes = 0;
-    try {
-        while (p < end) {
-            uint64_t tag, v;
-            if (!get_varint(p, end, tag)) return GUBER_E_WIRE_MALFORMED;
-            const uint32_t wt = (uint32_t)(tag & 7);
-            if ((tag >> 3) == 0 || (tag >> 3) > 0x1fffffffull) return GUBER_E_WIRE_MALFORMED;
-            if ((tag >> 3) == 1 && wt == 2) {
-                if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return GUBER_E_WIRE_MALFORMED;
-                ReqFields f;
-                if (!parse_req(p, p + v, f)) return GUBER_E_WIRE_MALFORMED;
-                p += v;
-                if (f.unique_key.n && f.name.n) key_bytes += (uint64_t)f.name.n + 1 + f.unique_key.n;
-                items.push_back(f);
-            } else if (!skip_field(p, end, wt, tag >> 3)) {
-                return GUBER_E_WIRE_MALFORMED;
-            }
+    while (p < end) {
+        uint64_t tag, v;
+        if (*p < 0x80) tag = *p++;                                  // one-byte tag: the common case
+        else if (!get_varint(p, end, tag)) return GUBER_E_WIRE_MALFORMED;
+        const uint32_t wt = (uint32_t)(tag & 7);
+        if ((tag >> 3) == 0 || (tag >> 3) > 0x1fffffffull) return GUBER_E_WIRE_MALFORMED;
+        if ((tag >> 3) != 1 || wt != 2) {
+            if (!skip_field(p, end, wt, tag >> 3)) return GUBER_E_WIRE_MALFORMED;
+            continue;
         }
-    } catch (...) { return GUBER_E_NOMEM; }
-    if (max_per_rpc && items.size() > max_per_rpc) { *count = (uint32_t)items.size(); return GUBER_E_WIRE_TOO_LARGE; }
-    if (items.size() > b->cap_items - b->n || key_bytes > (uint64_t)(b->cap_keys - b->key_used)) return GUBER_E_WIRE_FULL;
-    // pass 2: append
-    uint32_t i = b->n;
-    for (const ReqFields& f : items) {
+        if (p < end && *p < 0x80) v = *p++;
+        else if (!get_varint(p, end, v)) return GUBER_E_WIRE_MALFORMED;
+        if ((uint64_t)(end - p) < v) return GUBER_E_WIRE_MALFORMED;
+        ReqFields f;
+        if (!parse_req(p, p + v, f)) return GUBER_E_WIRE_MALFORMED;
+        p += v;
+        if (full) { ++i; continue; }                                // keep validating and counting; nothing is stored any more
         uint8_t pre = GUBER_WIRE_PRE_OK;
         if (f.unique_key.n == 0) pre = GUBER_WIRE_PRE_EMPTY_UNIQUE_KEY;          // gubernator.go:208-212
         else if (f.name.n == 0) pre = GUBER_WIRE_PRE_EMPTY_NAME;                 // gubernator.go:213-217
+        const uint64_t klen = pre == GUBER_WIRE_PRE_OK ? (uint64_t)f.name.n + 1 + f.unique_key.n : 0;
+        if (i >= b->cap_items || klen > (uint64_t)(b->cap_keys - kused)) { full = true; ++i; continue; }
         b->pre_err[i] = pre;
-        if (pre == GUBER_WIRE_PRE_OK) {                                          // client.go:39-41
-            uint8_t* k = b->key_bytes + b->key_used;
+        if (klen) {                                                              // client.go:39-41
+            uint8_t* k = b->key_bytes + kused;
             memcpy(k, f.name.p, f.name.n); k[f.name.n] = '_'; memcpy(k + f.name.n + 1, f.unique_key.p, f.unique_key.n);
-            b->key_used += f.name.n + 1 + f.unique_key.n;
+            kused += (uint32_t)klen;
         }
-        b->key_off[i + 1] = b->key_used;
+        b->key_off[i + 1] = kused;
         b->hits[i] = f.hits; b->limit[i] = f.limit; b->duration[i] = f.duration; b->burst[i] = f.burst;
         b->created_at[i] = f.created_at ? f.created_at : b->now_ms;              // gubernator.go:218-220
         b->algo_raw[i] = (int32_t)f.algorithm;
@@ -257,8 +256,8 @@ extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* 
         b->behavior[i] = (uint32_t)f.behavior;
         b->is_owner[i] = is_owner ? 1 : 0;
         b->greg_expire[i] = 0; b->greg_duration[i] = 0;
-        if (pre == GUBER_WIRE_PRE_OK && (b->behavior[i] & GUBER_BEHAVIOR_DURATION_IS_GREGORIAN)) {   // interval.go:84-148 at clock.Now()
-            b->any_greg = true;
+        if (pre == GUBER_WIRE_PRE_OK && ((uint32_t)f.behavior & GUBER_BEHAVIOR_DURATION_IS_GREGORIAN)) {   // interval.go:84-148 at clock.Now()
+            any_greg = true;
             int64_t e = 0, d = 0;
             int rc = guber_gregorian_expiration(b->now_ms * 1000000, f.duration, &e);
             if (rc == 0) rc = guber_gregorian_duration(b->now_ms * 1000000, f.duration, &d);
@@ -266,9 +265,12 @@ extern "C" int guber_wire_decode_requests(guber_wire_batch_t* b, const uint8_t* 
         }
         ++i;
     }
-    *count = (uint32_t)items.size();
-    b->n = i;
-    memset(b->key_bytes + b->key_used, 0, 16);
+    const uint32_t items = i - n0;
+    if (max_per_rpc && items > max_per_rpc) { *count = items; return GUBER_E_WIRE_TOO_LARGE; }
+    if (full) return GUBER_E_WIRE_FULL;
+    *count = items;
+    b->n = i; b->key_used = kused; b->any_greg = any_greg;
+    memset(b->key_bytes + kused, 0, 16);
     return GUBER_OK;
 }
 
