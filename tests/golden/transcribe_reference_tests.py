@@ -240,6 +240,28 @@ with open(os.path.join(HERE, "store_events_vectors.json"), "w") as f:
                    cases=store_event_cases), f, indent=1)
 
 # ------------------------------------------------------------------------------------------------
+# lrucache_test.go TestLRUCache: the Cache contract the path relies on (Add returns "existed", Size, GetItem, Remove,
+# replace-on-Add, and which evictions count as gubernator_unexpired_evictions_count).  ops: ["add", key, expire_in_ms,
+# want_existed] / ["get", key, want_found] / ["remove", key] / ["size", want] / ["advance", ms] / ["unexpired_evictions", want]
+# ------------------------------------------------------------------------------------------------
+HOUR = 3_600_000
+cache_cases = [
+    dict(name="TestLRUCache/Happy path", source="lrucache_test.go:42-81", cache_size=0, evicting=False,
+         ops=[["add", str(i), HOUR, False] for i in range(1000)] + [["size", 1000]] + [["get", str(i), True] for i in range(1000)]
+             + [["remove", str(i)] for i in range(1000)] + [["size", 0]]),
+    dict(name="TestLRUCache/Update an existing key", source="lrucache_test.go:83-109", cache_size=0, evicting=False,
+         ops=[["add", "foobar", HOUR, False, 1], ["add", "foobar", HOUR, True, 2], ["get", "foobar", True, 2], ["size", 1]]),
+    dict(name="TestLRUCache/expired item evicted: unexpired_evictions stays 0", source="lrucache_test.go:339-384", cache_size=10, evicting=True,
+         ops=[["add", "short-expiry-%d" % i, 5 * 60_000, False] for i in range(10)] + [["advance", 6 * 60_000], ["add", "evict1", HOUR, False],
+              ["unexpired_evictions", 0], ["size", 10]]),
+    dict(name="TestLRUCache/unexpired item evicted: unexpired_evictions is 1", source="lrucache_test.go:386-430", cache_size=10, evicting=True,
+         ops=[["add", "long-expiry-%d" % i, HOUR, False] for i in range(10)] + [["add", "evict2", HOUR, False], ["unexpired_evictions", 1], ["size", 10],
+              ["get", "long-expiry-0", False], ["get", "long-expiry-1", True]]),
+]
+with open(os.path.join(HERE, "cache_vectors.json"), "w") as f:
+    json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 lrucache_test.go TestLRUCache", cases=cache_cases), f, indent=1)
+
+# ------------------------------------------------------------------------------------------------
 # known-answer tests: interval_test.go, replicated_hash_test.go, workers_internal_test.go
 # ------------------------------------------------------------------------------------------------
 def utc_ms(y, mo, d, h=0, mi=0, s=0, ns=0):

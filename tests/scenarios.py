@@ -149,3 +149,40 @@ def run_store_events(make_backend):
         if hasattr(be, "close"):
             be.close()
     return n
+
+
+def run_cache_vectors(make_backend, evicting=True):
+    """tests/golden/cache_vectors.json (lrucache_test.go TestLRUCache) on a backend with add_item / get_item / remove_item /
+    size (+ counters() for the eviction cases).  evicting=False skips the cases that need the bounded LRU (the HBM table
+    compacts instead of evicting)."""
+    n = 0
+    for case in load("cache_vectors.json")["cases"]:
+        if case["evicting"] and not evicting:
+            continue
+        be = make_backend(case["cache_size"])
+        now = 1_700_000_000_000
+        for op in case["ops"]:
+            where = f"{case['name']} {op} ({case['source']})"
+            if op[0] == "add":
+                remaining = op[4] if len(op) > 4 else 7
+                existed = be.add_item(support.make_item(op[1], support.LEAKY if case["evicting"] else support.TOKEN, limit=10, duration=op[2],
+                                                        remaining=remaining, remaining_f=float(remaining), stamp=now, burst=10,
+                                                        expire_at=now + op[2]), now)
+                assert bool(existed) == op[3], where
+            elif op[0] == "get":
+                it = be.get_item(op[1], now)
+                assert (it is not None) == op[2], where
+                if len(op) > 3:
+                    assert it["remaining"] == op[3], where
+            elif op[0] == "remove":
+                be.remove_item(op[1])
+            elif op[0] == "size":
+                assert be.size() == op[1], where
+            elif op[0] == "advance":
+                now += op[1]
+            elif op[0] == "unexpired_evictions":
+                assert be.counters()[3] == op[1], where
+            n += 1
+        if hasattr(be, "close"):
+            be.close()
+    return n

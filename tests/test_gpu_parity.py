@@ -482,3 +482,9 @@ def test_claim_table_epoch_wraps():
         else:
             e.eval(b); o.eval(b)
     e.close()
+
+
+def test_lrucache_vectors_on_the_engine():
+    """lrucache_test.go TestLRUCache (Happy path, Update an existing key) through guber_add_items / guber_get_item /
+    guber_remove_item / guber_size.  The two eviction cases need the bounded LRU and stay oracle-only."""
+    assert scenarios.run_cache_vectors(lambda cs: engine(cache_size=4096, max_batch=1024), evicting=False) > 3000

@@ -139,3 +139,8 @@ def test_mt_matches_sequential():
 def test_store_callbacks_follow_teststore():
     """store_test.go TestStore: Get on a miss, OnChange after the request, Remove on a foreign Value."""
     assert scenarios.run_store_events(lambda: Oracle(cache_size=1 << 12)) == 10
+
+
+def test_lrucache_vectors():
+    """lrucache_test.go TestLRUCache: Add / GetItem / Remove / Size, replace-on-Add, and which evictions are counted."""
+    assert scenarios.run_cache_vectors(lambda cs: Oracle(cache_size=cs, workers=1)) > 3000
