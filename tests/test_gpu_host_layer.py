@@ -227,3 +227,21 @@ def test_pool_shards_follow_the_reference_worker_rule():
     assert [o_["remaining"] for o_ in out[:500]] == [2] * 500 and [o_["remaining"] for o_ in out[500:]] == [1] * 500
     assert len(inst.store()) == 500
     inst.close()
+
+
+@pytest.mark.parametrize("workers", [1, 4])
+def test_gubernator_pool_load_store(workers):
+    """workers_test.go:31-130 TestGubernatorPool (Single-threaded / Multi-threaded): Load() hands the Loader's 100 items to the
+    workers' caches, Store() gives Loader.Save exactly those items back (compared sorted by key, as the reference does)."""
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200, shards=workers)
+    inst.set_clock(1_700_000_000_000)
+    loaded = [dict(key=b"Foobar%04d" % i, algorithm=0, limit=10 + i, duration=1000, remaining=i, stamp=1_700_000_000_000 - i,
+                   expire_at=4131978658000) for i in range(100)]
+    inst.load([ga.make_item(d["key"], d["algorithm"], limit=d["limit"], duration=d["duration"], remaining=d["remaining"], stamp=d["stamp"],
+                            expire_at=d["expire_at"]) for d in loaded])
+    saved = sorted(inst.store(), key=lambda d: d["key"])
+    assert len(saved) == 100
+    for want, got in zip(loaded, saved):
+        for f in ("key", "algorithm", "limit", "duration", "remaining", "stamp", "expire_at"):
+            assert got[f] == want[f], (f, want, got)
+    inst.close()
