@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box at the end of a round: full GPU test suite, the three bench lines, rocprofv3 kernel stats + PMC
-# traffic (scripts_gpu_profile.sh), hardware-counter attribution passes (scripts_gpu_pmc.sh), phase timestamps.
+# traffic (scripts/gpu_profile.sh), hardware-counter attribution passes (scripts/gpu_pmc.sh), phase timestamps.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
@@ -10,6 +10,6 @@ timeout 300 python bench.py --algo leaky --no-cpu-baseline > gpurun_out/bench_le
 timeout 300 python bench.py --dist uniform --no-cpu-baseline > gpurun_out/bench_uniform.json 2>/dev/null; echo "uniform rc=$?"; cat gpurun_out/bench_uniform.json
 timeout 300 python bench.py --shards 1 --no-cpu-baseline > gpurun_out/bench_token_s1.json 2>/dev/null; echo "s1 rc=$?"; cat gpurun_out/bench_token_s1.json
 timeout 300 python bench.py --global-sync 16 --steps 64 --no-cpu-baseline --profile-steps 0 > gpurun_out/bench_global.json 2>/dev/null; echo "global rc=$?"; cat gpurun_out/bench_global.json
-./scripts_gpu_profile.sh r01_final 2>&1 | tail -12
-./scripts_gpu_pmc.sh "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum" 2>&1 | tail -6
+./scripts/gpu_profile.sh r01_final 2>&1 | tail -12
+./scripts/gpu_pmc.sh "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum" 2>&1 | tail -6
 ./tools/phase_timing.sh 2>&1 | tail -3
