@@ -107,7 +107,7 @@ int hs_add_item(void* hp, const guber_item_t* in, int* existed) {
     Rec s; rec_clear(s);
     s.limit = in->limit; s.duration = in->duration; s.stamp = in->stamp; s.burst = in->burst;
     s.expire_at = in->expire_at; s.invalid_at = in->invalid_at;
-    if (in->algorithm == ALGO_TOKEN) { s.remaining = in->remaining; s.meta = make_meta(K_TOKEN, in->status, ALGO_TOKEN); }
+    if (in->algorithm == ALGO_TOKEN) { s.remaining = in->remaining; s.burst = 0; s.meta = make_meta(K_TOKEN, in->status, ALGO_TOKEN); }   // as rec_from_item (guber_engine.hip)
     else if (in->algorithm == ALGO_LEAKY) { s.remaining = f2bits(in->remaining_f); s.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY); }
     else s.meta = make_meta(K_NIL, 0, in->algorithm);
     auto it = h->table.find(k);

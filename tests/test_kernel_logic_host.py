@@ -239,3 +239,46 @@ def test_created_at_only_variation_on_hot_leaky_keys():
         o.close(); h.close()
     assert cases == 56
     assert sum(p for p, _ in paths) >= 12 and sum(s_ for _, s_ in paths) >= 12, paths   # both paths exercised
+
+
+def test_extreme_value_runs_vs_oracle():
+    """The closed forms (skip / eval_uniform_rank) under Go's wrap-around and float->int rules: int64 extremes and
+    negatives for hits / limit / duration / burst / created_at, items pre-loaded with extreme Remaining (token int64,
+    leaky float64 incl. fractions, negatives, 1e300), then runs of identical requests — rank by rank equal to the
+    sequential oracle."""
+    rng = np.random.default_rng(2024)
+    now = streams.NOW0
+    I64 = [0, 1, -1, 2, 3, 7, 100, 2**31, 2**53, 2**53 + 1, 2**62, -(2**62), 2**63 - 1, -(2**63), 2**63 - 2, -(2**63) + 1]
+    F64 = [0.0, 0.5, 1.0, 1.5, -1.0, -0.25, 99.999, 2.0**53, 2.0**53 + 2, 9.3e18, -9.3e18, 1e300, -1e300, 3.0, 10.0]
+    for trial in range(2500):
+        o, h = Oracle(cache_size=1 << 12), HostSim(mode=0)
+        t = now + int(rng.integers(0, 10_000))
+        algo0 = int(rng.integers(0, 2))
+        if rng.random() < 0.7:                       # pre-load an item with an extreme state
+            it = dict(limit=int(rng.choice(I64)), duration=int(rng.choice([1000, 60_000, 0, -5, 2**62])), remaining=int(rng.choice(I64)),
+                      remaining_f=float(rng.choice(F64)), stamp=t - int(rng.choice([0, 1, 999, 10**9])), burst=int(rng.choice(I64[:8] + [2**62])),
+                      expire_at=t + int(rng.choice([0, 1, 60_000, -1, 2**62])))
+            for be in (o, h):
+                be.add_item(support.make_item("xk", algo0, **it), t)
+        for phase in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([1, 2, 3, 5, 40, 200]))
+            hits = int(rng.choice(I64 + [1, 1, 1, 2, 5]))
+            limit = int(rng.choice(I64 + [10, 100]))
+            duration = int(rng.choice([0, 1, 3, 1000, 60_000, -1, -(2**62), 2**62, 2**63 - 1]))
+            algo = int(rng.choice([0, 1]))
+            beh = int(rng.choice([0, 0, 32, 8, 40]))
+            burst = int(rng.choice([0, 0, 15, -3, 2**62, 2**63 - 1]))
+            created = int(rng.choice([t, t, t - 5, t + 5, 0, -1, 2**62, -(2**62), t - 10**9]))
+            b = HostBatch([b"xk"] * n, hits, limit, duration, t, burst=burst, created_at=created, algorithm=algo, behavior=beh)
+            support.assert_results_equal(h.eval(b), o.eval(b), f"trial {trial} phase {phase} algo {algo} hits {hits} limit {limit} dur {duration} "
+                                                            f"burst {burst} created {created} beh {beh}")
+            assert h.size() == o.size()
+            a, b_ = o.get_item("xk", t), h.get_item("xk", t)
+            if a is None or b_ is None:
+                assert a is None and b_ is None, (trial, phase)
+            else:
+                for f in ("algorithm", "status", "limit", "duration", "remaining", "stamp", "burst", "expire_at"):
+                    assert a[f] == b_[f], (trial, phase, f, a, b_)
+                assert a["remaining_f"] == b_["remaining_f"] or (a["remaining_f"] != a["remaining_f"] and b_["remaining_f"] != b_["remaining_f"]), (trial, a, b_)
+            t += int(rng.choice([0, 1, 40, 1200, 70_000]))
+        o.close(); h.close()
