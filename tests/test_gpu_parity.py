@@ -488,3 +488,45 @@ def test_lrucache_vectors_on_the_engine():
     """lrucache_test.go TestLRUCache (Happy path, Update an existing key) through guber_add_items / guber_get_item /
     guber_remove_item / guber_size.  The two eviction cases need the bounded LRU and stay oracle-only."""
     assert scenarios.run_cache_vectors(lambda cs: engine(cache_size=4096, max_batch=1024), evicting=False) > 3000
+
+
+def test_extreme_value_runs_on_the_device():
+    """Go's wrap-around and float->int rules on the device: int64 extremes / negatives for every request field, items
+    pre-loaded with extreme Remaining (token int64, leaky float64 incl. fractions, negatives, 1e300), runs of identical
+    requests on one key — rank by rank and state by state equal to the oracle (CPU twin: test_kernel_logic_host.py)."""
+    rng = np.random.default_rng(2025)
+    now = streams.NOW0
+    I64 = [0, 1, -1, 2, 3, 7, 100, 2**31, 2**53, 2**53 + 1, 2**62, -(2**62), 2**63 - 1, -(2**63), 2**63 - 2, -(2**63) + 1]
+    F64 = [0.0, 0.5, 1.0, 1.5, -1.0, -0.25, 99.999, 2.0**53, 2.0**53 + 2, 9.3e18, -9.3e18, 1e300, -1e300, 3.0, 10.0]
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=1 << 14, max_batch=1024)
+    for trial in range(400):
+        key = b"xk_%d" % trial
+        t = now + int(rng.integers(0, 10_000))
+        algo0 = int(rng.integers(0, 2))
+        if rng.random() < 0.7:
+            it = dict(limit=int(rng.choice(I64)), duration=int(rng.choice([1000, 60_000, 0, -5, 2**62])), remaining=int(rng.choice(I64)),
+                      remaining_f=float(rng.choice(F64)), stamp=t - int(rng.choice([0, 1, 999, 10**9])), burst=int(rng.choice(I64[:8] + [2**62])),
+                      expire_at=t + int(rng.choice([0, 1, 60_000, -1, 2**62])))
+            for be in (o, e):
+                be.add_item(support.make_item(key, algo0, **it), t)
+        for phase in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([1, 2, 3, 5, 40, 200]))
+            hits = int(rng.choice(I64 + [1, 1, 1, 2, 5]))
+            limit = int(rng.choice(I64 + [10, 100]))
+            duration = int(rng.choice([0, 1, 3, 1000, 60_000, -1, -(2**62), 2**62, 2**63 - 1]))
+            algo = int(rng.choice([0, 1]))
+            beh = int(rng.choice([0, 0, 32, 8, 40]))
+            burst = int(rng.choice([0, 0, 15, -3, 2**62, 2**63 - 1]))
+            created = int(rng.choice([t, t, t - 5, t + 5, 0, -1, 2**62, -(2**62), t - 10**9]))
+            b = HostBatch([key] * n, hits, limit, duration, t, burst=burst, created_at=created, algorithm=algo, behavior=beh)
+            support.assert_results_equal(e.eval(b), o.eval(b), f"trial {trial} phase {phase} algo {algo} hits {hits} limit {limit} dur {duration} "
+                                                            f"burst {burst} created {created} beh {beh}")
+            a, b_ = o.get_item(key, t), e.get_item(key, t)
+            if a is None or b_ is None:
+                assert a is None and b_ is None, (trial, phase)
+            else:
+                for f in ("algorithm", "status", "limit", "duration", "remaining", "stamp", "burst", "expire_at"):
+                    assert a[f] == b_[f], (trial, phase, f, a, b_)
+                assert a["remaining_f"] == b_["remaining_f"] or (a["remaining_f"] != a["remaining_f"] and b_["remaining_f"] != b_["remaining_f"]), (trial, a, b_)
+            t += int(rng.choice([0, 1, 40, 1200, 70_000]))
+    e.close()
