@@ -367,3 +367,166 @@ extern "C" int guber_wire_encode_responses(const guber_wire_batch_t* b, uint32_t
     *len = used;
     return overflow ? GUBER_E_NOMEM : GUBER_OK;
 }
+
+// ---- UpdatePeerGlobals ---------------------------------------------------------------------------------------------
+struct guber_wire_items {
+    uint32_t cap_items = 0, cap_keys = 0;
+    std::vector<guber_item_t> items;
+    std::vector<uint8_t> keys;
+};
+
+extern "C" int guber_wire_items_create(uint32_t max_items, uint32_t max_key_bytes, guber_wire_items_t** out) {
+    if (!out || max_items == 0 || max_key_bytes == 0) return GUBER_E_INVALID_ARG;
+    *out = nullptr;
+    guber_wire_items* w = new (std::nothrow) guber_wire_items();
+    if (!w) return GUBER_E_NOMEM;
+    try { w->items.resize(max_items); w->keys.resize((size_t)max_key_bytes + 16); } catch (...) { delete w; return GUBER_E_NOMEM; }
+    w->cap_items = max_items; w->cap_keys = max_key_bytes;
+    *out = w;
+    return GUBER_OK;
+}
+extern "C" void guber_wire_items_destroy(guber_wire_items_t* w) { delete w; }
+
+namespace {
+struct RespFieldsIn { int64_t status = 0, limit = 0, remaining = 0, reset_time = 0; };
+// RateLimitResp (gubernator.proto:189-203) as it arrives inside UpdatePeerGlobal.status; error / metadata are validated and ignored
+bool parse_resp(const uint8_t* p, const uint8_t* end, RespFieldsIn& f) {
+    while (p < end) {
+        uint64_t tag, v;
+        if (!get_varint(p, end, tag)) return false;
+        const uint32_t wt = (uint32_t)(tag & 7);
+        const uint64_t field = tag >> 3;
+        if (field == 0 || field > 0x1fffffffull) return false;
+        if (wt == 0 && field >= 1 && field <= 4) {
+            if (!get_varint(p, end, v)) return false;
+            if (field == 1) f.status = (int64_t)(int32_t)v;
+            else if (field == 2) f.limit = (int64_t)v;
+            else if (field == 3) f.remaining = (int64_t)v;
+            else f.reset_time = (int64_t)v;
+        } else if (field == 5 && wt == 2) {
+            if (!get_varint(p, end, v) || (uint64_t)(end - p) < v || v > 0xffffffffull || !valid_utf8(p, (uint32_t)v)) return false;
+            p += v;
+        } else if (field == 6 && wt == 2) {                       // metadata map entry: structure and UTF-8 as the runtimes check them
+            if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return false;
+            const uint8_t* q = p; const uint8_t* qe = p + v;
+            while (q < qe) {
+                uint64_t t2, l2;
+                if (!get_varint(q, qe, t2)) return false;
+                const uint32_t w2 = (uint32_t)(t2 & 7);
+                const uint64_t f2 = t2 >> 3;
+                if (f2 == 0 || f2 > 0x1fffffffull) return false;
+                if ((f2 == 1 || f2 == 2) && w2 == 2) {
+                    if (!get_varint(q, qe, l2) || (uint64_t)(qe - q) < l2 || l2 > 0xffffffffull || !valid_utf8(q, (uint32_t)l2)) return false;
+                    q += l2;
+                } else if (!skip_field(q, qe, w2, f2)) return false;
+            }
+            p = qe;
+        } else if (!skip_field(p, end, wt, field)) {
+            return false;
+        }
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int guber_wire_decode_globals(guber_wire_items_t* w, const uint8_t* msg, size_t len, int64_t now_ms,
+                                         const guber_item_t** out, uint32_t* count) {
+    if (!w || (!msg && len) || !out || !count) return GUBER_E_INVALID_ARG;
+    *out = w->items.data(); *count = 0;
+    uint32_t n = 0, kused = 0;
+    const uint8_t* p = msg; const uint8_t* end = msg + len;
+    while (p < end) {
+        uint64_t tag, v;
+        if (!get_varint(p, end, tag)) return GUBER_E_WIRE_MALFORMED;
+        const uint32_t wt = (uint32_t)(tag & 7);
+        if ((tag >> 3) == 0 || (tag >> 3) > 0x1fffffffull) return GUBER_E_WIRE_MALFORMED;
+        if ((tag >> 3) != 1 || wt != 2) {
+            if (!skip_field(p, end, wt, tag >> 3)) return GUBER_E_WIRE_MALFORMED;
+            continue;
+        }
+        if (!get_varint(p, end, v) || (uint64_t)(end - p) < v) return GUBER_E_WIRE_MALFORMED;
+        const uint8_t* q = p; const uint8_t* qe = p + v;
+        p = qe;
+        Span key; RespFieldsIn st; int64_t algorithm = 0, duration = 0;
+        while (q < qe) {                                          // UpdatePeerGlobal
+            uint64_t t2, x;
+            if (!get_varint(q, qe, t2)) return GUBER_E_WIRE_MALFORMED;
+            const uint32_t w2 = (uint32_t)(t2 & 7);
+            const uint64_t f2 = t2 >> 3;
+            if (f2 == 0 || f2 > 0x1fffffffull) return GUBER_E_WIRE_MALFORMED;
+            if (f2 == 1 && w2 == 2) {
+                if (!get_varint(q, qe, x) || (uint64_t)(qe - q) < x || x > 0xffffffffull || !valid_utf8(q, (uint32_t)x)) return GUBER_E_WIRE_MALFORMED;
+                key.p = q; key.n = (uint32_t)x; q += x;
+            } else if (f2 == 2 && w2 == 2) {
+                if (!get_varint(q, qe, x) || (uint64_t)(qe - q) < x) return GUBER_E_WIRE_MALFORMED;
+                // a repeated occurrence of a singular message field merges into the previous one: parse into the same struct
+                if (!parse_resp(q, q + x, st)) return GUBER_E_WIRE_MALFORMED;
+                q += x;
+            } else if (w2 == 0 && (f2 == 3 || f2 == 4 || f2 == 5)) {
+                if (!get_varint(q, qe, x)) return GUBER_E_WIRE_MALFORMED;
+                if (f2 == 3) algorithm = (int64_t)(int32_t)x;
+                else if (f2 == 4) duration = (int64_t)x;          // 5 = created_at: not used by the receiver (gubernator.go:427 takes now)
+            } else if (!skip_field(q, qe, w2, f2)) {
+                return GUBER_E_WIRE_MALFORMED;
+            }
+        }
+        if (n >= w->cap_items || key.n > w->cap_keys - kused) return GUBER_E_WIRE_FULL;
+        guber_item_t& it = w->items[n];
+        memset(&it, 0, sizeof(it));
+        memcpy(w->keys.data() + kused, key.p, key.n);
+        it.key = w->keys.data() + kused; it.key_len = key.n;
+        kused += key.n;
+        it.expire_at = st.reset_time;                                             // gubernator.go:430
+        if (algorithm == GUBER_ALGO_LEAKY_BUCKET) {                               // :435-442
+            it.algorithm = GUBER_ALGO_LEAKY_BUCKET;
+            it.remaining_f = (double)st.remaining; it.limit = st.limit; it.duration = duration; it.burst = st.limit; it.stamp = now_ms;
+        } else if (algorithm == GUBER_ALGO_TOKEN_BUCKET) {                        // :443-451
+            it.algorithm = GUBER_ALGO_TOKEN_BUCKET;
+            it.status = (uint8_t)st.status; it.limit = st.limit; it.duration = duration; it.remaining = st.remaining; it.stamp = now_ms;
+        } else {
+            it.algorithm = (uint8_t)(algorithm < 0 || algorithm > 254 ? 255 : algorithm);   // no Value: the switch at :434 matches nothing
+        }
+        ++n;
+    }
+    *count = n;
+    return GUBER_OK;
+}
+
+extern "C" int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off, const uint8_t* algorithm,
+                                         const int64_t* duration, const int64_t* created_at, const guber_result_t* status, uint32_t n,
+                                         uint8_t* out, size_t cap, size_t* len) {
+    if (!len || (n && (!key_bytes || !key_off || !algorithm || !duration || !created_at || !status)) || (!out && cap)) return GUBER_E_INVALID_ARG;
+    size_t used = 0;
+    bool overflow = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (status->err[i] != GUBER_ITEM_OK) continue;                            // global.go:246-249: status read failed -> skipped
+        const RespFields f{(uint64_t)status->status[i], (uint64_t)status->limit[i], (uint64_t)status->remaining[i], (uint64_t)status->reset_time[i]};
+        const size_t sbody = resp_body_size(f, 0);
+        const uint32_t klen = key_off[i + 1] - key_off[i];
+        size_t body = 0;
+        if (klen) body += 1 + varint_size(klen) + klen;
+        body += 1 + varint_size(sbody) + sbody;                                   // the status message is always present (non-nil pointer)
+        if (algorithm[i]) body += 1 + varint_size(algorithm[i]);
+        if (duration[i]) body += 1 + varint_size((uint64_t)duration[i]);
+        if (created_at[i]) body += 1 + varint_size((uint64_t)created_at[i]);
+        const size_t total = 1 + varint_size(body) + body;
+        if (!overflow && used + total <= cap) {
+            uint8_t* p = out + used;
+            *p++ = 0x0a; p = put_varint(p, body);
+            if (klen) { *p++ = 0x0a; p = put_varint(p, klen); memcpy(p, key_bytes + key_off[i], klen); p += klen; }
+            *p++ = 0x12; p = put_varint(p, sbody);
+            if (f.status) { *p++ = 0x08; p = put_varint(p, f.status); }
+            if (f.limit) { *p++ = 0x10; p = put_varint(p, f.limit); }
+            if (f.remaining) { *p++ = 0x18; p = put_varint(p, f.remaining); }
+            if (f.reset) { *p++ = 0x20; p = put_varint(p, f.reset); }
+            if (algorithm[i]) { *p++ = 0x18; p = put_varint(p, algorithm[i]); }
+            if (duration[i]) { *p++ = 0x20; p = put_varint(p, (uint64_t)duration[i]); }
+            if (created_at[i]) { *p++ = 0x28; p = put_varint(p, (uint64_t)created_at[i]); }
+        } else {
+            overflow = true;
+        }
+        used += total;
+    }
+    *len = used;
+    return overflow ? GUBER_E_NOMEM : GUBER_OK;
+}

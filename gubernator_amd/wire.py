@@ -13,6 +13,7 @@ WIRE_SYMBOLS = [
     "guber_wire_batch_create", "guber_wire_batch_destroy", "guber_wire_batch_reset", "guber_wire_batch_size",
     "guber_wire_decode_requests", "guber_wire_batch_view", "guber_wire_batch_result", "guber_wire_batch_pre_errors",
     "guber_wire_eval", "guber_wire_encode_bound", "guber_wire_encode_responses",
+    "guber_wire_items_create", "guber_wire_items_destroy", "guber_wire_decode_globals", "guber_wire_encode_globals",
 ]
 _bound = False
 
@@ -41,6 +42,12 @@ def _lib():
         L.guber_wire_encode_bound.restype = C.c_size_t
         L.guber_wire_encode_responses.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t,
                                                   C.POINTER(C.c_size_t)]
+        L.guber_wire_items_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_wire_items_destroy.argtypes = [C.c_void_p]
+        L.guber_wire_items_destroy.restype = None
+        L.guber_wire_decode_globals.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
+        L.guber_wire_encode_globals.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GuberResult), C.c_uint32,
+                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _bound = True
     return L
 
@@ -120,3 +127,52 @@ class WireBatch:
         if rc:
             raise GuberError(rc, self.L.guber_strerror(rc).decode())
         return bytes(buf[:n.value])
+
+
+class WireItems:
+    """UpdatePeerGlobalsReq payload -> the CacheItems the receiver installs (gubernator.go:425-459), ready for guber_add_items."""
+
+    def __init__(self, max_items=65536, max_key_bytes=4 << 20):
+        self.L = _lib()
+        self.h = C.c_void_p()
+        rc = self.L.guber_wire_items_create(max_items, max_key_bytes, C.byref(self.h))
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+
+    def close(self):
+        if self.h:
+            self.L.guber_wire_items_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, payload: bytes, now_ms):
+        """-> (ctypes array view of GuberItem, count); valid until the next decode."""
+        from .abi import GuberItem
+        out, n = C.c_void_p(), C.c_uint32()
+        rc = self.L.guber_wire_decode_globals(self.h, payload, len(payload), now_ms, C.byref(out), C.byref(n))
+        if rc:
+            raise GuberError(rc, self.L.guber_strerror(rc).decode())
+        return C.cast(out, C.POINTER(GuberItem)), n.value
+
+
+def encode_globals(host_batch, status):
+    """UpdatePeerGlobalsReq bytes for the update rows in `host_batch` (HostBatch: keys, algorithm, duration, created_at) and
+    their hits = 0 status (HostResult), as broadcastPeers builds it (global.go:234-262)."""
+    import numpy as np
+    L = _lib()
+    n = host_batch.n
+    created = host_batch.created_at if host_batch.created_at is not None else np.full(max(n, 1), host_batch.now_ms, np.int64)
+    need = C.c_size_t()
+    args = (host_batch.key_bytes.ctypes.data, host_batch.key_off.ctypes.data, host_batch.algorithm.ctypes.data,
+            host_batch.duration.ctypes.data, created.ctypes.data, C.byref(status.c), n)
+    L.guber_wire_encode_globals(*args, None, 0, C.byref(need))
+    buf = (C.c_uint8 * max(need.value, 1))()
+    rc = L.guber_wire_encode_globals(*args, buf, need.value, C.byref(need))
+    if rc:
+        raise GuberError(rc, L.guber_strerror(rc).decode())
+    return bytes(buf[:need.value])

@@ -83,6 +83,30 @@ size_t guber_wire_encode_bound(const guber_wire_batch_t* b, uint32_t first, uint
 int guber_wire_encode_responses(const guber_wire_batch_t* b, uint32_t first, uint32_t count, int wrap_errors,
                                 uint8_t* out, size_t cap, size_t* len);
 
+/* ---- UpdatePeerGlobals (peers.proto:51-63; sender global.go:234-283 broadcastPeers, receiver gubernator.go:425-459) ----
+ * The third payload kind that touches the path: the owner of GLOBAL keys broadcasts their state, every other peer
+ * installs it in its cache.
+ *   UpdatePeerGlobalsReq: globals 1 (repeated UpdatePeerGlobal)
+ *   UpdatePeerGlobal    : key 1 (string), status 2 (RateLimitResp), algorithm 3 (enum), duration 4, created_at 5 (int64)
+ *
+ * guber_wire_encode_globals  the sender side: one UpdatePeerGlobal per update row (key, algorithm, duration, created_at
+ *     of the queued request — what guber_global_take role 2 returns) with `status` = the owner's hits = 0 read of the
+ *     bucket; rows whose status read failed (status->err[i] != 0) are skipped (global.go:246-249).
+ *     GUBER_E_NOMEM + *len = size needed when cap is too small.
+ * guber_wire_decode_globals  the receiver side: the CacheItem of every global exactly as UpdatePeerGlobals builds it
+ *     (ExpireAt = status.reset_time; leaky: Remaining = float64(status.remaining), Burst = Limit = status.limit,
+ *     UpdatedAt = now; token: Status, Limit, Remaining from status, CreatedAt = now; Duration = the message's; any other
+ *     algorithm: an item without a value), as a guber_item_t array ready for guber_add_items.  The array and the key
+ *     bytes it points to belong to `items` and stay valid until the next decode into it or its destruction. */
+typedef struct guber_wire_items guber_wire_items_t;
+int guber_wire_items_create(uint32_t max_items, uint32_t max_key_bytes, guber_wire_items_t** out);
+void guber_wire_items_destroy(guber_wire_items_t* items);
+int guber_wire_decode_globals(guber_wire_items_t* items, const uint8_t* msg, size_t len, int64_t now_ms,
+                              const guber_item_t** out, uint32_t* count);
+int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off, const uint8_t* algorithm,
+                              const int64_t* duration, const int64_t* created_at, const guber_result_t* status, uint32_t n,
+                              uint8_t* out, size_t cap, size_t* len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,9 +69,19 @@ def build():
     m = fd.message_type.add(name="GetPeerRateLimitsResp")              # peers.proto:43-47
     _field(m, "rate_limits", 1, F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".pb.gubernator.RateLimitResp")
 
+    m = fd.message_type.add(name="UpdatePeerGlobal")                   # peers.proto:55-62
+    _field(m, "key", 1, F.TYPE_STRING)
+    _field(m, "status", 2, F.TYPE_MESSAGE, type_name=".pb.gubernator.RateLimitResp")
+    _field(m, "algorithm", 3, F.TYPE_ENUM, type_name=".pb.gubernator.Algorithm")
+    _field(m, "duration", 4, F.TYPE_INT64)
+    _field(m, "created_at", 5, F.TYPE_INT64)
+    m = fd.message_type.add(name="UpdatePeerGlobalsReq")               # peers.proto:51-53
+    _field(m, "globals", 1, F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".pb.gubernator.UpdatePeerGlobal")
+
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
-    names = ["RateLimitReq", "RateLimitResp", "GetRateLimitsReq", "GetRateLimitsResp", "GetPeerRateLimitsReq", "GetPeerRateLimitsResp"]
+    names = ["RateLimitReq", "RateLimitResp", "GetRateLimitsReq", "GetRateLimitsResp", "GetPeerRateLimitsReq", "GetPeerRateLimitsResp",
+             "UpdatePeerGlobal", "UpdatePeerGlobalsReq"]
     return {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("pb.gubernator." + n)) for n in names}
 
 

@@ -255,7 +255,11 @@ def _reference_view(payload):
     return m
 
 
-def _has_overflowing_varint(buf, depth=0, known_nested=(1,)):
+REQ_NESTED = {0: (1,), 1: (9,)}                 # GetRateLimitsReq.requests, RateLimitReq.metadata entries
+GLOBALS_NESTED = {0: (1,), 1: (2,), 2: (6,)}     # UpdatePeerGlobalsReq.globals, UpdatePeerGlobal.status, RateLimitResp.metadata entries
+
+
+def _has_overflowing_varint(buf, depth=0, nested=REQ_NESTED):
     """True when some varint of the message occupies 10 bytes with a last byte >= 2 (more than 64 bits).  The
     reference's runtime (google.golang.org/protobuf v1.32.0, go.mod:32: protowire.ConsumeVarint) rejects such
     input as overflow — and so does the transcoder — while the python runtime truncates silently.  Only called on
@@ -293,9 +297,9 @@ def _has_overflowing_varint(buf, depth=0, known_nested=(1,)):
                 ln |= (c & 0x7f) << (7 * k)
             body = buf[pos:pos + ln]
             pos += ln
-            # nested messages the schema knows: requests (1) at the top, metadata entries (9) inside a request
-            if (depth == 0 and field == 1) or (depth == 1 and field == 9):
-                if _has_overflowing_varint(body, depth + 1):
+            # nested messages the schema knows (their content is parsed by the runtimes, unknown LEN fields are not)
+            if field in nested.get(depth, ()):
+                if _has_overflowing_varint(body, depth + 1, nested):
                     return True
         # groups: the fuzz corpus only has them at the top level with plain varint content; tags were checked above
     return False
@@ -351,3 +355,128 @@ def test_fuzzed_payloads_agree_with_the_protobuf_runtime():
             assert got["algorithm"][i] == (q.algorithm if q.algorithm in (0, 1) else 255)
     assert accepted > 1500 and rejected > 1500 and overflow < 60, (accepted, rejected, overflow)
     wb.close()
+
+
+def test_update_peer_globals_codec_against_the_protobuf_runtime():
+    """UpdatePeerGlobalsReq (peers.proto:51-63): the sender's bytes equal the protobuf runtime's for the message
+    broadcastPeers builds (global.go:234-262), and the receiver's decoded items are the CacheItems UpdatePeerGlobals
+    constructs (gubernator.go:425-459)."""
+    from gubernator_amd.abi import HostBatch, HostResult, item_dict
+    rng = np.random.default_rng(8)
+    n = 500
+    keys = [("glob_%d" % i if i % 50 else "ключ_%d" % i).encode() for i in range(n)]
+    algo = rng.integers(0, 2, n).astype(np.uint8)
+    duration = rng.choice([0, 1, 60_000, -5, 2**50], n).astype(np.int64)
+    created = rng.choice([0, NOW, NOW - 3, 12345], n).astype(np.int64)
+    b = HostBatch(keys, 0, 10, duration, NOW, created_at=created, algorithm=algo)
+    st = HostResult(n)
+    st.status[:n] = rng.integers(0, 2, n)
+    st.limit[:n] = rng.choice([0, 10, 100, -1], n)
+    st.remaining[:n] = rng.choice([0, 5, 99, -7, 2**62], n)
+    st.reset_time[:n] = rng.choice([0, NOW + 60_000, NOW - 1], n)
+    st.err[:n] = (rng.random(n) < 0.05).astype(np.uint8)            # a few failed status reads: skipped by the sender
+    got = gw.encode_globals(b, st)
+    want = PB["UpdatePeerGlobalsReq"]()
+    sent = []
+    for i in range(n):
+        if st.err[i]:
+            continue
+        g = want.globals.add(key=keys[i].decode(), algorithm=int(algo[i]), duration=int(duration[i]), created_at=int(created[i]))
+        g.status.SetInParent()
+        g.status.status, g.status.limit, g.status.remaining, g.status.reset_time = int(st.status[i]), int(st.limit[i]), int(st.remaining[i]), int(st.reset_time[i])
+        sent.append(i)
+    assert got == want.SerializeToString(deterministic=True)
+    # receiver: decode what the runtime serialised (plus metadata / unknown fields, which are ignored)
+    for g in want.globals[:5]:
+        g.status.metadata["owner"] = "10.0.0.1:81"
+    payload = want.SerializeToString() + bytes([0x78, 0x01])
+    wi = gw.WireItems(1024, 1 << 16)
+    now2 = NOW + 77
+    items, cnt = wi.decode(payload, now2)
+    assert cnt == len(sent)
+    for j, i in enumerate(sent):
+        d = item_dict(items[j])
+        assert d["key"] == keys[i] and d["algorithm"] == algo[i] and d["expire_at"] == st.reset_time[i] and d["duration"] == duration[i]
+        assert d["stamp"] == now2 and d["limit"] == st.limit[i] and d["invalid_at"] == 0
+        if algo[i] == 1:   # gubernator.go:435-442
+            assert d["remaining_f"] == float(st.remaining[i]) and d["burst"] == st.limit[i] and d["remaining"] == 0 and d["status"] == 0
+        else:              # :443-451
+            assert d["remaining"] == st.remaining[i] and d["status"] == st.status[i] and d["burst"] == 0 and d["remaining_f"] == 0.0
+    # malformed payloads are rejected, capacity is reported
+    with pytest.raises(ga.GuberError) as ei:
+        wi.decode(payload[:-3] + b"\xff", now2)
+    assert ei.value.code == gw.E_WIRE_MALFORMED
+    small = gw.WireItems(10, 1 << 16)
+    with pytest.raises(ga.GuberError) as ei:
+        small.decode(payload, now2)
+    assert ei.value.code == gw.E_WIRE_FULL
+    # the oracle installs these items exactly as it installs hand-built ones: a replica answers from them
+    o = support.Oracle(cache_size=1 << 12)
+    for j in range(cnt):
+        o.add_item(items[j], now2)
+    k = sent[0]
+    it = o.get_item(keys[k], now2)
+    if st.reset_time[k] >= now2:
+        assert it is not None and it["limit"] == st.limit[k]
+    wi.close(); small.close()
+
+
+def test_fuzzed_update_peer_globals_agree_with_the_protobuf_runtime():
+    rng = np.random.default_rng(303)
+    wi = gw.WireItems(256, 1 << 15)
+    base = []
+    for _ in range(30):
+        m = PB["UpdatePeerGlobalsReq"]()
+        for i in range(int(rng.integers(1, 8))):
+            g = m.globals.add(key="k%d_ü" % rng.integers(0, 99), algorithm=int(rng.choice([0, 1, 1, 5])), duration=int(rng.choice([0, 60000, -1])),
+                              created_at=int(rng.choice([0, NOW])))
+            g.status.SetInParent()
+            g.status.status, g.status.limit, g.status.remaining, g.status.reset_time = int(rng.integers(0, 2)), int(rng.choice([0, 10, -3])), \
+                int(rng.choice([0, 7, 2**62])), int(rng.choice([0, NOW + 5]))
+            if rng.random() < 0.3:
+                g.status.error = "é"
+                g.status.metadata["a"] = "b"
+        base.append(m.SerializeToString())
+    acc = rej = ovf = 0
+    for it in range(4000):
+        p = bytearray(base[int(rng.integers(0, len(base)))])
+        for _ in range(int(rng.integers(0, 4))):
+            if not p:
+                break
+            op, i = rng.integers(0, 5), int(rng.integers(0, len(p)))
+            if op == 0:
+                p[i] ^= 1 << int(rng.integers(0, 8))
+            elif op == 1:
+                p.insert(i, int(rng.integers(0, 256)))
+            elif op == 2:
+                del p[i]
+            elif op == 3:
+                del p[i:]
+            else:
+                p[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8))
+        p = bytes(p)
+        ref = PB["UpdatePeerGlobalsReq"]()
+        try:
+            ref.ParseFromString(p)
+        except Exception:
+            ref = None
+        try:
+            items, cnt = wi.decode(p, NOW)
+            got = [(bytes(C.string_at(items[j].key, items[j].key_len)), items[j].algorithm, items[j].duration, items[j].expire_at) for j in range(cnt)]
+        except ga.GuberError as e:
+            assert e.code == gw.E_WIRE_MALFORMED, e
+            got = None
+        if got is None and ref is not None and _has_overflowing_varint(p, nested=GLOBALS_NESTED):
+            ovf += 1
+            continue
+        assert (got is None) == (ref is None), (it, p.hex())
+        if ref is None:
+            rej += 1
+            continue
+        acc += 1
+        assert len(got) == len(ref.globals)
+        for (k, a, d, ex), g in zip(got, ref.globals):
+            assert k == g.key.encode() and d == (g.duration if g.algorithm in (0, 1) else 0) and ex == g.status.reset_time, (it, p.hex())
+            assert a == (g.algorithm if 0 <= g.algorithm <= 254 else 255)
+    assert acc > 800 and rej > 800 and ovf < 60, (acc, rej, ovf)
+    wi.close()
