@@ -347,6 +347,30 @@ global_scenarios = [
          duration=1000 * MINUTE, steps=[g(f"p{i}", 50, UNDER, 50) for i in range(4)] + [g("p4", 50, UNDER, 50, sync_after=True),
                                         g("p0", 1, OVER, 0), g("p0", 0, sync_after=True, behavior=RESET_REMAINING), g("p1", 0, UNDER)]),
 ]
+# :1690-2097 TestGlobalBehavior (token, limit 1000, 3 min).  Besides the answers it pins WHO talks to whom at the sync:
+# which peers send a hits update to the owner (GetPeerRateLimits count on the owner, :1966-1974, :2080-2087), that only the
+# owner broadcasts and exactly once (:1762-1783), and that afterwards every peer reports limit - hits for a hits = 0
+# request (:1815-1821).  expect_sync = {"hits_from": peers whose queue must be flushed to the owner, "broadcast_from": ["o"]}.
+def all_report(remaining):
+    return [g(pr, 0, UNDER, remaining) for pr in ["o"] + [f"p{i}" for i in range(5)]]
+
+for hits in (1, 10):       # :1708-1828 "Hits on owner peer"
+    global_scenarios.append(dict(
+        name=f"TestGlobalBehavior/Hits on owner peer/{hits}", source="functional_test.go:1708-1828", algorithm=TOKEN, limit=1000, duration=3 * MINUTE,
+        steps=[dict(g("o", 1, UNDER, 999 - i, sync_after=(i == hits - 1)), **({"expect_sync": dict(hits_from=[], broadcast_from=["o"])} if i == hits - 1 else {}))
+               for i in range(hits)] + all_report(1000 - hits)))
+for hits in (1, 10):       # :1830-1960 "Hits on non-owner peer"
+    global_scenarios.append(dict(
+        name=f"TestGlobalBehavior/Hits on non-owner peer/{hits}", source="functional_test.go:1830-1960", algorithm=TOKEN, limit=1000, duration=3 * MINUTE,
+        steps=[dict(g("p0", 1, UNDER, 999 - i, sync_after=(i == hits - 1)), **({"expect_sync": dict(hits_from=["p0"], broadcast_from=["o"])} if i == hits - 1 else {}))
+               for i in range(hits)] + all_report(1000 - hits)))
+for hits in (2, 10, 100):  # :1962-2097 "Distributed hits": round robin over the five local non-owner peers
+    touched = sorted({f"p{i % 5}" for i in range(hits)})
+    global_scenarios.append(dict(
+        name=f"TestGlobalBehavior/Distributed hits/{hits}", source="functional_test.go:1962-2097", algorithm=TOKEN, limit=1000, duration=3 * MINUTE,
+        steps=[dict(g(f"p{i % 5}", 1, UNDER, sync_after=(i == hits - 1)), **({"expect_sync": dict(hits_from=touched, broadcast_from=["o"])} if i == hits - 1 else {}))
+               for i in range(hits)] + all_report(1000 - hits)))
+
 with open(os.path.join(HERE, "global_vectors.json"), "w") as f:
     json.dump(dict(_comment="Transcribed from mailgun/gubernator v2 functional_test.go GLOBAL tests", scenarios=global_scenarios), f, indent=1)
 print("wrote", len(global_scenarios), "global scenarios")

@@ -54,7 +54,16 @@ def run_vectors(request_fn, sync_fn, ring, n_peers):
             n += 1
             now += 3
             if st["sync_after"]:
-                sync_fn(now)
+                stats = sync_fn(now)
+                es = st.get("expect_sync")
+                if es and isinstance(stats, list) and stats and isinstance(stats[0], dict):   # per-rank stats of the orchestrator
+                    rk = lambda pr: 0 if pr == "o" else 1 + int(pr[1:])
+                    senders = sorted(r for r, s_ in enumerate(stats) if s_["hits_sent"] > 0)
+                    assert senders == sorted(rk(pr) for pr in es["hits_from"]), (where, stats)
+                    assert all(stats[r]["hits_sent"] == 1 for r in senders), (where, stats)        # one aggregated row per sender and key
+                    casters = sorted(r for r, s_ in enumerate(stats) if s_["broadcast"] > 0)
+                    assert casters == sorted(rk(pr) for pr in es["broadcast_from"]) and stats[0]["broadcast"] == 1, (where, stats)
+                    n += 1
     return n
 
 
