@@ -473,7 +473,7 @@ extern "C" int guber_wire_decode_globals(guber_wire_items_t* w, const uint8_t* m
         if (n >= w->cap_items || key.n > w->cap_keys - kused) return GUBER_E_WIRE_FULL;
         guber_item_t& it = w->items[n];
         memset(&it, 0, sizeof(it));
-        memcpy(w->keys.data() + kused, key.p, key.n);
+        if (key.n) memcpy(w->keys.data() + kused, key.p, key.n);
         it.key = w->keys.data() + kused; it.key_len = key.n;
         kused += key.n;
         it.expire_at = st.reset_time;                                             // gubernator.go:430

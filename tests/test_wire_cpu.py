@@ -480,3 +480,19 @@ def test_fuzzed_update_peer_globals_agree_with_the_protobuf_runtime():
             assert a == (g.algorithm if 0 <= g.algorithm <= 254 else 255)
     assert acc > 800 and rej > 800 and ovf < 60, (acc, rej, ovf)
     wi.close()
+
+
+def test_wire_parser_is_memory_safe_under_asan_fuzz(tmp_path):
+    """tools/wire_fuzz_asan.cpp: 300 000 mutated payloads through decode / encode, compiled with -fsanitize=address,undefined
+    against exact-size heap buffers — any out-of-bounds access or undefined behaviour aborts the run."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "wire_fuzz")
+    root = support.ROOT
+    subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tools", "wire_fuzz_asan.cpp"), os.path.join(root, "gubernator_amd", "csrc", "wire.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe, "300000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "no sanitizer report" in out.stdout
