@@ -159,12 +159,13 @@ extern "C" int guber_gregorian_expiration(int64_t now_ns, int64_t d, int64_t* ex
     civil_from_days(day, y, m, dd);
     int64_t end_ns;
     switch (d) {
-    case GUBER_GREGORIAN_MINUTES: end_ns = floor_div(now_ns, kMin) * kMin + kMin - 1; break;
-    case GUBER_GREGORIAN_HOURS: end_ns = floor_div(now_ns, kHour) * kHour + kHour - 1; break;
-    case GUBER_GREGORIAN_DAYS: end_ns = day * kDay + kDay - 1; break;
+    // wrap-around arithmetic (guber::wmul / wadd): a clock within one interval of the int64 range must not be undefined behaviour
+    case GUBER_GREGORIAN_MINUTES: end_ns = guber::wadd(guber::wmul(floor_div(now_ns, kMin), kMin), kMin - 1); break;
+    case GUBER_GREGORIAN_HOURS: end_ns = guber::wadd(guber::wmul(floor_div(now_ns, kHour), kHour), kHour - 1); break;
+    case GUBER_GREGORIAN_DAYS: end_ns = guber::wadd(guber::wmul(day, kDay), kDay - 1); break;
     case GUBER_GREGORIAN_WEEKS: return -(int)GUBER_ITEM_E_GREGORIAN_WEEKS;
-    case GUBER_GREGORIAN_MONTHS: end_ns = days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1) * kDay - 1; break;
-    case GUBER_GREGORIAN_YEARS: end_ns = days_from_civil(y + 1, 1, 1) * kDay - 1; break;
+    case GUBER_GREGORIAN_MONTHS: end_ns = guber::wsub(guber::wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1); break;
+    case GUBER_GREGORIAN_YEARS: end_ns = guber::wsub(guber::wmul(days_from_civil(y + 1, 1, 1), kDay), 1); break;
     default: return -(int)GUBER_ITEM_E_GREGORIAN_INVALID;
     }
     *expire_ms = floor_div(end_ns, kMs);
@@ -183,15 +184,15 @@ extern "C" int guber_gregorian_duration(int64_t now_ns, int64_t d, int64_t* dura
     case GUBER_GREGORIAN_DAYS: *duration = 86400000; return GUBER_OK;
     case GUBER_GREGORIAN_WEEKS: return -(int)GUBER_ITEM_E_GREGORIAN_WEEKS;
     case GUBER_GREGORIAN_MONTHS: {
-        const int64_t begin = days_from_civil(y, m, 1) * kDay;
-        const int64_t end = days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1) * kDay - 1;
-        *duration = end - begin / kMs;
+        const int64_t begin = guber::wmul(days_from_civil(y, m, 1), kDay);
+        const int64_t end = guber::wsub(guber::wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
+        *duration = guber::wsub(end, begin / kMs);
         return GUBER_OK;
     }
     case GUBER_GREGORIAN_YEARS: {
-        const int64_t begin = days_from_civil(y, 1, 1) * kDay;
-        const int64_t end = days_from_civil(y + 1, 1, 1) * kDay - 1;
-        *duration = end - begin / kMs;
+        const int64_t begin = guber::wmul(days_from_civil(y, 1, 1), kDay);
+        const int64_t end = guber::wsub(guber::wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
+        *duration = guber::wsub(end, begin / kMs);
         return GUBER_OK;
     }
     default: return -(int)GUBER_ITEM_E_GREGORIAN_INVALID;
