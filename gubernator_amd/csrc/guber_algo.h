@@ -377,6 +377,161 @@ GB_HD uint32_t eval_uniform_rank(const Rec& s0, const Req& r, int64_t now, uint6
     return apply(s_after, r, now, out);
 }
 
+// eval_uniform_rank with ONE apply() site (the kernels inline it: a third of the code and registers of the three-site
+// form above).  k = applications still due before the request's own; the shortcuts of skip() are taken after every
+// application, the first one included — each is exact wherever it triggers, so the results are identical.
+GB_HD uint32_t eval_uniform_rank_1x(const Rec& s0, const Req& r, int64_t now, uint64_t rank, Resp& out, Rec& s) {
+    s = s0;
+    uint64_t k = rank;
+    Rec prev2; rec_clear(prev2);
+    bool have_prev2 = false;
+    for (;;) {
+        const Rec before = s;
+        const uint32_t ev = apply(s, r, now, out);
+        if (k == 0) return ev;
+        k--;
+        if (k == 0) continue;
+        if (rec_eq(s, before)) { k = 0; continue; }                       // fixed point
+        if (have_prev2 && rec_eq(s, prev2)) {                             // period 2
+            if (k & 1) s = before;
+            k = 0;
+            continue;
+        }
+        prev2 = before; have_prev2 = true;
+        if (pure_subtract(before, s, r, now)) {
+            const uint32_t kind = rec_kind(s);
+            const int64_t n = kind == K_TOKEN ? s.remaining : go_f2i(bits2f(s.remaining));
+            if (n > 0) {
+                const uint64_t m = (uint64_t)(n - 1) / (uint64_t)r.hits;
+                const uint64_t j = m < k ? m : k;
+                if (j > 0) {
+                    const int64_t dec = (int64_t)(j * (uint64_t)r.hits);  // <= n-1, exact
+                    if (kind == K_TOKEN) s.remaining -= dec;
+                    else s.remaining = f2bits(bits2f(s.remaining) - (double)dec);
+                    k -= j;
+                    have_prev2 = false;
+                }
+            }
+        }
+    }
+}
+
+// ---- closed forms for the regimes real traffic lives in ---------------------------------------
+// A run of identical requests with hits = h > 0 against a LIVE bucket whose configuration the request does not
+// change is a counter walk on the integer level I (token: Remaining; leaky: int64(Remaining)): while I > h the
+// request subtracts (algorithms.go:196-198 / :427-430); the request that finds I == h takes the last tokens
+// (:173-178 / :398-403); one that finds 0 < I < h is refused (:182-194 / :407-420) and leaves the level alone
+// unless DRAIN_OVER_LIMIT zeroes it; one that finds I == 0 is refused (:162-170 / :389-395).  So the request of
+// rank k can tell which of these it is from (I0, h, k) alone — one 64x64 multiply, no stepping, and a division only
+// for the requests that come after a refused one without DRAIN.  token_fast / leaky_fast return exactly what
+// eval_uniform_rank returns for the same arguments (tests/test_kernel_logic_host.py fuzzes the equality); everything
+// they decline goes through apply() / skip().
+enum : uint32_t { RUN_PLAIN = 0, RUN_EXACT = 1, RUN_SHORT = 2, RUN_STUCK = 3, RUN_ZERO = 4 };
+
+// a * h < lim without overflow (a < 2^32, h and lim < 2^63)
+GB_HD bool mul_lt(uint64_t a, uint64_t h, uint64_t lim) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, h) == 0ull && a * h < lim;
+#else
+    return (unsigned __int128)a * h < (unsigned __int128)lim;
+#endif
+}
+// What request k (0-based) of the run finds: `level` = the integer level right before it acts.
+GB_HD uint32_t run_position(uint64_t I0, uint64_t h, uint64_t k, bool drain, uint64_t& level) {
+    if (I0 == 0) { level = 0; return RUN_ZERO; }
+    if (mul_lt(k + 1, h, I0)) { level = I0 - k * h; return RUN_PLAIN; }       // k < P = (I0 - 1) / h
+    if (mul_lt(k, h, I0)) { level = I0 - k * h; return level == h ? RUN_EXACT : RUN_SHORT; }   // k == P
+    if (drain || h == 1) { level = 0; return RUN_ZERO; }                      // the level was zeroed at request P
+    const uint64_t lp = (I0 - 1) % h + 1;                                     // level request P found, 1..h
+    if (lp == h) { level = 0; return RUN_ZERO; }
+    level = lp;
+    return RUN_STUCK;
+}
+
+GB_HD bool token_fast_ok(const Rec& s0, const Req& r, int64_t now) {
+    return r.algorithm == ALGO_TOKEN && rec_kind(s0) == K_TOKEN && !rec_expired(s0, now) &&
+           !(r.behavior & BH_RESET_REMAINING) && s0.limit == r.limit && s0.duration == r.duration && r.hits > 0 &&
+           s0.remaining >= 0;
+}
+GB_HD uint32_t token_fast(const Rec& s0, const Req& r, uint64_t k, Resp& out, Rec& after) {
+    uint64_t level;
+    const bool drain = (r.behavior & BH_DRAIN_OVER_LIMIT) != 0;
+    const uint32_t kind = run_position((uint64_t)s0.remaining, (uint64_t)r.hits, k, drain, level);
+    uint32_t ev = EV_HIT | (r.is_owner ? EV_ONCHANGE : 0u);
+    after = s0;
+    out.err = 0; out.limit = r.limit; out.reset_time = s0.expire_at; out.status = (uint8_t)rec_status(s0);
+    if (kind == RUN_PLAIN) { after.remaining = (int64_t)level - r.hits; out.remaining = after.remaining; }
+    else if (kind == RUN_EXACT) { after.remaining = 0; out.remaining = 0; }
+    else if (kind == RUN_ZERO) {
+        after.remaining = 0; out.remaining = 0; out.status = ST_OVER; rec_set_status(after, ST_OVER);
+        if (r.is_owner) ev |= EV_OVER;
+    } else {                                                                  // RUN_SHORT / RUN_STUCK
+        out.status = ST_OVER;
+        if (r.is_owner) ev |= EV_OVER;
+        after.remaining = drain ? 0 : (int64_t)level; out.remaining = after.remaining;
+    }
+    return ev;
+}
+
+// false = not a case for the closed form (the caller uses eval_uniform_rank)
+GB_HD bool leaky_fast(const Rec& s0, const Req& r, int64_t now, uint64_t k, Resp& out, Rec& after, uint32_t& ev_out) {
+    if (r.algorithm != ALGO_LEAKY || rec_kind(s0) != K_LEAKY || rec_expired(s0, now)) return false;
+    if ((r.behavior & (BH_RESET_REMAINING | BH_GREGORIAN)) || r.hits <= 0) return false;
+    const int64_t burst = r.burst == 0 ? r.limit : r.burst;
+    if (s0.burst != burst) return false;
+    if (wadd(r.created_at, r.duration) < now) return false;   // UpdateExpiration (:356-358) would expire the bucket for the next request of the run
+    // what every request of the run does before it looks at the level (algorithms.go:332-378); only the first one
+    // can leak — it moves UpdatedAt to created_at, and one that does not leak leaves the same elapsed time behind
+    double rem = bits2f(s0.remaining);
+    const double rate = (double)r.duration / (double)r.limit;
+    const double leak = (double)wsub(r.created_at, s0.stamp) / rate;
+    const bool leaked = go_f2i(leak) > 0;
+    if (leaked) rem = rem + leak;
+    if (go_f2i(rem) > burst) rem = (double)burst;
+    if (!(rem >= 0.0 && rem < 9007199254740992.0)) return false;
+    const int64_t irate = go_f2i(rate);
+    const uint64_t I0 = (uint64_t)go_f2i(rem), h = (uint64_t)r.hits;
+    uint64_t level;
+    const bool drain = (r.behavior & BH_DRAIN_OVER_LIMIT) != 0;
+    const uint32_t kind = run_position(I0, h, k, drain, level);
+    uint32_t ev = EV_HIT | (r.is_owner ? EV_ONCHANGE : 0u);
+    double rem_a;
+    out.err = 0; out.limit = r.limit; out.status = ST_UNDER;
+    if (kind == RUN_PLAIN) {
+        rem_a = rem - (double)(I0 - level + h);           // (k + 1) * h, exact: an integer below 2^53 off a double below 2^53
+        out.remaining = (int64_t)(level - h);
+    } else if (kind == RUN_EXACT) {
+        rem_a = 0.0; out.remaining = 0;
+    } else if (kind == RUN_ZERO) {
+        rem_a = I0 == 0 ? rem : 0.0; out.remaining = 0; out.status = ST_OVER;
+        if (r.is_owner) ev |= EV_OVER;
+    } else {
+        out.status = ST_OVER;
+        if (r.is_owner) ev |= EV_OVER;
+        out.remaining = (int64_t)level;
+        rem_a = drain ? 0.0 : rem - (double)(I0 - level);
+    }
+    out.reset_time = wadd(r.created_at, wmul(wsub(r.limit, out.remaining), irate));
+    if ((kind == RUN_SHORT || kind == RUN_STUCK) && drain) out.remaining = 0;   // :417-420: ResetTime is not recomputed
+    after = s0;
+    after.limit = r.limit; after.duration = r.duration; after.remaining = f2bits(rem_a);
+    if (leaked) after.stamp = r.created_at;
+    after.expire_at = wadd(r.created_at, r.duration);
+    ev_out = ev;
+    return true;
+}
+
+// Response of the request of rank `rank` in a run of identical requests: closed form where it applies,
+// apply() / skip() otherwise.  `generic` is the slow path (the kernels pass an out-of-line function so that the
+// common case keeps a small register footprint).
+template <typename Generic>
+GB_HD uint32_t eval_rank(const Rec& s0, const Req& r, int64_t now, uint64_t rank, Resp& out, Rec& after, Generic generic) {
+    if (token_fast_ok(s0, r, now)) return token_fast(s0, r, rank, out, after);
+    uint32_t ev;
+    if (leaky_fast(s0, r, now, rank, out, after, ev)) return ev;
+    return generic(s0, r, now, rank, out, after);
+}
+
 // ---- hashes on the path ----------------------------------------------------------------------
 // XXH64 (published xxHash spec); the reference hashes the key with it to pick a worker shard
 // (workers.go:153-155, OneOfOne/xxhash v1.2.8); here it addresses the HBM bucket directory.

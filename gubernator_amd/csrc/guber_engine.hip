@@ -80,7 +80,7 @@ struct guber_engine {
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
     PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
     // tile-bitmap grouping path (batches <= 65536)
-    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_lrank; DevBuf<uint32_t> w_tilerow;
+    DevBuf<unsigned long long> w_tilemask; DevBuf<uint32_t> w_flags2; DevBuf<uint16_t> w_tilerow;
     DevBuf<uint32_t> w_did2;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
@@ -192,7 +192,6 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_flags2.ensure((size_t)2 * e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
-    rc |= e->w_lrank.ensure(e->fast_cap);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
@@ -235,10 +234,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.hist = e->w_hist.p;
     e->W.tiles = tiles; e->W.epoch = 0;
     e->W.seg_tilemask = e->w_tilemask.p; e->W.seg_flags2 = e->w_flags2.p; e->W.tilerow = e->w_tilerow.p;
-    e->W.lrank = e->w_lrank.p;
 
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
-    e->W.claims = (cfg->flags & GUBER_FLAG_DIR_CLAIMS) ? nullptr : e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
+    e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -273,7 +271,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_flags2.release(); e->w_tilerow.release();
-    e->w_lrank.release(); e->w_did2.release();
+    e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -331,7 +329,7 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
         e->span_begin(KT_EVAL2);
-        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, B2, R, W);
+        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, B2, R, W});
         e->span_end();
         HIPCHK(hipGetLastError());
 #ifdef GUBER_PHASE_TIMING

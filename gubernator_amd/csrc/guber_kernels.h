@@ -79,67 +79,69 @@ __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, ui
     return true;
 }
 
-// claim the segment id of a directory entry for this batch; m = last known meta value
-__device__ __forceinline__ uint32_t claim_segment(unsigned long long* mp, unsigned long long m, uint32_t epoch, uint32_t g,
-                                                 bool& claimed) {
+// claim the segment id of one key for this batch in the claims table (see Work::claims).  Insert-only open addressing:
+// cells of older epochs count as empty; everybody scans from the same home cell in the same order, so a key is
+// inserted at most once and later arrivers find it.  Cell = epoch16 << 48 | fp32 << 16 | request index of the first
+// toucher.  The table is keyed by the 64-bit KEY HASH (home cell from bits 40.., fingerprint = low 32 bits), so the claim
+// does not depend on the directory lookup and runs concurrently with it; two keys that agree in home-cell chain and
+// fingerprint fall into one segment and are told apart by the exact key comparison against the claimer's request
+// (SEG_RETRY -> careful round).  The careful round keys the same table by the verified bucket slot (fp32 = slot,
+// exact).
+__device__ __forceinline__ uint32_t claim_home_slot(uint32_t slot, uint32_t cmask) { return ((slot * 0x9E3779B1u) >> 11) & cmask; }
+__device__ __forceinline__ uint32_t claim_home_hash(uint64_t h, uint32_t cmask) { return (uint32_t)(h >> 40) & cmask; }
+// `cur` = the value of the home cell as the caller saw it (a fresh, L1-bypassing look: for a hot key all but the first
+// workgroup find the cell taken and issue no CAS at all — CAS-ing on a stale early look was measured and lost, failed
+// CASes on exactly the hot cells; profiles/r01_claims_ab.txt)
+__device__ __forceinline__ uint32_t claim_key(unsigned long long* claims, uint32_t cmask, uint32_t hcell, unsigned long long cur,
+                                              uint32_t fp, uint32_t e16, uint32_t g, bool& claimed) {
+    const unsigned long long want = ((unsigned long long)e16 << 48) | ((unsigned long long)fp << 16) | g;
     for (;;) {
-        if ((uint32_t)((m >> 32) & 0x7fffffffu) == epoch) return (uint32_t)m;
-        const unsigned long long want = (m & META_READY) | ((unsigned long long)epoch << 32) | g;
-        const unsigned long long old = atomicCAS(mp, m, want);
-        if (old == m) { claimed = true; return g; }
-        m = old;
-    }
-}
-
-// claim the segment id of bucket `slot` for this batch in the claims table (see Work::claims).  Insert-only open
-// addressing: cells of older epochs count as empty; everybody scans from the same home cell in the same order, so a
-// slot is inserted at most once and later arrivers find it.
-__device__ __forceinline__ uint32_t claim_cell(uint32_t slot, uint32_t cmask) { return ((slot * 0x9E3779B1u) >> 11) & cmask; }
-__device__ __forceinline__ uint32_t claim_slot(unsigned long long* claims, uint32_t cmask, uint32_t slot, uint32_t e16,
-                                               uint32_t g, bool& claimed) {
-    uint32_t h = claim_cell(slot, cmask);
-    const unsigned long long want = ((unsigned long long)e16 << 48) | ((unsigned long long)slot << 16) | g;
-    for (;;) {
-        // a fresh (L1-bypassing) look first: for a hot key all but the first workgroup find the cell taken and issue no
-        // CAS at all — requesting the cell early with the directory entry and CAS-ing on that value was measured and lost
-        // (failed CASes on the hot cells; profiles/r01_claims_ab.txt)
-        unsigned long long cur = ld_agent(&claims[h]);
         for (;;) {
             if ((uint32_t)(cur >> 48) == e16) {
-                if ((uint32_t)(cur >> 16) == slot) return (uint32_t)(cur & 0xffffull);
-                break;                                          // another bucket's cell: next
+                if ((uint32_t)(cur >> 16) == fp) return (uint32_t)(cur & 0xffffull);
+                break;                                          // another key's cell: next
             }
-            const unsigned long long old = atomicCAS(&claims[h], cur, want);
+            const unsigned long long old = atomicCAS(&claims[hcell], cur, want);
             if (old == cur) { claimed = true; return g; }
             cur = old;                                          // lost the race for this cell: look at the winner
         }
-        h = (h + 1) & cmask;
+        hcell = (hcell + 1) & cmask;
+        cur = ld_agent(&claims[hcell]);
     }
 }
 
+// per-request word handed from k_front to k_eval2: segment id | thread of the (segment, tile) group's head | rank in group
+__device__ __forceinline__ uint32_t pack_dl(uint32_t d, uint32_t head_tid, uint32_t rank) { return (d << 16) | (head_tid << 8) | rank; }
+
 __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
-    __shared__ uint32_t skey[FT];       // stage 2: candidate slot per thread; phase B: segment id per thread
-    __shared__ uint32_t sd[FT];         // stage 2: segment id obtained by each leader
-    __shared__ uint32_t ltab[2 * FT];   // stage 2: slot-hash -> some thread holding that slot
-    __shared__ int red[FT / 64];
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
-    __shared__ uint32_t gkey[GT];
-    __shared__ unsigned long long gbits[FT / 64][GT];
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x;
+    __shared__ unsigned long long gkey[GT];                       // grouping key (0 = free)
+    __shared__ unsigned long long gbits[FT / 64][GT];             // per wave: lanes holding the entry's key
+    __shared__ uint32_t sd[FT];                                   // head -> segment id
+    __shared__ uint32_t sslot[FT];                                // head -> bucket slot (for the rare member that needs the bucket)
+    __shared__ int red[FT / 64];
+    __shared__ uint32_t soft_any;
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
 
     GB_STAMP(0);
-    // ---- phase A, stage 1: find (or insert) the directory entry; start fetching its bucket -----------
-    uint32_t d = 0xffffffffu, slot = 0, errcode = 0, len = 0;
+    if (tid == 0) soft_any = 0u;
+    for (uint32_t j = tid; j < GT; j += FT) {
+        gkey[j] = 0ull;
+#pragma unroll
+        for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
+    }
+    // ---- stage 0: key -> hash.  Grouping key gk: the 64-bit hash; in a careful (retry) round the verified slot ----
+    uint32_t errcode = 0, len = 0, slot = 0;
     int inserted = 0;
-    bool fresh = false, claimed = false, cand = false, ready = false;
+    bool cand = false, ready = false;
     const uint8_t* key = nullptr;
+    unsigned long long gk = 0ull;
+    uint64_t h = 0;
     Rec rec; rec_clear(rec);
-    uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
-    unsigned long long meta0 = 0ull;
     if (valid) {
         const uint32_t off = B.key_off[g];
         len = B.key_off[g + 1] - off;
@@ -147,88 +149,146 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
         GB_STAMPW(6);
-        if (!errcode && W.careful) {
-            // retry round: verify the stored key BEFORE claiming (no speculation, no dedup)
-            uint32_t cslot = 0;
-            const uint32_t pr = probe(T, key, len, xxhash64(key, len, 0), true, cslot);
-            slot = cslot;
-            inserted = (pr & PR_INSERTED) ? 1 : 0;
-            if (pr & PR_FULL) errcode = 6;
-            else {
-                fresh = (pr & (PR_INSERTED | PR_NEED_VERIFY)) != 0;
-                bool cl = false;
-                if (W.claims) d = claim_slot(W.claims, W.cmask, cslot, W.epoch16, g, cl);
-                else { unsigned long long* mp = &T.dir[cslot].meta; d = claim_segment(mp, ld_agent(mp), W.epoch, g, cl); }
-                claimed = cl;
-                rec = T.buckets[cslot].rec;
-            }
-        } else if (!errcode) {
-            const uint64_t h = xxhash64(key, len, 0) & T.hash_mask;
-            const unsigned long long tag = h ? h : 1ull;
-            uint64_t pos = (h >> 7) & T.mask;
-            GB_STAMPW(7);
-            // speculation: the key's bucket is at its home position for most resident keys (load <= 0.5), so the
-            // home bucket is requested together with the home directory entry — one round trip instead of two.
-            // Plain loads: L1 may serve a line that is stale within this launch, which is safe here — a stale
-            // "empty" tag is corrected by the insert CAS, a stale meta by the claim CAS (only one leader per
-            // workgroup and key claims), READY never changes during k_front — and it keeps the thousands of
-            // re-reads of a hot key's entry out of L2 / the memory-side atomics' way.
-            const uint32_t home = (uint32_t)pos;
-            const ulonglong2 de0 = *(const ulonglong2*)&T.dir[home];
-            {
-                const Bucket* hb = &T.buckets[home];
-                const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
-                rec = hb->rec;
-            }
-            for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
-                ulonglong2 de = de0;
-                if (step) de = *(const ulonglong2*)&T.dir[pos];
-                unsigned long long t = de.x, m = de.y;
-                if (t == 0ull) {
-                    const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
-                    if (old == 0ull) {                               // new key: this thread inserts it
-                        slot = (uint32_t)pos; inserted = 1; fresh = true; cand = true;
-                        if (!key_store(T, pos, key, len)) { errcode = 6; cand = false; }
-                        break;
-                    }
-                    t = old;
-                    m = ld_agent(&T.dir[pos].meta);
-                }
-                if (t == tag) { slot = (uint32_t)pos; cand = true; meta0 = m; ready = (m & META_READY) != 0; fresh = !ready; break; }
-            }
-            if (!cand && !errcode) errcode = 6;                      // probe bound exceeded: table full
-            if (cand && slot != home) {
-                const Bucket* bk = &T.buckets[slot];
-                if (ready) { const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3]; }
-                rec = bk->rec;                                       // (zero for a bucket never used)
+        if (!errcode) {
+            h = xxhash64(key, len, 0) & T.hash_mask;
+            if (W.careful) {
+                // retry round: every request finds its bucket with a full, verifying probe BEFORE anything is claimed
+                uint32_t cslot = 0;
+                const uint32_t pr = probe(T, key, len, h, true, cslot);
+                slot = cslot;
+                inserted = (pr & PR_INSERTED) ? 1 : 0;
+                if (pr & PR_FULL) errcode = 6;
+                else { cand = true; rec = T.buckets[cslot].rec; gk = 0x8000000000000000ull | cslot; }
+            } else {
+                gk = h ? h : 1ull;
             }
         }
+        GB_STAMPW(7);
     }
-    // ---- stage 2: one claim per (workgroup, slot).  Threads holding the same slot elect a leader
-    // through an LDS table; only leaders touch the entry's meta word (atomics on one address serialise
-    // at ~12 ns each, and a hot key shows up thousands of times in a batch).
+    lds_barrier();
+    // ---- stage 1: group the tile by gk through an LDS hash table with per-wave member bitmaps: a request's rank
+    // inside its (key, tile) group, the group size and the group's first thread come from four popcounts ----
+    uint32_t gh = 0;
+    if (gk) {
+        gh = (uint32_t)((gk * 0x9E3779B97F4A7C15ull) >> (64 - GT_BITS));
+        for (;;) {
+            const unsigned long long old = atomicCAS(&gkey[gh], 0ull, gk);
+            if (old == 0ull || old == gk) break;
+            gh = (gh + 1) & (GT - 1);
+        }
+        atomicOr(&gbits[wave][gh], 1ull << lane);
+    }
+    lds_barrier();
+    uint32_t eq_before = 0, eq_total = 1, head_tid = tid;
+    if (gk) {
+        bool found_head = false;
+        eq_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < FT / 64; ++w) {
+            const unsigned long long bw = gbits[w][gh];
+            const uint32_t c = __popcll(bw);
+            eq_total += c;
+            if (w < wave) eq_before += c;
+            else if (w == wave) eq_before += __popcll(bw & ((1ull << lane) - 1ull));
+            if (!found_head && bw) { head_tid = w * 64 + (uint32_t)__ffsll((unsigned long long)bw) - 1; found_head = true; }
+        }
+    }
+    const bool head = valid && eq_before == 0;
+    const bool khead = head && gk != 0ull;                           // heads that have a key to resolve
     GB_STAMP(1);
-    const bool fast = cand && !W.careful;
-    const uint32_t hidx = (slot * 0x9E3779B1u) >> 23;                // 9 bits
-    skey[tid] = fast ? slot : 0xffffffffu;
-    if (fast) ltab[hidx] = tid;
-    lds_barrier();
-    uint32_t lead = tid;
-    if (fast) { const uint32_t l = ltab[hidx]; if (skey[l] == slot) lead = l; }
-    if (fast && lead == tid) {
-        d = W.claims ? claim_slot(W.claims, W.cmask, slot, W.epoch16, g, claimed)
-                     : claim_segment(&T.dir[slot].meta, meta0, W.epoch, g, claimed);   // GUBER_FLAG_DIR_CLAIMS
-        sd[tid] = d;
+
+    // ---- stage 2 (heads): look at the claim cell, start the directory + bucket fetch, claim ----------------------
+    // The look is issued first so that it can be consumed while the table loads are still in flight; the home bucket is
+    // requested together with the home directory entry (most resident keys sit at their home position at load <= 0.5).
+    // Plain table loads: L1 may serve a line that is stale within this launch, which is safe — a stale "empty" tag is
+    // corrected by the insert CAS, and READY never changes during k_front.
+    const uint32_t e16 = W.epoch16;
+    uint32_t hcell = 0, fp = 0;
+    unsigned long long look = 0ull;
+    uint64_t pos = (h >> 7) & T.mask;
+    ulonglong2 de0 = {0ull, 0ull};
+    uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    if (khead) {
+        if (W.careful) { hcell = claim_home_slot(slot, W.cmask); fp = slot; }
+        else { hcell = claim_home_hash(h, W.cmask); fp = (uint32_t)h; }
+        look = ld_agent(&W.claims[hcell]);
+        if (!W.careful) {
+            de0 = *(const ulonglong2*)&T.dir[pos];
+            const Bucket* hb = &T.buckets[pos];
+            const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
+            rec = hb->rec;
+        }
+    }
+    uint32_t d = g;                                                  // error requests: a solo segment that only carries the code
+    bool claimed = false;
+    if (khead) d = claim_key(W.claims, W.cmask, hcell, look, fp, e16, g, claimed);
+    if (head) sd[tid] = d;
+    // group heads publish their group: ONE atomic per (segment, tile) — set the tile's bit and add the group size (bits are
+    // set once each, so the add never carries into the count).  Its return value tells whether other tiles of this 32-tile
+    // word already hold the key — only then are per-tile counts needed (k_eval2 ranks a request by the members in earlier
+    // tiles), so the scattered count is written only for keys spanning several tiles: every arriver but the first writes
+    // its own, and the second also writes the first's (= the word's count so far, the first having been alone).
+    if (khead) {
+        const unsigned long long old = atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)],
+                                                 ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
+        const uint32_t ob = (uint32_t)old;
+        if (ob) {
+            uint16_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
+            row[tile] = (uint16_t)eq_total;
+            if ((ob & (ob - 1u)) == 0u) row[(tile & ~31u) + (uint32_t)__ffs((int)ob) - 1u] = (uint16_t)(old >> 32);
+        }
     }
     lds_barrier();
-    if (fast && lead != tid) d = sd[lead];
-    lds_barrier();
+    if (valid && !head) d = sd[head_tid];
     GB_STAMP(2);
 
-    // ---- stage 3: verify, flag, snapshot -----------------------------------------------------------
-    if (valid) {
-        uint8_t rf = 0;
-        if (!errcode && fast && ready) {
+    // ---- stage 3: one key, one request shape per segment.  Members are compared with their tile's head, heads with the
+    // segment's claimer (equality is transitive), on the exact key bytes and on every request field ----------------
+    const uint32_t ref = head ? d : tile * FT + head_tid;
+    uint32_t my_flags = 0;                                           // SEG_* bits this request raises on its segment
+    bool soft_leaky = false;
+    Req a;
+    if (valid && gk && ref != g) {
+        if (!req_key_equal(B, g, ref)) my_flags |= SEG_RETRY;        // two keys under one hash / fingerprint: careful round
+        a = load_req(B, g);
+        const Req b = load_req(B, ref);
+        if (!req_eq(a, b)) {
+            // created_at-only differences keep the parallel path when created_at cannot matter: decided in k_eval2 for
+            // token buckets; a leaky request must leak nothing (checked below against the bucket as it is before the
+            // batch; the claimer's own created_at is checked in k_eval2)
+            if (!req_eq_but_created(a, b)) my_flags |= SEG_NONUNIFORM;
+            else if (a.algorithm == ALGO_LEAKY) soft_leaky = true;
+            else my_flags |= SEG_CREATED_DIFFERS;
+        }
+    }
+
+    // ---- stage 4 (heads): finish the directory probe, verify the stored key, snapshot ------------------------------
+    if (khead && !W.careful) {
+        const unsigned long long tag = gk;
+        const uint32_t home = (uint32_t)pos;
+        for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
+            ulonglong2 de = de0;
+            if (step) de = *(const ulonglong2*)&T.dir[pos];
+            unsigned long long t = de.x, m = de.y;
+            if (t == 0ull) {
+                const unsigned long long old = atomicCAS(&T.dir[pos].tag, 0ull, tag);
+                if (old == 0ull) {                                   // new key: this thread inserts it
+                    slot = (uint32_t)pos; inserted = 1; cand = true;
+                    if (!key_store(T, pos, key, len)) { errcode = 6; cand = false; }
+                    break;
+                }
+                t = old;
+                m = ld_agent(&T.dir[pos].meta);
+            }
+            if (t == tag) { slot = (uint32_t)pos; cand = true; ready = (m & META_READY) != 0; break; }
+        }
+        if (!cand && !errcode) errcode = 6;                          // probe bound exceeded: table full
+        if (cand && slot != home) {
+            const Bucket* bk = &T.buckets[slot];
+            if (ready) { const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3]; }
+            rec = bk->rec;                                           // (zero for a bucket never used)
+        }
+        if (cand && ready) {
             const uint64_t cell[8] = {((uint64_t)c0.y << 32) | c0.x, ((uint64_t)c0.w << 32) | c0.z,
                                       ((uint64_t)c1.y << 32) | c1.x, ((uint64_t)c1.w << 32) | c1.z,
                                       ((uint64_t)c2.y << 32) | c2.x, ((uint64_t)c2.w << 32) | c2.z,
@@ -250,106 +310,48 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                     eq = key_equal(T, slot, key, len);
                 }
             }
-            // the claim was issued before this comparison (speculation).  A mismatch = a 64-bit hash
-            // collision with a resident key: I joined a foreign segment, so everybody in it is answered
-            // RETRY and re-run in careful mode.
-            if (!eq) atomicOr(&seg_flags[d], SEG_RETRY);
+            // the claim was issued before this comparison.  A mismatch = a 64-bit hash collision with a resident key:
+            // the whole segment is answered RETRY and re-run in careful mode (verify first, claim by slot).
+            if (!eq) my_flags |= SEG_RETRY;
         }
-        if (errcode) {
-            d = g;
-            atomicOr(&seg_flags[d], SEG_ERR | (errcode << 8));
-            rf = RF_ERR | (inserted ? RF_INSERTED : 0);
-        } else {
-            if (inserted) rf |= RF_INSERTED;
-            if (claimed) {
-                rec.pad = slot;                                // the segment's slot rides in the snapshot's spare word
-                W.snap[d] = rec;                               // claimer snapshots the bucket
-            } else {
-                // entry created during this launch: prove key equality against the claimer's request
-                if (fresh && !req_key_equal(B, g, d)) atomicOr(&seg_flags[d], SEG_RETRY);
-                const Req a = load_req(B, g), b = load_req(B, d);
-                if (!req_eq(a, b)) {
-                    // created_at-only differences keep the parallel path when created_at cannot matter: decided in
-                    // k_eval2 for token buckets; a leaky request must leak nothing (checked here against the bucket
-                    // as it is before the batch; the claimer's own created_at is checked in k_eval2)
-                    bool soft = req_eq_but_created(a, b);
-                    if (soft && a.algorithm == ALGO_LEAKY) soft = leaky_created_harmless(rec, a, B.now_ms);
-                    atomicOr(&seg_flags[d], soft ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM);
-                }
-            }
-        }
-        W.did[g] = d; W.rflags[g] = rf;
-        if (inserted) W.slot[g] = slot;
+        // an entry that is not READY was inserted during this launch; its key bytes may still be in flight, but every
+        // head — the inserter included — has compared its key with the claimer's request, so the key that ends up
+        // stored is provably the segment's key.
     }
+    if (khead) sslot[tid] = slot;
+    if (soft_leaky) soft_any = 1u;
+    uint8_t rf = 0;
+    if (valid) {
+        if (errcode) { my_flags |= SEG_ERR | (errcode << 8); rf = RF_ERR; }
+        if (inserted) { rf |= RF_INSERTED; W.slot[g] = slot; }
+        if (claimed && !errcode) { W.seg_slot[d] = slot; W.snap[d] = rec; }   // the claimer snapshots the bucket
+        W.did[g] = pack_dl(d, head_tid, eq_before);
+        W.rflags[g] = rf;
+    }
+    lds_barrier();
+    if (soft_any) {                                                  // rare: requests of a leaky key stamped differently
+        if (soft_leaky) {
+            Rec cur = rec;
+            if (!head) cur = T.buckets[sslot[head_tid]].rec;
+            my_flags |= leaky_created_harmless(cur, a, B.now_ms) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM;
+        }
+    }
+    if (my_flags) atomicOr(&seg_flags[d], my_flags);
     const int ins = block_sum_lds(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
     GB_STAMP(3);
-
-    // ---- phase B: group the tile's FT segment ids through an LDS hash table ------------------------
-    // Every distinct id gets one table entry (open addressing, CAS on the key); each wave ORs its lane
-    // into the entry's per-wave 64-bit member bitmap.  A request's rank inside its (segment, tile) group,
-    // the group size and the group's first thread then come from four popcounts — O(1) per request
-    // instead of comparing against all 256 ids.
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    for (uint32_t j = tid; j < GT; j += FT) {
-        gkey[j] = 0xffffffffu;
-#pragma unroll
-        for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
-    }
-    lds_barrier();
-    uint32_t gh = 0;
-    if (valid) {
-        gh = (d * 0x9E3779B1u) >> (32 - GT_BITS);
-        for (;;) {
-            const uint32_t old = atomicCAS(&gkey[gh], 0xffffffffu, d);
-            if (old == 0xffffffffu || old == d) break;
-            gh = (gh + 1) & (GT - 1);
-        }
-        atomicOr(&gbits[wave][gh], 1ull << lane);
-    }
-    lds_barrier();
-    uint32_t eq_before = 0, eq_total = 0, head_tid = tid;
-    if (valid) {
-        bool found_head = false;
-#pragma unroll
-        for (uint32_t w = 0; w < FT / 64; ++w) {
-            const unsigned long long bw = gbits[w][gh];
-            const uint32_t c = __popcll(bw);
-            eq_total += c;
-            if (w < wave) eq_before += c;
-            else if (w == wave) eq_before += __popcll(bw & ((1ull << lane) - 1ull));
-            if (!found_head && bw) { head_tid = w * 64 + (uint32_t)__ffsll((unsigned long long)bw) - 1; found_head = true; }
-        }
-    }
     GB_STAMP(4);
-    // ---- phase C: publish groups -------------------------------------------------------------------
-    if (valid) {
-        W.lrank[g] = (uint16_t)(eq_before | (head_tid << 8));   // rank in group | tid of the group's head
-        if (eq_before == 0) {
-            // ONE atomic per (segment, tile) group: set the tile's bit and add the group size (bits are set once
-            // each, so the add never carries into the count).  Its return value tells whether other tiles of this
-            // 32-tile word already hold the key — only then are per-tile counts needed (k_eval2 ranks a request by
-            // the members in earlier tiles), so the scattered count is written only for keys spanning several tiles:
-            // every arriver but the first writes its own, and the second also writes the first's (= the word's
-            // count so far, the first having been alone).
-            const unsigned long long old = atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)],
-                                                     ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
-            const uint32_t ob = (uint32_t)old;
-            if (ob) {
-                uint32_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
-                row[tile] = eq_total;
-                if ((ob & (ob - 1u)) == 0u) row[(tile & ~31u) + (uint32_t)__ffs((int)ob) - 1u] = (uint32_t)(old >> 32);
-            }
-        }
-    }
     GB_STAMP(5);
 }
 
-#ifndef GUBER_EVAL2_BLOCKS
-#define GUBER_EVAL2_BLOCKS 1
+struct EvalArgs { Table T; BatchView B; ResultView R; Work W; };
+
+#ifndef GUBER_EVAL2_WAVES
+#define GUBER_EVAL2_WAVES 4      // waves per SIMD the register allocation must allow (<= 128 VGPRs): 4 co-resident workgroups per CU
 #endif
-__global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, BatchView B, ResultView R, Work W) {
-    __shared__ int red[4];
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
+    const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
+    __shared__ unsigned long long cnt[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
         uint4* om = (uint4*)(W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS);
         const uint4 z = {0, 0, 0, 0};
         for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
-            if (W.did_prev[j] == j) {
+            if ((W.did_prev[j] >> 16) == (j & 0xffffu)) {
                 of[j] = 0;
 #pragma unroll
                 for (int q = 0; q < FT_WORDS / 2; ++q) om[(size_t)j * (FT_WORDS / 2) + q] = z;
@@ -371,12 +373,12 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
     // other members pick both up from LDS (eval workgroup == tile, FT == 256).
     __shared__ uint32_t sbase[FT], stotal[FT];
     const bool live = i < B.n;
-    const uint32_t lr = live ? W.lrank[i] : 0u;
-    const uint32_t d = live ? W.did[i] : 0u;
+    const uint32_t dl = live ? W.did[i] : 0u;
+    const uint32_t d = dl >> 16, lr = dl & 0xffffu;
     // everything that depends only on (i, d) is requested now, so that these loads are in flight together
     // with the heads' bitmap loads below instead of after the barrier
-    uint32_t sf = 0; uint8_t rf = 0; Req r; Rec s0;
-    if (live) { sf = seg_flags[d]; rf = W.rflags[i]; r = load_req(B, i); s0 = W.snap[d]; }
+    uint32_t sf = 0, slot = 0; uint8_t rf = 0; Req r; Rec s0;
+    if (live) { sf = seg_flags[d]; rf = W.rflags[i]; slot = W.seg_slot[d]; r = load_req_nogreg(B, i); s0 = W.snap[d]; }
     if (live && (lr & 0xffu) == 0u) {
         const uint32_t t = i / FT;
         const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip
@@ -396,20 +398,24 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
             if (w == mw) below = (uint32_t)sw[w] & ((1u << mb) - 1u);
         }
         if (below) {
-            // members in earlier tiles of my own 32-tile word: their per-tile counts, 64 bytes, masked by the bitmap
+            // members in earlier tiles of my own 32-tile word: their per-tile counts (u16, 64 bytes), masked by the bitmap
             const uint4* r4 = (const uint4*)(W.tilerow + (size_t)d * FT_MAX_TILES + mw * 32);
-            uint4 v[8];
+            uint4 v[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = r4[q];
+            for (int q = 0; q < 4; ++q) v[q] = r4[q];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) base += ((below >> (q * 4 + e)) & 1u) ? (w4[e] & 0xffffu) : 0u;
+                for (int e = 0; e < 4; ++e) {
+                    base += ((below >> (q * 8 + e * 2)) & 1u) ? (w4[e] & 0xffffu) : 0u;
+                    base += ((below >> (q * 8 + e * 2 + 1)) & 1u) ? (w4[e] >> 16) : 0u;
+                }
             }
         }
         sbase[threadIdx.x] = base; stotal[threadIdx.x] = total;
     }
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
     GB_STAMP2(1);
     lds_barrier();
     GB_STAMP2(2);
@@ -424,8 +430,6 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
         } else {
             const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
-            const uint32_t slot = s0.pad;
-            s0.pad = 0;
             // requests differing only in created_at still take the parallel path when created_at cannot matter: live
             // token bucket (never read), or live leaky bucket where no request of the run leaks (the other members
             // were checked in k_front; the claimer's created_at is checked here, identically by every member)
@@ -440,57 +444,112 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_BLOCKS) void k_eval2(Table T, Batc
                     parallel = created_at_irrelevant(s0, r, B.now_ms);
                 }
             }
+            // The requests real traffic consists of — a live bucket, a request that does not reconfigure it — are answered by
+            // the closed forms of guber_algo.h (a few dozen instructions).  Everything else goes through ONE inlined
+            // apply() site that serves both the rank-stepping of a uniform run (eval_uniform_rank_1x) and the serial walk
+            // of a heterogeneous segment, so the kernel carries the general state machine once, not four times.
+            Rec after; Resp out;
+            uint32_t ev = 0;
+            bool done = false;
             if (parallel) {
-                Rec after; Resp out;
-                const uint32_t ev = eval_uniform_rank(s0, r, B.now_ms, rank, out, after);
-                store_resp(R, i, out);
-                store_events(W, i, ev, after);
-                c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
-                if (rank == total - 1) {
-                    T.buckets[slot].rec = after;
-                    c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
-                    if (out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
+                if (token_fast_ok(s0, r, B.now_ms)) { ev = token_fast(s0, r, rank, out, after); done = true; }
+                else if (leaky_fast(s0, r, B.now_ms, rank, out, after, ev)) done = true;
+            }
+            const bool walk = !parallel && rank == 0;
+            if ((parallel && !done) || walk) {
+                Req cur = r;
+                if (parallel) {                                          // the calendar values are loaded only here
+                    cur.greg_expire = B.greg_expire ? B.greg_expire[i] : 0;
+                    cur.greg_duration = B.greg_duration ? B.greg_duration[i] : 0;
                 }
-            } else if (rank == 0) {
-                // requests to this key differ: apply them one by one in request order — tiles in order (bitmap), and
-                // inside a tile the requests whose segment id is d, found by scanning the tile's 256 ids
-                Rec s = s0;
-                for (int w = 0; w < FT_WORDS; ++w) {
-                    uint32_t mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + w];
-                    while (mm) {
-                        const uint32_t tt = w * 32 + (uint32_t)__ffs((int)mm) - 1;
-                        mm &= mm - 1u;
-                        const uint4* ids = (const uint4*)(W.did + (size_t)tt * FT);
-                        for (uint32_t q4 = 0; q4 < FT / 4 && tt * FT + q4 * 4 < B.n; ++q4) {
-                          const uint4 v = ids[q4];
-                          const uint32_t four[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                          for (uint32_t e4 = 0; e4 < 4; ++e4) {
-                            const uint32_t j = tt * FT + q4 * 4 + e4;
-                            if (four[e4] != d || j >= B.n) continue;
-                            const Req rj = load_req(B, j);
-                            Resp out;
-                            const uint32_t ev = apply(s, rj, B.now_ms, out);
-                            store_resp(R, j, out);
-                            store_events(W, j, ev, s);
-                            if (out.err == 0) queue_global(T, slot, rj, 1);
-                            c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
-                          }
+                after = s0;
+                uint64_t k = rank;
+                Rec prev2; rec_clear(prev2);
+                bool have_prev2 = false;
+                // walk iterator: tiles holding the segment in order (bitmap), inside a tile the packed words whose id is d
+                uint32_t wv = 0, mm = 0, tt = 0, q = FT;
+                for (;;) {
+                    uint32_t j = i;
+                    if (walk) {
+                        bool found = false, end = false;
+                        while (!found && !end) {
+                            if (q < FT && tt * FT + q < B.n) {
+                                const uint32_t id = W.did[(size_t)tt * FT + q];
+                                if ((id >> 16) == d) { j = tt * FT + q; found = true; }
+                                q++;
+                            } else {
+                                while (mm == 0u && wv < FT_WORDS) { mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + wv]; tt = wv * 32; wv++; }
+                                if (mm == 0u) end = true;
+                                else { const uint32_t bpos = (uint32_t)__ffs((int)mm) - 1u; mm &= mm - 1u; tt = (tt & ~31u) + bpos; q = 0; }
+                            }
+                        }
+                        if (end) break;
+                        cur = load_req(B, j);
+                    }
+                    const Rec before = after;
+                    const uint32_t e1 = apply(after, cur, B.now_ms, out);
+                    if (walk) {
+                        store_resp(R, j, out);
+                        store_events(W, j, e1, after);
+                        if (out.err == 0) queue_global(T, slot, cur, 1);
+                        c_over += (e1 & EV_OVER) ? 1 : 0; c_hit += (e1 & EV_HIT) ? 1 : 0; c_miss += (e1 & EV_MISS) ? 1 : 0;
+                        continue;
+                    }
+                    if (k == 0) { ev = e1; break; }
+                    k--;
+                    if (k == 0) continue;
+                    if (rec_eq(after, before)) { k = 0; continue; }                       // fixed point
+                    if (have_prev2 && rec_eq(after, prev2)) {                             // period 2
+                        if (k & 1) after = before;
+                        k = 0;
+                        continue;
+                    }
+                    prev2 = before; have_prev2 = true;
+                    if (pure_subtract(before, after, cur, B.now_ms)) {
+                        const uint32_t kind = rec_kind(after);
+                        const int64_t n = kind == K_TOKEN ? after.remaining : go_f2i(bits2f(after.remaining));
+                        if (n > 0) {
+                            const uint64_t m = (uint64_t)(n - 1) / (uint64_t)cur.hits;
+                            const uint64_t jj = m < k ? m : k;
+                            if (jj > 0) {
+                                const int64_t dec = (int64_t)(jj * (uint64_t)cur.hits);   // <= n-1, exact
+                                if (kind == K_TOKEN) after.remaining -= dec;
+                                else after.remaining = f2bits(bits2f(after.remaining) - (double)dec);
+                                k -= jj;
+                                have_prev2 = false;
+                            }
                         }
                     }
                 }
-                T.buckets[slot].rec = s;
-                c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+            }
+            if (parallel) {
+                store_resp(R, i, out);
+                store_events(W, i, ev, after);
+                c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+            }
+            if ((parallel && rank == total - 1) || walk) {
+                after.pad = W.epoch;                                  // last touch (approximate LRU order for eviction)
+                T.buckets[slot].rec = after;
+                c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
             }
         }
     }
     GB_STAMP2(3);
-    const int t_over = block_sum_lds(c_over, red), t_hit = block_sum_lds(c_hit, red), t_miss = block_sum_lds(c_miss, red),
-              t_size = block_sum_lds(c_size, red);
-    if (threadIdx.x == 0 && (t_over | t_hit | t_miss | t_size)) {
-        BlockCounters* bc = &T.bctr[blockIdx.x];
-        bc->over += (unsigned long long)t_over; bc->hits += (unsigned long long)t_hit;
-        bc->misses += (unsigned long long)t_miss; bc->size_delta += t_size;
+    // event counters of the workgroup: wave-level sums, one LDS atomic per wave and counter, one barrier
+    {
+        const int w_over = wave_sum(c_over), w_hit = wave_sum(c_hit), w_miss = wave_sum(c_miss), w_size = wave_sum(c_size);
+        if ((threadIdx.x & 63) == 0 && (w_over | w_hit | w_miss | w_size)) {
+            if (w_over) atomicAdd(&cnt[0], (unsigned long long)w_over);
+            if (w_hit) atomicAdd(&cnt[1], (unsigned long long)w_hit);
+            if (w_miss) atomicAdd(&cnt[2], (unsigned long long)w_miss);
+            if (w_size) atomicAdd(&cnt[3], (unsigned long long)(long long)w_size);
+        }
+        lds_barrier();
+        if (threadIdx.x == 0 && (cnt[0] | cnt[1] | cnt[2] | cnt[3])) {
+            BlockCounters* bc = &T.bctr[blockIdx.x];
+            bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
+        }
     }
     GB_STAMP2(4);
 }

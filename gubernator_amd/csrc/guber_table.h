@@ -85,15 +85,15 @@ struct Work {
     // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
     uint8_t* store_flags; Rec* store_after;
-    // per-batch segment claims of the two-launch pipeline: an insert-only hash table slot -> first toucher, 2 x fast_cap
-    // cells of (epoch16 << 48 | slot << 16 | request index), small enough to live in L2 / Infinity Cache, so that the
-    // HBM table is not written by k_front at all in steady state (a claim in the directory's meta word would dirty one
-    // directory sector per distinct key and batch).  null = claim in the directory entry instead (GUBER_FLAG_DIR_CLAIMS).
+    // per-batch segment claims of the two-launch pipeline: an insert-only hash table key hash -> first toucher, 4 x fast_cap
+    // cells of (epoch16 << 48 | fingerprint32 << 16 | request index), small enough to live in L2 / Infinity Cache, so that
+    // the HBM table is not written by k_front at all in steady state (a claim in the directory's meta word would dirty
+    // one directory sector per distinct key and batch) and the claim does not wait for the directory lookup.
     unsigned long long* claims; uint32_t cmask; uint32_t epoch16;
 #ifdef GUBER_PHASE_TIMING
     unsigned long long* dbg;
 #endif
-    uint32_t *slot, *did; uint8_t* rflags;
+    uint32_t *slot, *did; uint8_t* rflags;   // two-launch pipeline: did[g] = segment id << 16 | head thread << 8 | rank in (segment, tile) group
     uint32_t *keyA, *valA, *keyB, *valB;
     uint32_t *pos, *order, *sdid;
     uint32_t *seg_first, *seg_last, *seg_flags, *seg_rep, *seg_slot;
@@ -108,8 +108,7 @@ struct Work {
     unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
     uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
     uint32_t* seg_flags2;               // [2][cap]
-    uint32_t* tilerow;                  // [cap][FT_MAX_TILES]: members per (segment, tile) — written only for keys that span several tiles of a word
-    uint16_t* lrank;                    // [max_batch] rank of a request inside its (segment, tile) group
+    uint16_t* tilerow;                  // [cap][FT_MAX_TILES]: members per (segment, tile) — written only for keys that span several tiles of a word
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
@@ -133,6 +132,18 @@ __device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
     r.created_at = B.created_at ? B.created_at[i] : B.now_ms;
     r.greg_expire = B.greg_expire ? B.greg_expire[i] : 0;
     r.greg_duration = B.greg_duration ? B.greg_duration[i] : 0;
+    r.behavior = B.behavior ? B.behavior[i] : 0;
+    r.algorithm = B.algorithm ? B.algorithm[i] : 0;
+    r.is_owner = B.is_owner ? B.is_owner[i] : 1;
+    return r;
+}
+// the request without the calendar values (only the general path reads them: the closed forms decline GREGORIAN requests)
+__device__ __forceinline__ Req load_req_nogreg(const BatchView& B, uint32_t i) {
+    Req r;
+    r.hits = B.hits[i]; r.limit = B.limit[i]; r.duration = B.duration[i];
+    r.burst = B.burst ? B.burst[i] : 0;
+    r.created_at = B.created_at ? B.created_at[i] : B.now_ms;
+    r.greg_expire = 0; r.greg_duration = 0;
     r.behavior = B.behavior ? B.behavior[i] : 0;
     r.algorithm = B.algorithm ? B.algorithm[i] : 0;
     r.is_owner = B.is_owner ? B.is_owner[i] : 1;

@@ -78,10 +78,7 @@ typedef struct guber_engine guber_engine_t;
 
 /* guber_config_t.flags */
 #define GUBER_FLAG_GLOBAL 8u          /* keep per-bucket pending GLOBAL hits / updates (guber_global_take) */
-#define GUBER_FLAG_DIR_CLAIMS 16u     /* tuning: keep the per-batch "first toucher" claims of the two-launch pipeline in the
-                                          directory entries instead of the engine's small claim table.  Measured on MI355X,
-                                          10 M keys, 4 logical shards: the table is +18 % on Zipf-1.1 traffic (no directory
-                                          write-back, no CAS on hot entries) and -7 % when no key repeats inside a batch */
+#define GUBER_FLAG_DIR_CLAIMS 16u     /* accepted and ignored (round-1 tuning knob: per-batch claims in the directory entries) */
 #define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
                                           sort) kernel sequence as well */

@@ -79,7 +79,7 @@ int hs_eval_batch(void* hp, const guber_batch_t* b, guber_result_t* res, int mod
             for (size_t j = 0; j < idx.size(); j++) {
                 Req r = load_req(b, idx[j]);
                 Resp out; Rec after;
-                uint32_t ev = eval_uniform_rank(s0, r, b->now_ms, j, out, after);
+                uint32_t ev = eval_rank(s0, r, b->now_ms, j, out, after, eval_uniform_rank_1x);   // closed forms first, as the kernels do
                 store(res, idx[j], out);
                 h->over += (ev & EV_OVER) ? 1 : 0; h->hits += (ev & EV_HIT) ? 1 : 0; h->misses += (ev & EV_MISS) ? 1 : 0;
                 if (j + 1 == idx.size()) fin = after;
@@ -99,6 +99,69 @@ int hs_eval_batch(void* hp, const guber_batch_t* b, guber_result_t* res, int mod
     res->over_limit_count = h->over - over0; res->cache_hits = h->hits - hit0; res->cache_misses = h->misses - miss0;
     res->unexpired_evictions = 0; res->cache_size = h->size;
     return 0;
+}
+
+// Differential fuzz of the closed forms (token_fast / leaky_fast) against apply() / skip(): random live buckets and
+// requests in the regimes the closed forms accept, every rank of a run.  out[0] = comparisons made on the token closed
+// form, out[1] = on the leaky one, out[2] = mismatches.
+static uint64_t fz_next(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+void hs_fuzz_closed_forms(uint64_t seed, uint32_t iters, uint64_t* out) {
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + 1;
+    out[0] = out[1] = out[2] = 0;
+    static const int64_t kHits[] = {1, 1, 1, 2, 3, 5, 7, 10, 100, 1000, (int64_t)1 << 40, (int64_t)1 << 62};
+    static const int64_t kLim[] = {1, 2, 5, 10, 10, 100, 100, 2000, 65536, (int64_t)1 << 40, (int64_t)1 << 62, 0, -5};
+    static const int64_t kDur[] = {0, 1, 5, 50, 1000, 30000, 60000, (int64_t)1 << 40};
+    for (uint32_t it = 0; it < iters; ++it) {
+        const int64_t now = 1700000000000ll + (int64_t)(fz_next(st) % 100000);
+        Req r; memset(&r, 0, sizeof r);
+        r.hits = kHits[fz_next(st) % 12]; r.limit = kLim[fz_next(st) % 13]; r.duration = kDur[fz_next(st) % 8];
+        r.created_at = now + (int64_t)(fz_next(st) % 200) - 100;
+        r.behavior = (fz_next(st) % 3 == 0 ? BH_DRAIN_OVER_LIMIT : 0u) | (fz_next(st) % 7 == 0 ? BH_GLOBAL : 0u) |
+                     (fz_next(st) % 11 == 0 ? BH_GREGORIAN : 0u);
+        r.is_owner = fz_next(st) % 4 != 0;
+        r.algorithm = fz_next(st) & 1;
+        r.burst = fz_next(st) % 3 == 0 ? (int64_t)(fz_next(st) % 50) : 0;
+        Rec s0; rec_clear(s0);
+        s0.limit = fz_next(st) % 5 ? r.limit : r.limit + 3; s0.duration = fz_next(st) % 5 ? r.duration : r.duration + 1;
+        s0.expire_at = now + (int64_t)(fz_next(st) % 100000) - (fz_next(st) % 16 == 0 ? 200000 : 0);
+        s0.invalid_at = fz_next(st) % 9 == 0 ? now + (int64_t)(fz_next(st) % 100) - 50 : 0;
+        s0.stamp = now - (int64_t)(fz_next(st) % 100000);
+        if (r.algorithm == ALGO_TOKEN) {
+            const uint64_t pick = fz_next(st) % 8;
+            s0.remaining = pick == 0 ? 0 : pick == 1 ? r.hits : pick == 2 ? r.hits - 1 : pick == 3 ? (int64_t)(fz_next(st) % 20) * r.hits
+                         : pick == 4 ? -3 : (int64_t)(fz_next(st) % 300000);
+            s0.meta = make_meta(K_TOKEN, fz_next(st) % 5 == 0 ? ST_OVER : ST_UNDER, ALGO_TOKEN);
+        } else {
+            const int64_t burst = r.burst == 0 ? r.limit : r.burst;
+            s0.burst = fz_next(st) % 6 ? burst : burst + 1;
+            const uint64_t pick = fz_next(st) % 8;
+            double rem = pick == 0 ? 0.0 : pick == 1 ? (double)r.hits : pick == 2 ? (double)r.hits + 0.75 : pick == 3 ? 0.5
+                       : pick == 4 ? -2.5 : (double)(fz_next(st) % 200000) / 7.0;
+            if (fz_next(st) % 40 == 0) rem = 1e300;
+            s0.remaining = f2bits(rem);
+            s0.meta = make_meta(K_LEAKY, 0, ALGO_LEAKY);
+        }
+        static const uint64_t kRank[] = {0, 1, 2, 3, 7, 63, 64, 99, 100, 101, 255, 4096, 65535, 1u << 20};
+        for (uint64_t k : kRank) {
+            Resp a, b; Rec sa, sb; uint32_t ea = 0;
+            bool fast = false;
+            if (token_fast_ok(s0, r, now)) { ea = token_fast(s0, r, k, a, sa); fast = true; out[0]++; }
+            else if (leaky_fast(s0, r, now, k, a, sa, ea)) { fast = true; out[1]++; }
+            if (!fast) break;
+            if (k > 4096 && r.hits > 1 && !(r.behavior & BH_DRAIN_OVER_LIMIT)) { /* generic path steps: keep it */ }
+            const uint32_t eb = eval_uniform_rank(s0, r, now, k, b, sb);
+            {   // the one-site form the kernels inline must agree with the three-site form everywhere
+                Resp c; Rec sc;
+                const uint32_t ec = eval_uniform_rank_1x(s0, r, now, k, c, sc);
+                if (ec != eb || c.status != b.status || c.err != b.err || c.limit != b.limit || c.remaining != b.remaining ||
+                    c.reset_time != b.reset_time || !rec_eq(sc, sb))
+                    out[2]++;
+            }
+            if (ea != eb || a.status != b.status || a.err != b.err || a.limit != b.limit || a.remaining != b.remaining ||
+                a.reset_time != b.reset_time || !rec_eq(sa, sb))
+                out[2]++;
+        }
+    }
 }
 
 int hs_add_item(void* hp, const guber_item_t* in, int* existed) {

@@ -282,3 +282,19 @@ def test_extreme_value_runs_vs_oracle():
                 assert a["remaining_f"] == b_["remaining_f"] or (a["remaining_f"] != a["remaining_f"] and b_["remaining_f"] != b_["remaining_f"]), (trial, a, b_)
             t += int(rng.choice([0, 1, 40, 1200, 70_000]))
         o.close(); h.close()
+
+
+def test_closed_forms_equal_apply_skip_on_random_states():
+    """token_fast / leaky_fast (guber_algo.h: the counter-walk closed forms the kernels try first) against
+    eval_uniform_rank (apply + skip) on random live buckets and requests, ranks 0 .. 2^20: responses, event flags and
+    the bucket after the request must be identical wherever a closed form accepts the case."""
+    lib = hostsim_lib()
+    lib.hs_fuzz_closed_forms.argtypes = [C.c_uint64, C.c_uint32, C.c_void_p]
+    lib.hs_fuzz_closed_forms.restype = None
+    tok = leaky = 0
+    for seed in range(1, 9):
+        out = (C.c_uint64 * 3)()
+        lib.hs_fuzz_closed_forms(seed, 40_000, out)
+        assert out[2] == 0, f"seed {seed}: {out[2]} mismatches"
+        tok += out[0]; leaky += out[1]
+    assert tok > 200_000 and leaky > 100_000, (tok, leaky)
