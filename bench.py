@@ -1,29 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — rate-limit decisions/sec of the MI355X engine on BASELINE.json's workload.
 
-One "step" = one GetRateLimits batch of 65536 checks evaluated by the HIP path
-(guber_eval_batch_dev: k_resolve -> radix passes -> k_heads -> k_eval) with every input array
-already resident in HBM.  Workload (BASELINE.json configs[1]): 10M resident
-keys per GPU, Zipf(1.1) key popularity (stream seed 1234, permutation seed 99), TOKEN_BUCKET, hits 1,
-limit 100, duration 60 s, now_ms advancing 1 ms per batch.  `--algo leaky` switches to configs[2].
+One "step" = one GetRateLimits batch of 65536 checks evaluated by the HIP path (guber_eval_batch_dev: k_front ->
+k_eval2) with every input array already resident in HBM.  Workload (BASELINE.json configs[1]):
+10M resident keys per GPU, ONE Zipf(1.1) request stream over those keys (stream seed 1234, permutation seed 99),
+TOKEN_BUCKET, hits 1, limit 100, duration 60 s, now_ms advancing 1 ms per batch.
 
-Inside a GPU the resident keys are split into S logical shards (default 4; the reference shards its key
-space the same way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables
-and HIP streams, the front end routes a key to its shard with the same consistent hash, and step s
-evaluates one 65536-request batch of shard s % S — consecutive steps are independent and overlap on the
-GPU.  `--shards 1` gives the single-table number (2.1 G/s vs 3.5 G/s on MI355X).
+Inside a GPU the resident keys are split into S logical shards (default 4; the reference shards its key space the same
+way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables and HIP streams.  The request
+stream is routed request by request to the shard that owns the key (consistent hash, k_route) and every shard flushes a
+batch when 65536 requests are waiting — the policy of the reference's batcher (peer_client.go:284-337) — so batches are
+exactly 65536 requests, hot shards flush more often, and per-key request order is the stream's order.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by
-the reference's replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1),
-every rank evaluates batches over the keys it owns — no data-path collective (weak scaling).
+Timing: the batches of the timed region are enqueued by S pre-started batcher threads (one per shard, released by a
+barrier; no thread is created and nothing is allocated inside the timed region); the region is repeated until it lasts
+at least --min-ms, whatever --steps says.  Extras in the same JSON line: `leaky` (configs[2], parity-gated), `shards_1`
+(one table, the literal single-stream configuration), `uniform` (no duplicate keys), `end_to_end` (host pointers in,
+host results out, PCIe included).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by the reference's
+replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1), every rank evaluates the requests
+for the keys it owns — no data-path collective (weak scaling).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -50,13 +57,16 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--algo", choices=["token", "leaky"], default="token")
     ap.add_argument("--dist", choices=["zipf", "uniform"], default="zipf")
+    ap.add_argument("--min-ms", type=float, default=250.0, help="minimum duration of the timed region: the timed steps are repeated until it is reached")
+    ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end",
+                    help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batches", type=int, default=48)
-    ap.add_argument("--cpu-threads", type=int, default=32, help="worker shards/threads of the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
+    ap.add_argument("--cpu-threads", default="1,32,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--shards", type=int, default=4, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
-                         "engines with their own tables and streams; step s evaluates a batch of shard s %% S")
+                         "engines with their own tables and streams, the stream routed to them key by key")
     ap.add_argument("--global-host", action="store_true", help="with --global-sync: use the host-staged exchange (global_sync.py)")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
                     help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
@@ -67,19 +77,328 @@ def parse():
     return ap.parse_args()
 
 
+class Ctx:
+    """process-wide state: torch device, distributed world, key table"""
+
+
+def percentile(sorted_vals, p):
+    return sorted_vals[min(len(sorted_vals) - 1, int(len(sorted_vals) * p))]
+
+
+class BatcherThreads:
+    """S pre-started threads, one per logical shard (the batcher goroutine of a shard).  run(jobs) releases them through a
+    barrier, each executes its job (enqueue its batches), and a second barrier collects them: nothing is created inside
+    the timed region."""
+
+    def __init__(self, n):
+        self.n = n
+        self.start = threading.Barrier(n + 1)
+        self.end = threading.Barrier(n + 1)
+        self.jobs = [None] * n
+        self.err = [None] * n
+        self.stop = False
+        self.threads = [threading.Thread(target=self._loop, args=(j,), daemon=True) for j in range(n)]
+        for t in self.threads:
+            t.start()
+
+    def _loop(self, j):
+        while True:
+            self.start.wait()
+            if self.stop:
+                return
+            try:
+                if self.jobs[j] is not None:
+                    self.jobs[j]()
+            except Exception as ex:   # noqa: BLE001
+                self.err[j] = ex
+            self.end.wait()
+
+    def run(self, jobs):
+        self.jobs = list(jobs)
+        self.start.wait()
+        self.end.wait()
+        for ex in self.err:
+            if ex is not None:
+                raise ex
+
+    def close(self):
+        self.stop = True
+        self.start.wait()
+        for t in self.threads:
+            t.join()
+
+
+class Rig:
+    """One measured configuration: S engines (tables + streams) over this rank's keys, a routed request sequence resident
+    in HBM, and the machinery to run it."""
+
+    def __init__(self, ctx, algo, dist_kind, S, flags=0, max_key_bytes=0):
+        import torch
+        import gubernator_amd as ga
+        import streams
+        from gubernator_amd import shard
+        self.ctx, self.algo, self.dist_kind, self.S = ctx, algo, dist_kind, S
+        self.algo_id = 0 if algo == "token" else 1
+        self.torch, self.ga, self.streams = torch, ga, streams
+        dev, K, B = ctx.dev, ctx.K, ctx.B
+        self.sstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        nk = len(ctx.my_ids)
+        self.engines = [ga.Engine(cache_size=(nk + nk // 4) // S + 1024, device=ctx.local_rank, max_batch=B,
+                                  stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
+        # logical shards inside this GPU: the rank's keys are split once more by the same kind of ring (k_route)
+        if S > 1:
+            sring = ga.Ring([f"gpu{ctx.rank}-shard{j}" for j in range(S)], 512, "fnv1")
+            self.sown = np.concatenate([ctx.route_on_device(self.engines[0], sring, *streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 4_000_000]))
+                                        for lo in range(0, nk, 4_000_000)]).astype(np.uint8)
+            sring.close()
+        else:
+            self.sown = np.zeros(nk, np.uint8)
+        self.local_of_shard = [np.nonzero(self.sown == j)[0] for j in range(S)]
+        # arrays every batch of this rig shares (fixed-width keys, constant request fields)
+        L = ctx.table.shape[1]
+        self.t_off = torch.from_numpy((np.arange(B + 1, dtype=np.int64) * L).astype(np.int32)).to(dev)
+        self.t_hits1 = torch.full((B,), 1, dtype=torch.int64, device=dev)
+        self.t_hits0 = torch.zeros((B,), dtype=torch.int64, device=dev)
+        self.t_limit = torch.full((B,), 100, dtype=torch.int64, device=dev)
+        self.t_dur = torch.full((B,), 60_000, dtype=torch.int64, device=dev)
+        self.t_algo = torch.full((B,), self.algo_id, dtype=torch.uint8, device=dev)
+        self.t_beh = torch.full((B,), 2 if (flags & ga.FLAG_GLOBAL) else 0, dtype=torch.int32, device=dev)
+        self.scratch = [self.DevResult(self, B) for _ in range(S)]
+        self.workers = BatcherThreads(S) if S > 1 else None
+        self.keep = []          # tensors referenced by C structs
+
+    class DevResult:
+        def __init__(self, rig, n):
+            torch, ga, dev = rig.torch, rig.ga, rig.ctx.dev
+            self.status = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.err = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.limit = torch.empty(n, dtype=torch.int64, device=dev)
+            self.remaining = torch.empty(n, dtype=torch.int64, device=dev)
+            self.reset_time = torch.empty(n, dtype=torch.int64, device=dev)
+            self.c = ga.GuberResult(self.status.data_ptr(), self.limit.data_ptr(), self.remaining.data_ptr(),
+                                    self.reset_time.data_ptr(), self.err.data_ptr(), 0, 0, 0, 0, 0)
+            self.ga = ga
+
+        def host(self):
+            h = self.ga.HostResult(len(self.status))
+            for name in ("status", "limit", "remaining", "reset_time", "err"):
+                getattr(h, name)[:] = getattr(self, name).cpu().numpy()
+            return h
+
+    def dev_batch(self, ids, now_ms, hits=1, owner_ptr=None):
+        """GuberBatch over global key ids `ids` (device pointers); len(ids) <= B"""
+        torch, ga = self.torch, self.ga
+        kb, _ = self.streams.keys_for_ids(self.ctx.table, ids)
+        t_keys = torch.from_numpy(kb).to(self.ctx.dev)
+        self.keep.append(t_keys)
+        return ga.GuberBatch(len(ids), 0, t_keys.data_ptr(), self.t_off.data_ptr(),
+                             (self.t_hits1 if hits else self.t_hits0).data_ptr(), self.t_limit.data_ptr(), self.t_dur.data_ptr(),
+                             None, None, self.t_algo.data_ptr(), self.t_beh.data_ptr(), owner_ptr, None, None, int(now_ms))
+
+    def populate(self, now0):
+        """residency: every owned key gets a bucket before anything is timed (hits 0 = create, consume nothing)"""
+        B = self.ctx.B
+        for j in range(self.S):
+            ids = self.ctx.my_ids[self.local_of_shard[j]]
+            for lo in range(0, len(ids), B):
+                b = self.dev_batch(ids[lo:lo + B], now0, hits=0)
+                self.engines[j].eval_dev(b, self.scratch[j].c)
+                self.engines[j].synchronize()
+                self.keep.pop()
+        return sum(e_.size() for e_ in self.engines)
+
+    def build_sequence(self, total, now0, seed):
+        """Draw ONE request stream over this rank's keys, route it to the shards, flush a shard's batch whenever B requests
+        are waiting (batches in flush order).  -> list of (shard, global ids of the batch, now_ms)."""
+        B, S = self.ctx.B, self.S
+        nk = len(self.ctx.my_ids)
+        if self.dist_kind == "zipf":
+            smp = self.streams.ZipfSampler(nk, s=1.1, seed=seed, perm_seed=99)
+            draw = smp.draw
+        else:
+            rg = np.random.default_rng(seed)
+            draw = (lambda n: rg.permutation(nk)[:n]) if B * S <= nk else (lambda n: rg.integers(0, nk, n))
+        pend_ids = [np.zeros(0, np.int64) for _ in range(S)]
+        pend_pos = [np.zeros(0, np.int64) for _ in range(S)]
+        out, offset = [], 0
+        while len(out) < total + S:        # a few more than needed, then cut in flush order
+            li = draw(B * S)
+            sh = self.sown[li]
+            pos = offset + np.arange(len(li), dtype=np.int64)
+            offset += len(li)
+            for j in range(S):
+                m = sh == j if S > 1 else slice(None)
+                pend_ids[j] = np.concatenate([pend_ids[j], li[m]])
+                pend_pos[j] = np.concatenate([pend_pos[j], pos[m]])
+                while len(pend_ids[j]) >= B:
+                    out.append((int(pend_pos[j][B - 1]), j, pend_ids[j][:B]))
+                    pend_ids[j], pend_pos[j] = pend_ids[j][B:], pend_pos[j][B:]
+        out.sort(key=lambda x: x[0])
+        return [(j, self.ctx.my_ids[li], now0 + 1 + s) for s, (_, j, li) in enumerate(out[:total])]
+
+    def load_sequence(self, seq, keep_first):
+        """device batches + result targets for a sequence; the first `keep_first` batches keep their results"""
+        B = self.ctx.B
+        self.seq = seq
+        self.batches = [self.dev_batch(ids, now) for (_, ids, now) in seq]
+        self.kept = [self.DevResult(self, B) for _ in range(min(keep_first, len(seq)))]
+
+    def _arrays(self, lo, hi, keep):
+        """per shard: ctypes arrays (GuberBatch[], GuberResult[], count) of the sequence's batches lo..hi in order"""
+        ga = self.ga
+        per = []
+        for j in range(self.S):
+            idx = [s for s in range(lo, hi) if self.seq[s][0] == j]
+            ba = (ga.GuberBatch * max(len(idx), 1))(*[self.batches[s] for s in idx])
+            ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if (keep and s < len(self.kept)) else self.scratch[j].c) for s in idx])
+            per.append((ba, ra, len(idx)))
+        return per
+
+    def run(self, lo, hi, repeats=1, keep=False, timed=False):
+        """enqueue batches lo..hi of the sequence `repeats` times.  timed: returns (wall seconds, max per-stream event ms)"""
+        torch = self.torch
+        per = self._arrays(lo, hi, keep)
+
+        def job(j):
+            ba, ra, cnt = per[j]
+            eng = self.engines[j]
+
+            def f():
+                for _ in range(repeats):
+                    if cnt:
+                        eng.eval_many_dev(ba, ra, cnt)
+            return f
+        jobs = [job(j) for j in range(self.S)]
+        ev0 = ev1 = None
+        if timed:
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(self.S)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(self.S)]
+            torch.cuda.synchronize(self.ctx.dev)
+            self.ctx.barrier()
+            for j in range(self.S):
+                ev0[j].record(self.sstreams[j])
+        t0 = time.perf_counter()
+        if self.workers is not None:
+            self.workers.run(jobs)
+        else:
+            jobs[0]()
+        if timed:
+            for j in range(self.S):
+                ev1[j].record(self.sstreams[j])
+        torch.cuda.synchronize(self.ctx.dev)
+        t1 = time.perf_counter()
+        if timed:
+            self.ctx.barrier()
+            return t1 - t0, max(ev0[j].elapsed_time(ev1[j]) for j in range(self.S))
+        return t1 - t0, None
+
+    def measure(self, steps, warmup, min_ms, now0, seed, keep_first=8):
+        """warm up, calibrate the repeat count, time.  -> dict"""
+        ctx = self.ctx
+        seq = self.build_sequence(warmup + steps, now0, seed)
+        self.load_sequence(seq, keep_first)
+        if warmup:
+            self.run(0, warmup, keep=True)
+        cal, _ = self.run(warmup, warmup + steps, keep=True)          # first execution of the timed steps: calibration (untimed)
+        cal = ctx.max_over_ranks(cal)
+        repeats = max(1, int(math.ceil(min_ms * 1e-3 / max(cal, 1e-6))))
+        wall, ev_ms = self.run(warmup, warmup + steps, repeats=repeats, timed=True)
+        wall = ctx.max_over_ranks(wall)
+        n_batches = steps * repeats
+        return {"value": n_batches * ctx.B * ctx.world / wall, "ms_per_step": wall / n_batches * 1e3, "repeats": repeats,
+                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / n_batches, "steps": steps}
+
+    def kernel_profile(self, n_steps, lo, hi):
+        """per-kernel durations with one batch in flight on shard 0 (HIP events around every launch)"""
+        eng = self.engines[0]
+        idx = [s for s in range(lo, hi) if self.seq[s][0] == 0] or [lo]
+        eng.profile(True)
+        eng.profile_read()
+        for k in range(n_steps):
+            eng.eval_dev(self.batches[idx[k % len(idx)]], self.scratch[0].c)
+        prof = eng.profile_read()
+        eng.profile(False)
+        return {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
+
+    def latency(self, lo, hi, n=256):
+        """single-batch latency: submit -> complete, one batch in flight (BASELINE metric: p99 batch latency)"""
+        torch = self.torch
+        eng, stream = self.engines[0], self.sstreams[0]
+        idx = [s for s in range(lo, hi) if self.seq[s][0] == 0] or [lo]
+        lat = []
+        for k in range(n):
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            eng.eval_dev(self.batches[idx[k % len(idx)]], self.scratch[0].c)
+            b_.record(stream)
+            b_.synchronize()
+            lat.append(a.elapsed_time(b_) * 1e3)
+        lat.sort()
+        return {"unit": "us", "p50": round(percentile(lat, 0.5), 2), "p99": round(percentile(lat, 0.99), 2), "min": round(lat[0], 2),
+                "n": len(lat), "what": f"one {self.ctx.B}-request batch, HIP events around guber_eval_batch_dev, nothing else in flight"}
+
+    def host_batches(self, lo, hi):
+        return [self.streams.bench_batch(self.ctx.table, self.seq[s][1], self.seq[s][2], algorithm=self.algo_id) for s in range(lo, hi)]
+
+    def close(self):
+        if self.workers is not None:
+            self.workers.close()
+        for e_ in self.engines:
+            e_.close()
+        self.keep.clear()
+        self.batches = []
+
+
+def parity_gate(rig, orc, threads, now0, label):
+    """the GPU's answers for the first kept batches of the rig's sequence against the oracle evaluating the same
+    batches in the same order; returns (ok, oracle outputs consumed)"""
+    import support
+    ctx = rig.ctx
+    for lo in range(0, len(ctx.my_ids), 1 << 18):
+        orc.eval(rig.streams.bench_batch(ctx.table, ctx.my_ids[lo:lo + (1 << 18)], now0, hits=0, algorithm=rig.algo_id), threads=threads)
+    ok = True
+    hb = rig.host_batches(0, len(rig.kept))
+    for s, b in enumerate(hb):
+        want = orc.eval(b, threads=threads)
+        try:
+            support.assert_results_equal(rig.kept[s].host(), want, f"{label} batch {s}")
+        except AssertionError as ex:
+            ok = False
+            print("PARITY FAILURE:", ex, file=sys.stderr)
+    return ok
+
+
+def cpu_baseline(rig, orc_by_threads, lo, hi, seconds):
+    """the oracle in the reference's worker-sharded design (oracle_eval_batch_mt: XXH64-range sharding to W worker caches,
+    one thread per worker) on this host's cores, same resident keys, same stream, a time-bounded sample per W"""
+    hb = rig.host_batches(lo, hi)
+    res = {}
+    for w, orc in orc_by_threads.items():
+        done, t0 = 0, time.perf_counter()
+        while True:
+            orc.eval(hb[done % len(hb)], threads=(w if w > 1 else 0))
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 4 * len(hb):
+                break
+        res[w] = (done * rig.ctx.B / el, done, el)
+    return res
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
     import gubernator_amd as ga
     import streams
+    from gubernator_amd import shard
 
+    ctx = Ctx()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     if args.one_device:
@@ -93,321 +412,291 @@ def main():
         else:
             dist.init_process_group(args.backend)
     red_dev = dev if args.backend == "nccl" else None
-
+    ctx.world, ctx.rank, ctx.local_rank, ctx.dev = world, rank, local_rank, dev
+    ctx.K, ctx.B = args.keys, args.batch
+    ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
+    ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
-    algo_id = 0 if args.algo == "token" else 1
-    stream = torch.cuda.Stream(device=dev)
     GSYNC = args.global_sync
-    S = max(1, args.shards)
-    if GSYNC:
-        S = 1   # GLOBAL replicas: one table per GPU
-    sstreams = [stream] + [torch.cuda.Stream(device=dev) for _ in range(S - 1)]
-    engines = [ga.Engine(cache_size=(K + K // 4) // S + 1024, device=local_rank, max_batch=B, stream=sstreams[j].cuda_stream,
-                         max_key_bytes=64 if GSYNC else 0, flags=ga.FLAG_GLOBAL if GSYNC else 0) for j in range(S)]
-    eng = engines[0]
+    NOW0 = streams.NOW0
 
-    # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
-    total_keys = K if GSYNC else K * world      # GLOBAL: one key space, replicated on every GPU
-    table = streams.key_table(total_keys)
-    from gubernator_amd import shard
-
-    def route_on_device(ring, kb, ko):       # ReplicatedConsistentHash.Get for a chunk of keys (k_route)
+    def route_on_device(eng, ring, kb, ko):       # ReplicatedConsistentHash.Get for a chunk of keys (k_route)
         d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
         d_owner = torch.empty(len(ko) - 1, dtype=torch.int32, device=dev)
         eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ko) - 1, d_owner.data_ptr())
         return d_owner.cpu().numpy()
+    ctx.route_on_device = route_on_device
+
+    # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
+    total_keys = K if GSYNC else K * world      # GLOBAL: one key space, replicated on every GPU
+    ctx.table = streams.key_table(total_keys)
+    if GSYNC or world == 1:
+        ctx.my_ids = np.arange(total_keys, dtype=np.int64)
+    else:
+        tmp = ga.Engine(cache_size=1024, device=local_rank, max_batch=1024)
+        ctx.my_ids = shard.owned_key_ids(ctx.table, world, rank, route=lambda ring, kb, ko: route_on_device(tmp, ring, kb, ko), chunk=4_000_000)
+        tmp.close()
 
     if GSYNC:
-        my_ids = np.arange(total_keys)          # every rank holds (a replica of) every key
-        ring = ga.Ring(shard.peer_names(world), 512, "fnv1")
-    else:
-        my_ids = shard.owned_key_ids(table, world, rank, route=route_on_device, chunk=4_000_000)
-    nk = len(my_ids)
-    # logical shards inside this GPU: the rank's keys are split once more by the same kind of ring
-    if S > 1:
-        sring = ga.Ring([f"gpu{rank}-shard{j}" for j in range(S)], 512, "fnv1")
-        sown = np.concatenate([route_on_device(sring, *streams.keys_for_ids(table, my_ids[lo:lo + 4_000_000]))
-                               for lo in range(0, nk, 4_000_000)])
-        shard_ids = [my_ids[sown == j] for j in range(S)]
-    else:
-        shard_ids = [my_ids]
+        return run_global(args, ctx, dist)
 
-    # ---- device-resident batches ------------------------------------------------------------
-    def to_dev(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    S = max(1, args.shards)
+    seed = 1234 + rank * 64
+    rig = Rig(ctx, args.algo, args.dist, S)
+    resident = rig.populate(NOW0)
+    m = rig.measure(args.steps, args.warmup, args.min_ms, NOW0, seed)
+    lo, hi = args.warmup, args.warmup + args.steps
 
-    class DevBatch:
-        def __init__(self, ids, now_ms, hits=1):
-            kb, ko = streams.keys_for_ids(table, ids)
-            n = len(ids)
-            self.n = n
-            self.t = [to_dev(kb), to_dev(ko.view(np.int32)),
-                      torch.full((n,), hits, dtype=torch.int64, device=dev),
-                      torch.full((n,), 100, dtype=torch.int64, device=dev),
-                      torch.full((n,), 60_000, dtype=torch.int64, device=dev),
-                      torch.full((n,), algo_id, dtype=torch.uint8, device=dev),
-                      torch.full((n,), 2 if GSYNC else 0, dtype=torch.int32, device=dev)]
-            p = [x.data_ptr() for x in self.t]
-            owner_ptr = None
-            if GSYNC and world > 1:                 # is_owner[i] = (ring owner of key i == this rank), on device
-                d_owner = torch.empty(n, dtype=torch.int32, device=dev)
-                eng.route_dev(ring, p[0], p[1], n, d_owner.data_ptr())
-                self.t.append((d_owner == rank).to(torch.uint8))
-                owner_ptr = self.t[-1].data_ptr()
-            self.c = ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], owner_ptr, None, None,
-                                   int(now_ms))
+    roofline = latency = cpu = parity = None
+    extras = {}
+    if rank == 0:
+        # ---- per-kernel durations (HIP events on the engine stream around every launch), one batch in flight ----
+        kernel_ms = rig.kernel_profile(args.profile_steps, lo, hi) if args.profile_steps > 0 else {}
+        latency = rig.latency(lo, hi)
+        cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo] and v > 0}
+        if cand:
+            dom = max(cand, key=cand.get)
+            dom_bytes = KERNEL_BYTES[args.algo][dom] * B
+            achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
+            traffic = measured = None
+            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(args.algo, {}).get(dom)
+                hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
+                cor = sum(tj.get(args.algo, {}).get(k, 0) for k in ("k_front", "k_eval2"))
+                raw = sum(tj.get(args.algo + "_raw", {}).get(k, 0) for k in ("k_front", "k_eval2"))
+                if cor and raw:
+                    g_raw, g_cor = (x / (m["ms_per_step"] * 1e-3) / 1e9 for x in (raw, cor))
+                    measured = {"stream_read_GBps": hp["stream_read_GBps"], "random_gather_GBps": hp["random_gather_128B_GBps"],
+                                "hbm_traffic_bytes_per_batch": {"raw": raw, "corrected": cor, "source": tj.get("source", "profiles/roofline_traffic.json")},
+                                "hbm_traffic_GBps": {"raw": round(g_raw, 1), "corrected": round(g_cor, 1)},
+                                "frac_of_random_gather": {"raw": round(g_raw / hp["random_gather_128B_GBps"], 4),
+                                                          "corrected": round(g_cor / hp["random_gather_128B_GBps"], 4)}}
+            except Exception:   # noqa: BLE001
+                pass
+            pipe = BYTES_PER_DECISION[args.algo] * B / (m["ms_per_step"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": dom_bytes,
+                        "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items() if v > 0},
+                        "kernel_timing": "HIP events around every launch on the engine stream, one batch in flight",
+                        "measured_ceilings": measured,
+                        "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
+                                     "ms_per_batch": round(m["ms_per_step"], 5),
+                                     "achieved": round(pipe, 2), "frac": round(pipe / HBM_PEAK_GBPS, 6),
+                                     "what": "algorithmic bytes of the whole pipeline / timed ms per step (all shards overlapping)"}}
 
-    class DevResult:
-        def __init__(self, n):
-            self.status = torch.empty(n, dtype=torch.uint8, device=dev)
-            self.err = torch.empty(n, dtype=torch.uint8, device=dev)
-            self.limit = torch.empty(n, dtype=torch.int64, device=dev)
-            self.remaining = torch.empty(n, dtype=torch.int64, device=dev)
-            self.reset_time = torch.empty(n, dtype=torch.int64, device=dev)
-            self.c = ga.GuberResult(self.status.data_ptr(), self.limit.data_ptr(), self.remaining.data_ptr(),
-                                    self.reset_time.data_ptr(), self.err.data_ptr(), 0, 0, 0, 0, 0)
+    # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import support
+        ncpu = os.cpu_count() or 1
+        ws = []
+        for tok in args.cpu_threads.split(","):
+            tok = tok.strip()
+            if tok:
+                w = ncpu if tok == "all" else max(1, min(ncpu, int(tok)))
+                if w not in ws:
+                    ws.append(w)
+        orcs = {w: support.Oracle(cache_size=4 * K, workers=w) for w in ws}
+        gate_w = max(ws)
+        ok = parity_gate(rig, orcs[gate_w], gate_w, NOW0, "headline")
+        for w in ws:
+            if w != gate_w:
+                for s in range(0, len(ctx.my_ids), 1 << 18):
+                    orcs[w].eval(streams.bench_batch(ctx.table, ctx.my_ids[s:s + (1 << 18)], NOW0, hits=0, algorithm=rig.algo_id), threads=(w if w > 1 else 0))
+        parity = f"bit-exact vs oracle on the first {len(rig.kept)} batches of the timed stream" if ok else "FAILED"
+        if not ok:
+            raise SystemExit("parity gate failed: refusing to report a number")
+        res = cpu_baseline(rig, orcs, len(rig.kept), min(len(rig.seq), len(rig.kept) + 64), args.cpu_seconds)
+        best = max(res, key=lambda w: res[w][0])
+        cpu = {"value": round(res[best][0], 1), "unit": "decisions/s", "cores": best, "kind": "port",
+               "sample": f"{res[best][1]} batches of {B} from the same routed stream ({res[best][2]:.1f} s), {K} resident keys, the oracle in the "
+                         f"reference's worker-sharded design (W caches / threads, XXH64-range sharding, workers.go:180-184); host has {ncpu} cores",
+               "by_threads": {str(w): {"value": round(v[0], 1), "batches": v[1], "seconds": round(v[2], 2)} for w, v in res.items()}}
+        for o in orcs.values():
+            o.close()
 
-        def host(self):
-            h = ga.HostResult(len(self.status))
-            for name in ("status", "limit", "remaining", "reset_time", "err"):
-                getattr(h, name)[:] = getattr(self, name).cpu().numpy()
-            return h
+    headline_cfg = {"workload": f"{K} resident keys per GPU, one {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") +
+                                f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, {world}xMI355X"
+                                + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
+                                + (f", {S} logical shards per GPU (own table + stream + batcher thread each; the stream is routed by consistent hash, "
+                                   f"a shard flushes a batch when {B} requests are waiting)" if S > 1 else ", one table"),
+                    "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
+                    "logical_shards_per_gpu": S, "host_cores": os.cpu_count()}
+    rig.close()
+    del rig
+    torch.cuda.empty_cache()
 
-    NOW0 = streams.NOW0
-    # residency: every owned key gets a bucket before anything is timed (hits 0 = create, consume nothing)
-    scratches = [DevResult(B) for _ in range(S)]
-    scratch = scratches[0]
-    for j in range(S):
-        with torch.cuda.stream(sstreams[j]):
-            for lo in range(0, len(shard_ids[j]), B):
-                db = DevBatch(shard_ids[j][lo:lo + B], NOW0, hits=0)
-                engines[j].eval_dev(db.c, scratches[j].c)
-                engines[j].synchronize()
-    resident = sum(e_.size() for e_ in engines)
+    # ---- extras (rank 0 of a 1-GPU run): other configurations, same machinery, shorter timed region ----
+    if rank == 0 and world == 1 and args.extras:
+        want = [x.strip() for x in args.extras.split(",") if x.strip()]
+        for name in want:
+            try:
+                extras[name] = run_extra(name, args, ctx, NOW0, seed)
+            except Exception as ex:   # noqa: BLE001
+                extras[name] = {"error": repr(ex)}
+            torch.cuda.empty_cache()
 
-    draws = []
-    for j in range(S):
-        ids_j = shard_ids[j]
-        if args.dist == "zipf":
-            smp = streams.ZipfSampler(len(ids_j), s=1.1, seed=1234 + rank * 64 + j, perm_seed=99)
-            draws.append(lambda n, smp=smp, ids_j=ids_j: ids_j[smp.draw(n)])
-        else:
-            rg = np.random.default_rng(1234 + rank * 64 + j)
-            draws.append(lambda n, rg=rg, ids_j=ids_j: ids_j[rg.permutation(len(ids_j))[:n]] if n <= len(ids_j) else ids_j[rg.integers(0, len(ids_j), n)])
+    if rank == 0:
+        out = {
+            "metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)",
+            "value": round(m["value"], 1), "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(m["ms_per_step"], 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
+            "config": headline_cfg,
+            "timed_region": {"repeats_of_the_step_list": m["repeats"], "ms": round(m["timed_ms"], 2), "min_ms": args.min_ms,
+                             "ms_per_step_hip_events": round(m["ms_per_step_events"], 5),
+                             "enqueue": f"{S} pre-started batcher threads behind a barrier" if S > 1 else "caller thread"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
+        }
+        out.update(extras)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
 
+
+def run_extra(name, args, ctx, NOW0, seed):
+    """one extra configuration -> sub-object of the JSON line"""
+    import support
+    K, B = ctx.K, ctx.B
+    steps = max(8, min(args.steps, 64))
+    warmup = max(4, min(args.warmup, 16))
+    min_ms = min(args.min_ms, 150.0)
+    if name == "end_to_end":
+        return run_end_to_end(args, ctx, NOW0, seed)
+    algo, dist_kind, S = {"leaky": ("leaky", "zipf", max(1, args.shards)), "shards_1": (args.algo, args.dist, 1),
+                          "uniform": (args.algo, "uniform", max(1, args.shards))}[name]
+    rig = Rig(ctx, algo, dist_kind, S)
+    rig.populate(NOW0)
+    m = rig.measure(steps, warmup, min_ms, NOW0, seed)
+    out = {"value": round(m["value"], 1), "unit": "decisions/s", "ms_per_step": round(m["ms_per_step"], 5), "steps": steps,
+           "repeats": m["repeats"], "dtype": "int64" if algo == "token" else "f64",
+           "workload": f"{K} keys, {dist_kind}, {algo.upper()}_BUCKET, batch {B}, {S} logical shard(s)"}
+    if name in ("leaky", "shards_1"):
+        out["batch_latency"] = rig.latency(warmup, warmup + steps, n=128)
+        km = rig.kernel_profile(16, warmup, warmup + steps)
+        out["kernel_avg_us"] = {k: round(v * 1e3, 2) for k, v in km.items() if v > 0}
+    if name == "leaky" and not args.no_cpu_baseline:
+        w = min(os.cpu_count() or 1, 32)
+        orc = support.Oracle(cache_size=4 * K, workers=w)
+        ok = parity_gate(rig, orc, w, NOW0, "leaky")
+        orc.close()
+        out["parity"] = f"bit-exact vs oracle on the first {len(rig.kept)} batches (tolerance 0)" if ok else "FAILED"
+        if not ok:
+            out.pop("value")
+    rig.close()
+    return out
+
+
+def run_end_to_end(args, ctx, NOW0, seed):
+    """host pointers in, host results out (guber_eval_batch): staging copy, H2D, kernels, D2H — PCIe included"""
+    import gubernator_amd as ga
+    import streams
+    K, B = ctx.K, ctx.B
+    rig = Rig(ctx, args.algo, args.dist, 1)
+    rig.populate(NOW0)
+    seq = rig.build_sequence(72, NOW0, seed)
+    eng = rig.engines[0]
+    hb = [streams.bench_batch(ctx.table, ids, now, algorithm=rig.algo_id) for (_, ids, now) in seq]
+    for b in hb[:8]:
+        eng.eval(b)
+    lat = []
+    t0 = time.perf_counter()
+    for b in hb[8:]:
+        a = time.perf_counter()
+        eng.eval(b)
+        lat.append((time.perf_counter() - a) * 1e6)
+    el = time.perf_counter() - t0
+    lat.sort()
+    rig.close()
+    n = len(hb) - 8
+    bytes_per_req = 15 + 4 + 7 * 8 + 4 + 2 + 3 * 8 + 2
+    return {"value": round(n * B / el, 1), "unit": "decisions/s", "ms_per_step": round(el / n * 1e3, 4), "steps": n,
+            "latency_us": {"p50": round(percentile(lat, 0.5), 1), "p99": round(percentile(lat, 0.99), 1)},
+            "pcie_GBps": round(bytes_per_req * B * n / el / 1e9, 2),
+            "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_eval_batch from one host thread "
+                        "(numpy arrays -> pinned staging -> H2D -> kernels -> D2H -> caller's arrays)"}
+
+
+def run_global(args, ctx, dist):
+    """BASELINE config 5: every request carries GLOBAL, every rank serves all keys from its replica, every K steps the
+    ranks exchange pending hits / owner state."""
+    import torch
+    import gubernator_amd as ga
+    import streams
+    from gubernator_amd import shard
+    K, B, world, rank, dev = ctx.K, ctx.B, ctx.world, ctx.rank, ctx.dev
+    GSYNC, NOW0 = args.global_sync, streams.NOW0
+    rig = Rig(ctx, args.algo, args.dist, 1, flags=ga.FLAG_GLOBAL, max_key_bytes=64)
+    eng, stream = rig.engines[0], rig.sstreams[0]
+    ring = ga.Ring(shard.peer_names(world), 512, "fnv1")
+    resident = rig.populate(NOW0)
     total_steps = args.warmup + args.steps
-    host_ids = [draws[s % S](B) for s in range(total_steps)]
-    batches = [DevBatch(host_ids[s], NOW0 + 1 + s) for s in range(total_steps)]
-    KEEP = min(8, total_steps)           # results of the first KEEP steps are kept for the parity gate
-    kept = [DevResult(B) for _ in range(KEEP)]
-
-    gsync = None
-    if GSYNC:
-        eng.max_batch = B
-        if args.global_host:      # host-staged exchange (numpy rows, pickled all_gather): kept for comparison
-            from gubernator_amd import global_sync
-            transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
-            gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
-        else:                     # rows stay in HBM: take_dev -> route -> RCCL all_to_all / all_gather -> eval_dev / add_items_dev
-            from gubernator_amd import global_sync_dev
-            if world > 1:
-                transport = global_sync_dev.TorchTransportDev(dev)
-            else:
-                transport = type("T", (), {"exchange_rows": staticmethod(lambda send, counts: send),
-                                           "gather_rows": staticmethod(lambda rows: [rows])})()
-            gsync = global_sync_dev.GlobalSyncDev(eng, rank, world, ring, transport, dev, key_stride=64)
+    seq = rig.build_sequence(total_steps, NOW0, 1234 + rank * 64)
+    rig.seq = seq
+    batches, owners = [], []
+    for (_, ids, now) in seq:
+        owner_ptr = None
+        b = rig.dev_batch(ids, now)
+        if world > 1:                 # is_owner[i] = (ring owner of key i == this rank), on device
+            d_owner = torch.empty(len(ids), dtype=torch.int32, device=dev)
+            eng.route_dev(ring, b.key_bytes, b.key_off, len(ids), d_owner.data_ptr())
+            t = (d_owner == rank).to(torch.uint8)
+            owners.append(t)
+            b.is_owner = t.data_ptr()
+        batches.append(b)
+    eng.max_batch = B
+    if args.global_host:      # host-staged exchange (numpy rows, pickled all_gather): kept for comparison
+        from gubernator_amd import global_sync
+        transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
+        gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
+    else:                     # rows stay in HBM: take_dev -> route -> RCCL all_to_all / all_gather -> eval_dev / add_items_dev
+        from gubernator_amd import global_sync_dev
+        if world > 1:
+            transport = global_sync_dev.TorchTransportDev(dev)
+        else:
+            transport = type("T", (), {"exchange_rows": staticmethod(lambda send, counts: send),
+                                       "gather_rows": staticmethod(lambda rows: [rows])})()
+        gsync = global_sync_dev.GlobalSyncDev(eng, rank, world, ring, transport, dev, key_stride=64)
     sync_stats = []
 
     def run(s):
-        engines[s % S].eval_dev(batches[s].c, (kept[s] if s < KEEP else scratches[s % S]).c)
-        if gsync is not None and (s + 1) % GSYNC == 0:
+        eng.eval_dev(batches[s], rig.scratch[0].c)
+        if (s + 1) % GSYNC == 0:
             t_s = time.perf_counter()
             with torch.cuda.stream(stream):          # the engine's stream: torch ops of the exchange and engine kernels stay ordered
                 st = gsync.sync(NOW0 + 1 + s)
                 stream.synchronize()
             st["ms"] = (time.perf_counter() - t_s) * 1e3
             sync_stats.append(st)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    import threading
-
-    def run_range(lo, hi, j):
-        # steps of shard j in [lo, hi): one driver thread per shard, as one batcher goroutine per shard would
-        for s_ in range(lo, hi):
-            if s_ % S == j:
-                run(s_)
-
-    def run_steps(lo, hi):
-        if S == 1 or gsync is not None:
-            for s_ in range(lo, hi):
-                run(s_)
-            return
-        ts = [threading.Thread(target=run_range, args=(lo, hi, j)) for j in range(S)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
-
-    run_steps(0, args.warmup)
+    for s in range(args.warmup):
+        run(s)
     torch.cuda.synchronize(dev)
-    barrier()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(S)]
+    ctx.barrier()
     t0 = time.perf_counter()
-    for j in range(S):
-        ev0[j].record(sstreams[j])
-    run_steps(args.warmup, total_steps)
-    for j in range(S):
-        ev1[j].record(sstreams[j])
+    for s in range(args.warmup, total_steps):
+        run(s)
     torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    barrier()
-    wall = t1 - t0
-    ev_ms = max(ev0[j].elapsed_time(ev1[j]) for j in range(S))
-    wall = shard.max_over_ranks(wall, device=red_dev)
-    decisions = args.steps * B * world
-    value = decisions / wall
-
-    # ---- per-kernel durations (HIP events on the engine stream), same inputs ---------------------
-    roofline = None
-    kernel_ms = {}
-    if rank == 0 and args.profile_steps > 0:
-        shard0_steps = [s_ for s_ in range(args.warmup, total_steps) if s_ % S == 0]
-        eng.profile(True)
-        eng.profile_read()
-        with torch.cuda.stream(stream):
-            for j in range(args.profile_steps):
-                eng.eval_dev(batches[shard0_steps[j % len(shard0_steps)]].c, scratch.c)
-        prof = eng.profile_read()
-        eng.profile(False)
-        kernel_ms = {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
-        cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo] and v > 0}
-        dom = max(cand, key=cand.get)
-        dom_bytes = KERNEL_BYTES[args.algo][dom] * B
-        achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.algo, {}).get(dom)
-            except Exception:
-                traffic = None
-        step_ms_events = ev_ms / args.steps
-        # measured ceilings of this GPU (tools/hbm_peak.hip -> profiles/hbm_peak.json) and the HBM traffic of one batch
-        # from the PMC passes (profiles/roofline_traffic.json): how close the pipeline runs to what random access allows
-        measured = None
-        try:
-            hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
-            tj = json.load(open(tpath))
-            cor = sum(tj.get(args.algo, {}).get(k, 0) for k in KERNEL_BYTES[args.algo])
-            raw = sum(tj.get(args.algo + "_raw", {}).get(k, 0) for k in KERNEL_BYTES[args.algo])
-            if cor and raw:
-                g_raw, g_cor = (x / (step_ms_events * 1e-3) / 1e9 for x in (raw, cor))
-                measured = {"stream_read_GBps": hp["stream_read_GBps"], "random_gather_GBps": hp["random_gather_128B_GBps"],
-                            "hbm_traffic_bytes_per_batch": {"raw": raw, "corrected": cor},
-                            "hbm_traffic_GBps": {"raw": round(g_raw, 1), "corrected": round(g_cor, 1)},
-                            "frac_of_random_gather": {"raw": round(g_raw / hp["random_gather_128B_GBps"], 4),
-                                                      "corrected": round(g_cor / hp["random_gather_128B_GBps"], 4)}}
-        except Exception:
-            measured = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": dom_bytes,
-                    "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items()},
-                    "measured_ceilings": measured,
-                    "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
-                                 "ms_per_batch_events": round(step_ms_events, 5),
-                                 "achieved": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9, 2),
-                                 "frac": round(BYTES_PER_DECISION[args.algo] * B / (step_ms_events * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)}}
-
-    # ---- single-batch latency: submit -> complete, one batch in flight (BASELINE metric: p99 batch latency) ----
-    latency = None
-    if rank == 0 and not GSYNC:
-        lat = []
-        shard0 = [s_ for s_ in range(args.warmup, total_steps) if s_ % S == 0]
-        with torch.cuda.stream(stream):
-            for j in range(min(200, 4 * len(shard0))):
-                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                eng.eval_dev(batches[shard0[j % len(shard0)]].c, scratch.c)
-                b_.record(stream)
-                b_.synchronize()
-                lat.append(a.elapsed_time(b_) * 1e3)
-        lat.sort()
-        latency = {"unit": "us", "p50": round(lat[len(lat) // 2], 2), "p99": round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 2),
-                   "min": round(lat[0], 2), "n": len(lat), "what": "one 65536-request batch, HIP events around guber_eval_batch_dev, nothing else in flight"}
-
-    # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
-    cpu = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not GSYNC:
-        import support
-        threads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
-        orc = support.Oracle(cache_size=4 * K, workers=threads)
-        for lo in range(0, nk, 1 << 18):
-            orc.eval(streams.bench_batch(table, my_ids[lo:lo + (1 << 18)], NOW0, hits=0, algorithm=algo_id), threads=threads)
-        nb = min(args.cpu_batches, total_steps)
-        hb = [streams.bench_batch(table, host_ids[s], NOW0 + 1 + s, algorithm=algo_id) for s in range(nb)]
-        # parity gate: the GPU's answers for the first KEEP batches of this very stream
-        ok = True
-        c0 = time.perf_counter()
-        outs = [orc.eval(hb[s], threads=threads) for s in range(nb)]
-        c1 = time.perf_counter()
-        for s in range(KEEP):
-            try:
-                support.assert_results_equal(kept[s].host(), outs[s], f"bench batch {s}")
-            except AssertionError as ex:
-                ok = False
-                print("PARITY FAILURE:", ex, file=sys.stderr)
-        parity = "bit-exact vs oracle on the first %d batches" % KEEP if ok else "FAILED"
-        mt = nb * B / (c1 - c0)
-        # single-thread leg on a fresh, smaller sample of the same stream
-        nb1 = max(4, nb // 4)
-        c0 = time.perf_counter()
-        for s in range(nb1):
-            orc.eval(hb[s])
-        c1 = time.perf_counter()
-        st = nb1 * B / (c1 - c0)
-        cpu = {"value": round(mt, 1), "unit": "decisions/s", "cores": threads, "kind": "port",
-               "sample": f"{nb} batches of {B} from the same stream, {K} resident keys, oracle in the reference's "
-                         f"worker-sharded design ({threads} workers/threads); single thread: {round(st, 1)} decisions/s "
-                         f"over {nb1} batches",
-               "single_thread_value": round(st, 1)}
-        if not ok:
-            raise SystemExit("parity gate failed: refusing to report a number")
-
+    wall = ctx.max_over_ranks(time.perf_counter() - t0)
+    ctx.barrier()
     if rank == 0:
-        out = {
-            "metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)",
-            "value": round(value, 1), "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
-            "config": {"workload": f"{K} resident keys per GPU, {args.dist} key popularity"
-                                   + (" s=1.1" if args.dist == "zipf" else "") +
-                                   f", batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, "
-                                   f"{world}xMI355X" + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
-                                   + (f", {S} logical shards per GPU (own table + stream each, batches routed by the same hash)" if S > 1 else ""),
-                       "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
-                       "logical_shards_per_gpu": S,
-                       "host_cores": os.cpu_count()},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
-        }
-        if GSYNC:
-            timed = sync_stats[args.warmup // GSYNC:] or sync_stats
-            out["config"]["workload"] += f", GLOBAL behaviour, sync every {GSYNC} batches"
-            out["global_sync"] = {"every_batches": GSYNC, "syncs": len(sync_stats),
-                                  "avg_ms": round(sum(x["ms"] for x in timed) / max(len(timed), 1), 3),
-                                  "avg_rows_broadcast": int(sum(x["broadcast"] for x in timed) / max(len(timed), 1)),
-                                  "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
-                                  "bytes_moved_rank0": gsync.bytes_moved,
-                                  "exchange": "host-staged" if args.global_host else "device-resident (RCCL on HBM rows)"}
+        timed = sync_stats[args.warmup // GSYNC:] or sync_stats
+        out = {"metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)", "value": round(args.steps * B * world / wall, 1),
+               "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
+               "config": {"workload": f"{K} keys replicated on every GPU, {args.dist} stream, batch={B}, {args.algo.upper()}_BUCKET, GLOBAL behaviour, "
+                                      f"sync every {GSYNC} batches, {world}xMI355X", "keys_per_gpu": K, "batch": B, "resident_items_rank0": int(resident)},
+               "global_sync": {"every_batches": GSYNC, "syncs": len(sync_stats),
+                               "avg_ms": round(sum(x["ms"] for x in timed) / max(len(timed), 1), 3),
+                               "avg_rows_broadcast": int(sum(x["broadcast"] for x in timed) / max(len(timed), 1)),
+                               "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
+                               "bytes_moved_rank0": gsync.bytes_moved,
+                               "exchange": "host-staged" if args.global_host else "device-resident (RCCL on HBM rows)"}}
         print(json.dumps(out))
-    for e_ in engines:
-        e_.close()
+    rig.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_eval_batches_dev", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS = 1, 2, 4, 8, 16
@@ -55,6 +55,7 @@ def lib():
         L.guber_engine_destroy.restype = None
         for name in ("guber_eval_batch", "guber_eval_batch_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult)]
+        L.guber_eval_batches_dev.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_add_items.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_uint32, C.c_void_p]
         L.guber_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
                                      C.POINTER(C.c_int)]
@@ -239,6 +240,10 @@ class Engine:
     def eval_dev(self, batch_struct, result_struct):
         """GuberBatch / GuberResult whose pointers are DEVICE pointers; asynchronous."""
         _check(lib().guber_eval_batch_dev(self.h, C.byref(batch_struct), C.byref(result_struct)))
+
+    def eval_many_dev(self, batch_array, result_array, count):
+        """ctypes arrays of GuberBatch / GuberResult (device pointers): enqueue `count` batches back to back."""
+        _check(lib().guber_eval_batches_dev(self.h, batch_array, result_array, count, None))
 
     # -- cache operations -----------------------------------------------------------------------
     def add_item(self, item, now_ms=0):

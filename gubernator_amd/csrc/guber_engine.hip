@@ -250,7 +250,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
 #ifdef GUBER_PHASE_TIMING
     if (e->dbg_n) {
-        static const char* names[2][8] = {{"entry", "stage 1 done (probe)", "claims done", "verify+snapshot done", "grouping done", "end", "key_off loaded", "key hashed"},
+        static const char* names[2][8] = {{"entry", "grouped in LDS", "claimed + published", "requests compared", "probe + verify done", "end (all drained)", "key_off loaded", "key hashed"},
                                           {"entry", "loads issued+prepass", "after barrier", "eval done", "end", "", "", ""}};
         for (int kern = 0; kern < 2; ++kern) {
             fprintf(stderr, "[phase timing] %s over %llu full batches (us since the first workgroup's entry: avg over workgroups / last workgroup)\n",
@@ -408,6 +408,29 @@ extern "C" int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* b, g
     ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
     r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
     return launch_batch(e, B, R);
+}
+
+extern "C" int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* batches, guber_result_t* results, uint32_t count,
+                                      uint32_t* done) {
+    if (done) *done = 0;
+    if (!e || (count && (!batches || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    for (uint32_t k = 0; k < count; ++k) {
+        const int rc = check_batch_args(&batches[k], &results[k]);
+        if (rc) return rc;
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    for (uint32_t k = 0; k < count; ++k) {
+        const guber_batch_t* b = &batches[k]; guber_result_t* r = &results[k];
+        BatchView B{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                    b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
+        ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
+        r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+        const int rc = launch_batch(e, B, R);
+        if (rc) return rc;
+        if (done) *done = k + 1;
+    }
+    return GUBER_OK;
 }
 
 // Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of

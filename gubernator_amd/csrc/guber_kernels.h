@@ -262,6 +262,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         }
     }
 
+    GB_STAMP(3);
     // ---- stage 4 (heads): finish the directory probe, verify the stored key, snapshot ------------------------------
     if (khead && !W.careful) {
         const unsigned long long tag = gk;
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         // head — the inserter included — has compared its key with the claimer's request, so the key that ends up
         // stored is provably the segment's key.
     }
+    GB_STAMPW(4);
     if (khead) sslot[tid] = slot;
     if (soft_leaky) soft_any = 1u;
     uint8_t rf = 0;
@@ -339,9 +341,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     if (my_flags) atomicOr(&seg_flags[d], my_flags);
     const int ins = block_sum_lds(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
-    GB_STAMP(3);
-    GB_STAMP(4);
-    GB_STAMP(5);
+    GB_STAMPW(5);
 }
 
 struct EvalArgs { Table T; BatchView B; ResultView R; Work W; };

@@ -184,6 +184,13 @@ int guber_eval_batch(guber_engine_t* e, const guber_batch_t* batch, guber_result
  * the host).  Asynchronous on the engine stream. */
 int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_result_t* result);
 
+/* A queue of device-resident batches enqueued back to back on the engine stream in one call (what a batcher goroutine
+ * that has several full batches waiting does, peer_client.go:284-337): batches[i] -> results[i], i = 0..count-1, in
+ * order.  Asynchronous like guber_eval_batch_dev; stops at the first batch that fails to enqueue and returns its code
+ * (*done, optional, receives the number of batches enqueued). */
+int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* batches, guber_result_t* results, uint32_t count,
+                           uint32_t* done);
+
 /* ---- WorkerPool.AddCacheItem (workers.go:537; callers gubernator.go:452 UpdatePeerGlobals,
  *      workers.go:329 Load).  Add semantics = LRUCache.Add (lrucache.go:88): replace if present.
  *      existed[i] (optional) receives Add's return value. */
