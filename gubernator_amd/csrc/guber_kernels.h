@@ -113,19 +113,79 @@ __device__ __forceinline__ uint32_t claim_key(unsigned long long* claims, uint32
 // per-request word handed from k_front to k_eval2: segment id | thread of the (segment, tile) group's head | rank in group
 __device__ __forceinline__ uint32_t pack_dl(uint32_t d, uint32_t head_tid, uint32_t rank) { return (d << 16) | (head_tid << 8) | rank; }
 
+// exact comparison of two request keys of the batch given their offsets and lengths (keys <= 64 bytes: every load is
+// issued before any is consumed; longer keys loop)
+__device__ __forceinline__ bool req_key_equal_at(const BatchView& B, uint32_t oa, uint32_t la, uint32_t ob, uint32_t lb) {
+    if (la != lb) return false;
+    const uint8_t* pa = B.key_bytes + oa; const uint8_t* pb = B.key_bytes + ob;
+    const uint32_t nw = (la + 7) >> 3;
+    if (nw <= 8) {
+        uint64_t diff = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; ++w) {
+            if (w < nw) {
+                uint64_t x = ld_key_word(pa + 8 * w) ^ ld_key_word(pb + 8 * w);
+                if (w == nw - 1) x &= tail_mask(la - 8 * w);
+                diff |= x;
+            }
+        }
+        return diff == 0;
+    }
+    for (uint32_t w = 0; w < nw; ++w) {
+        uint64_t x = ld_key_word(pa + 8 * w) ^ ld_key_word(pb + 8 * w);
+        if (w == nw - 1) x &= tail_mask(la - 8 * w);
+        if (x) return false;
+    }
+    return true;
+}
+// SEG_* bits a request raises on its segment when its fields differ from the reference request's; soft = the requests
+// differ only in created_at on a leaky bucket (decided against the bucket state by the caller)
+__device__ __forceinline__ uint32_t req_diff_flags(const BatchView& B, uint32_t ia, uint32_t ib, const Req& a, const Req& b, bool& soft_leaky) {
+    // a / b carry no calendar values (never read unless DURATION_IS_GREGORIAN is set): compare those only when it is
+    if ((a.behavior & BH_GREGORIAN) && a.behavior == b.behavior && B.greg_expire && B.greg_duration &&
+        (B.greg_expire[ia] != B.greg_expire[ib] || B.greg_duration[ia] != B.greg_duration[ib]))
+        return SEG_NONUNIFORM;
+    if (req_eq(a, b)) return 0u;
+    if (!req_eq_but_created(a, b)) return SEG_NONUNIFORM;
+    if (a.algorithm == ALGO_LEAKY) { soft_leaky = true; return 0u; }
+    return SEG_CREATED_DIFFERS;
+}
+
+// the tile's requests in LDS (structure of arrays, one 8-byte column per field): members compare themselves with
+// their head without touching global memory
+struct TileReqs {
+    int64_t hits[FT], limit[FT], duration[FT], burst[FT], created_at[FT];
+    unsigned long long misc[FT];          // behavior | algorithm << 32 | is_owner << 40
+    // (the calendar values of DURATION_IS_GREGORIAN requests stay in global memory: they are compared only when the bit is set)
+};
+__device__ __forceinline__ void tile_put(TileReqs& t, uint32_t i, const Req& r) {
+    t.hits[i] = r.hits; t.limit[i] = r.limit; t.duration[i] = r.duration; t.burst[i] = r.burst; t.created_at[i] = r.created_at;
+    t.misc[i] = (unsigned long long)r.behavior | ((unsigned long long)r.algorithm << 32) | ((unsigned long long)r.is_owner << 40);
+}
+__device__ __forceinline__ Req tile_get(const TileReqs& t, uint32_t i) {
+    Req r;
+    r.hits = t.hits[i]; r.limit = t.limit[i]; r.duration = t.duration[i]; r.burst = t.burst[i]; r.created_at = t.created_at[i];
+    r.greg_expire = 0; r.greg_duration = 0;
+    const unsigned long long m = t.misc[i];
+    r.behavior = (uint32_t)m; r.algorithm = (uint8_t)(m >> 32); r.is_owner = (uint8_t)(m >> 40);
+    return r;
+}
+
 __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
     __shared__ unsigned long long gkey[GT];                       // grouping key (0 = free)
     __shared__ unsigned long long gbits[FT / 64][GT];             // per wave: lanes holding the entry's key
     __shared__ uint32_t sd[FT];                                   // head -> segment id
     __shared__ uint32_t sslot[FT];                                // head -> bucket slot (for the rare member that needs the bucket)
+    __shared__ uint32_t soff[FT], slen[FT];                       // where each request's key lives (members fetch their head's key)
+    __shared__ TileReqs sreq;
     __shared__ int red[FT / 64];
     __shared__ uint32_t soft_any;
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
-    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
+    const uint32_t e16 = W.epoch16;
 
     GB_STAMP(0);
     if (tid == 0) soft_any = 0u;
@@ -134,8 +194,9 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
 #pragma unroll
         for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
     }
-    // ---- stage 0: key -> hash.  Grouping key gk: the 64-bit hash; in a careful (retry) round the verified slot ----
-    uint32_t errcode = 0, len = 0, slot = 0;
+    // ---- stage 0: key -> hash.  Grouping key gk: the 64-bit hash; in a careful (retry) round the verified slot.  The
+    // request's own fields are requested first: they arrive while the key is fetched and hashed and go to LDS ----
+    uint32_t errcode = 0, off = 0, len = 0, slot = 0;
     int inserted = 0;
     bool cand = false, ready = false;
     const uint8_t* key = nullptr;
@@ -143,7 +204,8 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     uint64_t h = 0;
     Rec rec; rec_clear(rec);
     if (valid) {
-        const uint32_t off = B.key_off[g];
+        const Req mine = load_req_nogreg(B, g);
+        off = B.key_off[g];
         len = B.key_off[g + 1] - off;
         key = B.key_bytes + off;
         if (len == 0) errcode = IE_EMPTY_KEY;
@@ -163,8 +225,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
                 gk = h ? h : 1ull;
             }
         }
+        tile_put(sreq, tid, mine);
         GB_STAMPW(7);
     }
+    soff[tid] = off; slen[tid] = len;
     lds_barrier();
     // ---- stage 1: group the tile by gk through an LDS hash table with per-wave member bitmaps: a request's rank
     // inside its (key, tile) group, the group size and the group's first thread come from four popcounts ----
@@ -195,6 +259,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     }
     const bool head = valid && eq_before == 0;
     const bool khead = head && gk != 0ull;                           // heads that have a key to resolve
+    const bool member = valid && gk != 0ull && eq_before != 0;
     GB_STAMP(1);
 
     // ---- stage 2 (heads): look at the claim cell, start the directory + bucket fetch, claim ----------------------
@@ -202,7 +267,6 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     // requested together with the home directory entry (most resident keys sit at their home position at load <= 0.5).
     // Plain table loads: L1 may serve a line that is stale within this launch, which is safe — a stale "empty" tag is
     // corrected by the insert CAS, and READY never changes during k_front.
-    const uint32_t e16 = W.epoch16;
     uint32_t hcell = 0, fp = 0;
     unsigned long long look = 0ull;
     uint64_t pos = (h >> 7) & T.mask;
@@ -219,16 +283,23 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             rec = hb->rec;
         }
     }
+    // One key, one request shape per segment: members are compared with their tile's head, heads with the segment's
+    // claimer (equality is transitive), on the exact key bytes and on every request field.  Members: fields from LDS.
+    uint32_t my_flags = 0;                                           // SEG_* bits this request raises on its segment
+    bool soft_leaky = false;
+    if (member) my_flags |= req_diff_flags(B, g, tile * FT + head_tid, tile_get(sreq, tid), tile_get(sreq, head_tid), soft_leaky);
     uint32_t d = g;                                                  // error requests: a solo segment that only carries the code
     bool claimed = false;
     if (khead) d = claim_key(W.claims, W.cmask, hcell, look, fp, e16, g, claimed);
     if (head) sd[tid] = d;
-    // group heads publish their group: ONE atomic per (segment, tile) — set the tile's bit and add the group size (bits are
-    // set once each, so the add never carries into the count).  Its return value tells whether other tiles of this 32-tile
-    // word already hold the key — only then are per-tile counts needed (k_eval2 ranks a request by the members in earlier
-    // tiles), so the scattered count is written only for keys spanning several tiles: every arriver but the first writes
-    // its own, and the second also writes the first's (= the word's count so far, the first having been alone).
-    if (khead) {
+    // A head that is not the claimer publishes its group: ONE atomic per (segment, tile) — set the tile's bit and add the
+    // group size (bits are set once each, so the add never carries into the count).  The claimer's own group is not
+    // published: its size travels in the segment record, so a key that only one tile touches costs no atomic here and
+    // no bitmap traffic at all.  The return value tells whether other tiles of this 32-tile word already published —
+    // only then are per-tile counts needed (k_eval2 ranks a request by the members in earlier tiles), so the scattered
+    // count is written only when a word holds several published tiles: every arriver but the first writes its own, and
+    // the second also writes the first's (= the word's count so far, the first having been alone).
+    if (khead && !claimed) {
         const unsigned long long old = atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)],
                                                  ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
         const uint32_t ob = (uint32_t)old;
@@ -239,30 +310,21 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         }
     }
     lds_barrier();
-    if (valid && !head) d = sd[head_tid];
+    if (member) d = sd[head_tid];
     GB_STAMP(2);
 
-    // ---- stage 3: one key, one request shape per segment.  Members are compared with their tile's head, heads with the
-    // segment's claimer (equality is transitive), on the exact key bytes and on every request field ----------------
-    const uint32_t ref = head ? d : tile * FT + head_tid;
-    uint32_t my_flags = 0;                                           // SEG_* bits this request raises on its segment
-    bool soft_leaky = false;
-    Req a;
-    if (valid && gk && ref != g) {
-        if (!req_key_equal(B, g, ref)) my_flags |= SEG_RETRY;        // two keys under one hash / fingerprint: careful round
-        a = load_req(B, g);
-        const Req b = load_req(B, ref);
-        if (!req_eq(a, b)) {
-            // created_at-only differences keep the parallel path when created_at cannot matter: decided in k_eval2 for
-            // token buckets; a leaky request must leak nothing (checked below against the bucket as it is before the
-            // batch; the claimer's own created_at is checked in k_eval2)
-            if (!req_eq_but_created(a, b)) my_flags |= SEG_NONUNIFORM;
-            else if (a.algorithm == ALGO_LEAKY) soft_leaky = true;
-            else my_flags |= SEG_CREATED_DIFFERS;
-        }
+    // ---- stage 3: exact key comparison (member: its head's key, same tile; head: the claimer's key), and the head's
+    // request against the claimer's ----
+    if (member) {
+        if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) my_flags |= SEG_RETRY;   // two keys under one hash: careful round
+    } else if (khead && d != g) {
+        const uint32_t c_off = B.key_off[d], c_len = B.key_off[d + 1] - c_off;
+        const Req cq = load_req_nogreg(B, d);
+        if (!req_key_equal_at(B, off, len, c_off, c_len)) my_flags |= SEG_RETRY;   // two keys under one claim fingerprint
+        my_flags |= req_diff_flags(B, g, d, tile_get(sreq, tid), cq, soft_leaky);
     }
-
     GB_STAMP(3);
+
     // ---- stage 4 (heads): finish the directory probe, verify the stored key, snapshot ------------------------------
     if (khead && !W.careful) {
         const unsigned long long tag = gk;
@@ -326,19 +388,28 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     if (valid) {
         if (errcode) { my_flags |= SEG_ERR | (errcode << 8); rf = RF_ERR; }
         if (inserted) { rf |= RF_INSERTED; W.slot[g] = slot; }
-        if (claimed && !errcode) { W.seg_slot[d] = slot; W.snap[d] = rec; }   // the claimer snapshots the bucket
+        if (claimed && !errcode) {
+            // the claimer writes the segment record: the bucket before the batch, its slot, the size of the claimer's own
+            // group — 56 bytes; the flags word next to them is only ever touched by seg_raise
+            SegRec* sr = &W.srec[d];
+            ulonglong2* q = (ulonglong2*)sr;
+            q[0] = make_ulonglong2((unsigned long long)rec.limit, (unsigned long long)rec.duration);
+            q[1] = make_ulonglong2((unsigned long long)rec.remaining, (unsigned long long)rec.stamp);
+            q[2] = make_ulonglong2((unsigned long long)rec.burst, (unsigned long long)rec.expire_at);
+            *(unsigned long long*)&sr->smeta = (unsigned long long)pack_smeta(rec, eq_total) | ((unsigned long long)slot << 32);
+            if (rec.invalid_at != 0) W.sinv[d] = rec.invalid_at;
+        }
         W.did[g] = pack_dl(d, head_tid, eq_before);
         W.rflags[g] = rf;
     }
     lds_barrier();
     if (soft_any) {                                                  // rare: requests of a leaky key stamped differently
         if (soft_leaky) {
-            Rec cur = rec;
-            if (!head) cur = T.buckets[sslot[head_tid]].rec;
-            my_flags |= leaky_created_harmless(cur, a, B.now_ms) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM;
+            const Rec cur = T.buckets[head ? slot : sslot[head_tid]].rec;
+            my_flags |= leaky_created_harmless(cur, tile_get(sreq, tid), B.now_ms) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM;   // (declines GREGORIAN requests)
         }
     }
-    if (my_flags) atomicOr(&seg_flags[d], my_flags);
+    if (my_flags) seg_raise(&W.srec[d], e16, my_flags);
     const int ins = block_sum_lds(inserted, red);
     if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
     GB_STAMPW(5);
@@ -353,32 +424,39 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
     const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
     __shared__ unsigned long long cnt[4];
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    uint32_t* seg_flags = W.seg_flags2 + (size_t)W.parity * B.n_cap;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
+    const uint32_t e16 = W.epoch16;
     GB_STAMP2(0);
-    {   // clear, for the next batch, the entries of the other copy that the previous batch used
-        uint32_t* of = W.seg_flags2 + (size_t)(W.parity ^ 1u) * B.n_cap;
-        uint4* om = (uint4*)(W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS);
-        const uint4 z = {0, 0, 0, 0};
+    {   // clear, for the next batch, what the previous batch's publishers added to the other copy of the tile bitmaps: a
+        // publisher = the head of a (segment, tile) group that is not the segment's claimer; it zeroes the word it added to
+        unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
         for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
-            if ((W.did_prev[j] >> 16) == (j & 0xffffu)) {
-                of[j] = 0;
-#pragma unroll
-                for (int q = 0; q < FT_WORDS / 2; ++q) om[(size_t)j * (FT_WORDS / 2) + q] = z;
-            }
+            const uint32_t pd = W.did_prev[j];
+            if ((pd & 0xffu) == 0u && (pd >> 16) != j) om[(size_t)(pd >> 16) * FT_WORDS + (j / FT >> 5)] = 0ull;
         }
     }
-    // pre-pass: the head of every (segment, tile) group computes the group's base = members of the
-    // segment in earlier tiles, and the segment's total, from the bitmap and the per-tile counts; the
-    // other members pick both up from LDS (eval workgroup == tile, FT == 256).
+    // pre-pass: the head of every (segment, tile) group computes the group's base = members of the segment in earlier
+    // tiles, and the segment's total, from the claimer's group (segment record), the bitmap and the per-tile counts of the
+    // published groups; the other members pick both up from LDS (eval workgroup == tile, FT == 256).
     __shared__ uint32_t sbase[FT], stotal[FT];
     const bool live = i < B.n;
     const uint32_t dl = live ? W.did[i] : 0u;
     const uint32_t d = dl >> 16, lr = dl & 0xffffu;
     // everything that depends only on (i, d) is requested now, so that these loads are in flight together
     // with the heads' bitmap loads below instead of after the barrier
-    uint32_t sf = 0, slot = 0; uint8_t rf = 0; Req r; Rec s0;
-    if (live) { sf = seg_flags[d]; rf = W.rflags[i]; slot = W.seg_slot[d]; r = load_req_nogreg(B, i); s0 = W.snap[d]; }
+    uint32_t sf = 0, slot = 0, smeta = 0; uint8_t rf = 0; Req r; Rec s0;
+    rec_clear(s0);
+    if (live) {
+        rf = W.rflags[i];
+        r = load_req_nogreg(B, i);
+        const ulonglong2* q = (const ulonglong2*)&W.srec[d];             // one 64-byte sector: bucket, slot, flags
+        const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        s0.limit = (int64_t)q0.x; s0.duration = (int64_t)q0.y; s0.remaining = (int64_t)q1.x; s0.stamp = (int64_t)q1.y;
+        s0.burst = (int64_t)q2.x; s0.expire_at = (int64_t)q2.y;
+        smeta = (uint32_t)q3.x; slot = (uint32_t)(q3.x >> 32);
+        s0.meta = smeta_meta(smeta);
+        sf = seg_flags_of(q3.y, e16);
+    }
     if (live && (lr & 0xffu) == 0u) {
         const uint32_t t = i / FT;
         const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip
@@ -389,27 +467,32 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
             sw[2 * q] = ((unsigned long long)v.y << 32) | v.x; sw[2 * q + 1] = ((unsigned long long)v.w << 32) | v.z;
         }
         const uint32_t mw = t >> 5, mb = t & 31;
-        uint32_t base = 0, total = 0, below = 0;
+        const uint32_t ct = d / FT, cc = smeta_group(smeta);               // the claimer's tile and its group (not in the bitmap)
+        uint32_t base = ct < t ? cc : 0u, total = cc, below = 0, wcount = 0, wbits = 0;
 #pragma unroll
         for (uint32_t w = 0; w < FT_WORDS; ++w) {
             const uint32_t c = (uint32_t)(sw[w] >> 32);
             total += c;
             base += w < mw ? c : 0u;
-            if (w == mw) below = (uint32_t)sw[w] & ((1u << mb) - 1u);
+            if (w == mw) { wbits = (uint32_t)sw[w]; wcount = c; below = wbits & ((1u << mb) - 1u); }
         }
         if (below) {
-            // members in earlier tiles of my own 32-tile word: their per-tile counts (u16, 64 bytes), masked by the bitmap
-            const uint4* r4 = (const uint4*)(W.tilerow + (size_t)d * FT_MAX_TILES + mw * 32);
-            uint4 v[4];
+            if ((wbits & (wbits - 1u)) == 0u) {
+                base += wcount;                                            // the word holds one published tile: the count is its
+            } else {
+                // several published tiles in my 32-tile word: their per-tile counts (u16, 64 bytes), masked by the bitmap
+                const uint4* r4 = (const uint4*)(W.tilerow + (size_t)d * FT_MAX_TILES + mw * 32);
+                uint4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = r4[q];
+                for (int q = 0; q < 4; ++q) v[q] = r4[q];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t w4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    base += ((below >> (q * 8 + e * 2)) & 1u) ? (w4[e] & 0xffffu) : 0u;
-                    base += ((below >> (q * 8 + e * 2 + 1)) & 1u) ? (w4[e] >> 16) : 0u;
+                    for (int e = 0; e < 4; ++e) {
+                        base += ((below >> (q * 8 + e * 2)) & 1u) ? (w4[e] & 0xffffu) : 0u;
+                        base += ((below >> (q * 8 + e * 2 + 1)) & 1u) ? (w4[e] >> 16) : 0u;
+                    }
                 }
             }
         }
@@ -428,6 +511,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
             store_err(R, i, IE_RETRY);
             atomicAdd(&T.ctr->retries, 1ull);
         } else {
+            if (smeta & SM_HAS_INVALID) s0.invalid_at = W.sinv[d];
             const uint32_t base = sbase[lr >> 8], total = stotal[lr >> 8];
             const uint32_t rank = base + (lr & 0xffu);
             // requests differing only in created_at still take the parallel path when created_at cannot matter: live
@@ -478,7 +562,11 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
                                 if ((id >> 16) == d) { j = tt * FT + q; found = true; }
                                 q++;
                             } else {
-                                while (mm == 0u && wv < FT_WORDS) { mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + wv]; tt = wv * 32; wv++; }
+                                while (mm == 0u && wv < FT_WORDS) {
+                                    mm = (uint32_t)seg_mask[(size_t)d * FT_WORDS + wv];
+                                    if (wv == (d / FT >> 5)) mm |= 1u << (d / FT & 31);      // the claimer's tile is not published
+                                    tt = wv * 32; wv++;
+                                }
                                 if (mm == 0u) end = true;
                                 else { const uint32_t bpos = (uint32_t)__ffs((int)mm) - 1u; mm &= mm - 1u; tt = (tt & ~31u) + bpos; q = 0; }
                             }

@@ -67,6 +67,28 @@ struct BatchView {
 };
 struct ResultView { uint8_t* status; int64_t *limit, *remaining, *reset_time; uint8_t* err; };
 
+// Per-batch record of one segment (= one key of the batch) in the two-launch pipeline, indexed by the request index of the
+// key's first toucher ("claimer"): the bucket as it was before the batch, where it lives, how many requests the claimer's
+// own (key, tile) group has, and the segment's flags — everything k_eval2 needs for a key that only one tile touches, in
+// ONE 64-byte sector written by ONE thread.  `flags` is the only word other threads write (CAS, tagged with the 16-bit
+// claim epoch so that it never has to be cleared); the claimer stores the 56 bytes before it and leaves it alone.
+// CacheItem.InvalidAt does not fit: a bucket that has one (only Store / Loader items do) sets SM_HAS_INVALID and the
+// value travels in a side array.
+struct alignas(64) SegRec {
+    int64_t limit, duration, remaining, stamp, burst, expire_at;
+    uint32_t smeta;                  // kind (2 bits) | status << 2 | SM_HAS_INVALID | algorithm << 8 | (claimer group size - 1) << 16
+    uint32_t slot;
+    unsigned long long flags;        // epoch16 << 48 | SEG_* bits (error code in bits 8..15)
+};
+static_assert(sizeof(SegRec) == 64, "one segment record = one 64-byte sector");
+enum : uint32_t { SM_HAS_INVALID = 8 };
+GB_HD uint32_t pack_smeta(const Rec& s, uint32_t group_size) {
+    return (rec_kind(s) & 3u) | ((rec_status(s) & 1u) << 2) | (s.invalid_at != 0 ? SM_HAS_INVALID : 0u) | ((rec_algo(s) & 0xffu) << 8) |
+           (((group_size - 1u) & 0xffu) << 16);
+}
+GB_HD uint32_t smeta_group(uint32_t m) { return ((m >> 16) & 0xffu) + 1u; }
+GB_HD uint32_t smeta_meta(uint32_t m) { return make_meta(m & 3u, (m >> 2) & 1u, (m >> 8) & 0xffu); }
+
 // request flags written by k_resolve
 enum : uint8_t { RF_INSERTED = 1, RF_NEED_VERIFY = 2, RF_ERR = 4 };
 // segment flags
@@ -103,12 +125,13 @@ struct Work {
     uint32_t epoch;        // 1 .. 2^31-1
     // tile-bitmap grouping (batches of <= FT_MAX_TILES tiles of FT requests): per segment a bitmap of the tiles holding its
     // requests and, per (segment, tile), the group's size and start inside the tile's sorted order.
-    // seg_flags / seg_tilemask are double-buffered by batch parity: a batch's eval kernel clears the
-    // other copy for the next batch, so no memset launch is needed.
+    // seg_tilemask is double-buffered by batch parity: a batch's eval kernel clears, in the other copy, the words the
+    // previous batch's publishers added to, so no memset launch is needed.
     unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
     uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
-    uint32_t* seg_flags2;               // [2][cap]
     uint16_t* tilerow;                  // [cap][FT_MAX_TILES]: members per (segment, tile) — written only for keys that span several tiles of a word
+    SegRec* srec;                       // [cap] segment records of the two-launch pipeline
+    int64_t* sinv;                      // [cap] CacheItem.InvalidAt of the segments whose record says SM_HAS_INVALID
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
@@ -117,6 +140,22 @@ struct Work {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// raise SEG_* bits on a segment record (rare: errors, hash collisions, requests of one key that differ)
+__device__ __forceinline__ void seg_raise(SegRec* r, uint32_t e16, uint32_t bits) {
+    unsigned long long* p = &r->flags;
+    unsigned long long cur = ld_agent(p);
+    for (;;) {
+        const unsigned long long base = (uint32_t)(cur >> 48) == e16 ? cur : ((unsigned long long)e16 << 48);
+        const unsigned long long want = base | bits;
+        if (want == cur) return;
+        const unsigned long long old = atomicCAS(p, cur, want);
+        if (old == cur) return;
+        cur = old;
+    }
+}
+__device__ __forceinline__ uint32_t seg_flags_of(unsigned long long w, uint32_t e16) {
+    return (uint32_t)(w >> 48) == e16 ? (uint32_t)w : 0u;
 }
 __device__ __forceinline__ uint64_t ld_key_word(const uint8_t* p) {
     uint64_t v; __builtin_memcpy(&v, p, 8); return v;
