@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_eval_batches_dev", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_eval_batches_dev", "guber_set_clock", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS = 1, 2, 4, 8, 16
@@ -67,6 +67,7 @@ def lib():
         L.guber_stats.argtypes = [C.c_void_p, C.POINTER(GuberStats)]
         L.guber_synchronize.argtypes = [C.c_void_p]
         L.guber_compact.argtypes = [C.c_void_p, C.c_int64]
+        L.guber_set_clock.argtypes = [C.c_void_p, C.c_int64]
         L.guber_probe_missing.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.c_void_p]
         L.guber_eval_batch_store.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.POINTER(abi.GuberStoreEvents)]
         L.guber_global_take.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(abi.GuberGlobalRows)]
@@ -247,6 +248,8 @@ class Engine:
 
     # -- cache operations -----------------------------------------------------------------------
     def add_item(self, item, now_ms=0):
+        if now_ms:
+            lib().guber_set_clock(self.h, now_ms)       # the clock Add's eviction classifies expired items against
         ex = (C.c_uint8 * 1)()
         _check(lib().guber_add_items(self.h, C.byref(item), 1, ex))
         return bool(ex[0])
@@ -280,6 +283,11 @@ class Engine:
         arena = C.create_string_buffer(acap)
         _check(lib().guber_dump(self.h, items, cap, arena, acap, C.byref(n), C.byref(a)))
         return [item_dict(items[i]) for i in range(n.value)]
+
+    def counters(self):
+        """(over_limit, cache_hits, cache_misses, unexpired_evictions, size) — the tuple HostResult.counters() has"""
+        st = self.stats()
+        return (st["over_limit_count"], st["cache_hits"], st["cache_misses"], st["unexpired_evictions"], st["cache_size"])
 
     def stats(self):
         s = GuberStats()
@@ -320,6 +328,10 @@ class Engine:
 
     def compact(self, now_ms):
         _check(lib().guber_compact(self.h, now_ms))
+
+    def set_clock(self, now_ms):
+        """clock.Freeze / clock.Advance for maintenance between batches (eviction after Add)"""
+        _check(lib().guber_set_clock(self.h, now_ms))
 
     def synchronize(self):
         _check(lib().guber_synchronize(self.h))

@@ -106,6 +106,13 @@ struct guber_engine {
     uint32_t epoch = 0;
     uint64_t batches = 0;
     uint64_t tags_upper = 0;   // host-side upper bound of ctr.tags_used
+    uint64_t size_upper = 0;   // host-side upper bound of the live items (ctr.size)
+    int64_t clock_ms = 0;      // latest `now` seen (guber_set_clock / batches / lookups): classifies evictions as expired or not
+    uint64_t evict_passes = 0;
+    uint32_t touch = 0;        // advances with every call that touches items (batch, Add, GetItem): approximate LRU order
+    // asynchronous counter read-back (maintain): enqueued when an upper bound crosses its soft limit, folded when its event
+    // has completed — the hot path never waits for it
+    hipEvent_t rb_event = nullptr; bool rb_inflight = false; uint64_t rb_added = 0;
     uint64_t compactions = 0;
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
@@ -142,6 +149,8 @@ static void fold_counters(guber_engine* e) {
     }
     e->last_ctr = c;
     e->tags_upper = c.tags_used;
+    e->size_upper = (uint64_t)std::max<long long>(c.size, 0);
+    e->rb_inflight = false; e->rb_added = 0;
 }
 static int enqueue_counter_readback(guber_engine* e) {
     HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
@@ -167,9 +176,11 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->device = cfg->device;
     if (hipSetDevice(e->device) != hipSuccess) { delete e; return fail(GUBER_E_HIP, "hipSetDevice"); }
     e->cache_size = cfg->cache_size ? cfg->cache_size : 50000;  // workers.go:126
-    e->slots = cfg->table_slots ? next_pow2(cfg->table_slots) : next_pow2(std::max<uint64_t>(2 * e->cache_size, 1024));
-    if (e->slots > (1ull << 32)) { delete e; return fail(GUBER_E_INVALID_ARG, "table_slots above 2^32"); }
     e->max_batch = cfg->max_batch ? cfg->max_batch : 65536;
+    // the cache may hold cache_size items when a batch of max_batch new keys arrives (eviction runs between batches): both fit
+    // under the directory's load limit
+    e->slots = cfg->table_slots ? next_pow2(cfg->table_slots) : next_pow2(std::max<uint64_t>(2 * (e->cache_size + std::min<uint64_t>(e->max_batch, 1u << 20)), 1024));
+    if (e->slots > (1ull << 32)) { delete e; return fail(GUBER_E_INVALID_ARG, "table_slots above 2^32"); }
     if (e->max_batch > (1u << 24)) { delete e; return fail(GUBER_E_INVALID_ARG, "max_batch above 2^24"); }
     e->max_key = cfg->max_key_bytes ? cfg->max_key_bytes : 1024;
     if (e->max_key > 65000) e->max_key = 65000;
@@ -223,7 +234,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->T.gpend = e->gpend.p; e->T.gdirty = e->gdirty.p; e->T.gdirty_cap = gdirty_cap;
     e->T.dir = e->dir.p; e->T.buckets = e->buckets.p; e->T.arena = e->arena.p;
     e->T.mask = e->slots - 1; e->T.arena_cap = arena_cap; e->T.ctr = e->ctr.p; e->T.bctr = e->bctr.p;
-    e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 16); e->T.max_key = e->max_key;
+    e->T.max_probe = (uint32_t)std::min<uint64_t>(e->slots, 1u << 12); e->T.max_key = e->max_key;
     e->T.hash_mask = (cfg->flags & GUBER_FLAG_TEST_WEAK_HASH) ? 0x1f80ull : ~0ull;   // 6 significant bits
     uint32_t* u = e->w_u32.p;
     uint32_t** fields[] = {&e->W.slot, &e->W.did, &e->W.keyA, &e->W.valA, &e->W.keyB, &e->W.valB, &e->W.pos,
@@ -274,30 +285,28 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
+    if (e->rb_event) (void)hipEventDestroy(e->rb_event);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
 static int compact_table(guber_engine* e, int64_t now_ms);
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms);
 static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R) {
     const uint32_t n = B.n;
     if (n == 0) return 0;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
-    // load guard.  tags_upper is a host-side upper bound (every request might claim a new directory
-    // entry); only when it crosses the limit is the real count read back.  A batch that would overflow
-    // anyway gets per-item GUBER_ITEM_E_TABLE_FULL from the bounded probe.
-    const uint64_t limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
-    if (e->tags_upper + n > limit) {
-        int rc = engine_refresh_counters(e);
+    if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
+    // Bounded cache and directory load.  size_upper / tags_upper are host-side upper bounds (every request might create a
+    // new item); only when one crosses its limit are the real counters read back, the least recently used items evicted
+    // (lrucache.go:98-100) and, if the directory is above its load limit, the table rebuilt without its dead entries.  A
+    // batch that still finds no room gets per-item GUBER_ITEM_E_TABLE_FULL from the bounded probe, for NEW keys only.
+    {
+        const int rc = maintain(e, n, B.now_ms);
         if (rc) return rc;
-        if (e->tags_upper >= limit && !e->T.gpend) {
-            // drop expired / removed buckets before giving up (the reference's cache would have evicted them)
-            rc = compact_table(e, B.now_ms);
-            if (rc) return rc;
-        }
-        if (e->tags_upper >= limit) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
+    e->size_upper += n; e->rb_added += n;
     e->tags_upper += n;
     if (++e->epoch >= 0x7fffffffu) {   // 31-bit epoch wrapped: drop all dense-id claims
         hipLaunchKernelGGL(k_clear_claims, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots);
@@ -306,6 +315,7 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
     const uint32_t tiles = (n + TILE - 1) / TILE;
     Work W = e->W;
     W.epoch = e->epoch;
+    W.touch = e->touch = (e->touch + 1) & 0x7fffffffu;
     W.tiles = tiles;
     if (n <= e->fast_cap && !e->force_radix) {
         // two launches: resolve + in-tile grouping, then evaluation
@@ -550,6 +560,8 @@ static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_resu
             if (rc) return rc;
         }
         fold_counters(e);
+        rc = maintain(e, 0, b->now_ms);
+        if (rc) return rc;
     }
     r->over_limit_count = e->last_ctr.over - before.over;
     r->cache_hits = e->last_ctr.hits - before.hits;
@@ -645,7 +657,7 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
         cleanup(); return fail(GUBER_E_HIP, "add_items H2D", he);
     }
     hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p);
-    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p);
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p, (e->touch = (e->touch + 1) & 0x7fffffffu));
     std::vector<uint8_t> res(n);
     if ((he = hipMemcpyAsync(res.data(), d_res.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipStreamSynchronize(st)) != hipSuccess) {
@@ -665,12 +677,11 @@ extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uin
         if (!items[i].key || items[i].key_len == 0) return fail(GUBER_E_INVALID_ARG, "item without a key");
         if (items[i].key_len > e->max_key) return fail(GUBER_E_KEY_TOO_LONG, "item key longer than max_key_bytes");
     }
-    if (e->tags_upper + n > e->slots - e->slots / 8) {
-        int rc = engine_refresh_counters(e);
+    {
+        const int rc = maintain(e, n, e->clock_ms);
         if (rc) return rc;
-        if (e->tags_upper >= e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
-    e->tags_upper += n;
+    e->tags_upper += n; e->size_upper += n; e->rb_added += n;
     // LRUCache.Add is applied item by item (workers.go:566-581): with duplicates of a key in one call
     // the LAST one must win and the later ones report existed = 1.  Waves of distinct keys keep that.
     std::vector<uint8_t> res(n, 0);
@@ -698,7 +709,7 @@ extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uin
         pending.swap(next);
     }
     if (existed) for (uint32_t i = 0; i < n; ++i) existed[i] = res[i];
-    return GUBER_OK;
+    return maintain(e, 0, e->clock_ms);       // Add evicts as soon as the cache is over its size (lrucache.go:98-100)
 }
 
 static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, int mode, guber_item_t* out, int* found) {
@@ -717,7 +728,8 @@ static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, in
     hipStream_t st = e->stream;
     hipError_t he;
     if ((he = hipMemcpyAsync(d_key.p, kb.data(), kb.size(), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup H2D", he); }
-    hipLaunchKernelGGL(k_item_lookup, dim3(1), dim3(64), 0, st, e->T, d_key.p, key_len, now_ms, mode, d_rec.p, d_found.p);
+    if (mode == 0 && now_ms > e->clock_ms) e->clock_ms = now_ms;
+    hipLaunchKernelGGL(k_item_lookup, dim3(1), dim3(64), 0, st, e->T, d_key.p, key_len, now_ms, mode, d_rec.p, d_found.p, (e->touch = (e->touch + 1) & 0x7fffffffu));
     if ((he = hipMemcpyAsync(&hfound, d_found.p, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipMemcpyAsync(&hrec, d_rec.p, sizeof(Rec), hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipStreamSynchronize(st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup D2H", he); }
@@ -740,6 +752,8 @@ extern "C" int guber_stats(guber_engine_t* e, guber_stats_t* out) {
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     int rc = engine_refresh_counters(e);
+    if (rc) return rc;
+    rc = maintain(e, 0, e->clock_ms);
     if (rc) return rc;
     const DevCounters& c = e->last_ctr;
     out->over_limit_count = c.over; out->cache_hits = c.hits; out->cache_misses = c.misses;
@@ -915,19 +929,18 @@ extern "C" int guber_add_items_dev(guber_engine_t* e, const guber_items_dev_t* i
         return fail(GUBER_E_INVALID_ARG, "item column missing");
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    if (e->tags_upper + n > e->slots - e->slots / 8) {
-        int rc = engine_refresh_counters(e);
+    {
+        const int rc = maintain(e, n, e->clock_ms);
         if (rc) return rc;
-        if (e->tags_upper >= e->slots - e->slots / 8) return fail(GUBER_E_TABLE_FULL, "bucket directory above its load limit");
     }
-    e->tags_upper += n;
+    e->tags_upper += n; e->size_upper += n; e->rb_added += n;
     if (e->d_items.ensure(n) || e->d_islots.ensure(n) || e->d_iflags.ensure(n)) return GUBER_E_NOMEM;
     ItemsSoA S{it->key_off, it->algorithm, it->status, it->limit, it->duration, it->remaining, it->remaining_f, it->stamp, it->burst,
                it->expire_at, it->invalid_at};
     hipStream_t st = e->stream;
     hipLaunchKernelGGL(k_items_from_soa, dim3((n + 255) / 256), dim3(256), 0, st, S, n, e->d_items.p);
     hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p);
-    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p, result);
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p, result, (e->touch = (e->touch + 1) & 0x7fffffffu));
     HIPCHK(hipGetLastError());
     return GUBER_OK;
 }
@@ -975,47 +988,141 @@ extern "C" int guber_global_take(guber_engine_t* e, uint32_t role_mask, guber_gl
     return GUBER_OK;
 }
 
-// Rebuild the table keeping only live buckets.  Called explicitly (guber_compact) or automatically by
-// launch_batch when the directory is above its load limit.
+// Rebuild the table keeping only live buckets (and buckets with pending GLOBAL work).  Called explicitly (guber_compact) or
+// by maintain() when the directory is above its load limit.
 static int compact_table(guber_engine* e, int64_t now_ms) {
     quiesce_all(e);
-    DevBuf<DirEntry> ndir; DevBuf<Bucket> nb; DevBuf<unsigned long long> kept;
-    int rc = ndir.ensure(e->slots) | nb.ensure(e->slots) | kept.ensure(1);
-    if (rc) { ndir.release(); nb.release(); kept.release(); return GUBER_E_NOMEM; }
+    DevBuf<DirEntry> ndir; DevBuf<Bucket> nb; DevBuf<uint8_t> narena; DevBuf<GPend> ngp; DevBuf<CompactOut> d_out;
+    int rc = ndir.ensure(e->slots) | nb.ensure(e->slots) | narena.ensure(e->T.arena_cap + 64) | d_out.ensure(1);
+    if (e->T.gpend) rc |= ngp.ensure(e->slots);
+    auto cleanup = [&]() { ndir.release(); nb.release(); narena.release(); ngp.release(); d_out.release(); };
+    if (rc) { cleanup(); return GUBER_E_NOMEM; }
     hipError_t he;
     if ((he = hipMemsetAsync(ndir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(nb.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
-        (he = hipMemsetAsync(kept.p, 0, sizeof(unsigned long long), e->stream)) != hipSuccess) {
-        ndir.release(); nb.release(); kept.release();
+        (he = hipMemsetAsync(d_out.p, 0, sizeof(CompactOut), e->stream)) != hipSuccess ||
+        (ngp.p && (he = hipMemsetAsync(ngp.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess)) {
+        cleanup();
         return fail(GUBER_E_HIP, "compaction", he);
     }
     Table N = e->T;
-    N.dir = ndir.p; N.buckets = nb.p;
-    hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots, N, now_ms, kept.p);
-    unsigned long long k = 0;
-    if ((he = hipMemcpyAsync(&k, kept.p, sizeof(k), hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
+    N.dir = ndir.p; N.buckets = nb.p; N.arena = narena.p;
+    if (e->T.gpend) { N.gpend = ngp.p; N.gdirty = e->gdirty2.p; }
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots, N, now_ms, d_out.p);
+    CompactOut co{};
+    if ((he = hipMemcpyAsync(&co, d_out.p, sizeof(co), hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
         (he = hipStreamSynchronize(e->stream)) != hipSuccess) {
-        ndir.release(); nb.release(); kept.release();
+        cleanup();
         return fail(GUBER_E_HIP, "compaction", he);
     }
-    kept.release();
-    // size = live buckets, tags_used = kept entries; pending GLOBAL records are per slot and cannot be carried over
+    // tags_used = kept entries; the live count is unchanged except for the expired buckets that were dropped: recount it
+    // from the kept entries that are live (kept - pending-but-dead is not tracked separately: size := live kept)
     DevCounters c;
     HIPCHK(hipMemcpy(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
-    long long bsize = 0;
     std::vector<BlockCounters> bc(e->n_bctr);
     HIPCHK(hipMemcpy(bc.data(), e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost));
-    for (auto& x : bc) { bsize += x.size_delta; x.size_delta = 0; }
-    (void)bsize;
-    c.size = (long long)k; c.tags_used = k;
+    for (auto& x : bc) x.size_delta = 0;
+    c.size = (long long)co.live; c.tags_used = co.kept; c.arena_head = co.arena_head;
+    if (e->T.gpend) c.gdirty_n = co.gdirty_n;
     HIPCHK(hipMemcpy(e->ctr.p, &c, sizeof(c), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->bctr.p, bc.data(), e->n_bctr * sizeof(BlockCounters), hipMemcpyHostToDevice));
-    std::swap(e->dir.p, ndir.p); std::swap(e->buckets.p, nb.p);
-    std::swap(e->dir.cap, ndir.cap); std::swap(e->buckets.cap, nb.cap);
-    ndir.release(); nb.release();
-    e->T.dir = e->dir.p; e->T.buckets = e->buckets.p;
-    e->tags_upper = k;
+    std::swap(e->dir.p, ndir.p); std::swap(e->buckets.p, nb.p); std::swap(e->arena.p, narena.p);
+    std::swap(e->dir.cap, ndir.cap); std::swap(e->buckets.cap, nb.cap); std::swap(e->arena.cap, narena.cap);
+    if (e->T.gpend) {
+        std::swap(e->gpend.p, ngp.p); std::swap(e->gpend.cap, ngp.cap);
+        std::swap(e->gdirty.p, e->gdirty2.p);
+        e->T.gpend = e->gpend.p; e->T.gdirty = e->gdirty.p;
+    }
+    cleanup();
+    e->T.dir = e->dir.p; e->T.buckets = e->buckets.p; e->T.arena = e->arena.p;
+    e->tags_upper = co.kept; e->size_upper = co.live;
+    e->last_ctr.size = (long long)co.live; e->last_ctr.tags_used = co.kept;
+    e->rb_inflight = false; e->rb_added = 0;
     e->compactions++;
+    return 0;
+}
+
+// Evict the least recently used items until at most `target` are live (lrucache.go:98-100,138-149; order approximated by
+// the epoch of the last touch, expired items first).  The counters must be fresh (engine_refresh_counters).
+static int evict_to(guber_engine* e, uint64_t target, int64_t now_ms) {
+    const uint64_t live = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
+    if (live <= target) return 0;
+    const uint64_t need = live - target;
+    DevBuf<unsigned long long> d_hist, d_q;
+    if (d_hist.ensure(EV_BINS) || d_q.ensure(4)) { d_hist.release(); d_q.release(); return GUBER_E_NOMEM; }
+    auto cleanup = [&]() { d_hist.release(); d_q.release(); };
+    std::vector<unsigned long long> hist(EV_BINS);
+    hipError_t he;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((e->slots + 255) / 256, 4096);
+    if ((he = hipMemsetAsync(d_hist.p, 0, EV_BINS * 8, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
+    hipLaunchKernelGGL(k_evict_hist, dim3(blocks), dim3(256), 0, e->stream, e->T, e->slots, now_ms, e->touch, d_hist.p);
+    if ((he = hipMemcpyAsync(hist.data(), d_hist.p, EV_BINS * 8, hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
+    // exactly `need` items go: expired ones first (they are dead anyway and do not count), then whole age classes from
+    // the oldest down, then a quota of the class at the cut
+    const unsigned long long q_expired = std::min<unsigned long long>(need, hist[0]);
+    uint64_t left = need - q_expired;
+    uint32_t cut = EV_BINS;                       // classes > cut are dropped entirely
+    unsigned long long quota = 0;
+    for (uint32_t b = EV_BINS - 1; b >= 1 && left > 0; --b) {
+        if (hist[b] <= left) { left -= hist[b]; cut = b - 1; }
+        else { cut = b; quota = left; left = 0; }
+    }
+    unsigned long long q[4] = {quota, 0, 0, q_expired};
+    if ((he = hipMemcpyAsync(d_q.p, q, sizeof(q), hipMemcpyHostToDevice, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
+    hipLaunchKernelGGL(k_evict_apply, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots, now_ms, e->touch,
+                       cut, d_q.p);
+    if ((he = hipMemcpyAsync(q, d_q.p, sizeof(q), hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
+        (he = hipStreamSynchronize(e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
+    cleanup();
+    // fold into the device counters (the kernels only cleared the buckets)
+    DevCounters c;
+    HIPCHK(hipMemcpy(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
+    c.size -= (long long)q[1]; c.evictions += q[2];
+    HIPCHK(hipMemcpy(e->ctr.p, &c, sizeof(c), hipMemcpyHostToDevice));
+    e->last_ctr.size -= (long long)q[1]; e->last_ctr.evictions += q[2];
+    e->size_upper = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
+    e->evict_passes++;
+    return 0;
+}
+
+// Keep the cache within cache_size and the directory under its load limit before `incoming` more requests arrive.
+// The bounds are upper bounds (every request might create an item).  Crossing a SOFT limit only enqueues an asynchronous
+// read-back of the real counters, folded by a later call once its event has completed; the stream is drained only when
+// an eviction / rebuild is really due or a HARD limit (physical room) is at stake.
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms) {
+    const uint64_t tag_limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
+    const uint64_t hard_size = e->cache_size + std::max<uint64_t>(e->cache_size / 2, 4ull * e->max_batch);
+    if (e->rb_inflight && hipEventQuery(e->rb_event) == hipSuccess) {
+        const uint64_t added = e->rb_added;
+        fold_counters(e);                                 // exact as of the read-back; what was enqueued since is added back
+        e->size_upper += added; e->tags_upper += added;
+    }
+    const bool soft = e->size_upper > e->cache_size || e->tags_upper + incoming > tag_limit;
+    if (!soft) return 0;
+    const bool sure_over = (uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size && !e->rb_inflight;
+    const bool hard = incoming == 0 || e->size_upper > hard_size || e->tags_upper + incoming > tag_limit || sure_over;
+    if (!hard) {
+        if (!e->rb_inflight) {
+            if (!e->rb_event && hipEventCreateWithFlags(&e->rb_event, hipEventDisableTiming) != hipSuccess) return fail(GUBER_E_HIP, "hipEventCreate");
+            int rc = enqueue_counter_readback(e);
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(e->rb_event, e->stream));
+            e->rb_inflight = true; e->rb_added = 0;
+        }
+        return 0;
+    }
+    int rc = engine_refresh_counters(e);
+    if (rc) return rc;
+    if ((uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size) {
+        rc = evict_to(e, e->cache_size - e->cache_size / 64, now_ms);   // a little below the bound, so that a churning key set does not evict every batch
+        if (rc) return rc;
+    }
+    if (e->tags_upper + incoming > tag_limit) {
+        // dead entries (expired, removed, evicted) still hold their tags: rebuild without them
+        rc = compact_table(e, now_ms);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -1023,8 +1130,17 @@ extern "C" int guber_compact(guber_engine_t* e, int64_t now_ms) {
     if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    if (e->T.gpend) return fail(GUBER_E_INVALID_ARG, "compaction with pending GLOBAL queues: call guber_global_take first");
+    if (now_ms > e->clock_ms) e->clock_ms = now_ms;
     return compact_table(e, now_ms);
+}
+
+// the engine has no clock of its own: `now` comes with every batch; maintenance between batches (eviction after Add) uses
+// the latest value seen, which a caller with a frozen or external clock sets here (clock.Freeze / clock.Advance)
+extern "C" int guber_set_clock(guber_engine_t* e, int64_t now_ms) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->clock_ms = now_ms;
+    return GUBER_OK;
 }
 
 extern "C" int guber_profile_enable(guber_engine_t* e, int enable) {

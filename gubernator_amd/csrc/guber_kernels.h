@@ -180,7 +180,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ uint32_t soff[FT], slen[FT];                       // where each request's key lives (members fetch their head's key)
     __shared__ TileReqs sreq;
     __shared__ int red[FT / 64];
-    __shared__ uint32_t soft_any;
+    __shared__ uint32_t soft_any, ins_any;
     const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     const uint32_t e16 = W.epoch16;
 
     GB_STAMP(0);
-    if (tid == 0) soft_any = 0u;
+    if (tid == 0) { soft_any = 0u; ins_any = 0u; }
     for (uint32_t j = tid; j < GT; j += FT) {
         gkey[j] = 0ull;
 #pragma unroll
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     GB_STAMPW(4);
     if (khead) sslot[tid] = slot;
     if (soft_leaky) soft_any = 1u;
+    if (inserted) ins_any = 1u;
     uint8_t rf = 0;
     if (valid) {
         if (errcode) { my_flags |= SEG_ERR | (errcode << 8); rf = RF_ERR; }
@@ -410,8 +411,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
         }
     }
     if (my_flags) seg_raise(&W.srec[d], e16, my_flags);
-    const int ins = block_sum_lds(inserted, red);
-    if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+    if (ins_any) {                                                   // new keys in this tile (rare in steady state)
+        const int ins = block_sum_lds(inserted, red);
+        if (tid == 0 && ins) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins);
+    }
     GB_STAMPW(5);
 }
 
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             }
             if ((parallel && rank == total - 1) || walk) {
-                after.pad = W.epoch;                                  // last touch (approximate LRU order for eviction)
+                after.pad = W.touch;                                  // last touch (approximate LRU order for eviction)
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);

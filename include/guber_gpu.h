@@ -56,7 +56,7 @@ extern "C" {
 #define GUBER_E_NO_DEVICE (-2)     /* HIP runtime / GPU missing: the product path never falls back to CPU */
 #define GUBER_E_HIP (-3)           /* a HIP call failed; guber_last_error() has the text */
 #define GUBER_E_BATCH_TOO_LARGE (-4)
-#define GUBER_E_TABLE_FULL (-5)    /* open-addressed table above its load limit and nothing evictable */
+#define GUBER_E_TABLE_FULL (-5)    /* guber_add_items only: no directory entry for an item although nothing is evictable */
 #define GUBER_E_NOMEM (-6)
 #define GUBER_E_KEY_TOO_LONG (-7)
 #define GUBER_E_NOT_FOUND (-8)
@@ -238,12 +238,24 @@ typedef struct guber_store_events {
 int guber_probe_missing(guber_engine_t* e, const guber_batch_t* b, uint8_t* missing);
 int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* ev);
 
-/* ---- bounded cache: the reference keeps at most CacheSize items and evicts the least recently used
- *      (lrucache.go:98-100,138-149).  The HBM table instead drops every bucket that is expired at now_ms
- *      or was removed, by rebuilding itself (also done automatically when the directory passes 7/8 full).
- *      Unexpired buckets are never evicted: if the live set itself outgrows the table, new keys get
- *      GUBER_ITEM_E_TABLE_FULL (documented divergence). */
+/* ---- bounded cache: the reference keeps at most CacheSize items and evicts the least recently used when an Add makes it
+ *      grow beyond that (lrucache.go:98-100,138-149), counting the evictions of items that had not expired yet
+ *      (gubernator_unexpired_evictions_count, :142-146).  The engine does the same between batches: every bucket carries the
+ *      batch epoch of its last touch; when more than cache_size items are live the oldest are dropped — already-expired
+ *      ones first, which do not count — until cache_size (minus 1/64 of hysteresis) remain, and guber_result_t /
+ *      guber_stats_t.unexpired_evictions report the rest.  Differences from the reference's exact list order (documented in
+ *      DESIGN.md): order inside one batch epoch is arbitrary; a batch that brings more new keys than fit is evaluated first
+ *      and trimmed afterwards (the table is sized for cache_size + max_batch items), so a key requested twice in such a batch
+ *      is not evicted between its two requests; buckets holding pending GLOBAL work are never evicted.
+ *      The directory entries of evicted / expired / removed keys are reclaimed by a rebuild of the table (guber_compact,
+ *      also automatic when the directory passes 7/8 full; GLOBAL engines included, pending records move with their
+ *      buckets; the long-key arena is rebuilt too).  Only when the LIVE set itself cannot be placed do new keys get
+ *      GUBER_ITEM_E_TABLE_FULL — per item; resident keys are always served.
+ *      The engine has no clock: "now" arrives with every batch; maintenance between batches (eviction right after
+ *      guber_add_items) classifies items as expired against the latest value seen, which guber_set_clock overrides
+ *      (the reference's clock.Freeze / clock.Advance). */
 int guber_compact(guber_engine_t* e, int64_t now_ms);
+int guber_set_clock(guber_engine_t* e, int64_t now_ms);
 
 int guber_stats(guber_engine_t* e, guber_stats_t* out);
 int guber_synchronize(guber_engine_t* e);

@@ -331,7 +331,7 @@ def test_back_to_back_device_batches_match_oracle():
 def test_compaction_keeps_churning_key_sets_going():
     """A key population that keeps changing: the directory would fill with expired / removed buckets; the
     table rebuilds itself (guber_compact, also automatic) and results stay identical to the oracle."""
-    o, e = Oracle(cache_size=1 << 20), engine(cache_size=2048, max_batch=1024)     # 4096 slots, limit 3584 tags
+    o, e = Oracle(cache_size=1 << 20), engine(cache_size=2048, max_batch=1024, table_slots=4096)     # 4096 slots, limit 3584 tags
     now = streams.NOW0
     for step in range(40):
         keys = [f"churn_{step}_{i}" for i in range(400)] + [f"steady_{i}" for i in range(100)]
@@ -490,9 +490,75 @@ def test_claim_table_epoch_wraps():
 
 
 def test_lrucache_vectors_on_the_engine():
-    """lrucache_test.go TestLRUCache (Happy path, Update an existing key) through guber_add_items / guber_get_item /
-    guber_remove_item / guber_size.  The two eviction cases need the bounded LRU and stay oracle-only."""
-    assert scenarios.run_cache_vectors(lambda cs: engine(cache_size=4096, max_batch=1024), evicting=False) > 3000
+    """lrucache_test.go TestLRUCache through guber_add_items / guber_get_item / guber_remove_item / guber_size, the two
+    eviction cases included (lrucache_test.go:339-428): adding an 11th item to a cache of 10 evicts exactly one — the least
+    recently used — and gubernator_unexpired_evictions_count moves only when the victim had not expired."""
+    assert scenarios.run_cache_vectors(lambda cs: engine(cache_size=cs or 4096, max_batch=1024), evicting=True) > 3000
+
+
+def test_live_set_larger_than_the_cache_is_served_by_evicting():
+    """A key population that outgrows CacheSize: the reference evicts the least recently used items and keeps answering
+    (lrucache.go:98-100); so does the engine — no GUBER_ITEM_E_TABLE_FULL, the size stays bounded, keys touched in every batch
+    survive, evictions of live items are counted.  Every answer equals the oracle's (a bounded LRU of the same size)."""
+    cs = 2000
+    o, e = Oracle(cache_size=cs), engine(cache_size=cs, max_batch=1024)
+    now = streams.NOW0
+    for step in range(24):
+        keys = [f"steady_{i}" for i in range(100)] + [f"churn_{step}_{i}" for i in range(900)]
+        b = HostBatch(keys, 1, 50, 3_600_000, now)
+        got, want = e.eval(b), o.eval(b)
+        support.assert_results_equal(got, want, f"churn step {step}")
+        assert (got.err[:b.n] == 0).all()
+        st = e.stats()
+        assert st["cache_size"] <= cs, (step, st)
+        assert st["cache_size"] >= min(cs - cs // 16, 1000 * (step + 1)), (step, st)
+        now += 1000
+    st = e.stats()
+    assert st["unexpired_evictions"] >= 24 * 900 + 100 - cs, st
+    assert o.size() == cs
+    for i in range(100):                                   # touched by every batch: never the least recently used
+        a, b_ = o.get_item(f"steady_{i}", now), e.get_item(f"steady_{i}", now)
+        assert a is not None and b_ is not None and a["remaining"] == b_["remaining"] == 50 - 24, (i, a, b_)
+    e.close()
+
+
+def test_global_engine_keeps_serving_across_rebuilds():
+    """An engine created with GUBER_FLAG_GLOBAL whose directory fills with the entries of expired keys: the table is rebuilt
+    (pending GLOBAL records move with their buckets) instead of rejecting the batch, and what was queued before the rebuild
+    is still delivered by guber_global_take."""
+    e = engine(cache_size=512, max_batch=1024, max_key_bytes=64, flags=ga.FLAG_GLOBAL)     # 4096 slots, 3584 tags
+    o = Oracle(cache_size=1 << 20)
+    now = streams.NOW0
+    gk = [f"glob_{i}" for i in range(40)]
+    b = HostBatch(gk, 3, 100, 3_600_000, now, behavior=support.GLOBAL, is_owner=0)
+    support.assert_results_equal(e.eval(b), o.eval(b), "global batch")
+    for step in range(30):                                 # 30 x 400 short-lived keys >> 3584 directory entries
+        keys = [f"shortlived_{step}_{i}" for i in range(400)]
+        b = HostBatch(keys, 1, 5, 20, now)
+        got = e.eval(b)
+        support.assert_results_equal(got, o.eval(b), f"step {step}")
+        now += 1000
+    st = e.stats()
+    assert st["compactions"] >= 2 and st["tags_used"] < 3584, st
+    rows = e.global_take(2)
+    assert len(rows) == 40 and sorted(rows.keys()) == sorted(k.encode() for k in gk) and (rows.hits == 3).all()
+    e.close()
+
+
+def test_long_key_arena_is_reclaimed_by_rebuilds():
+    """Keys above 62 bytes live in an append-only arena; the rebuild copies the live ones into a fresh arena, so a churning
+    population of long keys never exhausts it."""
+    o, e = Oracle(cache_size=1 << 20), engine(cache_size=2048, max_batch=1024, max_key_bytes=200, table_slots=4096)    # 1 MiB arena, 3584 tags
+    now = streams.NOW0
+    for step in range(40):                                  # 40 x 600 x 160 B = 3.8 MB of key bytes through a 1 MiB arena
+        keys = [f"long_{step}_{i}_" + "x" * 140 for i in range(600)] + ["resident_" + "y" * 100 + str(i) for i in range(50)]
+        b = HostBatch(keys, 1, 9, [30] * 600 + [3_600_000] * 50, now)
+        got = e.eval(b)
+        support.assert_results_equal(got, o.eval(b), f"step {step}")
+        assert (got.err[:b.n] == 0).all(), step
+        now += 1000
+    assert e.stats()["compactions"] >= 3
+    e.close()
 
 
 def test_extreme_value_runs_on_the_device():
