@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1171,3 +1172,5 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
 }
 
 extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }
+
+#include "guber_global_sync.h"

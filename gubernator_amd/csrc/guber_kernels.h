@@ -66,8 +66,8 @@ constexpr int FT_MAX_TILES = 256;       // bitmap bits per segment
 constexpr int FT_WORDS = FT_MAX_TILES / 32;   // per segment: 8 x u64, each = members << 32 | bitmap of 32 tiles
 
 __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, uint32_t b) {
-    const uint32_t oa = B.key_off[a], ob = B.key_off[b];
-    const uint32_t la = B.key_off[a + 1] - oa, lb = B.key_off[b + 1] - ob;
+    const uint32_t oa = key_off_of(B, a), ob = key_off_of(B, b);
+    const uint32_t la = key_len_of(B, a, oa), lb = key_len_of(B, b, ob);
     if (la != lb) return false;
     const uint8_t* pa = B.key_bytes + oa; const uint8_t* pb = B.key_bytes + ob;
     const uint32_t nw = (la + 7) >> 3;
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     Rec rec; rec_clear(rec);
     if (valid) {
         const Req mine = load_req_nogreg(B, g);
-        off = B.key_off[g];
-        len = B.key_off[g + 1] - off;
+        off = key_off_of(B, g);
+        len = key_len_of(B, g, off);
         key = B.key_bytes + off;
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     if (member) {
         if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) my_flags |= SEG_RETRY;   // two keys under one hash: careful round
     } else if (khead && d != g) {
-        const uint32_t c_off = B.key_off[d], c_len = B.key_off[d + 1] - c_off;
+        const uint32_t c_off = key_off_of(B, d), c_len = key_len_of(B, d, c_off);
         const Req cq = load_req_nogreg(B, d);
         if (!req_key_equal_at(B, off, len, c_off, c_len)) my_flags |= SEG_RETRY;   // two keys under one claim fingerprint
         my_flags |= req_diff_flags(B, g, d, tile_get(sreq, tid), cq, soft_leaky);

@@ -31,8 +31,8 @@ __global__ __launch_bounds__(TILE) void k_resolve(Table T, BatchView B, Work W) 
     uint32_t d = 0;
     int inserted = 0;
     if (valid) {
-        const uint32_t off = B.key_off[i];
-        const uint32_t len = B.key_off[i + 1] - off;
+        const uint32_t off = key_off_of(B, i);
+        const uint32_t len = key_len_of(B, i, off);
         const uint8_t* key = B.key_bytes + off;
         uint32_t slot = 0;
         uint8_t rf = 0;
@@ -139,8 +139,8 @@ __global__ __launch_bounds__(TILE) void k_scatter(Table T, BatchView B, Work W, 
         if (!(rf & RF_ERR)) {
             const uint32_t slot = W.slot[g];
             if (rf & RF_NEED_VERIFY) {
-                const uint32_t off = B.key_off[g];
-                if (!key_equal(T, slot, B.key_bytes + off, B.key_off[g + 1] - off)) atomicOr(&W.seg_flags[d], SEG_RETRY);
+                const uint32_t off = key_off_of(B, g);
+                if (!key_equal(T, slot, B.key_bytes + off, key_len_of(B, g, off))) atomicOr(&W.seg_flags[d], SEG_RETRY);
             }
             if (rf & RF_INSERTED) atomicOr(&T.dir[slot].meta, META_READY);
             if (d == g) {

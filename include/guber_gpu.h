@@ -387,6 +387,39 @@ int guber_ring_route_rows_dev(guber_engine_t* e, const guber_ring_t* r, const ui
                               const uint32_t* key_len, uint32_t n, uint32_t* owner);
 int guber_add_items_dev(guber_engine_t* e, const guber_items_dev_t* items, uint8_t* result);
 
+/* ---- GLOBAL behaviour across the GPUs of one node, natively (BASELINE config 5; global.go:91-283, gubernator.go:395-459,
+ *      510-512).  Every GPU ("rank") holds a replica of the GLOBAL keys in an engine created with GUBER_FLAG_GLOBAL; ranks
+ *      answer from their replica and queue hits for the owner (replicated consistent hash over the ranks, peer i = rank i).
+ *      guber_global_sync is one GlobalSyncWait tick: pending hits -> owners (one exchange: grouped ncclSend / ncclRecv over
+ *      RCCL / xGMI, every pair directly) -> owners apply them (IsOwner, GLOBAL => DRAIN_OVER_LIMIT) -> owners read back the
+ *      state of every changed key (hits = 0) and build UpdatePeerGlobals items -> all ranks receive and install them.
+ *      Rows stay in HBM end to end; the host waits only for the row counts.
+ *        guber_comm_create_local   every rank lives in this process (a daemon driving all GPUs of the node):
+ *                                  use_rccl = 1 -> ncclCommInitAll over the engines' devices (distinct GPUs);
+ *                                  use_rccl = 0 -> device-to-device copies (also correct for several logical ranks on
+ *                                  ONE GPU, which RCCL refuses: tests and single-GPU boxes)
+ *        guber_comm_unique_id + guber_comm_create_rank   one rank per process (torchrun-style): rank 0 creates the
+ *                                  128-byte id, the application distributes it, every rank joins with its engine
+ *      RCCL is loaded with dlopen at first use (GUBER_RCCL_LIB overrides the name), so the library itself does not
+ *      depend on it. */
+typedef struct guber_comm guber_comm_t;
+typedef struct guber_global_sync_stats {
+    uint64_t hits_rows_sent;      /* aggregated non-owner hit rows leaving the local ranks (global.go:144-187) */
+    uint64_t hits_rows_applied;   /* rows the local owners applied */
+    uint64_t update_rows;         /* keys the local owners broadcast (global.go:234-283) */
+    uint64_t items_installed;     /* items the local ranks installed from other owners (gubernator.go:425-459) */
+    uint64_t bytes_moved;         /* bytes received by the local ranks in both exchanges */
+    uint64_t fallbacks;           /* batches that needed the host path (64-bit hash collision inside the exchange) */
+    double ms;                    /* wall time of the call */
+} guber_global_sync_stats_t;
+int guber_comm_create_local(guber_engine_t* const* engines, uint32_t n, const guber_ring_t* ring, int use_rccl, guber_comm_t** out);
+int guber_comm_unique_id(uint8_t* id128);
+int guber_comm_create_rank(guber_engine_t* e, uint32_t rank, uint32_t world, const uint8_t* id128, const guber_ring_t* ring,
+                           guber_comm_t** out);
+void guber_comm_destroy(guber_comm_t* c);
+int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_sync_stats_t* stats);       /* stats (optional): summed over the local ranks */
+int guber_comm_last_stats(guber_comm_t* c, uint32_t local_index, guber_global_sync_stats_t* out);   /* one local rank's share of the last sync */
+
 /* ---- calendar helpers the host layer uses to fill greg_expire / greg_duration
  *      (interval.go:84-148), UTC. Return 0 or -GUBER_ITEM_E_GREGORIAN_*. */
 int guber_gregorian_expiration(int64_t now_unix_nano, int64_t d, int64_t* expire_ms);

@@ -471,6 +471,65 @@ def test_global_behaviour_device_resident_exchange_vs_model():
             dist.destroy_process_group()
 
 
+def test_global_behaviour_native_exchange_vs_model():
+    """guber_global_sync (C++: device kernels + one exchange, include/guber_gpu.h) with N logical ranks of this process on one
+    GPU (device-copy transport; RCCL needs distinct GPUs): the reference's GLOBAL vectors — who sends hits, who broadcasts —
+    and random streams against the global.go model, replicas converging, no host fallbacks; then 200 000 pending rows
+    through one sync in under a millisecond per ... (timing is reported, the bound checked loosely)."""
+    import time
+    import test_global as tg
+    from global_model import GlobalModel
+    from gubernator_amd import global_native as gn
+    mk = lambda: engine(cache_size=4096, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL)
+    ring = ga.Ring([f"gpu{i}" for i in range(6)])
+    cluster = gn.Comm.local([mk() for _ in range(6)], ring)
+    assert tg.run_vectors(lambda r, q, now: tg.cluster_request(cluster, r, q, now), cluster.sync, ring, 6) >= 40
+    cluster.close()
+    n = 4
+    for seed in (1, 2, 3):
+        ring4 = ga.Ring([f"gpu{i}" for i in range(n)])
+        cl = gn.Comm.local([mk() for _ in range(n)], ring4)
+        model = GlobalModel(n, lambda k: int(ring4.route([k])[0]))
+        tg.run_random(lambda r, b, now: cl.ranks[r].evaluate(b["keys"], b["hits"], b["limit"], b["duration"], now,
+                                                             algorithm=b["algorithm"], behavior=b["behavior"], burst=0,
+                                                             created_at=now),
+                      cl.sync, model, n, seed, steps=200)
+        cl.sync(tg.NOW + 10_000); model.sync(tg.NOW + 10_000)
+        for k in range(40):
+            key = f"glob_{k}".encode()
+            vals = {r: (cl.ranks[r].node.get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+            want = {r: (model.oracles[r].get_item(key, tg.NOW + 10_000) or {}).get("remaining") for r in range(n)}
+            assert vals == want, (seed, key, vals, want)
+        assert cl.last["fallbacks"] == 0
+        cl.close()
+    # volume: 2 ranks, 100 000 distinct GLOBAL keys hit on each rank -> ~200 000 rows per sync
+    K = 100_000
+    ring2 = ga.Ring(["gpu0", "gpu1"])
+    big = lambda: engine(cache_size=2 * K, max_batch=65536, max_key_bytes=64, flags=ga.FLAG_GLOBAL)
+    cl = gn.Comm.local([big(), big()], ring2)
+    tab = streams.key_table(K)
+    now = streams.NOW0
+    ms = []
+    for rnd in range(4):
+        for r in range(2):
+            for lo in range(0, K, 65536):
+                ids = np.arange(lo, min(K, lo + 65536))
+                kb, ko = streams.keys_for_ids(tab, ids)
+                cl.ranks[r].evaluate((kb, ko), 1, 1000, 600_000, now)
+        t0 = time.perf_counter()
+        st = cl.sync(now)
+        ms.append((time.perf_counter() - t0) * 1e3)
+        assert sum(s_["hits_sent"] for s_ in st) == K and sum(s_["hits_applied"] for s_ in st) == K, st   # every key: one row from its non-owner
+        assert sum(s_["broadcast"] for s_ in st) == K and sum(s_["installed"] for s_ in st) == K, st
+        now += 10
+    for r in range(2):       # both replicas agree with what 2 hits per key and round leave
+        it = cl.ranks[r].node.get_item(bytes(tab[12345]), now)
+        assert it["remaining"] == 1000 - 2 * 4, it
+    print("native global sync, 2 ranks, 100k rows each way:", [round(x, 3) for x in ms], "ms")
+    assert min(ms) < 5.0, ms
+    cl.close()
+
+
 def test_claim_table_epoch_wraps():
     """The claim table's cells are tagged with a 16-bit batch epoch; after 65 535 batches the table is wiped and the
     epoch restarts.  66 500 small batches (duplicates inside each) straddle the wrap and must stay bit-exact."""
