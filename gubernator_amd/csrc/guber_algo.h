@@ -130,6 +130,84 @@ GB_HD bool leaky_created_harmless(const Rec& s0, const Req& r, int64_t now) {
     return wadd(r.created_at, r.duration) >= now;
 }
 
+// ---- DURATION_IS_GREGORIAN (interval.go:84-148), UTC: the end of the calendar interval `now` falls into, and the
+// interval's length.  Proleptic Gregorian calendar from day numbers (no table, no branches on the year): the kernels
+// evaluate it per request from the batch clock, the host helpers (guber_gregorian_*) call the same code.
+// Wrap-around arithmetic: a clock within one interval of the int64 range must not be undefined behaviour.
+// Returns 0 or the reference's error as an item code (IE_GREG_WEEKS / IE_GREG_INVALID).
+namespace cal {
+constexpr int64_t kSec = 1000000000LL, kMin = 60 * kSec, kHour = 3600 * kSec, kDay = 86400 * kSec, kMs = 1000000LL;
+GB_HD int64_t floor_div(int64_t a, int64_t b) { const int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+GB_HD int64_t days_from_civil(int64_t y, int m, int d) {
+    y -= m <= 2;
+    const int64_t era = floor_div(y, 400);
+    const int64_t yoe = y - era * 400;
+    const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+    const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return era * 146097 + doe - 719468;
+}
+GB_HD void civil_from_days(int64_t z, int64_t& y, int& m, int& d) {
+    z += 719468;
+    const int64_t era = floor_div(z, 146097);
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const int64_t mp = (5 * doy + 2) / 153;
+    d = (int)(doy - (153 * mp + 2) / 5 + 1);
+    m = (int)(mp < 10 ? mp + 3 : mp - 9);
+    y = yoe + era * 400 + (m <= 2);
+}
+}  // namespace cal
+// interval.go:117-148 GregorianExpiration
+GB_HD uint32_t greg_expiration(int64_t now_ns, int64_t d, int64_t& expire_ms) {
+    using namespace cal;
+    expire_ms = 0;
+    int64_t y; int m, dd;
+    const int64_t day = floor_div(now_ns, kDay);
+    civil_from_days(day, y, m, dd);
+    int64_t end_ns;
+    if (d == 0) end_ns = wadd(wmul(floor_div(now_ns, kMin), kMin), kMin - 1);
+    else if (d == 1) end_ns = wadd(wmul(floor_div(now_ns, kHour), kHour), kHour - 1);
+    else if (d == 2) end_ns = wadd(wmul(day, kDay), kDay - 1);
+    else if (d == 3) return 2u;                                                     // IE_GREG_WEEKS
+    else if (d == 4) end_ns = wsub(wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
+    else if (d == 5) end_ns = wsub(wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
+    else return 3u;                                                                 // IE_GREG_INVALID
+    expire_ms = floor_div(end_ns, kMs);
+    return 0u;
+}
+// interval.go:84-110 GregorianDuration.  The months / years arms keep the reference's expression exactly as written:
+//   end.UnixNano() - begin.UnixNano()/1000000
+GB_HD uint32_t greg_duration(int64_t now_ns, int64_t d, int64_t& duration) {
+    using namespace cal;
+    duration = 0;
+    if (d == 0) { duration = 60000; return 0u; }
+    if (d == 1) { duration = 3600000; return 0u; }
+    if (d == 2) { duration = 86400000; return 0u; }
+    if (d == 3) return 2u;
+    if (d != 4 && d != 5) return 3u;
+    int64_t y; int m, dd;
+    civil_from_days(floor_div(now_ns, kDay), y, m, dd);
+    int64_t begin, end;
+    if (d == 4) {
+        begin = wmul(days_from_civil(y, m, 1), kDay);
+        end = wsub(wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
+    } else {
+        begin = wmul(days_from_civil(y, 1, 1), kDay);
+        end = wsub(wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
+    }
+    duration = wsub(end, begin / kMs);
+    return 0u;
+}
+// the two values a request carries when the host has not precomputed them: greg_duration < 0 = -error, as in guber_batch_t
+GB_HD void greg_fill(int64_t now_ms, int64_t d, int64_t& g_expire, int64_t& g_duration) {
+    const int64_t now_ns = wmul(now_ms, cal::kMs);
+    int64_t e = 0, du = 0;
+    uint32_t rc = greg_expiration(now_ns, d, e);
+    if (rc == 0u) rc = greg_duration(now_ns, d, du);
+    g_expire = e; g_duration = rc ? -(int64_t)rc : du;
+}
+
 struct Resp {
     int64_t limit, remaining, reset_time;
     uint8_t status, err;

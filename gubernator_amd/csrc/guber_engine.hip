@@ -498,7 +498,7 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     HIPCHK(hipMemcpyAsync(e->d_u8.p, su8, (size_t)n * 2, hipMemcpyHostToDevice, st));
     int64_t* d64 = e->d_i64.p;
     BatchView B{n, 0, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
-                e->d_u8.p, e->d_beh.p, e->d_u8.p + n, d64 + 5 * (size_t)n, d64 + 6 * (size_t)n, b->now_ms};
+                e->d_u8.p, e->d_beh.p, e->d_u8.p + n, has_greg ? d64 + 5 * (size_t)n : nullptr, has_greg ? d64 + 6 * (size_t)n : nullptr, b->now_ms};
     ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
     std::vector<uint8_t> h_sflags; std::vector<Rec> h_safter;
     if (sev) {

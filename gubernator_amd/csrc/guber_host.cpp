@@ -68,29 +68,6 @@ struct Md5 {
     }
 };
 
-// ---- proleptic Gregorian calendar, UTC ----------------------------------------------------------
-int64_t floor_div(int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
-int64_t days_from_civil(int64_t y, int m, int d) {
-    y -= m <= 2;
-    const int64_t era = floor_div(y, 400);
-    const int64_t yoe = y - era * 400;
-    const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
-    const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-    return era * 146097 + doe - 719468;
-}
-void civil_from_days(int64_t z, int64_t& y, int& m, int& d) {
-    z += 719468;
-    const int64_t era = floor_div(z, 146097);
-    const int64_t doe = z - era * 146097;
-    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
-    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
-    const int64_t mp = (5 * doy + 2) / 153;
-    d = (int)(doy - (153 * mp + 2) / 5 + 1);
-    m = (int)(mp < 10 ? mp + 3 : mp - 9);
-    y = yoe + era * 400 + (m <= 2);
-}
-constexpr int64_t kSec = 1000000000LL, kMin = 60 * kSec, kHour = 3600 * kSec, kDay = 86400 * kSec, kMs = 1000000LL;
-
 }  // namespace
 
 struct guber_ring {
@@ -150,53 +127,14 @@ extern "C" int guber_ring_route(const guber_ring_t* r, const uint8_t* key_bytes,
     return GUBER_OK;
 }
 
-// interval.go:117-148
+// interval.go:84-148 (the calendar arithmetic lives in guber_algo.h: the kernels evaluate the same code per request)
 extern "C" int guber_gregorian_expiration(int64_t now_ns, int64_t d, int64_t* expire_ms) {
     if (!expire_ms) return GUBER_E_INVALID_ARG;
-    *expire_ms = 0;
-    int64_t y; int m, dd;
-    const int64_t day = floor_div(now_ns, kDay);
-    civil_from_days(day, y, m, dd);
-    int64_t end_ns;
-    switch (d) {
-    // wrap-around arithmetic (guber::wmul / wadd): a clock within one interval of the int64 range must not be undefined behaviour
-    case GUBER_GREGORIAN_MINUTES: end_ns = guber::wadd(guber::wmul(floor_div(now_ns, kMin), kMin), kMin - 1); break;
-    case GUBER_GREGORIAN_HOURS: end_ns = guber::wadd(guber::wmul(floor_div(now_ns, kHour), kHour), kHour - 1); break;
-    case GUBER_GREGORIAN_DAYS: end_ns = guber::wadd(guber::wmul(day, kDay), kDay - 1); break;
-    case GUBER_GREGORIAN_WEEKS: return -(int)GUBER_ITEM_E_GREGORIAN_WEEKS;
-    case GUBER_GREGORIAN_MONTHS: end_ns = guber::wsub(guber::wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1); break;
-    case GUBER_GREGORIAN_YEARS: end_ns = guber::wsub(guber::wmul(days_from_civil(y + 1, 1, 1), kDay), 1); break;
-    default: return -(int)GUBER_ITEM_E_GREGORIAN_INVALID;
-    }
-    *expire_ms = floor_div(end_ns, kMs);
-    return GUBER_OK;
+    return -(int)guber::greg_expiration(now_ns, d, *expire_ms);
 }
-// interval.go:84-110.  The months / years arms keep the reference's expression exactly as written:
-//   end.UnixNano() - begin.UnixNano()/1000000
 extern "C" int guber_gregorian_duration(int64_t now_ns, int64_t d, int64_t* duration) {
     if (!duration) return GUBER_E_INVALID_ARG;
-    *duration = 0;
-    int64_t y; int m, dd;
-    civil_from_days(floor_div(now_ns, kDay), y, m, dd);
-    switch (d) {
-    case GUBER_GREGORIAN_MINUTES: *duration = 60000; return GUBER_OK;
-    case GUBER_GREGORIAN_HOURS: *duration = 3600000; return GUBER_OK;
-    case GUBER_GREGORIAN_DAYS: *duration = 86400000; return GUBER_OK;
-    case GUBER_GREGORIAN_WEEKS: return -(int)GUBER_ITEM_E_GREGORIAN_WEEKS;
-    case GUBER_GREGORIAN_MONTHS: {
-        const int64_t begin = guber::wmul(days_from_civil(y, m, 1), kDay);
-        const int64_t end = guber::wsub(guber::wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
-        *duration = guber::wsub(end, begin / kMs);
-        return GUBER_OK;
-    }
-    case GUBER_GREGORIAN_YEARS: {
-        const int64_t begin = guber::wmul(days_from_civil(y, 1, 1), kDay);
-        const int64_t end = guber::wsub(guber::wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
-        *duration = guber::wsub(end, begin / kMs);
-        return GUBER_OK;
-    }
-    default: return -(int)GUBER_ITEM_E_GREGORIAN_INVALID;
-    }
+    return -(int)guber::greg_duration(now_ns, d, *duration);
 }
 
 extern "C" uint64_t guber_xxhash64(const uint8_t* p, size_t len, uint64_t seed) { return guber::xxhash64(p, (uint32_t)len, seed); }

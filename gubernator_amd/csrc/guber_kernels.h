@@ -142,6 +142,7 @@ __device__ __forceinline__ bool req_key_equal_at(const BatchView& B, uint32_t oa
 // differ only in created_at on a leaky bucket (decided against the bucket state by the caller)
 __device__ __forceinline__ uint32_t req_diff_flags(const BatchView& B, uint32_t ia, uint32_t ib, const Req& a, const Req& b, bool& soft_leaky) {
     // a / b carry no calendar values (never read unless DURATION_IS_GREGORIAN is set): compare those only when it is
+    // (without host-precomputed values they derive from the batch clock and `duration`, which is compared below)
     if ((a.behavior & BH_GREGORIAN) && a.behavior == b.behavior && B.greg_expire && B.greg_duration &&
         (B.greg_expire[ia] != B.greg_expire[ib] || B.greg_duration[ia] != B.greg_duration[ib]))
         return SEG_NONUNIFORM;
@@ -546,8 +547,8 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
             if ((parallel && !done) || walk) {
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
-                    cur.greg_expire = B.greg_expire ? B.greg_expire[i] : 0;
-                    cur.greg_duration = B.greg_duration ? B.greg_duration[i] : 0;
+                    if (B.greg_expire && B.greg_duration) { cur.greg_expire = B.greg_expire[i]; cur.greg_duration = B.greg_duration[i]; }
+                    else if (cur.behavior & BH_GREGORIAN) greg_fill(B.now_ms, cur.duration, cur.greg_expire, cur.greg_duration);
                 }
                 after = s0;
                 uint64_t k = rank;

@@ -182,6 +182,8 @@ __device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
     r.behavior = B.behavior ? B.behavior[i] : 0;
     r.algorithm = B.algorithm ? B.algorithm[i] : 0;
     r.is_owner = B.is_owner ? B.is_owner[i] : 1;
+    // DURATION_IS_GREGORIAN without host-precomputed values: the calendar interval of the batch clock (interval.go:84-148, UTC)
+    if ((r.behavior & BH_GREGORIAN) && !(B.greg_expire && B.greg_duration)) greg_fill(B.now_ms, r.duration, r.greg_expire, r.greg_duration);
     return r;
 }
 // the request without the calendar values (only the general path reads them: the closed forms decline GREGORIAN requests)

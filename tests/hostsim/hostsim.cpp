@@ -30,6 +30,8 @@ static Req load_req(const guber_batch_t* b, uint32_t i) {
     r.behavior = b->behavior ? b->behavior[i] : 0;
     r.algorithm = b->algorithm ? b->algorithm[i] : 0;
     r.is_owner = b->is_owner ? b->is_owner[i] : 1;
+    // as load_req() of the kernels: calendar values from the batch clock when the host did not precompute them
+    if ((r.behavior & BH_GREGORIAN) && !(b->greg_expire && b->greg_duration)) greg_fill(b->now_ms, r.duration, r.greg_expire, r.greg_duration);
     return r;
 }
 static void store(guber_result_t* res, uint32_t i, const Resp& rl) {

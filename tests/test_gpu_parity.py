@@ -530,6 +530,17 @@ def test_global_behaviour_native_exchange_vs_model():
     cl.close()
 
 
+def test_gregorian_intervals_on_the_device():
+    """DURATION_IS_GREGORIAN evaluated in the kernels from the batch clock (no greg_expire / greg_duration arrays): equal to the
+    oracle fed with the host-computed calendar values — minutes .. years, the weeks / invalid-interval errors, both pipelines."""
+    from test_kernel_logic_host import _gregorian_batches
+    for flags in (0, 2):
+        o, e = Oracle(cache_size=1 << 12), engine(cache_size=1024, max_batch=1024, flags=flags)
+        for bi, (with_vals, without) in enumerate(_gregorian_batches(6 + flags)):
+            support.assert_results_equal(e.eval(without), o.eval(with_vals), f"flags {flags} batch {bi}")
+        e.close()
+
+
 def test_claim_table_epoch_wraps():
     """The claim table's cells are tagged with a 16-bit batch epoch; after 65 535 batches the table is wiped and the
     epoch restarts.  66 500 small batches (duplicates inside each) straddle the wrap and must stay bit-exact."""

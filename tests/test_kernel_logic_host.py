@@ -298,3 +298,33 @@ def test_closed_forms_equal_apply_skip_on_random_states():
         assert out[2] == 0, f"seed {seed}: {out[2]} mismatches"
         tok += out[0]; leaky += out[1]
     assert tok > 200_000 and leaky > 100_000, (tok, leaky)
+
+
+def _gregorian_batches(seed, n_batches=40):
+    """(batch with host-precomputed calendar values, the same batch without them)"""
+    rng = np.random.default_rng(seed)
+    now = streams.NOW0
+    for _ in range(n_batches):
+        n = int(rng.integers(1, 300))
+        keys = [b"greg_%d" % int(i) for i in rng.integers(0, 12, n)]
+        hits = rng.choice([0, 1, 1, 2, 7], n)
+        limit = rng.choice([5, 10, 100], n)
+        sel = rng.choice([0, 1, 2, 3, 4, 5, 9], n, p=[0.25, 0.2, 0.2, 0.05, 0.15, 0.1, 0.05])     # interval selector carried in `duration`
+        algo = rng.integers(0, 2, n).astype(np.uint8)
+        beh = np.where(rng.random(n) < 0.9, 4, 0).astype(np.uint32) | np.where(rng.random(n) < 0.1, 32, 0).astype(np.uint32)
+        dur = np.where(beh & 4, sel, 60_000)
+        ge, gd = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        for i in range(n):
+            if beh[i] & 4:
+                ge[i], gd[i] = support.gregorian(now, int(dur[i]))
+        yield (HostBatch(keys, hits, limit, dur, now, algorithm=algo, behavior=beh, greg_expire=ge, greg_duration=gd),
+               HostBatch(keys, hits, limit, dur, now, algorithm=algo, behavior=beh))
+        now += int(rng.choice([1, 1000, 61_000, 3_600_000, 86_400_000 * 20]))
+
+
+def test_gregorian_intervals_computed_from_the_batch_clock():
+    """DURATION_IS_GREGORIAN without host-precomputed values: the kernel logic derives the calendar interval (interval.go:84-148,
+    UTC) from the batch clock itself; answers equal the oracle fed with the host-computed values, errors included."""
+    o, h = Oracle(cache_size=1 << 12), HostSim(mode=0)
+    for bi, (with_vals, without) in enumerate(_gregorian_batches(5)):
+        support.assert_results_equal(h.eval(without), o.eval(with_vals), f"batch {bi}")
