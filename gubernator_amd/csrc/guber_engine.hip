@@ -66,6 +66,22 @@ struct PinBuf {
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// host memory the kernels read and write in place (device-visible, coherent): no copy launches on the host-pointer path
+template <typename T>
+struct CohBuf {
+    T* p = nullptr; size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = std::max(n, (size_t)64);
+        hipError_t e = hipHostMalloc((void**)&p, want * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent);
+        if (e != hipSuccess) return fail(GUBER_E_NOMEM, "hipHostMalloc(coherent)", e);
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace
 
 struct guber_engine {
@@ -101,7 +117,10 @@ struct guber_engine {
     // staging for the host-pointer entry points
     DevBuf<uint8_t> d_keys; DevBuf<uint32_t> d_off; DevBuf<int64_t> d_i64; DevBuf<uint32_t> d_beh; DevBuf<uint8_t> d_u8;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
-    PinBuf<uint8_t> h_stage;   // one pinned arena for inputs and outputs
+    PinBuf<uint8_t> h_stage;   // one pinned arena for inputs and outputs (copy path)
+    CohBuf<uint8_t> z_stage;   // device-visible arena of the zero-copy path: inputs, outputs, SmallOut
+    hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
+    uint64_t small_batches = 0, small_fallbacks = 0;
     PinBuf<DevCounters> h_ctr;
     DevCounters last_ctr{};
     uint32_t epoch = 0;
@@ -202,6 +221,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->fast_cap = std::min<uint32_t>(M, FT * FT_MAX_TILES);
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
+    e->no_small = (cfg->flags & GUBER_FLAG_TEST_NO_SMALL) != 0 || e->force_radix || e->always_careful;
+    e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
@@ -285,7 +306,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
     e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
-    e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release();
+    e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->z_stage.release();
+    if (e->z_event) (void)hipEventDestroy(e->z_event);
     if (e->rb_event) (void)hipEventDestroy(e->rb_event);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -448,6 +470,19 @@ extern "C" int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* ba
 // Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of
 // the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
 static void item_from_rec(const Rec& s, guber_item_t* out);
+// the same prelude launch_batch has, for the one-launch path
+static int launch_small(guber_engine* e, const BatchView& B, const ResultView& R, SmallOut* out, uint32_t seq) {
+    if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
+    const int rc = maintain(e, B.n, B.now_ms);
+    if (rc) return rc;
+    e->size_upper += B.n; e->rb_added += B.n; e->tags_upper += B.n;
+    e->touch = (e->touch + 1) & 0x7fffffffu;
+    hipLaunchKernelGGL(k_small, dim3(1), dim3(FT), 0, e->stream, e->T, B, R, out, seq, e->touch);
+    HIPCHK(hipGetLastError());
+    e->batches++; e->small_batches++;
+    return 0;
+}
+
 static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_t* r, const uint32_t* idx, uint32_t n,
                           guber_store_events_t* sev = nullptr) {
     const bool has_burst = b->burst, has_created = b->created_at, has_greg = b->greg_expire && b->greg_duration;
@@ -457,15 +492,20 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     if (kbytes > 0xfffffff0ull) return fail(GUBER_E_BATCH_TOO_LARGE, "key bytes exceed 4 GiB");
     const size_t n64 = (size_t)n * 7;   // hits limit duration burst created greg_expire greg_duration
     const size_t stage_bytes = (kbytes + 16) + (size_t)(n + 1) * 4 + n64 * 8 + (size_t)n * 4 + (size_t)n * 2 + 64 +
-                               (size_t)n * (3 * 8 + 2);
+                               (size_t)n * (3 * 8 + 2) + 64 + sizeof(SmallOut);
+    const bool zc = e->zero_copy;
     int rc = 0;
-    rc |= e->h_stage.ensure(stage_bytes + 256);
-    rc |= e->d_keys.ensure(kbytes + 16); rc |= e->d_off.ensure(n + 1); rc |= e->d_i64.ensure(n64);
-    rc |= e->d_beh.ensure(n); rc |= e->d_u8.ensure((size_t)n * 2);
-    rc |= e->d_out64.ensure((size_t)n * 3); rc |= e->d_out8.ensure((size_t)n * 2);
+    if (zc) rc |= e->z_stage.ensure(stage_bytes + 256);
+    else {
+        rc |= e->h_stage.ensure(stage_bytes + 256);
+        rc |= e->d_keys.ensure(kbytes + 16); rc |= e->d_off.ensure(n + 1); rc |= e->d_i64.ensure(n64);
+        rc |= e->d_beh.ensure(n); rc |= e->d_u8.ensure((size_t)n * 2);
+        rc |= e->d_out64.ensure((size_t)n * 3); rc |= e->d_out8.ensure((size_t)n * 2);
+    }
     if (rc) return GUBER_E_NOMEM;
-    // carve the pinned arena (8-byte aligned pieces first)
-    uint8_t* base = e->h_stage.p;
+    // carve the arena (8-byte aligned pieces first)
+    uint8_t* base = zc ? e->z_stage.p : e->h_stage.p;
+    SmallOut* sout = (SmallOut*)base; base += 64;
     int64_t* s64 = (int64_t*)base; base += n64 * 8;
     int64_t* o64 = (int64_t*)base; base += (size_t)n * 3 * 8;
     uint32_t* soff = (uint32_t*)base; base += (size_t)(n + 1) * 4;
@@ -491,34 +531,75 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     soff[n] = off;
     memset(skeys + off, 0, 16);
     hipStream_t st = e->stream;
-    HIPCHK(hipMemcpyAsync(e->d_keys.p, skeys, kbytes + 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_off.p, soff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_i64.p, s64, n64 * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_beh.p, sbeh, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_u8.p, su8, (size_t)n * 2, hipMemcpyHostToDevice, st));
-    int64_t* d64 = e->d_i64.p;
-    BatchView B{n, 0, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
-                e->d_u8.p, e->d_beh.p, e->d_u8.p + n, has_greg ? d64 + 5 * (size_t)n : nullptr, has_greg ? d64 + 6 * (size_t)n : nullptr, b->now_ms};
-    ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
     std::vector<uint8_t> h_sflags; std::vector<Rec> h_safter;
     if (sev) {
         if (e->d_sflags.ensure(n) || e->d_safter.ensure(n)) return GUBER_E_NOMEM;
         HIPCHK(hipMemsetAsync(e->d_sflags.p, 0, n, st));
         e->W.store_flags = e->d_sflags.p; e->W.store_after = e->d_safter.p;
     }
-    rc = launch_batch(e, B, R);
-    e->W.store_flags = nullptr; e->W.store_after = nullptr;
-    if (rc) return rc;
-    if (sev) {
-        try { h_sflags.resize(n); h_safter.resize(n); } catch (...) { return GUBER_E_NOMEM; }
-        HIPCHK(hipMemcpyAsync(h_sflags.data(), e->d_sflags.p, n, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_safter.data(), e->d_safter.p, (size_t)n * sizeof(Rec), hipMemcpyDeviceToHost, st));
+    if (zc) {
+        // the kernels read the request arrays and write the responses in place, over PCIe: no copy launches
+        BatchView B{n, 0, skeys, soff, s64, s64 + n, s64 + 2 * (size_t)n, s64 + 3 * (size_t)n, s64 + 4 * (size_t)n,
+                    su8, sbeh, su8 + n, has_greg ? s64 + 5 * (size_t)n : nullptr, has_greg ? s64 + 6 * (size_t)n : nullptr, b->now_ms};
+        ResultView R{o8, o64, o64 + n, o64 + 2 * (size_t)n, o8 + n};
+        bool done = false;
+        if (n <= FT && !sev && !e->no_small && !e->careful) {
+            // one launch, one workgroup; completion = a sequence number in host memory, polled
+            const uint32_t seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
+            sout->done = 0;
+            rc = launch_small(e, B, R, sout, seq);
+            if (rc) return rc;
+            volatile unsigned int* flag = &sout->done;
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCHK(hipStreamSynchronize(st)); break; }
+            }
+            if (!sout->fallback) {
+                e->last_ctr.over += sout->over; e->last_ctr.hits += sout->hits; e->last_ctr.misses += sout->misses; e->last_ctr.size += sout->size_delta;
+                done = true;
+            } else e->small_fallbacks++;
+        }
+        if (!done) {
+            rc = launch_batch(e, B, R);
+            e->W.store_flags = nullptr; e->W.store_after = nullptr;
+            if (rc) return rc;
+            if (sev) {
+                try { h_sflags.resize(n); h_safter.resize(n); } catch (...) { return GUBER_E_NOMEM; }
+                HIPCHK(hipMemcpyAsync(h_sflags.data(), e->d_sflags.p, n, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(h_safter.data(), e->d_safter.p, (size_t)n * sizeof(Rec), hipMemcpyDeviceToHost, st));
+            }
+            rc = enqueue_counter_readback(e);
+            if (rc) return rc;
+            HIPCHK(hipStreamSynchronize(st));
+            fold_counters(e);
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(e->d_keys.p, skeys, kbytes + 16, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->d_off.p, soff, (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->d_i64.p, s64, n64 * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->d_beh.p, sbeh, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->d_u8.p, su8, (size_t)n * 2, hipMemcpyHostToDevice, st));
+        int64_t* d64 = e->d_i64.p;
+        BatchView B{n, 0, e->d_keys.p, e->d_off.p, d64, d64 + n, d64 + 2 * (size_t)n, d64 + 3 * (size_t)n, d64 + 4 * (size_t)n,
+                    e->d_u8.p, e->d_beh.p, e->d_u8.p + n, has_greg ? d64 + 5 * (size_t)n : nullptr, has_greg ? d64 + 6 * (size_t)n : nullptr, b->now_ms};
+        ResultView R{e->d_out8.p, e->d_out64.p, e->d_out64.p + n, e->d_out64.p + 2 * (size_t)n, e->d_out8.p + n};
+        rc = launch_batch(e, B, R);
+        e->W.store_flags = nullptr; e->W.store_after = nullptr;
+        if (rc) return rc;
+        if (sev) {
+            try { h_sflags.resize(n); h_safter.resize(n); } catch (...) { return GUBER_E_NOMEM; }
+            HIPCHK(hipMemcpyAsync(h_sflags.data(), e->d_sflags.p, n, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(h_safter.data(), e->d_safter.p, (size_t)n * sizeof(Rec), hipMemcpyDeviceToHost, st));
+        }
+        HIPCHK(hipMemcpyAsync(o64, e->d_out64.p, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(o8, e->d_out8.p, (size_t)n * 2, hipMemcpyDeviceToHost, st));
+        rc = enqueue_counter_readback(e);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        fold_counters(e);
     }
-    HIPCHK(hipMemcpyAsync(o64, e->d_out64.p, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(o8, e->d_out8.p, (size_t)n * 2, hipMemcpyDeviceToHost, st));
-    rc = enqueue_counter_readback(e);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(st));
+    e->W.store_flags = nullptr; e->W.store_after = nullptr;
     for (uint32_t j = 0; j < n; ++j) {
         const uint32_t i = idx ? idx[j] : j;
         r->status[i] = o8[j]; r->err[i] = o8[n + j];
@@ -560,7 +641,6 @@ static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_resu
             e->careful = false;
             if (rc) return rc;
         }
-        fold_counters(e);
         rc = maintain(e, 0, b->now_ms);
         if (rc) return rc;
     }

@@ -649,3 +649,4 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
 }  // namespace guber
 
 #include "guber_kernels_ops.h"
+#include "guber_kernels_small.h"

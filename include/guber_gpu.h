@@ -79,6 +79,7 @@ typedef struct guber_engine guber_engine_t;
 /* guber_config_t.flags */
 #define GUBER_FLAG_GLOBAL 8u          /* keep per-bucket pending GLOBAL hits / updates (guber_global_take) */
 #define GUBER_FLAG_DIR_CLAIMS 16u     /* accepted and ignored (round-1 tuning knob: per-batch claims in the directory entries) */
+#define GUBER_FLAG_TEST_NO_SMALL 32u   /* tests only: batches of <= 256 requests take the two-launch pipeline too (not the one-launch small path) */
 #define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
                                           sort) kernel sequence as well */

@@ -21,7 +21,8 @@ def engine(**kw):
 
 
 def test_golden_functional_vectors():
-    assert scenarios.run_functional(lambda: engine(cache_size=4096, max_batch=1024)) >= 75
+    assert scenarios.run_functional(lambda: engine(cache_size=4096, max_batch=1024)) >= 75                               # one-launch small path
+    assert scenarios.run_functional(lambda: engine(cache_size=4096, max_batch=1024, flags=ga.FLAG_TEST_NO_SMALL)) >= 75   # two-launch pipeline
 
 
 def test_golden_store_vectors():
@@ -41,8 +42,9 @@ def test_get_peer_rate_limits_order_stable():
 
 
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
-# mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline
-@pytest.mark.parametrize("flags", [0, 2, 4])
+# mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline;
+# 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path)
+@pytest.mark.parametrize("flags", [0, 2, 4, 32])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_adversarial_streams(seed, flags):
     o, e = Oracle(cache_size=1 << 20), engine(flags=flags)
@@ -539,6 +541,29 @@ def test_gregorian_intervals_on_the_device():
         for bi, (with_vals, without) in enumerate(_gregorian_batches(6 + flags)):
             support.assert_results_equal(e.eval(without), o.eval(with_vals), f"flags {flags} batch {bi}")
         e.close()
+
+
+def test_small_batches_one_launch_path():
+    """Batches of <= 256 requests (BASELINE configs[0]: one request per call, benchmark_test.go:63-84) take one launch of one
+    workgroup; duplicate-heavy, mixed-algorithm, error-carrying small batches equal the oracle, and what the path declines
+    (requests of one key that differ) is answered by the general pipeline with the same result."""
+    rng = np.random.default_rng(41)
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096)
+    now = streams.NOW0
+    for step in range(400):
+        n = int(rng.choice([1, 1, 2, 3, 17, 64, 255, 256]))
+        ids = rng.integers(0, 30, n)
+        keys = [b"small_%d" % int(i) for i in ids]
+        uniform = rng.random() < 0.7
+        hits = np.full(n, int(rng.choice([0, 1, 2, 5]))) if uniform else rng.choice([0, 1, 2, 5], n)
+        algo = (ids % 2).astype(np.uint8) if rng.random() < 0.9 else rng.choice([0, 1, 7], n).astype(np.uint8)
+        b = HostBatch(keys, hits, 20, int(rng.choice([50, 5000])), now, algorithm=algo, behavior=int(rng.choice([0, 0, 32])))
+        got, want = e.eval(b), o.eval(b)
+        support.assert_results_equal(got, want, f"step {step} n {n}")
+        assert got.counters()[:3] == want.counters()[:3], step
+        now += int(rng.choice([0, 1, 40, 6000]))
+    assert e.size() == o.size()
+    e.close()
 
 
 def test_claim_table_epoch_wraps():
