@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
     "guber_eval_batches_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
-    "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_stage_create", "guber_stage_destroy",
+    "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
@@ -339,6 +340,98 @@ class Engine:
 
     def route_dev(self, ring, key_bytes_ptr, key_off_ptr, n, owner_ptr):
         _check(lib().guber_ring_route_dev(self.h, ring.h, key_bytes_ptr, key_off_ptr, n, owner_ptr))
+
+
+class Stage:
+    """guber_stage_t: one batch's request / response arrays in device-visible host memory, filled in place (numpy views),
+    submitted asynchronously.  Two stages per engine = the overlapped end-to-end path."""
+
+    def __init__(self, engine, max_n, key_bytes_cap=0):
+        L = lib()
+        L.guber_stage_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_stage_destroy.argtypes = [C.c_void_p]
+        L.guber_stage_destroy.restype = None
+        L.guber_stage_batch.argtypes = [C.c_void_p]
+        L.guber_stage_batch.restype = C.POINTER(GuberBatch)
+        L.guber_stage_result.argtypes = [C.c_void_p]
+        L.guber_stage_result.restype = C.POINTER(GuberResult)
+        L.guber_stage_capacity.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.guber_stage_capacity.restype = C.c_uint32
+        L.guber_stage_submit.argtypes = [C.c_void_p]
+        L.guber_stage_wait.argtypes = [C.c_void_p]
+        self.h = C.c_void_p()
+        _check(L.guber_stage_create(engine.h, max_n, key_bytes_cap, C.byref(self.h)))
+        kc = C.c_uint32()
+        self.max_n = L.guber_stage_capacity(self.h, C.byref(kc))
+        self.key_cap = kc.value
+        self.b = L.guber_stage_batch(self.h).contents
+        self.r = L.guber_stage_result(self.h).contents
+        n = self.max_n
+
+        def view(ptr, ct, count):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(count,))
+        self.key_bytes = view(self.b.key_bytes, C.c_uint8, self.key_cap + 16)
+        self.key_off = view(self.b.key_off, C.c_uint32, n + 1)
+        self.hits, self.limit, self.duration, self.burst, self.created_at = (view(getattr(self.b, f), C.c_int64, n)
+                                                                              for f in ("hits", "limit", "duration", "burst", "created_at"))
+        self.algorithm = view(self.b.algorithm, C.c_uint8, n)
+        self.behavior = view(self.b.behavior, C.c_uint32, n)
+        self.is_owner = view(self.b.is_owner, C.c_uint8, n)
+        self.status, self.err = view(self.r.status, C.c_uint8, n), view(self.r.err, C.c_uint8, n)
+        self.out_limit, self.remaining, self.reset_time = (view(getattr(self.r, f), C.c_int64, n) for f in ("limit", "remaining", "reset_time"))
+        self._ptrs = {f: getattr(self.b, f) for f in ("burst", "created_at", "is_owner", "behavior", "algorithm")}
+
+    def disable(self, *fields):
+        """switch optional request arrays off (NULL pointer: the guber_batch_t default applies)"""
+        for f in fields:
+            setattr(self.b, f, None)
+
+    def fill(self, hb):
+        """copy a HostBatch into the stage (what a batcher does request by request)"""
+        n = hb.n
+        kb = int(hb.key_off[n])
+        self.key_bytes[:kb] = hb.key_bytes[:kb]
+        self.key_off[:n + 1] = hb.key_off[:n + 1]
+        self.hits[:n] = hb.hits[:n]; self.limit[:n] = hb.limit[:n]; self.duration[:n] = hb.duration[:n]
+        for f in ("burst", "created_at", "algorithm", "behavior", "is_owner"):
+            src = getattr(hb, f)
+            if src is None:
+                if f in ("burst",):
+                    getattr(self, f)[:n] = 0
+                elif f == "created_at":
+                    self.created_at[:n] = hb.now_ms
+                elif f == "is_owner":
+                    self.is_owner[:n] = 1
+            else:
+                getattr(self, f)[:n] = src[:n]
+        self.b.n = n
+        self.b.now_ms = hb.now_ms
+
+    def submit(self):
+        _check(lib().guber_stage_submit(self.h))
+
+    def wait(self):
+        _check(lib().guber_stage_wait(self.h))
+
+    def result(self):
+        n = self.b.n
+        res = HostResult(n)
+        res.status[:n] = self.status[:n]; res.err[:n] = self.err[:n]; res.limit[:n] = self.out_limit[:n]
+        res.remaining[:n] = self.remaining[:n]; res.reset_time[:n] = self.reset_time[:n]
+        res.c.over_limit_count, res.c.cache_hits, res.c.cache_misses = self.r.over_limit_count, self.r.cache_hits, self.r.cache_misses
+        res.c.unexpired_evictions, res.c.cache_size = self.r.unexpired_evictions, self.r.cache_size
+        return res
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().guber_stage_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 class V1Instance:

@@ -119,6 +119,7 @@ struct guber_engine {
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
     PinBuf<uint8_t> h_stage;   // one pinned arena for inputs and outputs (copy path)
     CohBuf<uint8_t> z_stage;   // device-visible arena of the zero-copy path: inputs, outputs, SmallOut
+    DevBuf<int64_t> d_stash64; DevBuf<uint32_t> d_stash32; DevBuf<uint8_t> d_stash8;   // k_front's HBM copy of host-resident request columns
     hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
     uint64_t small_batches = 0, small_fallbacks = 0;
     PinBuf<DevCounters> h_ctr;
@@ -307,6 +308,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->z_stage.release();
+    e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
     if (e->z_event) (void)hipEventDestroy(e->z_event);
     if (e->rb_event) (void)hipEventDestroy(e->rb_event);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -316,7 +318,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
 static int compact_table(guber_engine* e, int64_t now_ms);
 static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms);
-static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R) {
+static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident = false) {
     const uint32_t n = B.n;
     if (n == 0) return 0;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
@@ -359,11 +361,22 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
 #ifdef GUBER_PHASE_TIMING
         W.dbg = e->dbg.p;
 #endif
+        BatchView B3 = B2;                     // what k_eval2 reads
+        W.st_hits = nullptr;
+        if (host_resident) {
+            const size_t c = e->fast_cap;
+            if (e->d_stash64.ensure(5 * c) || e->d_stash32.ensure(c) || e->d_stash8.ensure(2 * c)) return GUBER_E_NOMEM;
+            int64_t* q = e->d_stash64.p;
+            W.st_hits = q; W.st_limit = q + c; W.st_duration = q + 2 * c; W.st_burst = q + 3 * c; W.st_created = q + 4 * c;
+            W.st_behavior = e->d_stash32.p; W.st_algorithm = e->d_stash8.p; W.st_owner = e->d_stash8.p + c;
+            B3.hits = W.st_hits; B3.limit = W.st_limit; B3.duration = W.st_duration; B3.burst = W.st_burst; B3.created_at = W.st_created;
+            B3.behavior = W.st_behavior; B3.algorithm = W.st_algorithm; B3.is_owner = W.st_owner;
+        }
         e->span_begin(KT_FRONT);
         hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
         e->span_end();
         e->span_begin(KT_EVAL2);
-        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, B2, R, W});
+        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, B3, R, W});
         e->span_end();
         HIPCHK(hipGetLastError());
 #ifdef GUBER_PHASE_TIMING
@@ -561,7 +574,7 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
             } else e->small_fallbacks++;
         }
         if (!done) {
-            rc = launch_batch(e, B, R);
+            rc = launch_batch(e, B, R, true);
             e->W.store_flags = nullptr; e->W.store_after = nullptr;
             if (rc) return rc;
             if (sev) {
@@ -651,6 +664,167 @@ static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_resu
     r->cache_size = e->last_ctr.size;
     return GUBER_OK;
 }
+
+// ---- stages: batch buffers in device-visible host memory that the CALLER fills in place and the kernels read / write in
+// place.  A batcher that owns two of them fills one while the GPU evaluates the other: no staging copy, no copy launch,
+// no allocation per batch (what SURVEY.md section 8d calls the overlapped end-to-end path).
+struct guber_stage {
+    guber_engine* e = nullptr;
+    uint32_t max_n = 0, key_cap = 0;
+    CohBuf<uint8_t> mem;
+    guber_batch_t batch{}; guber_result_t result{};
+    SmallOut* sout = nullptr;
+    DevCounters* rb_ctr = nullptr; BlockCounters* rb_bctr = nullptr;     // this stage's own counter read-back after its batch ...
+    DevCounters* rb0_ctr = nullptr; BlockCounters* rb0_bctr = nullptr;   // ... and before it: the difference is exactly this batch
+    hipEvent_t ev = nullptr;
+    uint32_t seq = 0, n = 0; int64_t now_ms = 0;
+    int mode = 0;                    // 0 idle, 1 small path in flight, 2 pipeline in flight
+};
+
+extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
+    if (!e || !out || max_n == 0) return fail(GUBER_E_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (max_n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "stage larger than guber_config_t.max_batch");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    guber_stage* s = new guber_stage();
+    s->e = e; s->max_n = max_n; s->key_cap = key_bytes_cap ? key_bytes_cap : max_n * 64u;
+    const size_t n = max_n;
+    const size_t bytes = 256 + (n * 8) * 8 /* 5 in + 3 out */ + (n + 1) * 4 + n * 4 + n * 4 /* algo,owner,status,err */ + (size_t)s->key_cap + 64 +
+                         2 * (sizeof(DevCounters) + (size_t)e->n_bctr * sizeof(BlockCounters) + 128) + 256;
+    if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { s->mem.release(); delete s; return GUBER_E_NOMEM; }
+    memset(s->mem.p, 0, bytes);
+    uint8_t* p = s->mem.p;
+    s->sout = (SmallOut*)p; p += 64;
+    s->rb_ctr = (DevCounters*)p; p += (sizeof(DevCounters) + 63) & ~(size_t)63;
+    s->rb_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
+    s->rb0_ctr = (DevCounters*)p; p += (sizeof(DevCounters) + 63) & ~(size_t)63;
+    s->rb0_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
+    int64_t* q = (int64_t*)p; p += n * 8 * 8;
+    uint32_t* off = (uint32_t*)p; p += ((n + 1) * 4 + 7) & ~(size_t)7;
+    uint32_t* beh = (uint32_t*)p; p += n * 4;
+    uint8_t* u8 = p; p += n * 4;
+    guber_batch_t& b = s->batch; guber_result_t& r = s->result;
+    b.hits = q; b.limit = q + n; b.duration = q + 2 * n; b.burst = q + 3 * n; b.created_at = q + 4 * n;
+    r.limit = q + 5 * n; r.remaining = q + 6 * n; r.reset_time = q + 7 * n;
+    b.key_off = off; b.behavior = beh; b.algorithm = u8; b.is_owner = u8 + n; r.status = u8 + 2 * n; r.err = u8 + 3 * n;
+    b.key_bytes = p;
+    *out = s;
+    return GUBER_OK;
+}
+extern "C" void guber_stage_destroy(guber_stage_t* s) {
+    if (!s) return;
+    if (s->mode) (void)guber_stage_wait(s);
+    if (s->ev) (void)hipEventDestroy(s->ev);
+    s->mem.release();
+    delete s;
+}
+extern "C" guber_batch_t* guber_stage_batch(guber_stage_t* s) { return s ? &s->batch : nullptr; }
+extern "C" guber_result_t* guber_stage_result(guber_stage_t* s) { return s ? &s->result : nullptr; }
+extern "C" uint32_t guber_stage_capacity(guber_stage_t* s, uint32_t* key_bytes_cap) { if (s && key_bytes_cap) *key_bytes_cap = s->key_cap; return s ? s->max_n : 0; }
+
+extern "C" int guber_stage_submit(guber_stage_t* s) {
+    if (!s) return fail(GUBER_E_INVALID_ARG, "null stage");
+    if (s->mode) return fail(GUBER_E_INVALID_ARG, "stage already in flight");
+    guber_engine* e = s->e;
+    const guber_batch_t& b = s->batch;
+    s->n = b.n; s->now_ms = b.now_ms;
+    if (b.n == 0) { s->mode = 0; return GUBER_OK; }
+    if (b.n > s->max_n || b.key_off[b.n] > s->key_cap) return fail(GUBER_E_BATCH_TOO_LARGE, "stage overfilled");
+    memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);            // the kernels read keys as 8-byte words
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
+                b.greg_expire, b.greg_duration, b.now_ms};
+    ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
+    if (b.n <= FT && !e->no_small) {
+        s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
+        s->sout->done = 0;
+        int rc = launch_small(e, B, R, s->sout, s->seq);
+        if (rc) return rc;
+        // One workgroup, a few microseconds: wait for it here.  If the small path declined the batch (requests of one key
+        // that differ, a hash collision) the general pipeline has to run it BEFORE anything submitted later, so the
+        // decision cannot be left to guber_stage_wait.
+        volatile unsigned int* flag = &s->sout->done;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != s->seq) {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCHK(hipStreamSynchronize(e->stream)); break; }
+        }
+        if (!s->sout->fallback) {
+            e->last_ctr.over += s->sout->over; e->last_ctr.hits += s->sout->hits; e->last_ctr.misses += s->sout->misses; e->last_ctr.size += s->sout->size_delta;
+            s->mode = 1;
+            return GUBER_OK;
+        }
+        e->small_fallbacks++;
+    }
+    // (maintenance first: it may synchronise and rebuild; the read-back pair must bracket the kernels only)
+    int rc = maintain(e, b.n, b.now_ms);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->rb0_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(s->rb0_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
+    rc = launch_batch(e, B, R, true);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->rb_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(s->rb_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipEventRecord(s->ev, e->stream));
+    s->mode = 2;
+    return GUBER_OK;
+}
+
+extern "C" int guber_stage_wait(guber_stage_t* s) {
+    if (!s) return fail(GUBER_E_INVALID_ARG, "null stage");
+    guber_engine* e = s->e;
+    guber_result_t& r = s->result;
+    r.over_limit_count = r.cache_hits = r.cache_misses = r.unexpired_evictions = 0;
+    if (s->mode == 0) return GUBER_OK;
+    bool general = s->mode == 2;
+    if (s->mode == 1) {                                      // answered by the one-launch path, already complete (guber_stage_submit)
+        s->mode = 0;
+        std::lock_guard<std::mutex> lk(e->mu);
+        r.over_limit_count = s->sout->over; r.cache_hits = s->sout->hits; r.cache_misses = s->sout->misses; r.cache_size = e->last_ctr.size;
+        return GUBER_OK;
+    }
+    if (general) {
+        if (hipEventSynchronize(s->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");
+        s->mode = 0;
+        std::lock_guard<std::mutex> lk(e->mu);
+        // the read-backs taken right before and right after this batch's kernels: their difference is this batch alone
+        auto fold = [&](const DevCounters* c0, const BlockCounters* b0) {
+            DevCounters c = *c0;
+            for (uint32_t k = 0; k < e->n_bctr; ++k) { c.over += b0[k].over; c.hits += b0[k].hits; c.misses += b0[k].misses; c.size += b0[k].size_delta; }
+            return c;
+        };
+        const DevCounters c1 = fold(s->rb_ctr, s->rb_bctr), c0 = fold(s->rb0_ctr, s->rb0_bctr);
+        r.over_limit_count = c1.over - c0.over; r.cache_hits = c1.hits - c0.hits; r.cache_misses = c1.misses - c0.misses;
+        r.cache_size = c1.size;
+    }
+    // two new keys sharing one 64-bit hash (or one claim fingerprint) inside the batch: re-submit those items on the host
+    // path, which runs the careful rounds
+    if (memchr(r.err, GUBER_ITEM_E_RETRY, s->n)) {
+        std::vector<uint32_t> again;
+        for (uint32_t i = 0; i < s->n; ++i) if (r.err[i] == GUBER_ITEM_E_RETRY) again.push_back(i);
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+        guber_batch_t hb = s->batch;
+        int rc0 = engine_refresh_counters(e);
+        if (rc0) return rc0;
+        const DevCounters t0 = e->last_ctr;
+        for (int round = 0; round < 64 && !again.empty(); ++round) {
+            e->careful = true;
+            const int rc = eval_host_once(e, &hb, &r, again.data(), (uint32_t)again.size(), nullptr);
+            e->careful = false;
+            if (rc) return rc;
+            std::vector<uint32_t> next;
+            for (uint32_t i : again) if (r.err[i] == GUBER_ITEM_E_RETRY) next.push_back(i);
+            again.swap(next);
+        }
+        r.over_limit_count += e->last_ctr.over - t0.over; r.cache_hits += e->last_ctr.hits - t0.hits; r.cache_misses += e->last_ctr.misses - t0.misses;
+        r.cache_size = e->last_ctr.size;
+    }
+    return GUBER_OK;
+}
+
 extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) { return eval_batch_host(e, b, r, nullptr); }
 extern "C" int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* ev) {
     if (!ev) return fail(GUBER_E_INVALID_ARG, "null store events");

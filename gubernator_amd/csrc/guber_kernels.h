@@ -227,6 +227,10 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
             }
         }
         tile_put(sreq, tid, mine);
+        if (W.st_hits) {                                             // the batch is in host memory: keep a copy for k_eval2
+            W.st_hits[g] = mine.hits; W.st_limit[g] = mine.limit; W.st_duration[g] = mine.duration; W.st_burst[g] = mine.burst;
+            W.st_created[g] = mine.created_at; W.st_behavior[g] = mine.behavior; W.st_algorithm[g] = mine.algorithm; W.st_owner[g] = mine.is_owner;
+        }
         GB_STAMPW(7);
     }
     soff[tid] = off; slen[tid] = len;

@@ -134,6 +134,9 @@ struct Work {
     unsigned long long* seg_tilemask;   // [2][cap][FT_WORDS]: (members in these 32 tiles) << 32 | tile bitmap
     uint32_t* did_prev;                 // segment ids of the previous batch (which entries of the other copy to clear)
     uint16_t* tilerow;                  // [cap][FT_MAX_TILES]: members per (segment, tile) — written only for keys that span several tiles of a word
+    // request columns copied to HBM by k_front when the batch lives in host memory (zero-copy path): k_eval2 reads the copy,
+    // so every request field crosses PCIe once.  null = k_eval2 reads the batch's own arrays.
+    int64_t *st_hits, *st_limit, *st_duration, *st_burst, *st_created; uint32_t* st_behavior; uint8_t *st_algorithm, *st_owner;
     SegRec* srec;                       // [cap] segment records of the two-launch pipeline
     int64_t* sinv;                      // [cap] CacheItem.InvalidAt of the segments whose record says SM_HAS_INVALID
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)

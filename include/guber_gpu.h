@@ -185,6 +185,27 @@ int guber_eval_batch(guber_engine_t* e, const guber_batch_t* batch, guber_result
  * the host).  Asynchronous on the engine stream. */
 int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_result_t* result);
 
+/* ---- stages: the overlapped end-to-end path.  A stage is one batch's worth of request / response arrays in device-visible
+ *      host memory.  The caller (a batcher goroutine) writes requests straight into guber_stage_batch()'s arrays as they
+ *      arrive — no Go pointers are retained, nothing is copied or allocated per batch — sets n and now_ms, and submits; the
+ *      kernels read the arrays and write guber_stage_result()'s arrays in place over PCIe.  guber_stage_submit returns at
+ *      once; guber_stage_wait blocks until the responses are there (a polled sequence number for batches <= 256, a HIP
+ *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With two stages per engine the
+ *      batcher fills one while the GPU evaluates the other.  Stages of one engine are evaluated in submission order; the one
+ *      exception are items that hit the internal retry (two keys under one 64-bit hash inside a batch, ~1e-6 per batch): they
+ *      are re-run by guber_stage_wait, i.e. possibly after the next stage already in flight — the order two concurrent
+ *      GetRateLimits calls have in the reference too (none).  Callers that need strict order keep one stage in flight.
+ *      Optional request arrays may be switched off by setting the pointer in guber_stage_batch() to NULL (burst, created_at,
+ *      is_owner, behavior, algorithm: the guber_batch_t defaults apply); key_bytes_cap = 0 -> 64 bytes per request. */
+typedef struct guber_stage guber_stage_t;
+int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out);
+void guber_stage_destroy(guber_stage_t* s);
+guber_batch_t* guber_stage_batch(guber_stage_t* s);
+guber_result_t* guber_stage_result(guber_stage_t* s);
+uint32_t guber_stage_capacity(guber_stage_t* s, uint32_t* key_bytes_cap);
+int guber_stage_submit(guber_stage_t* s);
+int guber_stage_wait(guber_stage_t* s);
+
 /* A queue of device-resident batches enqueued back to back on the engine stream in one call (what a batcher goroutine
  * that has several full batches waiting does, peer_client.go:284-337): batches[i] -> results[i], i = 0..count-1, in
  * order.  Asynchronous like guber_eval_batch_dev; stops at the first batch that fails to enqueue and returns its code

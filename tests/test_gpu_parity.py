@@ -566,6 +566,49 @@ def test_small_batches_one_launch_path():
     e.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1])
+def test_stage_path_two_in_flight_matches_oracle(flags):
+    """guber_stage_*: request arrays written in place into device-visible host memory, two batches in flight, responses read in
+    place — against the oracle, batch sizes on both sides of the one-launch limit; with the weak test hash (flags 1) distinct
+    keys collide and guber_stage_wait has to resolve the internal retries."""
+    rng = np.random.default_rng(77 + flags)
+    o, e = Oracle(cache_size=1 << 16), engine(cache_size=8192, max_batch=4096, flags=flags)
+    stages = [ga.Stage(e, 4096, key_bytes_cap=4096 * 24) for _ in range(2)]
+    now = streams.NOW0
+    pending = None
+    for step in range(120):
+        n = int(rng.choice([1, 3, 200, 256, 257, 1000, 4096]))
+        ids = rng.integers(0, 60 if flags else 400, n)
+        keys = [b"stage_%d" % int(i) for i in ids]
+        hits = np.full(n, int(rng.choice([0, 1, 2]))) if rng.random() < 0.8 else rng.choice([0, 1, 3], n)
+        hb = HostBatch(keys, hits, 50, int(rng.choice([100, 60_000])), now, algorithm=(ids % 2).astype(np.uint8), burst=0,
+                       created_at=now, is_owner=1, behavior=int(rng.choice([0, 32])))
+        st = stages[step % 2]
+        st.fill(hb)
+        st.submit()
+        if flags:                        # colliding keys go through the internal retry in wait(): strict order needs one stage in flight
+            st.wait()
+            support.assert_results_equal(st.result(), o.eval(hb), f"flags {flags} step {step} n {n}")
+            now += int(rng.choice([0, 1, 30, 700]))
+            continue
+        if pending is not None:
+            pst, phb, pstep = pending
+            pst.wait()
+            got, want = pst.result(), o.eval(phb)
+            support.assert_results_equal(got, want, f"flags {flags} step {pstep} n {phb.n}")
+            assert got.counters()[:3] == want.counters()[:3], (pstep, got.counters(), want.counters())
+        pending = (st, hb, step)
+        now += int(rng.choice([0, 1, 30, 700]))
+    if pending is not None:
+        pst, phb, pstep = pending
+        pst.wait()
+        support.assert_results_equal(pst.result(), o.eval(phb), f"flags {flags} last step")
+    assert e.size() == o.size()
+    for st in stages:
+        st.close()
+    e.close()
+
+
 def test_claim_table_epoch_wraps():
     """The claim table's cells are tagged with a 16-bit batch epoch; after 65 535 batches the table is wiped and the
     epoch restarts.  66 500 small batches (duplicates inside each) straddle the wrap and must stay bit-exact."""
