@@ -30,7 +30,8 @@ ABI_SYMBOLS = [
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
     "guber_eval_batches_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
     "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_stage_create", "guber_stage_destroy",
-    "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_create_multi",
+    "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
@@ -439,12 +440,48 @@ class V1Instance:
     GPUWorkerPool.  Thread-safe; requests are dicts with the RateLimitReq field names."""
     ERR_STRIDE = 200
 
-    def __init__(self, cache_size=50_000, device=0, batch_limit=1000, batch_wait_us=500, flags=0, shards=1):
-        cfg = GuberConfig(C.sizeof(GuberConfig), device, cache_size, 0, max(batch_limit, 1024), 0, None, flags, 0)
+    def __init__(self, cache_size=50_000, device=0, batch_limit=1000, batch_wait_us=500, flags=0, shards=1, devices=None, max_key_bytes=0):
+        """devices: list of HIP ordinals = the peers gpu0..gpuN-1 of the replicated consistent hash (the same ordinal may repeat:
+        logical devices on one GPU); shards = Config.Workers per device."""
+        cfg = GuberConfig(C.sizeof(GuberConfig), device, cache_size, 0, max(batch_limit, 1024), max_key_bytes, None, flags, 0)
         self.h = C.c_void_p()
         L = lib()
-        L.guber_pool_create_sharded.argtypes = [C.POINTER(GuberConfig), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
-        _check(L.guber_pool_create_sharded(C.byref(cfg), shards, batch_limit, batch_wait_us, C.byref(self.h)))
+        L.guber_pool_create_multi.argtypes = [C.POINTER(GuberConfig), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_pool_shards.argtypes = [C.c_void_p]
+        L.guber_pool_shards.restype = C.c_uint32
+        L.guber_pool_device_of.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.guber_pool_device_of.restype = C.c_uint32
+        L.guber_pool_shard_of.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.guber_pool_shard_of.restype = C.c_uint32
+        L.guber_pool_engine_at.argtypes = [C.c_void_p, C.c_uint32]
+        L.guber_pool_engine_at.restype = C.c_void_p
+        L.guber_pool_metrics.argtypes = [C.c_void_p, C.c_void_p]
+        devs = list(devices) if devices else []
+        arr = (C.c_int32 * max(len(devs), 1))(*devs) if devs else None
+        _check(L.guber_pool_create_multi(C.byref(cfg), arr, len(devs), shards, batch_limit, batch_wait_us, C.byref(self.h)))
+
+    def device_of(self, key):
+        kb = key if isinstance(key, bytes) else key.encode()
+        return lib().guber_pool_device_of(self.h, kb, len(kb))
+
+    def shard_of(self, key):
+        kb = key if isinstance(key, bytes) else key.encode()
+        return lib().guber_pool_shard_of(self.h, kb, len(kb))
+
+    def n_shards(self):
+        return lib().guber_pool_shards(self.h)
+
+    def shard_size(self, shard):
+        return lib().guber_size(lib().guber_pool_engine_at(self.h, shard))
+
+    def metrics(self):
+        class M(C.Structure):
+            _fields_ = [(f, C.c_uint64) for f in ("batches", "requests", "queue_length", "queue_length_max", "send_duration_us_sum",
+                                                  "send_duration_us_max", "batch_size_max", "in_flight", "key_too_long", "flush_on_key_bytes")] + \
+                       [("shards", C.c_uint32), ("devices", C.c_uint32)]
+        m = M()
+        _check(lib().guber_pool_metrics(self.h, C.byref(m)))
+        return {f[0]: getattr(m, f[0]) for f in M._fields_}
 
     def set_clock(self, now_ms):
         lib().guber_pool_set_clock(self.h, now_ms)

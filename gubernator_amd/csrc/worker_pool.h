@@ -1,10 +1,18 @@
 // worker_pool.h — C++ host layer above the C ABI, mirroring the reference's call surface for the path:
 //   gubernator::GPUWorkerPool   <->  WorkerPool            workers.go:54-626
 //   gubernator::V1Instance      <->  V1Instance.GetRateLimits (local-owner slice)  gubernator.go:183-306
-// Same names, argument meaning and error behaviour; what changes is the mechanism: callers from any
-// number of threads are collected by one batcher thread (flush at batch_limit items or batch_wait after
-// the first one — the policy of peer_client.go:284-337) and evaluated with one guber_eval_batch.
+// Same names, argument meaning and error behaviour; what changes is the mechanism: callers from any number of threads
+// are collected per shard by one batcher thread (flush at batch_limit items or batch_wait after the first one — the
+// policy of peer_client.go:284-337), written IN PLACE into one of the shard's two stages (device-visible host memory,
+// include/guber_gpu.h guber_stage_*) and submitted; while the GPU evaluates one stage the batcher fills the other.
+// Nothing is allocated per flush.
+//
+// Shards: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
+// over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers —
+// and inside a device the shard follows the reference's worker rule (XXH64 range, workers.go:153-155,180-184).  The same
+// device ordinal may be listed several times: logical devices on one GPU (single-GPU boxes, tests).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -37,11 +45,10 @@ constexpr uint32_t kMaxBatchSize = 1000;              // gubernator.go:40
 
 class GPUWorkerPool {
  public:
-    // `shards` = Config.Workers of the reference (config.go:110, workers.go:125-151): the key space is split by
-    // hash range into that many independent caches, here one HBM table + HIP stream + batcher thread each, so that
-    // batches of different shards overlap on the GPU (4 saturate an MI355X).  cfg.cache_size is per pool, as in the
-    // reference (each shard gets cache_size / shards, workers.go:132).
-    GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards = 1);
+    // `shards` = Config.Workers of the reference (config.go:110, workers.go:125-151) per device; cfg.cache_size is per pool, as
+    // in the reference (each shard gets cache_size / shards, workers.go:132).  devices empty = {cfg.device}.
+    GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards = 1,
+                  const std::vector<int32_t>& devices = {});
     ~GPUWorkerPool();
     bool ok() const { return !shards_.empty() && create_rc_ == 0; }
     int create_error() const { return create_rc_; }
@@ -49,7 +56,8 @@ class GPUWorkerPool {
     // WorkerPool.GetRateLimit (workers.go:261): blocks until the request's batch has been evaluated.
     // Returns false with resp->error set when the reference would return an error.
     bool GetRateLimit(const RateLimitReq& r, RateLimitReqState st, RateLimitResp* resp);
-    // Submit many requests, answer all (used by V1Instance::GetRateLimits; order of same-key requests is kept).
+    // Submit many requests, answer all (used by V1Instance::GetRateLimits; order of same-key requests is kept; a mixed batch
+    // is split by owning device / shard and the answers land in the callers' slots: functional_test.go:1638-1686).
     void GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
                           std::vector<RateLimitResp*>& out);
     int AddCacheItem(const guber_item_t& item);                                  // workers.go:537
@@ -60,39 +68,53 @@ class GPUWorkerPool {
     int Store(const std::function<void(const guber_item_t&)>& save);
     int64_t Size();
     void Close();                                                                // workers.go:157
-    // clock.Freeze / clock.Advance of the reference's tests: 0 = wall clock
     // Config.Store (config.go:99, store.go:49-65): call before the first request; nullptr = none
-    void SetStore(const guber_store_callbacks_t* cb) { has_store_ = cb != nullptr; if (cb) store_ = *cb; }
-    void SetClockMs(int64_t now_ms) { frozen_ms_ = now_ms; }
+    void SetStore(const guber_store_callbacks_t* cb) { if (cb) store_ = *cb; has_store_.store(cb != nullptr); }
+    // clock.Freeze / clock.Advance of the reference's tests: 0 = wall clock
+    void SetClockMs(int64_t now_ms) { frozen_ms_.store(now_ms); }
     int64_t NowMs() const;
     guber_engine_t* engine(uint32_t shard = 0) { return shard < shards_.size() ? shards_[shard]->engine : nullptr; }
     uint32_t shards() const { return (uint32_t)shards_.size(); }
-    // WorkerPool.getWorker (workers.go:180-184): shard = (XXH64(key) >> 1) / (2^63 / shards)
-    uint32_t ShardOf(const std::string& key) const;
+    uint32_t devices() const { return n_devices_; }
+    // the device a key belongs to (ReplicatedConsistentHash.Get, replicated_hash.go:104-119) and its shard index
+    // (device * shards_per_device + WorkerPool.getWorker, workers.go:180-184)
+    uint32_t DeviceOf(const uint8_t* key, uint32_t len) const;
+    uint32_t ShardOf(const std::string& key) const { return ShardOf((const uint8_t*)key.data(), (uint32_t)key.size()); }
+    uint32_t ShardOf(const uint8_t* key, uint32_t len) const;
     uint64_t batches_flushed() const;
+    void Metrics(guber_pool_metrics_t* out) const;   // gubernator_batch_queue_length / gubernator_batch_send_duration analogues (gubernator.go:96-107)
 
  private:
     struct Call { std::mutex mu; std::condition_variable cv; size_t remaining = 0; };
-    struct Pending { const RateLimitReq* req; RateLimitReqState st; RateLimitResp* resp; Call* call; };
+    struct Pending { const RateLimitReq* req; RateLimitReqState st; RateLimitResp* resp; Call* call; uint32_t key_len; };
     struct Shard {              // one "worker" of the reference: its own cache (engine), queue and goroutine (thread)
         guber_engine_t* engine = nullptr;
+        guber_stage_t* stage[2] = {nullptr, nullptr};
+        int32_t device = 0;
         std::mutex mu;
         std::condition_variable cv;
         std::vector<Pending> queue;
         bool closing = false;
         std::thread thread;
-        uint64_t flushed = 0;
+        std::atomic<uint64_t> flushed{0}, requests{0}, queue_max{0}, send_us_sum{0}, send_us_max{0}, batch_max{0}, in_flight{0},
+            key_too_long{0}, flush_on_key_bytes{0};
     };
+    struct Flight { guber_stage_t* stage = nullptr; std::vector<Pending> batch; int64_t t0_us = 0; };
     void run(Shard& sh);
-    void flush(Shard& sh, std::vector<Pending>& batch);
+    bool fill_and_submit(Shard& sh, Flight& f);           // false: the batch was answered synchronously (Store path / error)
+    void complete(Shard& sh, Flight& f, int rc);
+    void flush_with_store(Shard& sh, std::vector<Pending>& batch);
+    static void answer(Pending& p, int rc, uint8_t err, uint8_t status, int64_t limit, int64_t remaining, int64_t reset_time);
 
     std::vector<std::unique_ptr<Shard>> shards_;
+    guber_ring_t* ring_ = nullptr;
+    uint32_t n_devices_ = 1, shards_per_device_ = 1;
     uint64_t ring_step_ = 0;
     int create_rc_ = 0;
-    uint32_t batch_limit_, batch_wait_us_;
-    bool closed_ = false;
-    volatile int64_t frozen_ms_ = 0;
-    bool has_store_ = false;
+    uint32_t batch_limit_, batch_wait_us_, max_key_ = 1024, key_cap_ = 0;
+    std::atomic<bool> closed_{false};
+    std::atomic<int64_t> frozen_ms_{0};
+    std::atomic<bool> has_store_{false};
     guber_store_callbacks_t store_{};
 };
 

@@ -328,6 +328,30 @@ int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t 
  * engines + batcher threads inside one GPU, so that batches of different shards overlap; cfg->cache_size is the pool total. */
 int guber_pool_create_sharded(const guber_config_t* cfg, uint32_t shards, uint32_t batch_limit, uint32_t batch_wait_us,
                               guber_pool_t** out);
+/* Several devices: devices[i] = HIP ordinal of peer "gpu<i>" on the reference's replicated consistent hash (replicated_hash.go:
+ * 78-119, 512 vnodes, fnv1) — a key belongs to the device the ring assigns it to, and inside the device to the shard of the
+ * worker rule above.  A mixed batch is split by owner on the host and every request is answered in its own slot
+ * (functional_test.go:1638-1686).  The same ordinal may appear several times: logical devices on one GPU.  n_devices = 0 ->
+ * {cfg->device}.  cfg->cache_size is the pool total. */
+int guber_pool_create_multi(const guber_config_t* cfg, const int32_t* devices, uint32_t n_devices, uint32_t shards_per_device,
+                            uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out);
+uint32_t guber_pool_shards(guber_pool_t* p);
+uint32_t guber_pool_device_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len);   /* ReplicatedConsistentHash.Get over gpu0..gpuN-1 */
+guber_engine_t* guber_pool_engine_at(guber_pool_t* p, uint32_t shard);
+/* batcher metrics: the pool's analogues of gubernator_batch_queue_length / gubernator_batch_send_duration (gubernator.go:96-107) */
+typedef struct guber_pool_metrics {
+    uint64_t batches, requests;            /* flushed so far */
+    uint64_t queue_length;                 /* requests waiting in the shards' queues right now */
+    uint64_t queue_length_max;             /* high-water mark of one shard's queue */
+    uint64_t send_duration_us_sum;         /* flush start -> responses delivered, summed over batches (divide by `batches`) */
+    uint64_t send_duration_us_max;
+    uint64_t batch_size_max;
+    uint64_t in_flight;                    /* batches submitted and not yet delivered */
+    uint64_t key_too_long;                 /* requests answered GUBER_ITEM_E_KEY_TOO_LONG without touching the device */
+    uint64_t flush_on_key_bytes;           /* batches flushed early because the next key did not fit the stage's key buffer */
+    uint32_t shards, devices;
+} guber_pool_metrics_t;
+int guber_pool_metrics(guber_pool_t* p, guber_pool_metrics_t* out);
 void guber_pool_destroy(guber_pool_t* p);
 void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms);
 /* Config.Store for the pool: the batcher drives guber_probe_missing / guber_add_items / guber_eval_batch_store and

@@ -245,3 +245,43 @@ def test_gubernator_pool_load_store(workers):
         for f in ("key", "algorithm", "limit", "duration", "remaining", "stamp", "expire_at"):
             assert got[f] == want[f], (f, want, got)
     inst.close()
+
+
+def test_multi_device_pool_routes_by_the_ring_and_answers_in_place():
+    """guber_pool_create_multi with three LOGICAL devices on this GPU (peers gpu0..gpu2 of the replicated consistent hash) x 2
+    shards: a key's device is the ring's owner (replicated_hash.go:104-119), mixed batches are split by owner and every request
+    is answered in its own slot (functional_test.go:1638-1686) — equal to ONE unsharded oracle on a mixed stream; the batcher
+    metrics move (gubernator.go:96-107 analogues); over-long keys are answered per item without touching the device."""
+    from support import HostBatch, Oracle
+    inst = ga.V1Instance(cache_size=60_000, batch_limit=512, batch_wait_us=100, shards=2, devices=[0, 0, 0], max_key_bytes=64)
+    assert inst.n_shards() == 6
+    ring = ga.Ring(["gpu0", "gpu1", "gpu2"])
+    keys = [f"multi_k{i}" for i in range(3000)]
+    want_dev = ring.route([f"mdp_{k}" for k in keys])
+    assert [inst.device_of(f"mdp_{k}") for k in keys] == want_dev.tolist()
+    assert all(inst.shard_of(f"mdp_{k}") // 2 == d for k, d in zip(keys, want_dev.tolist()))
+    o = Oracle(cache_size=1 << 20)
+    rng = np.random.default_rng(8)
+    now = 1_700_000_000_000
+    for step in range(30):
+        inst.set_clock(now)
+        ids = rng.integers(0, 300, 900)
+        reqs = [dict(name="mdp", unique_key=f"multi_k{int(i)}", hits=int(h), limit=40, duration=60_000, algorithm=int(i) % 2, created_at=now)
+                for i, h in zip(ids, rng.choice([0, 1, 2], 900))]
+        out = inst.GetRateLimits(reqs)
+        want = o.eval(HostBatch([f"mdp_multi_k{int(i)}" for i in ids], [r["hits"] for r in reqs], 40, 60_000, now, algorithm=(ids % 2).astype(np.uint8),
+                                created_at=now))
+        got_rows = [(x["status"], x["limit"], x["remaining"], x["reset_time"], 0 if not x["error"] else 1) for x in out]
+        assert got_rows == want.rows(), f"step {step}"
+        now += 7
+    sizes = [inst.shard_size(j) for j in range(6)]
+    # (fnv1 — the reference's library default — spreads keys that differ only in their last digits unevenly: no balance claim here)
+    assert sum(sizes) == o.size() and sum(1 for d in range(3) if sizes[2 * d] + sizes[2 * d + 1] > 0) >= 2, sizes
+    m = inst.metrics()
+    assert m["devices"] == 3 and m["shards"] == 6 and m["requests"] == 30 * 900 and m["batches"] >= 30 and m["queue_length"] == 0
+    assert m["send_duration_us_sum"] > 0 and m["batch_size_max"] <= 512 and m["in_flight"] == 0
+    long_key = "x" * 200
+    out = inst.GetRateLimits([dict(name="mdp", unique_key=long_key, hits=1, limit=5, duration=1000), dict(name="mdp", unique_key="ok", hits=1, limit=5, duration=1000)])
+    assert "too long" in out[0]["error"] and out[1]["error"] == "" and out[1]["remaining"] == 4
+    assert inst.metrics()["key_too_long"] == 1
+    inst.close()
