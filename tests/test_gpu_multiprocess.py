@@ -1,0 +1,93 @@
+"""N > 1 with REAL engines: two processes (one rank each, both on this box's GPU), a gloo process group for the host-side
+collectives.  (i) the key space split by the reference's ring, every rank evaluating only what it owns on its own engine,
+equals one unsharded oracle; (ii) GLOBAL behaviour — replicas, hit forwarding, owner broadcast (global.go) — with engines as
+the nodes equals the global.go model on every rank; (iii) the native exchange (guber_comm_create_rank + guber_global_sync over
+RCCL) is attempted with both ranks on the one GPU: RCCL rejects two ranks on one device, which is reported, not hidden — on a
+multi-GPU node the same code path runs over xGMI."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gubernator_amd as ga
+    import streams
+    import support
+    import test_global as tg
+    from global_model import GlobalModel
+    from gubernator_amd import global_sync, shard
+    # ---- (i) sharded evaluation on engines == one unsharded oracle ----
+    K = 50_000
+    table = streams.key_table(K)
+    mine = shard.owned_key_ids(table, world, rank, chunk=25_000)
+    assert shard.sum_over_ranks(len(mine)) == K
+    eng = ga.Engine(cache_size=K, device=0, max_batch=8192)
+    glob = support.Oracle(cache_size=1 << 20)
+    rng = np.random.default_rng(4321)                      # the same stream on every rank
+    now = streams.NOW0
+    for step in range(8):
+        ids = rng.zipf(1.2, 6000) % K
+        want = glob.eval(streams.bench_batch(table, ids, now + step * 7000, algorithm=step % 2, limit=5))
+        sel = np.nonzero(np.isin(ids, mine))[0]
+        got = eng.eval(streams.bench_batch(table, ids[sel], now + step * 7000, algorithm=step % 2, limit=5))
+        for name in ("status", "remaining", "reset_time", "limit", "err"):
+            assert np.array_equal(getattr(got, name)[:len(sel)], getattr(want, name)[:len(ids)][sel]), (rank, step, name)
+    assert shard.sum_over_ranks(eng.size()) == glob.size()
+    eng.close()
+    # ---- (ii) GLOBAL with engines as the nodes == the global.go model ----
+    ring = ga.Ring([f"gpu{i}" for i in range(world)])
+    node = ga.Engine(cache_size=4096, device=0, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL)
+    gs = global_sync.GlobalSync(node, rank, world, ring, global_sync.TorchTransport())
+    model = GlobalModel(world, lambda k: int(ring.route([k])[0]))   # every rank replays the whole model
+    for r, b, t, do_sync in tg.random_global_stream(11, world, 120):
+        want = [model.request(r, dict(key=k, hits=int(h), limit=int(l), duration=int(d), algorithm=int(a), behavior=int(bh) | 2, burst=0), t)
+                for k, h, l, d, a, bh in zip(b["keys"], b["hits"], b["limit"], b["duration"], b["algorithm"], b["behavior"])]
+        if r == rank:
+            got = gs.evaluate(b["keys"], b["hits"], b["limit"], b["duration"], t, algorithm=b["algorithm"], behavior=b["behavior"], burst=0,
+                              created_at=t)
+            assert got.rows() == want, (rank, t)
+        if do_sync:
+            gs.sync(t)
+            model.sync(t)
+    # ---- (iii) the native RCCL exchange with two ranks on ONE GPU ----
+    from gubernator_amd import global_native as gn
+    note = "not attempted"
+    try:
+        uid = [gn.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = gn.Comm.rank(node, rank, world, uid[0], ring)
+        comm.sync(t + 1)
+        note = "RCCL accepted two ranks on one GPU: native guber_global_sync ran"
+        comm.close()
+    except ga.GuberError as ex:
+        note = f"RCCL refused two ranks on one GPU (expected on a 1-GPU box): {ex}"
+    node.close()
+    dist.barrier()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(note)
+    dist.destroy_process_group()
+
+
+def test_two_processes_real_engines_partition_and_global(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    notes = [open(tmp_path / f"ok{r}").read() for r in range(world)]
+    print("native RCCL on one GPU:", notes[0])
+    assert len(notes) == world
