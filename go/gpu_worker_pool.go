@@ -10,9 +10,13 @@
 //	GetCacheItem(ctx, key) (*CacheItem, bool, error)                               workers.go:583
 //	Load(ctx) error / Store(ctx) error / Close() error                             gubernator.go:143,161,169
 //
-// Requests from any number of gRPC goroutines are routed to their key's shard (the reference's worker rule) and
-// collected there by one batcher goroutine (same policy as peer_client.go:284-337: flush at BatchLimit items or
-// after BatchWait) into C-owned pinned SoA buffers and evaluated with ONE guber_eval_batch call.
+// Requests from any number of gRPC goroutines are routed to their key's device (the reference's replicated consistent
+// hash over the peers gpu0..gpuN-1) and shard (the reference's worker rule) and collected there by one batcher goroutine
+// (same policy as peer_client.go:284-337: flush at BatchLimit items or after BatchWait).  The batcher writes every request
+// IN PLACE into a stage — request / response arrays in device-visible host memory owned by the C side (cgo: no Go pointer
+// is retained) — and submits it; the kernels read and write the stage over PCIe, and while one stage is being evaluated
+// the batcher fills the other (guber_stage_*).  This file mirrors gubernator_amd/csrc/worker_pool.cpp, which IS compiled
+// and tested in this repository (tests/test_gpu_host_layer.py), statement by statement.
 
 //go:build gpu
 
@@ -22,6 +26,7 @@ package gubernator
 #cgo CFLAGS: -I${SRCDIR}/include
 #cgo LDFLAGS: -L${SRCDIR}/lib -lguber_hip
 #include <stdlib.h>
+#include <string.h>
 #include "guber_gpu.h"
 */
 import "C"
@@ -47,14 +52,17 @@ type gpuResponse struct {
 	err error
 }
 
-// GPUWorkerPool satisfies the call surface of *WorkerPool.  Like WorkerPool it splits the key space over
-// conf.Workers shards by hash range (workers.go:125-151,180-184); a shard here is one engine (HBM table + HIP
-// stream) with its own batcher goroutine, so that batches of different shards overlap on the GPU — 4 saturate an
-// MI355X (bench.py --shards).
+// GPUWorkerPool satisfies the call surface of *WorkerPool.  devices[i] is the HIP ordinal of peer "gpu<i>"; inside a
+// device the key space is split over conf.Workers shards by hash range like WorkerPool (workers.go:125-151,180-184).  A
+// shard is one engine (HBM table + HIP stream) with its own batcher goroutine, so that batches of different shards
+// overlap on the GPU.
 type GPUWorkerPool struct {
 	conf         *Config
 	hasher       workerHasher // workers.go:70-72
 	hashRingStep uint64       // workers.go:132
+	perDevice    int
+	ring         *C.guber_ring_t // nil with one device
+	comm         *C.guber_comm_t // GLOBAL exchange between the devices' replicas (nil until EnableGlobalSync)
 	shards       []*gpuShard
 }
 
@@ -62,43 +70,101 @@ type GPUWorkerPool struct {
 type gpuShard struct {
 	conf   *Config
 	engine *C.guber_engine_t
+	stage  [2]*C.guber_stage_t
 	queue  chan gpuRequest
 	done   chan struct{}
-	// pinned SoA staging (C memory: cgo forbids the callee to keep Go pointers)
-	cap                                     int
-	keyBytes                                *C.uint8_t
-	keyOff                                  *C.uint32_t
-	hits, limit, duration, burst, createdAt *C.int64_t
-	gregExpire, gregDuration                *C.int64_t
-	algorithm, isOwner                      *C.uint8_t
-	behavior                                *C.uint32_t
-	status, errCode                         *C.uint8_t
-	rLimit, rRemaining, rReset              *C.int64_t
-	// Config.Store side channel (only allocated when conf.Store != nil)
+	limit  int
+	maxKey int // guber_config_t.max_key_bytes: longer keys are answered per item, never copied
+	keyCap int // bytes of a stage's key buffer: a batch whose keys would not fit is flushed early
+	// Config.Store side channel (only allocated when conf.Store != nil; that path is synchronous)
 	missing, storeFlags *C.uint8_t
 	storeItems          *C.guber_item_t
 }
 
-func NewGPUWorkerPool(conf *Config, device int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
+// one batch being filled / in flight: the stage's arrays, the callers waiting for it
+type gpuFlight struct {
+	stage   *C.guber_stage_t
+	b       *C.guber_batch_t
+	r       *C.guber_result_t
+	waiting []gpuRequest
+	tooLong []bool
+	n, off  int
+}
+
+func NewGPUWorkerPool(conf *Config, devices []int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
 	workers := conf.Workers // config.go:110; default = NumCPU, GUBER_GPU_SHARDS overrides it for the GPU pool (4 is enough)
 	if workers <= 0 {
 		workers = 1
 	}
-	p := &GPUWorkerPool{conf: conf, hasher: &hasher{}, hashRingStep: uint64(1<<63) / uint64(workers)} // workers.go:80,132
-	for i := 0; i < workers; i++ {
-		sh, err := newGPUShard(conf, device, conf.CacheSize/workers+1, batchLimit, batchWait) // workers.go:132
-		if err != nil {
-			_ = p.Close()
-			return nil, err
+	if len(devices) == 0 {
+		devices = []int{0}
+	}
+	p := &GPUWorkerPool{conf: conf, hasher: &hasher{}, hashRingStep: uint64(1<<63) / uint64(workers), perDevice: workers} // workers.go:80,132
+	if len(devices) > 1 { // the GPUs of the node are the peers of the reference's ring (replicated_hash.go:78-119)
+		names := make([]*C.char, len(devices))
+		for i := range devices {
+			names[i] = C.CString(fmt.Sprintf("gpu%d", i))
+			defer C.free(unsafe.Pointer(names[i]))
 		}
-		p.shards = append(p.shards, sh)
+		if rc := C.guber_ring_create(&names[0], C.uint32_t(len(devices)), 512, 0, &p.ring); rc != C.GUBER_OK {
+			return nil, fmt.Errorf("guber_ring_create: %s", C.GoString(C.guber_strerror(rc)))
+		}
+	}
+	total := workers * len(devices)
+	for _, dev := range devices {
+		for i := 0; i < workers; i++ {
+			sh, err := newGPUShard(conf, dev, conf.CacheSize/total+1, batchLimit, batchWait) // workers.go:132
+			if err != nil {
+				_ = p.Close()
+				return nil, err
+			}
+			p.shards = append(p.shards, sh)
+		}
 	}
 	return p, nil
 }
 
-// shardOf = WorkerPool.getWorker (workers.go:180-184)
+// shardOf = device by ReplicatedConsistentHash.Get (replicated_hash.go:104-119), then WorkerPool.getWorker
+// (workers.go:180-184) inside the device.
 func (p *GPUWorkerPool) shardOf(key string) *gpuShard {
-	return p.shards[p.hasher.ComputeHash63(key)/p.hashRingStep]
+	dev := 0
+	if p.ring != nil {
+		off := [2]C.uint32_t{0, C.uint32_t(len(key))}
+		var owner C.uint32_t
+		C.guber_ring_route(p.ring, (*C.uint8_t)(unsafe.Pointer(unsafe.StringData(key))), &off[0], 1, &owner)
+		dev = int(owner)
+	}
+	local := int(p.hasher.ComputeHash63(key) / p.hashRingStep)
+	if local >= p.perDevice { // 2^63 is not a multiple of every worker count
+		local = p.perDevice - 1
+	}
+	return p.shards[dev*p.perDevice+local]
+}
+
+// EnableGlobalSync prepares the GLOBAL exchange between the devices' replicas (engines must have been created with
+// GUBER_FLAG_GLOBAL: conf.Behaviors.ForceGlobal or any GLOBAL traffic).  GlobalSync is then one GlobalSyncWait tick
+// (global.go:91-283): hits to their owners over RCCL / xGMI, owners apply and broadcast, every replica installs.
+func (p *GPUWorkerPool) EnableGlobalSync() error {
+	engines := make([]*C.guber_engine_t, 0, len(p.shards)/p.perDevice)
+	for i := 0; i < len(p.shards); i += p.perDevice {
+		engines = append(engines, p.shards[i].engine)
+	}
+	useRccl := C.int(0)
+	if len(engines) > 1 {
+		useRccl = 1
+	}
+	if rc := C.guber_comm_create_local(&engines[0], C.uint32_t(len(engines)), p.ring, useRccl, &p.comm); rc != C.GUBER_OK {
+		return fmt.Errorf("guber_comm_create_local: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
+	}
+	return nil
+}
+func (p *GPUWorkerPool) GlobalSync() error {
+	var st C.guber_global_sync_stats_t
+	if rc := C.guber_global_sync(p.comm, C.int64_t(MillisecondNow()), &st); rc != C.GUBER_OK {
+		return fmt.Errorf("guber_global_sync: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
+	}
+	metricGlobalSendDuration.Observe(float64(st.ms) / 1000)
+	return nil
 }
 
 func (p *GPUWorkerPool) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimitReqState) (*RateLimitResp, error) {
@@ -119,6 +185,16 @@ func (p *GPUWorkerPool) Load(ctx context.Context) error {
 	}
 	pending := make(map[*gpuShard][]C.guber_item_t, len(p.shards))
 	for item := range ch {
+		select { // workers.go:349-360: Load stops when the context is cancelled
+		case <-ctx.Done():
+			for _, items := range pending {
+				for i := range items {
+					C.free(unsafe.Pointer(items[i].key))
+				}
+			}
+			return ctx.Err()
+		default:
+		}
 		sh := p.shardOf(item.Key)
 		pending[sh] = append(pending[sh], toCItem(item.Key, item))
 		if len(pending[sh]) >= 4096 {
@@ -157,33 +233,40 @@ func (p *GPUWorkerPool) Store(ctx context.Context) error {
 }
 
 func (p *GPUWorkerPool) Close() error {
+	if p.comm != nil {
+		C.guber_comm_destroy(p.comm)
+		p.comm = nil
+	}
 	for _, sh := range p.shards {
 		_ = sh.Close()
+	}
+	if p.ring != nil {
+		C.guber_ring_destroy(p.ring)
+		p.ring = nil
 	}
 	return nil
 }
 
 func newGPUShard(conf *Config, device int, cacheSize int, batchLimit int, batchWait time.Duration) (*gpuShard, error) {
+	const maxKey = 1024 // guber_config_t.max_key_bytes default
 	cfg := C.guber_config_t{struct_size: C.uint32_t(unsafe.Sizeof(C.guber_config_t{})), device: C.int32_t(device),
-		cache_size: C.uint64_t(cacheSize), max_batch: C.uint32_t(batchLimit)}
-	p := &gpuShard{conf: conf, queue: make(chan gpuRequest, batchLimit), done: make(chan struct{}), cap: batchLimit}
+		cache_size: C.uint64_t(cacheSize), max_batch: C.uint32_t(batchLimit), max_key_bytes: maxKey, flags: C.GUBER_FLAG_GLOBAL}
+	p := &gpuShard{conf: conf, queue: make(chan gpuRequest, batchLimit), done: make(chan struct{}), limit: batchLimit, maxKey: maxKey}
 	if rc := C.guber_engine_create(&cfg, &p.engine); rc != C.GUBER_OK {
 		return nil, fmt.Errorf("guber_engine_create: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
 	}
-	n := C.size_t(batchLimit)
-	p.keyBytes = (*C.uint8_t)(C.guber_alloc_pinned(n*256 + 16))
-	p.keyOff = (*C.uint32_t)(C.guber_alloc_pinned((n + 1) * 4))
-	alloc64 := func() *C.int64_t { return (*C.int64_t)(C.guber_alloc_pinned(n * 8)) }
-	p.hits, p.limit, p.duration, p.burst, p.createdAt = alloc64(), alloc64(), alloc64(), alloc64(), alloc64()
-	p.gregExpire, p.gregDuration, p.rLimit, p.rRemaining, p.rReset = alloc64(), alloc64(), alloc64(), alloc64(), alloc64()
-	p.algorithm, p.isOwner = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
-	p.status, p.errCode = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
-	p.behavior = (*C.uint32_t)(C.guber_alloc_pinned(n * 4))
+	p.keyCap = batchLimit*96 + maxKey // typical keys; a batch of longer ones is flushed early, never overrun
+	for k := range p.stage {
+		if rc := C.guber_stage_create(p.engine, C.uint32_t(batchLimit), C.uint32_t(p.keyCap), &p.stage[k]); rc != C.GUBER_OK {
+			return nil, fmt.Errorf("guber_stage_create: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
+		}
+	}
 	if conf.Store != nil {
+		n := C.size_t(batchLimit)
 		p.missing, p.storeFlags = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
 		p.storeItems = (*C.guber_item_t)(C.guber_alloc_pinned(n * C.sizeof_guber_item_t))
 	}
-	go p.run(batchLimit, batchWait)
+	go p.run(batchWait)
 	return p, nil
 }
 
@@ -204,101 +287,165 @@ func (p *gpuShard) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimi
 	}
 }
 
-func (p *gpuShard) run(limit int, wait time.Duration) {
+func at64(p *C.int64_t, i int) *C.int64_t { return (*C.int64_t)(unsafe.Add(unsafe.Pointer(p), i*8)) }
+func at32(p *C.uint32_t, i int) *C.uint32_t { return (*C.uint32_t)(unsafe.Add(unsafe.Pointer(p), i*4)) }
+func at8(p *C.uint8_t, i int) *C.uint8_t   { return (*C.uint8_t)(unsafe.Add(unsafe.Pointer(p), i)) }
+
+func stopTimer(t *time.Timer) { // Stop + drain: a stale tick must not flush the next batch's first request alone
+	if !t.Stop() {
+		select {
+		case <-t.C:
+		default:
+		}
+	}
+}
+
+// run is the shard's batcher (worker_pool.cpp GPUWorkerPool::run): requests are written into the current stage as they
+// arrive; the stage is submitted at `limit` requests, when the next key would not fit its key buffer, or `wait` after its
+// first request; while it is evaluated the other stage fills.
+func (p *gpuShard) run(wait time.Duration) {
 	runtime.LockOSThread() // one OS thread owns the HIP context
-	pending := make([]gpuRequest, 0, limit)
+	var fl [2]gpuFlight
+	for k := range fl {
+		fl[k] = gpuFlight{stage: p.stage[k], b: C.guber_stage_batch(p.stage[k]), r: C.guber_stage_result(p.stage[k]),
+			waiting: make([]gpuRequest, 0, p.limit), tooLong: make([]bool, 0, p.limit)}
+	}
+	cur, inflight := 0, false
 	timer := time.NewTimer(wait)
+	stopTimer(timer)
+	submit := func() {
+		stopTimer(timer)
+		f := &fl[cur]
+		if p.conf.Store != nil {
+			p.flushWithStore(f) // synchronous: Store.Get / OnChange / Remove are made in request order
+		} else {
+			*at32(f.b.key_off, f.n) = C.uint32_t(f.off)
+			f.b.n, f.b.now_ms = C.uint32_t(f.n), C.int64_t(clock.Now().UnixNano()/1000000) // MillisecondNow(); DURATION_IS_GREGORIAN is derived from it on the device
+			rc := C.guber_stage_submit(f.stage)
+			if inflight {
+				p.complete(&fl[cur^1], C.GUBER_OK)
+			}
+			if rc != C.GUBER_OK {
+				p.complete(f, rc)
+				inflight = false
+			} else {
+				inflight = true
+				cur ^= 1
+			}
+			return
+		}
+		if inflight {
+			p.complete(&fl[cur^1], C.GUBER_OK)
+			inflight = false
+		}
+	}
 	for {
+		if inflight && len(p.queue) == 0 && fl[cur].n == 0 { // nothing to overlap with: deliver the batch in flight
+			p.complete(&fl[cur^1], C.GUBER_OK)
+			inflight = false
+		}
 		select {
 		case g := <-p.queue:
-			pending = append(pending, g)
-			if len(pending) == 1 {
+			f := &fl[cur]
+			klen := len(g.req.Name) + 1 + len(g.req.UniqueKey)
+			if klen <= p.maxKey && f.off+klen > p.keyCap { // the key would overrun the stage: flush what is there first
+				submit()
+				f = &fl[cur]
+			}
+			p.put(f, g, klen)
+			if f.n == 1 {
 				timer.Reset(wait)
 			}
-			if len(pending) >= limit {
-				p.flush(pending)
-				pending = pending[:0]
+			if f.n >= p.limit {
+				submit()
 			}
 		case <-timer.C:
-			if len(pending) > 0 {
-				p.flush(pending)
-				pending = pending[:0]
+			if fl[cur].n > 0 {
+				submit()
 			}
 		case <-p.done:
+			if inflight {
+				p.complete(&fl[cur^1], C.GUBER_OK)
+			}
 			return
 		}
 	}
 }
 
-func at64(p *C.int64_t, i int) *C.int64_t { return (*C.int64_t)(unsafe.Add(unsafe.Pointer(p), i*8)) }
-func at8(p *C.uint8_t, i int) *C.uint8_t   { return (*C.uint8_t)(unsafe.Add(unsafe.Pointer(p), i)) }
+// put writes one request into the stage in place (HashKey = name + "_" + unique_key, client.go:39-41).
+func (p *gpuShard) put(f *gpuFlight, g gpuRequest, klen int) {
+	r, i := g.req, f.n
+	*at32(f.b.key_off, i) = C.uint32_t(f.off)
+	long := klen > p.maxKey
+	if !long {
+		dst := unsafe.Add(unsafe.Pointer(f.b.key_bytes), f.off)
+		C.memcpy(dst, unsafe.Pointer(unsafe.StringData(r.Name)), C.size_t(len(r.Name)))
+		*(*byte)(unsafe.Add(dst, len(r.Name))) = '_'
+		C.memcpy(unsafe.Add(dst, len(r.Name)+1), unsafe.Pointer(unsafe.StringData(r.UniqueKey)), C.size_t(len(r.UniqueKey)))
+		f.off += klen
+	} // else: an empty key in the batch; the caller is answered GUBER_ITEM_E_KEY_TOO_LONG without the device seeing it
+	*at64(f.b.hits, i), *at64(f.b.limit, i), *at64(f.b.duration, i) = C.int64_t(r.Hits), C.int64_t(r.Limit), C.int64_t(r.Duration)
+	*at64(f.b.burst, i), *at64(f.b.created_at, i) = C.int64_t(r.Burst), C.int64_t(*r.CreatedAt)
+	alg := r.Algorithm
+	if alg < 0 || alg > 1 {
+		alg = 255 // workers.go:317: the engine answers GUBER_ITEM_E_INVALID_ALGORITHM
+	}
+	*at8(f.b.algorithm, i) = C.uint8_t(alg)
+	*at32(f.b.behavior, i) = C.uint32_t(r.Behavior)
+	owner := C.uint8_t(0)
+	if g.state.IsOwner {
+		owner = 1
+	}
+	*at8(f.b.is_owner, i) = owner
+	f.waiting, f.tooLong = append(f.waiting, g), append(f.tooLong, long)
+	f.n++
+}
 
-func (p *gpuShard) flush(batch []gpuRequest) {
-	now := clock.Now()
-	nowMs := now.UnixNano() / 1000000
-	off := 0
-	for i, g := range batch {
-		r := g.req
-		key := r.HashKey() // client.go:39-41
-		C.memcpy(unsafe.Add(unsafe.Pointer(p.keyBytes), off), unsafe.Pointer(unsafe.StringData(key)), C.size_t(len(key)))
-		*(*C.uint32_t)(unsafe.Add(unsafe.Pointer(p.keyOff), i*4)) = C.uint32_t(off)
-		off += len(key)
-		*at64(p.hits, i), *at64(p.limit, i), *at64(p.duration, i) = C.int64_t(r.Hits), C.int64_t(r.Limit), C.int64_t(r.Duration)
-		*at64(p.burst, i), *at64(p.createdAt, i) = C.int64_t(r.Burst), C.int64_t(*r.CreatedAt)
-		alg := r.Algorithm
-		if alg < 0 || alg > 1 {
-			alg = 255 // workers.go:317: the engine answers GUBER_ITEM_E_INVALID_ALGORITHM
-		}
-		*at8(p.algorithm, i) = C.uint8_t(alg)
-		*(*C.uint32_t)(unsafe.Add(unsafe.Pointer(p.behavior), i*4)) = C.uint32_t(r.Behavior)
-		owner := C.uint8_t(0)
-		if g.state.IsOwner {
-			owner = 1
-		}
-		*at8(p.isOwner, i) = owner
-		*at64(p.gregExpire, i), *at64(p.gregDuration, i) = 0, 0
-		if HasBehavior(r.Behavior, Behavior_DURATION_IS_GREGORIAN) { // interval.go:84-148, evaluated once per batch
-			var e, d C.int64_t
-			if rc := C.guber_gregorian_expiration(C.int64_t(now.UnixNano()), C.int64_t(r.Duration), &e); rc != 0 {
-				d = C.int64_t(rc) // negative = the reference's error, surfaced only on the paths that call it
-			} else if rc := C.guber_gregorian_duration(C.int64_t(now.UnixNano()), C.int64_t(r.Duration), &d); rc != 0 {
-				d = C.int64_t(rc)
-			}
-			*at64(p.gregExpire, i), *at64(p.gregDuration, i) = e, d
-		}
+// complete waits for the stage (unless rc already carries a submit error) and answers its callers.
+func (p *gpuShard) complete(f *gpuFlight, rc C.int) {
+	if rc == C.GUBER_OK {
+		rc = C.guber_stage_wait(f.stage)
 	}
-	*(*C.uint32_t)(unsafe.Add(unsafe.Pointer(p.keyOff), len(batch)*4)) = C.uint32_t(off)
-	b := C.guber_batch_t{n: C.uint32_t(len(batch)), key_bytes: p.keyBytes, key_off: p.keyOff, hits: p.hits, limit: p.limit,
-		duration: p.duration, burst: p.burst, created_at: p.createdAt, algorithm: p.algorithm, behavior: p.behavior,
-		is_owner: p.isOwner, greg_expire: p.gregExpire, greg_duration: p.gregDuration, now_ms: C.int64_t(nowMs)}
-	res := C.guber_result_t{status: p.status, limit: p.rLimit, remaining: p.rRemaining, reset_time: p.rReset, err: p.errCode}
-	var rc C.int
-	if p.conf.Store == nil {
-		rc = C.guber_eval_batch(p.engine, &b, &res)
-	} else {
-		rc = p.evalWithStore(batch, &b, &res)
+	res := f.r
+	if rc == C.GUBER_OK { // prometheus: the engine returns the per-batch aggregates of the reference's counters
+		metricOverLimitCounter.Add(float64(res.over_limit_count))             // algorithms.go:165,185,243,391,409,471
+		metricCacheAccess.WithLabelValues("hit").Add(float64(res.cache_hits)) // lrucache.go:117,121,126
+		metricCacheAccess.WithLabelValues("miss").Add(float64(res.cache_misses))
+		metricCacheSize.Set(float64(res.cache_size))
+		metricCacheUnexpiredEvictions.Add(float64(res.unexpired_evictions)) // lrucache.go:142-146
 	}
-	// prometheus: the engine returns the per-batch aggregates of the reference's counters
-	metricOverLimitCounter.Add(float64(res.over_limit_count))             // algorithms.go:165,185,243,391,409,471
-	metricCacheAccess.WithLabelValues("hit").Add(float64(res.cache_hits)) // lrucache.go:117,121,126
-	metricCacheAccess.WithLabelValues("miss").Add(float64(res.cache_misses))
-	metricCacheSize.Set(float64(res.cache_size))
-	for i, g := range batch {
-		if rc != C.GUBER_OK {
-			g.resp <- gpuResponse{nil, errors.Errorf("gpu engine: %s", C.GoString(C.guber_strerror(rc)))}
-			continue
-		}
-		if e := *at8(p.errCode, i); e != 0 {
-			msg := C.GoString(C.guber_item_strerror(C.uint8_t(e)))
-			if e == C.GUBER_ITEM_E_INVALID_ALGORITHM {
-				msg = fmt.Sprintf(msg, g.req.Algorithm) // "Invalid rate limit algorithm '%d'"
-			}
-			g.resp <- gpuResponse{nil, errors.New(msg)}
-			continue
-		}
-		g.resp <- gpuResponse{&RateLimitResp{Status: Status(*at8(p.status, i)), Limit: int64(*at64(p.rLimit, i)),
-			Remaining: int64(*at64(p.rRemaining, i)), ResetTime: int64(*at64(p.rReset, i))}, nil}
+	for i, g := range f.waiting {
+		g.resp <- p.answer(g, rc, f.tooLong[i], *at8(res.err, i), *at8(res.status, i), *at64(res.limit, i), *at64(res.remaining, i), *at64(res.reset_time, i))
 	}
+	f.waiting, f.tooLong, f.n, f.off = f.waiting[:0], f.tooLong[:0], 0, 0
+}
+
+func (p *gpuShard) answer(g gpuRequest, rc C.int, tooLong bool, e, status C.uint8_t, limit, remaining, reset C.int64_t) gpuResponse {
+	if rc != C.GUBER_OK {
+		return gpuResponse{nil, errors.Errorf("gpu engine: %s", C.GoString(C.guber_strerror(rc)))}
+	}
+	if tooLong {
+		e = C.GUBER_ITEM_E_KEY_TOO_LONG
+	}
+	if e != 0 {
+		msg := C.GoString(C.guber_item_strerror(e))
+		if e == C.GUBER_ITEM_E_INVALID_ALGORITHM {
+			msg = fmt.Sprintf(msg, g.req.Algorithm) // "Invalid rate limit algorithm '%d'"
+		}
+		return gpuResponse{nil, errors.New(msg)}
+	}
+	return gpuResponse{&RateLimitResp{Status: Status(status), Limit: int64(limit), Remaining: int64(remaining), ResetTime: int64(reset)}, nil}
+}
+
+// flushWithStore evaluates the stage's batch through the synchronous host entry points that report the Store calls.
+func (p *gpuShard) flushWithStore(f *gpuFlight) {
+	*at32(f.b.key_off, f.n) = C.uint32_t(f.off)
+	f.b.n, f.b.now_ms = C.uint32_t(f.n), C.int64_t(clock.Now().UnixNano()/1000000)
+	rc := p.evalWithStore(f.waiting, f.b, f.r)
+	for i, g := range f.waiting {
+		g.resp <- p.answer(g, rc, f.tooLong[i], *at8(f.r.err, i), *at8(f.r.status, i), *at64(f.r.limit, i), *at64(f.r.remaining, i), *at64(f.r.reset_time, i))
+	}
+	f.waiting, f.tooLong, f.n, f.off = f.waiting[:0], f.tooLong[:0], 0, 0
 }
 
 // evalWithStore is the Config.Store path (store.go:49-65).  The reference calls the store from inside the
@@ -403,6 +550,9 @@ func (p *gpuShard) dump(out chan<- *CacheItem) error {
 
 func (p *gpuShard) Close() error {
 	close(p.done)
+	for k := range p.stage {
+		C.guber_stage_destroy(p.stage[k])
+	}
 	C.guber_engine_destroy(p.engine)
 	return nil
 }
