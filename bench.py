@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--min-ms", type=float, default=250.0, help="minimum duration of the timed region: the timed steps are repeated until it is reached")
     ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
+    ap.add_argument("--dispatch", choices=["threads", "one"], default="threads",
+                    help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
+                         "(guber_eval_batches_routed_dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
     ap.add_argument("--cpu-threads", default="1,32,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
@@ -138,10 +141,13 @@ class Rig:
         import streams
         from gubernator_amd import shard
         self.ctx, self.algo, self.dist_kind, self.S = ctx, algo, dist_kind, S
+        self.dispatch = getattr(ctx, "dispatch", "threads")
         self.algo_id = 0 if algo == "token" else 1
         self.torch, self.ga, self.streams = torch, ga, streams
         dev, K, B = ctx.dev, ctx.K, ctx.B
         self.sstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+        if self.dispatch == "one":             # one dispatcher: the shards share a stream, their batches share launches
+            self.sstreams = [self.sstreams[0]] * S
         nk = len(ctx.my_ids)
         self.engines = [ga.Engine(cache_size=(nk + nk // 4) // S + 1024, device=ctx.local_rank, max_batch=B,
                                   stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
@@ -254,10 +260,22 @@ class Rig:
             per.append((ba, ra, len(idx)))
         return per
 
+    def _routed(self, lo, hi, keep):
+        """the sequence's batches lo..hi in flush order for ONE dispatcher: (which[], GuberBatch[], GuberResult[], count)"""
+        import ctypes as C
+        ga = self.ga
+        idx = list(range(lo, hi))
+        wa = (C.c_uint32 * max(len(idx), 1))(*[self.seq[s][0] for s in idx])
+        ba = (ga.GuberBatch * max(len(idx), 1))(*[self.batches[s] for s in idx])
+        ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if (keep and s < len(self.kept)) else self.scratch[self.seq[s][0]].c) for s in idx])
+        return wa, ba, ra, len(idx)
+
     def run(self, lo, hi, repeats=1, keep=False, timed=False):
         """enqueue batches lo..hi of the sequence `repeats` times.  timed: returns (wall seconds, max per-stream event ms)"""
         torch = self.torch
         per = self._arrays(lo, hi, keep)
+        if self.dispatch == "one" and self.S > 1:
+            wa, ba1, ra1, cnt1 = self._routed(lo, hi, keep)
 
         def job(j):
             ba, ra, cnt = per[j]
@@ -278,7 +296,10 @@ class Rig:
             for j in range(self.S):
                 ev0[j].record(self.sstreams[j])
         t0 = time.perf_counter()
-        if self.workers is not None:
+        if self.dispatch == "one" and self.S > 1:
+            for _ in range(repeats):
+                self.ga.Engine.eval_routed_dev(self.engines, wa, ba1, ra1, cnt1)
+        elif self.workers is not None:
             self.workers.run(jobs)
         else:
             jobs[0]()
@@ -289,7 +310,9 @@ class Rig:
         t1 = time.perf_counter()
         if timed:
             self.ctx.barrier()
-            return t1 - t0, max(ev0[j].elapsed_time(ev1[j]) for j in range(self.S))
+            self.last_stream_ms = [ev0[j].elapsed_time(ev1[j]) for j in range(self.S)]
+            self.last_stream_batches = [per[j][2] * repeats for j in range(self.S)]
+            return t1 - t0, max(self.last_stream_ms)
         return t1 - t0, None
 
     def measure(self, steps, warmup, min_ms, now0, seed, keep_first=8):
@@ -306,7 +329,9 @@ class Rig:
         wall = ctx.max_over_ranks(wall)
         n_batches = steps * repeats
         return {"value": n_batches * ctx.B * ctx.world / wall, "ms_per_step": wall / n_batches * 1e3, "repeats": repeats,
-                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / n_batches, "steps": steps}
+                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / n_batches, "steps": steps,
+                "shard_streams": [{"batches": b, "stream_ms": round(m, 3), "us_per_batch": round(m * 1e3 / max(b, 1), 2)}
+                                  for b, m in zip(self.last_stream_batches, self.last_stream_ms)]}
 
     def kernel_profile(self, n_steps, lo, hi):
         """per-kernel durations with one batch in flight on shard 0 (HIP events around every launch)"""
@@ -414,6 +439,7 @@ def main():
     red_dev = dev if args.backend == "nccl" else None
     ctx.world, ctx.rank, ctx.local_rank, ctx.dev = world, rank, local_rank, dev
     ctx.K, ctx.B = args.keys, args.batch
+    ctx.dispatch = args.dispatch
     ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
@@ -548,7 +574,9 @@ def main():
             "config": headline_cfg,
             "timed_region": {"repeats_of_the_step_list": m["repeats"], "ms": round(m["timed_ms"], 2), "min_ms": args.min_ms,
                              "ms_per_step_hip_events": round(m["ms_per_step_events"], 5),
-                             "enqueue": f"{S} pre-started batcher threads behind a barrier" if S > 1 else "caller thread"},
+                             "enqueue": ("caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
+                                         else f"one dispatcher for {S} shards on one stream (guber_eval_batches_routed_dev: batches of different shards share launches)"),
+                             "shard_streams": m["shard_streams"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
         }
         out.update(extras)
@@ -603,7 +631,9 @@ def run_end_to_end(args, ctx, NOW0, seed):
     seq = rig.build_sequence(NB, NOW0, seed)
     eng = rig.engines[0]
     hb = [streams.bench_batch(ctx.table, ids, now, algorithm=rig.algo_id) for (_, ids, now) in seq]
-    stages = [ga.Stage(eng, B, key_bytes_cap=B * 16) for _ in range(3)]
+    depth = max(1, int(os.environ.get("GUBER_BENCH_E2E_DEPTH", "3")))      # batches in flight
+    NS = depth + 1                                                          # one more stage is being filled / drained by the host
+    stages = [ga.Stage(eng, B, key_bytes_cap=B * 16) for _ in range(NS)]
     for st in stages:
         st.disable("burst", "created_at", "is_owner")
     out = {}
@@ -612,24 +642,23 @@ def run_end_to_end(args, ctx, NOW0, seed):
             for k, st in enumerate(stages):
                 st.fill(hb[k])
         t_sub, lat = {}, []
-        depth = 2
         t0 = time.perf_counter()
         for i in range(NB):
-            st = stages[i % 3]
+            st = stages[i % NS]
             if fill:
                 st.fill(hb[i])
             t_sub[i] = time.perf_counter()
             st.submit()
             if i >= depth - 1:
                 j = i - (depth - 1)
-                stages[j % 3].wait()
+                stages[j % NS].wait()
                 lat.append((time.perf_counter() - t_sub[j]) * 1e6)
         for j in range(NB - depth + 1, NB):
-            stages[j % 3].wait()
+            stages[j % NS].wait()
             lat.append((time.perf_counter() - t_sub[j]) * 1e6)
         el = time.perf_counter() - t0
         lat = sorted(lat[32:])
-        bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4) + 26              # every request array crosses PCIe once (k_front keeps an HBM copy for k_eval2), responses once
+        bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4 + 1) + 26          # every request column crosses PCIe once (one DMA block copy), responses once
         out[label] = {"value": round(NB * B / el, 1), "ms_per_step": round(el / NB * 1e3, 4),
                       "latency_us": {"p50": round(percentile(lat, 0.5), 1), "p99": round(percentile(lat, 0.99), 1), "n": len(lat)},
                       "pcie_GBps": round(bytes_per_req * B * NB / el / 1e9, 2)}
@@ -641,7 +670,8 @@ def run_end_to_end(args, ctx, NOW0, seed):
     return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NB,
             "latency_us": best["latency_us"], "pcie_GBps": best["pcie_GBps"], "with_host_fill": out["with_host_fill"],
             "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_stage_submit / guber_stage_wait from one host thread: "
-                        "request arrays in device-visible host memory read in place by the kernels, responses written in place, 2 batches in flight; "
+                        "request block -> HBM by one DMA copy beside the previous batch's kernels, response block back by one DMA copy "
+                        f"(GUBER_NO_STAGE_DMA=1: the kernels read / write the host arrays in place), {depth} batches in flight; "
                         "`with_host_fill` adds the copy of every batch into the stage (numpy, one thread)"}
 
 

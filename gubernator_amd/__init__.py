@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_eval_batches_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
+    "guber_eval_batches_dev", "guber_eval_batches_routed_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
     "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_stage_create", "guber_stage_destroy",
     "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_create_multi",
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
@@ -59,6 +59,8 @@ def lib():
         for name in ("guber_eval_batch", "guber_eval_batch_dev"):
             getattr(L, name).argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult)]
         L.guber_eval_batches_dev.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.guber_eval_batches_routed_dev.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(GuberBatch),
+                                                    C.POINTER(GuberResult), C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_add_items.argtypes = [C.c_void_p, C.POINTER(GuberItem), C.c_uint32, C.c_void_p]
         L.guber_get_item.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int64, C.POINTER(GuberItem),
                                      C.POINTER(C.c_int)]
@@ -248,6 +250,12 @@ class Engine:
     def eval_many_dev(self, batch_array, result_array, count):
         """ctypes arrays of GuberBatch / GuberResult (device pointers): enqueue `count` batches back to back."""
         _check(lib().guber_eval_batches_dev(self.h, batch_array, result_array, count, None))
+
+    @staticmethod
+    def eval_routed_dev(engines, which_array, batch_array, result_array, count):
+        """one dispatcher for several engines: batch k -> engines[which[k]] (ctypes arrays, device pointers)"""
+        hs = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        _check(lib().guber_eval_batches_routed_dev(hs, len(engines), which_array, batch_array, result_array, count, None))
 
     # -- cache operations -----------------------------------------------------------------------
     def add_item(self, item, now_ms=0):

@@ -87,6 +87,7 @@ struct CohBuf {
 struct guber_engine {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t copy_in = nullptr, copy_out = nullptr; bool stage_dma = true;   // stages: DMA copies beside the kernels (guber_stage_submit)
     uint64_t slots = 0, cache_size = 0;
     uint32_t max_batch = 0, max_key = 0;
     Table T{};
@@ -121,6 +122,7 @@ struct guber_engine {
     CohBuf<uint8_t> z_stage;   // device-visible arena of the zero-copy path: inputs, outputs, SmallOut
     DevBuf<int64_t> d_stash64; DevBuf<uint32_t> d_stash32; DevBuf<uint8_t> d_stash8;   // k_front's HBM copy of host-resident request columns
     hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
+    bool fuse = true; uint64_t fused_batches = 0;                 // guber_eval_batches_routed_dev: several engines per launch
     uint64_t small_batches = 0, small_fallbacks = 0;
     PinBuf<DevCounters> h_ctr;
     DevCounters last_ctr{};
@@ -224,6 +226,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
     e->no_small = (cfg->flags & GUBER_FLAG_TEST_NO_SMALL) != 0 || e->force_radix || e->always_careful;
     e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
+    e->fuse = getenv("GUBER_NO_FUSE") == nullptr;
+    e->stage_dma = getenv("GUBER_NO_STAGE_DMA") == nullptr;
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
@@ -311,6 +315,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
     if (e->z_event) (void)hipEventDestroy(e->z_event);
     if (e->rb_event) (void)hipEventDestroy(e->rb_event);
+    if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
+    if (e->copy_out) (void)hipStreamDestroy(e->copy_out);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -318,9 +324,13 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
 static int compact_table(guber_engine* e, int64_t now_ms);
 static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms);
-static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident = false) {
+// What a batch needs before its kernels can be enqueued, shared by the single-engine and the fused multi-engine launch:
+// cache maintenance, the engine's epochs, and (two-launch pipeline) the views / work arrays of this batch.
+struct FastPlan { BatchView B2, B3; Work W; uint32_t ftiles; };
+static bool takes_fast_path(const guber_engine* e, uint32_t n) { return n != 0 && n <= e->fast_cap && !e->force_radix; }
+
+static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
     const uint32_t n = B.n;
-    if (n == 0) return 0;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
     if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
     // Bounded cache and directory load.  size_upper / tags_upper are host-side upper bounds (every request might create a
@@ -337,46 +347,73 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         hipLaunchKernelGGL(k_clear_claims, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots);
         e->epoch = 1;
     }
-    const uint32_t tiles = (n + TILE - 1) / TILE;
-    Work W = e->W;
+    W = e->W;
     W.epoch = e->epoch;
     W.touch = e->touch = (e->touch + 1) & 0x7fffffffu;
-    W.tiles = tiles;
-    if (n <= e->fast_cap && !e->force_radix) {
-        // two launches: resolve + in-tile grouping, then evaluation
-        BatchView B2 = B;
-        B2.n_cap = e->fast_cap;
-        const uint32_t ftiles = (n + FT - 1) / FT;
-        W.careful = (e->careful || e->always_careful) ? 1u : 0u;
-        if (++e->fast_epoch16 > 0xffffu) {   // 16-bit claim epoch wrapped: forget every cell
-            HIPCHK(hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream));
-            HIPCHK(hipMemset2DAsync(&e->w_srec.p[0].flags, sizeof(SegRec), 0, sizeof(unsigned long long), e->fast_cap, e->stream));   // epoch-tagged flag words
-            e->fast_epoch16 = 1;
-        }
-        W.epoch16 = e->fast_epoch16;
-        W.parity = e->fast_batches & 1u;
-        W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
-        W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;
-        W.clear_n = e->fast_prev_n;
+    W.tiles = (n + TILE - 1) / TILE;
+    return 0;
+}
+
+static int plan_fast(guber_engine* e, const BatchView& B, bool host_resident, Work& W, FastPlan& P) {
+    const uint32_t n = B.n;
+    BatchView B2 = B;
+    B2.n_cap = e->fast_cap;
+    W.careful = (e->careful || e->always_careful) ? 1u : 0u;
+    if (++e->fast_epoch16 > 0xffffu) {   // 16-bit claim epoch wrapped: forget every cell
+        HIPCHK(hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream));
+        HIPCHK(hipMemset2DAsync(&e->w_srec.p[0].flags, sizeof(SegRec), 0, sizeof(unsigned long long), e->fast_cap, e->stream));   // epoch-tagged flag words
+        e->fast_epoch16 = 1;
+    }
+    W.epoch16 = e->fast_epoch16;
+    W.parity = e->fast_batches & 1u;
+    W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
+    W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;
+    W.clear_n = e->fast_prev_n;
 #ifdef GUBER_PHASE_TIMING
-        W.dbg = e->dbg.p;
+    W.dbg = e->dbg.p;
 #endif
-        BatchView B3 = B2;                     // what k_eval2 reads
-        W.st_hits = nullptr;
-        if (host_resident) {
-            const size_t c = e->fast_cap;
-            if (e->d_stash64.ensure(5 * c) || e->d_stash32.ensure(c) || e->d_stash8.ensure(2 * c)) return GUBER_E_NOMEM;
-            int64_t* q = e->d_stash64.p;
-            W.st_hits = q; W.st_limit = q + c; W.st_duration = q + 2 * c; W.st_burst = q + 3 * c; W.st_created = q + 4 * c;
-            W.st_behavior = e->d_stash32.p; W.st_algorithm = e->d_stash8.p; W.st_owner = e->d_stash8.p + c;
-            B3.hits = W.st_hits; B3.limit = W.st_limit; B3.duration = W.st_duration; B3.burst = W.st_burst; B3.created_at = W.st_created;
-            B3.behavior = W.st_behavior; B3.algorithm = W.st_algorithm; B3.is_owner = W.st_owner;
+    BatchView B3 = B2;                     // what k_eval2 reads
+    W.st_hits = nullptr;
+    if (host_resident) {
+        const size_t c = e->fast_cap;
+        if (e->d_stash64.ensure(5 * c) || e->d_stash32.ensure(c) || e->d_stash8.ensure(2 * c)) return GUBER_E_NOMEM;
+        int64_t* q = e->d_stash64.p;
+        W.st_hits = q; W.st_limit = q + c; W.st_duration = q + 2 * c; W.st_burst = q + 3 * c; W.st_created = q + 4 * c;
+        W.st_behavior = e->d_stash32.p; W.st_algorithm = e->d_stash8.p; W.st_owner = e->d_stash8.p + c;
+        B3.hits = W.st_hits; B3.limit = W.st_limit; B3.duration = W.st_duration; B3.burst = W.st_burst; B3.created_at = W.st_created;
+        B3.behavior = W.st_behavior; B3.algorithm = W.st_algorithm; B3.is_owner = W.st_owner;
+    }
+    P.B2 = B2; P.B3 = B3; P.W = W; P.ftiles = (n + FT - 1) / FT;
+    return 0;
+}
+static void finish_fast(guber_engine* e, uint32_t n) {
+    e->fast_batches++;
+    e->fast_prev_n = n;
+    e->batches++;
+}
+
+static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident = false) {
+    const uint32_t n = B.n;
+    if (n == 0) return 0;
+    Work W;
+    {
+        const int rc = batch_prelude(e, B, W);
+        if (rc) return rc;
+    }
+    const uint32_t tiles = W.tiles;
+    if (takes_fast_path(e, n)) {
+        // two launches: resolve + in-tile grouping, then evaluation
+        FastPlan P;
+        {
+            const int rc = plan_fast(e, B, host_resident, W, P);
+            if (rc) return rc;
         }
+        const uint32_t ftiles = P.ftiles;
         e->span_begin(KT_FRONT);
-        hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, B2, W);
+        hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, P.B2, P.W);
         e->span_end();
         e->span_begin(KT_EVAL2);
-        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, B3, R, W});
+        hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
         e->span_end();
         HIPCHK(hipGetLastError());
 #ifdef GUBER_PHASE_TIMING
@@ -398,9 +435,7 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
             e->dbg_n++;
         }
 #endif
-        e->fast_batches++;
-        e->fast_prev_n = n;
-        e->batches++;
+        finish_fast(e, n);
         return 0;
     }
     int passes = 1;
@@ -477,6 +512,115 @@ extern "C" int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* ba
         if (rc) return rc;
         if (done) *done = k + 1;
     }
+    return GUBER_OK;
+}
+
+// One dispatcher for several engines (the logical shards of a GPU, each a table of its own): batch k goes to
+// engines[which[k]]; per engine the array order is kept, between engines there is nothing to order (disjoint keys, no
+// shared state).  Each round takes the next batch of every engine that has one and, where the engines share device and
+// stream and the batches take the two-launch pipeline, enqueues up to MULTI_MAX of them as ONE k_front_multi + ONE
+// k_eval2_multi (guber_kernels.h): the batches' dependent memory trips then overlap inside a launch, without the
+// per-stream kernel boundaries that throttle shards running on separate streams (profiles/r02_m_shard_streams.txt).
+static bool can_fuse(const guber_engine* e, uint32_t n) {
+#ifdef GUBER_PHASE_TIMING
+    return false;
+#else
+    return e->fuse && !e->profiling && takes_fast_path(e, n);
+#endif
+}
+
+static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
+                        uint32_t* enqueued) {
+    auto views = [&](int i, BatchView& B, ResultView& R) {
+        const guber_batch_t* b = &batches[gk[i]]; guber_result_t* r = &results[gk[i]];
+        B = BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                      b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
+        R = ResultView{r->status, r->limit, r->remaining, r->reset_time, r->err};
+        r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+    };
+    if (g == 1) {
+        guber_engine* e = grp[0];
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+        BatchView B; ResultView R; views(0, B, R);
+        const int rc = launch_batch(e, B, R);
+        if (rc == 0) ++*enqueued;
+        return rc;
+    }
+    // lock the group's engines in address order (any other caller holds at most one engine lock, or locks in this order)
+    guber_engine* order[MULTI_MAX];
+    for (int i = 0; i < g; ++i) order[i] = grp[i];
+    std::sort(order, order + g);
+    for (int i = 0; i < g; ++i) order[i]->mu.lock();
+    struct Unlock { guber_engine** o; int g; ~Unlock() { for (int i = g - 1; i >= 0; --i) o[i]->mu.unlock(); } } unlock{order, g};
+    if (grp[0]->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    MultiFront MF{}; MultiEval ME{};
+    uint32_t tiles = 0, ns[MULTI_MAX];
+    int planned = 0, rc = 0;
+    for (int i = 0; i < g; ++i) {
+        guber_engine* e = grp[i];
+        BatchView B; ResultView R; views(i, B, R);
+        Work W; FastPlan P;
+        rc = batch_prelude(e, B, W);
+        if (!rc) rc = plan_fast(e, B, false, W, P);
+        if (rc) break;                                            // enqueue what is planned, then report
+        tiles += P.ftiles;
+        MF.end_tile[planned] = ME.end_tile[planned] = tiles;
+        MF.sub[planned] = FrontArgs{e->T, P.B2, P.W};
+        ME.sub[planned] = EvalArgs{e->T, P.B3, R, P.W};
+        ns[planned++] = B.n;
+    }
+    if (planned) {
+        static_assert(FT == 256, "k_eval2's workgroup is k_front's tile");
+        MF.nb = ME.nb = (uint32_t)planned;
+        hipLaunchKernelGGL(k_front_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
+        hipLaunchKernelGGL(k_eval2_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
+        for (int i = 0; i < planned; ++i) { finish_fast(grp[i], ns[i]); grp[i]->fused_batches++; }
+        *enqueued += (uint32_t)planned;
+        if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    }
+    return rc;
+}
+
+extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* which,
+                                             const guber_batch_t* batches, guber_result_t* results, uint32_t count, uint32_t* done) {
+    if (done) *done = 0;
+    if (!engines || !n_engines || (count && (!which || !batches || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::vector<std::vector<uint32_t>> fifo(n_engines);
+    for (uint32_t k = 0; k < count; ++k) {
+        if (which[k] >= n_engines || !engines[which[k]]) return fail(GUBER_E_INVALID_ARG, "which[k] names no engine");
+        const int rc = check_batch_args(&batches[k], &results[k]);
+        if (rc) return rc;
+        if (batches[k].n) fifo[which[k]].push_back(k);
+    }
+    std::vector<size_t> pos(n_engines, 0);
+    uint32_t enqueued = 0, empty = 0;
+    for (uint32_t k = 0; k < count; ++k) empty += batches[k].n == 0;
+    for (;;) {
+        guber_engine* grp[MULTI_MAX]; uint32_t gk[MULTI_MAX]; int g = 0;
+        bool any = false;
+        int rc = 0;
+        for (uint32_t j = 0; j < n_engines && !rc; ++j) {
+            if (pos[j] >= fifo[j].size()) continue;
+            any = true;
+            guber_engine* e = engines[j];
+            const uint32_t k = fifo[j][pos[j]++];
+            bool fits = can_fuse(e, batches[k].n);
+            for (int i = 0; i < g && fits; ++i) fits = grp[i] != e;
+            if (g && (!fits || g == MULTI_MAX || e->stream != grp[0]->stream || e->device != grp[0]->device)) {
+                rc = launch_group(grp, gk, g, batches, results, &enqueued);
+                g = 0;
+                if (rc) break;
+            }
+            grp[g] = e; gk[g] = k; ++g;
+            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued); g = 0; }
+        }
+        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued);
+        if (done) *done = enqueued;
+        if (rc) return rc;
+        if (!any) break;
+    }
+    if (done) *done = enqueued + empty;
     return GUBER_OK;
 }
 
@@ -679,6 +823,13 @@ struct guber_stage {
     hipEvent_t ev = nullptr;
     uint32_t seq = 0, n = 0; int64_t now_ms = 0;
     int mode = 0;                    // 0 idle, 1 small path in flight, 2 pipeline in flight
+    // Large batches: the request block travels by ONE DMA copy into the stage's device mirror while the previous batch's
+    // kernels run, the kernels work on HBM, and ONE DMA copy brings the response block back while the next batch's
+    // kernels run.  The link then carries both directions at once at the copy engines' rate (tools/pcie_peak.hip: 46 GB/s
+    // in + 25 GB/s out) instead of the kernels' own host reads and writes, one after the other (24 GB/s in total).
+    DevBuf<uint8_t> dmem;            // device mirror of [in block | out block]
+    uint8_t *h_in = nullptr, *h_out = nullptr; size_t in_fixed = 0, in_opt = 0, out_bytes = 0;   // host blocks; in_fixed = bytes before the keys, in_opt = before burst
+    hipEvent_t ev_in = nullptr, ev_k = nullptr;
 };
 
 extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
@@ -690,9 +841,18 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     guber_stage* s = new guber_stage();
     s->e = e; s->max_n = max_n; s->key_cap = key_bytes_cap ? key_bytes_cap : max_n * 64u;
     const size_t n = max_n;
-    const size_t bytes = 256 + (n * 8) * 8 /* 5 in + 3 out */ + (n + 1) * 4 + n * 4 + n * 4 /* algo,owner,status,err */ + (size_t)s->key_cap + 64 +
-                         2 * (sizeof(DevCounters) + (size_t)e->n_bctr * sizeof(BlockCounters) + 128) + 256;
-    if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess) { s->mem.release(); delete s; return GUBER_E_NOMEM; }
+    // [counters | in block: key_off, hits, limit, duration, behavior, algorithm, is_owner, (burst, created_at), keys |
+    //  out block: 3 int64 columns, status, err] — the optional columns sit right before the keys so that a batch without
+    // them is two copies
+    const size_t in_fixed = (((n + 1) * 4 + 63) & ~(size_t)63) + n * 8 * 5 + n * 4 + n * 2;
+    const size_t in_bytes = (in_fixed + (size_t)s->key_cap + 64 + 63) & ~(size_t)63;
+    const size_t out_bytes = n * 8 * 3 + n * 2;
+    const size_t head = 256 + 2 * (((sizeof(DevCounters) + 63) & ~(size_t)63) + (((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63));
+    const size_t bytes = head + in_bytes + out_bytes + 256;
+    if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming) != hipSuccess) {
+        s->mem.release(); delete s; return GUBER_E_NOMEM;
+    }
     memset(s->mem.p, 0, bytes);
     uint8_t* p = s->mem.p;
     s->sout = (SmallOut*)p; p += 64;
@@ -700,15 +860,22 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     s->rb_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
     s->rb0_ctr = (DevCounters*)p; p += (sizeof(DevCounters) + 63) & ~(size_t)63;
     s->rb0_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
-    int64_t* q = (int64_t*)p; p += n * 8 * 8;
-    uint32_t* off = (uint32_t*)p; p += ((n + 1) * 4 + 7) & ~(size_t)7;
-    uint32_t* beh = (uint32_t*)p; p += n * 4;
-    uint8_t* u8 = p; p += n * 4;
+    p = s->mem.p + head;
+    s->h_in = p; s->h_out = p + in_bytes; s->in_fixed = in_fixed; s->out_bytes = out_bytes;
     guber_batch_t& b = s->batch; guber_result_t& r = s->result;
-    b.hits = q; b.limit = q + n; b.duration = q + 2 * n; b.burst = q + 3 * n; b.created_at = q + 4 * n;
-    r.limit = q + 5 * n; r.remaining = q + 6 * n; r.reset_time = q + 7 * n;
-    b.key_off = off; b.behavior = beh; b.algorithm = u8; b.is_owner = u8 + n; r.status = u8 + 2 * n; r.err = u8 + 3 * n;
+    b.key_off = (uint32_t*)p; p += ((n + 1) * 4 + 63) & ~(size_t)63;
+    int64_t* q = (int64_t*)p; p += n * 8 * 3;
+    b.hits = q; b.limit = q + n; b.duration = q + 2 * n;
+    b.behavior = (uint32_t*)p; p += n * 4;
+    b.algorithm = p; b.is_owner = p + n; p += n * 2;
+    s->in_opt = (size_t)(p - s->h_in);
+    q = (int64_t*)p; p += n * 8 * 2;
+    b.burst = q; b.created_at = q + n;
     b.key_bytes = p;
+    p = s->h_out;
+    q = (int64_t*)p; p += n * 8 * 3;
+    r.limit = q; r.remaining = q + n; r.reset_time = q + 2 * n;
+    r.status = p; r.err = p + n;
     *out = s;
     return GUBER_OK;
 }
@@ -716,6 +883,9 @@ extern "C" void guber_stage_destroy(guber_stage_t* s) {
     if (!s) return;
     if (s->mode) (void)guber_stage_wait(s);
     if (s->ev) (void)hipEventDestroy(s->ev);
+    if (s->ev_in) (void)hipEventDestroy(s->ev_in);
+    if (s->ev_k) (void)hipEventDestroy(s->ev_k);
+    s->dmem.release();
     s->mem.release();
     delete s;
 }
@@ -761,13 +931,45 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     // (maintenance first: it may synchronise and rebuild; the read-back pair must bracket the kernels only)
     int rc = maintain(e, b.n, b.now_ms);
     if (rc) return rc;
+    // a batch that fills at least half of the stage travels by DMA (one block each way); smaller ones are read in place
+    const bool dma = e->stage_dma && s->max_n >= 4096 && (size_t)b.n * 2 >= s->max_n && !b.greg_expire && !b.greg_duration;
+    if (dma) {
+        if (!e->copy_in && (hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) != hipSuccess ||
+                            hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking) != hipSuccess)) return fail(GUBER_E_HIP, "hipStreamCreate");
+        const size_t in_bytes = (size_t)(s->h_out - s->h_in);
+        if (s->dmem.ensure(in_bytes + s->out_bytes)) return GUBER_E_NOMEM;
+        uint8_t* d_in = s->dmem.p; uint8_t* d_out = s->dmem.p + in_bytes;
+        const size_t used = (s->in_fixed + b.key_off[b.n] + 16 + 63) & ~(size_t)63;
+        if (b.burst || b.created_at) {
+            HIPCHK(hipMemcpyAsync(d_in, s->h_in, used, hipMemcpyHostToDevice, e->copy_in));
+        } else {                                                    // skip the two optional columns
+            HIPCHK(hipMemcpyAsync(d_in, s->h_in, s->in_opt, hipMemcpyHostToDevice, e->copy_in));
+            HIPCHK(hipMemcpyAsync(d_in + s->in_fixed, s->h_in + s->in_fixed, used - s->in_fixed, hipMemcpyHostToDevice, e->copy_in));
+        }
+        HIPCHK(hipEventRecord(s->ev_in, e->copy_in));
+        HIPCHK(hipStreamWaitEvent(e->stream, s->ev_in, 0));
+        auto dev = [&](const void* hp) { return hp ? d_in + ((const uint8_t*)hp - s->h_in) : nullptr; };
+        auto devo = [&](void* hp) { return d_out + ((uint8_t*)hp - s->h_out); };
+        B = BatchView{b.n, 0, dev(b.key_bytes), (const uint32_t*)dev(b.key_off), (const int64_t*)dev(b.hits), (const int64_t*)dev(b.limit),
+                      (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
+                      (const uint32_t*)dev(b.behavior), dev(b.is_owner), nullptr, nullptr, b.now_ms};
+        R = ResultView{devo(s->result.status), (int64_t*)devo(s->result.limit), (int64_t*)devo(s->result.remaining),
+                       (int64_t*)devo(s->result.reset_time), devo(s->result.err)};
+    }
     HIPCHK(hipMemcpyAsync(s->rb0_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(s->rb0_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
-    rc = launch_batch(e, B, R, true);
+    rc = launch_batch(e, B, R, !dma);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(s->rb_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipMemcpyAsync(s->rb_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipEventRecord(s->ev, e->stream));
+    if (dma) {
+        HIPCHK(hipEventRecord(s->ev_k, e->stream));
+        HIPCHK(hipStreamWaitEvent(e->copy_out, s->ev_k, 0));
+        HIPCHK(hipMemcpyAsync(s->h_out, s->dmem.p + (size_t)(s->h_out - s->h_in), s->out_bytes, hipMemcpyDeviceToHost, e->copy_out));
+        HIPCHK(hipEventRecord(s->ev, e->copy_out));
+    } else {
+        HIPCHK(hipEventRecord(s->ev, e->stream));
+    }
     s->mode = 2;
     return GUBER_OK;
 }
@@ -1014,6 +1216,7 @@ extern "C" int guber_stats(guber_engine_t* e, guber_stats_t* out) {
     out->over_limit_count = c.over; out->cache_hits = c.hits; out->cache_misses = c.misses;
     out->unexpired_evictions = c.evictions; out->cache_size = c.size; out->table_slots = e->slots;
     out->tags_used = c.tags_used; out->batches = e->batches; out->retries = c.retries; out->compactions = e->compactions;
+    out->small_batches = e->small_batches; out->fused_batches = e->fused_batches;
     return GUBER_OK;
 }
 extern "C" int64_t guber_size(guber_engine_t* e) {

@@ -172,7 +172,7 @@ __device__ __forceinline__ Req tile_get(const TileReqs& t, uint32_t i) {
     return r;
 }
 
-__global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
+__device__ __forceinline__ void front_body(const Table& T, const BatchView& B, const Work& W, const uint32_t tile) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
     __shared__ unsigned long long gkey[GT];                       // grouping key (0 = free)
     __shared__ unsigned long long gbits[FT / 64][GT];             // per wave: lanes holding the entry's key
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     __shared__ TileReqs sreq;
     __shared__ int red[FT / 64];
     __shared__ uint32_t soft_any, ins_any;
-    const uint32_t tid = threadIdx.x, tile = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
@@ -423,22 +423,24 @@ __global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) {
     GB_STAMPW(5);
 }
 
+__global__ __launch_bounds__(FT) void k_front(Table T, BatchView B, Work W) { front_body(T, B, W, blockIdx.x); }
+
 struct EvalArgs { Table T; BatchView B; ResultView R; Work W; };
 
 #ifndef GUBER_EVAL2_WAVES
 #define GUBER_EVAL2_WAVES 4      // waves per SIMD the register allocation must allow (<= 128 VGPRs): 4 co-resident workgroups per CU
 #endif
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
+__device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t tile, const uint32_t ntiles) {
     const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
     __shared__ unsigned long long cnt[4];
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = tile * 256 + threadIdx.x;
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
     const uint32_t e16 = W.epoch16;
     GB_STAMP2(0);
     {   // clear, for the next batch, what the previous batch's publishers added to the other copy of the tile bitmaps: a
         // publisher = the head of a (segment, tile) group that is not the segment's claimer; it zeroes the word it added to
         unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
-        for (uint32_t j = i; j < W.clear_n; j += gridDim.x * 256) {
+        for (uint32_t j = i; j < W.clear_n; j += ntiles * 256) {
             const uint32_t pd = W.did_prev[j];
             if ((pd & 0xffu) == 0u && (pd >> 16) != j) om[(size_t)(pd >> 16) * FT_WORDS + (j / FT >> 5)] = 0ull;
         }
@@ -643,11 +645,43 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
         }
         lds_barrier();
         if (threadIdx.x == 0 && (cnt[0] | cnt[1] | cnt[2] | cnt[3])) {
-            BlockCounters* bc = &T.bctr[blockIdx.x];
+            BlockCounters* bc = &T.bctr[tile];
             bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
         }
     }
     GB_STAMP2(4);
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) { eval2_body(A, blockIdx.x, gridDim.x); }
+
+// ---- several engines in one launch ------------------------------------------------------------------------------------
+// The logical shards of a GPU (one table each, disjoint keys) have nothing to order between them, and one batch's two
+// launches leave most of the chip idle (256 workgroups, one per CU, waiting on dependent memory trips).  A dispatcher that
+// has batches for several shards waiting puts up to MULTI_MAX of them — one per engine — into ONE k_front_multi and ONE
+// k_eval2_multi: workgroup -> (batch, tile) by a prefix table, every workgroup then runs exactly the single-batch body on
+// its engine's table and work arrays.  Same results by construction; what changes is that the batches' memory trips
+// overlap inside one launch instead of across streams (where every kernel boundary of every stream costs the others:
+// profiles/r02_m_shard_streams.txt).
+constexpr int MULTI_MAX = 4;
+struct FrontArgs { Table T; BatchView B; Work W; };
+struct MultiFront { uint32_t nb; uint32_t end_tile[MULTI_MAX]; FrontArgs sub[MULTI_MAX]; };
+struct MultiEval { uint32_t nb; uint32_t end_tile[MULTI_MAX]; EvalArgs sub[MULTI_MAX]; };
+static_assert(sizeof(MultiFront) <= 4096 && sizeof(MultiEval) <= 4096, "kernel arguments are limited to 4 KB");
+
+__global__ __launch_bounds__(FT) void k_front_multi(MultiFront A) {
+    uint32_t sb = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < MULTI_MAX - 1; ++k)
+        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const FrontArgs* a = (const FrontArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiFront, sub)) + sb;
+    front_body(a->T, a->B, a->W, blockIdx.x - first);
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi(MultiEval A) {
+    uint32_t sb = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < MULTI_MAX - 1; ++k)
+        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
+    eval2_body(*a, blockIdx.x - first, A.end_tile[sb] - first);
 }
 
 }  // namespace guber

@@ -171,6 +171,8 @@ typedef struct guber_stats {
     uint64_t batches;
     uint64_t retries;         /* GUBER_ITEM_E_RETRY re-submissions */
     uint64_t compactions;     /* table rebuilds (guber_compact or automatic) */
+    uint64_t small_batches;   /* batches of <= 256 requests answered by the one-launch path */
+    uint64_t fused_batches;   /* batches that shared their two launches with other engines' batches (guber_eval_batches_routed_dev) */
 } guber_stats_t;
 
 /* ---- lifecycle: NewWorkerPool / WorkerPool.Close (workers.go:125,157) -------- */
@@ -187,8 +189,12 @@ int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_re
 
 /* ---- stages: the overlapped end-to-end path.  A stage is one batch's worth of request / response arrays in device-visible
  *      host memory.  The caller (a batcher goroutine) writes requests straight into guber_stage_batch()'s arrays as they
- *      arrive — no Go pointers are retained, nothing is copied or allocated per batch — sets n and now_ms, and submits; the
- *      kernels read the arrays and write guber_stage_result()'s arrays in place over PCIe.  guber_stage_submit returns at
+ *      arrive — no Go pointers are retained, nothing is copied or allocated per batch on the host — sets n and now_ms, and
+ *      submits.  How the arrays reach the kernels depends on the batch: <= 256 requests: one launch reads and writes them in
+ *      place over PCIe; a batch that fills at least half of the stage: ONE DMA copy of the request block into the stage's
+ *      HBM mirror while the previous batch's kernels run, the two-launch pipeline on HBM, ONE DMA copy of the response block
+ *      back while the next batch's kernels run (both directions of the link busy at the copy engines' rate); in between:
+ *      the pipeline's kernels read / write the host arrays in place.  guber_stage_submit returns at
  *      once; guber_stage_wait blocks until the responses are there (a polled sequence number for batches <= 256, a HIP
  *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With two stages per engine the
  *      batcher fills one while the GPU evaluates the other.  Stages of one engine are evaluated in submission order; the one
@@ -212,6 +218,16 @@ int guber_stage_wait(guber_stage_t* s);
  * (*done, optional, receives the number of batches enqueued). */
 int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* batches, guber_result_t* results, uint32_t count,
                            uint32_t* done);
+
+/* The same for several engines from ONE dispatcher (the logical shards of one GPU, workers.go:125-151: one cache per
+ * worker): batch k belongs to engines[which[k]].  Per engine the array order is kept; batches of different engines share no
+ * state (disjoint keys) and are enqueued round by round — the next batch of every engine that has one — so that up to four
+ * engines' batches travel in ONE pair of launches when the engines were created on the same device and stream
+ * (guber_config_t.stream) and the batches take the two-launch pipeline (n <= 65 536).  Results are identical to enqueueing
+ * every batch on its own; what changes is the rate (the launches of one batch leave most of the GPU idle).
+ * On failure *done counts the batches enqueued (each engine's enqueued batches are a prefix of its own). */
+int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* which,
+                                  const guber_batch_t* batches, guber_result_t* results, uint32_t count, uint32_t* done);
 
 /* ---- WorkerPool.AddCacheItem (workers.go:537; callers gubernator.go:452 UpdatePeerGlobals,
  *      workers.go:329 Load).  Add semantics = LRUCache.Add (lrucache.go:88): replace if present.

@@ -330,6 +330,63 @@ def test_back_to_back_device_batches_match_oracle():
     e.close()
 
 
+@pytest.mark.parametrize("n_engines,shared_stream", [(3, True), (6, True), (4, False)])
+def test_routed_batches_of_several_engines_share_launches(n_engines, shared_stream):
+    """guber_eval_batches_routed_dev: one dispatcher, several engines (logical shards with disjoint keys).  Engines on one
+    stream get up to four batches per pair of launches (k_front_multi / k_eval2_multi); every batch must equal the oracle
+    of ITS engine evaluated in the engine's own order — hot keys, both algorithms, ragged batch sizes, a batch too small
+    and one too large for the two-launch pipeline in between."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    K, B, steps = 2500, 4096, 36
+    rng = np.random.default_rng(11)
+    tab = streams.key_table(K * n_engines)
+    stream = torch.cuda.Stream(device=dev)
+    strs = [stream if shared_stream else torch.cuda.Stream(device=dev) for _ in range(n_engines)]
+    engs = [ga.Engine(cache_size=4 * K, max_batch=3 * B, stream=strs[j].cuda_stream) for j in range(n_engines)]
+    orcs = [Oracle(cache_size=1 << 16) for _ in range(n_engines)]
+    zs = [streams.ZipfSampler(K, seed=100 + j) for j in range(n_engines)]
+    which, hbs, keep, cb, cr = [], [], [], [], []
+    for s in range(steps):
+        j = int(rng.integers(0, n_engines)) if s % 5 else s % n_engines
+        n = [B, B, 1000, B, 3 * B, 200, B][s % 7]                       # 200: one-tile batch; 3 * B: still two launches (<= 65 536)
+        hb = streams.bench_batch(tab, j * K + zs[j].draw(n), streams.NOW0 + s * 700, algorithm=s % 2, limit=30, duration=4000)
+        t = [torch.from_numpy(hb.key_bytes).to(dev), torch.from_numpy(hb.key_off.view(np.int32)).to(dev),
+             torch.from_numpy(hb.hits).to(dev), torch.from_numpy(hb.limit).to(dev), torch.from_numpy(hb.duration).to(dev),
+             torch.from_numpy(hb.algorithm).to(dev), torch.from_numpy(hb.behavior.view(np.int32)).to(dev)]
+        p = [x.data_ptr() for x in t]
+        r = dict(status=torch.empty(n, dtype=torch.uint8, device=dev), err=torch.empty(n, dtype=torch.uint8, device=dev),
+                 limit=torch.empty(n, dtype=torch.int64, device=dev), remaining=torch.empty(n, dtype=torch.int64, device=dev),
+                 reset_time=torch.empty(n, dtype=torch.int64, device=dev))
+        keep.append((t, r)); which.append(j); hbs.append(hb)
+        cb.append(ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], None, None, None, hb.now_ms))
+        cr.append(ga.GuberResult(r["status"].data_ptr(), r["limit"].data_ptr(), r["remaining"].data_ptr(),
+                                 r["reset_time"].data_ptr(), r["err"].data_ptr(), 0, 0, 0, 0, 0))
+    torch.cuda.synchronize(dev)
+    wa = (C.c_uint32 * steps)(*which)
+    ba = (ga.GuberBatch * steps)(*cb)
+    ra = (ga.GuberResult * steps)(*cr)
+    ga.Engine.eval_routed_dev(engs, wa, ba, ra, steps)
+    for e in engs:
+        e.synchronize()
+    sums = [[0, 0, 0] for _ in range(n_engines)]
+    for s in range(steps):
+        want = orcs[which[s]].eval(hbs[s])
+        got = ga.HostResult(hbs[s].n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = keep[s][1][name].cpu().numpy()
+        support.assert_results_equal(got, want, f"batch {s} of engine {which[s]}")
+        for q in range(3):
+            sums[which[s]][q] += want.counters()[q]
+    fused = sum(e.stats()["fused_batches"] for e in engs)
+    assert (fused > steps // 3) if shared_stream else fused == 0, fused
+    for j, (e, o) in enumerate(zip(engs, orcs)):
+        assert e.size() == o.size()
+        assert list(e.counters()[:3]) == sums[j], (j, e.counters(), sums[j])
+        e.close()
+
+
 def test_compaction_keeps_churning_key_sets_going():
     """A key population that keeps changing: the directory would fill with expired / removed buckets; the
     table rebuilds itself (guber_compact, also automatic) and results stay identical to the oracle."""
