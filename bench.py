@@ -642,6 +642,7 @@ def run_end_to_end(args, ctx, NOW0, seed):
             for k, st in enumerate(stages):
                 st.fill(hb[k])
         t_sub, lat = {}, []
+        h_submit = h_wait = 0.0
         t0 = time.perf_counter()
         for i in range(NB):
             st = stages[i % NS]
@@ -649,29 +650,34 @@ def run_end_to_end(args, ctx, NOW0, seed):
                 st.fill(hb[i])
             t_sub[i] = time.perf_counter()
             st.submit()
+            h_submit += time.perf_counter() - t_sub[i]
             if i >= depth - 1:
                 j = i - (depth - 1)
+                tw = time.perf_counter()
                 stages[j % NS].wait()
+                h_wait += time.perf_counter() - tw
                 lat.append((time.perf_counter() - t_sub[j]) * 1e6)
         for j in range(NB - depth + 1, NB):
             stages[j % NS].wait()
             lat.append((time.perf_counter() - t_sub[j]) * 1e6)
         el = time.perf_counter() - t0
         lat = sorted(lat[32:])
-        bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4 + 1) + 26          # every request column crosses PCIe once (one DMA block copy), responses once
+        bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4) + 26              # every request column present crosses PCIe once, responses once
         out[label] = {"value": round(NB * B / el, 1), "ms_per_step": round(el / NB * 1e3, 4),
                       "latency_us": {"p50": round(percentile(lat, 0.5), 1), "p99": round(percentile(lat, 0.99), 1), "n": len(lat)},
-                      "pcie_GBps": round(bytes_per_req * B * NB / el / 1e9, 2)}
+                      "pcie_GBps": round(bytes_per_req * B * NB / el / 1e9, 2),
+                      "host_us_per_batch": {"submit": round(h_submit / NB * 1e6, 1), "wait": round(h_wait / NB * 1e6, 1)}}
     # parity of the path: the last prefilled pass must equal what the oracle-checked device path gives — checked in tests/ (test_stage_*)
     for st in stages:
         st.close()
     rig.close()
     best = out["prefilled"]
     return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NB,
-            "latency_us": best["latency_us"], "pcie_GBps": best["pcie_GBps"], "with_host_fill": out["with_host_fill"],
+            "latency_us": best["latency_us"], "pcie_GBps": best["pcie_GBps"], "host_us_per_batch": best["host_us_per_batch"],
+            "with_host_fill": out["with_host_fill"],
             "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_stage_submit / guber_stage_wait from one host thread: "
-                        "request block -> HBM by one DMA copy beside the previous batch's kernels, response block back by one DMA copy "
-                        f"(GUBER_NO_STAGE_DMA=1: the kernels read / write the host arrays in place), {depth} batches in flight; "
+                        "request columns -> the stage's HBM mirror by DMA on a copy stream beside the previous batches' kernels, responses written "
+                        f"straight into the host arrays by k_eval2 (GUBER_NO_STAGE_DMA=1: everything read / written in place), {depth} batches in flight; "
                         "`with_host_fill` adds the copy of every batch into the stage (numpy, one thread)"}
 
 

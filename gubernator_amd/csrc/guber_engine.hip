@@ -87,7 +87,7 @@ struct CohBuf {
 struct guber_engine {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
-    hipStream_t copy_in = nullptr, copy_out = nullptr; bool stage_dma = true;   // stages: DMA copies beside the kernels (guber_stage_submit)
+    hipStream_t copy_in = nullptr, copy_out = nullptr; bool stage_dma = true, stage_out_inplace = true; uint32_t stage_in_wgs = 0;   // stages: DMA copies beside the kernels (guber_stage_submit)
     uint64_t slots = 0, cache_size = 0;
     uint32_t max_batch = 0, max_key = 0;
     Table T{};
@@ -228,6 +228,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
     e->fuse = getenv("GUBER_NO_FUSE") == nullptr;
     e->stage_dma = getenv("GUBER_NO_STAGE_DMA") == nullptr;
+    e->stage_out_inplace = getenv("GUBER_STAGE_OUT_DMA") == nullptr;
+    if (const char* v = getenv("GUBER_STAGE_IN_WGS")) e->stage_in_wgs = (uint32_t)atoi(v);   // > 0: copy kernel with that many workgroups instead of DMA
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
@@ -823,12 +825,15 @@ struct guber_stage {
     hipEvent_t ev = nullptr;
     uint32_t seq = 0, n = 0; int64_t now_ms = 0;
     int mode = 0;                    // 0 idle, 1 small path in flight, 2 pipeline in flight
-    // Large batches: the request block travels by ONE DMA copy into the stage's device mirror while the previous batch's
-    // kernels run, the kernels work on HBM, and ONE DMA copy brings the response block back while the next batch's
-    // kernels run.  The link then carries both directions at once at the copy engines' rate (tools/pcie_peak.hip: 46 GB/s
-    // in + 25 GB/s out) instead of the kernels' own host reads and writes, one after the other (24 GB/s in total).
+    // Large batches: two DMA copies on a copy stream (the fixed-width columns present, the keys) bring the requests into the
+    // stage's device mirror while the previous batches' kernels run; the pipeline then works on HBM and k_eval2 writes the
+    // responses straight into the host arrays (posted writes).  The link carries the requests at the copy engine's rate
+    // (46-48 GB/s) instead of at the rate of k_front's dependent reads (24 GB/s in total with everything in place).
+    // Measured alternatives (profiles/r02_v_end_to_end_variants.txt): GUBER_STAGE_OUT_DMA=1 — responses to HBM, then a DMA
+    // copy: slower, a hipMemcpyAsync costs 40-60 us of host time; GUBER_STAGE_IN_WGS=n — a copy kernel of n workgroups
+    // instead of the DMA: slower, kernels of two streams overlap badly.
     DevBuf<uint8_t> dmem;            // device mirror of [in block | out block]
-    uint8_t *h_in = nullptr, *h_out = nullptr; size_t in_fixed = 0, in_opt = 0, out_bytes = 0;   // host blocks; in_fixed = bytes before the keys, in_opt = before burst
+    uint8_t *h_in = nullptr, *h_out = nullptr; size_t in_fixed = 0, out_bytes = 0;   // host blocks; in_fixed = bytes before the keys
     hipEvent_t ev_in = nullptr, ev_k = nullptr;
 };
 
@@ -841,13 +846,13 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     guber_stage* s = new guber_stage();
     s->e = e; s->max_n = max_n; s->key_cap = key_bytes_cap ? key_bytes_cap : max_n * 64u;
     const size_t n = max_n;
-    // [counters | in block: key_off, hits, limit, duration, behavior, algorithm, is_owner, (burst, created_at), keys |
-    //  out block: 3 int64 columns, status, err] — the optional columns sit right before the keys so that a batch without
-    // them is two copies
-    const size_t in_fixed = (((n + 1) * 4 + 63) & ~(size_t)63) + n * 8 * 5 + n * 4 + n * 2;
-    const size_t in_bytes = (in_fixed + (size_t)s->key_cap + 64 + 63) & ~(size_t)63;
-    const size_t out_bytes = n * 8 * 3 + n * 2;
-    const size_t head = 256 + 2 * (((sizeof(DevCounters) + 63) & ~(size_t)63) + (((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63));
+    // [counters | in block: key_off, hits, limit, duration, behavior, algorithm, is_owner, burst, created_at, keys |
+    //  out block: limit, remaining, reset_time, status, err]; every column starts on a 64-byte boundary and is padded to one
+    auto col = [](size_t bytes) { return (bytes + 63) & ~(size_t)63; };
+    const size_t in_fixed = col((n + 1) * 4) + 5 * col(n * 8) + col(n * 4) + 2 * col(n);
+    const size_t in_bytes = col(in_fixed + (size_t)s->key_cap + 64);
+    const size_t out_bytes = 3 * col(n * 8) + 2 * col(n);
+    const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters)));
     const size_t bytes = head + in_bytes + out_bytes + 256;
     if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming) != hipSuccess) {
@@ -856,26 +861,29 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     memset(s->mem.p, 0, bytes);
     uint8_t* p = s->mem.p;
     s->sout = (SmallOut*)p; p += 64;
-    s->rb_ctr = (DevCounters*)p; p += (sizeof(DevCounters) + 63) & ~(size_t)63;
-    s->rb_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
-    s->rb0_ctr = (DevCounters*)p; p += (sizeof(DevCounters) + 63) & ~(size_t)63;
-    s->rb0_bctr = (BlockCounters*)p; p += ((size_t)e->n_bctr * sizeof(BlockCounters) + 63) & ~(size_t)63;
+    s->rb_ctr = (DevCounters*)p; p += col(sizeof(DevCounters));
+    s->rb_bctr = (BlockCounters*)p; p += col((size_t)e->n_bctr * sizeof(BlockCounters));
+    s->rb0_ctr = (DevCounters*)p; p += col(sizeof(DevCounters));
+    s->rb0_bctr = (BlockCounters*)p; p += col((size_t)e->n_bctr * sizeof(BlockCounters));
     p = s->mem.p + head;
     s->h_in = p; s->h_out = p + in_bytes; s->in_fixed = in_fixed; s->out_bytes = out_bytes;
     guber_batch_t& b = s->batch; guber_result_t& r = s->result;
-    b.key_off = (uint32_t*)p; p += ((n + 1) * 4 + 63) & ~(size_t)63;
-    int64_t* q = (int64_t*)p; p += n * 8 * 3;
-    b.hits = q; b.limit = q + n; b.duration = q + 2 * n;
-    b.behavior = (uint32_t*)p; p += n * 4;
-    b.algorithm = p; b.is_owner = p + n; p += n * 2;
-    s->in_opt = (size_t)(p - s->h_in);
-    q = (int64_t*)p; p += n * 8 * 2;
-    b.burst = q; b.created_at = q + n;
+    b.key_off = (uint32_t*)p; p += col((n + 1) * 4);
+    b.hits = (int64_t*)p; p += col(n * 8);
+    b.limit = (int64_t*)p; p += col(n * 8);
+    b.duration = (int64_t*)p; p += col(n * 8);
+    b.behavior = (uint32_t*)p; p += col(n * 4);
+    b.algorithm = p; p += col(n);
+    b.is_owner = p; p += col(n);
+    b.burst = (int64_t*)p; p += col(n * 8);
+    b.created_at = (int64_t*)p; p += col(n * 8);
     b.key_bytes = p;
     p = s->h_out;
-    q = (int64_t*)p; p += n * 8 * 3;
-    r.limit = q; r.remaining = q + n; r.reset_time = q + 2 * n;
-    r.status = p; r.err = p + n;
+    r.limit = (int64_t*)p; p += col(n * 8);
+    r.remaining = (int64_t*)p; p += col(n * 8);
+    r.reset_time = (int64_t*)p; p += col(n * 8);
+    r.status = p; p += col(n);
+    r.err = p;
     *out = s;
     return GUBER_OK;
 }
@@ -939,12 +947,26 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
         const size_t in_bytes = (size_t)(s->h_out - s->h_in);
         if (s->dmem.ensure(in_bytes + s->out_bytes)) return GUBER_E_NOMEM;
         uint8_t* d_in = s->dmem.p; uint8_t* d_out = s->dmem.p + in_bytes;
-        const size_t used = (s->in_fixed + b.key_off[b.n] + 16 + 63) & ~(size_t)63;
-        if (b.burst || b.created_at) {
-            HIPCHK(hipMemcpyAsync(d_in, s->h_in, used, hipMemcpyHostToDevice, e->copy_in));
-        } else {                                                    // skip the two optional columns
-            HIPCHK(hipMemcpyAsync(d_in, s->h_in, s->in_opt, hipMemcpyHostToDevice, e->copy_in));
-            HIPCHK(hipMemcpyAsync(d_in + s->in_fixed, s->h_in + s->in_fixed, used - s->in_fixed, hipMemcpyHostToDevice, e->copy_in));
+        // the used part of every column present, 16 bytes per thread and step (k_stage_in): the kernel's reads of host memory
+        // run at the link's rate like a DMA copy, but cost one launch and move exactly what the batch uses
+        StageSegs G{};
+        auto seg = [&](const void* hp, size_t bytes) {
+            if (!hp || !bytes) return;
+            G.off[G.n] = (uint32_t)((const uint8_t*)hp - s->h_in); G.end16[G.n] = (G.n ? G.end16[G.n - 1] : 0u) + (uint32_t)((bytes + 15) >> 4); ++G.n;
+        };
+        seg(b.key_off, ((size_t)b.n + 1) * 4); seg(b.hits, (size_t)b.n * 8); seg(b.limit, (size_t)b.n * 8); seg(b.duration, (size_t)b.n * 8);
+        seg(b.behavior, (size_t)b.n * 4); seg(b.algorithm, b.n); seg(b.is_owner, b.n); seg(b.burst, (size_t)b.n * 8); seg(b.created_at, (size_t)b.n * 8);
+        seg(b.key_bytes, (size_t)b.key_off[b.n] + 16);
+        const uint32_t total16 = G.end16[G.n - 1];
+        if (e->stage_in_wgs) {
+            // few workgroups: the copy must leave wave slots for the previous batch's kernels it runs beside
+            hipLaunchKernelGGL(k_stage_in, dim3(std::min<uint32_t>((total16 + 255) / 256, e->stage_in_wgs)), dim3(256), 0, e->copy_in, (uint4*)d_in, (const uint4*)s->h_in, G);
+        } else {
+            // DMA: the fixed columns up to the last one present, then the keys
+            const void* last = b.created_at ? (const void*)(b.created_at + b.n) : b.burst ? (const void*)(b.burst + b.n) : b.is_owner ? (const void*)(b.is_owner + b.n) : (const void*)(b.algorithm + b.n);
+            const size_t fixed = (size_t)((const uint8_t*)last - s->h_in);
+            HIPCHK(hipMemcpyAsync(d_in, s->h_in, fixed, hipMemcpyHostToDevice, e->copy_in));
+            HIPCHK(hipMemcpyAsync(d_in + s->in_fixed, s->h_in + s->in_fixed, (size_t)b.key_off[b.n] + 16, hipMemcpyHostToDevice, e->copy_in));
         }
         HIPCHK(hipEventRecord(s->ev_in, e->copy_in));
         HIPCHK(hipStreamWaitEvent(e->stream, s->ev_in, 0));
@@ -953,16 +975,16 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
         B = BatchView{b.n, 0, dev(b.key_bytes), (const uint32_t*)dev(b.key_off), (const int64_t*)dev(b.hits), (const int64_t*)dev(b.limit),
                       (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
                       (const uint32_t*)dev(b.behavior), dev(b.is_owner), nullptr, nullptr, b.now_ms};
-        R = ResultView{devo(s->result.status), (int64_t*)devo(s->result.limit), (int64_t*)devo(s->result.remaining),
-                       (int64_t*)devo(s->result.reset_time), devo(s->result.err)};
+        if (!e->stage_out_inplace)
+            R = ResultView{devo(s->result.status), (int64_t*)devo(s->result.limit), (int64_t*)devo(s->result.remaining),
+                           (int64_t*)devo(s->result.reset_time), devo(s->result.err)};
     }
-    HIPCHK(hipMemcpyAsync(s->rb0_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(s->rb0_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb0_ctr, s->rb0_bctr);
     rc = launch_batch(e, B, R, !dma);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->rb_ctr, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(s->rb_bctr, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
-    if (dma) {
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb_ctr, s->rb_bctr);
+    HIPCHK(hipGetLastError());
+    if (dma && !e->stage_out_inplace) {
         HIPCHK(hipEventRecord(s->ev_k, e->stream));
         HIPCHK(hipStreamWaitEvent(e->copy_out, s->ev_k, 0));
         HIPCHK(hipMemcpyAsync(s->h_out, s->dmem.p + (size_t)(s->h_out - s->h_in), s->out_bytes, hipMemcpyDeviceToHost, e->copy_out));

@@ -191,10 +191,10 @@ int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_re
  *      host memory.  The caller (a batcher goroutine) writes requests straight into guber_stage_batch()'s arrays as they
  *      arrive — no Go pointers are retained, nothing is copied or allocated per batch on the host — sets n and now_ms, and
  *      submits.  How the arrays reach the kernels depends on the batch: <= 256 requests: one launch reads and writes them in
- *      place over PCIe; a batch that fills at least half of the stage: ONE DMA copy of the request block into the stage's
- *      HBM mirror while the previous batch's kernels run, the two-launch pipeline on HBM, ONE DMA copy of the response block
- *      back while the next batch's kernels run (both directions of the link busy at the copy engines' rate); in between:
- *      the pipeline's kernels read / write the host arrays in place.  guber_stage_submit returns at
+ *      place over PCIe; a batch that fills at least half of the stage: DMA copies on a copy stream bring the request
+ *      columns into the stage's HBM mirror while the previous batches' kernels run, the two-launch pipeline works on HBM
+ *      and writes the responses straight into the host arrays; in between: the pipeline's kernels read / write the host
+ *      arrays in place.  guber_stage_submit returns at
  *      once; guber_stage_wait blocks until the responses are there (a polled sequence number for batches <= 256, a HIP
  *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With two stages per engine the
  *      batcher fills one while the GPU evaluates the other.  Stages of one engine are evaluated in submission order; the one

@@ -75,5 +75,34 @@ int main() {
                G, (t1 - t0) / L * 1e6, (t1 - t0) / L / G * 1e6, (double)L * G / (t1 - t0), (double)L * G / (t2 - t0));
         hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(s);
     }
+    // host-side cost of the other calls a stage submit makes (enqueue only; the GPU side drains afterwards)
+    {
+        hipStream_t a, b; hipStreamCreateWithFlags(&a, hipStreamNonBlocking); hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+        hipEvent_t ev; hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        char *h, *d; const size_t bytes = 1700000;
+        hipHostMalloc(&h, bytes * 4, hipHostMallocDefault); hipMalloc(&d, bytes * 4);
+        const int M = 200;
+        hipDeviceSynchronize();
+        double t0 = now_s();
+        for (int i = 0; i < M; ++i) hipMemcpyAsync(d + (i % 4) * bytes, h + (i % 4) * bytes, bytes, hipMemcpyHostToDevice, a);
+        double t1 = now_s(); hipDeviceSynchronize();
+        printf("hipMemcpyAsync H2D 1.7 MB pinned : %6.2f us host time per call\n", (t1 - t0) / M * 1e6);
+        t0 = now_s();
+        for (int i = 0; i < M; ++i) hipMemcpyAsync(h + (i % 4) * bytes, d + (i % 4) * bytes, bytes, hipMemcpyDeviceToHost, a);
+        t1 = now_s(); hipDeviceSynchronize();
+        printf("hipMemcpyAsync D2H 1.7 MB pinned : %6.2f us host time per call\n", (t1 - t0) / M * 1e6);
+        t0 = now_s();
+        for (int i = 0; i < M; ++i) hipMemcpyAsync(h + (i % 4) * bytes, d + (i % 4) * bytes, 4096, hipMemcpyDeviceToHost, a);
+        t1 = now_s(); hipDeviceSynchronize();
+        printf("hipMemcpyAsync D2H 4 KB pinned   : %6.2f us host time per call\n", (t1 - t0) / M * 1e6);
+        t0 = now_s();
+        for (int i = 0; i < 2000; ++i) hipEventRecord(ev, a);
+        t1 = now_s(); hipDeviceSynchronize();
+        printf("hipEventRecord                   : %6.2f us host time per call\n", (t1 - t0) / 2000 * 1e6);
+        t0 = now_s();
+        for (int i = 0; i < 2000; ++i) { hipEventRecord(ev, a); hipStreamWaitEvent(b, ev, 0); }
+        t1 = now_s(); hipDeviceSynchronize();
+        printf("hipEventRecord + StreamWaitEvent : %6.2f us host time per pair\n", (t1 - t0) / 2000 * 1e6);
+    }
     return 0;
 }
