@@ -273,6 +273,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     // Plain table loads: L1 may serve a line that is stale within this launch, which is safe — a stale "empty" tag is
     // corrected by the insert CAS, and READY never changes during k_front.
     uint32_t hcell = 0, fp = 0;
+    bool table_wanted = true;
     unsigned long long look = 0ull;
     uint64_t pos = (h >> 7) & T.mask;
     ulonglong2 de0 = {0ull, 0ull};
@@ -281,7 +282,12 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
         if (W.careful) { hcell = claim_home_slot(slot, W.cmask); fp = slot; }
         else { hcell = claim_home_hash(h, W.cmask); fp = (uint32_t)h; }
         look = ld_agent(&W.claims[hcell]);
-        if (!W.careful) {
+        // the look is consumed first: a head that finds its key claimed by another tile needs neither the directory entry nor
+        // the bucket (it compares its key with the claimer's request, the claimer verifies against the table), which spares
+        // three sector requests for every (key, tile) group but one (same-box A/B: +2.4 % at 4 shards, +1 % with one table;
+        // profiles/r02_w_lean_front_ab.txt)
+        table_wanted = !((uint32_t)(look >> 48) == e16 && (uint32_t)(look >> 16) == fp);
+        if (!W.careful && table_wanted) {
             de0 = *(const ulonglong2*)&T.dir[pos];
             const Bucket* hb = &T.buckets[pos];
             const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
@@ -331,7 +337,8 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     GB_STAMP(3);
 
     // ---- stage 4 (heads): finish the directory probe, verify the stored key, snapshot ------------------------------
-    if (khead && !W.careful) {
+    const bool resolve = khead && !W.careful && claimed;             // (a claimer saw its home cell free or foreign: its table lines are here)
+    if (resolve) {
         const unsigned long long tag = gk;
         const uint32_t home = (uint32_t)pos;
         for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
@@ -387,7 +394,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
         // stored is provably the segment's key.
     }
     GB_STAMPW(4);
-    if (khead) sslot[tid] = slot;
+    if (khead) sslot[tid] = resolve || W.careful ? slot : 0xffffffffu;
     if (soft_leaky) soft_any = 1u;
     if (inserted) ins_any = 1u;
     uint8_t rf = 0;
@@ -411,8 +418,12 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     lds_barrier();
     if (soft_any) {                                                  // rare: requests of a leaky key stamped differently
         if (soft_leaky) {
-            const Rec cur = T.buckets[head ? slot : sslot[head_tid]].rec;
-            my_flags |= leaky_created_harmless(cur, tile_get(sreq, tid), B.now_ms) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM;   // (declines GREGORIAN requests)
+            const uint32_t bs = sslot[head_tid];
+            if (bs == 0xffffffffu) my_flags |= SEG_NONUNIFORM;       // a group that did not resolve its bucket (not the claimer's): the exact serial walk
+            else {
+                const Rec cur = T.buckets[bs].rec;
+                my_flags |= leaky_created_harmless(cur, tile_get(sreq, tid), B.now_ms) ? SEG_CREATED_DIFFERS : SEG_NONUNIFORM;   // (declines GREGORIAN requests)
+            }
         }
     }
     if (my_flags) seg_raise(&W.srec[d], e16, my_flags);
