@@ -52,15 +52,18 @@ namespace guber {
 // atomics other than one packed add per (key, tile) group.
 //
 // k_front (one workgroup = one tile of FT requests):
-//   A  resolve: key -> directory entry || home bucket (one round trip) -> claim CAS by the leader -> verify.
-//      Segment id of a key = request index of its first toucher.  A match on an entry that is not
-//      READY (inserted during this launch) is verified against the CLAIMER's request key (input data)
-//      instead of the stored key, whose writer may still be in flight; the inserter performs the same
-//      comparison, so every member of a segment provably has the key that ends up stored.
-//   B  group the tile by segment id through an LDS hash table with per-wave member bitmaps: a request's sorted
-//      position, its rank inside its (segment, tile) group and the group size come from four popcounts.
-//   C  group heads publish size / start for (segment, tile) and add (size << 32 | tile bit) to the segment's word.
-// k_eval2 (request order): rank = members in earlier tiles (bitmap + per-tile counts) + rank in tile.
+//   0  key -> 64-bit hash; the request's own fields go to LDS.
+//   1  group the tile by hash through an LDS hash table with per-wave member bitmaps: a request's rank inside its
+//      (key, tile) group, the group size and the group's head come from four popcounts.  Only heads go on.
+//   2  claim: a fresh look at the key's cell of the per-batch claim table, a CAS only when the cell is free.  Segment id of
+//      a key = request index of its first toucher (the claimer).  A head that finds its key claimed by another tile is
+//      done with the table (no directory entry, no bucket) and publishes its group: ONE atomic (size << 32 | tile bit) on
+//      the segment's word; the claimer's own group travels in the segment record.
+//   3  one key, one request shape per segment: members against their head (LDS), heads against the claimer's request.
+//   4  the claimer: directory entry || home bucket in one trip, displaced bucket if needed, insert if absent, exact key
+//      verification, and the segment record (bucket before the batch, slot, group size) in ONE 64-byte sector.  An entry
+//      that is not READY (inserted during this launch) is trusted because every head compared its key with the claimer's.
+// k_eval2 (request order): rank = members in earlier tiles (claimer's group, bitmap + per-tile counts) + rank in tile.
 constexpr int FT = 256;                 // requests per tile in the two-launch pipeline
 constexpr int FT_MAX_TILES = 256;       // bitmap bits per segment
 constexpr int FT_WORDS = FT_MAX_TILES / 32;   // per segment: 8 x u64, each = members << 32 | bitmap of 32 tiles
@@ -267,11 +270,10 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     const bool member = valid && gk != 0ull && eq_before != 0;
     GB_STAMP(1);
 
-    // ---- stage 2 (heads): look at the claim cell, start the directory + bucket fetch, claim ----------------------
-    // The look is issued first so that it can be consumed while the table loads are still in flight; the home bucket is
-    // requested together with the home directory entry (most resident keys sit at their home position at load <= 0.5).
-    // Plain table loads: L1 may serve a line that is stale within this launch, which is safe — a stale "empty" tag is
-    // corrected by the insert CAS, and READY never changes during k_front.
+    // ---- stage 2 (heads): look at the claim cell, then (unless the key is already claimed) start the directory + bucket
+    // fetch, claim.  The home bucket is requested together with the home directory entry (most resident keys sit at their
+    // home position at load <= 0.5).  Plain table loads: L1 may serve a line that is stale within this launch, which is
+    // safe — a stale "empty" tag is corrected by the insert CAS, and READY never changes during k_front.
     uint32_t hcell = 0, fp = 0;
     bool table_wanted = true;
     unsigned long long look = 0ull;

@@ -7,10 +7,14 @@ TAG=${1:-r02_final}
 cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.txt | cut -c1-200
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$?"
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+T0=$SECONDS
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$? wall $((SECONDS-T0)) s"
+T0=$SECONDS
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall $((SECONDS-T0)) s"
+timeout 300 python bench.py --no-cpu-baseline --extras "" --dispatch one > $O/bench_one_dispatcher.json 2>/dev/null; echo "bench(one dispatcher) rc=$?"
 python - <<PY
 import json
+d=json.load(open("$O/bench_one_dispatcher.json")); print("one dispatcher, fused launches:", round(d["value"]/1e9,3), "G/s", d["ms_per_step"])
 for f in ("bench_driver_cmd", "bench"):
     d=json.load(open("$O/%s.json" % f))
     print(f, "value", round(d["value"]/1e9,3), "ms/step", d["ms_per_step"], "timed ms", d["timed_region"]["ms"], "lat", d["batch_latency"]["p50"], d["batch_latency"]["p99"], d["roofline"]["kernel_avg_us"], "frac", d["roofline"]["frac"], d["parity"])
