@@ -1,12 +1,31 @@
 // worker_pool.cpp — see worker_pool.h.
 #include "worker_pool.h"
 
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 
 namespace gubernator {
+
+// short timed waits against the system clock (pthread_cond_timedwait, which ThreadSanitizer understands; a clock step only
+// makes one of these microsecond waits end early or late, and every waiter re-checks its condition)
+static void wait_us(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, int64_t us) {
+    cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us));
+}
+
+// Callers wait for their generation on a plain futex word: the batcher's announcement wakes exactly the threads sleeping on
+// that stage, each of which re-reads the word and goes on — no mutex to queue up behind (a condition variable made every
+// batch of small RPCs a convoy of all its callers).
+static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) {
+    syscall(SYS_futex, (uint32_t*)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+}
+static void futex_wake_all(std::atomic<uint32_t>* w) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
 
 static int64_t mono_us() {
     using namespace std::chrono;
@@ -42,13 +61,19 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
             sh->device = devs[d];
             create_rc_ = guber_engine_create(&c, &sh->engine);
             if (create_rc_ != GUBER_OK) { sh->engine = nullptr; break; }
-            for (int k = 0; k < 2 && create_rc_ == GUBER_OK; ++k) create_rc_ = guber_stage_create(sh->engine, batch_limit_, key_cap_, &sh->stage[k]);
+            for (uint32_t k = 0; k < kStages && create_rc_ == GUBER_OK; ++k) {
+                Stage& st = sh->st[k];
+                create_rc_ = guber_stage_create(sh->engine, batch_limit_, key_cap_, &st.stage);
+                if (create_rc_ != GUBER_OK) break;
+                st.b = guber_stage_batch(st.stage); st.r = guber_stage_result(st.stage);
+                st.name_len.assign(batch_limit_, 0);
+            }
             shards_.push_back(std::move(sh));
             if (create_rc_ != GUBER_OK) break;
         }
     }
     if (create_rc_ != GUBER_OK) {
-        for (auto& sh : shards_) { for (auto* st : sh->stage) guber_stage_destroy(st); guber_engine_destroy(sh->engine); }
+        for (auto& sh : shards_) { for (auto& st : sh->st) guber_stage_destroy(st.stage); guber_engine_destroy(sh->engine); }
         shards_.clear();
         return;
     }
@@ -64,11 +89,15 @@ void GPUWorkerPool::Close() {
     if (closed_.exchange(true)) return;
     for (auto& sh : shards_) {
         { std::lock_guard<std::mutex> lk(sh->mu); sh->closing = true; }
-        sh->cv.notify_all();
+        sh->cv_batcher.notify_all();
     }
     for (auto& sh : shards_) {
-        if (sh->thread.joinable()) sh->thread.join();
-        for (auto*& st : sh->stage) { guber_stage_destroy(st); st = nullptr; }
+        if (sh->thread.joinable()) sh->thread.join();            // every reserved request has been evaluated and announced
+        for (auto& st : sh->st) {
+            // callers may still be copying their responses out of the stage
+            while (st.gen.load() && st.consumed.load(std::memory_order_acquire) != st.n) std::this_thread::yield();
+            guber_stage_destroy(st.stage); st.stage = nullptr;
+        }
         if (sh->engine) { guber_engine_destroy(sh->engine); sh->engine = nullptr; }
     }
 }
@@ -98,7 +127,7 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
     memset(out, 0, sizeof(*out));
     for (auto& sh : shards_) {
         out->batches += sh->flushed.load(); out->requests += sh->requests.load();
-        { std::lock_guard<std::mutex> lk(sh->mu); out->queue_length += sh->queue.size(); }
+        for (auto& st : sh->st) { const uint64_t w = st.word.load(); if (!(w & kClosed)) out->queue_length += (uint32_t)w; }
         out->queue_length_max = std::max<uint64_t>(out->queue_length_max, sh->queue_max.load());
         out->send_duration_us_sum += sh->send_us_sum.load();
         out->send_duration_us_max = std::max<uint64_t>(out->send_duration_us_max, sh->send_us_max.load());
@@ -124,6 +153,31 @@ bool GPUWorkerPool::GetRateLimit(const RateLimitReq& r, RateLimitReqState st, Ra
     return resp->error.empty();
 }
 
+// ---- the callers' side ---------------------------------------------------------------------------------------------------
+struct GPUWorkerPool::Job {
+    const std::vector<const RateLimitReq*>& reqs;
+    const std::vector<RateLimitReqState>& st;
+    std::vector<RateLimitResp*>& out;
+    std::vector<uint32_t> key_len;                    // HashKey length per request
+    std::vector<std::vector<uint32_t>> per;           // per shard: request indices in call order
+    std::vector<Ticket> tickets;
+};
+
+static void answer_item(RateLimitResp& o, const RateLimitReq& req, int rc, uint8_t err, uint8_t status, int64_t limit, int64_t remaining,
+                        int64_t reset_time) {
+    o = RateLimitResp{};
+    if (rc != GUBER_OK) {
+        o.error = std::string("gpu engine: ") + guber_strerror(rc);
+    } else if (err != 0) {
+        char buf[256];
+        if (err == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, sizeof buf, guber_item_strerror(err), req.algorithm);
+        else snprintf(buf, sizeof buf, "%s", guber_item_strerror(err));
+        o.error = buf;                                               // nil response + error (workers.go:317-321)
+    } else {
+        o.status = status; o.limit = limit; o.remaining = remaining; o.reset_time = reset_time;
+    }
+}
+
 void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
                                      std::vector<RateLimitResp*>& out) {
     if (reqs.empty()) return;
@@ -131,179 +185,259 @@ void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& req
         for (auto* r : out) r->error = "worker pool is closed";
         return;
     }
-    Call call;
-    call.remaining = reqs.size();
-    // every request goes to the queue of its key's shard (workers.go:261-291); requests of one key keep their order
-    std::vector<std::vector<Pending>> per(shards_.size());
+    Job job{reqs, st, out, {}, {}, {}};
+    job.key_len.resize(reqs.size());
+    job.per.resize(shards_.size());
+    // every request belongs to the shard of its key (workers.go:261-291); requests of one key keep their order
     std::string k;
     for (size_t i = 0; i < reqs.size(); ++i) {
         k.assign(reqs[i]->name); k.push_back('_'); k.append(reqs[i]->unique_key);               // HashKey, client.go:39-41
-        per[ShardOf((const uint8_t*)k.data(), (uint32_t)k.size())].push_back({reqs[i], st[i], out[i], &call, (uint32_t)k.size()});
-    }
-    for (size_t j = 0; j < per.size(); ++j) {
-        if (per[j].empty()) continue;
-        Shard& sh = *shards_[j];
-        {
-            std::lock_guard<std::mutex> lk(sh.mu);
-            sh.queue.insert(sh.queue.end(), per[j].begin(), per[j].end());
-            const uint64_t q = sh.queue.size();
-            if (q > sh.queue_max.load()) sh.queue_max.store(q);
+        job.key_len[i] = (uint32_t)k.size();
+        const uint32_t j = ShardOf((const uint8_t*)k.data(), (uint32_t)k.size());
+        if (k.size() > max_key_) {                                   // answered here, never reaches the device
+            shards_[j]->key_too_long++;
+            answer_item(*out[i], *reqs[i], GUBER_OK, GUBER_ITEM_E_KEY_TOO_LONG, 0, 0, 0, 0);
+            continue;
         }
-        sh.cv.notify_all();
+        job.per[j].push_back((uint32_t)i);
     }
-    std::unique_lock<std::mutex> lk(call.mu);
-    call.cv.wait(lk, [&] { return call.remaining == 0; });
+    for (size_t j = 0; j < job.per.size(); ++j) {
+        const std::vector<uint32_t>& list = job.per[j];
+        uint32_t begin = 0;
+        while (begin < list.size()) {
+            Ticket t{};
+            const uint32_t got = reserve(job, *shards_[j], list, begin, &t);
+            if (!got) { fail_rest(job, list, begin, "worker pool is closed"); break; }
+            write_requests(job, t, list);
+            job.tickets.push_back(t);
+            begin += got;
+        }
+    }
+    for (auto& t : job.tickets)
+        if (!t.consumed) try_consume(job, t, true);
 }
 
-void GPUWorkerPool::answer(Pending& p, int rc, uint8_t err, uint8_t status, int64_t limit, int64_t remaining, int64_t reset_time) {
-    RateLimitResp& o = *p.resp;
-    o = RateLimitResp{};
-    if (rc != GUBER_OK) {
-        o.error = std::string("gpu engine: ") + guber_strerror(rc);
-    } else if (err != 0) {
-        char buf[256];
-        if (err == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, sizeof buf, guber_item_strerror(err), p.req->algorithm);
-        else snprintf(buf, sizeof buf, "%s", guber_item_strerror(err));
-        o.error = buf;                                               // nil response + error (workers.go:317-321)
-    } else {
-        o.status = status; o.limit = limit; o.remaining = remaining; o.reset_time = reset_time;
-    }
-    Call* c = p.call;
-    // notify while holding the lock: the waiter owns the Call (it lives on its stack) and may destroy it as soon as it
-    // can re-acquire the mutex and sees remaining == 0
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (--c->remaining == 0) c->cv.notify_all();
+void GPUWorkerPool::fail_rest(Job& job, const std::vector<uint32_t>& list, uint32_t begin, const char* why) {
+    for (size_t q = begin; q < list.size(); ++q) { *job.out[list[q]] = RateLimitResp{}; job.out[list[q]]->error = why; }
 }
 
-void GPUWorkerPool::run(Shard& sh) {
-    Flight fl[2];
-    fl[0].stage = sh.stage[0]; fl[1].stage = sh.stage[1];
-    for (auto& f : fl) f.batch.reserve(batch_limit_);
-    int cur = 0;
-    bool inflight = false;                      // fl[cur ^ 1] has been submitted and not completed yet
+// Reserve slots for as many of list[begin..] as the shard's open stage still takes: ONE compare-and-swap on the stage's
+// reservation word (slots | key bytes << 32).  Returns the number reserved (>= 1), or 0 when the pool has been closed.
+uint32_t GPUWorkerPool::reserve(Job& job, Shard& sh, const std::vector<uint32_t>& list, uint32_t begin, Ticket* out) {
     for (;;) {
-        Flight& f = fl[cur];
-        {
-            std::unique_lock<std::mutex> lk(sh.mu);
-            if (inflight && (sh.queue.empty() || (sh.queue.size() < batch_limit_ && !sh.closing))) {
-                // nothing (or not yet a full batch) to overlap with: deliver the batch in flight first
-                lk.unlock();
-                complete(sh, fl[cur ^ 1], GUBER_OK);
-                inflight = false;
-                continue;
+        const uint32_t k = sh.open.load(std::memory_order_acquire);
+        if (k == kStages + 1) return 0;
+        if (k < kStages) {
+            Stage& s = sh.st[k];
+            uint64_t w = s.word.load(std::memory_order_acquire);
+            while (!(w & kClosed)) {
+                const uint32_t cnt = (uint32_t)w, kb = (uint32_t)(w >> 32);
+                const uint32_t room = batch_limit_ - cnt;
+                uint32_t take = 0; uint64_t bytes = 0;
+                while (take < room && begin + take < list.size()) {
+                    const uint32_t kl = job.key_len[list[begin + take]];
+                    if ((uint64_t)kb + bytes + kl > key_cap_) break;
+                    bytes += kl; ++take;
+                }
+                if (take == 0) {                                     // no slot or no key bytes left: flush it now, take the next stage
+                    if (!s.flush_now.exchange(true)) {
+                        if (room) sh.flush_on_key_bytes++;
+                        { std::lock_guard<std::mutex> lk(sh.mu); }
+                        sh.cv_batcher.notify_one();
+                    }
+                    break;
+                }
+                if (s.word.compare_exchange_weak(w, w + take + (bytes << 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
+                    *out = Ticket{&sh, &s, s.gen.load(std::memory_order_relaxed), cnt, take, begin, kb, &list, false};
+                    const bool first = cnt == 0, full = cnt + take >= batch_limit_;
+                    if (first) s.first_us.store(mono_us(), std::memory_order_release);
+                    const uint64_t q = (uint64_t)cnt + take;
+                    if (q > sh.queue_max.load(std::memory_order_relaxed)) sh.queue_max.store(q, std::memory_order_relaxed);
+                    if (first || full) {
+                        { std::lock_guard<std::mutex> lk(sh.mu); }
+                        sh.cv_batcher.notify_one();
+                    }
+                    return take;
+                }
             }
-            sh.cv.wait(lk, [&] { return sh.closing || !sh.queue.empty(); });
-            if (sh.queue.empty() && sh.closing) break;
-            // flush at batch_limit or batch_wait after the first queued item (peer_client.go:284-337)
-            if (sh.queue.size() < batch_limit_ && !sh.closing)
-                sh.cv.wait_for(lk, std::chrono::microseconds(batch_wait_us_), [&] { return sh.closing || sh.queue.size() >= batch_limit_; });
-            // take as many as fit: batch_limit items, and their keys into the stage's key buffer
-            size_t take = 0; uint64_t kb = 0;
-            while (take < sh.queue.size() && take < batch_limit_) {
-                const uint32_t kl = sh.queue[take].key_len <= max_key_ ? sh.queue[take].key_len : 0;   // over-long keys are answered, not copied
-                if (kb + kl > key_cap_) { sh.flush_on_key_bytes++; break; }
-                kb += kl; take++;
-            }
-            f.batch.assign(sh.queue.begin(), sh.queue.begin() + take);
-            sh.queue.erase(sh.queue.begin(), sh.queue.begin() + take);
         }
-        f.t0_us = mono_us();
-        const bool submitted = fill_and_submit(sh, f);
-        if (inflight) { complete(sh, fl[cur ^ 1], GUBER_OK); inflight = false; }
-        if (submitted) { inflight = true; cur ^= 1; }
+        // no stage takes reservations right now: pick up responses that are ready (so that stages drain and the batcher can
+        // rotate), then wait for the batcher to open the next one
+        for (auto& t : job.tickets)
+            if (!t.consumed) try_consume(job, t, false);
+        std::unique_lock<std::mutex> lk(sh.mu);
+        if (sh.open.load(std::memory_order_acquire) == k) wait_us(sh.cv_callers, lk, 50);
     }
-    if (inflight) complete(sh, fl[cur ^ 1], GUBER_OK);
 }
 
-// write the batch into the stage in place and submit it (asynchronous).  With a persistent Store configured the batch takes
-// the synchronous path that makes the Store's calls (flush_with_store).
-bool GPUWorkerPool::fill_and_submit(Shard& sh, Flight& f) {
-    const uint32_t n = (uint32_t)f.batch.size();
-    sh.requests += n;
-    if (n > sh.batch_max.load()) sh.batch_max.store(n);
-    if (has_store_.load()) { flush_with_store(sh, f.batch); sh.flushed++; f.batch.clear(); return false; }
-    guber_batch_t* b = guber_stage_batch(f.stage);
-    const int64_t now = NowMs();
+// the caller writes its requests into the slots it reserved: HashKey = name + "_" + unique_key straight into the key buffer
+void GPUWorkerPool::write_requests(Job& job, const Ticket& t, const std::vector<uint32_t>& list) {
+    Stage& s = *t.st;
+    const guber_batch_t* b = s.b;
     uint8_t* kp = (uint8_t*)b->key_bytes;
     uint32_t* off = (uint32_t*)b->key_off;
     int64_t *hits = (int64_t*)b->hits, *limit = (int64_t*)b->limit, *duration = (int64_t*)b->duration, *burst = (int64_t*)b->burst,
             *created = (int64_t*)b->created_at;
     uint8_t *algo = (uint8_t*)b->algorithm, *owner = (uint8_t*)b->is_owner;
     uint32_t* beh = (uint32_t*)b->behavior;
-    uint32_t o = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const RateLimitReq& r = *f.batch[i].req;
+    int64_t now = 0;
+    uint32_t o = t.key_base;
+    for (uint32_t q = 0; q < t.count; ++q) {
+        const uint32_t ri = list[t.list_begin + q], i = t.first_slot + q;
+        const RateLimitReq& r = *job.reqs[ri];
         off[i] = o;
-        if (f.batch[i].key_len <= max_key_) {                         // HashKey = name + "_" + unique_key, written in place
-            memcpy(kp + o, r.name.data(), r.name.size()); o += (uint32_t)r.name.size();
-            kp[o++] = '_';
-            memcpy(kp + o, r.unique_key.data(), r.unique_key.size()); o += (uint32_t)r.unique_key.size();
-        }                                                            // else: zero-length key -> answered below as key too long
+        memcpy(kp + o, r.name.data(), r.name.size()); o += (uint32_t)r.name.size();
+        kp[o++] = '_';
+        memcpy(kp + o, r.unique_key.data(), r.unique_key.size()); o += (uint32_t)r.unique_key.size();
         hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
-        created[i] = r.created_at ? r.created_at : now;
+        if (r.created_at) created[i] = r.created_at;
+        else { if (!now) now = NowMs(); created[i] = now; }
         algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
-        beh[i] = r.behavior; owner[i] = f.batch[i].st.is_owner ? 1 : 0;
+        beh[i] = r.behavior; owner[i] = job.st[ri].is_owner ? 1 : 0;
+        s.name_len[i] = (uint16_t)std::min<size_t>(r.name.size(), 0xffff);
     }
-    off[n] = o;
-    b->n = n; b->now_ms = now;                                        // DURATION_IS_GREGORIAN: the kernels derive the interval from now_ms
-    sh.in_flight++;
-    const int rc = guber_stage_submit(f.stage);
-    if (rc != GUBER_OK) { complete(sh, f, rc); return false; }
+    s.written.fetch_add(t.count, std::memory_order_release);
+}
+
+// the responses of a ticket, once its generation has been announced; returns false when not ready and !block
+bool GPUWorkerPool::try_consume(Job& job, Ticket& t, bool block) {
+    Stage& s = *t.st;
+    // (a stage carries generation g + 1 only after every ticket of g has been consumed, so the word reads g - 1 or g here)
+    for (uint32_t v; (v = s.done_gen.load(std::memory_order_acquire)) != (uint32_t)t.gen;) {
+        if (!block) return false;
+        futex_wait(&s.done_gen, v);
+    }
+    const int rc = s.rc;
+    const guber_result_t* r = s.r;
+    for (uint32_t q = 0; q < t.count; ++q) {
+        const uint32_t ri = (*t.list)[t.list_begin + q], i = t.first_slot + q;
+        answer_item(*job.out[ri], *job.reqs[ri], rc, rc == GUBER_OK ? r->err[i] : 0, r->status[i], r->limit[i], r->remaining[i], r->reset_time[i]);
+    }
+    t.consumed = true;
+    s.consumed.fetch_add(t.count, std::memory_order_release);
     return true;
 }
 
-void GPUWorkerPool::complete(Shard& sh, Flight& f, int rc) {
-    if (rc == GUBER_OK) rc = guber_stage_wait(f.stage);
-    const guber_result_t* r = guber_stage_result(f.stage);
-    const uint32_t n = (uint32_t)f.batch.size();
-    for (uint32_t i = 0; i < n; ++i) {
-        Pending& p = f.batch[i];
-        if (p.key_len > max_key_) { sh.key_too_long++; answer(p, GUBER_OK, GUBER_ITEM_E_KEY_TOO_LONG, 0, 0, 0, 0); continue; }
-        answer(p, rc, rc == GUBER_OK ? r->err[i] : 0, r->status[i], r->limit[i], r->remaining[i], r->reset_time[i]);
+// ---- the batcher's side --------------------------------------------------------------------------------------------------
+void GPUWorkerPool::open_stage(Shard& sh, uint32_t k) {
+    Stage& s = sh.st[k];
+    s.n = 0; s.rc = GUBER_OK;
+    s.written.store(0); s.consumed.store(0); s.first_us.store(0); s.flush_now.store(false);
+    s.gen.store(s.gen.load() + 1);
+    s.word.store(0, std::memory_order_release);
+    sh.open.store(k, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(sh.mu); }
+    sh.cv_callers.notify_all();
+}
+
+void GPUWorkerPool::run(Shard& sh) {
+    uint32_t cur = 0;
+    int inflight = -1;                                               // stage submitted and not yet announced
+    open_stage(sh, cur);
+    for (;;) {
+        Stage& s = sh.st[cur];
+        bool due = false, closing = false;
+        {
+            // flush at batch_limit, at batch_wait after the first reservation (peer_client.go:284-337), or when a caller found
+            // no room; with nothing due, deliver the batch in flight instead of sitting on it
+            std::unique_lock<std::mutex> lk(sh.mu);
+            for (;;) {
+                closing = sh.closing;
+                const uint32_t cnt = (uint32_t)s.word.load(std::memory_order_acquire);
+                if (cnt >= batch_limit_ || (cnt && (closing || s.flush_now.load()))) { due = true; break; }
+                if (cnt) {
+                    const int64_t first = s.first_us.load(std::memory_order_acquire), now = mono_us();
+                    if (first && now - first >= (int64_t)batch_wait_us_) { due = true; break; }
+                    if (inflight >= 0) break;
+                    const int64_t left = first ? (int64_t)batch_wait_us_ - (now - first) : (int64_t)batch_wait_us_;
+                    wait_us(sh.cv_batcher, lk, std::max<int64_t>(left, 1));
+                    continue;
+                }
+                if (inflight >= 0 || closing) break;
+                sh.cv_batcher.wait(lk);
+            }
+        }
+        if (!due) {
+            if (inflight >= 0) { complete(sh, sh.st[inflight]); inflight = -1; continue; }
+            if (closing) {
+                // nothing reserved, nothing in flight: stop taking reservations; a caller may have slipped one in meanwhile
+                sh.open.store(kStages + 1, std::memory_order_release);
+                const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
+                if ((uint32_t)w == 0) break;
+                s.n = (uint32_t)w;
+                while (s.written.load(std::memory_order_acquire) != s.n) std::this_thread::yield();
+                ((uint32_t*)s.b->key_off)[s.n] = (uint32_t)(w >> 32);
+                submit(sh, s);
+                complete(sh, s);
+                break;
+            }
+            continue;
+        }
+        // the next stage takes the reservations from here on; it was announced two flushes ago and has been read out since
+        const uint32_t next = (cur + 1) % kStages;
+        Stage& nx = sh.st[next];
+        if (inflight == (int)next) { complete(sh, nx); inflight = -1; }
+        for (uint32_t spins = 0; nx.gen.load() && nx.consumed.load(std::memory_order_acquire) != nx.n; ++spins) {
+            if (spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        open_stage(sh, next);
+        const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
+        s.n = (uint32_t)w;
+        while (s.written.load(std::memory_order_acquire) != s.n) std::this_thread::yield();   // callers still copying their requests in
+        ((uint32_t*)s.b->key_off)[s.n] = (uint32_t)(w >> 32);
+        submit(sh, s);
+        if (inflight >= 0) complete(sh, sh.st[inflight]);
+        inflight = (int)cur;
+        cur = next;
     }
-    const uint64_t us = (uint64_t)std::max<int64_t>(mono_us() - f.t0_us, 0);
+    if (inflight >= 0) complete(sh, sh.st[inflight]);
+    sh.open.store(kStages + 1, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(sh.mu); }
+    sh.cv_callers.notify_all();
+}
+
+// hand a sealed stage to the engine (asynchronous).  With a persistent Store configured the batch takes the synchronous
+// path that makes the Store's calls.
+void GPUWorkerPool::submit(Shard& sh, Stage& s) {
+    s.t0_us = mono_us();
+    sh.requests += s.n;
+    if (s.n > sh.batch_max.load()) sh.batch_max.store(s.n);
+    guber_batch_t* b = s.b;
+    b->n = s.n; b->now_ms = NowMs();                                  // DURATION_IS_GREGORIAN: the kernels derive the interval from now_ms
+    sh.in_flight++;
+    if (has_store_.load()) { submit_with_store(sh, s); return; }
+    s.rc = guber_stage_submit(s.stage);
+    s.submitted = s.rc == GUBER_OK;
+}
+
+// wait for a submitted stage and announce its generation: the callers read their responses themselves
+void GPUWorkerPool::complete(Shard& sh, Stage& s) {
+    if (s.submitted) { s.rc = guber_stage_wait(s.stage); s.submitted = false; }
+    const uint64_t us = (uint64_t)std::max<int64_t>(mono_us() - s.t0_us, 0);
     sh.send_us_sum += us;
     if (us > sh.send_us_max.load()) sh.send_us_max.store(us);
     sh.flushed++; sh.in_flight--;
-    f.batch.clear();
+    s.done_gen.store((uint32_t)s.gen.load(), std::memory_order_release);
+    futex_wake_all(&s.done_gen);
 }
 
 // Config.Store (store.go:49-65) configured: ask the store for keys that are not resident BEFORE the batch
 // (algorithms.go:45-51 `s.Get` on a cache miss, then `c.Add(item)`), evaluate, then issue the Remove / OnChange
-// calls the reference makes from inside the algorithms, in request order.  Synchronous, host-pointer entry points.
-void GPUWorkerPool::flush_with_store(Shard& sh, std::vector<Pending>& batch) {
+// calls the reference makes from inside the algorithms, in request order.  Synchronous, host-pointer entry points over
+// the stage's own arrays.
+void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
     guber_engine_t* const engine_ = sh.engine;
-    const uint32_t n = (uint32_t)batch.size();
-    const int64_t now = NowMs();
-    std::vector<uint8_t> keys; std::vector<uint32_t> off(n + 1), beh(n);
-    std::vector<int64_t> hits(n), limit(n), duration(n), burst(n), created(n);
-    std::vector<uint8_t> algo(n), owner(n), status(n), err(n);
-    std::vector<int64_t> rlimit(n), rremaining(n), rreset(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const RateLimitReq& r = *batch[i].req;
-        off[i] = (uint32_t)keys.size();
-        if (batch[i].key_len <= max_key_) { const std::string k = r.HashKey(); keys.insert(keys.end(), k.begin(), k.end()); }
-        hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
-        created[i] = r.created_at ? r.created_at : now;
-        algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
-        beh[i] = r.behavior; owner[i] = batch[i].st.is_owner ? 1 : 0;
-    }
-    off[n] = (uint32_t)keys.size();
-    keys.resize(keys.size() + 16, 0);
-    guber_batch_t b{}; guber_result_t res{};
-    b.n = n; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = limit.data();
-    b.duration = duration.data(); b.burst = burst.data(); b.created_at = created.data(); b.algorithm = algo.data();
-    b.behavior = beh.data(); b.is_owner = owner.data(); b.now_ms = now;
-    res.status = status.data(); res.limit = rlimit.data(); res.remaining = rremaining.data(); res.reset_time = rreset.data();
-    res.err = err.data();
+    const uint32_t n = s.n;
+    guber_batch_t b = *s.b;
+    guber_result_t res = *s.r;
+    const uint8_t* keys = b.key_bytes; const uint32_t* off = b.key_off;
     std::vector<uint8_t> sflags(n, 0); std::vector<guber_item_t> sitems(n);
     guber_store_events_t sev{sflags.data(), sitems.data()};
     auto store_req = [&](uint32_t i) {
-        const RateLimitReq& r = *batch[i].req;
         guber_store_req_t q{};
-        q.key = keys.data() + off[i]; q.key_len = off[i + 1] - off[i]; q.name_len = (uint32_t)r.name.size();
-        q.hits = r.hits; q.limit = r.limit; q.duration = r.duration; q.burst = r.burst; q.created_at = created[i];
-        q.algorithm = r.algorithm; q.behavior = r.behavior;
+        q.key = keys + off[i]; q.key_len = off[i + 1] - off[i]; q.name_len = s.name_len[i];
+        q.hits = b.hits[i]; q.limit = b.limit[i]; q.duration = b.duration[i]; q.burst = b.burst[i]; q.created_at = b.created_at[i];
+        q.algorithm = b.algorithm[i] == 255 ? -1 : b.algorithm[i]; q.behavior = b.behavior[i];
         return q;
     };
     std::vector<uint8_t> missing(n, 0);
@@ -312,7 +446,7 @@ void GPUWorkerPool::flush_with_store(Shard& sh, std::vector<Pending>& batch) {
         std::vector<std::string> asked;
         for (uint32_t i = 0; i < n && rc == GUBER_OK; ++i) {
             if (!missing[i] || off[i + 1] == off[i]) continue;
-            std::string k((const char*)keys.data() + off[i], off[i + 1] - off[i]);
+            std::string k((const char*)keys + off[i], off[i + 1] - off[i]);
             if (std::find(asked.begin(), asked.end(), k) != asked.end()) continue;
             asked.push_back(k);
             guber_item_t it{};
@@ -326,14 +460,11 @@ void GPUWorkerPool::flush_with_store(Shard& sh, std::vector<Pending>& batch) {
     if (rc == GUBER_OK) rc = guber_eval_batch_store(engine_, &b, &res, &sev);
     if (rc == GUBER_OK) {
         for (uint32_t i = 0; i < n; ++i) {
-            if ((sflags[i] & GUBER_STORE_REMOVE) && store_.remove) store_.remove(store_.user, keys.data() + off[i], off[i + 1] - off[i]);
+            if ((sflags[i] & GUBER_STORE_REMOVE) && store_.remove) store_.remove(store_.user, keys + off[i], off[i + 1] - off[i]);
             if ((sflags[i] & GUBER_STORE_ONCHANGE) && store_.on_change) { const guber_store_req_t q = store_req(i); store_.on_change(store_.user, &q, &sitems[i]); }
         }
     }
-    for (uint32_t i = 0; i < n; ++i) {
-        if (batch[i].key_len > max_key_) { answer(batch[i], GUBER_OK, GUBER_ITEM_E_KEY_TOO_LONG, 0, 0, 0, 0); continue; }
-        answer(batch[i], rc, rc == GUBER_OK ? err[i] : 0, status[i], rlimit[i], rremaining[i], rreset[i]);
-    }
+    s.rc = rc; s.submitted = false;
 }
 
 int GPUWorkerPool::AddCacheItem(const guber_item_t& item) {

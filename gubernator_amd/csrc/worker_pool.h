@@ -1,11 +1,14 @@
 // worker_pool.h — C++ host layer above the C ABI, mirroring the reference's call surface for the path:
 //   gubernator::GPUWorkerPool   <->  WorkerPool            workers.go:54-626
 //   gubernator::V1Instance      <->  V1Instance.GetRateLimits (local-owner slice)  gubernator.go:183-306
-// Same names, argument meaning and error behaviour; what changes is the mechanism: callers from any number of threads
-// are collected per shard by one batcher thread (flush at batch_limit items or batch_wait after the first one — the
-// policy of peer_client.go:284-337), written IN PLACE into one of the shard's two stages (device-visible host memory,
-// include/guber_gpu.h guber_stage_*) and submitted; while the GPU evaluates one stage the batcher fills the other.
-// Nothing is allocated per flush.
+// Same names, argument meaning and error behaviour; what changes is the mechanism.  The reference hands every request to
+// its worker's goroutine through a channel (workers.go:261-291); here the CALLERS do the per-request work, in parallel:
+// a caller reserves a contiguous range of request slots (and key bytes) in the open stage of its key's shard with one
+// compare-and-swap per RPC and shard, writes its requests IN PLACE into the stage's arrays (device-visible host memory,
+// include/guber_gpu.h guber_stage_*), and later reads its responses straight out of the stage's result arrays.  The
+// shard's batcher thread never touches a request: it seals the open stage at batch_limit items or batch_wait after the
+// first one (the policy of peer_client.go:284-337), submits it, opens the next of its three stages (one filling, one on
+// the GPU, one being read out by its callers), and announces completed generations.  Nothing is allocated per flush.
 //
 // Shards: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
 // over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers —
@@ -85,26 +88,44 @@ class GPUWorkerPool {
     void Metrics(guber_pool_metrics_t* out) const;   // gubernator_batch_queue_length / gubernator_batch_send_duration analogues (gubernator.go:96-107)
 
  private:
-    struct Call { std::mutex mu; std::condition_variable cv; size_t remaining = 0; };
-    struct Pending { const RateLimitReq* req; RateLimitReqState st; RateLimitResp* resp; Call* call; uint32_t key_len; };
-    struct Shard {              // one "worker" of the reference: its own cache (engine), queue and goroutine (thread)
+    static constexpr uint32_t kStages = 3;                // filling / on the GPU / being read out
+    static constexpr uint64_t kClosed = 1ull << 63;       // Stage::word: not accepting reservations
+    struct Stage {                                        // one of a shard's stages and the generation it currently carries
+        guber_stage_t* stage = nullptr;
+        guber_batch_t* b = nullptr; guber_result_t* r = nullptr;
+        std::vector<uint16_t> name_len;                   // per slot: length of the request's name (Store callbacks)
+        std::atomic<uint64_t> word{kClosed};              // kClosed | key bytes reserved << 32 | slots reserved
+        std::atomic<uint32_t> written{0}, consumed{0};    // slots filled by their callers / responses picked up
+        std::atomic<uint64_t> gen{0};                     // generation carried
+        std::atomic<uint32_t> done_gen{0};                // low half of the last generation whose responses are ready (futex word)
+        std::atomic<int64_t> first_us{0};                 // when the generation's first reservation was made (batch_wait)
+        std::atomic<bool> flush_now{false};               // a caller found no room: do not wait for batch_wait
+        uint32_t n = 0; int rc = 0; int64_t t0_us = 0;    // sealed size, result code, flush start (batcher only; rc read after done_gen)
+        bool submitted = false;                           // guber_stage_submit succeeded, guber_stage_wait is due
+    };
+    struct Shard {              // one "worker" of the reference: its own cache (engine) and goroutine (batcher thread)
         guber_engine_t* engine = nullptr;
-        guber_stage_t* stage[2] = {nullptr, nullptr};
+        Stage st[kStages];
         int32_t device = 0;
+        std::atomic<uint32_t> open{kStages};              // index of the stage accepting reservations; kStages = none right now, kStages + 1 = closed for good
         std::mutex mu;
-        std::condition_variable cv;
-        std::vector<Pending> queue;
+        std::condition_variable cv_batcher, cv_callers;   // batcher: first item / full / closing; callers in reserve(): a stage opened
         bool closing = false;
         std::thread thread;
         std::atomic<uint64_t> flushed{0}, requests{0}, queue_max{0}, send_us_sum{0}, send_us_max{0}, batch_max{0}, in_flight{0},
             key_too_long{0}, flush_on_key_bytes{0};
     };
-    struct Flight { guber_stage_t* stage = nullptr; std::vector<Pending> batch; int64_t t0_us = 0; };
+    struct Ticket { Shard* sh; Stage* st; uint64_t gen; uint32_t first_slot, count, list_begin, key_base; const std::vector<uint32_t>* list; bool consumed; };
+    struct Job;                                           // one GetRateLimitMany call: its per-shard request lists and tickets
     void run(Shard& sh);
-    bool fill_and_submit(Shard& sh, Flight& f);           // false: the batch was answered synchronously (Store path / error)
-    void complete(Shard& sh, Flight& f, int rc);
-    void flush_with_store(Shard& sh, std::vector<Pending>& batch);
-    static void answer(Pending& p, int rc, uint8_t err, uint8_t status, int64_t limit, int64_t remaining, int64_t reset_time);
+    void open_stage(Shard& sh, uint32_t k);
+    void submit(Shard& sh, Stage& s);
+    void submit_with_store(Shard& sh, Stage& s);
+    void complete(Shard& sh, Stage& s);
+    uint32_t reserve(Job& job, Shard& sh, const std::vector<uint32_t>& list, uint32_t begin, Ticket* out);
+    void write_requests(Job& job, const Ticket& t, const std::vector<uint32_t>& list);
+    bool try_consume(Job& job, Ticket& t, bool block);
+    void fail_rest(Job& job, const std::vector<uint32_t>& list, uint32_t begin, const char* why);
 
     std::vector<std::unique_ptr<Shard>> shards_;
     guber_ring_t* ring_ = nullptr;

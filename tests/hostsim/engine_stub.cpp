@@ -1,0 +1,79 @@
+// engine_stub.cpp — TEST INFRASTRUCTURE: the subset of the engine's C ABI that gubernator::GPUWorkerPool calls, answered on
+// the CPU by the oracle, so that the pool's host logic (slot reservation by the callers, stage rotation, generations,
+// shutdown) can be exercised — also under ThreadSanitizer — on a machine without a GPU.  Linked only into
+// tests/hostsim/pool_test; never part of the product library, which has no CPU path at all.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../include/guber_gpu.h"
+#include "../../oracle/guber_oracle.h"
+
+struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; };
+struct guber_stage {
+    guber_engine* e; uint32_t max_n, key_cap;
+    std::vector<uint32_t> off, beh; std::vector<int64_t> hits, limit, duration, burst, created, rl, rr, rs;
+    std::vector<uint8_t> algo, owner, status, err, keys;
+    guber_batch_t b{}; guber_result_t r{};
+    bool in_flight = false;
+    std::mt19937 rng{12345};
+};
+
+extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** out) {
+    guber_engine* e = new guber_engine();
+    e->o = oracle_create(cfg->cache_size ? cfg->cache_size : 50000, 1);
+    e->max_batch = cfg->max_batch;
+    *out = e;
+    return GUBER_OK;
+}
+extern "C" void guber_engine_destroy(guber_engine_t* e) { if (e) { oracle_destroy(e->o); delete e; } }
+extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
+    guber_stage* s = new guber_stage();
+    s->e = e; s->max_n = max_n; s->key_cap = key_bytes_cap ? key_bytes_cap : max_n * 64;
+    const size_t n = max_n;
+    s->off.assign(n + 1, 0); s->beh.assign(n, 0); s->hits.assign(n, 0); s->limit.assign(n, 0); s->duration.assign(n, 0);
+    s->burst.assign(n, 0); s->created.assign(n, 0); s->rl.assign(n, 0); s->rr.assign(n, 0); s->rs.assign(n, 0);
+    s->algo.assign(n, 0); s->owner.assign(n, 0); s->status.assign(n, 0); s->err.assign(n, 0); s->keys.assign(s->key_cap + 64, 0);
+    s->b.key_bytes = s->keys.data(); s->b.key_off = s->off.data(); s->b.hits = s->hits.data(); s->b.limit = s->limit.data();
+    s->b.duration = s->duration.data(); s->b.burst = s->burst.data(); s->b.created_at = s->created.data();
+    s->b.algorithm = s->algo.data(); s->b.behavior = s->beh.data(); s->b.is_owner = s->owner.data();
+    s->r.status = s->status.data(); s->r.limit = s->rl.data(); s->r.remaining = s->rr.data(); s->r.reset_time = s->rs.data(); s->r.err = s->err.data();
+    *out = s;
+    return GUBER_OK;
+}
+extern "C" void guber_stage_destroy(guber_stage_t* s) { delete s; }
+extern "C" guber_batch_t* guber_stage_batch(guber_stage_t* s) { return &s->b; }
+extern "C" guber_result_t* guber_stage_result(guber_stage_t* s) { return &s->r; }
+extern "C" int guber_stage_submit(guber_stage_t* s) {
+    if (s->in_flight) return GUBER_E_INVALID_ARG;
+    if (s->b.n > s->max_n || (s->b.n && s->b.key_off[s->b.n] > s->key_cap)) return GUBER_E_BATCH_TOO_LARGE;
+    {   // evaluation order = submission order, like the engine stream
+        std::lock_guard<std::mutex> lk(s->e->mu);
+        if (s->b.n) oracle_eval_batch(s->e->o, &s->b, &s->r);
+    }
+    s->in_flight = true;
+    return GUBER_OK;
+}
+extern "C" int guber_stage_wait(guber_stage_t* s) {
+    if (s->in_flight) std::this_thread::sleep_for(std::chrono::microseconds(s->rng() % 300));   // the GPU takes a while
+    s->in_flight = false;
+    return GUBER_OK;
+}
+extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t i = 0; i < n; ++i) { int ex = 0; oracle_add_item(e->o, &items[i], 0, &ex); if (existed) existed[i] = (uint8_t)ex; }
+    return GUBER_OK;
+}
+extern "C" int guber_get_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, guber_item_t* out, int* found) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    return oracle_get_item(e->o, key, key_len, now_ms, out, found);
+}
+extern "C" int64_t guber_size(guber_engine_t* e) { std::lock_guard<std::mutex> lk(e->mu); return oracle_size(e->o); }
+// not exercised on the CPU (the Store / Loader paths are covered by the GPU tests)
+extern "C" int guber_dump(guber_engine_t*, guber_item_t*, uint64_t, uint8_t*, uint64_t, uint64_t*, uint64_t*) { return GUBER_E_INVALID_ARG; }
+extern "C" int guber_probe_missing(guber_engine_t*, const guber_batch_t*, uint8_t*) { return GUBER_E_INVALID_ARG; }
+extern "C" int guber_eval_batch_store(guber_engine_t*, const guber_batch_t*, guber_result_t*, guber_store_events_t*) { return GUBER_E_INVALID_ARG; }

@@ -1,0 +1,165 @@
+// pool_test.cpp — TEST: gubernator::GPUWorkerPool's host logic on the CPU (engine_stub.cpp answers the engine's C ABI with
+// the oracle).  Checks that what the callers get back equals the oracle evaluating every key's requests in the caller's
+// order — across shard routing, partial reservations (RPCs larger than what a stage still takes), stage rotation, many
+// concurrent callers and shutdown under load.  Built plain and with -fsanitize=thread by tests/test_pool_cpu.py.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../gubernator_amd/csrc/worker_pool.h"
+#include "../../oracle/guber_oracle.h"
+
+using namespace gubernator;
+static const int64_t NOW0 = 1700000000000ll;
+static int failures = 0;
+#define CHECK(c, ...) do { if (!(c)) { if (++failures < 20) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+
+// the oracle on a list of requests, in order (keys = HashKey)
+struct Ref {
+    oracle_t* o = oracle_create(200000, 1);
+    ~Ref() { oracle_destroy(o); }
+    void eval(const std::vector<RateLimitReq>& reqs, int64_t now, std::vector<uint8_t>& status, std::vector<int64_t>& limit,
+              std::vector<int64_t>& remaining, std::vector<int64_t>& reset, std::vector<uint8_t>& err) {
+        const uint32_t n = (uint32_t)reqs.size();
+        std::vector<uint8_t> keys, algo(n), owner(n, 1); std::vector<uint32_t> off(n + 1), beh(n);
+        std::vector<int64_t> hits(n), lim(n), dur(n), burst(n), created(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            const std::string k = reqs[i].HashKey();
+            off[i] = (uint32_t)keys.size(); keys.insert(keys.end(), k.begin(), k.end());
+            hits[i] = reqs[i].hits; lim[i] = reqs[i].limit; dur[i] = reqs[i].duration; burst[i] = reqs[i].burst;
+            created[i] = reqs[i].created_at ? reqs[i].created_at : now;
+            algo[i] = (reqs[i].algorithm == 0 || reqs[i].algorithm == 1) ? (uint8_t)reqs[i].algorithm : 255; beh[i] = reqs[i].behavior;
+        }
+        off[n] = (uint32_t)keys.size(); keys.resize(keys.size() + 16, 0);
+        status.assign(n, 0); limit.assign(n, 0); remaining.assign(n, 0); reset.assign(n, 0); err.assign(n, 0);
+        guber_batch_t b{}; guber_result_t r{};
+        b.n = n; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = lim.data(); b.duration = dur.data();
+        b.burst = burst.data(); b.created_at = created.data(); b.algorithm = algo.data(); b.behavior = beh.data(); b.is_owner = owner.data();
+        b.now_ms = now;
+        r.status = status.data(); r.limit = limit.data(); r.remaining = remaining.data(); r.reset_time = reset.data(); r.err = err.data();
+        oracle_eval_batch(o, &b, &r);
+    }
+};
+
+static std::vector<RateLimitReq> random_rpc(std::mt19937& rng, const std::string& ns, int n_keys, int max_items) {
+    std::vector<RateLimitReq> reqs(1 + rng() % max_items);
+    const int hot = (int)(rng() % n_keys);
+    for (auto& r : reqs) {
+        const int k = (rng() % 3 == 0) ? hot : (int)(rng() % n_keys);
+        r.name = ns; r.unique_key = "k" + std::to_string(k);
+        r.algorithm = k % 2; r.hits = (int64_t)(rng() % 4 == 0 ? 0 : 1 + rng() % 3); r.limit = 20 + k % 5; r.duration = 5000;
+        r.burst = 0; r.behavior = (rng() % 40 == 0) ? 8u /* RESET_REMAINING */ : (rng() % 10 == 0 ? 32u /* DRAIN_OVER_LIMIT */ : 0u);
+    }
+    return reqs;
+}
+static void compare(const std::vector<RateLimitReq>& reqs, const std::vector<RateLimitResp>& got, Ref& ref, int64_t now, const char* what) {
+    std::vector<uint8_t> st, er; std::vector<int64_t> li, re, rs;
+    ref.eval(reqs, now, st, li, re, rs, er);
+    CHECK(got.size() == reqs.size(), "%s: %zu responses for %zu requests", what, got.size(), reqs.size());
+    for (size_t i = 0; i < reqs.size() && i < got.size(); ++i) {
+        if (er[i]) { CHECK(!got[i].error.empty(), "%s item %zu: oracle err %d, pool none", what, i, er[i]); continue; }
+        CHECK(got[i].error.empty(), "%s item %zu: unexpected error '%s'", what, i, got[i].error.c_str());
+        CHECK(got[i].status == st[i] && got[i].limit == li[i] && got[i].remaining == re[i] && got[i].reset_time == rs[i],
+              "%s item %zu key %s: got (%d,%lld,%lld,%lld) want (%d,%lld,%lld,%lld)", what, i, reqs[i].HashKey().c_str(), got[i].status,
+              (long long)got[i].limit, (long long)got[i].remaining, (long long)got[i].reset_time, st[i], (long long)li[i], (long long)re[i], (long long)rs[i]);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int scale = argc > 1 ? atoi(argv[1]) : 1;       // 1 = full, larger = shorter runs (sanitizer builds)
+    guber_config_t cfg{};
+    cfg.cache_size = 600000; cfg.max_batch = 64;
+    {   // 1. one caller, three shards, tiny stages: RPCs span several stages and generations, order per key is kept
+        GPUWorkerPool pool(cfg, 64, 100, 3);
+        V1Instance inst(&pool);
+        Ref ref;
+        std::mt19937 rng(7);
+        int64_t now = NOW0;
+        for (int it = 0; it < 400 / scale; ++it) {
+            pool.SetClockMs(now);
+            std::vector<RateLimitReq> reqs = random_rpc(rng, "one", 40, 200);
+            std::vector<RateLimitResp> resps; std::string err;
+            CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+            compare(reqs, resps, ref, now, "single caller");
+            now += rng() % 700;
+        }
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        CHECK(m.batches > 0 && m.batch_size_max <= 64 && m.shards == 3, "metrics: batches %llu max %llu shards %u", (unsigned long long)m.batches,
+              (unsigned long long)m.batch_size_max, m.shards);
+        printf("single caller: %llu batches, %llu requests, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests, failures);
+    }
+    {   // 2. many callers: each thread owns its keys (exact comparison with its own oracle) and all hammer one shared key
+        GPUWorkerPool pool(cfg, 512, 200, 4);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        const int T = 12, limit = 5000;
+        std::atomic<long> shared_under{0}, shared_total{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(100 + t);
+            const std::string ns = "th" + std::to_string(t);
+            for (int it = 0; it < 150 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 30, 300);
+                std::vector<RateLimitReq> mine = reqs;
+                const size_t extra = 1 + rng() % 20;
+                for (size_t q = 0; q < extra; ++q) { RateLimitReq s; s.name = "all"; s.unique_key = "shared"; s.hits = 1; s.limit = limit; s.duration = 3600000; reqs.push_back(s); }
+                std::vector<RateLimitResp> resps; std::string err;
+                CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+                std::vector<RateLimitResp> own(resps.begin(), resps.begin() + mine.size());
+                compare(mine, own, ref, NOW0, "concurrent callers");
+                for (size_t q = mine.size(); q < resps.size(); ++q) { shared_total++; if (resps[q].error.empty() && resps[q].status == 0) shared_under++; }
+            }
+        });
+        for (auto& x : th) x.join();
+        CHECK(shared_under.load() == std::min<long>(shared_total.load(), limit), "shared key: %ld of %ld under the limit %d", shared_under.load(), shared_total.load(), limit);
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        printf("concurrent callers: %llu batches, %llu requests (max batch %llu), shared key %ld/%ld under, failures so far %d\n",
+               (unsigned long long)m.batches, (unsigned long long)m.requests, (unsigned long long)m.batch_size_max, shared_under.load(), shared_total.load(), failures);
+    }
+    {   // 3. per-item errors that never reach (or come back from) the device
+        guber_config_t c2 = cfg; c2.max_key_bytes = 64;
+        GPUWorkerPool pool(c2, 64, 100, 2);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        std::vector<RateLimitReq> reqs(4);
+        for (auto& r : reqs) { r.name = "e"; r.unique_key = "x"; r.hits = 1; r.limit = 5; r.duration = 1000; }
+        reqs[1].unique_key = std::string(200, 'y'); reqs[2].algorithm = 7; reqs[3].unique_key = "";
+        std::vector<RateLimitResp> resps; std::string err;
+        CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed");
+        CHECK(resps[0].error.empty() && resps[0].remaining == 4, "plain item: '%s' %lld", resps[0].error.c_str(), (long long)resps[0].remaining);
+        CHECK(resps[1].error.find("key") != std::string::npos, "long key: '%s'", resps[1].error.c_str());
+        CHECK(resps[2].error.find("nvalid rate limit algorithm '7'") != std::string::npos, "algorithm: '%s'", resps[2].error.c_str());
+        CHECK(resps[3].error == "field 'unique_key' cannot be empty", "empty key: '%s'", resps[3].error.c_str());
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        CHECK(m.key_too_long == 1, "key_too_long %llu", (unsigned long long)m.key_too_long);
+    }
+    {   // 4. Close() under load: every call returns, with answers or with the pool's closed error
+        GPUWorkerPool pool(cfg, 256, 100, 3);
+        V1Instance inst(&pool);
+        std::atomic<bool> stop{false}; std::atomic<long> ok{0}, closed{0}, other{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 8; ++t) th.emplace_back([&, t] {
+            std::mt19937 rng(900 + t);
+            while (!stop.load()) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, "c" + std::to_string(t), 20, 120);
+                std::vector<RateLimitResp> resps; std::string err;
+                inst.GetRateLimits(reqs, &resps, &err);
+                for (auto& o : resps) { if (o.error.empty()) ok++; else if (o.error.find("worker pool is closed") != std::string::npos) closed++; else other++; }
+            }
+        });
+        std::this_thread::sleep_for(std::chrono::milliseconds(60));
+        pool.Close();
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        stop.store(true);
+        for (auto& x : th) x.join();
+        CHECK(ok.load() > 0 && closed.load() > 0 && other.load() == 0, "close under load: ok %ld closed %ld other %ld", ok.load(), closed.load(), other.load());
+        printf("close under load: %ld answered, %ld refused, failures so far %d\n", ok.load(), closed.load(), failures);
+    }
+    printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
+    return failures ? 1 : 0;
+}
