@@ -11,12 +11,16 @@
 //	Load(ctx) error / Store(ctx) error / Close() error                             gubernator.go:143,161,169
 //
 // Requests from any number of gRPC goroutines are routed to their key's device (the reference's replicated consistent
-// hash over the peers gpu0..gpuN-1) and shard (the reference's worker rule) and collected there by one batcher goroutine
-// (same policy as peer_client.go:284-337: flush at BatchLimit items or after BatchWait).  The batcher writes every request
-// IN PLACE into a stage — request / response arrays in device-visible host memory owned by the C side (cgo: no Go pointer
-// is retained) — and submits it; the kernels read and write the stage over PCIe, and while one stage is being evaluated
-// the batcher fills the other (guber_stage_*).  This file mirrors gubernator_amd/csrc/worker_pool.cpp, which IS compiled
-// and tested in this repository (tests/test_gpu_host_layer.py), statement by statement.
+// hash over the peers gpu0..gpuN-1) and shard (the reference's worker rule).  There the CALLING goroutine does the
+// per-request work itself: it reserves a slot (and its key bytes) in the shard's open stage with one compare-and-swap,
+// writes its request IN PLACE into the stage — request / response arrays in device-visible host memory owned by the C side
+// (cgo: no Go pointer is retained) — and, once the stage's generation has been announced, reads its response out of the
+// stage's result arrays.  The shard's batcher goroutine never touches a request: it seals the open stage at BatchLimit
+// items or BatchWait after the first one (the policy of peer_client.go:284-337), submits it, opens the next of its three
+// stages (one filling, one on the GPU, one being read out) and announces completed generations by closing a channel.
+// This file mirrors gubernator_amd/csrc/worker_pool.cpp, which IS compiled and tested in this repository
+// (tests/test_gpu_host_layer.py on the GPU, tests/test_pool_cpu.py under ThreadSanitizer), function by function:
+// reserve / writeRequest / consume / run / openStage / submit / complete.
 
 //go:build gpu
 
@@ -35,22 +39,14 @@ import (
 	"context"
 	"fmt"
 	"runtime"
+	"sync"
+	"sync/atomic"
 	"time"
 	"unsafe"
 
 	"github.com/mailgun/holster/v4/clock"
 	"github.com/pkg/errors"
 )
-
-type gpuRequest struct {
-	req   *RateLimitReq
-	state RateLimitReqState
-	resp  chan gpuResponse
-}
-type gpuResponse struct {
-	rl  *RateLimitResp
-	err error
-}
 
 // GPUWorkerPool satisfies the call surface of *WorkerPool.  devices[i] is the HIP ordinal of peer "gpu<i>"; inside a
 // device the key space is split over conf.Workers shards by hash range like WorkerPool (workers.go:125-151,180-184).  A
@@ -66,29 +62,51 @@ type GPUWorkerPool struct {
 	shards       []*gpuShard
 }
 
+const (
+	gpuStages      = 3       // filling / on the GPU / being read out
+	gpuStageClosed = 1 << 63 // gpuStage.word: not accepting reservations
+	gpuOpenNone    = gpuStages
+	gpuOpenDead    = gpuStages + 1
+)
+
+// gpuStage = one of a shard's stages and the generation it currently carries (worker_pool.h Stage).
+type gpuStage struct {
+	stage    *C.guber_stage_t
+	b        *C.guber_batch_t
+	r        *C.guber_result_t
+	reqs     []*RateLimitReq // per slot, written by the slot's owner (Config.Store callbacks need the request)
+	word     atomic.Uint64   // gpuStageClosed | key bytes reserved << 32 | slots reserved
+	written  atomic.Uint32   // slots filled by their callers
+	consumed atomic.Uint32   // responses picked up
+	firstNs  atomic.Int64    // when the generation's first reservation was made (BatchWait)
+	flushNow atomic.Bool     // a caller found no room: do not wait for BatchWait
+	done     chan struct{}   // closed when the generation's responses are ready
+	n        int             // sealed size (batcher; callers read it after <-done)
+	rc       C.int
+	sent     bool      // guber_stage_submit succeeded, guber_stage_wait is due
+	t0       time.Time // flush start
+	used     bool
+}
+
 // gpuShard = one "worker" of the reference: single writer of its own cache.
 type gpuShard struct {
 	conf   *Config
 	engine *C.guber_engine_t
-	stage  [2]*C.guber_stage_t
-	queue  chan gpuRequest
-	done   chan struct{}
+	st     [gpuStages]gpuStage
+	open   atomic.Uint32 // index of the stage accepting reservations, gpuOpenNone, or gpuOpenDead after Close
+	mu     sync.Mutex
+	opened *sync.Cond    // callers in reserve(): a stage opened
+	wake   chan struct{} // batcher: first item / full / flush requested
+	quit   chan struct{}
+	exited chan struct{}
+	label  string // metrics label of the shard's device (the reference labels these series by peer address)
 	limit  int
+	wait   time.Duration
 	maxKey int // guber_config_t.max_key_bytes: longer keys are answered per item, never copied
 	keyCap int // bytes of a stage's key buffer: a batch whose keys would not fit is flushed early
 	// Config.Store side channel (only allocated when conf.Store != nil; that path is synchronous)
 	missing, storeFlags *C.uint8_t
 	storeItems          *C.guber_item_t
-}
-
-// one batch being filled / in flight: the stage's arrays, the callers waiting for it
-type gpuFlight struct {
-	stage   *C.guber_stage_t
-	b       *C.guber_batch_t
-	r       *C.guber_result_t
-	waiting []gpuRequest
-	tooLong []bool
-	n, off  int
 }
 
 func NewGPUWorkerPool(conf *Config, devices []int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
@@ -251,39 +269,109 @@ func newGPUShard(conf *Config, device int, cacheSize int, batchLimit int, batchW
 	const maxKey = 1024 // guber_config_t.max_key_bytes default
 	cfg := C.guber_config_t{struct_size: C.uint32_t(unsafe.Sizeof(C.guber_config_t{})), device: C.int32_t(device),
 		cache_size: C.uint64_t(cacheSize), max_batch: C.uint32_t(batchLimit), max_key_bytes: maxKey, flags: C.GUBER_FLAG_GLOBAL}
-	p := &gpuShard{conf: conf, queue: make(chan gpuRequest, batchLimit), done: make(chan struct{}), limit: batchLimit, maxKey: maxKey}
+	p := &gpuShard{conf: conf, wake: make(chan struct{}, 1), quit: make(chan struct{}), exited: make(chan struct{}),
+		label: fmt.Sprintf("gpu%d", device), limit: batchLimit, wait: batchWait, maxKey: maxKey}
+	p.opened = sync.NewCond(&p.mu)
+	p.open.Store(gpuOpenNone)
 	if rc := C.guber_engine_create(&cfg, &p.engine); rc != C.GUBER_OK {
 		return nil, fmt.Errorf("guber_engine_create: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
 	}
 	p.keyCap = batchLimit*96 + maxKey // typical keys; a batch of longer ones is flushed early, never overrun
-	for k := range p.stage {
-		if rc := C.guber_stage_create(p.engine, C.uint32_t(batchLimit), C.uint32_t(p.keyCap), &p.stage[k]); rc != C.GUBER_OK {
+	for k := range p.st {
+		s := &p.st[k]
+		s.word.Store(gpuStageClosed)
+		if rc := C.guber_stage_create(p.engine, C.uint32_t(batchLimit), C.uint32_t(p.keyCap), &s.stage); rc != C.GUBER_OK {
 			return nil, fmt.Errorf("guber_stage_create: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
 		}
+		s.b, s.r = C.guber_stage_batch(s.stage), C.guber_stage_result(s.stage)
+		s.reqs = make([]*RateLimitReq, batchLimit)
 	}
 	if conf.Store != nil {
 		n := C.size_t(batchLimit)
 		p.missing, p.storeFlags = (*C.uint8_t)(C.guber_alloc_pinned(n)), (*C.uint8_t)(C.guber_alloc_pinned(n))
 		p.storeItems = (*C.guber_item_t)(C.guber_alloc_pinned(n * C.sizeof_guber_item_t))
 	}
-	go p.run(batchWait)
+	go p.run()
 	return p, nil
 }
 
-// GetRateLimit enqueues the request and waits for its batch (workers.go:261-291 semantics: ctx honoured
-// at both waits).
-func (p *gpuShard) GetRateLimit(ctx context.Context, r *RateLimitReq, s RateLimitReqState) (*RateLimitResp, error) {
-	g := gpuRequest{req: r, state: s, resp: make(chan gpuResponse, 1)}
+// GetRateLimit = reserve a slot, write the request, wait for the generation, read the response (worker_pool.cpp
+// GetRateLimitMany for one request; workers.go:261-291 semantics: ctx honoured at both waits).
+func (p *gpuShard) GetRateLimit(ctx context.Context, r *RateLimitReq, st RateLimitReqState) (*RateLimitResp, error) {
+	klen := len(r.Name) + 1 + len(r.UniqueKey)
+	if klen > p.maxKey { // answered here, never reaches the device
+		return nil, errors.New(C.GoString(C.guber_item_strerror(C.GUBER_ITEM_E_KEY_TOO_LONG)))
+	}
+	s, slot, koff, err := p.reserve(ctx, klen)
+	if err != nil {
+		return nil, err
+	}
+	p.writeRequest(s, slot, koff, r, st)
+	done := s.done
 	select {
-	case p.queue <- g:
+	case <-done:
 	case <-ctx.Done():
+		go func() { <-done; s.consumed.Add(1) }() // the slot still counts towards the stage being read out
 		return nil, ctx.Err()
 	}
+	resp, err := p.answer(r, s.rc, *at8(s.r.err, slot), *at8(s.r.status, slot), *at64(s.r.limit, slot), *at64(s.r.remaining, slot), *at64(s.r.reset_time, slot))
+	s.consumed.Add(1)
+	return resp, err
+}
+
+// reserve takes one slot and klen key bytes of the open stage: ONE compare-and-swap on its reservation word.
+func (p *gpuShard) reserve(ctx context.Context, klen int) (*gpuStage, int, int, error) {
+	for {
+		k := p.open.Load()
+		if k == gpuOpenDead {
+			return nil, 0, 0, errors.New("worker pool is closed")
+		}
+		if k < gpuStages {
+			s := &p.st[k]
+			for w := s.word.Load(); w&gpuStageClosed == 0; w = s.word.Load() {
+				cnt, kb := int(uint32(w)), int(w>>32)
+				if cnt >= p.limit || kb+klen > p.keyCap { // no slot or no key bytes left: flush it now, take the next stage
+					if s.flushNow.CompareAndSwap(false, true) {
+						p.kick()
+					}
+					break
+				}
+				if s.word.CompareAndSwap(w, w+1+uint64(klen)<<32) {
+					if cnt == 0 {
+						s.firstNs.Store(time.Now().UnixNano())
+					}
+					if cnt == 0 || cnt+1 >= p.limit {
+						p.kick()
+					}
+					return s, cnt, kb, nil
+				}
+			}
+		}
+		if err := ctx.Err(); err != nil {
+			return nil, 0, 0, err
+		}
+		p.mu.Lock() // wait for the batcher to open the next stage (it broadcasts under mu)
+		if p.open.Load() == k {
+			p.opened.Wait()
+		}
+		p.mu.Unlock()
+	}
+}
+
+// orWord = fetch-or (sync/atomic has no Or for Uint64 before Go 1.23)
+func orWord(w *atomic.Uint64, bits uint64) uint64 {
+	for {
+		old := w.Load()
+		if w.CompareAndSwap(old, old|bits) {
+			return old
+		}
+	}
+}
+
+func (p *gpuShard) kick() {
 	select {
-	case out := <-g.resp:
-		return out.rl, out.err
-	case <-ctx.Done():
-		return nil, ctx.Err()
+	case p.wake <- struct{}{}:
+	default:
 	}
 }
 
@@ -291,161 +379,185 @@ func at64(p *C.int64_t, i int) *C.int64_t { return (*C.int64_t)(unsafe.Add(unsaf
 func at32(p *C.uint32_t, i int) *C.uint32_t { return (*C.uint32_t)(unsafe.Add(unsafe.Pointer(p), i*4)) }
 func at8(p *C.uint8_t, i int) *C.uint8_t   { return (*C.uint8_t)(unsafe.Add(unsafe.Pointer(p), i)) }
 
-func stopTimer(t *time.Timer) { // Stop + drain: a stale tick must not flush the next batch's first request alone
-	if !t.Stop() {
-		select {
-		case <-t.C:
-		default:
-		}
-	}
-}
-
-// run is the shard's batcher (worker_pool.cpp GPUWorkerPool::run): requests are written into the current stage as they
-// arrive; the stage is submitted at `limit` requests, when the next key would not fit its key buffer, or `wait` after its
-// first request; while it is evaluated the other stage fills.
-func (p *gpuShard) run(wait time.Duration) {
-	runtime.LockOSThread() // one OS thread owns the HIP context
-	var fl [2]gpuFlight
-	for k := range fl {
-		fl[k] = gpuFlight{stage: p.stage[k], b: C.guber_stage_batch(p.stage[k]), r: C.guber_stage_result(p.stage[k]),
-			waiting: make([]gpuRequest, 0, p.limit), tooLong: make([]bool, 0, p.limit)}
-	}
-	cur, inflight := 0, false
-	timer := time.NewTimer(wait)
-	stopTimer(timer)
-	submit := func() {
-		stopTimer(timer)
-		f := &fl[cur]
-		if p.conf.Store != nil {
-			p.flushWithStore(f) // synchronous: Store.Get / OnChange / Remove are made in request order
-		} else {
-			*at32(f.b.key_off, f.n) = C.uint32_t(f.off)
-			f.b.n, f.b.now_ms = C.uint32_t(f.n), C.int64_t(clock.Now().UnixNano()/1000000) // MillisecondNow(); DURATION_IS_GREGORIAN is derived from it on the device
-			rc := C.guber_stage_submit(f.stage)
-			if inflight {
-				p.complete(&fl[cur^1], C.GUBER_OK)
-			}
-			if rc != C.GUBER_OK {
-				p.complete(f, rc)
-				inflight = false
-			} else {
-				inflight = true
-				cur ^= 1
-			}
-			return
-		}
-		if inflight {
-			p.complete(&fl[cur^1], C.GUBER_OK)
-			inflight = false
-		}
-	}
-	for {
-		if inflight && len(p.queue) == 0 && fl[cur].n == 0 { // nothing to overlap with: deliver the batch in flight
-			p.complete(&fl[cur^1], C.GUBER_OK)
-			inflight = false
-		}
-		select {
-		case g := <-p.queue:
-			f := &fl[cur]
-			klen := len(g.req.Name) + 1 + len(g.req.UniqueKey)
-			if klen <= p.maxKey && f.off+klen > p.keyCap { // the key would overrun the stage: flush what is there first
-				submit()
-				f = &fl[cur]
-			}
-			p.put(f, g, klen)
-			if f.n == 1 {
-				timer.Reset(wait)
-			}
-			if f.n >= p.limit {
-				submit()
-			}
-		case <-timer.C:
-			if fl[cur].n > 0 {
-				submit()
-			}
-		case <-p.done:
-			if inflight {
-				p.complete(&fl[cur^1], C.GUBER_OK)
-			}
-			return
-		}
-	}
-}
-
-// put writes one request into the stage in place (HashKey = name + "_" + unique_key, client.go:39-41).
-func (p *gpuShard) put(f *gpuFlight, g gpuRequest, klen int) {
-	r, i := g.req, f.n
-	*at32(f.b.key_off, i) = C.uint32_t(f.off)
-	long := klen > p.maxKey
-	if !long {
-		dst := unsafe.Add(unsafe.Pointer(f.b.key_bytes), f.off)
-		C.memcpy(dst, unsafe.Pointer(unsafe.StringData(r.Name)), C.size_t(len(r.Name)))
-		*(*byte)(unsafe.Add(dst, len(r.Name))) = '_'
-		C.memcpy(unsafe.Add(dst, len(r.Name)+1), unsafe.Pointer(unsafe.StringData(r.UniqueKey)), C.size_t(len(r.UniqueKey)))
-		f.off += klen
-	} // else: an empty key in the batch; the caller is answered GUBER_ITEM_E_KEY_TOO_LONG without the device seeing it
-	*at64(f.b.hits, i), *at64(f.b.limit, i), *at64(f.b.duration, i) = C.int64_t(r.Hits), C.int64_t(r.Limit), C.int64_t(r.Duration)
-	*at64(f.b.burst, i), *at64(f.b.created_at, i) = C.int64_t(r.Burst), C.int64_t(*r.CreatedAt)
+// writeRequest writes one request into its slot in place (HashKey = name + "_" + unique_key, client.go:39-41).
+func (p *gpuShard) writeRequest(s *gpuStage, i, koff int, r *RateLimitReq, st RateLimitReqState) {
+	b := s.b
+	*at32(b.key_off, i) = C.uint32_t(koff)
+	dst := unsafe.Add(unsafe.Pointer(b.key_bytes), koff)
+	C.memcpy(dst, unsafe.Pointer(unsafe.StringData(r.Name)), C.size_t(len(r.Name)))
+	*(*byte)(unsafe.Add(dst, len(r.Name))) = '_'
+	C.memcpy(unsafe.Add(dst, len(r.Name)+1), unsafe.Pointer(unsafe.StringData(r.UniqueKey)), C.size_t(len(r.UniqueKey)))
+	*at64(b.hits, i), *at64(b.limit, i), *at64(b.duration, i) = C.int64_t(r.Hits), C.int64_t(r.Limit), C.int64_t(r.Duration)
+	*at64(b.burst, i), *at64(b.created_at, i) = C.int64_t(r.Burst), C.int64_t(*r.CreatedAt)
 	alg := r.Algorithm
 	if alg < 0 || alg > 1 {
 		alg = 255 // workers.go:317: the engine answers GUBER_ITEM_E_INVALID_ALGORITHM
 	}
-	*at8(f.b.algorithm, i) = C.uint8_t(alg)
-	*at32(f.b.behavior, i) = C.uint32_t(r.Behavior)
+	*at8(b.algorithm, i) = C.uint8_t(alg)
+	*at32(b.behavior, i) = C.uint32_t(r.Behavior)
 	owner := C.uint8_t(0)
-	if g.state.IsOwner {
+	if st.IsOwner {
 		owner = 1
 	}
-	*at8(f.b.is_owner, i) = owner
-	f.waiting, f.tooLong = append(f.waiting, g), append(f.tooLong, long)
-	f.n++
+	*at8(b.is_owner, i) = owner
+	s.reqs[i] = r
+	s.written.Add(1)
 }
 
-// complete waits for the stage (unless rc already carries a submit error) and answers its callers.
-func (p *gpuShard) complete(f *gpuFlight, rc C.int) {
-	if rc == C.GUBER_OK {
-		rc = C.guber_stage_wait(f.stage)
+// openStage lets callers reserve in stage k (worker_pool.cpp open_stage).
+func (p *gpuShard) openStage(k int) {
+	s := &p.st[k]
+	s.n, s.rc, s.sent, s.used = 0, C.GUBER_OK, false, true
+	s.written.Store(0)
+	s.consumed.Store(0)
+	s.firstNs.Store(0)
+	s.flushNow.Store(false)
+	s.done = make(chan struct{})
+	s.word.Store(0)
+	p.open.Store(uint32(k))
+	p.mu.Lock()
+	p.opened.Broadcast()
+	p.mu.Unlock()
+}
+
+// run is the shard's batcher (worker_pool.cpp GPUWorkerPool::run): it seals the open stage at `limit` requests, when a
+// caller found no room in it, or `wait` after its first reservation, submits it and opens the next one; with nothing due
+// it delivers the batch in flight.
+func (p *gpuShard) run() {
+	runtime.LockOSThread() // one OS thread owns the HIP context
+	defer close(p.exited)
+	cur, inflight := 0, -1
+	p.openStage(cur)
+	timer := time.NewTimer(time.Hour)
+	for {
+		s := &p.st[cur]
+		due, closing := false, false
+		for !due {
+			select {
+			case <-p.quit:
+				closing = true
+			default:
+			}
+			cnt := int(uint32(s.word.Load()))
+			if cnt >= p.limit || (cnt > 0 && (closing || s.flushNow.Load())) {
+				due = true
+				break
+			}
+			left := time.Hour
+			if cnt > 0 {
+				if first := s.firstNs.Load(); first != 0 {
+					left = p.wait - time.Duration(time.Now().UnixNano()-first)
+				} else {
+					left = p.wait
+				}
+				if left <= 0 {
+					due = true
+					break
+				}
+			}
+			if inflight >= 0 || closing {
+				break // nothing due: deliver the batch in flight / finish
+			}
+			if !timer.Stop() {
+				select {
+				case <-timer.C:
+				default:
+				}
+			}
+			timer.Reset(left)
+			select {
+			case <-p.wake:
+			case <-timer.C:
+			case <-p.quit:
+			}
+		}
+		if !due {
+			if inflight >= 0 {
+				p.complete(&p.st[inflight])
+				inflight = -1
+				continue
+			}
+			// closing, nothing reserved, nothing in flight: stop taking reservations; a caller may have slipped one in meanwhile
+			p.open.Store(gpuOpenDead)
+			w := orWord(&s.word, gpuStageClosed)
+			if n := int(uint32(w)); n > 0 {
+				p.seal(s, w)
+				p.submit(s)
+				p.complete(s)
+			}
+			p.mu.Lock()
+			p.opened.Broadcast()
+			p.mu.Unlock()
+			return
+		}
+		// the next stage takes the reservations from here on; it was announced two flushes ago and has been read out since
+		next := (cur + 1) % gpuStages
+		nx := &p.st[next]
+		for nx.used && int(nx.consumed.Load()) != nx.n {
+			runtime.Gosched()
+		}
+		p.openStage(next)
+		p.seal(s, orWord(&s.word, gpuStageClosed))
+		p.submit(s)
+		if inflight >= 0 {
+			p.complete(&p.st[inflight])
+		}
+		inflight, cur = cur, next
 	}
-	res := f.r
-	if rc == C.GUBER_OK { // prometheus: the engine returns the per-batch aggregates of the reference's counters
+}
+
+// seal fixes the stage's size and waits for the callers that are still copying their requests in.
+func (p *gpuShard) seal(s *gpuStage, w uint64) {
+	s.n = int(uint32(w))
+	for int(s.written.Load()) != s.n {
+		runtime.Gosched()
+	}
+	*at32(s.b.key_off, s.n) = C.uint32_t(w >> 32)
+}
+
+// submit hands a sealed stage to the engine (asynchronous); with a persistent Store configured the batch takes the
+// synchronous path that makes the Store's calls.
+func (p *gpuShard) submit(s *gpuStage) {
+	s.t0 = time.Now()
+	s.b.n, s.b.now_ms = C.uint32_t(s.n), C.int64_t(clock.Now().UnixNano()/1000000) // MillisecondNow(); DURATION_IS_GREGORIAN is derived from it on the device
+	metricBatchQueueLength.WithLabelValues(p.label).Set(float64(s.n)) // gubernator.go:100-103
+	if p.conf.Store != nil {
+		s.rc = p.evalWithStore(s.reqs[:s.n], s.b, s.r) // synchronous: Store.Get / OnChange / Remove are made in request order
+		return
+	}
+	s.rc = C.guber_stage_submit(s.stage)
+	s.sent = s.rc == C.GUBER_OK
+}
+
+// complete waits for a submitted stage and announces its generation: the callers read their responses themselves.
+func (p *gpuShard) complete(s *gpuStage) {
+	if s.sent {
+		s.rc, s.sent = C.guber_stage_wait(s.stage), false
+	}
+	if s.rc == C.GUBER_OK { // prometheus: the engine returns the per-batch aggregates of the reference's counters
+		res := s.r
 		metricOverLimitCounter.Add(float64(res.over_limit_count))             // algorithms.go:165,185,243,391,409,471
 		metricCacheAccess.WithLabelValues("hit").Add(float64(res.cache_hits)) // lrucache.go:117,121,126
 		metricCacheAccess.WithLabelValues("miss").Add(float64(res.cache_misses))
 		metricCacheSize.Set(float64(res.cache_size))
 		metricCacheUnexpiredEvictions.Add(float64(res.unexpired_evictions)) // lrucache.go:142-146
 	}
-	for i, g := range f.waiting {
-		g.resp <- p.answer(g, rc, f.tooLong[i], *at8(res.err, i), *at8(res.status, i), *at64(res.limit, i), *at64(res.remaining, i), *at64(res.reset_time, i))
-	}
-	f.waiting, f.tooLong, f.n, f.off = f.waiting[:0], f.tooLong[:0], 0, 0
+	metricBatchSendDuration.WithLabelValues(p.label).Observe(time.Since(s.t0).Seconds()) // gubernator.go:104-110
+	close(s.done)
 }
 
-func (p *gpuShard) answer(g gpuRequest, rc C.int, tooLong bool, e, status C.uint8_t, limit, remaining, reset C.int64_t) gpuResponse {
+func (p *gpuShard) answer(r *RateLimitReq, rc C.int, e, status C.uint8_t, limit, remaining, reset C.int64_t) (*RateLimitResp, error) {
 	if rc != C.GUBER_OK {
-		return gpuResponse{nil, errors.Errorf("gpu engine: %s", C.GoString(C.guber_strerror(rc)))}
-	}
-	if tooLong {
-		e = C.GUBER_ITEM_E_KEY_TOO_LONG
+		return nil, errors.Errorf("gpu engine: %s", C.GoString(C.guber_strerror(rc)))
 	}
 	if e != 0 {
 		msg := C.GoString(C.guber_item_strerror(e))
 		if e == C.GUBER_ITEM_E_INVALID_ALGORITHM {
-			msg = fmt.Sprintf(msg, g.req.Algorithm) // "Invalid rate limit algorithm '%d'"
+			msg = fmt.Sprintf(msg, r.Algorithm) // "Invalid rate limit algorithm '%d'"
 		}
-		return gpuResponse{nil, errors.New(msg)}
+		return nil, errors.New(msg)
 	}
-	return gpuResponse{&RateLimitResp{Status: Status(status), Limit: int64(limit), Remaining: int64(remaining), ResetTime: int64(reset)}, nil}
-}
-
-// flushWithStore evaluates the stage's batch through the synchronous host entry points that report the Store calls.
-func (p *gpuShard) flushWithStore(f *gpuFlight) {
-	*at32(f.b.key_off, f.n) = C.uint32_t(f.off)
-	f.b.n, f.b.now_ms = C.uint32_t(f.n), C.int64_t(clock.Now().UnixNano()/1000000)
-	rc := p.evalWithStore(f.waiting, f.b, f.r)
-	for i, g := range f.waiting {
-		g.resp <- p.answer(g, rc, f.tooLong[i], *at8(f.r.err, i), *at8(f.r.status, i), *at64(f.r.limit, i), *at64(f.r.remaining, i), *at64(f.r.reset_time, i))
-	}
-	f.waiting, f.tooLong, f.n, f.off = f.waiting[:0], f.tooLong[:0], 0, 0
+	return &RateLimitResp{Status: Status(status), Limit: int64(limit), Remaining: int64(remaining), ResetTime: int64(reset)}, nil
 }
 
 // evalWithStore is the Config.Store path (store.go:49-65).  The reference calls the store from inside the
@@ -453,22 +565,22 @@ func (p *gpuShard) flushWithStore(f *gpuFlight) {
 //   Store.Get      for the first request of every key that is not resident before the batch (algorithms.go:45-51)
 //   Store.Remove   token RESET_REMAINING / algorithm switched                                 (:79-84, :96-100, :311-315)
 //   Store.OnChange with the CacheItem as it is right after THAT request, owner only           (:149-153, :252-254, ...)
-func (p *gpuShard) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, res *C.guber_result_t) C.int {
+func (p *gpuShard) evalWithStore(batch []*RateLimitReq, b *C.guber_batch_t, res *C.guber_result_t) C.int {
 	ctx := context.Background()
 	if rc := C.guber_probe_missing(p.engine, b, p.missing); rc != C.GUBER_OK {
 		return rc
 	}
 	asked := map[string]struct{}{}
-	for i, g := range batch {
+	for i, req := range batch {
 		if *at8(p.missing, i) == 0 {
 			continue
 		}
-		key := g.req.HashKey()
+		key := req.HashKey()
 		if _, dup := asked[key]; dup {
 			continue
 		}
 		asked[key] = struct{}{}
-		if item, ok := p.conf.Store.Get(ctx, g.req); ok {
+		if item, ok := p.conf.Store.Get(ctx, req); ok {
 			if err := p.AddCacheItem(ctx, key, item); err != nil {
 				return C.GUBER_E_HIP
 			}
@@ -479,14 +591,14 @@ func (p *gpuShard) evalWithStore(batch []gpuRequest, b *C.guber_batch_t, res *C.
 	if rc != C.GUBER_OK {
 		return rc
 	}
-	for i, g := range batch {
+	for i, req := range batch {
 		f := *at8(p.storeFlags, i)
 		if f&C.GUBER_STORE_REMOVE != 0 {
-			p.conf.Store.Remove(ctx, g.req.HashKey())
+			p.conf.Store.Remove(ctx, req.HashKey())
 		}
 		if f&C.GUBER_STORE_ONCHANGE != 0 {
 			ci := (*C.guber_item_t)(unsafe.Add(unsafe.Pointer(p.storeItems), i*C.sizeof_guber_item_t))
-			p.conf.Store.OnChange(ctx, g.req, fromCItem(g.req.HashKey(), ci))
+			p.conf.Store.OnChange(ctx, req, fromCItem(req.HashKey(), ci))
 		}
 	}
 	return C.GUBER_OK
@@ -548,10 +660,17 @@ func (p *gpuShard) dump(out chan<- *CacheItem) error {
 	return nil
 }
 
+// Close (workers.go:157): the batcher evaluates and announces what has been reserved, later callers are refused, and the
+// stages go away once their responses have been read out.
 func (p *gpuShard) Close() error {
-	close(p.done)
-	for k := range p.stage {
-		C.guber_stage_destroy(p.stage[k])
+	close(p.quit)
+	<-p.exited
+	for k := range p.st {
+		s := &p.st[k]
+		for s.used && int(s.consumed.Load()) != s.n {
+			runtime.Gosched()
+		}
+		C.guber_stage_destroy(s.stage)
 	}
 	C.guber_engine_destroy(p.engine)
 	return nil
