@@ -16,7 +16,7 @@ Timing: the batches of the timed region are enqueued by S pre-started batcher th
 barrier; no thread is created and nothing is allocated inside the timed region); the region is repeated until it lasts
 at least --min-ms, whatever --steps says.  Extras in the same JSON line: `leaky` (configs[2], parity-gated), `shards_1`
 (one table, the literal single-stream configuration), `uniform` (no duplicate keys), `end_to_end` (host pointers in,
-host results out, PCIe included).
+host results out, PCIe included), `pool` (caller threads -> V1Instance::GetRateLimits -> the C++ GPUWorkerPool).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by the reference's
 replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1), every rank evaluates the requests
@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--algo", choices=["token", "leaky"], default="token")
     ap.add_argument("--dist", choices=["zipf", "uniform"], default="zipf")
     ap.add_argument("--min-ms", type=float, default=250.0, help="minimum duration of the timed region: the timed steps are repeated until it is reached")
-    ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end",
+    ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end,pool",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="threads",
                     help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
@@ -594,6 +594,8 @@ def run_extra(name, args, ctx, NOW0, seed):
     min_ms = min(args.min_ms, 150.0)
     if name == "end_to_end":
         return run_end_to_end(args, ctx, NOW0, seed)
+    if name == "pool":
+        return run_pool(args)
     algo, dist_kind, S = {"leaky": ("leaky", "zipf", max(1, args.shards)), "shards_1": (args.algo, args.dist, 1),
                           "uniform": (args.algo, "uniform", max(1, args.shards))}[name]
     rig = Rig(ctx, algo, dist_kind, S)
@@ -616,6 +618,25 @@ def run_extra(name, args, ctx, NOW0, seed):
             out.pop("value")
     rig.close()
     return out
+
+
+def run_pool(args):
+    """the drop-in surface: caller threads -> V1Instance::GetRateLimits -> GPUWorkerPool (C++), tools/bench_pool.cpp"""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "bench_pool_c")
+    if not os.path.exists(exe):
+        return {"error": "tools/bench_pool_c is not built (make -C gubernator_amd/csrc bench_pool)"}
+    T, S, items, keys = 64, max(1, args.shards), 1000, 1_000_000
+    p = subprocess.run([exe, str(T), str(S), str(items), str(keys), "1.5"], capture_output=True, text=True, timeout=120)
+    m = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)", p.stdout)
+    if not m:
+        return {"error": (p.stdout + p.stderr)[-400:]}
+    return {"value": float(m.group(1)) * 1e6, "unit": "decisions/s", "batches_per_s": float(m.group(2)), "avg_batch": float(m.group(3)),
+            "errors": int(m.group(4)),
+            "workload": f"{T} caller threads x RPCs of {items} requests through V1Instance::GetRateLimits -> GPUWorkerPool ({S} shards, batch limit 65536, "
+                        f"batch wait 200 us), {keys} keys Zipf-1.1, closed loop: validation, HashKey, shard routing, slot reservation, in-place stage "
+                        "filling, submit / wait and response fan-out included (what the Go shim does per request)"}
 
 
 def run_end_to_end(args, ctx, NOW0, seed):
