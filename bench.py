@@ -6,17 +6,20 @@ k_eval2) with every input array already resident in HBM.  Workload (BASELINE.jso
 10M resident keys per GPU, ONE Zipf(1.1) request stream over those keys (stream seed 1234, permutation seed 99),
 TOKEN_BUCKET, hits 1, limit 100, duration 60 s, now_ms advancing 1 ms per batch.
 
-Inside a GPU the resident keys are split into S logical shards (default 4; the reference shards its key space the same
-way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables and HIP streams.  The request
+Inside a GPU the resident keys are split into S logical shards (default 12; the reference shards its key space the same
+way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables.  The request
 stream is routed request by request to the shard that owns the key (consistent hash, k_route) and every shard flushes a
 batch when 65536 requests are waiting — the policy of the reference's batcher (peer_client.go:284-337) — so batches are
 exactly 65536 requests, hot shards flush more often, and per-key request order is the stream's order.
 
-Timing: the batches of the timed region are enqueued by S pre-started batcher threads (one per shard, released by a
-barrier; no thread is created and nothing is allocated inside the timed region); the region is repeated until it lasts
-at least --min-ms, whatever --steps says.  Extras in the same JSON line: `leaky` (configs[2], parity-gated), `shards_1`
-(one table, the literal single-stream configuration), `uniform` (no duplicate keys), `end_to_end` (host pointers in,
-host results out, PCIe included), `pool` (caller threads -> V1Instance::GetRateLimits -> the C++ GPUWorkerPool).
+Timing: the batches of the timed region are enqueued by ONE dispatcher (guber_eval_batches_routed_dev: round by round the
+next batch of every shard; shards that share a stream — 12 shards over 3 streams by default — share their two launches,
+k_front_multi / k_eval2_multi), or with --dispatch threads by S pre-started batcher threads, one per shard and stream
+(released by a barrier; no thread is created and nothing is allocated inside the timed region).  The region is repeated
+until it lasts at least --min-ms, whatever --steps says.  Extras in the same JSON line: `leaky` (configs[2],
+parity-gated), `shards_1` (one table, the literal single-stream configuration), `uniform` (no duplicate keys),
+`end_to_end` (host pointers in, host results out, PCIe included), `pool` (caller threads -> V1Instance::GetRateLimits ->
+the C++ GPUWorkerPool).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by the reference's
 replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1), every rank evaluates the requests
@@ -44,8 +47,8 @@ BYTES_PER_DECISION = {"token": 149, "leaky": 173}
 # split of the algorithmic bytes over the kernels that touch request / table / response data (DESIGN.md
 # "Algorithmic bytes"): k_front reads key_off 4 + key 16 + table 56 (token) / 64 (leaky); k_eval2 reads
 # the request fields 32 / 40, writes table 16 / 24 and the response 25.
-KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_resolve": 28, "k_eval": 121},
-                "leaky": {"k_front": 84, "k_eval2": 89, "k_resolve": 28, "k_eval": 145}}
+KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73, "k_resolve": 28, "k_eval": 121},
+                "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89, "k_resolve": 28, "k_eval": 145}}
 
 
 def parse():
@@ -60,16 +63,17 @@ def parse():
     ap.add_argument("--min-ms", type=float, default=250.0, help="minimum duration of the timed region: the timed steps are repeated until it is reached")
     ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end,pool",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
-    ap.add_argument("--dispatch", choices=["threads", "one"], default="threads",
+    ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
                     help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
                          "(guber_eval_batches_routed_dev)")
+    ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
     ap.add_argument("--cpu-threads", default="1,32,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
     ap.add_argument("--profile-steps", type=int, default=32)
-    ap.add_argument("--shards", type=int, default=4, metavar="S",
+    ap.add_argument("--shards", type=int, default=12, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
-                         "engines with their own tables and streams, the stream routed to them key by key")
+                         "engines with their own tables, the stream routed to them key by key")
     ap.add_argument("--global-host", action="store_true", help="with --global-sync: use the host-staged exchange (global_sync.py)")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
                     help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
@@ -146,8 +150,9 @@ class Rig:
         self.torch, self.ga, self.streams = torch, ga, streams
         dev, K, B = ctx.dev, ctx.K, ctx.B
         self.sstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-        if self.dispatch == "one":             # one dispatcher: the shards share a stream, their batches share launches
-            self.sstreams = [self.sstreams[0]] * S
+        if self.dispatch == "one":             # one dispatcher: shards that share a stream share launches
+            ns = max(1, min(S, int(getattr(ctx, "streams", 1))))
+            self.sstreams = [self.sstreams[j * ns // S] for j in range(S)]
         nk = len(ctx.my_ids)
         self.engines = [ga.Engine(cache_size=(nk + nk // 4) // S + 1024, device=ctx.local_rank, max_batch=B,
                                   stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
@@ -345,6 +350,23 @@ class Rig:
         eng.profile(False)
         return {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
 
+    def kernel_profile_routed(self, lo, hi):
+        """one dispatcher: the timed steps once more with HIP events around every (fused) launch, all shards overlapping as in
+        the timed region.  -> ({kernel: avg ms per launch}, {kernel: avg requests per launch})"""
+        for e in self.engines:
+            e.profile(True)
+            e.profile_read()
+        self.run(lo, hi)
+        ms, n, units = {}, {}, {}
+        for e in self.engines:
+            prof = e.profile_read()
+            e.profile(False)
+            for k, (cnt, tot) in prof.items():
+                n[k] = n.get(k, 0) + cnt
+                ms[k] = ms.get(k, 0.0) + tot
+                units[k] = units.get(k, 0) + e.last_profile_units.get(k, 0)
+        return ({k: ms[k] / n[k] for k in n if n[k]}, {k: units[k] / n[k] for k in n if n[k]})
+
     def latency(self, lo, hi, n=256):
         """single-batch latency: submit -> complete, one batch in flight (BASELINE metric: p99 batch latency)"""
         torch = self.torch
@@ -440,6 +462,7 @@ def main():
     ctx.world, ctx.rank, ctx.local_rank, ctx.dev = world, rank, local_rank, dev
     ctx.K, ctx.B = args.keys, args.batch
     ctx.dispatch = args.dispatch
+    ctx.streams = args.streams
     ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
@@ -477,18 +500,29 @@ def main():
     extras = {}
     if rank == 0:
         # ---- per-kernel durations (HIP events on the engine stream around every launch), one batch in flight ----
-        kernel_ms = rig.kernel_profile(args.profile_steps, lo, hi) if args.profile_steps > 0 else {}
+        fused = args.dispatch == "one" and S > 1
+        per_launch = {}
+        if args.profile_steps <= 0:
+            kernel_ms = {}
+        elif fused:
+            kernel_ms, per_launch = rig.kernel_profile_routed(lo, hi)
+        else:
+            kernel_ms = rig.kernel_profile(args.profile_steps, lo, hi)
         latency = rig.latency(lo, hi)
         cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo] and v > 0}
         if cand:
+            # the dominant kernel = the one the GPU spends most time in; its bytes per launch = bytes per request x the
+            # requests one launch carries (a fused launch carries the batches of up to four shards)
             dom = max(cand, key=cand.get)
-            dom_bytes = KERNEL_BYTES[args.algo][dom] * B
+            dom_bytes = int(KERNEL_BYTES[args.algo][dom] * per_launch.get(dom, B))
             achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
             traffic = measured = None
             tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get(args.algo, {}).get(dom)
+                traffic = tj.get(args.algo, {}).get(dom.replace("_multi", ""))        # PMC bytes per 65536-request launch (profiles/)
+                if traffic and dom in per_launch:
+                    traffic = int(traffic * per_launch[dom] / B)
                 hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
                 cor = sum(tj.get(args.algo, {}).get(k, 0) for k in ("k_front", "k_eval2"))
                 raw = sum(tj.get(args.algo + "_raw", {}).get(k, 0) for k in ("k_front", "k_eval2"))
@@ -506,7 +540,10 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                         "algorithmic_bytes_per_launch": dom_bytes,
                         "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items() if v > 0},
-                        "kernel_timing": "HIP events around every launch on the engine stream, one batch in flight",
+                        "requests_per_launch": round(per_launch.get(dom, B), 1),
+                        "kernel_timing": ("HIP events around every launch on the shards' stream while the timed steps run once more, all shards "
+                                          "overlapping: a launch carries the next batch of up to four shards (k_front_multi / k_eval2_multi)") if fused
+                        else "HIP events around every launch on the engine stream, one batch in flight",
                         "measured_ceilings": measured,
                         "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
                                      "ms_per_batch": round(m["ms_per_step"], 5),
@@ -546,10 +583,12 @@ def main():
     headline_cfg = {"workload": f"{K} resident keys per GPU, one {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") +
                                 f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, {world}xMI355X"
                                 + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
-                                + (f", {S} logical shards per GPU (own table + stream + batcher thread each; the stream is routed by consistent hash, "
-                                   f"a shard flushes a batch when {B} requests are waiting)" if S > 1 else ", one table"),
+                                + ((f", {S} logical shards per GPU (own table each; the stream is routed by consistent hash, a shard flushes a batch "
+                                    f"when {B} requests are waiting), " +
+                                    ("own stream + batcher thread each" if args.dispatch == "threads" else
+                                     "one dispatcher and stream: the next batch of up to four shards per pair of launches")) if S > 1 else ", one table"),
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
-                    "logical_shards_per_gpu": S, "host_cores": os.cpu_count()}
+                    "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "host_cores": os.cpu_count()}
     rig.close()
     del rig
     torch.cuda.empty_cache()
@@ -627,7 +666,7 @@ def run_pool(args):
     exe = os.path.join(ROOT, "tools", "bench_pool_c")
     if not os.path.exists(exe):
         return {"error": "tools/bench_pool_c is not built (make -C gubernator_amd/csrc bench_pool)"}
-    T, S, items, keys = 64, max(1, args.shards), 1000, 1_000_000
+    T, S, items, keys = 64, 4, 1000, 1_000_000
     p = subprocess.run([exe, str(T), str(S), str(items), str(keys), "1.5"], capture_output=True, text=True, timeout=120)
     m = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)", p.stdout)
     if not m:

@@ -335,6 +335,7 @@ class Engine:
         arr = (abi.GuberKernelTime * 16)()
         n = C.c_uint32(0)
         _check(lib().guber_profile_read(self.h, arr, 16, C.byref(n)))
+        self.last_profile_units = {arr[i].name.decode(): arr[i].units for i in range(n.value)}
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
 
     def compact(self, now_ms):

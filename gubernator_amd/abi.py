@@ -56,7 +56,7 @@ class GuberGlobalRows(C.Structure):
 
 
 class GuberKernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 32), ("launches", C.c_uint64), ("total_ms", C.c_double), ("units", C.c_uint64)]
 
 
 def _ptr(a):

@@ -143,21 +143,21 @@ struct guber_engine {
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[16] = {0}; uint64_t prof_n[16] = {0};
+    double prof_ms[16] = {0}; uint64_t prof_n[16] = {0}, prof_units[16] = {0};
 
     hipEvent_t get_event() {
         if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
         hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); return ev;
     }
-    void span_begin(int k) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); } }
+    void span_begin(int k, uint64_t units = 0) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); prof_units[k] += units; } }
     void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, stream); }
 
     int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
-enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_COUNT };
+enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI, KT_COUNT };
 static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
-                                                   "k_scatter", "k_heads", "k_eval"};
+                                                   "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -411,10 +411,10 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
             if (rc) return rc;
         }
         const uint32_t ftiles = P.ftiles;
-        e->span_begin(KT_FRONT);
+        e->span_begin(KT_FRONT, n);
         hipLaunchKernelGGL(k_front, dim3(ftiles), dim3(FT), 0, e->stream, e->T, P.B2, P.W);
         e->span_end();
-        e->span_begin(KT_EVAL2);
+        e->span_begin(KT_EVAL2, n);
         hipLaunchKernelGGL(k_eval2, dim3((n + 255) / 256), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
         e->span_end();
         HIPCHK(hipGetLastError());
@@ -527,7 +527,7 @@ static bool can_fuse(const guber_engine* e, uint32_t n) {
 #ifdef GUBER_PHASE_TIMING
     return false;
 #else
-    return e->fuse && !e->profiling && takes_fast_path(e, n);
+    return e->fuse && takes_fast_path(e, n);
 #endif
 }
 
@@ -575,8 +575,14 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     if (planned) {
         static_assert(FT == 256, "k_eval2's workgroup is k_front's tile");
         MF.nb = ME.nb = (uint32_t)planned;
+        uint64_t units = 0;
+        for (int i = 0; i < planned; ++i) units += ns[i];
+        grp[0]->span_begin(KT_FRONT_MULTI, units);                    // (per-kernel timing, when enabled, is kept by the group's first engine)
         hipLaunchKernelGGL(k_front_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
+        grp[0]->span_end();
+        grp[0]->span_begin(KT_EVAL2_MULTI, units);
         hipLaunchKernelGGL(k_eval2_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
+        grp[0]->span_end();
         for (int i = 0; i < planned; ++i) { finish_fast(grp[i], ns[i]); grp[i]->fused_batches++; }
         *enqueued += (uint32_t)planned;
         if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
@@ -1644,9 +1650,9 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
     for (uint32_t k = 0; k < KT_COUNT && k < cap && out; ++k) {
         memset(&out[k], 0, sizeof(out[k]));
         snprintf(out[k].name, sizeof(out[k].name), "%s", kKernelNames[k]);
-        out[k].launches = e->prof_n[k]; out[k].total_ms = e->prof_ms[k];
+        out[k].launches = e->prof_n[k]; out[k].total_ms = e->prof_ms[k]; out[k].units = e->prof_units[k];
     }
-    if (out) for (int k = 0; k < KT_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; }
+    if (out) for (int k = 0; k < KT_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; e->prof_units[k] = 0; }
     return GUBER_OK;
 }
 

@@ -306,6 +306,7 @@ typedef struct guber_kernel_time {
     char name[32];
     uint64_t launches;
     double total_ms;
+    uint64_t units;      /* requests those launches processed (a fused launch carries several engines' batches) */
 } guber_kernel_time_t;
 int guber_profile_enable(guber_engine_t* e, int enable);
 int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out);

@@ -9,8 +9,10 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="--no-cpu-baseline --extras= --steps 64 --warmup 8 --min-ms 40 --profile-steps 0"
 for s in 1 4; do
   rm -rf $O/trace_s$s
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s$s -o t -- python $R/bench.py $ARGS --shards $s > $O/trace_s$s.log 2>&1; echo "trace S=$s rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s$s -o t -- python $R/bench.py $ARGS --shards $s --dispatch threads > $O/trace_s$s.log 2>&1; echo "trace S=$s rc=$?"
 done
+rm -rf $O/trace_fused
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fused -o t -- python $R/bench.py $ARGS --shards 12 --streams 3 --dispatch one > $O/trace_fused.log 2>&1; echo "trace fused rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_EA0_ATOMIC_sum TCC_ATOMIC_sum"; do
   n=$(echo $ctr | tr ' ' '+')
   rm -rf $O/pmc_$n

@@ -11,10 +11,10 @@ T0=$SECONDS
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$? wall $((SECONDS-T0)) s"
 T0=$SECONDS
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$? wall $((SECONDS-T0)) s"
-timeout 300 python bench.py --no-cpu-baseline --extras "" --dispatch one > $O/bench_one_dispatcher.json 2>/dev/null; echo "bench(one dispatcher) rc=$?"
+timeout 300 python bench.py --no-cpu-baseline --extras "" --dispatch threads --shards 4 > $O/bench_threads_4_shards.json 2>/dev/null; echo "bench(thread per shard, 4 shards) rc=$?"
 python - <<PY
 import json
-d=json.load(open("$O/bench_one_dispatcher.json")); print("one dispatcher, fused launches:", round(d["value"]/1e9,3), "G/s", d["ms_per_step"])
+d=json.load(open("$O/bench_threads_4_shards.json")); print("one thread + stream per shard, 4 shards:", round(d["value"]/1e9,3), "G/s", d["ms_per_step"])
 for f in ("bench_driver_cmd", "bench"):
     d=json.load(open("$O/%s.json" % f))
     print(f, "value", round(d["value"]/1e9,3), "ms/step", d["ms_per_step"], "timed ms", d["timed_region"]["ms"], "lat", d["batch_latency"]["p50"], d["batch_latency"]["p99"], d["roofline"]["kernel_avg_us"], "frac", d["roofline"]["frac"], d["parity"])

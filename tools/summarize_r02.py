@@ -19,26 +19,36 @@ def find(d, pat):
     return hits[0] if hits else None
 
 
-for s in (1, 4):
-    path = find(f"trace_s{s}", "*kernel_trace.csv")
+for s in (1, 4, "fused"):
+    path = find(f"trace_s{s}" if s != "fused" else "trace_fused", "*kernel_trace.csv")
     if not path:
         continue
     per = collections.defaultdict(list)
+    grid = collections.defaultdict(list)
     cols = {}
     for row in csv.DictReader(open(path)):
         name = row["Kernel_Name"].split("(")[0]
         if "guber::" in name:
             per[name.replace("guber::", "")].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            grid[name.replace("guber::", "")].append(int(row.get("Grid_Size_X") or row.get("Grid_Size") or 0))
             cols[name.replace("guber::", "")] = {k: row.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
-    lines += [f"## {s} logical shard(s): kernel durations" + (" (one batch in flight)" if s == 1 else " (shards overlapping)"), "",
-              "| kernel | launches | avg us | min us | p50 us | max us | VGPR | SGPR | LDS B | scratch B |", "|---|---|---|---|---|---|---|---|---|---|"]
+    title = {1: "1 logical shard(s): kernel durations (one batch in flight)", 4: "4 logical shard(s), one thread + stream each: kernel durations (shards overlapping)",
+             "fused": "12 logical shards, one dispatcher, 3 streams (the bench default): up to four tables per launch (k_front_multi / k_eval2_multi)"}[s]
+    lines += [f"## {title}", "",
+              "| kernel | launches | avg us | min us | p50 us | max us | VGPR | SGPR | LDS B | scratch B | avg requests per launch | algorithmic GB/s |", "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     out["kernels"][f"shards_{s}"] = {}
+    alg_b = {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73}
     for name, d in per.items():
         d = d[-N:]
-        st = dict(launches=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, p50_us=statistics.median(d) / 1e3, max_us=max(d) / 1e3, **cols[name])
+        g = grid[name][-N:]
+        st = dict(launches=len(d), avg_us=sum(d) / len(d) / 1e3, min_us=min(d) / 1e3, p50_us=statistics.median(d) / 1e3, max_us=max(d) / 1e3,
+                  avg_requests_per_launch=sum(g) / len(g), **cols[name])
+        if name in alg_b:
+            st["algorithmic_GBps"] = alg_b[name] * st["avg_requests_per_launch"] / (st["avg_us"] * 1e3)
         out["kernels"][f"shards_{s}"][name] = st
         c = cols[name]
-        lines.append(f"| {name} | {st['launches']} | {st['avg_us']:.2f} | {st['min_us']:.2f} | {st['p50_us']:.2f} | {st['max_us']:.2f} | {c['VGPR_Count']} | {c['SGPR_Count']} | {c['LDS_Block_Size']} | {c['Scratch_Size']} |")
+        lines.append(f"| {name} | {st['launches']} | {st['avg_us']:.2f} | {st['min_us']:.2f} | {st['p50_us']:.2f} | {st['max_us']:.2f} | {c['VGPR_Count']} | {c['SGPR_Count']} | {c['LDS_Block_Size']} | {c['Scratch_Size']} | "
+                     f"{st['avg_requests_per_launch']:.0f} | " + (f"{st['algorithmic_GBps']:.0f}" if "algorithmic_GBps" in st else "") + " |")
     lines.append("")
 pm = collections.defaultdict(dict)
 for d in sorted(glob.glob(os.path.join(base, "pmc_*"))):
