@@ -674,7 +674,10 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) { 
 // its engine's table and work arrays.  Same results by construction; what changes is that the batches' memory trips
 // overlap inside one launch instead of across streams (where every kernel boundary of every stream costs the others:
 // profiles/r02_m_shard_streams.txt).
-constexpr int MULTI_MAX = 4;
+#ifndef GUBER_MULTI_MAX
+#define GUBER_MULTI_MAX 4        // tables per fused launch (the kernel-argument segment holds at most 7: static_assert below)
+#endif
+constexpr int MULTI_MAX = GUBER_MULTI_MAX;
 struct FrontArgs { Table T; BatchView B; Work W; };
 struct MultiFront { uint32_t nb; uint32_t end_tile[MULTI_MAX]; FrontArgs sub[MULTI_MAX]; };
 struct MultiEval { uint32_t nb; uint32_t end_tile[MULTI_MAX]; EvalArgs sub[MULTI_MAX]; };
