@@ -87,7 +87,7 @@ struct CohBuf {
 struct guber_engine {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
-    hipStream_t copy_in = nullptr, copy_out = nullptr; bool stage_dma = true, stage_out_inplace = true; uint32_t stage_in_wgs = 0;   // stages: DMA copies beside the kernels (guber_stage_submit)
+    hipStream_t copy_in = nullptr; bool stage_dma = true;        // stages: DMA copies beside the kernels (guber_stage_submit)
     uint64_t slots = 0, cache_size = 0;
     uint32_t max_batch = 0, max_key = 0;
     Table T{};
@@ -228,8 +228,6 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
     e->fuse = getenv("GUBER_NO_FUSE") == nullptr;
     e->stage_dma = getenv("GUBER_NO_STAGE_DMA") == nullptr;
-    e->stage_out_inplace = getenv("GUBER_STAGE_OUT_DMA") == nullptr;
-    if (const char* v = getenv("GUBER_STAGE_IN_WGS")) e->stage_in_wgs = (uint32_t)atoi(v);   // > 0: copy kernel with that many workgroups instead of DMA
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
@@ -318,7 +316,6 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (e->z_event) (void)hipEventDestroy(e->z_event);
     if (e->rb_event) (void)hipEventDestroy(e->rb_event);
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
-    if (e->copy_out) (void)hipStreamDestroy(e->copy_out);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -835,12 +832,11 @@ struct guber_stage {
     // stage's device mirror while the previous batches' kernels run; the pipeline then works on HBM and k_eval2 writes the
     // responses straight into the host arrays (posted writes).  The link carries the requests at the copy engine's rate
     // (46-48 GB/s) instead of at the rate of k_front's dependent reads (24 GB/s in total with everything in place).
-    // Measured alternatives (profiles/r02_v_end_to_end_variants.txt): GUBER_STAGE_OUT_DMA=1 — responses to HBM, then a DMA
-    // copy: slower, a hipMemcpyAsync costs 40-60 us of host time; GUBER_STAGE_IN_WGS=n — a copy kernel of n workgroups
-    // instead of the DMA: slower, kernels of two streams overlap badly.
-    DevBuf<uint8_t> dmem;            // device mirror of [in block | out block]
+    // Measured and dropped (profiles/r02_v_end_to_end_variants.txt): responses to HBM and a DMA copy back (a hipMemcpyAsync
+    // costs 40-60 us of host time), a copy kernel instead of the DMA (kernels of two streams overlap badly).
+    DevBuf<uint8_t> dmem;            // device mirror of the in block
     uint8_t *h_in = nullptr, *h_out = nullptr; size_t in_fixed = 0, out_bytes = 0;   // host blocks; in_fixed = bytes before the keys
-    hipEvent_t ev_in = nullptr, ev_k = nullptr;
+    hipEvent_t ev_in = nullptr;
 };
 
 extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
@@ -861,7 +857,7 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters)));
     const size_t bytes = head + in_bytes + out_bytes + 256;
     if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess) {
         s->mem.release(); delete s; return GUBER_E_NOMEM;
     }
     memset(s->mem.p, 0, bytes);
@@ -898,7 +894,6 @@ extern "C" void guber_stage_destroy(guber_stage_t* s) {
     if (s->mode) (void)guber_stage_wait(s);
     if (s->ev) (void)hipEventDestroy(s->ev);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
-    if (s->ev_k) (void)hipEventDestroy(s->ev_k);
     s->dmem.release();
     s->mem.release();
     delete s;
@@ -945,59 +940,31 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     // (maintenance first: it may synchronise and rebuild; the read-back pair must bracket the kernels only)
     int rc = maintain(e, b.n, b.now_ms);
     if (rc) return rc;
-    // a batch that fills at least half of the stage travels by DMA (one block each way); smaller ones are read in place
+    // a batch that fills at least half of the stage reaches HBM by DMA; smaller ones are read in place
     const bool dma = e->stage_dma && s->max_n >= 4096 && (size_t)b.n * 2 >= s->max_n && !b.greg_expire && !b.greg_duration;
     if (dma) {
-        if (!e->copy_in && (hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) != hipSuccess ||
-                            hipStreamCreateWithFlags(&e->copy_out, hipStreamNonBlocking) != hipSuccess)) return fail(GUBER_E_HIP, "hipStreamCreate");
+        if (!e->copy_in && hipStreamCreateWithFlags(&e->copy_in, hipStreamNonBlocking) != hipSuccess) return fail(GUBER_E_HIP, "hipStreamCreate");
         const size_t in_bytes = (size_t)(s->h_out - s->h_in);
-        if (s->dmem.ensure(in_bytes + s->out_bytes)) return GUBER_E_NOMEM;
-        uint8_t* d_in = s->dmem.p; uint8_t* d_out = s->dmem.p + in_bytes;
-        // the used part of every column present, 16 bytes per thread and step (k_stage_in): the kernel's reads of host memory
-        // run at the link's rate like a DMA copy, but cost one launch and move exactly what the batch uses
-        StageSegs G{};
-        auto seg = [&](const void* hp, size_t bytes) {
-            if (!hp || !bytes) return;
-            G.off[G.n] = (uint32_t)((const uint8_t*)hp - s->h_in); G.end16[G.n] = (G.n ? G.end16[G.n - 1] : 0u) + (uint32_t)((bytes + 15) >> 4); ++G.n;
-        };
-        seg(b.key_off, ((size_t)b.n + 1) * 4); seg(b.hits, (size_t)b.n * 8); seg(b.limit, (size_t)b.n * 8); seg(b.duration, (size_t)b.n * 8);
-        seg(b.behavior, (size_t)b.n * 4); seg(b.algorithm, b.n); seg(b.is_owner, b.n); seg(b.burst, (size_t)b.n * 8); seg(b.created_at, (size_t)b.n * 8);
-        seg(b.key_bytes, (size_t)b.key_off[b.n] + 16);
-        const uint32_t total16 = G.end16[G.n - 1];
-        if (e->stage_in_wgs) {
-            // few workgroups: the copy must leave wave slots for the previous batch's kernels it runs beside
-            hipLaunchKernelGGL(k_stage_in, dim3(std::min<uint32_t>((total16 + 255) / 256, e->stage_in_wgs)), dim3(256), 0, e->copy_in, (uint4*)d_in, (const uint4*)s->h_in, G);
-        } else {
-            // DMA: the fixed columns up to the last one present, then the keys
-            const void* last = b.created_at ? (const void*)(b.created_at + b.n) : b.burst ? (const void*)(b.burst + b.n) : b.is_owner ? (const void*)(b.is_owner + b.n) : (const void*)(b.algorithm + b.n);
-            const size_t fixed = (size_t)((const uint8_t*)last - s->h_in);
-            HIPCHK(hipMemcpyAsync(d_in, s->h_in, fixed, hipMemcpyHostToDevice, e->copy_in));
-            HIPCHK(hipMemcpyAsync(d_in + s->in_fixed, s->h_in + s->in_fixed, (size_t)b.key_off[b.n] + 16, hipMemcpyHostToDevice, e->copy_in));
-        }
+        if (s->dmem.ensure(in_bytes)) return GUBER_E_NOMEM;
+        uint8_t* d_in = s->dmem.p;
+        // two copies: the fixed-width columns up to the last one present, then the keys
+        const void* last = b.created_at ? (const void*)(b.created_at + b.n) : b.burst ? (const void*)(b.burst + b.n) : b.is_owner ? (const void*)(b.is_owner + b.n) : (const void*)(b.algorithm + b.n);
+        const size_t fixed = (size_t)((const uint8_t*)last - s->h_in);
+        HIPCHK(hipMemcpyAsync(d_in, s->h_in, fixed, hipMemcpyHostToDevice, e->copy_in));
+        HIPCHK(hipMemcpyAsync(d_in + s->in_fixed, s->h_in + s->in_fixed, (size_t)b.key_off[b.n] + 16, hipMemcpyHostToDevice, e->copy_in));
         HIPCHK(hipEventRecord(s->ev_in, e->copy_in));
         HIPCHK(hipStreamWaitEvent(e->stream, s->ev_in, 0));
         auto dev = [&](const void* hp) { return hp ? d_in + ((const uint8_t*)hp - s->h_in) : nullptr; };
-        auto devo = [&](void* hp) { return d_out + ((uint8_t*)hp - s->h_out); };
         B = BatchView{b.n, 0, dev(b.key_bytes), (const uint32_t*)dev(b.key_off), (const int64_t*)dev(b.hits), (const int64_t*)dev(b.limit),
                       (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
                       (const uint32_t*)dev(b.behavior), dev(b.is_owner), nullptr, nullptr, b.now_ms};
-        if (!e->stage_out_inplace)
-            R = ResultView{devo(s->result.status), (int64_t*)devo(s->result.limit), (int64_t*)devo(s->result.remaining),
-                           (int64_t*)devo(s->result.reset_time), devo(s->result.err)};
     }
     hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb0_ctr, s->rb0_bctr);
     rc = launch_batch(e, B, R, !dma);
     if (rc) return rc;
     hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb_ctr, s->rb_bctr);
     HIPCHK(hipGetLastError());
-    if (dma && !e->stage_out_inplace) {
-        HIPCHK(hipEventRecord(s->ev_k, e->stream));
-        HIPCHK(hipStreamWaitEvent(e->copy_out, s->ev_k, 0));
-        HIPCHK(hipMemcpyAsync(s->h_out, s->dmem.p + (size_t)(s->h_out - s->h_in), s->out_bytes, hipMemcpyDeviceToHost, e->copy_out));
-        HIPCHK(hipEventRecord(s->ev, e->copy_out));
-    } else {
-        HIPCHK(hipEventRecord(s->ev, e->stream));
-    }
+    HIPCHK(hipEventRecord(s->ev, e->stream));
     s->mode = 2;
     return GUBER_OK;
 }

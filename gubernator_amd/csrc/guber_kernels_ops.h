@@ -303,17 +303,4 @@ __global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr
     if (threadIdx.x == 0) *out_c = *ctr;
 }
 
-// a stage's request block, host memory -> its HBM mirror: the used part of each column (guber_stage_submit)
-struct StageSegs { uint32_t n; uint32_t off[10]; uint32_t end16[10]; };      // byte offset of a segment; running end in 16-byte units
-__global__ void k_stage_in(uint4* dst, const uint4* src, StageSegs G) {
-    const uint32_t total = G.end16[G.n - 1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        uint32_t k = 0, first = 0;
-#pragma unroll
-        for (int j = 0; j < 9; ++j) if (k == (uint32_t)j && j + 1 < (int)G.n && i >= G.end16[j]) { first = G.end16[j]; k = j + 1; }
-        const uint32_t at = (G.off[k] >> 4) + (i - first);
-        dst[at] = src[at];
-    }
-}
-
 }  // namespace guber
