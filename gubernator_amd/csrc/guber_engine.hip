@@ -96,7 +96,7 @@ struct guber_engine {
     DevBuf<DirEntry> dir; DevBuf<Bucket> buckets; DevBuf<uint8_t> arena; DevBuf<DevCounters> ctr;
     DevBuf<uint32_t> w_u32;    // all u32 work arrays carved from one allocation
     DevBuf<uint8_t> w_rflags; DevBuf<Rec> w_snap; DevBuf<uint32_t> w_hist; DevBuf<BlockCounters> bctr;
-    PinBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;
+    CohBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;   // (device-visible: written by k_ctr_snapshot)
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<SegRec> w_srec; DevBuf<int64_t> w_sinv; DevBuf<uint16_t> w_tilerow;
     DevBuf<uint32_t> w_did2;
@@ -124,7 +124,7 @@ struct guber_engine {
     hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
     bool fuse = true; uint64_t fused_batches = 0;                 // guber_eval_batches_routed_dev: several engines per launch
     uint64_t small_batches = 0, small_fallbacks = 0;
-    PinBuf<DevCounters> h_ctr;
+    CohBuf<DevCounters> h_ctr; CohBuf<uint32_t> h_rb_seq; uint32_t rb_seq = 0;   // counter snapshot + its completion stamp
     DevCounters last_ctr{};
     uint32_t epoch = 0;
     uint64_t batches = 0;
@@ -135,7 +135,7 @@ struct guber_engine {
     uint32_t touch = 0;        // advances with every call that touches items (batch, Add, GetItem): approximate LRU order
     // asynchronous counter read-back (maintain): enqueued when an upper bound crosses its soft limit, folded when its event
     // has completed — the hot path never waits for it
-    hipEvent_t rb_event = nullptr; bool rb_inflight = false; uint64_t rb_added = 0;
+    bool rb_inflight = false; uint64_t rb_added = 0;
     uint64_t compactions = 0;
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
@@ -175,10 +175,17 @@ static void fold_counters(guber_engine* e) {
     e->size_upper = (uint64_t)std::max<long long>(c.size, 0);
     e->rb_inflight = false; e->rb_added = 0;
 }
+// The engine's counters -> host memory by ONE small launch (k_ctr_snapshot writes device-visible host memory and stamps a
+// sequence number when it is done): no copy engine, no event — the asynchronous reader just looks at the stamp.
 static int enqueue_counter_readback(guber_engine* e) {
-    HIPCHK(hipMemcpyAsync(e->h_ctr.p, e->ctr.p, sizeof(DevCounters), hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(hipMemcpyAsync(e->h_bctr.p, e->bctr.p, e->n_bctr * sizeof(BlockCounters), hipMemcpyDeviceToHost, e->stream));
+    if (e->h_rb_seq.ensure(1)) return GUBER_E_NOMEM;
+    ++e->rb_seq;
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p, e->h_bctr.p, e->h_rb_seq.p, e->rb_seq);
+    HIPCHK(hipGetLastError());
     return 0;
+}
+static bool counter_readback_done(const guber_engine* e) {
+    return __atomic_load_n((volatile uint32_t*)e->h_rb_seq.p, __ATOMIC_ACQUIRE) == e->rb_seq;
 }
 static int engine_refresh_counters(guber_engine* e) {
     int rc = enqueue_counter_readback(e);
@@ -311,10 +318,9 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
     e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
-    e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->z_stage.release();
+    e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
     if (e->z_event) (void)hipEventDestroy(e->z_event);
-    if (e->rb_event) (void)hipEventDestroy(e->rb_event);
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -959,10 +965,10 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
                       (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
                       (const uint32_t*)dev(b.behavior), dev(b.is_owner), nullptr, nullptr, b.now_ms};
     }
-    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb0_ctr, s->rb0_bctr);
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb0_ctr, s->rb0_bctr, (uint32_t*)nullptr, 0u);
     rc = launch_batch(e, B, R, !dma);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb_ctr, s->rb_bctr);
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb_ctr, s->rb_bctr, (uint32_t*)nullptr, 0u);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev, e->stream));
     s->mode = 2;
@@ -1546,7 +1552,7 @@ static int evict_to(guber_engine* e, uint64_t target, int64_t now_ms) {
 static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms) {
     const uint64_t tag_limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
     const uint64_t hard_size = e->cache_size + std::max<uint64_t>(e->cache_size / 2, 4ull * e->max_batch);
-    if (e->rb_inflight && hipEventQuery(e->rb_event) == hipSuccess) {
+    if (e->rb_inflight && counter_readback_done(e)) {
         const uint64_t added = e->rb_added;
         fold_counters(e);                                 // exact as of the read-back; what was enqueued since is added back
         e->size_upper += added; e->tags_upper += added;
@@ -1557,10 +1563,8 @@ static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms) {
     const bool hard = incoming == 0 || e->size_upper > hard_size || e->tags_upper + incoming > tag_limit || sure_over;
     if (!hard) {
         if (!e->rb_inflight) {
-            if (!e->rb_event && hipEventCreateWithFlags(&e->rb_event, hipEventDisableTiming) != hipSuccess) return fail(GUBER_E_HIP, "hipEventCreate");
             int rc = enqueue_counter_readback(e);
             if (rc) return rc;
-            HIPCHK(hipEventRecord(e->rb_event, e->stream));
             e->rb_inflight = true; e->rb_added = 0;
         }
         return 0;

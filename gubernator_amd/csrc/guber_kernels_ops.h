@@ -298,9 +298,15 @@ __global__ __launch_bounds__(256) void k_items_from_soa(ItemsSoA S, uint32_t n, 
 
 // the engine's event counters -> a snapshot in device-visible host memory (stages bracket their batch with two of these:
 // one launch each instead of two small copies)
-__global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr, uint32_t n_bctr, DevCounters* out_c, BlockCounters* out_b) {
+__global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr, uint32_t n_bctr, DevCounters* out_c, BlockCounters* out_b,
+                               uint32_t* seq_out, uint32_t seq) {
     for (uint32_t k = threadIdx.x; k < n_bctr; k += blockDim.x) out_b[k] = bctr[k];
     if (threadIdx.x == 0) *out_c = *ctr;
+    __syncthreads();                                             // every store of the workgroup has been issued and drained
+    if (threadIdx.x == 0 && seq_out) {
+        __threadfence_system();
+        __hip_atomic_store(seq_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace guber
