@@ -68,7 +68,7 @@ def parse():
                          "(guber_eval_batches_routed_dev)")
     ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per thread count of the baseline")
     ap.add_argument("--cpu-threads", default="1,32,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
     ap.add_argument("--profile-steps", type=int, default=32)
     ap.add_argument("--shards", type=int, default=12, metavar="S",
@@ -426,7 +426,7 @@ def cpu_baseline(rig, orc_by_threads, lo, hi, seconds):
             orc.eval(hb[done % len(hb)], threads=(w if w > 1 else 0))
             done += 1
             el = time.perf_counter() - t0
-            if el >= seconds or done >= 4 * len(hb):
+            if el >= seconds:                      # the sample is bounded by time: the stream's batches are replayed until it is up
                 break
         res[w] = (done * rig.ctx.B / el, done, el)
     return res
