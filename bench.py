@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
                     help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
                          "(guber_eval_batches_routed_dev)")
+    ap.add_argument("--router", choices=["slots", "ring"], default="slots",
+                    help="placement of a GPU's keys on its logical shards: load-aware hash slots (shard.SlotMap) or a plain consistent hash")
     ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per thread count of the baseline")
@@ -154,17 +156,37 @@ class Rig:
             ns = max(1, min(S, int(getattr(ctx, "streams", 1))))
             self.sstreams = [self.sstreams[j * ns // S] for j in range(S)]
         nk = len(ctx.my_ids)
-        self.engines = [ga.Engine(cache_size=(nk + nk // 4) // S + 1024, device=ctx.local_rank, max_batch=B,
-                                  stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
-        # logical shards inside this GPU: the rank's keys are split once more by the same kind of ring (k_route)
-        if S > 1:
+        # logical shards inside this GPU: the rank's keys are placed on them first (k_route on a scratch engine), then every
+        # shard gets a table for the keys it really holds (+ 25 %)
+        router_engine = ga.Engine(cache_size=1024, device=ctx.local_rank, max_batch=1024) if S > 1 else None
+        self.engines = [router_engine]
+        self.placement = None
+        if S > 1 and getattr(ctx, "router", "slots") == "slots":
+            # load-aware placement (gubernator_amd/shard.py SlotMap): keys -> 256 hash slots (k_route), slots and the few keys
+            # that alone outweigh a slot -> shards by what an earlier sample of the traffic carried
+            sm = shard.SlotMap(S)
+            slot_of = np.concatenate([ctx.route_on_device(self.engines[0], sm.ring, *streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 4_000_000]))
+                                      for lo in range(0, nk, 4_000_000)]).astype(np.int64)
+            observed = (streams.ZipfSampler(nk, s=1.1, seed=990_001 + ctx.rank, perm_seed=99).draw(1 << 21) if dist_kind == "zipf"
+                        else np.zeros(0, np.int64))
+            self.sown = sm.place(slot_of, observed).astype(np.uint8)
+            self.placement = {"router": "256 hash slots placed on the shards by observed load (2 M earlier requests), hot keys individually",
+                              "keys_placed_individually": int(len(sm.hot_ids)), "expected_share_max": round(float(sm.load.max()), 4),
+                              "expected_share_min": round(float(sm.load.min()), 4)}
+            sm.close()
+        elif S > 1:
             sring = ga.Ring([f"gpu{ctx.rank}-shard{j}" for j in range(S)], 512, "fnv1")
             self.sown = np.concatenate([ctx.route_on_device(self.engines[0], sring, *streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 4_000_000]))
                                         for lo in range(0, nk, 4_000_000)]).astype(np.uint8)
             sring.close()
+            self.placement = {"router": "replicated consistent hash over the shards (512 vnodes, fnv1)"}
         else:
             self.sown = np.zeros(nk, np.uint8)
         self.local_of_shard = [np.nonzero(self.sown == j)[0] for j in range(S)]
+        if router_engine is not None:
+            router_engine.close()
+        self.engines = [ga.Engine(cache_size=len(self.local_of_shard[j]) + len(self.local_of_shard[j]) // 4 + 1024, device=ctx.local_rank, max_batch=B,
+                                  stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
         # arrays every batch of this rig shares (fixed-width keys, constant request fields)
         L = ctx.table.shape[1]
         self.t_off = torch.from_numpy((np.arange(B + 1, dtype=np.int64) * L).astype(np.int32)).to(dev)
@@ -463,6 +485,7 @@ def main():
     ctx.K, ctx.B = args.keys, args.batch
     ctx.dispatch = args.dispatch
     ctx.streams = args.streams
+    ctx.router = args.router
     ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
@@ -588,7 +611,7 @@ def main():
                                     ("own stream + batcher thread each" if args.dispatch == "threads" else
                                      "one dispatcher and stream: the next batch of up to four shards per pair of launches")) if S > 1 else ", one table"),
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
-                    "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "host_cores": os.cpu_count()}
+                    "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count()}
     rig.close()
     del rig
     torch.cuda.empty_cache()
