@@ -8,7 +8,9 @@ TOKEN_BUCKET, hits 1, limit 100, duration 60 s, now_ms advancing 1 ms per batch.
 
 Inside a GPU the resident keys are split into S logical shards (default 12; the reference shards its key space the same
 way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables.  The request
-stream is routed request by request to the shard that owns the key (consistent hash, k_route) and every shard flushes a
+stream is routed request by request to the shard that holds the key (load-aware hash slots, gubernator_amd/shard.py
+SlotMap: 256 slots by consistent hash / k_route, slots and the few hottest keys placed on the shards by what a sample of
+earlier traffic carried; --router ring = a plain consistent hash over the shards) and every shard flushes a
 batch when 65536 requests are waiting — the policy of the reference's batcher (peer_client.go:284-337) — so batches are
 exactly 65536 requests, hot shards flush more often, and per-key request order is the stream's order.
 
