@@ -2,7 +2,7 @@
 // calling V1Instance::GetRateLimits with RPCs of `items` requests (gubernator.go:183-306, cap 1000), against a
 // GPUWorkerPool of S shards (workers.go:54-626).  Everything the Go shim would do per request happens here in C++:
 // validation, HashKey, shard routing, queueing, in-place stage filling, submit / wait, response fan-out.
-//   make -C gubernator_amd/csrc bench_pool && tools/bench_pool_c [threads] [shards] [items] [keys] [seconds]
+//   make -C gubernator_amd/csrc bench_pool && tools/bench_pool_c [threads] [shards] [items] [keys] [seconds] [batch_wait_us]
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -22,9 +22,10 @@ int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 32, S = argc > 2 ? atoi(argv[2]) : 4, items = argc > 3 ? atoi(argv[3]) : 1000;
     const int K = argc > 4 ? atoi(argv[4]) : 1000000;
     const double seconds = argc > 5 ? atof(argv[5]) : 2.0;
+    const int wait_us = argc > 6 ? atoi(argv[6]) : 200;
     guber_config_t cfg{};
     cfg.cache_size = (uint64_t)K * 2; cfg.max_batch = 65536; cfg.device = 0;
-    GPUWorkerPool pool(cfg, 65536, 200, (uint32_t)S);
+    GPUWorkerPool pool(cfg, 65536, (uint32_t)wait_us, (uint32_t)S);
     if (!pool.ok()) { printf("pool: error %d\n", pool.create_error()); return 1; }
     V1Instance inst(&pool);
     // Zipf-1.1 ranks over K keys by inverse-CDF on a precomputed table
