@@ -135,7 +135,7 @@ struct guber_engine {
     uint32_t touch = 0;        // advances with every call that touches items (batch, Add, GetItem): approximate LRU order
     // asynchronous counter read-back (maintain): enqueued when an upper bound crosses its soft limit, folded when its event
     // has completed — the hot path never waits for it
-    bool rb_inflight = false; uint64_t rb_added = 0;
+    bool rb_inflight = false, snap_pending = false; uint64_t rb_added = 0;   // snap_pending: the read-back waits for a batch to ride on
     uint64_t compactions = 0;
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
@@ -173,7 +173,7 @@ static void fold_counters(guber_engine* e) {
     e->last_ctr = c;
     e->tags_upper = c.tags_used;
     e->size_upper = (uint64_t)std::max<long long>(c.size, 0);
-    e->rb_inflight = false; e->rb_added = 0;
+    e->rb_inflight = false; e->snap_pending = false; e->rb_added = 0;
 }
 // The engine's counters -> host memory by ONE small launch (k_ctr_snapshot writes device-visible host memory and stamps a
 // sequence number when it is done): no copy engine, no event — the asynchronous reader just looks at the stamp.
@@ -183,6 +183,11 @@ static int enqueue_counter_readback(guber_engine* e) {
     hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p, e->h_bctr.p, e->h_rb_seq.p, e->rb_seq);
     HIPCHK(hipGetLastError());
     return 0;
+}
+// the same read-back riding on the next two-launch batch instead of a launch of its own (Work::snap_*)
+static void attach_counter_readback(guber_engine* e, Work& W) {
+    W.snap_seq = e->rb_seq; W.snap_n = e->n_bctr; W.snap_c = e->h_ctr.p; W.snap_b = e->h_bctr.p; W.snap_stamp = e->h_rb_seq.p;
+    e->snap_pending = false;
 }
 static bool counter_readback_done(const guber_engine* e) {
     return __atomic_load_n((volatile uint32_t*)e->h_rb_seq.p, __ATOMIC_ACQUIRE) == e->rb_seq;
@@ -280,6 +285,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.tiles = tiles; e->W.epoch = 0;
     e->W.seg_tilemask = e->w_tilemask.p; e->W.srec = e->w_srec.p; e->W.sinv = e->w_sinv.p; e->W.tilerow = e->w_tilerow.p;
 
+    e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
 #ifdef GUBER_PHASE_TIMING
@@ -328,7 +334,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
 
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
 static int compact_table(guber_engine* e, int64_t now_ms);
-static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms);
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows = false);
 // What a batch needs before its kernels can be enqueued, shared by the single-engine and the fused multi-engine launch:
 // cache maintenance, the engine's epochs, and (two-launch pipeline) the views / work arrays of this batch.
 struct FastPlan { BatchView B2, B3; Work W; uint32_t ftiles; };
@@ -343,7 +349,7 @@ static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
     // (lrucache.go:98-100) and, if the directory is above its load limit, the table rebuilt without its dead entries.  A
     // batch that still finds no room gets per-item GUBER_ITEM_E_TABLE_FULL from the bounded probe, for NEW keys only.
     {
-        const int rc = maintain(e, n, B.now_ms);
+        const int rc = maintain(e, n, B.now_ms, takes_fast_path(e, n));
         if (rc) return rc;
     }
     e->size_upper += n; e->rb_added += n;
@@ -364,6 +370,8 @@ static int plan_fast(guber_engine* e, const BatchView& B, bool host_resident, Wo
     BatchView B2 = B;
     B2.n_cap = e->fast_cap;
     W.careful = (e->careful || e->always_careful) ? 1u : 0u;
+    W.snap_seq = 0;
+    if (e->snap_pending) attach_counter_readback(e, W);
     if (++e->fast_epoch16 > 0xffffu) {   // 16-bit claim epoch wrapped: forget every cell
         HIPCHK(hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream));
         HIPCHK(hipMemset2DAsync(&e->w_srec.p[0].flags, sizeof(SegRec), 0, sizeof(unsigned long long), e->fast_cap, e->stream));   // epoch-tagged flag words
@@ -1549,10 +1557,14 @@ static int evict_to(guber_engine* e, uint64_t target, int64_t now_ms) {
 // The bounds are upper bounds (every request might create an item).  Crossing a SOFT limit only enqueues an asynchronous
 // read-back of the real counters, folded by a later call once its event has completed; the stream is drained only when
 // an eviction / rebuild is really due or a HARD limit (physical room) is at stake.
-static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms) {
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows) {
     const uint64_t tag_limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
     const uint64_t hard_size = e->cache_size + std::max<uint64_t>(e->cache_size / 2, 4ull * e->max_batch);
-    if (e->rb_inflight && counter_readback_done(e)) {
+    if (e->snap_pending && !batch_follows) {              // a read-back that was to ride on a batch that never came: launch it now
+        hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p, e->h_bctr.p, e->h_rb_seq.p, e->rb_seq);
+        e->snap_pending = false;
+    }
+    if (e->rb_inflight && !e->snap_pending && counter_readback_done(e)) {
         const uint64_t added = e->rb_added;
         fold_counters(e);                                 // exact as of the read-back; what was enqueued since is added back
         e->size_upper += added; e->tags_upper += added;
@@ -1563,8 +1575,14 @@ static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms) {
     const bool hard = incoming == 0 || e->size_upper > hard_size || e->tags_upper + incoming > tag_limit || sure_over;
     if (!hard) {
         if (!e->rb_inflight) {
-            int rc = enqueue_counter_readback(e);
-            if (rc) return rc;
+            if (batch_follows) {                              // no launch of its own: the batch's k_front carries it
+                if (e->h_rb_seq.ensure(1)) return GUBER_E_NOMEM;
+                ++e->rb_seq;
+                e->snap_pending = true;
+            } else {
+                int rc = enqueue_counter_readback(e);
+                if (rc) return rc;
+            }
             e->rb_inflight = true; e->rb_added = 0;
         }
         return 0;

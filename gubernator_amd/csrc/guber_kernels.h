@@ -192,6 +192,15 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     const uint32_t e16 = W.epoch16;
 
     GB_STAMP(0);
+    if (tile == 0 && W.snap_seq) {                                  // a counter read-back rides on this launch (Work::snap_*)
+        for (uint32_t k = tid; k < W.snap_n; k += FT) W.snap_b[k] = T.bctr[k];
+        if (tid == 0) *W.snap_c = *T.ctr;
+        __syncthreads();                                             // every store of the workgroup issued and drained
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(W.snap_stamp, W.snap_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (tid == 0) { soft_any = 0u; ins_any = 0u; }
     for (uint32_t j = tid; j < GT; j += FT) {
         gkey[j] = 0ull;

@@ -142,6 +142,10 @@ struct Work {
     uint32_t careful;                   // 1 = retry round: verify the key before claiming (no speculation)
     uint32_t parity;                    // batch & 1
     uint32_t clear_n;                   // entries of the other copy dirtied by the previous batch
+    // counter read-back riding on this batch's k_front (0 = none): its first workgroup copies the engine's counters, as they
+    // are before the batch, to device-visible host memory and stamps snap_seq when done (guber_engine.hip maintain())
+    uint32_t snap_seq, snap_n;
+    DevCounters* snap_c; BlockCounters* snap_b; uint32_t* snap_stamp;
 };
 
 // ---------------------------------------------------------------------------------------------
