@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -35,6 +36,7 @@ static int64_t mono_us() {
 GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards,
                              const std::vector<int32_t>& devices)
     : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
+    if (const char* v = getenv("GUBER_POOL_IDLE_US")) idle_us_ = (uint32_t)atoi(v);   // 0 = off (the reference's policy: limit or wait only)
     if (shards == 0) shards = 1;
     std::vector<int32_t> devs = devices;
     if (devs.empty()) devs.push_back(cfg.device);
@@ -337,6 +339,7 @@ void GPUWorkerPool::run(Shard& sh) {
     for (;;) {
         Stage& s = sh.st[cur];
         bool due = false, closing = false;
+        uint32_t seen_cnt = 0; int64_t seen_us = 0;                 // idle flush: when the reserved count last changed
         {
             // flush at batch_limit, at batch_wait after the first reservation (peer_client.go:284-337), or when a caller found
             // no room; with nothing due, deliver the batch in flight instead of sitting on it
@@ -348,8 +351,15 @@ void GPUWorkerPool::run(Shard& sh) {
                 if (cnt) {
                     const int64_t first = s.first_us.load(std::memory_order_acquire), now = mono_us();
                     if (first && now - first >= (int64_t)batch_wait_us_) { due = true; break; }
+                    int64_t left = first ? (int64_t)batch_wait_us_ - (now - first) : (int64_t)batch_wait_us_;
+                    if (idle_us_) {
+                        // optional: nobody has reserved anything for idle_us and every reserved slot is written — the callers are
+                        // all waiting for this batch, so holding it until batch_wait only adds latency
+                        if (cnt != seen_cnt) { seen_cnt = cnt; seen_us = now; }
+                        else if (now - seen_us >= (int64_t)idle_us_ && s.written.load(std::memory_order_acquire) == cnt) { due = true; break; }
+                        left = std::min<int64_t>(left, (int64_t)idle_us_ - (now - seen_us));
+                    }
                     if (inflight >= 0) break;
-                    const int64_t left = first ? (int64_t)batch_wait_us_ - (now - first) : (int64_t)batch_wait_us_;
                     wait_us(sh.cv_batcher, lk, std::max<int64_t>(left, 1));
                     continue;
                 }

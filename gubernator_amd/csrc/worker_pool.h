@@ -9,6 +9,8 @@
 // shard's batcher thread never touches a request: it seals the open stage at batch_limit items or batch_wait after the
 // first one (the policy of peer_client.go:284-337), submits it, opens the next of its three stages (one filling, one on
 // the GPU, one being read out by its callers), and announces completed generations.  Nothing is allocated per flush.
+// (Optional, off by default: GUBER_POOL_IDLE_US=n also flushes when nobody has reserved anything for n microseconds and all
+// reserved slots are written — lower latency under light load; profiles/r02_y_pool_throughput.txt.)
 //
 // Shards: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
 // over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers —
@@ -132,7 +134,7 @@ class GPUWorkerPool {
     uint32_t n_devices_ = 1, shards_per_device_ = 1;
     uint64_t ring_step_ = 0;
     int create_rc_ = 0;
-    uint32_t batch_limit_, batch_wait_us_, max_key_ = 1024, key_cap_ = 0;
+    uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, max_key_ = 1024, key_cap_ = 0;
     std::atomic<bool> closed_{false};
     std::atomic<int64_t> frozen_ms_{0};
     std::atomic<bool> has_store_{false};

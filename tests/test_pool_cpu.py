@@ -20,11 +20,13 @@ def build(tag, flags):
     return out
 
 
-@pytest.mark.parametrize("tag,flags,scale", [("plain", [], 1), ("tsan", ["-fsanitize=thread"], 2),
-                                             ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2)])
-def test_pool_host_logic(tag, flags, scale):
+@pytest.mark.parametrize("tag,flags,scale,idle_us", [("plain", [], 1, 0), ("plain", [], 2, 20), ("tsan", ["-fsanitize=thread"], 2, 0),
+                                                     ("tsan", ["-fsanitize=thread"], 4, 20),
+                                                     ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2, 0)])
+def test_pool_host_logic(tag, flags, scale, idle_us):
     exe = build(tag, flags)
-    p = subprocess.run([exe, str(scale)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, GUBER_POOL_IDLE_US=str(idle_us))          # 20: the optional idle flush of the batcher
+    p = subprocess.run([exe, str(scale)], capture_output=True, text=True, timeout=600, env=env)
     tail = (p.stdout + p.stderr)[-3000:]
     assert p.returncode == 0 and "POOL TEST OK" in p.stdout, tail
     assert "ThreadSanitizer" not in p.stderr and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, tail
