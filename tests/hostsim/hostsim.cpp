@@ -130,7 +130,7 @@ void hs_fuzz_closed_forms(uint64_t seed, uint32_t iters, uint64_t* out) {
         s0.stamp = now - (int64_t)(fz_next(st) % 100000);
         if (r.algorithm == ALGO_TOKEN) {
             const uint64_t pick = fz_next(st) % 8;
-            s0.remaining = pick == 0 ? 0 : pick == 1 ? r.hits : pick == 2 ? r.hits - 1 : pick == 3 ? (int64_t)(fz_next(st) % 20) * r.hits
+            s0.remaining = pick == 0 ? 0 : pick == 1 ? r.hits : pick == 2 ? (int64_t)((uint64_t)r.hits - 1) : pick == 3 ? (int64_t)((fz_next(st) % 20) * (uint64_t)r.hits)
                          : pick == 4 ? -3 : (int64_t)(fz_next(st) % 300000);
             s0.meta = make_meta(K_TOKEN, fz_next(st) % 5 == 0 ? ST_OVER : ST_UNDER, ALGO_TOKEN);
         } else {
