@@ -101,3 +101,12 @@ def test_hashes(L):
     assert L.guber_fnv1a_64(b"foobar", 6) == 0x85944171f73967e8
     assert b"Invalid rate limit algorithm" in L.guber_item_strerror(1)
     assert L.guber_strerror(-2).startswith(b"no HIP device")
+
+
+def test_argument_checks_need_no_device(L):
+    """entry points reject malformed calls before touching HIP (so the checks hold on a machine without a GPU)"""
+    assert L.guber_eval_batches_routed_dev(None, 0, None, None, None, 0, None) != 0
+    assert L.guber_stage_submit(None) != 0 and L.guber_stage_wait(None) != 0
+    st = C.c_void_p()
+    assert L.guber_stage_create(None, 16, 0, C.byref(st)) != 0 and not st.value
+    assert L.guber_eval_batches_dev(None, None, None, 0, None) != 0
