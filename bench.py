@@ -68,8 +68,9 @@ def parse():
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
                     help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
                          "(guber_eval_batches_routed_dev)")
-    ap.add_argument("--router", choices=["slots", "ring"], default="slots",
-                    help="placement of a GPU's keys on its logical shards: load-aware hash slots (shard.SlotMap) or a plain consistent hash")
+    ap.add_argument("--router", choices=["slots", "ring"], default=None,
+                    help="placement of a GPU's keys on its logical shards: load-aware hash slots (shard.SlotMap; default with --dispatch one) or "
+                         "a plain consistent hash (default with --dispatch threads)")
     ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per thread count of the baseline")
@@ -491,7 +492,7 @@ def main():
     ctx.K, ctx.B = args.keys, args.batch
     ctx.dispatch = args.dispatch
     ctx.streams = args.streams
-    ctx.router = args.router
+    ctx.router = args.router or ("slots" if args.dispatch == "one" else "ring")
     ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
