@@ -29,9 +29,13 @@
  * Go semantics emulated: int64 wrap-around (built with -fwrapv), float64->int64 conversion as
  * amd64 CVTTSD2SQ (NaN / +-Inf / out of range -> INT64_MIN), int64->float64 round-to-nearest-even.
  */
+#define _GNU_SOURCE   /* sched_getaffinity / pthread_setaffinity_np: the CPU-baseline harness pins its threads */
 #include "guber_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -176,6 +180,7 @@ struct oracle {
     uint64_t over_limit, hits, misses, unexpired_evictions;
     /* Config.Store (store.go:49-65) for oracle_eval_batch_store; NULL = no store (the `s != nil` tests) */
     const oracle_store_t* store; uint32_t cur_req;
+    struct mt_pool* mt;   /* persistent threads of oracle_eval_batch_mt (CPU baseline harness) */
 };
 
 static void lru_init(lru_t* c, int64_t cache_size) {
@@ -538,8 +543,11 @@ oracle_t* oracle_create(uint64_t cache_size, uint32_t workers) {
     for (uint32_t i = 0; i < workers; i++) lru_init(&o->workers[i], (int64_t)(cache_size / workers)); /* :132 */
     return o;
 }
+struct mt_pool;
+static void mt_destroy(struct mt_pool* p);
 void oracle_destroy(oracle_t* o) {
     if (!o) return;
+    mt_destroy(o->mt);
     for (uint32_t i = 0; i < o->nworkers; i++) {
         lru_t* c = &o->workers[i];
         citem_t* e = c->head;
@@ -549,15 +557,18 @@ void oracle_destroy(oracle_t* o) {
     free(o->workers); free(o);
 }
 /* workers.go:180-184 getWorker: idx = (xxhash64(key) >> 1) / hashRingStep */
-static inline uint32_t worker_index(const oracle_t* o, uint64_t h) { return (uint32_t)((h >> 1) / o->ring_step); }
+static inline uint32_t worker_index(const oracle_t* o, uint64_t h) {
+    const uint32_t w = (uint32_t)((h >> 1) / o->ring_step);
+    return w < o->nworkers ? w : o->nworkers - 1;   /* (2^63 / W) * W < 2^63 when W is not a power of two: the last worker takes the remainder */
+}
 uint32_t oracle_worker_index_for_hash63(uint32_t workers, uint64_t hash63) {
     return (uint32_t)(hash63 / ((1ULL << 63) / workers));
 }
 
-static void load_req(const guber_batch_t* b, uint32_t i, req_t* r) {
+static void load_req_h(const guber_batch_t* b, uint32_t i, uint64_t h, req_t* r) {
     r->key = (const char*)b->key_bytes + b->key_off[i];
     r->klen = b->key_off[i + 1] - b->key_off[i];
-    r->h = oracle_xxhash64((const uint8_t*)r->key, r->klen, 0);
+    r->h = h;
     r->hits = b->hits[i]; r->limit = b->limit[i]; r->duration = b->duration[i];
     r->burst = b->burst ? b->burst[i] : 0;
     r->created_at = b->created_at ? b->created_at[i] : b->now_ms;
@@ -566,6 +577,10 @@ static void load_req(const guber_batch_t* b, uint32_t i, req_t* r) {
     r->is_owner = b->is_owner ? b->is_owner[i] : 1;
     r->greg_expire = b->greg_expire ? b->greg_expire[i] : 0;
     r->greg_duration = b->greg_duration ? b->greg_duration[i] : 0;
+}
+static void load_req(const guber_batch_t* b, uint32_t i, req_t* r) {
+    const uint8_t* k = b->key_bytes + b->key_off[i];
+    load_req_h(b, i, oracle_xxhash64(k, b->key_off[i + 1] - b->key_off[i], 0), r);
 }
 static void store_resp(guber_result_t* res, uint32_t i, const resp_t* rl) {
     res->status[i] = rl->status; res->limit[i] = rl->limit; res->remaining[i] = rl->remaining;
@@ -611,48 +626,155 @@ int oracle_eval_batch_store(oracle_t* o, const guber_batch_t* b, guber_result_t*
 /* "Reference design" multi-core evaluation for the CPU baseline: requests are routed to their
  * worker shard (workers.go:180-184) and every worker applies its own requests in request order on
  * its own thread, as the reference's worker goroutines do.  Results are identical to
- * oracle_eval_batch because shards are disjoint. */
-int oracle_eval_batch_mt(oracle_t* o, const guber_batch_t* b, guber_result_t* res, int threads) {
-    uint32_t W = o->nworkers, n = b->n;
-    uint64_t* hashes = (uint64_t*)malloc(sizeof(uint64_t) * (n ? n : 1));
-    uint32_t* widx = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-    uint32_t* start = (uint32_t*)calloc(W + 1, sizeof(uint32_t));
-    uint32_t* order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
-    uint64_t* ctr = (uint64_t*)calloc((size_t)W * 4, sizeof(uint64_t));
-#pragma omp parallel for num_threads(threads) schedule(static)
-    for (uint32_t i = 0; i < n; i++) {
-        const uint8_t* k = b->key_bytes + b->key_off[i];
-        hashes[i] = oracle_xxhash64(k, b->key_off[i + 1] - b->key_off[i], 0);
-        widx[i] = worker_index(o, hashes[i]);
+ * oracle_eval_batch because shards are disjoint.
+ *
+ * The harness keeps `threads` persistent worker threads per oracle (created on first use, pinned round-robin to the
+ * CPUs the process may run on when there are enough of them), hands a batch over with one generation counter and runs
+ * it in phases separated by spin-then-yield barriers: (1) every thread hashes a contiguous slice of the batch and
+ * counts its requests per worker; (2) per-worker totals and the slices' offsets (a parallel stable counting sort:
+ * inside a worker the request order is kept); (3) every thread applies the queues of the workers it owns (worker w
+ * belongs to thread w mod T).  Nothing is allocated per batch once the buffers have grown to the batch size. */
+struct mt_arg { struct mt_pool* p; int t; };
+struct mt_pool {
+    oracle_t* o; int T;
+    pthread_t* th;
+    volatile uint32_t gen, stop;               /* gen: a batch is posted (threads spin, then nap) */
+    volatile uint32_t bar_count, bar_gen, done;
+    const guber_batch_t* b; guber_result_t* res;
+    uint64_t* hashes; uint32_t *widx, *order, *hist /* [T][W+1] */, *start /* [W+1] */; uint32_t cap;
+    uint64_t* ctr;                              /* [W][4] per-batch counters */
+    struct mt_arg* args;
+};
+static inline void mt_relax(uint32_t* spins) {
+    if (++*spins < 2000) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    } else sched_yield();
+}
+static void mt_barrier(struct mt_pool* p) {
+    const uint32_t g = __atomic_load_n(&p->bar_gen, __ATOMIC_ACQUIRE);
+    if (__atomic_add_fetch(&p->bar_count, 1, __ATOMIC_ACQ_REL) == (uint32_t)p->T) {
+        __atomic_store_n(&p->bar_count, 0, __ATOMIC_RELAXED);
+        __atomic_store_n(&p->bar_gen, g + 1, __ATOMIC_RELEASE);
+        return;
     }
-    for (uint32_t i = 0; i < n; i++) start[widx[i] + 1]++;
-    for (uint32_t w = 0; w < W; w++) start[w + 1] += start[w];
-    uint32_t* fill = (uint32_t*)malloc(sizeof(uint32_t) * (W + 1));
-    memcpy(fill, start, sizeof(uint32_t) * (W + 1));
-    for (uint32_t i = 0; i < n; i++) order[fill[widx[i]]++] = i;
-#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
-    for (uint32_t w = 0; w < W; w++) {
+    uint32_t spins = 0;
+    while (__atomic_load_n(&p->bar_gen, __ATOMIC_ACQUIRE) == g) mt_relax(&spins);
+}
+static void mt_run_batch(struct mt_pool* p, int t) {
+    oracle_t* o = p->o;
+    const guber_batch_t* b = p->b; guber_result_t* res = p->res;
+    const uint32_t W = o->nworkers, n = b->n, T = (uint32_t)p->T;
+    const uint32_t lo = (uint32_t)((uint64_t)n * (uint32_t)t / T), hi = (uint32_t)((uint64_t)n * ((uint32_t)t + 1) / T);
+    uint32_t* myhist = p->hist + (size_t)t * (W + 1);
+    memset(myhist, 0, sizeof(uint32_t) * (W + 1));
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint8_t* k = b->key_bytes + b->key_off[i];
+        const uint64_t h = oracle_xxhash64(k, b->key_off[i + 1] - b->key_off[i], 0);
+        const uint32_t w = worker_index(o, h);
+        p->hashes[i] = h; p->widx[i] = w;
+        myhist[w]++;
+    }
+    mt_barrier(p);
+    /* for the workers this thread owns: the slices' offsets inside the worker's queue (exclusive scan over the threads) */
+    for (uint32_t w = (uint32_t)t; w < W; w += T) {
+        uint32_t acc = 0;
+        for (uint32_t q = 0; q < T; q++) { uint32_t* hq = p->hist + (size_t)q * (W + 1) + w; const uint32_t c = *hq; *hq = acc; acc += c; }
+        p->start[w + 1] = acc;                                      /* total of worker w; made a prefix by thread 0 below */
+    }
+    mt_barrier(p);
+    if (t == 0) { p->start[0] = 0; for (uint32_t w = 0; w < W; w++) p->start[w + 1] += p->start[w]; }
+    mt_barrier(p);
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t w = p->widx[i]; p->order[p->start[w] + myhist[w]++] = i; }
+    mt_barrier(p);
+    for (uint32_t w = (uint32_t)t; w < W; w += T) {
         oracle_t local = *o; /* private counters; caches are disjoint per worker */
         local.over_limit = local.hits = local.misses = local.unexpired_evictions = 0;
-        for (uint32_t p = start[w]; p < start[w + 1]; p++) {
-            uint32_t i = order[p];
+        for (uint32_t q = p->start[w]; q < p->start[w + 1]; q++) {
+            const uint32_t i = p->order[q];
             req_t r; resp_t rl;
-            load_req(b, i, &r);
+            load_req_h(b, i, p->hashes[i], &r);
             handle_get_rate_limit(&local, &o->workers[w], &r, b->now_ms, &rl);
             store_resp(res, i, &rl);
         }
-        ctr[w * 4 + 0] = local.over_limit; ctr[w * 4 + 1] = local.hits;
-        ctr[w * 4 + 2] = local.misses; ctr[w * 4 + 3] = local.unexpired_evictions;
+        p->ctr[w * 4 + 0] = local.over_limit; p->ctr[w * 4 + 1] = local.hits;
+        p->ctr[w * 4 + 2] = local.misses; p->ctr[w * 4 + 3] = local.unexpired_evictions;
     }
+    mt_barrier(p);
+}
+static void* mt_main(void* arg) {
+    struct mt_pool* p = ((struct mt_arg*)arg)->p; const int t = ((struct mt_arg*)arg)->t;
+    uint32_t seen = 0;
+    for (;;) {
+        uint32_t spins = 0, g;
+        while ((g = __atomic_load_n(&p->gen, __ATOMIC_ACQUIRE)) == seen) {
+            if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) return NULL;
+            if (++spins < 20000) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+            } else { struct timespec ts = {0, 50000}; nanosleep(&ts, NULL); }   /* idle between batches: do not burn the core */
+        }
+        seen = g;
+        mt_run_batch(p, t);
+        __atomic_add_fetch(&p->done, 1, __ATOMIC_ACQ_REL);
+    }
+}
+static void mt_destroy(struct mt_pool* p) {
+    if (!p) return;
+    __atomic_store_n(&p->stop, 1, __ATOMIC_RELEASE);
+    for (int t = 1; t < p->T; t++) pthread_join(p->th[t], NULL);
+    free(p->th); free(p->args); free(p->hashes); free(p->widx); free(p->order); free(p->hist); free(p->start); free(p->ctr);
+    free(p);
+}
+static struct mt_pool* mt_create(oracle_t* o, int T) {
+    struct mt_pool* p = (struct mt_pool*)calloc(1, sizeof(*p));
+    p->o = o; p->T = T;
+    p->th = (pthread_t*)calloc((size_t)T, sizeof(pthread_t));
+    p->args = (struct mt_arg*)calloc((size_t)T, sizeof(*p->args));
+    p->hist = (uint32_t*)calloc((size_t)T * (o->nworkers + 1), sizeof(uint32_t));
+    p->start = (uint32_t*)calloc(o->nworkers + 1, sizeof(uint32_t));
+    p->ctr = (uint64_t*)calloc((size_t)o->nworkers * 4, sizeof(uint64_t));
+    cpu_set_t allowed; int ncpu = 0; static int cpus[CPU_SETSIZE];
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    for (int t = 1; t < T; t++) {                                   /* thread 0 is the caller */
+        p->args[t].p = p; p->args[t].t = t;
+        pthread_create(&p->th[t], NULL, mt_main, &p->args[t]);
+        if (ncpu >= T) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[t % ncpu], &one); pthread_setaffinity_np(p->th[t], sizeof(one), &one); }
+    }
+    return p;
+}
+int oracle_eval_batch_mt(oracle_t* o, const guber_batch_t* b, guber_result_t* res, int threads) {
+    const uint32_t W = o->nworkers, n = b->n;
+    if (threads < 1) threads = 1;
+    if ((uint32_t)threads > W) threads = (int)W;                    /* a worker is single-threaded (workers.go:190-258) */
+    if (o->mt && o->mt->T != threads) { mt_destroy(o->mt); o->mt = NULL; }
+    if (!o->mt) o->mt = mt_create(o, threads);
+    struct mt_pool* p = o->mt;
+    if (n > p->cap) {
+        free(p->hashes); free(p->widx); free(p->order);
+        p->cap = n + n / 4 + 16;
+        p->hashes = (uint64_t*)malloc(sizeof(uint64_t) * p->cap);
+        p->widx = (uint32_t*)malloc(sizeof(uint32_t) * p->cap);
+        p->order = (uint32_t*)malloc(sizeof(uint32_t) * p->cap);
+    }
+    p->b = b; p->res = res;
+    memset(p->ctr, 0, sizeof(uint64_t) * W * 4);
+    __atomic_store_n(&p->done, 0, __ATOMIC_RELAXED);
+    __atomic_add_fetch(&p->gen, 1, __ATOMIC_ACQ_REL);
+    mt_run_batch(p, 0);
+    uint32_t spins = 0;
+    while (__atomic_load_n(&p->done, __ATOMIC_ACQUIRE) != (uint32_t)(p->T - 1)) mt_relax(&spins);
     res->over_limit_count = res->cache_hits = res->cache_misses = res->unexpired_evictions = 0;
     for (uint32_t w = 0; w < W; w++) {
-        res->over_limit_count += ctr[w * 4]; res->cache_hits += ctr[w * 4 + 1];
-        res->cache_misses += ctr[w * 4 + 2]; res->unexpired_evictions += ctr[w * 4 + 3];
+        res->over_limit_count += p->ctr[w * 4]; res->cache_hits += p->ctr[w * 4 + 1];
+        res->cache_misses += p->ctr[w * 4 + 2]; res->unexpired_evictions += p->ctr[w * 4 + 3];
     }
     o->over_limit += res->over_limit_count; o->hits += res->cache_hits;
     o->misses += res->cache_misses; o->unexpired_evictions += res->unexpired_evictions;
     res->cache_size = oracle_size(o);
-    free(hashes); free(widx); free(start); free(order); free(fill); free(ctr);
     return 0;
 }
 
