@@ -1,38 +1,48 @@
 #!/usr/bin/env python3
 """bench.py — rate-limit decisions/sec of the MI355X engine on BASELINE.json's workload.
 
-One "step" = one GetRateLimits batch of 65536 checks evaluated by the HIP path (guber_eval_batch_dev: k_front ->
-k_eval2) with every input array already resident in HBM.  Workload (BASELINE.json configs[1]):
-10M resident keys per GPU, ONE Zipf(1.1) request stream over those keys (stream seed 1234, permutation seed 99),
-TOKEN_BUCKET, hits 1, limit 100, duration 60 s, now_ms advancing 1 ms per batch.
+One "step" = one GetRateLimits batch of 65536 checks evaluated by the HIP path (k_front -> k_eval2, or their fused
+multi-table forms) with every input array already resident in HBM.  Workload (BASELINE.json configs[1], SURVEY.md section
+8d): 10M resident keys per GPU, ONE Zipf(1.1) request stream over those keys (numpy PCG64 stream seed 1234, permutation
+seed 99), TOKEN_BUCKET, hits 1, limit 100, duration 60 s, now_ms advancing 1 ms per batch.
 
-Inside a GPU the resident keys are split into S logical shards (default 12; the reference shards its key space the same
-way over Config.Workers goroutines, workers.go:19-25): S engines with their own HBM tables.  The request
-stream is routed request by request to the shard that holds the key (load-aware hash slots, gubernator_amd/shard.py
-SlotMap: 256 slots by consistent hash / k_route, slots and the few hottest keys placed on the shards by what a sample of
-earlier traffic carried; --router ring = a plain consistent hash over the shards) and every shard flushes a
-batch when 65536 requests are waiting — the policy of the reference's batcher (peer_client.go:284-337) — so batches are
-exactly 65536 requests, hot shards flush more often, and per-key request order is the stream's order.
+The stream is NEVER replayed: the timed region is max(--steps, 2048) DISTINCT batches drawn once (134 M requests touching
+~5.6 M distinct keys = ~0.8 GB of table lines at 144 B per key, 1.1 GB in 64-byte sectors — past the 256 MiB Infinity
+Cache), each with its own now_ms.  Warm-up batches, the batches used for per-kernel HIP-event timing and for the
+single-batch latency are further distinct parts of the same stream.  Key ids are drawn on the host (the canonical numpy
+generator), ranked on the device (torch.searchsorted over the exact CDF), routed to the shards and gathered into key bytes by
+device-side index ops — all outside the clock.
 
-Timing: the batches of the timed region are enqueued by ONE dispatcher (guber_eval_batches_routed_dev: round by round the
-next batch of every shard; shards that share a stream — 12 shards over 3 streams by default — share their two launches,
-k_front_multi / k_eval2_multi), or with --dispatch threads by S pre-started batcher threads, one per shard and stream
-(released by a barrier; no thread is created and nothing is allocated inside the timed region).  The region is repeated
-until it lasts at least --min-ms, whatever --steps says.  Extras in the same JSON line: `leaky` (configs[2],
-parity-gated), `shards_1` (one table, the literal single-stream configuration), `uniform` (no duplicate keys),
-`end_to_end` (host pointers in, host results out, PCIe included), `pool` (caller threads -> V1Instance::GetRateLimits ->
-the C++ GPUWorkerPool).
+Inside a GPU the resident keys are split into S logical shards (default 12; the reference shards its key space the same way
+over Config.Workers goroutines, workers.go:19-25,125-151): S engines with their own HBM tables.  Placement of keys on shards
+is the product's (guber_placement_*, gubernator_amd/csrc/placement.cpp: hash slots + individually placed hot key HASHES,
+fitted to a 2 M-request sample of earlier traffic; --router plain = untouched XXH64 ranges = the reference's getWorker).  The
+stream is split request by request by that placement, and a shard flushes a batch whenever 65536 of its requests are waiting
+— the policy of the reference's batcher (peer_client.go:284-337) — so batches are exactly 65536 requests, hot shards flush
+more often, and per-key request order is the stream's order.  The per-request routing itself is the front end's work (the
+callers of GPUWorkerPool do it while they write their requests into the shard's stage) and is NOT in the kernel-path number:
+`shards_1` is the literal single-table configuration and `pool` the full product surface, routing included.
+
+Timing: all timed batches are enqueued by ONE dispatcher call (guber_eval_batches_routed_dev: round by round the next batch
+of every shard; shards that share a stream — 12 shards over 3 streams by default — share their two launches), bracketed by
+barrier + device synchronize; nothing is created or allocated inside.  Parity is checked over the TIMED work: the oracle
+is fed the whole stream (populate, warm-up, every timed batch, in order) and every 64th timed batch's answers (plus the
+first 8 and the last) must equal the oracle's element-wise; the engine's internal-retry counter must not have moved.
+
+Extras in the same JSON line: `leaky` (configs[2], parity-gated), `expiring` (duration 500 ms: every bucket expires and is
+renewed several times under the clock), `shards_1`, `uniform` (no skew), `end_to_end` (host memory in / out, PCIe
+included), `pool` (caller threads -> V1Instance::GetRateLimits -> the C++ GPUWorkerPool, 10 M keys).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the key space is N x 10M keys sharded by the reference's
 replicated consistent hash (replicated_hash.go; 512 vnodes, fnv1, peers gpu0..gpuN-1), every rank evaluates the requests
-for the keys it owns — no data-path collective (weak scaling).
+for the keys it owns — no data-path collective (weak scaling).  --global-sync K = BASELINE config 5 on the native exchange
+(guber_comm_* + guber_global_sync: RCCL between ranks, device copies between logical ranks of one GPU).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
-import math
 import os
 import sys
 import threading
@@ -45,44 +55,49 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0           # MI355X spec (MI355X_MICROARCH.md)
+MIN_TIMED_BATCHES = 2048         # the timed region is never shorter than this many distinct batches
 BYTES_PER_DECISION = {"token": 149, "leaky": 173}   # SURVEY.md section 8d, 16-byte keys
 # split of the algorithmic bytes over the kernels that touch request / table / response data (DESIGN.md
 # "Algorithmic bytes"): k_front reads key_off 4 + key 16 + table 56 (token) / 64 (leaky); k_eval2 reads
 # the request fields 32 / 40, writes table 16 / 24 and the response 25.
-KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73, "k_resolve": 28, "k_eval": 121},
-                "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89, "k_resolve": 28, "k_eval": 145}}
+KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73},
+                "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89}}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=2048, help=f"timed batches; at least {MIN_TIMED_BATCHES} distinct batches are always timed")
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--keys", type=int, default=10_000_000, help="resident keys per GPU")
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--algo", choices=["token", "leaky"], default="token")
     ap.add_argument("--dist", choices=["zipf", "uniform"], default="zipf")
-    ap.add_argument("--min-ms", type=float, default=250.0, help="minimum duration of the timed region: the timed steps are repeated until it is reached")
-    ap.add_argument("--extras", default="leaky,shards_1,uniform,end_to_end,pool",
+    ap.add_argument("--duration-ms", type=int, default=60_000, help="RateLimitReq.duration of the stream")
+    ap.add_argument("--min-batches", type=int, default=MIN_TIMED_BATCHES, help="lower bound of the timed region in distinct batches (measurement scripts may lower it)")
+    ap.add_argument("--min-ms", type=float, default=0.0, help="accepted and ignored (the timed region is a fixed number of distinct batches, never a replay)")
+    ap.add_argument("--extras", default="leaky,expiring,shards_1,uniform,end_to_end,pool",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
+    ap.add_argument("--extra-batches", type=int, default=1024, help="timed distinct batches of the extra configurations")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
                     help="who enqueues the shards' batches: one pre-started thread per shard, or ONE dispatcher for all shards in flush order "
                          "(guber_eval_batches_routed_dev)")
-    ap.add_argument("--router", choices=["slots", "ring"], default=None,
-                    help="placement of a GPU's keys on its logical shards: load-aware hash slots (shard.SlotMap; default with --dispatch one) or "
-                         "a plain consistent hash (default with --dispatch threads)")
+    ap.add_argument("--router", choices=["placed", "plain"], default="placed",
+                    help="placement of a GPU's keys on its logical shards: guber_placement fitted to a sample of earlier traffic, or its "
+                         "untouched initial table (XXH64 ranges = the reference's getWorker)")
     ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="CPU time budget per thread count of the baseline")
-    ap.add_argument("--cpu-threads", default="1,32,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
-    ap.add_argument("--profile-steps", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the oracle parity pass")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
+    ap.add_argument("--cpu-threads", default="1,32,64,128,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
+    ap.add_argument("--profile-steps", type=int, default=128, help="distinct batches run once more with HIP events around every launch")
+    ap.add_argument("--latency-steps", type=int, default=128, help="distinct batches run one at a time for the single-batch latency")
     ap.add_argument("--shards", type=int, default=12, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
                          "engines with their own tables, the stream routed to them key by key")
-    ap.add_argument("--global-host", action="store_true", help="with --global-sync: use the host-staged exchange (global_sync.py)")
     ap.add_argument("--global-sync", type=int, default=0, metavar="K",
                     help="BASELINE config 5: every request carries GLOBAL, every rank serves ALL keys from its replica, "
-                         "and every K steps the ranks exchange pending hits / broadcast owner state (0 = off)")
+                         "and every K steps the ranks run guber_global_sync (0 = off)")
+    ap.add_argument("--logical-ranks", type=int, default=2, help="with --global-sync on ONE process: logical ranks sharing the GPU (device-copy transport)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: all ranks share GPU 0 (single-GPU box; use with --backend gloo)")
@@ -140,68 +155,119 @@ class BatcherThreads:
             t.join()
 
 
-class Rig:
-    """One measured configuration: S engines (tables + streams) over this rank's keys, a routed request sequence resident
-    in HBM, and the machinery to run it."""
+class ZipfRanker:
+    """The stream of tests/streams.py ZipfSampler (same generator, same seeds, same values), drawn in bulk: the uniforms
+    come from the canonical numpy generator, the inverse-CDF search and the rank -> key permutation run on the device."""
 
-    def __init__(self, ctx, algo, dist_kind, S, flags=0, max_key_bytes=0):
+    def __init__(self, torch, dev, n_keys, s=1.1, seed=1234, perm_seed=99):
+        w = 1.0 / np.power(np.arange(1, n_keys + 1, dtype=np.float64), s)
+        cdf = np.cumsum(w)
+        cdf /= cdf[-1]
+        self.torch, self.dev, self.n_keys = torch, dev, n_keys
+        self.d_cdf = torch.from_numpy(cdf).to(dev)
+        self.d_perm = torch.from_numpy(np.random.default_rng(perm_seed).permutation(n_keys).astype(np.int32)).to(dev)
+        self.rng = np.random.default_rng(seed)
+
+    def draw_dev(self, n, chunk=1 << 25):
+        """-> int32 device tensor of n local key ids"""
+        torch = self.torch
+        out = torch.empty(n, dtype=torch.int32, device=self.dev)
+        for lo in range(0, n, chunk):
+            m = min(chunk, n - lo)
+            u = torch.from_numpy(self.rng.random(m)).to(self.dev)
+            r = torch.searchsorted(self.d_cdf, u, right=False).clamp_(max=self.n_keys - 1)
+            out[lo:lo + m] = self.d_perm[r]
+        return out
+
+
+def split_stream(torch, d_ids, d_sown, S, B, total):
+    """One request stream (d_ids: key ids in arrival order) -> the first `total` batches in flush order when every shard
+    flushes a batch as soon as B of its requests are waiting (peer_client.go:284-337): (ids[total, B], shard of every batch).
+    Inside a batch and between the batches of one shard the stream's order is kept."""
+    if S <= 1:
+        if d_ids.numel() < total * B:
+            raise SystemExit("stream too short for the requested number of batches")
+        return d_ids[:total * B].view(total, B), [0] * total
+    d_sh = d_sown.index_select(0, d_ids)
+    order = torch.sort(d_sh, stable=True).indices                    # stream positions grouped by shard, ascending inside
+    counts = torch.bincount(d_sh.to(torch.int32), minlength=S).cpu().numpy()
+    del d_sh
+    rows, meta, start = [], [], 0
+    for j in range(S):
+        nb = int(counts[j]) // B
+        if nb:
+            pos = order[start:start + nb * B].view(nb, B)
+            rows.append(pos)
+            last = pos[:, B - 1].cpu().numpy()
+            meta += [(int(last[k]), j) for k in range(nb)]           # a batch is flushed when its last request arrives
+        start += int(counts[j])
+    idx = sorted(range(len(meta)), key=lambda q: meta[q][0])[:total]
+    if len(idx) < total:
+        raise SystemExit("stream too short for the requested number of batches")
+    # a batch flushed at position p is complete only if the stream was drawn at least up to p: true for every batch kept
+    sel = torch.cat(rows, 0).index_select(0, torch.tensor(idx, device=d_ids.device))
+    return d_ids.index_select(0, sel.reshape(-1)).view(total, B), [meta[q][1] for q in idx]
+
+
+class Rig:
+    """One measured configuration: S engines (tables + streams) over this rank's keys, a routed non-repeating request stream
+    resident in HBM, and the machinery to run it."""
+
+    def __init__(self, ctx, algo, dist_kind, S, flags=0, max_key_bytes=0, duration_ms=60_000):
         import torch
         import gubernator_amd as ga
         import streams
-        from gubernator_amd import shard
         self.ctx, self.algo, self.dist_kind, self.S = ctx, algo, dist_kind, S
+        self.duration_ms = int(duration_ms)
         self.dispatch = getattr(ctx, "dispatch", "threads")
         self.algo_id = 0 if algo == "token" else 1
         self.torch, self.ga, self.streams = torch, ga, streams
-        dev, K, B = ctx.dev, ctx.K, ctx.B
+        dev, B = ctx.dev, ctx.B
         self.sstreams = [torch.cuda.Stream(device=dev) for _ in range(S)]
         if self.dispatch == "one":             # one dispatcher: shards that share a stream share launches
             ns = max(1, min(S, int(getattr(ctx, "streams", 1))))
             self.sstreams = [self.sstreams[j * ns // S] for j in range(S)]
         nk = len(ctx.my_ids)
-        # logical shards inside this GPU: the rank's keys are placed on them first (k_route on a scratch engine), then every
-        # shard gets a table for the keys it really holds (+ 25 %)
-        router_engine = ga.Engine(cache_size=1024, device=ctx.local_rank, max_batch=1024) if S > 1 else None
-        self.engines = [router_engine]
+        # logical shards inside this GPU: the product's placement (guber_placement_*) says which shard holds a key; every shard
+        # then gets a table for the keys it really holds (+ 25 %)
         self.placement = None
-        if S > 1 and getattr(ctx, "router", "slots") == "slots":
-            # load-aware placement (gubernator_amd/shard.py SlotMap): keys -> 256 hash slots (k_route), slots and the few keys
-            # that alone outweigh a slot -> shards by what an earlier sample of the traffic carried
-            sm = shard.SlotMap(S)
-            slot_of = np.concatenate([ctx.route_on_device(self.engines[0], sm.ring, *streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 4_000_000]))
-                                      for lo in range(0, nk, 4_000_000)]).astype(np.int64)
-            observed = (streams.ZipfSampler(nk, s=1.1, seed=990_001 + ctx.rank, perm_seed=99).draw(1 << 21) if dist_kind == "zipf"
-                        else np.zeros(0, np.int64))
-            self.sown = sm.place(slot_of, observed).astype(np.uint8)
-            self.placement = {"router": "256 hash slots placed on the shards by observed load (2 M earlier requests), hot keys individually",
-                              "keys_placed_individually": int(len(sm.hot_ids)), "expected_share_max": round(float(sm.load.max()), 4),
-                              "expected_share_min": round(float(sm.load.min()), 4)}
-            sm.close()
-        elif S > 1:
-            sring = ga.Ring([f"gpu{ctx.rank}-shard{j}" for j in range(S)], 512, "fnv1")
-            self.sown = np.concatenate([ctx.route_on_device(self.engines[0], sring, *streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 4_000_000]))
-                                        for lo in range(0, nk, 4_000_000)]).astype(np.uint8)
-            sring.close()
-            self.placement = {"router": "replicated consistent hash over the shards (512 vnodes, fnv1)"}
+        self.place = None
+        if S > 1:
+            self.place = ga.Placement(S)
+            info = {"router": "guber_placement: 4096 XXH64-range slots -> shards (initial table = the reference's getWorker, workers.go:180-184)"}
+            if getattr(ctx, "router", "placed") == "placed" and dist_kind == "zipf":
+                # fitted to what an earlier sample of the traffic carried (2 M requests of the same distribution, another seed)
+                obs = streams.ZipfSampler(nk, s=1.1, seed=990_001 + ctx.rank, perm_seed=99).draw(1 << 21)
+                self.place.observe_keys(*streams.keys_for_ids(ctx.table, ctx.my_ids[obs]))
+                self.place.rebalance(0.125, True)
+                info = {"router": "guber_placement (C++, on key hashes): 4096 XXH64-range slots and the keys that alone outweigh 1/8 of a shard's fair "
+                                  "share placed longest-processing-time-first on what 2 M earlier requests carried",
+                        "keys_placed_individually": self.place.n_hot()}
+            sown = np.empty(nk, np.uint8 if S <= 256 else np.uint16)
+            for lo in range(0, nk, 2_000_000):
+                sh, _ = self.place.route_keys(*streams.keys_for_ids(ctx.table, ctx.my_ids[lo:lo + 2_000_000]))
+                sown[lo:lo + len(sh)] = sh
+            self.sown = sown
+            self.placement = info
         else:
             self.sown = np.zeros(nk, np.uint8)
         self.local_of_shard = [np.nonzero(self.sown == j)[0] for j in range(S)]
-        if router_engine is not None:
-            router_engine.close()
         self.engines = [ga.Engine(cache_size=len(self.local_of_shard[j]) + len(self.local_of_shard[j]) // 4 + 1024, device=ctx.local_rank, max_batch=B,
                                   stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
         # arrays every batch of this rig shares (fixed-width keys, constant request fields)
         L = ctx.table.shape[1]
+        self.L = L
         self.t_off = torch.from_numpy((np.arange(B + 1, dtype=np.int64) * L).astype(np.int32)).to(dev)
         self.t_hits1 = torch.full((B,), 1, dtype=torch.int64, device=dev)
         self.t_hits0 = torch.zeros((B,), dtype=torch.int64, device=dev)
         self.t_limit = torch.full((B,), 100, dtype=torch.int64, device=dev)
-        self.t_dur = torch.full((B,), 60_000, dtype=torch.int64, device=dev)
+        self.t_dur = torch.full((B,), self.duration_ms, dtype=torch.int64, device=dev)
         self.t_algo = torch.full((B,), self.algo_id, dtype=torch.uint8, device=dev)
         self.t_beh = torch.full((B,), 2 if (flags & ga.FLAG_GLOBAL) else 0, dtype=torch.int32, device=dev)
         self.scratch = [self.DevResult(self, B) for _ in range(S)]
-        self.workers = BatcherThreads(S) if S > 1 else None
+        self.workers = BatcherThreads(S) if (S > 1 and self.dispatch == "threads") else None
         self.keep = []          # tensors referenced by C structs
+        self.d_keytab = torch.from_numpy(np.ascontiguousarray(ctx.table[ctx.my_ids])).to(dev)      # (nk, L) key bytes by local id
 
     class DevResult:
         def __init__(self, rig, n):
@@ -221,102 +287,91 @@ class Rig:
                 getattr(h, name)[:] = getattr(self, name).cpu().numpy()
             return h
 
-    def dev_batch(self, ids, now_ms, hits=1, owner_ptr=None):
-        """GuberBatch over global key ids `ids` (device pointers); len(ids) <= B"""
-        torch, ga = self.torch, self.ga
-        kb, _ = self.streams.keys_for_ids(self.ctx.table, ids)
-        t_keys = torch.from_numpy(kb).to(self.ctx.dev)
-        self.keep.append(t_keys)
-        return ga.GuberBatch(len(ids), 0, t_keys.data_ptr(), self.t_off.data_ptr(),
+    def batch_struct(self, keys_ptr, n, now_ms, hits=1, owner_ptr=None):
+        ga = self.ga
+        return ga.GuberBatch(n, 0, keys_ptr, self.t_off.data_ptr(),
                              (self.t_hits1 if hits else self.t_hits0).data_ptr(), self.t_limit.data_ptr(), self.t_dur.data_ptr(),
                              None, None, self.t_algo.data_ptr(), self.t_beh.data_ptr(), owner_ptr, None, None, int(now_ms))
 
     def populate(self, now0):
         """residency: every owned key gets a bucket before anything is timed (hits 0 = create, consume nothing)"""
-        B = self.ctx.B
+        torch, B, L = self.torch, self.ctx.B, self.L
+        pad = torch.zeros(8, dtype=torch.uint8, device=self.ctx.dev)
         for j in range(self.S):
-            ids = self.ctx.my_ids[self.local_of_shard[j]]
-            for lo in range(0, len(ids), B):
-                b = self.dev_batch(ids[lo:lo + B], now0, hits=0)
-                self.engines[j].eval_dev(b, self.scratch[j].c)
+            loc = torch.from_numpy(self.local_of_shard[j]).to(self.ctx.dev)
+            for lo in range(0, len(loc), B):
+                sel = loc[lo:lo + B]
+                kb = torch.cat([self.d_keytab.index_select(0, sel).reshape(-1), pad])
+                self.engines[j].eval_dev(self.batch_struct(kb.data_ptr(), len(sel), now0, hits=0), self.scratch[j].c)
                 self.engines[j].synchronize()
-                self.keep.pop()
         return sum(e_.size() for e_ in self.engines)
 
-    def build_sequence(self, total, now0, seed):
-        """Draw ONE request stream over this rank's keys, route it to the shards, flush a shard's batch whenever B requests
-        are waiting (batches in flush order).  -> list of (shard, global ids of the batch, now_ms)."""
-        B, S = self.ctx.B, self.S
+    def build_stream(self, total, now0, seed):
+        """Draw ONE request stream over this rank's keys, split it by the placement, flush a shard's batch whenever B of its
+        requests are waiting; keep the first `total` batches in flush order.  Everything stays on the device; the local key
+        ids of every batch also go to the host for the oracle.  Sets seq = [(shard, now_ms)], d_keys (all batches' key bytes,
+        batch s at offset s*B*L), h_ids[(total, B)]."""
+        torch, B, S, L, dev = self.torch, self.ctx.B, self.S, self.L, self.ctx.dev
         nk = len(self.ctx.my_ids)
+        n = (total + 2 * S + 2) * B
         if self.dist_kind == "zipf":
-            smp = self.streams.ZipfSampler(nk, s=1.1, seed=seed, perm_seed=99)
-            draw = smp.draw
+            d_ids = ZipfRanker(torch, dev, nk, s=1.1, seed=seed, perm_seed=99).draw_dev(n)
         else:
-            rg = np.random.default_rng(seed)
-            draw = (lambda n: rg.permutation(nk)[:n]) if B * S <= nk else (lambda n: rg.integers(0, nk, n))
-        pend_ids = [np.zeros(0, np.int64) for _ in range(S)]
-        pend_pos = [np.zeros(0, np.int64) for _ in range(S)]
-        out, offset = [], 0
-        while len(out) < total + S:        # a few more than needed, then cut in flush order
-            li = draw(B * S)
-            sh = self.sown[li]
-            pos = offset + np.arange(len(li), dtype=np.int64)
-            offset += len(li)
-            for j in range(S):
-                m = sh == j if S > 1 else slice(None)
-                pend_ids[j] = np.concatenate([pend_ids[j], li[m]])
-                pend_pos[j] = np.concatenate([pend_pos[j], pos[m]])
-                while len(pend_ids[j]) >= B:
-                    out.append((int(pend_pos[j][B - 1]), j, pend_ids[j][:B]))
-                    pend_ids[j], pend_pos[j] = pend_ids[j][B:], pend_pos[j][B:]
-        out.sort(key=lambda x: x[0])
-        return [(j, self.ctx.my_ids[li], now0 + 1 + s) for s, (_, j, li) in enumerate(out[:total])]
+            d_ids = torch.from_numpy(np.random.default_rng(seed).integers(0, nk, n, dtype=np.int32)).to(dev)
+        d_sown = torch.from_numpy(self.sown.astype(np.uint8)).to(dev) if S > 1 else None
+        d_bids, shard_of = split_stream(torch, d_ids, d_sown, S, B, total)
+        del d_ids
+        self.seq = [(shard_of[s], now0 + 1 + s) for s in range(total)]
+        self.h_ids = d_bids.cpu().numpy()
+        d_keys = torch.empty(total * B * L + 8, dtype=torch.uint8, device=dev)
+        d_keys[-8:] = 0
+        step = 256
+        for lo in range(0, total, step):
+            hi = min(total, lo + step)
+            d_keys[lo * B * L:hi * B * L] = self.d_keytab.index_select(0, d_bids[lo:hi].reshape(-1)).reshape(-1)
+        self.d_keys = d_keys
+        self.distinct_keys = int(torch.unique(d_bids).numel())
+        del d_bids
+        self.batches = [self.batch_struct(d_keys.data_ptr() + s * B * L, B, self.seq[s][1]) for s in range(total)]
+        torch.cuda.synchronize(dev)
 
-    def load_sequence(self, seq, keep_first):
-        """device batches + result targets for a sequence; the first `keep_first` batches keep their results"""
-        B = self.ctx.B
-        self.seq = seq
-        self.batches = [self.dev_batch(ids, now) for (_, ids, now) in seq]
-        self.kept = [self.DevResult(self, B) for _ in range(min(keep_first, len(seq)))]
+    def keep_results(self, which):
+        self.kept = {s: self.DevResult(self, self.ctx.B) for s in which}
 
-    def _arrays(self, lo, hi, keep):
+    def _arrays(self, lo, hi):
         """per shard: ctypes arrays (GuberBatch[], GuberResult[], count) of the sequence's batches lo..hi in order"""
         ga = self.ga
         per = []
         for j in range(self.S):
             idx = [s for s in range(lo, hi) if self.seq[s][0] == j]
             ba = (ga.GuberBatch * max(len(idx), 1))(*[self.batches[s] for s in idx])
-            ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if (keep and s < len(self.kept)) else self.scratch[j].c) for s in idx])
+            ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if s in self.kept else self.scratch[j].c) for s in idx])
             per.append((ba, ra, len(idx)))
         return per
 
-    def _routed(self, lo, hi, keep):
+    def _routed(self, lo, hi):
         """the sequence's batches lo..hi in flush order for ONE dispatcher: (which[], GuberBatch[], GuberResult[], count)"""
-        import ctypes as C
         ga = self.ga
         idx = list(range(lo, hi))
         wa = (C.c_uint32 * max(len(idx), 1))(*[self.seq[s][0] for s in idx])
         ba = (ga.GuberBatch * max(len(idx), 1))(*[self.batches[s] for s in idx])
-        ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if (keep and s < len(self.kept)) else self.scratch[self.seq[s][0]].c) for s in idx])
+        ra = (ga.GuberResult * max(len(idx), 1))(*[(self.kept[s].c if s in self.kept else self.scratch[self.seq[s][0]].c) for s in idx])
         return wa, ba, ra, len(idx)
 
-    def run(self, lo, hi, repeats=1, keep=False, timed=False):
-        """enqueue batches lo..hi of the sequence `repeats` times.  timed: returns (wall seconds, max per-stream event ms)"""
+    def run(self, lo, hi, timed=False):
+        """enqueue batches lo..hi of the sequence once.  timed: returns (wall seconds, max per-stream event ms)"""
         torch = self.torch
-        per = self._arrays(lo, hi, keep)
-        if self.dispatch == "one" and self.S > 1:
-            wa, ba1, ra1, cnt1 = self._routed(lo, hi, keep)
+        one = self.dispatch == "one" and self.S > 1
+        if one:
+            wa, ba1, ra1, cnt1 = self._routed(lo, hi)
+        else:
+            per = self._arrays(lo, hi)
 
-        def job(j):
-            ba, ra, cnt = per[j]
-            eng = self.engines[j]
-
-            def f():
-                for _ in range(repeats):
-                    if cnt:
-                        eng.eval_many_dev(ba, ra, cnt)
-            return f
-        jobs = [job(j) for j in range(self.S)]
+            def job(j):
+                ba, ra, cnt = per[j]
+                eng = self.engines[j]
+                return (lambda: eng.eval_many_dev(ba, ra, cnt)) if cnt else None
+            jobs = [job(j) for j in range(self.S)]
         ev0 = ev1 = None
         if timed:
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(self.S)]
@@ -326,13 +381,15 @@ class Rig:
             for j in range(self.S):
                 ev0[j].record(self.sstreams[j])
         t0 = time.perf_counter()
-        if self.dispatch == "one" and self.S > 1:
-            for _ in range(repeats):
-                self.ga.Engine.eval_routed_dev(self.engines, wa, ba1, ra1, cnt1)
+        if one:
+            self.ga.Engine.eval_routed_dev(self.engines, wa, ba1, ra1, cnt1)
         elif self.workers is not None:
             self.workers.run(jobs)
         else:
-            jobs[0]()
+            for f in jobs:
+                if f:
+                    f()
+        t_enq = time.perf_counter()
         if timed:
             for j in range(self.S):
                 ev1[j].record(self.sstreams[j])
@@ -341,47 +398,40 @@ class Rig:
         if timed:
             self.ctx.barrier()
             self.last_stream_ms = [ev0[j].elapsed_time(ev1[j]) for j in range(self.S)]
-            self.last_stream_batches = [per[j][2] * repeats for j in range(self.S)]
+            self.last_stream_batches = [sum(1 for s in range(lo, hi) if self.seq[s][0] == j) for j in range(self.S)]
+            self.last_enqueue_s = t_enq - t0
             return t1 - t0, max(self.last_stream_ms)
         return t1 - t0, None
 
-    def measure(self, steps, warmup, min_ms, now0, seed, keep_first=8):
-        """warm up, calibrate the repeat count, time.  -> dict"""
+    def measure(self, steps, warmup, now0, seed, profile_steps=0, latency_steps=0):
+        """build the stream, warm up, time `steps` distinct batches once.  -> dict"""
         ctx = self.ctx
-        seq = self.build_sequence(warmup + steps, now0, seed)
-        self.load_sequence(seq, keep_first)
+        total = warmup + steps + profile_steps + latency_steps
+        self.warmup, self.steps, self.profile_steps, self.latency_steps = warmup, steps, profile_steps, latency_steps
+        self.build_stream(total, now0, seed)
+        lo, hi = warmup, warmup + steps
+        self.keep_results(sorted(set(range(lo, min(hi, lo + 8))) | set(range(lo, hi, 64)) | {hi - 1}))
+        retries0 = sum(e.stats()["retries"] for e in self.engines)
         if warmup:
-            self.run(0, warmup, keep=True)
-        cal, _ = self.run(warmup, warmup + steps, keep=True)          # first execution of the timed steps: calibration (untimed)
-        cal = ctx.max_over_ranks(cal)
-        repeats = max(1, int(math.ceil(min_ms * 1e-3 / max(cal, 1e-6))))
-        for _ in range(3):                     # the calibration pass runs cold: repeat until the timed region really lasts min_ms
-            wall, ev_ms = self.run(warmup, warmup + steps, repeats=repeats, timed=True)
-            wall = ctx.max_over_ranks(wall)
-            if wall * 1e3 >= 0.95 * min_ms:
-                break
-            repeats = int(math.ceil(repeats * min_ms * 1e-3 / wall * 1.1))
-        n_batches = steps * repeats
-        return {"value": n_batches * ctx.B * ctx.world / wall, "ms_per_step": wall / n_batches * 1e3, "repeats": repeats,
-                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / n_batches, "steps": steps,
+            self.run(0, warmup)
+        wall, ev_ms = self.run(lo, hi, timed=True)
+        wall = ctx.max_over_ranks(wall)
+        self.retries = sum(e.stats()["retries"] for e in self.engines) - retries0
+        B = ctx.B
+        return {"value": steps * B * ctx.world / wall, "ms_per_step": wall / steps * 1e3, "timed_batches": steps,
+                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / steps, "enqueue_ms": self.last_enqueue_s * 1e3,
+                "distinct_keys_in_stream": self.distinct_keys,
+                "internal_retries": int(self.retries),
                 "shard_streams": [{"batches": b, "stream_ms": round(m, 3), "us_per_batch": round(m * 1e3 / max(b, 1), 2)}
                                   for b, m in zip(self.last_stream_batches, self.last_stream_ms)]}
 
-    def kernel_profile(self, n_steps, lo, hi):
-        """per-kernel durations with one batch in flight on shard 0 (HIP events around every launch)"""
-        eng = self.engines[0]
-        idx = [s for s in range(lo, hi) if self.seq[s][0] == 0] or [lo]
-        eng.profile(True)
-        eng.profile_read()
-        for k in range(n_steps):
-            eng.eval_dev(self.batches[idx[k % len(idx)]], self.scratch[0].c)
-        prof = eng.profile_read()
-        eng.profile(False)
-        return {k: (ms / n if n else 0.0) for k, (n, ms) in prof.items()}
-
-    def kernel_profile_routed(self, lo, hi):
-        """one dispatcher: the timed steps once more with HIP events around every (fused) launch, all shards overlapping as in
-        the timed region.  -> ({kernel: avg ms per launch}, {kernel: avg requests per launch})"""
+    def kernel_profile(self):
+        """the profile segment (distinct batches after the timed ones), dispatched exactly like the timed region, with HIP events
+        around every launch.  -> ({kernel: avg ms per launch}, {kernel: avg requests per launch}, {kernel: launches})"""
+        lo = self.warmup + self.steps
+        hi = lo + self.profile_steps
+        if hi <= lo:
+            return {}, {}, {}
         for e in self.engines:
             e.profile(True)
             e.profile_read()
@@ -394,71 +444,102 @@ class Rig:
                 n[k] = n.get(k, 0) + cnt
                 ms[k] = ms.get(k, 0.0) + tot
                 units[k] = units.get(k, 0) + e.last_profile_units.get(k, 0)
-        return ({k: ms[k] / n[k] for k in n if n[k]}, {k: units[k] / n[k] for k in n if n[k]})
+        return ({k: ms[k] / n[k] for k in n if n[k]}, {k: units[k] / n[k] for k in n if n[k]}, {k: n[k] for k in n if n[k]})
 
-    def latency(self, lo, hi, n=256):
-        """single-batch latency: submit -> complete, one batch in flight (BASELINE metric: p99 batch latency)"""
+    def latency(self):
+        """single-batch latency: submit -> complete, one batch in flight, every batch a fresh one (BASELINE metric: p99 batch latency)"""
         torch = self.torch
-        eng, stream = self.engines[0], self.sstreams[0]
-        idx = [s for s in range(lo, hi) if self.seq[s][0] == 0] or [lo]
+        lo = self.warmup + self.steps + self.profile_steps
+        hi = lo + self.latency_steps
         lat = []
-        for k in range(n):
+        for s in range(lo, hi):
+            j = self.seq[s][0]
+            eng, stream = self.engines[j], self.sstreams[j]
             a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(stream)
-            eng.eval_dev(self.batches[idx[k % len(idx)]], self.scratch[0].c)
+            eng.eval_dev(self.batches[s], self.scratch[j].c)
             b_.record(stream)
             b_.synchronize()
             lat.append(a.elapsed_time(b_) * 1e3)
+        if not lat:
+            return None
         lat.sort()
         return {"unit": "us", "p50": round(percentile(lat, 0.5), 2), "p99": round(percentile(lat, 0.99), 2), "min": round(lat[0], 2),
-                "n": len(lat), "what": f"one {self.ctx.B}-request batch, HIP events around guber_eval_batch_dev, nothing else in flight"}
+                "n": len(lat), "what": f"one {self.ctx.B}-request batch (each a fresh part of the stream), HIP events around guber_eval_batch_dev, nothing else in flight"}
 
-    def host_batches(self, lo, hi):
-        return [self.streams.bench_batch(self.ctx.table, self.seq[s][1], self.seq[s][2], algorithm=self.algo_id) for s in range(lo, hi)]
+    def host_batch(self, s):
+        ids = self.ctx.my_ids[self.h_ids[s]]
+        return self.streams.bench_batch(self.ctx.table, ids, self.seq[s][1], algorithm=self.algo_id, duration=self.duration_ms)
 
     def close(self):
         if self.workers is not None:
             self.workers.close()
         for e_ in self.engines:
             e_.close()
+        if self.place is not None:
+            self.place.close()
         self.keep.clear()
         self.batches = []
+        self.d_keys = None
+        self.d_keytab = None
+        self.kept = {}
 
 
-def parity_gate(rig, orc, threads, now0, label):
-    """the GPU's answers for the first kept batches of the rig's sequence against the oracle evaluating the same
-    batches in the same order; returns (ok, oracle outputs consumed)"""
-    import support
+def oracle_populate(rig, orc, threads, now0):
     ctx = rig.ctx
     for lo in range(0, len(ctx.my_ids), 1 << 18):
-        orc.eval(rig.streams.bench_batch(ctx.table, ctx.my_ids[lo:lo + (1 << 18)], now0, hits=0, algorithm=rig.algo_id), threads=threads)
-    ok = True
-    hb = rig.host_batches(0, len(rig.kept))
-    for s, b in enumerate(hb):
-        want = orc.eval(b, threads=threads)
-        try:
-            support.assert_results_equal(rig.kept[s].host(), want, f"{label} batch {s}")
-        except AssertionError as ex:
-            ok = False
-            print("PARITY FAILURE:", ex, file=sys.stderr)
-    return ok
+        orc.eval(rig.streams.bench_batch(ctx.table, ctx.my_ids[lo:lo + (1 << 18)], now0, hits=0, algorithm=rig.algo_id, duration=rig.duration_ms),
+                 threads=threads)
 
 
-def cpu_baseline(rig, orc_by_threads, lo, hi, seconds):
-    """the oracle in the reference's worker-sharded design (oracle_eval_batch_mt: XXH64-range sharding to W worker caches,
-    one thread per worker) on this host's cores, same resident keys, same stream, a time-bounded sample per W"""
-    hb = rig.host_batches(lo, hi)
-    res = {}
-    for w, orc in orc_by_threads.items():
-        done, t0 = 0, time.perf_counter()
-        while True:
-            orc.eval(hb[done % len(hb)], threads=(w if w > 1 else 0))
-            done += 1
-            el = time.perf_counter() - t0
-            if el >= seconds:                      # the sample is bounded by time: the stream's batches are replayed until it is up
-                break
-        res[w] = (done * rig.ctx.B / el, done, el)
-    return res
+def parity_over_timed_work(rig, orc, threads, now0, label):
+    """The oracle is fed what the engine was fed — populate, warm-up, every timed batch, in order, with the same clocks — and
+    the engine's kept answers (every 64th timed batch, the first 8, the last) must equal the oracle's element-wise.
+    -> (ok, compared batches, oracle seconds for the timed batches)"""
+    import support
+    oracle_populate(rig, orc, threads, now0)
+    ok, compared, el = True, 0, 0.0
+    for s in range(0, rig.warmup + rig.steps):
+        hb = rig.host_batch(s)
+        t0 = time.perf_counter()
+        want = orc.eval(hb, threads=threads)
+        if s >= rig.warmup:
+            el += time.perf_counter() - t0
+        if s in rig.kept:
+            compared += 1
+            try:
+                support.assert_results_equal(rig.kept[s].host(), want, f"{label} batch {s}")
+            except AssertionError as ex:
+                ok = False
+                print("PARITY FAILURE:", ex, file=sys.stderr)
+    return ok, compared, el
+
+
+def cpu_baseline_sample(rig, orc, w, now0, seconds):
+    """one thread count of the CPU baseline: a fresh oracle with W worker caches / threads, the same resident keys, the timed
+    stream's batches from its beginning for a bounded time"""
+    th = w if w > 1 else 0
+    oracle_populate(rig, orc, th, now0)
+    done, t0 = 0, time.perf_counter()
+    for s in range(rig.warmup, rig.warmup + rig.steps):
+        orc.eval(rig.host_batch(s), threads=th)
+        done += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    el = time.perf_counter() - t0
+    return done * rig.ctx.B / el, done, el
+
+
+def rocprof_reference(algo):
+    """the committed rocprofv3 summary of this command (profiles/r03_rocprof_summary.json), if any: the same formula on its
+    average kernel duration, so that the line and the file can be checked against each other"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "r03_rocprof_summary.json")))
+        k = j["dominant_kernel"]
+        return {"file": "profiles/r03_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "requests_per_launch": k["requests_per_launch"],
+                "achieved": k["achieved_GBps"], "frac": k["frac"], "command": j.get("command")}
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def main():
@@ -492,7 +573,7 @@ def main():
     ctx.K, ctx.B = args.keys, args.batch
     ctx.dispatch = args.dispatch
     ctx.streams = args.streams
-    ctx.router = args.router or ("slots" if args.dispatch == "one" else "ring")
+    ctx.router = args.router
     ctx.barrier = (lambda: dist.barrier()) if world > 1 else (lambda: None)
     ctx.max_over_ranks = lambda v: shard.max_over_ranks(v, device=red_dev)
     K, B = args.keys, args.batch
@@ -521,66 +602,53 @@ def main():
 
     S = max(1, args.shards)
     seed = 1234 + rank * 64
-    rig = Rig(ctx, args.algo, args.dist, S)
+    steps = max(args.steps, args.min_batches)
+    rig = Rig(ctx, args.algo, args.dist, S, duration_ms=args.duration_ms)
     resident = rig.populate(NOW0)
-    m = rig.measure(args.steps, args.warmup, args.min_ms, NOW0, seed)
-    lo, hi = args.warmup, args.warmup + args.steps
+    m = rig.measure(steps, args.warmup, NOW0, seed, profile_steps=max(0, args.profile_steps), latency_steps=max(0, args.latency_steps))
 
     roofline = latency = cpu = parity = None
     extras = {}
     if rank == 0:
-        # ---- per-kernel durations (HIP events on the engine stream around every launch), one batch in flight ----
+        # ---- per-kernel durations: HIP events around every launch of the profile segment, dispatched like the timed region ----
         fused = args.dispatch == "one" and S > 1
-        per_launch = {}
-        if args.profile_steps <= 0:
-            kernel_ms = {}
-        elif fused:
-            kernel_ms, per_launch = rig.kernel_profile_routed(lo, hi)
-        else:
-            kernel_ms = rig.kernel_profile(args.profile_steps, lo, hi)
-        latency = rig.latency(lo, hi)
+        kernel_ms, per_launch, launches = rig.kernel_profile()
+        latency = rig.latency()
         cand = {k: v for k, v in kernel_ms.items() if k in KERNEL_BYTES[args.algo] and v > 0}
         if cand:
             # the dominant kernel = the one the GPU spends most time in; its bytes per launch = bytes per request x the
             # requests one launch carries (a fused launch carries the batches of up to four shards)
-            dom = max(cand, key=cand.get)
+            dom = max(cand, key=lambda k: cand[k] * launches.get(k, 1))
             dom_bytes = int(KERNEL_BYTES[args.algo][dom] * per_launch.get(dom, B))
             achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
             traffic = measured = None
-            tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(args.algo, {}).get(dom.replace("_multi", ""))        # PMC bytes per 65536-request launch (profiles/)
-                if traffic and dom in per_launch:
-                    traffic = int(traffic * per_launch[dom] / B)
-                hp = json.load(open(os.path.join(ROOT, "profiles", "hbm_peak.json")))
-                cor = sum(tj.get(args.algo, {}).get(k, 0) for k in ("k_front", "k_eval2"))
-                raw = sum(tj.get(args.algo + "_raw", {}).get(k, 0) for k in ("k_front", "k_eval2"))
-                if cor and raw:
-                    g_raw, g_cor = (x / (m["ms_per_step"] * 1e-3) / 1e9 for x in (raw, cor))
-                    measured = {"stream_read_GBps": hp["stream_read_GBps"], "random_gather_GBps": hp["random_gather_128B_GBps"],
-                                "hbm_traffic_bytes_per_batch": {"raw": raw, "corrected": cor, "source": tj.get("source", "profiles/roofline_traffic.json")},
-                                "hbm_traffic_GBps": {"raw": round(g_raw, 1), "corrected": round(g_cor, 1)},
-                                "frac_of_random_gather": {"raw": round(g_raw / hp["random_gather_128B_GBps"], 4),
-                                                          "corrected": round(g_cor / hp["random_gather_128B_GBps"], 4)}}
+                tj = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+                traffic = tj.get(args.algo, {}).get(dom.replace("_multi", ""))        # PMC bytes per 65536-request batch (profiles/)
+                if traffic:
+                    traffic = int(traffic * per_launch.get(dom, B) / B)
+                measured = tj.get("note")
             except Exception:   # noqa: BLE001
                 pass
             pipe = BYTES_PER_DECISION[args.algo] * B / (m["ms_per_step"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_note": measured,
                         "algorithmic_bytes_per_launch": dom_bytes,
-                        "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items() if v > 0},
+                        "bytes_per_request": KERNEL_BYTES[args.algo][dom],
                         "requests_per_launch": round(per_launch.get(dom, B), 1),
-                        "kernel_timing": ("HIP events around every launch on the shards' stream while the timed steps run once more, all shards "
-                                          "overlapping: a launch carries the next batch of up to four shards (k_front_multi / k_eval2_multi)") if fused
-                        else "HIP events around every launch on the engine stream, one batch in flight",
-                        "measured_ceilings": measured,
+                        "kernel_avg_us": {k: round(v * 1e3, 2) for k, v in kernel_ms.items() if v > 0},
+                        "launches_profiled": launches,
+                        "kernel_timing": (f"HIP events around every launch of {args.profile_steps} further distinct batches dispatched exactly like the timed "
+                                          "region (all shards' streams overlapping; a launch carries the next batch of up to four shards).  The durations "
+                                          "include the contention between the streams and overlap in time: they cannot be summed to the step time") if fused
+                        else f"HIP events around every launch of {args.profile_steps} further distinct batches on the engine stream, one batch in flight",
+                        "rocprof": rocprof_reference(args.algo),
                         "pipeline": {"bytes_per_decision": BYTES_PER_DECISION[args.algo],
                                      "ms_per_batch": round(m["ms_per_step"], 5),
                                      "achieved": round(pipe, 2), "frac": round(pipe / HBM_PEAK_GBPS, 6),
                                      "what": "algorithmic bytes of the whole pipeline / timed ms per step (all shards overlapping)"}}
 
-    # ---- CPU baseline + parity gate (rank 0, N = 1 only) -------------------------------------------
+    # ---- parity over the timed work + CPU baseline (rank 0, N = 1 only) ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import support
         ncpu = os.cpu_count() or 1
@@ -591,39 +659,48 @@ def main():
                 w = ncpu if tok == "all" else max(1, min(ncpu, int(tok)))
                 if w not in ws:
                     ws.append(w)
-        orcs = {w: support.Oracle(cache_size=4 * K, workers=w) for w in ws}
-        gate_w = max(ws)
-        ok = parity_gate(rig, orcs[gate_w], gate_w, NOW0, "headline")
-        for w in ws:
-            if w != gate_w:
-                for s in range(0, len(ctx.my_ids), 1 << 18):
-                    orcs[w].eval(streams.bench_batch(ctx.table, ctx.my_ids[s:s + (1 << 18)], NOW0, hits=0, algorithm=rig.algo_id), threads=(w if w > 1 else 0))
-        parity = f"bit-exact vs oracle on the first {len(rig.kept)} batches of the timed stream" if ok else "FAILED"
+        gate_w = min(ncpu, 32)
+        orc = support.Oracle(cache_size=4 * K, workers=gate_w)
+        ok, compared, el = parity_over_timed_work(rig, orc, gate_w if gate_w > 1 else 0, NOW0, "headline")
+        orc.close()
+        ok = ok and m["internal_retries"] == 0
+        parity = (f"bit-exact vs the oracle fed the whole stream (populate, warm-up, all {steps} timed batches in order): {compared} timed batches compared "
+                  f"element-wise (the first 8, every 64th, the last), internal retries in the timed region: {m['internal_retries']}") if ok else "FAILED"
         if not ok:
             raise SystemExit("parity gate failed: refusing to report a number")
-        res = cpu_baseline(rig, orcs, len(rig.kept), min(len(rig.seq), len(rig.kept) + 64), args.cpu_seconds)
+        res = {gate_w: (steps * B / el, steps, el)}
+        for w in ws:
+            if w == gate_w:
+                continue
+            o = support.Oracle(cache_size=4 * K, workers=w)
+            res[w] = cpu_baseline_sample(rig, o, w, NOW0, args.cpu_seconds)
+            o.close()
         best = max(res, key=lambda w: res[w][0])
         cpu = {"value": round(res[best][0], 1), "unit": "decisions/s", "cores": best, "kind": "port",
-               "sample": f"{res[best][1]} batches of {B} from the same routed stream ({res[best][2]:.1f} s), {K} resident keys, the oracle in the "
-                         f"reference's worker-sharded design (W caches / threads, XXH64-range sharding, workers.go:180-184); host has {ncpu} cores",
-               "by_threads": {str(w): {"value": round(v[0], 1), "batches": v[1], "seconds": round(v[2], 2)} for w, v in res.items()}}
-        for o in orcs.values():
-            o.close()
+               "sample": f"{res[best][1]} batches of {B} from the beginning of the timed stream ({res[best][2]:.1f} s), {K} resident keys, the oracle in the "
+                         f"reference's worker-sharded design (W caches, one persistent pinned thread each, XXH64-range sharding, workers.go:180-184); "
+                         f"W = {gate_w} ran the whole timed stream (it is the parity pass); host has {ncpu} cores",
+               "by_threads": {str(w): {"value": round(v[0], 1), "batches": v[1], "seconds": round(v[2], 2)} for w, v in sorted(res.items())}}
 
+    touched = m["distinct_keys_in_stream"]
     headline_cfg = {"workload": f"{K} resident keys per GPU, one {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") +
-                                f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration=60000ms, {world}xMI355X"
+                                f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration={args.duration_ms}ms, {world}xMI355X"
                                 + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
-                                + ((f", {S} logical shards per GPU (own table each; the stream is routed key by key, a shard flushes a batch "
+                                + ((f", {S} logical shards per GPU (own table each; the stream is split key by key by the placement, a shard flushes a batch "
                                     f"when {B} requests are waiting), " +
                                     ("own stream + batcher thread each" if args.dispatch == "threads" else
                                      f"one dispatcher, shards spread over {args.streams} stream(s): the next batch of up to four shards of a stream per pair of launches")) if S > 1 else ", one table"),
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
-                    "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count()}
+                    "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
+                    "stream": {"replayed": False, "distinct_batches_total": len(rig.seq), "timed_batches": steps,
+                               "distinct_keys_touched": touched, "table_bytes_touched": touched * 144, "table_bytes_touched_in_64B_sectors": touched * 192,
+                               "now_ms": "advances 1 ms per batch",
+                               "routing": "per-request routing to the shards is outside the clock (the front end's work: see `pool`); `shards_1` needs none"}}
     rig.close()
     del rig
     torch.cuda.empty_cache()
 
-    # ---- extras (rank 0 of a 1-GPU run): other configurations, same machinery, shorter timed region ----
+    # ---- extras (rank 0 of a 1-GPU run): other configurations, same machinery ----
     if rank == 0 and world == 1 and args.extras:
         want = [x.strip() for x in args.extras.split(",") if x.strip()]
         for name in want:
@@ -641,8 +718,10 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
             "config": headline_cfg,
-            "timed_region": {"repeats_of_the_step_list": m["repeats"], "ms": round(m["timed_ms"], 2), "min_ms": args.min_ms,
-                             "ms_per_step_hip_events": round(m["ms_per_step_events"], 5),
+            "timed_region": {"distinct_batches": steps, "replays": 0, "ms": round(m["timed_ms"], 3),
+                             "note": (f"--steps {args.steps} was raised to {steps}: the timed region is never shorter than {args.min_batches} distinct batches"
+                                      if steps != args.steps else "every timed batch is a distinct part of the stream"),
+                             "ms_per_step_hip_events": round(m["ms_per_step_events"], 5), "host_enqueue_ms": round(m["enqueue_ms"], 3),
                              "enqueue": ("caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
                                          else f"one dispatcher for {S} shards over {args.streams} stream(s) (guber_eval_batches_routed_dev: batches of shards that share a stream share launches)"),
                              "shard_streams": m["shard_streams"]},
@@ -658,31 +737,39 @@ def run_extra(name, args, ctx, NOW0, seed):
     """one extra configuration -> sub-object of the JSON line"""
     import support
     K, B = ctx.K, ctx.B
-    steps = max(8, min(args.steps, 64))
+    steps = max(64, args.extra_batches)
     warmup = max(4, min(args.warmup, 16))
-    min_ms = min(args.min_ms, 150.0)
     if name == "end_to_end":
         return run_end_to_end(args, ctx, NOW0, seed)
     if name == "pool":
         return run_pool(args)
-    algo, dist_kind, S = {"leaky": ("leaky", "zipf", max(1, args.shards)), "shards_1": (args.algo, args.dist, 1),
-                          "uniform": (args.algo, "uniform", max(1, args.shards))}[name]
-    rig = Rig(ctx, algo, dist_kind, S)
+    algo, dist_kind, S, dur = {"leaky": ("leaky", "zipf", max(1, args.shards), 60_000), "shards_1": (args.algo, args.dist, 1, args.duration_ms),
+                               "uniform": (args.algo, "uniform", max(1, args.shards), args.duration_ms),
+                               "expiring": (args.algo, "zipf", max(1, args.shards), 500)}[name]
+    rig = Rig(ctx, algo, dist_kind, S, duration_ms=dur)
     rig.populate(NOW0)
-    m = rig.measure(steps, warmup, min_ms, NOW0, seed)
-    out = {"value": round(m["value"], 1), "unit": "decisions/s", "ms_per_step": round(m["ms_per_step"], 5), "steps": steps,
-           "repeats": m["repeats"], "dtype": "int64" if algo == "token" else "f64",
-           "workload": f"{K} keys, {dist_kind}, {algo.upper()}_BUCKET, batch {B}, {S} logical shard(s)"}
-    if name in ("leaky", "shards_1"):
-        out["batch_latency"] = rig.latency(warmup, warmup + steps, n=128)
-        km = rig.kernel_profile(16, warmup, warmup + steps)
+    prof = 64 if name in ("leaky", "shards_1") else 0
+    lat = 64 if name in ("leaky", "shards_1") else 0
+    m = rig.measure(steps, warmup, NOW0, seed, profile_steps=prof, latency_steps=lat)
+    out = {"value": round(m["value"], 1), "unit": "decisions/s", "ms_per_step": round(m["ms_per_step"], 5), "timed_batches": steps, "replays": 0,
+           "distinct_keys_touched": m["distinct_keys_in_stream"], "dtype": "int64" if algo == "token" else "f64",
+           "workload": f"{K} keys, {dist_kind}, {algo.upper()}_BUCKET, batch {B}, duration {dur} ms, {S} logical shard(s), {steps} distinct batches"}
+    if prof:
+        km, per_launch, _ = rig.kernel_profile()
         out["kernel_avg_us"] = {k: round(v * 1e3, 2) for k, v in km.items() if v > 0}
-    if name == "leaky" and not args.no_cpu_baseline:
+        kb = KERNEL_BYTES[algo]
+        out["roofline_frac"] = {k: round(kb[k] * per_launch.get(k, B) / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) for k, v in km.items() if v > 0 and k in kb}
+        out["batch_latency"] = rig.latency()
+    if name in ("leaky", "expiring") and not args.no_cpu_baseline:
         w = min(os.cpu_count() or 1, 32)
         orc = support.Oracle(cache_size=4 * K, workers=w)
-        ok = parity_gate(rig, orc, w, NOW0, "leaky")
+        ok, compared, _ = parity_over_timed_work(rig, orc, w if w > 1 else 0, NOW0, name)
         orc.close()
-        out["parity"] = f"bit-exact vs oracle on the first {len(rig.kept)} batches (tolerance 0)" if ok else "FAILED"
+        ok = ok and m["internal_retries"] == 0
+        out["parity"] = (f"bit-exact vs the oracle fed the whole stream: {compared} timed batches compared (tolerance 0), internal retries {m['internal_retries']}"
+                         if ok else "FAILED")
+        if name == "expiring":
+            out["renewals"] = "duration 500 ms, now_ms +1 per batch: every touched bucket expires and is recreated about every 500 batches under the clock"
         if not ok:
             out.pop("value")
     rig.close()
@@ -696,131 +783,144 @@ def run_pool(args):
     exe = os.path.join(ROOT, "tools", "bench_pool_c")
     if not os.path.exists(exe):
         return {"error": "tools/bench_pool_c is not built (make -C gubernator_amd/csrc bench_pool)"}
-    T, S, items, keys = 64, 4, 1000, 1_000_000
-    p = subprocess.run([exe, str(T), str(S), str(items), str(keys), "1.5"], capture_output=True, text=True, timeout=120)
-    m = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)", p.stdout)
-    if not m:
-        return {"error": (p.stdout + p.stderr)[-400:]}
-    return {"value": float(m.group(1)) * 1e6, "unit": "decisions/s", "batches_per_s": float(m.group(2)), "avg_batch": float(m.group(3)),
-            "errors": int(m.group(4)),
-            "workload": f"{T} caller threads x RPCs of {items} requests through V1Instance::GetRateLimits -> GPUWorkerPool ({S} shards, batch limit 65536, "
-                        f"batch wait 200 us), {keys} keys Zipf-1.1, closed loop: validation, HashKey, shard routing, slot reservation, in-place stage "
-                        "filling, submit / wait and response fan-out included (what the Go shim does per request)"}
+    out = {}
+    for label, (T, S, items, keys, secs) in {"rpc_1000": (128, 8, 1000, args.keys, 2.0), "rpc_1": (16, 8, 1, args.keys, 1.0)}.items():
+        p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs)], capture_output=True, text=True, timeout=300)
+        mm = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)(?:, rpc latency p50 ([0-9.]+) us p99 ([0-9.]+) us)?", p.stdout)
+        if not mm:
+            out[label] = {"error": (p.stdout + p.stderr)[-400:]}
+            continue
+        out[label] = {"value": float(mm.group(1)) * 1e6, "unit": "decisions/s", "batches_per_s": float(mm.group(2)), "avg_batch": float(mm.group(3)),
+                      "errors": int(mm.group(4)), "caller_threads": T, "shards": S, "items_per_rpc": items, "keys": keys}
+        if mm.group(5):
+            out[label]["rpc_latency_us"] = {"p50": float(mm.group(5)), "p99": float(mm.group(6))}
+    head = out.get("rpc_1000", {})
+    return {"value": head.get("value"), "unit": "decisions/s", "rpc_1000": out.get("rpc_1000"), "rpc_1": out.get("rpc_1"),
+            "workload": "caller threads x RPCs through V1Instance::GetRateLimits -> GPUWorkerPool (one dispatcher per device, fused launches, hash placement), "
+                        "Zipf-1.1, closed loop: validation, HashKey, placement, slot reservation, in-place stage filling, submit / completion and response "
+                        "fan-out included (what the Go shim does per request)"}
 
 
 def run_end_to_end(args, ctx, NOW0, seed):
-    """host memory in, host memory out: guber_stage_* — requests written into device-visible host arrays, the kernels read them
-    and write the responses in place over PCIe, two batches in flight (one being filled / drained by the host while the other
-    is evaluated).  Reported with and without the host's fill copy."""
+    """host memory in, host memory out: guber_stage_* — requests written into device-visible host arrays, DMA brings them to
+    HBM beside the previous batches' kernels, responses are written in place over PCIe, several batches in flight.  Every
+    batch is a distinct part of the stream and every stage is used once per pass: `prefilled` = NP stages filled before the
+    clock (what caller threads filling their own slots look like to the engine), `with_host_fill` = 4 stages refilled by this
+    one thread (numpy) inside the clock."""
     import gubernator_amd as ga
-    import streams
     K, B = ctx.K, ctx.B
-    rig = Rig(ctx, args.algo, args.dist, 1)
+    rig = Rig(ctx, args.algo, args.dist, 1, duration_ms=args.duration_ms)
     rig.populate(NOW0)
-    NB = 288
-    seq = rig.build_sequence(NB, NOW0, seed)
+    NP, NB = int(os.environ.get("GUBER_BENCH_E2E_PREFILLED", "160")), 288
+    rig.warmup, rig.steps = 0, NP + NB
+    rig.build_stream(NP + NB, NOW0, seed)
     eng = rig.engines[0]
-    hb = [streams.bench_batch(ctx.table, ids, now, algorithm=rig.algo_id) for (_, ids, now) in seq]
     depth = max(1, int(os.environ.get("GUBER_BENCH_E2E_DEPTH", "3")))      # batches in flight
-    NS = depth + 1                                                          # one more stage is being filled / drained by the host
-    stages = [ga.Stage(eng, B, key_bytes_cap=B * 16) for _ in range(NS)]
-    for st in stages:
-        st.disable("burst", "created_at", "is_owner")
-    out = {}
-    for label, fill in (("with_host_fill", True), ("prefilled", False)):
-        if not fill:
-            for k, st in enumerate(stages):
-                st.fill(hb[k])
+    bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4) + 26                          # every request column present crosses PCIe once, responses once
+
+    def pump(stages, nb, fill_from):
         t_sub, lat = {}, []
         h_submit = h_wait = 0.0
+        ns = len(stages)
         t0 = time.perf_counter()
-        for i in range(NB):
-            st = stages[i % NS]
-            if fill:
-                st.fill(hb[i])
+        for i in range(nb):
+            st = stages[i % ns]
+            if fill_from is not None:
+                st.fill(fill_from[i])
             t_sub[i] = time.perf_counter()
             st.submit()
             h_submit += time.perf_counter() - t_sub[i]
             if i >= depth - 1:
                 j = i - (depth - 1)
                 tw = time.perf_counter()
-                stages[j % NS].wait()
+                stages[j % ns].wait()
                 h_wait += time.perf_counter() - tw
                 lat.append((time.perf_counter() - t_sub[j]) * 1e6)
-        for j in range(NB - depth + 1, NB):
-            stages[j % NS].wait()
+        for j in range(max(0, nb - depth + 1), nb):
+            stages[j % ns].wait()
             lat.append((time.perf_counter() - t_sub[j]) * 1e6)
         el = time.perf_counter() - t0
-        lat = sorted(lat[32:])
-        bytes_per_req = (15 + 4 + 3 * 8 + 1 + 4) + 26              # every request column present crosses PCIe once, responses once
-        out[label] = {"value": round(NB * B / el, 1), "ms_per_step": round(el / NB * 1e3, 4),
-                      "latency_us": {"p50": round(percentile(lat, 0.5), 1), "p99": round(percentile(lat, 0.99), 1), "n": len(lat)},
-                      "pcie_GBps": round(bytes_per_req * B * NB / el / 1e9, 2),
-                      "host_us_per_batch": {"submit": round(h_submit / NB * 1e6, 1), "wait": round(h_wait / NB * 1e6, 1)}}
-    # parity of the path: the last prefilled pass must equal what the oracle-checked device path gives — checked in tests/ (test_stage_*)
-    for st in stages:
+        lat = sorted(lat[min(16, len(lat) // 4):])
+        return {"value": round(nb * B / el, 1), "ms_per_step": round(el / nb * 1e3, 4), "batches": nb,
+                "latency_us": {"p50": round(percentile(lat, 0.5), 1), "p99": round(percentile(lat, 0.99), 1), "n": len(lat)},
+                "pcie_GBps": round(bytes_per_req * B * nb / el / 1e9, 2),
+                "host_us_per_batch": {"submit": round(h_submit / nb * 1e6, 1), "wait": round(h_wait / nb * 1e6, 1)}}
+
+    def make(n):
+        ss = [ga.Stage(eng, B, key_bytes_cap=B * 16) for _ in range(n)]
+        for st in ss:
+            st.disable("burst", "created_at", "is_owner")
+        return ss
+    few = make(depth + 1)
+    with_fill = pump(few, NB, [rig.host_batch(i) for i in range(NB)])          # also warms the path up
+    for st in few:
+        st.close()
+    many = make(NP)
+    for k, st in enumerate(many):
+        st.fill(rig.host_batch(NB + k))
+    best = pump(many, NP, None)
+    for st in many:
         st.close()
     rig.close()
-    best = out["prefilled"]
-    return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NB,
+    return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NP, "replays": 0,
             "latency_us": best["latency_us"], "pcie_GBps": best["pcie_GBps"], "host_us_per_batch": best["host_us_per_batch"],
-            "with_host_fill": out["with_host_fill"],
-            "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_stage_submit / guber_stage_wait from one host thread: "
-                        "request columns -> the stage's HBM mirror by DMA on a copy stream beside the previous batches' kernels, responses written "
-                        f"straight into the host arrays by k_eval2 (GUBER_NO_STAGE_DMA=1: everything read / written in place), {depth} batches in flight; "
-                        "`with_host_fill` adds the copy of every batch into the stage (numpy, one thread)"}
+            "with_host_fill": with_fill,
+            "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_stage_submit / guber_stage_wait from one host thread: request "
+                        "columns -> the stage's HBM mirror by DMA on a copy stream beside the previous batches' kernels, responses written straight into the host "
+                        f"arrays by k_eval2, {depth} batches in flight; the headline line: {NP} distinct batches in {NP} stages filled before the clock, each used "
+                        f"once; `with_host_fill`: {NB} further distinct batches through {depth + 1} stages, this thread's copy of every batch into the stage (numpy) included"}
 
 
 def run_global(args, ctx, dist):
-    """BASELINE config 5: every request carries GLOBAL, every rank serves all keys from its replica, every K steps the
-    ranks exchange pending hits / owner state."""
+    """BASELINE config 5 on the NATIVE exchange: every request carries GLOBAL, every rank serves all keys from its replica,
+    every K steps one guber_global_sync tick (guber_global_sync.h: hits -> owners over RCCL / device copies, owners apply and
+    broadcast).  world > 1: one rank per process, guber_comm_create_rank (the unique id travels through torch.distributed);
+    world == 1: --logical-ranks R engines on this GPU behind guber_comm_create_local (device-copy transport: RCCL refuses two
+    ranks on one device)."""
     import torch
     import gubernator_amd as ga
     import streams
+    from gubernator_amd import global_native as gn
     from gubernator_amd import shard
     K, B, world, rank, dev = ctx.K, ctx.B, ctx.world, ctx.rank, ctx.dev
     GSYNC, NOW0 = args.global_sync, streams.NOW0
-    rig = Rig(ctx, args.algo, args.dist, 1, flags=ga.FLAG_GLOBAL, max_key_bytes=64)
-    eng, stream = rig.engines[0], rig.sstreams[0]
-    ring = ga.Ring(shard.peer_names(world), 512, "fnv1")
-    resident = rig.populate(NOW0)
+    R = 1 if world > 1 else max(1, args.logical_ranks)          # ranks living in this process
+    nranks = world if world > 1 else R
+    ring = ga.Ring(shard.peer_names(nranks), 512, "fnv1")
+    ctx.dispatch, ctx.streams = "threads", 1
+    rigs = [Rig(ctx, args.algo, args.dist, 1, flags=ga.FLAG_GLOBAL, max_key_bytes=64, duration_ms=args.duration_ms) for _ in range(R)]
+    engines = [r.engines[0] for r in rigs]
+    resident = sum(r.populate(NOW0) for r in rigs)
     total_steps = args.warmup + args.steps
-    seq = rig.build_sequence(total_steps, NOW0, 1234 + rank * 64)
-    rig.seq = seq
-    batches, owners = [], []
-    for (_, ids, now) in seq:
-        owner_ptr = None
-        b = rig.dev_batch(ids, now)
-        if world > 1:                 # is_owner[i] = (ring owner of key i == this rank), on device
-            d_owner = torch.empty(len(ids), dtype=torch.int32, device=dev)
-            eng.route_dev(ring, b.key_bytes, b.key_off, len(ids), d_owner.data_ptr())
-            t = (d_owner == rank).to(torch.uint8)
+    owners = []
+    for q, rig in enumerate(rigs):
+        my_rank = rank if world > 1 else q
+        rig.warmup, rig.steps, rig.profile_steps, rig.latency_steps = args.warmup, args.steps, 0, 0
+        rig.build_stream(total_steps, NOW0, 1234 + my_rank * 64)
+        rig.kept = {}
+        for s, b in enumerate(rig.batches):                     # is_owner[i] = (ring owner of key i == this rank), on device
+            d_owner = torch.empty(B, dtype=torch.int32, device=dev)
+            rig.engines[0].route_dev(ring, b.key_bytes, b.key_off, B, d_owner.data_ptr())
+            t = (d_owner == my_rank).to(torch.uint8)
             owners.append(t)
             b.is_owner = t.data_ptr()
-        batches.append(b)
-    eng.max_batch = B
-    if args.global_host:      # host-staged exchange (numpy rows, pickled all_gather): kept for comparison
-        from gubernator_amd import global_sync
-        transport = global_sync.TorchTransport() if world > 1 else type("T", (), {"all_gather": staticmethod(lambda o: [o])})()
-        gsync = global_sync.GlobalSync(eng, rank, world, ring, transport)
-    else:                     # rows stay in HBM: take_dev -> route -> RCCL all_to_all / all_gather -> eval_dev / add_items_dev
-        from gubernator_amd import global_sync_dev
-        if world > 1:
-            transport = global_sync_dev.TorchTransportDev(dev)
-        else:
-            transport = type("T", (), {"exchange_rows": staticmethod(lambda send, counts: send),
-                                       "gather_rows": staticmethod(lambda rows: [rows])})()
-        gsync = global_sync_dev.GlobalSyncDev(eng, rank, world, ring, transport, dev, key_stride=64)
+    if world > 1:
+        uid = [gn.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = gn.Comm.rank(engines[0], rank, world, uid[0], ring)
+    else:
+        comm = gn.Comm.local(engines, ring, use_rccl=False)
     sync_stats = []
 
     def run(s):
-        eng.eval_dev(batches[s], rig.scratch[0].c)
+        for rig in rigs:
+            rig.engines[0].eval_dev(rig.batches[s], rig.scratch[0].c)
         if (s + 1) % GSYNC == 0:
             t_s = time.perf_counter()
-            with torch.cuda.stream(stream):          # the engine's stream: torch ops of the exchange and engine kernels stay ordered
-                st = gsync.sync(NOW0 + 1 + s)
-                stream.synchronize()
-            st["ms"] = (time.perf_counter() - t_s) * 1e3
+            per = comm.sync(NOW0 + 1 + s)
+            st = dict(comm.last)
+            st["wall_ms"] = (time.perf_counter() - t_s) * 1e3
+            st["per_rank"] = per
             sync_stats.append(st)
     for s in range(args.warmup):
         run(s)
@@ -832,22 +932,46 @@ def run_global(args, ctx, dist):
     torch.cuda.synchronize(dev)
     wall = ctx.max_over_ranks(time.perf_counter() - t0)
     ctx.barrier()
+    # convergence as functional_test.go:1815-1821: after a final tick with nothing new in between, every replica reports the
+    # same remaining for the keys of the last batch (hits = 0 reads)
+    comm.sync(NOW0 + 1 + total_steps)
+    comm.sync(NOW0 + 2 + total_steps)
+    probe = rigs[0].batches[total_steps - 1]
+    reads = []
+    for rig in rigs:
+        b = rig.batch_struct(probe.key_bytes, B, NOW0 + 3 + total_steps, hits=0)
+        res = rig.DevResult(rig, B)
+        rig.engines[0].eval_dev(b, res.c)
+        rig.engines[0].synchronize()
+        reads.append(res.remaining.clone())
+    converged = all(bool(torch.equal(reads[0], r)) for r in reads[1:])
+    if world > 1:
+        ref = reads[0].clone()
+        dist.broadcast(ref, src=0)
+        flag = torch.tensor([1 if torch.equal(ref, reads[0]) else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        converged = bool(flag.item())
     if rank == 0:
         timed = sync_stats[args.warmup // GSYNC:] or sync_stats
-        out = {"metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)", "value": round(args.steps * B * world / wall, 1),
+        avg = lambda k: sum(x[k] for x in timed) / max(len(timed), 1)   # noqa: E731
+        out = {"metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)", "value": round(args.steps * B * nranks / wall, 1),
                "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(wall / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
-               "config": {"workload": f"{K} keys replicated on every GPU, {args.dist} stream, batch={B}, {args.algo.upper()}_BUCKET, GLOBAL behaviour, "
-                                      f"sync every {GSYNC} batches, {world}xMI355X", "keys_per_gpu": K, "batch": B, "resident_items_rank0": int(resident)},
-               "global_sync": {"every_batches": GSYNC, "syncs": len(sync_stats),
-                               "avg_ms": round(sum(x["ms"] for x in timed) / max(len(timed), 1), 3),
-                               "avg_rows_broadcast": int(sum(x["broadcast"] for x in timed) / max(len(timed), 1)),
-                               "avg_hits_rows_sent": int(sum(x["hits_sent"] for x in timed) / max(len(timed), 1)),
-                               "bytes_moved_rank0": gsync.bytes_moved,
-                               "exchange": "host-staged" if args.global_host else "device-resident (RCCL on HBM rows)"}}
+               "config": {"workload": f"{K} keys replicated on every rank, {args.dist} stream (distinct batches, never replayed), batch={B}, {args.algo.upper()}_BUCKET, GLOBAL behaviour, "
+                                      f"guber_global_sync every {GSYNC} batches, {world}xMI355X" + (f", {R} logical ranks on one GPU" if world == 1 else ""),
+                          "keys_per_gpu": K, "batch": B, "resident_items_local": int(resident), "ranks": nranks},
+               "global_sync": {"every_batches": GSYNC, "syncs": len(sync_stats), "implementation": "native: guber_comm_* + guber_global_sync (guber_global_sync.h)",
+                               "transport": "RCCL grouped send/recv (xGMI)" if world > 1 else "device copies between logical ranks of one GPU",
+                               "avg_ms": round(avg("ms"), 3), "avg_wall_ms": round(avg("wall_ms"), 3),
+                               "avg_hits_rows_sent": int(avg("hits_rows_sent")), "avg_hits_rows_applied": int(avg("hits_rows_applied")),
+                               "avg_update_rows": int(avg("update_rows")), "avg_items_installed": int(avg("items_installed")),
+                               "avg_bytes_moved": int(avg("bytes_moved")), "host_fallbacks": int(sum(x["fallbacks"] for x in sync_stats)),
+                               "replicas_converged": converged}}
         print(json.dumps(out))
-    rig.close()
+    comm.close()
+    for rig in rigs:
+        rig.close()
     if world > 1:
         dist.destroy_process_group()
 

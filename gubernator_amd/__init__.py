@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_stage_create", "guber_stage_destroy",
     "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_create_multi",
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
+    "guber_placement_create", "guber_placement_destroy", "guber_placement_shard", "guber_placement_version", "guber_placement_route_keys",
+    "guber_placement_observe", "guber_placement_observe_keys", "guber_placement_rebalance", "guber_placement_info",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
@@ -165,6 +167,63 @@ class Ring:
     def close(self):
         if self.h:
             lib().guber_ring_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Placement:
+    """guber_placement_t: which logical shard of a GPU holds a key — hash slots -> shards plus individually placed hot keys,
+    fitted to observed traffic (include/guber_gpu.h; the generalisation of WorkerPool.getWorker, workers.go:180-184)."""
+
+    def __init__(self, n_shards, n_slots=0):
+        L = lib()
+        L.guber_placement_create.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_placement_destroy.argtypes = [C.c_void_p]
+        L.guber_placement_destroy.restype = None
+        L.guber_placement_shard.argtypes = [C.c_void_p, C.c_uint64]
+        L.guber_placement_shard.restype = C.c_uint32
+        L.guber_placement_route_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.guber_placement_observe_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.guber_placement_rebalance.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.guber_placement_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        self.n_shards = n_shards
+        self.h = C.c_void_p()
+        _check(L.guber_placement_create(n_shards, n_slots, C.byref(self.h)))
+
+    def route_keys(self, key_bytes, key_off):
+        """(shard uint32[n], hash uint64[n]) of packed keys"""
+        n = len(key_off) - 1
+        sh, hh = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint64)
+        _check(lib().guber_placement_route_keys(self.h, key_bytes.ctypes.data, key_off.ctypes.data, n, sh.ctypes.data, hh.ctypes.data))
+        return sh[:n], hh[:n]
+
+    def shard(self, key_hash):
+        return lib().guber_placement_shard(self.h, int(key_hash))
+
+    def observe_keys(self, key_bytes, key_off):
+        _check(lib().guber_placement_observe_keys(self.h, key_bytes.ctypes.data, key_off.ctypes.data, len(key_off) - 1))
+
+    def rebalance(self, heavy_fraction=0.125, move_slots=True):
+        """-> list of (key_hash, from, to) for the hot keys whose shard changed"""
+        mv = np.zeros(64 * 4, np.uint32)          # guber_placement_move_t = u64 + 2 x u32
+        nm = C.c_uint32(0)
+        _check(lib().guber_placement_rebalance(self.h, heavy_fraction, 1 if move_slots else 0, mv.ctypes.data, 64, C.byref(nm)))
+        rec = mv.view(np.dtype([("h", np.uint64), ("from", np.uint32), ("to", np.uint32)]))
+        return [(int(r["h"]), int(r["from"]), int(r["to"])) for r in rec[:nm.value]]
+
+    def n_hot(self):
+        nh = C.c_uint32(0)
+        _check(lib().guber_placement_info(self.h, None, None, C.byref(nh)))
+        return nh.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().guber_placement_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -402,6 +402,33 @@ int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uint8_t* name_
                                const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
                                guber_result_t* out, char* err_text, uint32_t err_stride);
 
+/* ---- placement of one GPU's keys on its logical shards (replaces WorkerPool.getWorker, workers.go:180-184, where the
+ *      reference picks the worker by XXH64 range).  key_hash = XXH64(HashKey, seed 0) as in workers.go:153-155.  Keys map to
+ *      n_slots hash slots by the reference's rule (slot = hash63 / (2^63 / n_slots)); slots map to shards through a table
+ *      that starts as contiguous runs (= getWorker exactly); keys that alone outweigh heavy_fraction of a shard's fair share
+ *      are placed individually (at most 64).  Which shard holds a key never shows in a response.
+ *        guber_placement_observe[_keys]   feed observed traffic (thread-safe, approximate: relaxed atomics)
+ *        guber_placement_rebalance        longest-processing-time-first over what was observed since the last call.
+ *                                         move_slots = 1: slots and hot keys are placed afresh — only while no key of this
+ *                                         placement is resident (before the first request, offline);
+ *                                         move_slots = 0: the slot table stays; keys that became heavy get the least loaded
+ *                                         shard.  moves[] lists the hot keys whose shard changed: the caller migrates their
+ *                                         buckets (GPUWorkerPool does, at a batch boundary) before serving them there.
+ *      Readers are wait-free; guber_placement_version changes with every rebalance. */
+typedef struct guber_placement guber_placement_t;
+typedef struct guber_placement_move { uint64_t key_hash; uint32_t from, to; } guber_placement_move_t;
+int guber_placement_create(uint32_t n_shards, uint32_t n_slots /* 0 = 4096 */, guber_placement_t** out);
+void guber_placement_destroy(guber_placement_t* p);
+uint32_t guber_placement_shard(const guber_placement_t* p, uint64_t key_hash);
+uint32_t guber_placement_version(const guber_placement_t* p);
+int guber_placement_route_keys(const guber_placement_t* p, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
+                               uint32_t* shard_out /* optional */, uint64_t* hash_out /* optional */);
+void guber_placement_observe(guber_placement_t* p, uint64_t key_hash, uint32_t weight);
+int guber_placement_observe_keys(guber_placement_t* p, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n);
+int guber_placement_rebalance(guber_placement_t* p, double heavy_fraction /* <= 0: 0.125 */, int move_slots,
+                              guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves);
+int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_t* n_slots, uint32_t* n_hot);
+
 /* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
 void* guber_alloc_pinned(size_t bytes);
 void guber_free_pinned(void* p);
