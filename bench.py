@@ -302,6 +302,7 @@ class Rig:
             for lo in range(0, len(loc), B):
                 sel = loc[lo:lo + B]
                 kb = torch.cat([self.d_keytab.index_select(0, sel).reshape(-1), pad])
+                torch.cuda.current_stream(self.ctx.dev).synchronize()    # kb is produced on torch's stream, consumed on the engine's
                 self.engines[j].eval_dev(self.batch_struct(kb.data_ptr(), len(sel), now0, hits=0), self.scratch[j].c)
                 self.engines[j].synchronize()
         return sum(e_.size() for e_ in self.engines)
@@ -904,6 +905,7 @@ def run_global(args, ctx, dist):
             t = (d_owner == my_rank).to(torch.uint8)
             owners.append(t)
             b.is_owner = t.data_ptr()
+    torch.cuda.synchronize(dev)                                 # the owner flags are produced on torch's stream
     if world > 1:
         uid = [gn.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -941,6 +943,7 @@ def run_global(args, ctx, dist):
     for rig in rigs:
         b = rig.batch_struct(probe.key_bytes, B, NOW0 + 3 + total_steps, hits=0)
         res = rig.DevResult(rig, B)
+        torch.cuda.synchronize(dev)
         rig.engines[0].eval_dev(b, res.c)
         rig.engines[0].synchronize()
         reads.append(res.remaining.clone())

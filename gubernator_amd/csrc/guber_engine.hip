@@ -123,6 +123,7 @@ struct guber_engine {
     DevBuf<int64_t> d_stash64; DevBuf<uint32_t> d_stash32; DevBuf<uint8_t> d_stash8;   // k_front's HBM copy of host-resident request columns
     hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
     bool fuse = true; uint64_t fused_batches = 0;                 // guber_eval_batches_routed_dev: several engines per launch
+    struct guber_stage* small_pending = nullptr;                  // a <= 256-request stage launched by guber_stages_submit whose outcome has not been looked at yet
     uint64_t small_batches = 0, small_fallbacks = 0;
     CohBuf<DevCounters> h_ctr; CohBuf<uint32_t> h_rb_seq; uint32_t rb_seq = 0;   // counter snapshot + its completion stamp
     DevCounters last_ctr{};
@@ -841,7 +842,8 @@ struct guber_stage {
     DevCounters* rb0_ctr = nullptr; BlockCounters* rb0_bctr = nullptr;   // ... and before it: the difference is exactly this batch
     hipEvent_t ev = nullptr;
     uint32_t seq = 0, n = 0; int64_t now_ms = 0;
-    int mode = 0;                    // 0 idle, 1 small path in flight, 2 pipeline in flight
+    int mode = 0;                    // 0 idle, 1 small path complete, 2 pipeline in flight, 3 small path launched, outcome not looked at yet (guber_stages_submit)
+    bool no_agg = false;             // submitted without per-batch aggregates (guber_stages_submit)
     // Large batches: two DMA copies on a copy stream (the fixed-width columns present, the keys) bring the requests into the
     // stage's device mirror while the previous batches' kernels run; the pipeline then works on HBM and k_eval2 writes the
     // responses straight into the host arrays (posted writes).  The link carries the requests at the copy engine's rate
@@ -853,6 +855,8 @@ struct guber_stage {
     hipEvent_t ev_in = nullptr;
 };
 
+static int resolve_small(guber_stage* s, bool block);
+static int resolve_small_locked(guber_stage* s, bool block);
 extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
     if (!e || !out || max_n == 0) return fail(GUBER_E_INVALID_ARG, "null argument");
     *out = nullptr;
@@ -921,12 +925,13 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     if (s->mode) return fail(GUBER_E_INVALID_ARG, "stage already in flight");
     guber_engine* e = s->e;
     const guber_batch_t& b = s->batch;
-    s->n = b.n; s->now_ms = b.now_ms;
+    s->n = b.n; s->now_ms = b.now_ms; s->no_agg = false;
     if (b.n == 0) { s->mode = 0; return GUBER_OK; }
     if (b.n > s->max_n || b.key_off[b.n] > s->key_cap) return fail(GUBER_E_BATCH_TOO_LARGE, "stage overfilled");
     memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);            // the kernels read keys as 8-byte words
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (e->small_pending) { const int rcp = resolve_small_locked(e->small_pending, true); if (rcp < 0) return rcp; }
     BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                 b.greg_expire, b.greg_duration, b.now_ms};
     ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
@@ -989,6 +994,10 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
     guber_result_t& r = s->result;
     r.over_limit_count = r.cache_hits = r.cache_misses = r.unexpired_evictions = 0;
     if (s->mode == 0) return GUBER_OK;
+    if (s->mode == 3) {                                      // launched by guber_stages_submit: look at the outcome now
+        const int rc3 = resolve_small(s, true);
+        if (rc3 < 0) return rc3;
+    }
     bool general = s->mode == 2;
     if (s->mode == 1) {                                      // answered by the one-launch path, already complete (guber_stage_submit)
         s->mode = 0;
@@ -1000,15 +1009,18 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
         if (hipEventSynchronize(s->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");
         s->mode = 0;
         std::lock_guard<std::mutex> lk(e->mu);
+        if (s->no_agg) general = false;                       // no read-backs were taken: the aggregates stay 0 (guber_stats has the totals)
         // the read-backs taken right before and right after this batch's kernels: their difference is this batch alone
         auto fold = [&](const DevCounters* c0, const BlockCounters* b0) {
             DevCounters c = *c0;
             for (uint32_t k = 0; k < e->n_bctr; ++k) { c.over += b0[k].over; c.hits += b0[k].hits; c.misses += b0[k].misses; c.size += b0[k].size_delta; }
             return c;
         };
-        const DevCounters c1 = fold(s->rb_ctr, s->rb_bctr), c0 = fold(s->rb0_ctr, s->rb0_bctr);
-        r.over_limit_count = c1.over - c0.over; r.cache_hits = c1.hits - c0.hits; r.cache_misses = c1.misses - c0.misses;
-        r.cache_size = c1.size;
+        if (general) {
+            const DevCounters c1 = fold(s->rb_ctr, s->rb_bctr), c0 = fold(s->rb0_ctr, s->rb0_bctr);
+            r.over_limit_count = c1.over - c0.over; r.cache_hits = c1.hits - c0.hits; r.cache_misses = c1.misses - c0.misses;
+            r.cache_size = c1.size;
+        }
     }
     // two new keys sharing one 64-bit hash (or one claim fingerprint) inside the batch: re-submit those items on the host
     // path, which runs the careful rounds
@@ -1034,6 +1046,219 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
         r.cache_size = e->last_ctr.size;
     }
     return GUBER_OK;
+}
+
+// ---- several stages in one submission: what the dispatcher of a GPUWorkerPool calls (worker_pool.cpp).  Never waits for the GPU.
+// A <= 256-request stage launched here is in mode 3 until somebody looks at its outcome (guber_stage_poll / guber_stage_wait,
+// or the next submission on its engine): the one-launch path may decline a batch (requests of one key that differ, a hash
+// collision), and then the general pipeline has to run it before anything later of the same engine.
+static int resolve_small_locked(guber_stage* s, bool block) {        // engine mutex held; 1 = resolved, 0 = still running
+    guber_engine* e = s->e;
+    if (s->mode != 3) return 1;
+    volatile unsigned int* flag = &s->sout->done;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != s->seq) {
+        if (!block) return 0;
+        if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCHK(hipStreamSynchronize(e->stream)); break; }
+    }
+    if (e->small_pending == s) e->small_pending = nullptr;
+    if (!s->sout->fallback) {
+        e->last_ctr.over += s->sout->over; e->last_ctr.hits += s->sout->hits; e->last_ctr.misses += s->sout->misses; e->last_ctr.size += s->sout->size_delta;
+        s->mode = 1;
+        return 1;
+    }
+    e->small_fallbacks++;
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    const guber_batch_t& b = s->batch;
+    BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
+                b.greg_expire, b.greg_duration, b.now_ms};
+    ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
+    int rc = launch_batch(e, B, R, true);
+    if (rc) { s->mode = 0; return rc; }
+    HIPCHK(hipEventRecord(s->ev, e->stream));
+    s->mode = 2;
+    return 1;
+}
+static int resolve_small(guber_stage* s, bool block) {
+    std::lock_guard<std::mutex> lk(s->e->mu);
+    return resolve_small_locked(s, block);
+}
+
+extern "C" int guber_stage_poll(guber_stage_t* s) {
+    if (!s) return fail(GUBER_E_INVALID_ARG, "null stage");
+    if (s->mode == 3) {
+        const int rc = resolve_small(s, false);
+        if (rc <= 0) return rc;
+    }
+    if (s->mode == 2) {
+        const hipError_t q = hipEventQuery(s->ev);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return fail(GUBER_E_HIP, "hipEventQuery", q);
+    }
+    return 1;
+}
+
+namespace {
+struct StagePlan { guber_stage* s; BatchView B; ResultView R; bool copy; StageIn in; };
+}
+// the views of a large stage batch: a batch of >= 2048 requests reaches HBM through the copy kernel (the stage's device mirror),
+// smaller ones are read in place over PCIe (k_front keeps a copy of the request columns for k_eval2)
+static int stage_views(guber_stage* s, StagePlan& P) {
+    guber_engine* e = s->e;
+    const guber_batch_t& b = s->batch;
+    P.s = s;
+    P.B = BatchView{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
+                    b.greg_expire, b.greg_duration, b.now_ms};
+    P.R = ResultView{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
+    P.copy = e->stage_dma && b.n >= 2048 && !b.greg_expire && !b.greg_duration;
+    P.in = StageIn{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (!P.copy) return 0;
+    const size_t in_bytes = (size_t)(s->h_out - s->h_in);
+    if (s->dmem.ensure(in_bytes)) return GUBER_E_NOMEM;
+    uint8_t* d_in = s->dmem.p;
+    const void* last = b.created_at ? (const void*)(b.created_at + b.n) : b.burst ? (const void*)(b.burst + b.n) : b.is_owner ? (const void*)(b.is_owner + b.n) : (const void*)(b.algorithm + b.n);
+    const size_t fixed = ((size_t)((const uint8_t*)last - s->h_in) + 15) & ~(size_t)15;
+    const size_t kbytes = ((size_t)b.key_off[b.n] + 16 + 15) & ~(size_t)15;
+    P.in = StageIn{(const uint4*)s->h_in, (uint4*)d_in, (const uint4*)(s->h_in + s->in_fixed), (uint4*)(d_in + s->in_fixed), (uint32_t)(fixed / 16), (uint32_t)(kbytes / 16)};
+    auto dev = [&](const void* hp) { return hp ? d_in + ((const uint8_t*)hp - s->h_in) : nullptr; };
+    P.B = BatchView{b.n, 0, dev(b.key_bytes), (const uint32_t*)dev(b.key_off), (const int64_t*)dev(b.hits), (const int64_t*)dev(b.limit),
+                    (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
+                    (const uint32_t*)dev(b.behavior), dev(b.is_owner), nullptr, nullptr, b.now_ms};
+    return 0;
+}
+
+// one group: <= MULTI_MAX large stages of engines that share device and stream (engine mutexes held by the caller)
+static int launch_stage_group(StagePlan* P, int g) {
+    guber_engine* e0 = P[0].s->e;
+    MultiStageIn MI{}; MultiFront MF{}; MultiEval ME{};
+    uint32_t tiles = 0; int planned = 0, rc = 0; bool any_copy = false;
+    FastPlan FP[MULTI_MAX];
+    for (int i = 0; i < g; ++i) {
+        guber_engine* e = P[i].s->e;
+        Work W;
+        rc = batch_prelude(e, P[i].B, W);
+        if (!rc) rc = plan_fast(e, P[i].B, !P[i].copy, W, FP[i]);
+        if (rc) break;
+        tiles += FP[i].ftiles;
+        MF.end_tile[planned] = ME.end_tile[planned] = tiles;
+        MF.sub[planned] = FrontArgs{e->T, FP[i].B2, FP[i].W};
+        ME.sub[planned] = EvalArgs{e->T, FP[i].B3, P[i].R, FP[i].W};
+        MI.sub[planned] = P[i].in;
+        any_copy = any_copy || P[i].copy;
+        ++planned;
+    }
+    if (!planned) return rc;
+    hipStream_t st = e0->stream;
+    if (any_copy) {
+        MI.nb = (uint32_t)planned; MI.wg_per = 16;
+        hipLaunchKernelGGL(k_stage_in_multi, dim3(MI.nb * MI.wg_per), dim3(256), 0, st, MI);
+    }
+    uint64_t units = 0;
+    for (int i = 0; i < planned; ++i) units += P[i].B.n;
+    if (planned == 1) {
+        e0->span_begin(KT_FRONT, units);
+        hipLaunchKernelGGL(k_front, dim3(FP[0].ftiles), dim3(FT), 0, st, e0->T, FP[0].B2, FP[0].W);
+        e0->span_end();
+        e0->span_begin(KT_EVAL2, units);
+        hipLaunchKernelGGL(k_eval2, dim3(FP[0].ftiles), dim3(256), 0, st, EvalArgs{e0->T, FP[0].B3, P[0].R, FP[0].W});
+        e0->span_end();
+    } else {
+        MF.nb = ME.nb = (uint32_t)planned;
+        e0->span_begin(KT_FRONT_MULTI, units);
+        hipLaunchKernelGGL(k_front_multi, dim3(tiles), dim3(FT), 0, st, MF);
+        e0->span_end();
+        e0->span_begin(KT_EVAL2_MULTI, units);
+        hipLaunchKernelGGL(k_eval2_multi, dim3(tiles), dim3(256), 0, st, ME);
+        e0->span_end();
+    }
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    for (int i = 0; i < planned; ++i) {
+        guber_stage* s = P[i].s;
+        finish_fast(s->e, P[i].B.n);
+        if (planned > 1) s->e->fused_batches++;
+        if (hipEventRecord(s->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
+        s->mode = 2;
+    }
+    return rc;
+}
+
+extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uint32_t flags, uint32_t* done) {
+    if (done) *done = 0;
+    if (!stages && n) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (!(flags & GUBER_STAGES_NO_AGGREGATES)) {                  // per-batch aggregates wanted: the stages go one by one
+        for (uint32_t k = 0; k < n; ++k) {
+            const int rc = guber_stage_submit(stages[k]);
+            if (rc) return rc;
+            if (done) *done = k + 1;
+        }
+        return GUBER_OK;
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        guber_stage* s = stages[k];
+        if (!s) return fail(GUBER_E_INVALID_ARG, "null stage");
+        if (s->mode) return fail(GUBER_E_INVALID_ARG, "stage already in flight");
+        const guber_batch_t& b = s->batch;
+        if (b.n > s->max_n || (b.n && b.key_off[b.n] > s->key_cap)) return fail(GUBER_E_BATCH_TOO_LARGE, "stage overfilled");
+        for (uint32_t q = 0; q < k; ++q) if (stages[q]->e == s->e) return fail(GUBER_E_INVALID_ARG, "two stages of one engine in one submission");
+    }
+    uint32_t enq = 0;
+    StagePlan grp[MULTI_MAX]; int g = 0;
+    auto flush = [&]() -> int {
+        if (!g) return 0;
+        guber_engine* order[MULTI_MAX];
+        for (int i = 0; i < g; ++i) order[i] = grp[i].s->e;
+        std::sort(order, order + g);                               // engine locks in address order (launch_group's rule)
+        for (int i = 0; i < g; ++i) order[i]->mu.lock();
+        int rc = 0;
+        if (grp[0].s->e->set_device()) rc = fail(GUBER_E_HIP, "hipSetDevice");
+        for (int i = 0; i < g && !rc; ++i) {
+            guber_engine* e = grp[i].s->e;
+            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) rc = r2; }
+            if (!rc) rc = stage_views(grp[i].s, grp[i]);
+        }
+        if (!rc) rc = launch_stage_group(grp, g);
+        for (int i = g - 1; i >= 0; --i) order[i]->mu.unlock();
+        if (!rc) enq += (uint32_t)g;
+        g = 0;
+        return rc;
+    };
+    int rc = 0;
+    for (uint32_t k = 0; k < n && !rc; ++k) {
+        guber_stage* s = stages[k];
+        guber_engine* e = s->e;
+        const guber_batch_t& b = s->batch;
+        s->n = b.n; s->now_ms = b.now_ms; s->no_agg = true;
+        if (b.n == 0) { s->mode = 0; ++enq; continue; }
+        memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);        // the kernels read keys as 8-byte words
+        const bool small = b.n <= FT && !e->no_small;
+        const bool fusable = !small && can_fuse(e, b.n);
+        if (g && (!fusable || g == MULTI_MAX || e->stream != grp[0].s->e->stream || e->device != grp[0].s->e->device)) rc = flush();
+        if (rc) break;
+        if (fusable) { grp[g++].s = s; continue; }
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->set_device()) { rc = fail(GUBER_E_HIP, "hipSetDevice"); break; }
+        if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) { rc = r2; break; } }
+        BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
+                    b.greg_expire, b.greg_duration, b.now_ms};
+        ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
+        if (small) {
+            s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
+            s->sout->done = 0;
+            rc = launch_small(e, B, R, s->sout, s->seq);
+            if (rc) break;
+            s->mode = 3; e->small_pending = s;
+        } else {                                                   // the radix pipeline (n > 65 536) or a test configuration
+            rc = launch_batch(e, B, R, true);
+            if (rc) break;
+            if (hipEventRecord(s->ev, e->stream) != hipSuccess) { rc = fail(GUBER_E_HIP, "hipEventRecord"); break; }
+            s->mode = 2;
+        }
+        ++enq;
+    }
+    if (!rc) rc = flush();
+    if (done) *done = enq;
+    return rc;
 }
 
 extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) { return eval_batch_host(e, b, r, nullptr); }

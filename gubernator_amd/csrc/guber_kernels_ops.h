@@ -309,4 +309,17 @@ __global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr
     }
 }
 
+// Request columns of up to MULTI_MAX stages: device-visible host memory -> each stage's HBM mirror, ONE launch on the stream the
+// batches' kernels follow on (the pool's dispatcher: a hipMemcpyAsync costs 40-60 us of host time, a launch 4-5).  Two blocks per
+// stage: the fixed-width columns up to the last one present, and the keys.  16-byte loads over PCIe, fully coalesced.
+struct StageIn { const uint4* src0; uint4* dst0; const uint4* src1; uint4* dst1; uint32_t n16_0, n16_1; };
+struct MultiStageIn { uint32_t nb, wg_per; StageIn sub[MULTI_MAX]; };
+__global__ __launch_bounds__(256) void k_stage_in_multi(MultiStageIn A) {
+    const uint32_t sb = blockIdx.x / A.wg_per, w = blockIdx.x - sb * A.wg_per;
+    const StageIn* s = (const StageIn*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiStageIn, sub)) + sb;
+    const uint32_t stride = A.wg_per * 256u;
+    for (uint32_t i = w * 256u + threadIdx.x; i < s->n16_0; i += stride) s->dst0[i] = s->src0[i];
+    for (uint32_t i = w * 256u + threadIdx.x; i < s->n16_1; i += stride) s->dst1[i] = s->src1[i];
+}
+
 }  // namespace guber

@@ -211,6 +211,18 @@ guber_result_t* guber_stage_result(guber_stage_t* s);
 uint32_t guber_stage_capacity(guber_stage_t* s, uint32_t* key_bytes_cap);
 int guber_stage_submit(guber_stage_t* s);
 int guber_stage_wait(guber_stage_t* s);
+/* Several stages in one submission — what ONE dispatcher serving all logical shards of a GPU calls (GPUWorkerPool): at most one
+ * stage per engine; batches of > 256 requests of engines that share device and stream travel as fused launches (one copy
+ * kernel bringing the request columns of up to four stages to HBM, then k_front_multi / k_eval2_multi), batches of <= 256
+ * requests take the one-launch path WITHOUT waiting for it.  Never blocks on the GPU.  With GUBER_STAGES_NO_AGGREGATES the
+ * per-batch aggregates of guber_result_t are not produced (no counter read-back launches; guber_stats has the totals);
+ * without it the stages are submitted one by one exactly as guber_stage_submit does.  *done (optional) = stages enqueued.
+ * guber_stage_poll: 1 = the stage's responses are in its result arrays (guber_stage_wait then returns at once, after resolving
+ * the rare internal retry), 0 = still running, < 0 = error.  Polling is how the dispatcher learns of completions without
+ * parking a thread per batch. */
+#define GUBER_STAGES_NO_AGGREGATES 1u
+int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uint32_t flags, uint32_t* done);
+int guber_stage_poll(guber_stage_t* s);
 
 /* A queue of device-resident batches enqueued back to back on the engine stream in one call (what a batcher goroutine
  * that has several full batches waiting does, peer_client.go:284-337): batches[i] -> results[i], i = 0..count-1, in
