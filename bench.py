@@ -785,7 +785,15 @@ def run_pool(args):
     if not os.path.exists(exe):
         return {"error": "tools/bench_pool_c is not built (make -C gubernator_amd/csrc bench_pool)"}
     out = {}
-    for label, (T, S, items, keys, secs) in {"rpc_1000": (128, 8, 1000, args.keys, 2.0), "rpc_1": (16, 8, 1, args.keys, 1.0)}.items():
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 2)
+    except Exception:   # noqa: BLE001
+        pass
+    cases = {"rpc_1000": (64, 8, 1000, args.keys, 2.0), "rpc_1000_256_callers": (256, 8, 1000, args.keys, 2.0), "rpc_1000_12_shards": (64, 12, 1000, args.keys, 2.0),
+             "rpc_1000_one_table": (64, 1, 1000, args.keys, 2.0), "rpc_1": (16, 8, 1, args.keys, 1.0)}
+    for label, (T, S, items, keys, secs) in cases.items():
         p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs)], capture_output=True, text=True, timeout=300)
         mm = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)(?:, rpc latency p50 ([0-9.]+) us p99 ([0-9.]+) us)?", p.stdout)
         if not mm:
@@ -796,10 +804,14 @@ def run_pool(args):
         if mm.group(5):
             out[label]["rpc_latency_us"] = {"p50": float(mm.group(5)), "p99": float(mm.group(6))}
     head = out.get("rpc_1000", {})
-    return {"value": head.get("value"), "unit": "decisions/s", "rpc_1000": out.get("rpc_1000"), "rpc_1": out.get("rpc_1"),
-            "workload": "caller threads x RPCs through V1Instance::GetRateLimits -> GPUWorkerPool (one dispatcher per device, fused launches, hash placement), "
-                        "Zipf-1.1, closed loop: validation, HashKey, placement, slot reservation, in-place stage filling, submit / completion and response "
-                        "fan-out included (what the Go shim does per request)"}
+    res = {"value": head.get("value"), "unit": "decisions/s"}
+    res.update(out)
+    res["host_cpus_usable"] = quota if quota else os.cpu_count()
+    res["workload"] = ("caller threads x RPCs through guber_pool_get_rate_limits (the C ABI a binding calls: structure-of-arrays in and out) -> GPUWorkerPool: "
+                       "one dispatcher per device, fused launches over the shards' stages, placement on key hashes with online hot-key isolation, Zipf-1.1, "
+                       "closed loop: front-end checks, HashKey, XXH64, placement, slot reservation, in-place stage filling, completion and response fan-out "
+                       "included.  The callers' work is CPU-bound: host_cpus_usable is what the cgroup grants (cpu.max), not the core count")
+    return res
 
 
 def run_end_to_end(args, ctx, NOW0, seed):

@@ -88,6 +88,7 @@ struct guber_engine {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
     hipStream_t copy_in = nullptr; bool stage_dma = true;        // stages: DMA copies beside the kernels (guber_stage_submit)
+    uint32_t stage_copy_min = 257;                                // guber_stages_submit: batches from this size on reach HBM through the copy kernel
     uint64_t slots = 0, cache_size = 0;
     uint32_t max_batch = 0, max_key = 0;
     Table T{};
@@ -112,6 +113,7 @@ struct guber_engine {
     DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; uint64_t ring_cached_id = 0; uint32_t ring_npts = 0;   // ring image for the *_dev routers
     DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags, d_ikeys, d_ires;   // guber_add_items[_dev] scratch (persistent)
     DevBuf<uint8_t> d_lkey; DevBuf<Rec> d_lrec; DevBuf<int> d_lfound;                 // guber_get_item / guber_remove_item scratch
+    DevBuf<uint64_t> d_mvh;                                                           // guber_move_items_by_hash: the hashes
     DevBuf<unsigned long long> w_claims; uint32_t claims_cells = 0; uint32_t fast_epoch16 = 0;   // k_front's per-batch claim table
     DevBuf<uint8_t> d_sflags; DevBuf<Rec> d_safter;   // Store side channel (guber_eval_batch_store), allocated on first use
     DevBuf<GPend> gpend; DevBuf<uint32_t> gdirty, gdirty2, gtake_ctr; DevBuf<uint8_t> d_take; PinBuf<uint8_t> h_take;
@@ -241,6 +243,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
     e->fuse = getenv("GUBER_NO_FUSE") == nullptr;
     e->stage_dma = getenv("GUBER_NO_STAGE_DMA") == nullptr;
+    if (const char* v = getenv("GUBER_STAGE_COPY_MIN")) e->stage_copy_min = (uint32_t)atoi(v);
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
@@ -314,7 +317,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->dbg.release();
 #endif
     e->d_ring_h.release(); e->d_ring_o.release(); e->d_items.release(); e->d_islots.release(); e->d_iflags.release(); e->d_ikeys.release(); e->d_ires.release();
-    e->d_lkey.release(); e->d_lrec.release(); e->d_lfound.release();
+    e->d_lkey.release(); e->d_lrec.release(); e->d_lfound.release(); e->d_mvh.release();
     e->w_claims.release();
     e->d_sflags.release(); e->d_safter.release();
     e->gpend.release(); e->gdirty.release(); e->gdirty2.release(); e->gtake_ctr.release();
@@ -648,15 +651,20 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
 // the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
 static void item_from_rec(const Rec& s, guber_item_t* out);
 // the same prelude launch_batch has, for the one-launch path
-static int launch_small(guber_engine* e, const BatchView& B, const ResultView& R, SmallOut* out, uint32_t seq) {
+static int small_prelude(guber_engine* e, const BatchView& B) {
     if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
     const int rc = maintain(e, B.n, B.now_ms);
     if (rc) return rc;
     e->size_upper += B.n; e->rb_added += B.n; e->tags_upper += B.n;
     e->touch = (e->touch + 1) & 0x7fffffffu;
+    e->batches++; e->small_batches++;
+    return 0;
+}
+static int launch_small(guber_engine* e, const BatchView& B, const ResultView& R, SmallOut* out, uint32_t seq) {
+    const int rc = small_prelude(e, B);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_small, dim3(1), dim3(FT), 0, e->stream, e->T, B, R, out, seq, e->touch);
     HIPCHK(hipGetLastError());
-    e->batches++; e->small_batches++;
     return 0;
 }
 
@@ -1102,8 +1110,9 @@ extern "C" int guber_stage_poll(guber_stage_t* s) {
 namespace {
 struct StagePlan { guber_stage* s; BatchView B; ResultView R; bool copy; StageIn in; };
 }
-// the views of a large stage batch: a batch of >= 2048 requests reaches HBM through the copy kernel (the stage's device mirror),
-// smaller ones are read in place over PCIe (k_front keeps a copy of the request columns for k_eval2)
+// the views of a stage batch: it reaches HBM through the copy kernel (the stage's device mirror; one PCIe round trip for all of
+// it, where k_front reading host memory in place pays one per dependent load: key offset, key bytes, fields) unless the engine
+// was told otherwise (GUBER_STAGE_COPY_MIN / GUBER_NO_STAGE_DMA: k_front then keeps a copy of the request columns for k_eval2)
 static int stage_views(guber_stage* s, StagePlan& P) {
     guber_engine* e = s->e;
     const guber_batch_t& b = s->batch;
@@ -1111,16 +1120,22 @@ static int stage_views(guber_stage* s, StagePlan& P) {
     P.B = BatchView{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                     b.greg_expire, b.greg_duration, b.now_ms};
     P.R = ResultView{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
-    P.copy = e->stage_dma && b.n >= 2048 && !b.greg_expire && !b.greg_duration;
-    P.in = StageIn{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    P.copy = e->stage_dma && b.n >= e->stage_copy_min && !b.greg_expire && !b.greg_duration;
+    P.in = StageIn{};
     if (!P.copy) return 0;
     const size_t in_bytes = (size_t)(s->h_out - s->h_in);
     if (s->dmem.ensure(in_bytes)) return GUBER_E_NOMEM;
     uint8_t* d_in = s->dmem.p;
-    const void* last = b.created_at ? (const void*)(b.created_at + b.n) : b.burst ? (const void*)(b.burst + b.n) : b.is_owner ? (const void*)(b.is_owner + b.n) : (const void*)(b.algorithm + b.n);
-    const size_t fixed = ((size_t)((const uint8_t*)last - s->h_in) + 15) & ~(size_t)15;
-    const size_t kbytes = ((size_t)b.key_off[b.n] + 16 + 15) & ~(size_t)15;
-    P.in = StageIn{(const uint4*)s->h_in, (uint4*)d_in, (const uint4*)(s->h_in + s->in_fixed), (uint4*)(d_in + s->in_fixed), (uint32_t)(fixed / 16), (uint32_t)(kbytes / 16)};
+    P.in.src = (const uint4*)s->h_in; P.in.dst = (uint4*)d_in;
+    auto seg = [&](const void* col, size_t bytes) {                 // the first `bytes` of a column that is present
+        if (!col || !bytes) return;
+        P.in.off16[P.in.nseg] = (uint32_t)(((const uint8_t*)col - s->h_in) / 16);
+        P.in.n16[P.in.nseg] = (uint32_t)((bytes + 15) / 16);
+        P.in.nseg++;
+    };
+    const size_t n = b.n;
+    seg(b.key_off, (n + 1) * 4); seg(b.hits, n * 8); seg(b.limit, n * 8); seg(b.duration, n * 8); seg(b.behavior, n * 4);
+    seg(b.algorithm, n); seg(b.is_owner, n); seg(b.burst, n * 8); seg(b.created_at, n * 8); seg(b.key_bytes, (size_t)b.key_off[b.n] + 16);
     auto dev = [&](const void* hp) { return hp ? d_in + ((const uint8_t*)hp - s->h_in) : nullptr; };
     P.B = BatchView{b.n, 0, dev(b.key_bytes), (const uint32_t*)dev(b.key_off), (const int64_t*)dev(b.hits), (const int64_t*)dev(b.limit),
                     (const int64_t*)dev(b.duration), (const int64_t*)dev(b.burst), (const int64_t*)dev(b.created_at), dev(b.algorithm),
@@ -1151,7 +1166,7 @@ static int launch_stage_group(StagePlan* P, int g) {
     if (!planned) return rc;
     hipStream_t st = e0->stream;
     if (any_copy) {
-        MI.nb = (uint32_t)planned; MI.wg_per = 16;
+        MI.nb = (uint32_t)planned; MI.wg_per = 64;
         hipLaunchKernelGGL(k_stage_in_multi, dim3(MI.nb * MI.wg_per), dim3(256), 0, st, MI);
     }
     uint64_t units = 0;
@@ -1223,6 +1238,44 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         g = 0;
         return rc;
     };
+    // batches of <= 256 requests of engines that share device and stream: ONE k_small_multi, one workgroup per batch
+    guber_stage* sgrp[SMALL_MULTI_MAX]; int sg = 0;
+    auto flush_small = [&]() -> int {
+        if (!sg) return 0;
+        guber_engine* order[SMALL_MULTI_MAX];
+        for (int i = 0; i < sg; ++i) order[i] = sgrp[i]->e;
+        std::sort(order, order + sg);
+        for (int i = 0; i < sg; ++i) order[i]->mu.lock();
+        int rc = 0, planned = 0;
+        MultiSmall MS{};
+        guber_engine* e0 = sgrp[0]->e;
+        if (e0->set_device()) rc = fail(GUBER_E_HIP, "hipSetDevice");
+        for (int i = 0; i < sg && !rc; ++i) {
+            guber_stage* s = sgrp[i]; guber_engine* e = s->e;
+            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) { rc = r2; break; } }
+            const guber_batch_t& b = s->batch;
+            BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
+                        b.greg_expire, b.greg_duration, b.now_ms};
+            rc = small_prelude(e, B);
+            if (rc) break;
+            s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
+            s->sout->done = 0;
+            MS.sub[planned] = SmallArgs{e->T, B, ResultView{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err},
+                                        s->sout, s->seq, e->touch};
+            ++planned;
+        }
+        if (planned) {
+            MS.nb = (uint32_t)planned;
+            if (planned == 1) hipLaunchKernelGGL(k_small, dim3(1), dim3(FT), 0, e0->stream, MS.sub[0].T, MS.sub[0].B, MS.sub[0].R, MS.sub[0].out, MS.sub[0].seq, MS.sub[0].touch);
+            else hipLaunchKernelGGL(k_small_multi, dim3(planned), dim3(FT), 0, e0->stream, MS);
+            if (hipGetLastError() != hipSuccess && !rc) rc = fail(GUBER_E_HIP, "kernel launch");
+            for (int i = 0; i < planned; ++i) { sgrp[i]->mode = 3; sgrp[i]->e->small_pending = sgrp[i]; }
+            enq += (uint32_t)planned;
+        }
+        for (int i = sg - 1; i >= 0; --i) order[i]->mu.unlock();
+        sg = 0;
+        return rc;
+    };
     int rc = 0;
     for (uint32_t k = 0; k < n && !rc; ++k) {
         guber_stage* s = stages[k];
@@ -1233,6 +1286,12 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);        // the kernels read keys as 8-byte words
         const bool small = b.n <= FT && !e->no_small;
         const bool fusable = !small && can_fuse(e, b.n);
+        if (small) {
+            if (sg && (sg == SMALL_MULTI_MAX || e->stream != sgrp[0]->e->stream || e->device != sgrp[0]->e->device)) rc = flush_small();
+            if (rc) break;
+            sgrp[sg++] = s;
+            continue;
+        }
         if (g && (!fusable || g == MULTI_MAX || e->stream != grp[0].s->e->stream || e->device != grp[0].s->e->device)) rc = flush();
         if (rc) break;
         if (fusable) { grp[g++].s = s; continue; }
@@ -1242,22 +1301,21 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                     b.greg_expire, b.greg_duration, b.now_ms};
         ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
-        if (small) {
-            s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
-            s->sout->done = 0;
-            rc = launch_small(e, B, R, s->sout, s->seq);
-            if (rc) break;
-            s->mode = 3; e->small_pending = s;
-        } else {                                                   // the radix pipeline (n > 65 536) or a test configuration
-            rc = launch_batch(e, B, R, true);
-            if (rc) break;
-            if (hipEventRecord(s->ev, e->stream) != hipSuccess) { rc = fail(GUBER_E_HIP, "hipEventRecord"); break; }
-            s->mode = 2;
-        }
+        // the radix pipeline (n > 65 536) or a test configuration
+        rc = launch_batch(e, B, R, true);
+        if (rc) break;
+        if (hipEventRecord(s->ev, e->stream) != hipSuccess) { rc = fail(GUBER_E_HIP, "hipEventRecord"); break; }
+        s->mode = 2;
         ++enq;
     }
     if (!rc) rc = flush();
-    if (done) *done = enq;
+    if (!rc) rc = flush_small();
+    if (done) {                                                      // the leading stages (array order) that were enqueued; after an
+        uint32_t lead = 0;                                           // error the caller settles the others with guber_stage_wait
+        while (lead < n && (stages[lead]->mode != 0 || stages[lead]->batch.n == 0)) ++lead;
+        *done = rc ? lead : n;
+    }
+    (void)enq;
     return rc;
 }
 
@@ -1429,6 +1487,47 @@ static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, in
     if (hfound && out) { item_from_rec(hrec, out); out->key = nullptr; out->key_len = key_len; }
     return GUBER_OK;
 }
+
+// A hot key changes its logical shard (GPUWorkerPool's placement): its bucket leaves `from`'s table and enters `to`'s, on the
+// device (both engines live on one GPU).  The caller guarantees that no batch of either engine is being formed or is in
+// flight for those keys (the pool quiesces its stages first).
+extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to, const uint64_t* hashes, uint32_t n, uint32_t* moved) {
+    if (moved) *moved = 0;
+    if (!from || !to || from == to || (n && !hashes)) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (from->device != to->device) return fail(GUBER_E_INVALID_ARG, "engines on different devices");
+    if (n == 0) return GUBER_OK;
+    guber_engine* a = from < to ? from : to; guber_engine* b = from < to ? to : from;     // address order, as every multi-locker
+    std::lock_guard<std::mutex> la(a->mu); std::lock_guard<std::mutex> lb(b->mu);
+    if (from->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    const uint32_t stride = (std::min(from->max_key, to->max_key) + 23u) & ~7u;
+    DevBuf<uint64_t>& d_h = from->d_mvh;
+    if (d_h.ensure(n) || from->d_items.ensure(n) || from->d_ikeys.ensure((size_t)n * stride + 16) || to->d_islots.ensure(n) || to->d_iflags.ensure(n) ||
+        to->d_ires.ensure(n)) return GUBER_E_NOMEM;
+    std::vector<uint8_t> res(n);
+    hipError_t he = hipSuccess;
+    int rc = 0;
+    do {
+        if ((he = hipMemcpyAsync(d_h.p, hashes, (size_t)n * 8, hipMemcpyHostToDevice, from->stream)) != hipSuccess) break;
+        hipLaunchKernelGGL(k_items_take_by_hash, dim3((n + 63) / 64), dim3(64), 0, from->stream, from->T, d_h.p, n, stride, from->d_items.p, from->d_ikeys.p);
+        if ((he = hipStreamSynchronize(from->stream)) != hipSuccess) break;
+        rc = maintain(to, n, to->clock_ms);
+        if (rc) break;
+        to->tags_upper += n; to->size_upper += n; to->rb_added += n;
+        hipStream_t st = to->stream;
+        hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, to->T, from->d_items.p, from->d_ikeys.p, n, to->d_islots.p, to->d_iflags.p);
+        hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, to->T, from->d_items.p, from->d_ikeys.p, n, to->d_islots.p, to->d_iflags.p,
+                           to->d_ires.p, (to->touch = (to->touch + 1) & 0x7fffffffu));
+        if ((he = hipMemcpyAsync(res.data(), to->d_ires.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+        he = hipStreamSynchronize(st);
+    } while (0);
+    if (he != hipSuccess) return fail(GUBER_E_HIP, "guber_move_items_by_hash", he);
+    if (rc) return rc;
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) m += res[i] <= 1;                // (0xFE: the hash named no live bucket)
+    if (moved) *moved = m;
+    return GUBER_OK;
+}
+extern "C" void* guber_engine_stream(guber_engine_t* e) { return e ? (void*)e->stream : nullptr; }
 
 extern "C" int guber_get_item(guber_engine_t* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, guber_item_t* out, int* found) {
     return item_lookup(e, key, key_len, now_ms, 0, out, found);

@@ -47,6 +47,38 @@ __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* ite
     result[i] = existed ? 1 : 0;
 }
 
+// Take the buckets of up to n keys out of a table BY KEY HASH (the directory tag is the key's XXH64): the item and its key
+// bytes go to a staging image that k_items_probe / k_items_commit of ANOTHER table on the same device consume (a hot key moves
+// to another logical shard: GPUWorkerPool, guber_move_items_by_hash).  A hash that names no live bucket yields key_len 0 (the
+// probe skips it).  One thread per hash; `stride` bytes of key room each.
+__global__ __launch_bounds__(64) void k_items_take_by_hash(Table T, const uint64_t* hashes, uint32_t n, uint32_t stride, ItemIn* items, uint8_t* keys) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    ItemIn out; rec_clear(out.rec); out.key_off = i * stride; out.key_len = 0;
+    const uint64_t h = hashes[i] & T.hash_mask;
+    const unsigned long long tag = h ? h : 1ull;
+    uint64_t pos = (h >> 7) & T.mask;
+    for (uint32_t step = 0; step < T.max_probe; ++step, pos = (pos + 1) & T.mask) {
+        const unsigned long long t = ld_agent(&T.dir[pos].tag);
+        if (t == 0ull) break;
+        if (t != tag || !(ld_agent(&T.dir[pos].meta) & META_READY)) continue;
+        const Rec s = T.buckets[pos].rec;
+        if (rec_kind(s) == K_ABSENT) break;
+        const KeyCell* c = &T.buckets[pos].cell;
+        const uint32_t len = (uint32_t)(c->w[7] >> 48);
+        if (len == 0 || len > stride || len > T.max_key) break;
+        const uint8_t* src = len > INLINE_KEY ? T.arena + c->w[0] : (const uint8_t*)c->w;
+        for (uint32_t b = 0; b < len; ++b) keys[(size_t)i * stride + b] = src[b];
+        for (uint32_t b = len; b < ((len + 15u) & ~7u) && b < stride; ++b) keys[(size_t)i * stride + b] = 0;
+        out.rec = s; out.key_len = len;
+        Rec z; rec_clear(z);
+        T.buckets[pos].rec = z;                                  // (the tag stays, as for any removed bucket)
+        atomicAdd((unsigned long long*)&T.ctr->size, (unsigned long long)(long long)-1);
+        break;
+    }
+    items[i] = out;
+}
+
 // LRUCache.GetItem (lrucache.go:111-128) / Remove (:131-135) for one key. mode 0 = get, 1 = remove
 __global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found, uint32_t touch) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -309,17 +341,23 @@ __global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr
     }
 }
 
-// Request columns of up to MULTI_MAX stages: device-visible host memory -> each stage's HBM mirror, ONE launch on the stream the
-// batches' kernels follow on (the pool's dispatcher: a hipMemcpyAsync costs 40-60 us of host time, a launch 4-5).  Two blocks per
-// stage: the fixed-width columns up to the last one present, and the keys.  16-byte loads over PCIe, fully coalesced.
-struct StageIn { const uint4* src0; uint4* dst0; const uint4* src1; uint4* dst1; uint32_t n16_0, n16_1; };
+// Request columns of up to MULTI_MAX stages: device-visible host memory -> each stage's HBM mirror (same layout), ONE launch on the
+// stream the batches' kernels follow on (the pool's dispatcher: a hipMemcpyAsync costs 40-60 us of host time, a launch 4-5).
+// Only what the batch uses is moved: per column the first n entries (a stage's columns are laid out for max_n requests), then
+// the key bytes.  16-byte loads over PCIe, fully coalesced; every column starts on a 64-byte boundary.
+constexpr int STAGE_SEGS = 10;
+struct StageIn { const uint4* src; uint4* dst; uint32_t nseg; uint32_t off16[STAGE_SEGS], n16[STAGE_SEGS]; };
 struct MultiStageIn { uint32_t nb, wg_per; StageIn sub[MULTI_MAX]; };
+static_assert(sizeof(MultiStageIn) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(256) void k_stage_in_multi(MultiStageIn A) {
     const uint32_t sb = blockIdx.x / A.wg_per, w = blockIdx.x - sb * A.wg_per;
     const StageIn* s = (const StageIn*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiStageIn, sub)) + sb;
     const uint32_t stride = A.wg_per * 256u;
-    for (uint32_t i = w * 256u + threadIdx.x; i < s->n16_0; i += stride) s->dst0[i] = s->src0[i];
-    for (uint32_t i = w * 256u + threadIdx.x; i < s->n16_1; i += stride) s->dst1[i] = s->src1[i];
+    for (uint32_t k = 0; k < s->nseg; ++k) {
+        const uint4* src = s->src + s->off16[k]; uint4* dst = s->dst + s->off16[k];
+        const uint32_t n16 = s->n16[k];
+        for (uint32_t i = w * 256u + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    }
 }
 
 }  // namespace guber

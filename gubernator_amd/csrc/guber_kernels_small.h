@@ -28,7 +28,7 @@ struct SmallReqs {
     unsigned long long misc[FT];          // behavior | algorithm << 32 | is_owner << 40
 };
 
-__global__ __launch_bounds__(FT) void k_small(Table T, BatchView B, ResultView R, SmallOut* out, uint32_t seq, uint32_t touch) {
+__device__ __forceinline__ void small_body(const Table& T, const BatchView& B, const ResultView& R, SmallOut* out, const uint32_t seq, const uint32_t touch) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
     __shared__ unsigned long long gkey[GT];
     __shared__ unsigned long long gbits[FT / 64][GT];
@@ -217,6 +217,18 @@ __global__ __launch_bounds__(FT) void k_small(Table T, BatchView B, ResultView R
         __threadfence_system();
         __hip_atomic_store(&out->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+__global__ __launch_bounds__(FT) void k_small(Table T, BatchView B, ResultView R, SmallOut* out, uint32_t seq, uint32_t touch) { small_body(T, B, R, out, seq, touch); }
+
+// the small batches of several engines (the logical shards of a GPU: one table each) in ONE launch, one workgroup per batch —
+// what a pool's dispatcher has when a handful of requests arrive spread over its shards (guber_stages_submit)
+constexpr int SMALL_MULTI_MAX = 8;
+struct SmallArgs { Table T; BatchView B; ResultView R; SmallOut* out; uint32_t seq, touch; };
+struct MultiSmall { uint32_t nb; SmallArgs sub[SMALL_MULTI_MAX]; };
+static_assert(sizeof(MultiSmall) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(FT) void k_small_multi(MultiSmall A) {
+    const SmallArgs* a = (const SmallArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiSmall, sub)) + blockIdx.x;
+    small_body(a->T, a->B, a->R, a->out, a->seq, a->touch);
 }
 
 }  // namespace guber

@@ -25,47 +25,8 @@
 
 #include "../../include/guber_gpu.h"
 
-namespace {
-constexpr uint32_t kMaxHot = 64, kExCells = 256, kSketchBits = 14, kSketchRows = 2;
-
-struct Exceptions {                     // open addressing on the key hash, immutable once published
-    uint32_t n = 0;
-    uint64_t h[kExCells] = {0};
-    uint16_t s[kExCells] = {0};
-    static uint32_t home(uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 56); }
-    void put(uint64_t key, uint16_t shard) {
-        uint32_t i = home(key);
-        while (h[i] != 0 && h[i] != key) i = (i + 1) & (kExCells - 1);
-        if (h[i] == 0) n++;
-        h[i] = key; s[i] = shard;
-    }
-    int get(uint64_t key) const {
-        if (n == 0) return -1;
-        for (uint32_t i = home(key);; i = (i + 1) & (kExCells - 1)) {
-            if (h[i] == key) return s[i];
-            if (h[i] == 0) return -1;
-        }
-    }
-};
-struct Cell { std::atomic<uint64_t> h{0}; std::atomic<uint32_t> c{0}; };
-}  // namespace
-
-struct guber_placement {
-    uint32_t n_shards = 1, n_slots = 1;
-    uint64_t step = 0;
-    std::unique_ptr<std::atomic<uint16_t>[]> table;        // slot -> shard
-    std::atomic<const Exceptions*> ex{nullptr};
-    std::vector<std::unique_ptr<Exceptions>> retired;       // every snapshot ever published (a few hundred bytes each)
-    std::unique_ptr<std::atomic<uint64_t>[]> slot_w;        // requests observed per slot
-    std::unique_ptr<Cell[]> sketch;                         // [rows][1 << bits]
-    std::atomic<uint64_t> total{0};
-    std::atomic<uint32_t> version{0};
-    std::mutex mu;                                          // rebalance vs rebalance
-    uint32_t slot_of(uint64_t h) const {
-        const uint64_t s = (h >> 1) / step;                 // workers.go:153-155,180-184 with n_slots virtual workers
-        return s < n_slots ? (uint32_t)s : n_slots - 1;
-    }
-};
+#include "guber_placement_impl.h"
+using namespace guber_placement_detail;
 
 static uint32_t sketch_cell(uint64_t h, uint32_t row) {
     const uint64_t m = row ? 0xC2B2AE3D27D4EB4Full : 0x9E3779B97F4A7C15ull;
@@ -75,15 +36,16 @@ static uint32_t sketch_cell(uint64_t h, uint32_t row) {
 extern "C" int guber_placement_create(uint32_t n_shards, uint32_t n_slots, guber_placement_t** out) {
     if (!out || n_shards == 0 || n_shards > 4096) return GUBER_E_INVALID_ARG;
     if (n_slots == 0) n_slots = 4096;
-    if (n_slots < n_shards) n_slots = n_shards;
     if (n_slots > (1u << 20)) return GUBER_E_INVALID_ARG;
     guber_placement* p = new guber_placement();
-    p->n_shards = n_shards; p->n_slots = n_slots;
-    p->step = (1ull << 63) / n_slots;
+    p->n_shards = n_shards; p->per = std::max(1u, n_slots / n_shards); p->n_slots = n_slots = p->per * n_shards;
+    p->step = (1ull << 63) / n_shards;
+    p->inv_step = (uint64_t)((((unsigned __int128)1) << 64) / p->step);
+    p->inv_sub = (uint64_t)(((((unsigned __int128)1) << 64) * p->per) / p->step);
     p->table.reset(new std::atomic<uint16_t>[n_slots]);
     p->slot_w.reset(new std::atomic<uint64_t>[n_slots]);
     for (uint32_t s = 0; s < n_slots; ++s) {
-        p->table[s].store((uint16_t)((uint64_t)s * n_shards / n_slots));     // contiguous runs: the reference's getWorker
+        p->table[s].store((uint16_t)(s / p->per));                             // contiguous runs: the reference's getWorker
         p->slot_w[s].store(0);
     }
     p->sketch.reset(new Cell[(size_t)kSketchRows << kSketchBits]);
@@ -93,19 +55,13 @@ extern "C" int guber_placement_create(uint32_t n_shards, uint32_t n_slots, guber
 extern "C" void guber_placement_destroy(guber_placement_t* p) { delete p; }
 
 extern "C" uint32_t guber_placement_shard(const guber_placement_t* p, uint64_t key_hash) {
-    if (!p) return 0;
-    if (const Exceptions* e = p->ex.load(std::memory_order_acquire)) {
-        const int s = e->get(key_hash);
-        if (s >= 0) return (uint32_t)s;
-    }
-    return p->table[p->slot_of(key_hash)].load(std::memory_order_relaxed);
+    return p ? guber_placement_shard_inl(p, key_hash) : 0;
 }
 extern "C" uint32_t guber_placement_version(const guber_placement_t* p) { return p ? p->version.load(std::memory_order_acquire) : 0; }
 
 extern "C" void guber_placement_observe(guber_placement_t* p, uint64_t h, uint32_t weight) {
     if (!p || weight == 0) return;
-    p->slot_w[p->slot_of(h)].fetch_add(weight, std::memory_order_relaxed);
-    p->total.fetch_add(weight, std::memory_order_relaxed);
+    p->slot_w[p->slot_of(h)].fetch_add(weight, std::memory_order_relaxed);   // (the total is the sum of these: no shared hot word)
     for (uint32_t row = 0; row < kSketchRows; ++row) {       // Misra-Gries, one counter per cell: the cell's majority key survives
         Cell& c = p->sketch[((size_t)row << kSketchBits) + sketch_cell(h, row)];
         const uint64_t cur = c.h.load(std::memory_order_relaxed);
@@ -136,14 +92,14 @@ extern "C" int guber_placement_observe_keys(guber_placement_t* p, const uint8_t*
 // placed afresh (only legal while no key of this placement is resident anywhere: before the first request, or offline);
 // move_slots == 0: the slot table stays, only keys that became heavy are given a shard of their own choice (the least
 // loaded one) — those are the moves reported, for the caller to migrate.
-extern "C" int guber_placement_rebalance(guber_placement_t* p, double heavy_fraction, int move_slots, guber_placement_move_t* moves,
-                                         uint32_t cap, uint32_t* n_moves) {
-    if (n_moves) *n_moves = 0;
-    if (!p) return GUBER_E_INVALID_ARG;
+// plan (p->mu held): the new exception list (and, with move_slots, the new slot table written in place); nothing published
+static uint32_t plan_locked(guber_placement* p, double heavy_fraction, int move_slots, guber_placement_move_t* moves, uint32_t cap,
+                            std::unique_ptr<Exceptions>& ne) {
     if (heavy_fraction <= 0) heavy_fraction = 0.125;
-    std::lock_guard<std::mutex> lk(p->mu);
-    const uint64_t total = p->total.load();
-    if (total == 0) return GUBER_OK;
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < p->n_slots; ++s) total += p->slot_w[s].load();
+    ne.reset();
+    if (total == 0) return 0;
     const double fair = (double)total / p->n_shards;
     const Exceptions* old = p->ex.load();
     // heavy hitters: the larger of the two rows' estimates per key
@@ -163,7 +119,7 @@ extern "C" int guber_placement_rebalance(guber_placement_t* p, double heavy_frac
     for (uint32_t s = 0; s < p->n_slots; ++s) sw[s] = (double)p->slot_w[s].load();
     for (auto& x : hot) { double& w = sw[p->slot_of(x.h)]; w = std::max(0.0, w - x.w); }
     std::vector<double> load(p->n_shards, 0.0);
-    std::unique_ptr<Exceptions> ne(new Exceptions());
+    ne.reset(new Exceptions());
     if (old) *ne = *old;
     uint32_t nm = 0;
     auto least = [&]() { return (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin()); };
@@ -193,21 +149,54 @@ extern "C" int guber_placement_rebalance(guber_placement_t* p, double heavy_frac
             const uint32_t from = p->table[p->slot_of(x.h)].load();
             const uint32_t j = least();
             load[j] += x.w;
-            if (j == from) { ne->put(x.h, (uint16_t)j); continue; }                     // pinned where it is: no migration
             ne->put(x.h, (uint16_t)j);
+            if (j == from) continue;                                                     // pinned where it is: no migration
             if (moves && nm < cap) moves[nm] = guber_placement_move_t{x.h, from, j};
             nm++;
         }
     }
-    p->retired.push_back(std::move(ne));
-    p->ex.store(p->retired.back().get(), std::memory_order_release);
-    p->version.fetch_add(1, std::memory_order_acq_rel);
-    // the next round observes afresh
+    return nm;
+}
+// publish a planned list (p->mu held); the next round observes afresh
+static void publish_locked(guber_placement* p, std::unique_ptr<Exceptions>& ne) {
+    if (ne) {
+        p->retired.push_back(std::move(ne));
+        p->ex.store(p->retired.back().get(), std::memory_order_release);
+        p->version.fetch_add(1, std::memory_order_acq_rel);
+    }
     for (uint32_t s = 0; s < p->n_slots; ++s) p->slot_w[s].store(0);
     for (size_t k = 0; k < ((size_t)kSketchRows << kSketchBits); ++k) { p->sketch[k].h.store(0); p->sketch[k].c.store(0); }
-    p->total.store(0);
+}
+
+extern "C" int guber_placement_rebalance(guber_placement_t* p, double heavy_fraction, int move_slots, guber_placement_move_t* moves,
+                                         uint32_t cap, uint32_t* n_moves) {
+    if (n_moves) *n_moves = 0;
+    if (!p) return GUBER_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    std::unique_ptr<Exceptions> ne;
+    const uint32_t nm = plan_locked(p, heavy_fraction, move_slots, moves, cap, ne);
+    p->pending.reset();
+    publish_locked(p, ne);
     if (n_moves) *n_moves = nm;
     return (moves && nm > cap) ? GUBER_E_NOMEM : GUBER_OK;
+}
+
+// The same in two steps, for a caller that has to quiesce its shards between learning which resident keys move and letting
+// requests follow the new placement (GPUWorkerPool): plan (move_slots = 0 semantics; nothing a reader sees changes), then
+// — after the buckets have been migrated — commit.
+extern "C" int guber_placement_plan(guber_placement_t* p, double heavy_fraction, guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves) {
+    if (n_moves) *n_moves = 0;
+    if (!p) return GUBER_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    const uint32_t nm = plan_locked(p, heavy_fraction, 0, moves, cap, p->pending);
+    if (n_moves) *n_moves = nm;
+    return (moves && nm > cap) ? GUBER_E_NOMEM : GUBER_OK;
+}
+extern "C" int guber_placement_commit(guber_placement_t* p) {
+    if (!p) return GUBER_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    publish_locked(p, p->pending);
+    return GUBER_OK;
 }
 
 extern "C" int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_t* n_slots, uint32_t* n_hot) {

@@ -2,7 +2,9 @@
 #include "worker_pool.h"
 
 #include <linux/futex.h>
+#include <semaphore.h>
 #include <sys/syscall.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -12,37 +14,64 @@
 #include <cstdio>
 #include <cstring>
 
+#include "guber_algo.h"
+#include "guber_placement_impl.h"
+
 namespace gubernator {
 
-// short timed waits against the system clock (pthread_cond_timedwait, which ThreadSanitizer understands; a clock step only
-// makes one of these microsecond waits end early or late, and every waiter re-checks its condition)
-static void wait_us(std::condition_variable& cv, std::unique_lock<std::mutex>& lk, int64_t us) {
-    cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(us));
-}
-
-// Callers wait for their generation on a plain futex word: the batcher's announcement wakes exactly the threads sleeping on
-// that stage, each of which re-reads the word and goes on — no mutex to queue up behind (a condition variable made every
-// batch of small RPCs a convoy of all its callers).
-static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen) {
-    syscall(SYS_futex, (uint32_t*)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+// Callers wait for their generation — and the dispatcher for work — on plain futex words: an announcement wakes exactly the
+// threads sleeping on that word, each of which re-reads it and goes on; no mutex to queue up behind.
+static void futex_wait(std::atomic<uint32_t>* w, uint32_t seen, int64_t timeout_us = -1) {
+    if (timeout_us < 0) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0); return; }
+    struct timespec ts; ts.tv_sec = timeout_us / 1000000; ts.tv_nsec = (timeout_us % 1000000) * 1000;
+    syscall(SYS_futex, (uint32_t*)w, FUTEX_WAIT_PRIVATE, seen, &ts, nullptr, 0);
 }
 static void futex_wake_all(std::atomic<uint32_t>* w) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+static void futex_wake_n(std::atomic<uint32_t>* w, int n) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAKE_PRIVATE, n, nullptr, nullptr, 0); }
 
 static int64_t mono_us() {
     using namespace std::chrono;
     return duration_cast<microseconds>(steady_clock::now().time_since_epoch()).count();
 }
+static inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+static uint32_t env_u32(const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; }
 
 GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards,
                              const std::vector<int32_t>& devices)
     : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
-    if (const char* v = getenv("GUBER_POOL_IDLE_US")) idle_us_ = (uint32_t)atoi(v);   // 0 = off (the reference's policy: limit or wait only)
+    idle_us_ = env_u32("GUBER_POOL_IDLE_US", 0);                     // optional extra trigger: nobody reserved for this long and all slots written
+    depth_ = std::max(1u, std::min(env_u32("GUBER_POOL_DEPTH", 2), kStages - 2));   // batches of one shard on the GPU at a time
+    eager_ = env_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
+    eager_min_ = env_u32("GUBER_POOL_EAGER_MIN", 4096);
+    spin_us_ = env_u32("GUBER_POOL_SPIN_US", 40);                    // how long a waiting caller looks before it sleeps
+    {   // callers allowed in the CPU part of a call at a time: the CPUs this process may really use (a cgroup CPU quota counts),
+        // minus one for the dispatcher.  More runnable callers than CPUs only get the whole group throttled.
+        uint32_t cpus = std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0}; unsigned long long period = 0;
+            if (fscanf(f, "%31s %llu", q, &period) == 2 && period && strcmp(q, "max") != 0) {
+                const unsigned long long quota = strtoull(q, nullptr, 10);
+                if (quota) cpus = std::min<uint32_t>(cpus, (uint32_t)((quota + period - 1) / period));
+            }
+            fclose(f);
+        }
+        max_active_ = env_u32("GUBER_POOL_MAX_ACTIVE", cpus > 4 ? cpus - 2 - cpus / 8 : cpus);
+        limit_active_ = max_active_ != 0;
+        max_spinners_ = std::max(1u, std::min(cpus / 2, 16u));
+        if (limit_active_) sem_init(&active_sem_, 0, max_active_);
+    }
+    rebalance_ms_ = env_u32("GUBER_POOL_REBALANCE_MS", 250);         // 0 = placement stays the reference's worker rule
     if (shards == 0) shards = 1;
+    if (shards > 1024) shards = 1024;
     std::vector<int32_t> devs = devices;
     if (devs.empty()) devs.push_back(cfg.device);
-    n_devices_ = (uint32_t)devs.size(); shards_per_device_ = shards;
-    ring_step_ = (1ull << 63) / shards;                              // workers.go:132 hashRingStep
-    if (n_devices_ > 1) {                                            // the GPUs of the node are the peers of the ring
+    has_global_ = (cfg.flags & GUBER_FLAG_GLOBAL) != 0;
+    n_devices_ = (uint32_t)devs.size(); plain_per_device_ = shards; shards_per_device_ = shards + (has_global_ ? 1 : 0);
+    if (n_devices_ > 1 || has_global_) {                             // the GPUs of the node are the peers of the ring
         std::vector<std::string> names; std::vector<const char*> ptrs;
         for (uint32_t i = 0; i < n_devices_; ++i) names.push_back("gpu" + std::to_string(i));
         for (auto& n : names) ptrs.push_back(n.c_str());
@@ -52,56 +81,93 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     guber_config_t c = cfg;
     if (c.max_batch < batch_limit_) c.max_batch = batch_limit_;
     const uint32_t total = n_devices_ * shards;
-    if (total > 1) c.cache_size = c.cache_size / total + 1;          // workers.go:132 `CacheSize / Workers` per worker
+    const uint64_t per_shard = total > 1 ? cfg.cache_size / total + 1 : cfg.cache_size;   // workers.go:132 `CacheSize / Workers` per worker
     max_key_ = c.max_key_bytes ? c.max_key_bytes : 1024;
     // room for batch_limit keys of typical size; a batch whose keys do not fit is flushed early (never overrun)
-    key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)batch_limit_ * std::min<uint32_t>(max_key_, 96u) + max_key_, 1u << 30);
+    key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)batch_limit_ * std::min<uint32_t>(max_key_, 96u) + max_key_, (1u << 24) - 1);
+    // the shards of a device are spread over a few streams; shards that share one share their launches (guber_stages_submit)
+    uint32_t n_streams = env_u32("GUBER_POOL_STREAMS", 0);
+    if (n_streams == 0) n_streams = (shards + 3) / 4;                // a fused launch carries the batches of up to four shards
+    n_streams = std::max(1u, std::min(n_streams, shards));
     for (uint32_t d = 0; d < n_devices_ && create_rc_ == GUBER_OK; ++d) {
-        for (uint32_t i = 0; i < shards; ++i) {
+        std::unique_ptr<Device> dev(new Device());
+        dev->index = d; dev->ordinal = devs[d]; dev->n_plain = shards;
+        if (shards > 1) {
+            create_rc_ = guber_placement_create(shards, 0, &dev->place);
+            if (create_rc_ != GUBER_OK) { devs_.push_back(std::move(dev)); break; }
+        }
+        std::vector<void*> stream_of(n_streams, nullptr);
+        for (uint32_t i = 0; i < shards_per_device_; ++i) {
             std::unique_ptr<Shard> sh(new Shard());
+            const bool global = i >= shards;
+            const uint32_t sidx = global ? n_streams - 1 : (uint32_t)((uint64_t)i * n_streams / shards);
             c.device = devs[d];
-            sh->device = devs[d];
+            c.flags = global ? cfg.flags : (cfg.flags & ~(uint32_t)GUBER_FLAG_GLOBAL);
+            c.cache_size = global ? std::max<uint64_t>(cfg.cache_size / n_devices_, 1) : per_shard;
+            c.stream = stream_of[sidx];
+            sh->device = devs[d]; sh->global = global; sh->dev = dev.get();
             create_rc_ = guber_engine_create(&c, &sh->engine);
             if (create_rc_ != GUBER_OK) { sh->engine = nullptr; break; }
+            if (!stream_of[sidx]) { stream_of[sidx] = guber_engine_stream(sh->engine); sh->owns_stream = true; }
             for (uint32_t k = 0; k < kStages && create_rc_ == GUBER_OK; ++k) {
                 Stage& st = sh->st[k];
                 create_rc_ = guber_stage_create(sh->engine, batch_limit_, key_cap_, &st.stage);
                 if (create_rc_ != GUBER_OK) break;
                 st.b = guber_stage_batch(st.stage); st.r = guber_stage_result(st.stage);
+                st.shard = sh.get();
                 st.name_len.assign(batch_limit_, 0);
             }
+            dev->shards.push_back(sh.get());
             shards_.push_back(std::move(sh));
             if (create_rc_ != GUBER_OK) break;
         }
+        devs_.push_back(std::move(dev));
     }
     if (create_rc_ != GUBER_OK) {
-        for (auto& sh : shards_) { for (auto& st : sh->st) guber_stage_destroy(st.stage); guber_engine_destroy(sh->engine); }
+        destroy_engines();
         shards_.clear();
         return;
     }
-    for (auto& sh : shards_) { Shard* p = sh.get(); p->thread = std::thread([this, p] { run(*p); }); }
+    for (auto& d : devs_) { Device* p = d.get(); p->thread = std::thread([this, p] { run(*p); }); }
+}
+
+void GPUWorkerPool::destroy_engines() {
+    for (auto& sh : shards_) for (auto& st : sh->st) if (st.stage) { guber_stage_destroy(st.stage); st.stage = nullptr; }
+    for (int pass = 0; pass < 2; ++pass)                             // the engines that own a stream go last
+        for (auto& sh : shards_)
+            if (sh->engine && (pass == 1 || !sh->owns_stream)) { guber_engine_destroy(sh->engine); sh->engine = nullptr; }
+    // (the Shard objects and the placements stay until the destructor: a caller that raced Close() may still look at them)
 }
 
 GPUWorkerPool::~GPUWorkerPool() {
     Close();
+    for (auto& d : devs_) if (d->place) { guber_placement_destroy(d->place); d->place = nullptr; }
     if (ring_) guber_ring_destroy(ring_);
+    if (limit_active_) sem_destroy(&active_sem_);
+}
+
+// at most max_active_ callers are in the CPU part of a call at a time; the others wait their turn asleep (a counting semaphore:
+// one sleeper is woken per slot that frees up — no herd)
+void GPUWorkerPool::enter() { if (limit_active_) while (sem_wait(&active_sem_) != 0) {} }
+void GPUWorkerPool::leave() { if (limit_active_) sem_post(&active_sem_); }
+
+void GPUWorkerPool::wake(Device& d) {
+    d.wake.fetch_add(1, std::memory_order_seq_cst);
+    if (d.sleeping.load(std::memory_order_seq_cst)) futex_wake_all(&d.wake);
 }
 
 void GPUWorkerPool::Close() {
     if (closed_.exchange(true)) return;
-    for (auto& sh : shards_) {
-        { std::lock_guard<std::mutex> lk(sh->mu); sh->closing = true; }
-        sh->cv_batcher.notify_all();
+    for (auto& d : devs_) { d->closing.store(true); wake(*d); }
+    for (auto& d : devs_) if (d->thread.joinable()) d->thread.join();   // every reserved request has been evaluated and announced
+    {
+        std::lock_guard<std::mutex> lk(comm_mu_);
+        if (comm_) { guber_comm_destroy(comm_); comm_ = nullptr; }
     }
-    for (auto& sh : shards_) {
-        if (sh->thread.joinable()) sh->thread.join();            // every reserved request has been evaluated and announced
-        for (auto& st : sh->st) {
-            // callers may still be copying their responses out of the stage
-            while (st.gen.load() && st.consumed.load(std::memory_order_acquire) != st.n) std::this_thread::yield();
-            guber_stage_destroy(st.stage); st.stage = nullptr;
-        }
-        if (sh->engine) { guber_engine_destroy(sh->engine); sh->engine = nullptr; }
-    }
+    for (auto& sh : shards_)
+        for (auto& st : sh->st)                                      // callers may still be copying their responses out of the stage
+            while (st.gen.load() && st.state != Stage::kFree && st.state != Stage::kOpen && st.consumed.load(std::memory_order_acquire) != st.n) std::this_thread::yield();
+    destroy_engines();
 }
 
 uint32_t GPUWorkerPool::DeviceOf(const uint8_t* key, uint32_t len) const {
@@ -111,14 +177,14 @@ uint32_t GPUWorkerPool::DeviceOf(const uint8_t* key, uint32_t len) const {
     guber_ring_route(ring_, key, off, 1, &owner);                                           // replicated_hash.go:104-119
     return owner < n_devices_ ? owner : 0;
 }
-uint32_t GPUWorkerPool::ShardOf(const uint8_t* key, uint32_t len) const {
+uint32_t GPUWorkerPool::route(const Device& d, uint64_t h, uint32_t behavior) const {
+    if (has_global_ && (behavior & 2u)) return d.n_plain;                                   // Behavior_GLOBAL: the device's GLOBAL engine
+    return d.place ? guber_placement_shard_inl(d.place, h) : 0;                             // workers.go:180-184 getWorker, generalised
+}
+uint32_t GPUWorkerPool::ShardOf(const uint8_t* key, uint32_t len, uint32_t behavior) const {
     if (shards_.size() <= 1) return 0;
-    uint32_t local = 0;
-    if (shards_per_device_ > 1) {
-        const uint64_t h63 = guber_xxhash64(key, len, 0) >> 1;                              // workers.go:153-155 ComputeHash63
-        local = (uint32_t)std::min<uint64_t>(h63 / ring_step_, shards_per_device_ - 1);     // workers.go:180-184 getWorker
-    }
-    return DeviceOf(key, len) * shards_per_device_ + local;
+    const uint32_t dv = DeviceOf(key, len);
+    return dv * shards_per_device_ + route(*devs_[dv], guber_xxhash64(key, len, 0), behavior);   // workers.go:153-155 ComputeHash63
 }
 uint64_t GPUWorkerPool::batches_flushed() const {
     uint64_t n = 0;
@@ -129,7 +195,7 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
     memset(out, 0, sizeof(*out));
     for (auto& sh : shards_) {
         out->batches += sh->flushed.load(); out->requests += sh->requests.load();
-        for (auto& st : sh->st) { const uint64_t w = st.word.load(); if (!(w & kClosed)) out->queue_length += (uint32_t)w; }
+        for (auto& st : sh->st) { const uint64_t w = st.word.load(); if (!(w & kClosed)) out->queue_length += word_count(w); }
         out->queue_length_max = std::max<uint64_t>(out->queue_length_max, sh->queue_max.load());
         out->send_duration_us_sum += sh->send_us_sum.load();
         out->send_duration_us_max = std::max<uint64_t>(out->send_duration_us_max, sh->send_us_max.load());
@@ -137,11 +203,16 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
         out->in_flight += sh->in_flight.load();
         out->key_too_long += sh->key_too_long.load(); out->flush_on_key_bytes += sh->flush_on_key_bytes.load();
     }
+    for (auto& d : devs_) { out->rebalances += d->rebalances.load(); out->keys_moved += d->moves.load(); out->submit_us_sum += d->submit_us.load(); out->submits += d->submits.load(); }
     out->shards = (uint32_t)shards_.size(); out->devices = n_devices_;
+    if (getenv("GUBER_POOL_DEBUG") && d_dbg_[3].load())
+        fprintf(stderr, "[pool] per batch: wait for writers %.1f us, submit %.1f us, on the GPU until seen %.1f us (%llu batches); dispatcher loops %llu, polls %llu\n",
+                (double)d_dbg_[0] / d_dbg_[3], (double)d_dbg_[1] / d_dbg_[3], (double)d_dbg_[2] / d_dbg_[3], (unsigned long long)d_dbg_[3].load(),
+                (unsigned long long)d_dbg_[4].load(), (unsigned long long)d_dbg_[5].load());
 }
 
 int64_t GPUWorkerPool::NowMs() const {
-    const int64_t f = frozen_ms_.load();
+    const int64_t f = frozen_ms_.load(std::memory_order_relaxed);
     if (f) return f;
     using namespace std::chrono;
     return duration_cast<milliseconds>(system_clock::now().time_since_epoch()).count();   // MillisecondNow, lrucache.go:106
@@ -156,279 +227,642 @@ bool GPUWorkerPool::GetRateLimit(const RateLimitReq& r, RateLimitReqState st, Ra
 }
 
 // ---- the callers' side ---------------------------------------------------------------------------------------------------
-struct GPUWorkerPool::Job {
-    const std::vector<const RateLimitReq*>& reqs;
-    const std::vector<RateLimitReqState>& st;
-    std::vector<RateLimitResp*>& out;
-    std::vector<uint32_t> key_len;                    // HashKey length per request
-    std::vector<std::vector<uint32_t>> per;           // per shard: request indices in call order
-    std::vector<Ticket> tickets;
+// One call = a list of requests from some source (C++ objects, or the structure-of-arrays a binding hands over) whose answers go
+// to some sink.  The work per request is a few dozen nanoseconds and all of it is the caller's: HashKey bytes, XXH64, device and
+// shard, a share of one compare-and-swap, eight stores into the stage, four loads out of it.
+struct ReqRef {
+    const uint8_t *name, *ukey; uint32_t name_len, ukey_len;
+    int64_t hits, limit, duration, burst, created_at; int32_t algorithm; uint32_t behavior; bool is_owner;
+};
+// per-thread scratch: nothing is allocated per call once a thread has served a few RPCs
+struct GPUWorkerPool::Scratch {
+    std::vector<uint8_t> keys;                        // HashKey bytes of every request, back to back
+    std::vector<uint32_t> koff, klen;
+    std::vector<uint64_t> hash;
+    std::vector<uint16_t> dev;
+    std::vector<uint32_t> shard, order, todo, next, count, vers;
+    std::vector<Ticket2> tickets;
+    uint32_t observe_tick = 0;
 };
 
-static void answer_item(RateLimitResp& o, const RateLimitReq& req, int rc, uint8_t err, uint8_t status, int64_t limit, int64_t remaining,
-                        int64_t reset_time) {
-    o = RateLimitResp{};
-    if (rc != GUBER_OK) {
-        o.error = std::string("gpu engine: ") + guber_strerror(rc);
-    } else if (err != 0) {
-        char buf[256];
-        if (err == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, sizeof buf, guber_item_strerror(err), req.algorithm);
-        else snprintf(buf, sizeof buf, "%s", guber_item_strerror(err));
-        o.error = buf;                                               // nil response + error (workers.go:317-321)
-    } else {
-        o.status = status; o.limit = limit; o.remaining = remaining; o.reset_time = reset_time;
+#ifdef GUBER_POOL_PHASES
+static std::atomic<uint64_t> g_ph[6];
+static inline uint64_t tsc() { return __builtin_ia32_rdtsc(); }
+struct PhasePrinter { ~PhasePrinter() { uint64_t t = 0; for (int k = 0; k < 5; ++k) t += g_ph[k]; if (g_ph[5]) fprintf(stderr, "[phases] per request cycles: build %.1f route+sort %.1f reserve+write %.1f wait %.1f consume %.1f (n=%llu)\n", (double)g_ph[0] / g_ph[5], (double)g_ph[1] / g_ph[5], (double)g_ph[2] / g_ph[5], (double)g_ph[3] / g_ph[5], (double)g_ph[4] / g_ph[5], (unsigned long long)g_ph[5].load()); } } g_phase_printer;
+#define PH(k) do { const uint64_t _t = tsc(); g_ph[k] += _t - ph_t; ph_t = _t; } while (0)
+#else
+#define PH(k) do {} while (0)
+#endif
+template <class Src, class Sink>
+struct GPUWorkerPool::Call {
+    GPUWorkerPool& P; const Src& src; Sink& sink; Scratch& S;
+
+    void run() {
+        const uint32_t n = src.size();
+        if (n == 0) return;
+        if (P.closed_.load() || P.shards_.empty()) { for (uint32_t i = 0; i < n; ++i) sink.closed(i); return; }
+        P.enter();
+#ifdef GUBER_POOL_PHASES
+        uint64_t ph_t = tsc(); g_ph[5] += n;
+#endif
+        S.koff.resize(n + 1); S.klen.resize(n); S.hash.resize(n); S.dev.resize(n); S.shard.resize(n); S.todo.resize(n);
+        S.order.clear(); S.tickets.clear();
+        // HashKey = name + "_" + unique_key (client.go:39-41), its XXH64 (workers.go:153-155), its device (replicated_hash.go:104-119)
+        S.keys.resize(src.key_bytes_total() + 16);
+        uint8_t* const kb = S.keys.data();
+        uint32_t o = 0, nt = 0;
+        const bool multi = P.n_devices_ > 1;
+        ReqRef r;
+        for (uint32_t i = 0; i < n; ++i) {
+            src.key(i, r);
+            S.koff[i] = o;
+            const uint32_t len = r.name_len + 1 + r.ukey_len;
+            S.klen[i] = len;
+            uint8_t* k = kb + o;
+            memcpy(k, r.name, r.name_len); k[r.name_len] = '_'; memcpy(k + r.name_len + 1, r.ukey, r.ukey_len);
+            o += len;
+            if (r.name_len == 0 || r.ukey_len == 0) { if (src.front_end_checks()) continue; }   // (answered by the front end: empty field)
+            const uint32_t dv = multi ? P.DeviceOf(k, len) : 0;
+            S.dev[i] = (uint16_t)dv;
+            if (len > P.max_key_) {                                  // answered here, never reaches the device
+                P.shards_[(size_t)dv * P.shards_per_device_]->key_too_long++;
+                sink.item_error(i, GUBER_ITEM_E_KEY_TOO_LONG, src.algorithm(i));
+                continue;
+            }
+            const uint64_t h = guber::xxhash64(k, len, 0);
+            S.hash[i] = h;
+            S.todo[nt++] = i;
+            Device& d = *P.devs_[dv];
+            if (d.place && (++S.observe_tick & 63u) == 0 && P.rebalance_ms_ && !(P.has_global_ && (src.behavior(i) & 2u)))
+                guber_placement_observe(d.place, h, 64);             // every 64th request feeds the placement's view of the traffic
+        }
+        S.koff[n] = o;
+        S.todo.resize(nt);
+        PH(0);
+        // Every request belongs to the shard of its key (workers.go:261-291); requests of one key keep their order.  A round
+        // routes what is left with the devices' current placement versions; a reservation refused as stale (the placement
+        // changed between routing and reserving) sends the rest of that list into the next round.
+        const uint32_t n_shards = (uint32_t)P.shards_.size();
+        while (!S.todo.empty()) {
+            S.vers.assign(P.n_devices_, 0xffffffffu);
+            S.count.assign(n_shards + 1, 0);
+            for (uint32_t i : S.todo) {
+                const uint32_t dv = S.dev[i];
+                Device& d = *P.devs_[dv];
+                if (S.vers[dv] == 0xffffffffu) S.vers[dv] = d.ver.load(std::memory_order_acquire) & 0x7fu;
+                const uint32_t j = dv * P.shards_per_device_ + P.route(d, S.hash[i], src.behavior(i));
+                S.shard[i] = j;
+                S.count[j + 1]++;
+            }
+            for (uint32_t j = 0; j < n_shards; ++j) S.count[j + 1] += S.count[j];
+            const uint32_t base = (uint32_t)S.order.size();
+            S.order.resize(base + S.todo.size());
+            {
+                std::vector<uint32_t>& fill = S.next;                // (scratch: running positions)
+                fill.assign(S.count.begin(), S.count.end() - 1);
+                for (uint32_t i : S.todo) S.order[base + fill[S.shard[i]]++] = i;
+            }
+            S.next.clear();
+            PH(1);
+            bool closed = false;
+            for (uint32_t j = 0; j < n_shards; ++j) {
+                uint32_t pos = base + S.count[j], left = S.count[j + 1] - S.count[j];
+                if (!left) continue;
+                Shard& sh = *P.shards_[j];
+                while (left) {
+                    if (closed) { for (uint32_t q = 0; q < left; ++q) sink.closed(S.order[pos + q]); break; }
+                    Ticket2 t{};
+                    const int got = reserve(sh, S.vers[sh.dev->index], pos, left, &t);
+                    if (got == 0) { closed = true; continue; }
+                    if (got < 0) { S.next.insert(S.next.end(), S.order.begin() + pos, S.order.begin() + pos + left); break; }
+                    write(t);
+                    S.tickets.push_back(t);
+                    pos += (uint32_t)got; left -= (uint32_t)got;
+                }
+            }
+            PH(2);
+            S.todo.swap(S.next);
+            if (closed) { for (uint32_t i : S.todo) sink.closed(i); S.todo.clear(); }
+        }
+        P.leave();                                                   // (waiting for the answers needs no CPU)
+#ifdef GUBER_POOL_PHASES
+        for (auto& t : S.tickets) { Stage& s = *t.st; while (s.done_gen.load(std::memory_order_acquire) != (uint32_t)t.gen) cpu_relax(); }
+        PH(3);
+#endif
+        for (auto& t : S.tickets)
+            if (!t.consumed) consume(t, true);
+        PH(4);
     }
+
+    // Reserve slots for as many of order[pos .. pos + count) as the shard's open stage still takes: ONE compare-and-swap on the
+    // stage's reservation word (slots | key bytes << 32 | placement version << 56).  Returns the number reserved (>= 1), 0 when
+    // the pool has been closed, -1 when the device's placement is no longer the one the caller routed with.
+    int reserve(Shard& sh, uint32_t ver, uint32_t pos, uint32_t count, Ticket2* out) {
+        Device& d = *sh.dev;
+        for (;;) {
+            const uint32_t seq = sh.open_seq.load(std::memory_order_acquire);
+            const uint32_t k = sh.open.load(std::memory_order_acquire);
+            if (k == kOpenDead) return 0;
+            if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver) return -1;
+            if (k < kStages) {
+                Stage& s = sh.st[k];
+                uint64_t w = s.word.load(std::memory_order_acquire);
+                while (!(w & kClosed)) {
+                    if (word_ver(w) != ver) return -1;
+                    const uint32_t cnt = word_count(w), kbytes = word_bytes(w);
+                    const uint32_t room = P.batch_limit_ - cnt;
+                    uint32_t take = std::min(room, count); uint64_t bytes = 0;
+                    const uint32_t* list = S.order.data() + pos;
+                    for (uint32_t q = 0; q < take; ++q) bytes += S.klen[list[q]];
+                    if ((uint64_t)kbytes + bytes > P.key_cap_) {          // rare: the stage's key buffer is the limit
+                        take = 0; bytes = 0;
+                        while (take < room && take < count) {
+                            const uint32_t kl = S.klen[list[take]];
+                            if ((uint64_t)kbytes + bytes + kl > P.key_cap_) break;
+                            bytes += kl; ++take;
+                        }
+                    }
+                    if (take == 0) {                                 // no slot or no key bytes left: flush it now, take the next stage
+                        if (!s.flush_now.exchange(true)) {
+                            if (room) sh.flush_on_key_bytes++;
+                            P.wake(d);
+                        }
+                        break;
+                    }
+                    if (s.word.compare_exchange_weak(w, w + take + (bytes << 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
+                        *out = Ticket2{&s, s.gen.load(std::memory_order_relaxed), cnt, take, pos, kbytes, false};
+                        const bool first = cnt == 0, full = cnt + take >= P.batch_limit_;
+                        const int64_t now = mono_us();
+                        if (first) s.first_us.store(now, std::memory_order_release);
+                        s.last_us.store(now, std::memory_order_release);
+                        const uint64_t q = (uint64_t)cnt + take;
+                        if (q > sh.queue_max.load(std::memory_order_relaxed)) sh.queue_max.store(q, std::memory_order_relaxed);
+                        if (first || full) P.wake(d);
+                        return (int)take;
+                    }
+                }
+            }
+            // no stage takes reservations right now: pick up responses that are ready (so that stages drain and the dispatcher
+            // can rotate), then wait for it to open the next one
+            for (auto& t : S.tickets)
+                if (!t.consumed) consume(t, false);
+            sh.open_waiters.fetch_add(1, std::memory_order_seq_cst);
+            if (sh.open_seq.load(std::memory_order_seq_cst) == seq) futex_wait(&sh.open_seq, seq, 200);
+            sh.open_waiters.fetch_sub(1, std::memory_order_seq_cst);
+        }
+    }
+
+    // the caller writes its requests into the slots it reserved: the HashKey bytes straight into the stage's key buffer
+    void write(const Ticket2& t) {
+        Stage& s = *t.st;
+        const guber_batch_t* b = s.b;
+        uint8_t* kp = (uint8_t*)b->key_bytes;
+        uint32_t* off = (uint32_t*)b->key_off;
+        int64_t *hits = (int64_t*)b->hits, *limit = (int64_t*)b->limit, *duration = (int64_t*)b->duration, *burst = (int64_t*)b->burst,
+                *created = (int64_t*)b->created_at;
+        uint8_t *algo = (uint8_t*)b->algorithm, *owner = (uint8_t*)b->is_owner;
+        uint32_t* beh = (uint32_t*)b->behavior;
+        int64_t now = 0;
+        uint32_t o = t.key_base;
+        const uint32_t* list = S.order.data() + t.list_begin;
+        const uint8_t* kb = S.keys.data();
+        ReqRef r;
+        for (uint32_t q = 0; q < t.count; ++q) {
+            const uint32_t ri = list[q], i = t.first_slot + q;
+            src.get(ri, r);
+            off[i] = o;
+            {   // exactly the key's bytes: the next slot's key may belong to another caller, who may have written it already
+                const uint8_t* from = kb + S.koff[ri]; uint8_t* to = kp + o; const uint32_t len = S.klen[ri];
+                uint32_t w = 0;
+                for (; w + 8 <= len; w += 8) { uint64_t v; memcpy(&v, from + w, 8); memcpy(to + w, &v, 8); }
+                for (; w < len; ++w) to[w] = from[w];
+                o += len;
+            }
+            hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
+            if (r.created_at) created[i] = r.created_at;
+            else { if (!now) now = P.NowMs(); created[i] = now; }
+            algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
+            beh[i] = r.behavior; owner[i] = r.is_owner ? 1 : 0;
+            s.name_len[i] = (uint16_t)std::min<uint32_t>(S.klen[ri] - 1 - r.ukey_len, 0xffff);
+        }
+        s.written.fetch_add(t.count, std::memory_order_release);
+    }
+
+    // the responses of a ticket, once its generation has been announced; returns false when not ready and !block
+    bool consume(Ticket2& t, bool block) {
+        Stage& s = *t.st;
+        // (a stage carries generation g + 1 only after every ticket of g has been consumed, so the word reads g - 1 or g here)
+        // A caller of a small batch looks for a moment (the answer is a few microseconds away), everybody else sleeps on the
+        // word at once: a host's cores belong to the callers that still have requests to write.  The dispatcher wakes TWO
+        // sleepers per announcement and every woken caller wakes two more — the wake-ups fan out as a tree instead of being
+        // one thread's serial work (hundreds of callers may wait for one generation).
+        uint32_t v = s.done_gen.load(std::memory_order_acquire);
+        if (v != (uint32_t)t.gen) {
+            if (!block) return false;
+            bool spin = P.spin_us_ && word_count(s.word.load(std::memory_order_relaxed)) <= 256;
+            if (spin && P.spinners_.fetch_add(1, std::memory_order_relaxed) >= P.max_spinners_) { P.spinners_.fetch_sub(1, std::memory_order_relaxed); spin = false; }
+            if (spin) {
+                const int64_t t0 = mono_us();
+                for (uint32_t spins = 0; (v = s.done_gen.load(std::memory_order_acquire)) != (uint32_t)t.gen; ++spins) {
+                    if ((spins & 63u) == 63u && mono_us() - t0 >= (int64_t)P.spin_us_) break;
+                    cpu_relax();
+                }
+                P.spinners_.fetch_sub(1, std::memory_order_relaxed);
+            }
+            if (v != (uint32_t)t.gen) {
+                s.sleepers.fetch_add(1, std::memory_order_seq_cst);
+                while ((v = s.done_gen.load(std::memory_order_seq_cst)) != (uint32_t)t.gen) futex_wait(&s.done_gen, v);
+                if (s.sleepers.fetch_sub(1, std::memory_order_seq_cst) > 1) futex_wake_n(&s.done_gen, 2);
+            }
+        }
+        const int rc = s.rc;
+        const guber_result_t* r = s.r;
+        const uint32_t* list = S.order.data() + t.list_begin;
+        if (rc != GUBER_OK) {
+            for (uint32_t q = 0; q < t.count; ++q) sink.engine_error(list[q], rc);
+        } else {
+            for (uint32_t q = 0; q < t.count; ++q) {
+                const uint32_t ri = list[q], i = t.first_slot + q;
+                if (r->err[i] == 0) sink.ok(ri, r->status[i], r->limit[i], r->remaining[i], r->reset_time[i]);
+                else sink.item_error(ri, r->err[i], src.algorithm(ri));
+            }
+        }
+        t.consumed = true;
+        s.consumed.fetch_add(t.count, std::memory_order_release);
+        return true;
+    }
+};
+
+static void item_error_text(char* buf, size_t cap, uint8_t err, int32_t algorithm) {
+    if (err == GUBER_ITEM_E_INVALID_ALGORITHM) snprintf(buf, cap, guber_item_strerror(err), algorithm);
+    else snprintf(buf, cap, "%s", guber_item_strerror(err));
 }
+
+// ---- source / sink of the C++ interface: RateLimitReq / RateLimitResp objects
+namespace {
+struct VecSrc {
+    const std::vector<const RateLimitReq*>& reqs; const std::vector<RateLimitReqState>& st;
+    uint32_t size() const { return (uint32_t)reqs.size(); }
+    bool front_end_checks() const { return false; }                  // (V1Instance::GetRateLimits has made them)
+    size_t key_bytes_total() const { size_t t = 0; for (auto* q : reqs) t += q->name.size() + 1 + q->unique_key.size(); return t; }
+    void key(uint32_t i, ReqRef& r) const {
+        const RateLimitReq& q = *reqs[i];
+        r.name = (const uint8_t*)q.name.data(); r.name_len = (uint32_t)q.name.size();
+        r.ukey = (const uint8_t*)q.unique_key.data(); r.ukey_len = (uint32_t)q.unique_key.size();
+    }
+    uint32_t behavior(uint32_t i) const { return reqs[i]->behavior; }
+    int32_t algorithm(uint32_t i) const { return reqs[i]->algorithm; }
+    void get(uint32_t i, ReqRef& r) const {
+        const RateLimitReq& q = *reqs[i];
+        r.name = (const uint8_t*)q.name.data(); r.name_len = (uint32_t)q.name.size();
+        r.ukey = (const uint8_t*)q.unique_key.data(); r.ukey_len = (uint32_t)q.unique_key.size();
+        r.hits = q.hits; r.limit = q.limit; r.duration = q.duration; r.burst = q.burst; r.created_at = q.created_at;
+        r.algorithm = q.algorithm; r.behavior = q.behavior; r.is_owner = st[i].is_owner;
+    }
+};
+struct VecSink {
+    std::vector<RateLimitResp*>& out;
+    void ok(uint32_t i, uint8_t status, int64_t limit, int64_t remaining, int64_t reset_time) {
+        RateLimitResp& o = *out[i];
+        o.status = status; o.limit = limit; o.remaining = remaining; o.reset_time = reset_time;
+        if (!o.error.empty()) o.error.clear();
+    }
+    void item_error(uint32_t i, uint8_t err, int32_t algorithm) {
+        char buf[256];
+        item_error_text(buf, sizeof buf, err, algorithm);
+        *out[i] = RateLimitResp{}; out[i]->error = buf;              // nil response + error (workers.go:317-321)
+    }
+    void engine_error(uint32_t i, int rc) { *out[i] = RateLimitResp{}; out[i]->error = std::string("gpu engine: ") + guber_strerror(rc); }
+    void closed(uint32_t i) { *out[i] = RateLimitResp{}; out[i]->error = "worker pool is closed"; }
+};
+}  // namespace
 
 void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
                                      std::vector<RateLimitResp*>& out) {
-    if (reqs.empty()) return;
-    if (closed_.load() || shards_.empty()) {
-        for (auto* r : out) r->error = "worker pool is closed";
+    static thread_local Scratch tls;
+    VecSrc src{reqs, st}; VecSink sink{out};
+    Call<VecSrc, VecSink>{*this, src, sink, tls}.run();
+}
+
+// ---- source / sink of the C interface (what a binding hands over: structure-of-arrays in, structure-of-arrays out) with the
+// V1Instance.GetRateLimits front end folded in (gubernator.go:183-306): empty-field errors, CreatedAt default, error wrapping
+namespace {
+struct SoaSrc {
+    uint32_t n; const uint8_t* name_bytes; const uint32_t* name_off; const uint8_t* ukey_bytes; const uint32_t* ukey_off;
+    const int64_t *hits, *limit, *duration, *burst, *created_at; const int32_t* algo; const uint32_t* beh;
+    int64_t created_default;
+    uint32_t size() const { return n; }
+    bool front_end_checks() const { return true; }                   // empty fields have been answered: skip them
+    size_t key_bytes_total() const { return (size_t)(name_off[n] - name_off[0]) + (ukey_off[n] - ukey_off[0]) + n; }
+    void key(uint32_t i, ReqRef& r) const {
+        r.name = name_bytes + name_off[i]; r.name_len = name_off[i + 1] - name_off[i];
+        r.ukey = ukey_bytes + ukey_off[i]; r.ukey_len = ukey_off[i + 1] - ukey_off[i];
+    }
+    uint32_t behavior(uint32_t i) const { return beh ? beh[i] : 0; }
+    int32_t algorithm(uint32_t i) const { return algo ? algo[i] : 0; }
+    void get(uint32_t i, ReqRef& r) const {
+        r.name = name_bytes + name_off[i]; r.name_len = name_off[i + 1] - name_off[i];
+        r.ukey = ukey_bytes + ukey_off[i]; r.ukey_len = ukey_off[i + 1] - ukey_off[i];
+        r.hits = hits[i]; r.limit = limit[i]; r.duration = duration[i]; r.burst = burst ? burst[i] : 0;
+        r.created_at = created_at && created_at[i] ? created_at[i] : created_default;                    // gubernator.go:218-220
+        r.algorithm = algorithm(i); r.behavior = behavior(i); r.is_owner = true;
+    }
+};
+struct SoaSink {
+    const SoaSrc& src; guber_result_t* out; char* err_text; uint32_t stride;
+    void fail(uint32_t i, const char* msg, bool wrap) {
+        out->status[i] = 0; out->limit[i] = 0; out->remaining[i] = 0; out->reset_time[i] = 0; out->err[i] = 1;
+        if (!err_text || !stride) return;
+        char* dst = err_text + (size_t)i * stride;
+        if (!wrap) { snprintf(dst, stride, "%s", msg); return; }
+        // gubernator.go:250-255: errors of the local path are wrapped with the key
+        ReqRef r; src.get(i, r);
+        snprintf(dst, stride, "Error while apply rate limit for '%.*s_%.*s': %s", (int)r.name_len, (const char*)r.name, (int)r.ukey_len, (const char*)r.ukey, msg);
+    }
+    void ok(uint32_t i, uint8_t status, int64_t limit, int64_t remaining, int64_t reset_time) {
+        out->status[i] = status; out->limit[i] = limit; out->remaining[i] = remaining; out->reset_time[i] = reset_time; out->err[i] = 0;
+    }
+    void item_error(uint32_t i, uint8_t err, int32_t algorithm) { char buf[256]; item_error_text(buf, sizeof buf, err, algorithm); fail(i, buf, true); }
+    void engine_error(uint32_t i, int rc) { char buf[128]; snprintf(buf, sizeof buf, "gpu engine: %s", guber_strerror(rc)); fail(i, buf, true); }
+    void closed(uint32_t i) { fail(i, "worker pool is closed", true); }
+};
+}  // namespace
+
+int GPUWorkerPool::GetRateLimitsSoA(uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off, const uint8_t* ukey_bytes,
+                                    const uint32_t* ukey_off, const int64_t* hits, const int64_t* limit, const int64_t* duration,
+                                    const int64_t* burst, const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
+                                    guber_result_t* out, char* err_text, uint32_t err_stride) {
+    if (n > kMaxBatchSize) {                                          // gubernator.go:189-193
+        if (err_text && err_stride) snprintf(err_text, err_stride, "Requests.RateLimits list too large; max size is '%u'", kMaxBatchSize);
+        return GUBER_E_BATCH_TOO_LARGE;
+    }
+    static thread_local Scratch tls;
+    SoaSrc src{n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior, NowMs()};
+    SoaSink sink{src, out, err_text, err_stride};
+    if (err_text && err_stride) for (uint32_t i = 0; i < n; ++i) err_text[(size_t)i * err_stride] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ukey_off[i + 1] == ukey_off[i]) sink.fail(i, "field 'unique_key' cannot be empty", false);       // gubernator.go:208-212
+        else if (name_off[i + 1] == name_off[i]) sink.fail(i, "field 'namespace' cannot be empty", false);   // :213-217
+    }
+    Call<SoaSrc, SoaSink>{*this, src, sink, tls}.run();
+    return GUBER_OK;
+}
+
+// ---- the dispatcher's side -----------------------------------------------------------------------------------------------
+void GPUWorkerPool::open_stage(Shard& sh, uint32_t k, uint32_t ver) {
+    Stage& s = sh.st[k];
+    s.n = 0; s.rc = GUBER_OK; s.submitted = false;
+    s.written.store(0); s.consumed.store(0); s.first_us.store(0); s.last_us.store(0); s.flush_now.store(false);
+    s.gen.store(s.gen.load() + 1);
+    s.state = Stage::kOpen;
+    s.word.store((uint64_t)(ver & 0x7fu) << 56, std::memory_order_release);
+    sh.cur = k;
+    sh.open.store(k, std::memory_order_release);
+    sh.open_seq.fetch_add(1, std::memory_order_seq_cst);
+    if (sh.open_waiters.load(std::memory_order_seq_cst) > 0) futex_wake_all(&sh.open_seq);
+}
+
+// a stage whose responses have all been picked up is free again
+int GPUWorkerPool::find_free(Shard& sh) {
+    for (uint32_t k = 0; k < kStages; ++k) {
+        Stage& s = sh.st[k];
+        if (s.state == Stage::kDraining && s.consumed.load(std::memory_order_acquire) == s.n) s.state = Stage::kFree;
+        if (s.state == Stage::kFree) return (int)k;
+    }
+    return -1;
+}
+
+// close the shard's open stage to reservations; with requests in it, it joins `due`
+void GPUWorkerPool::seal(Shard& sh, Stage& s, std::vector<Stage*>& due) {
+    const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
+    s.n = word_count(w);
+    if (s.n == 0) { s.state = Stage::kFree; return; }
+    ((uint32_t*)s.b->key_off)[s.n] = word_bytes(w);
+    s.state = Stage::kSealed;
+    due.push_back(&s);
+}
+
+// Flush policy of one shard: at batch_limit, at batch_wait after the first reservation (peer_client.go:284-337), when a caller
+// found no room, and — by default — as soon as nobody has reserved anything for idle_us and every reserved slot is written
+// (the callers are all waiting: holding the batch only adds latency).  *deadline = when to look again at the latest.
+void GPUWorkerPool::seal_if_due(Shard& sh, int64_t now, bool force, bool eager_ok, std::vector<Stage*>& due, int64_t* deadline) {
+    Device& d = *sh.dev;
+    if (sh.open.load(std::memory_order_relaxed) == kOpenNone) {      // no stage was free when the last one was sealed
+        const int k = find_free(sh);
+        if (k >= 0) open_stage(sh, (uint32_t)k, d.ver.load(std::memory_order_relaxed));
+        else *deadline = std::min(*deadline, now + 20);
         return;
     }
-    Job job{reqs, st, out, {}, {}, {}};
-    job.key_len.resize(reqs.size());
-    job.per.resize(shards_.size());
-    // every request belongs to the shard of its key (workers.go:261-291); requests of one key keep their order
-    std::string k;
-    for (size_t i = 0; i < reqs.size(); ++i) {
-        k.assign(reqs[i]->name); k.push_back('_'); k.append(reqs[i]->unique_key);               // HashKey, client.go:39-41
-        job.key_len[i] = (uint32_t)k.size();
-        const uint32_t j = ShardOf((const uint8_t*)k.data(), (uint32_t)k.size());
-        if (k.size() > max_key_) {                                   // answered here, never reaches the device
-            shards_[j]->key_too_long++;
-            answer_item(*out[i], *reqs[i], GUBER_OK, GUBER_ITEM_E_KEY_TOO_LONG, 0, 0, 0, 0);
-            continue;
-        }
-        job.per[j].push_back((uint32_t)i);
-    }
-    for (size_t j = 0; j < job.per.size(); ++j) {
-        const std::vector<uint32_t>& list = job.per[j];
-        uint32_t begin = 0;
-        while (begin < list.size()) {
-            Ticket t{};
-            const uint32_t got = reserve(job, *shards_[j], list, begin, &t);
-            if (!got) { fail_rest(job, list, begin, "worker pool is closed"); break; }
-            write_requests(job, t, list);
-            job.tickets.push_back(t);
-            begin += got;
-        }
-    }
-    for (auto& t : job.tickets)
-        if (!t.consumed) try_consume(job, t, true);
-}
-
-void GPUWorkerPool::fail_rest(Job& job, const std::vector<uint32_t>& list, uint32_t begin, const char* why) {
-    for (size_t q = begin; q < list.size(); ++q) { *job.out[list[q]] = RateLimitResp{}; job.out[list[q]]->error = why; }
-}
-
-// Reserve slots for as many of list[begin..] as the shard's open stage still takes: ONE compare-and-swap on the stage's
-// reservation word (slots | key bytes << 32).  Returns the number reserved (>= 1), or 0 when the pool has been closed.
-uint32_t GPUWorkerPool::reserve(Job& job, Shard& sh, const std::vector<uint32_t>& list, uint32_t begin, Ticket* out) {
-    for (;;) {
-        const uint32_t k = sh.open.load(std::memory_order_acquire);
-        if (k == kStages + 1) return 0;
-        if (k < kStages) {
-            Stage& s = sh.st[k];
-            uint64_t w = s.word.load(std::memory_order_acquire);
-            while (!(w & kClosed)) {
-                const uint32_t cnt = (uint32_t)w, kb = (uint32_t)(w >> 32);
-                const uint32_t room = batch_limit_ - cnt;
-                uint32_t take = 0; uint64_t bytes = 0;
-                while (take < room && begin + take < list.size()) {
-                    const uint32_t kl = job.key_len[list[begin + take]];
-                    if ((uint64_t)kb + bytes + kl > key_cap_) break;
-                    bytes += kl; ++take;
-                }
-                if (take == 0) {                                     // no slot or no key bytes left: flush it now, take the next stage
-                    if (!s.flush_now.exchange(true)) {
-                        if (room) sh.flush_on_key_bytes++;
-                        { std::lock_guard<std::mutex> lk(sh.mu); }
-                        sh.cv_batcher.notify_one();
-                    }
-                    break;
-                }
-                if (s.word.compare_exchange_weak(w, w + take + (bytes << 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
-                    *out = Ticket{&sh, &s, s.gen.load(std::memory_order_relaxed), cnt, take, begin, kb, &list, false};
-                    const bool first = cnt == 0, full = cnt + take >= batch_limit_;
-                    if (first) s.first_us.store(mono_us(), std::memory_order_release);
-                    const uint64_t q = (uint64_t)cnt + take;
-                    if (q > sh.queue_max.load(std::memory_order_relaxed)) sh.queue_max.store(q, std::memory_order_relaxed);
-                    if (first || full) {
-                        { std::lock_guard<std::mutex> lk(sh.mu); }
-                        sh.cv_batcher.notify_one();
-                    }
-                    return take;
-                }
+    Stage& s = sh.st[sh.cur];
+    if (s.state != Stage::kOpen) return;
+    const uint32_t cnt = word_count(s.word.load(std::memory_order_acquire));
+    if (cnt == 0) return;
+    bool is_due = cnt >= batch_limit_ || force || s.flush_now.load(std::memory_order_relaxed);
+    if (!is_due && eager_ok) is_due = true;                          // (the device has room: see run())
+    if (!is_due) {
+        const int64_t first = s.first_us.load(std::memory_order_acquire), last = s.last_us.load(std::memory_order_acquire);
+        if (!first) { *deadline = std::min(*deadline, now + 5); return; }       // the first reserver is about to stamp it
+        if (now - first >= (int64_t)batch_wait_us_) is_due = true;
+        else {
+            *deadline = std::min(*deadline, first + (int64_t)batch_wait_us_);
+            if (idle_us_) {
+                if (now - last >= (int64_t)idle_us_) {
+                    if (s.written.load(std::memory_order_acquire) == cnt && word_count(s.word.load(std::memory_order_acquire)) == cnt) is_due = true;
+                    else *deadline = std::min(*deadline, now + 2);
+                } else *deadline = std::min(*deadline, last + (int64_t)idle_us_);
             }
         }
-        // no stage takes reservations right now: pick up responses that are ready (so that stages drain and the batcher can
-        // rotate), then wait for the batcher to open the next one
-        for (auto& t : job.tickets)
-            if (!t.consumed) try_consume(job, t, false);
-        std::unique_lock<std::mutex> lk(sh.mu);
-        if (sh.open.load(std::memory_order_acquire) == k) wait_us(sh.cv_callers, lk, 50);
     }
+    if (!is_due) return;
+    // the next free stage takes the reservations from here on
+    const int k = find_free(sh);
+    const uint32_t cur = sh.cur;
+    if (k >= 0) open_stage(sh, (uint32_t)k, d.ver.load(std::memory_order_relaxed));
+    else sh.open.store(kOpenNone, std::memory_order_release);
+    seal(sh, sh.st[cur], due);
 }
 
-// the caller writes its requests into the slots it reserved: HashKey = name + "_" + unique_key straight into the key buffer
-void GPUWorkerPool::write_requests(Job& job, const Ticket& t, const std::vector<uint32_t>& list) {
-    Stage& s = *t.st;
-    const guber_batch_t* b = s.b;
-    uint8_t* kp = (uint8_t*)b->key_bytes;
-    uint32_t* off = (uint32_t*)b->key_off;
-    int64_t *hits = (int64_t*)b->hits, *limit = (int64_t*)b->limit, *duration = (int64_t*)b->duration, *burst = (int64_t*)b->burst,
-            *created = (int64_t*)b->created_at;
-    uint8_t *algo = (uint8_t*)b->algorithm, *owner = (uint8_t*)b->is_owner;
-    uint32_t* beh = (uint32_t*)b->behavior;
-    int64_t now = 0;
-    uint32_t o = t.key_base;
-    for (uint32_t q = 0; q < t.count; ++q) {
-        const uint32_t ri = list[t.list_begin + q], i = t.first_slot + q;
-        const RateLimitReq& r = *job.reqs[ri];
-        off[i] = o;
-        memcpy(kp + o, r.name.data(), r.name.size()); o += (uint32_t)r.name.size();
-        kp[o++] = '_';
-        memcpy(kp + o, r.unique_key.data(), r.unique_key.size()); o += (uint32_t)r.unique_key.size();
-        hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
-        if (r.created_at) created[i] = r.created_at;
-        else { if (!now) now = NowMs(); created[i] = now; }
-        algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
-        beh[i] = r.behavior; owner[i] = job.st[ri].is_owner ? 1 : 0;
-        s.name_len[i] = (uint16_t)std::min<size_t>(r.name.size(), 0xffff);
+// hand the sealed stages to the engines: ONE submission for all of them (fused launches), or — with a persistent Store
+// configured — the synchronous path that makes the Store's calls
+void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<Stage*>& inflight) {
+    if (due.empty()) return;
+    const int64_t t0 = mono_us();
+    const int64_t now_ms = NowMs();
+    for (Stage* s : due) {
+        for (uint32_t spins = 0; s->written.load(std::memory_order_acquire) != s->n; ++spins) {   // callers still copying their requests in
+            if (spins < 200) cpu_relax(); else std::this_thread::yield();
+        }
+        s->t_written_us = mono_us();
+        Shard& sh = *s->shard;
+        s->t0_us = t0;
+        sh.requests += s->n;
+        if (s->n > sh.batch_max.load(std::memory_order_relaxed)) sh.batch_max.store(s->n, std::memory_order_relaxed);
+        s->b->n = s->n; s->b->now_ms = now_ms;                       // DURATION_IS_GREGORIAN: the kernels derive the interval from now_ms
+        sh.in_flight++;
     }
-    s.written.fetch_add(t.count, std::memory_order_release);
-}
-
-// the responses of a ticket, once its generation has been announced; returns false when not ready and !block
-bool GPUWorkerPool::try_consume(Job& job, Ticket& t, bool block) {
-    Stage& s = *t.st;
-    // (a stage carries generation g + 1 only after every ticket of g has been consumed, so the word reads g - 1 or g here)
-    for (uint32_t v; (v = s.done_gen.load(std::memory_order_acquire)) != (uint32_t)t.gen;) {
-        if (!block) return false;
-        futex_wait(&s.done_gen, v);
+    if (has_store_.load()) {
+        for (Stage* s : due) { submit_with_store(*s->shard, *s); announce(*s->shard, *s); }
+        due.clear();
+        return;
     }
-    const int rc = s.rc;
-    const guber_result_t* r = s.r;
-    for (uint32_t q = 0; q < t.count; ++q) {
-        const uint32_t ri = (*t.list)[t.list_begin + q], i = t.first_slot + q;
-        answer_item(*job.out[ri], *job.reqs[ri], rc, rc == GUBER_OK ? r->err[i] : 0, r->status[i], r->limit[i], r->remaining[i], r->reset_time[i]);
-    }
-    t.consumed = true;
-    s.consumed.fetch_add(t.count, std::memory_order_release);
-    return true;
-}
-
-// ---- the batcher's side --------------------------------------------------------------------------------------------------
-void GPUWorkerPool::open_stage(Shard& sh, uint32_t k) {
-    Stage& s = sh.st[k];
-    s.n = 0; s.rc = GUBER_OK;
-    s.written.store(0); s.consumed.store(0); s.first_us.store(0); s.flush_now.store(false);
-    s.gen.store(s.gen.load() + 1);
-    s.word.store(0, std::memory_order_release);
-    sh.open.store(k, std::memory_order_release);
-    { std::lock_guard<std::mutex> lk(sh.mu); }
-    sh.cv_callers.notify_all();
-}
-
-void GPUWorkerPool::run(Shard& sh) {
-    uint32_t cur = 0;
-    int inflight = -1;                                               // stage submitted and not yet announced
-    open_stage(sh, cur);
-    for (;;) {
-        Stage& s = sh.st[cur];
-        bool due = false, closing = false;
-        uint32_t seen_cnt = 0; int64_t seen_us = 0;                 // idle flush: when the reserved count last changed
-        {
-            // flush at batch_limit, at batch_wait after the first reservation (peer_client.go:284-337), or when a caller found
-            // no room; with nothing due, deliver the batch in flight instead of sitting on it
-            std::unique_lock<std::mutex> lk(sh.mu);
-            for (;;) {
-                closing = sh.closing;
-                const uint32_t cnt = (uint32_t)s.word.load(std::memory_order_acquire);
-                if (cnt >= batch_limit_ || (cnt && (closing || s.flush_now.load()))) { due = true; break; }
-                if (cnt) {
-                    const int64_t first = s.first_us.load(std::memory_order_acquire), now = mono_us();
-                    if (first && now - first >= (int64_t)batch_wait_us_) { due = true; break; }
-                    int64_t left = first ? (int64_t)batch_wait_us_ - (now - first) : (int64_t)batch_wait_us_;
-                    if (idle_us_) {
-                        // optional: nobody has reserved anything for idle_us and every reserved slot is written — the callers are
-                        // all waiting for this batch, so holding it until batch_wait only adds latency
-                        if (cnt != seen_cnt) { seen_cnt = cnt; seen_us = now; }
-                        else if (now - seen_us >= (int64_t)idle_us_ && s.written.load(std::memory_order_acquire) == cnt) { due = true; break; }
-                        left = std::min<int64_t>(left, (int64_t)idle_us_ - (now - seen_us));
-                    }
-                    if (inflight >= 0) break;
-                    wait_us(sh.cv_batcher, lk, std::max<int64_t>(left, 1));
-                    continue;
-                }
-                if (inflight >= 0 || closing) break;
-                sh.cv_batcher.wait(lk);
+    guber_stage_t* arr[64];
+    const uint32_t gen = d.gen_seq++ & 7u;
+    for (size_t lo = 0; lo < due.size(); lo += 64) {
+        const uint32_t m = (uint32_t)std::min<size_t>(64, due.size() - lo);
+        for (uint32_t q = 0; q < m; ++q) arr[q] = due[lo + q]->stage;
+        uint32_t done = 0;
+        const int64_t ts = mono_us();
+        const int rc = guber_stages_submit(arr, m, GUBER_STAGES_NO_AGGREGATES, &done);
+        d.submit_us.fetch_add((uint64_t)(mono_us() - ts), std::memory_order_relaxed); d.submits.fetch_add(1, std::memory_order_relaxed);
+        for (uint32_t q = 0; q < m; ++q) {
+            Stage* s = due[lo + q];
+            if (q < done) {
+                s->submitted = true; s->state = Stage::kInFlight; s->shard->stages_in_flight++; s->t_submitted_us = mono_us(); inflight.push_back(s);
+                s->dev_gen = gen;
+                if (d.gen_left[gen]++ == 0) d.gens_in_flight++;
             }
+            else { (void)guber_stage_wait(s->stage); s->rc = rc != GUBER_OK ? rc : GUBER_E_HIP; announce(*s->shard, *s); }   // (it may have been enqueued after all)
         }
-        if (!due) {
-            if (inflight >= 0) { complete(sh, sh.st[inflight]); inflight = -1; continue; }
-            if (closing) {
-                // nothing reserved, nothing in flight: stop taking reservations; a caller may have slipped one in meanwhile
-                sh.open.store(kStages + 1, std::memory_order_release);
-                const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
-                if ((uint32_t)w == 0) break;
-                s.n = (uint32_t)w;
-                while (s.written.load(std::memory_order_acquire) != s.n) std::this_thread::yield();
-                ((uint32_t*)s.b->key_off)[s.n] = (uint32_t)(w >> 32);
-                submit(sh, s);
-                complete(sh, s);
-                break;
-            }
-            continue;
-        }
-        // the next stage takes the reservations from here on; it was announced two flushes ago and has been read out since
-        const uint32_t next = (cur + 1) % kStages;
-        Stage& nx = sh.st[next];
-        if (inflight == (int)next) { complete(sh, nx); inflight = -1; }
-        for (uint32_t spins = 0; nx.gen.load() && nx.consumed.load(std::memory_order_acquire) != nx.n; ++spins) {
-            if (spins < 64) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(20));
-        }
-        open_stage(sh, next);
-        const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
-        s.n = (uint32_t)w;
-        while (s.written.load(std::memory_order_acquire) != s.n) std::this_thread::yield();   // callers still copying their requests in
-        ((uint32_t*)s.b->key_off)[s.n] = (uint32_t)(w >> 32);
-        submit(sh, s);
-        if (inflight >= 0) complete(sh, sh.st[inflight]);
-        inflight = (int)cur;
-        cur = next;
     }
-    if (inflight >= 0) complete(sh, sh.st[inflight]);
-    sh.open.store(kStages + 1, std::memory_order_release);
-    { std::lock_guard<std::mutex> lk(sh.mu); }
-    sh.cv_callers.notify_all();
+    due.clear();
 }
 
-// hand a sealed stage to the engine (asynchronous).  With a persistent Store configured the batch takes the synchronous
-// path that makes the Store's calls.
-void GPUWorkerPool::submit(Shard& sh, Stage& s) {
-    s.t0_us = mono_us();
-    sh.requests += s.n;
-    if (s.n > sh.batch_max.load()) sh.batch_max.store(s.n);
-    guber_batch_t* b = s.b;
-    b->n = s.n; b->now_ms = NowMs();                                  // DURATION_IS_GREGORIAN: the kernels derive the interval from now_ms
-    sh.in_flight++;
-    if (has_store_.load()) { submit_with_store(sh, s); return; }
-    s.rc = guber_stage_submit(s.stage);
-    s.submitted = s.rc == GUBER_OK;
+// look at the stages in flight; announce the ones whose responses are there.  Returns whether any finished.
+bool GPUWorkerPool::poll(std::vector<Stage*>& inflight) {
+    bool any = false;
+    for (size_t q = 0; q < inflight.size();) {
+        Stage* s = inflight[q];
+        const int r = guber_stage_poll(s->stage);
+        if (r == 0) { ++q; continue; }
+        s->rc = r < 0 ? r : guber_stage_wait(s->stage);              // (already complete: resolves the rare internal retry)
+        s->submitted = false; s->shard->stages_in_flight--;
+        { Device& d = *s->shard->dev; if (--d.gen_left[s->dev_gen] == 0) d.gens_in_flight--; }
+        { const int64_t t = mono_us(); d_dbg_[0] += (uint64_t)(s->t_written_us - s->t0_us); d_dbg_[1] += (uint64_t)(s->t_submitted_us - s->t_written_us); d_dbg_[2] += (uint64_t)(t - s->t_submitted_us); d_dbg_[3]++; }
+        announce(*s->shard, *s);
+        inflight[q] = inflight.back(); inflight.pop_back();
+        any = true;
+    }
+    return any;
 }
 
-// wait for a submitted stage and announce its generation: the callers read their responses themselves
-void GPUWorkerPool::complete(Shard& sh, Stage& s) {
-    if (s.submitted) { s.rc = guber_stage_wait(s.stage); s.submitted = false; }
+// announce a stage's generation: the callers read their responses themselves
+void GPUWorkerPool::announce(Shard& sh, Stage& s) {
     const uint64_t us = (uint64_t)std::max<int64_t>(mono_us() - s.t0_us, 0);
     sh.send_us_sum += us;
-    if (us > sh.send_us_max.load()) sh.send_us_max.store(us);
+    if (us > sh.send_us_max.load(std::memory_order_relaxed)) sh.send_us_max.store(us, std::memory_order_relaxed);
     sh.flushed++; sh.in_flight--;
-    s.done_gen.store((uint32_t)s.gen.load(), std::memory_order_release);
-    futex_wake_all(&s.done_gen);
+    s.state = Stage::kDraining;
+    s.done_gen.store((uint32_t)s.gen.load(), std::memory_order_seq_cst);
+    if (s.sleepers.load(std::memory_order_seq_cst) > 0) futex_wake_n(&s.done_gen, 2);
+}
+
+void GPUWorkerPool::drain(std::vector<Stage*>& inflight) {
+    for (uint32_t spins = 0; !inflight.empty(); ++spins) {
+        if (!poll(inflight)) { if (spins < 2000) cpu_relax(); else std::this_thread::yield(); }
+    }
+}
+
+// Placement pass: the keys that turned out to carry a large share of the device's traffic get a shard of their own choice.
+// A resident key moves at a batch boundary — every open stage is sealed, the batches in flight drain, the bucket changes
+// tables on the device, the new exception list is published and the stages reopen under the next placement version — so that
+// every request of the key routed with the old placement has been evaluated before the first one routed with the new.
+void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
+    if (!d.place || d.n_plain < 2) return;
+    guber_placement_move_t moves[64];
+    uint32_t nm = 0;
+    if (guber_placement_plan(d.place, 0.125, moves, 64, &nm) != GUBER_OK) { (void)guber_placement_commit(d.place); return; }
+    d.rebalances++;
+    if (nm == 0) { (void)guber_placement_commit(d.place); return; }  // (keys pinned where they are change nothing a caller can see)
+    std::vector<Stage*> due;
+    for (Shard* sh : d.shards) {
+        if (sh->open.load(std::memory_order_relaxed) == kOpenNone) continue;
+        sh->open.store(kOpenNone, std::memory_order_release);
+        Stage& s = sh->st[sh->cur];
+        if (s.state == Stage::kOpen) seal(*sh, s, due);
+    }
+    submit_due(d, due, inflight);
+    drain(inflight);
+    {
+        std::unique_lock<std::shared_mutex> lk(d.place_mu);
+        for (uint32_t q = 0; q < nm; ++q) {
+            if (moves[q].from >= d.n_plain || moves[q].to >= d.n_plain) continue;
+            uint32_t moved = 0;
+            (void)guber_move_items_by_hash(d.shards[moves[q].from]->engine, d.shards[moves[q].to]->engine, &moves[q].key_hash, 1, &moved);
+            d.moves += 1;
+        }
+        (void)guber_placement_commit(d.place);
+        d.ver.fetch_add(1, std::memory_order_acq_rel);
+    }
+    const uint32_t ver = d.ver.load();
+    for (Shard* sh : d.shards) {
+        const int k = find_free(*sh);
+        if (k >= 0) open_stage(*sh, (uint32_t)k, ver);               // (none free: seal_if_due opens one as soon as its callers have read it out)
+        else { sh->open_seq.fetch_add(1, std::memory_order_release); futex_wake_all(&sh->open_seq); }
+    }
+}
+
+void GPUWorkerPool::RebalanceNow() {
+    for (auto& d : devs_) { d->rebalance_now.store(true); wake(*d); }
+}
+
+void GPUWorkerPool::run(Device& d) {
+    std::vector<Stage*> inflight, due;
+    for (Shard* sh : d.shards) open_stage(*sh, 0, 0);
+    int64_t next_rebalance = rebalance_ms_ ? mono_us() + (int64_t)rebalance_ms_ * 1000 : INT64_MAX;
+    uint32_t idle_spins = 0;
+    int64_t last_active = 0;
+    for (;;) {
+        const uint32_t seen = d.wake.load(std::memory_order_seq_cst);
+        const bool closing = d.closing.load(std::memory_order_acquire);
+        d_dbg_[4]++; d_dbg_[5] += inflight.size();
+        const int64_t now = mono_us();
+        bool progressed = !inflight.empty() && poll(inflight);
+        int64_t deadline = INT64_MAX;
+        // The reference's workers take a request the moment it arrives (workers.go:261-291): what is waiting goes — the batches of
+        // ALL the device's shards together, so that they share launches — as soon as the device has nothing in flight; it then
+        // collects what arrives while that runs, so batches grow with the load by themselves.  A second generation follows
+        // behind the first once it is worth its launches.
+        bool eager_ok = false;
+        if (eager_ && d.gens_in_flight < depth_) {
+            if (d.gens_in_flight == 0) eager_ok = true;
+            else {
+                uint64_t pending = 0;
+                for (Shard* sh : d.shards) if (sh->st[sh->cur].state == Stage::kOpen) pending += word_count(sh->st[sh->cur].word.load(std::memory_order_relaxed));
+                eager_ok = pending >= eager_min_;
+            }
+        }
+        for (Shard* sh : d.shards) seal_if_due(*sh, now, closing, eager_ok, due, &deadline);
+        if (!due.empty()) { submit_due(d, due, inflight); progressed = true; }
+        if (closing && inflight.empty()) {
+            // stop taking reservations; a caller may have slipped one in meanwhile: those are still evaluated
+            for (Shard* sh : d.shards) {
+                const uint32_t was = sh->open.exchange(kOpenDead, std::memory_order_acq_rel);
+                if (was < kStages && sh->st[was].state == Stage::kOpen) seal(*sh, sh->st[was], due);
+                sh->open_seq.fetch_add(1, std::memory_order_release);
+                futex_wake_all(&sh->open_seq);
+            }
+            submit_due(d, due, inflight);
+            drain(inflight);
+            break;
+        }
+        if (!closing && (now >= next_rebalance || d.rebalance_now.exchange(false))) {
+            rebalance(d, inflight);
+            if (rebalance_ms_) next_rebalance = mono_us() + (int64_t)rebalance_ms_ * 1000;
+            progressed = true;
+        }
+        if (progressed) { idle_spins = 0; last_active = now; continue; }
+        if (!inflight.empty()) {                                     // something is on the GPU: keep looking (completion latency matters)
+            if (++idle_spins < 4000) cpu_relax(); else std::this_thread::yield();
+            last_active = now;
+            continue;
+        }
+        int64_t wait = deadline == INT64_MAX ? 2000 : std::max<int64_t>(deadline - now, 1);
+        if (next_rebalance != INT64_MAX) wait = std::min(wait, std::max<int64_t>(next_rebalance - now, 1));
+        if (wait <= 3 || now - last_active < (int64_t)spin_us_ * 4) { cpu_relax(); continue; }   // requests tend to come in trains: stay awake a little
+        d.sleeping.store(true, std::memory_order_seq_cst);
+        if (d.wake.load(std::memory_order_seq_cst) == seen) futex_wait(&d.wake, seen, wait);
+        d.sleeping.store(false, std::memory_order_seq_cst);
+    }
 }
 
 // Config.Store (store.go:49-65) configured: ask the store for keys that are not resident BEFORE the batch
@@ -477,19 +911,26 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
     s.rc = rc; s.submitted = false;
 }
 
+// ---- cache operations from other threads: they follow the placement and exclude a move in progress -----------------------
 int GPUWorkerPool::AddCacheItem(const guber_item_t& item) {
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
+    Device& d = *devs_[DeviceOf(item.key, item.key_len)];
+    std::shared_lock<std::shared_mutex> lk(d.place_mu);
     return guber_add_items(shards_[ShardOf(item.key, item.key_len)]->engine, &item, 1, nullptr);
 }
 int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool* found) {
     int f = 0;
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
+    Device& d = *devs_[DeviceOf((const uint8_t*)key.data(), (uint32_t)key.size())];
+    std::shared_lock<std::shared_mutex> lk(d.place_mu);
     const int rc = guber_get_item(shards_[ShardOf(key)]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
     *found = f != 0;
     return rc;
 }
 int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n) {
     // workers.go:329-449: every item goes to the worker that owns its key; chunks bound the staging buffers
+    std::vector<std::shared_lock<std::shared_mutex>> locks;
+    for (auto& d : devs_) locks.emplace_back(d->place_mu);
     std::vector<std::vector<guber_item_t>> per(shards_.size());
     for (uint32_t i = 0; i < n; ++i) per[ShardOf(items[i].key, items[i].key_len)].push_back(items[i]);
     for (size_t j = 0; j < per.size(); ++j)
@@ -500,6 +941,8 @@ int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n) {
     return GUBER_OK;
 }
 int GPUWorkerPool::Store(const std::function<void(const guber_item_t&)>& save) {
+    std::vector<std::shared_lock<std::shared_mutex>> locks;
+    for (auto& d : devs_) locks.emplace_back(d->place_mu);
     for (auto& sh : shards_) {                                                        // workers.go:451-534: every worker in turn
         uint64_t n = 0, arena = 0;
         int rc = guber_dump(sh->engine, nullptr, 0, nullptr, 0, &n, &arena);          // sizes first
@@ -518,6 +961,26 @@ int64_t GPUWorkerPool::Size() {
     return n;
 }
 
+// one GlobalSyncWait tick (global.go:91-283) over the devices' GLOBAL engines: pending hits travel to the owners, the owners
+// apply them and broadcast their state to the other devices' replicas — natively (guber_global_sync).  A daemon that is one
+// rank of a multi-node ring builds its own communicator over GlobalEngine(device) instead (guber_comm_create_rank).
+int GPUWorkerPool::GlobalSync(guber_global_sync_stats_t* stats) {
+    if (!has_global_ || shards_.empty()) return GUBER_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(comm_mu_);
+    if (closed_.load()) return GUBER_E_INVALID_ARG;
+    if (!comm_) {
+        std::vector<guber_engine_t*> eng;
+        for (auto& d : devs_) eng.push_back(d->shards[d->n_plain]->engine);
+        const int rc = guber_comm_create_local(eng.data(), (uint32_t)eng.size(), ring_, 0, &comm_);
+        if (rc != GUBER_OK) return rc;
+    }
+    return guber_global_sync(comm_, NowMs(), stats);
+}
+guber_engine_t* GPUWorkerPool::GlobalEngine(uint32_t device) {
+    if (!has_global_ || device >= devs_.size()) return nullptr;
+    return devs_[device]->shards[devs_[device]->n_plain]->engine;
+}
+
 bool V1Instance::GetRateLimits(std::vector<RateLimitReq>& reqs, std::vector<RateLimitResp>* resps, std::string* rpc_error) {
     if (reqs.size() > kMaxBatchSize) {                                // gubernator.go:189-193
         char buf[128];
@@ -526,14 +989,16 @@ bool V1Instance::GetRateLimits(std::vector<RateLimitReq>& reqs, std::vector<Rate
         return false;
     }
     const int64_t created_at = pool_->NowMs();                        // :195
-    resps->assign(reqs.size(), RateLimitResp{});
-    std::vector<const RateLimitReq*> send; std::vector<RateLimitReqState> st; std::vector<RateLimitResp*> out;
+    resps->resize(reqs.size());
+    static thread_local std::vector<const RateLimitReq*> send; static thread_local std::vector<RateLimitReqState> st; static thread_local std::vector<RateLimitResp*> out;
+    send.clear(); st.clear(); out.clear();
     for (size_t i = 0; i < reqs.size(); ++i) {
         RateLimitReq& r = reqs[i];
-        if (r.unique_key.empty()) { (*resps)[i].error = "field 'unique_key' cannot be empty"; continue; }   // :208-212
-        if (r.name.empty()) { (*resps)[i].error = "field 'namespace' cannot be empty"; continue; }          // :213-217
+        RateLimitResp& o = (*resps)[i];
+        if (r.unique_key.empty()) { o = RateLimitResp{}; o.error = "field 'unique_key' cannot be empty"; continue; }   // :208-212
+        if (r.name.empty()) { o = RateLimitResp{}; o.error = "field 'namespace' cannot be empty"; continue; }          // :213-217
         if (r.created_at == 0) r.created_at = created_at;                                                    // :218-220
-        send.push_back(&r); st.push_back(RateLimitReqState{true}); out.push_back(&(*resps)[i]);
+        send.push_back(&r); st.push_back(RateLimitReqState{true}); out.push_back(&o);
     }
     pool_->GetRateLimitMany(send, st, out);
     for (size_t i = 0; i < reqs.size(); ++i) {
@@ -564,7 +1029,7 @@ extern "C" int guber_pool_create_multi(const guber_config_t* cfg, const int32_t*
     if (!cfg || !out || (n_devices && !devices)) return GUBER_E_INVALID_ARG;
     std::vector<int32_t> devs(devices, devices + n_devices);
     GPUWorkerPool* p = new GPUWorkerPool(*cfg, batch_limit, batch_wait_us, shards_per_device, devs);
-    if (!p->ok()) { const int rc = p->create_error(); delete p; return rc; }
+    if (!p->ok()) { const int rc = p->create_error(); delete p; return rc ? rc : GUBER_E_INVALID_ARG; }
     *out = new guber_pool{p, new V1Instance(p)};
     return GUBER_OK;
 }
@@ -585,6 +1050,9 @@ extern "C" void guber_pool_set_store(guber_pool_t* p, const guber_store_callback
 extern "C" void guber_pool_set_clock(guber_pool_t* p, int64_t now_ms) { if (p) p->pool->SetClockMs(now_ms); }
 extern "C" guber_engine_t* guber_pool_engine(guber_pool_t* p) { return p ? p->pool->engine() : nullptr; }
 extern "C" guber_engine_t* guber_pool_engine_at(guber_pool_t* p, uint32_t shard) { return p ? p->pool->engine(shard) : nullptr; }
+extern "C" guber_engine_t* guber_pool_global_engine(guber_pool_t* p, uint32_t device) { return p ? p->pool->GlobalEngine(device) : nullptr; }
+extern "C" int guber_pool_global_sync(guber_pool_t* p, guber_global_sync_stats_t* stats) { return p ? p->pool->GlobalSync(stats) : GUBER_E_INVALID_ARG; }
+extern "C" void guber_pool_rebalance(guber_pool_t* p) { if (p) p->pool->RebalanceNow(); }
 extern "C" uint32_t guber_pool_shards(guber_pool_t* p) { return p ? p->pool->shards() : 0; }
 extern "C" uint32_t guber_pool_device_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len) { return p ? p->pool->DeviceOf(key, key_len) : 0; }
 extern "C" int guber_pool_metrics(guber_pool_t* p, guber_pool_metrics_t* out) {
@@ -599,26 +1067,7 @@ extern "C" int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uin
                                           const int64_t* limit, const int64_t* duration, const int64_t* burst,
                                           const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
                                           guber_result_t* out, char* err_text, uint32_t err_stride) {
-    if (!p || !out) return GUBER_E_INVALID_ARG;
-    std::vector<RateLimitReq> reqs(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        RateLimitReq& r = reqs[i];
-        r.name.assign((const char*)name_bytes + name_off[i], name_off[i + 1] - name_off[i]);
-        r.unique_key.assign((const char*)ukey_bytes + ukey_off[i], ukey_off[i + 1] - ukey_off[i]);
-        r.hits = hits[i]; r.limit = limit[i]; r.duration = duration[i]; r.burst = burst ? burst[i] : 0;
-        r.created_at = created_at ? created_at[i] : 0; r.algorithm = algorithm ? algorithm[i] : 0;
-        r.behavior = behavior ? behavior[i] : 0;
-    }
-    std::vector<RateLimitResp> resps;
-    std::string rpc_error;
-    if (!p->inst->GetRateLimits(reqs, &resps, &rpc_error)) {
-        if (err_text && err_stride) snprintf(err_text, err_stride, "%s", rpc_error.c_str());
-        return GUBER_E_BATCH_TOO_LARGE;
-    }
-    for (uint32_t i = 0; i < n; ++i) {
-        out->status[i] = (uint8_t)resps[i].status; out->limit[i] = resps[i].limit; out->remaining[i] = resps[i].remaining;
-        out->reset_time[i] = resps[i].reset_time; out->err[i] = resps[i].error.empty() ? 0 : 1;
-        if (err_text && err_stride) snprintf(err_text + (size_t)i * err_stride, err_stride, "%s", resps[i].error.c_str());
-    }
-    return GUBER_OK;
+    if (!p || !out || (n && (!name_bytes || !name_off || !ukey_bytes || !ukey_off || !hits || !limit || !duration))) return GUBER_E_INVALID_ARG;
+    return p->pool->GetRateLimitsSoA(n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior,
+                                     out, err_text, err_stride);
 }

@@ -3,26 +3,40 @@
 //   gubernator::V1Instance      <->  V1Instance.GetRateLimits (local-owner slice)  gubernator.go:183-306
 // Same names, argument meaning and error behaviour; what changes is the mechanism.  The reference hands every request to
 // its worker's goroutine through a channel (workers.go:261-291); here the CALLERS do the per-request work, in parallel:
-// a caller reserves a contiguous range of request slots (and key bytes) in the open stage of its key's shard with one
-// compare-and-swap per RPC and shard, writes its requests IN PLACE into the stage's arrays (device-visible host memory,
-// include/guber_gpu.h guber_stage_*), and later reads its responses straight out of the stage's result arrays.  The
-// shard's batcher thread never touches a request: it seals the open stage at batch_limit items or batch_wait after the
-// first one (the policy of peer_client.go:284-337), submits it, opens the next of its three stages (one filling, one on
-// the GPU, one being read out by its callers), and announces completed generations.  Nothing is allocated per flush.
-// (Optional, off by default: GUBER_POOL_IDLE_US=n also flushes when nobody has reserved anything for n microseconds and all
-// reserved slots are written — lower latency under light load; profiles/r02_y_pool_throughput.txt.)
+// a caller hashes its keys, looks up the shard of each (guber_placement: hash slots + individually placed hot keys),
+// reserves a contiguous range of request slots (and key bytes) in the open stage of that shard with ONE compare-and-swap
+// per RPC and shard, writes its requests IN PLACE into the stage's arrays (device-visible host memory, include/guber_gpu.h
+// guber_stage_*), and later reads its responses straight out of the stage's result arrays.
 //
-// Shards: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
-// over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers —
-// and inside a device the shard follows the reference's worker rule (XXH64 range, workers.go:153-155,180-184).  The same
-// device ordinal may be listed several times: logical devices on one GPU (single-GPU boxes, tests).
+// ONE dispatcher thread per device serves all of the device's shards (round 2 had a batcher thread and stream per shard:
+// the launches of different streams overlap badly on the GPU and the threads fought for the host).  It seals the stages
+// that are due — batch_limit items, batch_wait after the first one (the policy of peer_client.go:284-337), or, by
+// default, as soon as nobody has reserved anything for idle_us and every reserved slot is written (the callers are all
+// waiting: holding the batch only adds latency) — and submits them together (guber_stages_submit): the batches of up to
+// four shards travel in ONE copy kernel + ONE k_front_multi + ONE k_eval2_multi, the shards spread over three streams,
+// batches of <= 256 requests take the one-launch path without being waited for.  It polls for completions
+// (guber_stage_poll), announces finished generations (futex), and never touches a request.  Nothing is allocated per flush.
+//
+// Placement: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
+// over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers.
+// Inside a device the shard comes from the device's guber_placement_t: XXH64-range slots whose initial table IS the
+// reference's worker rule (workers.go:153-155,180-184), plus the keys that turn out to carry a large share of the traffic,
+// observed online (every 16th request feeds the placement's sketch) and isolated on the least loaded shard.  Moving a
+// resident key is done by the dispatcher at a batch boundary: every open stage of the device is sealed, the batches in
+// flight drain, the key's bucket is taken from the old shard's table and added to the new one's, the new exception list is
+// published and the stages reopen carrying the new placement version — a caller that routed with the old version cannot
+// reserve in them (the version is part of the word its compare-and-swap expects) and routes again.  Per-key request order
+// is therefore kept across a move.
 #pragma once
+#include <semaphore.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -51,7 +65,9 @@ constexpr uint32_t kMaxBatchSize = 1000;              // gubernator.go:40
 class GPUWorkerPool {
  public:
     // `shards` = Config.Workers of the reference (config.go:110, workers.go:125-151) per device; cfg.cache_size is per pool, as
-    // in the reference (each shard gets cache_size / shards, workers.go:132).  devices empty = {cfg.device}.
+    // in the reference (each shard gets cache_size / shards, workers.go:132).  devices empty = {cfg.device}.  With
+    // GUBER_FLAG_GLOBAL in cfg.flags every device gets one more engine that holds the keys of GLOBAL-behaviour requests (the
+    // replica the GLOBAL manager synchronises: GlobalSync()); the other engines are created without the flag.
     GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards = 1,
                   const std::vector<int32_t>& devices = {});
     ~GPUWorkerPool();
@@ -65,6 +81,12 @@ class GPUWorkerPool {
     // is split by owning device / shard and the answers land in the callers' slots: functional_test.go:1638-1686).
     void GetRateLimitMany(const std::vector<const RateLimitReq*>& reqs, const std::vector<RateLimitReqState>& st,
                           std::vector<RateLimitResp*>& out);
+    // The same for a binding's structure-of-arrays (names / unique keys as packed strings + offsets, numeric columns), with the
+    // V1Instance.GetRateLimits front end folded in (1000-item cap, empty-field errors, CreatedAt default, error wrapping):
+    // include/guber_gpu.h guber_pool_get_rate_limits.  No per-request allocation, no intermediate objects.
+    int GetRateLimitsSoA(uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off, const uint8_t* ukey_bytes, const uint32_t* ukey_off,
+                         const int64_t* hits, const int64_t* limit, const int64_t* duration, const int64_t* burst, const int64_t* created_at,
+                         const int32_t* algorithm, const uint32_t* behavior, guber_result_t* out, char* err_text, uint32_t err_stride);
     int AddCacheItem(const guber_item_t& item);                                  // workers.go:537
     int GetCacheItem(const std::string& key, guber_item_t* out, bool* found);    // workers.go:583
     // WorkerPool.Load (workers.go:329-449): hand every item of a Loader to the cache; WorkerPool.Store (workers.go:451-534):
@@ -82,59 +104,105 @@ class GPUWorkerPool {
     uint32_t shards() const { return (uint32_t)shards_.size(); }
     uint32_t devices() const { return n_devices_; }
     // the device a key belongs to (ReplicatedConsistentHash.Get, replicated_hash.go:104-119) and its shard index
-    // (device * shards_per_device + WorkerPool.getWorker, workers.go:180-184)
+    // (device * shards_per_device + the placement's shard: WorkerPool.getWorker generalised, workers.go:180-184)
     uint32_t DeviceOf(const uint8_t* key, uint32_t len) const;
     uint32_t ShardOf(const std::string& key) const { return ShardOf((const uint8_t*)key.data(), (uint32_t)key.size()); }
-    uint32_t ShardOf(const uint8_t* key, uint32_t len) const;
+    uint32_t ShardOf(const uint8_t* key, uint32_t len, uint32_t behavior = 0) const;
     uint64_t batches_flushed() const;
     void Metrics(guber_pool_metrics_t* out) const;   // gubernator_batch_queue_length / gubernator_batch_send_duration analogues (gubernator.go:96-107)
+    // one GlobalSyncWait tick over the devices' GLOBAL engines (global.go:91-283 natively: guber_global_sync)
+    int GlobalSync(guber_global_sync_stats_t* stats);
+    guber_engine_t* GlobalEngine(uint32_t device);   // for a communicator of one's own (guber_comm_create_rank: one rank per daemon)
+    // ask the dispatchers for a placement pass now (tests, operators); the periodic one runs every GUBER_POOL_REBALANCE_MS (250)
+    void RebalanceNow();
 
  private:
-    static constexpr uint32_t kStages = 3;                // filling / on the GPU / being read out
+    static constexpr uint32_t kStages = 4;                // filling / sealed or on the GPU (up to two) / being read out
     static constexpr uint64_t kClosed = 1ull << 63;       // Stage::word: not accepting reservations
+    static constexpr uint32_t kOpenNone = kStages, kOpenDead = kStages + 1;
+    // Stage::word = kClosed | placement version (7 bits) << 56 | key bytes reserved (24 bits) << 32 | slots reserved
+    static uint32_t word_count(uint64_t w) { return (uint32_t)w; }
+    static uint32_t word_bytes(uint64_t w) { return (uint32_t)(w >> 32) & 0xffffffu; }
+    static uint32_t word_ver(uint64_t w) { return (uint32_t)(w >> 56) & 0x7fu; }
+    struct Shard;
     struct Stage {                                        // one of a shard's stages and the generation it currently carries
         guber_stage_t* stage = nullptr;
         guber_batch_t* b = nullptr; guber_result_t* r = nullptr;
+        Shard* shard = nullptr;
         std::vector<uint16_t> name_len;                   // per slot: length of the request's name (Store callbacks)
-        std::atomic<uint64_t> word{kClosed};              // kClosed | key bytes reserved << 32 | slots reserved
+        std::atomic<uint64_t> word{kClosed};
         std::atomic<uint32_t> written{0}, consumed{0};    // slots filled by their callers / responses picked up
         std::atomic<uint64_t> gen{0};                     // generation carried
         std::atomic<uint32_t> done_gen{0};                // low half of the last generation whose responses are ready (futex word)
-        std::atomic<int64_t> first_us{0};                 // when the generation's first reservation was made (batch_wait)
-        std::atomic<bool> flush_now{false};               // a caller found no room: do not wait for batch_wait
-        uint32_t n = 0; int rc = 0; int64_t t0_us = 0;    // sealed size, result code, flush start (batcher only; rc read after done_gen)
-        bool submitted = false;                           // guber_stage_submit succeeded, guber_stage_wait is due
+        std::atomic<uint32_t> sleepers{0};                // callers asleep on done_gen
+        std::atomic<int64_t> first_us{0}, last_us{0};     // the generation's first / latest reservation (batch_wait, idle flush)
+        std::atomic<bool> flush_now{false};               // a caller found no room: do not wait
+        uint32_t n = 0; int rc = 0; int64_t t0_us = 0;    // sealed size, result code, flush start (dispatcher only; rc read after done_gen)
+        int64_t t_written_us = 0, t_submitted_us = 0;     // (GUBER_POOL_DEBUG breakdown)
+        uint32_t dev_gen = 0;                             // the device generation (one submission) it travelled in
+        enum State : uint8_t { kFree, kOpen, kSealed, kInFlight, kDraining } state = kFree;   // dispatcher only
+        bool submitted = false;                           // guber_stages_submit succeeded, guber_stage_wait is due
     };
-    struct Shard {              // one "worker" of the reference: its own cache (engine) and goroutine (batcher thread)
+    struct Device;
+    struct Shard {              // one "worker" of the reference: its own cache (engine)
         guber_engine_t* engine = nullptr;
         Stage st[kStages];
+        Device* dev = nullptr;
         int32_t device = 0;
-        std::atomic<uint32_t> open{kStages};              // index of the stage accepting reservations; kStages = none right now, kStages + 1 = closed for good
-        std::mutex mu;
-        std::condition_variable cv_batcher, cv_callers;   // batcher: first item / full / closing; callers in reserve(): a stage opened
-        bool closing = false;
-        std::thread thread;
+        bool global = false;                              // the device's GLOBAL engine
+        bool owns_stream = false;                         // its engine created the stream other shards' engines share: destroyed last
+        uint32_t cur = 0;                                 // dispatcher: index of the open stage
+        std::atomic<uint32_t> open{kOpenNone};            // index of the stage accepting reservations, kOpenNone, or kOpenDead for good
+        std::atomic<uint32_t> open_seq{0}, open_waiters{0};   // futex word of callers waiting for a stage to open, and how many sleep on it
+        uint32_t stages_in_flight = 0;                    // dispatcher: stages of this shard on the GPU
         std::atomic<uint64_t> flushed{0}, requests{0}, queue_max{0}, send_us_sum{0}, send_us_max{0}, batch_max{0}, in_flight{0},
             key_too_long{0}, flush_on_key_bytes{0};
     };
-    struct Ticket { Shard* sh; Stage* st; uint64_t gen; uint32_t first_slot, count, list_begin, key_base; const std::vector<uint32_t>* list; bool consumed; };
-    struct Job;                                           // one GetRateLimitMany call: its per-shard request lists and tickets
-    void run(Shard& sh);
-    void open_stage(Shard& sh, uint32_t k);
-    void submit(Shard& sh, Stage& s);
+    struct Device {             // one GPU (or logical device): its shards, their placement, the dispatcher thread
+        uint32_t index = 0; int32_t ordinal = 0;
+        std::vector<Shard*> shards;                       // plain shards first; the GLOBAL engine, if any, last
+        uint32_t n_plain = 0;
+        guber_placement_t* place = nullptr;
+        std::atomic<uint32_t> ver{0};                     // placement version the stages are tagged with
+        std::shared_mutex place_mu;                       // cache operations from other threads vs a move in progress
+        std::thread thread;
+        std::atomic<uint32_t> wake{0};                    // futex word: bumped by callers (first reservation, full stage), Close, RebalanceNow
+        std::atomic<bool> sleeping{false}, closing{false}, rebalance_now{false};
+        std::atomic<uint64_t> rebalances{0}, moves{0}, submit_us{0}, submits{0};
+        uint32_t gen_seq = 0, gen_left[8] = {0}, gens_in_flight = 0;   // dispatcher: submissions whose batches are not all back
+    };
+    struct Ticket2 { Stage* st; uint64_t gen; uint32_t first_slot, count, list_begin, key_base; bool consumed; };
+    struct Scratch;                                       // per-thread buffers of a call
+    template <class Src, class Sink> struct Call;         // one GetRateLimitMany / GetRateLimitsSoA call (worker_pool.cpp)
+    void run(Device& d);
+    void open_stage(Shard& sh, uint32_t k, uint32_t ver);
+    int find_free(Shard& sh);
+    void seal(Shard& sh, Stage& s, std::vector<Stage*>& due);
+    void seal_if_due(Shard& sh, int64_t now, bool force, bool eager_ok, std::vector<Stage*>& due, int64_t* deadline);
     void submit_with_store(Shard& sh, Stage& s);
-    void complete(Shard& sh, Stage& s);
-    uint32_t reserve(Job& job, Shard& sh, const std::vector<uint32_t>& list, uint32_t begin, Ticket* out);
-    void write_requests(Job& job, const Ticket& t, const std::vector<uint32_t>& list);
-    bool try_consume(Job& job, Ticket& t, bool block);
-    void fail_rest(Job& job, const std::vector<uint32_t>& list, uint32_t begin, const char* why);
+    void announce(Shard& sh, Stage& s);
+    bool poll(std::vector<Stage*>& inflight);
+    void drain(std::vector<Stage*>& inflight);
+    void submit_due(Device& d, std::vector<Stage*>& due, std::vector<Stage*>& inflight);
+    void rebalance(Device& d, std::vector<Stage*>& inflight);
+    void wake(Device& d);
+    void enter();
+    void leave();
+    uint32_t route(const Device& d, uint64_t h, uint32_t behavior) const;
+    void destroy_engines();
 
     std::vector<std::unique_ptr<Shard>> shards_;
+    std::vector<std::unique_ptr<Device>> devs_;
     guber_ring_t* ring_ = nullptr;
-    uint32_t n_devices_ = 1, shards_per_device_ = 1;
-    uint64_t ring_step_ = 0;
+    guber_comm_t* comm_ = nullptr; std::mutex comm_mu_;
+    uint32_t n_devices_ = 1, shards_per_device_ = 1, plain_per_device_ = 1;
+    bool has_global_ = false;
     int create_rc_ = 0;
-    uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, max_key_ = 1024, key_cap_ = 0;
+    uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, rebalance_ms_ = 250, max_key_ = 1024, key_cap_ = 0;
+    uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true;
+    std::atomic<uint32_t> spinners_{0}; uint32_t max_spinners_ = 4;   // callers looking at a word instead of sleeping on it
+    sem_t active_sem_; bool limit_active_ = false;        // callers in the CPU part of a call (bounded by max_active_)
+    mutable std::atomic<uint64_t> d_dbg_[6] = {};         // GUBER_POOL_DEBUG: where a batch's time goes
     std::atomic<bool> closed_{false};
     std::atomic<int64_t> frozen_ms_{0};
     std::atomic<bool> has_store_{false};

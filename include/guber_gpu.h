@@ -367,6 +367,16 @@ int guber_pool_create_multi(const guber_config_t* cfg, const int32_t* devices, u
 uint32_t guber_pool_shards(guber_pool_t* p);
 uint32_t guber_pool_device_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len);   /* ReplicatedConsistentHash.Get over gpu0..gpuN-1 */
 guber_engine_t* guber_pool_engine_at(guber_pool_t* p, uint32_t shard);
+/* With GUBER_FLAG_GLOBAL in cfg->flags every device gets ONE more engine, which holds the keys of GLOBAL-behaviour requests (the
+ * replica the GLOBAL manager synchronises); the plain shards are created without the flag.  guber_pool_global_sync = one
+ * GlobalSyncWait tick (global.go:91-283) over the pool's devices; a daemon that is one rank of a multi-node ring builds its
+ * own communicator over guber_pool_global_engine(device) (guber_comm_create_rank). */
+struct guber_global_sync_stats;
+guber_engine_t* guber_pool_global_engine(guber_pool_t* p, uint32_t device);
+int guber_pool_global_sync(guber_pool_t* p, struct guber_global_sync_stats* stats /* optional */);
+/* ask the dispatchers for a placement pass now (hot keys observed since the last one get a shard of their own choice; resident
+ * buckets migrate at a batch boundary).  The periodic pass runs every GUBER_POOL_REBALANCE_MS (default 250; 0 = never). */
+void guber_pool_rebalance(guber_pool_t* p);
 /* batcher metrics: the pool's analogues of gubernator_batch_queue_length / gubernator_batch_send_duration (gubernator.go:96-107) */
 typedef struct guber_pool_metrics {
     uint64_t batches, requests;            /* flushed so far */
@@ -378,6 +388,9 @@ typedef struct guber_pool_metrics {
     uint64_t in_flight;                    /* batches submitted and not yet delivered */
     uint64_t key_too_long;                 /* requests answered GUBER_ITEM_E_KEY_TOO_LONG without touching the device */
     uint64_t flush_on_key_bytes;           /* batches flushed early because the next key did not fit the stage's key buffer */
+    uint64_t rebalances;                   /* placement passes of the dispatchers */
+    uint64_t keys_moved;                   /* hot keys whose bucket changed its logical shard */
+    uint64_t submits, submit_us_sum;       /* dispatcher submissions (one may carry the batches of all shards) and the host time inside them */
     uint32_t shards, devices;
 } guber_pool_metrics_t;
 int guber_pool_metrics(guber_pool_t* p, guber_pool_metrics_t* out);
@@ -440,6 +453,19 @@ int guber_placement_observe_keys(guber_placement_t* p, const uint8_t* key_bytes,
 int guber_placement_rebalance(guber_placement_t* p, double heavy_fraction /* <= 0: 0.125 */, int move_slots,
                               guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves);
 int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_t* n_slots, uint32_t* n_hot);
+/* guber_placement_rebalance(move_slots = 0) in two steps, for a caller that must quiesce between learning which RESIDENT keys
+ * move and letting requests follow the new placement: plan changes nothing a reader sees; commit publishes the planned list
+ * (version + 1) and starts a fresh observation round. */
+int guber_placement_plan(guber_placement_t* p, double heavy_fraction, guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves);
+int guber_placement_commit(guber_placement_t* p);
+/* The buckets of the keys with these XXH64 hashes leave `from`'s table and enter `to`'s (two logical shards of ONE GPU), on
+ * the device.  The caller guarantees that neither engine has a batch with those keys being formed or in flight.  *moved
+ * (optional) = buckets that were live and moved. */
+int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to, const uint64_t* key_hashes, uint32_t n, uint32_t* moved);
+/* The HIP stream the engine enqueues on (hipStream_t), to be handed to guber_config_t.stream of further engines: engines that
+ * share device and stream can share launches (guber_stages_submit, guber_eval_batches_routed_dev).  The engine that owns the
+ * stream must be destroyed last. */
+void* guber_engine_stream(guber_engine_t* e);
 
 /* ---- pinned staging memory for the cgo side (no Go pointers may be retained) */
 void* guber_alloc_pinned(size_t bytes);

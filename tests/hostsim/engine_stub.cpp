@@ -13,20 +13,21 @@
 #include "../../include/guber_gpu.h"
 #include "../../oracle/guber_oracle.h"
 
-struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; };
+struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; };
 struct guber_stage {
     guber_engine* e; uint32_t max_n, key_cap;
     std::vector<uint32_t> off, beh; std::vector<int64_t> hits, limit, duration, burst, created, rl, rr, rs;
     std::vector<uint8_t> algo, owner, status, err, keys;
     guber_batch_t b{}; guber_result_t r{};
     bool in_flight = false;
+    std::chrono::steady_clock::time_point ready_at{};                // guber_stages_submit: when the "GPU" is done with it
     std::mt19937 rng{12345};
 };
 
 extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** out) {
     guber_engine* e = new guber_engine();
     e->o = oracle_create(cfg->cache_size ? cfg->cache_size : 50000, 1);
-    e->max_batch = cfg->max_batch;
+    e->max_batch = cfg->max_batch; e->cache_size = cfg->cache_size;
     *out = e;
     return GUBER_OK;
 }
@@ -66,6 +67,48 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
     s->in_flight = false;
     return GUBER_OK;
 }
+// several stages in one submission (the pool's dispatcher): evaluated in array order, "complete" a little later
+extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uint32_t, uint32_t* done) {
+    static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;
+    if (done) *done = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        guber_stage* s = stages[k];
+        for (uint32_t q = 0; q < k; ++q) if (stages[q]->e == s->e) return GUBER_E_INVALID_ARG;
+        const int rc = guber_stage_submit(s);
+        if (rc) return rc;
+        s->ready_at = std::chrono::steady_clock::now() + std::chrono::microseconds(null_engine ? 0 : s->rng() % 300);
+        if (done) *done = k + 1;
+    }
+    return GUBER_OK;
+}
+extern "C" int guber_stage_poll(guber_stage_t* s) { return !s->in_flight || std::chrono::steady_clock::now() >= s->ready_at ? 1 : 0; }
+extern "C" void* guber_engine_stream(guber_engine_t*) { return nullptr; }
+// a hot key changes its logical shard: found by its XXH64 among the oracle's items (test-only: a scan)
+extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to, const uint64_t* hashes, uint32_t n, uint32_t* moved) {
+    if (moved) *moved = 0;
+    if (!from || !to || from == to) return GUBER_E_INVALID_ARG;
+    guber_engine* a = from < to ? from : to; guber_engine* b = from < to ? to : from;
+    std::lock_guard<std::mutex> la(a->mu); std::lock_guard<std::mutex> lb(b->mu);
+    std::vector<guber_item_t> items((size_t)oracle_size(from->o) + 16);
+    const uint64_t m = oracle_each(from->o, items.data(), items.size());
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint64_t q = 0; q < m; ++q) {
+            if (oracle_xxhash64(items[q].key, items[q].key_len, 0) != hashes[i]) continue;
+            guber_item_t it = items[q];
+            std::vector<uint8_t> key(it.key, it.key + it.key_len);
+            it.key = key.data();
+            int ex = 0;
+            oracle_add_item(to->o, &it, 0, &ex);
+            oracle_remove_item(from->o, key.data(), (uint32_t)key.size());
+            if (moved) ++*moved;
+            break;
+        }
+    return GUBER_OK;
+}
+// the GLOBAL exchange needs devices: not part of the CPU checks
+extern "C" int guber_comm_create_local(guber_engine_t* const*, uint32_t, const guber_ring_t*, int, guber_comm_t**) { return GUBER_E_INVALID_ARG; }
+extern "C" void guber_comm_destroy(guber_comm_t*) {}
+extern "C" int guber_global_sync(guber_comm_t*, int64_t, guber_global_sync_stats_t*) { return GUBER_E_INVALID_ARG; }
 extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
     std::lock_guard<std::mutex> lk(e->mu);
     for (uint32_t i = 0; i < n; ++i) { int ex = 0; oracle_add_item(e->o, &items[i], 0, &ex); if (existed) existed[i] = (uint8_t)ex; }

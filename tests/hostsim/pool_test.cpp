@@ -160,6 +160,72 @@ int main(int argc, char** argv) {
         CHECK(ok.load() > 0 && closed.load() > 0 && other.load() == 0, "close under load: ok %ld closed %ld other %ld", ok.load(), closed.load(), other.load());
         printf("close under load: %ld answered, %ld refused, failures so far %d\n", ok.load(), closed.load(), failures);
     }
+    {   // 5. placement passes under load: every thread hammers a key of its own (exact comparison with its own oracle) while the
+        //    dispatcher is asked for a rebalance every few milliseconds — hot keys move to other shards WITH their buckets, at
+        //    batch boundaries, and no request of a key is evaluated out of order or against a stale bucket
+        GPUWorkerPool pool(cfg, 256, 150, 4);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        std::atomic<bool> stop{false};
+        std::thread kicker([&] { while (!stop.load()) { pool.RebalanceNow(); std::this_thread::sleep_for(std::chrono::milliseconds(3)); } });
+        std::vector<std::thread> th;
+        for (int t = 0; t < 6; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(500 + t);
+            const std::string ns = "mv" + std::to_string(t);
+            for (int it = 0; it < 300 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 25, 200);
+                for (size_t q = 0; q < reqs.size(); ++q)
+                    if (rng() % 5 != 0) { reqs[q].unique_key = "hot"; reqs[q].algorithm = t % 2; reqs[q].hits = 1; reqs[q].limit = 1000000; reqs[q].duration = 3600000; reqs[q].behavior = 0; }
+                std::vector<RateLimitResp> resps; std::string err;
+                CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+                compare(reqs, resps, ref, NOW0, "placement passes");
+            }
+        });
+        for (auto& x : th) x.join();
+        stop.store(true); kicker.join();
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        CHECK(m.rebalances > 0 && m.keys_moved > 0, "rebalances %llu, keys moved %llu", (unsigned long long)m.rebalances, (unsigned long long)m.keys_moved);
+        printf("placement passes: %llu passes, %llu hot keys moved, %llu batches, failures so far %d\n", (unsigned long long)m.rebalances,
+               (unsigned long long)m.keys_moved, (unsigned long long)m.batches, failures);
+    }
+    {   // 6. the C entry point a binding calls (structure-of-arrays in and out, V1Instance front end folded in) against the same oracle
+        guber_pool_t* cp = nullptr;
+        CHECK(guber_pool_create_sharded(&cfg, 3, 128, 100, &cp) == GUBER_OK, "pool create");
+        guber_pool_set_clock(cp, NOW0);
+        Ref ref; std::mt19937 rng(77);
+        for (int it = 0; it < 200 / scale; ++it) {
+            std::vector<RateLimitReq> reqs = random_rpc(rng, "soa", 50, 300);
+            const uint32_t n = (uint32_t)reqs.size();
+            std::vector<uint8_t> nb, ub; std::vector<uint32_t> no{0}, uo{0}, beh(n); std::vector<int64_t> hits(n), lim(n), dur(n), burst(n), created(n, 0);
+            std::vector<int32_t> algo(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                nb.insert(nb.end(), reqs[i].name.begin(), reqs[i].name.end()); no.push_back((uint32_t)nb.size());
+                ub.insert(ub.end(), reqs[i].unique_key.begin(), reqs[i].unique_key.end()); uo.push_back((uint32_t)ub.size());
+                hits[i] = reqs[i].hits; lim[i] = reqs[i].limit; dur[i] = reqs[i].duration; burst[i] = reqs[i].burst; algo[i] = reqs[i].algorithm; beh[i] = reqs[i].behavior;
+            }
+            std::vector<uint8_t> st(n), er(n); std::vector<int64_t> li(n), re(n), rs(n); std::vector<char> text((size_t)n * 160);
+            guber_result_t out{}; out.status = st.data(); out.limit = li.data(); out.remaining = re.data(); out.reset_time = rs.data(); out.err = er.data();
+            CHECK(guber_pool_get_rate_limits(cp, n, nb.data(), no.data(), ub.data(), uo.data(), hits.data(), lim.data(), dur.data(), burst.data(), created.data(),
+                                             algo.data(), beh.data(), &out, text.data(), 160) == GUBER_OK, "soa rpc");
+            std::vector<RateLimitResp> got(n);
+            for (uint32_t i = 0; i < n; ++i) { got[i].status = st[i]; got[i].limit = li[i]; got[i].remaining = re[i]; got[i].reset_time = rs[i]; if (er[i]) got[i].error = &text[(size_t)i * 160]; }
+            compare(reqs, got, ref, NOW0, "C entry point");
+        }
+        // front-end errors and wrapping (gubernator.go:208-217, 250-255)
+        const char* names = "nsnsns"; const uint32_t no[4] = {0, 2, 4, 4}; const char* uk = "ab"; const uint32_t uo[4] = {0, 1, 1, 2};
+        const int64_t one[3] = {1, 1, 1}, ten[3] = {10, 10, 10}; const int32_t al[3] = {7, 0, 0};
+        uint8_t st[3], er[3]; int64_t li[3], re[3], rs[3]; char text[3 * 160];
+        guber_result_t out{}; out.status = st; out.limit = li; out.remaining = re; out.reset_time = rs; out.err = er;
+        CHECK(guber_pool_get_rate_limits(cp, 3, (const uint8_t*)names, no, (const uint8_t*)uk, uo, one, ten, ten, nullptr, nullptr, al, nullptr, &out, text, 160) == GUBER_OK, "soa errors");
+        CHECK(er[0] && strcmp(text, "Error while apply rate limit for 'ns_a': Invalid rate limit algorithm '7'") == 0, "algorithm text '%s'", text);
+        CHECK(er[1] && strcmp(text + 160, "field 'unique_key' cannot be empty") == 0, "unique_key text '%s'", text + 160);
+        CHECK(er[2] && strcmp(text + 320, "field 'namespace' cannot be empty") == 0, "namespace text '%s'", text + 320);
+        std::vector<uint32_t> big(1002, 0);
+        CHECK(guber_pool_get_rate_limits(cp, 1001, (const uint8_t*)names, big.data(), (const uint8_t*)uk, big.data(), one, ten, ten, nullptr, nullptr, nullptr, nullptr, &out, text, 160) == GUBER_E_BATCH_TOO_LARGE &&
+              strstr(text, "list too large; max size is '1000'"), "cap text '%s'", text);
+        guber_pool_destroy(cp);
+        printf("C entry point: failures so far %d\n", failures);
+    }
     printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
     return failures ? 1 : 0;
 }

@@ -74,7 +74,12 @@ def test_peer_order_stability_batch_sizes():
 def test_concurrent_callers_are_batched_and_consistent(shards):
     """Many goroutine-like callers on one key set (benchmark_test.go "Thundering herd" shape): every hit is
     accounted exactly once — admitted hits == limit per key — and callers share device batches."""
-    inst = ga.V1Instance(cache_size=8192, batch_limit=512, batch_wait_us=300, shards=shards)
+    import os
+    os.environ["GUBER_POOL_EAGER"] = "0"          # the reference's peer-batcher policy alone (limit or wait): arrivals inside batch_wait share a batch
+    try:
+        inst = ga.V1Instance(cache_size=8192, batch_limit=512, batch_wait_us=300, shards=shards)
+    finally:
+        del os.environ["GUBER_POOL_EAGER"]
     inst.set_clock(1_700_000_000_000)
     keys, limit, threads, per_thread = 20, 50, 16, 25
     admitted = np.zeros(keys, np.int64)

@@ -1,5 +1,5 @@
-"""The C++ pool's host logic (gubernator_amd/csrc/worker_pool.cpp: slot reservation by the callers, stage rotation,
-generations, shutdown) on the CPU: tests/hostsim/pool_test.cpp links the pool against a test-only stub of the engine's C
+"""The C++ pool's host logic (gubernator_amd/csrc/worker_pool.cpp: slot reservation by the callers, one dispatcher per device,
+stage rotation, generations, placement passes with bucket migration, the C entry point, shutdown) on the CPU: tests/hostsim/pool_test.cpp links the pool against a test-only stub of the engine's C
 ABI that answers with the oracle (tests/hostsim/engine_stub.cpp), and compares what callers get back with the oracle
 evaluating every key's requests in the caller's order.  Run plain and under ThreadSanitizer / AddressSanitizer."""
 import os
@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = ["tests/hostsim/pool_test.cpp", "tests/hostsim/engine_stub.cpp", "gubernator_amd/csrc/worker_pool.cpp",
-       "gubernator_amd/csrc/guber_host.cpp"]
+       "gubernator_amd/csrc/placement.cpp", "gubernator_amd/csrc/guber_host.cpp"]
 
 
 def build(tag, flags):
@@ -20,13 +20,20 @@ def build(tag, flags):
     return out
 
 
-@pytest.mark.parametrize("tag,flags,scale,idle_us", [("plain", [], 1, 0), ("plain", [], 2, 20), ("tsan", ["-fsanitize=thread"], 2, 0),
-                                                     ("tsan", ["-fsanitize=thread"], 4, 20),
-                                                     ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2, 0)])
-def test_pool_host_logic(tag, flags, scale, idle_us):
+ENVS = {"eager": {},                                                          # the default policy: a batch goes as soon as the device has room
+        "limit_or_wait": {"GUBER_POOL_EAGER": "0"},                            # the reference's peer-batcher policy alone
+        "idle_flush": {"GUBER_POOL_EAGER": "0", "GUBER_POOL_IDLE_US": "20"},
+        "few_active": {"GUBER_POOL_MAX_ACTIVE": "2", "GUBER_POOL_DEPTH": "1"}}
+
+
+@pytest.mark.parametrize("tag,flags,scale,env,repeats", [("plain", [], 1, "eager", 5), ("plain", [], 2, "limit_or_wait", 2), ("plain", [], 2, "idle_flush", 2),
+                                                         ("plain", [], 2, "few_active", 2),
+                                                         ("tsan", ["-fsanitize=thread"], 2, "eager", 1), ("tsan", ["-fsanitize=thread"], 4, "idle_flush", 1),
+                                                         ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2, "eager", 1)])
+def test_pool_host_logic(tag, flags, scale, env, repeats):
     exe = build(tag, flags)
-    env = dict(os.environ, GUBER_POOL_IDLE_US=str(idle_us))          # 20: the optional idle flush of the batcher
-    p = subprocess.run([exe, str(scale)], capture_output=True, text=True, timeout=600, env=env)
-    tail = (p.stdout + p.stderr)[-3000:]
-    assert p.returncode == 0 and "POOL TEST OK" in p.stdout, tail
-    assert "ThreadSanitizer" not in p.stderr and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, tail
+    for _ in range(repeats):                                         # (races show up in some runs only)
+        p = subprocess.run([exe, str(scale)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **ENVS[env]))
+        tail = (p.stdout + p.stderr)[-3000:]
+        assert p.returncode == 0 and "POOL TEST OK" in p.stdout, tail
+        assert "ThreadSanitizer" not in p.stderr and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, tail

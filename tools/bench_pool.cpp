@@ -1,15 +1,20 @@
-// bench_pool.cpp — throughput of the drop-in surface itself: T caller threads (the gRPC goroutines of a daemon) each
-// calling V1Instance::GetRateLimits with RPCs of `items` requests (gubernator.go:183-306, cap 1000), against a
-// GPUWorkerPool of S shards (workers.go:54-626).  Everything the Go shim would do per request happens here in C++:
-// validation, HashKey, shard routing, queueing, in-place stage filling, submit / wait, response fan-out.
-//   make -C gubernator_amd/csrc bench_pool && tools/bench_pool_c [threads] [shards] [items] [keys] [seconds] [batch_wait_us]
+// bench_pool.cpp — throughput of the drop-in surface itself: T caller threads (the gRPC goroutines of a daemon) each issuing RPCs
+// of `items` requests (gubernator.go:183-306, cap 1000) against a GPUWorkerPool of S shards (workers.go:54-626).  Everything a
+// front end does per request happens inside the timed calls: validation, HashKey, XXH64, placement, slot reservation, in-place
+// stage filling, completion, response fan-out.
+//   api = c   : guber_pool_get_rate_limits — the C ABI a binding calls (include/guber_gpu.h): structure-of-arrays in and out,
+//               what the Go shim hands over per RPC (go/gpu_worker_pool.go)
+//   api = cpp : V1Instance::GetRateLimits on std::string RateLimitReq objects (the mirror of the reference's Go types)
+//   make -C gubernator_amd/csrc bench_pool && tools/bench_pool_c [threads] [shards] [items] [keys] [seconds] [batch_wait_us] [api]
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -18,21 +23,33 @@
 using namespace gubernator;
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+struct SoaRpc {                       // one RPC as a binding holds it after decoding the protobuf
+    std::vector<uint8_t> name_bytes, ukey_bytes; std::vector<uint32_t> name_off, ukey_off, behavior;
+    std::vector<int64_t> hits, limit, duration, burst, created; std::vector<int32_t> algorithm;
+};
+
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 32, S = argc > 2 ? atoi(argv[2]) : 4, items = argc > 3 ? atoi(argv[3]) : 1000;
     const int K = argc > 4 ? atoi(argv[4]) : 1000000;
     const double seconds = argc > 5 ? atof(argv[5]) : 2.0;
     const int wait_us = argc > 6 ? atoi(argv[6]) : 200;
+    const bool c_api = !(argc > 7 && strcmp(argv[7], "cpp") == 0);
     guber_config_t cfg{};
     cfg.cache_size = (uint64_t)K * 2; cfg.max_batch = 65536; cfg.device = 0;
-    GPUWorkerPool pool(cfg, 65536, (uint32_t)wait_us, (uint32_t)S);
-    if (!pool.ok()) { printf("pool: error %d\n", pool.create_error()); return 1; }
-    V1Instance inst(&pool);
+    guber_pool_t* cp = nullptr;
+    const int rc0 = guber_pool_create_sharded(&cfg, (uint32_t)S, 65536, (uint32_t)wait_us, &cp);
+    if (rc0 != GUBER_OK) { printf("pool: error %d\n", rc0); return 1; }
+    // (the C++ objects behind the handle, for api = cpp: layout of struct guber_pool in worker_pool.cpp)
+    struct Handle { GPUWorkerPool* pool; V1Instance* inst; };
+    GPUWorkerPool& pool = *((Handle*)cp)->pool;
+    V1Instance& inst = *((Handle*)cp)->inst;
     // Zipf-1.1 ranks over K keys by inverse-CDF on a precomputed table
     std::vector<double> cdf(K);
     double acc = 0;
     for (int i = 0; i < K; ++i) { acc += 1.0 / std::pow((double)(i + 1), 1.1); cdf[i] = acc; }
     std::atomic<uint64_t> done{0}, errors{0};
+    std::vector<std::vector<float>> lat(T);                           // per-RPC latency samples (us) of the timed window
+    std::atomic<bool> timing{false};
     std::atomic<bool> stop{false}, go{false};
     std::atomic<int> ready{0};
     auto worker = [&](int t) {
@@ -40,25 +57,51 @@ int main(int argc, char** argv) {
         std::uniform_real_distribution<double> U(0.0, acc);
         // the RPCs are drawn before the clock starts: what is timed is the pool, not the generator
         const int NR = std::max(4, 20000 / items);
-        std::vector<std::vector<RateLimitReq>> rpcs(NR, std::vector<RateLimitReq>(items));
+        std::vector<std::vector<RateLimitReq>> rpcs;
+        std::vector<SoaRpc> soa;
         char buf[32];
-        for (auto& reqs : rpcs)
+        for (int q = 0; q < NR; ++q) {
+            std::vector<RateLimitReq> reqs(items);
+            SoaRpc a;
+            a.name_off.push_back(0); a.ukey_off.push_back(0);
             for (auto& r : reqs) {
                 const int k = (int)(std::lower_bound(cdf.begin(), cdf.end(), U(rng)) - cdf.begin());
                 r.name = "bench";
                 snprintf(buf, sizeof buf, "acct:%08d", k);
                 r.unique_key = buf;
                 r.hits = 1; r.limit = 100; r.duration = 60000; r.algorithm = 0; r.behavior = 0; r.created_at = 0;
+                a.name_bytes.insert(a.name_bytes.end(), r.name.begin(), r.name.end()); a.name_off.push_back((uint32_t)a.name_bytes.size());
+                a.ukey_bytes.insert(a.ukey_bytes.end(), r.unique_key.begin(), r.unique_key.end()); a.ukey_off.push_back((uint32_t)a.ukey_bytes.size());
+                a.hits.push_back(1); a.limit.push_back(100); a.duration.push_back(60000); a.burst.push_back(0); a.created.push_back(0);
+                a.algorithm.push_back(0); a.behavior.push_back(0);
             }
+            if (c_api) soa.push_back(std::move(a)); else rpcs.push_back(std::move(reqs));
+        }
+        std::vector<uint8_t> o_status(items), o_err(items); std::vector<int64_t> o_limit(items), o_rem(items), o_reset(items);
+        guber_result_t out{};
+        out.status = o_status.data(); out.limit = o_limit.data(); out.remaining = o_rem.data(); out.reset_time = o_reset.data(); out.err = o_err.data();
         ready++;
         while (!go.load()) std::this_thread::yield();
         std::vector<RateLimitResp> resps;
         std::string err;
         for (size_t it = 0; !stop.load(std::memory_order_relaxed); ++it) {
-            std::vector<RateLimitReq>& reqs = rpcs[it % NR];
-            for (auto& r : reqs) r.created_at = 0;
-            if (!inst.GetRateLimits(reqs, &resps, &err)) { errors++; continue; }
-            for (const auto& o : resps) if (!o.error.empty()) errors++;
+            const double c0 = now_s();
+            if (c_api) {
+                const SoaRpc& a = soa[it % NR];
+                const int rc = guber_pool_get_rate_limits(cp, (uint32_t)items, a.name_bytes.data(), a.name_off.data(), a.ukey_bytes.data(), a.ukey_off.data(),
+                                                          a.hits.data(), a.limit.data(), a.duration.data(), a.burst.data(), a.created.data(), a.algorithm.data(),
+                                                          a.behavior.data(), &out, nullptr, 0);
+                if (rc != GUBER_OK) { errors++; continue; }
+                uint64_t bad = 0;
+                for (int q = 0; q < items; ++q) bad += o_err[q] != 0;
+                if (bad) errors += bad;
+            } else {
+                std::vector<RateLimitReq>& reqs = rpcs[it % NR];
+                for (auto& r : reqs) r.created_at = 0;
+                if (!inst.GetRateLimits(reqs, &resps, &err)) { errors++; continue; }
+                for (const auto& o : resps) if (!o.error.empty()) errors++;
+            }
+            if (timing.load(std::memory_order_relaxed) && lat[t].size() < 2000000) lat[t].push_back((float)((now_s() - c0) * 1e6));
             done.fetch_add((uint64_t)items, std::memory_order_relaxed);
         }
     };
@@ -67,18 +110,26 @@ int main(int argc, char** argv) {
     while (ready.load() < T) std::this_thread::sleep_for(std::chrono::milliseconds(5));
     go.store(true);
     std::this_thread::sleep_for(std::chrono::milliseconds(500));      // warm-up: keys become resident, threads spread out
+    timing.store(true);
     const uint64_t d0 = done.load(); const uint64_t b0 = pool.batches_flushed();
     const double t0 = now_s();
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
     const uint64_t d1 = done.load(); const uint64_t b1 = pool.batches_flushed();
     const double t1 = now_s();
+    timing.store(false);
     stop.store(true);
     for (auto& x : th) x.join();
     guber_pool_metrics_t m{};
     pool.Metrics(&m);
-    printf("pool: %3d caller threads x %4d-item RPCs, %d shard(s), %d keys: %8.2f M decisions/s, %6.0f batches/s, avg batch %6.0f requests, errors %llu\n",
+    std::vector<float> all;
+    for (auto& v : lat) all.insert(all.end(), v.begin(), v.end());
+    std::sort(all.begin(), all.end());
+    const double p50 = all.empty() ? 0 : all[all.size() / 2], p99 = all.empty() ? 0 : all[(size_t)(all.size() * 0.99)];
+    printf("pool: %3d caller threads x %4d-item RPCs, %d shard(s), %d keys: %8.2f M decisions/s, %6.0f batches/s, avg batch %6.0f requests, errors %llu, rpc latency p50 %.1f us p99 %.1f us"
+           " (api %s; placement passes %llu, hot keys moved %llu; per batch: %.0f us flush->answers; per submission: %.1f us host, %.1f batches)\n",
            T, items, S, K, (d1 - d0) / (t1 - t0) / 1e6, (b1 - b0) / (t1 - t0), (b1 - b0) ? (double)(d1 - d0) / (b1 - b0) : 0.0,
-           (unsigned long long)errors.load());
-    pool.Close();
+           (unsigned long long)errors.load(), p50, p99, c_api ? "c" : "cpp", (unsigned long long)m.rebalances, (unsigned long long)m.keys_moved,
+           m.batches ? (double)m.send_duration_us_sum / m.batches : 0.0, m.submits ? (double)m.submit_us_sum / m.submits : 0.0, m.submits ? (double)m.batches / m.submits : 0.0);
+    guber_pool_destroy(cp);
     return 0;
 }
