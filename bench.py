@@ -88,7 +88,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=3, help="with --dispatch one: streams the shards are spread over (shards of one stream share launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the oracle parity pass")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU time budget per thread count of the baseline")
-    ap.add_argument("--cpu-threads", default="1,32,64,128,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
+    ap.add_argument("--cpu-threads", default="1,8,16,32,64,128,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
     ap.add_argument("--profile-steps", type=int, default=128, help="distinct batches run once more with HIP events around every launch")
     ap.add_argument("--latency-steps", type=int, default=128, help="distinct batches run one at a time for the single-batch latency")
     ap.add_argument("--shards", type=int, default=12, metavar="S",
@@ -516,10 +516,23 @@ def parity_over_timed_work(rig, orc, threads, now0, label):
     return ok, compared, el
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by a cgroup CPU quota (cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, -(-int(q) // int(per))))
+    except Exception:   # noqa: BLE001
+        pass
+    return n
+
+
 def cpu_baseline_sample(rig, orc, w, now0, seconds):
-    """one thread count of the CPU baseline: a fresh oracle with W worker caches / threads, the same resident keys, the timed
-    stream's batches from its beginning for a bounded time"""
-    th = w if w > 1 else 0
+    """one configuration of the CPU baseline: a fresh oracle with W worker caches served by min(W, usable CPUs) threads (a thread
+    owns the workers w mod T, as goroutines share cores), the same resident keys, the timed stream's batches from its
+    beginning for a bounded time"""
+    th = min(w, usable_cpus()) if w > 1 else 0
     oracle_populate(rig, orc, th, now0)
     done, t0 = 0, time.perf_counter()
     for s in range(rig.warmup, rig.warmup + rig.steps):
@@ -653,6 +666,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import support
         ncpu = os.cpu_count() or 1
+        ucpu = usable_cpus()
         ws = []
         for tok in args.cpu_threads.split(","):
             tok = tok.strip()
@@ -662,7 +676,7 @@ def main():
                     ws.append(w)
         gate_w = min(ncpu, 32)
         orc = support.Oracle(cache_size=4 * K, workers=gate_w)
-        ok, compared, el = parity_over_timed_work(rig, orc, gate_w if gate_w > 1 else 0, NOW0, "headline")
+        ok, compared, el = parity_over_timed_work(rig, orc, min(gate_w, ucpu) if gate_w > 1 else 0, NOW0, "headline")
         orc.close()
         ok = ok and m["internal_retries"] == 0
         parity = (f"bit-exact vs the oracle fed the whole stream (populate, warm-up, all {steps} timed batches in order): {compared} timed batches compared "
@@ -677,10 +691,11 @@ def main():
             res[w] = cpu_baseline_sample(rig, o, w, NOW0, args.cpu_seconds)
             o.close()
         best = max(res, key=lambda w: res[w][0])
-        cpu = {"value": round(res[best][0], 1), "unit": "decisions/s", "cores": best, "kind": "port",
+        cpu = {"value": round(res[best][0], 1), "unit": "decisions/s", "cores": min(best, ucpu), "kind": "port", "workers": best,
+               "host": {"cpus": ncpu, "usable": ucpu, "note": "usable = affinity mask capped by the cgroup CPU quota (cpu.max); W workers are served by min(W, usable) threads"},
                "sample": f"{res[best][1]} batches of {B} from the beginning of the timed stream ({res[best][2]:.1f} s), {K} resident keys, the oracle in the "
-                         f"reference's worker-sharded design (W caches, one persistent pinned thread each, XXH64-range sharding, workers.go:180-184); "
-                         f"W = {gate_w} ran the whole timed stream (it is the parity pass); host has {ncpu} cores",
+                         f"reference's worker-sharded design (W caches, XXH64-range sharding, workers.go:180-184; persistent threads, a parallel stable partition "
+                         f"per batch); W = {gate_w} ran the whole timed stream (it is the parity pass); host has {ncpu} cores of which {ucpu} are usable",
                "by_threads": {str(w): {"value": round(v[0], 1), "batches": v[1], "seconds": round(v[2], 2)} for w, v in sorted(res.items())}}
 
     touched = m["distinct_keys_in_stream"]
@@ -764,7 +779,7 @@ def run_extra(name, args, ctx, NOW0, seed):
     if name in ("leaky", "expiring") and not args.no_cpu_baseline:
         w = min(os.cpu_count() or 1, 32)
         orc = support.Oracle(cache_size=4 * K, workers=w)
-        ok, compared, _ = parity_over_timed_work(rig, orc, w if w > 1 else 0, NOW0, name)
+        ok, compared, _ = parity_over_timed_work(rig, orc, min(w, usable_cpus()) if w > 1 else 0, NOW0, name)
         orc.close()
         ok = ok and m["internal_retries"] == 0
         out["parity"] = (f"bit-exact vs the oracle fed the whole stream: {compared} timed batches compared (tolerance 0), internal retries {m['internal_retries']}"

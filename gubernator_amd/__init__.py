@@ -367,8 +367,8 @@ class Engine:
 
     def global_take(self, role_mask=6):
         """Pending GLOBAL rows of the requested roles (bit 1 = hits for the owner, bit 2 = owner updates) as
-        a global_sync.Rows (structure of numpy arrays); those queues are cleared."""
-        from .global_sync import Rows
+        a rows.Rows (structure of numpy arrays); those queues are cleared."""
+        from .rows import Rows
         rows = abi.GuberGlobalRows()
         _check(lib().guber_global_take(self.h, role_mask, C.byref(rows)))
         n = rows.n
@@ -382,7 +382,7 @@ class Engine:
                     arr(rows.behavior, C.c_uint32), arr(rows.algorithm, C.c_uint8), arr(rows.role, C.c_uint8))
 
     def add_items_struct(self, items, keepalive=None):
-        """guber_add_items on a numpy structured array laid out as guber_item_t (global_sync.ITEM_DTYPE)."""
+        """guber_add_items on a numpy structured array laid out as guber_item_t (rows.ITEM_DTYPE)."""
         n = len(items)
         if n:
             _check(lib().guber_add_items(self.h, C.cast(items.ctypes.data, C.POINTER(GuberItem)), n, None))

@@ -100,7 +100,7 @@ struct guber_engine {
     CohBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;   // (device-visible: written by k_ctr_snapshot)
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<SegRec> w_srec; DevBuf<int64_t> w_sinv; DevBuf<uint16_t> w_tilerow;
-    DevBuf<uint32_t> w_did2;
+    DevBuf<uint32_t> w_did2, w_ccell;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -246,7 +246,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (const char* v = getenv("GUBER_STAGE_COPY_MIN")) e->stage_copy_min = (uint32_t)atoi(v);
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
-    rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
+    rc |= e->w_did2.ensure((size_t)2 * e->fast_cap); rc |= e->w_ccell.ensure(e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
     rc |= e->w_claims.ensure(e->claims_cells);
@@ -267,6 +267,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_srec.p, 0, (size_t)e->fast_cap * sizeof(SegRec), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_ccell.p, 0, (size_t)e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
@@ -291,7 +292,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
 
     e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
-    e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
+    e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0; e->W.ccell = e->w_ccell.p;
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -326,7 +327,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
-    e->w_did2.release();
+    e->w_did2.release(); e->w_ccell.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
@@ -801,13 +802,9 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
     return 0;
 }
 
-static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* sev) {
-    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
-    int rc = check_batch_args(b, r);
-    if (rc) return rc;
-    if (sev && b->n && (!sev->flags || !sev->items)) return fail(GUBER_E_INVALID_ARG, "null store event arrays");
-    if (sev && b->n) memset(sev->flags, 0, b->n);
-    std::lock_guard<std::mutex> lk(e->mu);
+// (engine mutex held by the caller: the GLOBAL exchange re-runs collided rows through here without letting go of its engines)
+static int eval_batch_host_locked(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* sev) {
+    int rc = 0;
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     const DevCounters before = e->last_ctr;
     r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0;
@@ -835,6 +832,15 @@ static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_resu
     r->unexpired_evictions = e->last_ctr.evictions - before.evictions;
     r->cache_size = e->last_ctr.size;
     return GUBER_OK;
+}
+static int eval_batch_host(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* sev) {
+    if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+    const int rc = check_batch_args(b, r);
+    if (rc) return rc;
+    if (sev && b->n && (!sev->flags || !sev->items)) return fail(GUBER_E_INVALID_ARG, "null store event arrays");
+    if (sev && b->n) memset(sev->flags, 0, b->n);
+    std::lock_guard<std::mutex> lk(e->mu);
+    return eval_batch_host_locked(e, b, r, sev);
 }
 
 // ---- stages: batch buffers in device-visible host memory that the CALLER fills in place and the kernels read / write in
@@ -1417,10 +1423,14 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
     return 0;
 }
 
+static int add_items_locked(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed);
 extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
     if (!e || (!items && n)) return fail(GUBER_E_INVALID_ARG, "null argument");
     if (n == 0) return GUBER_OK;
     std::lock_guard<std::mutex> lk(e->mu);
+    return add_items_locked(e, items, n, existed);
+}
+static int add_items_locked(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     for (uint32_t i = 0; i < n; ++i) {
         if (!items[i].key || items[i].key_len == 0) return fail(GUBER_E_INVALID_ARG, "item without a key");

@@ -329,9 +329,7 @@ static int gs_retry_on_host(guber_comm* c, GsRank* r, const uint8_t* rows, uint3
     b.n = m; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = limit.data(); b.duration = dur.data();
     b.burst = burst.data(); b.created_at = created.data(); b.algorithm = algo.data(); b.behavior = beh.data(); b.is_owner = owner.data(); b.now_ms = now_ms;
     res.status = st.data(); res.limit = ol.data(); res.remaining = orem.data(); res.reset_time = ors.data(); res.err = er.data();
-    e->mu.unlock();
-    const int rc = guber_eval_batch(e, &b, &res);
-    e->mu.lock();
+    const int rc = eval_batch_host_locked(e, &b, &res, nullptr);      // (the engine's mutex stays held: see guber_global_sync)
     if (rc) return rc;
     // patch the device-side results (the item builder reads them)
     for (uint32_t k = 0; k < m; ++k) {
@@ -394,6 +392,10 @@ static int gs_comm_common(guber_comm* c, const guber_ring_t* ring) {
 extern "C" int guber_comm_create_local(guber_engine_t* const* engines, uint32_t n, const guber_ring_t* ring, int use_rccl, guber_comm_t** out) {
     if (!engines || !n || !out || (n > 1 && !ring)) return fail(GUBER_E_INVALID_ARG, "null argument");
     *out = nullptr;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!engines[i]) return fail(GUBER_E_INVALID_ARG, "null engine");
+        for (uint32_t j = 0; j < i; ++j) if (engines[j] == engines[i]) return fail(GUBER_E_INVALID_ARG, "the same engine listed twice");
+    }
     guber_comm* c = new guber_comm();
     c->world = n; c->local_all = true; c->use_rccl = use_rccl != 0 && n > 1;
     for (uint32_t i = 0; i < n; ++i) { GsRank* r = new GsRank(); r->e = engines[i]; r->rank = i; c->ranks.push_back(r); }
@@ -549,8 +551,13 @@ extern "C" int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_s
     std::lock_guard<std::mutex> lk(c->mu);
     const auto t0 = std::chrono::steady_clock::now();
     guber_global_sync_stats_t st{};
-    for (GsRank* r : c->ranks) r->e->mu.lock();
-    struct Unlock { guber_comm* c; ~Unlock() { for (GsRank* r : c->ranks) r->e->mu.unlock(); } } unlock{c};
+    // every local rank's engine, locked in ADDRESS order — the rule of every path that holds several engines at once (fused
+    // launches, guber_stages_submit, guber_move_items_by_hash) — and held until the tick is over
+    std::vector<guber_engine*> held;
+    for (GsRank* r : c->ranks) held.push_back(r->e);
+    std::sort(held.begin(), held.end());
+    for (guber_engine* e : held) e->mu.lock();
+    struct Unlock { std::vector<guber_engine*>& h; ~Unlock() { for (size_t i = h.size(); i-- > 0;) h[i]->mu.unlock(); } } unlock{held};
     const uint32_t W = c->world;
     int rc = 0;
     // ---- A: pending hits -> rows grouped by owner ----
@@ -669,9 +676,7 @@ extern "C" int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_s
                 it.limit = *(const int64_t*)(y + 8); it.duration = *(const int64_t*)(y + 16); it.remaining = *(const int64_t*)(y + 24);
                 it.remaining_f = *(const double*)(y + 32); it.stamp = *(const int64_t*)(y + 40); it.burst = *(const int64_t*)(y + 48);
                 it.expire_at = *(const int64_t*)(y + 56);
-                e->mu.unlock();
-                const int rc2 = guber_add_items(e, &it, 1, nullptr);
-                e->mu.lock();
+                const int rc2 = add_items_locked(e, &it, 1, nullptr);
                 if (rc2) return rc2;
             }
         }

@@ -37,6 +37,7 @@
 #include <stdint.h>
 
 #include "guber_table.h"
+
 #include "guber_kernels_radix.h"
 
 namespace guber {
@@ -92,24 +93,26 @@ __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, ui
 // exact).
 __device__ __forceinline__ uint32_t claim_home_slot(uint32_t slot, uint32_t cmask) { return ((slot * 0x9E3779B1u) >> 11) & cmask; }
 __device__ __forceinline__ uint32_t claim_home_hash(uint64_t h, uint32_t cmask) { return (uint32_t)(h >> 40) & cmask; }
-// `cur` = the value of the home cell as the caller saw it (a fresh, L1-bypassing look: for a hot key all but the first
-// workgroup find the cell taken and issue no CAS at all — CAS-ing on a stale early look was measured and lost, failed
-// CASes on exactly the hot cells; profiles/r01_claims_ab.txt)
-__device__ __forceinline__ uint32_t claim_key(unsigned long long* claims, uint32_t cmask, uint32_t hcell, unsigned long long cur,
-                                              uint32_t fp, uint32_t e16, uint32_t g, bool& claimed) {
+// `first` = what the caller's CAS(0 -> want) on the home cell returned.  The cells a batch claims are zeroed again by its own
+// k_eval2 (the claimer's thread, Work::ccell), so the expected value of a free cell is known without looking first: the claim
+// and the speculative table fetch of a head travel in ONE round trip.  A cell that is neither zero nor of this epoch (left
+// behind by a batch that was not cleaned up: an aborted launch pair, a wrapped epoch) is still taken over correctly, one
+// trip later.  hcell ends up as the cell that holds the key.
+__device__ __forceinline__ uint32_t claim_finish(unsigned long long* claims, uint32_t cmask, uint32_t& hcell, unsigned long long first,
+                                                 uint32_t fp, uint32_t e16, uint32_t g, bool& claimed) {
     const unsigned long long want = ((unsigned long long)e16 << 48) | ((unsigned long long)fp << 16) | g;
+    unsigned long long cur = first;
     for (;;) {
-        for (;;) {
-            if ((uint32_t)(cur >> 48) == e16) {
-                if ((uint32_t)(cur >> 16) == fp) return (uint32_t)(cur & 0xffffull);
-                break;                                          // another key's cell: next
-            }
-            const unsigned long long old = atomicCAS(&claims[hcell], cur, want);
-            if (old == cur) { claimed = true; return g; }
-            cur = old;                                          // lost the race for this cell: look at the winner
+        if (cur == 0ull) { claimed = true; return g; }              // the CAS went through
+        if ((uint32_t)(cur >> 48) == e16) {
+            if ((uint32_t)(cur >> 16) == fp) return (uint32_t)(cur & 0xffffull);
+            hcell = (hcell + 1) & cmask;                             // another key's cell: next
+            cur = atomicCAS(&claims[hcell], 0ull, want);
+            continue;
         }
-        hcell = (hcell + 1) & cmask;
-        cur = ld_agent(&claims[hcell]);
+        const unsigned long long old = atomicCAS(&claims[hcell], cur, want);   // a stale cell
+        if (old == cur) { claimed = true; return g; }
+        cur = old;                                                   // lost the race for it: look at the winner
     }
 }
 
@@ -217,6 +220,21 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     uint64_t h = 0;
     Rec rec; rec_clear(rec);
     if (valid) {
+        // Fixed-width keys (every front end that formats its keys does): the key's words are requested at the offset the first
+        // two keys suggest, together with the request's own offsets instead of after them — one dependent trip less.  The words
+        // are used only if the offsets confirm the guess.
+        uint64_t kw[4] = {0, 0, 0, 0};
+        uint32_t off_g = 0, len_g = 0;
+        bool spec = false;
+        if (!B.key_stride && !W.careful && B.n >= 2) {
+            const uint32_t o0 = B.key_off[0], o1 = B.key_off[1], oend = B.key_off[B.n];
+            len_g = o1 - o0; off_g = o0 + g * len_g;
+            if (len_g != 0 && len_g < 32 && (uint64_t)off_g + 32 <= (uint64_t)oend + 8) {   // (the buffer is padded by 8 bytes)
+                spec = true;
+                const uint8_t* kp = B.key_bytes + off_g;
+                kw[0] = ld_key_word(kp); kw[1] = ld_key_word(kp + 8); kw[2] = ld_key_word(kp + 16); kw[3] = ld_key_word(kp + 24);
+            }
+        }
         const Req mine = load_req_nogreg(B, g);
         off = key_off_of(B, g);
         len = key_len_of(B, g, off);
@@ -225,7 +243,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
         else if (len > T.max_key) errcode = 7;
         GB_STAMPW(6);
         if (!errcode) {
-            h = xxhash64(key, len, 0) & T.hash_mask;
+            h = (spec && off == off_g && len == len_g ? xxhash64_words4(kw, len, 0) : xxhash64(key, len, 0)) & T.hash_mask;
             if (W.careful) {
                 // retry round: every request finds its bucket with a full, verifying probe BEFORE anything is claimed
                 uint32_t cslot = 0;
@@ -279,26 +297,20 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     const bool member = valid && gk != 0ull && eq_before != 0;
     GB_STAMP(1);
 
-    // ---- stage 2 (heads): look at the claim cell, then (unless the key is already claimed) start the directory + bucket
-    // fetch, claim.  The home bucket is requested together with the home directory entry (most resident keys sit at their
-    // home position at load <= 0.5).  Plain table loads: L1 may serve a line that is stale within this launch, which is
-    // safe — a stale "empty" tag is corrected by the insert CAS, and READY never changes during k_front.
+    // ---- stage 2 (heads): claim the key's cell and fetch directory entry + home bucket in the SAME round trip (most resident
+    // keys sit at their home position at load <= 0.5).  A head that turns out not to be the claimer has fetched three sectors for
+    // nothing; in exchange nobody waits for a look before the fetch.  Plain table loads: L1 may serve a line that is stale within
+    // this launch, which is safe — a stale "empty" tag is corrected by the insert CAS, and READY never changes during k_front.
     uint32_t hcell = 0, fp = 0;
-    bool table_wanted = true;
-    unsigned long long look = 0ull;
+    unsigned long long first = 0ull;
     uint64_t pos = (h >> 7) & T.mask;
     ulonglong2 de0 = {0ull, 0ull};
     uint4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     if (khead) {
         if (W.careful) { hcell = claim_home_slot(slot, W.cmask); fp = slot; }
         else { hcell = claim_home_hash(h, W.cmask); fp = (uint32_t)h; }
-        look = ld_agent(&W.claims[hcell]);
-        // the look is consumed first: a head that finds its key claimed by another tile needs neither the directory entry nor
-        // the bucket (it compares its key with the claimer's request, the claimer verifies against the table), which spares
-        // three sector requests for every (key, tile) group but one (same-box A/B: +2.4 % at 4 shards, +1 % with one table;
-        // profiles/r02_w_lean_front_ab.txt)
-        table_wanted = !((uint32_t)(look >> 48) == e16 && (uint32_t)(look >> 16) == fp);
-        if (!W.careful && table_wanted) {
+        first = atomicCAS(&W.claims[hcell], 0ull, ((unsigned long long)e16 << 48) | ((unsigned long long)fp << 16) | g);
+        if (!W.careful) {
             de0 = *(const ulonglong2*)&T.dir[pos];
             const Bucket* hb = &T.buckets[pos];
             const uint4* cw = (const uint4*)&hb->cell; c0 = cw[0]; c1 = cw[1]; c2 = cw[2]; c3 = cw[3];
@@ -312,24 +324,19 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     if (member) my_flags |= req_diff_flags(B, g, tile * FT + head_tid, tile_get(sreq, tid), tile_get(sreq, head_tid), soft_leaky);
     uint32_t d = g;                                                  // error requests: a solo segment that only carries the code
     bool claimed = false;
-    if (khead) d = claim_key(W.claims, W.cmask, hcell, look, fp, e16, g, claimed);
+    if (khead) {
+        d = claim_finish(W.claims, W.cmask, hcell, first, fp, e16, g, claimed);
+        if (claimed) W.ccell[g] = hcell;                             // k_eval2's thread g zeroes the cell for the next batch
+    }
     if (head) sd[tid] = d;
     // A head that is not the claimer publishes its group: ONE atomic per (segment, tile) — set the tile's bit and add the
-    // group size (bits are set once each, so the add never carries into the count).  The claimer's own group is not
-    // published: its size travels in the segment record, so a key that only one tile touches costs no atomic here and
-    // no bitmap traffic at all.  The return value tells whether other tiles of this 32-tile word already published —
-    // only then are per-tile counts needed (k_eval2 ranks a request by the members in earlier tiles), so the scattered
-    // count is written only when a word holds several published tiles: every arriver but the first writes its own, and
-    // the second also writes the first's (= the word's count so far, the first having been alone).
+    // group size (bits are set once each, so the add never carries into the count) — and the group's size in the segment's
+    // per-tile row.  Nothing comes back: no dependent trip.  The claimer's own group is not published: its size travels in
+    // the segment record, so a key that only one tile touches costs no atomic here and no bitmap traffic at all.
     if (khead && !claimed) {
-        const unsigned long long old = atomicAdd(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)],
-                                                 ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)));
-        const uint32_t ob = (uint32_t)old;
-        if (ob) {
-            uint16_t* row = W.tilerow + (size_t)d * FT_MAX_TILES;
-            row[tile] = (uint16_t)eq_total;
-            if ((ob & (ob - 1u)) == 0u) row[(tile & ~31u) + (uint32_t)__ffs((int)ob) - 1u] = (uint16_t)(old >> 32);
-        }
+        (void)__hip_atomic_fetch_add(&seg_mask[(size_t)d * FT_WORDS + (tile >> 5)], ((unsigned long long)eq_total << 32) | (1ull << (tile & 31)),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        W.tilerow[(size_t)d * FT_MAX_TILES + tile] = (uint16_t)eq_total;
     }
     lds_barrier();
     if (member) d = sd[head_tid];
@@ -489,6 +496,7 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
         s0.meta = smeta_meta(smeta);
         sf = seg_flags_of(q3.y, e16);
     }
+    if (live && d == i) W.claims[W.ccell[i] & W.cmask] = 0ull;           // this batch's claim (or, for a request that claimed nothing, a cell that is free anyway)
     if (live && (lr & 0xffu) == 0u) {
         const uint32_t t = i / FT;
         const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip
@@ -673,7 +681,12 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
     }
     GB_STAMP2(4);
 }
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) { eval2_body(A, blockIdx.x, gridDim.x); }
+// (the arguments are read through the kernel-argument pointer, as k_eval2_multi does: preloading all of them into scalar registers
+// cost this kernel four spilled vector registers and a scratch allocation)
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
+    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    eval2_body(*a, blockIdx.x, gridDim.x);
+}
 
 // ---- several engines in one launch ------------------------------------------------------------------------------------
 // The logical shards of a GPU (one table each, disjoint keys) have nothing to order between them, and one batch's two

@@ -115,6 +115,7 @@ struct Work {
     // the HBM table is not written by k_front at all in steady state (a claim in the directory's meta word would dirty
     // one directory sector per distinct key and batch) and the claim does not wait for the directory lookup.
     unsigned long long* claims; uint32_t cmask; uint32_t epoch16;
+    uint32_t* ccell;                    // [cap] per claimer (request index): the cell it claimed — k_eval2 zeroes it again
 #ifdef GUBER_PHASE_TIMING
     unsigned long long* dbg;
 #endif

@@ -34,6 +34,10 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <limits.h>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <sched.h>
 #include <time.h>
 #include <stdio.h>
@@ -630,7 +634,7 @@ int oracle_eval_batch_store(oracle_t* o, const guber_batch_t* b, guber_result_t*
  *
  * The harness keeps `threads` persistent worker threads per oracle (created on first use, pinned round-robin to the
  * CPUs the process may run on when there are enough of them), hands a batch over with one generation counter and runs
- * it in phases separated by spin-then-yield barriers: (1) every thread hashes a contiguous slice of the batch and
+ * it in phases separated by barriers (a waiter looks briefly, then sleeps on a futex): (1) every thread hashes a contiguous slice of the batch and
  * counts its requests per worker; (2) per-worker totals and the slices' offsets (a parallel stable counting sort:
  * inside a worker the request order is kept); (3) every thread applies the queues of the workers it owns (worker w
  * belongs to thread w mod T).  Nothing is allocated per batch once the buffers have grown to the batch size. */
@@ -640,27 +644,34 @@ struct mt_pool {
     pthread_t* th;
     volatile uint32_t gen, stop;               /* gen: a batch is posted (threads spin, then nap) */
     volatile uint32_t bar_count, bar_gen, done;
+    uint32_t spin_limit;                        /* how long a waiter looks before it sleeps (0 with more threads than usable CPUs) */
     const guber_batch_t* b; guber_result_t* res;
     uint64_t* hashes; uint32_t *widx, *order, *hist /* [T][W+1] */, *start /* [W+1] */; uint32_t cap;
     uint64_t* ctr;                              /* [W][4] per-batch counters */
     struct mt_arg* args;
 };
-static inline void mt_relax(uint32_t* spins) {
-    if (++*spins < 2000) {
+/* Waiting: look at the word for a moment, then sleep on it (futex).  With more threads than the CPUs this process may really
+ * use — a cgroup CPU quota counts — spinning waiters only get the whole group throttled, so they sleep at once. */
+static void mt_fwait(volatile uint32_t* w, uint32_t seen) { syscall(SYS_futex, w, FUTEX_WAIT_PRIVATE, seen, NULL, NULL, 0); }
+static void mt_fwake(volatile uint32_t* w) { syscall(SYS_futex, w, FUTEX_WAKE_PRIVATE, INT_MAX, NULL, NULL, 0); }
+static void mt_wait_change(struct mt_pool* p, volatile uint32_t* w, uint32_t seen) {
+    for (uint32_t spins = 0; spins < p->spin_limit; spins++) {
+        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) != seen) return;
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
-    } else sched_yield();
+    }
+    while (__atomic_load_n(w, __ATOMIC_ACQUIRE) == seen) mt_fwait(w, seen);
 }
 static void mt_barrier(struct mt_pool* p) {
     const uint32_t g = __atomic_load_n(&p->bar_gen, __ATOMIC_ACQUIRE);
     if (__atomic_add_fetch(&p->bar_count, 1, __ATOMIC_ACQ_REL) == (uint32_t)p->T) {
         __atomic_store_n(&p->bar_count, 0, __ATOMIC_RELAXED);
-        __atomic_store_n(&p->bar_gen, g + 1, __ATOMIC_RELEASE);
+        __atomic_store_n(&p->bar_gen, g + 1, __ATOMIC_SEQ_CST);
+        mt_fwake(&p->bar_gen);
         return;
     }
-    uint32_t spins = 0;
-    while (__atomic_load_n(&p->bar_gen, __ATOMIC_ACQUIRE) == g) mt_relax(&spins);
+    mt_wait_change(p, &p->bar_gen, g);
 }
 static void mt_run_batch(struct mt_pool* p, int t) {
     oracle_t* o = p->o;
@@ -707,23 +718,19 @@ static void* mt_main(void* arg) {
     struct mt_pool* p = ((struct mt_arg*)arg)->p; const int t = ((struct mt_arg*)arg)->t;
     uint32_t seen = 0;
     for (;;) {
-        uint32_t spins = 0, g;
-        while ((g = __atomic_load_n(&p->gen, __ATOMIC_ACQUIRE)) == seen) {
-            if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) return NULL;
-            if (++spins < 20000) {
-#if defined(__x86_64__) || defined(__i386__)
-                __builtin_ia32_pause();
-#endif
-            } else { struct timespec ts = {0, 50000}; nanosleep(&ts, NULL); }   /* idle between batches: do not burn the core */
-        }
-        seen = g;
+        mt_wait_change(p, &p->gen, seen);                            /* a batch is posted, or the pool is being destroyed */
+        if (__atomic_load_n(&p->stop, __ATOMIC_ACQUIRE)) return NULL;
+        seen = __atomic_load_n(&p->gen, __ATOMIC_ACQUIRE);
         mt_run_batch(p, t);
-        __atomic_add_fetch(&p->done, 1, __ATOMIC_ACQ_REL);
+        __atomic_add_fetch(&p->done, 1, __ATOMIC_SEQ_CST);
+        mt_fwake(&p->done);
     }
 }
 static void mt_destroy(struct mt_pool* p) {
     if (!p) return;
     __atomic_store_n(&p->stop, 1, __ATOMIC_RELEASE);
+    __atomic_add_fetch(&p->gen, 1, __ATOMIC_SEQ_CST);
+    mt_fwake(&p->gen);
     for (int t = 1; t < p->T; t++) pthread_join(p->th[t], NULL);
     free(p->th); free(p->args); free(p->hashes); free(p->widx); free(p->order); free(p->hist); free(p->start); free(p->ctr);
     free(p);
@@ -739,6 +746,19 @@ static struct mt_pool* mt_create(oracle_t* o, int T) {
     cpu_set_t allowed; int ncpu = 0; static int cpus[CPU_SETSIZE];
     if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
         for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &allowed)) cpus[ncpu++] = c;
+    int usable = ncpu > 0 ? ncpu : 1;                               /* CPUs really available: a cgroup quota counts */
+    {
+        FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+        if (f) {
+            char q[32] = {0}; unsigned long long period = 0;
+            if (fscanf(f, "%31s %llu", q, &period) == 2 && period && strcmp(q, "max") != 0) {
+                const unsigned long long quota = strtoull(q, NULL, 10);
+                if (quota && (int)((quota + period - 1) / period) < usable) usable = (int)((quota + period - 1) / period);
+            }
+            fclose(f);
+        }
+    }
+    p->spin_limit = T <= usable ? 4000u : 0u;
     for (int t = 1; t < T; t++) {                                   /* thread 0 is the caller */
         p->args[t].p = p; p->args[t].t = t;
         pthread_create(&p->th[t], NULL, mt_main, &p->args[t]);
@@ -763,10 +783,10 @@ int oracle_eval_batch_mt(oracle_t* o, const guber_batch_t* b, guber_result_t* re
     p->b = b; p->res = res;
     memset(p->ctr, 0, sizeof(uint64_t) * W * 4);
     __atomic_store_n(&p->done, 0, __ATOMIC_RELAXED);
-    __atomic_add_fetch(&p->gen, 1, __ATOMIC_ACQ_REL);
+    __atomic_add_fetch(&p->gen, 1, __ATOMIC_SEQ_CST);
+    mt_fwake(&p->gen);
     mt_run_batch(p, 0);
-    uint32_t spins = 0;
-    while (__atomic_load_n(&p->done, __ATOMIC_ACQUIRE) != (uint32_t)(p->T - 1)) mt_relax(&spins);
+    for (uint32_t d; (d = __atomic_load_n(&p->done, __ATOMIC_ACQUIRE)) != (uint32_t)(p->T - 1);) mt_wait_change(p, &p->done, d);
     res->over_limit_count = res->cache_hits = res->cache_misses = res->unexpired_evictions = 0;
     for (uint32_t w = 0; w < W; w++) {
         res->over_limit_count += p->ctr[w * 4]; res->cache_hits += p->ctr[w * 4 + 1];

@@ -8,7 +8,7 @@ queues of the reference's globalManager, written to follow global.go / gubernato
   UpdatePeerGlobals       gubernator.go:425-459 (replica item construction)
 Peers' flushes are applied in rank order (the reference's order is nondeterministic).
 Also OracleNode: an oracle with the SAME pending-queue behaviour as the HIP engine (guber_global_take),
-so the product orchestrator (gubernator_amd.global_sync) can be exercised on a machine without a GPU."""
+so the product orchestrator (tests/pyglobal.py) can be exercised on a machine without a GPU."""
 import numpy as np
 
 import support
@@ -124,7 +124,7 @@ class OracleNode:
                                               status=int(r["status"])), 0)
 
     def global_take(self, role_mask=6):
-        from gubernator_amd.global_sync import Rows
+        from gubernator_amd.rows import Rows
         take = [k for k, r in self.pending.items() if (role_mask >> r["role"]) & 1]
         rows = [self.pending.pop(k) for k in take]
         return Rows.from_dicts(rows) if rows else Rows.empty()

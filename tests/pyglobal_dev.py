@@ -1,5 +1,8 @@
-"""GLOBAL behaviour across the GPUs of one node with every row staying in HBM (reference: global.go,
-gubernator.go:395-459,510-512; host-staged twin: global_sync.py, which also documents the semantics).
+"""TEST INFRASTRUCTURE (a Python model of the device-resident exchange; the product's implementation is native:
+csrc/guber_global_sync.h).
+
+GLOBAL behaviour across the GPUs of one node with every row staying in HBM (reference: global.go,
+gubernator.go:395-459,510-512; host-staged twin: pyglobal.py, which also documents the semantics).
 
 Per sync and rank:
   guber_global_take_dev(role hits)   pending hit rows, device arrays                       (= sendHits, global.go:144-187)
@@ -20,8 +23,8 @@ import ctypes as C
 
 import torch
 
-from . import GuberError, abi, lib
-from .abi import GuberBatch, GuberResult
+from gubernator_amd import GuberError, abi, lib
+from gubernator_amd.abi import GuberBatch, GuberResult
 
 GLOBAL, DRAIN_OVER_LIMIT = abi.GLOBAL, abi.DRAIN_OVER_LIMIT
 ROLE_HITS, ROLE_UPDATE = 1, 2
@@ -155,7 +158,7 @@ class GlobalSyncDev:
         """A batch of GLOBAL requests arriving at this rank from clients (V1Instance.GetRateLimits,
         gubernator.go:247-270): owned keys are evaluated as the owner, the others against the local replica."""
         import numpy as np
-        from .abi import HostBatch
+        from gubernator_amd.abi import HostBatch
         hb = HostBatch(keys, hits, limit, duration, now_ms, **kw)
         owner = self.ring.route((hb.key_bytes, hb.key_off)) if hb.n else np.zeros(0, np.uint32)
         kw = dict(kw)
@@ -216,7 +219,7 @@ class GlobalSyncDev:
 
     def _eval_on_host(self, sub, retry, now_ms, is_owner, zero_hits, drain, part):
         import numpy as np
-        from .abi import HostBatch
+        from gubernator_amd.abi import HostBatch
         self.fallbacks += 1
         idx = torch.nonzero(retry).reshape(-1)
         r = sub.select(idx)
@@ -279,7 +282,7 @@ class GlobalSyncDev:
         if bool(bad.any()):               # in-call hash collision: hand those few to the host entry point
             self.fallbacks += 1
             import numpy as np
-            from . import make_item
+            from gubernator_amd import make_item
             idx = torch.nonzero(bad).reshape(-1).cpu().numpy()
             km, kl = key_mat.cpu().numpy(), key_len.cpu().numpy()
             h = {f: t.cpu().numpy() for f, t in dict(limit=limit, duration=duration, remaining=remaining, remaining_f=remaining_f,

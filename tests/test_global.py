@@ -1,7 +1,7 @@
 """GLOBAL behaviour (BASELINE config 5) on the CPU:
  * the reference model (tests/global_model.py, global.go restated over N oracles) reproduces the GLOBAL
    vectors of the reference's functional tests;
- * the product orchestrator (gubernator_amd.global_sync.GlobalSync) driven with oracle-backed nodes gives
+ * the product orchestrator (tests/pyglobal.py GlobalSync) driven with oracle-backed nodes gives
    the same answers as the model, in-process (LocalCluster) and across 2 gloo ranks."""
 import os
 import socket
@@ -15,7 +15,7 @@ import gubernator_amd as ga
 import scenarios
 import support
 from global_model import GlobalModel, OracleNode
-from gubernator_amd import global_sync
+import pyglobal as global_sync
 from support import HostBatch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -164,12 +164,12 @@ def test_global_sync_over_gloo_two_ranks(tmp_path):
 
 
 def _gloo_transport_worker(rank, world, port, out_dir):
-    """The row collectives of the device-resident exchange (global_sync_dev.TorchTransportDev): all_to_all_single with
+    """The row collectives of the device-resident exchange (pyglobal_dev.TorchTransportDev): all_to_all_single with
     variable splits and a padded all_gather_into_tensor, here over gloo on CPU tensors (RCCL on the GPU)."""
     import torch
     import torch.distributed as dist
     sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
-    from gubernator_amd import global_sync_dev as gsd
+    import pyglobal_dev as gsd
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = gsd.TorchTransportDev("cpu")

@@ -32,7 +32,8 @@ def _worker(rank, world, port, out_dir):
     import support
     import test_global as tg
     from global_model import GlobalModel
-    from gubernator_amd import global_sync, shard
+    import pyglobal as global_sync
+    from gubernator_amd import shard
     # ---- (i) sharded evaluation on engines == one unsharded oracle ----
     K = 50_000
     table = streams.key_table(K)

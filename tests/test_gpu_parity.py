@@ -155,35 +155,99 @@ def test_zipf_bench_stream_midsize(flags):
         e.close()
 
 
+def _routed_eval(torch, engines, sown, hb, ids, dev):
+    """one host batch through S engines by ONE dispatcher call (guber_eval_batches_routed_dev, fused launches): split by the
+    placement, per-shard device arrays, answers scattered back to the batch's order"""
+    import ctypes as C
+    S, n = len(engines), hb.n
+    sh = sown[ids]
+    L = int(hb.key_off[1] - hb.key_off[0])
+    keymat = hb.key_bytes[:n * L].reshape(n, L)
+    keep, batches, results, which, outs = [], [], [], [], []
+    for j in range(S):
+        pos = np.nonzero(sh == j)[0]
+        if len(pos) == 0:
+            continue
+        m = len(pos)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        kb = t(np.concatenate([keymat[pos].reshape(-1), np.zeros(8, np.uint8)]))
+        ko = t((np.arange(m + 1, dtype=np.int64) * L).astype(np.int32))
+        cols = [t(hb.hits[pos]), t(hb.limit[pos]), t(hb.duration[pos]), t(hb.algorithm[pos]), t(hb.behavior[pos].view(np.int32))]
+        out = [torch.empty(m, dtype=torch.uint8, device=dev), torch.empty(m, dtype=torch.int64, device=dev), torch.empty(m, dtype=torch.int64, device=dev),
+               torch.empty(m, dtype=torch.int64, device=dev), torch.empty(m, dtype=torch.uint8, device=dev)]
+        keep += [kb, ko] + cols + out
+        batches.append(ga.GuberBatch(m, 0, kb.data_ptr(), ko.data_ptr(), cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(), None, None,
+                                     cols[3].data_ptr(), cols[4].data_ptr(), None, None, None, hb.now_ms))
+        results.append(ga.GuberResult(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), 0, 0, 0, 0, 0))
+        which.append(j); outs.append((pos, out))
+    torch.cuda.synchronize(dev)
+    ga.Engine.eval_routed_dev(engines, (C.c_uint32 * len(which))(*which), (ga.GuberBatch * len(which))(*batches), (ga.GuberResult * len(which))(*results), len(which))
+    for e in engines:
+        e.synchronize()
+    got = ga.HostResult(n)
+    for pos, out in outs:
+        for name, tns in zip(("status", "limit", "remaining", "reset_time", "err"), out):
+            getattr(got, name)[pos] = tns.cpu().numpy()
+    return got
+
+
 def test_full_size_10m_keys_batch_65536():
-    """BASELINE config 2/3 at full size: 10M resident keys, Zipf-1.1 batches of 65536, element-wise
-    against the oracle, plus size-independent properties of the token bucket."""
-    K, B = 10_000_000, 65536
+    """BASELINE config 2/3 at full size ACROSS TIME: 10M resident keys, Zipf-1.1 batches of 65536, 16 batches per algorithm with
+    the clock stepping 700 ms (leaky tokens leak: algorithms.go:356-371), one jump past `duration` (mass expiry and renewal:
+    :106-147), a limit change and a duration change mid-run (:90-105, :296-320) — element-wise against the oracle, with the
+    event counters, through ONE engine and through 12 engines behind one dispatcher (fused launches, the product's placement)."""
+    import torch
+    K, B, S = 10_000_000, 65536, 12
+    dev = torch.device("cuda", 0)
     tab = streams.key_table(K)
-    z = streams.ZipfSampler(K)
     o, e = Oracle(cache_size=2 * K), engine(cache_size=K, max_batch=B)
+    place = ga.Placement(S)
+    place.observe_keys(*streams.keys_for_ids(tab, streams.ZipfSampler(K, seed=991).draw(1 << 20)))
+    place.rebalance(0.125, True)
+    sown = np.empty(K, np.uint8)
+    for lo in range(0, K, 2_000_000):
+        sown[lo:lo + 2_000_000] = place.route_keys(*streams.keys_for_ids(tab, np.arange(lo, min(K, lo + 2_000_000))))[0]
+    per = np.bincount(sown, minlength=S)
+    tstreams = [torch.cuda.Stream(device=dev) for _ in range(3)]        # shards that share a stream share their launches
+    shards = [engine(cache_size=int(per[j]) + int(per[j]) // 4 + 1024, max_batch=B, stream=tstreams[j * 3 // S].cuda_stream) for j in range(S)]
     now = streams.NOW0
     # residency: one insert pass (hits 0 creates every bucket without consuming)
     for lo in range(0, K, B):
         ids = np.arange(lo, min(lo + B, K))
         b = streams.bench_batch(tab, ids, now, hits=0)
         o.eval(b); e.eval(b)
-    assert e.size() == o.size() == K
+        _routed_eval(torch, shards, sown, b, ids, dev)
+    assert e.size() == o.size() == K == sum(x.size() for x in shards)
+    z = streams.ZipfSampler(K)
     for algo in (0, 1):
-        for bi in range(3):
+        t = now
+        c0 = (e.counters()[:3], [x.counters()[:3] for x in shards], o.counters()[:3])
+        for bi in range(16):
+            t += 700 if bi != 9 else 61_000                          # batch 9: every bucket of this algorithm's earlier batches has expired
+            limit = 100 if bi < 5 else 40 if bi < 12 else 250        # limit changes mid-run (down, then up)
+            duration = 60_000 if bi < 7 else 30_000                  # duration change mid-run
             ids = z.draw(B)
-            b = streams.bench_batch(tab, ids, now + 1 + bi, algorithm=algo)
-            got, want = e.eval(b), o.eval(b)
-            support.assert_results_equal(got, want, f"algo {algo} batch {bi}")
-            if algo == 0:
+            b = streams.bench_batch(tab, ids, t, algorithm=algo, limit=limit, duration=duration)
+            want = o.eval(b)
+            support.assert_results_equal(e.eval(b), want, f"one engine, algo {algo} batch {bi}")
+            support.assert_results_equal(_routed_eval(torch, shards, sown, b, ids, dev), want, f"12 engines, algo {algo} batch {bi}")
+            if algo == 0 and bi < 5:
                 # per key: remaining strictly decreases by 1 per admitted request, in request order
                 order = np.argsort(ids, kind="stable")
-                sid, rem, st = ids[order], got.remaining[:B][order], got.status[:B][order]
+                sid, rem, st = ids[order], want.remaining[:B][order], want.status[:B][order]
                 same = sid[1:] == sid[:-1]
                 under = (st[1:] == 0) & (st[:-1] == 0) & same
                 assert (rem[:-1][under] - rem[1:][under] == 1).all()
-                assert (rem[st == 1] == 0).all() and (got.limit[:B] == 100).all()
-    assert e.size() == o.size()
+        d_one = tuple(a - b_ for a, b_ in zip(e.counters()[:3], c0[0]))
+        d_many = tuple(sum(x.counters()[:3][k] - c[k] for x, c in zip(shards, c0[1])) for k in range(3))
+        d_orc = tuple(a - b_ for a, b_ in zip(o.counters()[:3], c0[2]))
+        assert d_one == d_many == d_orc, (algo, d_one, d_many, d_orc)   # over-limit / cache hit / cache miss events
+        now = t + 120_000
+    assert e.size() == o.size() == sum(x.size() for x in shards)
+    assert sum(x.stats()["retries"] for x in shards) == 0 and sum(x.stats()["fused_batches"] for x in shards) > 0
+    for x in shards:
+        x.close()
+    place.close()
     e.close()
 
 
@@ -235,7 +299,7 @@ def test_global_behaviour_engines_vs_model():
     GLOBAL vectors of the reference's functional tests."""
     import test_global as tg
     from global_model import GlobalModel
-    from gubernator_amd import global_sync
+    import pyglobal as global_sync
     n = 4
     ring = ga.Ring([f"gpu{i}" for i in range(6)])
     mk = lambda: engine(cache_size=4096, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL)
@@ -491,7 +555,7 @@ def test_global_behaviour_device_resident_exchange_vs_model():
     import torch
     import test_global as tg
     from global_model import GlobalModel
-    from gubernator_amd import global_sync_dev as gsd
+    import pyglobal_dev as gsd
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
         mk = lambda: ga.Engine(cache_size=4096, max_batch=4096, max_key_bytes=64, flags=ga.FLAG_GLOBAL, stream=s.cuda_stream)
@@ -586,7 +650,28 @@ def test_global_behaviour_native_exchange_vs_model():
         assert it["remaining"] == 1000 - 2 * 4, it
     print("native global sync, 2 ranks, 100k rows each way:", [round(x, 3) for x in ms], "ms")
     assert min(ms) < 5.0, ms
+    # a tick holds every local engine's lock, taken in address order — the order fused launches over the same engines use: a
+    # dispatcher hammering guber_eval_batches_routed_dev on both engines while ticks run must not deadlock
+    import threading
+    stop = threading.Event()
+    engines = [r_.node for r_ in cl.ranks]
+    kb, ko = streams.keys_for_ids(tab, np.arange(4096))
+    def hammer():
+        while not stop.is_set():
+            for e_ in reversed(engines):
+                e_.eval(ga.HostBatch((kb, ko), 0, 1000, 600_000, now))
+    th = threading.Thread(target=hammer)
+    th.start()
+    for _ in range(20):
+        cl.sync(now)
+    stop.set()
+    th.join(timeout=30)
+    assert not th.is_alive()
     cl.close()
+    e1 = big()
+    with pytest.raises(ga.GuberError):                                   # one engine cannot be two ranks
+        gn.Comm.local([e1, e1], ring2)
+    e1.close()
 
 
 def test_gregorian_intervals_on_the_device():

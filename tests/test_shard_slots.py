@@ -1,52 +1,72 @@
-"""shard.SlotMap: load-aware placement of a GPU's keys on its logical shards (hash slots + hot-key isolation)."""
+"""guber_placement_* (csrc/placement.cpp): placement of a GPU's keys on its logical shards — hash slots whose initial table IS the
+reference's worker rule (workers.go:153-155,180-184), plus individually placed hot key hashes fitted to observed traffic."""
 import numpy as np
+import xxhash
 
 import gubernator_amd as ga
 import streams
-from gubernator_amd import shard
+import support
 
 
-def _slots(sm, nk):
+def _keys(nk, ids=None):
     tab = streams.key_table(nk)
-    kb, ko = streams.keys_for_ids(tab, np.arange(nk))
-    return sm.ring.route((kb, ko)).astype(np.int64), (kb, ko)
+    return streams.keys_for_ids(tab, np.arange(nk) if ids is None else ids)
 
 
-def test_slotmap_balances_a_zipf_stream_and_isolates_the_hot_key():
+def test_initial_placement_is_the_reference_worker_rule():
+    o = support.oracle_lib()
+    for workers in (1, 2, 3, 5, 8, 12, 13):
+        pl = ga.Placement(workers)
+        rng = np.random.default_rng(workers)
+        for h in [int(x) for x in rng.integers(0, 2 ** 63, 400, dtype=np.int64)] + [0, 1, 2 ** 64 - 1, 2 ** 63, 2 ** 63 - 1]:
+            # (hash63 / hashRingStep can reach `workers` when workers does not divide 2^63 — the reference would index past its slice;
+            #  the engine gives those last few hashes to the last worker)
+            assert pl.shard(h) == min(o.oracle_worker_index_for_hash63(workers, h >> 1), workers - 1), (workers, h)
+        k = b"shardkey_77"
+        assert pl.shard(xxhash.xxh64(k, seed=0).intdigest()) == min(o.oracle_worker_index_for_hash63(workers, xxhash.xxh64(k, seed=0).intdigest() >> 1), workers - 1)
+        pl.close()
+
+
+def test_placement_balances_a_zipf_stream_and_isolates_the_hot_keys():
     nk, S = 200_000, 12
-    sm = shard.SlotMap(S)
-    slot_of, keys = _slots(sm, nk)
-    assert slot_of.min() >= 0 and slot_of.max() < sm.n_slots
+    pl = ga.Placement(S)
     observed = streams.ZipfSampler(nk, s=1.1, seed=7).draw(1 << 20)
-    sown = sm.place(slot_of, observed)
-    assert sown.shape == (nk,) and sown.min() >= 0 and sown.max() < S
+    pl.observe_keys(*_keys(nk, observed))
+    moves = pl.rebalance(0.125, True)
+    assert pl.n_hot() >= 3 and len(moves) == pl.n_hot()
+    sown, hashes = pl.route_keys(*_keys(nk))
+    assert sown.min() >= 0 and sown.max() < S
     later = streams.ZipfSampler(nk, s=1.1, seed=1234).draw(1 << 21)           # the stream that is measured later
     share = np.bincount(sown[later], minlength=S) / len(later)
     hot = np.bincount(later).max() / len(later)
-    assert share.max() <= max(hot, 1.0 / S) * 1.08, share                     # no shard above the hottest key's own share
+    assert share.max() <= max(hot, 1.0 / S) * 1.10, share                     # no shard above the hottest key's own share
     rest = np.sort(share)[:-1]
-    assert rest.max() / rest.min() < 1.15, share                              # the others are even
-    # a plain consistent hash over the shards leaves the hot key's shard with its 1/S of everything else on top
-    ring = ga.Ring([f"s{j}" for j in range(S)], 512, "fnv1")
-    plain = np.bincount(ring.route(keys)[later], minlength=S) / len(later)
-    ring.close()
-    assert plain.max() > share.max() * 1.2, (plain, share)
-    # the hottest key sits (almost) alone; every key has exactly one shard; placement is deterministic
+    assert rest.max() / rest.min() < 1.25, share                              # the others are even
+    plain = ga.Placement(S)                                                    # the untouched worker rule: the hot key's shard carries its 1/S on top
+    psown, _ = plain.route_keys(*_keys(nk))
+    pshare = np.bincount(psown[later], minlength=S) / len(later)
+    assert pshare.max() > share.max() * 1.2, (pshare, share)
     top = int(np.bincount(later).argmax())
-    assert top in set(sm.hot_ids.tolist())
-    sm2 = shard.SlotMap(S)
-    assert np.array_equal(sm2.place(slot_of, observed), sown)
-    sm.close(); sm2.close()
+    assert int(hashes[top]) in {m[0] for m in moves}                           # the hottest key is placed individually
+    # deterministic: the same observations give the same placement
+    pl2 = ga.Placement(S)
+    pl2.observe_keys(*_keys(nk, observed))
+    pl2.rebalance(0.125, True)
+    assert np.array_equal(pl2.route_keys(*_keys(nk))[0], sown)
+    pl.close(); pl2.close(); plain.close()
 
 
-def test_slotmap_without_traffic_spreads_keys_evenly():
-    nk, S = 100_000, 8
-    sm = shard.SlotMap(S)
-    slot_of, _ = _slots(sm, nk)
-    sown = sm.place(slot_of, np.zeros(0, np.int64))
-    per = np.bincount(sown, minlength=S)
-    assert per.min() > 0 and per.max() / per.min() < 1.2, per
-    assert len(sm.hot_ids) == 0
-    sub = np.array([5, 17, 99_999])
-    assert np.array_equal(sm.shard_of(slot_of[sub], key_ids=sub), sown[sub])
-    sm.close()
+def test_online_pass_moves_only_hot_keys_and_reports_them():
+    nk, S = 50_000, 8
+    pl = ga.Placement(S)
+    before, hashes = pl.route_keys(*_keys(nk))
+    before = before.copy()
+    ids = np.concatenate([np.full(60_000, 4242), np.random.default_rng(3).integers(0, nk, 140_000)])
+    pl.observe_keys(*_keys(nk, ids))
+    moves = pl.rebalance(0.125, False)                                         # slots stay; hot keys get the least loaded shard
+    after, _ = pl.route_keys(*_keys(nk))
+    changed = np.nonzero(after != before)[0]
+    assert set(changed.tolist()) <= {4242}
+    assert all(m[0] == int(hashes[4242]) for m in moves) and len(moves) <= 1
+    assert pl.n_hot() == 1
+    pl.close()
