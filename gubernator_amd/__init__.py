@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
     "guber_placement_create", "guber_placement_destroy", "guber_placement_shard", "guber_placement_version", "guber_placement_route_keys",
     "guber_placement_observe", "guber_placement_observe_keys", "guber_placement_rebalance", "guber_placement_info",
-    "guber_stages_submit", "guber_stage_poll", "guber_placement_plan", "guber_placement_commit", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance",
+    "guber_stages_submit", "guber_stage_poll", "guber_placement_plan", "guber_placement_commit", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_get_item", "guber_pool_size",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
@@ -611,9 +611,30 @@ class V1Instance:
         self._store_cbs = cbs
         L.guber_pool_set_store(self.h, C.byref(cbs))
 
-    def GetRateLimits(self, reqs):
+    def global_sync(self):
+        """one GlobalSyncWait tick over the pool's devices (guber_pool_global_sync) -> stats dict"""
+        from .global_native import SyncStats
+        st = SyncStats()
+        L = lib()
+        L.guber_pool_global_sync.argtypes = [C.c_void_p, C.c_void_p]
+        _check(L.guber_pool_global_sync(self.h, C.byref(st)))
+        return {f[0]: getattr(st, f[0]) for f in SyncStats._fields_}
+
+    def global_engine_size(self, device):
+        L = lib()
+        L.guber_pool_global_engine.argtypes = [C.c_void_p, C.c_uint32]
+        L.guber_pool_global_engine.restype = C.c_void_p
+        return L.guber_size(L.guber_pool_global_engine(self.h, device))
+
+    def size(self):
+        L = lib()
+        L.guber_pool_size.argtypes = [C.c_void_p]
+        L.guber_pool_size.restype = C.c_int64
+        return L.guber_pool_size(self.h)
+
+    def GetRateLimits(self, reqs, is_owner=None):
         """-> list of dicts {status, limit, remaining, reset_time, error}; raises GuberError for the
-        RPC-level OutOfRange error (more than 1000 requests)."""
+        RPC-level OutOfRange error (more than 1000 requests).  is_owner: RateLimitReqState.IsOwner per request (None = all)."""
         n = len(reqs)
         def strs(field):
             bs = [r.get(field, "").encode() for r in reqs]
@@ -628,10 +649,17 @@ class V1Instance:
         algo, beh = col("algorithm", np.int32), col("behavior", np.uint32)
         res = HostResult(n)
         txt = C.create_string_buffer(max(n, 1) * self.ERR_STRIDE)
-        rc = lib().guber_pool_get_rate_limits(self.h, n, nb.ctypes.data, no.ctypes.data, kb.ctypes.data, ko.ctypes.data,
-                                              hits.ctypes.data, limit.ctypes.data, duration.ctypes.data, burst.ctypes.data,
-                                              created.ctypes.data, algo.ctypes.data, beh.ctypes.data, C.byref(res.c), txt,
-                                              self.ERR_STRIDE)
+        if is_owner is not None:
+            own = np.array([1 if x else 0 for x in is_owner], np.uint8) if n else np.zeros(1, np.uint8)
+            rc = lib().guber_pool_get_rate_limits_owner(self.h, n, nb.ctypes.data, no.ctypes.data, kb.ctypes.data, ko.ctypes.data,
+                                                        hits.ctypes.data, limit.ctypes.data, duration.ctypes.data, burst.ctypes.data,
+                                                        created.ctypes.data, algo.ctypes.data, beh.ctypes.data, own.ctypes.data, C.byref(res.c), txt,
+                                                        self.ERR_STRIDE)
+        else:
+            rc = lib().guber_pool_get_rate_limits(self.h, n, nb.ctypes.data, no.ctypes.data, kb.ctypes.data, ko.ctypes.data,
+                                                  hits.ctypes.data, limit.ctypes.data, duration.ctypes.data, burst.ctypes.data,
+                                                  created.ctypes.data, algo.ctypes.data, beh.ctypes.data, C.byref(res.c), txt,
+                                                  self.ERR_STRIDE)
         if rc != 0:
             raise GuberError(rc, txt.raw[:self.ERR_STRIDE].split(b"\0")[0].decode())
         out = []

@@ -658,13 +658,17 @@ GB_HD uint64_t xxhash64_words4(const uint64_t w[4], uint32_t len, uint64_t seed)
     using namespace xxh;
     uint64_t h = seed + P5 + (uint64_t)len;
     const uint32_t n8 = len >> 3;
+#ifdef __clang__
 #pragma unroll
+#endif
     for (uint32_t k = 0; k < 3; ++k)
         if (k < n8) { h ^= round1(0, w[k]); h = rotl(h, 27) * P1 + P4; }
     uint64_t t = n8 == 0 ? w[0] : n8 == 1 ? w[1] : n8 == 2 ? w[2] : w[3];   // the word holding the tail bytes
     uint32_t rest = len & 7u;
     if (rest >= 4) { h ^= (uint64_t)(uint32_t)t * P1; h = rotl(h, 23) * P2 + P3; t >>= 32; rest -= 4; }
+#ifdef __clang__
 #pragma unroll
+#endif
     for (uint32_t k = 0; k < 3; ++k)
         if (k < rest) { h ^= (t & 0xffull) * P5; h = rotl(h, 11) * P1; t >>= 8; }
     h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;

@@ -549,7 +549,7 @@ void GPUWorkerPool::GetRateLimitMany(const std::vector<const RateLimitReq*>& req
 namespace {
 struct SoaSrc {
     uint32_t n; const uint8_t* name_bytes; const uint32_t* name_off; const uint8_t* ukey_bytes; const uint32_t* ukey_off;
-    const int64_t *hits, *limit, *duration, *burst, *created_at; const int32_t* algo; const uint32_t* beh;
+    const int64_t *hits, *limit, *duration, *burst, *created_at; const int32_t* algo; const uint32_t* beh; const uint8_t* owner;
     int64_t created_default;
     uint32_t size() const { return n; }
     bool front_end_checks() const { return true; }                   // empty fields have been answered: skip them
@@ -565,7 +565,7 @@ struct SoaSrc {
         r.ukey = ukey_bytes + ukey_off[i]; r.ukey_len = ukey_off[i + 1] - ukey_off[i];
         r.hits = hits[i]; r.limit = limit[i]; r.duration = duration[i]; r.burst = burst ? burst[i] : 0;
         r.created_at = created_at && created_at[i] ? created_at[i] : created_default;                    // gubernator.go:218-220
-        r.algorithm = algorithm(i); r.behavior = behavior(i); r.is_owner = true;
+        r.algorithm = algorithm(i); r.behavior = behavior(i); r.is_owner = owner ? owner[i] != 0 : true;
     }
 };
 struct SoaSink {
@@ -591,13 +591,13 @@ struct SoaSink {
 int GPUWorkerPool::GetRateLimitsSoA(uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off, const uint8_t* ukey_bytes,
                                     const uint32_t* ukey_off, const int64_t* hits, const int64_t* limit, const int64_t* duration,
                                     const int64_t* burst, const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
-                                    guber_result_t* out, char* err_text, uint32_t err_stride) {
+                                    guber_result_t* out, char* err_text, uint32_t err_stride, const uint8_t* is_owner) {
     if (n > kMaxBatchSize) {                                          // gubernator.go:189-193
         if (err_text && err_stride) snprintf(err_text, err_stride, "Requests.RateLimits list too large; max size is '%u'", kMaxBatchSize);
         return GUBER_E_BATCH_TOO_LARGE;
     }
     static thread_local Scratch tls;
-    SoaSrc src{n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior, NowMs()};
+    SoaSrc src{n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior, is_owner, NowMs()};
     SoaSink sink{src, out, err_text, err_stride};
     if (err_text && err_stride) for (uint32_t i = 0; i < n; ++i) err_text[(size_t)i * err_stride] = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -871,41 +871,74 @@ void GPUWorkerPool::run(Device& d) {
 // the stage's own arrays.
 void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
     guber_engine_t* const engine_ = sh.engine;
-    const uint32_t n = s.n;
-    guber_batch_t b = *s.b;
-    guber_result_t res = *s.r;
-    const uint8_t* keys = b.key_bytes; const uint32_t* off = b.key_off;
-    std::vector<uint8_t> sflags(n, 0); std::vector<guber_item_t> sitems(n);
-    guber_store_events_t sev{sflags.data(), sitems.data()};
-    auto store_req = [&](uint32_t i) {
-        guber_store_req_t q{};
-        q.key = keys + off[i]; q.key_len = off[i + 1] - off[i]; q.name_len = s.name_len[i];
-        q.hits = b.hits[i]; q.limit = b.limit[i]; q.duration = b.duration[i]; q.burst = b.burst[i]; q.created_at = b.created_at[i];
-        q.algorithm = b.algorithm[i] == 255 ? -1 : b.algorithm[i]; q.behavior = b.behavior[i];
-        return q;
-    };
-    std::vector<uint8_t> missing(n, 0);
-    int rc = guber_probe_missing(engine_, &b, missing.data());
-    if (rc == GUBER_OK && store_.get) {
-        std::vector<std::string> asked;
-        for (uint32_t i = 0; i < n && rc == GUBER_OK; ++i) {
-            if (!missing[i] || off[i + 1] == off[i]) continue;
-            std::string k((const char*)keys + off[i], off[i + 1] - off[i]);
-            if (std::find(asked.begin(), asked.end(), k) != asked.end()) continue;
-            asked.push_back(k);
-            guber_item_t it{};
-            const guber_store_req_t q = store_req(i);
-            if (store_.get(store_.user, &q, &it)) {
-                it.key = (const uint8_t*)k.data(); it.key_len = (uint32_t)k.size();
-                rc = guber_add_items(engine_, &it, 1, nullptr);
+    const uint32_t n_all = s.n;
+    const guber_batch_t& B = *s.b;
+    const uint8_t* keys = B.key_bytes; const uint32_t* off = B.key_off;
+    // The store is asked on EVERY cache miss (algorithms.go:45-51), also on the miss a request causes for a later request of
+    // the same key in the same batch: RESET_REMAINING removes the item from cache and store (:78-90), and the key's next
+    // request misses again.  The batch is therefore cut in front of any request whose key an earlier request of the cut has
+    // reset: each piece is a batch of its own (residency probe, Store.Get, evaluation, callbacks), which changes nothing else.
+    std::vector<uint32_t> cuts{0};
+    {
+        bool any_reset = false;
+        for (uint32_t i = 0; i < n_all && !any_reset; ++i) any_reset = (B.behavior[i] & 8u) != 0;      // Behavior_RESET_REMAINING
+        if (any_reset) {
+            std::vector<uint32_t> reset;                             // requests of the current piece that carry the bit
+            for (uint32_t i = 0; i < n_all; ++i) {
+                const uint32_t len = off[i + 1] - off[i];
+                for (uint32_t q : reset)
+                    if (off[q + 1] - off[q] == len && memcmp(keys + off[q], keys + off[i], len) == 0) { cuts.push_back(i); reset.clear(); break; }
+                if (B.behavior[i] & 8u) reset.push_back(i);
             }
         }
+        cuts.push_back(n_all);
     }
-    if (rc == GUBER_OK) rc = guber_eval_batch_store(engine_, &b, &res, &sev);
-    if (rc == GUBER_OK) {
-        for (uint32_t i = 0; i < n; ++i) {
-            if ((sflags[i] & GUBER_STORE_REMOVE) && store_.remove) store_.remove(store_.user, keys + off[i], off[i + 1] - off[i]);
-            if ((sflags[i] & GUBER_STORE_ONCHANGE) && store_.on_change) { const guber_store_req_t q = store_req(i); store_.on_change(store_.user, &q, &sitems[i]); }
+    int rc = GUBER_OK;
+    for (size_t piece = 0; piece + 1 < cuts.size() && rc == GUBER_OK; ++piece) {
+        const uint32_t lo = cuts[piece], n = cuts[piece + 1] - lo;
+        if (n == 0) continue;
+        guber_batch_t b = B;
+        guber_result_t res = *s.r;
+        b.n = n; b.key_off = B.key_off + lo; b.hits = B.hits + lo; b.limit = B.limit + lo; b.duration = B.duration + lo;
+        if (B.burst) b.burst = B.burst + lo;
+        if (B.created_at) b.created_at = B.created_at + lo;
+        if (B.algorithm) b.algorithm = B.algorithm + lo;
+        if (B.behavior) b.behavior = B.behavior + lo;
+        if (B.is_owner) b.is_owner = B.is_owner + lo;
+        res.status += lo; res.limit += lo; res.remaining += lo; res.reset_time += lo; res.err += lo;
+        const uint32_t* poff = b.key_off;
+        std::vector<uint8_t> sflags(n, 0); std::vector<guber_item_t> sitems(n);
+        guber_store_events_t sev{sflags.data(), sitems.data()};
+        auto store_req = [&](uint32_t i) {
+            guber_store_req_t q{};
+            q.key = keys + poff[i]; q.key_len = poff[i + 1] - poff[i]; q.name_len = s.name_len[lo + i];
+            q.hits = b.hits[i]; q.limit = b.limit[i]; q.duration = b.duration[i]; q.burst = b.burst[i]; q.created_at = b.created_at[i];
+            q.algorithm = b.algorithm[i] == 255 ? -1 : b.algorithm[i]; q.behavior = b.behavior[i];
+            return q;
+        };
+        std::vector<uint8_t> missing(n, 0);
+        rc = guber_probe_missing(engine_, &b, missing.data());
+        if (rc == GUBER_OK && store_.get) {
+            std::vector<std::string> asked;
+            for (uint32_t i = 0; i < n && rc == GUBER_OK; ++i) {
+                if (!missing[i] || poff[i + 1] == poff[i]) continue;
+                std::string k((const char*)keys + poff[i], poff[i + 1] - poff[i]);
+                if (std::find(asked.begin(), asked.end(), k) != asked.end()) continue;
+                asked.push_back(k);
+                guber_item_t it{};
+                const guber_store_req_t q = store_req(i);
+                if (store_.get(store_.user, &q, &it)) {
+                    it.key = (const uint8_t*)k.data(); it.key_len = (uint32_t)k.size();
+                    rc = guber_add_items(engine_, &it, 1, nullptr);
+                }
+            }
+        }
+        if (rc == GUBER_OK) rc = guber_eval_batch_store(engine_, &b, &res, &sev);
+        if (rc == GUBER_OK) {
+            for (uint32_t i = 0; i < n; ++i) {
+                if ((sflags[i] & GUBER_STORE_REMOVE) && store_.remove) store_.remove(store_.user, keys + poff[i], poff[i + 1] - poff[i]);
+                if ((sflags[i] & GUBER_STORE_ONCHANGE) && store_.on_change) { const guber_store_req_t q = store_req(i); store_.on_change(store_.user, &q, &sitems[i]); }
+            }
         }
     }
     s.rc = rc; s.submitted = false;
@@ -1069,5 +1102,25 @@ extern "C" int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uin
                                           guber_result_t* out, char* err_text, uint32_t err_stride) {
     if (!p || !out || (n && (!name_bytes || !name_off || !ukey_bytes || !ukey_off || !hits || !limit || !duration))) return GUBER_E_INVALID_ARG;
     return p->pool->GetRateLimitsSoA(n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior,
-                                     out, err_text, err_stride);
+                                     out, err_text, err_stride, nullptr);
 }
+// the same with RateLimitReqState.IsOwner per request (workers.go:261 GetRateLimit(ctx, req, reqState); NULL = every request owned):
+// what V1Instance hands over for GLOBAL requests it answers from its replica (gubernator.go:395-421)
+extern "C" int guber_pool_get_rate_limits_owner(guber_pool_t* p, uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off,
+                                                const uint8_t* ukey_bytes, const uint32_t* ukey_off, const int64_t* hits,
+                                                const int64_t* limit, const int64_t* duration, const int64_t* burst,
+                                                const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
+                                                const uint8_t* is_owner, guber_result_t* out, char* err_text, uint32_t err_stride) {
+    if (!p || !out || (n && (!name_bytes || !name_off || !ukey_bytes || !ukey_off || !hits || !limit || !duration))) return GUBER_E_INVALID_ARG;
+    return p->pool->GetRateLimitsSoA(n, name_bytes, name_off, ukey_bytes, ukey_off, hits, limit, duration, burst, created_at, algorithm, behavior,
+                                     out, err_text, err_stride, is_owner);
+}
+extern "C" int guber_pool_add_item(guber_pool_t* p, const guber_item_t* item) { return p && item ? p->pool->AddCacheItem(*item) : GUBER_E_INVALID_ARG; }
+extern "C" int guber_pool_get_item(guber_pool_t* p, const uint8_t* key, uint32_t key_len, guber_item_t* out, int* found) {
+    if (!p || !key || !out || !found) return GUBER_E_INVALID_ARG;
+    bool f = false;
+    const int rc = p->pool->GetCacheItem(std::string((const char*)key, key_len), out, &f);
+    *found = f ? 1 : 0;
+    return rc;
+}
+extern "C" int64_t guber_pool_size(guber_pool_t* p) { return p ? p->pool->Size() : -1; }

@@ -86,7 +86,8 @@ class GPUWorkerPool {
     // include/guber_gpu.h guber_pool_get_rate_limits.  No per-request allocation, no intermediate objects.
     int GetRateLimitsSoA(uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off, const uint8_t* ukey_bytes, const uint32_t* ukey_off,
                          const int64_t* hits, const int64_t* limit, const int64_t* duration, const int64_t* burst, const int64_t* created_at,
-                         const int32_t* algorithm, const uint32_t* behavior, guber_result_t* out, char* err_text, uint32_t err_stride);
+                         const int32_t* algorithm, const uint32_t* behavior, guber_result_t* out, char* err_text, uint32_t err_stride,
+                         const uint8_t* is_owner = nullptr);
     int AddCacheItem(const guber_item_t& item);                                  // workers.go:537
     int GetCacheItem(const std::string& key, guber_item_t* out, bool* found);    // workers.go:583
     // WorkerPool.Load (workers.go:329-449): hand every item of a Loader to the cache; WorkerPool.Store (workers.go:451-534):

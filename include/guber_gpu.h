@@ -426,6 +426,18 @@ int guber_pool_get_rate_limits(guber_pool_t* p, uint32_t n, const uint8_t* name_
                                const int64_t* limit, const int64_t* duration, const int64_t* burst,
                                const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
                                guber_result_t* out, char* err_text, uint32_t err_stride);
+/* The same with RateLimitReqState.IsOwner per request (WorkerPool.GetRateLimit(ctx, req, reqState), workers.go:261; NULL = every
+ * request owned): what V1Instance hands over for GLOBAL requests it answers from its replica (gubernator.go:395-421). */
+int guber_pool_get_rate_limits_owner(guber_pool_t* p, uint32_t n, const uint8_t* name_bytes, const uint32_t* name_off,
+                                     const uint8_t* ukey_bytes, const uint32_t* ukey_off, const int64_t* hits,
+                                     const int64_t* limit, const int64_t* duration, const int64_t* burst,
+                                     const int64_t* created_at, const int32_t* algorithm, const uint32_t* behavior,
+                                     const uint8_t* is_owner, guber_result_t* out, char* err_text, uint32_t err_stride);
+/* WorkerPool.AddCacheItem / GetCacheItem (workers.go:537-626) and the sum of the workers' cache sizes: the item goes to / comes
+ * from the shard the placement gives its key */
+int guber_pool_add_item(guber_pool_t* p, const guber_item_t* item);
+int guber_pool_get_item(guber_pool_t* p, const uint8_t* key, uint32_t key_len, guber_item_t* out, int* found);
+int64_t guber_pool_size(guber_pool_t* p);
 
 /* ---- placement of one GPU's keys on its logical shards (replaces WorkerPool.getWorker, workers.go:180-184, where the
  *      reference picks the worker by XXH64 range).  key_hash = XXH64(HashKey, seed 0) as in workers.go:153-155.  Keys map to

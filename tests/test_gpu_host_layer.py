@@ -189,6 +189,36 @@ def test_store_callbacks_through_the_pool_teststore():
     assert scenarios.run_store_events(PoolBackend) == 10
 
 
+def test_store_is_asked_again_after_a_reset_inside_one_batch():
+    """algorithms.go:45-51 after :78-90 — RESET_REMAINING removes the item from cache and store; the key's next request, in the SAME
+    GetRateLimits call, misses the cache again and the reference calls Store.Get again.  A store that still has the item (it
+    ignores Remove) shows the difference: the third request continues from the store's state, not from a fresh bucket."""
+    now = 1_700_000_000_000
+    calls = []
+
+    class Sticky:
+        def get(self, r, key):
+            calls.append(("get", key))
+            return dict(algorithm=0, limit=10, duration=60_000, remaining=7, stamp=now, expire_at=now + 60_000)
+
+        def on_change(self, r, key, item):
+            calls.append(("on_change", key, item["remaining"]))
+
+        def remove(self, r, key):
+            calls.append(("remove", key))
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+    inst.set_clock(now)
+    inst.set_store(Sticky())
+    req = dict(name="sticky", unique_key="account:1", hits=1, limit=10, duration=60_000)
+    out = inst.GetRateLimits([req, dict(req, behavior=8), req, dict(name="sticky", unique_key="account:2", hits=1, limit=10, duration=60_000), req])
+    key = "sticky_account:1"
+    assert [o["remaining"] for o in out] == [6, 10, 6, 6, 5], out            # 7-1; reset answer (Limit); store's 7 again -1; other key 7-1; 6-1
+    assert out[1]["reset_time"] == 0                                          # algorithms.go:84-89
+    mine = [c for c in calls if c[1] == key]
+    assert mine == [("get", key), ("on_change", key, 6), ("remove", key), ("get", key), ("on_change", key, 6), ("on_change", key, 5)], mine
+    inst.close()
+
+
 @pytest.mark.parametrize("shards", [1, 3])
 def test_loader_round_trip_through_the_pool(shards):
     """store_test.go:76-125 TestLoader: items handed over by Loader.Load are served from the cache, and Loader.Save at
@@ -289,4 +319,42 @@ def test_multi_device_pool_routes_by_the_ring_and_answers_in_place():
     out = inst.GetRateLimits([dict(name="mdp", unique_key=long_key, hits=1, limit=5, duration=1000), dict(name="mdp", unique_key="ok", hits=1, limit=5, duration=1000)])
     assert "too long" in out[0]["error"] and out[1]["error"] == "" and out[1]["remaining"] == 4
     assert inst.metrics()["key_too_long"] == 1
+    inst.close()
+
+
+def test_pool_global_engine_and_hot_key_migration():
+    """(a) With GUBER_FLAG_GLOBAL the pool keeps the keys of GLOBAL requests in ONE dedicated engine per device (the replica the
+    GLOBAL manager synchronises) and guber_pool_global_sync ticks natively over the devices: the owner's state is installed on the
+    other device's replica (global.go:234-283).  (b) A key that carries most of the traffic is moved to another logical shard WITH
+    its bucket by the dispatcher's placement pass, and nothing a caller sees changes: equal to ONE unsharded oracle throughout."""
+    from support import HostBatch, Oracle
+    now = 1_700_000_000_000
+    inst = ga.V1Instance(cache_size=40_000, batch_limit=512, batch_wait_us=100, shards=4, devices=[0, 0], flags=ga.FLAG_GLOBAL, max_key_bytes=64)
+    inst.set_clock(now)
+    assert inst.n_shards() == 2 * (4 + 1)
+    o = Oracle(cache_size=1 << 20)
+    greqs = [dict(name="glob", unique_key=f"g{i}", hits=1, limit=50, duration=60_000, behavior=2, created_at=now) for i in range(200)]
+    out = inst.GetRateLimits(greqs)
+    want = o.eval(HostBatch([f"glob_g{i}" for i in range(200)], 1, 50, 60_000, now, behavior=2, created_at=now))
+    assert [(x["status"], x["limit"], x["remaining"], x["reset_time"]) for x in out] == [r[:4] for r in want.rows()]
+    assert inst.global_engine_size(0) + inst.global_engine_size(1) == 200 == inst.size()      # only the GLOBAL engines hold them
+    st = inst.global_sync()
+    assert st["update_rows"] == 200 and st["items_installed"] == 200 and st["fallbacks"] == 0, st   # every owner broadcast, the other replica installed
+    assert inst.global_engine_size(0) == inst.global_engine_size(1) == 200
+    # (b) one key hammered, placement passes asked for in between
+    rng = np.random.default_rng(5)
+    L = ga.lib()
+    import ctypes
+    L.guber_pool_rebalance.argtypes = [ctypes.c_void_p]
+    L.guber_pool_rebalance.restype = None
+    for step in range(30):
+        ids = np.where(rng.random(900) < 0.6, 7, rng.integers(0, 400, 900))
+        reqs = [dict(name="hot", unique_key=f"k{int(i)}", hits=1, limit=100_000, duration=600_000, algorithm=int(i) % 2, created_at=now) for i in ids]
+        got = inst.GetRateLimits(reqs)
+        want = o.eval(HostBatch([f"hot_k{int(i)}" for i in ids], 1, 100_000, 600_000, now, algorithm=(ids % 2).astype(np.uint8), created_at=now))
+        assert [(x["status"], x["limit"], x["remaining"], x["reset_time"], 0 if not x["error"] else 1) for x in got] == want.rows(), step
+        L.guber_pool_rebalance(inst.h)
+    m = inst.metrics()
+    assert m["rebalances"] >= 1 and m["keys_moved"] >= 1, m
+    assert inst.size() == o.size() + 200                                    # (the GLOBAL keys live on both devices' replicas)
     inst.close()
