@@ -47,6 +47,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     depth_ = std::max(1u, std::min(env_u32("GUBER_POOL_DEPTH", 2), kStages - 2));   // batches of one shard on the GPU at a time
     eager_ = env_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
     eager_min_ = env_u32("GUBER_POOL_EAGER_MIN", 4096);
+    nt_stores_ = env_u32("GUBER_POOL_NT_STORES", 1) != 0;            // the 8-byte request columns go into the stage with non-temporal stores
     spin_us_ = env_u32("GUBER_POOL_SPIN_US", 40);                    // how long a waiting caller looks before it sleeps
     {   // callers allowed in the CPU part of a call at a time: the CPUs this process may really use (a cgroup CPU quota counts),
         // minus one for the dispatcher.  More runnable callers than CPUs only get the whole group throttled.
@@ -242,6 +243,7 @@ struct GPUWorkerPool::Scratch {
     std::vector<uint16_t> dev;
     std::vector<uint32_t> shard, order, todo, next, count, vers;
     std::vector<Ticket2> tickets;
+    std::vector<int64_t> col;                         // a ticket's 8-byte columns, gathered before they are streamed into the stage
     uint32_t observe_tick = 0;
 };
 
@@ -413,24 +415,36 @@ struct GPUWorkerPool::Call {
     }
 
     // the caller writes its requests into the slots it reserved: the HashKey bytes straight into the stage's key buffer
+    // A ticket's share of a stage is a short run in each of ten columns, and the lines were last touched by other cores or read by
+    // the GPU: ordinary stores would first fetch every line for ownership.  The 8-byte columns (40 of a request's 54 bytes) are
+    // therefore gathered into per-thread scratch and streamed out column by column with non-temporal stores — no ownership
+    // fetch, the data is next read over PCIe anyway; the small columns and the key bytes go through the cache.
+    void stream64(int64_t* dst, const int64_t* from, uint32_t n) {
+#if defined(__x86_64__)
+        if (P.nt_stores_) { for (uint32_t q = 0; q < n; ++q) __builtin_ia32_movnti64((long long*)dst + q, (long long)from[q]); return; }
+#endif
+        memcpy(dst, from, (size_t)n * 8);
+    }
     void write(const Ticket2& t) {
         Stage& s = *t.st;
         const guber_batch_t* b = s.b;
         uint8_t* kp = (uint8_t*)b->key_bytes;
-        uint32_t* off = (uint32_t*)b->key_off;
-        int64_t *hits = (int64_t*)b->hits, *limit = (int64_t*)b->limit, *duration = (int64_t*)b->duration, *burst = (int64_t*)b->burst,
-                *created = (int64_t*)b->created_at;
-        uint8_t *algo = (uint8_t*)b->algorithm, *owner = (uint8_t*)b->is_owner;
-        uint32_t* beh = (uint32_t*)b->behavior;
+        uint32_t* off = (uint32_t*)b->key_off + t.first_slot;
+        uint8_t *algo = (uint8_t*)b->algorithm + t.first_slot, *owner = (uint8_t*)b->is_owner + t.first_slot;
+        uint32_t* beh = (uint32_t*)b->behavior + t.first_slot;
+        uint16_t* nlen = s.name_len.data() + t.first_slot;
         int64_t now = 0;
         uint32_t o = t.key_base;
+        const uint32_t n = t.count;
         const uint32_t* list = S.order.data() + t.list_begin;
         const uint8_t* kb = S.keys.data();
+        if (S.col.size() < (size_t)5 * n) S.col.resize((size_t)5 * n);
+        int64_t *c_hits = S.col.data(), *c_limit = c_hits + n, *c_dur = c_limit + n, *c_burst = c_dur + n, *c_created = c_burst + n;
         ReqRef r;
-        for (uint32_t q = 0; q < t.count; ++q) {
-            const uint32_t ri = list[q], i = t.first_slot + q;
+        for (uint32_t q = 0; q < n; ++q) {
+            const uint32_t ri = list[q];
             src.get(ri, r);
-            off[i] = o;
+            off[q] = o;
             {   // exactly the key's bytes: the next slot's key may belong to another caller, who may have written it already
                 const uint8_t* from = kb + S.koff[ri]; uint8_t* to = kp + o; const uint32_t len = S.klen[ri];
                 uint32_t w = 0;
@@ -438,14 +452,20 @@ struct GPUWorkerPool::Call {
                 for (; w < len; ++w) to[w] = from[w];
                 o += len;
             }
-            hits[i] = r.hits; limit[i] = r.limit; duration[i] = r.duration; burst[i] = r.burst;
-            if (r.created_at) created[i] = r.created_at;
-            else { if (!now) now = P.NowMs(); created[i] = now; }
-            algo[i] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
-            beh[i] = r.behavior; owner[i] = r.is_owner ? 1 : 0;
-            s.name_len[i] = (uint16_t)std::min<uint32_t>(S.klen[ri] - 1 - r.ukey_len, 0xffff);
+            c_hits[q] = r.hits; c_limit[q] = r.limit; c_dur[q] = r.duration; c_burst[q] = r.burst;
+            if (r.created_at) c_created[q] = r.created_at;
+            else { if (!now) now = P.NowMs(); c_created[q] = now; }
+            algo[q] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
+            beh[q] = r.behavior; owner[q] = r.is_owner ? 1 : 0;
+            nlen[q] = (uint16_t)std::min<uint32_t>(S.klen[ri] - 1 - r.ukey_len, 0xffff);
         }
-        s.written.fetch_add(t.count, std::memory_order_release);
+        stream64((int64_t*)b->hits + t.first_slot, c_hits, n); stream64((int64_t*)b->limit + t.first_slot, c_limit, n);
+        stream64((int64_t*)b->duration + t.first_slot, c_dur, n); stream64((int64_t*)b->burst + t.first_slot, c_burst, n);
+        stream64((int64_t*)b->created_at + t.first_slot, c_created, n);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();                                      // the streamed stores are globally visible before the count says so
+#endif
+        s.written.fetch_add(n, std::memory_order_release);
     }
 
     // the responses of a ticket, once its generation has been announced; returns false when not ready and !block

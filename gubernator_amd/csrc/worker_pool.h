@@ -200,7 +200,7 @@ class GPUWorkerPool {
     bool has_global_ = false;
     int create_rc_ = 0;
     uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, rebalance_ms_ = 250, max_key_ = 1024, key_cap_ = 0;
-    uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true;
+    uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true, nt_stores_ = true;
     std::atomic<uint32_t> spinners_{0}; uint32_t max_spinners_ = 4;   // callers looking at a word instead of sleeping on it
     sem_t active_sem_; bool limit_active_ = false;        // callers in the CPU part of a call (bounded by max_active_)
     mutable std::atomic<uint64_t> d_dbg_[6] = {};         // GUBER_POOL_DEBUG: where a batch's time goes
