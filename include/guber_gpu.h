@@ -119,7 +119,9 @@ typedef struct guber_batch {
     const uint8_t* is_owner;    /* RateLimitReqState.IsOwner; NULL = all 1 */
     /* Host-precomputed calendar values for DURATION_IS_GREGORIAN items (interval.go:84-148),
      * NULL when no item carries the bit.  greg_duration < 0 encodes the reference's error:
-     * -GUBER_ITEM_E_GREGORIAN_WEEKS or -GUBER_ITEM_E_GREGORIAN_INVALID. */
+     * -GUBER_ITEM_E_GREGORIAN_WEEKS or -GUBER_ITEM_E_GREGORIAN_INVALID.
+     * With both NULL the kernels compute the interval from now_ms themselves, IN UTC.  The reference uses now.Location()
+     * (interval.go:97-142), the daemon's local zone: a daemon that does not run in UTC passes the two arrays. */
     const int64_t* greg_expire;
     const int64_t* greg_duration;
     int64_t now_ms;             /* MillisecondNow() at batch evaluation (lrucache.go:106, cache.go:44) */
