@@ -100,7 +100,7 @@ struct guber_engine {
     CohBuf<BlockCounters> h_bctr; uint32_t n_bctr = 0;   // (device-visible: written by k_ctr_snapshot)
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<SegRec> w_srec; DevBuf<int64_t> w_sinv; DevBuf<uint16_t> w_tilerow;
-    DevBuf<uint32_t> w_did2, w_ccell;
+    DevBuf<uint32_t> w_did2;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -246,7 +246,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (const char* v = getenv("GUBER_STAGE_COPY_MIN")) e->stage_copy_min = (uint32_t)atoi(v);
     rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
     rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
-    rc |= e->w_did2.ensure((size_t)2 * e->fast_cap); rc |= e->w_ccell.ensure(e->fast_cap);
+    rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
     rc |= e->w_claims.ensure(e->claims_cells);
@@ -267,7 +267,6 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_srec.p, 0, (size_t)e->fast_cap * sizeof(SegRec), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
-        (he = hipMemsetAsync(e->w_ccell.p, 0, (size_t)e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
@@ -292,7 +291,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
 
     e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
-    e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0; e->W.ccell = e->w_ccell.p;
+    e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -327,7 +326,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->w_u32.release(); e->w_rflags.release(); e->w_snap.release(); e->w_hist.release();
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
-    e->w_did2.release(); e->w_ccell.release();
+    e->w_did2.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
@@ -383,6 +382,11 @@ static int plan_fast(guber_engine* e, const BatchView& B, bool host_resident, Wo
         e->fast_epoch16 = 1;
     }
     W.epoch16 = e->fast_epoch16;
+    {   // the batch's share of the claim table: 4 cells per request (k_eval2 zeroes exactly that part again)
+        uint32_t cells = 1024;
+        while (cells < 4 * n && cells < e->claims_cells) cells <<= 1;
+        W.cmask = cells - 1;
+    }
     W.parity = e->fast_batches & 1u;
     W.did = e->w_did2.p + (size_t)W.parity * e->fast_cap;
     W.did_prev = e->w_did2.p + (size_t)(W.parity ^ 1u) * e->fast_cap;

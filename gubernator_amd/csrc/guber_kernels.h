@@ -93,8 +93,8 @@ __device__ __forceinline__ bool req_key_equal(const BatchView& B, uint32_t a, ui
 // exact).
 __device__ __forceinline__ uint32_t claim_home_slot(uint32_t slot, uint32_t cmask) { return ((slot * 0x9E3779B1u) >> 11) & cmask; }
 __device__ __forceinline__ uint32_t claim_home_hash(uint64_t h, uint32_t cmask) { return (uint32_t)(h >> 40) & cmask; }
-// `first` = what the caller's CAS(0 -> want) on the home cell returned.  The cells a batch claims are zeroed again by its own
-// k_eval2 (the claimer's thread, Work::ccell), so the expected value of a free cell is known without looking first: the claim
+// `first` = what the caller's CAS(0 -> want) on the home cell returned.  The part of the table a batch uses is zeroed again by its
+// own k_eval2 (whole sectors, sequentially), so the expected value of a free cell is known without looking first: the claim
 // and the speculative table fetch of a head travel in ONE round trip.  A cell that is neither zero nor of this epoch (left
 // behind by a batch that was not cleaned up: an aborted launch pair, a wrapped epoch) is still taken over correctly, one
 // trip later.  hcell ends up as the cell that holds the key.
@@ -326,7 +326,6 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     bool claimed = false;
     if (khead) {
         d = claim_finish(W.claims, W.cmask, hcell, first, fp, e16, g, claimed);
-        if (claimed) W.ccell[g] = hcell;                             // k_eval2's thread g zeroes the cell for the next batch
     }
     if (head) sd[tid] = d;
     // A head that is not the claimer publishes its group: ONE atomic per (segment, tile) — set the tile's bit and add the
@@ -466,6 +465,12 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
     unsigned long long* seg_mask = W.seg_tilemask + (size_t)W.parity * B.n_cap * FT_WORDS;
     const uint32_t e16 = W.epoch16;
     GB_STAMP2(0);
+    {   // zero this batch's claim cells for the next batch: the part of the claim table the batch used (4 cells per request),
+        // as whole sectors written once each — cheaper than one 8-byte store into a random sector per claim
+        ulonglong2* cz = (ulonglong2*)W.claims;
+        const uint32_t pairs = (W.cmask + 1u) >> 1;
+        for (uint32_t j = i; j < pairs; j += ntiles * 256) cz[j] = make_ulonglong2(0ull, 0ull);
+    }
     {   // clear, for the next batch, what the previous batch's publishers added to the other copy of the tile bitmaps: a
         // publisher = the head of a (segment, tile) group that is not the segment's claimer; it zeroes the word it added to
         unsigned long long* om = W.seg_tilemask + (size_t)(W.parity ^ 1u) * B.n_cap * FT_WORDS;
@@ -496,7 +501,6 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
         s0.meta = smeta_meta(smeta);
         sf = seg_flags_of(q3.y, e16);
     }
-    if (live && d == i) W.claims[W.ccell[i] & W.cmask] = 0ull;           // this batch's claim (or, for a request that claimed nothing, a cell that is free anyway)
     if (live && (lr & 0xffu) == 0u) {
         const uint32_t t = i / FT;
         const uint4* wp = (const uint4*)(seg_mask + (size_t)d * FT_WORDS);     // 64 bytes, one round trip

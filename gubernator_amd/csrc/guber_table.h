@@ -111,11 +111,10 @@ struct Work {
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
     uint8_t* store_flags; Rec* store_after;
     // per-batch segment claims of the two-launch pipeline: an insert-only hash table key hash -> first toucher, 4 x fast_cap
-    // cells of (epoch16 << 48 | fingerprint32 << 16 | request index), small enough to live in L2 / Infinity Cache, so that
+    // cells of (epoch16 << 48 | fingerprint32 << 16 | request index) of which a batch uses 4 per request (cmask), small enough to live in L2 / Infinity Cache, so that
     // the HBM table is not written by k_front at all in steady state (a claim in the directory's meta word would dirty
     // one directory sector per distinct key and batch) and the claim does not wait for the directory lookup.
     unsigned long long* claims; uint32_t cmask; uint32_t epoch16;
-    uint32_t* ccell;                    // [cap] per claimer (request index): the cell it claimed — k_eval2 zeroes it again
 #ifdef GUBER_PHASE_TIMING
     unsigned long long* dbg;
 #endif
