@@ -408,6 +408,22 @@ class Engine:
     def synchronize(self):
         _check(lib().guber_synchronize(self.h))
 
+    def stream_handle(self):
+        """the hipStream_t the engine enqueues on (guber_engine_stream): hand it to further engines so that they share launches"""
+        L = lib()
+        L.guber_engine_stream.argtypes = [C.c_void_p]
+        L.guber_engine_stream.restype = C.c_void_p
+        return L.guber_engine_stream(self.h)
+
+    def move_items_to(self, other, key_hashes):
+        """guber_move_items_by_hash: the buckets of the keys with these XXH64 hashes leave this engine's table for `other`'s -> moved"""
+        L = lib()
+        L.guber_move_items_by_hash.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint32)]
+        arr = (C.c_uint64 * max(len(key_hashes), 1))(*[int(h) for h in key_hashes])
+        moved = C.c_uint32(0)
+        _check(L.guber_move_items_by_hash(self.h, other.h, arr, len(key_hashes), C.byref(moved)))
+        return moved.value
+
     def route_dev(self, ring, key_bytes_ptr, key_off_ptr, n, owner_ptr):
         _check(lib().guber_ring_route_dev(self.h, ring.h, key_bytes_ptr, key_off_ptr, n, owner_ptr))
 
@@ -482,6 +498,25 @@ class Stage:
 
     def wait(self):
         _check(lib().guber_stage_wait(self.h))
+
+    def poll(self):
+        """True once the stage's responses are in its result arrays (guber_stage_poll)"""
+        L = lib()
+        L.guber_stage_poll.argtypes = [C.c_void_p]
+        rc = L.guber_stage_poll(self.h)
+        if rc < 0:
+            _check(rc)
+        return rc == 1
+
+    @staticmethod
+    def submit_many(stages, aggregates=False):
+        """guber_stages_submit: at most one stage per engine; stages of engines that share device and stream share launches"""
+        L = lib()
+        L.guber_stages_submit.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        arr = (C.c_void_p * len(stages))(*[s.h for s in stages])
+        done = C.c_uint32(0)
+        _check(L.guber_stages_submit(arr, len(stages), 0 if aggregates else 1, C.byref(done)))
+        return done.value
 
     def result(self):
         n = self.b.n

@@ -881,3 +881,71 @@ def test_extreme_value_runs_on_the_device():
                 assert a["remaining_f"] == b_["remaining_f"] or (a["remaining_f"] != a["remaining_f"] and b_["remaining_f"] != b_["remaining_f"]), (trial, a, b_)
             t += int(rng.choice([0, 1, 40, 1200, 70_000]))
     e.close()
+
+
+def test_stages_of_several_engines_in_one_submission():
+    """guber_stages_submit (what the pool's dispatcher calls): stages of three engines on one stream — an empty one, batches of 5
+    and 200 requests (one k_small_multi), 300, 3000 and 40 000 requests (copy kernel + fused two-launch pipeline) — never blocks,
+    guber_stage_poll reports completion, every answer equals the oracle's, and a second submission of the same engines keeps
+    per-key order."""
+    import time
+    rng = np.random.default_rng(12)
+    now = streams.NOW0
+    first = engine(cache_size=1 << 17, max_batch=65536)
+    engines = [first] + [engine(cache_size=1 << 17, max_batch=65536, stream=first.stream_handle()) for _ in range(2)]
+    oracles = [Oracle(cache_size=1 << 18) for _ in engines]
+    stages = [[ga.Stage(e, 65536, key_bytes_cap=65536 * 24) for _ in range(2)] for e in engines]
+    sizes = [(0, 5, 300), (200, 3000, 40_000), (40_000, 7, 0), (1, 1, 1)]
+    for rnd, ns in enumerate(sizes):
+        batch = []
+        for j, n in enumerate(ns):
+            ids = rng.zipf(1.3, n) % 5000 if n else np.zeros(0, np.int64)
+            hb = HostBatch([f"st{j}_k{int(i)}" for i in ids], rng.integers(0, 3, n), 40, 5_000, now + rnd * 2_600, algorithm=(ids % 2).astype(np.uint8),
+                           created_at=now + rnd * 2_600)
+            stages[j][rnd % 2].fill(hb)
+            batch.append(hb)
+        assert ga.Stage.submit_many([stages[j][rnd % 2] for j in range(3)]) == 3
+        t0 = time.time()
+        while not all(stages[j][rnd % 2].poll() for j in range(3)):
+            assert time.time() - t0 < 10
+        for j, hb in enumerate(batch):
+            stages[j][rnd % 2].wait()
+            if hb.n:
+                support.assert_results_equal(stages[j][rnd % 2].result(), oracles[j].eval(hb), f"round {rnd} engine {j}")
+    assert sum(e.stats()["fused_batches"] for e in engines) >= 2 and sum(e.stats()["small_batches"] for e in engines) >= 4
+    for j, e in enumerate(engines):
+        assert e.size() == oracles[j].size()
+    for row in stages:
+        for st in row:
+            st.close()
+    for e in reversed(engines):                                               # (the engine that owns the stream goes last)
+        e.close()
+
+
+def test_buckets_move_between_tables_by_key_hash():
+    """guber_move_items_by_hash (a hot key changes its logical shard): token and leaky items, an inline key and a 200-byte key
+    (arena), an expired item and a hash that names nothing — the items arrive unchanged, leave nothing behind, and both
+    engines keep evaluating exactly like ONE oracle that never heard of the move."""
+    import xxhash
+    now = streams.NOW0
+    a = engine(cache_size=4096, max_batch=1024, max_key_bytes=256)
+    b = engine(cache_size=4096, max_batch=1024, max_key_bytes=256, stream=a.stream_handle())
+    o = Oracle(cache_size=1 << 16)
+    keys = ["mv_token", "mv_leaky", "mv_" + "L" * 197, "mv_expired", "mv_stays"]
+    algo = np.array([0, 1, 0, 0, 1], np.uint8)
+    hb = HostBatch(keys, 3, 10, [60_000, 60_000, 60_000, 5, 60_000], now, algorithm=algo, created_at=now)
+    support.assert_results_equal(a.eval(hb), o.eval(hb), "before")
+    hashes = [xxhash.xxh64(k.encode(), seed=0).intdigest() for k in keys[:4]] + [0x1234567890abcdef]
+    assert a.move_items_to(b, hashes) == 4
+    assert a.size() == 1 and b.size() == 4
+    for k in keys[:3]:
+        assert a.get_item(k, now + 1) is None
+        it = b.get_item(k, now + 1)
+        assert it is not None and it["limit"] == 10
+    later = now + 10
+    moved = HostBatch(keys[:4], 2, 10, [60_000, 60_000, 60_000, 5], later, algorithm=algo[:4], created_at=later)
+    stays = HostBatch(keys[4:], 2, 10, 60_000, later, algorithm=algo[4:], created_at=later)
+    support.assert_results_equal(b.eval(moved), o.eval(moved), "moved keys on their new table")       # incl. the expired one: renewed, as the oracle does
+    support.assert_results_equal(a.eval(stays), o.eval(stays), "the key that stayed")
+    assert a.size() + b.size() == o.size()
+    b.close(); a.close()
