@@ -546,6 +546,20 @@ def cpu_baseline_sample(rig, orc, w, now0, seconds):
     return done * rig.ctx.B / el, done, el
 
 
+def finish_distributed(dist):
+    """The line is out: leave without the interpreter's teardown.  With several processes on a node the order in which the process
+    group, the HIP runtime and the library's statics go away at exit is not ours to choose (an abort there — seen once with two
+    ranks sharing one GPU — would turn a finished measurement into a failed run)."""
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
+
+
 def rocprof_reference(algo):
     """the committed rocprofv3 summary of this command (profiles/r03_rocprof_summary.json), if any: the same formula on its
     average kernel duration, so that the line and the file can be checked against each other"""
@@ -746,9 +760,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
         }
         out.update(extras)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        finish_distributed(dist)
 
 
 def run_extra(name, args, ctx, NOW0, seed):
@@ -914,6 +928,8 @@ def run_global(args, ctx, dist):
     from gubernator_amd import shard
     K, B, world, rank, dev = ctx.K, ctx.B, ctx.world, ctx.rank, ctx.dev
     GSYNC, NOW0 = args.global_sync, streams.NOW0
+    if world > 1 and args.one_device:
+        raise SystemExit("--global-sync with --one-device: RCCL refuses two ranks on one GPU; run ONE process with --logical-ranks R instead")
     R = 1 if world > 1 else max(1, args.logical_ranks)          # ranks living in this process
     nranks = world if world > 1 else R
     ring = ga.Ring(shard.peer_names(nranks), 512, "fnv1")
@@ -1000,12 +1016,12 @@ def run_global(args, ctx, dist):
                                "avg_update_rows": int(avg("update_rows")), "avg_items_installed": int(avg("items_installed")),
                                "avg_bytes_moved": int(avg("bytes_moved")), "host_fallbacks": int(sum(x["fallbacks"] for x in sync_stats)),
                                "replicas_converged": converged}}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     comm.close()
     for rig in rigs:
         rig.close()
     if world > 1:
-        dist.destroy_process_group()
+        finish_distributed(dist)
 
 
 if __name__ == "__main__":
