@@ -199,7 +199,7 @@ int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_re
  *      arrays in place.  guber_stage_submit returns at
  *      once; guber_stage_wait blocks until the responses are there (a polled sequence number for batches <= 256, a HIP
  *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With several stages per engine one
- *      is filled while the GPU evaluates another (the pool keeps three: filling / on the GPU / being read out).  Stages of one engine are evaluated in submission order; the one
+ *      is filled while the GPU evaluates another (the pool keeps four per shard: filling / up to two on the GPU / being read out).  Stages of one engine are evaluated in submission order; the one
  *      exception are items that hit the internal retry (two keys under one 64-bit hash inside a batch, ~1e-6 per batch): they
  *      are re-run by guber_stage_wait, i.e. possibly after the next stage already in flight — the order two concurrent
  *      GetRateLimits calls have in the reference too (none).  Callers that need strict order keep one stage in flight.
