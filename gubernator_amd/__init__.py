@@ -581,7 +581,7 @@ class V1Instance:
     def metrics(self):
         class M(C.Structure):
             _fields_ = [(f, C.c_uint64) for f in ("batches", "requests", "queue_length", "queue_length_max", "send_duration_us_sum",
-                                                  "send_duration_us_max", "batch_size_max", "in_flight", "key_too_long", "flush_on_key_bytes", "rebalances", "keys_moved", "submits", "submit_us_sum")] + \
+                                                  "send_duration_us_max", "batch_size_max", "in_flight", "key_too_long", "flush_on_key_bytes", "rebalances", "keys_moved", "submits", "submit_us_sum", "direct_batches")] + \
                        [("shards", C.c_uint32), ("devices", C.c_uint32)]
         m = M()
         _check(lib().guber_pool_metrics(self.h, C.byref(m)))

@@ -47,6 +47,8 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     depth_ = std::max(1u, std::min(env_u32("GUBER_POOL_DEPTH", 2), kStages - 2));   // batches of one shard on the GPU at a time
     eager_ = env_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
     eager_min_ = env_u32("GUBER_POOL_EAGER_MIN", 4096);
+    direct_max_ = env_u32("GUBER_POOL_DIRECT_MAX", 4);               // RPCs of at most this many requests may be evaluated by their caller (0 = never)
+    direct_callers_ = env_u32("GUBER_POOL_DIRECT_CALLERS", 0);       // ... while at most this many calls are in progress (0 = half the shards, at least 2)
     nt_stores_ = env_u32("GUBER_POOL_NT_STORES", 1) != 0;            // the 8-byte request columns go into the stage with non-temporal stores
     spin_us_ = env_u32("GUBER_POOL_SPIN_US", 40);                    // how long a waiting caller looks before it sleeps
     {   // callers allowed in the CPU part of a call at a time: the CPUs this process may really use (a cgroup CPU quota counts),
@@ -71,6 +73,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     std::vector<int32_t> devs = devices;
     if (devs.empty()) devs.push_back(cfg.device);
     has_global_ = (cfg.flags & GUBER_FLAG_GLOBAL) != 0;
+    if (direct_callers_ == 0) direct_callers_ = std::max<uint32_t>(2u, (uint32_t)devs.size() * shards / 2);
     n_devices_ = (uint32_t)devs.size(); plain_per_device_ = shards; shards_per_device_ = shards + (has_global_ ? 1 : 0);
     if (n_devices_ > 1 || has_global_) {                             // the GPUs of the node are the peers of the ring
         std::vector<std::string> names; std::vector<const char*> ptrs;
@@ -204,6 +207,7 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
         out->in_flight += sh->in_flight.load();
         out->key_too_long += sh->key_too_long.load(); out->flush_on_key_bytes += sh->flush_on_key_bytes.load();
     }
+    for (auto& sh : shards_) out->direct_batches += sh->direct.load();
     for (auto& d : devs_) { out->rebalances += d->rebalances.load(); out->keys_moved += d->moves.load(); out->submit_us_sum += d->submit_us.load(); out->submits += d->submits.load(); }
     out->shards = (uint32_t)shards_.size(); out->devices = n_devices_;
     if (getenv("GUBER_POOL_DEBUG") && d_dbg_[3].load())
@@ -244,6 +248,7 @@ struct GPUWorkerPool::Scratch {
     std::vector<uint32_t> shard, order, todo, next, count, vers;
     std::vector<Ticket2> tickets;
     std::vector<int64_t> col;                         // a ticket's 8-byte columns, gathered before they are streamed into the stage
+    std::vector<uint8_t> dkeys;                       // key bytes of a batch the caller evaluates itself
     uint32_t observe_tick = 0;
 };
 
@@ -263,6 +268,7 @@ struct GPUWorkerPool::Call {
         const uint32_t n = src.size();
         if (n == 0) return;
         if (P.closed_.load() || P.shards_.empty()) { for (uint32_t i = 0; i < n; ++i) sink.closed(i); return; }
+        struct InCall { std::atomic<uint32_t>& c; InCall(std::atomic<uint32_t>& x) : c(x) { c.fetch_add(1, std::memory_order_relaxed); } ~InCall() { c.fetch_sub(1, std::memory_order_relaxed); } } in_call{P.in_calls_};
         P.enter();
 #ifdef GUBER_POOL_PHASES
         uint64_t ph_t = tsc(); g_ph[5] += n;
@@ -326,11 +332,17 @@ struct GPUWorkerPool::Call {
             }
             S.next.clear();
             PH(1);
+            // a handful of requests and nobody else at their shard: the caller evaluates them itself, now (the reference's worker
+            // takes a request the moment it arrives) — one launch, no hand-off to the dispatcher and back
+            // — when the pool is lightly loaded: with many callers at once, requests that share a launch serve more of them per microsecond
+            const bool direct_ok = base == 0 && P.eager_ && S.todo.size() <= P.direct_max_ && !P.has_store_.load(std::memory_order_relaxed) &&
+                                   P.in_calls_.load(std::memory_order_relaxed) <= P.direct_callers_;
             bool closed = false;
             for (uint32_t j = 0; j < n_shards; ++j) {
                 uint32_t pos = base + S.count[j], left = S.count[j + 1] - S.count[j];
                 if (!left) continue;
                 Shard& sh = *P.shards_[j];
+                if (direct_ok && direct(sh, S.vers[sh.dev->index], pos, left)) continue;
                 while (left) {
                     if (closed) { for (uint32_t q = 0; q < left; ++q) sink.closed(S.order[pos + q]); break; }
                     Ticket2 t{};
@@ -354,6 +366,49 @@ struct GPUWorkerPool::Call {
         for (auto& t : S.tickets)
             if (!t.consumed) consume(t, true);
         PH(4);
+    }
+
+    // Evaluate order[pos .. pos + n) of one shard on the caller's thread (guber_eval_batch: the engine's one-launch path, polled).
+    // Only when nobody else does the same at this shard and the placement is still the one the caller routed with; a move of a hot
+    // key waits for it (place_mu).  Requests of one key from different callers have no order among each other; a caller's own
+    // earlier calls have been answered.  false = not taken: the staged path applies.
+    bool direct(Shard& sh, uint32_t ver, uint32_t pos, uint32_t n) {
+        constexpr uint32_t kMax = 16;
+        if (n > kMax || sh.direct_busy.exchange(true, std::memory_order_acquire)) return false;
+        struct Release { std::atomic<bool>& f; ~Release() { f.store(false, std::memory_order_release); } } release{sh.direct_busy};
+        Device& d = *sh.dev;
+        std::shared_lock<std::shared_mutex> lk(d.place_mu);
+        if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver || sh.open.load(std::memory_order_acquire) == kOpenDead) return false;
+        const uint32_t* list = S.order.data() + pos;
+        uint32_t off[kMax + 1], beh[kMax]; int64_t hits[kMax], limit[kMax], duration[kMax], burst[kMax], created[kMax], ol[kMax], orem[kMax], ors[kMax];
+        uint8_t algo[kMax], owner[kMax], ost[kMax], oerr[kMax];
+        uint32_t bytes = 0;
+        for (uint32_t q = 0; q < n; ++q) bytes += S.klen[list[q]];
+        if (S.dkeys.size() < (size_t)bytes + 16) S.dkeys.resize((size_t)bytes + 16);
+        const int64_t now = P.NowMs();
+        ReqRef r;
+        uint32_t o = 0;
+        for (uint32_t q = 0; q < n; ++q) {
+            const uint32_t ri = list[q];
+            src.get(ri, r);
+            off[q] = o; memcpy(S.dkeys.data() + o, S.keys.data() + S.koff[ri], S.klen[ri]); o += S.klen[ri];
+            hits[q] = r.hits; limit[q] = r.limit; duration[q] = r.duration; burst[q] = r.burst; created[q] = r.created_at ? r.created_at : now;
+            algo[q] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255; beh[q] = r.behavior; owner[q] = r.is_owner ? 1 : 0;
+        }
+        off[n] = o; memset(S.dkeys.data() + o, 0, 16);
+        guber_batch_t b{}; guber_result_t res{};
+        b.n = n; b.key_bytes = S.dkeys.data(); b.key_off = off; b.hits = hits; b.limit = limit; b.duration = duration; b.burst = burst; b.created_at = created;
+        b.algorithm = algo; b.behavior = beh; b.is_owner = owner; b.now_ms = now;
+        res.status = ost; res.limit = ol; res.remaining = orem; res.reset_time = ors; res.err = oerr;
+        const int rc = guber_eval_batch(sh.engine, &b, &res);
+        for (uint32_t q = 0; q < n; ++q) {
+            const uint32_t ri = list[q];
+            if (rc != GUBER_OK) sink.engine_error(ri, rc);
+            else if (oerr[q] == 0) sink.ok(ri, ost[q], ol[q], orem[q], ors[q]);
+            else sink.item_error(ri, oerr[q], src.algorithm(ri));
+        }
+        sh.requests += n; sh.flushed++; sh.direct++;
+        return true;
     }
 
     // Reserve slots for as many of order[pos .. pos + count) as the shard's open stage still takes: ONE compare-and-swap on the

@@ -157,7 +157,8 @@ class GPUWorkerPool {
         std::atomic<uint32_t> open_seq{0}, open_waiters{0};   // futex word of callers waiting for a stage to open, and how many sleep on it
         uint32_t stages_in_flight = 0;                    // dispatcher: stages of this shard on the GPU
         std::atomic<uint64_t> flushed{0}, requests{0}, queue_max{0}, send_us_sum{0}, send_us_max{0}, batch_max{0}, in_flight{0},
-            key_too_long{0}, flush_on_key_bytes{0};
+            key_too_long{0}, flush_on_key_bytes{0}, direct{0};
+        std::atomic<bool> direct_busy{false};             // a caller is evaluating a handful of requests at this shard itself
     };
     struct Device {             // one GPU (or logical device): its shards, their placement, the dispatcher thread
         uint32_t index = 0; int32_t ordinal = 0;
@@ -201,6 +202,8 @@ class GPUWorkerPool {
     int create_rc_ = 0;
     uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, rebalance_ms_ = 250, max_key_ = 1024, key_cap_ = 0;
     uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true, nt_stores_ = true;
+    uint32_t direct_max_ = 4, direct_callers_ = 0;
+    std::atomic<uint32_t> in_calls_{0};                   // calls in progress
     std::atomic<uint32_t> spinners_{0}; uint32_t max_spinners_ = 4;   // callers looking at a word instead of sleeping on it
     sem_t active_sem_; bool limit_active_ = false;        // callers in the CPU part of a call (bounded by max_active_)
     mutable std::atomic<uint64_t> d_dbg_[6] = {};         // GUBER_POOL_DEBUG: where a batch's time goes

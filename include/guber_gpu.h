@@ -393,6 +393,7 @@ typedef struct guber_pool_metrics {
     uint64_t rebalances;                   /* placement passes of the dispatchers */
     uint64_t keys_moved;                   /* hot keys whose bucket changed its logical shard */
     uint64_t submits, submit_us_sum;       /* dispatcher submissions (one may carry the batches of all shards) and the host time inside them */
+    uint64_t direct_batches;               /* RPCs of a handful of requests evaluated by their caller's thread (counted in `batches` too) */
     uint32_t shards, devices;
 } guber_pool_metrics_t;
 int guber_pool_metrics(guber_pool_t* p, guber_pool_metrics_t* out);

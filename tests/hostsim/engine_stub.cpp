@@ -109,6 +109,14 @@ extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to
 extern "C" int guber_comm_create_local(guber_engine_t* const*, uint32_t, const guber_ring_t*, int, guber_comm_t**) { return GUBER_E_INVALID_ARG; }
 extern "C" void guber_comm_destroy(guber_comm_t*) {}
 extern "C" int guber_global_sync(guber_comm_t*, int64_t, guber_global_sync_stats_t*) { return GUBER_E_INVALID_ARG; }
+extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) {
+    std::lock_guard<std::mutex> lk(e->mu);
+    static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;
+    if (b->n && !null_engine) oracle_eval_batch(e->o, b, r);
+    if (null_engine) memset(r->err, 0, b->n);
+    else { static thread_local std::mt19937 rng{99}; std::this_thread::sleep_for(std::chrono::microseconds(rng() % 40)); }   // the launch + the GPU take a while
+    return GUBER_OK;
+}
 extern "C" int guber_add_items(guber_engine_t* e, const guber_item_t* items, uint32_t n, uint8_t* existed) {
     std::lock_guard<std::mutex> lk(e->mu);
     for (uint32_t i = 0; i < n; ++i) { int ex = 0; oracle_add_item(e->o, &items[i], 0, &ex); if (existed) existed[i] = (uint8_t)ex; }

@@ -226,6 +226,40 @@ int main(int argc, char** argv) {
         guber_pool_destroy(cp);
         printf("C entry point: failures so far %d\n", failures);
     }
+    {   // 7. RPCs of a handful of requests: the caller evaluates them itself when nobody else is at the shard, otherwise they travel in
+        //    stages — both ways while placement passes move the hot keys; exact per thread, the shared key exact in total
+        GPUWorkerPool pool(cfg, 256, 150, 4);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        std::atomic<bool> stop{false};
+        std::thread kicker([&] { while (!stop.load()) { pool.RebalanceNow(); std::this_thread::sleep_for(std::chrono::milliseconds(2)); } });
+        const int limit = 3000;
+        std::atomic<long> shared_under{0}, shared_total{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 10; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(700 + t);
+            const std::string ns = "sm" + std::to_string(t);
+            for (int it = 0; it < 2500 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 12, 3);
+                if (rng() % 2) { reqs[0].unique_key = "hot"; reqs[0].hits = 1; reqs[0].limit = 1000000; reqs[0].duration = 3600000; reqs[0].behavior = 0; reqs[0].algorithm = 0; }
+                std::vector<RateLimitReq> mine = reqs;
+                if (rng() % 3 == 0) { RateLimitReq s; s.name = "all"; s.unique_key = "shared"; s.hits = 1; s.limit = limit; s.duration = 3600000; reqs.push_back(s); }
+                std::vector<RateLimitResp> resps; std::string err;
+                CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+                std::vector<RateLimitResp> own(resps.begin(), resps.begin() + mine.size());
+                compare(mine, own, ref, NOW0, "small RPCs");
+                for (size_t q = mine.size(); q < resps.size(); ++q) { shared_total++; if (resps[q].error.empty() && resps[q].status == 0) shared_under++; }
+            }
+        });
+        for (auto& x : th) x.join();
+        stop.store(true); kicker.join();
+        CHECK(shared_under.load() == std::min<long>(shared_total.load(), limit), "shared key: %ld of %ld under the limit %d", shared_under.load(), shared_total.load(), limit);
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        const bool eager = !(getenv("GUBER_POOL_EAGER") && atoi(getenv("GUBER_POOL_EAGER")) == 0);   // (the caller-evaluated path belongs to the eager policy)
+        CHECK((m.direct_batches > 0 || !eager) && m.batches >= m.direct_batches, "direct %llu of %llu batches", (unsigned long long)m.direct_batches, (unsigned long long)m.batches);
+        printf("small RPCs: %llu batches of which %llu evaluated by their callers, %llu hot keys moved, failures so far %d\n", (unsigned long long)m.batches,
+               (unsigned long long)m.direct_batches, (unsigned long long)m.keys_moved, failures);
+    }
     printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
     return failures ? 1 : 0;
 }
