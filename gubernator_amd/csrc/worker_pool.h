@@ -10,18 +10,22 @@
 //
 // ONE dispatcher thread per device serves all of the device's shards (round 2 had a batcher thread and stream per shard:
 // the launches of different streams overlap badly on the GPU and the threads fought for the host).  It seals the stages
-// that are due — batch_limit items, batch_wait after the first one (the policy of peer_client.go:284-337), or, by
-// default, as soon as nobody has reserved anything for idle_us and every reserved slot is written (the callers are all
-// waiting: holding the batch only adds latency) — and submits them together (guber_stages_submit): the batches of up to
-// four shards travel in ONE copy kernel + ONE k_front_multi + ONE k_eval2_multi, the shards spread over three streams,
-// batches of <= 256 requests take the one-launch path without being waited for.  It polls for completions
-// (guber_stage_poll), announces finished generations (futex), and never touches a request.  Nothing is allocated per flush.
+// that are due — as soon as the device has room (the reference's workers take a request the moment it arrives; a batch then
+// collects what arrives while the previous one runs, so batches grow with the load by themselves), at batch_limit items, at
+// batch_wait after the first one (the policy of peer_client.go:284-337), when a caller found no room — and submits them
+// together (guber_stages_submit): the batches of up to four shards of a stream travel in ONE copy kernel + ONE k_front_multi +
+// ONE k_eval2_multi, batches of <= 256 requests in ONE k_small_multi, nothing is waited for.  It polls for completions
+// (guber_stage_poll), announces finished generations (futex; wake-ups fan out as a tree), and never touches a request.
+// Nothing is allocated per flush.  Lightly loaded (at most shards/2 calls in progress) an RPC of a handful of requests does
+// not travel through stages at all: its caller evaluates it through guber_eval_batch and answers.
+// The host's CPUs are the pool's bottleneck, so it counts them (a cgroup CPU quota included): at most that many callers are
+// in the CPU part of a call at a time, and callers of large batches sleep at once instead of spinning.
 //
 // Placement: `devices` x `shards_per_device`.  A key's device is its owner on the reference's replicated consistent hash
 // over the peers "gpu0".."gpuN-1" (replicated_hash.go:78-119, 512 vnodes, fnv1) — the N GPUs of a node are N peers.
 // Inside a device the shard comes from the device's guber_placement_t: XXH64-range slots whose initial table IS the
 // reference's worker rule (workers.go:153-155,180-184), plus the keys that turn out to carry a large share of the traffic,
-// observed online (every 16th request feeds the placement's sketch) and isolated on the least loaded shard.  Moving a
+// observed online (every 64th request feeds the placement's sketch) and isolated on the least loaded shard.  Moving a
 // resident key is done by the dispatcher at a batch boundary: every open stage of the device is sealed, the batches in
 // flight drain, the key's bucket is taken from the old shard's table and added to the new one's, the new exception list is
 // published and the stages reopen carrying the new placement version — a caller that routed with the old version cannot
