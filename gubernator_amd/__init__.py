@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
     "guber_placement_create", "guber_placement_destroy", "guber_placement_shard", "guber_placement_version", "guber_placement_route_keys",
     "guber_placement_observe", "guber_placement_observe_keys", "guber_placement_rebalance", "guber_placement_info",
-    "guber_stages_submit", "guber_stage_poll", "guber_placement_plan", "guber_placement_commit", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_get_item", "guber_pool_size",
+    "guber_stages_submit", "guber_stage_poll", "guber_stage_dest", "guber_stage_submit_routed", "guber_placement_plan", "guber_placement_commit", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_get_item", "guber_pool_size",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
@@ -517,6 +517,26 @@ class Stage:
         done = C.c_uint32(0)
         _check(L.guber_stages_submit(arr, len(stages), 0 if aggregates else 1, C.byref(done)))
         return done.value
+
+    def submit_routed(self, engines, shard_of):
+        """guber_stage_submit_routed: the stage's requests (already filled, arrival order) belong to several engines — shard_of[i]
+        is request i's index in `engines`; ranks inside an engine's share follow the arrival order, as a pool's callers assign them"""
+        L = lib()
+        L.guber_stage_dest.argtypes = [C.c_void_p]
+        L.guber_stage_dest.restype = C.POINTER(C.c_uint32)
+        L.guber_stage_submit_routed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        n = self.b.n
+        shard_of = np.asarray(shard_of, np.uint32)[:n]
+        dest = np.ctypeslib.as_array(L.guber_stage_dest(self.h), shape=(self.max_n,))
+        counts = np.bincount(shard_of, minlength=len(engines)).astype(np.uint32)
+        order = np.argsort(shard_of, kind="stable")
+        start = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+        rank = np.empty(n, np.uint32)
+        rank[order] = (np.arange(n, dtype=np.int64) - start[shard_of[order]]).astype(np.uint32)
+        dest[:n] = (shard_of << 24) | rank
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        _check(L.guber_stage_submit_routed(self.h, arr, len(engines), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return counts
 
     def result(self):
         n = self.b.n

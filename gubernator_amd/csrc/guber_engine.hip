@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -126,6 +127,13 @@ struct guber_engine {
     hipEvent_t z_event = nullptr; uint32_t small_seq = 0; bool zero_copy = true, no_small = false;
     bool fuse = true; uint64_t fused_batches = 0;                 // guber_eval_batches_routed_dev: several engines per launch
     struct guber_stage* small_pending = nullptr;                  // a <= 256-request stage launched by guber_stages_submit whose outcome has not been looked at yet
+    // guber_stages_submit, stages of several engines in one pair of launches: ONE completion event per group (a ring, owned by the
+    // group's first engine; a slot is reused only after its previous use has completed, so "the slot has moved on" means
+    // "complete"), and the device copy of the launches' argument blocks when these do not fit the kernel-argument segment
+    struct GroupEv { hipEvent_t ev = nullptr; std::atomic<uint32_t> seq{0}; };
+    static constexpr uint32_t kGroupEvs = 16;
+    GroupEv gev[kGroupEvs]; uint32_t gev_next = 0;
+    DevBuf<uint8_t> d_margs;
     uint64_t small_batches = 0, small_fallbacks = 0;
     CohBuf<DevCounters> h_ctr; CohBuf<uint32_t> h_rb_seq; uint32_t rb_seq = 0;   // counter snapshot + its completion stamp
     DevCounters last_ctr{};
@@ -331,6 +339,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
     if (e->z_event) (void)hipEventDestroy(e->z_event);
+    for (auto& g : e->gev) if (g.ev) (void)hipEventDestroy(g.ev);
+    e->d_margs.release();
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -859,8 +869,16 @@ struct guber_stage {
     DevCounters* rb_ctr = nullptr; BlockCounters* rb_bctr = nullptr;     // this stage's own counter read-back after its batch ...
     DevCounters* rb0_ctr = nullptr; BlockCounters* rb0_bctr = nullptr;   // ... and before it: the difference is exactly this batch
     hipEvent_t ev = nullptr;
+    guber_engine::GroupEv* gev = nullptr; uint32_t gev_seq = 0;   // submitted as one of a group: the group's completion event (the slot's use)
+    MultiArgsMem* h_margs = nullptr;                               // argument blocks of a group this stage leads (device-visible host memory)
+    uint32_t* h_dest = nullptr;                                    // guber_stage_submit_routed: per request, engine index << 24 | rank in that engine's share
+    std::vector<guber_engine*> routed;                             // ... and the engines of the submission in flight (retries go back to them)
+    // a routed stage of <= 256 requests: one workgroup per engine in ONE launch (k_small_routed); every share has its own outcome
+    struct RoutedPart { guber_engine* e; uint32_t engine, n, seq; SmallOut* out; bool pending; int rc; };
+    std::vector<RoutedPart> parts; uint8_t* h_parts_out = nullptr;  // (mode 4; a part is only touched under its engine's mutex)
     uint32_t seq = 0, n = 0; int64_t now_ms = 0;
-    int mode = 0;                    // 0 idle, 1 small path complete, 2 pipeline in flight, 3 small path launched, outcome not looked at yet (guber_stages_submit)
+    int mode = 0;                    // 0 idle, 1 small path complete, 2 pipeline in flight, 3 small path launched, outcome not looked at yet (guber_stages_submit),
+                                     // 4 routed small path launched (guber_stage_submit_routed): outcomes per part
     bool no_agg = false;             // submitted without per-batch aggregates (guber_stages_submit)
     // Large batches: two DMA copies on a copy stream (the fixed-width columns present, the keys) bring the requests into the
     // stage's device mirror while the previous batches' kernels run; the pipeline then works on HBM and k_eval2 writes the
@@ -874,7 +892,8 @@ struct guber_stage {
 };
 
 static int resolve_small(guber_stage* s, bool block);
-static int resolve_small_locked(guber_stage* s, bool block);
+static int resolve_routed_small(guber_stage* s, bool block);
+static int resolve_small_locked(guber_stage* s, bool block, guber_engine* holder = nullptr);
 extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t key_bytes_cap, guber_stage_t** out) {
     if (!e || !out || max_n == 0) return fail(GUBER_E_INVALID_ARG, "null argument");
     *out = nullptr;
@@ -890,7 +909,7 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     const size_t in_fixed = col((n + 1) * 4) + 5 * col(n * 8) + col(n * 4) + 2 * col(n);
     const size_t in_bytes = col(in_fixed + (size_t)s->key_cap + 64);
     const size_t out_bytes = 3 * col(n * 8) + 2 * col(n);
-    const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters)));
+    const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters))) + col(sizeof(MultiArgsMem)) + col(n * 4) + 16 * 64;
     const size_t bytes = head + in_bytes + out_bytes + 256;
     if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess) {
@@ -903,6 +922,9 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     s->rb_bctr = (BlockCounters*)p; p += col((size_t)e->n_bctr * sizeof(BlockCounters));
     s->rb0_ctr = (DevCounters*)p; p += col(sizeof(DevCounters));
     s->rb0_bctr = (BlockCounters*)p; p += col((size_t)e->n_bctr * sizeof(BlockCounters));
+    s->h_margs = (MultiArgsMem*)p; p += col(sizeof(MultiArgsMem));
+    s->h_dest = (uint32_t*)p; p += col(n * 4);
+    s->h_parts_out = p;
     p = s->mem.p + head;
     s->h_in = p; s->h_out = p + in_bytes; s->in_fixed = in_fixed; s->out_bytes = out_bytes;
     guber_batch_t& b = s->batch; guber_result_t& r = s->result;
@@ -949,7 +971,7 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);            // the kernels read keys as 8-byte words
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    if (e->small_pending) { const int rcp = resolve_small_locked(e->small_pending, true); if (rcp < 0) return rcp; }
+    if (e->small_pending) { const int rcp = resolve_small_locked(e->small_pending, true, e); if (rcp < 0) return rcp; }
     BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                 b.greg_expire, b.greg_duration, b.now_ms};
     ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
@@ -1002,7 +1024,7 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, s->rb_ctr, s->rb_bctr, (uint32_t*)nullptr, 0u);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev, e->stream));
-    s->mode = 2;
+    s->gev = nullptr; s->mode = 2;
     return GUBER_OK;
 }
 
@@ -1016,15 +1038,25 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
         const int rc3 = resolve_small(s, true);
         if (rc3 < 0) return rc3;
     }
+    if (s->mode == 4) {                                      // a routed stage on the one-launch path: every share's outcome
+        const int rc4 = resolve_routed_small(s, true);
+        if (rc4 < 0) { s->mode = 0; s->routed.clear(); s->parts.clear(); return rc4; }
+    }
     bool general = s->mode == 2;
     if (s->mode == 1) {                                      // answered by the one-launch path, already complete (guber_stage_submit)
         s->mode = 0;
-        std::lock_guard<std::mutex> lk(e->mu);
-        r.over_limit_count = s->sout->over; r.cache_hits = s->sout->hits; r.cache_misses = s->sout->misses; r.cache_size = e->last_ctr.size;
-        return GUBER_OK;
+        if (s->parts.empty()) {
+            std::lock_guard<std::mutex> lk(e->mu);
+            r.over_limit_count = s->sout->over; r.cache_hits = s->sout->hits; r.cache_misses = s->sout->misses; r.cache_size = e->last_ctr.size;
+            return GUBER_OK;
+        }
+        s->parts.clear();                                    // (a routed stage: no aggregates; a re-run share may have left internal retries)
     }
     if (general) {
-        if (hipEventSynchronize(s->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");
+        if (s->gev) {
+            if (s->gev->seq.load(std::memory_order_acquire) == s->gev_seq && hipEventSynchronize(s->gev->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");
+            s->gev = nullptr;
+        } else if (hipEventSynchronize(s->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");
         s->mode = 0;
         std::lock_guard<std::mutex> lk(e->mu);
         if (s->no_agg) general = false;                       // no read-backs were taken: the aggregates stay 0 (guber_stats has the totals)
@@ -1043,26 +1075,34 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
     // two new keys sharing one 64-bit hash (or one claim fingerprint) inside the batch: re-submit those items on the host
     // path, which runs the careful rounds
     if (memchr(r.err, GUBER_ITEM_E_RETRY, s->n)) {
-        std::vector<uint32_t> again;
-        for (uint32_t i = 0; i < s->n; ++i) if (r.err[i] == GUBER_ITEM_E_RETRY) again.push_back(i);
-        std::lock_guard<std::mutex> lk(e->mu);
-        if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-        guber_batch_t hb = s->batch;
-        int rc0 = engine_refresh_counters(e);
-        if (rc0) return rc0;
-        const DevCounters t0 = e->last_ctr;
-        for (int round = 0; round < 64 && !again.empty(); ++round) {
-            e->careful = true;
-            const int rc = eval_host_once(e, &hb, &r, again.data(), (uint32_t)again.size(), nullptr);
-            e->careful = false;
-            if (rc) return rc;
-            std::vector<uint32_t> next;
-            for (uint32_t i : again) if (r.err[i] == GUBER_ITEM_E_RETRY) next.push_back(i);
-            again.swap(next);
+        std::vector<guber_engine*> engs = s->routed;
+        if (engs.empty()) engs.push_back(e);
+        for (size_t j = 0; j < engs.size(); ++j) {
+            guber_engine* ej = engs[j];
+            std::vector<uint32_t> again;
+            for (uint32_t i = 0; i < s->n; ++i)
+                if (r.err[i] == GUBER_ITEM_E_RETRY && (s->routed.empty() || (s->h_dest[i] >> 24) == j)) again.push_back(i);
+            if (again.empty()) continue;
+            std::lock_guard<std::mutex> lk(ej->mu);
+            if (ej->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+            guber_batch_t hb = s->batch;
+            int rc0 = engine_refresh_counters(ej);
+            if (rc0) return rc0;
+            const DevCounters t0 = ej->last_ctr;
+            for (int round = 0; round < 64 && !again.empty(); ++round) {
+                ej->careful = true;
+                const int rc = eval_host_once(ej, &hb, &r, again.data(), (uint32_t)again.size(), nullptr);
+                ej->careful = false;
+                if (rc) return rc;
+                std::vector<uint32_t> next;
+                for (uint32_t i : again) if (r.err[i] == GUBER_ITEM_E_RETRY) next.push_back(i);
+                again.swap(next);
+            }
+            r.over_limit_count += ej->last_ctr.over - t0.over; r.cache_hits += ej->last_ctr.hits - t0.hits; r.cache_misses += ej->last_ctr.misses - t0.misses;
+            r.cache_size = ej->last_ctr.size;
         }
-        r.over_limit_count += e->last_ctr.over - t0.over; r.cache_hits += e->last_ctr.hits - t0.hits; r.cache_misses += e->last_ctr.misses - t0.misses;
-        r.cache_size = e->last_ctr.size;
     }
+    s->routed.clear();
     return GUBER_OK;
 }
 
@@ -1070,8 +1110,37 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
 // A <= 256-request stage launched here is in mode 3 until somebody looks at its outcome (guber_stage_poll / guber_stage_wait,
 // or the next submission on its engine): the one-launch path may decline a batch (requests of one key that differ, a hash
 // collision), and then the general pipeline has to run it before anything later of the same engine.
-static int resolve_small_locked(guber_stage* s, bool block) {        // engine mutex held; 1 = resolved, 0 = still running
+// the shares of a routed small stage that belong to `holder` (its mutex held): outcome looked at, a declined share re-run through
+// the general pipeline — synchronously, on the host-pointer path, picking the share out of the stage by its ranks
+static int resolve_routed_parts_locked(guber_stage* s, guber_engine* holder, bool block) {
+    for (auto& part : s->parts) {
+        if (part.e != holder || !part.pending) continue;
+        volatile unsigned int* flag = &part.out->done;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != part.seq) {
+            if (!block) return 0;
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) { HIPCHK(hipStreamSynchronize(holder->stream)); break; }
+        }
+        part.pending = false;
+        if (holder->small_pending == s) holder->small_pending = nullptr;
+        if (!part.out->fallback) {
+            holder->last_ctr.over += part.out->over; holder->last_ctr.hits += part.out->hits; holder->last_ctr.misses += part.out->misses; holder->last_ctr.size += part.out->size_delta;
+            continue;
+        }
+        holder->small_fallbacks++;
+        if (holder->set_device()) return part.rc = fail(GUBER_E_HIP, "hipSetDevice");
+        std::vector<uint32_t> idx(part.n, 0);
+        for (uint32_t i = 0; i < s->n; ++i) if ((s->h_dest[i] >> 24) == part.engine && (s->h_dest[i] & 0xffffffu) < part.n) idx[s->h_dest[i] & 0xffffffu] = i;
+        guber_batch_t hb = s->batch;
+        part.rc = eval_host_once(holder, &hb, &s->result, idx.data(), part.n, nullptr);
+        if (part.rc) return part.rc;
+    }
+    return 1;
+}
+static int resolve_small_locked(guber_stage* s, bool block, guber_engine* holder) {   // engine mutex held; 1 = resolved, 0 = still running
     guber_engine* e = s->e;
+    if (s->mode == 4) return resolve_routed_parts_locked(s, holder ? holder : e, block);
     if (s->mode != 3) return 1;
     volatile unsigned int* flag = &s->sout->done;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1095,12 +1164,25 @@ static int resolve_small_locked(guber_stage* s, bool block) {        // engine m
     int rc = launch_batch(e, B, R, true);
     if (rc) { s->mode = 0; return rc; }
     HIPCHK(hipEventRecord(s->ev, e->stream));
-    s->mode = 2;
+    s->gev = nullptr; s->mode = 2;
     return 1;
 }
 static int resolve_small(guber_stage* s, bool block) {
     std::lock_guard<std::mutex> lk(s->e->mu);
     return resolve_small_locked(s, block);
+}
+// every share of a routed small stage (mode 4), each under its engine's mutex; all resolved: the stage is complete (mode 1)
+static int resolve_routed_small(guber_stage* s, bool block) {
+    for (size_t k = 0; k < s->parts.size(); ++k) {
+        guber_engine* e = s->parts[k].e;
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (s->parts[k].rc) return s->parts[k].rc;
+        if (!s->parts[k].pending) continue;
+        const int rc = resolve_routed_parts_locked(s, e, block);
+        if (rc <= 0) return rc;
+    }
+    s->mode = 1;
+    return 1;
 }
 
 extern "C" int guber_stage_poll(guber_stage_t* s) {
@@ -1109,8 +1191,13 @@ extern "C" int guber_stage_poll(guber_stage_t* s) {
         const int rc = resolve_small(s, false);
         if (rc <= 0) return rc;
     }
+    if (s->mode == 4) {
+        const int rc = resolve_routed_small(s, false);
+        if (rc <= 0) return rc;
+    }
     if (s->mode == 2) {
-        const hipError_t q = hipEventQuery(s->ev);
+        if (s->gev && s->gev->seq.load(std::memory_order_acquire) != s->gev_seq) return 1;   // the group's event slot has moved on: complete
+        const hipError_t q = hipEventQuery(s->gev ? s->gev->ev : s->ev);
         if (q == hipErrorNotReady) return 0;
         if (q != hipSuccess) return fail(GUBER_E_HIP, "hipEventQuery", q);
     }
@@ -1153,12 +1240,22 @@ static int stage_views(guber_stage* s, StagePlan& P) {
     return 0;
 }
 
-// one group: <= MULTI_MAX large stages of engines that share device and stream (engine mutexes held by the caller)
+// stages per group of launches (GUBER_STAGES_GROUP_MAX: 1 .. MULTI_MEM_MAX; the A/B knob of profiles/r03_*pool*)
+static int stages_group_max() {
+    static const int v = [] { const char* x = getenv("GUBER_STAGES_GROUP_MAX"); const int k = x ? atoi(x) : MULTI_MEM_MAX; return k < 1 ? 1 : (k > MULTI_MEM_MAX ? MULTI_MEM_MAX : k); }();
+    return v;
+}
+// one group: <= MULTI_MEM_MAX large stages of engines that share device and stream (engine mutexes held by the caller).  Up to
+// MULTI_MAX of them take the launches whose arguments travel by value; more (a pool dispatcher's generation over 8, 12 shards)
+// take the same launches with their argument blocks in device memory: written into the leading stage's host block here,
+// brought over by the copy kernel that also moves the request columns.  Three launches and one event record per group.
 static int launch_stage_group(StagePlan* P, int g) {
     guber_engine* e0 = P[0].s->e;
+    const bool mem_args = g > MULTI_MAX;
     MultiStageIn MI{}; MultiFront MF{}; MultiEval ME{};
+    MultiArgsMem* HA = P[0].s->h_margs;
     uint32_t tiles = 0; int planned = 0, rc = 0; bool any_copy = false;
-    FastPlan FP[MULTI_MAX];
+    FastPlan FP[MULTI_MEM_MAX];
     for (int i = 0; i < g; ++i) {
         guber_engine* e = P[i].s->e;
         Work W;
@@ -1166,17 +1263,35 @@ static int launch_stage_group(StagePlan* P, int g) {
         if (!rc) rc = plan_fast(e, P[i].B, !P[i].copy, W, FP[i]);
         if (rc) break;
         tiles += FP[i].ftiles;
-        MF.end_tile[planned] = ME.end_tile[planned] = tiles;
-        MF.sub[planned] = FrontArgs{e->T, FP[i].B2, FP[i].W};
-        ME.sub[planned] = EvalArgs{e->T, FP[i].B3, P[i].R, FP[i].W};
+        if (mem_args) {
+            HA->F.end_tile[planned] = HA->E.end_tile[planned] = tiles;
+            HA->F.sub[planned] = FrontArgs{e->T, FP[i].B2, FP[i].W};
+            HA->E.sub[planned] = EvalArgs{e->T, FP[i].B3, P[i].R, FP[i].W};
+        } else {
+            MF.end_tile[planned] = ME.end_tile[planned] = tiles;
+            MF.sub[planned] = FrontArgs{e->T, FP[i].B2, FP[i].W};
+            ME.sub[planned] = EvalArgs{e->T, FP[i].B3, P[i].R, FP[i].W};
+        }
         MI.sub[planned] = P[i].in;
         any_copy = any_copy || P[i].copy;
         ++planned;
     }
     if (!planned) return rc;
     hipStream_t st = e0->stream;
-    if (any_copy) {
-        MI.nb = (uint32_t)planned; MI.wg_per = 64;
+    MultiArgsMem* DA = nullptr;
+    MI.nb = (uint32_t)planned;
+    if (mem_args) {
+        if (e0->d_margs.ensure(sizeof(MultiArgsMem))) return GUBER_E_NOMEM;
+        DA = (MultiArgsMem*)e0->d_margs.p;
+        HA->F.nb = HA->E.nb = (uint32_t)planned;
+        StageIn& a = MI.sub[MI.nb++];                                // the argument blocks: one more segment list of the copy kernel
+        a = StageIn{};
+        a.src = (const uint4*)HA; a.dst = (uint4*)DA; a.nseg = 2;
+        a.off16[0] = 0; a.n16[0] = (uint32_t)((offsetof(MultiFrontMem, sub) + (size_t)planned * sizeof(FrontArgs) + 15) / 16);
+        a.off16[1] = (uint32_t)(offsetof(MultiArgsMem, E) / 16); a.n16[1] = (uint32_t)((offsetof(MultiEvalMem, sub) + (size_t)planned * sizeof(EvalArgs) + 15) / 16);
+    }
+    if (any_copy || mem_args) {
+        MI.wg_per = 64;
         hipLaunchKernelGGL(k_stage_in_multi, dim3(MI.nb * MI.wg_per), dim3(256), 0, st, MI);
     }
     uint64_t units = 0;
@@ -1188,6 +1303,13 @@ static int launch_stage_group(StagePlan* P, int g) {
         e0->span_begin(KT_EVAL2, units);
         hipLaunchKernelGGL(k_eval2, dim3(FP[0].ftiles), dim3(256), 0, st, EvalArgs{e0->T, FP[0].B3, P[0].R, FP[0].W});
         e0->span_end();
+    } else if (mem_args) {
+        e0->span_begin(KT_FRONT_MULTI, units);
+        hipLaunchKernelGGL(k_front_multi_mem, dim3(tiles), dim3(FT), 0, st, (const MultiFrontMem*)&DA->F);
+        e0->span_end();
+        e0->span_begin(KT_EVAL2_MULTI, units);
+        hipLaunchKernelGGL(k_eval2_multi_mem, dim3(tiles), dim3(256), 0, st, (const MultiEvalMem*)&DA->E);
+        e0->span_end();
     } else {
         MF.nb = ME.nb = (uint32_t)planned;
         e0->span_begin(KT_FRONT_MULTI, units);
@@ -1198,11 +1320,21 @@ static int launch_stage_group(StagePlan* P, int g) {
         e0->span_end();
     }
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    guber_engine::GroupEv* G = nullptr; uint32_t gseq = 0;
+    if (planned > 1) {
+        G = &e0->gev[e0->gev_next++ % guber_engine::kGroupEvs];
+        if (!G->ev) { if (hipEventCreateWithFlags(&G->ev, hipEventDisableTiming) != hipSuccess) return fail(GUBER_E_HIP, "hipEventCreate"); }
+        else if (hipEventSynchronize(G->ev) != hipSuccess) return fail(GUBER_E_HIP, "hipEventSynchronize");   // (kGroupEvs groups back: long complete)
+        gseq = G->seq.load(std::memory_order_relaxed) + 1;
+        if (hipEventRecord(G->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
+        G->seq.store(gseq, std::memory_order_release);
+    }
     for (int i = 0; i < planned; ++i) {
         guber_stage* s = P[i].s;
         finish_fast(s->e, P[i].B.n);
         if (planned > 1) s->e->fused_batches++;
-        if (hipEventRecord(s->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
+        s->gev = G; s->gev_seq = gseq;
+        if (!G && hipEventRecord(s->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
         s->mode = 2;
     }
     return rc;
@@ -1228,10 +1360,11 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         for (uint32_t q = 0; q < k; ++q) if (stages[q]->e == s->e) return fail(GUBER_E_INVALID_ARG, "two stages of one engine in one submission");
     }
     uint32_t enq = 0;
-    StagePlan grp[MULTI_MAX]; int g = 0;
+    StagePlan grp[MULTI_MEM_MAX]; int g = 0;
+    const int group_max = (flags & GUBER_STAGES_NO_AGGREGATES) ? stages_group_max() : MULTI_MAX;
     auto flush = [&]() -> int {
         if (!g) return 0;
-        guber_engine* order[MULTI_MAX];
+        guber_engine* order[MULTI_MEM_MAX];
         for (int i = 0; i < g; ++i) order[i] = grp[i].s->e;
         std::sort(order, order + g);                               // engine locks in address order (launch_group's rule)
         for (int i = 0; i < g; ++i) order[i]->mu.lock();
@@ -1239,7 +1372,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         if (grp[0].s->e->set_device()) rc = fail(GUBER_E_HIP, "hipSetDevice");
         for (int i = 0; i < g && !rc; ++i) {
             guber_engine* e = grp[i].s->e;
-            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) rc = r2; }
+            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true, e); if (r2 < 0) rc = r2; }
             if (!rc) rc = stage_views(grp[i].s, grp[i]);
         }
         if (!rc) rc = launch_stage_group(grp, g);
@@ -1262,7 +1395,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         if (e0->set_device()) rc = fail(GUBER_E_HIP, "hipSetDevice");
         for (int i = 0; i < sg && !rc; ++i) {
             guber_stage* s = sgrp[i]; guber_engine* e = s->e;
-            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) { rc = r2; break; } }
+            if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true, e); if (r2 < 0) { rc = r2; break; } }
             const guber_batch_t& b = s->batch;
             BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                         b.greg_expire, b.greg_duration, b.now_ms};
@@ -1302,12 +1435,12 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
             sgrp[sg++] = s;
             continue;
         }
-        if (g && (!fusable || g == MULTI_MAX || e->stream != grp[0].s->e->stream || e->device != grp[0].s->e->device)) rc = flush();
+        if (g && (!fusable || g == group_max || e->stream != grp[0].s->e->stream || e->device != grp[0].s->e->device)) rc = flush();
         if (rc) break;
         if (fusable) { grp[g++].s = s; continue; }
         std::lock_guard<std::mutex> lk(e->mu);
         if (e->set_device()) { rc = fail(GUBER_E_HIP, "hipSetDevice"); break; }
-        if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true); if (r2 < 0) { rc = r2; break; } }
+        if (e->small_pending) { const int r2 = resolve_small_locked(e->small_pending, true, e); if (r2 < 0) { rc = r2; break; } }
         BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                     b.greg_expire, b.greg_duration, b.now_ms};
         ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
@@ -1315,7 +1448,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         rc = launch_batch(e, B, R, true);
         if (rc) break;
         if (hipEventRecord(s->ev, e->stream) != hipSuccess) { rc = fail(GUBER_E_HIP, "hipEventRecord"); break; }
-        s->mode = 2;
+        s->gev = nullptr; s->mode = 2;
         ++enq;
     }
     if (!rc) rc = flush();
@@ -1327,6 +1460,142 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
     }
     (void)enq;
     return rc;
+}
+
+// ---- ONE stage for several engines: the device-level stage of a pool.  Callers fill it in arrival order and say, per request,
+// which engine it belongs to and which place it has in that engine's share (guber_stage_dest); the copy kernel scatters the
+// request columns into HBM so that every share is contiguous (k_stage_in_routed), the shares then run as the batches of ONE
+// k_front_multi_mem + ONE k_eval2_multi_mem, and a last launch takes the answers back to the callers' slots.  Four launches
+// and one event for a whole generation, whatever the number of shards; nothing on the host is proportional to the requests.
+extern "C" uint32_t* guber_stage_dest(guber_stage_t* s) { return s ? s->h_dest : nullptr; }
+extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts) {
+    if (!s || !engines || !counts) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (n_engines == 0 || n_engines > (uint32_t)MULTI_MEM_MAX) return fail(GUBER_E_INVALID_ARG, "1 .. 16 engines per routed stage");
+    if (s->mode) return fail(GUBER_E_INVALID_ARG, "stage already in flight");
+    const guber_batch_t& b = s->batch;
+    s->n = b.n; s->now_ms = b.now_ms; s->no_agg = true; s->routed.clear();
+    if (b.n > s->max_n || (b.n && b.key_off[b.n] > s->key_cap)) return fail(GUBER_E_BATCH_TOO_LARGE, "stage overfilled");
+    if (b.greg_expire || b.greg_duration) return fail(GUBER_E_INVALID_ARG, "a routed stage takes its calendar intervals from the device");
+    if (!b.burst || !b.created_at || !b.behavior || !b.algorithm || !b.is_owner) return fail(GUBER_E_INVALID_ARG, "a routed stage carries every request column");
+    uint64_t total = 0; bool own = false;
+    for (uint32_t j = 0; j < n_engines; ++j) {
+        guber_engine* e = engines[j];
+        if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+        if (e->device != s->e->device || e->stream != s->e->stream) return fail(GUBER_E_INVALID_ARG, "the engines of a routed stage share device and stream");
+        for (uint32_t q = 0; q < j; ++q) if (engines[q] == e) return fail(GUBER_E_INVALID_ARG, "an engine twice in one routed stage");
+        if (counts[j] && !can_fuse(e, counts[j])) return fail(GUBER_E_BATCH_TOO_LARGE, "an engine's share is larger than its two-launch pipeline takes");
+        own = own || e == s->e;
+        total += counts[j];
+    }
+    if (!own) return fail(GUBER_E_INVALID_ARG, "the stage's own engine is one of the engines");
+    if (total != b.n) return fail(GUBER_E_INVALID_ARG, "the shares do not add up to the batch");
+    if (b.n == 0) { s->mode = 0; return GUBER_OK; }
+    memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);            // the kernels read keys as 8-byte words
+    guber_engine* order[MULTI_MEM_MAX];
+    for (uint32_t j = 0; j < n_engines; ++j) order[j] = engines[j];
+    std::sort(order, order + n_engines);                             // engine locks in address order (launch_group's rule)
+    for (uint32_t j = 0; j < n_engines; ++j) order[j]->mu.lock();
+    struct Unlock { guber_engine** o; uint32_t n; ~Unlock() { for (uint32_t j = n; j-- > 0;) o[j]->mu.unlock(); } } unlock{order, n_engines};
+    guber_engine* e0 = s->e;
+    if (e0->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    for (uint32_t j = 0; j < n_engines; ++j)
+        if (engines[j]->small_pending) { const int r2 = resolve_small_locked(engines[j]->small_pending, true, engines[j]); if (r2 < 0) return r2; }
+    if (b.n <= FT) {                                                 // a handful of requests: ONE launch, a workgroup per share, in place
+        bool small_ok = true;
+        for (uint32_t j = 0; j < n_engines; ++j) small_ok = small_ok && !engines[j]->no_small;
+        if (small_ok) {
+            MultiSmallRouted MS{};
+            s->parts.clear();
+            BatchView BH{0, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner, nullptr, nullptr, b.now_ms};
+            for (uint32_t j = 0; j < n_engines; ++j) {
+                if (!counts[j]) continue;
+                guber_engine* e = engines[j];
+                BatchView Bj = BH; Bj.n = counts[j];
+                const int rc = small_prelude(e, Bj);
+                if (rc) { s->parts.clear(); return rc; }             // (nothing has been launched; the stage stays idle)
+                const uint32_t seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
+                SmallOut* out = (SmallOut*)(s->h_parts_out + 64 * s->parts.size());
+                out->done = 0;
+                MS.sub[s->parts.size()] = SmallRoutedSub{e->T, out, seq, e->touch, counts[j], j};
+                s->parts.push_back(guber_stage::RoutedPart{e, j, counts[j], seq, out, true, 0});
+            }
+            MS.nb = (uint32_t)s->parts.size(); MS.n_total = b.n; MS.dest = s->h_dest; MS.B = BH;
+            MS.R = ResultView{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
+            hipLaunchKernelGGL(k_small_routed, dim3(MS.nb), dim3(FT), 0, e0->stream, MS);
+            if (hipGetLastError() != hipSuccess) { s->parts.clear(); return fail(GUBER_E_HIP, "kernel launch"); }
+            for (auto& part : s->parts) part.e->small_pending = s;
+            s->routed.assign(engines, engines + n_engines);
+            s->gev = nullptr; s->mode = 4;
+            return GUBER_OK;
+        }
+    }
+    // the HBM mirror: every fixed-width column for max_n requests (each 64-byte aligned), where the request came from, the keys
+    const size_t n = b.n, cap = s->max_n;
+    auto col = [](size_t bytes) { return (bytes + 63) & ~(size_t)63; };
+    const size_t fixed = 3 * col(cap * 4 + 4) + 5 * col(cap * 8) + col(cap * 4) + 2 * col(cap) + 3 * col(cap * 8) + 2 * col(cap);
+    if (s->dmem.ensure(fixed + col((size_t)s->key_cap + 64)) || e0->d_margs.ensure(sizeof(MultiArgsMem))) return GUBER_E_NOMEM;
+    uint8_t* p = s->dmem.p;
+    RoutedIn A{};
+    A.d_key_off = (uint32_t*)p; p += col(cap * 4 + 4); A.d_key_len = (uint32_t*)p; p += col(cap * 4 + 4); A.d_fwd = (uint32_t*)p; p += col(cap * 4 + 4);
+    A.d_hits = (int64_t*)p; p += col(cap * 8); A.d_limit = (int64_t*)p; p += col(cap * 8); A.d_duration = (int64_t*)p; p += col(cap * 8);
+    A.d_burst = (int64_t*)p; p += col(cap * 8); A.d_created_at = (int64_t*)p; p += col(cap * 8);
+    A.d_behavior = (uint32_t*)p; p += col(cap * 4); A.d_algorithm = p; p += col(cap); A.d_is_owner = p; p += col(cap);
+    RoutedOut O{};                                                   // the answers: HBM in the shares' order, then home in arrival order
+    O.n = (uint32_t)n; O.fwd = A.d_fwd;
+    int64_t* o_limit = (int64_t*)p; p += col(cap * 8); int64_t* o_remaining = (int64_t*)p; p += col(cap * 8); int64_t* o_reset = (int64_t*)p; p += col(cap * 8);
+    uint8_t* o_status = p; p += col(cap); uint8_t* o_err = p; p += col(cap);
+    O.d_status = o_status; O.d_err = o_err; O.d_limit = o_limit; O.d_remaining = o_remaining; O.d_reset_time = o_reset;
+    O.status = s->result.status; O.err = s->result.err; O.limit = s->result.limit; O.remaining = s->result.remaining; O.reset_time = s->result.reset_time;
+    uint8_t* d_keys = p;
+    A.n = (uint32_t)n; A.dest = s->h_dest;
+    A.key_off = b.key_off; A.hits = b.hits; A.limit = b.limit; A.duration = b.duration; A.burst = b.burst; A.created_at = b.created_at;
+    A.behavior = b.behavior; A.algorithm = b.algorithm; A.is_owner = b.is_owner;
+    A.key_src = (const uint4*)b.key_bytes; A.key_dst = (uint4*)d_keys; A.key_n16 = (uint32_t)(((size_t)b.key_off[b.n] + 16 + 15) / 16);
+    MultiArgsMem* HA = s->h_margs; MultiArgsMem* DA = (MultiArgsMem*)e0->d_margs.p;
+    uint32_t tiles = 0, base = 0; int planned = 0;
+    guber_engine* took[MULTI_MEM_MAX]; uint32_t took_n[MULTI_MEM_MAX];
+    for (uint32_t j = 0; j < n_engines; ++j) {
+        A.base[j] = base;
+        const uint32_t nj = counts[j];
+        if (!nj) continue;
+        guber_engine* e = engines[j];
+        BatchView B{nj, 0, d_keys, A.d_key_off + base, A.d_hits + base, A.d_limit + base, A.d_duration + base, A.d_burst + base, A.d_created_at + base,
+                    A.d_algorithm + base, A.d_behavior + base, A.d_is_owner + base, nullptr, nullptr, b.now_ms, 0, A.d_key_len + base};
+        ResultView R{o_status + base, o_limit + base, o_remaining + base, o_reset + base, o_err + base};
+        Work W; FastPlan FP;
+        int rc = batch_prelude(e, B, W);
+        if (!rc) rc = plan_fast(e, B, false, W, FP);
+        if (rc) return rc;                                           // (nothing has been launched; the stage stays idle)
+        tiles += FP.ftiles;
+        HA->F.end_tile[planned] = HA->E.end_tile[planned] = tiles;
+        HA->F.sub[planned] = FrontArgs{e->T, FP.B2, FP.W};
+        HA->E.sub[planned] = EvalArgs{e->T, FP.B3, R, FP.W};
+        took[planned] = e; took_n[planned] = nj;
+        ++planned;
+        base += nj;
+    }
+    HA->F.nb = HA->E.nb = (uint32_t)planned;
+    A.arg_src = (const uint4*)HA; A.arg_dst = (uint4*)DA;
+    A.arg_off16[0] = 0; A.arg_n16[0] = (uint32_t)((offsetof(MultiFrontMem, sub) + (size_t)planned * sizeof(FrontArgs) + 15) / 16);
+    A.arg_off16[1] = (uint32_t)(offsetof(MultiArgsMem, E) / 16); A.arg_n16[1] = (uint32_t)((offsetof(MultiEvalMem, sub) + (size_t)planned * sizeof(EvalArgs) + 15) / 16);
+    A.nb_req = (uint32_t)((n + 255) / 256);
+    A.nb_key = std::max<uint32_t>(1u, std::min<uint32_t>(256u, (A.key_n16 + 1023) / 1024));
+    A.nb_arg = 4;
+    hipStream_t st = e0->stream;
+    hipLaunchKernelGGL(k_stage_in_routed, dim3(A.nb_req + A.nb_key + A.nb_arg), dim3(256), 0, st, A);
+    e0->span_begin(KT_FRONT_MULTI, n);
+    hipLaunchKernelGGL(k_front_multi_mem, dim3(tiles), dim3(FT), 0, st, (const MultiFrontMem*)&DA->F);
+    e0->span_end();
+    e0->span_begin(KT_EVAL2_MULTI, n);
+    hipLaunchKernelGGL(k_eval2_multi_mem, dim3(tiles), dim3(256), 0, st, (const MultiEvalMem*)&DA->E);
+    e0->span_end();
+    hipLaunchKernelGGL(k_stage_out_routed, dim3(A.nb_req), dim3(256), 0, st, O);
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    for (int i = 0; i < planned; ++i) { finish_fast(took[i], took_n[i]); if (planned > 1) took[i]->fused_batches++; }
+    if (hipEventRecord(s->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
+    s->routed.assign(engines, engines + n_engines);
+    s->gev = nullptr; s->mode = 2;
+    return GUBER_OK;
 }
 
 extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) { return eval_batch_host(e, b, r, nullptr); }

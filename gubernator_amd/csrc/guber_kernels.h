@@ -226,7 +226,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
         uint64_t kw[4] = {0, 0, 0, 0};
         uint32_t off_g = 0, len_g = 0;
         bool spec = false;
-        if (!B.key_stride && !W.careful && B.n >= 2) {
+        if (!B.key_stride && !B.key_len && !W.careful && B.n >= 2) {
             const uint32_t o0 = B.key_off[0], o1 = B.key_off[1], oend = B.key_off[B.n];
             len_g = o1 - o0; off_g = o0 + g * len_g;
             if (len_g != 0 && len_g < 32 && (uint64_t)off_g + 32 <= (uint64_t)oend + 8) {   // (the buffer is padded by 8 bytes)
@@ -724,6 +724,36 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi(MultiEva
         if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
     const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
     eval2_body(*a, blockIdx.x - first, A.end_tile[sb] - first);
+}
+
+
+// The same two launches for up to MULTI_MEM_MAX batches (a pool dispatcher's whole generation: every shard of a device plus its
+// GLOBAL engine): the argument blocks do not fit the 4 KB kernel-argument segment, so they live in device memory — the copy
+// kernel that brings the stages' request columns into HBM brings them along (guber_engine.hip launch_stage_group) — and are
+// read like kernel arguments: uniform loads from the constant address space (scalar loads, nothing held in vector registers).
+constexpr int MULTI_MEM_MAX = 16;
+struct MultiFrontMem { uint32_t nb; uint32_t end_tile[MULTI_MEM_MAX]; uint32_t pad_[15]; FrontArgs sub[MULTI_MEM_MAX]; };
+struct MultiEvalMem { uint32_t nb; uint32_t end_tile[MULTI_MEM_MAX]; uint32_t pad_[15]; EvalArgs sub[MULTI_MEM_MAX]; };
+struct MultiArgsMem { MultiFrontMem F; MultiEvalMem E; };
+typedef const __attribute__((address_space(4))) char* const_mem_t;
+__device__ __forceinline__ uint32_t multi_mem_batch(const uint32_t* end_tile, uint32_t nb, uint32_t wg, uint32_t& first) {
+    uint32_t sb = 0; first = 0;
+    for (uint32_t k = 0; k + 1 < nb; ++k)
+        if (wg >= end_tile[k]) { first = end_tile[k]; sb = k + 1; }
+    return sb;
+}
+__global__ __launch_bounds__(FT) void k_front_multi_mem(const MultiFrontMem* Ag) {
+    const MultiFrontMem* A = (const MultiFrontMem*)(const_mem_t)(uintptr_t)Ag;
+    uint32_t first;
+    const uint32_t sb = multi_mem_batch(A->end_tile, A->nb, blockIdx.x, first);
+    const FrontArgs* a = A->sub + sb;
+    front_body(a->T, a->B, a->W, blockIdx.x - first);
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi_mem(const MultiEvalMem* Ag) {
+    const MultiEvalMem* A = (const MultiEvalMem*)(const_mem_t)(uintptr_t)Ag;
+    uint32_t first;
+    const uint32_t sb = multi_mem_batch(A->end_tile, A->nb, blockIdx.x, first);
+    eval2_body(A->sub[sb], blockIdx.x - first, A->end_tile[sb] - first);
 }
 
 }  // namespace guber

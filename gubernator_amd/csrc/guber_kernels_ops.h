@@ -341,13 +341,13 @@ __global__ void k_ctr_snapshot(const DevCounters* ctr, const BlockCounters* bctr
     }
 }
 
-// Request columns of up to MULTI_MAX stages: device-visible host memory -> each stage's HBM mirror (same layout), ONE launch on the
+// Request columns of up to MULTI_MEM_MAX stages (+ one more segment list: the fused launches' argument blocks, guber_kernels.h): device-visible host memory -> each stage's HBM mirror (same layout), ONE launch on the
 // stream the batches' kernels follow on (the pool's dispatcher: a hipMemcpyAsync costs 40-60 us of host time, a launch 4-5).
 // Only what the batch uses is moved: per column the first n entries (a stage's columns are laid out for max_n requests), then
 // the key bytes.  16-byte loads over PCIe, fully coalesced; every column starts on a 64-byte boundary.
 constexpr int STAGE_SEGS = 10;
 struct StageIn { const uint4* src; uint4* dst; uint32_t nseg; uint32_t off16[STAGE_SEGS], n16[STAGE_SEGS]; };
-struct MultiStageIn { uint32_t nb, wg_per; StageIn sub[MULTI_MAX]; };
+struct MultiStageIn { uint32_t nb, wg_per; StageIn sub[MULTI_MEM_MAX + 1]; };
 static_assert(sizeof(MultiStageIn) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(256) void k_stage_in_multi(MultiStageIn A) {
     const uint32_t sb = blockIdx.x / A.wg_per, w = blockIdx.x - sb * A.wg_per;
@@ -358,6 +358,66 @@ __global__ __launch_bounds__(256) void k_stage_in_multi(MultiStageIn A) {
         const uint32_t n16 = s->n16[k];
         for (uint32_t i = w * 256u + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
     }
+}
+
+
+// A stage whose requests belong to SEVERAL engines (guber_stage_submit_routed: the device-level stage of a pool, filled by the
+// callers in arrival order): request i carries dest[i] = engine index << 24 | its rank inside that engine's share, the host
+// knows the shares' sizes, so request i's place in HBM is base[engine] + rank — every engine's share ends up contiguous, in
+// the order of the ranks, and the two-launch pipeline runs on it as on any batch.  ONE launch, three kinds of workgroups:
+// [0, nb_req) scatter the fixed-width columns (coalesced reads over PCIe, 4/8-byte writes to HBM) and record where each
+// request went (fwd: where its answer will be); [nb_req, nb_req + nb_key) copy the key bytes as they are (keys stay in
+// arrival order: the requests carry offset + length); the rest copy the argument blocks of the launches that follow.
+// The answers take the way back in a launch of their own (k_stage_out_routed): k_eval2 writes them to HBM next to the shares,
+// and they reach the stage's host arrays in arrival order as full, coalesced lines (answers written from the shares' order
+// straight over PCIe would be one small transaction each: measured 4x the batch's time on the device).
+struct RoutedIn {
+    uint32_t n, nb_req, nb_key, nb_arg;
+    const uint32_t* dest; uint32_t base[MULTI_MEM_MAX];
+    const uint32_t* key_off; const int64_t *hits, *limit, *duration, *burst, *created_at; const uint32_t* behavior; const uint8_t *algorithm, *is_owner;   // stage (host)
+    uint32_t *d_key_off, *d_key_len, *d_fwd; int64_t *d_hits, *d_limit, *d_duration, *d_burst, *d_created_at; uint32_t* d_behavior; uint8_t *d_algorithm, *d_is_owner;   // HBM
+    const uint4* key_src; uint4* key_dst; uint32_t key_n16;
+    const uint4* arg_src; uint4* arg_dst; uint32_t arg_off16[2], arg_n16[2];
+};
+static_assert(sizeof(RoutedIn) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256) void k_stage_in_routed(RoutedIn A) {
+    const uint32_t b = blockIdx.x;
+    if (b < A.nb_req) {
+        const uint32_t i = b * 256u + threadIdx.x;
+        if (i >= A.n) return;
+        const uint32_t dv = A.dest[i], o0 = A.key_off[i], o1 = A.key_off[i + 1];
+        const int64_t hits = A.hits[i], limit = A.limit[i], duration = A.duration[i], burst = A.burst[i], created = A.created_at[i];
+        const uint32_t beh = A.behavior[i]; const uint8_t algo = A.algorithm[i], owner = A.is_owner[i];
+        const uint32_t d = A.base[(dv >> 24) & (MULTI_MEM_MAX - 1)] + (dv & 0xffffffu);
+        A.d_fwd[i] = d < A.n ? d : 0u;
+        if (d >= A.n) return;                                        // (ranks that are no permutation: nothing is written out of bounds)
+        A.d_key_off[d] = o0; A.d_key_len[d] = o1 - o0;
+        A.d_hits[d] = hits; A.d_limit[d] = limit; A.d_duration[d] = duration; A.d_burst[d] = burst; A.d_created_at[d] = created;
+        A.d_behavior[d] = beh; A.d_algorithm[d] = algo; A.d_is_owner[d] = owner;
+    } else if (b < A.nb_req + A.nb_key) {
+        const uint32_t stride = A.nb_key * 256u;
+        for (uint32_t i = (b - A.nb_req) * 256u + threadIdx.x; i < A.key_n16; i += stride) A.key_dst[i] = A.key_src[i];
+    } else {
+        const uint32_t stride = A.nb_arg * 256u;
+        for (uint32_t k = 0; k < 2; ++k) {
+            const uint4* src = A.arg_src + A.arg_off16[k]; uint4* dst = A.arg_dst + A.arg_off16[k];
+            for (uint32_t i = (b - A.nb_req - A.nb_key) * 256u + threadIdx.x; i < A.arg_n16[k]; i += stride) dst[i] = src[i];
+        }
+    }
+}
+
+struct RoutedOut {
+    uint32_t n; const uint32_t* fwd;
+    const uint8_t *d_status, *d_err; const int64_t *d_limit, *d_remaining, *d_reset_time;      // HBM, in the shares' order
+    uint8_t *status, *err; int64_t *limit, *remaining, *reset_time;                           // the stage's result arrays (host), arrival order
+};
+__global__ __launch_bounds__(256) void k_stage_out_routed(RoutedOut A) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= A.n) return;
+    const uint32_t d = A.fwd[i];
+    const uint8_t st = A.d_status[d], er = A.d_err[d];
+    const int64_t l = A.d_limit[d], r = A.d_remaining[d], t = A.d_reset_time[d];
+    A.limit[i] = l; A.remaining[i] = r; A.reset_time[i] = t; A.status[i] = st; A.err[i] = er;
 }
 
 }  // namespace guber

@@ -28,7 +28,10 @@ struct SmallReqs {
     unsigned long long misc[FT];          // behavior | algorithm << 32 | is_owner << 40
 };
 
-__device__ __forceinline__ void small_body(const Table& T, const BatchView& B, const ResultView& R, SmallOut* out, const uint32_t seq, const uint32_t touch) {
+// map (LDS, or nullptr): request tid of this workgroup's batch is entry map[tid] of the arrays B and R point at — a share of a
+// routed stage, picked out of the stage's arrival order (k_small_routed)
+__device__ __forceinline__ void small_body(const Table& T, const BatchView& B, const ResultView& R, SmallOut* out, const uint32_t seq, const uint32_t touch,
+                                           const uint32_t* map = nullptr) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
     __shared__ unsigned long long gkey[GT];
     __shared__ unsigned long long gbits[FT / 64][GT];
@@ -39,6 +42,7 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
     __shared__ unsigned long long cnt[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool valid = tid < B.n;
+    const uint32_t at = (map && valid) ? map[tid] : tid;              // where this request's columns and its answer live
     if (tid == 0) { bail = 0u; ins_n = 0u; }
     if (tid < 4) cnt[tid] = 0ull;
     for (uint32_t j = tid; j < GT; j += FT) {
@@ -52,9 +56,9 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
     uint64_t h = 0;
     Req r;
     if (valid) {
-        r = load_req(B, tid);
-        off = key_off_of(B, tid);
-        len = key_len_of(B, tid, off);
+        r = load_req(B, at);
+        off = key_off_of(B, at);
+        len = key_len_of(B, at, off);
         key = B.key_bytes + off;
         if (len == 0) errcode = IE_EMPTY_KEY;
         else if (len > T.max_key) errcode = 7;
@@ -180,7 +184,7 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
     if (valid) {
         if (gk) { errcode = serr[head_tid]; slot = sslot[head_tid]; }
         if (errcode) {
-            store_err(R, tid, (uint8_t)errcode);
+            store_err(R, at, (uint8_t)errcode);
         } else {
             const Rec s0 = srec[head_tid];
             Rec after; Resp o;
@@ -189,7 +193,7 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
             if (token_fast_ok(s0, r, B.now_ms)) { ev = token_fast(s0, r, rank, o, after); done = true; }
             else if (leaky_fast(s0, r, B.now_ms, rank, o, after, ev)) done = true;
             if (!done) ev = eval_uniform_rank_1x(s0, r, B.now_ms, rank, o, after);
-            store_resp(R, tid, o);
+            store_resp(R, at, o);
             c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             if (rank == total - 1) {
                 after.pad = touch;
@@ -229,6 +233,27 @@ static_assert(sizeof(MultiSmall) <= 4096, "kernel arguments are limited to 4 KB"
 __global__ __launch_bounds__(FT) void k_small_multi(MultiSmall A) {
     const SmallArgs* a = (const SmallArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiSmall, sub)) + blockIdx.x;
     small_body(a->T, a->B, a->R, a->out, a->seq, a->touch);
+}
+
+// The one-launch path for a routed stage of at most one tile (guber_stage_submit_routed: a handful of requests spread over the
+// shards of a GPU — a lightly loaded pool): one workgroup per engine that has a share; it picks its requests out of the stage's
+// arrival order by the dest column (engine << 24 | rank: the rank is the request's place in the workgroup), then runs the
+// one-launch body on them in place.  Every share reports its own outcome (SmallOut): a share the fast path declines is re-run by
+// the host through the general pipeline, the others stand.
+struct SmallRoutedSub { Table T; SmallOut* out; uint32_t seq, touch, n, engine; };
+struct MultiSmallRouted { uint32_t nb, n_total; const uint32_t* dest; BatchView B; ResultView R; SmallRoutedSub sub[16]; };
+static_assert(sizeof(MultiSmallRouted) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(FT) void k_small_routed(MultiSmallRouted A) {
+    __shared__ uint32_t map[FT];
+    const SmallRoutedSub* a = (const SmallRoutedSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiSmallRouted, sub)) + blockIdx.x;
+    if (threadIdx.x < A.n_total) {
+        const uint32_t dv = A.dest[threadIdx.x];
+        if ((dv >> 24) == a->engine) map[dv & (FT - 1)] = threadIdx.x;
+    }
+    __syncthreads();
+    BatchView B = A.B;
+    B.n = a->n;
+    small_body(a->T, B, A.R, a->out, a->seq, a->touch, map);
 }
 
 }  // namespace guber

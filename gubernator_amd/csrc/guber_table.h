@@ -65,7 +65,8 @@ struct BatchView {
     const int64_t *greg_expire, *greg_duration;
     int64_t now_ms;
     // keys as rows of a matrix instead of a packed buffer (the GLOBAL exchange evaluates received rows in place):
-    // key i = key_bytes + i * key_stride, key_len[i] bytes.  0 = packed, key_off[] applies.
+    // key i = key_bytes + i * key_stride, key_len[i] bytes.  0 = packed, key_off[] applies — with key_len[] as well when the
+    // requests are not in the order of their keys (a stage routed to several engines: guber_stage_submit_routed).
     uint32_t key_stride; const uint32_t* key_len;
 };
 struct ResultView { uint8_t* status; int64_t *limit, *remaining, *reset_time; uint8_t* err; };
@@ -177,7 +178,7 @@ __device__ __forceinline__ uint64_t tail_mask(uint32_t nbytes) {  // nbytes in 1
 
 __device__ __forceinline__ uint32_t key_off_of(const BatchView& B, uint32_t i) { return B.key_stride ? i * B.key_stride : B.key_off[i]; }
 __device__ __forceinline__ uint32_t key_len_of(const BatchView& B, uint32_t i, uint32_t off) {
-    return B.key_stride ? B.key_len[i] : B.key_off[i + 1] - off;
+    return (B.key_stride || B.key_len) ? B.key_len[i] : B.key_off[i + 1] - off;
 }
 __device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
     Req r;

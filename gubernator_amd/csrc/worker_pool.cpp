@@ -82,17 +82,29 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
         create_rc_ = guber_ring_create(ptrs.data(), n_devices_, 512, 0, &ring_);
         if (create_rc_ != GUBER_OK) return;
     }
+    // Several shards per device: the callers of a device share ONE set of stages (its front) and tag every request with its
+    // shard and its place in that shard's share; the copy kernel that brings a batch to HBM hands the requests to the shards
+    // (guber_stage_submit_routed).  What a caller pays per RPC — one compare-and-swap, contiguous writes, one sleep — then
+    // does not grow with the number of shards.  GUBER_POOL_ROUTED=0: every shard has stages of its own and the callers sort
+    // their requests by shard (the arrangement this replaced; also what a build without the routed entry point would do).
+    routed_ = env_u32("GUBER_POOL_ROUTED", 1) != 0 && shards_per_device_ >= 2 && shards_per_device_ <= kMaxEngines;
+    stage_cap_ = routed_ ? (uint32_t)std::min<uint64_t>((uint64_t)batch_limit_ * shards, 65536) : batch_limit_;
+    if (routed_ && batch_limit_ > 65536) { routed_ = false; stage_cap_ = batch_limit_; }     // (a share may be the whole stage: the two-launch pipeline takes 65 536)
+    // a second generation behind the one in flight: per-shard stages pay a set of launches per group of four shards, so it waits
+    // until it is worth them; a front stage pays ONE launch for a handful of requests (k_small_routed) and four beyond
+    if (!getenv("GUBER_POOL_EAGER_MIN")) eager_min_ = routed_ ? 16 : 4096;
     guber_config_t c = cfg;
-    if (c.max_batch < batch_limit_) c.max_batch = batch_limit_;
+    if (c.max_batch < stage_cap_) c.max_batch = stage_cap_;
     const uint32_t total = n_devices_ * shards;
     const uint64_t per_shard = total > 1 ? cfg.cache_size / total + 1 : cfg.cache_size;   // workers.go:132 `CacheSize / Workers` per worker
     max_key_ = c.max_key_bytes ? c.max_key_bytes : 1024;
     // room for batch_limit keys of typical size; a batch whose keys do not fit is flushed early (never overrun)
-    key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)batch_limit_ * std::min<uint32_t>(max_key_, 96u) + max_key_, (1u << 24) - 1);
+    key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)stage_cap_ * std::min<uint32_t>(max_key_, 96u) + max_key_, (1u << 24) - 1);
     // the shards of a device are spread over a few streams; shards that share one share their launches (guber_stages_submit)
     uint32_t n_streams = env_u32("GUBER_POOL_STREAMS", 0);
     if (n_streams == 0) n_streams = (shards + 3) / 4;                // a fused launch carries the batches of up to four shards
     n_streams = std::max(1u, std::min(n_streams, shards));
+    if (routed_) n_streams = 1;                                      // (the shares of a front stage travel in one pair of launches)
     for (uint32_t d = 0; d < n_devices_ && create_rc_ == GUBER_OK; ++d) {
         std::unique_ptr<Device> dev(new Device());
         dev->index = d; dev->ordinal = devs[d]; dev->n_plain = shards;
@@ -113,17 +125,20 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
             create_rc_ = guber_engine_create(&c, &sh->engine);
             if (create_rc_ != GUBER_OK) { sh->engine = nullptr; break; }
             if (!stream_of[sidx]) { stream_of[sidx] = guber_engine_stream(sh->engine); sh->owns_stream = true; }
-            for (uint32_t k = 0; k < kStages && create_rc_ == GUBER_OK; ++k) {
-                Stage& st = sh->st[k];
-                create_rc_ = guber_stage_create(sh->engine, batch_limit_, key_cap_, &st.stage);
-                if (create_rc_ != GUBER_OK) break;
-                st.b = guber_stage_batch(st.stage); st.r = guber_stage_result(st.stage);
-                st.shard = sh.get();
-                st.name_len.assign(batch_limit_, 0);
-            }
+            if (!routed_) create_rc_ = create_stages(*sh);
             dev->shards.push_back(sh.get());
             shards_.push_back(std::move(sh));
             if (create_rc_ != GUBER_OK) break;
+        }
+        if (routed_ && create_rc_ == GUBER_OK) {
+            dev->front.reset(new Shard());
+            Shard& f = *dev->front;
+            f.front = true; f.engine = dev->shards[0]->engine; f.device = devs[d]; f.dev = dev.get();
+            create_rc_ = create_stages(f);
+            for (auto& st : f.st) if (st.stage) st.dest = guber_stage_dest(st.stage);
+            dev->staging.push_back(&f);
+        } else {
+            dev->staging = dev->shards;
         }
         devs_.push_back(std::move(dev));
     }
@@ -132,11 +147,25 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
         shards_.clear();
         return;
     }
+    for (auto& d : devs_) for (Shard* sh : d->staging) staging_.push_back(sh);
     for (auto& d : devs_) { Device* p = d.get(); p->thread = std::thread([this, p] { run(*p); }); }
+}
+
+int GPUWorkerPool::create_stages(Shard& sh) {
+    for (uint32_t k = 0; k < kStages; ++k) {
+        Stage& st = sh.st[k];
+        const int rc = guber_stage_create(sh.engine, stage_cap_, key_cap_, &st.stage);
+        if (rc != GUBER_OK) return rc;
+        st.b = guber_stage_batch(st.stage); st.r = guber_stage_result(st.stage);
+        st.shard = &sh;
+        st.name_len.assign(stage_cap_, 0);
+    }
+    return GUBER_OK;
 }
 
 void GPUWorkerPool::destroy_engines() {
     for (auto& sh : shards_) for (auto& st : sh->st) if (st.stage) { guber_stage_destroy(st.stage); st.stage = nullptr; }
+    for (auto& d : devs_) if (d->front) for (auto& st : d->front->st) if (st.stage) { guber_stage_destroy(st.stage); st.stage = nullptr; }
     for (int pass = 0; pass < 2; ++pass)                             // the engines that own a stream go last
         for (auto& sh : shards_)
             if (sh->engine && (pass == 1 || !sh->owns_stream)) { guber_engine_destroy(sh->engine); sh->engine = nullptr; }
@@ -168,7 +197,7 @@ void GPUWorkerPool::Close() {
         std::lock_guard<std::mutex> lk(comm_mu_);
         if (comm_) { guber_comm_destroy(comm_); comm_ = nullptr; }
     }
-    for (auto& sh : shards_)
+    for (Shard* sh : staging_)
         for (auto& st : sh->st)                                      // callers may still be copying their responses out of the stage
             while (st.gen.load() && st.state != Stage::kFree && st.state != Stage::kOpen && st.consumed.load(std::memory_order_acquire) != st.n) std::this_thread::yield();
     destroy_engines();
@@ -193,11 +222,15 @@ uint32_t GPUWorkerPool::ShardOf(const uint8_t* key, uint32_t len, uint32_t behav
 uint64_t GPUWorkerPool::batches_flushed() const {
     uint64_t n = 0;
     for (auto& sh : shards_) n += sh->flushed.load();
+    for (auto& d : devs_) if (d->front) n += d->front->flushed.load();
     return n;
 }
 void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
     memset(out, 0, sizeof(*out));
-    for (auto& sh : shards_) {
+    std::vector<const Shard*> counted;                               // the shards (their direct batches, key errors) and the devices' fronts (the staged batches)
+    for (auto& sh : shards_) counted.push_back(sh.get());
+    for (auto& d : devs_) if (d->front) counted.push_back(d->front.get());
+    for (const Shard* sh : counted) {
         out->batches += sh->flushed.load(); out->requests += sh->requests.load();
         for (auto& st : sh->st) { const uint64_t w = st.word.load(); if (!(w & kClosed)) out->queue_length += word_count(w); }
         out->queue_length_max = std::max<uint64_t>(out->queue_length_max, sh->queue_max.load());
@@ -207,7 +240,7 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
         out->in_flight += sh->in_flight.load();
         out->key_too_long += sh->key_too_long.load(); out->flush_on_key_bytes += sh->flush_on_key_bytes.load();
     }
-    for (auto& sh : shards_) out->direct_batches += sh->direct.load();
+    for (const Shard* sh : counted) out->direct_batches += sh->direct.load();
     for (auto& d : devs_) { out->rebalances += d->rebalances.load(); out->keys_moved += d->moves.load(); out->submit_us_sum += d->submit_us.load(); out->submits += d->submits.load(); }
     out->shards = (uint32_t)shards_.size(); out->devices = n_devices_;
     if (getenv("GUBER_POOL_DEBUG") && d_dbg_[3].load())
@@ -245,6 +278,7 @@ struct GPUWorkerPool::Scratch {
     std::vector<uint32_t> koff, klen;
     std::vector<uint64_t> hash;
     std::vector<uint16_t> dev;
+    std::vector<uint8_t> eng;                         // a request's shard inside its device (routed pools: what the front stage's dest column carries)
     std::vector<uint32_t> shard, order, todo, next, count, vers;
     std::vector<Ticket2> tickets;
     std::vector<int64_t> col;                         // a ticket's 8-byte columns, gathered before they are streamed into the stage
@@ -255,7 +289,7 @@ struct GPUWorkerPool::Scratch {
 #ifdef GUBER_POOL_PHASES
 static std::atomic<uint64_t> g_ph[6];
 static inline uint64_t tsc() { return __builtin_ia32_rdtsc(); }
-struct PhasePrinter { ~PhasePrinter() { uint64_t t = 0; for (int k = 0; k < 5; ++k) t += g_ph[k]; if (g_ph[5]) fprintf(stderr, "[phases] per request cycles: build %.1f route+sort %.1f reserve+write %.1f wait %.1f consume %.1f (n=%llu)\n", (double)g_ph[0] / g_ph[5], (double)g_ph[1] / g_ph[5], (double)g_ph[2] / g_ph[5], (double)g_ph[3] / g_ph[5], (double)g_ph[4] / g_ph[5], (unsigned long long)g_ph[5].load()); } } g_phase_printer;
+struct PhasePrinter { ~PhasePrinter() { uint64_t t = 0; for (int k = 0; k < 5; ++k) t += g_ph[k]; if (g_ph[5]) fprintf(stderr, "[phases] per request cycles: build %.1f route+sort %.1f reserve+write %.1f leave %.1f wait+consume %.1f (n=%llu)\n", (double)g_ph[0] / g_ph[5], (double)g_ph[1] / g_ph[5], (double)g_ph[2] / g_ph[5], (double)g_ph[3] / g_ph[5], (double)g_ph[4] / g_ph[5], (unsigned long long)g_ph[5].load()); } } g_phase_printer;
 #define PH(k) do { const uint64_t _t = tsc(); g_ph[k] += _t - ph_t; ph_t = _t; } while (0)
 #else
 #define PH(k) do {} while (0)
@@ -273,7 +307,7 @@ struct GPUWorkerPool::Call {
 #ifdef GUBER_POOL_PHASES
         uint64_t ph_t = tsc(); g_ph[5] += n;
 #endif
-        S.koff.resize(n + 1); S.klen.resize(n); S.hash.resize(n); S.dev.resize(n); S.shard.resize(n); S.todo.resize(n);
+        S.koff.resize(n + 1); S.klen.resize(n); S.hash.resize(n); S.dev.resize(n); S.shard.resize(n); S.eng.resize(n); S.todo.resize(n);
         S.order.clear(); S.tickets.clear();
         // HashKey = name + "_" + unique_key (client.go:39-41), its XXH64 (workers.go:153-155), its device (replicated_hash.go:104-119)
         S.keys.resize(src.key_bytes_total() + 16);
@@ -310,7 +344,7 @@ struct GPUWorkerPool::Call {
         // Every request belongs to the shard of its key (workers.go:261-291); requests of one key keep their order.  A round
         // routes what is left with the devices' current placement versions; a reservation refused as stale (the placement
         // changed between routing and reserving) sends the rest of that list into the next round.
-        const uint32_t n_shards = (uint32_t)P.shards_.size();
+        const uint32_t n_shards = (uint32_t)P.staging_.size();       // (routed pools: one per device — the requests stay in arrival order)
         while (!S.todo.empty()) {
             S.vers.assign(P.n_devices_, 0xffffffffu);
             S.count.assign(n_shards + 1, 0);
@@ -318,8 +352,9 @@ struct GPUWorkerPool::Call {
                 const uint32_t dv = S.dev[i];
                 Device& d = *P.devs_[dv];
                 if (S.vers[dv] == 0xffffffffu) S.vers[dv] = d.ver.load(std::memory_order_acquire) & 0x7fu;
-                const uint32_t j = dv * P.shards_per_device_ + P.route(d, S.hash[i], src.behavior(i));
-                S.shard[i] = j;
+                const uint32_t e = P.route(d, S.hash[i], src.behavior(i));
+                const uint32_t j = P.routed_ ? dv : dv * P.shards_per_device_ + e;
+                S.shard[i] = j; S.eng[i] = (uint8_t)e;
                 S.count[j + 1]++;
             }
             for (uint32_t j = 0; j < n_shards; ++j) S.count[j + 1] += S.count[j];
@@ -341,8 +376,16 @@ struct GPUWorkerPool::Call {
             for (uint32_t j = 0; j < n_shards; ++j) {
                 uint32_t pos = base + S.count[j], left = S.count[j + 1] - S.count[j];
                 if (!left) continue;
-                Shard& sh = *P.shards_[j];
-                if (direct_ok && direct(sh, S.vers[sh.dev->index], pos, left)) continue;
+                Shard& sh = *P.staging_[j];
+                if (direct_ok) {
+                    Shard* table = &sh;                              // routed pools: the handful of requests must belong to one shard
+                    if (P.routed_) {
+                        const uint32_t e0 = S.eng[S.order[pos]];
+                        table = sh.dev->shards[e0];
+                        for (uint32_t q = 1; q < left; ++q) if (S.eng[S.order[pos + q]] != e0) { table = nullptr; break; }
+                    }
+                    if (table && direct(*table, sh, S.vers[sh.dev->index], pos, left)) continue;
+                }
                 while (left) {
                     if (closed) { for (uint32_t q = 0; q < left; ++q) sink.closed(S.order[pos + q]); break; }
                     Ticket2 t{};
@@ -359,10 +402,7 @@ struct GPUWorkerPool::Call {
             if (closed) { for (uint32_t i : S.todo) sink.closed(i); S.todo.clear(); }
         }
         P.leave();                                                   // (waiting for the answers needs no CPU)
-#ifdef GUBER_POOL_PHASES
-        for (auto& t : S.tickets) { Stage& s = *t.st; while (s.done_gen.load(std::memory_order_acquire) != (uint32_t)t.gen) cpu_relax(); }
         PH(3);
-#endif
         for (auto& t : S.tickets)
             if (!t.consumed) consume(t, true);
         PH(4);
@@ -372,13 +412,13 @@ struct GPUWorkerPool::Call {
     // Only when nobody else does the same at this shard and the placement is still the one the caller routed with; a move of a hot
     // key waits for it (place_mu).  Requests of one key from different callers have no order among each other; a caller's own
     // earlier calls have been answered.  false = not taken: the staged path applies.
-    bool direct(Shard& sh, uint32_t ver, uint32_t pos, uint32_t n) {
+    bool direct(Shard& sh, Shard& staging, uint32_t ver, uint32_t pos, uint32_t n) {
         constexpr uint32_t kMax = 16;
         if (n > kMax || sh.direct_busy.exchange(true, std::memory_order_acquire)) return false;
         struct Release { std::atomic<bool>& f; ~Release() { f.store(false, std::memory_order_release); } } release{sh.direct_busy};
         Device& d = *sh.dev;
         std::shared_lock<std::shared_mutex> lk(d.place_mu);
-        if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver || sh.open.load(std::memory_order_acquire) == kOpenDead) return false;
+        if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver || staging.open.load(std::memory_order_acquire) == kOpenDead) return false;
         const uint32_t* list = S.order.data() + pos;
         uint32_t off[kMax + 1], beh[kMax]; int64_t hits[kMax], limit[kMax], duration[kMax], burst[kMax], created[kMax], ol[kMax], orem[kMax], ors[kMax];
         uint8_t algo[kMax], owner[kMax], ost[kMax], oerr[kMax];
@@ -427,7 +467,7 @@ struct GPUWorkerPool::Call {
                 while (!(w & kClosed)) {
                     if (word_ver(w) != ver) return -1;
                     const uint32_t cnt = word_count(w), kbytes = word_bytes(w);
-                    const uint32_t room = P.batch_limit_ - cnt;
+                    const uint32_t room = P.stage_cap_ - cnt;
                     uint32_t take = std::min(room, count); uint64_t bytes = 0;
                     const uint32_t* list = S.order.data() + pos;
                     for (uint32_t q = 0; q < take; ++q) bytes += S.klen[list[q]];
@@ -448,7 +488,7 @@ struct GPUWorkerPool::Call {
                     }
                     if (s.word.compare_exchange_weak(w, w + take + (bytes << 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
                         *out = Ticket2{&s, s.gen.load(std::memory_order_relaxed), cnt, take, pos, kbytes, false};
-                        const bool first = cnt == 0, full = cnt + take >= P.batch_limit_;
+                        const bool first = cnt == 0, full = cnt + take >= P.stage_cap_;
                         const int64_t now = mono_us();
                         if (first) s.first_us.store(now, std::memory_order_release);
                         s.last_us.store(now, std::memory_order_release);
@@ -513,6 +553,13 @@ struct GPUWorkerPool::Call {
             algo[q] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
             beh[q] = r.behavior; owner[q] = r.is_owner ? 1 : 0;
             nlen[q] = (uint16_t)std::min<uint32_t>(S.klen[ri] - 1 - r.ukey_len, 0xffff);
+        }
+        if (s.dest) {                                                // a front stage: every request's shard and its place in the shard's share
+            uint32_t cnt[kMaxEngines] = {0}, at[kMaxEngines];
+            for (uint32_t q = 0; q < n; ++q) cnt[S.eng[list[q]] & (kMaxEngines - 1)]++;
+            for (uint32_t e = 0; e < kMaxEngines; ++e) at[e] = cnt[e] ? s.eng_n[e].fetch_add(cnt[e], std::memory_order_relaxed) : 0;
+            uint32_t* dest = s.dest + t.first_slot;
+            for (uint32_t q = 0; q < n; ++q) { const uint32_t e = S.eng[list[q]] & (kMaxEngines - 1); dest[q] = e << 24 | at[e]++; }
         }
         stream64((int64_t*)b->hits + t.first_slot, c_hits, n); stream64((int64_t*)b->limit + t.first_slot, c_limit, n);
         stream64((int64_t*)b->duration + t.first_slot, c_dur, n); stream64((int64_t*)b->burst + t.first_slot, c_burst, n);
@@ -688,6 +735,7 @@ void GPUWorkerPool::open_stage(Shard& sh, uint32_t k, uint32_t ver) {
     Stage& s = sh.st[k];
     s.n = 0; s.rc = GUBER_OK; s.submitted = false;
     s.written.store(0); s.consumed.store(0); s.first_us.store(0); s.last_us.store(0); s.flush_now.store(false);
+    if (sh.front) for (auto& c : s.eng_n) c.store(0, std::memory_order_relaxed);
     s.gen.store(s.gen.load() + 1);
     s.state = Stage::kOpen;
     s.word.store((uint64_t)(ver & 0x7fu) << 56, std::memory_order_release);
@@ -732,7 +780,7 @@ void GPUWorkerPool::seal_if_due(Shard& sh, int64_t now, bool force, bool eager_o
     if (s.state != Stage::kOpen) return;
     const uint32_t cnt = word_count(s.word.load(std::memory_order_acquire));
     if (cnt == 0) return;
-    bool is_due = cnt >= batch_limit_ || force || s.flush_now.load(std::memory_order_relaxed);
+    bool is_due = cnt >= stage_cap_ || force || s.flush_now.load(std::memory_order_relaxed);
     if (!is_due && eager_ok) is_due = true;                          // (the device has room: see run())
     if (!is_due) {
         const int64_t first = s.first_us.load(std::memory_order_acquire), last = s.last_us.load(std::memory_order_acquire);
@@ -765,7 +813,8 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
     const int64_t now_ms = NowMs();
     for (Stage* s : due) {
         for (uint32_t spins = 0; s->written.load(std::memory_order_acquire) != s->n; ++spins) {   // callers still copying their requests in
-            if (spins < 200) cpu_relax(); else std::this_thread::yield();
+            if ((spins & 15u) == 15u && !inflight.empty()) (void)poll(inflight);                  // (the batches on the GPU are announced meanwhile)
+            if (spins < 2000) cpu_relax(); else std::this_thread::yield();
         }
         s->t_written_us = mono_us();
         Shard& sh = *s->shard;
@@ -780,8 +829,26 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
         due.clear();
         return;
     }
-    guber_stage_t* arr[64];
     const uint32_t gen = d.gen_seq++ & 7u;
+    if (routed_) {                                                   // the device's front stage: the GPU hands the requests to the shards
+        guber_engine_t* eng[kMaxEngines]; uint32_t counts[kMaxEngines];
+        const uint32_t ne = (uint32_t)d.shards.size();
+        for (uint32_t j = 0; j < ne; ++j) eng[j] = d.shards[j]->engine;
+        for (Stage* s : due) {
+            for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_acquire);
+            const int64_t ts = mono_us();
+            const int rc = guber_stage_submit_routed(s->stage, eng, ne, counts);
+            d.submit_us.fetch_add((uint64_t)(mono_us() - ts), std::memory_order_relaxed); d.submits.fetch_add(1, std::memory_order_relaxed);
+            if (rc == GUBER_OK) {
+                s->submitted = true; s->state = Stage::kInFlight; s->shard->stages_in_flight++; s->t_submitted_us = mono_us(); inflight.push_back(s);
+                s->dev_gen = gen;
+                if (d.gen_left[gen]++ == 0) d.gens_in_flight++;
+            } else { s->rc = rc; announce(*s->shard, *s); }
+        }
+        due.clear();
+        return;
+    }
+    guber_stage_t* arr[64];
     for (size_t lo = 0; lo < due.size(); lo += 64) {
         const uint32_t m = (uint32_t)std::min<size_t>(64, due.size() - lo);
         for (uint32_t q = 0; q < m; ++q) arr[q] = due[lo + q]->stage;
@@ -849,7 +916,7 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
     d.rebalances++;
     if (nm == 0) { (void)guber_placement_commit(d.place); return; }  // (keys pinned where they are change nothing a caller can see)
     std::vector<Stage*> due;
-    for (Shard* sh : d.shards) {
+    for (Shard* sh : d.staging) {
         if (sh->open.load(std::memory_order_relaxed) == kOpenNone) continue;
         sh->open.store(kOpenNone, std::memory_order_release);
         Stage& s = sh->st[sh->cur];
@@ -869,7 +936,7 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
         d.ver.fetch_add(1, std::memory_order_acq_rel);
     }
     const uint32_t ver = d.ver.load();
-    for (Shard* sh : d.shards) {
+    for (Shard* sh : d.staging) {
         const int k = find_free(*sh);
         if (k >= 0) open_stage(*sh, (uint32_t)k, ver);               // (none free: seal_if_due opens one as soon as its callers have read it out)
         else { sh->open_seq.fetch_add(1, std::memory_order_release); futex_wake_all(&sh->open_seq); }
@@ -882,7 +949,7 @@ void GPUWorkerPool::RebalanceNow() {
 
 void GPUWorkerPool::run(Device& d) {
     std::vector<Stage*> inflight, due;
-    for (Shard* sh : d.shards) open_stage(*sh, 0, 0);
+    for (Shard* sh : d.staging) open_stage(*sh, 0, 0);
     int64_t next_rebalance = rebalance_ms_ ? mono_us() + (int64_t)rebalance_ms_ * 1000 : INT64_MAX;
     uint32_t idle_spins = 0;
     int64_t last_active = 0;
@@ -902,15 +969,15 @@ void GPUWorkerPool::run(Device& d) {
             if (d.gens_in_flight == 0) eager_ok = true;
             else {
                 uint64_t pending = 0;
-                for (Shard* sh : d.shards) if (sh->st[sh->cur].state == Stage::kOpen) pending += word_count(sh->st[sh->cur].word.load(std::memory_order_relaxed));
+                for (Shard* sh : d.staging) if (sh->st[sh->cur].state == Stage::kOpen) pending += word_count(sh->st[sh->cur].word.load(std::memory_order_relaxed));
                 eager_ok = pending >= eager_min_;
             }
         }
-        for (Shard* sh : d.shards) seal_if_due(*sh, now, closing, eager_ok, due, &deadline);
+        for (Shard* sh : d.staging) seal_if_due(*sh, now, closing, eager_ok, due, &deadline);
         if (!due.empty()) { submit_due(d, due, inflight); progressed = true; }
         if (closing && inflight.empty()) {
             // stop taking reservations; a caller may have slipped one in meanwhile: those are still evaluated
-            for (Shard* sh : d.shards) {
+            for (Shard* sh : d.staging) {
                 const uint32_t was = sh->open.exchange(kOpenDead, std::memory_order_acq_rel);
                 if (was < kStages && sh->st[was].state == Stage::kOpen) seal(*sh, sh->st[was], due);
                 sh->open_seq.fetch_add(1, std::memory_order_release);
@@ -945,9 +1012,48 @@ void GPUWorkerPool::run(Device& d) {
 // calls the reference makes from inside the algorithms, in request order.  Synchronous, host-pointer entry points over
 // the stage's own arrays.
 void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
-    guber_engine_t* const engine_ = sh.engine;
-    const uint32_t n_all = s.n;
+    s.submitted = false;
+    if (!sh.front) {
+        guber_batch_t B = *s.b; B.n = s.n;
+        s.rc = store_eval(sh.engine, B, *s.r, s.name_len.data());
+        return;
+    }
+    // a device's front stage: every shard's share is gathered in rank order (the order the device would apply it in), goes
+    // through the Store sequence on that shard's engine, and the answers return to the slots the callers wrote
+    Device& d = *sh.dev;
     const guber_batch_t& B = *s.b;
+    int rc = GUBER_OK;
+    for (uint32_t e = 0; e < d.shards.size() && rc == GUBER_OK; ++e) {
+        const uint32_t ne = s.eng_n[e].load(std::memory_order_acquire);
+        if (!ne) continue;
+        std::vector<uint32_t> at(ne, 0);
+        for (uint32_t i = 0; i < s.n; ++i) if ((s.dest[i] >> 24) == e) at[s.dest[i] & 0xffffffu] = i;
+        std::vector<uint8_t> keys; std::vector<uint32_t> off(ne + 1, 0), beh(ne); std::vector<uint16_t> nlen(ne);
+        std::vector<int64_t> hits(ne), limit(ne), duration(ne), burst(ne), created(ne), rl(ne), rr(ne), rs(ne);
+        std::vector<uint8_t> algo(ne), owner(ne), status(ne), err(ne);
+        for (uint32_t r = 0; r < ne; ++r) {
+            const uint32_t i = at[r];
+            keys.insert(keys.end(), B.key_bytes + B.key_off[i], B.key_bytes + (i + 1 < s.n ? B.key_off[i + 1] : B.key_off[s.n]));
+            off[r + 1] = (uint32_t)keys.size();
+            hits[r] = B.hits[i]; limit[r] = B.limit[i]; duration[r] = B.duration[i]; burst[r] = B.burst[i]; created[r] = B.created_at[i];
+            algo[r] = B.algorithm[i]; beh[r] = B.behavior[i]; owner[r] = B.is_owner[i]; nlen[r] = s.name_len[i];
+        }
+        keys.resize(keys.size() + 16, 0);
+        guber_batch_t b{}; guber_result_t res{};
+        b.n = ne; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = limit.data(); b.duration = duration.data();
+        b.burst = burst.data(); b.created_at = created.data(); b.algorithm = algo.data(); b.behavior = beh.data(); b.is_owner = owner.data(); b.now_ms = B.now_ms;
+        res.status = status.data(); res.limit = rl.data(); res.remaining = rr.data(); res.reset_time = rs.data(); res.err = err.data();
+        rc = store_eval(d.shards[e]->engine, b, res, nlen.data());
+        for (uint32_t r = 0; r < ne && rc == GUBER_OK; ++r) {
+            const uint32_t i = at[r];
+            s.r->status[i] = status[r]; s.r->limit[i] = rl[r]; s.r->remaining[i] = rr[r]; s.r->reset_time[i] = rs[r]; s.r->err[i] = err[r];
+        }
+    }
+    s.rc = rc;
+}
+
+int GPUWorkerPool::store_eval(guber_engine_t* engine_, const guber_batch_t& B, guber_result_t& R, const uint16_t* name_len) {
+    const uint32_t n_all = B.n;
     const uint8_t* keys = B.key_bytes; const uint32_t* off = B.key_off;
     // The store is asked on EVERY cache miss (algorithms.go:45-51), also on the miss a request causes for a later request of
     // the same key in the same batch: RESET_REMAINING removes the item from cache and store (:78-90), and the key's next
@@ -973,7 +1079,7 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
         const uint32_t lo = cuts[piece], n = cuts[piece + 1] - lo;
         if (n == 0) continue;
         guber_batch_t b = B;
-        guber_result_t res = *s.r;
+        guber_result_t res = R;
         b.n = n; b.key_off = B.key_off + lo; b.hits = B.hits + lo; b.limit = B.limit + lo; b.duration = B.duration + lo;
         if (B.burst) b.burst = B.burst + lo;
         if (B.created_at) b.created_at = B.created_at + lo;
@@ -986,7 +1092,7 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
         guber_store_events_t sev{sflags.data(), sitems.data()};
         auto store_req = [&](uint32_t i) {
             guber_store_req_t q{};
-            q.key = keys + poff[i]; q.key_len = poff[i + 1] - poff[i]; q.name_len = s.name_len[lo + i];
+            q.key = keys + poff[i]; q.key_len = poff[i + 1] - poff[i]; q.name_len = name_len[lo + i];
             q.hits = b.hits[i]; q.limit = b.limit[i]; q.duration = b.duration[i]; q.burst = b.burst[i]; q.created_at = b.created_at[i];
             q.algorithm = b.algorithm[i] == 255 ? -1 : b.algorithm[i]; q.behavior = b.behavior[i];
             return q;
@@ -1016,7 +1122,7 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
             }
         }
     }
-    s.rc = rc; s.submitted = false;
+    return rc;
 }
 
 // ---- cache operations from other threads: they follow the placement and exclude a move in progress -----------------------

@@ -123,6 +123,7 @@ class GPUWorkerPool {
 
  private:
     static constexpr uint32_t kStages = 4;                // filling / sealed or on the GPU (up to two) / being read out
+    static constexpr uint32_t kMaxEngines = 16;           // engines behind one front stage (guber_stage_submit_routed)
     static constexpr uint64_t kClosed = 1ull << 63;       // Stage::word: not accepting reservations
     static constexpr uint32_t kOpenNone = kStages, kOpenDead = kStages + 1;
     // Stage::word = kClosed | placement version (7 bits) << 56 | key bytes reserved (24 bits) << 32 | slots reserved
@@ -135,6 +136,8 @@ class GPUWorkerPool {
         guber_batch_t* b = nullptr; guber_result_t* r = nullptr;
         Shard* shard = nullptr;
         std::vector<uint16_t> name_len;                   // per slot: length of the request's name (Store callbacks)
+        uint32_t* dest = nullptr;                         // a device's front stage: per slot, engine index << 24 | rank in that engine's share
+        std::atomic<uint32_t> eng_n[kMaxEngines] = {};    // ... and the shares' sizes so far (callers take their ranks here)
         std::atomic<uint64_t> word{kClosed};
         std::atomic<uint32_t> written{0}, consumed{0};    // slots filled by their callers / responses picked up
         std::atomic<uint64_t> gen{0};                     // generation carried
@@ -156,6 +159,7 @@ class GPUWorkerPool {
         int32_t device = 0;
         bool global = false;                              // the device's GLOBAL engine
         bool owns_stream = false;                         // its engine created the stream other shards' engines share: destroyed last
+        bool front = false;                               // a device's front: stages only (on the first shard's engine), no table of its own
         uint32_t cur = 0;                                 // dispatcher: index of the open stage
         std::atomic<uint32_t> open{kOpenNone};            // index of the stage accepting reservations, kOpenNone, or kOpenDead for good
         std::atomic<uint32_t> open_seq{0}, open_waiters{0};   // futex word of callers waiting for a stage to open, and how many sleep on it
@@ -167,6 +171,8 @@ class GPUWorkerPool {
     struct Device {             // one GPU (or logical device): its shards, their placement, the dispatcher thread
         uint32_t index = 0; int32_t ordinal = 0;
         std::vector<Shard*> shards;                       // plain shards first; the GLOBAL engine, if any, last
+        std::unique_ptr<Shard> front;                     // routed pools: the ONE set of stages all callers of the device write into
+        std::vector<Shard*> staging;                      // where the callers' reservations go: {front}, or the shards themselves
         uint32_t n_plain = 0;
         guber_placement_t* place = nullptr;
         std::atomic<uint32_t> ver{0};                     // placement version the stages are tagged with
@@ -181,11 +187,13 @@ class GPUWorkerPool {
     struct Scratch;                                       // per-thread buffers of a call
     template <class Src, class Sink> struct Call;         // one GetRateLimitMany / GetRateLimitsSoA call (worker_pool.cpp)
     void run(Device& d);
+    int create_stages(Shard& sh);
     void open_stage(Shard& sh, uint32_t k, uint32_t ver);
     int find_free(Shard& sh);
     void seal(Shard& sh, Stage& s, std::vector<Stage*>& due);
     void seal_if_due(Shard& sh, int64_t now, bool force, bool eager_ok, std::vector<Stage*>& due, int64_t* deadline);
     void submit_with_store(Shard& sh, Stage& s);
+    int store_eval(guber_engine_t* engine, const guber_batch_t& B, guber_result_t& R, const uint16_t* name_len);
     void announce(Shard& sh, Stage& s);
     bool poll(std::vector<Stage*>& inflight);
     void drain(std::vector<Stage*>& inflight);
@@ -203,6 +211,9 @@ class GPUWorkerPool {
     guber_comm_t* comm_ = nullptr; std::mutex comm_mu_;
     uint32_t n_devices_ = 1, shards_per_device_ = 1, plain_per_device_ = 1;
     bool has_global_ = false;
+    bool routed_ = false;                                 // one front stage per device, the GPU hands the requests to the shards
+    uint32_t stage_cap_ = 0;                              // requests a stage takes (routed: up to batch_limit per shard, at most 65536)
+    std::vector<Shard*> staging_;                         // every device's staging shards, index = what a caller's routing round counts by
     int create_rc_ = 0;
     uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, rebalance_ms_ = 250, max_key_ = 1024, key_cap_ = 0;
     uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true, nt_stores_ = true;

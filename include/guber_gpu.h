@@ -225,6 +225,18 @@ int guber_stage_wait(guber_stage_t* s);
 #define GUBER_STAGES_NO_AGGREGATES 1u
 int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uint32_t flags, uint32_t* done);
 int guber_stage_poll(guber_stage_t* s);
+/* ONE stage for the requests of several engines — the logical shards of a GPU behind one reservation word (GPUWorkerPool:
+ * WorkerPool.getWorker / dispatch, workers.go:180-258, with the hand-over to the worker done by the GPU).  The callers write
+ * their requests in arrival order and, per request, into guber_stage_dest()[i] the index of its engine in `engines` << 24 |
+ * its rank inside that engine's share (the ranks of an engine are 0 .. counts[engine]-1, each exactly once; requests of one
+ * key carry ranks in the order they are to be applied).  The copy kernel that brings the request columns to HBM places every
+ * share contiguously in rank order, the shares run as the batches of ONE k_front_multi_mem + ONE k_eval2_multi_mem, and the
+ * answers land in the result arrays at the index the request was written at.  Four launches and one event whatever the number
+ * of engines (<= 16; they share device and stream, the stage's own engine is one of them); never blocks on the GPU;
+ * completion through guber_stage_poll / guber_stage_wait (no per-batch aggregates).  Every request column of the stage is
+ * present (none switched off). */
+uint32_t* guber_stage_dest(guber_stage_t* s);
+int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts);
 
 /* A queue of device-resident batches enqueued back to back on the engine stream in one call (what a batcher goroutine
  * that has several full batches waiting does, peer_client.go:284-337): batches[i] -> results[i], i = 0..count-1, in

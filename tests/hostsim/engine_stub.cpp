@@ -3,6 +3,7 @@
 // shutdown) can be exercised — also under ThreadSanitizer — on a machine without a GPU.  Linked only into
 // tests/hostsim/pool_test; never part of the product library, which has no CPU path at all.
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -18,6 +19,7 @@ struct guber_stage {
     guber_engine* e; uint32_t max_n, key_cap;
     std::vector<uint32_t> off, beh; std::vector<int64_t> hits, limit, duration, burst, created, rl, rr, rs;
     std::vector<uint8_t> algo, owner, status, err, keys;
+    std::vector<uint32_t> dest;
     guber_batch_t b{}; guber_result_t r{};
     bool in_flight = false;
     std::chrono::steady_clock::time_point ready_at{};                // guber_stages_submit: when the "GPU" is done with it
@@ -36,7 +38,7 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     guber_stage* s = new guber_stage();
     s->e = e; s->max_n = max_n; s->key_cap = key_bytes_cap ? key_bytes_cap : max_n * 64;
     const size_t n = max_n;
-    s->off.assign(n + 1, 0); s->beh.assign(n, 0); s->hits.assign(n, 0); s->limit.assign(n, 0); s->duration.assign(n, 0);
+    s->off.assign(n + 1, 0); s->dest.assign(n, 0); s->beh.assign(n, 0); s->hits.assign(n, 0); s->limit.assign(n, 0); s->duration.assign(n, 0);
     s->burst.assign(n, 0); s->created.assign(n, 0); s->rl.assign(n, 0); s->rr.assign(n, 0); s->rs.assign(n, 0);
     s->algo.assign(n, 0); s->owner.assign(n, 0); s->status.assign(n, 0); s->err.assign(n, 0); s->keys.assign(s->key_cap + 64, 0);
     s->b.key_bytes = s->keys.data(); s->b.key_off = s->off.data(); s->b.hits = s->hits.data(); s->b.limit = s->limit.data();
@@ -76,9 +78,61 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         for (uint32_t q = 0; q < k; ++q) if (stages[q]->e == s->e) return GUBER_E_INVALID_ARG;
         const int rc = guber_stage_submit(s);
         if (rc) return rc;
-        s->ready_at = std::chrono::steady_clock::now() + std::chrono::microseconds(null_engine ? 0 : s->rng() % 300);
+        static const long null_lat = getenv("GUBER_STUB_LAT_US") ? atol(getenv("GUBER_STUB_LAT_US")) : 0;   // a fixed device latency under GUBER_STUB_NULL
+        s->ready_at = std::chrono::steady_clock::now() + std::chrono::microseconds(null_engine ? null_lat : (long)(s->rng() % 300));
         if (done) *done = k + 1;
     }
+    return GUBER_OK;
+}
+// one stage for several engines: every engine's share is gathered in rank order, evaluated by that engine's oracle, and the
+// answers go back to the slots the requests were written at; the ranks must be a permutation of each share (checked)
+extern "C" uint32_t* guber_stage_dest(guber_stage_t* s) { return s->dest.data(); }
+extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts) {
+    static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;
+    static const long null_lat = getenv("GUBER_STUB_LAT_US") ? atol(getenv("GUBER_STUB_LAT_US")) : 0;
+    if (s->in_flight || n_engines == 0 || n_engines > 16) return GUBER_E_INVALID_ARG;
+    const uint32_t n = s->b.n;
+    if (n > s->max_n || (n && s->b.key_off[n] > s->key_cap)) return GUBER_E_BATCH_TOO_LARGE;
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < n_engines; ++j) total += counts[j];
+    if (total != n) return GUBER_E_INVALID_ARG;
+    if (null_engine) memset(s->err.data(), 0, n);
+    for (uint32_t j = 0; j < n_engines && !null_engine; ++j) {
+        const uint32_t nj = counts[j];
+        if (!nj) continue;
+        std::vector<uint32_t> at(nj, 0xffffffffu);
+        for (uint32_t i = 0; i < n; ++i) {
+            if ((s->dest[i] >> 24) != j) continue;
+            const uint32_t r = s->dest[i] & 0xffffffu;
+            if (r >= nj || at[r] != 0xffffffffu) { fprintf(stderr, "engine stub: ranks of engine %u are no permutation (request %u, rank %u of %u)\n", j, i, r, nj); abort(); }
+            at[r] = i;
+        }
+        for (uint32_t r = 0; r < nj; ++r) if (at[r] == 0xffffffffu) { fprintf(stderr, "engine stub: rank %u of engine %u is missing\n", r, j); abort(); }
+        std::vector<uint8_t> keys; std::vector<uint32_t> off(nj + 1, 0), beh(nj); std::vector<int64_t> hits(nj), limit(nj), duration(nj), burst(nj), created(nj), rl(nj), rr(nj), rs(nj);
+        std::vector<uint8_t> algo(nj), owner(nj), status(nj), err(nj);
+        for (uint32_t r = 0; r < nj; ++r) {
+            const uint32_t i = at[r];
+            keys.insert(keys.end(), s->b.key_bytes + s->b.key_off[i], s->b.key_bytes + s->b.key_off[i + 1]);
+            off[r + 1] = (uint32_t)keys.size();
+            hits[r] = s->b.hits[i]; limit[r] = s->b.limit[i]; duration[r] = s->b.duration[i]; burst[r] = s->b.burst[i]; created[r] = s->b.created_at[i];
+            algo[r] = s->b.algorithm[i]; beh[r] = s->b.behavior[i]; owner[r] = s->b.is_owner[i];
+        }
+        keys.resize(keys.size() + 16, 0);
+        guber_batch_t b{}; guber_result_t res{};
+        b.n = nj; b.key_bytes = keys.data(); b.key_off = off.data(); b.hits = hits.data(); b.limit = limit.data(); b.duration = duration.data(); b.burst = burst.data();
+        b.created_at = created.data(); b.algorithm = algo.data(); b.behavior = beh.data(); b.is_owner = owner.data(); b.now_ms = s->b.now_ms;
+        res.status = status.data(); res.limit = rl.data(); res.remaining = rr.data(); res.reset_time = rs.data(); res.err = err.data();
+        {
+            std::lock_guard<std::mutex> lk(engines[j]->mu);
+            oracle_eval_batch(engines[j]->o, &b, &res);
+        }
+        for (uint32_t r = 0; r < nj; ++r) {
+            const uint32_t i = at[r];
+            s->status[i] = status[r]; s->rl[i] = rl[r]; s->rr[i] = rr[r]; s->rs[i] = rs[r]; s->err[i] = err[r];
+        }
+    }
+    s->in_flight = true;
+    s->ready_at = std::chrono::steady_clock::now() + std::chrono::microseconds(null_engine ? null_lat : (long)(s->rng() % 300));
     return GUBER_OK;
 }
 extern "C" int guber_stage_poll(guber_stage_t* s) { return !s->in_flight || std::chrono::steady_clock::now() >= s->ready_at ? 1 : 0; }

@@ -922,6 +922,104 @@ def test_stages_of_several_engines_in_one_submission():
         e.close()
 
 
+def test_a_generation_of_nine_engines_in_one_pair_of_launches():
+    """guber_stages_submit with more stages than fit the kernel-argument segment (a pool dispatcher's generation over 8 shards
+    and the GLOBAL engine): the argument blocks travel through device memory, ONE completion event serves the group — 40
+    generations (more than the ring of group events holds) alternating two stages per engine, sizes ragged between 257 and
+    5000 requests with a small batch and an empty stage mixed in, time moving so buckets renew: every answer equals the
+    oracle's and all but the small / empty stages went through fused launches."""
+    import time
+    rng = np.random.default_rng(77)
+    now = streams.NOW0
+    first = engine(cache_size=1 << 16, max_batch=8192)
+    engines = [first] + [engine(cache_size=1 << 16, max_batch=8192, stream=first.stream_handle()) for _ in range(8)]
+    oracles = [Oracle(cache_size=1 << 17) for _ in engines]
+    stages = [[ga.Stage(e, 8192, key_bytes_cap=8192 * 24) for _ in range(2)] for e in engines]
+    fused_expected = 0
+    for rnd in range(40):
+        batch = []
+        t = now + rnd * 700
+        for j in range(9):
+            n = int(rng.integers(257, 5000))
+            if (rnd + j) % 11 == 0: n = 0
+            if (rnd + j) % 7 == 3: n = int(rng.integers(1, 200))
+            ids = rng.zipf(1.2, n) % 3000 if n else np.zeros(0, np.int64)
+            hb = HostBatch([f"g{j}_k{int(i)}" for i in ids], rng.integers(0, 3, n), 25, 2_000, t, algorithm=(ids % 2).astype(np.uint8), created_at=t)
+            stages[j][rnd % 2].fill(hb)
+            batch.append(hb)
+            fused_expected += n > 256
+        assert ga.Stage.submit_many([stages[j][rnd % 2] for j in range(9)]) == 9
+        t0 = time.time()
+        while not all(stages[j][rnd % 2].poll() for j in range(9)):
+            assert time.time() - t0 < 10
+        for j, hb in enumerate(batch):
+            stages[j][rnd % 2].wait()
+            if hb.n:
+                support.assert_results_equal(stages[j][rnd % 2].result(), oracles[j].eval(hb), f"generation {rnd} engine {j}")
+    assert sum(e.stats()["fused_batches"] for e in engines) >= fused_expected - 40       # (a generation with one large stage is not "fused")
+    for j, e in enumerate(engines):
+        assert e.size() == oracles[j].size()
+    for row in stages:
+        for st in row:
+            st.close()
+    for e in reversed(engines):
+        e.close()
+
+
+def test_one_stage_routed_to_nine_engines():
+    """guber_stage_submit_routed (the device-level stage of a pool): requests in arrival order, each tagged with its engine and
+    its rank there; the device places the shares, runs them as ONE pair of launches and answers in arrival order.  30 batches
+    over 9 engines (ragged: 1 .. 20 000 requests, variable-length keys, token and leaky, hits 0..2, an engine with no share,
+    an engine with one request, duplicate keys inside and across batches, time moving so buckets renew and expire) — every
+    answer equals what that engine's oracle says for its share, table sizes agree, and a plain batch on one of the engines
+    afterwards still agrees (the engines' work arrays were left consistent)."""
+    import time
+    rng = np.random.default_rng(2024)
+    now = streams.NOW0
+    first = engine(cache_size=1 << 16, max_batch=32768)
+    engines = [first] + [engine(cache_size=1 << 16, max_batch=32768, stream=first.stream_handle()) for _ in range(8)]
+    oracles = [Oracle(cache_size=1 << 17) for _ in engines]
+    stages = [ga.Stage(first, 32768, key_bytes_cap=32768 * 40) for _ in range(2)]
+    sizes = [1, 2, 9, 255, 256, 257, 1000, 5000, 20_000, 3, 700, 12_000]
+    for rnd in range(30):
+        n = sizes[rnd % len(sizes)]
+        t = now + rnd * 450
+        ids = rng.zipf(1.15, n) % 6000
+        keys = [f"acct_{int(i)}" + "x" * int(i % 23) for i in ids]                  # variable-length keys
+        shard = (ids * 2654435761 % 9).astype(np.uint32)                            # a key always goes to the same engine
+        if rnd % 5 == 1: shard[shard == 4] = 5                                      # ... except when a "placement pass" empties engine 4 for a batch
+        hb = HostBatch(keys, rng.integers(0, 3, n), 30, 3_000, t, algorithm=(ids % 2).astype(np.uint8), created_at=t, burst=np.where(ids % 2 == 1, 40, 0))
+        st = stages[rnd % 2]
+        st.fill(hb)
+        counts = st.submit_routed(engines, shard)
+        t0 = time.time()
+        while not st.poll():
+            assert time.time() - t0 < 10
+        st.wait()
+        got = st.result()
+        for j in range(9):
+            idx = np.nonzero(shard == j)[0]
+            assert len(idx) == counts[j]
+            if not len(idx):
+                continue
+            sub = HostBatch([keys[i] for i in idx], hb.hits[idx], 30, 3_000, t, algorithm=hb.algorithm[idx], created_at=t, burst=hb.burst[idx])
+            want = oracles[j].eval(sub)
+            for f in ("status", "err", "limit", "remaining", "reset_time"):
+                a, b = getattr(got, f)[idx], getattr(want, f)[:len(idx)]
+                assert np.array_equal(a, b), f"round {rnd} engine {j} field {f}: first difference at {idx[np.nonzero(a != b)[0][:5]]}"
+    for j, e in enumerate(engines):
+        assert e.size() == oracles[j].size(), j
+    hb = HostBatch([f"acct_{i}" + "x" * (i % 23) for i in range(3000)], 1, 30, 3_000, now + 30 * 450, algorithm=(np.arange(3000) % 2).astype(np.uint8), created_at=now + 30 * 450)
+    sel = [i for i in range(3000) if i * 2654435761 % 9 == 2]
+    sub = HostBatch([hb_key for hb_key in (f"acct_{i}" + "x" * (i % 23) for i in sel)], 1, 30, 3_000, now + 30 * 450, algorithm=(np.array(sel) % 2).astype(np.uint8),
+                    created_at=now + 30 * 450)
+    support.assert_results_equal(engines[2].eval(sub), oracles[2].eval(sub), "a plain batch after the routed ones")
+    for st in stages:
+        st.close()
+    for e in reversed(engines):
+        e.close()
+
+
 def test_buckets_move_between_tables_by_key_hash():
     """guber_move_items_by_hash (a hot key changes its logical shard): token and leaky items, an inline key and a 200-byte key
     (arena), an expired item and a hash that names nothing — the items arrive unchanged, leave nothing behind, and both
