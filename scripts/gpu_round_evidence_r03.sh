@@ -36,8 +36,15 @@ done
 unset GUBER_HIP_LIB
 cat $O/phase_timing.txt
 timeout 300 tools/tlb_latency 2>&1 | grep -v burst | tee $O/dependent_load_latency.txt
-for cfg in "16 8 1000" "32 8 1000" "64 8 1000" "128 8 1000" "256 8 1000" "64 12 1000" "64 4 1000" "64 1 1000" "256 1 1000" "64 8 1000 cpp" "64 8 100" "16 8 1" "16 1 1" "64 8 1"; do
+{
+for cfg in "1 8 1" "4 8 1" "16 8 1" "64 8 1" "16 1 1" "16 8 1000" "32 8 1000" "64 8 1000" "128 8 1000" "256 8 1000" "64 12 1000" "256 12 1000" "64 4 1000" "64 1 1000" "256 1 1000" "64 8 1000 cpp" "64 8 100"; do
   set -- $cfg
   timeout 120 tools/bench_pool_c $1 $2 $3 10000000 2.0 200 $4 2>&1 | grep -v amdgpu.ids
-done | tee $O/pool_throughput.txt
+done
+echo "== GUBER_POOL_ROUTED=0: stages per shard, callers sort by shard (what the front stage replaced)"
+for cfg in "64 8 1000" "256 8 1000" "64 12 1000" "16 8 1"; do
+  set -- $cfg
+  GUBER_POOL_ROUTED=0 timeout 120 tools/bench_pool_c $1 $2 $3 10000000 2.0 200 2>&1 | grep -v amdgpu.ids
+done
+} | tee $O/pool_throughput.txt
 tools/bench_config1_c | tee $O/config1.txt
