@@ -4,18 +4,22 @@
 // Same names, argument meaning and error behaviour; what changes is the mechanism.  The reference hands every request to
 // its worker's goroutine through a channel (workers.go:261-291); here the CALLERS do the per-request work, in parallel:
 // a caller hashes its keys, looks up the shard of each (guber_placement: hash slots + individually placed hot keys),
-// reserves a contiguous range of request slots (and key bytes) in the open stage of that shard with ONE compare-and-swap
-// per RPC and shard, writes its requests IN PLACE into the stage's arrays (device-visible host memory, include/guber_gpu.h
-// guber_stage_*), and later reads its responses straight out of the stage's result arrays.
+// reserves a contiguous range of request slots (and key bytes) in the open stage of the key's DEVICE — its front — with ONE
+// compare-and-swap per RPC, takes its requests' places in their shards' shares from the stage's per-shard counters, writes
+// its requests IN PLACE into the stage's arrays (device-visible host memory, include/guber_gpu.h guber_stage_*) together
+// with `shard << 24 | place` per request, and later reads its responses straight out of the stage's result arrays.  The GPU
+// hands the requests to the shards: the copy kernel that brings a stage to HBM places every shard's share contiguously
+// (guber_stage_submit_routed).  GUBER_POOL_ROUTED=0 (or more than 16 engines per device): every shard has stages of its own,
+// the callers sort their requests by shard and pay one compare-and-swap per RPC and shard.
 //
-// ONE dispatcher thread per device serves all of the device's shards (round 2 had a batcher thread and stream per shard:
-// the launches of different streams overlap badly on the GPU and the threads fought for the host).  It seals the stages
-// that are due — as soon as the device has room (the reference's workers take a request the moment it arrives; a batch then
-// collects what arrives while the previous one runs, so batches grow with the load by themselves), at batch_limit items, at
-// batch_wait after the first one (the policy of peer_client.go:284-337), when a caller found no room — and submits them
-// together (guber_stages_submit): the batches of up to four shards of a stream travel in ONE copy kernel + ONE k_front_multi +
-// ONE k_eval2_multi, batches of <= 256 requests in ONE k_small_multi, nothing is waited for.  It polls for completions
-// (guber_stage_poll), announces finished generations (futex; wake-ups fan out as a tree), and never touches a request.
+// ONE dispatcher thread per device (round 2 had a batcher thread and stream per shard: the launches of different streams
+// overlap badly on the GPU and the threads fought for the host).  It seals the stage when it is due — as soon as the device
+// has room (the reference's workers take a request the moment it arrives; a batch then collects what arrives while the
+// previous one runs, so batches grow with the load by themselves), at the stage's capacity (batch_limit per shard), at
+// batch_wait after the first reservation (the policy of peer_client.go:284-337), when a caller found no room — and submits
+// it: four launches for a generation whatever the number of shards, ONE for a generation of <= 256 requests, nothing is
+// waited for.  It polls for completions (guber_stage_poll), announces finished generations (futex; wake-ups fan out as a
+// tree), and never touches a request.
 // Nothing is allocated per flush.  Lightly loaded (at most shards/2 calls in progress) an RPC of a handful of requests does
 // not travel through stages at all: its caller evaluates it through guber_eval_batch and answers.
 // The host's CPUs are the pool's bottleneck, so it counts them (a cgroup CPU quota included): at most that many callers are

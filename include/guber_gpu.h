@@ -199,7 +199,7 @@ int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_re
  *      arrays in place.  guber_stage_submit returns at
  *      once; guber_stage_wait blocks until the responses are there (a polled sequence number for batches <= 256, a HIP
  *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With several stages per engine one
- *      is filled while the GPU evaluates another (the pool keeps four per shard: filling / up to two on the GPU / being read out).  Stages of one engine are evaluated in submission order; the one
+ *      is filled while the GPU evaluates another (the pool keeps four per device: filling / up to two on the GPU / being read out).  Stages of one engine are evaluated in submission order; the one
  *      exception are items that hit the internal retry (two keys under one 64-bit hash inside a batch, ~1e-6 per batch): they
  *      are re-run by guber_stage_wait, i.e. possibly after the next stage already in flight — the order two concurrent
  *      GetRateLimits calls have in the reference too (none).  Callers that need strict order keep one stage in flight.
@@ -368,7 +368,10 @@ int guber_global_take(guber_engine_t* e, uint32_t role_mask /* bit 1: hits rows,
 typedef struct guber_pool guber_pool_t;
 int guber_pool_create(const guber_config_t* cfg, uint32_t batch_limit, uint32_t batch_wait_us, guber_pool_t** out);
 /* `shards` = Config.Workers (config.go:110): the key space split by XXH64 range (workers.go:153-155,180-184) over that many
- * engines + batcher threads inside one GPU, so that batches of different shards overlap; cfg->cache_size is the pool total. */
+ * engines (tables) inside one GPU, whose batches share launches; cfg->cache_size is the pool total.  With 2 .. 16 shards per
+ * device (GLOBAL engine included) the callers of a device share ONE set of stages and the GPU hands the requests to the shards
+ * (guber_stage_submit_routed); batch_limit is per shard: a device's batch carries up to batch_limit x shards requests (at most
+ * 65 536).  GUBER_POOL_ROUTED=0 in the environment: every shard has stages of its own and the callers sort by shard. */
 int guber_pool_create_sharded(const guber_config_t* cfg, uint32_t shards, uint32_t batch_limit, uint32_t batch_wait_us,
                               guber_pool_t** out);
 /* Several devices: devices[i] = HIP ordinal of peer "gpu<i>" on the reference's replicated consistent hash (replicated_hash.go:
