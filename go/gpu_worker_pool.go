@@ -13,8 +13,8 @@
 // gubernator.go:221-300).
 //
 // The binding is deliberately THIN: everything that decides anything — key hashing, device and shard placement (with the
-// online isolation of hot keys), slot reservation in the shards' stages, the dispatcher that fuses the shards' batches into
-// shared launches, completion, the Store call sequence — lives in the C++ pool (gubernator_amd/csrc/worker_pool.cpp), which IS
+// online isolation of hot keys), slot reservation in the devices' stages, the dispatcher whose batches the GPU hands to the
+// shards' tables, completion, the Store call sequence — lives in the C++ pool (gubernator_amd/csrc/worker_pool.cpp), which IS
 // compiled and tested in this repository (tests/test_gpu_host_layer.py on the GPU; tests/test_pool_cpu.py under
 // ThreadSanitizer / AddressSanitizer).  A Go re-implementation of that logic could only drift from it.  What happens here:
 // the requests of a call are laid out as structure-of-arrays in C memory (no Go pointer is retained by C: cgo rules), ONE cgo
