@@ -155,15 +155,18 @@ def test_aggregated_rpc_payloads_match_the_oracle_on_the_gpu():
     e.close()
 
 
-def test_store_callbacks_through_the_pool_teststore():
+@pytest.mark.parametrize("shards", [1, 3])
+def test_store_callbacks_through_the_pool_teststore(shards):
     """store_test.go TestStore through the C++ pool: Config.Store as C callbacks (guber_pool_set_store); the batcher
-    must call Get on the miss, Remove for a foreign Value, OnChange with the item after the request."""
+    must call Get on the miss, Remove for a foreign Value, OnChange with the item after the request.  With several shards the
+    requests sit in the device's front stage in arrival order and every shard's share goes through the Store sequence on its own
+    engine (worker_pool.cpp submit_with_store)."""
     import scenarios
     import support
 
     class PoolBackend:
         def __init__(self):
-            self.inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+            self.inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200, shards=shards)
 
         def eval_store(self, batch, store):
             # adapter: MockStore speaks (req_index, key); the pool hands (req dict, key)
@@ -189,7 +192,8 @@ def test_store_callbacks_through_the_pool_teststore():
     assert scenarios.run_store_events(PoolBackend) == 10
 
 
-def test_store_is_asked_again_after_a_reset_inside_one_batch():
+@pytest.mark.parametrize("shards", [1, 4])
+def test_store_is_asked_again_after_a_reset_inside_one_batch(shards):
     """algorithms.go:45-51 after :78-90 — RESET_REMAINING removes the item from cache and store; the key's next request, in the SAME
     GetRateLimits call, misses the cache again and the reference calls Store.Get again.  A store that still has the item (it
     ignores Remove) shows the difference: the third request continues from the store's state, not from a fresh bucket."""
@@ -206,7 +210,7 @@ def test_store_is_asked_again_after_a_reset_inside_one_batch():
 
         def remove(self, r, key):
             calls.append(("remove", key))
-    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200)
+    inst = ga.V1Instance(cache_size=4096, batch_limit=64, batch_wait_us=200, shards=shards)
     inst.set_clock(now)
     inst.set_store(Sticky())
     req = dict(name="sticky", unique_key="account:1", hits=1, limit=10, duration=60_000)
