@@ -49,6 +49,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     eager_min_ = env_u32("GUBER_POOL_EAGER_MIN", 4096);
     direct_max_ = env_u32("GUBER_POOL_DIRECT_MAX", 4);               // RPCs of at most this many requests may be evaluated by their caller (0 = never)
     direct_callers_ = env_u32("GUBER_POOL_DIRECT_CALLERS", 0);       // ... while at most this many calls are in progress (0 = half the shards, at least 2)
+    one_pass_ = env_u32("GUBER_POOL_ONE_PASS", 1) != 0;              // one shard on one device: reserve first, then touch every request once
     nt_stores_ = env_u32("GUBER_POOL_NT_STORES", 1) != 0;            // the 8-byte request columns go into the stage with non-temporal stores
     spin_us_ = env_u32("GUBER_POOL_SPIN_US", 40);                    // how long a waiting caller looks before it sleeps
     {   // callers allowed in the CPU part of a call at a time: the CPUs this process may really use (a cgroup CPU quota counts),
@@ -309,6 +310,15 @@ struct GPUWorkerPool::Call {
 #endif
         S.koff.resize(n + 1); S.klen.resize(n); S.hash.resize(n); S.dev.resize(n); S.shard.resize(n); S.eng.resize(n); S.todo.resize(n);
         S.order.clear(); S.tickets.clear();
+        if (P.one_pass_ && one_pass(n)) {
+            PH(2);
+            P.leave();
+            PH(3);
+            for (auto& t : S.tickets)
+                if (!t.consumed) consume(t, true);
+            PH(4);
+            return;
+        }
         // HashKey = name + "_" + unique_key (client.go:39-41), its XXH64 (workers.go:153-155), its device (replicated_hash.go:104-119)
         S.keys.resize(src.key_bytes_total() + 16);
         uint8_t* const kb = S.keys.data();
@@ -360,7 +370,8 @@ struct GPUWorkerPool::Call {
             for (uint32_t j = 0; j < n_shards; ++j) S.count[j + 1] += S.count[j];
             const uint32_t base = (uint32_t)S.order.size();
             S.order.resize(base + S.todo.size());
-            {
+            if (n_shards == 1) std::copy(S.todo.begin(), S.todo.end(), S.order.begin() + base);   // (one target: arrival order as it is)
+            else {
                 std::vector<uint32_t>& fill = S.next;                // (scratch: running positions)
                 fill.assign(S.count.begin(), S.count.end() - 1);
                 for (uint32_t i : S.todo) S.order[base + fill[S.shard[i]]++] = i;
@@ -406,6 +417,86 @@ struct GPUWorkerPool::Call {
         for (auto& t : S.tickets)
             if (!t.consumed) consume(t, true);
         PH(4);
+    }
+
+    // ONE shard on ONE device (the reference's Workers = 1): nothing about a request has to be known before its slot is
+    // reserved — no device to pick, no shard, so no hash on the host at all — and the call reserves first, lengths only, then
+    // touches every request ONCE: HashKey bytes straight into the stage's key buffer, the request columns.  With several shards
+    // the hashing and the placement lookups would sit between the reservation and the `written` count, i.e. inside the time the
+    // dispatcher waits for a sealed stage's writers (measured on the host-only stub: 8 shards 37 instead of 44 M/s; one shard 80
+    // instead of 61), so those pools keep hashing before they reserve.  Reserving first also means that an overloaded pool queues
+    // its requests INSIDE the stages: with more outstanding than two stages hold, callers end up asleep on a full stage while
+    // holding one of the few CPU slots (256 callers: 124 instead of 240 M/s on the GPU box) — then the general path runs, whose
+    // callers arrive at the stage with their work done.  false = not applicable.
+    bool one_pass(uint32_t n) {
+        if (P.staging_.size() != 1 || n <= P.direct_max_) return false;
+        Shard& sh = *P.staging_[0];
+        Device& d = *sh.dev;
+        if (d.place || sh.front) return false;
+        if ((uint64_t)P.in_calls_.load(std::memory_order_relaxed) * n > 2ull * P.stage_cap_) return false;
+        ReqRef r;
+        uint32_t nt = 0;
+        S.order.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            src.key(i, r);
+            const uint32_t len = r.name_len + 1 + r.ukey_len;
+            S.klen[i] = len;
+            if (r.name_len == 0 || r.ukey_len == 0) { if (src.front_end_checks()) continue; }   // (answered by the front end: empty field)
+            if (len > P.max_key_) {                                  // answered here, never reaches the device
+                P.shards_[0]->key_too_long++;
+                sink.item_error(i, GUBER_ITEM_E_KEY_TOO_LONG, src.algorithm(i));
+                continue;
+            }
+            S.order[nt++] = i;
+        }
+        S.order.resize(nt);
+        uint32_t pos = 0, left = nt;
+        while (left) {
+            const uint32_t ver = d.ver.load(std::memory_order_acquire) & 0x7fu;
+            Ticket2 t{};
+            const int got = reserve(sh, ver, pos, left, &t);
+            if (got == 0) { for (uint32_t q = 0; q < left; ++q) sink.closed(S.order[pos + q]); break; }
+            if (got < 0) continue;                                   // (no placement, no versions: cannot happen)
+            write_one_pass(t);
+            S.tickets.push_back(t);
+            pos += (uint32_t)got; left -= (uint32_t)got;
+        }
+        return true;
+    }
+    void write_one_pass(const Ticket2& t) {
+        Stage& s = *t.st;
+        const guber_batch_t* b = s.b;
+        uint8_t* kp = (uint8_t*)b->key_bytes;
+        uint32_t* off = (uint32_t*)b->key_off + t.first_slot;
+        uint8_t *algo = (uint8_t*)b->algorithm + t.first_slot, *owner = (uint8_t*)b->is_owner + t.first_slot;
+        uint32_t* beh = (uint32_t*)b->behavior + t.first_slot;
+        uint16_t* nlen = s.name_len.data() + t.first_slot;
+        int64_t now = 0;
+        uint32_t o = t.key_base;
+        const uint32_t n = t.count;
+        const uint32_t* list = S.order.data() + t.list_begin;
+        if (S.col.size() < (size_t)5 * n) S.col.resize((size_t)5 * n);
+        int64_t *c_hits = S.col.data(), *c_limit = c_hits + n, *c_dur = c_limit + n, *c_burst = c_dur + n, *c_created = c_burst + n;
+        ReqRef r;
+        for (uint32_t q = 0; q < n; ++q) {
+            src.get(list[q], r);
+            uint8_t* k = kp + o;                                     // HashKey = name + "_" + unique_key (client.go:39-41), exactly its bytes
+            memcpy(k, r.name, r.name_len); k[r.name_len] = '_'; memcpy(k + r.name_len + 1, r.ukey, r.ukey_len);
+            off[q] = o; o += r.name_len + 1 + r.ukey_len;
+            c_hits[q] = r.hits; c_limit[q] = r.limit; c_dur[q] = r.duration; c_burst[q] = r.burst;
+            if (r.created_at) c_created[q] = r.created_at;
+            else { if (!now) now = P.NowMs(); c_created[q] = now; }
+            algo[q] = (r.algorithm == 0 || r.algorithm == 1) ? (uint8_t)r.algorithm : 255;
+            beh[q] = r.behavior; owner[q] = r.is_owner ? 1 : 0;
+            nlen[q] = (uint16_t)std::min<uint32_t>(r.name_len, 0xffff);
+        }
+        stream64((int64_t*)b->hits + t.first_slot, c_hits, n); stream64((int64_t*)b->limit + t.first_slot, c_limit, n);
+        stream64((int64_t*)b->duration + t.first_slot, c_dur, n); stream64((int64_t*)b->burst + t.first_slot, c_burst, n);
+        stream64((int64_t*)b->created_at + t.first_slot, c_created, n);
+#if defined(__x86_64__)
+        __builtin_ia32_sfence();
+#endif
+        s.written.fetch_add(n, std::memory_order_release);
     }
 
     // Evaluate order[pos .. pos + n) of one shard on the caller's thread (guber_eval_batch: the engine's one-launch path, polled).

@@ -220,7 +220,7 @@ class GPUWorkerPool {
     std::vector<Shard*> staging_;                         // every device's staging shards, index = what a caller's routing round counts by
     int create_rc_ = 0;
     uint32_t batch_limit_, batch_wait_us_, idle_us_ = 0, rebalance_ms_ = 250, max_key_ = 1024, key_cap_ = 0;
-    uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true, nt_stores_ = true;
+    uint32_t depth_ = 2, eager_min_ = 4096, spin_us_ = 40, max_active_ = 0x7fffffffu; bool eager_ = true, nt_stores_ = true, one_pass_ = true;
     uint32_t direct_max_ = 4, direct_callers_ = 0;
     std::atomic<uint32_t> in_calls_{0};                   // calls in progress
     std::atomic<uint32_t> spinners_{0}; uint32_t max_spinners_ = 4;   // callers looking at a word instead of sleeping on it

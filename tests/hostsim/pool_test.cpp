@@ -261,6 +261,40 @@ int main(int argc, char** argv) {
         printf("small RPCs: %llu batches of which %llu evaluated by their callers, %llu hot keys moved, failures so far %d\n", (unsigned long long)m.batches,
                (unsigned long long)m.direct_batches, (unsigned long long)m.keys_moved, failures);
     }
+    {   // 8. ONE shard on one device (the reference's Workers = 1): the callers reserve first and touch every request once (no hash on
+        //    the host); tiny stages, so RPCs span stages and generations; over-long keys and empty fields answered in between
+        guber_config_t c8 = cfg; c8.max_key_bytes = 64;
+        GPUWorkerPool pool(c8, 96, 100, 1);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        const int limit = 4000;
+        std::atomic<long> shared_under{0}, shared_total{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 8; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(800 + t);
+            const std::string ns = "one" + std::to_string(t);
+            for (int it = 0; it < 200 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 25, 250);
+                std::vector<RateLimitReq> mine = reqs;
+                const size_t extra = 1 + rng() % 10;
+                for (size_t q = 0; q < extra; ++q) { RateLimitReq s; s.name = "all"; s.unique_key = "shared"; s.hits = 1; s.limit = limit; s.duration = 3600000; reqs.push_back(s); }
+                { RateLimitReq bad; bad.name = "e"; bad.unique_key = std::string(100, 'z'); bad.hits = 1; bad.limit = 5; bad.duration = 1000; reqs.push_back(bad); }
+                { RateLimitReq bad; bad.name = "e"; bad.unique_key = ""; bad.hits = 1; bad.limit = 5; bad.duration = 1000; reqs.push_back(bad); }
+                std::vector<RateLimitResp> resps; std::string err;
+                CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+                std::vector<RateLimitResp> own(resps.begin(), resps.begin() + mine.size());
+                compare(mine, own, ref, NOW0, "one shard");
+                for (size_t q = mine.size(); q + 2 < resps.size(); ++q) { shared_total++; if (resps[q].error.empty() && resps[q].status == 0) shared_under++; }
+                CHECK(resps[resps.size() - 2].error.find("key") != std::string::npos, "long key: '%s'", resps[resps.size() - 2].error.c_str());
+                CHECK(resps.back().error == "field 'unique_key' cannot be empty", "empty key: '%s'", resps.back().error.c_str());
+            }
+        });
+        for (auto& x : th) x.join();
+        CHECK(shared_under.load() == std::min<long>(shared_total.load(), limit), "shared key: %ld of %ld under the limit %d", shared_under.load(), shared_total.load(), limit);
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        CHECK(m.batch_size_max <= 96 && m.shards == 1 && m.key_too_long > 0, "metrics: max %llu shards %u too long %llu", (unsigned long long)m.batch_size_max, m.shards, (unsigned long long)m.key_too_long);
+        printf("one shard: %llu batches, %llu requests, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests, failures);
+    }
     printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
     return failures ? 1 : 0;
 }
