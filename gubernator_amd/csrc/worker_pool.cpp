@@ -1261,6 +1261,8 @@ int GPUWorkerPool::Store(const std::function<void(const guber_item_t&)>& save) {
     return GUBER_OK;
 }
 int64_t GPUWorkerPool::Size() {
+    std::vector<std::shared_lock<std::shared_mutex>> locks;         // (a bucket on its way between two tables is in neither for a moment)
+    for (auto& d : devs_) locks.emplace_back(d->place_mu);
     int64_t n = 0;
     for (auto& sh : shards_) n += guber_size(sh->engine);
     return n;
