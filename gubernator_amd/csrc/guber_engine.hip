@@ -1240,11 +1240,6 @@ static int stage_views(guber_stage* s, StagePlan& P) {
     return 0;
 }
 
-// stages per group of launches (GUBER_STAGES_GROUP_MAX: 1 .. MULTI_MEM_MAX; the A/B knob of profiles/r03_*pool*)
-static int stages_group_max() {
-    static const int v = [] { const char* x = getenv("GUBER_STAGES_GROUP_MAX"); const int k = x ? atoi(x) : MULTI_MEM_MAX; return k < 1 ? 1 : (k > MULTI_MEM_MAX ? MULTI_MEM_MAX : k); }();
-    return v;
-}
 // one group: <= MULTI_MEM_MAX large stages of engines that share device and stream (engine mutexes held by the caller).  Up to
 // MULTI_MAX of them take the launches whose arguments travel by value; more (a pool dispatcher's generation over 8, 12 shards)
 // take the same launches with their argument blocks in device memory: written into the leading stage's host block here,
@@ -1361,7 +1356,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
     }
     uint32_t enq = 0;
     StagePlan grp[MULTI_MEM_MAX]; int g = 0;
-    const int group_max = (flags & GUBER_STAGES_NO_AGGREGATES) ? stages_group_max() : MULTI_MAX;
+    const int group_max = MULTI_MEM_MAX;
     auto flush = [&]() -> int {
         if (!g) return 0;
         guber_engine* order[MULTI_MEM_MAX];
