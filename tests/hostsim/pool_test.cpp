@@ -295,6 +295,40 @@ int main(int argc, char** argv) {
         CHECK(m.batch_size_max <= 96 && m.shards == 1 && m.key_too_long > 0, "metrics: max %llu shards %u too long %llu", (unsigned long long)m.batch_size_max, m.shards, (unsigned long long)m.key_too_long);
         printf("one shard: %llu batches, %llu requests, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests, failures);
     }
+    {   // 9. three devices x two shards (logical devices: the ring decides, replicated_hash.go:104-119): every device has a front stage
+        //    of its own, an RPC is split by owner and answered in place, placement passes run on every device
+        GPUWorkerPool pool(cfg, 128, 100, 2, std::vector<int32_t>{0, 0, 0});
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        CHECK(pool.ok() && pool.devices() == 3 && pool.shards() == 6, "multi-device pool: %u devices %u shards", pool.devices(), pool.shards());
+        std::atomic<bool> stop{false};
+        std::thread kicker([&] { while (!stop.load()) { pool.RebalanceNow(); std::this_thread::sleep_for(std::chrono::milliseconds(3)); } });
+        const int limit = 3000;
+        std::atomic<long> shared_under{0}, shared_total{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 6; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(900 + t);
+            const std::string ns = "md" + std::to_string(t);
+            for (int it = 0; it < 150 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 30, 200);
+                std::vector<RateLimitReq> mine = reqs;
+                const size_t extra = 1 + rng() % 10;
+                for (size_t q = 0; q < extra; ++q) { RateLimitReq s; s.name = "all"; s.unique_key = "shared"; s.hits = 1; s.limit = limit; s.duration = 3600000; reqs.push_back(s); }
+                std::vector<RateLimitResp> resps; std::string err;
+                CHECK(inst.GetRateLimits(reqs, &resps, &err), "rpc failed: %s", err.c_str());
+                std::vector<RateLimitResp> own(resps.begin(), resps.begin() + mine.size());
+                compare(mine, own, ref, NOW0, "several devices");
+                for (size_t q = mine.size(); q < resps.size(); ++q) { shared_total++; if (resps[q].error.empty() && resps[q].status == 0) shared_under++; }
+            }
+        });
+        for (auto& x : th) x.join();
+        stop.store(true); kicker.join();
+        CHECK(shared_under.load() == std::min<long>(shared_total.load(), limit), "shared key: %ld of %ld under the limit %d", shared_under.load(), shared_total.load(), limit);
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        CHECK(m.devices == 3 && m.shards == 6 && m.in_flight == 0, "metrics: %u devices %u shards", m.devices, m.shards);
+        printf("several devices: %llu batches, %llu requests, %llu placement passes, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests,
+               (unsigned long long)m.rebalances, failures);
+    }
     printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
     return failures ? 1 : 0;
 }
