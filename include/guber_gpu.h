@@ -215,7 +215,8 @@ int guber_stage_submit(guber_stage_t* s);
 int guber_stage_wait(guber_stage_t* s);
 /* Several stages in one submission — what ONE dispatcher serving all logical shards of a GPU calls (GPUWorkerPool): at most one
  * stage per engine; batches of > 256 requests of engines that share device and stream travel as fused launches (one copy
- * kernel bringing the request columns of up to four stages to HBM, then k_front_multi / k_eval2_multi), batches of <= 256
+ * kernel bringing the request columns of the group's stages to HBM — up to 16 — then k_front_multi / k_eval2_multi, whose
+ * argument blocks travel by value for up to four stages and through device memory beyond; one completion event per group), batches of <= 256
  * requests take the one-launch path WITHOUT waiting for it.  Never blocks on the GPU.  With GUBER_STAGES_NO_AGGREGATES the
  * per-batch aggregates of guber_result_t are not produced (no counter read-back launches; guber_stats has the totals);
  * without it the stages are submitted one by one exactly as guber_stage_submit does.  *done (optional) = stages enqueued.
