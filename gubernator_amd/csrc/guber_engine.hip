@@ -552,7 +552,7 @@ extern "C" int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* ba
 // shared state).  Each round takes the next batch of every engine that has one and, where the engines share device and
 // stream and the batches take the two-launch pipeline, enqueues up to MULTI_MAX of them as ONE k_front_multi + ONE
 // k_eval2_multi (guber_kernels.h): the batches' dependent memory trips then overlap inside a launch, without the
-// per-stream kernel boundaries that throttle shards running on separate streams (profiles/r02_m_shard_streams.txt).
+// per-stream kernel boundaries that throttle shards running on separate streams (profiles/archive/r02_m_shard_streams.txt).
 static bool can_fuse(const guber_engine* e, uint32_t n) {
 #ifdef GUBER_PHASE_TIMING
     return false;
@@ -884,7 +884,7 @@ struct guber_stage {
     // stage's device mirror while the previous batches' kernels run; the pipeline then works on HBM and k_eval2 writes the
     // responses straight into the host arrays (posted writes).  The link carries the requests at the copy engine's rate
     // (46-48 GB/s) instead of at the rate of k_front's dependent reads (24 GB/s in total with everything in place).
-    // Measured and dropped (profiles/r02_v_end_to_end_variants.txt): responses to HBM and a DMA copy back (a hipMemcpyAsync
+    // Measured and dropped (profiles/archive/r02_v_end_to_end_variants.txt): responses to HBM and a DMA copy back (a hipMemcpyAsync
     // costs 40-60 us of host time), a copy kernel instead of the DMA (kernels of two streams overlap badly).
     DevBuf<uint8_t> dmem;            // device mirror of the in block
     uint8_t *h_in = nullptr, *h_out = nullptr; size_t in_fixed = 0, out_bytes = 0;   // host blocks; in_fixed = bytes before the keys

@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
 // k_eval2_multi: workgroup -> (batch, tile) by a prefix table, every workgroup then runs exactly the single-batch body on
 // its engine's table and work arrays.  Same results by construction; what changes is that the batches' memory trips
 // overlap inside one launch instead of across streams (where every kernel boundary of every stream costs the others:
-// profiles/r02_m_shard_streams.txt).
+// profiles/archive/r02_m_shard_streams.txt).
 #ifndef GUBER_MULTI_MAX
 #define GUBER_MULTI_MAX 4        // tables per fused launch (the kernel-argument segment holds at most 7: static_assert below)
 #endif
