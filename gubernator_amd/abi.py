@@ -98,7 +98,7 @@ class HostBatch:
             if n:
                 off[1:] = np.cumsum([len(b) for b in bs])
             self.key_off = off
-            self.key_bytes = np.frombuffer(b"".join(bs) + b"\0", np.uint8).copy()
+            self.key_bytes = np.frombuffer(b"".join(bs) + b"\0" * 8, np.uint8).copy()   # (the kernels read keys in 8-byte words)
 
         def arr(x, dt):
             if x is None:

@@ -34,6 +34,7 @@
 //   k_eval         as k_eval2, with the rank taken from the sorted position
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "guber_table.h"
@@ -758,5 +759,8 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi_mem(cons
 
 }  // namespace guber
 
+#include "guber_kernels_part.h"
+#ifndef GUBER_KERNELS_PIPELINES_ONLY   // (the host emulation of the batch pipelines, tests/hostsim/devsim.cpp, stops here)
 #include "guber_kernels_ops.h"
 #include "guber_kernels_small.h"
+#endif

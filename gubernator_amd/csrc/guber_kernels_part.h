@@ -1,0 +1,741 @@
+// guber_kernels_part.h — the owner-partitioned pipeline for batches of 257 .. 65 536 requests: THREE launches, every key of a
+// batch handled by exactly ONE workgroup, no atomics on device memory in steady state.  (Included at the end of guber_kernels.h.)
+//
+// Why.  The two-launch pipeline (k_front / k_eval2) lets every tile of 256 requests resolve its own keys and coordinates the
+// tiles that share a key through a per-batch claim table: one device-scope CAS per (key, tile) group, one publish atomic and one
+// per-tile count for every group that is not the key's first, three speculative table sectors per group head, and 2 MB of claim
+// cells zeroed again per batch — 67.8 k atomics and 5.7 MB of coordination writes per 65 536 requests (profiles/r03_*), on a
+// path whose rate follows the number of memory transactions per request.  Here the coordination is a partition instead:
+//
+//   k_part  (request order, one workgroup per tile of 256 requests): key -> XXH64, the tile grouped by hash in LDS exactly as
+//           k_front does, members compared with their group's head (fields from LDS, key bytes from L1).  Per (key, tile) GROUP
+//           one 64-byte MESSAGE {hash, key bytes (<= 16 inline), hits, limit, duration, burst, packed rest} written into the
+//           tile's own region, sorted (LDS counting sort) by the key's OWNER = the top 8 bits of its home position in the table,
+//           plus 256 x {start, count} per tile.  Per request one packed word (group, rank inside the group).  Streaming writes only.
+//   k_own   (one workgroup per owner, 256 per batch; thread t gathers tile t's run for this owner): the owner's messages in tile
+//           order = request order.  Grouped by hash in LDS; per key the exact comparison of every group's key bytes and request
+//           shape against the key's first-seen group (from the messages: no gathers from the request columns), the rank base of
+//           every group (requests of the key in earlier tiles: per 64-message chunk a wave scan per multi-group key + per-chunk
+//           sums) and the total; ONE table lookup per key (directory entry || home bucket in one trip, insert, exact key
+//           verification) by the only workgroup that can touch this key in this batch: no claim, no CAS except the insert of a
+//           new key's tag.  Per group one 64-byte RECORD back into the tile's region: the bucket as it was before the batch,
+//           slot, flags, base, total.  An owner touches one 1/256 of the table (translation locality).
+//   k_eval3 (request order): packed word -> the group's record -> every request evaluates its own rank exactly as k_eval2 does
+//           (closed forms / one apply() site / serial walk of heterogeneous segments); the last request writes the bucket.
+//
+// Request order semantics (gubernator.go:203 serial loop, workers.go:190-258 one goroutine per worker) hold as before: the rank
+// of a request inside its key's segment is (requests of the key in earlier tiles) + (rank inside its tile's group).
+// What this pipeline does not handle itself it reports per item as before (GUBER_ITEM_E_RETRY: two keys under one 64-bit hash;
+// the engine re-runs those through the careful round of the two-launch pipeline).
+#pragma once
+
+namespace guber {
+
+constexpr int PT_PARTS = 256;            // owners per batch (= k_own workgroups)
+
+// one (key, tile) group, tile -> owner
+struct alignas(64) GMsg {
+    unsigned long long hash;             // XXH64(key) & hash_mask, 0 -> 1
+    unsigned long long key0, key1;       // key bytes (length <= 16, zero padded) — or, G_LONG: key0 = key_off | len << 32 of the head's key
+    long long hits, limit, duration, burst;
+    unsigned long long misc;             // gm_*: head thread 8 | members-1 8 | G_* 8 | key length 5 | behavior 6 | algorithm 2 | owner 1 | created_at: min 18 (ms from the batch clock, signed), span 8
+};
+static_assert(sizeof(GMsg) == 64, "one message = one 64-byte sector");
+enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_ODD = 16, G_LONG = 32 };
+//   G_NONUNIFORM  members of the group differ in a request field other than created_at
+//   G_RETRY       members of the group differ in their key bytes (one hash, two keys)
+//   G_CREATED     members differ in created_at only (the range travels in misc)
+//   G_CFAR        the created_at range does not fit misc (further than +-131 s from the batch clock, or wider than 255 ms)
+//   G_ODD         a request the packed shape cannot carry exactly (behavior bits above 5, an algorithm other than 0 / 1, calendar
+//                 values precomputed by the host): equal to nothing but the members of its own group
+//   G_LONG        key longer than 16 bytes: compared through the request's key bytes in memory
+GB_HD uint32_t gm_head(unsigned long long m) { return (uint32_t)m & 0xffu; }
+GB_HD uint32_t gm_cnt(unsigned long long m) { return (((uint32_t)m >> 8) & 0xffu) + 1u; }
+GB_HD uint32_t gm_flags(unsigned long long m) { return ((uint32_t)m >> 16) & 0xffu; }
+GB_HD uint32_t gm_klen(unsigned long long m) { return ((uint32_t)m >> 24) & 31u; }
+GB_HD uint32_t gm_shape(unsigned long long m) { return (uint32_t)(m >> 29) & 0x1ffu; }       // behavior 6 | algorithm 2 | is_owner 1
+GB_HD uint32_t gm_algo(unsigned long long m) { return (uint32_t)(m >> 35) & 3u; }
+GB_HD uint32_t gm_behavior(unsigned long long m) { return (uint32_t)(m >> 29) & 63u; }
+GB_HD int64_t gm_cmin_delta(unsigned long long m) { return (int64_t)((int64_t)(m << 8) >> 46); }   // bits 38..55, sign-extended
+GB_HD uint32_t gm_cspan(unsigned long long m) { return (uint32_t)(m >> 56); }
+GB_HD unsigned long long gm_pack(uint32_t head, uint32_t cnt, uint32_t flags, uint32_t klen, uint32_t shape, int64_t cmin_delta, uint32_t span) {
+    return (unsigned long long)(head & 0xffu) | ((unsigned long long)((cnt - 1u) & 0xffu) << 8) | ((unsigned long long)(flags & 0xffu) << 16) |
+           ((unsigned long long)(klen & 31u) << 24) | ((unsigned long long)(shape & 0x1ffu) << 29) |
+           (((unsigned long long)cmin_delta & 0x3ffffull) << 38) | ((unsigned long long)(span & 0xffu) << 56);
+}
+
+// one (key, tile) group, owner -> tile: everything k_eval3 needs for the group's requests in ONE sector
+struct alignas(64) GRec {
+    int64_t limit, duration, remaining, stamp, burst, expire_at;     // the bucket as it was before the batch (guber::Rec)
+    uint32_t smeta;                      // pack_smeta: kind | status | SM_HAS_INVALID | algorithm
+    uint32_t slot;                       // where the bucket lives
+    unsigned long long tail;             // SEG_* 8 | item error code 8 | base 16 (requests of the key in earlier tiles) | total-1 16 | segment id 16
+};
+static_assert(sizeof(GRec) == 64, "one record = one 64-byte sector");
+GB_HD unsigned long long gr_tail(uint32_t sf, uint32_t err, uint32_t base, uint32_t total, uint32_t seg) {
+    return (unsigned long long)(sf & 0xffu) | ((unsigned long long)(err & 0xffu) << 8) | ((unsigned long long)(base & 0xffffu) << 16) |
+           ((unsigned long long)((total - 1u) & 0xffffu) << 32) | ((unsigned long long)(seg & 0xffffu) << 48);
+}
+
+// per-request word k_part -> k_eval3: group (position of its message in the tile's region) 8 | rank inside the group 8 | item error 8 | valid << 31
+GB_HD uint32_t pd_pack(uint32_t j, uint32_t rank, uint32_t err) { return (j & 0xffu) | ((rank & 0xffu) << 8) | ((err & 0xffu) << 16) | 0x80000000u; }
+
+// owner of a key: the top PT_PARTS bits of its home position — an owner's keys live in one contiguous 1/256 of the table
+__device__ __forceinline__ uint32_t owner_of(const Table& T, const Work& W, uint64_t h) { return (uint32_t)(((h >> 7) & T.mask) >> W.pshift) & (PT_PARTS - 1); }
+// launch order of the owners' workgroups is round-robin over the 8 XCDs: a tile writes the messages of the owners that share an
+// XCD next to each other, so that an L2 sees whole sectors of a tile's region
+GB_HD uint32_t owner_order(uint32_t p) { return ((p & 7u) << 5) | (p >> 3); }
+GB_HD uint32_t owner_from_order(uint32_t q) { return ((q & 31u) << 3) | (q >> 5); }
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
+    return v;
+}
+
+// ---- k_part ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void part_body(const Table& T, const BatchView& B, const Work& W, const uint32_t tile) {
+    constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
+    __shared__ unsigned long long gkey[GT];
+    __shared__ unsigned long long gbits[FT / 64][GT];
+    __shared__ uint32_t sd[FT];                                   // head -> position of its group's message in the tile's region
+    __shared__ uint32_t soff[FT], slen[FT];
+    __shared__ TileReqs sreq;
+    __shared__ uint32_t gfl[FT];                                  // head -> G_* raised by the group's members
+    __shared__ long long gcmin[FT], gcmax[FT];                    // head -> created_at range of the group
+    __shared__ uint32_t pc[PT_PARTS], pstart[PT_PARTS];           // groups per owner (in owner_order), where each owner's run starts
+    __shared__ uint32_t wsum[FT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t g = tile * FT + tid;
+    const bool valid = g < B.n;
+
+    if (tile == 0 && W.snap_seq) {                                // a counter read-back rides on this launch (Work::snap_*)
+        for (uint32_t k = tid; k < W.snap_n; k += FT) W.snap_b[k] = T.bctr[k];
+        if (tid == 0) *W.snap_c = *T.ctr;
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();
+            __hip_atomic_store(W.snap_stamp, W.snap_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    for (uint32_t j = tid; j < GT; j += FT) {
+        gkey[j] = 0ull;
+#pragma unroll
+        for (int w = 0; w < FT / 64; ++w) gbits[w][j] = 0ull;
+    }
+    pc[tid] = 0u;
+    // ---- key -> hash (as k_front: for fixed-width keys the key's words are requested together with the offsets) ----
+    uint32_t errcode = 0, off = 0, len = 0;
+    const uint8_t* key = nullptr;
+    unsigned long long gk = 0ull;
+    uint64_t h = 0;
+    uint64_t kw[4] = {0, 0, 0, 0};
+    Req mine;
+    mine.hits = mine.limit = mine.duration = mine.burst = mine.created_at = 0; mine.greg_expire = mine.greg_duration = 0;
+    mine.behavior = 0; mine.algorithm = 0; mine.is_owner = 0;
+    if (valid) {
+        uint32_t off_g = 0, len_g = 0;
+        bool spec = false;
+        if (!B.key_stride && !B.key_len && B.n >= 2) {
+            const uint32_t o0 = B.key_off[0], o1 = B.key_off[1], oend = B.key_off[B.n];
+            len_g = o1 - o0; off_g = o0 + g * len_g;
+            if (len_g != 0 && len_g < 32 && (uint64_t)off_g + 32 <= (uint64_t)oend + 8) {   // (the buffer is padded by 8 bytes)
+                spec = true;
+                const uint8_t* kp = B.key_bytes + off_g;
+                kw[0] = ld_key_word(kp); kw[1] = ld_key_word(kp + 8); kw[2] = ld_key_word(kp + 16); kw[3] = ld_key_word(kp + 24);
+            }
+        }
+        mine = load_req_nogreg(B, g);
+        off = key_off_of(B, g);
+        len = key_len_of(B, g, off);
+        key = B.key_bytes + off;
+        if (len == 0) errcode = IE_EMPTY_KEY;
+        else if (len > T.max_key) errcode = 7;
+        if (!errcode) {
+            if (!(spec && off == off_g && len == len_g)) {
+                spec = false;
+                if (len <= 16) { kw[0] = ld_key_word(key); kw[1] = len > 8 ? ld_key_word(key + 8) : 0ull; }
+            }
+            h = (spec ? xxhash64_words4(kw, len, 0) : xxhash64(key, len, 0)) & T.hash_mask;
+            gk = h ? h : 1ull;
+        }
+        tile_put(sreq, tid, mine);
+    }
+    soff[tid] = off; slen[tid] = len;
+    lds_barrier();
+    // ---- group the tile by hash (LDS table with per-wave member bitmaps, as k_front) ----
+    uint32_t gh = 0;
+    if (gk) {
+        gh = (uint32_t)((gk * 0x9E3779B97F4A7C15ull) >> (64 - GT_BITS));
+        for (;;) {
+            const unsigned long long old = atomicCAS(&gkey[gh], 0ull, gk);
+            if (old == 0ull || old == gk) break;
+            gh = (gh + 1) & (GT - 1);
+        }
+        atomicOr(&gbits[wave][gh], 1ull << lane);
+    }
+    lds_barrier();
+    uint32_t eq_before = 0, eq_total = 1, head_tid = tid;
+    if (gk) {
+        bool found_head = false;
+        eq_total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < FT / 64; ++w) {
+            const unsigned long long bw = gbits[w][gh];
+            const uint32_t c = __popcll(bw);
+            eq_total += c;
+            if (w < wave) eq_before += c;
+            else if (w == wave) eq_before += __popcll(bw & ((1ull << lane) - 1ull));
+            if (!found_head && bw) { head_tid = w * 64 + (uint32_t)__ffsll((unsigned long long)bw) - 1; found_head = true; }
+        }
+    }
+    const bool khead = valid && gk != 0ull && eq_before == 0;
+    const bool member = valid && gk != 0ull && eq_before != 0;
+    // heads: the group's accumulators, and a place among the tile's messages for this owner
+    uint32_t q = 0, qr = 0;
+    if (khead) {
+        uint32_t f = 0;
+        if ((mine.behavior >> 6) != 0u || mine.algorithm > 1u || ((mine.behavior & BH_GREGORIAN) && B.greg_expire && B.greg_duration)) f |= G_ODD;
+        if (len > 16) f |= G_LONG;
+        gfl[tid] = f; gcmin[tid] = mine.created_at; gcmax[tid] = mine.created_at;
+        q = owner_order(owner_of(T, W, h));
+        qr = atomicAdd(&pc[q], 1u);
+    }
+    lds_barrier();
+    // members: one key, one request shape per group — compared with the head on the exact key bytes and on every field
+    if (member) {
+        bool soft_leaky = false;
+        uint32_t f = 0;
+        const uint32_t df = req_diff_flags(B, g, tile * FT + head_tid, mine, tile_get(sreq, head_tid), soft_leaky);
+        if (df & SEG_NONUNIFORM) f |= G_NONUNIFORM;
+        if ((df & SEG_CREATED_DIFFERS) || soft_leaky) {
+            f |= G_CREATED;
+            atomicMin(&gcmin[head_tid], (long long)mine.created_at); atomicMax(&gcmax[head_tid], (long long)mine.created_at);
+        }
+        if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) f |= G_RETRY;
+        if (f) atomicOr(&gfl[head_tid], f);
+    }
+    // exclusive scan of the owners' group counts: where each owner's run starts in the tile's region
+    {
+        const uint32_t c = pc[tid];
+        const uint32_t incl = wave_incl_scan_u32(c);
+        if (lane == 63) wsum[wave] = incl;
+        lds_barrier();
+        uint32_t before = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < FT / 64; ++w) before += w < wave ? wsum[w] : 0u;
+        const uint32_t start = before + incl - c;
+        pstart[tid] = start;
+        W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid)] = start | (c << 16);
+    }
+    lds_barrier();
+    // heads: the message
+    if (khead) {
+        const uint32_t j = pstart[q] + qr;
+        sd[tid] = j;
+        uint32_t f = gfl[tid];
+        const int64_t cmin = gcmin[tid], cmax = gcmax[tid];
+        const int64_t dmin = wsub(cmin, B.now_ms);
+        const uint64_t span = (uint64_t)cmax - (uint64_t)cmin;
+        if (dmin < -131072 || dmin > 131071 || span > 255u) f |= G_CFAR;
+        const uint32_t shape = (mine.behavior & 63u) | ((mine.algorithm > 1u ? 2u : (uint32_t)mine.algorithm) << 6) | ((mine.is_owner ? 1u : 0u) << 8);
+        unsigned long long k0, k1;
+        if (len <= 16) {
+            k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
+            if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
+        } else { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
+        GMsg* m = &W.gmsg[(size_t)tile * FT + j];
+        ulonglong2* mq = (ulonglong2*)m;
+        mq[0] = make_ulonglong2(gk, k0);
+        mq[1] = make_ulonglong2(k1, (unsigned long long)mine.hits);
+        mq[2] = make_ulonglong2((unsigned long long)mine.limit, (unsigned long long)mine.duration);
+        mq[3] = make_ulonglong2((unsigned long long)mine.burst,
+                                gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : dmin, (f & G_CFAR) ? 0u : (uint32_t)span));
+    }
+    lds_barrier();
+    if (valid) {
+        if (errcode) W.did[g] = pd_pack(0, 0, errcode);
+        else W.did[g] = pd_pack(sd[head_tid], eq_before, 0);
+    }
+}
+
+__global__ __launch_bounds__(FT) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
+
+// ---- k_own ----------------------------------------------------------------------------------------------------------------
+constexpr int OW_MCAP = 1024;            // messages one round of an owner holds in LDS (more: the round splits by further hash bits)
+constexpr int OW_KCAP = 512;             // distinct keys of one round
+constexpr int OW_HT = 1024;              // LDS hash table of the round's keys
+constexpr int OW_CH = OW_MCAP / 64;      // 64-message chunks
+
+// SEG_* bits of a key from the G_* bits its groups raised, the number of groups and the created_at range over the groups
+GB_HD uint32_t own_seg_flags(uint32_t f, uint32_t groups, bool created_range) {
+    uint32_t sf = 0;
+    if (f & G_RETRY) sf |= SEG_RETRY;
+    if (f & G_NONUNIFORM) sf |= SEG_NONUNIFORM;
+    if ((f & G_ODD) && groups > 1) sf |= SEG_NONUNIFORM;
+    if ((f & G_CFAR) && (groups > 1 || (f & G_CREATED))) sf |= SEG_NONUNIFORM;
+    if ((f & G_CREATED) || created_range) sf |= SEG_CREATED_DIFFERS;
+    return sf;
+}
+
+// store the (<= 16-byte, zero-padded) key of a freshly claimed slot from its words
+__device__ __forceinline__ void key_store_words(const Table& T, uint64_t slot, unsigned long long k0, unsigned long long k1, uint32_t len) {
+    KeyCell* c = &T.buckets[slot].cell;
+    c->w[0] = k0; c->w[1] = k1;
+#pragma unroll
+    for (int i = 2; i < 7; ++i) c->w[i] = 0;
+    c->w[7] = (uint64_t)len << 48;
+}
+
+struct OwnKeyLoads { ulonglong2 de0; uint4 c0, c3; Rec rec; unsigned long long wk0, wk1, wmisc; long long wlimit, wduration; };
+
+__device__ __forceinline__ void own_body(const Table& T, const BatchView& B, const Work& W, const uint32_t p, const uint32_t ntiles) {
+    // phase 1 of a round: hash table of the round's keys + per-chunk sums; phase 2: the keys' records.  Same LDS.
+    __shared__ __attribute__((aligned(16))) unsigned char raw[OW_KCAP * 64];
+    unsigned long long* ktab = (unsigned long long*)raw;                                  // [OW_HT]      8 KB   hash (0 = free)
+    uint16_t* kidOf = (uint16_t*)(raw + OW_HT * 8);                                        // [OW_HT]      2 KB   slot -> key id
+    uint32_t* csum = (uint32_t*)(raw + OW_HT * 10);                                        // [OW_CH][OW_KCAP / 2]  16 KB  requests per (chunk, key), u16 pairs
+    GRec* krec = (GRec*)raw;                                                               // [OW_KCAP]   32 KB   (phase 2)
+    static_assert(OW_HT * 10 + OW_CH * (OW_KCAP / 2) * 4 <= OW_KCAP * 64, "phase 1 fits the records' space");
+    __shared__ uint16_t kwin[OW_KCAP];                  // key id -> list index of the message that installed the key
+    __shared__ unsigned long long khash[OW_KCAP];       // key id -> hash
+    __shared__ uint32_t kfl[OW_KCAP];                   // G_* over the key's groups
+    __shared__ uint32_t ktot[OW_KCAP];                  // requests | groups << 20
+    __shared__ long long kcmin[OW_KCAP], kcmax[OW_KCAP];
+    __shared__ uint32_t elist[OW_MCAP];                 // per message: hash-table slot, then key id 9 | members-1 8, then key id 9 | base 16
+    __shared__ uint16_t esrc[OW_MCAP];                  // per message: its index in gmsg / grec (tile << 8 | position)
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t nkeys, ins_n;
+    __shared__ uint32_t stk[40];                        // rounds to do: log2(split) << 24 | residue of the home position
+    __shared__ int sp;
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    uint32_t start = 0, c = 0;
+    if (t < ntiles) { const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16; }
+    const size_t mbase = (size_t)t * FT + start;
+    if (t == 0) { stk[0] = 0u; sp = 1; ins_n = 0u; }
+    for (;;) {
+        lds_barrier();
+        if (sp == 0) break;
+        const uint32_t cur = stk[sp - 1];
+        const uint32_t lg = cur >> 24, res = cur & 0xffffffu, smask = (1u << lg) - 1u;
+        lds_barrier();
+        if (t == 0) { sp--; nkeys = 0u; }
+        for (uint32_t j = t; j < OW_HT; j += 256) ktab[j] = 0ull;
+        for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2); j += 256) csum[j] = 0u;
+        // my run's messages of this round
+        uint32_t cm = c;
+        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((W.gmsg[mbase + r].hash >> 7) & T.mask) & smask) == res ? 1u : 0u; }
+        uint32_t pos, M;
+        {
+            const uint32_t incl = wave_incl_scan_u32(cm);
+            if (lane == 63) wsum[wave] = incl;
+            lds_barrier();                                            // (also: tables cleared, sp / nkeys settled)
+            uint32_t before = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4; ++w) before += w < wave ? wsum[w] : 0u;
+            pos = before + incl - cm;
+            M = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        }
+        if (M == 0) continue;
+        bool split = M > OW_MCAP;
+        if (!split) {
+            // ---- gather: hash -> LDS table slot, first come installs the key ----
+            uint32_t li = pos;
+            for (uint32_t r = 0; r < c; ++r) {
+                const unsigned long long hh = W.gmsg[mbase + r].hash;
+                if (lg && ((uint32_t)((hh >> 7) & T.mask) & smask) != res) continue;
+                uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 54) & (OW_HT - 1);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&ktab[s], 0ull, hh);
+                    if (old == 0ull) {
+                        const uint32_t kid = atomicAdd(&nkeys, 1u);
+                        if (kid < OW_KCAP) {
+                            kidOf[s] = (uint16_t)kid; kwin[kid] = (uint16_t)li; khash[kid] = hh; kfl[kid] = 0u; ktot[kid] = 0u;
+                            kcmin[kid] = INT64_MAX; kcmax[kid] = INT64_MIN;
+                        }
+                        break;
+                    }
+                    if (old == hh) break;
+                    s = (s + 1) & (OW_HT - 1);
+                }
+                elist[li] = s;
+                esrc[li] = (uint16_t)(mbase + r);
+                ++li;
+            }
+            lds_barrier();
+            split = nkeys > OW_KCAP;
+        }
+        if (split) {
+            // the round does not fit: two rounds on one more bit of the home position (nothing outside LDS was touched yet)
+            if (lg < 24) {
+                lds_barrier();
+                if (t == 0) { stk[sp] = ((lg + 1) << 24) | res; stk[sp + 1] = ((lg + 1) << 24) | (res | (1u << lg)); sp += 2; }
+            } else {
+                // (more than OW_KCAP keys on one home position: cannot happen below 2^24 slots; answered RETRY, never evaluated)
+                for (uint32_t r = 0; r < c; ++r) {
+                    const GMsg* m = &W.gmsg[mbase + r];
+                    if (((uint32_t)((m->hash >> 7) & T.mask) & smask) != res) continue;
+                    GRec* o = &W.grec[mbase + r];
+                    o->limit = o->duration = o->remaining = o->stamp = o->burst = o->expire_at = 0; o->smeta = 0; o->slot = 0;
+                    o->tail = gr_tail(SEG_RETRY, 0, 0, 1, (uint32_t)(mbase + r));
+                }
+            }
+            continue;
+        }
+        const uint32_t nk = nkeys;
+        // ---- the table lines of my first key are requested now and used after the messages have been compared ----
+        OwnKeyLoads L;
+        uint64_t kpos = 0;
+        const bool haskey = t < nk;
+        if (haskey) {
+            const uint64_t hh = khash[t];
+            kpos = (hh >> 7) & T.mask;
+            L.de0 = *(const ulonglong2*)&T.dir[kpos];
+            const Bucket* hb = &T.buckets[kpos];
+            const uint4* cw = (const uint4*)&hb->cell; L.c0 = cw[0]; L.c3 = cw[3];
+            L.rec = hb->rec;
+            const GMsg* wm = &W.gmsg[esrc[kwin[t]]];
+            L.wk0 = wm->key0; L.wk1 = wm->key1; L.wmisc = wm->misc; L.wlimit = wm->limit; L.wduration = wm->duration;
+        }
+        // ---- every message against the message that installed its key: exact key bytes, exact request shape ----
+        {
+            uint32_t li = pos;
+            for (uint32_t r = 0; r < c; ++r) {
+                const GMsg* m = &W.gmsg[mbase + r];
+                const ulonglong2* mq = (const ulonglong2*)m;
+                const ulonglong2 a0 = mq[0];
+                if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
+                const ulonglong2 a1 = mq[1], a2 = mq[2], a3 = mq[3];
+                const unsigned long long misc = a3.y;
+                const uint32_t kid = kidOf[elist[li]];
+                const uint32_t wl = kwin[kid];
+                uint32_t f = gm_flags(misc);
+                const uint32_t cnt = gm_cnt(misc);
+                if (wl != li) {
+                    const ulonglong2* wq = (const ulonglong2*)&W.gmsg[esrc[wl]];
+                    const ulonglong2 b0 = wq[0], b1 = wq[1], b2 = wq[2], b3 = wq[3];
+                    bool keq = gm_klen(misc) == gm_klen(b3.y);
+                    if (keq) {
+                        if (gm_klen(misc) != 31u) keq = a0.y == b0.y && a1.x == b1.x;
+                        else keq = req_key_equal_at(B, (uint32_t)a0.y, (uint32_t)(a0.y >> 32), (uint32_t)b0.y, (uint32_t)(b0.y >> 32));
+                    }
+                    if (!keq) f |= G_RETRY;
+                    if (a1.y != b1.y || a2.x != b2.x || a2.y != b2.y || a3.x != b3.x || gm_shape(misc) != gm_shape(b3.y)) f |= G_NONUNIFORM;
+                }
+                atomicOr(&kfl[kid], f);
+                atomicAdd(&ktot[kid], cnt | (1u << 20));
+                if (!(f & G_CFAR)) {
+                    const int64_t cmin = wadd(B.now_ms, gm_cmin_delta(misc));
+                    atomicMin(&kcmin[kid], (long long)cmin); atomicMax(&kcmax[kid], (long long)wadd(cmin, (int64_t)gm_cspan(misc)));
+                }
+                atomicAdd(&csum[(li >> 6) * (OW_KCAP / 2) + (kid >> 1)], cnt << (16 * (kid & 1)));
+                elist[li] = kid | ((cnt - 1u) << 9);
+                ++li;
+            }
+        }
+        lds_barrier();
+        // ---- rank base of every group: requests of its key in earlier tiles = in earlier messages of the list ----
+        for (uint32_t k = 0; k * 256 < M; ++k) {
+            const uint32_t e = k * 256 + t, chunk = e >> 6;
+            const bool act = e < M;
+            uint32_t kid = 0, cnt = 0, ctot = 0;
+            if (act) {
+                const uint32_t w = elist[e];
+                kid = w & 511u; cnt = ((w >> 9) & 255u) + 1u;
+                ctot = (csum[chunk * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
+            }
+            uint32_t base = 0;
+            unsigned long long mm = __ballot(act && ctot != cnt);       // keys with several groups inside this chunk: one wave scan each
+            while (mm) {
+                const int Lq = __ffsll(mm) - 1;
+                const uint32_t lk = __shfl(kid, Lq, 64);
+                const bool mine = act && kid == lk;
+                const uint32_t incl = wave_incl_scan_u32(mine ? cnt : 0u);
+                if (mine) base = incl - cnt;
+                mm &= ~__ballot(mine);
+            }
+            if (act) {
+                const uint32_t treq = ktot[kid] & 0xfffffu;
+                if (treq != ctot)
+                    for (uint32_t c2 = 0; c2 < chunk; ++c2) base += (csum[c2 * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
+                elist[e] = kid | (base << 9);
+            }
+        }
+        lds_barrier();                                               // phase 1 of the LDS space is dead from here
+        // ---- one table lookup per key, by the only workgroup that touches this key in this batch ----
+        int inserted = 0;
+        for (uint32_t kid = t; kid < nk; kid += 256) {
+            if (kid != t) {                                           // (more than 256 keys in a round: rare)
+                const uint64_t hh = khash[kid];
+                kpos = (hh >> 7) & T.mask;
+                L.de0 = *(const ulonglong2*)&T.dir[kpos];
+                const Bucket* hb = &T.buckets[kpos];
+                const uint4* cw = (const uint4*)&hb->cell; L.c0 = cw[0]; L.c3 = cw[3];
+                L.rec = hb->rec;
+                const GMsg* wm = &W.gmsg[esrc[kwin[kid]]];
+                L.wk0 = wm->key0; L.wk1 = wm->key1; L.wmisc = wm->misc; L.wlimit = wm->limit; L.wduration = wm->duration;
+            }
+            const unsigned long long tag = khash[kid];
+            const uint32_t klen = gm_klen(L.wmisc);
+            const uint32_t home = (uint32_t)kpos;
+            uint64_t ppos = kpos;
+            uint32_t slot = 0, errcode = 0;
+            bool cand = false, fresh = false;
+            Rec rec = L.rec;
+            uint4 c0 = L.c0, c3 = L.c3;
+            const uint8_t* lkey = nullptr; uint32_t llen = 0;
+            if (klen == 31u) { lkey = B.key_bytes + (uint32_t)L.wk0; llen = (uint32_t)(L.wk0 >> 32); }
+            for (uint32_t step = 0; step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
+                ulonglong2 de = L.de0;
+                if (step) de = *(const ulonglong2*)&T.dir[ppos];
+                unsigned long long tg = de.x;
+                if (tg == 0ull) {
+                    const unsigned long long old = atomicCAS(&T.dir[ppos].tag, 0ull, tag);
+                    if (old == 0ull) {                                // new key: this thread inserts it
+                        slot = (uint32_t)ppos; cand = true; fresh = true; inserted++;
+                        if (klen != 31u) key_store_words(T, ppos, L.wk0, L.wk1, klen);
+                        else if (!key_store(T, ppos, lkey, llen)) { errcode = 6; cand = false; }
+                        T.dir[ppos].meta = META_READY;               // (nobody else can be looking for this tag during this launch)
+                        break;
+                    }
+                    tg = old;
+                }
+                if (tg == tag) { slot = (uint32_t)ppos; cand = true; break; }
+            }
+            if (!cand && !errcode) errcode = 6;                       // probe bound exceeded: table full
+            uint32_t sf = 0;
+            if (cand && !fresh) {
+                if (slot != home) {
+                    const Bucket* bk = &T.buckets[slot];
+                    const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c3 = cw[3];
+                    rec = bk->rec;
+                }
+                bool eq;
+                if (klen != 31u) {
+                    eq = (((uint64_t)c0.y << 32) | c0.x) == L.wk0 && (((uint64_t)c0.w << 32) | c0.z) == L.wk1 && (c3.w >> 16) == klen;
+                } else {
+                    eq = key_equal(T, slot, lkey, llen);
+                }
+                if (!eq) sf |= SEG_RETRY;                             // a 64-bit hash collision with a resident key: careful round
+            }
+            if (fresh || !cand) rec_clear(rec);
+            const uint32_t tot = ktot[kid];
+            const uint32_t groups = tot >> 20;
+            const long long cmin = kcmin[kid], cmax = kcmax[kid];
+            sf |= own_seg_flags(kfl[kid], groups, cmin < cmax);
+            if ((sf & SEG_CREATED_DIFFERS) && !(sf & SEG_NONUNIFORM) && gm_algo(L.wmisc) == ALGO_LEAKY) {
+                // requests of a leaky key stamped differently: the run is uniform only if no request of it leaks and none lets the
+                // bucket look expired to the ones behind it (leaky_created_harmless, monotone in created_at while nothing wraps)
+                Req rq; rq.hits = 0; rq.limit = L.wlimit; rq.duration = L.wduration; rq.burst = 0; rq.greg_expire = rq.greg_duration = 0;
+                rq.behavior = gm_behavior(L.wmisc); rq.algorithm = ALGO_LEAKY; rq.is_owner = 1;
+                bool ok = !(kfl[kid] & G_CFAR);
+                const int64_t d0 = wsub(cmin, rec.stamp), d1 = wsub(cmax, rec.stamp);
+                ok = ok && d0 <= d1 && (uint64_t)d1 - (uint64_t)d0 == (uint64_t)cmax - (uint64_t)cmin;
+                ok = ok && wadd(cmax, rq.duration) >= wadd(cmin, rq.duration);
+                if (ok) { rq.created_at = cmax; ok = leaky_created_harmless(rec, rq, B.now_ms); }
+                if (ok) { rq.created_at = cmin; ok = leaky_created_harmless(rec, rq, B.now_ms); }
+                if (!ok) sf |= SEG_NONUNIFORM;
+            }
+            GRec kr;
+            kr.limit = rec.limit; kr.duration = rec.duration; kr.remaining = rec.remaining; kr.stamp = rec.stamp; kr.burst = rec.burst;
+            kr.expire_at = rec.expire_at;
+            kr.smeta = pack_smeta(rec, 1); kr.slot = slot;
+            const uint32_t seg = esrc[kwin[kid]];
+            kr.tail = gr_tail(sf | (errcode ? SEG_ERR : 0u), errcode, 0, tot & 0xfffffu, seg);
+            if (rec.invalid_at != 0) W.sinv[seg] = rec.invalid_at;
+            krec[kid] = kr;
+        }
+        lds_barrier();
+        // ---- every group gets its record: the key's, with the group's base ----
+        for (uint32_t k = 0; k * 256 < M; ++k) {
+            const uint32_t e = k * 256 + t;
+            if (e < M) {
+                const uint32_t w = elist[e];
+                const uint32_t kid = w & 511u, base = w >> 9;
+                const ulonglong2* kq = (const ulonglong2*)&krec[kid];
+                ulonglong2 q0 = kq[0], q1 = kq[1], q2 = kq[2], q3 = kq[3];
+                q3.y |= (unsigned long long)(base & 0xffffu) << 16;
+                const uint32_t src = esrc[e];
+                ulonglong2* o = (ulonglong2*)&W.grec[src];
+                o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+                if ((uint32_t)q3.y & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) {   // the walk's map: which tiles hold the segment, and as which group
+                    const uint32_t seg = (uint32_t)(q3.y >> 48), tile = src >> 8;
+                    atomicOr(&W.segtiles[(size_t)seg * 4 + (tile >> 6)], 1ull << (tile & 63));
+                    W.tilerow[(size_t)seg * FT_MAX_TILES + tile] = (uint16_t)(src & 255u);
+                }
+            }
+        }
+        if (inserted) atomicAdd(&ins_n, (uint32_t)inserted);
+    }
+    if (t == 0 && ins_n) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins_n);
+}
+
+__global__ __launch_bounds__(256) void k_own(Table T, BatchView B, Work W, uint32_t ntiles) { own_body(T, B, W, blockIdx.x, ntiles); }
+
+// ---- k_eval3 --------------------------------------------------------------------------------------------------------------
+// Request order, workgroup = tile.  As k_eval2 from the evaluation on; what differs is where a request learns its segment:
+// packed word -> its group's record (ONE sector: bucket, slot, flags, base, total), no bitmaps, no LDS pre-pass, no barrier
+// before the evaluation.  The serial walk of a heterogeneous segment follows the segment's tile map (Work::segtiles, tilerow).
+__device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t tile) {
+    const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
+    __shared__ unsigned long long cnt[4];
+    const uint32_t i = tile * 256 + threadIdx.x;
+    const bool live = i < B.n;
+    const uint32_t dl = live ? W.did[i] : 0u;
+    const uint32_t gj = dl & 0xffu, lr = (dl >> 8) & 0xffu, derr = (dl >> 16) & 0xffu;
+    uint32_t sf = 0, slot = 0, smeta = 0, base = 0, total = 1, d = 0, rerr = 0; Req r; Rec s0;
+    rec_clear(s0);
+    if (live) {
+        r = load_req_nogreg(B, i);
+        if (!derr) {
+            const ulonglong2* q = (const ulonglong2*)&W.grec[(size_t)tile * 256 + gj];   // one 64-byte sector per (key, tile) group
+            const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            s0.limit = (int64_t)q0.x; s0.duration = (int64_t)q0.y; s0.remaining = (int64_t)q1.x; s0.stamp = (int64_t)q1.y;
+            s0.burst = (int64_t)q2.x; s0.expire_at = (int64_t)q2.y;
+            smeta = (uint32_t)q3.x; slot = (uint32_t)(q3.x >> 32);
+            s0.meta = smeta_meta(smeta);
+            sf = (uint32_t)q3.y & 0xffu; rerr = (uint32_t)(q3.y >> 8) & 0xffu;
+            base = (uint32_t)(q3.y >> 16) & 0xffffu; total = ((uint32_t)(q3.y >> 32) & 0xffffu) + 1u; d = (uint32_t)(q3.y >> 48);
+        }
+    }
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
+    int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
+    if (live) {
+        const uint32_t rank = base + lr;
+        const bool flagged = (sf & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) != 0u;
+        if (derr) {
+            store_err(R, i, (uint8_t)derr);
+        } else if (sf & SEG_ERR) {
+            store_err(R, i, (uint8_t)rerr);
+        } else if (sf & SEG_RETRY) {
+            store_err(R, i, IE_RETRY);
+            atomicAdd(&T.ctr->retries, 1ull);
+        } else {
+            if (smeta & SM_HAS_INVALID) s0.invalid_at = W.sinv[d];
+            bool parallel = !(sf & SEG_NONUNIFORM);
+            if (parallel && (sf & SEG_CREATED_DIFFERS)) {
+                // requests that differ only in created_at: a live token bucket never reads it; for a leaky bucket the key's owner
+                // has checked that no request of the run leaks (k_own) — both decisions are the same for every request of the segment
+                parallel = !(T.gpend && (r.behavior & BH_GLOBAL));
+                if (parallel && r.algorithm != ALGO_LEAKY) parallel = created_at_irrelevant(s0, r, B.now_ms);
+            }
+            Rec after; Resp out;
+            uint32_t ev = 0;
+            bool done = false;
+            if (parallel) {
+                if (token_fast_ok(s0, r, B.now_ms)) { ev = token_fast(s0, r, rank, out, after); done = true; }
+                else if (leaky_fast(s0, r, B.now_ms, rank, out, after, ev)) done = true;
+            }
+            const bool walk = !parallel && rank == 0;
+            if ((parallel && !done) || walk) {
+                Req cur = r;
+                if (parallel) {                                          // the calendar values are loaded only here
+                    if (B.greg_expire && B.greg_duration) { cur.greg_expire = B.greg_expire[i]; cur.greg_duration = B.greg_duration[i]; }
+                    else if (cur.behavior & BH_GREGORIAN) greg_fill(B.now_ms, cur.duration, cur.greg_expire, cur.greg_duration);
+                }
+                after = s0;
+                uint64_t k = rank;
+                Rec prev2; rec_clear(prev2);
+                bool have_prev2 = false;
+                // walk iterator: the tiles holding the segment in order (its tile map), inside a tile the requests of the segment's group
+                uint32_t wv = 0, tt = 0, q = FT, tj = 0;
+                unsigned long long mm = 0ull;
+                for (;;) {
+                    uint32_t j = i;
+                    if (walk) {
+                        bool found = false, end = false;
+                        while (!found && !end) {
+                            if (q < FT && tt * FT + q < B.n) {
+                                const uint32_t id = W.did[(size_t)tt * FT + q];
+                                if ((id & 0xffu) == tj && ((id >> 16) & 0xffu) == 0u) { j = tt * FT + q; found = true; }
+                                q++;
+                            } else {
+                                while (mm == 0ull && wv < 4) { mm = W.segtiles[(size_t)d * 4 + wv]; tt = wv * 64; wv++; }
+                                if (mm == 0ull) end = true;
+                                else {
+                                    const uint32_t bpos = (uint32_t)__ffsll(mm) - 1u; mm &= mm - 1ull; tt = (tt & ~63u) + bpos; q = 0;
+                                    tj = W.tilerow[(size_t)d * FT_MAX_TILES + tt];
+                                }
+                            }
+                        }
+                        if (end) break;
+                        cur = load_req(B, j);
+                    }
+                    const Rec before = after;
+                    const uint32_t e1 = apply(after, cur, B.now_ms, out);
+                    if (walk) {
+                        store_resp(R, j, out);
+                        store_events(W, j, e1, after);
+                        if (out.err == 0) queue_global(T, slot, cur, 1);
+                        c_over += (e1 & EV_OVER) ? 1 : 0; c_hit += (e1 & EV_HIT) ? 1 : 0; c_miss += (e1 & EV_MISS) ? 1 : 0;
+                        continue;
+                    }
+                    if (k == 0) { ev = e1; break; }
+                    k--;
+                    if (k == 0) continue;
+                    if (rec_eq(after, before)) { k = 0; continue; }                       // fixed point
+                    if (have_prev2 && rec_eq(after, prev2)) {                             // period 2
+                        if (k & 1) after = before;
+                        k = 0;
+                        continue;
+                    }
+                    prev2 = before; have_prev2 = true;
+                    if (pure_subtract(before, after, cur, B.now_ms)) {
+                        const uint32_t kind = rec_kind(after);
+                        const int64_t n = kind == K_TOKEN ? after.remaining : go_f2i(bits2f(after.remaining));
+                        if (n > 0) {
+                            const uint64_t m = (uint64_t)(n - 1) / (uint64_t)cur.hits;
+                            const uint64_t jj = m < k ? m : k;
+                            if (jj > 0) {
+                                const int64_t dec = (int64_t)(jj * (uint64_t)cur.hits);   // <= n-1, exact
+                                if (kind == K_TOKEN) after.remaining -= dec;
+                                else after.remaining = f2bits(bits2f(after.remaining) - (double)dec);
+                                k -= jj;
+                                have_prev2 = false;
+                            }
+                        }
+                    }
+                }
+            }
+            if (parallel) {
+                store_resp(R, i, out);
+                store_events(W, i, ev, after);
+                c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+            }
+            if ((parallel && rank == total - 1) || walk) {
+                after.pad = W.touch;                                  // last touch (LRU order for eviction)
+                T.buckets[slot].rec = after;
+                c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
+            }
+        }
+        // the first request of a segment that carries a tile map clears it (walked or not): the map is all zero between batches
+        if (!derr && flagged && rank == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) W.segtiles[(size_t)d * 4 + w] = 0ull;
+        }
+    }
+    {
+        const int w_over = wave_sum(c_over), w_hit = wave_sum(c_hit), w_miss = wave_sum(c_miss), w_size = wave_sum(c_size);
+        lds_barrier();                                               // (cnt zeroed)
+        if ((threadIdx.x & 63) == 0 && (w_over | w_hit | w_miss | w_size)) {
+            if (w_over) atomicAdd(&cnt[0], (unsigned long long)w_over);
+            if (w_hit) atomicAdd(&cnt[1], (unsigned long long)w_hit);
+            if (w_miss) atomicAdd(&cnt[2], (unsigned long long)w_miss);
+            if (w_size) atomicAdd(&cnt[3], (unsigned long long)(long long)w_size);
+        }
+        lds_barrier();
+        if (threadIdx.x == 0 && (cnt[0] | cnt[1] | cnt[2] | cnt[3])) {
+            BlockCounters* bc = &T.bctr[tile];
+            bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
+        }
+    }
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
+    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    eval3_body(*a, blockIdx.x);
+}
+
+}  // namespace guber

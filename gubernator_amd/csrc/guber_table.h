@@ -107,6 +107,7 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMP2(k) do {} while (0)
 #define GB_STAMPW(k) do {} while (0)
 #endif
+struct GMsg; struct GRec;
 struct Work {
     // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
@@ -147,6 +148,13 @@ struct Work {
     // are before the batch, to device-visible host memory and stamps snap_seq when done (guber_engine.hip maintain())
     uint32_t snap_seq, snap_n;
     DevCounters* snap_c; BlockCounters* snap_b; uint32_t* snap_stamp;
+    // owner-partitioned pipeline (guber_kernels_part.h): per (key, tile) group one message from the tile to the key's owner
+    // workgroup and one record back; per (tile, owner) where the tile's messages for that owner start and how many there are
+    GMsg* gmsg;                         // [cap] tile t's messages: gmsg[t * FT ..], sorted by owner
+    uint32_t* gse;                      // [FT_MAX_TILES][PT_PARTS] start | count << 16
+    GRec* grec;                         // [cap] the owner's answer to message i: bucket before the batch, slot, flags, rank base, total
+    unsigned long long* segtiles;       // [cap][4] tiles holding a segment whose requests are walked serially (all zero between batches)
+    uint32_t pshift;                    // owner of a key = its home position >> pshift
 };
 
 // ---------------------------------------------------------------------------------------------

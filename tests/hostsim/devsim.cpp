@@ -1,0 +1,193 @@
+// devsim.cpp — TEST-ONLY: runs the engine's batch-pipeline KERNEL SOURCE (gubernator_amd/csrc/guber_kernels.h and
+// guber_kernels_part.h, compiled for the host against tests/hostsim/fakehip) one workgroup at a time, every device thread a
+// cooperative fiber, on a table in host memory — so that k_part / k_own / k_eval3 and k_front / k_eval2 can be differential-tested
+// against the oracle on a machine without a GPU (tests/test_kernels_devsim.py).  It checks the kernels' LOGIC (grouping, ranks,
+// flags, probing, the serial walk); it cannot see memory-ordering bugs or races between workgroups.  Nothing in the product links it.
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <string>
+
+#define GUBER_KERNELS_PIPELINES_ONLY
+#include "../../gubernator_amd/csrc/guber_kernels.h"
+#include "../../include/guber_gpu.h"
+
+// ---- the fiber runtime behind fakehip ------------------------------------------------------------------------------------
+namespace fakehip {
+State S;
+static std::function<void()> g_body;
+static constexpr size_t kStack = 256 * 1024;
+static int g_readers[16][2];
+
+static int live_count() { int n = 0; for (auto& f : S.fib) n += f.done ? 0 : 1; return n; }
+static int live_in_wave(int w) {
+    int n = 0;
+    for (int l = 0; l < kWave; ++l) { const size_t i = (size_t)w * kWave + l; if (i < S.fib.size() && !S.fib[i].done) n++; }
+    return n;
+}
+void yield() { Fiber& f = S.fib[S.cur]; swapcontext(&f.ctx, &S.sched); }
+void barrier() {
+    const unsigned long long gen = S.bar_gen;
+    S.bar_waiting++;
+    for (;;) {
+        if (S.bar_gen != gen) break;
+        if (S.bar_waiting == live_count()) { S.bar_waiting = 0; S.bar_gen++; break; }
+        S.fib[S.cur].waiting = 1;
+        yield();
+    }
+    S.fib[S.cur].waiting = 0;
+    S.progress++;
+}
+unsigned long long wave_exchange(unsigned long long v, int, unsigned long long* all, unsigned long long* live_mask) {
+    const int tid = S.cur, w = tid / kWave, lane = tid % kWave;
+    const int buf = (int)(S.lane_gen[tid]++ & 1);
+    S.wx[w][buf][lane] = v;
+    S.warrived[w][buf]++;
+    while (S.warrived[w][buf] < live_in_wave(w)) { S.fib[tid].waiting = 2; yield(); }
+    S.fib[tid].waiting = 0;
+    S.progress++;
+    unsigned long long lm = 0;
+    for (int l = 0; l < kWave; ++l) {
+        const size_t i = (size_t)w * kWave + l;
+        if (i < S.fib.size() && !S.fib[i].done) lm |= 1ull << l;
+        if (all) all[l] = S.wx[w][buf][l];
+    }
+    if (live_mask) *live_mask = lm;
+    // the last reader re-arms the buffer (everybody has arrived, so nobody can be two operations ahead)
+    if (++g_readers[w][buf] == live_in_wave(w)) { g_readers[w][buf] = 0; S.warrived[w][buf] = 0; }
+    return 0;
+}
+static void trampoline() {
+    g_body();
+    S.fib[S.cur].done = true;
+    S.progress++;
+    swapcontext(&S.fib[S.cur].ctx, &S.sched);
+}
+static std::vector<char*> g_stacks;
+template <class F> void launch(dim3 grid, dim3 block, const void* kernarg, F body) {
+    g_body = body;
+    S.gdim = grid; S.bdim = block; S.kernarg = kernarg;
+    while (g_stacks.size() < block.x) g_stacks.push_back((char*)malloc(kStack));
+    for (uint32_t b = 0; b < grid.x; ++b) {
+        S.bidx = dim3(b);
+        S.fib.assign(block.x, Fiber{});
+        S.bar_waiting = 0;
+        memset(S.warrived, 0, sizeof(S.warrived)); memset(S.lane_gen, 0, sizeof(S.lane_gen)); memset(g_readers, 0, sizeof(g_readers));
+        for (uint32_t t = 0; t < block.x; ++t) {
+            Fiber& f = S.fib[t];
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = g_stacks[t]; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = &S.sched;
+            f.done = false; f.waiting = 0;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        // run-to-yield, round robin (S.chaos reverses the order of every other pass and yields inside atomics)
+        unsigned pass = 0;
+        for (;;) {
+            const unsigned long long before = S.progress;
+            bool any = false;
+            for (uint32_t k = 0; k < block.x; ++k) {
+                const uint32_t t = (S.chaos && (pass & 1)) ? block.x - 1 - k : k;
+                if (S.fib[t].done) continue;
+                any = true;
+                S.cur = (int)t; S.tidx = dim3(t);
+                swapcontext(&S.sched, &S.fib[t].ctx);
+            }
+            if (!any) break;
+            if (S.progress == before) {
+                fprintf(stderr, "[devsim] deadlock in workgroup %u: ", b);
+                for (uint32_t t = 0; t < block.x; ++t) if (!S.fib[t].done) fprintf(stderr, "%u:%d ", t, S.fib[t].waiting);
+                fprintf(stderr, "\n");
+                abort();
+            }
+            pass++;
+        }
+    }
+}
+}  // namespace fakehip
+
+using namespace guber;
+
+// ---- a table and the per-batch work arrays in host memory, laid out as guber_engine_create does -----------------------------
+struct DevSim {
+    uint64_t slots = 0; uint32_t max_batch = 0, cap = 0;
+    Table T{}; Work W{};
+    std::vector<DirEntry> dir; std::vector<Bucket> buckets; std::vector<uint8_t> arena; DevCounters ctr{}; std::vector<BlockCounters> bctr;
+    std::vector<uint32_t> u32; std::vector<uint8_t> rflags; std::vector<unsigned long long> tilemask, claims, segtiles; std::vector<SegRec> srec;
+    std::vector<int64_t> sinv; std::vector<uint16_t> tilerow; std::vector<uint32_t> did2, did3, gse; std::vector<GMsg> gmsg; std::vector<GRec> grec;
+    uint32_t epoch16 = 0, fast_batches = 0, fast_prev_n = 0, touch = 0, claims_cells = 0;
+};
+
+extern "C" {
+void* ds_create(uint64_t slots, uint32_t max_batch, int weak_hash) {
+    DevSim* d = new DevSim();
+    uint64_t s = 1024; while (s < slots) s <<= 1;
+    d->slots = s; d->max_batch = max_batch; d->cap = (max_batch + 255u) & ~255u;
+    d->dir.assign(s, DirEntry{0, 0}); d->buckets.resize(s); memset(d->buckets.data(), 0, s * sizeof(Bucket));
+    d->arena.assign(std::max<uint64_t>(s * 16, 1 << 20) + 64, 0); d->bctr.assign((d->cap + 255) / 256, BlockCounters{0, 0, 0, 0});
+    d->u32.assign((size_t)d->cap * 2, 0); d->rflags.assign(d->cap, 0);
+    d->tilemask.assign((size_t)2 * d->cap * FT_WORDS, 0); d->srec.resize(d->cap); memset(d->srec.data(), 0, d->cap * sizeof(SegRec));
+    d->sinv.assign(d->cap, 0); d->tilerow.assign((size_t)d->cap * FT_MAX_TILES, 0); d->did2.assign((size_t)2 * d->cap, 0); d->did3.assign(d->cap, 0);
+    d->claims_cells = 1024; while (d->claims_cells < 4 * d->cap) d->claims_cells <<= 1;
+    d->claims.assign(d->claims_cells, 0);
+    d->gmsg.resize(d->cap); d->grec.resize(d->cap); d->gse.assign((size_t)FT_MAX_TILES * PT_PARTS, 0); d->segtiles.assign((size_t)d->cap * 4, 0);
+    memset(&d->T, 0, sizeof(Table)); memset(&d->W, 0, sizeof(Work));
+    d->T.dir = d->dir.data(); d->T.buckets = d->buckets.data(); d->T.arena = d->arena.data(); d->T.mask = s - 1;
+    d->T.arena_cap = d->arena.size() - 64; d->T.ctr = &d->ctr; d->T.bctr = d->bctr.data();
+    d->T.max_probe = (uint32_t)std::min<uint64_t>(s, 1u << 12); d->T.max_key = 1024;
+    d->T.hash_mask = weak_hash ? 0x1f80ull : ~0ull;
+    d->W.slot = d->u32.data(); d->W.rflags = d->rflags.data();
+    d->W.seg_tilemask = d->tilemask.data(); d->W.srec = d->srec.data(); d->W.sinv = d->sinv.data(); d->W.tilerow = d->tilerow.data();
+    d->W.claims = d->claims.data();
+    d->W.gmsg = d->gmsg.data(); d->W.grec = d->grec.data(); d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
+    uint32_t lg = 0; while ((1ull << lg) < s) lg++;
+    d->W.pshift = lg - 8;
+    return d;
+}
+void ds_destroy(void* h) { delete (DevSim*)h; }
+void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
+
+// pipeline 0: k_front + k_eval2 (careful = the retry round), 1: k_part + k_own + k_eval3
+int ds_eval(void* h, const guber_batch_t* b, guber_result_t* r, int pipeline, int careful) {
+    DevSim* d = (DevSim*)h;
+    const uint32_t n = b->n;
+    if (n == 0) return 0;
+    if (n > d->max_batch || n > 65536) return -1;
+    BatchView B{n, d->cap, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
+    B.key_stride = 0; B.key_len = nullptr;
+    ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
+    Work W = d->W;
+    W.touch = d->touch = (d->touch + 1) & 0x7fffffffu;
+    const uint32_t tiles = (n + FT - 1) / FT;
+    if (pipeline == 0) {
+        W.careful = careful ? 1u : 0u;
+        if (++d->epoch16 > 0xffffu) d->epoch16 = 1;
+        W.epoch16 = d->epoch16;
+        uint32_t cells = 1024; while (cells < 4 * n && cells < d->claims_cells) cells <<= 1;
+        W.cmask = cells - 1;
+        W.parity = d->fast_batches & 1u;
+        W.did = d->did2.data() + (size_t)W.parity * d->cap;
+        W.did_prev = d->did2.data() + (size_t)(W.parity ^ 1u) * d->cap;
+        W.clear_n = d->fast_prev_n;
+        fakehip::launch(dim3(tiles), dim3(FT), nullptr, [&] { k_front(d->T, B, W); });
+        EvalArgs A{d->T, B, R, W};
+        fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval2(A); });
+        d->fast_batches++; d->fast_prev_n = n;
+    } else {
+        W.did = d->did3.data();
+        fakehip::launch(dim3(tiles), dim3(FT), nullptr, [&] { k_part(d->T, B, W); });
+        fakehip::launch(dim3(PT_PARTS), dim3(256), nullptr, [&] { k_own(d->T, B, W, tiles); });
+        EvalArgs A{d->T, B, R, W};
+        fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
+        for (auto v : d->segtiles) if (v) return -2;      // the walk's tile maps must be all zero between batches
+    }
+    return 0;
+}
+// over, hits, misses, size, retries, tags_used
+void ds_counters(void* h, long long* out) {
+    DevSim* d = (DevSim*)h;
+    long long o = (long long)d->ctr.over, hi = (long long)d->ctr.hits, mi = (long long)d->ctr.misses, sz = d->ctr.size;
+    for (auto& bc : d->bctr) { o += (long long)bc.over; hi += (long long)bc.hits; mi += (long long)bc.misses; sz += bc.size_delta; }
+    out[0] = o; out[1] = hi; out[2] = mi; out[3] = sz; out[4] = (long long)d->ctr.retries; out[5] = (long long)d->ctr.tags_used;
+}
+}

@@ -1,0 +1,166 @@
+"""The batch pipelines' KERNEL SOURCE (gubernator_amd/csrc/guber_kernels.h: k_front / k_eval2, guber_kernels_part.h: k_part /
+k_own / k_eval3) compiled for the host against tests/hostsim/fakehip and run one workgroup at a time, every device thread a
+cooperative fiber, against the oracle — on a machine without a GPU.  A de-risking aid for the kernels' logic (grouping, rank
+bases, flags, probing and inserting, the serial walk of heterogeneous segments); the parity claim itself is the `-m gpu` suite."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import streams
+from support import ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle, assert_results_equal, gregorian
+
+HS = os.path.join(ROOT, "tests", "hostsim")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
+    L = C.CDLL(os.path.join(HS, "libdevsim.so"))
+    L.ds_create.restype = C.c_void_p
+    L.ds_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int]
+    L.ds_destroy.argtypes = [C.c_void_p]
+    L.ds_eval.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int, C.c_int]
+    L.ds_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.ds_chaos.argtypes = [C.c_uint32]
+    return L
+
+
+class Sim:
+    def __init__(self, lib, slots=4096, max_batch=4096, weak=0, pipeline=1):
+        self.lib, self.pipeline = lib, pipeline
+        self.h = lib.ds_create(slots, max_batch, weak)
+
+    def eval(self, batch, careful=0):
+        res = HostResult(batch.n)
+        rc = self.lib.ds_eval(self.h, C.byref(batch.c), C.byref(res.c), self.pipeline, careful)
+        assert rc == 0, rc
+        return res
+
+    def counters(self):
+        out = (C.c_longlong * 6)()
+        self.lib.ds_counters(self.h, out)
+        return tuple(out)
+
+    def close(self):
+        self.lib.ds_destroy(self.h)
+
+
+def sub_batch(b, idx):
+    """the requests `idx` of batch b as a batch of their own (the engine's retry round does the same by index list)"""
+    keys = [bytes(b.key_bytes[b.key_off[i]:b.key_off[i + 1]]) for i in idx]
+    def col(a, dt=None):
+        return None if a is None else np.asarray(a)[idx]
+    return HostBatch(keys, col(b.hits), col(b.limit), col(b.duration), b.now_ms, burst=col(b.burst), created_at=col(b.created_at),
+                     algorithm=col(b.algorithm), behavior=col(b.behavior), is_owner=col(b.is_owner),
+                     greg_expire=col(b.greg_expire), greg_duration=col(b.greg_duration))
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_adversarial_streams_through_the_kernel_source(lib, pipeline, seed):
+    """every branch of algorithms.go, duplicate-heavy keys, mixed request shapes: element-wise equal to the oracle, counters too"""
+    sim, orc = Sim(lib, pipeline=pipeline), Oracle()
+    for k, b in enumerate(streams.adversarial_batches(seed, 10, 1500, greg_fn=gregorian)):
+        want, got = orc.eval(b), sim.eval(b)
+        assert_results_equal(got, want, f"seed {seed} batch {k}")
+    o, hi, mi, sz, retries, _ = sim.counters()
+    assert retries == 0
+    co = orc.counters()
+    assert (o, hi, mi) == (co[0], co[1], co[2]) and sz == orc.size()
+    sim.close()
+
+
+def test_zipf_batches_with_hot_keys_spanning_every_tile(lib):
+    """5000-request Zipf batches over 3000 keys (hot keys in all 20 tiles: rank bases across tiles and chunks), token and leaky,
+    the clock stepping so that buckets leak, expire and renew"""
+    sim, orc = Sim(lib, slots=16384, max_batch=5000), Oracle()
+    table = streams.key_table(3000)
+    z = streams.ZipfSampler(3000, seed=7)
+    now = streams.NOW0
+    for k in range(8):
+        ids = z.draw(5000)
+        b = streams.bench_batch(table, ids, now, algorithm=k & 1, limit=40, duration=3000)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
+        now += [1, 700, 1, 3500, 2, 900, 1, 1][k]
+    assert sim.counters()[:3] == orc.counters()[:3]
+    sim.close()
+
+
+def test_owner_rounds_split_when_a_round_does_not_fit(lib):
+    """a table so small that all keys share ONE owner: 2304 distinct keys in a batch (> OW_MCAP messages, > OW_KCAP keys) force the
+    owner's round to split by further bits of the home position, repeatedly"""
+    sim, orc = Sim(lib, slots=1 << 20, max_batch=2304), Oracle()
+    # keys whose home positions all fall into owner 0: pick them by hash
+    from support import oracle_lib
+    ol = oracle_lib()
+    keys, i = [], 0
+    while len(keys) < 700:
+        k = b"own_%d" % i
+        i += 1
+        if ((ol.oracle_xxhash64(k, len(k), 0) >> 7) & ((1 << 20) - 1)) >> 12 == 0:
+            keys.append(k)
+    rng = np.random.default_rng(5)
+    now = streams.NOW0
+    for rnd in range(3):
+        ids = np.concatenate([np.arange(700), rng.integers(0, 700, 1604)])
+        rng.shuffle(ids)
+        b = HostBatch([keys[j] for j in ids], 1, 5, 60000, now + rnd)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"round {rnd}")
+    sim.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_hash_collisions_are_reported_and_resolved_by_the_careful_round(lib, pipeline):
+    """6 significant hash bits: distinct keys share hashes; the pipelines answer RETRY for those and nothing else, and the careful
+    round of the two-launch pipeline (what the engine re-runs them through) gives the oracle's answers"""
+    sim, fix, orc = Sim(lib, weak=1, pipeline=pipeline), None, Oracle()
+    rng = np.random.default_rng(11)
+    keys = [b"col_%d" % i for i in range(300)]
+    now = streams.NOW0
+    retried = 0
+    for rnd in range(4):
+        ids = rng.integers(0, 300, 900)
+        b = HostBatch([keys[j] for j in ids], 1, 50, 60000, now + rnd)
+        # the engine's way (eval_batch_host_locked): the batch, then careful rounds over what was answered RETRY until nothing is;
+        # the oracle sees the requests in the order they were really applied
+        pending, rounds = np.arange(b.n), 0
+        while len(pending):
+            sb = sub_batch(b, pending)
+            if rounds == 0:
+                got = sim.eval(sb)
+            else:
+                simc = Sim.__new__(Sim); simc.lib, simc.pipeline, simc.h = lib, 0, sim.h
+                got = simc.eval(sb, careful=1)
+            err = np.asarray(got.err)
+            ok = np.nonzero(err != 5)[0]
+            assert len(ok), "a round must answer something"
+            assert_results_equal(_take(got, ok), orc.eval(sub_batch(sb, ok)), f"round {rnd}.{rounds}")
+            pending = pending[np.nonzero(err == 5)[0]]
+            retried += len(pending)
+            rounds += 1
+            assert rounds < 64
+    assert retried > 0
+    sim.close()
+
+
+def _take(res, idx):
+    out = HostResult(len(idx))
+    for name in ("status", "limit", "remaining", "reset_time", "err"):
+        getattr(out, name)[:] = np.asarray(getattr(res, name))[idx]
+    return out
+
+
+def test_scheduling_order_does_not_matter(lib):
+    """the same stream with the fibers scheduled in alternating order and yielding inside atomics: same answers (catches a missing
+    barrier between an LDS write and its readers)"""
+    lib.ds_chaos(1)
+    try:
+        sim, orc = Sim(lib), Oracle()
+        for k, b in enumerate(streams.adversarial_batches(9, 6, 1200, greg_fn=gregorian)):
+            assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
+        sim.close()
+    finally:
+        lib.ds_chaos(0)
