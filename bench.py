@@ -60,8 +60,12 @@ BYTES_PER_DECISION = {"token": 149, "leaky": 173}
 # split of the algorithmic bytes over the kernels that touch request / table / response data (DESIGN.md
 # "Algorithmic bytes"): k_front reads key_off 4 + key 16 + table 56 (token) / 64 (leaky); k_eval2 reads
 # the request fields 32 / 40, writes table 16 / 24 and the response 25.
-KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73},
-                "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89}}
+KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73,
+                          # owner-partitioned pipeline: k_part reads key_off 4 + key 16, k_own the table 56, k_eval3 the request fields 32,
+                          # writes table 16 + response 25
+                          "k_part": 20, "k_own": 56, "k_eval3": 73, "k_part_multi": 20, "k_own_multi": 56, "k_eval3_multi": 73},
+                "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89,
+                          "k_part": 20, "k_own": 64, "k_eval3": 89, "k_part_multi": 20, "k_own_multi": 64, "k_eval3_multi": 89}}
 
 
 def parse():

@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
+FLAG_TEST_FORCE_PART, FLAG_NO_PART = 64, 128
 
 _lib = None
 

@@ -102,6 +102,10 @@ struct guber_engine {
     // tile-bitmap grouping path (batches <= 65536)
     DevBuf<unsigned long long> w_tilemask; DevBuf<SegRec> w_srec; DevBuf<int64_t> w_sinv; DevBuf<uint16_t> w_tilerow;
     DevBuf<uint32_t> w_did2;
+    // owner-partitioned pipeline (guber_kernels_part.h): messages tile -> owner, records owner -> tile, runs per (tile, owner),
+    // tile maps of walked segments, the per-request words.  cap256 = fast_cap rounded up to whole tiles.
+    DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3; DevBuf<unsigned long long> w_segtiles;
+    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, force_part = false; uint64_t part_batches = 0;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -166,9 +170,12 @@ struct guber_engine {
     int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
-enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI, KT_COUNT };
+enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI,
+       KT_PART, KT_OWN, KT_EVAL3, KT_PART_MULTI, KT_OWN_MULTI, KT_EVAL3_MULTI, KT_COUNT };
+static_assert(KT_COUNT <= 16, "guber_engine::prof_* hold 16 kernels");
 static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
-                                                   "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi"};
+                                                   "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi",
+                                                   "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi"};
 
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
@@ -247,13 +254,21 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->fast_cap = std::min<uint32_t>(M, FT * FT_MAX_TILES);
     e->force_radix = (cfg->flags & GUBER_FLAG_TEST_FORCE_RADIX) != 0;
     e->always_careful = (cfg->flags & GUBER_FLAG_TEST_CAREFUL) != 0;
-    e->no_small = (cfg->flags & GUBER_FLAG_TEST_NO_SMALL) != 0 || e->force_radix || e->always_careful;
+    e->no_small = (cfg->flags & (GUBER_FLAG_TEST_NO_SMALL | GUBER_FLAG_TEST_FORCE_PART)) != 0 || e->force_radix || e->always_careful;
     e->zero_copy = getenv("GUBER_NO_ZEROCOPY") == nullptr;
     e->fuse = getenv("GUBER_NO_FUSE") == nullptr;
     e->stage_dma = getenv("GUBER_NO_STAGE_DMA") == nullptr;
     if (const char* v = getenv("GUBER_STAGE_COPY_MIN")) e->stage_copy_min = (uint32_t)atoi(v);
-    rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->fast_cap);
-    rc |= e->w_tilerow.ensure((size_t)e->fast_cap * FT_MAX_TILES);
+    e->cap256 = (e->fast_cap + FT - 1) / FT * FT;
+    rc |= e->w_tilemask.ensure((size_t)2 * e->fast_cap * FT_WORDS); rc |= e->w_srec.ensure(e->fast_cap); rc |= e->w_sinv.ensure(e->cap256);
+    rc |= e->w_tilerow.ensure((size_t)e->cap256 * FT_MAX_TILES);
+    e->force_part = (cfg->flags & GUBER_FLAG_TEST_FORCE_PART) != 0;
+    e->use_part = !(cfg->flags & GUBER_FLAG_NO_PART) && !e->force_radix && !e->always_careful;
+    if (const char* v = getenv("GUBER_PIPELINE")) { if (!strcmp(v, "claims")) e->use_part = false; }
+    if (const char* v = getenv("GUBER_PART_MIN")) e->part_min = (uint32_t)std::max(257, atoi(v));
+    if (e->force_part) e->part_min = 1;
+    rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure(e->cap256); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);
+    rc |= e->w_did3.ensure(e->cap256); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
@@ -275,6 +290,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_tilemask.p, 0, (size_t)2 * e->fast_cap * FT_WORDS * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_srec.p, 0, (size_t)e->fast_cap * sizeof(SegRec), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_segtiles.p, 0, (size_t)e->cap256 * 4 * 8, e->stream)) != hipSuccess ||
+        (he = hipMemsetAsync(e->w_gse.p, 0, (size_t)FT_MAX_TILES * PT_PARTS * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
@@ -300,6 +317,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
+    e->W.gmsg = e->w_gmsg.p; e->W.grec = e->w_grec.p; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
+    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096);
 #endif
@@ -335,6 +354,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
     e->w_did2.release();
+    e->w_gmsg.release(); e->w_grec.release(); e->w_gse.release(); e->w_did3.release(); e->w_segtiles.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();
@@ -353,6 +373,11 @@ static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool bat
 // cache maintenance, the engine's epochs, and (two-launch pipeline) the views / work arrays of this batch.
 struct FastPlan { BatchView B2, B3; Work W; uint32_t ftiles; };
 static bool takes_fast_path(const guber_engine* e, uint32_t n) { return n != 0 && n <= e->fast_cap && !e->force_radix; }
+// the owner-partitioned pipeline (three launches, guber_kernels_part.h): batches the coordination between tiles is worth it for,
+// in HBM (k_part and k_eval3 both read the request columns), outside retry rounds (those verify before they group)
+static bool takes_part_path(const guber_engine* e, uint32_t n, bool host_resident) {
+    return takes_fast_path(e, n) && e->use_part && !e->careful && n >= e->part_min && (!host_resident || e->force_part);
+}
 
 static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
     const uint32_t n = B.n;
@@ -418,6 +443,17 @@ static int plan_fast(guber_engine* e, const BatchView& B, bool host_resident, Wo
     P.B2 = B2; P.B3 = B3; P.W = W; P.ftiles = (n + FT - 1) / FT;
     return 0;
 }
+static int plan_part(guber_engine* e, const BatchView& B, Work& W, FastPlan& P) {
+    BatchView B2 = B;
+    B2.n_cap = e->cap256;
+    W.careful = 0u;
+    W.snap_seq = 0;
+    if (e->snap_pending) attach_counter_readback(e, W);
+    W.did = e->w_did3.p;
+    W.st_hits = nullptr;
+    P.B2 = B2; P.B3 = B2; P.W = W; P.ftiles = (B.n + FT - 1) / FT;
+    return 0;
+}
 static void finish_fast(guber_engine* e, uint32_t n) {
     e->fast_batches++;
     e->fast_prev_n = n;
@@ -433,6 +469,25 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         if (rc) return rc;
     }
     const uint32_t tiles = W.tiles;
+    if (takes_part_path(e, n, host_resident)) {
+        FastPlan P;
+        {
+            const int rc = plan_part(e, B, W, P);
+            if (rc) return rc;
+        }
+        e->span_begin(KT_PART, n);
+        hipLaunchKernelGGL(k_part, dim3(P.ftiles), dim3(FT), 0, e->stream, e->T, P.B2, P.W);
+        e->span_end();
+        e->span_begin(KT_OWN, n);
+        hipLaunchKernelGGL(k_own, dim3(PT_PARTS), dim3(256), 0, e->stream, e->T, P.B2, P.W, P.ftiles);
+        e->span_end();
+        e->span_begin(KT_EVAL3, n);
+        hipLaunchKernelGGL(k_eval3, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
+        e->span_end();
+        HIPCHK(hipGetLastError());
+        e->batches++; e->part_batches++;
+        return 0;
+    }
     if (takes_fast_path(e, n)) {
         // two launches: resolve + in-tile grouping, then evaluation
         FastPlan P;
@@ -589,12 +644,14 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     MultiFront MF{}; MultiEval ME{};
     uint32_t tiles = 0, ns[MULTI_MAX];
     int planned = 0, rc = 0;
+    bool part = true;                                              // the group takes the owner-partitioned pipeline if all its batches do
+    for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false);
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);
         Work W; FastPlan P;
         rc = batch_prelude(e, B, W);
-        if (!rc) rc = plan_fast(e, B, false, W, P);
+        if (!rc) rc = part ? plan_part(e, B, W, P) : plan_fast(e, B, false, W, P);
         if (rc) break;                                            // enqueue what is planned, then report
         tiles += P.ftiles;
         MF.end_tile[planned] = ME.end_tile[planned] = tiles;
@@ -607,6 +664,21 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         MF.nb = ME.nb = (uint32_t)planned;
         uint64_t units = 0;
         for (int i = 0; i < planned; ++i) units += ns[i];
+        if (part) {
+            grp[0]->span_begin(KT_PART_MULTI, units);
+            hipLaunchKernelGGL(k_part_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
+            grp[0]->span_end();
+            grp[0]->span_begin(KT_OWN_MULTI, units);
+            hipLaunchKernelGGL(k_own_multi, dim3((unsigned)planned * PT_PARTS), dim3(256), 0, grp[0]->stream, MF);
+            grp[0]->span_end();
+            grp[0]->span_begin(KT_EVAL3_MULTI, units);
+            hipLaunchKernelGGL(k_eval3_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
+            grp[0]->span_end();
+            for (int i = 0; i < planned; ++i) { grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
+            *enqueued += (uint32_t)planned;
+            if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+            return rc;
+        }
         grp[0]->span_begin(KT_FRONT_MULTI, units);                    // (per-kernel timing, when enabled, is kept by the group's first engine)
         hipLaunchKernelGGL(k_front_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
         grp[0]->span_end();

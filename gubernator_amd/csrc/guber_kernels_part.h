@@ -640,8 +640,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                 Rec prev2; rec_clear(prev2);
                 bool have_prev2 = false;
                 // walk iterator: the tiles holding the segment in order (its tile map), inside a tile the requests of the segment's group
-                uint32_t wv = 0, tt = 0, q = FT, tj = 0;
-                unsigned long long mm = 0ull;
+                uint32_t wv = 0, tt = 0, q = FT, tj = 0, mm = 0u;          // (the map read as 8 x 32 tiles)
                 for (;;) {
                     uint32_t j = i;
                     if (walk) {
@@ -652,10 +651,10 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                                 if ((id & 0xffu) == tj && ((id >> 16) & 0xffu) == 0u) { j = tt * FT + q; found = true; }
                                 q++;
                             } else {
-                                while (mm == 0ull && wv < 4) { mm = W.segtiles[(size_t)d * 4 + wv]; tt = wv * 64; wv++; }
-                                if (mm == 0ull) end = true;
+                                while (mm == 0u && wv < 8) { mm = ((const uint32_t*)W.segtiles)[(size_t)d * 8 + wv]; tt = wv * 32; wv++; }
+                                if (mm == 0u) end = true;
                                 else {
-                                    const uint32_t bpos = (uint32_t)__ffsll(mm) - 1u; mm &= mm - 1ull; tt = (tt & ~63u) + bpos; q = 0;
+                                    const uint32_t bpos = (uint32_t)__ffs((int)mm) - 1u; mm &= mm - 1u; tt = (tt & ~31u) + bpos; q = 0;
                                     tj = W.tilerow[(size_t)d * FT_MAX_TILES + tt];
                                 }
                             }
@@ -736,6 +735,32 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
     const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     eval3_body(*a, blockIdx.x);
+}
+
+// ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
+// kernel arguments; k_own_multi: 256 owners per batch, so that an owner's XCD is the same in every batch) ----------------------
+__global__ __launch_bounds__(FT) void k_part_multi(MultiFront A) {
+    uint32_t sb = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < MULTI_MAX - 1; ++k)
+        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const FrontArgs* a = (const FrontArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiFront, sub)) + sb;
+    part_body(a->T, a->B, a->W, blockIdx.x - first);
+}
+__global__ __launch_bounds__(256) void k_own_multi(MultiFront A) {
+    const MultiFront* m = (const MultiFront*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t sb = blockIdx.x / PT_PARTS;
+    const uint32_t ntiles = m->end_tile[sb] - (sb ? m->end_tile[sb - 1] : 0u);
+    const FrontArgs* a = m->sub + sb;
+    own_body(a->T, a->B, a->W, blockIdx.x % PT_PARTS, ntiles);
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) {
+    uint32_t sb = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < MULTI_MAX - 1; ++k)
+        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
+    eval3_body(*a, blockIdx.x - first);
 }
 
 }  // namespace guber

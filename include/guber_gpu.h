@@ -83,6 +83,10 @@ typedef struct guber_engine guber_engine_t;
 #define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
 #define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
                                           sort) kernel sequence as well */
+#define GUBER_FLAG_TEST_FORCE_PART 64u /* tests only: every batch (also <= 256 requests, also host-resident ones) takes the
+                                          owner-partitioned three-launch pipeline (guber_kernels_part.h) */
+#define GUBER_FLAG_NO_PART 128u        /* never take the owner-partitioned pipeline: batches of 257 .. 65 536 requests run the
+                                          two-launch pipeline with per-batch claims (round 3's; kept as the retry round) */
 #define GUBER_FLAG_TEST_WEAK_HASH 1u /* tests only: keep 6 bits of the key hash so distinct keys collide and
                                         the exact-key verification / retry path is exercised */
 

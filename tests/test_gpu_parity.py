@@ -43,8 +43,10 @@ def test_get_peer_rate_limits_order_stable():
 
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
 # mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline;
-# 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path)
-@pytest.mark.parametrize("flags", [0, 2, 4, 32])
+# 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path);
+# 64 = every batch through the owner-partitioned three-launch pipeline (k_part / k_own / k_eval3; what device-resident batches of
+# >= 1024 requests take by default), 128 = never that one (the two-launch pipeline with per-batch claims)
+@pytest.mark.parametrize("flags", [0, 2, 4, 32, 64, 128])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_adversarial_streams(seed, flags):
     o, e = Oracle(cache_size=1 << 20), engine(flags=flags)
@@ -55,7 +57,7 @@ def test_adversarial_streams(seed, flags):
     e.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2, 4])
+@pytest.mark.parametrize("flags", [0, 2, 4, 64])
 def test_hot_key_runs(flags):
     now = streams.NOW0
     for algo in (0, 1):
@@ -68,7 +70,7 @@ def test_hot_key_runs(flags):
                 e.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_edge_cases_empty_ragged_long_keys(flags):
     o, e = Oracle(cache_size=1 << 16), engine(cache_size=4096, max_batch=4096, max_key_bytes=300, flags=flags)
     now = streams.NOW0
@@ -94,7 +96,7 @@ def test_edge_cases_empty_ragged_long_keys(flags):
     e.close()
 
 
-@pytest.mark.parametrize("flags", [1, 3, 5])
+@pytest.mark.parametrize("flags", [1, 3, 5, 65])
 def test_hash_collisions_are_resolved_exactly(flags):
     """GUBER_FLAG_TEST_WEAK_HASH keeps 6 bits of the key hash: hundreds of distinct keys share a
     tag, so the exact key verification, probing past a collision and the in-batch retry path all run."""
@@ -140,7 +142,7 @@ def test_cache_operations_add_get_remove_each():
     e.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_zipf_bench_stream_midsize(flags):
     """The BASELINE stream shape (Zipf 1.1, hits 1, limit 100, 60 s) at 200k keys / 16384 batch."""
     tab = streams.key_table(200_000)
@@ -322,7 +324,7 @@ def test_global_behaviour_engines_vs_model():
             assert vals == want, (seed, key, vals, want)
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_created_at_only_variation_on_hot_keys(flags):
     rng = np.random.default_rng(17)
     now = streams.NOW0
@@ -477,7 +479,7 @@ def test_store_events_golden_teststore():
     assert scenarios.run_store_events(lambda: engine(cache_size=4096, max_batch=1024)) == 10
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_store_events_match_the_oracle_on_random_batches(flags):
     """Every request's Store callbacks (which, in which order, and the CacheItem handed to OnChange — the state right
     after THAT request, also in the middle of a run on a hot key) equal the reference restatement's."""
@@ -517,7 +519,7 @@ def test_store_events_match_the_oracle_on_random_batches(flags):
     e.close()
 
 
-@pytest.mark.parametrize("flags", [0, 2])
+@pytest.mark.parametrize("flags", [0, 2, 64])
 def test_created_at_only_variation_on_hot_leaky_keys(flags):
     """Hot LEAKY keys whose requests carry slightly different created_at (aggregated RPC payloads): parallel path
     while no request leaks (leaky_created_harmless), serial otherwise; bit-exact either way."""
@@ -678,7 +680,7 @@ def test_gregorian_intervals_on_the_device():
     """DURATION_IS_GREGORIAN evaluated in the kernels from the batch clock (no greg_expire / greg_duration arrays): equal to the
     oracle fed with the host-computed calendar values — minutes .. years, the weeks / invalid-interval errors, both pipelines."""
     from test_kernel_logic_host import _gregorian_batches
-    for flags in (0, 2):
+    for flags in (0, 2, 64):
         o, e = Oracle(cache_size=1 << 12), engine(cache_size=1024, max_batch=1024, flags=flags)
         for bi, (with_vals, without) in enumerate(_gregorian_batches(6 + flags)):
             support.assert_results_equal(e.eval(without), o.eval(with_vals), f"flags {flags} batch {bi}")
