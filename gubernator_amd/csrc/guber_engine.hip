@@ -105,7 +105,7 @@ struct guber_engine {
     // owner-partitioned pipeline (guber_kernels_part.h): messages tile -> owner, records owner -> tile, runs per (tile, owner),
     // tile maps of walked segments, the per-request words.  cap256 = fast_cap rounded up to whole tiles.
     DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3; DevBuf<unsigned long long> w_segtiles;
-    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, force_part = false; uint64_t part_batches = 0;
+    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false; uint64_t part_batches = 0;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -113,7 +113,7 @@ struct guber_engine {
     bool always_careful = false;
     // GLOBAL pending queues
 #ifdef GUBER_PHASE_TIMING
-    DevBuf<unsigned long long> dbg; double dbg_avg[2][8] = {{0}}, dbg_max[2][8] = {{0}}; uint64_t dbg_n = 0;
+    DevBuf<unsigned long long> dbg; double dbg_avg[5][8] = {{0}}, dbg_max[5][8] = {{0}}; uint64_t dbg_n = 0, dbg_pn = 0;
 #endif
     DevBuf<uint64_t> d_ring_h; DevBuf<uint32_t> d_ring_o; uint64_t ring_cached_id = 0; uint32_t ring_npts = 0;   // ring image for the *_dev routers
     DevBuf<ItemIn> d_items; DevBuf<uint32_t> d_islots; DevBuf<uint8_t> d_iflags, d_ikeys, d_ires;   // guber_add_items[_dev] scratch (persistent)
@@ -264,7 +264,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     rc |= e->w_tilerow.ensure((size_t)e->cap256 * FT_MAX_TILES);
     e->force_part = (cfg->flags & GUBER_FLAG_TEST_FORCE_PART) != 0;
     e->use_part = !(cfg->flags & GUBER_FLAG_NO_PART) && !e->force_radix && !e->always_careful;
-    if (const char* v = getenv("GUBER_PIPELINE")) { if (!strcmp(v, "claims")) e->use_part = false; }
+    // GUBER_PIPELINE: "claims" = never the owner-partitioned pipeline, "part" = also for a batch launched on its own; default: the
+    // owner-partitioned pipeline when several tables share the launches (where it is faster: profiles/r04_*), claims otherwise
+    if (const char* v = getenv("GUBER_PIPELINE")) { if (!strcmp(v, "claims")) e->use_part = false; else if (!strcmp(v, "part")) e->part_single = true; }
     if (const char* v = getenv("GUBER_PART_MIN")) e->part_min = (uint32_t)std::max(257, atoi(v));
     if (e->force_part) e->part_min = 1;
     rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure(e->cap256); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);
@@ -320,7 +322,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.gmsg = e->w_gmsg.p; e->W.grec = e->w_grec.p; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
     { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
-    (void)e->dbg.ensure(4096);
+    (void)e->dbg.ensure(4096 + 3 * 2048);
 #endif
     *out = e;
     return GUBER_OK;
@@ -339,6 +341,18 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
                     kern ? "k_eval2" : "k_front", (unsigned long long)e->dbg_n);
             for (int k = 0; k < (kern ? 5 : 8); ++k)
                 fprintf(stderr, "    %-24s %7.2f / %7.2f\n", names[kern][k], e->dbg_avg[kern][k] / e->dbg_n, e->dbg_max[kern][k] / e->dbg_n);
+        }
+    }
+    if (e->dbg_pn) {
+        static const char* kn[3] = {"k_part", "k_own", "k_eval3"};
+        static const char* names[3][8] = {{"entry", "fields + key hashed", "grouped in LDS", "members compared", "owner runs scanned", "end (all drained)", "", ""},
+                                          {"runs read (gse)", "scanned", "gathered + keys installed", "table loads issued", "messages compared", "bases done", "table done (records in LDS)", "end (all drained)"},
+                                          {"entry", "word + record + fields loaded", "evaluated", "end (all drained)", "", "", "", ""}};
+        static const int ns[3] = {6, 8, 4};
+        for (int kern = 0; kern < 3; ++kern) {
+            fprintf(stderr, "[phase timing] %s over %llu full batches (us since the first workgroup's entry: avg over workgroups / last workgroup)\n", kn[kern], (unsigned long long)e->dbg_pn);
+            for (int k = 0; k < ns[kern]; ++k)
+                fprintf(stderr, "    %-30s %7.2f / %7.2f\n", names[kern][k], e->dbg_avg[2 + kern][k] / e->dbg_pn, e->dbg_max[2 + kern][k] / e->dbg_pn);
         }
     }
     e->dbg.release();
@@ -375,8 +389,9 @@ struct FastPlan { BatchView B2, B3; Work W; uint32_t ftiles; };
 static bool takes_fast_path(const guber_engine* e, uint32_t n) { return n != 0 && n <= e->fast_cap && !e->force_radix; }
 // the owner-partitioned pipeline (three launches, guber_kernels_part.h): batches the coordination between tiles is worth it for,
 // in HBM (k_part and k_eval3 both read the request columns), outside retry rounds (those verify before they group)
-static bool takes_part_path(const guber_engine* e, uint32_t n, bool host_resident) {
-    return takes_fast_path(e, n) && e->use_part && !e->careful && n >= e->part_min && (!host_resident || e->force_part);
+static bool takes_part_path(const guber_engine* e, uint32_t n, bool host_resident, bool fused) {
+    return takes_fast_path(e, n) && e->use_part && !e->careful && n >= e->part_min && (!host_resident || e->force_part) &&
+           (fused || e->part_single || e->force_part);
 }
 
 static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
@@ -451,6 +466,9 @@ static int plan_part(guber_engine* e, const BatchView& B, Work& W, FastPlan& P) 
     if (e->snap_pending) attach_counter_readback(e, W);
     W.did = e->w_did3.p;
     W.st_hits = nullptr;
+#ifdef GUBER_PHASE_TIMING
+    W.dbg = e->dbg.p;
+#endif
     P.B2 = B2; P.B3 = B2; P.W = W; P.ftiles = (B.n + FT - 1) / FT;
     return 0;
 }
@@ -469,7 +487,7 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         if (rc) return rc;
     }
     const uint32_t tiles = W.tiles;
-    if (takes_part_path(e, n, host_resident)) {
+    if (takes_part_path(e, n, host_resident, false)) {
         FastPlan P;
         {
             const int rc = plan_part(e, B, W, P);
@@ -485,6 +503,26 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         hipLaunchKernelGGL(k_eval3, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
         e->span_end();
         HIPCHK(hipGetLastError());
+#ifdef GUBER_PHASE_TIMING
+        if (n == e->fast_cap) {   // fold the stamps of full batches (as for the two-launch pipeline below)
+            static unsigned long long hb[3 * 2048];
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipMemcpy(hb, e->dbg.p + 4096, sizeof(hb), hipMemcpyDeviceToHost);
+            static const int nst[3] = {6, 8, 4};
+            for (int kern = 0; kern < 3; ++kern) {
+                const unsigned long long* b = hb + kern * 2048;
+                const uint32_t wgs = kern == 1 ? (uint32_t)PT_PARTS : P.ftiles;
+                unsigned long long t0 = ~0ull;
+                for (uint32_t t = 0; t < wgs; ++t) t0 = b[t * 8] < t0 ? b[t * 8] : t0;
+                for (int k = 0; k < nst[kern]; ++k) {
+                    double sum = 0, mx = 0;
+                    for (uint32_t t = 0; t < wgs; ++t) { const double v = (double)(b[t * 8 + k] - t0) * 0.01; sum += v; mx = v > mx ? v : mx; }
+                    e->dbg_avg[2 + kern][k] += sum / wgs; e->dbg_max[2 + kern][k] += mx;
+                }
+            }
+            e->dbg_pn++;
+        }
+#endif
         e->batches++; e->part_batches++;
         return 0;
     }
@@ -645,7 +683,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     uint32_t tiles = 0, ns[MULTI_MAX];
     int planned = 0, rc = 0;
     bool part = true;                                              // the group takes the owner-partitioned pipeline if all its batches do
-    for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false);
+    for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false, true);
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);

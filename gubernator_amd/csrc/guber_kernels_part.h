@@ -99,16 +99,17 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
     __shared__ unsigned long long gkey[GT];
     __shared__ unsigned long long gbits[FT / 64][GT];
-    __shared__ uint32_t sd[FT];                                   // head -> position of its group's message in the tile's region
+    __shared__ uint32_t sd[FT];                                   // head -> G_* raised by the group's members, then the position of its group's message in the tile's region
     __shared__ uint32_t soff[FT], slen[FT];
     __shared__ TileReqs sreq;
-    __shared__ uint32_t gfl[FT];                                  // head -> G_* raised by the group's members
-    __shared__ long long gcmin[FT], gcmax[FT];                    // head -> created_at range of the group
-    __shared__ uint32_t pc[PT_PARTS], pstart[PT_PARTS];           // groups per owner (in owner_order), where each owner's run starts
+    __shared__ int gcmin[FT], gcmax[FT];                          // head -> created_at range of the group (ms from the batch clock, clamped to +-2^17)
+    __shared__ uint32_t pc[PT_PARTS];                             // groups per owner (in owner_order), then where each owner's run starts
     __shared__ uint32_t wsum[FT / 64];
+    uint32_t* const gfl = sd;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
+    GP_STAMP(0, 0);
 
     if (tile == 0 && W.snap_seq) {                                // a counter read-back rides on this launch (Work::snap_*)
         for (uint32_t k = tid; k < W.snap_n; k += FT) W.snap_b[k] = T.bctr[k];
@@ -163,6 +164,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         tile_put(sreq, tid, mine);
     }
     soff[tid] = off; slen[tid] = len;
+    GP_STAMPW(0, 1);
     lds_barrier();
     // ---- group the tile by hash (LDS table with per-wave member bitmaps, as k_front) ----
     uint32_t gh = 0;
@@ -192,13 +194,22 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     }
     const bool khead = valid && gk != 0ull && eq_before == 0;
     const bool member = valid && gk != 0ull && eq_before != 0;
+    GP_STAMP(0, 2);
+    // created_at as the messages carry it: milliseconds from the batch clock
+    int cd = 0; bool cfar = false;
+    {
+        const int64_t d64 = wsub(mine.created_at, B.now_ms);
+        cfar = d64 < -131072 || d64 > 131071;
+        cd = cfar ? (d64 < 0 ? -131072 : 131071) : (int)d64;
+    }
     // heads: the group's accumulators, and a place among the tile's messages for this owner
     uint32_t q = 0, qr = 0;
     if (khead) {
         uint32_t f = 0;
         if ((mine.behavior >> 6) != 0u || mine.algorithm > 1u || ((mine.behavior & BH_GREGORIAN) && B.greg_expire && B.greg_duration)) f |= G_ODD;
         if (len > 16) f |= G_LONG;
-        gfl[tid] = f; gcmin[tid] = mine.created_at; gcmax[tid] = mine.created_at;
+        if (cfar) f |= G_CFAR;
+        gfl[tid] = f; gcmin[tid] = cd; gcmax[tid] = cd;
         q = owner_order(owner_of(T, W, h));
         qr = atomicAdd(&pc[q], 1u);
     }
@@ -210,12 +221,13 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         const uint32_t df = req_diff_flags(B, g, tile * FT + head_tid, mine, tile_get(sreq, head_tid), soft_leaky);
         if (df & SEG_NONUNIFORM) f |= G_NONUNIFORM;
         if ((df & SEG_CREATED_DIFFERS) || soft_leaky) {
-            f |= G_CREATED;
-            atomicMin(&gcmin[head_tid], (long long)mine.created_at); atomicMax(&gcmax[head_tid], (long long)mine.created_at);
+            f |= G_CREATED | (cfar ? G_CFAR : 0u);
+            atomicMin(&gcmin[head_tid], cd); atomicMax(&gcmax[head_tid], cd);
         }
         if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) f |= G_RETRY;
         if (f) atomicOr(&gfl[head_tid], f);
     }
+    GP_STAMPW(0, 3);
     // exclusive scan of the owners' group counts: where each owner's run starts in the tile's region
     {
         const uint32_t c = pc[tid];
@@ -226,19 +238,19 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
 #pragma unroll
         for (uint32_t w = 0; w < FT / 64; ++w) before += w < wave ? wsum[w] : 0u;
         const uint32_t start = before + incl - c;
-        pstart[tid] = start;
+        pc[tid] = start;
         W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid)] = start | (c << 16);
     }
     lds_barrier();
+    GP_STAMP(0, 4);
     // heads: the message
     if (khead) {
-        const uint32_t j = pstart[q] + qr;
-        sd[tid] = j;
+        const uint32_t j = pc[q] + qr;
         uint32_t f = gfl[tid];
-        const int64_t cmin = gcmin[tid], cmax = gcmax[tid];
-        const int64_t dmin = wsub(cmin, B.now_ms);
-        const uint64_t span = (uint64_t)cmax - (uint64_t)cmin;
-        if (dmin < -131072 || dmin > 131071 || span > 255u) f |= G_CFAR;
+        sd[tid] = j;
+        const int dmin = gcmin[tid];
+        const uint32_t span = (uint32_t)(gcmax[tid] - dmin);
+        if (span > 255u) f |= G_CFAR;
         const uint32_t shape = (mine.behavior & 63u) | ((mine.algorithm > 1u ? 2u : (uint32_t)mine.algorithm) << 6) | ((mine.is_owner ? 1u : 0u) << 8);
         unsigned long long k0, k1;
         if (len <= 16) {
@@ -251,22 +263,26 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         mq[1] = make_ulonglong2(k1, (unsigned long long)mine.hits);
         mq[2] = make_ulonglong2((unsigned long long)mine.limit, (unsigned long long)mine.duration);
         mq[3] = make_ulonglong2((unsigned long long)mine.burst,
-                                gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : dmin, (f & G_CFAR) ? 0u : (uint32_t)span));
+                                gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
     }
     lds_barrier();
     if (valid) {
         if (errcode) W.did[g] = pd_pack(0, 0, errcode);
         else W.did[g] = pd_pack(sd[head_tid], eq_before, 0);
     }
+    GP_STAMPW(0, 5);
 }
 
-__global__ __launch_bounds__(FT) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
+__global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
-constexpr int OW_MCAP = 1024;            // messages one round of an owner holds in LDS (more: the round splits by further hash bits)
-constexpr int OW_KCAP = 512;             // distinct keys of one round
-constexpr int OW_HT = 1024;              // LDS hash table of the round's keys
+constexpr int OW_MCAP = 768;             // messages one round of an owner holds in LDS (more: the round splits by further hash bits)
+constexpr int OW_KCAP = 384;             // distinct keys of one round (uniform keys: 256 +- 16 per owner)
+constexpr int OW_HT = 512;               // LDS hash table of the round's keys
 constexpr int OW_CH = OW_MCAP / 64;      // 64-message chunks
+#ifndef GUBER_OWN_WAVES
+#define GUBER_OWN_WAVES 3                // waves per SIMD the register allocation must allow: 3 co-resident workgroups per CU (LDS: 51 KB each)
+#endif
 
 // SEG_* bits of a key from the G_* bits its groups raised, the number of groups and the created_at range over the groups
 GB_HD uint32_t own_seg_flags(uint32_t f, uint32_t groups, bool created_range) {
@@ -288,33 +304,38 @@ __device__ __forceinline__ void key_store_words(const Table& T, uint64_t slot, u
     c->w[7] = (uint64_t)len << 48;
 }
 
-struct OwnKeyLoads { ulonglong2 de0; uint4 c0, c3; Rec rec; unsigned long long wk0, wk1, wmisc; long long wlimit, wduration; };
+// the request shape a message carries, exactly (everything of the request but created_at, whose range travels beside it)
+__device__ __forceinline__ bool msg_same_request(const ulonglong2& a1, const ulonglong2& a2, const ulonglong2& a3,
+                                                 const ulonglong2& b1, const ulonglong2& b2, const ulonglong2& b3) {
+    return a1.y == b1.y && a2.x == b2.x && a2.y == b2.y && a3.x == b3.x && gm_shape(a3.y) == gm_shape(b3.y);
+}
 
 __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, const Work& W, const uint32_t p, const uint32_t ntiles) {
-    // phase 1 of a round: hash table of the round's keys + per-chunk sums; phase 2: the keys' records.  Same LDS.
-    __shared__ __attribute__((aligned(16))) unsigned char raw[OW_KCAP * 64];
-    unsigned long long* ktab = (unsigned long long*)raw;                                  // [OW_HT]      8 KB   hash (0 = free)
-    uint16_t* kidOf = (uint16_t*)(raw + OW_HT * 8);                                        // [OW_HT]      2 KB   slot -> key id
-    uint32_t* csum = (uint32_t*)(raw + OW_HT * 10);                                        // [OW_CH][OW_KCAP / 2]  16 KB  requests per (chunk, key), u16 pairs
-    GRec* krec = (GRec*)raw;                                                               // [OW_KCAP]   32 KB   (phase 2)
-    static_assert(OW_HT * 10 + OW_CH * (OW_KCAP / 2) * 4 <= OW_KCAP * 64, "phase 1 fits the records' space");
-    __shared__ uint16_t kwin[OW_KCAP];                  // key id -> list index of the message that installed the key
-    __shared__ unsigned long long khash[OW_KCAP];       // key id -> hash
+    __shared__ unsigned long long ktab[OW_HT];          // the round's keys: hash (0 = free)
+    __shared__ uint16_t kidOf[OW_HT];                   // table slot -> key id
+    __shared__ uint32_t csum[OW_CH * (OW_KCAP / 2)];    // requests per (64-message chunk, key), two u16 per word
+    __shared__ GMsg kref[OW_KCAP];                      // key id -> the message that installed the key; then (same thread) the key's record
+    __shared__ uint16_t kwin[OW_KCAP];                  // key id -> list index of that message
     __shared__ uint32_t kfl[OW_KCAP];                   // G_* over the key's groups
     __shared__ uint32_t ktot[OW_KCAP];                  // requests | groups << 20
-    __shared__ long long kcmin[OW_KCAP], kcmax[OW_KCAP];
-    __shared__ uint32_t elist[OW_MCAP];                 // per message: hash-table slot, then key id 9 | members-1 8, then key id 9 | base 16
+    __shared__ int kcmin[OW_KCAP], kcmax[OW_KCAP];      // created_at range over the key's groups (ms from the batch clock)
+    __shared__ uint32_t elist[OW_MCAP];                 // per message: table slot, then key id 9 | members-1 8 (<< 9), then key id 9 | base 16 (<< 9)
     __shared__ uint16_t esrc[OW_MCAP];                  // per message: its index in gmsg / grec (tile << 8 | position)
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t nkeys, ins_n;
     __shared__ uint32_t stk[40];                        // rounds to do: log2(split) << 24 | residue of the home position
     __shared__ int sp;
+    GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     uint32_t start = 0, c = 0;
     if (t < ntiles) { const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16; }
     const size_t mbase = (size_t)t * FT + start;
+    // my run's first message is requested at once (its address does not depend on the scan below) and stays in registers
+    ulonglong2 f0 = {0ull, 0ull}, f1 = f0, f2 = f0, f3 = f0;
+    if (c) { const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase]; f0 = mq[0]; f1 = mq[1]; f2 = mq[2]; f3 = mq[3]; }
     if (t == 0) { stk[0] = 0u; sp = 1; ins_n = 0u; }
+    GP_STAMP(1, 0);
     for (;;) {
         lds_barrier();
         if (sp == 0) break;
@@ -326,7 +347,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2); j += 256) csum[j] = 0u;
         // my run's messages of this round
         uint32_t cm = c;
-        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((W.gmsg[mbase + r].hash >> 7) & T.mask) & smask) == res ? 1u : 0u; }
+        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)(((r ? W.gmsg[mbase + r].hash : f0.x) >> 7) & T.mask) & smask) == res ? 1u : 0u; }
         uint32_t pos, M;
         {
             const uint32_t incl = wave_incl_scan_u32(cm);
@@ -339,26 +360,36 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             M = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         }
         if (M == 0) continue;
+        GP_STAMP(1, 1);
         bool split = M > OW_MCAP;
         if (!split) {
-            // ---- gather: hash -> LDS table slot, first come installs the key ----
+            // ---- gather: hash -> LDS table slot; the first message of a key installs it and leaves its content as the key's reference ----
             uint32_t li = pos;
             for (uint32_t r = 0; r < c; ++r) {
-                const unsigned long long hh = W.gmsg[mbase + r].hash;
+                const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase + r];
+                const ulonglong2 a0 = r ? mq[0] : f0;
+                const unsigned long long hh = a0.x;
                 if (lg && ((uint32_t)((hh >> 7) & T.mask) & smask) != res) continue;
-                uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 54) & (OW_HT - 1);
+                ulonglong2 a1 = f1, a2 = f2, a3 = f3;
+                if (r) { a1 = mq[1]; a2 = mq[2]; a3 = mq[3]; }
+                uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 55) & (OW_HT - 1);
+                bool won = false;
                 for (;;) {
                     const unsigned long long old = atomicCAS(&ktab[s], 0ull, hh);
-                    if (old == 0ull) {
-                        const uint32_t kid = atomicAdd(&nkeys, 1u);
-                        if (kid < OW_KCAP) {
-                            kidOf[s] = (uint16_t)kid; kwin[kid] = (uint16_t)li; khash[kid] = hh; kfl[kid] = 0u; ktot[kid] = 0u;
-                            kcmin[kid] = INT64_MAX; kcmax[kid] = INT64_MIN;
-                        }
-                        break;
-                    }
+                    if (old == 0ull) { won = true; break; }
                     if (old == hh) break;
                     s = (s + 1) & (OW_HT - 1);
+                }
+                if (won) {
+                    const uint32_t kid = atomicAdd(&nkeys, 1u);
+                    if (kid < OW_KCAP) {
+                        kidOf[s] = (uint16_t)kid; kwin[kid] = (uint16_t)li; kfl[kid] = 0u; ktot[kid] = 0u;
+                        const bool far = (gm_flags(a3.y) & G_CFAR) != 0u;      // the installer's own created_at range starts the key's
+                        kcmin[kid] = far ? INT32_MAX : (int)gm_cmin_delta(a3.y);
+                        kcmax[kid] = far ? INT32_MIN : (int)gm_cmin_delta(a3.y) + (int)gm_cspan(a3.y);
+                        ulonglong2* kq = (ulonglong2*)&kref[kid];
+                        kq[0] = a0; kq[1] = a1; kq[2] = a2; kq[3] = a3;
+                    }
                 }
                 elist[li] = s;
                 esrc[li] = (uint16_t)(mbase + r);
@@ -385,36 +416,44 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             continue;
         }
         const uint32_t nk = nkeys;
-        // ---- the table lines of my first key are requested now and used after the messages have been compared ----
-        OwnKeyLoads L;
+        GP_STAMPW(1, 2);
+        // ---- the table lines of my first key (thread = key id) are requested now and used after the messages have been compared ----
+        ulonglong2 de0 = {0ull, 0ull};
+        uint4 tc0 = {0, 0, 0, 0}, tc3 = tc0;
+        Rec trec; rec_clear(trec);
         uint64_t kpos = 0;
         const bool haskey = t < nk;
         if (haskey) {
-            const uint64_t hh = khash[t];
-            kpos = (hh >> 7) & T.mask;
-            L.de0 = *(const ulonglong2*)&T.dir[kpos];
+            kpos = (kref[t].hash >> 7) & T.mask;
+            de0 = *(const ulonglong2*)&T.dir[kpos];
             const Bucket* hb = &T.buckets[kpos];
-            const uint4* cw = (const uint4*)&hb->cell; L.c0 = cw[0]; L.c3 = cw[3];
-            L.rec = hb->rec;
-            const GMsg* wm = &W.gmsg[esrc[kwin[t]]];
-            L.wk0 = wm->key0; L.wk1 = wm->key1; L.wmisc = wm->misc; L.wlimit = wm->limit; L.wduration = wm->duration;
+            const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
+            trec = hb->rec;
         }
-        // ---- every message against the message that installed its key: exact key bytes, exact request shape ----
+        GP_STAMP(1, 3);
+        // ---- every message against its key's reference: exact key bytes, exact request shape; the key's totals ----
         {
             uint32_t li = pos;
             for (uint32_t r = 0; r < c; ++r) {
-                const GMsg* m = &W.gmsg[mbase + r];
-                const ulonglong2* mq = (const ulonglong2*)m;
-                const ulonglong2 a0 = mq[0];
-                if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
-                const ulonglong2 a1 = mq[1], a2 = mq[2], a3 = mq[3];
+                ulonglong2 a0, a1, a2, a3;
+                if (r == 0) {
+                    a0 = f0; a1 = f1; a2 = f2; a3 = f3;
+                    if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
+                } else {
+                    const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase + r];
+                    a0 = mq[0];
+                    if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
+                    a1 = mq[1]; a2 = mq[2]; a3 = mq[3];
+                }
                 const unsigned long long misc = a3.y;
                 const uint32_t kid = kidOf[elist[li]];
-                const uint32_t wl = kwin[kid];
                 uint32_t f = gm_flags(misc);
                 const uint32_t cnt = gm_cnt(misc);
-                if (wl != li) {
-                    const ulonglong2* wq = (const ulonglong2*)&W.gmsg[esrc[wl]];
+                const bool far = (f & G_CFAR) != 0u;
+                const int cmin = (int)gm_cmin_delta(misc), cmax = cmin + (int)gm_cspan(misc);
+                bool range = false;                                   // does this group widen the key's created_at range?
+                if (kwin[kid] != li) {
+                    const ulonglong2* wq = (const ulonglong2*)&kref[kid];
                     const ulonglong2 b0 = wq[0], b1 = wq[1], b2 = wq[2], b3 = wq[3];
                     bool keq = gm_klen(misc) == gm_klen(b3.y);
                     if (keq) {
@@ -422,20 +461,19 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                         else keq = req_key_equal_at(B, (uint32_t)a0.y, (uint32_t)(a0.y >> 32), (uint32_t)b0.y, (uint32_t)(b0.y >> 32));
                     }
                     if (!keq) f |= G_RETRY;
-                    if (a1.y != b1.y || a2.x != b2.x || a2.y != b2.y || a3.x != b3.x || gm_shape(misc) != gm_shape(b3.y)) f |= G_NONUNIFORM;
+                    if (!msg_same_request(a1, a2, a3, b1, b2, b3)) f |= G_NONUNIFORM;
+                    range = !far && ((gm_flags(b3.y) & G_CFAR) || cmin != (int)gm_cmin_delta(b3.y) || cmax != (int)gm_cmin_delta(b3.y) + (int)gm_cspan(b3.y));
                 }
-                atomicOr(&kfl[kid], f);
+                if (f) atomicOr(&kfl[kid], f);
                 atomicAdd(&ktot[kid], cnt | (1u << 20));
-                if (!(f & G_CFAR)) {
-                    const int64_t cmin = wadd(B.now_ms, gm_cmin_delta(misc));
-                    atomicMin(&kcmin[kid], (long long)cmin); atomicMax(&kcmax[kid], (long long)wadd(cmin, (int64_t)gm_cspan(misc)));
-                }
+                if (range) { atomicMin(&kcmin[kid], cmin); atomicMax(&kcmax[kid], cmax); }
                 atomicAdd(&csum[(li >> 6) * (OW_KCAP / 2) + (kid >> 1)], cnt << (16 * (kid & 1)));
                 elist[li] = kid | ((cnt - 1u) << 9);
                 ++li;
             }
         }
         lds_barrier();
+        GP_STAMP(1, 4);
         // ---- rank base of every group: requests of its key in earlier tiles = in earlier messages of the list ----
         for (uint32_t k = 0; k * 256 < M; ++k) {
             const uint32_t e = k * 256 + t, chunk = e >> 6;
@@ -463,39 +501,37 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 elist[e] = kid | (base << 9);
             }
         }
-        lds_barrier();                                               // phase 1 of the LDS space is dead from here
+        GP_STAMP(1, 5);
         // ---- one table lookup per key, by the only workgroup that touches this key in this batch ----
+        // (no barrier needed before it: a key's reference is read and then replaced by its record by the same thread, and every
+        // comparison against references happened before the barrier above)
         int inserted = 0;
         for (uint32_t kid = t; kid < nk; kid += 256) {
-            if (kid != t) {                                           // (more than 256 keys in a round: rare)
-                const uint64_t hh = khash[kid];
-                kpos = (hh >> 7) & T.mask;
-                L.de0 = *(const ulonglong2*)&T.dir[kpos];
+            if (kid != t) {                                           // (more than 256 keys in a round: uniform keys)
+                kpos = (kref[kid].hash >> 7) & T.mask;
+                de0 = *(const ulonglong2*)&T.dir[kpos];
                 const Bucket* hb = &T.buckets[kpos];
-                const uint4* cw = (const uint4*)&hb->cell; L.c0 = cw[0]; L.c3 = cw[3];
-                L.rec = hb->rec;
-                const GMsg* wm = &W.gmsg[esrc[kwin[kid]]];
-                L.wk0 = wm->key0; L.wk1 = wm->key1; L.wmisc = wm->misc; L.wlimit = wm->limit; L.wduration = wm->duration;
+                const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
+                trec = hb->rec;
             }
-            const unsigned long long tag = khash[kid];
-            const uint32_t klen = gm_klen(L.wmisc);
+            const GMsg wm = kref[kid];
+            const unsigned long long tag = wm.hash;
+            const uint32_t klen = gm_klen(wm.misc);
             const uint32_t home = (uint32_t)kpos;
             uint64_t ppos = kpos;
             uint32_t slot = 0, errcode = 0;
             bool cand = false, fresh = false;
-            Rec rec = L.rec;
-            uint4 c0 = L.c0, c3 = L.c3;
             const uint8_t* lkey = nullptr; uint32_t llen = 0;
-            if (klen == 31u) { lkey = B.key_bytes + (uint32_t)L.wk0; llen = (uint32_t)(L.wk0 >> 32); }
+            if (klen == 31u) { lkey = B.key_bytes + (uint32_t)wm.key0; llen = (uint32_t)(wm.key0 >> 32); }
             for (uint32_t step = 0; step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
-                ulonglong2 de = L.de0;
+                ulonglong2 de = de0;
                 if (step) de = *(const ulonglong2*)&T.dir[ppos];
                 unsigned long long tg = de.x;
                 if (tg == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[ppos].tag, 0ull, tag);
                     if (old == 0ull) {                                // new key: this thread inserts it
                         slot = (uint32_t)ppos; cand = true; fresh = true; inserted++;
-                        if (klen != 31u) key_store_words(T, ppos, L.wk0, L.wk1, klen);
+                        if (klen != 31u) key_store_words(T, ppos, wm.key0, wm.key1, klen);
                         else if (!key_store(T, ppos, lkey, llen)) { errcode = 6; cand = false; }
                         T.dir[ppos].meta = META_READY;               // (nobody else can be looking for this tag during this launch)
                         break;
@@ -509,44 +545,46 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             if (cand && !fresh) {
                 if (slot != home) {
                     const Bucket* bk = &T.buckets[slot];
-                    const uint4* cw = (const uint4*)&bk->cell; c0 = cw[0]; c3 = cw[3];
-                    rec = bk->rec;
+                    const uint4* cw = (const uint4*)&bk->cell; tc0 = cw[0]; tc3 = cw[3];
+                    trec = bk->rec;
                 }
                 bool eq;
                 if (klen != 31u) {
-                    eq = (((uint64_t)c0.y << 32) | c0.x) == L.wk0 && (((uint64_t)c0.w << 32) | c0.z) == L.wk1 && (c3.w >> 16) == klen;
+                    eq = (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 && (tc3.w >> 16) == klen;
                 } else {
                     eq = key_equal(T, slot, lkey, llen);
                 }
                 if (!eq) sf |= SEG_RETRY;                             // a 64-bit hash collision with a resident key: careful round
             }
-            if (fresh || !cand) rec_clear(rec);
+            if (fresh || !cand) rec_clear(trec);
             const uint32_t tot = ktot[kid];
             const uint32_t groups = tot >> 20;
-            const long long cmin = kcmin[kid], cmax = kcmax[kid];
-            sf |= own_seg_flags(kfl[kid], groups, cmin < cmax);
-            if ((sf & SEG_CREATED_DIFFERS) && !(sf & SEG_NONUNIFORM) && gm_algo(L.wmisc) == ALGO_LEAKY) {
+            const int dmin = kcmin[kid], dmax = kcmax[kid];
+            sf |= own_seg_flags(kfl[kid], groups, dmin < dmax);
+            if ((sf & SEG_CREATED_DIFFERS) && !(sf & SEG_NONUNIFORM) && gm_algo(wm.misc) == ALGO_LEAKY) {
                 // requests of a leaky key stamped differently: the run is uniform only if no request of it leaks and none lets the
                 // bucket look expired to the ones behind it (leaky_created_harmless, monotone in created_at while nothing wraps)
-                Req rq; rq.hits = 0; rq.limit = L.wlimit; rq.duration = L.wduration; rq.burst = 0; rq.greg_expire = rq.greg_duration = 0;
-                rq.behavior = gm_behavior(L.wmisc); rq.algorithm = ALGO_LEAKY; rq.is_owner = 1;
-                bool ok = !(kfl[kid] & G_CFAR);
-                const int64_t d0 = wsub(cmin, rec.stamp), d1 = wsub(cmax, rec.stamp);
+                Req rq; rq.hits = 0; rq.limit = wm.limit; rq.duration = wm.duration; rq.burst = 0; rq.greg_expire = rq.greg_duration = 0;
+                rq.behavior = gm_behavior(wm.misc); rq.algorithm = ALGO_LEAKY; rq.is_owner = 1;
+                const int64_t cmin = wadd(B.now_ms, (int64_t)dmin), cmax = wadd(B.now_ms, (int64_t)dmax);
+                bool ok = !(kfl[kid] & G_CFAR) && dmin <= dmax;
+                const int64_t d0 = wsub(cmin, trec.stamp), d1 = wsub(cmax, trec.stamp);
                 ok = ok && d0 <= d1 && (uint64_t)d1 - (uint64_t)d0 == (uint64_t)cmax - (uint64_t)cmin;
                 ok = ok && wadd(cmax, rq.duration) >= wadd(cmin, rq.duration);
-                if (ok) { rq.created_at = cmax; ok = leaky_created_harmless(rec, rq, B.now_ms); }
-                if (ok) { rq.created_at = cmin; ok = leaky_created_harmless(rec, rq, B.now_ms); }
+                if (ok) { rq.created_at = cmax; ok = leaky_created_harmless(trec, rq, B.now_ms); }
+                if (ok) { rq.created_at = cmin; ok = leaky_created_harmless(trec, rq, B.now_ms); }
                 if (!ok) sf |= SEG_NONUNIFORM;
             }
             GRec kr;
-            kr.limit = rec.limit; kr.duration = rec.duration; kr.remaining = rec.remaining; kr.stamp = rec.stamp; kr.burst = rec.burst;
-            kr.expire_at = rec.expire_at;
-            kr.smeta = pack_smeta(rec, 1); kr.slot = slot;
+            kr.limit = trec.limit; kr.duration = trec.duration; kr.remaining = trec.remaining; kr.stamp = trec.stamp; kr.burst = trec.burst;
+            kr.expire_at = trec.expire_at;
+            kr.smeta = pack_smeta(trec, 1); kr.slot = slot;
             const uint32_t seg = esrc[kwin[kid]];
             kr.tail = gr_tail(sf | (errcode ? SEG_ERR : 0u), errcode, 0, tot & 0xfffffu, seg);
-            if (rec.invalid_at != 0) W.sinv[seg] = rec.invalid_at;
+            if (trec.invalid_at != 0) W.sinv[seg] = trec.invalid_at;
             krec[kid] = kr;
         }
+        GP_STAMPW(1, 6);
         lds_barrier();
         // ---- every group gets its record: the key's, with the group's base ----
         for (uint32_t k = 0; k * 256 < M; ++k) {
@@ -569,10 +607,11 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         }
         if (inserted) atomicAdd(&ins_n, (uint32_t)inserted);
     }
+    GP_STAMPW(1, 7);
     if (t == 0 && ins_n) atomicAdd(&T.ctr->tags_used, (unsigned long long)ins_n);
 }
 
-__global__ __launch_bounds__(256) void k_own(Table T, BatchView B, Work W, uint32_t ntiles) { own_body(T, B, W, blockIdx.x, ntiles); }
+__global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own(Table T, BatchView B, Work W, uint32_t ntiles) { own_body(T, B, W, blockIdx.x, ntiles); }
 
 // ---- k_eval3 --------------------------------------------------------------------------------------------------------------
 // Request order, workgroup = tile.  As k_eval2 from the evaluation on; what differs is where a request learns its segment:
@@ -583,6 +622,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
     __shared__ unsigned long long cnt[4];
     const uint32_t i = tile * 256 + threadIdx.x;
     const bool live = i < B.n;
+    GP_STAMP(2, 0);
     const uint32_t dl = live ? W.did[i] : 0u;
     const uint32_t gj = dl & 0xffu, lr = (dl >> 8) & 0xffu, derr = (dl >> 16) & 0xffu;
     uint32_t sf = 0, slot = 0, smeta = 0, base = 0, total = 1, d = 0, rerr = 0; Req r; Rec s0;
@@ -601,6 +641,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
         }
     }
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
+    GP_STAMPW(2, 1);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (live) {
         const uint32_t rank = base + lr;
@@ -716,6 +757,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             for (int w = 0; w < 4; ++w) W.segtiles[(size_t)d * 4 + w] = 0ull;
         }
     }
+    GP_STAMP(2, 2);
     {
         const int w_over = wave_sum(c_over), w_hit = wave_sum(c_hit), w_miss = wave_sum(c_miss), w_size = wave_sum(c_size);
         lds_barrier();                                               // (cnt zeroed)
@@ -731,6 +773,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
         }
     }
+    GP_STAMPW(2, 3);
 }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
     const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -739,7 +782,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
 
 // ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
 // kernel arguments; k_own_multi: 256 owners per batch, so that an owner's XCD is the same in every batch) ----------------------
-__global__ __launch_bounds__(FT) void k_part_multi(MultiFront A) {
+__global__ __launch_bounds__(FT, 4) void k_part_multi(MultiFront A) {
     uint32_t sb = 0, first = 0;
 #pragma unroll
     for (int k = 0; k < MULTI_MAX - 1; ++k)
@@ -747,7 +790,7 @@ __global__ __launch_bounds__(FT) void k_part_multi(MultiFront A) {
     const FrontArgs* a = (const FrontArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiFront, sub)) + sb;
     part_body(a->T, a->B, a->W, blockIdx.x - first);
 }
-__global__ __launch_bounds__(256) void k_own_multi(MultiFront A) {
+__global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own_multi(MultiFront A) {
     const MultiFront* m = (const MultiFront*)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t sb = blockIdx.x / PT_PARTS;
     const uint32_t ntiles = m->end_tile[sb] - (sb ? m->end_tile[sb - 1] : 0u);

@@ -102,7 +102,12 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMP(k) do { if (threadIdx.x == 0) W.dbg[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #define GB_STAMP2(k) do { if (threadIdx.x == 0) W.dbg[2048 + blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
 #define GB_STAMPW(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GB_STAMP(k); } while (0)
+// the owner-partitioned pipeline's kernels: kern 0 = k_part, 1 = k_own, 2 = k_eval3
+#define GP_STAMP(kern, k) do { if (threadIdx.x == 0) W.dbg[4096 + (kern) * 2048 + blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define GP_STAMPW(kern, k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); GP_STAMP(kern, k); } while (0)
 #else
+#define GP_STAMP(kern, k) do {} while (0)
+#define GP_STAMPW(kern, k) do {} while (0)
 #define GB_STAMP(k) do {} while (0)
 #define GB_STAMP2(k) do {} while (0)
 #define GB_STAMPW(k) do {} while (0)

@@ -81,6 +81,8 @@ static inline unsigned long long atomicOr(unsigned long long* p, unsigned long l
 static inline unsigned int atomicOr(unsigned int* p, unsigned int v) { fakehip::maybe_chaos(); auto o = *p; *p = o | v; return o; }
 static inline long long atomicMin(long long* p, long long v) { fakehip::maybe_chaos(); auto o = *p; if (v < o) *p = v; return o; }
 static inline long long atomicMax(long long* p, long long v) { fakehip::maybe_chaos(); auto o = *p; if (v > o) *p = v; return o; }
+static inline int atomicMin(int* p, int v) { fakehip::maybe_chaos(); auto o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int* p, int v) { fakehip::maybe_chaos(); auto o = *p; if (v > o) *p = v; return o; }
 static inline unsigned int atomicMin(unsigned int* p, unsigned int v) { fakehip::maybe_chaos(); auto o = *p; if (v < o) *p = v; return o; }
 static inline unsigned int atomicMax(unsigned int* p, unsigned int v) { fakehip::maybe_chaos(); auto o = *p; if (v > o) *p = v; return o; }
 #define __hip_atomic_load(p, order, scope) (*(p))
