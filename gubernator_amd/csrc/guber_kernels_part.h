@@ -276,8 +276,12 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
 __global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
-constexpr int OW_MCAP = 768;             // messages one round of an owner holds in LDS (more: the round splits by further hash bits)
-constexpr int OW_KCAP = 384;             // distinct keys of one round (uniform keys: 256 +- 16 per owner)
+#ifndef GUBER_OWN_EPT
+#define GUBER_OWN_EPT 3
+#endif
+constexpr int OW_EPT = GUBER_OWN_EPT;    // messages per thread and round
+constexpr int OW_MCAP = 256 * OW_EPT;    // messages of one round of an owner (more: the round splits by further bits of the home position)
+constexpr int OW_KCAP = 320;             // distinct keys of one round (uniform keys: 256 +- 16 per owner)
 constexpr int OW_HT = 512;               // LDS hash table of the round's keys
 constexpr int OW_CH = OW_MCAP / 64;      // 64-message chunks
 #ifndef GUBER_OWN_WAVES
@@ -319,8 +323,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ uint32_t kfl[OW_KCAP];                   // G_* over the key's groups
     __shared__ uint32_t ktot[OW_KCAP];                  // requests | groups << 20
     __shared__ int kcmin[OW_KCAP], kcmax[OW_KCAP];      // created_at range over the key's groups (ms from the batch clock)
-    __shared__ uint32_t elist[OW_MCAP];                 // per message: table slot, then key id 9 | members-1 8 (<< 9), then key id 9 | base 16 (<< 9)
-    __shared__ uint16_t esrc[OW_MCAP];                  // per message: its index in gmsg / grec (tile << 8 | position)
+    __shared__ uint16_t tpos[256 + 1], tstart[256];     // per tile: where its run starts in the owner's list, and in the tile's region
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t nkeys, ins_n;
     __shared__ uint32_t stk[40];                        // rounds to do: log2(split) << 24 | residue of the home position
@@ -331,11 +334,9 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     uint32_t start = 0, c = 0;
     if (t < ntiles) { const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16; }
     const size_t mbase = (size_t)t * FT + start;
-    // my run's first message is requested at once (its address does not depend on the scan below) and stays in registers
-    ulonglong2 f0 = {0ull, 0ull}, f1 = f0, f2 = f0, f3 = f0;
-    if (c) { const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase]; f0 = mq[0]; f1 = mq[1]; f2 = mq[2]; f3 = mq[3]; }
     if (t == 0) { stk[0] = 0u; sp = 1; ins_n = 0u; }
-    GP_STAMP(1, 0);
+    tstart[t] = (uint16_t)start;
+    GP_STAMPW(1, 0);
     for (;;) {
         lds_barrier();
         if (sp == 0) break;
@@ -345,10 +346,10 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         if (t == 0) { sp--; nkeys = 0u; }
         for (uint32_t j = t; j < OW_HT; j += 256) ktab[j] = 0ull;
         for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2); j += 256) csum[j] = 0u;
-        // my run's messages of this round
+        // my tile's messages of this round
         uint32_t cm = c;
-        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)(((r ? W.gmsg[mbase + r].hash : f0.x) >> 7) & T.mask) & smask) == res ? 1u : 0u; }
-        uint32_t pos, M;
+        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((W.gmsg[mbase + r].hash >> 7) & T.mask) & smask) == res ? 1u : 0u; }
+        uint32_t M;
         {
             const uint32_t incl = wave_incl_scan_u32(cm);
             if (lane == 63) wsum[wave] = incl;
@@ -356,44 +357,68 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             uint32_t before = 0;
 #pragma unroll
             for (uint32_t w = 0; w < 4; ++w) before += w < wave ? wsum[w] : 0u;
-            pos = before + incl - cm;
             M = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            const uint32_t pos = before + incl - cm;
+            tpos[t] = (uint16_t)(pos < 0xffffu ? pos : 0xffffu);
+            if (t == 255) tpos[256] = (uint16_t)(M < 0xffffu ? M : 0xffffu);
         }
         if (M == 0) continue;
         GP_STAMP(1, 1);
         bool split = M > OW_MCAP;
+        // The owner's list is dealt out evenly: thread t takes messages t, t + 256, t + 512 of the list (whatever tile they come
+        // from: binary search over the tiles' list positions), so that every message of the round is requested in ONE trip and a
+        // hot owner's long list costs every thread the same.  Per message: where it lives (tile << 8 | position) and its content.
+        uint32_t esrc[OW_EPT]; ulonglong2 m0[OW_EPT], m1[OW_EPT], m2[OW_EPT], m3[OW_EPT];
+        uint32_t eslot[OW_EPT];
+#pragma unroll
+        for (int k = 0; k < OW_EPT; ++k) { esrc[k] = 0xffffffffu; eslot[k] = 0; m0[k] = m1[k] = m2[k] = m3[k] = make_ulonglong2(0ull, 0ull); }
         if (!split) {
-            // ---- gather: hash -> LDS table slot; the first message of a key installs it and leaves its content as the key's reference ----
-            uint32_t li = pos;
-            for (uint32_t r = 0; r < c; ++r) {
-                const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase + r];
-                const ulonglong2 a0 = r ? mq[0] : f0;
-                const unsigned long long hh = a0.x;
-                if (lg && ((uint32_t)((hh >> 7) & T.mask) & smask) != res) continue;
-                ulonglong2 a1 = f1, a2 = f2, a3 = f3;
-                if (r) { a1 = mq[1]; a2 = mq[2]; a3 = mq[3]; }
-                uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 55) & (OW_HT - 1);
-                bool won = false;
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&ktab[s], 0ull, hh);
-                    if (old == 0ull) { won = true; break; }
-                    if (old == hh) break;
-                    s = (s + 1) & (OW_HT - 1);
-                }
-                if (won) {
-                    const uint32_t kid = atomicAdd(&nkeys, 1u);
-                    if (kid < OW_KCAP) {
-                        kidOf[s] = (uint16_t)kid; kwin[kid] = (uint16_t)li; kfl[kid] = 0u; ktot[kid] = 0u;
-                        const bool far = (gm_flags(a3.y) & G_CFAR) != 0u;      // the installer's own created_at range starts the key's
-                        kcmin[kid] = far ? INT32_MAX : (int)gm_cmin_delta(a3.y);
-                        kcmax[kid] = far ? INT32_MIN : (int)gm_cmin_delta(a3.y) + (int)gm_cspan(a3.y);
-                        ulonglong2* kq = (ulonglong2*)&kref[kid];
-                        kq[0] = a0; kq[1] = a1; kq[2] = a2; kq[3] = a3;
+            lds_barrier();                                            // tpos complete
+#pragma unroll
+            for (int k = 0; k < OW_EPT; ++k) {
+                const uint32_t e = (uint32_t)k * 256 + t;
+                if (e < M) {
+                    uint32_t lo = 0, hi = 256;                        // the last tile whose run starts at or before e and is not empty there
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpos[mid] <= e) lo = mid; else hi = mid; }
+                    uint32_t r = e - tpos[lo];
+                    uint32_t mi = lo * FT + tstart[lo] + r;
+                    if (lg) {                                         // a split round: the r-th message of the tile's run that belongs to this round
+                        const uint32_t mb = lo * FT + tstart[lo];
+                        uint32_t seen = 0, x = 0;
+                        for (;; ++x) { if (((uint32_t)((W.gmsg[mb + x].hash >> 7) & T.mask) & smask) == res) { if (seen == r) break; ++seen; } }
+                        mi = mb + x;
                     }
+                    esrc[k] = mi;
+                    const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mi];
+                    m0[k] = mq[0]; m1[k] = mq[1]; m2[k] = mq[2]; m3[k] = mq[3];
                 }
-                elist[li] = s;
-                esrc[li] = (uint16_t)(mbase + r);
-                ++li;
+            }
+            // ---- hash -> LDS table slot; the first message of a key installs it and leaves its content as the key's reference ----
+#pragma unroll
+            for (int k = 0; k < OW_EPT; ++k) {
+                if (esrc[k] != 0xffffffffu) {
+                    const unsigned long long hh = m0[k].x;
+                    uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 55) & (OW_HT - 1);
+                    bool won = false;
+                    for (;;) {
+                        const unsigned long long old = atomicCAS(&ktab[s], 0ull, hh);
+                        if (old == 0ull) { won = true; break; }
+                        if (old == hh) break;
+                        s = (s + 1) & (OW_HT - 1);
+                    }
+                    if (won) {
+                        const uint32_t kid = atomicAdd(&nkeys, 1u);
+                        if (kid < OW_KCAP) {
+                            kidOf[s] = (uint16_t)kid; kwin[kid] = (uint16_t)((uint32_t)k * 256 + t); kfl[kid] = 0u; ktot[kid] = 0u;
+                            const bool far = (gm_flags(m3[k].y) & G_CFAR) != 0u;      // the installer's own created_at range starts the key's
+                            kcmin[kid] = far ? INT32_MAX : (int)gm_cmin_delta(m3[k].y);
+                            kcmax[kid] = far ? INT32_MIN : (int)gm_cmin_delta(m3[k].y) + (int)gm_cspan(m3[k].y);
+                            ulonglong2* kq = (ulonglong2*)&kref[kid];
+                            kq[0] = m0[k]; kq[1] = m1[k]; kq[2] = m2[k]; kq[3] = m3[k];
+                        }
+                    }
+                    eslot[k] = s;
+                }
             }
             lds_barrier();
             split = nkeys > OW_KCAP;
@@ -417,36 +442,31 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         }
         const uint32_t nk = nkeys;
         GP_STAMPW(1, 2);
-        // ---- the table lines of my first key (thread = key id) are requested now and used after the messages have been compared ----
-        ulonglong2 de0 = {0ull, 0ull};
+        // ---- the home bucket of my first key (thread = key id) is requested now and used after the messages have been compared.
+        // ONLY the bucket: a resident key that sits at its home position (the usual case at load <= 0.5) is recognised by its stored
+        // key bytes alone — keys are inserted once and never move, so "this cell holds my key" is "this is my key's slot" — and the
+        // directory is read only for keys that are displaced or new ----
+        ulonglong2 de0 = {0ull, 0ull}, de1 = de0;
         uint4 tc0 = {0, 0, 0, 0}, tc3 = tc0;
         Rec trec; rec_clear(trec);
         uint64_t kpos = 0;
         const bool haskey = t < nk;
         if (haskey) {
             kpos = (kref[t].hash >> 7) & T.mask;
-            de0 = *(const ulonglong2*)&T.dir[kpos];
             const Bucket* hb = &T.buckets[kpos];
             const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
             trec = hb->rec;
         }
         GP_STAMP(1, 3);
         // ---- every message against its key's reference: exact key bytes, exact request shape; the key's totals ----
-        {
-            uint32_t li = pos;
-            for (uint32_t r = 0; r < c; ++r) {
-                ulonglong2 a0, a1, a2, a3;
-                if (r == 0) {
-                    a0 = f0; a1 = f1; a2 = f2; a3 = f3;
-                    if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
-                } else {
-                    const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mbase + r];
-                    a0 = mq[0];
-                    if (lg && ((uint32_t)((a0.x >> 7) & T.mask) & smask) != res) continue;
-                    a1 = mq[1]; a2 = mq[2]; a3 = mq[3];
-                }
-                const unsigned long long misc = a3.y;
-                const uint32_t kid = kidOf[elist[li]];
+        uint32_t ekid[OW_EPT], ecnt[OW_EPT], ebase[OW_EPT];
+#pragma unroll
+        for (int k = 0; k < OW_EPT; ++k) {
+            ekid[k] = 0; ecnt[k] = 0; ebase[k] = 0;
+            if (esrc[k] != 0xffffffffu) {
+                const uint32_t li = (uint32_t)k * 256 + t;
+                const unsigned long long misc = m3[k].y;
+                const uint32_t kid = kidOf[eslot[k]];
                 uint32_t f = gm_flags(misc);
                 const uint32_t cnt = gm_cnt(misc);
                 const bool far = (f & G_CFAR) != 0u;
@@ -457,48 +477,47 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                     const ulonglong2 b0 = wq[0], b1 = wq[1], b2 = wq[2], b3 = wq[3];
                     bool keq = gm_klen(misc) == gm_klen(b3.y);
                     if (keq) {
-                        if (gm_klen(misc) != 31u) keq = a0.y == b0.y && a1.x == b1.x;
-                        else keq = req_key_equal_at(B, (uint32_t)a0.y, (uint32_t)(a0.y >> 32), (uint32_t)b0.y, (uint32_t)(b0.y >> 32));
+                        if (gm_klen(misc) != 31u) keq = m0[k].y == b0.y && m1[k].x == b1.x;
+                        else keq = req_key_equal_at(B, (uint32_t)m0[k].y, (uint32_t)(m0[k].y >> 32), (uint32_t)b0.y, (uint32_t)(b0.y >> 32));
                     }
                     if (!keq) f |= G_RETRY;
-                    if (!msg_same_request(a1, a2, a3, b1, b2, b3)) f |= G_NONUNIFORM;
+                    if (!msg_same_request(m1[k], m2[k], m3[k], b1, b2, b3)) f |= G_NONUNIFORM;
                     range = !far && ((gm_flags(b3.y) & G_CFAR) || cmin != (int)gm_cmin_delta(b3.y) || cmax != (int)gm_cmin_delta(b3.y) + (int)gm_cspan(b3.y));
                 }
                 if (f) atomicOr(&kfl[kid], f);
                 atomicAdd(&ktot[kid], cnt | (1u << 20));
                 if (range) { atomicMin(&kcmin[kid], cmin); atomicMax(&kcmax[kid], cmax); }
                 atomicAdd(&csum[(li >> 6) * (OW_KCAP / 2) + (kid >> 1)], cnt << (16 * (kid & 1)));
-                elist[li] = kid | ((cnt - 1u) << 9);
-                ++li;
+                ekid[k] = kid; ecnt[k] = cnt;
             }
         }
         lds_barrier();
         GP_STAMP(1, 4);
         // ---- rank base of every group: requests of its key in earlier tiles = in earlier messages of the list ----
-        for (uint32_t k = 0; k * 256 < M; ++k) {
-            const uint32_t e = k * 256 + t, chunk = e >> 6;
-            const bool act = e < M;
-            uint32_t kid = 0, cnt = 0, ctot = 0;
-            if (act) {
-                const uint32_t w = elist[e];
-                kid = w & 511u; cnt = ((w >> 9) & 255u) + 1u;
-                ctot = (csum[chunk * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
-            }
-            uint32_t base = 0;
-            unsigned long long mm = __ballot(act && ctot != cnt);       // keys with several groups inside this chunk: one wave scan each
-            while (mm) {
-                const int Lq = __ffsll(mm) - 1;
-                const uint32_t lk = __shfl(kid, Lq, 64);
-                const bool mine = act && kid == lk;
-                const uint32_t incl = wave_incl_scan_u32(mine ? cnt : 0u);
-                if (mine) base = incl - cnt;
-                mm &= ~__ballot(mine);
-            }
-            if (act) {
-                const uint32_t treq = ktot[kid] & 0xfffffu;
-                if (treq != ctot)
-                    for (uint32_t c2 = 0; c2 < chunk; ++c2) base += (csum[c2 * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
-                elist[e] = kid | (base << 9);
+#pragma unroll
+        for (int k = 0; k < OW_EPT; ++k) {
+            if ((uint32_t)k * 256 < M) {                              // (uniform over the workgroup)
+                const uint32_t e = (uint32_t)k * 256 + t, chunk = e >> 6;
+                const bool act = esrc[k] != 0xffffffffu;
+                const uint32_t kid = ekid[k], cnt = ecnt[k];
+                uint32_t ctot = 0;
+                if (act) ctot = (csum[chunk * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
+                uint32_t base = 0;
+                unsigned long long mm = __ballot(act && ctot != cnt);   // keys with several groups inside this chunk: one wave scan each
+                while (mm) {
+                    const int Lq = __ffsll(mm) - 1;
+                    const uint32_t lk = __shfl(kid, Lq, 64);
+                    const bool mine = act && kid == lk;
+                    const uint32_t incl = wave_incl_scan_u32(mine ? cnt : 0u);
+                    if (mine) base = incl - cnt;
+                    mm &= ~__ballot(mine);
+                }
+                if (act) {
+                    const uint32_t treq = ktot[kid] & 0xfffffu;
+                    if (treq != ctot)
+                        for (uint32_t c2 = 0; c2 < chunk; ++c2) base += (csum[c2 * (OW_KCAP / 2) + (kid >> 1)] >> (16 * (kid & 1))) & 0xffffu;
+                    ebase[k] = base;
+                }
             }
         }
         GP_STAMP(1, 5);
@@ -509,7 +528,6 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         for (uint32_t kid = t; kid < nk; kid += 256) {
             if (kid != t) {                                           // (more than 256 keys in a round: uniform keys)
                 kpos = (kref[kid].hash >> 7) & T.mask;
-                de0 = *(const ulonglong2*)&T.dir[kpos];
                 const Bucket* hb = &T.buckets[kpos];
                 const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
                 trec = hb->rec;
@@ -523,9 +541,25 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             bool cand = false, fresh = false;
             const uint8_t* lkey = nullptr; uint32_t llen = 0;
             if (klen == 31u) { lkey = B.key_bytes + (uint32_t)wm.key0; llen = (uint32_t)(wm.key0 >> 32); }
-            for (uint32_t step = 0; step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
-                ulonglong2 de = de0;
-                if (step) de = *(const ulonglong2*)&T.dir[ppos];
+            // at home?  (keys of <= 16 bytes: the two key words and the length say it all; longer keys go through the directory)
+            const bool at_home = klen != 31u && (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 &&
+                                 (tc3.w >> 16) == klen;
+            if (at_home) { slot = home; cand = true; }
+            else {
+                // not there: the directory entries of the home position and of the next one, and the next bucket, in one trip
+                const uint64_t npos = (kpos + 1) & T.mask;
+                de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[npos];
+            }
+            for (uint32_t step = 0; !at_home && step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
+                ulonglong2 de = step == 0 ? de0 : de1;
+                if (step >= 1) {
+                    // a key that is not at its home position: the bucket behind every further directory entry is requested together
+                    // with the entry AFTER it (the first displaced step already has its entry: it came with the home position's)
+                    if (step >= 2) de = *(const ulonglong2*)&T.dir[ppos];
+                    const Bucket* bk = &T.buckets[ppos];
+                    const uint4* cw = (const uint4*)&bk->cell; tc0 = cw[0]; tc3 = cw[3];
+                    trec = bk->rec;
+                }
                 unsigned long long tg = de.x;
                 if (tg == 0ull) {
                     const unsigned long long old = atomicCAS(&T.dir[ppos].tag, 0ull, tag);
@@ -540,14 +574,10 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 }
                 if (tg == tag) { slot = (uint32_t)ppos; cand = true; break; }
             }
+            (void)home;
             if (!cand && !errcode) errcode = 6;                       // probe bound exceeded: table full
             uint32_t sf = 0;
-            if (cand && !fresh) {
-                if (slot != home) {
-                    const Bucket* bk = &T.buckets[slot];
-                    const uint4* cw = (const uint4*)&bk->cell; tc0 = cw[0]; tc3 = cw[3];
-                    trec = bk->rec;
-                }
+            if (cand && !fresh && !at_home) {
                 bool eq;
                 if (klen != 31u) {
                     eq = (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 && (tc3.w >> 16) == klen;
@@ -579,7 +609,19 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             kr.limit = trec.limit; kr.duration = trec.duration; kr.remaining = trec.remaining; kr.stamp = trec.stamp; kr.burst = trec.burst;
             kr.expire_at = trec.expire_at;
             kr.smeta = pack_smeta(trec, 1); kr.slot = slot;
-            const uint32_t seg = esrc[kwin[kid]];
+            const uint32_t wl = kwin[kid];                             // the installing message: list index -> its place in gmsg
+            uint32_t seg = 0;
+            {   // (the installer's esrc lives in its thread's registers: recomputed from the list index as every thread did)
+                uint32_t lo = 0, hi = 256;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpos[mid] <= wl) lo = mid; else hi = mid; }
+                seg = lo * FT + tstart[lo] + (wl - tpos[lo]);
+                if (lg) {
+                    const uint32_t mb = lo * FT + tstart[lo];
+                    uint32_t seen = 0, x = 0;
+                    for (;; ++x) { if (((uint32_t)((W.gmsg[mb + x].hash >> 7) & T.mask) & smask) == res) { if (seen == wl - tpos[lo]) break; ++seen; } }
+                    seg = mb + x;
+                }
+            }
             kr.tail = gr_tail(sf | (errcode ? SEG_ERR : 0u), errcode, 0, tot & 0xfffffu, seg);
             if (trec.invalid_at != 0) W.sinv[seg] = trec.invalid_at;
             krec[kid] = kr;
@@ -587,15 +629,13 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         GP_STAMPW(1, 6);
         lds_barrier();
         // ---- every group gets its record: the key's, with the group's base ----
-        for (uint32_t k = 0; k * 256 < M; ++k) {
-            const uint32_t e = k * 256 + t;
-            if (e < M) {
-                const uint32_t w = elist[e];
-                const uint32_t kid = w & 511u, base = w >> 9;
-                const ulonglong2* kq = (const ulonglong2*)&krec[kid];
+#pragma unroll
+        for (int k = 0; k < OW_EPT; ++k) {
+            if (esrc[k] != 0xffffffffu) {
+                const ulonglong2* kq = (const ulonglong2*)&krec[ekid[k]];
                 ulonglong2 q0 = kq[0], q1 = kq[1], q2 = kq[2], q3 = kq[3];
-                q3.y |= (unsigned long long)(base & 0xffffu) << 16;
-                const uint32_t src = esrc[e];
+                q3.y |= (unsigned long long)(ebase[k] & 0xffffu) << 16;
+                const uint32_t src = esrc[k];
                 ulonglong2* o = (ulonglong2*)&W.grec[src];
                 o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
                 if ((uint32_t)q3.y & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) {   // the walk's map: which tiles hold the segment, and as which group
