@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "guber_alloc_pinned", "guber_free_pinned", "guber_ring_create", "guber_ring_destroy", "guber_ring_route",
     "guber_ring_route_dev", "guber_ring_points", "guber_gregorian_expiration", "guber_gregorian_duration",
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
-    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_global_take",
+    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_profile_passes", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
     "guber_eval_batches_dev", "guber_eval_batches_routed_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
@@ -94,6 +94,7 @@ def lib():
         L.guber_pool_get_rate_limits.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 11 + [C.POINTER(GuberResult), C.c_void_p, C.c_uint32]
         L.guber_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.guber_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.guber_profile_passes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_alloc_pinned.restype = C.c_void_p
         L.guber_alloc_pinned.argtypes = [C.c_size_t]
         L.guber_free_pinned.argtypes = [C.c_void_p]
@@ -398,6 +399,15 @@ class Engine:
         _check(lib().guber_profile_read(self.h, arr, 16, C.byref(n)))
         self.last_profile_units = {arr[i].name.decode(): arr[i].units for i in range(n.value)}
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+
+    def profile_passes(self):
+        """after profile_read(): microseconds every pipeline pass (one batch, or one fused group) took from its first kernel's start
+        to its last kernel's end"""
+        n = C.c_uint32(0)
+        _check(lib().guber_profile_passes(self.h, None, 0, C.byref(n)))
+        arr = (C.c_float * max(n.value, 1))()
+        _check(lib().guber_profile_passes(self.h, arr, n.value, C.byref(n)))
+        return [arr[i] for i in range(n.value)]
 
     def compact(self, now_ms):
         _check(lib().guber_compact(self.h, now_ms))

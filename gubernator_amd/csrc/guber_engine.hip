@@ -159,6 +159,7 @@ struct guber_engine {
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[16] = {0}; uint64_t prof_n[16] = {0}, prof_units[16] = {0};
+    std::vector<float> group_us;   // per pipeline pass (the launches of one batch, or of one fused group): first kernel's start -> last kernel's end
 
     hipEvent_t get_event() {
         if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
@@ -2341,6 +2342,19 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
     std::lock_guard<std::mutex> lk(e->mu);
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     HIPCHK(hipStreamSynchronize(e->stream));
+    {   // one pipeline pass = the spans from a first-stage kernel up to the next first-stage kernel
+        auto first_stage = [](int k) { return k == KT_FRONT || k == KT_FRONT_MULTI || k == KT_PART || k == KT_PART_MULTI || k == KT_RESOLVE; };
+        size_t g0 = 0;
+        for (size_t i = 0; i <= e->spans.size(); ++i) {
+            if (i == e->spans.size() || (i > g0 && first_stage(e->spans[i].kernel))) {
+                if (i > g0 && first_stage(e->spans[g0].kernel)) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, e->spans[g0].a, e->spans[i - 1].b) == hipSuccess) e->group_us.push_back(ms * 1e3f);
+                }
+                g0 = i;
+            }
+        }
+    }
     for (auto& s : e->spans) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { e->prof_ms[s.kernel] += ms; e->prof_n[s.kernel]++; }
@@ -2354,6 +2368,17 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
         out[k].launches = e->prof_n[k]; out[k].total_ms = e->prof_ms[k]; out[k].units = e->prof_units[k];
     }
     if (out) for (int k = 0; k < KT_COUNT; ++k) { e->prof_ms[k] = 0; e->prof_n[k] = 0; e->prof_units[k] = 0; }
+    return GUBER_OK;
+}
+
+extern "C" int guber_profile_passes(guber_engine_t* e, float* us, uint32_t cap, uint32_t* n_out) {
+    if (!e || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    *n_out = (uint32_t)e->group_us.size();
+    if (us) {
+        for (uint32_t k = 0; k < cap && k < e->group_us.size(); ++k) us[k] = e->group_us[k];
+        e->group_us.clear();
+    }
     return GUBER_OK;
 }
 

@@ -341,6 +341,11 @@ typedef struct guber_kernel_time {
 } guber_kernel_time_t;
 int guber_profile_enable(guber_engine_t* e, int enable);
 int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out);
+/* After guber_profile_read(): the duration of every pipeline pass the profiled region made on this engine's stream — the launches
+ * of one batch, or of one fused group of up to four tables' batches (recorded by the group's first engine) — from the first
+ * kernel's start to the last kernel's end, in microseconds: what a batch spends on the GPU while the other streams are busy too.
+ * us = NULL: only the count.  Reading clears the list. */
+int guber_profile_passes(guber_engine_t* e, float* us, uint32_t cap, uint32_t* n_out);
 
 /* ---- GLOBAL behaviour (global.go): the engine accumulates, per bucket, what the reference's
  *      globalManager keeps in its hitsQueue / broadcastQueue maps.  A request carrying
