@@ -225,8 +225,10 @@ func (p *GPUWorkerPool) GetRateLimit(ctx context.Context, r *RateLimitReq, s Rat
 func (p *GPUWorkerPool) AddCacheItem(ctx context.Context, key string, item *CacheItem) error {
 	ci := toCItem(key, item)
 	defer C.free(unsafe.Pointer(ci.key))
-	if rc := C.guber_pool_add_item(p.pool, &ci); rc != C.GUBER_OK {
-		return errors.Errorf("guber_pool_add_item: %s", C.GoString(C.guber_strerror(rc)))
+	// The reference's only caller is UpdatePeerGlobals (gubernator.go:452): the broadcast state of a GLOBAL rate limit.  It belongs
+	// to the device's GLOBAL engine, where the non-owner's GLOBAL requests are answered from (guber_gpu.h: guber_pool_add_item_for).
+	if rc := C.guber_pool_add_item_for(p.pool, &ci, C.GUBER_BEHAVIOR_GLOBAL); rc != C.GUBER_OK {
+		return errors.Errorf("guber_pool_add_item_for: %s", C.GoString(C.guber_strerror(rc)))
 	}
 	return nil
 }

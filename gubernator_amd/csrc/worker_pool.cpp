@@ -1217,10 +1217,26 @@ int GPUWorkerPool::store_eval(guber_engine_t* engine_, const guber_batch_t& B, g
 }
 
 // ---- cache operations from other threads: they follow the placement and exclude a move in progress -----------------------
-int GPUWorkerPool::AddCacheItem(const guber_item_t& item) {
+// A key lives in ONE of two places on its device: the GLOBAL engine (requests with Behavior_GLOBAL go there: route()) or the plain
+// shard its hash selects.  The reference has one cache per worker, so its AddCacheItem / GetCacheItem need no such distinction;
+// here the caller says which (behavior: the RateLimitReq behaviour the item belongs to — UpdatePeerGlobals, gubernator.go:425-459,
+// installs GLOBAL state), or leaves it open (behavior < 0): then the item goes where the key already is, the GLOBAL engine first.
+int GPUWorkerPool::AddCacheItem(const guber_item_t& item, int behavior) {
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
-    Device& d = *devs_[DeviceOf(item.key, item.key_len)];
+    const uint32_t dv = DeviceOf(item.key, item.key_len);
+    Device& d = *devs_[dv];
     std::shared_lock<std::shared_mutex> lk(d.place_mu);
+    if (has_global_) {
+        guber_engine_t* ge = d.shards[d.n_plain]->engine;
+        bool global = behavior >= 0 && (behavior & 2);
+        if (behavior < 0) {
+            guber_item_t tmp; int f = 0;
+            const int rc = guber_get_item(ge, item.key, item.key_len, NowMs(), &tmp, &f);
+            if (rc != GUBER_OK) return rc;
+            global = f != 0;
+        }
+        if (global) return guber_add_items(ge, &item, 1, nullptr);
+    }
     return guber_add_items(shards_[ShardOf(item.key, item.key_len)]->engine, &item, 1, nullptr);
 }
 int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool* found) {
@@ -1228,16 +1244,23 @@ int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool*
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
     Device& d = *devs_[DeviceOf((const uint8_t*)key.data(), (uint32_t)key.size())];
     std::shared_lock<std::shared_mutex> lk(d.place_mu);
+    if (has_global_) {                                                                 // the GLOBAL engine first (see AddCacheItem)
+        const int rc = guber_get_item(d.shards[d.n_plain]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
+        if (rc != GUBER_OK) return rc;
+        if (f) { *found = true; return GUBER_OK; }
+    }
     const int rc = guber_get_item(shards_[ShardOf(key)]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
     *found = f != 0;
     return rc;
 }
-int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n) {
+int GPUWorkerPool::Load(const guber_item_t* items, uint32_t n, const uint8_t* global_hint) {
     // workers.go:329-449: every item goes to the worker that owns its key; chunks bound the staging buffers
     std::vector<std::shared_lock<std::shared_mutex>> locks;
     for (auto& d : devs_) locks.emplace_back(d->place_mu);
+    // (a restored item carries no behaviour — CacheItem has none, cache.go:29-41: it goes to its key's plain shard unless the caller
+    // says it belongs to GLOBAL requests, guber_pool_load_hinted)
     std::vector<std::vector<guber_item_t>> per(shards_.size());
-    for (uint32_t i = 0; i < n; ++i) per[ShardOf(items[i].key, items[i].key_len)].push_back(items[i]);
+    for (uint32_t i = 0; i < n; ++i) per[ShardOf(items[i].key, items[i].key_len, (global_hint && global_hint[i]) ? 2u : 0u)].push_back(items[i]);
     for (size_t j = 0; j < per.size(); ++j)
         for (size_t lo = 0; lo < per[j].size(); lo += 65536) {
             const int rc = guber_add_items(shards_[j]->engine, per[j].data() + lo, (uint32_t)std::min<size_t>(65536, per[j].size() - lo), nullptr);
@@ -1349,6 +1372,9 @@ extern "C" uint32_t guber_pool_shard_of(guber_pool_t* p, const uint8_t* key, uin
     return p ? p->pool->ShardOf(key, key_len) : 0;
 }
 extern "C" int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n) { return p ? p->pool->Load(items, n) : GUBER_E_INVALID_ARG; }
+extern "C" int guber_pool_load_hinted(guber_pool_t* p, const guber_item_t* items, uint32_t n, const uint8_t* global_hint) {
+    return p ? p->pool->Load(items, n, global_hint) : GUBER_E_INVALID_ARG;
+}
 extern "C" int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user) {
     if (!p || !save) return GUBER_E_INVALID_ARG;
     return p->pool->Store([&](const guber_item_t& it) { save(user, &it); });
@@ -1390,6 +1416,9 @@ extern "C" int guber_pool_get_rate_limits_owner(guber_pool_t* p, uint32_t n, con
                                      out, err_text, err_stride, is_owner);
 }
 extern "C" int guber_pool_add_item(guber_pool_t* p, const guber_item_t* item) { return p && item ? p->pool->AddCacheItem(*item) : GUBER_E_INVALID_ARG; }
+extern "C" int guber_pool_add_item_for(guber_pool_t* p, const guber_item_t* item, uint32_t behavior) {
+    return p && item ? p->pool->AddCacheItem(*item, (int)(behavior & 0x7fffffffu)) : GUBER_E_INVALID_ARG;
+}
 extern "C" int guber_pool_get_item(guber_pool_t* p, const uint8_t* key, uint32_t key_len, guber_item_t* out, int* found) {
     if (!p || !key || !out || !found) return GUBER_E_INVALID_ARG;
     bool f = false;

@@ -96,11 +96,11 @@ class GPUWorkerPool {
                          const int64_t* hits, const int64_t* limit, const int64_t* duration, const int64_t* burst, const int64_t* created_at,
                          const int32_t* algorithm, const uint32_t* behavior, guber_result_t* out, char* err_text, uint32_t err_stride,
                          const uint8_t* is_owner = nullptr);
-    int AddCacheItem(const guber_item_t& item);                                  // workers.go:537
+    int AddCacheItem(const guber_item_t& item, int behavior = -1);               // workers.go:537 (behavior: see worker_pool.cpp)
     int GetCacheItem(const std::string& key, guber_item_t* out, bool* found);    // workers.go:583
     // WorkerPool.Load (workers.go:329-449): hand every item of a Loader to the cache; WorkerPool.Store (workers.go:451-534):
     // visit every resident item (what Loader.Save receives).  Bulk paths: guber_add_items / guber_dump.
-    int Load(const guber_item_t* items, uint32_t n);
+    int Load(const guber_item_t* items, uint32_t n, const uint8_t* global_hint = nullptr);
     int Store(const std::function<void(const guber_item_t&)>& save);
     int64_t Size();
     void Close();                                                                // workers.go:157

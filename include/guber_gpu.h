@@ -443,6 +443,12 @@ void guber_pool_set_store(guber_pool_t* p, const guber_store_callbacks_t* cb);
  * resident item to Loader.Save at shutdown (`save` is called once per item; item->key is valid during the call). */
 uint32_t guber_pool_shard_of(guber_pool_t* p, const uint8_t* key, uint32_t key_len);   /* WorkerPool.getWorker, workers.go:180-184 */
 int guber_pool_load(guber_pool_t* p, const guber_item_t* items, uint32_t n);
+/* The same with a hint per item (NULL = none): global_hint[i] != 0 restores item i into its device's GLOBAL engine.  A CacheItem
+ * carries no behaviour (cache.go:29-41), so guber_pool_load restores everything into the plain shards: a bucket that GLOBAL requests
+ * had built up is then found by plain requests only, and the first GLOBAL request for its key starts a fresh bucket (as after a
+ * restart without a Loader).  A Loader that persists where an item came from (guber_pool_store reports the GLOBAL engines' items
+ * last) can pass it back here. */
+int guber_pool_load_hinted(guber_pool_t* p, const guber_item_t* items, uint32_t n, const uint8_t* global_hint);
 int guber_pool_store(guber_pool_t* p, void (*save)(void* user, const guber_item_t* item), void* user);      /* before the first request; NULL = none */   /* clock.Freeze of the reference tests; 0 = wall clock */
 guber_engine_t* guber_pool_engine(guber_pool_t* p);
 uint64_t guber_pool_batches(guber_pool_t* p);
@@ -464,6 +470,12 @@ int guber_pool_get_rate_limits_owner(guber_pool_t* p, uint32_t n, const uint8_t*
 /* WorkerPool.AddCacheItem / GetCacheItem (workers.go:537-626) and the sum of the workers' cache sizes: the item goes to / comes
  * from the shard the placement gives its key */
 int guber_pool_add_item(guber_pool_t* p, const guber_item_t* item);
+/* With GUBER_FLAG_GLOBAL a key lives either in its device's GLOBAL engine (where requests with Behavior_GLOBAL are evaluated) or in
+ * the plain shard its hash selects; the reference has ONE cache per worker and needs no such distinction.  guber_pool_add_item puts the
+ * item where the key already is (the GLOBAL engine is asked first) and in the plain shard otherwise; guber_pool_get_item asks the
+ * GLOBAL engine first.  guber_pool_add_item_for says which requests the item belongs to — `behavior` as in RateLimitReq: what
+ * UpdatePeerGlobals (gubernator.go:425-459, the broadcast of an owner's GLOBAL state) must use, with GUBER_BEHAVIOR_GLOBAL. */
+int guber_pool_add_item_for(guber_pool_t* p, const guber_item_t* item, uint32_t behavior);
 int guber_pool_get_item(guber_pool_t* p, const uint8_t* key, uint32_t key_len, guber_item_t* out, int* found);
 int64_t guber_pool_size(guber_pool_t* p);
 

@@ -1,0 +1,84 @@
+/* TEST-ONLY.  cgo compiles the preamble of go/gpu_worker_pool.go as C: this file is that preamble and the call sequence the Go
+ * binding makes, as plain C99 (gcc -std=c99 -pedantic -Wall -Werror), so that include/guber_gpu.h and include/guber_wire.h are
+ * checked to be usable from C — they are otherwise only ever included from C++ and mirrored by hand in ctypes.  Linked against the
+ * product library and run without a GPU: pool creation must fail with GUBER_E_NO_DEVICE and nothing else may be reached. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "guber_gpu.h"
+#include "guber_wire.h"
+
+/* the //export trampolines of the Go side */
+static int goStoreGet(void* user, guber_store_req_t* r, guber_item_t* out) { (void)user; (void)r; (void)out; return 0; }
+static void goStoreOnChange(void* user, guber_store_req_t* r, guber_item_t* item) { (void)user; (void)r; (void)item; }
+static void goStoreRemove(void* user, uint8_t* key, uint32_t key_len) { (void)user; (void)key; (void)key_len; }
+static void goStoreSave(void* user, guber_item_t* item) { (void)user; (void)item; }
+
+/* the cgo preamble's helpers, verbatim in shape */
+static void guber_go_set_store(guber_pool_t* p, void* user) {
+    guber_store_callbacks_t cb;
+    cb.get = (int (*)(void*, const guber_store_req_t*, guber_item_t*))goStoreGet;
+    cb.on_change = (void (*)(void*, const guber_store_req_t*, const guber_item_t*))goStoreOnChange;
+    cb.remove = (void (*)(void*, const uint8_t*, uint32_t))goStoreRemove;
+    cb.user = user;
+    guber_pool_set_store(p, &cb);
+}
+static int guber_go_store_all(guber_pool_t* p, void* user) { return guber_pool_store(p, (void (*)(void*, const guber_item_t*))goStoreSave, user); }
+
+/* NewGPUWorkerPool -> GetRateLimits -> AddCacheItem -> GetCacheItem -> Load -> Store -> GlobalSync -> Close, as the binding calls them */
+static int call_sequence(int really) {
+    guber_config_t cfg;
+    int32_t devs[1] = {0};
+    guber_pool_t* pool = NULL;
+    int rc;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (uint32_t)sizeof cfg;
+    cfg.cache_size = 50000;
+    cfg.max_batch = 1000;
+    cfg.flags = GUBER_FLAG_GLOBAL;
+    cfg.device = devs[0];
+    rc = guber_pool_create_multi(&cfg, devs, 1, 8, 1000, 500, &pool);
+    if (rc != GUBER_OK) {
+        printf("create: %s (%s)\n", guber_strerror(rc), guber_last_error());
+        return rc;
+    }
+    if (!really) return 0;
+    {
+        enum { N = 2, STRIDE = 200 };
+        const char names[] = "ab", ukeys[] = "xy";
+        uint32_t name_off[N + 1] = {0, 1, 2}, ukey_off[N + 1] = {0, 1, 2};
+        int64_t hits[N] = {1, 1}, limit[N] = {10, 10}, duration[N] = {1000, 1000}, burst[N] = {0, 0}, created[N] = {0, 0};
+        int64_t o_limit[N], o_rem[N], o_reset[N];
+        int32_t algo[N] = {0, 1};
+        uint32_t behavior[N] = {0, GUBER_BEHAVIOR_GLOBAL};
+        uint8_t owner[N] = {1, 0}, status[N], er[N];
+        char text[N * STRIDE];
+        guber_result_t out;
+        guber_item_t item, got;
+        int found = 0;
+        guber_global_sync_stats_t st;
+        memset(&out, 0, sizeof out);
+        out.status = status; out.limit = o_limit; out.remaining = o_rem; out.reset_time = o_reset; out.err = er;
+        guber_go_set_store(pool, NULL);
+        rc = guber_pool_get_rate_limits_owner(pool, N, (const uint8_t*)names, name_off, (const uint8_t*)ukeys, ukey_off, hits, limit, duration, burst,
+                                              created, algo, behavior, owner, &out, text, STRIDE);
+        memset(&item, 0, sizeof item);
+        item.key = (const uint8_t*)"a_x"; item.key_len = 3; item.limit = 10; item.duration = 1000; item.remaining = 5;
+        rc |= guber_pool_add_item_for(pool, &item, GUBER_BEHAVIOR_GLOBAL);
+        rc |= guber_pool_get_item(pool, (const uint8_t*)"a_x", 3, &got, &found);
+        rc |= guber_pool_load(pool, &item, 1);
+        rc |= guber_go_store_all(pool, NULL);
+        rc |= guber_pool_global_sync(pool, &st);
+    }
+    guber_pool_destroy(pool);
+    return rc;
+}
+
+int main(int argc, char** argv) {
+    const int rc = call_sequence(argc > 1 && !strcmp(argv[1], "--gpu"));
+    (void)argv;
+    if (argc > 1) return rc == GUBER_OK ? 0 : 1;
+    return rc == GUBER_E_NO_DEVICE ? 0 : 2;       /* no GPU: the product fails loudly, it has no CPU path */
+}

@@ -110,3 +110,20 @@ def test_argument_checks_need_no_device(L):
     st = C.c_void_p()
     assert L.guber_stage_create(None, 16, 0, C.byref(st)) != 0 and not st.value
     assert L.guber_eval_batches_dev(None, None, None, 0, None) != 0
+
+
+def test_headers_are_plain_c99_and_the_go_call_sequence_links(L, tmp_path):
+    """cgo compiles the binding's preamble as C.  tests/hostsim/abi_c99.c includes both public headers and makes the calls
+    go/gpu_worker_pool.go makes, with the binding's casts: gcc -std=c99 -pedantic -Werror must take it, it must link against the
+    product library, and without a GPU its pool creation must fail with GUBER_E_NO_DEVICE (exit 0) — never evaluate on the CPU."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "abi_c99")
+    libdir = os.path.join(support.ROOT, "gubernator_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(support.ROOT, "include"), "-o", exe,
+                    os.path.join(support.ROOT, "tests", "hostsim", "abi_c99.c"), "-L", libdir, "-lguber_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the no-device leg is for the CPU box (the --gpu leg runs in tests/test_gpu_host_layer.py)")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "no HIP device" in r.stdout or "no CPU fallback" in r.stdout, r.stdout

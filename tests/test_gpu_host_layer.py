@@ -1,5 +1,6 @@
 """The C++ host layer (GPUWorkerPool + V1Instance.GetRateLimits, csrc/worker_pool.h) driven the way the
 reference's functional tests drive a daemon: a frozen clock, one GetRateLimits call per step."""
+import os
 import threading
 
 import numpy as np
@@ -345,6 +346,26 @@ def test_pool_global_engine_and_hot_key_migration():
     st = inst.global_sync()
     assert st["update_rows"] == 200 and st["items_installed"] == 200 and st["fallbacks"] == 0, st   # every owner broadcast, the other replica installed
     assert inst.global_engine_size(0) == inst.global_engine_size(1) == 200
+    # (a2) UpdatePeerGlobals (gubernator.go:425-459) installs broadcast GLOBAL state through AddCacheItem: it must land where the
+    # non-owner's GLOBAL requests are answered from — the device's GLOBAL engine — and GetCacheItem must find it there
+    import support
+    it = support.make_item("glob_peer0", 0, limit=50, duration=60_000, remaining=7, stamp=now, expire_at=now + 60_000, status=0)
+    inst.add_item(it, behavior=2)
+    dv = inst.device_of("glob_peer0")
+    assert inst.global_engine_size(dv) == 201 and inst.size() == 401
+    got = inst.get_item("glob_peer0")
+    assert got is not None and got["remaining"] == 7 and got["limit"] == 50
+    out = inst.GetRateLimits([dict(name="glob", unique_key="peer0", hits=0, limit=50, duration=60_000, behavior=2, created_at=now)], is_owner=[False])
+    assert (out[0]["status"], out[0]["remaining"], out[0]["error"]) == (0, 7, ""), out
+    # without a behaviour the item goes where its key already lives: the GLOBAL engine for this key, a plain shard for a new one
+    it2 = support.make_item("glob_peer0", 0, limit=50, duration=60_000, remaining=3, stamp=now, expire_at=now + 60_000, status=0)
+    inst.add_item(it2)
+    assert inst.global_engine_size(dv) == 201 and inst.get_item("glob_peer0")["remaining"] == 3
+    inst.add_item(support.make_item("plain_x", 0, limit=9, duration=60_000, remaining=4, stamp=now, expire_at=now + 60_000, status=0))
+    assert inst.global_engine_size(0) + inst.global_engine_size(1) == 401 and inst.size() == 403 and inst.get_item("plain_x")["remaining"] == 4
+    out = inst.GetRateLimits([dict(name="plain", unique_key="x", hits=1, limit=9, duration=60_000, created_at=now)])
+    assert (out[0]["status"], out[0]["remaining"]) == (0, 3), out
+    extra = 2                                                       # items added above (glob_peer0, plain_x), on top of the oracle's
     # (b) one key hammered, placement passes asked for in between
     rng = np.random.default_rng(5)
     L = ga.lib()
@@ -360,5 +381,18 @@ def test_pool_global_engine_and_hot_key_migration():
         L.guber_pool_rebalance(inst.h)
     m = inst.metrics()
     assert m["rebalances"] >= 1 and m["keys_moved"] >= 1, m
-    assert inst.size() == o.size() + 200                                    # (the GLOBAL keys live on both devices' replicas)
+    assert inst.size() == o.size() + 200 + extra                            # (the GLOBAL keys live on both devices' replicas)
     inst.close()
+
+
+def test_the_go_bindings_call_sequence_in_plain_c(tmp_path):
+    """tests/hostsim/abi_c99.c — the cgo preamble and the calls go/gpu_worker_pool.go makes, compiled as C99 — against the real
+    library on the GPU: create, GetRateLimits with owner flags, AddCacheItem (GLOBAL), GetCacheItem, Load, Store, GlobalSync, Close."""
+    import subprocess
+    exe = str(tmp_path / "abi_c99")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "gubernator_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "tests", "hostsim", "abi_c99.c"), "-L", libdir, "-lguber_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    r = subprocess.run([exe, "--gpu"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
