@@ -727,6 +727,9 @@ def main():
     steps = max(args.steps, args.min_batches)
     rig = Rig(ctx, args.algo, args.dist, S, duration_ms=args.duration_ms)
     resident = rig.populate(NOW0)
+    # what every rank holds, and how many ranks the collective backend (nccl = RCCL for N > 1) really sees
+    resident_by_rank = shard.gather_over_ranks(resident, device=red_dev)
+    ranks_seen = shard.sum_over_ranks(1, device=red_dev)
     m = rig.measure(steps, args.warmup, NOW0, seed, profile_steps=max(0, args.profile_steps), latency_steps=max(0, args.latency_steps))
 
     roofline = latency = cpu = parity = None
@@ -826,6 +829,7 @@ def main():
                                     ("own stream + batcher thread each" if args.dispatch == "threads" else
                                      f"one dispatcher, shards spread over {args.streams} stream(s): the next batch of up to four shards of a stream per pair of launches")) if S > 1 else ", one table"),
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
+                    "resident_items_by_rank": resident_by_rank, "ranks_seen_by_the_collective_backend": ranks_seen, "backend": args.backend if world > 1 else None,
                     "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
                     "stream": {"replayed": False, "distinct_batches_total": len(rig.seq), "timed_batches": steps,
                                "distinct_keys_touched": touched, "table_bytes_touched": touched * 144, "table_bytes_touched_in_64B_sectors": touched * 192,

@@ -52,3 +52,15 @@ def sum_over_ranks(value, device=None):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def gather_over_ranks(value, device=None):
+    """[value of rank 0, value of rank 1, ...] (python ints) on every rank; [value] when not distributed."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [int(value)]
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if device is not None else "cpu")
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [int(x.item()) for x in out]
