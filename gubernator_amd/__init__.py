@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "guber_alloc_pinned", "guber_free_pinned", "guber_ring_create", "guber_ring_destroy", "guber_ring_route",
     "guber_ring_route_dev", "guber_ring_points", "guber_gregorian_expiration", "guber_gregorian_duration",
     "guber_xxhash64", "guber_fnv1_64", "guber_fnv1a_64", "guber_strerror", "guber_item_strerror",
-    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_profile_passes", "guber_global_take",
+    "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_profile_passes", "guber_set_timezone", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
     "guber_eval_batches_dev", "guber_eval_batches_routed_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
@@ -568,6 +568,47 @@ class Stage:
             self.close()
         except Exception:   # noqa: BLE001
             pass
+
+
+def set_timezone(offset0_s=0, transitions=()):
+    """guber_set_timezone: the daemon's zone for DURATION_IS_GREGORIAN (interval.go uses now.Location()).  offset0_s = UTC offset
+    before the first transition; transitions = [(utc_seconds, offset_s_from_then_on), ...] ascending, at most 16.  () and 0 = UTC."""
+    class _Tz(C.Structure):
+        _fields_ = [("n", C.c_uint32), ("offset0_s", C.c_int32), ("when_s", C.POINTER(C.c_int64)), ("offset_s", C.POINTER(C.c_int32))]
+    tr = list(transitions)
+    when = (C.c_int64 * max(len(tr), 1))(*[int(w) for w, _ in tr])
+    off = (C.c_int32 * max(len(tr), 1))(*[int(o) for _, o in tr])
+    tz = _Tz(len(tr), int(offset0_s), when, off)
+    L = lib()
+    L.guber_set_timezone.argtypes = [C.c_void_p]
+    _check(L.guber_set_timezone(C.byref(tz)))
+
+
+def zone_transitions(name, year_from, year_to):
+    """(offset0_s, [(utc_s, offset_s), ...]) of an IANA zone between two years, from the interpreter's zoneinfo — what a binding
+    derives from its runtime's zone database and hands to guber_set_timezone"""
+    import datetime as dt
+    from zoneinfo import ZoneInfo
+    z = ZoneInfo(name)
+    t = int(dt.datetime(year_from, 1, 1, tzinfo=dt.timezone.utc).timestamp())
+    end = int(dt.datetime(year_to + 1, 1, 1, tzinfo=dt.timezone.utc).timestamp())
+    off_at = lambda u: int(dt.datetime.fromtimestamp(u, z).utcoffset().total_seconds())
+    off0 = cur = off_at(t)
+    out = []
+    step = 3600
+    while t < end:
+        if off_at(t + step) != cur:
+            lo, hi = t, t + step                                  # bisect the transition to the second
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if off_at(mid) == cur:
+                    lo = mid
+                else:
+                    hi = mid
+            cur = off_at(hi)
+            out.append((hi, cur))
+        t += step
+    return off0, out
 
 
 class V1Instance:

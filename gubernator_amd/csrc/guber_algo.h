@@ -158,27 +158,73 @@ GB_HD void civil_from_days(int64_t z, int64_t& y, int& m, int& d) {
     y = yoe + era * 400 + (m <= 2);
 }
 }  // namespace cal
+// ---- the daemon's time zone (interval.go:97-142 build their civil dates with now.Location()) --------------------------------
+// A zone = the UTC offset in effect before the first listed transition and, per transition, the instant (UTC seconds) and the
+// offset from then on — the shape of Go's time.Location (zoneTrans / zone).  n == 0 and offset0 == 0 is UTC.  The engine keeps
+// one per process (guber_set_timezone), the kernels read it from a device global.
+constexpr int TZ_MAX = 16;
+struct TzTable { uint32_t n; int32_t offset0_s; int64_t when_s[TZ_MAX]; int32_t offset_s[TZ_MAX]; };
+namespace cal {
+// Location.lookup: the period [start, end) containing the instant, and its offset
+GB_HD void tz_lookup(const TzTable* tz, int64_t utc_s, int64_t& off, int64_t& start, int64_t& end) {
+    off = 0; start = INT64_MIN; end = INT64_MAX;
+    if (!tz) return;
+    off = tz->offset0_s;
+    if (tz->n) end = tz->when_s[0];
+    for (uint32_t k = 0; k < tz->n && k < (uint32_t)TZ_MAX; ++k) {
+        if (tz->when_s[k] > utc_s) break;
+        off = tz->offset_s[k]; start = tz->when_s[k]; end = k + 1 < tz->n ? tz->when_s[k + 1] : INT64_MAX;
+    }
+}
+// time.Date(..., loc): civil seconds of the zone -> UTC seconds, with Go's two-step resolution of the offset (time.go Date():
+// look the civil value up as if it were UTC; if the resulting instant falls outside that period, look the instant itself up)
+GB_HD int64_t tz_civil_to_utc_s(const TzTable* tz, int64_t civil_s) {
+    int64_t off, start, end;
+    tz_lookup(tz, civil_s, off, start, end);
+    if (off != 0) {
+        const int64_t utc = civil_s - off;
+        if (utc < start || utc >= end) { int64_t s2, e2; tz_lookup(tz, utc, off, s2, e2); }
+        return civil_s - off;
+    }
+    return civil_s;
+}
+}  // namespace cal
 // interval.go:117-148 GregorianExpiration
-GB_HD uint32_t greg_expiration(int64_t now_ns, int64_t d, int64_t& expire_ms) {
+GB_HD uint32_t greg_expiration(int64_t now_ns, int64_t d, int64_t& expire_ms, const TzTable* tz = nullptr) {
     using namespace cal;
     expire_ms = 0;
     int64_t y; int m, dd;
-    const int64_t day = floor_div(now_ns, kDay);
+    int64_t off = 0, ps, pe;
+    tz_lookup(tz, floor_div(now_ns, kSec), off, ps, pe);
+    const int64_t civil_ns = wadd(now_ns, wmul(off, kSec));                        // now.Date(), now.Hour(): the zone's civil time
+    const int64_t day = floor_div(civil_ns, kDay);
     civil_from_days(day, y, m, dd);
     int64_t end_ns;
-    if (d == 0) end_ns = wadd(wmul(floor_div(now_ns, kMin), kMin), kMin - 1);
-    else if (d == 1) end_ns = wadd(wmul(floor_div(now_ns, kHour), kHour), kHour - 1);
-    else if (d == 2) end_ns = wadd(wmul(day, kDay), kDay - 1);
+    if (d == 0) end_ns = wadd(wmul(floor_div(now_ns, kMin), kMin), kMin - 1);      // now.Truncate(Minute): on the absolute time
+    else if (d == 1) {
+        if (!tz) end_ns = wadd(wmul(floor_div(now_ns, kHour), kHour), kHour - 1);
+        else {
+            const int64_t hour = floor_div(civil_ns - day * kDay, kHour);
+            end_ns = wadd(wmul(tz_civil_to_utc_s(tz, day * 86400 + hour * 3600), kSec), kHour - 1);
+        }
+    }
+    else if (d == 2) end_ns = tz ? wadd(wmul(tz_civil_to_utc_s(tz, day * 86400 + 86399), kSec), kSec - 1) : wadd(wmul(day, kDay), kDay - 1);
     else if (d == 3) return 2u;                                                     // IE_GREG_WEEKS
-    else if (d == 4) end_ns = wsub(wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
-    else if (d == 5) end_ns = wsub(wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
+    else if (d == 4) {
+        const int64_t nd = days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1);
+        end_ns = tz ? wsub(wmul(tz_civil_to_utc_s(tz, nd * 86400), kSec), 1) : wsub(wmul(nd, kDay), 1);
+    }
+    else if (d == 5) {
+        const int64_t nd = days_from_civil(y + 1, 1, 1);
+        end_ns = tz ? wsub(wmul(tz_civil_to_utc_s(tz, nd * 86400), kSec), 1) : wsub(wmul(nd, kDay), 1);
+    }
     else return 3u;                                                                 // IE_GREG_INVALID
     expire_ms = floor_div(end_ns, kMs);
     return 0u;
 }
 // interval.go:84-110 GregorianDuration.  The months / years arms keep the reference's expression exactly as written:
 //   end.UnixNano() - begin.UnixNano()/1000000
-GB_HD uint32_t greg_duration(int64_t now_ns, int64_t d, int64_t& duration) {
+GB_HD uint32_t greg_duration(int64_t now_ns, int64_t d, int64_t& duration, const TzTable* tz = nullptr) {
     using namespace cal;
     duration = 0;
     if (d == 0) { duration = 60000; return 0u; }
@@ -187,24 +233,28 @@ GB_HD uint32_t greg_duration(int64_t now_ns, int64_t d, int64_t& duration) {
     if (d == 3) return 2u;
     if (d != 4 && d != 5) return 3u;
     int64_t y; int m, dd;
-    civil_from_days(floor_div(now_ns, kDay), y, m, dd);
+    int64_t off = 0, ps, pe;
+    tz_lookup(tz, floor_div(now_ns, kSec), off, ps, pe);
+    civil_from_days(floor_div(wadd(now_ns, wmul(off, kSec)), kDay), y, m, dd);
     int64_t begin, end;
-    if (d == 4) {
-        begin = wmul(days_from_civil(y, m, 1), kDay);
-        end = wsub(wmul(days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1), kDay), 1);
+    const int64_t d0 = d == 4 ? days_from_civil(y, m, 1) : days_from_civil(y, 1, 1);
+    const int64_t d1 = d == 4 ? days_from_civil(m == 12 ? y + 1 : y, m == 12 ? 1 : m + 1, 1) : days_from_civil(y + 1, 1, 1);
+    if (tz) {
+        begin = wmul(tz_civil_to_utc_s(tz, d0 * 86400), kSec);
+        end = wsub(wmul(tz_civil_to_utc_s(tz, d1 * 86400), kSec), 1);
     } else {
-        begin = wmul(days_from_civil(y, 1, 1), kDay);
-        end = wsub(wmul(days_from_civil(y + 1, 1, 1), kDay), 1);
+        begin = wmul(d0, kDay);
+        end = wsub(wmul(d1, kDay), 1);
     }
     duration = wsub(end, begin / kMs);
     return 0u;
 }
 // the two values a request carries when the host has not precomputed them: greg_duration < 0 = -error, as in guber_batch_t
-GB_HD void greg_fill(int64_t now_ms, int64_t d, int64_t& g_expire, int64_t& g_duration) {
+GB_HD void greg_fill(int64_t now_ms, int64_t d, int64_t& g_expire, int64_t& g_duration, const TzTable* tz = nullptr) {
     const int64_t now_ns = wmul(now_ms, cal::kMs);
     int64_t e = 0, du = 0;
-    uint32_t rc = greg_expiration(now_ns, d, e);
-    if (rc == 0u) rc = greg_duration(now_ns, d, du);
+    uint32_t rc = greg_expiration(now_ns, d, e, tz);
+    if (rc == 0u) rc = greg_duration(now_ns, d, du, tz);
     g_expire = e; g_duration = rc ? -(int64_t)rc : du;
 }
 

@@ -2371,6 +2371,22 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
     return GUBER_OK;
 }
 
+// the process's zone: the host helpers' copy and, on every visible device, the kernels' (guber_table.h g_tz)
+extern "C" int guber_set_timezone(const guber_tz_t* tz) {
+    const int rc = guber_host_set_tz(tz);
+    if (rc != GUBER_OK) return fail(rc, "time zone: at most 16 transitions, ascending");
+    int ndev = 0, cur = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GUBER_OK;          // (no device: the helpers still follow the zone)
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < ndev; ++d) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(guber::g_tz), guber_host_tz_table(), sizeof(guber::TzTable)));
+    }
+    (void)hipSetDevice(cur);
+    return GUBER_OK;
+}
+
 extern "C" int guber_profile_passes(guber_engine_t* e, float* us, uint32_t cap, uint32_t* n_out) {
     if (!e || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(e->mu);

@@ -128,13 +128,29 @@ extern "C" int guber_ring_route(const guber_ring_t* r, const uint8_t* key_bytes,
 }
 
 // interval.go:84-148 (the calendar arithmetic lives in guber_algo.h: the kernels evaluate the same code per request)
+static guber::TzTable g_host_tz{};                                   // the process's zone (guber_set_timezone); all zero = UTC
+static const guber::TzTable* host_tz() { return (g_host_tz.n || g_host_tz.offset0_s) ? &g_host_tz : nullptr; }
+const guber::TzTable* guber_host_tz_table() { return &g_host_tz; }
+int guber_host_set_tz(const guber_tz_t* tz) {
+    guber::TzTable t{};
+    if (tz) {
+        if (tz->n > (uint32_t)guber::TZ_MAX || (tz->n && (!tz->when_s || !tz->offset_s))) return GUBER_E_INVALID_ARG;
+        t.n = tz->n; t.offset0_s = tz->offset0_s;
+        for (uint32_t k = 0; k < tz->n; ++k) {
+            if (k && tz->when_s[k] <= tz->when_s[k - 1]) return GUBER_E_INVALID_ARG;        // ascending
+            t.when_s[k] = tz->when_s[k]; t.offset_s[k] = tz->offset_s[k];
+        }
+    }
+    g_host_tz = t;
+    return GUBER_OK;
+}
 extern "C" int guber_gregorian_expiration(int64_t now_ns, int64_t d, int64_t* expire_ms) {
     if (!expire_ms) return GUBER_E_INVALID_ARG;
-    return -(int)guber::greg_expiration(now_ns, d, *expire_ms);
+    return -(int)guber::greg_expiration(now_ns, d, *expire_ms, host_tz());
 }
 extern "C" int guber_gregorian_duration(int64_t now_ns, int64_t d, int64_t* duration) {
     if (!duration) return GUBER_E_INVALID_ARG;
-    return -(int)guber::greg_duration(now_ns, d, *duration);
+    return -(int)guber::greg_duration(now_ns, d, *duration, host_tz());
 }
 
 extern "C" uint64_t guber_xxhash64(const uint8_t* p, size_t len, uint64_t seed) { return guber::xxhash64(p, (uint32_t)len, seed); }

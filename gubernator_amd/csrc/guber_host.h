@@ -7,3 +7,6 @@
 
 extern "C" int guber_ring_kind(const guber_ring_t* r);   // 0 fnv1, 1 fnv1a
 extern "C" uint64_t guber_ring_id(const guber_ring_t* r);   // unique per guber_ring_create
+namespace guber { struct TzTable; }
+int guber_host_set_tz(const guber_tz_t* tz);                 // validates and stores the process's zone (host helpers); guber_set_timezone adds the devices
+const guber::TzTable* guber_host_tz_table();

@@ -714,7 +714,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
                     if (B.greg_expire && B.greg_duration) { cur.greg_expire = B.greg_expire[i]; cur.greg_duration = B.greg_duration[i]; }
-                    else if (cur.behavior & BH_GREGORIAN) greg_fill(B.now_ms, cur.duration, cur.greg_expire, cur.greg_duration);
+                    else if (cur.behavior & BH_GREGORIAN) greg_fill(B.now_ms, cur.duration, cur.greg_expire, cur.greg_duration, guber_tz());
                 }
                 after = s0;
                 uint64_t k = rank;

@@ -15,6 +15,11 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int MAX_PASSES = 3;           // dense ids < 2^24
 
+// the process's time zone for DURATION_IS_GREGORIAN requests whose calendar values the host did not precompute (guber_set_timezone;
+// all zero = UTC)
+__device__ TzTable g_tz;
+__device__ __forceinline__ const TzTable* guber_tz() { return (g_tz.n || g_tz.offset0_s) ? &g_tz : nullptr; }
+
 struct DirEntry { unsigned long long tag; unsigned long long meta; };
 struct alignas(64) KeyCell { uint64_t w[8]; };
 struct alignas(128) Bucket { KeyCell cell; Rec rec; };
@@ -204,7 +209,7 @@ __device__ __forceinline__ Req load_req(const BatchView& B, uint32_t i) {
     r.algorithm = B.algorithm ? B.algorithm[i] : 0;
     r.is_owner = B.is_owner ? B.is_owner[i] : 1;
     // DURATION_IS_GREGORIAN without host-precomputed values: the calendar interval of the batch clock (interval.go:84-148, UTC)
-    if ((r.behavior & BH_GREGORIAN) && !(B.greg_expire && B.greg_duration)) greg_fill(B.now_ms, r.duration, r.greg_expire, r.greg_duration);
+    if ((r.behavior & BH_GREGORIAN) && !(B.greg_expire && B.greg_duration)) greg_fill(B.now_ms, r.duration, r.greg_expire, r.greg_duration, guber_tz());
     return r;
 }
 // the request without the calendar values (only the general path reads them: the closed forms decline GREGORIAN requests)

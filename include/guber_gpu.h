@@ -600,8 +600,18 @@ void guber_comm_destroy(guber_comm_t* c);
 int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_sync_stats_t* stats);       /* stats (optional): summed over the local ranks */
 int guber_comm_last_stats(guber_comm_t* c, uint32_t local_index, guber_global_sync_stats_t* out);   /* one local rank's share of the last sync */
 
+/* ---- the daemon's time zone.  interval.go:97-142 build the civil dates of DURATION_IS_GREGORIAN intervals with now.Location():
+ *      a "day" ends at 23:59:59.999 of the daemon's zone, not of UTC.  guber_set_timezone hands the engine that zone — the UTC
+ *      offset in effect before the first listed transition and, per transition (ascending, at most 16), the instant in UTC seconds
+ *      and the offset in seconds from then on: the shape of Go's time.Location — for the kernels (requests without greg_expire /
+ *      greg_duration) and for the two host helpers below.  Civil times are resolved as Go's time.Date does (also inside the
+ *      gap / overlap of a transition).  NULL, or n = 0 with offset0_s = 0: UTC (the default).  One zone per process; call it
+ *      before traffic, or while no batch is in flight, e.g. once a year with the coming transitions. */
+typedef struct { uint32_t n; int32_t offset0_s; const int64_t* when_s; const int32_t* offset_s; } guber_tz_t;
+int guber_set_timezone(const guber_tz_t* tz);
+
 /* ---- calendar helpers the host layer uses to fill greg_expire / greg_duration
- *      (interval.go:84-148), UTC. Return 0 or -GUBER_ITEM_E_GREGORIAN_*. */
+ *      (interval.go:84-148), in the zone of guber_set_timezone. Return 0 or -GUBER_ITEM_E_GREGORIAN_*. */
 int guber_gregorian_expiration(int64_t now_unix_nano, int64_t d, int64_t* expire_ms);
 int guber_gregorian_duration(int64_t now_unix_nano, int64_t d, int64_t* duration);
 

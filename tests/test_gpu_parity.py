@@ -687,6 +687,32 @@ def test_gregorian_intervals_on_the_device():
         e.close()
 
 
+def test_gregorian_intervals_in_the_daemons_zone_on_the_device():
+    """guber_set_timezone: DURATION_IS_GREGORIAN intervals end where the DAEMON's zone says (interval.go uses now.Location()).  The
+    kernels — one-launch path, two-launch and owner-partitioned pipelines — evaluate requests without precomputed calendar values in
+    America/New_York from a clock that crosses the start of daylight saving time; the oracle is fed the values of an independent
+    restatement of Go's time.Date (tests/test_timezone_cpu.py, itself checked against zoneinfo)."""
+    import test_timezone_cpu as tz
+    from test_kernel_logic_host import _gregorian_batches
+    zone = ga.zone_transitions("America/New_York", 2018, 2021)
+    def greg(now_ms, d):
+        if d == 3:
+            return 0, -2
+        if d not in (0, 1, 2, 4, 5):
+            return 0, -3
+        return tz.go_expiration(zone, now_ms * 1_000_000, d), tz.go_duration(zone, now_ms * 1_000_000, d)
+    ga.set_timezone(*zone)
+    try:
+        now0 = (zone[1][2][0] - 3 * 3600) * 1000                      # three hours before the spring-forward of 2019
+        for flags in (0, 32, 64):
+            o, e = Oracle(cache_size=1 << 12), engine(cache_size=1024, max_batch=1024, flags=flags)
+            for bi, (with_vals, without) in enumerate(_gregorian_batches(21 + flags, n_batches=30, greg_fn=greg, now0=now0)):
+                support.assert_results_equal(e.eval(without), o.eval(with_vals), f"flags {flags} batch {bi}")
+            e.close()
+    finally:
+        ga.set_timezone()
+
+
 def test_small_batches_one_launch_path():
     """Batches of <= 256 requests (BASELINE configs[0]: one request per call, benchmark_test.go:63-84) take one launch of one
     workgroup; duplicate-heavy, mixed-algorithm, error-carrying small batches equal the oracle, and what the path declines

@@ -300,10 +300,12 @@ def test_closed_forms_equal_apply_skip_on_random_states():
     assert tok > 200_000 and leaky > 100_000, (tok, leaky)
 
 
-def _gregorian_batches(seed, n_batches=40):
-    """(batch with host-precomputed calendar values, the same batch without them)"""
+def _gregorian_batches(seed, n_batches=40, greg_fn=None, now0=None):
+    """(batch with host-precomputed calendar values, the same batch without them).  greg_fn(now_ms, d) -> (expire, duration):
+    default = the oracle's (UTC)"""
     rng = np.random.default_rng(seed)
-    now = streams.NOW0
+    now = streams.NOW0 if now0 is None else now0
+    greg_fn = greg_fn or support.gregorian
     for _ in range(n_batches):
         n = int(rng.integers(1, 300))
         keys = [b"greg_%d" % int(i) for i in rng.integers(0, 12, n)]
@@ -316,7 +318,7 @@ def _gregorian_batches(seed, n_batches=40):
         ge, gd = np.zeros(n, np.int64), np.zeros(n, np.int64)
         for i in range(n):
             if beh[i] & 4:
-                ge[i], gd[i] = support.gregorian(now, int(dur[i]))
+                ge[i], gd[i] = greg_fn(now, int(dur[i]))
         yield (HostBatch(keys, hits, limit, dur, now, algorithm=algo, behavior=beh, greg_expire=ge, greg_duration=gd),
                HostBatch(keys, hits, limit, dur, now, algorithm=algo, behavior=beh))
         now += int(rng.choice([1, 1000, 61_000, 3_600_000, 86_400_000 * 20]))
