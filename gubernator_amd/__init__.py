@@ -92,6 +92,7 @@ def lib():
         L.guber_pool_batches.argtypes = [C.c_void_p]
         L.guber_pool_batches.restype = C.c_uint64
         L.guber_pool_get_rate_limits.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 11 + [C.POINTER(GuberResult), C.c_void_p, C.c_uint32]
+        L.guber_pool_get_rate_limits_owner.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 12 + [C.POINTER(GuberResult), C.c_void_p, C.c_uint32]
         L.guber_profile_enable.argtypes = [C.c_void_p, C.c_int]
         L.guber_profile_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
         L.guber_profile_passes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]

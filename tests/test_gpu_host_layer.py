@@ -362,7 +362,7 @@ def test_pool_global_engine_and_hot_key_migration():
     inst.add_item(it2)
     assert inst.global_engine_size(dv) == 201 and inst.get_item("glob_peer0")["remaining"] == 3
     inst.add_item(support.make_item("plain_x", 0, limit=9, duration=60_000, remaining=4, stamp=now, expire_at=now + 60_000, status=0))
-    assert inst.global_engine_size(0) + inst.global_engine_size(1) == 401 and inst.size() == 403 and inst.get_item("plain_x")["remaining"] == 4
+    assert inst.global_engine_size(0) + inst.global_engine_size(1) == 401 and inst.size() == 402 and inst.get_item("plain_x")["remaining"] == 4
     out = inst.GetRateLimits([dict(name="plain", unique_key="x", hits=1, limit=9, duration=60_000, created_at=now)])
     assert (out[0]["status"], out[0]["remaining"]) == (0, 3), out
     extra = 2                                                       # items added above (glob_peer0, plain_x), on top of the oracle's
