@@ -281,7 +281,10 @@ __global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { 
 #endif
 constexpr int OW_EPT = GUBER_OWN_EPT;    // messages per thread and round
 constexpr int OW_MCAP = 256 * OW_EPT;    // messages of one round of an owner (more: the round splits by further bits of the home position)
-constexpr int OW_KCAP = 320;             // distinct keys of one round (uniform keys: 256 +- 16 per owner)
+#ifndef GUBER_OWN_KCAP
+#define GUBER_OWN_KCAP 320
+#endif
+constexpr int OW_KCAP = GUBER_OWN_KCAP;             // distinct keys of one round (uniform keys: 256 +- 16 per owner)
 constexpr int OW_HT = 512;               // LDS hash table of the round's keys
 constexpr int OW_CH = OW_MCAP / 64;      // 64-message chunks
 #ifndef GUBER_OWN_WAVES
