@@ -2401,3 +2401,4 @@ extern "C" int guber_profile_passes(guber_engine_t* e, float* us, uint32_t cap, 
 extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }
 
 #include "guber_global_sync.h"
+#include "guber_wire_dev.h"

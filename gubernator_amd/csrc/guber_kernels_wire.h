@@ -1,0 +1,220 @@
+// guber_kernels_wire.h — the protobuf wire format decoded ON THE DEVICE: serialized GetRateLimitsReq / GetPeerRateLimitsReq payloads
+// (gubernator.proto:137-182, peers.proto:36-44: `repeated RateLimitReq = 1`) straight into the structure of arrays the batch
+// pipelines evaluate, with the per-item validation of V1Instance.GetRateLimits (gubernator.go:189-220).  The host transcoder
+// (wire.cpp) does 21 M items/s per thread; the kernels it feeds do billions.
+//
+// A protobuf message is a chain: where record k+1 starts is known only after record k's length has been read.  So:
+//   k_wire_scan   one wave per RPC payload walks that chain — headers only (tag + length, 2-3 bytes per record), read from a window
+//                 of the payload staged in LDS, every lane computing the same thing (broadcast reads, no divergence) — and leaves
+//                 every record's offset and length, the RPC's item count and its status (ok / malformed / too many items);
+//   k_wire_prefix one workgroup: where each RPC's items start in the batch (exclusive scan of the counts of the RPCs that are ok);
+//   k_wire_fill   one thread per item: the record body through guber::wire::parse_req — the SAME source the host transcoder and its
+//                 AddressSanitizer fuzz compile (guber_wire_parse.h: every read bounded by the record) — into the arrays: HashKey
+//                 bytes `name + "_" + unique_key` (client.go:39-41) as one row per item, the CreatedAt default, the algorithm code,
+//                 the validation outcome.  A record whose body is malformed marks its whole RPC malformed, as the runtimes reject the
+//                 whole message; its items stay in place as dead slots (empty key: they never reach a bucket).
+// The top-level framing decisions live in scan_toplevel(), a host/device template over a byte source, so that the fuzz runs them too.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "guber_wire_parse.h"
+
+namespace guber {
+
+constexpr int32_t WIRE_OK = 0, WIRE_MALFORMED = -20, WIRE_TOO_LARGE = -21;      // = GUBER_E_WIRE_* (include/guber_wire.h)
+constexpr uint8_t WIRE_PRE_DEAD = 255;                                           // an item of an RPC that turned out malformed
+
+// The top level of one payload: field 1 (LEN) = one RateLimitReq; anything else is an unknown field, skipped by wire type.
+// Rd::peek8(pos) = the 8 bytes at pos (zero beyond the payload); Rd::slow(pos) = a plain pointer to the payload for the rare
+// constructs that are walked byte by byte (groups).  emit(k, body_offset, body_len) is called for every record, in order.
+template <class Rd, class Emit>
+GW_HD int32_t scan_toplevel(Rd& rd, uint32_t len, uint32_t max_items, uint32_t& count, Emit emit) {
+    uint32_t pos = 0;
+    count = 0;
+    while (pos < len) {
+        uint64_t w = rd.peek8(pos);
+        uint64_t tag; uint32_t used;
+        if (!(w & 0x80)) { tag = w & 0x7f; used = 1; }
+        else {                                                       // a multi-byte tag: by the book
+            const uint8_t* p = rd.slow(pos); const uint8_t* e = rd.slow(len);
+            if (!wire::get_varint(p, e, tag)) return WIRE_MALFORMED;
+            used = (uint32_t)(p - rd.slow(pos));
+            w = rd.peek8(pos + used) << 8;                           // (keeps "w >> 8" below = the bytes after the tag)
+        }
+        const uint32_t wt = (uint32_t)(tag & 7);
+        const uint64_t field = tag >> 3;
+        if (field == 0 || field > 0x1fffffffull) return WIRE_MALFORMED;
+        if (field != 1 || wt != 2) {                                 // unknown top-level field
+            const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
+            if (!wire::skip_field(p, e, wt, field)) return WIRE_MALFORMED;
+            pos = (uint32_t)(p - rd.slow(0));
+            continue;
+        }
+        uint64_t L; uint32_t lused;
+        const uint64_t v = w >> 8;                                   // the bytes after the tag
+        if (!(v & 0x80)) { L = v & 0x7f; lused = 1; }
+        else if (!(v & 0x8000)) { L = (v & 0x7f) | ((v >> 1) & 0x3f80); lused = 2; }
+        else {
+            const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
+            if (!wire::get_varint(p, e, L)) return WIRE_MALFORMED;
+            lused = (uint32_t)(p - rd.slow(pos + used));
+        }
+        const uint64_t body = (uint64_t)pos + used + lused;
+        if (body > len || L > (uint64_t)len - body) return WIRE_MALFORMED;
+        if (count < max_items) emit(count, (uint32_t)body, (uint32_t)L);
+        ++count;
+        pos = (uint32_t)(body + L);
+    }
+    return WIRE_OK;
+}
+
+struct WireIn {
+    const uint8_t* buf;             // the payloads back to back (16 readable bytes past the end)
+    const uint32_t* rpc_off;        // [nrpc] where each payload starts in buf (16-byte aligned)
+    const uint32_t* rpc_len;        // [nrpc]
+    const uint8_t* rpc_owner;       // [nrpc] RateLimitReqState.IsOwner of the RPC's items
+    uint32_t nrpc, cap_per_rpc;     // records per RPC the scratch holds
+    uint32_t max_per_rpc;           // 0 = no cap (gubernator.go:40 passes 1000)
+    uint32_t cap_items;             // items the output arrays hold
+};
+struct WireScratch { uint32_t* rec_off; uint32_t* rec_len; uint32_t* count; int32_t* status; uint32_t* first; };
+struct WireOut {
+    uint8_t* key_rows; uint32_t key_stride; uint32_t* key_len;
+    int64_t *hits, *limit, *duration, *burst, *created_at; uint32_t* behavior; int32_t* algo_raw;
+    uint8_t *algorithm, *is_owner, *pre_err; uint32_t* item_rpc;
+    int64_t now_ms;
+};
+
+constexpr uint32_t WIRE_WIN = 8192;
+struct LdsWindowReader {            // device byte source: a window of the payload in LDS, reloaded by the whole wave when the walk leaves it
+    const uint8_t* g; uint32_t len; unsigned char* win; uint32_t wbase, wend;
+    __device__ __forceinline__ void load(uint32_t pos) {
+        wbase = pos & ~15u;
+        wend = wbase + WIRE_WIN < len ? wbase + WIRE_WIN : len;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();     // the previous window is done with
+        for (uint32_t o = threadIdx.x * 16; wbase + o < wend; o += blockDim.x * 16) {
+            uint4 v = {0, 0, 0, 0};
+            if (wbase + o + 16 <= len) v = *(const uint4*)(g + wbase + o);                                    // (payload start is 16-byte aligned)
+            else { unsigned char t[16]; for (int k = 0; k < 16; ++k) t[k] = wbase + o + k < len ? g[wbase + o + k] : 0; v = *(uint4*)t; }
+            *(uint4*)(win + o) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    }
+    __device__ __forceinline__ uint64_t peek8(uint32_t pos) {
+        if (pos < wbase || pos + 8 > wend) {
+            if (pos + 8 > len) {                                     // the tail of the payload: byte by byte, zero beyond
+                uint64_t w = 0;
+                for (uint32_t k = 0; k < 8 && pos + k < len; ++k) w |= (uint64_t)g[pos + k] << (8 * k);
+                return w;
+            }
+            load(pos);
+        }
+        const uint32_t o = pos - wbase;
+        const uint32_t* d = (const uint32_t*)(win + (o & ~3u));
+        const uint32_t sh = (o & 3u) * 8;
+        const uint64_t lo = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
+        const uint64_t hi = d[2];
+        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+    }
+    __device__ __forceinline__ const uint8_t* slow(uint32_t pos) const { return g + pos; }
+};
+
+// one wave per RPC payload; every lane walks the same chain (uniform control flow, LDS broadcast reads)
+__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) {
+    __shared__ __attribute__((aligned(16))) unsigned char win[WIRE_WIN + 32];
+    const uint32_t r = blockIdx.x;
+    const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
+    LdsWindowReader rd{in.buf + off, len, win, 0xffffffffu, 0};
+    rd.wbase = 0; rd.wend = 0;
+    if (len >= 8) rd.load(0);
+    uint32_t count = 0;
+    uint32_t* ro = sc.rec_off + (size_t)r * in.cap_per_rpc; uint32_t* rl = sc.rec_len + (size_t)r * in.cap_per_rpc;
+    int32_t st = scan_toplevel(rd, len, in.cap_per_rpc, count, [&](uint32_t k, uint32_t bo, uint32_t bl) {
+        if (threadIdx.x == 0) { ro[k] = off + bo; rl[k] = bl; }
+    });
+    if (st == WIRE_OK && ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc)) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
+    if (threadIdx.x == 0) { sc.count[r] = count; sc.status[r] = st; }
+}
+
+// first[r] = where RPC r's items start (RPCs that are not ok contribute nothing), first[nrpc] = the batch size; an RPC that would not
+// fit the arrays any more is turned away as too large
+__global__ __launch_bounds__(256) void k_wire_prefix(WireIn in, WireScratch sc) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < in.nrpc; base += 256) {
+        const uint32_t r = base + threadIdx.x;
+        uint32_t c = (r < in.nrpc && sc.status[r] == WIRE_OK) ? sc.count[r] : 0u;
+        part[threadIdx.x] = c;
+        __syncthreads();
+        for (uint32_t o = 1; o < 256; o <<= 1) {                     // Hillis-Steele inclusive scan
+            const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = carry + part[threadIdx.x] - c;
+        if (r < in.nrpc) {
+            if (c && excl + c > in.cap_items) { sc.status[r] = WIRE_TOO_LARGE; }   // (rare: flagged; its slots stay unused — see k_wire_fill)
+            sc.first[r] = excl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sc.first[in.nrpc] = carry < in.cap_items ? carry : in.cap_items;
+}
+
+__global__ __launch_bounds__(256) void k_wire_fill(WireIn in, WireScratch sc, WireOut out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t total = sc.first[in.nrpc];
+    if (i >= total) return;
+    uint32_t lo = 0, hi = in.nrpc;                                   // the RPC whose slice holds item i: the last r with first[r] <= i that has items
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc.first[mid] <= i) lo = mid; else hi = mid; }
+    const uint32_t r = lo, k = i - sc.first[r];
+    out.item_rpc[i] = r;
+    const bool dead_rpc = sc.status[r] != WIRE_OK || k >= sc.count[r];
+    wire::ReqFields f;
+    bool ok = !dead_rpc;
+    if (ok) {
+        const uint8_t* p = in.buf + sc.rec_off[(size_t)r * in.cap_per_rpc + k];
+        ok = wire::parse_req(p, p + sc.rec_len[(size_t)r * in.cap_per_rpc + k], f);
+        if (!ok) atomicExch((int*)&sc.status[r], WIRE_MALFORMED);      // the whole message is rejected, as the runtimes do
+    }
+    uint8_t pre = 0;
+    uint32_t klen = 0;
+    if (!ok) pre = WIRE_PRE_DEAD;
+    else if (f.unique_key.n == 0) pre = 1;                            // gubernator.go:208-212 "field 'unique_key' cannot be empty"
+    else if (f.name.n == 0) pre = 2;                                  // gubernator.go:213-217 "field 'namespace' cannot be empty"
+    else {
+        const uint64_t kl = (uint64_t)f.name.n + 1 + f.unique_key.n;
+        klen = kl > 0xffffffffull ? 0xffffffffu : (uint32_t)kl;
+        if (klen + 8 <= out.key_stride) {                             // client.go:39-41 (a longer key is refused by the engine: max_key_bytes)
+            uint8_t* row = out.key_rows + (size_t)i * out.key_stride;
+            for (uint32_t b = 0; b < f.name.n; ++b) row[b] = f.name.p[b];
+            row[f.name.n] = '_';
+            for (uint32_t b = 0; b < f.unique_key.n; ++b) row[f.name.n + 1 + b] = f.unique_key.p[b];
+            for (uint32_t b = klen; b < ((klen + 7u) & ~7u); ++b) row[b] = 0;
+        }
+    }
+    out.key_len[i] = klen;
+    out.pre_err[i] = pre;
+    out.hits[i] = f.hits; out.limit[i] = f.limit; out.duration[i] = f.duration; out.burst[i] = f.burst;
+    out.created_at[i] = f.created_at ? f.created_at : out.now_ms;      // gubernator.go:218-220
+    out.algo_raw[i] = (int32_t)f.algorithm;
+    out.algorithm[i] = (f.algorithm == 0 || f.algorithm == 1) ? (uint8_t)f.algorithm : 255;
+    out.behavior[i] = (uint32_t)f.behavior;
+    out.is_owner[i] = in.rpc_owner ? (in.rpc_owner[r] ? 1 : 0) : 1;
+}
+
+// items of an RPC that a later record showed to be malformed (or that did not fit): dead slots — an empty key never reaches a bucket
+__global__ __launch_bounds__(256) void k_wire_kill(WireIn in, WireScratch sc, WireOut out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= sc.first[in.nrpc]) return;
+    if (sc.status[out.item_rpc[i]] != WIRE_OK) { out.key_len[i] = 0; out.pre_err[i] = WIRE_PRE_DEAD; }
+}
+
+}  // namespace guber

@@ -14,6 +14,7 @@ WIRE_SYMBOLS = [
     "guber_wire_decode_requests", "guber_wire_batch_view", "guber_wire_batch_result", "guber_wire_batch_pre_errors",
     "guber_wire_eval", "guber_wire_encode_bound", "guber_wire_encode_responses",
     "guber_wire_items_create", "guber_wire_items_destroy", "guber_wire_decode_globals", "guber_wire_encode_globals",
+    "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_eval", "guber_wire_dev_columns",
 ]
 _bound = False
 
@@ -176,3 +177,72 @@ def encode_globals(host_batch, status):
     if rc:
         raise GuberError(rc, L.guber_strerror(rc).decode())
     return bytes(buf[:need.value])
+
+
+class _Columns(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("key_stride", C.c_uint32), ("key_rows", C.c_void_p), ("key_len", C.c_void_p),
+                ("hits", C.c_void_p), ("limit", C.c_void_p), ("duration", C.c_void_p), ("burst", C.c_void_p), ("created_at", C.c_void_p),
+                ("behavior", C.c_void_p), ("algo_raw", C.c_void_p), ("algorithm", C.c_void_p), ("is_owner", C.c_void_p), ("pre_err", C.c_void_p)]
+
+
+class DevWireDecoder:
+    """guber_wire_dev_*: serialized RPC payloads decoded ON THE DEVICE into one batch of the engine (guber_kernels_wire.h)."""
+
+    def __init__(self, engine, max_items=65536, max_payload_bytes=8 << 20, max_rpcs=4096):
+        L = self.L = _lib()
+        L.guber_wire_dev_create.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_wire_dev_destroy.argtypes = [C.c_void_p]
+        L.guber_wire_dev_destroy.restype = None
+        L.guber_wire_dev_decode.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.guber_wire_dev_eval.argtypes = [C.c_void_p, C.POINTER(GuberResult)]
+        L.guber_wire_dev_columns.argtypes = [C.c_void_p, C.POINTER(_Columns)]
+        self.engine = engine
+        self.h = C.c_void_p()
+        rc = L.guber_wire_dev_create(engine.h, max_items, max_payload_bytes, max_rpcs, C.byref(self.h))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+
+    def decode(self, payloads, now_ms, is_owner=None, max_per_rpc=1000):
+        """-> (status[nrpc], first[nrpc], count[nrpc], n_items)"""
+        n = len(payloads)
+        msgs = (C.c_char_p * max(n, 1))(*payloads)
+        lens = np.array([len(p) for p in payloads], np.uint32) if n else np.zeros(1, np.uint32)
+        own = None if is_owner is None else np.asarray(is_owner, np.uint8)
+        status, first, count = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        items = C.c_uint32(0)
+        rc = self.L.guber_wire_dev_decode(self.h, msgs, lens.ctypes.data, n, own.ctypes.data if own is not None else None, max_per_rpc, now_ms,
+                                          status.ctypes.data, first.ctypes.data, count.ctypes.data, C.byref(items))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        self.n = items.value
+        return status[:n], first[:n], count[:n], items.value
+
+    def eval(self):
+        from .abi import HostResult
+        res = HostResult(max(self.n, 1))
+        rc = self.L.guber_wire_dev_eval(self.h, C.byref(res.c))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        return res
+
+    def columns(self):
+        """the decoded columns as numpy arrays (+ keys: list of bytes)"""
+        c = _Columns()
+        rc = self.L.guber_wire_dev_columns(self.h, C.byref(c))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        n = c.n
+        def arr(ptr, dt):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), (n,)).copy() if n else np.zeros(0, dt)
+        out = {k: arr(getattr(c, k), dt) for k, dt in (("hits", np.int64), ("limit", np.int64), ("duration", np.int64), ("burst", np.int64),
+                                                       ("created_at", np.int64), ("key_len", np.uint32), ("behavior", np.uint32), ("algo_raw", np.int32),
+                                                       ("algorithm", np.uint8), ("is_owner", np.uint8), ("pre_err", np.uint8))}
+        rows = np.ctypeslib.as_array(C.cast(c.key_rows, C.POINTER(C.c_uint8)), (n * c.key_stride,)).reshape(n, c.key_stride) if n else np.zeros((0, 8), np.uint8)
+        out["keys"] = [bytes(rows[i, :min(int(out["key_len"][i]), c.key_stride)]) for i in range(n)]
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.guber_wire_dev_destroy(self.h)
+            self.h = None

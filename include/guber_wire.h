@@ -107,6 +107,37 @@ int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off,
                               const int64_t* duration, const int64_t* created_at, const guber_result_t* status, uint32_t n,
                               uint8_t* out, size_t cap, size_t* len);
 
+/* ---- the same decode ON THE DEVICE (gubernator_amd/csrc/guber_kernels_wire.h): the serialized payloads of many RPCs -> one batch in
+ *      HBM, evaluated where it is.  The reference unmarshals every RateLimitReq into a heap object on the CPU (generated code of
+ *      gubernator.proto:137-182) and validates it there (gubernator.go:189-220); here a wave per payload walks the record chain,
+ *      a thread per item parses its record (the same source as guber_wire_decode_requests) and the items land in the structure of
+ *      arrays the engine's kernels read.
+ *   guber_wire_dev_create   a decoder bound to an engine: at most max_items items, max_payload_bytes payload bytes and max_rpcs
+ *                           payloads per decode (max_items <= the engine's max_batch; an RPC holds at most min(max_items, 4096) items)
+ *   guber_wire_dev_decode   nrpc payloads (msgs[r], lens[r]; is_owner[r] = RateLimitReqState.IsOwner of its items, NULL = all owner;
+ *                           max_per_rpc as guber_wire_decode_requests) -> per RPC: status[r] (GUBER_OK, GUBER_E_WIRE_MALFORMED,
+ *                           GUBER_E_WIRE_TOO_LARGE), first[r], count[r] = the slice of the batch its items occupy (responses are
+ *                           positionally aligned); *n_items = the batch size.  Items of a rejected RPC that were already placed stay
+ *                           as dead slots (pre_err GUBER_WIRE_PRE_DEAD, empty key): they never reach a bucket.
+ *   guber_wire_dev_eval     the batch through the engine (as guber_eval_batch_dev), results to host arrays of n_items entries
+ *   guber_wire_dev_columns  the decoded columns copied to host memory (keys as rows of key_stride bytes + key_len): what
+ *                           guber_wire_encode_responses-style code and the tests read */
+#define GUBER_WIRE_PRE_DEAD 255
+typedef struct guber_wire_dev guber_wire_dev_t;
+typedef struct {
+    uint32_t n, key_stride;
+    const uint8_t* key_rows; const uint32_t* key_len;
+    const int64_t *hits, *limit, *duration, *burst, *created_at;
+    const uint32_t* behavior; const int32_t* algo_raw;
+    const uint8_t *algorithm, *is_owner, *pre_err;
+} guber_wire_columns_t;
+int guber_wire_dev_create(guber_engine_t* e, uint32_t max_items, uint32_t max_payload_bytes, uint32_t max_rpcs, guber_wire_dev_t** out);
+void guber_wire_dev_destroy(guber_wire_dev_t* d);
+int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* msgs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
+                          uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items);
+int guber_wire_dev_eval(guber_wire_dev_t* d, guber_result_t* r);
+int guber_wire_dev_columns(guber_wire_dev_t* d, guber_wire_columns_t* c);
+
 #ifdef __cplusplus
 }
 #endif

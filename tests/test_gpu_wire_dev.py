@@ -1,0 +1,119 @@
+"""The protobuf wire format decoded ON THE DEVICE (include/guber_wire.h guber_wire_dev_*, kernels guber_kernels_wire.h): payloads
+serialized by the protobuf runtime on the reference's schema -> k_wire_scan / k_wire_prefix / k_wire_fill -> the batch the engine
+evaluates.  Checked against what the requests say (as tests/test_wire_cpu.py checks the host transcoder), against the host
+transcoder itself on fuzzed payloads (per RPC: the same verdict, the same items), and end to end against the oracle."""
+import time
+
+import numpy as np
+import pytest
+
+import gubernator_amd as ga
+import support
+import wire_replay
+from gubernator_amd import wire as gw
+from test_wire_cpu import NOW, check_decoded, expected_key, rand_reqs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_decode_matches_the_requests_and_the_host_transcoder():
+    rng = np.random.default_rng(7)
+    e = ga.Engine(cache_size=1 << 16, max_batch=16384, max_key_bytes=256)
+    dec = gw.DevWireDecoder(e, max_items=16384, max_payload_bytes=4 << 20, max_rpcs=256)
+    for rnd in range(6):
+        rpcs = [rand_reqs(rng, int(rng.integers(1, 400))) for _ in range(int(rng.integers(1, 30)))]
+        payloads = [wire_replay.pb_request(r, peer=bool(k & 1)) for k, r in enumerate(rpcs)]
+        owner = rng.integers(0, 2, len(rpcs)).astype(np.uint8)
+        status, first, count, n = dec.decode(payloads, NOW, is_owner=owner)
+        assert (status == 0).all() and n == sum(len(r) for r in rpcs)
+        cols = dec.columns()
+        for k, reqs in enumerate(rpcs):
+            assert count[k] == len(reqs)
+            check_decoded(cols, int(first[k]), reqs, NOW, is_owner=int(owner[k]))
+            for j, r in enumerate(reqs):
+                want = 1 if not r["unique_key"] else (2 if not r["name"] else 0)          # gubernator.go:208-217
+                assert cols["pre_err"][first[k] + j] == want
+    dec.close(); e.close()
+
+
+def _mutate(rng, p):
+    p = bytearray(p)
+    for _ in range(int(rng.integers(0, 4))):
+        if not p:
+            break
+        i = int(rng.integers(0, len(p)))
+        op = int(rng.integers(0, 5))
+        if op == 0:
+            p[i] ^= 1 << int(rng.integers(0, 8))
+        elif op == 1:
+            p.insert(i, int(rng.integers(0, 256)))
+        elif op == 2:
+            del p[i]
+        elif op == 3:
+            del p[i:]
+        else:
+            p[i:i] = bytes(rng.integers(0, 256, int(rng.integers(1, 9))).astype(np.uint8))
+    return bytes(p)
+
+
+def test_fuzzed_payloads_same_verdict_and_items_as_the_host_transcoder():
+    """mutated payloads (bit flips, insertions, truncations — also right at the window boundaries of the scan): per RPC the device
+    decoder rejects exactly what the host transcoder rejects, and accepts with the same items"""
+    rng = np.random.default_rng(11)
+    e = ga.Engine(cache_size=1 << 16, max_batch=32768, max_key_bytes=512)
+    dec = gw.DevWireDecoder(e, max_items=32768, max_payload_bytes=8 << 20, max_rpcs=512)
+    accepted = rejected = 0
+    for rnd in range(8):
+        base = [wire_replay.pb_request(rand_reqs(rng, int(rng.integers(1, 300)))) for _ in range(40)]
+        payloads = [_mutate(rng, base[int(rng.integers(0, len(base)))]) for _ in range(200)]
+        status, first, count, n = dec.decode(payloads, NOW, max_per_rpc=0)
+        cols = dec.columns()
+        for k, p in enumerate(payloads):
+            wb = gw.WireBatch(max_items=4096, max_key_bytes=1 << 20)
+            wb.reset(NOW)
+            try:
+                f0, c0 = wb.decode(p, max_per_rpc=0)
+                host = wb.arrays()
+                assert status[k] == 0, (rnd, k)
+                assert count[k] == c0
+                accepted += 1
+                for j in range(c0):
+                    i = int(first[k]) + j
+                    assert cols["keys"][i] == host["keys"][j] or (len(host["keys"][j]) > 512 and cols["key_len"][i] == len(host["keys"][j]))
+                    for name in ("hits", "limit", "duration", "burst", "created_at", "algorithm", "behavior"):
+                        assert cols[name][i] == host[name][j], (name, rnd, k, j)
+            except ga.GuberError as ex:
+                assert ex.code == gw.E_WIRE_MALFORMED, ex
+                assert status[k] == gw.E_WIRE_MALFORMED, (rnd, k, status[k])
+                rejected += 1
+            wb.close()
+    assert accepted > 200 and rejected > 200, (accepted, rejected)
+    dec.close(); e.close()
+
+
+def test_device_decoded_batches_evaluate_like_the_oracle_and_report_throughput():
+    rng = np.random.default_rng(3)
+    e, o = ga.Engine(cache_size=1 << 18, max_batch=65536, max_key_bytes=64), support.Oracle(cache_size=1 << 20)
+    dec = gw.DevWireDecoder(e, max_items=65536, max_payload_bytes=8 << 20, max_rpcs=1024)
+    now = NOW
+    for rnd in range(4):
+        rpcs = [[dict(name="ns_%d" % rng.integers(0, 5), unique_key="acct:%d" % rng.integers(0, 3000), hits=1, limit=50, duration=60_000, algorithm=int(rng.integers(0, 2)),
+                      behavior=0, burst=0, created_at=0) for _ in range(int(rng.integers(1, 1000)))] for _ in range(20)]
+        payloads = [wire_replay.pb_request(r) for r in rpcs]
+        status, first, count, n = dec.decode(payloads, now)
+        got = dec.eval()
+        flat = [r for reqs in rpcs for r in reqs]
+        want = o.eval(support.HostBatch([expected_key(r) for r in flat], 1, 50, 60_000, now, algorithm=np.array([r["algorithm"] for r in flat], np.uint8)))
+        support.assert_results_equal(got, want, f"round {rnd}")
+        now += 700
+    # throughput: 64 payloads of 1000 items (the reference's cap per RPC), decode only
+    reqs = [dict(name="bench", unique_key="k%08d" % i, hits=1, limit=100, duration=60_000, algorithm=0, behavior=0, burst=0, created_at=0) for i in range(1000)]
+    payloads = [wire_replay.pb_request(reqs)] * 64
+    dec.decode(payloads, now)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        _, _, _, n = dec.decode(payloads, now)
+    dt = (time.perf_counter() - t0) / reps
+    print(f"device wire decode: {n} items of {sum(map(len, payloads))} payload bytes in {dt * 1e6:.0f} us (host copy + 4 launches + read-back) = {n / dt / 1e6:.0f} M items/s")
+    dec.close(); e.close(); o.close()

@@ -12,6 +12,11 @@
 #include <vector>
 
 #include "../include/guber_wire.h"
+// the device decoder's framing logic (scan_toplevel: a host/device template) over a bounds-checked host byte source, and the shared
+// record parser it hands the bodies to: the SAME source the kernels k_wire_scan / k_wire_fill compile
+#define GUBER_FAKEHIP 1
+#include "../tests/hostsim/fakehip/hip/hip_runtime.h"
+#include "../gubernator_amd/csrc/guber_kernels_wire.h"
 
 // the few non-wire symbols wire.cpp links against, stubbed (no device here)
 extern "C" void* guber_alloc_pinned(size_t) { return nullptr; }
@@ -72,6 +77,25 @@ static void mutate(std::string& p) {
     }
 }
 
+namespace fakehip { State S; void yield() {} void barrier() {} unsigned long long wave_exchange(unsigned long long, int, unsigned long long*, unsigned long long*) { return 0; } }
+struct MemReader {                                                   // exact-size heap buffer: any read past it is an ASan error
+    const uint8_t* g; uint32_t len;
+    uint64_t peek8(uint32_t pos) const { uint64_t w = 0; for (uint32_t k = 0; k < 8 && pos + k < len; ++k) w |= (uint64_t)g[pos + k] << (8 * k); return w; }
+    const uint8_t* slow(uint32_t pos) const { return g + pos; }
+};
+// the device decoder's verdict on one payload: GUBER_OK / GUBER_E_WIRE_MALFORMED and the item count
+static int device_logic(const std::vector<uint8_t>& m, uint32_t& count) {
+    MemReader rd{m.data(), (uint32_t)m.size()};
+    std::vector<std::pair<uint32_t, uint32_t>> recs;
+    int32_t st = guber::scan_toplevel(rd, rd.len, 1u << 20, count, [&](uint32_t, uint32_t bo, uint32_t bl) { recs.push_back({bo, bl}); });
+    if (st != guber::WIRE_OK) return st;
+    for (auto& r : recs) {
+        guber::wire::ReqFields f;
+        if (!guber::wire::parse_req(m.data() + r.first, m.data() + r.first + r.second, f)) return guber::WIRE_MALFORMED;
+    }
+    return GUBER_OK;
+}
+
 int main(int argc, char** argv) {
     const long iters = argc > 1 ? atol(argv[1]) : 200000;
     guber_wire_batch_t* b = nullptr; guber_wire_items_t* w = nullptr;
@@ -88,6 +112,12 @@ int main(int argc, char** argv) {
         if (rnd() % 7 == 0) guber_wire_batch_reset(b, 1700000000000ll);
         uint32_t first = 0, count = 0;
         const int rc = guber_wire_decode_requests(b, exact.data(), exact.size(), rnd() % 4 ? 0 : 8, rnd() & 1, &first, &count);
+        {   // the device decoder's logic must reach the same verdict (capacity aside) and the same item count
+            uint32_t dcount = 0;
+            const int drc = device_logic(exact, dcount);
+            const bool host_ok = rc == GUBER_OK || rc == GUBER_E_WIRE_FULL || rc == GUBER_E_WIRE_TOO_LARGE;
+            if ((drc == GUBER_OK) != host_ok || (rc == GUBER_OK && dcount != count)) { printf("device framing disagrees with the host transcoder: host rc %d count %u, device rc %d count %u\n", rc, count, drc, dcount); return 1; }
+        }
         if (rc == GUBER_OK) {
             ++ok;
             guber_result_t* r = guber_wire_batch_result(b);
