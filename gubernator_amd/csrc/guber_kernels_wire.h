@@ -26,48 +26,61 @@ constexpr int32_t WIRE_OK = 0, WIRE_MALFORMED = -20, WIRE_TOO_LARGE = -21;      
 constexpr uint8_t WIRE_PRE_DEAD = 255;                                           // an item of an RPC that turned out malformed
 
 // The top level of one payload: field 1 (LEN) = one RateLimitReq; anything else is an unknown field, skipped by wire type.
-// Rd::peek8(pos) = the 8 bytes at pos (zero beyond the payload); Rd::slow(pos) = a plain pointer to the payload for the rare
-// constructs that are walked byte by byte (groups).  emit(k, body_offset, body_len) is called for every record, in order.
+// Rd::peek8(pos) = the 8 bytes at pos (zero beyond the payload); Rd::slow(pos) = a plain pointer into the payload for the rare
+// constructs that are walked byte by byte.  emit(k, body_offset, body_len) is called for every record, in order.
+// scan_one: ONE top-level field at `pos` (advances pos; counts a record); scan_toplevel: the whole payload.
+template <class Rd, class Emit>
+GW_HD int32_t scan_one(Rd& rd, uint32_t len, uint32_t& pos, uint32_t max_items, uint32_t& count, Emit& emit) {
+    uint64_t w = rd.peek8(pos);
+    uint64_t tag; uint32_t used;
+    if (!(w & 0x80)) { tag = w & 0x7f; used = 1; }
+    else {                                                           // a multi-byte tag: by the book
+        const uint8_t* p = rd.slow(pos); const uint8_t* e = rd.slow(len);
+        if (!wire::get_varint(p, e, tag)) return WIRE_MALFORMED;
+        used = (uint32_t)(p - rd.slow(pos));
+        w = rd.peek8(pos + used) << 8;                               // (keeps "w >> 8" below = the bytes after the tag)
+    }
+    const uint32_t wt = (uint32_t)(tag & 7);
+    const uint64_t field = tag >> 3;
+    if (field == 0 || field > 0x1fffffffull) return WIRE_MALFORMED;
+    if (field != 1 || wt != 2) {                                     // unknown top-level field
+        const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
+        if (!wire::skip_field(p, e, wt, field)) return WIRE_MALFORMED;
+        pos = (uint32_t)(p - rd.slow(0));
+        return WIRE_OK;
+    }
+    uint64_t L; uint32_t lused;
+    const uint64_t v = w >> 8;                                       // the bytes after the tag
+    if (!(v & 0x80)) { L = v & 0x7f; lused = 1; }
+    else if (!(v & 0x8000)) { L = (v & 0x7f) | ((v >> 1) & 0x3f80); lused = 2; }
+    else {
+        const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
+        if (!wire::get_varint(p, e, L)) return WIRE_MALFORMED;
+        lused = (uint32_t)(p - rd.slow(pos + used));
+    }
+    const uint64_t body = (uint64_t)pos + used + lused;
+    if (body > len || L > (uint64_t)len - body) return WIRE_MALFORMED;
+    if (count < max_items) emit(count, (uint32_t)body, (uint32_t)L);
+    ++count;
+    pos = (uint32_t)(body + L);
+    return WIRE_OK;
+}
 template <class Rd, class Emit>
 GW_HD int32_t scan_toplevel(Rd& rd, uint32_t len, uint32_t max_items, uint32_t& count, Emit emit) {
     uint32_t pos = 0;
     count = 0;
     while (pos < len) {
-        uint64_t w = rd.peek8(pos);
-        uint64_t tag; uint32_t used;
-        if (!(w & 0x80)) { tag = w & 0x7f; used = 1; }
-        else {                                                       // a multi-byte tag: by the book
-            const uint8_t* p = rd.slow(pos); const uint8_t* e = rd.slow(len);
-            if (!wire::get_varint(p, e, tag)) return WIRE_MALFORMED;
-            used = (uint32_t)(p - rd.slow(pos));
-            w = rd.peek8(pos + used) << 8;                           // (keeps "w >> 8" below = the bytes after the tag)
-        }
-        const uint32_t wt = (uint32_t)(tag & 7);
-        const uint64_t field = tag >> 3;
-        if (field == 0 || field > 0x1fffffffull) return WIRE_MALFORMED;
-        if (field != 1 || wt != 2) {                                 // unknown top-level field
-            const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
-            if (!wire::skip_field(p, e, wt, field)) return WIRE_MALFORMED;
-            pos = (uint32_t)(p - rd.slow(0));
-            continue;
-        }
-        uint64_t L; uint32_t lused;
-        const uint64_t v = w >> 8;                                   // the bytes after the tag
-        if (!(v & 0x80)) { L = v & 0x7f; lused = 1; }
-        else if (!(v & 0x8000)) { L = (v & 0x7f) | ((v >> 1) & 0x3f80); lused = 2; }
-        else {
-            const uint8_t* p = rd.slow(pos + used); const uint8_t* e = rd.slow(len);
-            if (!wire::get_varint(p, e, L)) return WIRE_MALFORMED;
-            lused = (uint32_t)(p - rd.slow(pos + used));
-        }
-        const uint64_t body = (uint64_t)pos + used + lused;
-        if (body > len || L > (uint64_t)len - body) return WIRE_MALFORMED;
-        if (count < max_items) emit(count, (uint32_t)body, (uint32_t)L);
-        ++count;
-        pos = (uint32_t)(body + L);
+        const int32_t st = scan_one(rd, len, pos, max_items, count, emit);
+        if (st != WIRE_OK) return st;
     }
     return WIRE_OK;
 }
+// a byte source over plain memory (the device's rare path: constructs the windowed walk does not shortcut; the host's only path)
+struct MemReader {
+    const uint8_t* g; uint32_t len;
+    GW_HD uint64_t peek8(uint32_t pos) const { uint64_t w = 0; for (uint32_t k = 0; k < 8 && pos + k < len; ++k) w |= (uint64_t)g[pos + k] << (8 * k); return w; }
+    GW_HD const uint8_t* slow(uint32_t pos) const { return g + pos; }
+};
 
 struct WireIn {
     const uint8_t* buf;             // the payloads back to back (16 readable bytes past the end)
@@ -87,53 +100,74 @@ struct WireOut {
 };
 
 constexpr uint32_t WIRE_WIN = 8192;
-struct LdsWindowReader {            // device byte source: a window of the payload in LDS, reloaded by the whole wave when the walk leaves it
-    const uint8_t* g; uint32_t len; unsigned char* win; uint32_t wbase, wend;
-    __device__ __forceinline__ void load(uint32_t pos) {
-        wbase = pos & ~15u;
-        wend = wbase + WIRE_WIN < len ? wbase + WIRE_WIN : len;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();     // the previous window is done with
-        for (uint32_t o = threadIdx.x * 16; wbase + o < wend; o += blockDim.x * 16) {
-            uint4 v = {0, 0, 0, 0};
-            if (wbase + o + 16 <= len) v = *(const uint4*)(g + wbase + o);                                    // (payload start is 16-byte aligned)
-            else { unsigned char t[16]; for (int k = 0; k < 16; ++k) t[k] = wbase + o + k < len ? g[wbase + o + k] : 0; v = *(uint4*)t; }
-            *(uint4*)(win + o) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-    }
-    __device__ __forceinline__ uint64_t peek8(uint32_t pos) {
-        if (pos < wbase || pos + 8 > wend) {
-            if (pos + 8 > len) {                                     // the tail of the payload: byte by byte, zero beyond
-                uint64_t w = 0;
-                for (uint32_t k = 0; k < 8 && pos + k < len; ++k) w |= (uint64_t)g[pos + k] << (8 * k);
-                return w;
-            }
-            load(pos);
-        }
-        const uint32_t o = pos - wbase;
-        const uint32_t* d = (const uint32_t*)(win + (o & ~3u));
-        const uint32_t sh = (o & 3u) * 8;
-        const uint64_t lo = (uint64_t)d[0] | ((uint64_t)d[1] << 32);
-        const uint64_t hi = d[2];
-        return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
-    }
-    __device__ __forceinline__ const uint8_t* slow(uint32_t pos) const { return g + pos; }
-};
-
-// one wave per RPC payload; every lane walks the same chain (uniform control flow, LDS broadcast reads)
+// One wave per RPC payload.  Every lane walks the same chain; what it reads from the LDS window goes through readfirstlane, so the
+// walk runs on the scalar unit (uniform branches, no exec-mask bookkeeping).  The usual record — tag 0x0a, a one- or two-byte
+// length — is decided from four bytes; everything else (multi-byte tags, unknown fields, long lengths) goes through scan_one over
+// plain memory: the shared, fuzzed code.
 __global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) {
-    __shared__ __attribute__((aligned(16))) unsigned char win[WIRE_WIN + 32];
+    __shared__ uint32_t win[WIRE_WIN / 4 + 8];
     const uint32_t r = blockIdx.x;
     const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
-    LdsWindowReader rd{in.buf + off, len, win, 0xffffffffu, 0};
-    rd.wbase = 0; rd.wend = 0;
-    if (len >= 8) rd.load(0);
-    uint32_t count = 0;
+    const uint8_t* g = in.buf + off;
+    const uint32_t lim = (len + 15u) & ~15u;                         // whole 16-byte chunks: the bytes past the payload are padding or the next payload's
     uint32_t* ro = sc.rec_off + (size_t)r * in.cap_per_rpc; uint32_t* rl = sc.rec_len + (size_t)r * in.cap_per_rpc;
-    int32_t st = scan_toplevel(rd, len, in.cap_per_rpc, count, [&](uint32_t k, uint32_t bo, uint32_t bl) {
-        if (threadIdx.x == 0) { ro[k] = off + bo; rl[k] = bl; }
-    });
+    uint32_t pos = 0, count = 0, wbase = 0, wend = 0;
+    int32_t st = WIRE_OK;
+    // records are collected in LDS and leave in whole lines of 64 (one coalesced store per line): no store sits in the walk's chain
+    __shared__ uint32_t lro[64], lrl[64];
+    auto flush = [&](uint32_t upto) {                                // records [upto - n, upto) of the line, n = ((upto - 1) & 63) + 1
+        const uint32_t base = (upto - 1u) & ~63u, n = upto - base;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        if (threadIdx.x < n) { ro[base + threadIdx.x] = lro[threadIdx.x]; rl[base + threadIdx.x] = lrl[threadIdx.x]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
+    };
+    auto emit = [&](uint32_t k, uint32_t bo, uint32_t bl) {
+        lro[k & 63u] = off + bo; lrl[k & 63u] = bl;                  // (every lane writes the same value)
+        if ((k & 63u) == 63u) flush(k + 1u);
+    };
+    while (pos < len) {
+        if (pos < wbase || pos + 4 > wend) {                         // the walk left the window: the whole wave fetches the next one
+            wbase = pos & ~15u; wend = wbase + WIRE_WIN;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
+            uint4 v[WIRE_WIN / (64 * 16)];
+#pragma unroll
+            for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) {
+                const uint32_t o = (c * 64 + threadIdx.x) * 16;
+                v[c] = make_uint4(0, 0, 0, 0);
+                if (wbase + o < lim) v[c] = *(const uint4*)(g + wbase + o);
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) *(uint4*)((unsigned char*)win + (c * 64 + threadIdx.x) * 16) = v[c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+        const uint32_t o = pos - wbase;
+        const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
+        uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
+        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+        const uint32_t avail = len - pos;
+        if (avail < 4) h &= (1u << (8 * avail)) - 1u;                 // zero beyond the payload
+        uint32_t L = 0, hdr = 0;
+        if ((h & 0xffu) == 0x0au) {
+            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
+            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+        }
+        if (hdr) {
+            if (hdr > avail || L > avail - hdr) { st = WIRE_MALFORMED; break; }
+            if (count < in.cap_per_rpc) emit(count, pos + hdr, L);
+            ++count;
+            pos += hdr + L;
+        } else {
+            MemReader rd{g, len};
+            st = scan_one(rd, len, pos, in.cap_per_rpc, count, emit);
+            pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos); count = (uint32_t)__builtin_amdgcn_readfirstlane((int)count);
+            if (st != WIRE_OK) break;
+        }
+    }
+    {
+        const uint32_t kept = count < in.cap_per_rpc ? count : in.cap_per_rpc;
+        if (kept & 63u) flush(kept);                                 // the last, partial line
+    }
     if (st == WIRE_OK && ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc)) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
     if (threadIdx.x == 0) { sc.count[r] = count; sc.status[r] = st; }
 }

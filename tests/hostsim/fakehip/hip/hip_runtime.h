@@ -64,6 +64,7 @@ static inline void __syncthreads() { fakehip::barrier(); }
 #define __builtin_amdgcn_s_barrier() fakehip::barrier()
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_kernarg_segment_ptr() (fakehip::S.kernarg)
 static inline void __threadfence_system() {}
 static inline void __threadfence() {}

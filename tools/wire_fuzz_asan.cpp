@@ -78,14 +78,9 @@ static void mutate(std::string& p) {
 }
 
 namespace fakehip { State S; void yield() {} void barrier() {} unsigned long long wave_exchange(unsigned long long, int, unsigned long long*, unsigned long long*) { return 0; } }
-struct MemReader {                                                   // exact-size heap buffer: any read past it is an ASan error
-    const uint8_t* g; uint32_t len;
-    uint64_t peek8(uint32_t pos) const { uint64_t w = 0; for (uint32_t k = 0; k < 8 && pos + k < len; ++k) w |= (uint64_t)g[pos + k] << (8 * k); return w; }
-    const uint8_t* slow(uint32_t pos) const { return g + pos; }
-};
 // the device decoder's verdict on one payload: GUBER_OK / GUBER_E_WIRE_MALFORMED and the item count
 static int device_logic(const std::vector<uint8_t>& m, uint32_t& count) {
-    MemReader rd{m.data(), (uint32_t)m.size()};
+    guber::MemReader rd{m.data(), (uint32_t)m.size()};
     std::vector<std::pair<uint32_t, uint32_t>> recs;
     int32_t st = guber::scan_toplevel(rd, rd.len, 1u << 20, count, [&](uint32_t, uint32_t bo, uint32_t bl) { recs.push_back({bo, bl}); });
     if (st != guber::WIRE_OK) return st;
