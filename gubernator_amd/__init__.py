@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
     "guber_placement_create", "guber_placement_destroy", "guber_placement_shard", "guber_placement_version", "guber_placement_route_keys",
     "guber_placement_observe", "guber_placement_observe_keys", "guber_placement_rebalance", "guber_placement_info",
-    "guber_stages_submit", "guber_stage_poll", "guber_stage_dest", "guber_stage_submit_routed", "guber_placement_plan", "guber_placement_commit", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_add_item_for", "guber_pool_load_hinted", "guber_pool_get_item", "guber_pool_size",
+    "guber_stages_submit", "guber_stage_poll", "guber_stage_dest", "guber_stage_submit_routed", "guber_placement_plan", "guber_placement_commit", "guber_placement_cancel", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_add_item_for", "guber_pool_load_hinted", "guber_pool_get_item", "guber_pool_size",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32

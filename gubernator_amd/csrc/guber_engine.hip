@@ -1058,9 +1058,20 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     *out = s;
     return GUBER_OK;
 }
+// no engine may keep pointing at a stage that is being abandoned or freed (its next submit would look at it: resolve_small_locked)
+static void forget_small_pending(guber_stage* s) {
+    std::vector<guber_engine*> engs;
+    if (s->e) engs.push_back(s->e);
+    for (auto& part : s->parts) if (part.e && std::find(engs.begin(), engs.end(), part.e) == engs.end()) engs.push_back(part.e);
+    for (guber_engine* e : engs) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->small_pending == s) e->small_pending = nullptr;
+    }
+}
 extern "C" void guber_stage_destroy(guber_stage_t* s) {
     if (!s) return;
     if (s->mode) (void)guber_stage_wait(s);
+    forget_small_pending(s);
     if (s->ev) (void)hipEventDestroy(s->ev);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     s->dmem.release();
@@ -1151,7 +1162,7 @@ extern "C" int guber_stage_wait(guber_stage_t* s) {
     }
     if (s->mode == 4) {                                      // a routed stage on the one-launch path: every share's outcome
         const int rc4 = resolve_routed_small(s, true);
-        if (rc4 < 0) { s->mode = 0; s->routed.clear(); s->parts.clear(); return rc4; }
+        if (rc4 < 0) { forget_small_pending(s); s->mode = 0; s->routed.clear(); s->parts.clear(); return rc4; }
     }
     bool general = s->mode == 2;
     if (s->mode == 1) {                                      // answered by the one-launch path, already complete (guber_stage_submit)
@@ -1892,13 +1903,16 @@ extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to
     DevBuf<uint64_t>& d_h = from->d_mvh;
     if (d_h.ensure(n) || from->d_items.ensure(n) || from->d_ikeys.ensure((size_t)n * stride + 16) || to->d_islots.ensure(n) || to->d_iflags.ensure(n) ||
         to->d_ires.ensure(n)) return GUBER_E_NOMEM;
-    std::vector<uint8_t> res(n);
+    std::vector<uint8_t> res(n, 0xFF);
     hipError_t he = hipSuccess;
     int rc = 0;
+    bool taken = false;
     do {
         if ((he = hipMemcpyAsync(d_h.p, hashes, (size_t)n * 8, hipMemcpyHostToDevice, from->stream)) != hipSuccess) break;
+        if ((he = hipMemsetAsync(to->d_ires.p, 0xFF, n, from->stream)) != hipSuccess) break;      // "not taken over" until the commit says otherwise
         hipLaunchKernelGGL(k_items_take_by_hash, dim3((n + 63) / 64), dim3(64), 0, from->stream, from->T, d_h.p, n, stride, from->d_items.p, from->d_ikeys.p);
         if ((he = hipStreamSynchronize(from->stream)) != hipSuccess) break;
+        taken = true;
         rc = maintain(to, n, to->clock_ms);
         if (rc) break;
         to->tags_upper += n; to->size_upper += n; to->rb_added += n;
@@ -1909,10 +1923,20 @@ extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to
         if ((he = hipMemcpyAsync(res.data(), to->d_ires.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
         he = hipStreamSynchronize(st);
     } while (0);
+    if (taken) {
+        // whatever the destination did not take over goes back into the source (the commit's verdicts, or 0xFF for everything
+        // when it never ran): a migration that fails loses no bucket
+        (void)hipStreamSynchronize(to->stream);
+        hipLaunchKernelGGL(k_items_restore, dim3((n + 63) / 64), dim3(64), 0, from->stream, from->T, from->d_items.p, from->d_ikeys.p, n, to->d_ires.p);
+        (void)hipMemcpyAsync(res.data(), to->d_ires.p, n, hipMemcpyDeviceToHost, from->stream);
+        (void)hipStreamSynchronize(from->stream);
+    }
     if (he != hipSuccess) return fail(GUBER_E_HIP, "guber_move_items_by_hash", he);
     if (rc) return rc;
-    uint32_t m = 0;
-    for (uint32_t i = 0; i < n; ++i) m += res[i] <= 1;                // (0xFE: the hash named no live bucket)
+    uint32_t m = 0, back = 0;
+    for (uint32_t i = 0; i < n; ++i) { m += res[i] <= 1; back += res[i] == 0xFD; }   // (0xFE / 0xFF left: the hash named no live bucket)
+    if (moved) *moved = m;
+    if (back) return fail(GUBER_E_TABLE_FULL, "guber_move_items_by_hash: the destination did not take every bucket; those went back to their table");
     if (moved) *moved = m;
     return GUBER_OK;
 }

@@ -79,6 +79,21 @@ __global__ __launch_bounds__(64) void k_items_take_by_hash(Table T, const uint64
     items[i] = out;
 }
 
+// Undo k_items_take_by_hash for the items the destination table did not take (result >= 2: table full, a colliding key, or the
+// whole commit never ran): the bucket goes back where it was — its tag and key bytes never left — so a failed migration loses nothing.
+// result[i] becomes 0xFD for a bucket that went back.
+__global__ __launch_bounds__(64) void k_items_restore(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n, uint8_t* result) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n || result[i] < 2 || items[i].key_len == 0) return;
+    const uint8_t* key = keys + items[i].key_off;
+    uint32_t slot = 0;
+    const uint32_t pr = probe(T, key, items[i].key_len, xxhash64(key, items[i].key_len, 0), false, slot);
+    if (!(pr & PR_FOUND)) return;
+    T.buckets[slot].rec = items[i].rec;
+    atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
+    result[i] = 0xFD;
+}
+
 // LRUCache.GetItem (lrucache.go:111-128) / Remove (:131-135) for one key. mode 0 = get, 1 = remove
 __global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found, uint32_t touch) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;

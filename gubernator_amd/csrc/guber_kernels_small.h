@@ -245,12 +245,32 @@ struct MultiSmallRouted { uint32_t nb, n_total; const uint32_t* dest; BatchView 
 static_assert(sizeof(MultiSmallRouted) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(FT) void k_small_routed(MultiSmallRouted A) {
     __shared__ uint32_t map[FT];
+    __shared__ uint32_t bad;
     const SmallRoutedSub* a = (const SmallRoutedSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiSmallRouted, sub)) + blockIdx.x;
+    // dest is written by the caller (guber_stage_dest is public ABI): the ranks of this engine's share must be a permutation of
+    // 0..n-1 — anything else (a rank twice, a rank >= n, a count that disagrees with dest) would send small_body to an arbitrary
+    // index of the stage's host arrays.  Such a share is not evaluated: it reports fallback and the host re-runs it by index list.
+    map[threadIdx.x] = 0xffffffffu;
+    if (threadIdx.x == 0) bad = 0u;
+    __syncthreads();
     if (threadIdx.x < A.n_total) {
         const uint32_t dv = A.dest[threadIdx.x];
-        if ((dv >> 24) == a->engine) map[dv & (FT - 1)] = threadIdx.x;
+        if ((dv >> 24) == a->engine) {
+            const uint32_t rank = dv & 0xffffffu;
+            if (rank >= a->n || rank >= FT || atomicCAS(&map[rank], 0xffffffffu, threadIdx.x) != 0xffffffffu) bad = 1u;
+        }
     }
     __syncthreads();
+    if (threadIdx.x < a->n && map[threadIdx.x] == 0xffffffffu) bad = 1u;     // a rank nobody took
+    __syncthreads();
+    if (bad) {
+        if (threadIdx.x == 0) {
+            a->out->fallback = 1u; a->out->over = a->out->hits = a->out->misses = 0u; a->out->size_delta = 0;
+            __threadfence_system();
+            __hip_atomic_store(&a->out->done, a->seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     BatchView B = A.B;
     B.n = a->n;
     small_body(a->T, B, A.R, a->out, a->seq, a->touch, map);

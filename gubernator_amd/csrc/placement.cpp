@@ -192,6 +192,17 @@ extern "C" int guber_placement_plan(guber_placement_t* p, double heavy_fraction,
     if (n_moves) *n_moves = nm;
     return (moves && nm > cap) ? GUBER_E_NOMEM : GUBER_OK;
 }
+// a planned move whose bucket could not be migrated: the key keeps following its slot (nothing a reader sees changes for it)
+extern "C" int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash) {
+    if (!p) return GUBER_E_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->pending || p->pending->get(key_hash) < 0) return GUBER_OK;
+    std::unique_ptr<guber_placement::Exceptions> ne(new guber_placement::Exceptions());
+    for (uint32_t i = 0; i < guber_placement_detail::kExCells; ++i)
+        if (p->pending->h[i] != 0 && p->pending->h[i] != key_hash) ne->put(p->pending->h[i], p->pending->s[i]);
+    p->pending = std::move(ne);
+    return GUBER_OK;
+}
 extern "C" int guber_placement_commit(guber_placement_t* p) {
     if (!p) return GUBER_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(p->mu);

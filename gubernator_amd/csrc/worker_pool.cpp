@@ -1020,8 +1020,12 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
         for (uint32_t q = 0; q < nm; ++q) {
             if (moves[q].from >= d.n_plain || moves[q].to >= d.n_plain) continue;
             uint32_t moved = 0;
-            (void)guber_move_items_by_hash(d.shards[moves[q].from]->engine, d.shards[moves[q].to]->engine, &moves[q].key_hash, 1, &moved);
-            d.moves += 1;
+            const int mrc = guber_move_items_by_hash(d.shards[moves[q].from]->engine, d.shards[moves[q].to]->engine, &moves[q].key_hash, 1, &moved);
+            // a bucket that did not arrive (an error, a full or colliding destination) went back to its table: its key must keep
+            // following its slot, or its requests would start a fresh bucket elsewhere.  (moved == 0 with no error also means
+            // "the hash named no live bucket" — nothing to lose, the new placement may stand.)
+            if (mrc != GUBER_OK) (void)guber_placement_cancel(d.place, moves[q].key_hash);
+            else d.moves += moved;
         }
         (void)guber_placement_commit(d.place);
         d.ver.fetch_add(1, std::memory_order_acq_rel);

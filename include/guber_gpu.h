@@ -56,7 +56,7 @@ extern "C" {
 #define GUBER_E_NO_DEVICE (-2)     /* HIP runtime / GPU missing: the product path never falls back to CPU */
 #define GUBER_E_HIP (-3)           /* a HIP call failed; guber_last_error() has the text */
 #define GUBER_E_BATCH_TOO_LARGE (-4)
-#define GUBER_E_TABLE_FULL (-5)    /* guber_add_items only: no directory entry for an item although nothing is evictable */
+#define GUBER_E_TABLE_FULL (-5)    /* guber_add_items: no directory entry for an item although nothing is evictable; guber_move_items_by_hash: the destination took not every bucket (those went back to the source: nothing is lost) */
 #define GUBER_E_NOMEM (-6)
 #define GUBER_E_KEY_TOO_LONG (-7)
 #define GUBER_E_NOT_FOUND (-8)
@@ -237,8 +237,12 @@ int guber_stage_poll(guber_stage_t* s);
  * key carry ranks in the order they are to be applied).  The copy kernel that brings the request columns to HBM places every
  * share contiguously in rank order, the shares run as the batches of ONE k_front_multi_mem + ONE k_eval2_multi_mem, and the
  * answers land in the result arrays at the index the request was written at.  Four launches and one event whatever the number
- * of engines (<= 16; they share device and stream, the stage's own engine is one of them); never blocks on the GPU;
- * completion through guber_stage_poll / guber_stage_wait (no per-batch aggregates).  Every request column of the stage is
+ * of engines (<= 16; they share device and stream, the stage's own engine is one of them).  The call does not wait for ITS work;
+ * it can wait — bounded: a polled sequence number, a stream synchronise after 2 s — for an EARLIER one-launch stage of one of
+ * the engines whose outcome has not been looked at yet (its declined shares must be re-run before later requests of their keys),
+ * and for a completion-event slot of sixteen to be free.  A stage of <= 256 requests goes as ONE launch (k_small_routed); ranks that
+ * are not a permutation of 0 .. counts[engine]-1 make that share report fallback (it is re-run by index list), never an access
+ * outside the stage.  Completion through guber_stage_poll / guber_stage_wait (no per-batch aggregates).  Every request column of the stage is
  * present (none switched off). */
 uint32_t* guber_stage_dest(guber_stage_t* s);
 int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts);
@@ -514,6 +518,8 @@ int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_
  * (version + 1) and starts a fresh observation round. */
 int guber_placement_plan(guber_placement_t* p, double heavy_fraction, guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves);
 int guber_placement_commit(guber_placement_t* p);
+/* between plan and commit: drop one planned move (its bucket could not be migrated): the key keeps following its slot */
+int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash);
 /* The buckets of the keys with these XXH64 hashes leave `from`'s table and enter `to`'s (two logical shards of ONE GPU), on
  * the device.  The caller guarantees that neither engine has a batch with those keys being formed or in flight.  *moved
  * (optional) = buckets that were live and moved. */
