@@ -34,13 +34,16 @@ ABI_SYMBOLS = [
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",
     "guber_placement_create", "guber_placement_destroy", "guber_placement_shard", "guber_placement_version", "guber_placement_route_keys",
     "guber_placement_observe", "guber_placement_observe_keys", "guber_placement_rebalance", "guber_placement_info",
-    "guber_stages_submit", "guber_stage_poll", "guber_stage_dest", "guber_stage_submit_routed", "guber_placement_plan", "guber_placement_commit", "guber_placement_cancel", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_add_item_for", "guber_pool_load_hinted", "guber_pool_get_item", "guber_pool_size",
+    "guber_stages_submit", "guber_stage_poll", "guber_stage_dest", "guber_stage_submit_routed", "guber_placement_plan", "guber_placement_commit", "guber_placement_cancel", "guber_placement_export", "guber_stage_route", "guber_stage_route_poll", "guber_move_items_by_hash", "guber_engine_stream", "guber_pool_global_engine", "guber_pool_global_sync", "guber_pool_rebalance", "guber_pool_get_rate_limits_owner", "guber_pool_add_item", "guber_pool_add_item_for", "guber_pool_load_hinted", "guber_pool_get_item", "guber_pool_size",
 ]
 
 FLAG_TEST_WEAK_HASH, FLAG_TEST_FORCE_RADIX, FLAG_TEST_CAREFUL, FLAG_GLOBAL, FLAG_DIR_CLAIMS, FLAG_TEST_NO_SMALL = 1, 2, 4, 8, 16, 32
 FLAG_TEST_FORCE_PART, FLAG_NO_PART = 64, 128
 
 _lib = None
+
+
+E_INVALID_ARG, E_NO_DEVICE, E_HIP, E_BATCH_TOO_LARGE, E_TABLE_FULL, E_NOMEM, E_KEY_TOO_LONG, E_NOT_FOUND = -1, -2, -3, -4, -5, -6, -7, -8   # include/guber_gpu.h
 
 
 class GuberError(RuntimeError):
@@ -180,6 +183,13 @@ class Ring:
             pass
 
 
+class RouteRule(C.Structure):
+    """guber_route_rule_t (include/guber_gpu.h): the placement in the form the device applies it (guber_stage_route)"""
+    _fields_ = [("n_shards", C.c_uint32), ("per", C.c_uint32), ("step", C.c_uint64), ("inv_step", C.c_uint64), ("inv_sub", C.c_uint64),
+                ("table", C.c_void_p), ("ex_cells", C.c_uint32), ("ex_n", C.c_uint32), ("ex_hash", C.c_void_p), ("ex_shard", C.c_void_p),
+                ("global_engine", C.c_int32)]
+
+
 class Placement:
     """guber_placement_t: which logical shard of a GPU holds a key — hash slots -> shards plus individually placed hot keys,
     fitted to observed traffic (include/guber_gpu.h; the generalisation of WorkerPool.getWorker, workers.go:180-184)."""
@@ -219,6 +229,15 @@ class Placement:
         _check(lib().guber_placement_rebalance(self.h, heavy_fraction, 1 if move_slots else 0, mv.ctypes.data, 64, C.byref(nm)))
         rec = mv.view(np.dtype([("h", np.uint64), ("from", np.uint32), ("to", np.uint32)]))
         return [(int(r["h"]), int(r["from"]), int(r["to"])) for r in rec[:nm.value]]
+
+    def export(self, global_engine=-1):
+        """guber_placement_export -> RouteRule (valid while this placement lives)"""
+        L = lib()
+        L.guber_placement_export.argtypes = [C.c_void_p, C.POINTER(RouteRule)]
+        r = RouteRule()
+        _check(L.guber_placement_export(self.h, C.byref(r)))
+        r.global_engine = global_engine
+        return r
 
     def n_hot(self):
         nh = C.c_uint32(0)
@@ -458,6 +477,7 @@ class Stage:
         L.guber_stage_submit.argtypes = [C.c_void_p]
         L.guber_stage_wait.argtypes = [C.c_void_p]
         self.h = C.c_void_p()
+        self.engine = engine
         _check(L.guber_stage_create(engine.h, max_n, key_bytes_cap, C.byref(self.h)))
         kc = C.c_uint32()
         self.max_n = L.guber_stage_capacity(self.h, C.byref(kc))
@@ -530,7 +550,36 @@ class Stage:
         _check(L.guber_stages_submit(arr, len(stages), 0 if aggregates else 1, C.byref(done)))
         return done.value
 
-    def submit_routed(self, engines, shard_of):
+    def route(self, rule, n_engines, timeout_s=10.0):
+        """guber_stage_route + guber_stage_route_poll: the device decides every request's engine and rank -> (dest uint32[n], counts)"""
+        import time
+        L = lib()
+        L.guber_stage_route.argtypes = [C.c_void_p, C.POINTER(RouteRule), C.c_uint32]
+        L.guber_stage_route_poll.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.guber_stage_dest.argtypes = [C.c_void_p]
+        L.guber_stage_dest.restype = C.POINTER(C.c_uint32)
+        _check(L.guber_stage_route(self.h, C.byref(rule) if rule is not None else None, n_engines))
+        counts = (C.c_uint32 * 16)()
+        t0 = time.time()
+        while True:
+            r = L.guber_stage_route_poll(self.h, counts)
+            if r:
+                _check(r if r < 0 else 0)
+                break
+            assert time.time() - t0 < timeout_s, "guber_stage_route did not complete"
+        self.engine.synchronize()                              # (dest is complete in stream order; a test reads it from the host)
+        dest = np.ctypeslib.as_array(L.guber_stage_dest(self.h), shape=(self.max_n,))[:self.b.n].copy()
+        return dest, np.array(counts[:n_engines], np.uint32)
+
+    def submit_routed_as_routed(self, engines, counts):
+        """guber_stage_submit_routed with the dest column as guber_stage_route left it"""
+        L = lib()
+        L.guber_stage_submit_routed.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(C.c_uint32)]
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        counts = np.ascontiguousarray(counts, np.uint32)
+        _check(L.guber_stage_submit_routed(self.h, arr, len(engines), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
+
+    def submit_routed(self, engines, shard_of, corrupt_dest=None):
         """guber_stage_submit_routed: the stage's requests (already filled, arrival order) belong to several engines — shard_of[i]
         is request i's index in `engines`; ranks inside an engine's share follow the arrival order, as a pool's callers assign them"""
         L = lib()
@@ -546,6 +595,8 @@ class Stage:
         rank = np.empty(n, np.uint32)
         rank[order] = (np.arange(n, dtype=np.int64) - start[shard_of[order]]).astype(np.uint32)
         dest[:n] = (shard_of << 24) | rank
+        if corrupt_dest is not None:                            # tests: what a faulty caller might write
+            corrupt_dest(dest[:n])
         arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
         _check(L.guber_stage_submit_routed(self.h, arr, len(engines), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
         return counts

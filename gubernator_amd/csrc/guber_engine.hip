@@ -139,6 +139,7 @@ struct guber_engine {
     GroupEv gev[kGroupEvs]; uint32_t gev_next = 0;
     DevBuf<uint8_t> d_margs;
     uint64_t small_batches = 0, small_fallbacks = 0;
+    DevBuf<uint16_t> d_rt_table, d_rt_exs; DevBuf<uint64_t> d_rt_exh; RouteRule rule{}; bool have_rule = false;   // guber_stage_route: the placement rule on the device
     CohBuf<DevCounters> h_ctr; CohBuf<uint32_t> h_rb_seq; uint32_t rb_seq = 0;   // counter snapshot + its completion stamp
     DevCounters last_ctr{};
     uint32_t epoch = 0;
@@ -987,6 +988,8 @@ struct guber_stage {
     // a routed stage of <= 256 requests: one workgroup per engine in ONE launch (k_small_routed); every share has its own outcome
     struct RoutedPart { guber_engine* e; uint32_t engine, n, seq; SmallOut* out; bool pending; int rc; };
     std::vector<RoutedPart> parts; uint8_t* h_parts_out = nullptr;  // (mode 4; a part is only touched under its engine's mutex)
+    // guber_stage_route: the shares' sizes + completion flag (host, device-visible), per-request engine and per-tile tables (HBM)
+    uint32_t* h_route = nullptr; DevBuf<uint8_t> d_route; uint32_t route_seq = 0; bool route_pending = false; uint32_t route_engines = 0;
     uint32_t seq = 0, n = 0; int64_t now_ms = 0;
     int mode = 0;                    // 0 idle, 1 small path complete, 2 pipeline in flight, 3 small path launched, outcome not looked at yet (guber_stages_submit),
                                      // 4 routed small path launched (guber_stage_submit_routed): outcomes per part
@@ -1020,7 +1023,7 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     const size_t in_fixed = col((n + 1) * 4) + 5 * col(n * 8) + col(n * 4) + 2 * col(n);
     const size_t in_bytes = col(in_fixed + (size_t)s->key_cap + 64);
     const size_t out_bytes = 3 * col(n * 8) + 2 * col(n);
-    const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters))) + col(sizeof(MultiArgsMem)) + col(n * 4) + 16 * 64;
+    const size_t head = 256 + 2 * (col(sizeof(DevCounters)) + col((size_t)e->n_bctr * sizeof(BlockCounters))) + col(sizeof(MultiArgsMem)) + col(n * 4) + 16 * 64 + 128;
     const size_t bytes = head + in_bytes + out_bytes + 256;
     if (s->mem.ensure(bytes) || hipEventCreateWithFlags(&s->ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming) != hipSuccess) {
@@ -1035,7 +1038,8 @@ extern "C" int guber_stage_create(guber_engine_t* e, uint32_t max_n, uint32_t ke
     s->rb0_bctr = (BlockCounters*)p; p += col((size_t)e->n_bctr * sizeof(BlockCounters));
     s->h_margs = (MultiArgsMem*)p; p += col(sizeof(MultiArgsMem));
     s->h_dest = (uint32_t*)p; p += col(n * 4);
-    s->h_parts_out = p;
+    s->h_parts_out = p; p += 16 * 64;
+    s->h_route = (uint32_t*)p;                                     // [0..15] counts, [16] done flag
     p = s->mem.p + head;
     s->h_in = p; s->h_out = p + in_bytes; s->in_fixed = in_fixed; s->out_bytes = out_bytes;
     guber_batch_t& b = s->batch; guber_result_t& r = s->result;
@@ -1071,10 +1075,12 @@ static void forget_small_pending(guber_stage* s) {
 extern "C" void guber_stage_destroy(guber_stage_t* s) {
     if (!s) return;
     if (s->mode) (void)guber_stage_wait(s);
+    if (s->route_pending && s->e && !s->e->set_device()) (void)hipStreamSynchronize(s->e->stream);   // (the routing launches write into the stage)
     forget_small_pending(s);
     if (s->ev) (void)hipEventDestroy(s->ev);
     if (s->ev_in) (void)hipEventDestroy(s->ev_in);
     s->dmem.release();
+    s->d_route.release();
     s->mem.release();
     delete s;
 }
@@ -1252,8 +1258,17 @@ static int resolve_routed_parts_locked(guber_stage* s, guber_engine* holder, boo
         }
         holder->small_fallbacks++;
         if (holder->set_device()) return part.rc = fail(GUBER_E_HIP, "hipSetDevice");
-        std::vector<uint32_t> idx(part.n, 0);
-        for (uint32_t i = 0; i < s->n; ++i) if ((s->h_dest[i] >> 24) == part.engine && (s->h_dest[i] & 0xffffffu) < part.n) idx[s->h_dest[i] & 0xffffffu] = i;
+        // the kernel also declines a share whose ranks in dest are not a permutation of 0..n-1 (the caller wrote dest): that is a
+        // caller error, not a batch for the general pipeline
+        std::vector<uint32_t> idx(part.n, 0xffffffffu);
+        uint32_t placed = 0;
+        for (uint32_t i = 0; i < s->n; ++i) {
+            if ((s->h_dest[i] >> 24) != part.engine) continue;
+            const uint32_t rk = s->h_dest[i] & 0xffffffu;
+            if (rk >= part.n || idx[rk] != 0xffffffffu) { placed = 0xffffffffu; break; }
+            idx[rk] = i; ++placed;
+        }
+        if (placed != part.n) return part.rc = fail(GUBER_E_INVALID_ARG, "dest: the ranks of an engine's share are not a permutation of 0 .. count-1");
         guber_batch_t hb = s->batch;
         part.rc = eval_host_once(holder, &hb, &s->result, idx.data(), part.n, nullptr);
         if (part.rc) return part.rc;
@@ -1585,6 +1600,69 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
 // k_front_multi_mem + ONE k_eval2_multi_mem, and a last launch takes the answers back to the callers' slots.  Four launches
 // and one event for a whole generation, whatever the number of shards; nothing on the host is proportional to the requests.
 extern "C" uint32_t* guber_stage_dest(guber_stage_t* s) { return s ? s->h_dest : nullptr; }
+// The routing of a front stage done by the device (k_route_count + k_route_dest): the callers wrote their requests in arrival
+// order and nothing else; afterwards guber_stage_dest(s) holds what they would have written and *counts the shares' sizes —
+// exactly the inputs of guber_stage_submit_routed.  The rule is the placement's (guber_placement_export); it is copied to the
+// device when given (NULL = the one given last).  Never waits for the GPU except when a rule is uploaded (a placement change).
+extern "C" int guber_stage_route(guber_stage_t* s, const guber_route_rule_t* rule, uint32_t n_engines) {
+    if (!s) return fail(GUBER_E_INVALID_ARG, "null stage");
+    if (n_engines == 0 || n_engines > (uint32_t)MULTI_MEM_MAX) return fail(GUBER_E_INVALID_ARG, "1 .. 16 engines per routed stage");
+    if (s->mode || s->route_pending) return fail(GUBER_E_INVALID_ARG, "stage already in flight");
+    const guber_batch_t& b = s->batch;
+    if (b.n > s->max_n || b.n > 65536u || (b.n && b.key_off[b.n] > s->key_cap)) return fail(GUBER_E_BATCH_TOO_LARGE, "stage overfilled (a routed stage holds at most 65 536 requests)");
+    if (!b.behavior) return fail(GUBER_E_INVALID_ARG, "a routed stage carries every request column");
+    guber_engine* e = s->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (rule) {
+        if (rule->n_shards == 0 || rule->per == 0 || !rule->table || rule->n_shards > 4096 || (rule->ex_cells & (rule->ex_cells - 1)) ||
+            (rule->ex_n && (!rule->ex_hash || !rule->ex_shard || rule->ex_n >= rule->ex_cells)))
+            return fail(GUBER_E_INVALID_ARG, "malformed route rule");
+        const size_t slots = (size_t)rule->n_shards * rule->per, cells = rule->ex_cells ? rule->ex_cells : 1;
+        if (e->d_rt_table.ensure(slots) || e->d_rt_exh.ensure(cells) || e->d_rt_exs.ensure(cells)) return GUBER_E_NOMEM;
+        hipError_t he = hipStreamSynchronize(e->stream);                // (launches still reading the previous rule)
+        if (he == hipSuccess) he = hipMemcpy(e->d_rt_table.p, rule->table, slots * 2, hipMemcpyHostToDevice);
+        if (he == hipSuccess && rule->ex_n) he = hipMemcpy(e->d_rt_exh.p, rule->ex_hash, cells * 8, hipMemcpyHostToDevice);
+        if (he == hipSuccess && rule->ex_n) he = hipMemcpy(e->d_rt_exs.p, rule->ex_shard, cells * 2, hipMemcpyHostToDevice);
+        if (he != hipSuccess) { e->have_rule = false; return fail(GUBER_E_HIP, "guber_stage_route: rule upload", he); }
+        e->rule = RouteRule{rule->n_shards, rule->per, rule->ex_cells, rule->ex_n, rule->global_engine, rule->step, rule->inv_step, rule->inv_sub,
+                            e->d_rt_table.p, (const unsigned long long*)e->d_rt_exh.p, e->d_rt_exs.p};
+        e->have_rule = true;
+    }
+    if (!e->have_rule) return fail(GUBER_E_INVALID_ARG, "guber_stage_route: no rule given yet");
+    s->route_engines = n_engines;
+    for (uint32_t j = 0; j < (uint32_t)MULTI_MEM_MAX; ++j) s->h_route[j] = 0;
+    if (b.n == 0) { s->route_pending = false; return GUBER_OK; }
+    const uint32_t tiles = (b.n + 255u) / 256u;
+    const size_t tab = (size_t)256 * MULTI_MEM_MAX * 4;
+    const bool fresh = s->d_route.p == nullptr;
+    if (s->d_route.ensure(2 * tab + 64 + (size_t)s->max_n)) return GUBER_E_NOMEM;
+    if (fresh && hipMemsetAsync(s->d_route.p + 2 * tab, 0, 64, e->stream) != hipSuccess) return fail(GUBER_E_HIP, "hipMemsetAsync");
+    memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);            // the kernels read keys as 8-byte words
+    RouteArgs A{};
+    A.n = b.n; A.n_engines = n_engines; A.max_key = e->max_key; A.seq = ++s->route_seq ? s->route_seq : ++s->route_seq;
+    A.key_bytes = b.key_bytes; A.key_off = b.key_off; A.behavior = b.behavior;
+    A.tile_cnt = (uint32_t*)s->d_route.p; A.tile_base = (uint32_t*)(s->d_route.p + tab); A.ticket = (uint32_t*)(s->d_route.p + 2 * tab);
+    A.eng = s->d_route.p + 2 * tab + 64;
+    A.dest = s->h_dest; A.counts = s->h_route; A.done = (unsigned int*)(s->h_route + MULTI_MEM_MAX);
+    A.R = e->rule;
+    hipLaunchKernelGGL(k_route_count, dim3(tiles), dim3(256), 0, e->stream, A);
+    hipLaunchKernelGGL(k_route_dest, dim3(tiles), dim3(256), 0, e->stream, A);
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    s->route_pending = true;
+    return GUBER_OK;
+}
+// 1 = the shares' sizes are in counts[0 .. n_engines) (guber_stage_dest is complete by the time anything enqueued later on the
+// engines' stream runs: guber_stage_submit_routed may follow at once), 0 = still running
+extern "C" int guber_stage_route_poll(guber_stage_t* s, uint32_t* counts) {
+    if (!s || !counts) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (s->route_pending) {
+        if (__atomic_load_n((volatile unsigned int*)(s->h_route + MULTI_MEM_MAX), __ATOMIC_ACQUIRE) != s->route_seq) return 0;
+        s->route_pending = false;
+    }
+    for (uint32_t j = 0; j < s->route_engines; ++j) counts[j] = s->h_route[j];
+    return 1;
+}
 extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts) {
     if (!s || !engines || !counts) return fail(GUBER_E_INVALID_ARG, "null argument");
     if (n_engines == 0 || n_engines > (uint32_t)MULTI_MEM_MAX) return fail(GUBER_E_INVALID_ARG, "1 .. 16 engines per routed stage");

@@ -760,6 +760,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi_mem(cons
 }  // namespace guber
 
 #include "guber_kernels_part.h"
+#include "guber_kernels_route.h"
 #ifndef GUBER_KERNELS_PIPELINES_ONLY   // (the host emulation of the batch pipelines, tests/hostsim/devsim.cpp, stops here)
 #include "guber_kernels_ops.h"
 #include "guber_kernels_small.h"

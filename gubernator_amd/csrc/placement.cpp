@@ -210,6 +210,18 @@ extern "C" int guber_placement_commit(guber_placement_t* p) {
     return GUBER_OK;
 }
 
+// the published state as plain arrays + numbers: what a device needs to apply slot_of / Exceptions::get itself (guber_stage_route)
+extern "C" int guber_placement_export(const guber_placement_t* p, guber_route_rule_t* out) {
+    if (!p || !out) return GUBER_E_INVALID_ARG;
+    static_assert(sizeof(std::atomic<uint16_t>) == sizeof(uint16_t), "the slot table is read as plain 16-bit words");
+    *out = guber_route_rule_t{};
+    out->n_shards = p->n_shards; out->per = p->per; out->step = p->step; out->inv_step = p->inv_step; out->inv_sub = p->inv_sub;
+    out->table = reinterpret_cast<const uint16_t*>(p->table.get());
+    out->ex_cells = kExCells; out->global_engine = -1;
+    if (const Exceptions* e = p->ex.load(std::memory_order_acquire)) { out->ex_n = e->n; out->ex_hash = e->h; out->ex_shard = e->s; }
+    return GUBER_OK;
+}
+
 extern "C" int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_t* n_slots, uint32_t* n_hot) {
     if (!p) return GUBER_E_INVALID_ARG;
     if (n_shards) *n_shards = p->n_shards;

@@ -93,6 +93,9 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     if (routed_ && batch_limit_ > 65536) { routed_ = false; stage_cap_ = batch_limit_; }     // (a share may be the whole stage: the two-launch pipeline takes 65 536)
     // a second generation behind the one in flight: per-shard stages pay a set of launches per group of four shards, so it waits
     // until it is worth them; a front stage pays ONE launch for a handful of requests (k_small_routed) and four beyond
+    // the device also ROUTES (XXH64 of the HashKey, slot table, hot-key list, rank in the shard's share: guber_stage_route): a caller's
+    // per-request work is writing the request.  GUBER_POOL_DEVROUTE=0: the callers hash, look up, sort and rank (what this replaced).
+    dev_route_ = routed_ && env_u32("GUBER_POOL_DEVROUTE", 1) != 0;
     if (!getenv("GUBER_POOL_EAGER_MIN")) eager_min_ = routed_ ? 16 : 4096;
     guber_config_t c = cfg;
     if (c.max_batch < stage_cap_) c.max_batch = stage_cap_;
@@ -324,6 +327,7 @@ struct GPUWorkerPool::Call {
         uint8_t* const kb = S.keys.data();
         uint32_t o = 0, nt = 0;
         const bool multi = P.n_devices_ > 1;
+        const bool need_route = !P.dev_route_ || n <= P.direct_max_;   // (a handful of requests may be evaluated by their caller: it must know their shard)
         ReqRef r;
         for (uint32_t i = 0; i < n; ++i) {
             src.key(i, r);
@@ -341,12 +345,13 @@ struct GPUWorkerPool::Call {
                 sink.item_error(i, GUBER_ITEM_E_KEY_TOO_LONG, src.algorithm(i));
                 continue;
             }
-            const uint64_t h = guber::xxhash64(k, len, 0);
-            S.hash[i] = h;
             S.todo[nt++] = i;
             Device& d = *P.devs_[dv];
-            if (d.place && (++S.observe_tick & 63u) == 0 && P.rebalance_ms_ && !(P.has_global_ && (src.behavior(i) & 2u)))
-                guber_placement_observe(d.place, h, 64);             // every 64th request feeds the placement's view of the traffic
+            const bool sample = d.place && (++S.observe_tick & 63u) == 0 && P.rebalance_ms_ && !(P.has_global_ && (src.behavior(i) & 2u));
+            if (!need_route && !sample) continue;                    // (the device routes: no hash on the host)
+            const uint64_t h = guber::xxhash64(k, len, 0);
+            S.hash[i] = h;
+            if (sample) guber_placement_observe(d.place, h, 64);     // every 64th request feeds the placement's view of the traffic
         }
         S.koff[n] = o;
         S.todo.resize(nt);
@@ -362,7 +367,7 @@ struct GPUWorkerPool::Call {
                 const uint32_t dv = S.dev[i];
                 Device& d = *P.devs_[dv];
                 if (S.vers[dv] == 0xffffffffu) S.vers[dv] = d.ver.load(std::memory_order_acquire) & 0x7fu;
-                const uint32_t e = P.route(d, S.hash[i], src.behavior(i));
+                const uint32_t e = need_route ? P.route(d, S.hash[i], src.behavior(i)) : 0;
                 const uint32_t j = P.routed_ ? dv : dv * P.shards_per_device_ + e;
                 S.shard[i] = j; S.eng[i] = (uint8_t)e;
                 S.count[j + 1]++;
@@ -381,7 +386,7 @@ struct GPUWorkerPool::Call {
             // a handful of requests and nobody else at their shard: the caller evaluates them itself, now (the reference's worker
             // takes a request the moment it arrives) — one launch, no hand-off to the dispatcher and back
             // — when the pool is lightly loaded: with many callers at once, requests that share a launch serve more of them per microsecond
-            const bool direct_ok = base == 0 && P.eager_ && S.todo.size() <= P.direct_max_ && !P.has_store_.load(std::memory_order_relaxed) &&
+            const bool direct_ok = base == 0 && need_route && P.eager_ && S.todo.size() <= P.direct_max_ && !P.has_store_.load(std::memory_order_relaxed) &&
                                    P.in_calls_.load(std::memory_order_relaxed) <= P.direct_callers_;
             bool closed = false;
             for (uint32_t j = 0; j < n_shards; ++j) {
@@ -432,7 +437,7 @@ struct GPUWorkerPool::Call {
         if (P.staging_.size() != 1 || n <= P.direct_max_) return false;
         Shard& sh = *P.staging_[0];
         Device& d = *sh.dev;
-        if (d.place || sh.front) return false;
+        if ((d.place || sh.front) && !P.dev_route_) return false;    // (several shards: only when the device routes)
         if ((uint64_t)P.in_calls_.load(std::memory_order_relaxed) * n > 2ull * P.stage_cap_) return false;
         ReqRef r;
         uint32_t nt = 0;
@@ -477,12 +482,15 @@ struct GPUWorkerPool::Call {
         const uint32_t* list = S.order.data() + t.list_begin;
         if (S.col.size() < (size_t)5 * n) S.col.resize((size_t)5 * n);
         int64_t *c_hits = S.col.data(), *c_limit = c_hits + n, *c_dur = c_limit + n, *c_burst = c_dur + n, *c_created = c_burst + n;
+        guber_placement_t* const place = P.rebalance_ms_ ? s.shard->dev->place : nullptr;
         ReqRef r;
         for (uint32_t q = 0; q < n; ++q) {
             src.get(list[q], r);
             uint8_t* k = kp + o;                                     // HashKey = name + "_" + unique_key (client.go:39-41), exactly its bytes
             memcpy(k, r.name, r.name_len); k[r.name_len] = '_'; memcpy(k + r.name_len + 1, r.ukey, r.ukey_len);
             off[q] = o; o += r.name_len + 1 + r.ukey_len;
+            if (place && (++S.observe_tick & 63u) == 0 && !(P.has_global_ && (r.behavior & 2u)))
+                guber_placement_observe(place, guber::xxhash64(k, r.name_len + 1 + r.ukey_len, 0), 64);   // every 64th request feeds the placement's view of the traffic
             c_hits[q] = r.hits; c_limit[q] = r.limit; c_dur[q] = r.duration; c_burst[q] = r.burst;
             if (r.created_at) c_created[q] = r.created_at;
             else { if (!now) now = P.NowMs(); c_created[q] = now; }
@@ -645,7 +653,7 @@ struct GPUWorkerPool::Call {
             beh[q] = r.behavior; owner[q] = r.is_owner ? 1 : 0;
             nlen[q] = (uint16_t)std::min<uint32_t>(S.klen[ri] - 1 - r.ukey_len, 0xffff);
         }
-        if (s.dest) {                                                // a front stage: every request's shard and its place in the shard's share
+        if (s.dest && !P.dev_route_) {                               // a front stage whose callers route: every request's shard and its place in the shard's share
             uint32_t cnt[kMaxEngines] = {0}, at[kMaxEngines];
             for (uint32_t q = 0; q < n; ++q) cnt[S.eng[list[q]] & (kMaxEngines - 1)]++;
             for (uint32_t e = 0; e < kMaxEngines; ++e) at[e] = cnt[e] ? s.eng_n[e].fetch_add(cnt[e], std::memory_order_relaxed) : 0;
@@ -922,16 +930,30 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
     }
     const uint32_t gen = d.gen_seq++ & 7u;
     if (routed_) {                                                   // the device's front stage: the GPU hands the requests to the shards
-        guber_engine_t* eng[kMaxEngines]; uint32_t counts[kMaxEngines];
         const uint32_t ne = (uint32_t)d.shards.size();
-        for (uint32_t j = 0; j < ne; ++j) eng[j] = d.shards[j]->engine;
         for (Stage* s : due) {
-            for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_acquire);
+            int rc;
             const int64_t ts = mono_us();
-            const int rc = guber_stage_submit_routed(s->stage, eng, ne, counts);
+            if (dev_route_) {
+                // ... after deciding which shard each belongs to: two small launches now, guber_stage_submit_routed as soon as the
+                // shares' sizes are back (poll) — the rule travels with the first stage after a placement change
+                static const uint16_t one_shard[1] = {0};
+                guber_route_rule_t rule{};
+                if (d.rule_dirty) {
+                    if (d.place) (void)guber_placement_export(d.place, &rule);
+                    else { rule.n_shards = 1; rule.per = 1; rule.step = 1ull << 63; rule.table = one_shard; }
+                    rule.global_engine = has_global_ ? (int32_t)d.n_plain : -1;
+                }
+                rc = guber_stage_route(s->stage, d.rule_dirty ? &rule : nullptr, ne);
+                if (rc == GUBER_OK) { d.rule_dirty = false; s->routing = true; }
+            } else {
+                uint32_t counts[kMaxEngines];
+                for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_acquire);
+                rc = submit_routed_now(d, *s, counts) ? GUBER_OK : s->rc;
+            }
             d.submit_us.fetch_add((uint64_t)(mono_us() - ts), std::memory_order_relaxed); d.submits.fetch_add(1, std::memory_order_relaxed);
             if (rc == GUBER_OK) {
-                s->submitted = true; s->state = Stage::kInFlight; s->shard->stages_in_flight++; s->t_submitted_us = mono_us(); inflight.push_back(s);
+                s->state = Stage::kInFlight; s->shard->stages_in_flight++; s->t_submitted_us = mono_us(); inflight.push_back(s);
                 s->dev_gen = gen;
                 if (d.gen_left[gen]++ == 0) d.gens_in_flight++;
             } else { s->rc = rc; announce(*s->shard, *s); }
@@ -960,18 +982,44 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
     due.clear();
 }
 
+// the shares of a front stage go to the engines (their sizes known: from the callers' ranks, or from guber_stage_route)
+bool GPUWorkerPool::submit_routed_now(Device& d, Stage& s, const uint32_t* counts) {
+    guber_engine_t* eng[kMaxEngines];
+    const uint32_t ne = (uint32_t)d.shards.size();
+    for (uint32_t j = 0; j < ne; ++j) eng[j] = d.shards[j]->engine;
+    const int rc = guber_stage_submit_routed(s.stage, eng, ne, counts);
+    s.submitted = rc == GUBER_OK;
+    if (rc != GUBER_OK) s.rc = rc;
+    return rc == GUBER_OK;
+}
+// a stage leaves the device: bookkeeping + announcement
+void GPUWorkerPool::finish(Stage& s) {
+    s.submitted = false; s.routing = false; s.shard->stages_in_flight--;
+    { Device& d = *s.shard->dev; if (--d.gen_left[s.dev_gen] == 0) d.gens_in_flight--; }
+    { const int64_t t = mono_us(); d_dbg_[0] += (uint64_t)(s.t_written_us - s.t0_us); d_dbg_[1] += (uint64_t)(s.t_submitted_us - s.t_written_us); d_dbg_[2] += (uint64_t)(t - s.t_submitted_us); d_dbg_[3]++; }
+    announce(*s.shard, s);
+}
 // look at the stages in flight; announce the ones whose responses are there.  Returns whether any finished.
 bool GPUWorkerPool::poll(std::vector<Stage*>& inflight) {
     bool any = false;
     for (size_t q = 0; q < inflight.size();) {
         Stage* s = inflight[q];
+        if (s->routing) {                                            // the device is deciding the shards: sizes back -> the batch itself goes
+            uint32_t counts[kMaxEngines] = {0};
+            const int r = guber_stage_route_poll(s->stage, counts);
+            if (r == 0) { ++q; continue; }
+            s->routing = false;
+            any = true;
+            if (r > 0 && submit_routed_now(*s->shard->dev, *s, counts)) { ++q; continue; }
+            if (r < 0) s->rc = r;
+            finish(*s);
+            inflight[q] = inflight.back(); inflight.pop_back();
+            continue;
+        }
         const int r = guber_stage_poll(s->stage);
         if (r == 0) { ++q; continue; }
         s->rc = r < 0 ? r : guber_stage_wait(s->stage);              // (already complete: resolves the rare internal retry)
-        s->submitted = false; s->shard->stages_in_flight--;
-        { Device& d = *s->shard->dev; if (--d.gen_left[s->dev_gen] == 0) d.gens_in_flight--; }
-        { const int64_t t = mono_us(); d_dbg_[0] += (uint64_t)(s->t_written_us - s->t0_us); d_dbg_[1] += (uint64_t)(s->t_submitted_us - s->t_written_us); d_dbg_[2] += (uint64_t)(t - s->t_submitted_us); d_dbg_[3]++; }
-        announce(*s->shard, *s);
+        finish(*s);
         inflight[q] = inflight.back(); inflight.pop_back();
         any = true;
     }
@@ -1028,6 +1076,7 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
             else d.moves += moved;
         }
         (void)guber_placement_commit(d.place);
+        d.rule_dirty = true;
         d.ver.fetch_add(1, std::memory_order_acq_rel);
     }
     const uint32_t ver = d.ver.load();
@@ -1118,6 +1167,7 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
     Device& d = *sh.dev;
     const guber_batch_t& B = *s.b;
     int rc = GUBER_OK;
+    if (dev_route_) route_on_host(d, s);                             // (this path is synchronous and on the host anyway)
     for (uint32_t e = 0; e < d.shards.size() && rc == GUBER_OK; ++e) {
         const uint32_t ne = s.eng_n[e].load(std::memory_order_acquire);
         if (!ne) continue;
@@ -1145,6 +1195,18 @@ void GPUWorkerPool::submit_with_store(Shard& sh, Stage& s) {
         }
     }
     s.rc = rc;
+}
+
+// what guber_stage_route computes, on the host: every request's shard and its rank in the shard's share, in arrival order
+void GPUWorkerPool::route_on_host(Device& d, Stage& s) {
+    const guber_batch_t& B = *s.b;
+    uint32_t cnt[kMaxEngines] = {0};
+    for (uint32_t i = 0; i < s.n; ++i) {
+        const uint32_t off = B.key_off[i], len = (i + 1 < s.n ? B.key_off[i + 1] : B.key_off[s.n]) - off;
+        const uint32_t e = route(d, guber::xxhash64(B.key_bytes + off, len, 0), B.behavior[i]) & (kMaxEngines - 1);
+        s.dest[i] = e << 24 | cnt[e]++;
+    }
+    for (uint32_t e = 0; e < kMaxEngines; ++e) s.eng_n[e].store(cnt[e], std::memory_order_relaxed);
 }
 
 int GPUWorkerPool::store_eval(guber_engine_t* engine_, const guber_batch_t& B, guber_result_t& R, const uint16_t* name_len) {

@@ -154,6 +154,7 @@ class GPUWorkerPool {
         uint32_t dev_gen = 0;                             // the device generation (one submission) it travelled in
         enum State : uint8_t { kFree, kOpen, kSealed, kInFlight, kDraining } state = kFree;   // dispatcher only
         bool submitted = false;                           // guber_stages_submit succeeded, guber_stage_wait is due
+        bool routing = false;                             // guber_stage_route enqueued, the shares' sizes not yet back (then guber_stage_submit_routed)
     };
     struct Device;
     struct Shard {              // one "worker" of the reference: its own cache (engine)
@@ -186,6 +187,7 @@ class GPUWorkerPool {
         std::atomic<bool> sleeping{false}, closing{false}, rebalance_now{false};
         std::atomic<uint64_t> rebalances{0}, moves{0}, submit_us{0}, submits{0};
         uint32_t gen_seq = 0, gen_left[8] = {0}, gens_in_flight = 0;   // dispatcher: submissions whose batches are not all back
+        bool rule_dirty = true;                           // dispatcher: the device has not seen the current placement yet (guber_stage_route)
     };
     struct Ticket2 { Stage* st; uint64_t gen; uint32_t first_slot, count, list_begin, key_base; bool consumed; };
     struct Scratch;                                       // per-thread buffers of a call
@@ -197,6 +199,9 @@ class GPUWorkerPool {
     void seal(Shard& sh, Stage& s, std::vector<Stage*>& due);
     void seal_if_due(Shard& sh, int64_t now, bool force, bool eager_ok, std::vector<Stage*>& due, int64_t* deadline);
     void submit_with_store(Shard& sh, Stage& s);
+    void route_on_host(Device& d, Stage& s);
+    bool submit_routed_now(Device& d, Stage& s, const uint32_t* counts);
+    void finish(Stage& s);
     int store_eval(guber_engine_t* engine, const guber_batch_t& B, guber_result_t& R, const uint16_t* name_len);
     void announce(Shard& sh, Stage& s);
     bool poll(std::vector<Stage*>& inflight);
@@ -216,6 +221,7 @@ class GPUWorkerPool {
     uint32_t n_devices_ = 1, shards_per_device_ = 1, plain_per_device_ = 1;
     bool has_global_ = false;
     bool routed_ = false;                                 // one front stage per device, the GPU hands the requests to the shards
+    bool dev_route_ = false;                              // ... and decides which shard a request belongs to (guber_stage_route): callers neither hash nor sort
     uint32_t stage_cap_ = 0;                              // requests a stage takes (routed: up to batch_limit per shard, at most 65536)
     std::vector<Shard*> staging_;                         // every device's staging shards, index = what a caller's routing round counts by
     int create_rc_ = 0;

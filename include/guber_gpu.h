@@ -246,6 +246,26 @@ int guber_stage_poll(guber_stage_t* s);
  * present (none switched off). */
 uint32_t* guber_stage_dest(guber_stage_t* s);
 int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts);
+/* The routing itself done by the device: WorkerPool.getWorker (workers.go:153-155 ComputeHash63, :180-184) for every request of a
+ * front stage at once, so that a caller's per-request work is writing the request and nothing else (no hash, no table lookup,
+ * no sort by shard, no rank).  The callers fill the stage in arrival order and leave guber_stage_dest alone;
+ *   guber_stage_route       enqueues two launches on the stage's engine: XXH64 of every HashKey + the rule -> engine, the shares'
+ *                           sizes, and dest[i] = engine << 24 | rank in arrival order.  `rule` = the placement as exported by
+ *                           guber_placement_export (copied to the device: waits for the stream, so hand it over only when the
+ *                           placement changed; NULL = the rule given last); global_engine >= 0: requests with
+ *                           GUBER_BEHAVIOR_GLOBAL go to that engine index.  At most 65 536 requests.
+ *   guber_stage_route_poll  1 = counts[0 .. n_engines) hold the shares' sizes, 0 = still running.  guber_stage_submit_routed may
+ *                           follow at once (stream order makes dest complete before it is read). */
+typedef struct guber_route_rule {
+    uint32_t n_shards, per;                       /* hash slots = n_shards x per; slot -> shard through table[] */
+    uint64_t step, inv_step, inv_sub;             /* 2^63 / n_shards (workers.go:132 hashRingStep) and the reciprocals slot_of multiplies by */
+    const uint16_t* table;
+    uint32_t ex_cells, ex_n;                      /* individually placed keys: open addressing on the key hash (0 = empty cell) */
+    const uint64_t* ex_hash; const uint16_t* ex_shard;
+    int32_t global_engine;                        /* -1 = none */
+} guber_route_rule_t;
+int guber_stage_route(guber_stage_t* s, const guber_route_rule_t* rule, uint32_t n_engines);
+int guber_stage_route_poll(guber_stage_t* s, uint32_t* counts);
 
 /* A queue of device-resident batches enqueued back to back on the engine stream in one call (what a batcher goroutine
  * that has several full batches waiting does, peer_client.go:284-337): batches[i] -> results[i], i = 0..count-1, in
@@ -520,6 +540,9 @@ int guber_placement_plan(guber_placement_t* p, double heavy_fraction, guber_plac
 int guber_placement_commit(guber_placement_t* p);
 /* between plan and commit: drop one planned move (its bucket could not be migrated): the key keeps following its slot */
 int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash);
+/* the published placement in the form guber_stage_route takes (global_engine = -1; the pointers stay valid until the placement is
+ * destroyed: a commit publishes new snapshots and retires, never frees, the old ones — export again after every commit) */
+int guber_placement_export(const guber_placement_t* p, struct guber_route_rule* out);
 /* The buckets of the keys with these XXH64 hashes leave `from`'s table and enter `to`'s (two logical shards of ONE GPU), on
  * the device.  The caller guarantees that neither engine has a batch with those keys being formed or in flight.  *moved
  * (optional) = buckets that were live and moved. */

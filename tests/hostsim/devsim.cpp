@@ -190,4 +190,26 @@ void ds_counters(void* h, long long* out) {
     for (auto& bc : d->bctr) { o += (long long)bc.over; hi += (long long)bc.hits; mi += (long long)bc.misses; sz += bc.size_delta; }
     out[0] = o; out[1] = hi; out[2] = mi; out[3] = sz; out[4] = (long long)d->ctr.retries; out[5] = (long long)d->ctr.tags_used;
 }
+// guber_stage_route's two launches (k_route_count + k_route_dest) on host memory: dest[n], counts[16]
+int ds_route(const uint8_t* key_bytes, const uint32_t* key_off, const uint32_t* behavior, uint32_t n, uint32_t n_engines, uint32_t max_key,
+             uint32_t n_shards, uint32_t per, unsigned long long step, unsigned long long inv_step, unsigned long long inv_sub, const uint16_t* table,
+             uint32_t ex_cells, uint32_t ex_n, const unsigned long long* ex_hash, const uint16_t* ex_shard, int global_engine,
+             uint32_t* dest, uint32_t* counts) {
+    if (n == 0 || n > 65536) return -1;
+    const uint32_t tiles = (n + 255u) / 256u;
+    std::vector<uint32_t> tile_cnt((size_t)256 * MULTI_MEM_MAX, 0xdeadbeefu), tile_base((size_t)256 * MULTI_MEM_MAX, 0xdeadbeefu);
+    std::vector<uint8_t> eng(n + 64, 0xee);
+    uint32_t ticket = 0; unsigned int done = 0; uint32_t cnt_out[MULTI_MEM_MAX];
+    RouteArgs A{};
+    A.n = n; A.n_engines = n_engines; A.max_key = max_key; A.seq = 7;
+    A.key_bytes = key_bytes; A.key_off = key_off; A.behavior = behavior;
+    A.eng = eng.data(); A.tile_cnt = tile_cnt.data(); A.tile_base = tile_base.data(); A.ticket = &ticket;
+    A.dest = dest; A.counts = cnt_out; A.done = &done;
+    A.R = RouteRule{n_shards, per, ex_cells, ex_n, global_engine, step, inv_step, inv_sub, table, ex_hash, ex_shard};
+    fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_route_count(A); });
+    if (done != 7 || ticket != 0) return -2;
+    fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_route_dest(A); });
+    for (int e = 0; e < MULTI_MEM_MAX; ++e) counts[e] = cnt_out[e];
+    return 0;
+}
 }

@@ -14,12 +14,14 @@
 #include "../../include/guber_gpu.h"
 #include "../../oracle/guber_oracle.h"
 
-struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; };
+struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; guber_route_rule_t rule{}; bool have_rule = false; };
 struct guber_stage {
     guber_engine* e; uint32_t max_n, key_cap;
     std::vector<uint32_t> off, beh; std::vector<int64_t> hits, limit, duration, burst, created, rl, rr, rs;
     std::vector<uint8_t> algo, owner, status, err, keys;
     std::vector<uint32_t> dest;
+    uint32_t route_counts[16] = {0}, route_engines = 0;
+    std::chrono::steady_clock::time_point route_ready{};
     guber_batch_t b{}; guber_result_t r{};
     bool in_flight = false;
     std::chrono::steady_clock::time_point ready_at{};                // guber_stages_submit: when the "GPU" is done with it
@@ -87,6 +89,56 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
 // one stage for several engines: every engine's share is gathered in rank order, evaluated by that engine's oracle, and the
 // answers go back to the slots the requests were written at; the ranks must be a permutation of each share (checked)
 extern "C" uint32_t* guber_stage_dest(guber_stage_t* s) { return s->dest.data(); }
+// guber_stage_route on the host: the same arithmetic as guber_placement_shard over the exported rule (what k_route_count applies)
+static uint32_t stub_route(const guber_route_rule_t& R, uint64_t h) {
+    if (R.ex_n) {
+        for (uint32_t i = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 56) & (R.ex_cells - 1);; i = (i + 1) & (R.ex_cells - 1)) {
+            if (R.ex_hash[i] == h) return R.ex_shard[i];
+            if (R.ex_hash[i] == 0) break;
+        }
+    }
+    const uint64_t h63 = h >> 1;
+    uint64_t w = (uint64_t)(((unsigned __int128)h63 * R.inv_step) >> 64);
+    if ((w + 1) * R.step <= h63) ++w;
+    if (w >= R.n_shards) w = R.n_shards - 1;
+    uint64_t sub = (uint64_t)(((unsigned __int128)(h63 - w * R.step) * R.inv_sub) >> 64);
+    if (sub >= R.per) sub = R.per - 1;
+    return R.table[(uint32_t)(w * R.per + sub)];
+}
+extern "C" int guber_stage_route(guber_stage_t* s, const guber_route_rule_t* rule, uint32_t n_engines) {
+    static const long null_lat = getenv("GUBER_STUB_ROUTE_LAT_US") ? atol(getenv("GUBER_STUB_ROUTE_LAT_US")) : 0;
+    if (!s || s->in_flight || n_engines == 0 || n_engines > 16) return GUBER_E_INVALID_ARG;
+    if (rule) { s->e->rule = *rule; s->e->have_rule = true; }
+    if (!s->e->have_rule) return GUBER_E_INVALID_ARG;
+    const guber_route_rule_t& R = s->e->rule;
+    const uint32_t n = s->b.n;
+    if (n > s->max_n || n > 65536) return GUBER_E_BATCH_TOO_LARGE;
+    memset(s->route_counts, 0, sizeof s->route_counts);
+    static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;   // the pool measured alone: the "device" routes at no host cost
+    if (null_engine) {
+        for (uint32_t i = 0; i < n; ++i) { const uint32_t e = i % n_engines; s->dest[i] = e << 24 | s->route_counts[e]++; }
+        s->route_engines = n_engines;
+        s->route_ready = std::chrono::steady_clock::now() + std::chrono::microseconds(null_lat);
+        return GUBER_OK;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t off = s->b.key_off[i], len = s->b.key_off[i + 1] - off;
+        uint32_t e = 0;
+        if (R.global_engine >= 0 && (s->b.behavior[i] & 2u)) e = (uint32_t)R.global_engine;
+        else if (len && R.n_shards > 1) e = stub_route(R, guber_xxhash64(s->b.key_bytes + off, len, 0));
+        if (e >= n_engines) e = 0;
+        s->dest[i] = e << 24 | s->route_counts[e]++;
+    }
+    s->route_engines = n_engines;
+    s->route_ready = std::chrono::steady_clock::now() + std::chrono::microseconds(null_lat);
+    return GUBER_OK;
+}
+extern "C" int guber_stage_route_poll(guber_stage_t* s, uint32_t* counts) {
+    if (!s || !counts) return GUBER_E_INVALID_ARG;
+    if (std::chrono::steady_clock::now() < s->route_ready) return 0;
+    for (uint32_t j = 0; j < s->route_engines; ++j) counts[j] = s->route_counts[j];
+    return 1;
+}
 extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* counts) {
     static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;
     static const long null_lat = getenv("GUBER_STUB_LAT_US") ? atol(getenv("GUBER_STUB_LAT_US")) : 0;

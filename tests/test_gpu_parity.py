@@ -1087,6 +1087,119 @@ def test_one_stage_routed_to_nine_engines():
         e.close()
 
 
+def test_a_routed_stage_with_faulty_ranks_is_refused_not_run():
+    """guber_stage_dest is written by the caller.  A share of a <= 256-request routed stage whose ranks are not a permutation of
+    0..count-1 (a rank twice, a rank past the share) is not evaluated — the wait reports GUBER_E_INVALID_ARG, nothing outside the
+    stage is touched, the engines keep working and a later well-formed stage on the same engines agrees with the oracle."""
+    first = engine(cache_size=1 << 12, max_batch=4096)
+    engines = [first] + [engine(cache_size=1 << 12, max_batch=4096, stream=first.stream_handle()) for _ in range(2)]
+    oracles = [Oracle(cache_size=1 << 13) for _ in engines]
+    st = ga.Stage(first, 4096, key_bytes_cap=4096 * 24)
+    now = streams.NOW0
+    keys = [f"rt_{i % 37}" for i in range(120)]
+    shard = (np.arange(120) % 37 % 3).astype(np.uint32)
+
+    def twice(dest):                                    # two requests of engine 1 claim the same rank
+        mine = np.nonzero((dest >> 24) == 1)[0]
+        dest[mine[3]] = dest[mine[2]]
+
+    def past(dest):                                     # a rank past the end of engine 2's share
+        mine = np.nonzero((dest >> 24) == 2)[0]
+        dest[mine[0]] = (2 << 24) | 200
+
+    for fault in (twice, past):
+        hb = HostBatch(keys, 1, 50, 60_000, now, created_at=now)
+        st.fill(hb)
+        st.submit_routed(engines, shard, corrupt_dest=fault)
+        with pytest.raises(ga.GuberError) as ei:
+            st.wait()
+        assert ei.value.code == ga.E_INVALID_ARG, ei.value
+    # the shares of the well-formed engines of those two stages did run (2 hits each on engine 0); a clean stage sees exactly that
+    for rnd in range(3):
+        hb = HostBatch(keys, 1, 50, 60_000, now + 1 + rnd, created_at=now + 1 + rnd)
+        st.fill(hb)
+        st.submit_routed(engines, shard)
+        st.wait()
+        got = st.result()
+        idx = np.nonzero(shard == 0)[0]
+        sub = HostBatch([keys[i] for i in idx], 1, 50, 60_000, now + 1 + rnd, created_at=now + 1 + rnd)
+        if rnd == 0:
+            for t in (now, now):
+                oracles[0].eval(HostBatch([keys[i] for i in idx], 1, 50, 60_000, t, created_at=t))
+        want = oracles[0].eval(sub)
+        for f in ("status", "err", "limit", "remaining", "reset_time"):
+            assert np.array_equal(getattr(got, f)[idx], getattr(want, f)[:len(idx)]), (rnd, f)
+    st.close()
+    for e in reversed(engines):
+        e.close()
+
+
+def _host_routing(pl, key_bytes, key_off, behavior, n_engines, global_engine):
+    """what the pool's callers computed before the device did: shard by the placement (or the GLOBAL engine), rank = arrival order"""
+    shard, _ = pl.route_keys(key_bytes, key_off)
+    shard = shard.astype(np.uint32).copy()
+    if global_engine >= 0:
+        shard[(behavior & 2) != 0] = global_engine
+    counts = np.bincount(shard, minlength=n_engines).astype(np.uint32)
+    order = np.argsort(shard, kind="stable")
+    start = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64)
+    rank = np.empty(len(shard), np.uint32)
+    rank[order] = (np.arange(len(shard), dtype=np.int64) - start[shard[order]]).astype(np.uint32)
+    return (shard << 24) | rank, counts
+
+
+def test_the_device_routes_a_front_stage_like_the_placement():
+    """guber_stage_route (k_route_count + k_route_dest): WorkerPool.getWorker (workers.go:153-155, 180-184) generalised by the placement's
+    slot table and hot-key list, for a whole stage on the device.  dest and the shares' sizes equal what the host computes with
+    guber_placement_route_keys + arrival-order ranks: before any traffic was observed (the reference's contiguous ranges), after
+    a rebalance that placed slots afresh and pinned hot keys, with GLOBAL requests going to the GLOBAL engine; sizes 1 .. 65 536,
+    variable-length keys; and the stage then runs through guber_stage_submit_routed and agrees with the oracles."""
+    rng = np.random.default_rng(77)
+    n_plain, glob = 7, 7
+    first = engine(cache_size=1 << 16, max_batch=65536)
+    engines = [first] + [engine(cache_size=1 << 16, max_batch=65536, stream=first.stream_handle()) for _ in range(n_plain)]
+    oracles = [Oracle(cache_size=1 << 17) for _ in engines]
+    st = ga.Stage(first, 65536, key_bytes_cap=65536 * 40)
+    pl = ga.Placement(n_plain)
+    now = streams.NOW0
+    rule = pl.export(global_engine=glob)
+    for rnd, n in enumerate([1, 255, 256, 257, 4000, 65536, 20_000, 3, 30_000]):
+        if rnd == 4:                                                 # traffic observed -> slots placed afresh, hot keys pinned
+            ids = rng.zipf(1.1, 200_000) % 50_000
+            seen = HostBatch([f"acct_{int(i)}" + "y" * int(i % 19) for i in ids], 1, 1, 1, now)
+            pl.observe_keys(seen.key_bytes, seen.key_off)
+            pl.rebalance(0.05, move_slots=True)
+            assert pl.n_hot() > 0
+            rule = pl.export(global_engine=glob)
+        t = now + rnd * 500
+        ids = rng.zipf(1.1, n) % 50_000
+        keys = [f"acct_{int(i)}" + "y" * int(i % 19) for i in ids]
+        beh = np.where(rng.random(n) < 0.1, 2, 0).astype(np.uint32) | np.where(rng.random(n) < 0.2, 1, 0).astype(np.uint32)
+        hb = HostBatch(keys, rng.integers(0, 3, n), 40, 5_000, t, algorithm=(ids % 2).astype(np.uint8), created_at=t, behavior=beh, burst=np.where(ids % 2 == 1, 50, 0))
+        st.fill(hb)
+        dest, counts = st.route(rule if rnd in (0, 4) else None, len(engines))
+        want_dest, want_counts = _host_routing(pl, hb.key_bytes, hb.key_off, beh, len(engines), glob)
+        assert np.array_equal(counts, want_counts), (rnd, counts, want_counts)
+        bad = np.nonzero(dest != want_dest)[0]
+        assert len(bad) == 0, (rnd, n, bad[:5], dest[bad[:5]], want_dest[bad[:5]])
+        st.submit_routed_as_routed(engines, counts)
+        st.wait()
+        got = st.result()
+        shard = dest >> 24
+        for j in range(len(engines)):
+            idx = np.nonzero(shard == j)[0]
+            if not len(idx):
+                continue
+            sub = HostBatch([keys[i] for i in idx], hb.hits[idx], 40, 5_000, t, algorithm=hb.algorithm[idx], created_at=t, behavior=beh[idx], burst=hb.burst[idx])
+            want = oracles[j].eval(sub)
+            for f in ("status", "err", "limit", "remaining", "reset_time"):
+                assert np.array_equal(getattr(got, f)[idx], getattr(want, f)[:len(idx)]), (rnd, j, f)
+    st.close()
+    pl.close()
+    for e in reversed(engines):
+        e.close()
+
+
 def test_buckets_move_between_tables_by_key_hash():
     """guber_move_items_by_hash (a hot key changes its logical shard): token and leaky items, an inline key and a 200-byte key
     (arena), an expired item and a hash that names nothing — the items arrive unchanged, leave nothing behind, and both

@@ -164,3 +164,41 @@ def test_scheduling_order_does_not_matter(lib):
         sim.close()
     finally:
         lib.ds_chaos(0)
+
+
+def test_the_routing_kernels_agree_with_the_placement(lib):
+    """guber_kernels_route.h (k_route_count + k_route_dest: what guber_stage_route launches) compiled for the host: every request's
+    shard = guber_placement_route_keys (workers.go:153-155, 180-184 generalised: slot table + hot-key list), GLOBAL requests go to
+    the GLOBAL engine, ranks follow the arrival order, the shares' sizes add up — before and after a rebalance that pins hot
+    keys; also with the workgroups in a shuffled order (the tile scan runs in whichever workgroup finishes last)."""
+    import gubernator_amd as ga
+    lib.ds_route.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
+                             C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    n_plain, glob = 5, 5
+    pl = ga.Placement(n_plain)
+    for rnd, n in enumerate([1, 255, 256, 257, 3000, 9000, 700]):
+        if rnd == 4:
+            ids = rng.zipf(1.1, 100_000) % 20_000
+            seen = HostBatch([f"k_{int(i)}" + "z" * int(i % 13) for i in ids], 1, 1, 1, 0)
+            pl.observe_keys(seen.key_bytes, seen.key_off)
+            pl.rebalance(0.05, move_slots=True)
+            assert pl.n_hot() > 0
+        lib.ds_chaos(rnd if rnd % 2 else 0)
+        rule = pl.export(global_engine=glob)
+        ids = rng.zipf(1.1, n) % 20_000
+        hb = HostBatch([f"k_{int(i)}" + "z" * int(i % 13) for i in ids], 1, 1, 1, 0, behavior=np.where(rng.random(n) < 0.15, 2, 0))
+        dest, counts = np.zeros(n, np.uint32), np.zeros(16, np.uint32)
+        rc = lib.ds_route(hb.key_bytes.ctypes.data, hb.key_off.ctypes.data, hb.behavior.ctypes.data, n, n_plain + 1, 1024, rule.n_shards, rule.per, rule.step,
+                          rule.inv_step, rule.inv_sub, rule.table, rule.ex_cells, rule.ex_n, rule.ex_hash, rule.ex_shard, glob, dest.ctypes.data, counts.ctypes.data)
+        assert rc == 0, rc
+        shard, _ = pl.route_keys(hb.key_bytes, hb.key_off)
+        shard = shard.astype(np.uint32).copy()
+        shard[(hb.behavior & 2) != 0] = glob
+        want_counts = np.bincount(shard, minlength=16).astype(np.uint32)
+        assert np.array_equal(counts, want_counts), (rnd, counts, want_counts)
+        assert np.array_equal(dest >> 24, shard), rnd
+        for e in range(n_plain + 1):
+            assert np.array_equal(dest[shard == e] & 0xffffff, np.arange(want_counts[e], dtype=np.uint32)), (rnd, e)   # arrival order
+    lib.ds_chaos(0)
+    pl.close()
