@@ -271,7 +271,9 @@ class Rig:
         else:
             self.sown = np.zeros(nk, np.uint8)
         self.local_of_shard = [np.nonzero(self.sown == j)[0] for j in range(S)]
+        slots_log2 = int(os.environ.get("GUBER_BENCH_TABLE_SLOTS_LOG2", "0"))       # experiments: 0 = the engine's own rule (2 x (cache_size + max_batch), rounded up)
         self.engines = [ga.Engine(cache_size=len(self.local_of_shard[j]) + len(self.local_of_shard[j]) // 4 + 1024, device=ctx.local_rank, max_batch=B,
+                                  table_slots=(1 << slots_log2) if slots_log2 else 0,
                                   stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
         # arrays every batch of this rig shares (fixed-width keys, constant request fields)
         L = ctx.table.shape[1]

@@ -276,6 +276,9 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
 __global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
+#ifndef GUBER_OWN_DIR_EARLY
+#define GUBER_OWN_DIR_EARLY 0
+#endif
 #ifndef GUBER_OWN_EPT
 #define GUBER_OWN_EPT 3
 #endif
@@ -459,6 +462,11 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             const Bucket* hb = &T.buckets[kpos];
             const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
             trec = hb->rec;
+#if GUBER_OWN_DIR_EARLY
+            // ... and the two directory entries a displaced key needs next (usually one 64-byte line more): a key one step from home
+            // then costs two trips instead of three, at the price of a line that the keys at home (the majority) do not use
+            de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[(kpos + 1) & T.mask];
+#endif
         }
         GP_STAMP(1, 3);
         // ---- every message against its key's reference: exact key bytes, exact request shape; the key's totals ----
@@ -534,6 +542,9 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 const Bucket* hb = &T.buckets[kpos];
                 const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
                 trec = hb->rec;
+#if GUBER_OWN_DIR_EARLY
+                de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[(kpos + 1) & T.mask];
+#endif
             }
             const GMsg wm = kref[kid];
             const unsigned long long tag = wm.hash;
@@ -548,11 +559,13 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             const bool at_home = klen != 31u && (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 &&
                                  (tc3.w >> 16) == klen;
             if (at_home) { slot = home; cand = true; }
+#if !GUBER_OWN_DIR_EARLY
             else {
                 // not there: the directory entries of the home position and of the next one, and the next bucket, in one trip
                 const uint64_t npos = (kpos + 1) & T.mask;
                 de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[npos];
             }
+#endif
             for (uint32_t step = 0; !at_home && step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
                 ulonglong2 de = step == 0 ? de0 : de1;
                 if (step >= 1) {

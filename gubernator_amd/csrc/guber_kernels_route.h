@@ -10,7 +10,8 @@ namespace guber {
 // individually placed hot keys (placement.cpp).  With many callers that is the host's largest per-request cost (the hash, the
 // lookup, the counting sort by shard, the rank inside the shard's share), so the callers write their requests in arrival order
 // and nothing else, and two launches produce what guber_stage_submit_routed needs:
-//   k_route_count  per request: XXH64 of the key (read from the stage over PCIe), the rule -> engine; per tile of 256 requests the
+//   k_route_in     keys, key offsets and behaviors of the stage -> HBM (coalesced)
+//   k_route_count  per request: XXH64 of the key, the rule -> engine; per tile of 256 requests the
 //                  requests per engine; the LAST workgroup to finish scans the tiles (every engine's share in arrival order),
 //                  writes the shares' sizes to the host and releases the flag the host polls
 //   k_route_dest   dest[i] = engine << 24 | rank in the engine's share (stable: arrival order), straight into the stage
@@ -21,7 +22,7 @@ struct RouteRule {                       // guber_placement's state, as the devi
 };
 struct RouteArgs {
     uint32_t n, n_engines, max_key, seq;
-    const uint8_t* key_bytes; const uint32_t* key_off; const uint32_t* behavior;      // the stage (host memory)
+    const uint8_t* key_bytes; const uint32_t* key_off; const uint32_t* behavior;      // the stage's columns (their HBM copies)
     uint8_t* eng; uint32_t* tile_cnt; uint32_t* tile_base; uint32_t* ticket;          // HBM scratch: per request, [tiles][16] twice, the finish counter
     uint32_t* dest;                                                                  // the stage's dest column (host)
     uint32_t* counts; unsigned int* done;                                            // host: the shares' sizes, then the flag (= seq)
@@ -42,6 +43,15 @@ __device__ __forceinline__ uint32_t route_engine(const RouteRule& R, const unsig
     unsigned long long sub = __umul64hi(h63 - w * R.step, R.inv_sub);
     if (sub >= R.per) sub = R.per - 1;
     return R.table[(uint32_t)(w * R.per + sub)];
+}
+// the columns the routing reads, brought to HBM first as full coalesced lines (XXH64 straight out of host memory would be a few small
+// dependent PCIe reads per request: measured 4x the whole batch's time); the keys stay there for guber_stage_submit_routed
+struct RouteIn { const uint4* src[3]; uint4* dst[3]; uint32_t n16[3]; uint32_t nb[3]; };
+__global__ __launch_bounds__(256) void k_route_in(RouteIn A) {
+    uint32_t b = blockIdx.x, k = 0;
+    while (k < 2 && b >= A.nb[k]) { b -= A.nb[k]; ++k; }
+    const uint32_t stride = A.nb[k] * 256u;
+    for (uint32_t i = b * 256u + threadIdx.x; i < A.n16[k]; i += stride) A.dst[k][i] = A.src[k][i];
 }
 __global__ __launch_bounds__(256) void k_route_count(RouteArgs A) {
     __shared__ uint32_t cnt[MULTI_MEM_MAX];

@@ -93,9 +93,13 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     if (routed_ && batch_limit_ > 65536) { routed_ = false; stage_cap_ = batch_limit_; }     // (a share may be the whole stage: the two-launch pipeline takes 65 536)
     // a second generation behind the one in flight: per-shard stages pay a set of launches per group of four shards, so it waits
     // until it is worth them; a front stage pays ONE launch for a handful of requests (k_small_routed) and four beyond
-    // the device also ROUTES (XXH64 of the HashKey, slot table, hot-key list, rank in the shard's share: guber_stage_route): a caller's
-    // per-request work is writing the request.  GUBER_POOL_DEVROUTE=0: the callers hash, look up, sort and rank (what this replaced).
-    dev_route_ = routed_ && env_u32("GUBER_POOL_DEVROUTE", 1) != 0;
+    // GUBER_POOL_DEVROUTE=1: the device also ROUTES (XXH64 of the HashKey, slot table, hot-key list, rank in the shard's share:
+    // guber_stage_route) and a caller's per-request work is writing the request — 62 instead of 130 cycles per request.  Off by
+    // default: the shares' sizes have to come back to the host before the batch can be enqueued, and that round trip (two launches,
+    // a flag over PCIe, then the submission: +45 us on a 2 000-request batch, +70..90 us on a 20 000-request one on MI355X) costs a
+    // closed loop of callers more than their CPUs gain (64 x 1000-item RPCs, 8 shards: 218 instead of 236 M decisions/s).  It pays
+    // where the callers' CPUs are the scarce resource and latency is not.
+    dev_route_ = routed_ && env_u32("GUBER_POOL_DEVROUTE", 0) != 0;
     if (!getenv("GUBER_POOL_EAGER_MIN")) eager_min_ = routed_ ? 16 : 4096;
     guber_config_t c = cfg;
     if (c.max_batch < stage_cap_) c.max_batch = stage_cap_;
@@ -934,7 +938,12 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
         for (Stage* s : due) {
             int rc;
             const int64_t ts = mono_us();
-            if (dev_route_) {
+            if (dev_route_ && s->n <= 256) {                         // a handful of requests: routed here (one launch then, no round trip for the sizes)
+                route_on_host(d, *s);
+                uint32_t counts[kMaxEngines];
+                for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_relaxed);
+                rc = submit_routed_now(d, *s, counts) ? GUBER_OK : s->rc;
+            } else if (dev_route_) {
                 // ... after deciding which shard each belongs to: two small launches now, guber_stage_submit_routed as soon as the
                 // shares' sizes are back (poll) — the rule travels with the first stage after a placement change
                 static const uint16_t one_shard[1] = {0};

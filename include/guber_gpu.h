@@ -96,7 +96,8 @@ typedef struct guber_config {
     uint32_t struct_size;    /* sizeof(guber_config_t), for ABI growth */
     int32_t device;          /* HIP device ordinal */
     uint64_t cache_size;     /* max resident rate limits (Config.CacheSize, default 50_000) */
-    uint64_t table_slots;    /* 0 = derive: next pow2 >= 2*cache_size (load factor <= 0.5) */
+    uint64_t table_slots;    /* 0 = derive: next pow2 >= 4 x (cache_size + max_batch) while the table stays below 4 GB (load <= 0.25: nine keys in ten at
+                                their home position), else >= 2 x (load <= 0.5) */
     uint32_t max_batch;      /* largest n accepted by one eval call (0 = 65536) */
     uint32_t max_key_bytes;  /* longest single key accepted (0 = 1024) */
     void* stream;            /* optional caller-owned hipStream_t; NULL = engine creates its own */
@@ -205,8 +206,12 @@ int guber_eval_batch_dev(guber_engine_t* e, const guber_batch_t* batch, guber_re
  *      event otherwise), resolves internal retries and fills the per-batch aggregates.  With several stages per engine one
  *      is filled while the GPU evaluates another (the pool keeps four per device: filling / up to two on the GPU / being read out).  Stages of one engine are evaluated in submission order; the one
  *      exception are items that hit the internal retry (two keys under one 64-bit hash inside a batch, ~1e-6 per batch): they
- *      are re-run by guber_stage_wait, i.e. possibly after the next stage already in flight — the order two concurrent
- *      GetRateLimits calls have in the reference too (none).  Callers that need strict order keep one stage in flight.
+ *      are re-run by the guber_stage_wait of their stage, i.e. after whatever is already in flight.  Later requests of such a key
+ *      meet the same resident key, are retried too and re-run by THEIR stage's wait: per key the order is the order of the
+ *      guber_stage_wait calls — waits in submission order keep the submission order also with several stages in flight; a caller
+ *      that waits in completion order (the pool) may apply a later stage's requests of such a key first: the order two concurrent
+ *      GetRateLimits calls have in the reference too (none).  (tests/test_gpu_parity.py
+ *      test_internal_retries_follow_the_order_of_the_waits pins both.)
  *      Optional request arrays may be switched off by setting the pointer in guber_stage_batch() to NULL (burst, created_at,
  *      is_owner, behavior, algorithm: the guber_batch_t defaults apply); key_bytes_cap = 0 -> 64 bytes per request. */
 typedef struct guber_stage guber_stage_t;
@@ -253,7 +258,8 @@ int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const* engines, 
  *                           sizes, and dest[i] = engine << 24 | rank in arrival order.  `rule` = the placement as exported by
  *                           guber_placement_export (copied to the device: waits for the stream, so hand it over only when the
  *                           placement changed; NULL = the rule given last); global_engine >= 0: requests with
- *                           GUBER_BEHAVIOR_GLOBAL go to that engine index.  At most 65 536 requests.
+ *                           GUBER_BEHAVIOR_GLOBAL go to that engine index.  At most 65 536 requests.  The stage's keys are brought to
+ *                           its HBM mirror on the way and stay there for guber_stage_submit_routed: the stage is not modified in between.
  *   guber_stage_route_poll  1 = counts[0 .. n_engines) hold the shares' sizes, 0 = still running.  guber_stage_submit_routed may
  *                           follow at once (stream order makes dest complete before it is read). */
 typedef struct guber_route_rule {

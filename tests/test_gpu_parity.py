@@ -873,7 +873,7 @@ def test_global_engine_keeps_serving_across_rebuilds():
     """An engine created with GUBER_FLAG_GLOBAL whose directory fills with the entries of expired keys: the table is rebuilt
     (pending GLOBAL records move with their buckets) instead of rejecting the batch, and what was queued before the rebuild
     is still delivered by guber_global_take."""
-    e = engine(cache_size=512, max_batch=1024, max_key_bytes=64, flags=ga.FLAG_GLOBAL)     # 4096 slots, 3584 tags
+    e = engine(cache_size=512, max_batch=1024, max_key_bytes=64, table_slots=4096, flags=ga.FLAG_GLOBAL)     # 4096 slots, 3584 tags
     o = Oracle(cache_size=1 << 20)
     now = streams.NOW0
     gk = [f"glob_{i}" for i in range(40)]
@@ -1198,6 +1198,53 @@ def test_the_device_routes_a_front_stage_like_the_placement():
     pl.close()
     for e in reversed(engines):
         e.close()
+
+
+def test_internal_retries_follow_the_order_of_the_waits():
+    """include/guber_gpu.h, stages: items that hit the internal retry (GUBER_ITEM_E_RETRY: a key whose 64-bit hash is another key's) are
+    re-run by the guber_stage_wait of THEIR stage, i.e. after whatever is already in flight.  A later stage's requests of such a key
+    meet the same resident key, are retried as well and re-run by THEIR stage's wait — so per key the order is the order of the
+    waits.  Pinned with the weak test hash (900 new keys under 64 hash values: most of the first batch retries), two stages in flight:
+      * waits in submission order: element-wise equal to the oracle evaluating stage one, then stage two;
+      * waits in the opposite order: every request still answered exactly once (per key the multiset of `remaining` is the
+        oracle's, the bucket ends where the oracle's ends, a stage's own requests of a key keep their order) and second-stage
+        requests were applied BEFORE retried first-stage ones — the reorder the header documents, which two concurrent GetRateLimits
+        calls have in the reference as well (gubernator.go:183-306 orders nothing between RPCs)."""
+    n = 3000
+    idx_a, idx_b = np.arange(n) % 900, (np.arange(n) * 7) % 900
+    now = streams.NOW0
+    ha = HostBatch([f"retry_{k}" for k in idx_a], 1, 1000, 600_000, now, created_at=now)
+    hb = HostBatch([f"retry_{k}" for k in idx_b], 1, 1000, 600_000, now, created_at=now)
+    for in_order in (True, False):
+        eng = engine(cache_size=1 << 14, max_batch=4096, flags=ga.FLAG_TEST_WEAK_HASH)
+        sa, sb = ga.Stage(eng, 4096), ga.Stage(eng, 4096)
+        sa.fill(ha); sb.fill(hb)
+        sa.submit(); sb.submit()
+        for st in ((sa, sb) if in_order else (sb, sa)):
+            st.wait()
+        ra, rb = sa.result(), sb.result()
+        assert eng.stats()["retries"] > 0, "the weak hash produced no internal retry: the test shows nothing"
+        orc = Oracle(cache_size=1 << 15)
+        wa, wb = orc.eval(ha), orc.eval(hb)
+        if in_order:
+            support.assert_results_equal(ra, wa, "first stage (two in flight, waits in submission order)")
+            support.assert_results_equal(rb, wb, "second stage (two in flight, waits in submission order)")
+        else:
+            assert not ra.err.any() and not rb.err.any()
+            overtaken = 0
+            for k in range(900):
+                ia, ib = np.nonzero(idx_a == k)[0], np.nonzero(idx_b == k)[0]
+                got = np.sort(np.concatenate([ra.remaining[ia], rb.remaining[ib]]))
+                want = np.sort(np.concatenate([wa.remaining[ia], wb.remaining[ib]]))
+                assert np.array_equal(got, want), (k, got, want)                 # each request applied exactly once
+                assert np.all(np.diff(ra.remaining[ia]) < 0) and np.all(np.diff(rb.remaining[ib]) < 0), k
+                if len(ia) and len(ib) and rb.remaining[ib].max() > ra.remaining[ia].min():
+                    overtaken += 1
+            assert overtaken > 0, "waiting for the second stage first did not re-run its retries first"
+            print(f"waits in the opposite order: {overtaken} of 900 keys had second-stage requests applied before retried first-stage ones; retries {eng.stats()['retries']}")
+        probe = HostBatch([f"retry_{k}" for k in range(900)], 0, 1000, 600_000, now + 1, created_at=now + 1)
+        support.assert_results_equal(eng.eval(probe), orc.eval(probe), "bucket state after both stages")
+        sa.close(); sb.close(); eng.close()
 
 
 def test_buckets_move_between_tables_by_key_hash():

@@ -26,12 +26,12 @@ ENVS = {"eager": {},                                                          # 
         "few_active": {"GUBER_POOL_MAX_ACTIVE": "2", "GUBER_POOL_DEPTH": "1"},
         "direct": {"GUBER_POOL_DIRECT_CALLERS": "64"},                         # small RPCs evaluated by their callers whatever the load
         "per_shard_stages": {"GUBER_POOL_ROUTED": "0"},                        # every shard its own stages, the callers sort by shard (default: one front stage per device)
-        "callers_route": {"GUBER_POOL_DEVROUTE": "0"}}                         # one front stage, the callers hash / look up / rank (default: the device does, guber_stage_route)
+        "device_routes": {"GUBER_POOL_DEVROUTE": "1"}}                         # one front stage, the DEVICE hashes / looks up / ranks (guber_stage_route; default: the callers do)
 
 
 @pytest.mark.parametrize("tag,flags,scale,env,repeats", [("plain", [], 1, "eager", 5), ("plain", [], 2, "limit_or_wait", 2), ("plain", [], 2, "idle_flush", 2),
-                                                         ("plain", [], 2, "few_active", 2), ("plain", [], 2, "direct", 3), ("plain", [], 2, "per_shard_stages", 2), ("plain", [], 2, "callers_route", 2),
-                                                         ("tsan", ["-fsanitize=thread"], 4, "direct", 1), ("tsan", ["-fsanitize=thread"], 4, "per_shard_stages", 1), ("tsan", ["-fsanitize=thread"], 2, "callers_route", 1),
+                                                         ("plain", [], 2, "few_active", 2), ("plain", [], 2, "direct", 3), ("plain", [], 2, "per_shard_stages", 2), ("plain", [], 2, "device_routes", 2),
+                                                         ("tsan", ["-fsanitize=thread"], 4, "direct", 1), ("tsan", ["-fsanitize=thread"], 4, "per_shard_stages", 1), ("tsan", ["-fsanitize=thread"], 2, "device_routes", 1),
                                                          ("tsan", ["-fsanitize=thread"], 2, "eager", 1), ("tsan", ["-fsanitize=thread"], 4, "idle_flush", 1),
                                                          ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2, "eager", 1)])
 def test_pool_host_logic(tag, flags, scale, env, repeats):
