@@ -271,8 +271,13 @@ class Rig:
         else:
             self.sown = np.zeros(nk, np.uint8)
         self.local_of_shard = [np.nonzero(self.sown == j)[0] for j in range(S)]
-        slots_log2 = int(os.environ.get("GUBER_BENCH_TABLE_SLOTS_LOG2", "0"))       # experiments: 0 = the engine's own rule (2 x (cache_size + max_batch), rounded up)
-        self.engines = [ga.Engine(cache_size=len(self.local_of_shard[j]) + len(self.local_of_shard[j]) // 4 + 1024, device=ctx.local_rank, max_batch=B,
+        slots_log2 = int(os.environ.get("GUBER_BENCH_TABLE_SLOTS_LOG2", "0"))       # experiments: 0 = the engine's own rule (4 x or 2 x (cache_size + max_batch), rounded up)
+        # CacheSize = twice the resident population (the reference's cache must not evict live limits either).  The engine evicts
+        # exactly like lrucache.go, which needs to know BEFORE a batch whether it can overflow the cache; the host only knows the
+        # exact item count as of the last batch that has reported, plus the requests in flight — so the headroom is also what lets
+        # `headroom / batch` batches per shard be in flight without waiting for the GPU (include/guber_gpu.h "bounded cache"): a shard
+        # that holds one hot key still sees batches of B requests, hence the 8 batches on top
+        self.engines = [ga.Engine(cache_size=2 * len(self.local_of_shard[j]) + 8 * B + 1024, device=ctx.local_rank, max_batch=B,
                                   table_slots=(1 << slots_log2) if slots_log2 else 0,
                                   stream=self.sstreams[j].cuda_stream, max_key_bytes=max_key_bytes, flags=flags) for j in range(S)]
         # arrays every batch of this rig shares (fixed-width keys, constant request fields)

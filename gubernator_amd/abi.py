@@ -46,7 +46,8 @@ class GuberStats(C.Structure):
     _fields_ = [("over_limit_count", C.c_uint64), ("cache_hits", C.c_uint64), ("cache_misses", C.c_uint64),
                 ("unexpired_evictions", C.c_uint64), ("cache_size", C.c_int64), ("table_slots", C.c_uint64),
                 ("tags_used", C.c_uint64), ("batches", C.c_uint64), ("retries", C.c_uint64),
-                ("compactions", C.c_uint64), ("small_batches", C.c_uint64), ("fused_batches", C.c_uint64)]
+                ("compactions", C.c_uint64), ("small_batches", C.c_uint64), ("fused_batches", C.c_uint64),
+                ("eviction_passes", C.c_uint64), ("tail_rebuilds", C.c_uint64), ("batch_cuts", C.c_uint64)]
 
 
 class GuberGlobalRows(C.Structure):

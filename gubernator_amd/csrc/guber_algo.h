@@ -63,23 +63,31 @@ struct alignas(16) Rec {
     int64_t burst;       // leaky: Burst
     int64_t expire_at;   // CacheItem.ExpireAt
     int64_t invalid_at;  // CacheItem.InvalidAt
-    uint32_t meta;       // kind | status << 8 | CacheItem.Algorithm << 16
-    uint32_t pad;
+    uint32_t meta;       // kind (2 bits) | status << 2 (1 bit) | CacheItem.Algorithm << 3 (8 bits) | bits 32..52 of the recency stamp << 11
+    uint32_t pad;        // bits 0..31 of the recency stamp
 };
+// The recency stamp (53 bits): the engine's request sequence number of the LAST request that touched the item (a batch of n
+// requests takes n numbers, the i-th request the i-th; Add and GetItem take theirs) — the total order of LRUCache's list
+// (lrucache.go:88-128: Add / GetItem move to the front): older stamp = nearer the back.  Unique per item.
+constexpr uint32_t REC_META_MASK = 0x7ffu;
+constexpr uint64_t REC_STAMP_MASK = (1ull << 53) - 1ull;
 static_assert(sizeof(Rec) == 64, "one record = one 64-byte sector");
 
-GB_HD uint32_t rec_kind(const Rec& s) { return s.meta & 0xffu; }
-GB_HD uint32_t rec_status(const Rec& s) { return (s.meta >> 8) & 0xffu; }
-GB_HD uint32_t rec_algo(const Rec& s) { return (s.meta >> 16) & 0xffu; }
-GB_HD uint32_t make_meta(uint32_t kind, uint32_t status, uint32_t algo) { return kind | (status << 8) | (algo << 16); }
-GB_HD void rec_set_status(Rec& s, uint32_t st) { s.meta = (s.meta & ~0xff00u) | (st << 8); }
+GB_HD uint32_t rec_kind(const Rec& s) { return s.meta & 3u; }
+GB_HD uint32_t rec_status(const Rec& s) { return (s.meta >> 2) & 1u; }
+GB_HD uint32_t rec_algo(const Rec& s) { return (s.meta >> 3) & 0xffu; }
+GB_HD uint32_t rec_meta(const Rec& s) { return s.meta & REC_META_MASK; }
+GB_HD uint32_t make_meta(uint32_t kind, uint32_t status, uint32_t algo) { return (kind & 3u) | ((status & 1u) << 2) | ((algo & 0xffu) << 3); }
+GB_HD void rec_set_status(Rec& s, uint32_t st) { s.meta = (s.meta & ~4u) | ((st & 1u) << 2); }
+GB_HD uint64_t rec_stamp(const Rec& s) { return ((uint64_t)(s.meta >> 11) << 32) | s.pad; }
+GB_HD void rec_set_stamp(Rec& s, uint64_t st) { s.pad = (uint32_t)st; s.meta = (s.meta & REC_META_MASK) | ((uint32_t)((st & REC_STAMP_MASK) >> 32) << 11); }
 GB_HD void rec_clear(Rec& s) {
     s.limit = s.duration = s.remaining = s.stamp = s.burst = s.expire_at = s.invalid_at = 0;
     s.meta = 0; s.pad = 0;
 }
 GB_HD bool rec_eq(const Rec& a, const Rec& b) {
     return a.limit == b.limit && a.duration == b.duration && a.remaining == b.remaining && a.stamp == b.stamp &&
-           a.burst == b.burst && a.expire_at == b.expire_at && a.invalid_at == b.invalid_at && a.meta == b.meta;
+           a.burst == b.burst && a.expire_at == b.expire_at && a.invalid_at == b.invalid_at && rec_meta(a) == rec_meta(b);
 }
 // cache.go:43-57 IsExpired
 GB_HD bool rec_expired(const Rec& s, int64_t now) {
@@ -436,7 +444,7 @@ GB_HD bool pure_subtract(const Rec& before, const Rec& after, const Req& r, int6
     if (r.hits <= 0 || (r.behavior & BH_RESET_REMAINING)) return false;
     if (before.limit != after.limit || before.duration != after.duration || before.stamp != after.stamp ||
         before.burst != after.burst || before.expire_at != after.expire_at || before.invalid_at != after.invalid_at ||
-        before.meta != after.meta)
+        rec_meta(before) != rec_meta(after))
         return false;
     if (rec_expired(after, now) || after.limit != r.limit) return false;
     uint32_t k = rec_kind(after);

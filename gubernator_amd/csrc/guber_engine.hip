@@ -19,6 +19,8 @@
 #include "../../include/guber_gpu.h"
 #include "guber_host.h"
 #include "guber_kernels.h"
+#include "guber_kernels_lru.h"
+#include <hipcub/hipcub.hpp>
 
 using namespace guber;
 
@@ -148,10 +150,26 @@ struct guber_engine {
     uint64_t size_upper = 0;   // host-side upper bound of the live items (ctr.size)
     int64_t clock_ms = 0;      // latest `now` seen (guber_set_clock / batches / lookups): classifies evictions as expired or not
     uint64_t evict_passes = 0;
-    uint32_t touch = 0;        // advances with every call that touches items (batch, Add, GetItem): approximate LRU order
+    // The recency order of LRUCache's list (lrucache.go:88-128) as request sequence numbers: a batch of n requests takes n stamps
+    // (request i the i-th), Add one per item, GetItem one; every bucket carries the stamp of its last touch (rec_stamp, 53 bits).
+    uint64_t seq_next = 1;     // the next stamp to hand out
+    // The exact victim order when the cache binds (guber_kernels_lru.h): the tail list (live items sorted by stamp), the pre-pass's
+    // control block and scratch.  Allocated by the first call that may overflow the cache.
+    DevBuf<LruCtl> lru_ctl; PinBuf<LruCtl> lru_hctl;
+    DevBuf<unsigned long long> lru_tstamp, lru_tstamp_in, lru_cnt; DevBuf<uint32_t> lru_tslot, lru_tslot_in; DevBuf<uint8_t> lru_sort_tmp;
+    DevBuf<unsigned long long> lru_u64; DevBuf<uint32_t> lru_u32; DevBuf<uint8_t> lru_u8;
+    bool lru_tail_ok = false;  // false: the slots' numbering or the table changed under the list (rebuild before use)
+    uint64_t lru_admits = 0, lru_applied = 0, lru_rebuilds = 0, lru_cuts = 0, lru_passes = 0;
+    uint64_t touch = 0;        // first stamp of the call in progress (take_stamps)
     // asynchronous counter read-back (maintain): enqueued when an upper bound crosses its soft limit, folded when its event
     // has completed — the hot path never waits for it
-    bool rb_inflight = false, snap_pending = false; uint64_t rb_added = 0;   // snap_pending: the read-back waits for a batch to ride on
+    // a ring of snapshot slots (+ one reserved for the synchronous refresh): every slot remembers how many requests had been
+    // enqueued when it was armed, so a completed snapshot gives  exact count as of then + requests enqueued since  as the bound
+    static constexpr uint32_t kRb = 32;
+    struct RbSlot { uint32_t seq = 0; uint64_t mark = 0; bool armed = false; };
+    RbSlot rb[kRb + 1]; int rb_ride = -1;      // rb_ride: the slot that waits for a batch to ride on (k_front / k_part carry it)
+    uint64_t added_total = 0;                  // requests (items) ever enqueued: each might have created an item and a directory entry
+    uint64_t settle_waits = 0;
     uint64_t compactions = 0;
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
@@ -179,38 +197,87 @@ static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_reso
                                                    "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi",
                                                    "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi"};
 
+static uint64_t take_stamps(guber_engine* e, uint64_t n) {
+    const uint64_t b = e->seq_next;
+    e->seq_next += n ? n : 1;
+    e->touch = b;
+    return b;
+}
 static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
 
 static void quiesce_all(guber_engine* e) { (void)hipStreamSynchronize(e->stream); }
 
-// fold the per-workgroup event counters into a DevCounters image (host side)
-static void fold_counters(guber_engine* e) {
-    DevCounters c = *e->h_ctr.p;
-    for (uint32_t b = 0; b < e->n_bctr; ++b) {
-        const BlockCounters& bc = e->h_bctr.p[b];
-        c.over += bc.over; c.hits += bc.hits; c.misses += bc.misses; c.size += bc.size_delta;
-    }
-    e->last_ctr = c;
-    e->tags_upper = c.tags_used;
-    e->size_upper = (uint64_t)std::max<long long>(c.size, 0);
-    e->rb_inflight = false; e->snap_pending = false; e->rb_added = 0;
+// ---- the engine's counters on the host -----------------------------------------------------------------------------------------
+// Snapshots of the device counters travel to device-visible host memory by a small launch of their own (k_ctr_snapshot) or riding
+// on a batch's first kernel (Work::snap_*), each into its own slot with a sequence number stamped when it is complete: no copy
+// engine, no event — the host just looks at the stamps.
+static void note_enqueued(guber_engine* e, uint64_t n) { e->size_upper += n; e->tags_upper += n; e->added_total += n; }
+static bool rb_slot_done(const guber_engine* e, uint32_t i) {
+    return __atomic_load_n((volatile uint32_t*)&e->h_rb_seq.p[i], __ATOMIC_ACQUIRE) == e->rb[i].seq;
 }
-// The engine's counters -> host memory by ONE small launch (k_ctr_snapshot writes device-visible host memory and stamps a
-// sequence number when it is done): no copy engine, no event — the asynchronous reader just looks at the stamp.
+static bool rb_any_armed(const guber_engine* e) { for (uint32_t i = 0; i < guber_engine::kRb; ++i) if (e->rb[i].armed) return true; return false; }
+// armed and already launched (a riding slot that has no batch yet is not on its way)
+static bool rb_any_launched(const guber_engine* e) {
+    for (uint32_t i = 0; i < guber_engine::kRb; ++i) if (e->rb[i].armed && (int)i != e->rb_ride) return true;
+    return false;
+}
+static void rb_disarm_all(guber_engine* e) { for (auto& s : e->rb) s.armed = false; e->rb_ride = -1; }
+// fold slot i (complete) into the host's image: the counters as of the snapshot, the bounds = that + what was enqueued since
+static void rb_fold_slot(guber_engine* e, uint32_t i) {
+    DevCounters c = e->h_ctr.p[i];
+    const BlockCounters* hb = e->h_bctr.p + (size_t)i * e->n_bctr;
+    for (uint32_t b = 0; b < e->n_bctr; ++b) { c.over += hb[b].over; c.hits += hb[b].hits; c.misses += hb[b].misses; c.size += hb[b].size_delta; }
+    const uint64_t since = e->added_total - e->rb[i].mark;
+    e->last_ctr = c;
+    e->tags_upper = c.tags_used + since;
+    e->size_upper = (uint64_t)std::max<long long>(c.size, 0) + since;
+}
+// the newest completed snapshot (if any) becomes the host's knowledge; every completed slot is free again
+static bool rb_fold_newest(guber_engine* e) {
+    int best = -1;
+    for (uint32_t i = 0; i < guber_engine::kRb; ++i) {
+        if (!e->rb[i].armed || (int)i == e->rb_ride || !rb_slot_done(e, i)) continue;
+        if (best < 0 || e->rb[i].mark > e->rb[best].mark) best = (int)i;
+    }
+    if (best < 0) return false;
+    rb_fold_slot(e, (uint32_t)best);
+    for (uint32_t i = 0; i < guber_engine::kRb; ++i) if (e->rb[i].armed && (int)i != e->rb_ride && e->rb[i].mark <= e->rb[best].mark) e->rb[i].armed = false;
+    return true;
+}
+static void rb_launch(guber_engine* e, uint32_t i) {
+    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p + i, e->h_bctr.p + (size_t)i * e->n_bctr,
+                       e->h_rb_seq.p + i, e->rb[i].seq);
+}
+// arm a free slot: ride = the next batch's first kernel carries it (free of charge), else a launch of its own.  -1 = every slot is on its way.
+static int rb_arm(guber_engine* e, bool ride) {
+    if (ride && e->rb_ride >= 0) return e->rb_ride;
+    for (uint32_t i = 0; i < guber_engine::kRb; ++i) {
+        if (e->rb[i].armed) continue;
+        e->rb[i].seq = ++e->rb_seq ? e->rb_seq : ++e->rb_seq;
+        e->rb[i].mark = e->added_total; e->rb[i].armed = true;
+        if (ride) e->rb_ride = (int)i; else rb_launch(e, i);
+        return (int)i;
+    }
+    return -1;
+}
+// the riding snapshot goes with this batch (Work::snap_*)
+static void attach_counter_readback(guber_engine* e, Work& W) {
+    const uint32_t i = (uint32_t)e->rb_ride;
+    W.snap_seq = e->rb[i].seq; W.snap_n = e->n_bctr; W.snap_c = e->h_ctr.p + i; W.snap_b = e->h_bctr.p + (size_t)i * e->n_bctr; W.snap_stamp = e->h_rb_seq.p + i;
+    e->rb_ride = -1;
+}
+// synchronous: a snapshot at the tail of the stream into the reserved slot; after the stream has drained fold_counters makes it
+// the host's knowledge (exact: nothing is in flight) and forgets every older snapshot
 static int enqueue_counter_readback(guber_engine* e) {
-    if (e->h_rb_seq.ensure(1)) return GUBER_E_NOMEM;
-    ++e->rb_seq;
-    hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p, e->h_bctr.p, e->h_rb_seq.p, e->rb_seq);
+    const uint32_t i = guber_engine::kRb;
+    e->rb[i].seq = ++e->rb_seq ? e->rb_seq : ++e->rb_seq; e->rb[i].mark = e->added_total;
+    rb_launch(e, i);
     HIPCHK(hipGetLastError());
     return 0;
 }
-// the same read-back riding on the next two-launch batch instead of a launch of its own (Work::snap_*)
-static void attach_counter_readback(guber_engine* e, Work& W) {
-    W.snap_seq = e->rb_seq; W.snap_n = e->n_bctr; W.snap_c = e->h_ctr.p; W.snap_b = e->h_bctr.p; W.snap_stamp = e->h_rb_seq.p;
-    e->snap_pending = false;
-}
-static bool counter_readback_done(const guber_engine* e) {
-    return __atomic_load_n((volatile uint32_t*)e->h_rb_seq.p, __ATOMIC_ACQUIRE) == e->rb_seq;
+static void fold_counters(guber_engine* e) {
+    rb_fold_slot(e, guber_engine::kRb);
+    rb_disarm_all(e);
 }
 static int engine_refresh_counters(guber_engine* e) {
     int rc = enqueue_counter_readback(e);
@@ -292,7 +359,9 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         rc |= e->gtake_ctr.ensure(4);
     }
     e->n_bctr = (M + 255) / 256;
-    rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure(e->n_bctr);
+    rc |= e->bctr.ensure(e->n_bctr); rc |= e->h_bctr.ensure((size_t)e->n_bctr * (guber_engine::kRb + 1));
+    rc |= e->h_ctr.ensure(guber_engine::kRb + 1); rc |= e->h_rb_seq.ensure(guber_engine::kRb + 1);
+    if (!rc) memset(e->h_rb_seq.p, 0, (guber_engine::kRb + 1) * sizeof(uint32_t));
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
     hipError_t he = hipSuccess;
     if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
@@ -342,6 +411,11 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (getenv("GUBER_ENGINE_STATS"))
+        fprintf(stderr, "[engine %p] batches %llu (small %llu fused %llu part %llu) cache_size %llu size_upper %llu last size %lld | eviction pre-passes: calls %llu launches %llu applied %llu cuts %llu tail rebuilds %llu | waits for a snapshot %llu | compactions %llu\n",
+                (void*)e, (unsigned long long)e->batches, (unsigned long long)e->small_batches, (unsigned long long)e->fused_batches, (unsigned long long)e->part_batches,
+                (unsigned long long)e->cache_size, (unsigned long long)e->size_upper, (long long)e->last_ctr.size, (unsigned long long)e->lru_admits, (unsigned long long)e->lru_passes,
+                (unsigned long long)e->lru_applied, (unsigned long long)e->lru_cuts, (unsigned long long)e->lru_rebuilds, (unsigned long long)e->settle_waits, (unsigned long long)e->compactions);
 #ifdef GUBER_PHASE_TIMING
     if (e->dbg_n) {
         static const char* names[2][8] = {{"entry", "grouped in LDS", "claimed + published", "requests compared", "probe + verify done", "end (all drained)", "key_off loaded", "key hashed"},
@@ -385,6 +459,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     if (e->z_event) (void)hipEventDestroy(e->z_event);
     for (auto& g : e->gev) if (g.ev) (void)hipEventDestroy(g.ev);
     e->d_margs.release();
+    e->lru_ctl.release(); e->lru_hctl.release(); e->lru_tstamp.release(); e->lru_tstamp_in.release(); e->lru_cnt.release(); e->lru_tslot.release();
+    e->lru_tslot_in.release(); e->lru_sort_tmp.release(); e->lru_u64.release(); e->lru_u32.release(); e->lru_u8.release();
     if (e->copy_in) (void)hipStreamDestroy(e->copy_in);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -404,6 +480,148 @@ static bool takes_part_path(const guber_engine* e, uint32_t n, bool host_residen
            (fused || e->part_single || e->force_part);
 }
 
+// ---- the bounded cache's exact victim order (guber_kernels_lru.h) --------------------------------------------------------------
+// May this call make the cache longer than cache_size?  size_upper is the host's upper bound of the live items (every request
+// might create one); lru_admit reads the exact figure when it matters.
+// When the bound says yes, the bound is first brought up to date: it counts every request in flight as a new item, so the host
+// looks at the counter snapshots that ride on the batches (maintain) and, as long as one is on its way, waits for the GPU to get
+// there — a wait for PROGRESS, not a drain: the queue stays as deep as the cache's headroom allows.  Only when nothing is left to
+// wait for is the answer yes (the pre-pass then synchronises and sees the exact figure).  Engine mutex held.
+static bool lru_may_bind(guber_engine* e, uint64_t n) {
+    if (e->size_upper + n <= e->cache_size) return false;
+    bool waited = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; ++spins) {
+        if (rb_fold_newest(e) && e->size_upper + n <= e->cache_size) { e->settle_waits += waited; return false; }
+        if (!rb_any_launched(e)) break;
+        waited = true;
+        if ((spins & 0xff) == 0xff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        __builtin_ia32_pause();
+    }
+    e->settle_waits += waited;
+    return true;
+}
+static bool lru_may_bind_unlocked(guber_engine* e, uint64_t n) { std::lock_guard<std::mutex> lk(e->mu); return lru_may_bind(e, n); }
+static LruKeys lru_keys_of(const BatchView& B) {
+    LruKeys K{};
+    K.bytes = B.key_bytes; K.algorithm = B.algorithm; K.key_stride = B.key_stride;
+    if (!B.key_stride) { K.off_p = (const uint8_t*)B.key_off; K.off_stride = 4; }
+    if (B.key_stride || B.key_len) { K.len_p = (const uint8_t*)B.key_len; K.len_stride = 4; }
+    return K;
+}
+// The tail list: every live item's (stamp, slot), sorted by stamp — one table scan and one radix sort, then good for as many
+// batches as it has valid entries left (an entry is valid while its bucket still carries that stamp).
+static int lru_rebuild(guber_engine* e) {
+    int rc = engine_refresh_counters(e);
+    if (rc) return rc;
+    const uint64_t live = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
+    const uint64_t cap = live + 64;
+    if (e->lru_ctl.ensure(1) || e->lru_hctl.ensure(1) || e->lru_cnt.ensure(1) || e->lru_tstamp.ensure(cap) || e->lru_tstamp_in.ensure(cap) ||
+        e->lru_tslot.ensure(cap) || e->lru_tslot_in.ensure(cap)) return GUBER_E_NOMEM;
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemsetAsync(e->lru_cnt.p, 0, 8, st));
+    hipLaunchKernelGGL(k_lru_gather, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, st, e->T, e->slots, e->lru_tstamp_in.p, e->lru_tslot_in.p, cap, e->lru_cnt.p);
+    unsigned long long cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, e->lru_cnt.p, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (cnt > cap) return fail(GUBER_E_HIP, "the table holds more live items than its counters say");
+    if (cnt) {
+        size_t tmp = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, e->lru_tstamp_in.p, e->lru_tstamp.p, e->lru_tslot_in.p, e->lru_tslot.p, (int)cnt, 0, 53, st));
+        if (e->lru_sort_tmp.ensure(tmp + 16)) return GUBER_E_NOMEM;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(e->lru_sort_tmp.p, tmp, e->lru_tstamp_in.p, e->lru_tstamp.p, e->lru_tslot_in.p, e->lru_tslot.p, (int)cnt, 0, 53, st));
+    }
+    LruCtl c{}; c.cursor = 0; c.tail_n = cnt;
+    HIPCHK(hipMemcpyAsync(e->lru_ctl.p, &c, sizeof(c), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e->lru_tail_ok = true; e->lru_rebuilds++;
+    return 0;
+}
+// The pre-pass of a call that may overflow the cache: n requests (or n = 0: only bring the cache down to cache_size).  On return
+// *status is LRU_NONE / LRU_APPLIED (the buckets that leave are absent, the counters adjusted: evaluate the batch) or LRU_CUT
+// (nothing done: the batch is larger than the cache and evictions are due — the caller evaluates it in pieces of cache_size).
+static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_ms, uint32_t* status) {
+    hipStream_t st = e->stream;
+    if (e->lru_ctl.ensure(1) || e->lru_hctl.ensure(1)) return GUBER_E_NOMEM;
+    if (!e->lru_tstamp.p) {                                          // first use: an empty list (the first check asks for a real one)
+        LruCtl c{};
+        HIPCHK(hipMemcpyAsync(e->lru_ctl.p, &c, sizeof(c), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (e->lru_tstamp.ensure(16) || e->lru_tslot.ensure(16)) return GUBER_E_NOMEM;
+        e->lru_tail_ok = true;                                       // (valid and empty)
+    }
+    uint32_t cells = 1024; while (cells < 2 * (uint64_t)n) cells <<= 1;
+    e->lru_admits++;
+    uint64_t w_len = std::max<uint64_t>(2 * (uint64_t)n, 4096);
+    for (int round = 0; round < 64; ++round) {
+        if (!e->lru_tail_ok) { const int rc = lru_rebuild(e); if (rc) return rc; }
+        const uint64_t live_cap = e->lru_tstamp.cap;
+        if (w_len > live_cap) w_len = live_cap;
+        const uint32_t W = (uint32_t)std::min<uint64_t>(w_len, 1u << 30), wblocks = (W + 255) / 256;
+        // scratch: u64 [cells gid | n rstamp | W zstamp], u32 [cells gfirst | n rfirst | n rslot | W zslot | W zwidx | n qfirst | n qrank | n qslot |
+        //               wblocks + 1 blockcnt | n + 1 new_before | W + 1 touched_before | 4 n_risk], u8 [n + 1 isnew_at | W wflag | W ztouched]
+        const size_t nn = (size_t)n + 1;
+        if (e->lru_u64.ensure((size_t)cells + nn + W + 8) || e->lru_u32.ensure((size_t)cells + 6 * nn + 3 * ((size_t)W + 1) + wblocks + 16) ||
+            e->lru_u8.ensure(nn + 2 * ((size_t)W + 1) + 64)) return GUBER_E_NOMEM;
+        unsigned long long* p64 = e->lru_u64.p; uint32_t* p32 = e->lru_u32.p; uint8_t* p8 = e->lru_u8.p;
+        LruGroups G{p64, p32, cells - 1}; p64 += cells; p32 += cells;
+        LruRes R{p32, p32 + nn, p64}; p32 += 2 * nn; p64 += nn;
+        LruWin Z{p64, p32, p32 + W + 1}; p64 += W; p32 += 2 * ((size_t)W + 1);
+        LruRisk Q{p32, p32 + nn, p32 + 2 * nn}; p32 += 3 * nn;
+        uint32_t* blockcnt = p32; p32 += wblocks + 1;
+        uint32_t* new_before = p32; p32 += nn;
+        uint32_t* touched_before = p32; p32 += (size_t)W + 1;
+        uint32_t* n_risk = p32;
+        uint8_t* isnew_at = p8; uint8_t* wflag = p8 + nn; uint8_t* ztouched = wflag + W + 1;
+        LruCtl* C = e->lru_ctl.p;
+        hipLaunchKernelGGL(k_lru_begin, dim3(1), dim3(256), 0, st, e->T, C, e->n_bctr);
+        if (n) {
+            HIPCHK(hipMemsetAsync(G.id, 0xff, (size_t)cells * 8, st));
+            HIPCHK(hipMemsetAsync(G.first, 0xff, (size_t)cells * 4, st));
+            HIPCHK(hipMemsetAsync(isnew_at, 0, nn, st));
+            hipLaunchKernelGGL(k_lru_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, K, n, G);
+            hipLaunchKernelGGL(k_lru_keys, dim3(cells / 256), dim3(256), 0, st, e->T, G, C, isnew_at, R);
+        }
+        HIPCHK(hipMemsetAsync(ztouched, 0, (size_t)W + 1, st));
+        HIPCHK(hipMemsetAsync(n_risk, 0, 4, st));
+        if (W) {
+            hipLaunchKernelGGL(k_lru_win_flag, dim3(wblocks), dim3(256), 0, st, e->T, e->lru_tstamp.p, e->lru_tslot.p, C, W, wflag, blockcnt);
+            hipLaunchKernelGGL(k_lru_scan_u32, dim3(1), dim3(1024), 0, st, blockcnt, wblocks, &C->win_valid);
+            hipLaunchKernelGGL(k_lru_win_emit, dim3(wblocks), dim3(256), 0, st, e->lru_tstamp.p, e->lru_tslot.p, C, W, wflag, blockcnt, Z);
+        }
+        hipLaunchKernelGGL(k_lru_check, dim3(1), dim3(1), 0, st, C, W, n, e->cache_size);
+        if (W) {
+            if (n) {
+                hipLaunchKernelGGL(k_lru_risk, dim3((n + 255) / 256), dim3(256), 0, st, C, R, Z, ztouched, Q, n_risk);
+                hipLaunchKernelGGL(k_lru_scan_u8, dim3(1), dim3(1024), 0, st, isnew_at, n, new_before);
+            }
+            hipLaunchKernelGGL(k_lru_scan_u8, dim3(1), dim3(1024), 0, st, ztouched, W, touched_before);
+            if (n) hipLaunchKernelGGL(k_lru_decide, dim3((n + 255) / 256), dim3(256), 0, st, e->T, C, e->cache_size, Q, n_risk, new_before, now_ms);
+            hipLaunchKernelGGL(k_lru_evict, dim3(wblocks), dim3(256), 0, st, e->T, C, Z, ztouched, touched_before, now_ms);
+            hipLaunchKernelGGL(k_lru_end, dim3(1), dim3(1), 0, st, e->T, C, Z);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(e->lru_hctl.p, C, sizeof(LruCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        const LruCtl& c = *e->lru_hctl.p;
+        e->lru_passes++;
+        if (c.status == LRU_NONE || c.status == LRU_APPLIED) {
+            const long long left = c.len0 - (long long)c.evicted;
+            e->size_upper = (uint64_t)std::max<long long>(left, 0);
+            rb_disarm_all(e);                                        // (the stream has drained: every snapshot on its way is older news)
+            e->last_ctr.size = left; e->last_ctr.evictions += c.unexpired;
+            if (c.status == LRU_APPLIED) e->lru_applied++;
+            *status = c.status;
+            return 0;
+        }
+        if (c.status == LRU_CUT) { e->lru_cuts++; *status = LRU_CUT; return 0; }
+        if (c.status == LRU_MORE) { w_len *= 4; continue; }
+        if (c.status == LRU_REBUILD) { e->lru_tail_ok = false; w_len = std::max<uint64_t>(w_len, 2 * (uint64_t)n + c.zone); continue; }
+        return fail(GUBER_E_HIP, "the eviction pre-pass left no verdict");
+    }
+    return fail(GUBER_E_HIP, "the eviction pre-pass did not converge");
+}
+
 static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
     const uint32_t n = B.n;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
@@ -416,15 +634,14 @@ static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
         const int rc = maintain(e, n, B.now_ms, takes_fast_path(e, n));
         if (rc) return rc;
     }
-    e->size_upper += n; e->rb_added += n;
-    e->tags_upper += n;
+    note_enqueued(e, n);
     if (++e->epoch >= 0x7fffffffu) {   // 31-bit epoch wrapped: drop all dense-id claims
         hipLaunchKernelGGL(k_clear_claims, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots);
         e->epoch = 1;
     }
     W = e->W;
     W.epoch = e->epoch;
-    W.touch = e->touch = (e->touch + 1) & 0x7fffffffu;
+    W.touch = take_stamps(e, n);
     W.tiles = (n + TILE - 1) / TILE;
     return 0;
 }
@@ -435,7 +652,7 @@ static int plan_fast(guber_engine* e, const BatchView& B, bool host_resident, Wo
     B2.n_cap = e->fast_cap;
     W.careful = (e->careful || e->always_careful) ? 1u : 0u;
     W.snap_seq = 0;
-    if (e->snap_pending) attach_counter_readback(e, W);
+    if (e->rb_ride >= 0) attach_counter_readback(e, W);
     if (++e->fast_epoch16 > 0xffffu) {   // 16-bit claim epoch wrapped: forget every cell
         HIPCHK(hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream));
         HIPCHK(hipMemset2DAsync(&e->w_srec.p[0].flags, sizeof(SegRec), 0, sizeof(unsigned long long), e->fast_cap, e->stream));   // epoch-tagged flag words
@@ -473,7 +690,7 @@ static int plan_part(guber_engine* e, const BatchView& B, Work& W, FastPlan& P) 
     B2.n_cap = e->cap256;
     W.careful = 0u;
     W.snap_seq = 0;
-    if (e->snap_pending) attach_counter_readback(e, W);
+    if (e->rb_ride >= 0) attach_counter_readback(e, W);
     W.did = e->w_did3.p;
     W.st_hits = nullptr;
 #ifdef GUBER_PHASE_TIMING
@@ -488,7 +705,49 @@ static void finish_fast(guber_engine* e, uint32_t n) {
     e->batches++;
 }
 
+static int launch_batch_inner(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident);
+// requests [pos, pos + len) of a batch as a batch of their own
+static BatchView batch_slice(const BatchView& B, uint32_t pos, uint32_t len) {
+    BatchView S = B;
+    S.n = len;
+    if (B.key_stride) S.key_bytes = B.key_bytes + (size_t)pos * B.key_stride; else S.key_off = B.key_off + pos;
+    if (B.key_len) S.key_len = B.key_len + pos;
+    S.hits = B.hits + pos; S.limit = B.limit + pos; S.duration = B.duration + pos;
+    if (B.burst) S.burst = B.burst + pos;
+    if (B.created_at) S.created_at = B.created_at + pos;
+    if (B.algorithm) S.algorithm = B.algorithm + pos;
+    if (B.behavior) S.behavior = B.behavior + pos;
+    if (B.is_owner) S.is_owner = B.is_owner + pos;
+    if (B.greg_expire) S.greg_expire = B.greg_expire + pos;
+    if (B.greg_duration) S.greg_duration = B.greg_duration + pos;
+    return S;
+}
+// One batch through the engine.  A batch that may overflow the cache first goes through the eviction pre-pass (lru_admit: the
+// reference evicts in the middle of a stream of requests, lrucache.go:98-100, and the pre-pass reproduces exactly that); a batch
+// larger than the cache is then evaluated in pieces of cache_size requests, each with its own pre-pass.
 static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident = false) {
+    if (B.n == 0) return 0;
+    if (!lru_may_bind(e, B.n)) return launch_batch_inner(e, B, R, host_resident);
+    if (B.n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
+    uint8_t* const sf0 = e->W.store_flags; Rec* const sa0 = e->W.store_after;
+    int rc = 0;
+    for (uint32_t pos = 0; pos < B.n && !rc;) {
+        uint32_t len = std::min<uint32_t>(B.n - pos, 1u << 20);
+        uint32_t st = 0;
+        rc = lru_admit(e, lru_keys_of(batch_slice(B, pos, len)), len, B.now_ms, &st);
+        if (!rc && st == LRU_CUT) {
+            len = (uint32_t)std::min<uint64_t>(len, std::max<uint64_t>(e->cache_size, 1));
+            rc = lru_admit(e, lru_keys_of(batch_slice(B, pos, len)), len, B.now_ms, &st);
+        }
+        if (rc) break;
+        if (sf0) { e->W.store_flags = sf0 + pos; e->W.store_after = sa0 + pos; }
+        rc = launch_batch_inner(e, batch_slice(B, pos, len), ResultView{R.status + pos, R.limit + pos, R.remaining + pos, R.reset_time + pos, R.err + pos}, host_resident);
+        pos += len;
+    }
+    e->W.store_flags = sf0; e->W.store_after = sa0;
+    return rc;
+}
+static int launch_batch_inner(guber_engine* e, const BatchView& B, const ResultView& R, bool host_resident) {
     const uint32_t n = B.n;
     if (n == 0) return 0;
     Work W;
@@ -656,13 +915,15 @@ extern "C" int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* ba
 // stream and the batches take the two-launch pipeline, enqueues up to MULTI_MAX of them as ONE k_front_multi + ONE
 // k_eval2_multi (guber_kernels.h): the batches' dependent memory trips then overlap inside a launch, without the
 // per-stream kernel boundaries that throttle shards running on separate streams (profiles/archive/r02_m_shard_streams.txt).
-static bool can_fuse(const guber_engine* e, uint32_t n) {
+static bool fits_fused(const guber_engine* e, uint32_t n) {
 #ifdef GUBER_PHASE_TIMING
     return false;
 #else
     return e->fuse && takes_fast_path(e, n);
 #endif
 }
+// (a batch that may overflow the cache goes alone, through launch_batch and its eviction pre-pass)
+static bool can_fuse(guber_engine* e, uint32_t n) { return fits_fused(e, n) && !lru_may_bind_unlocked(e, n); }   // (takes the engine mutex for the look)
 
 static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
                         uint32_t* enqueued) {
@@ -790,8 +1051,8 @@ static int small_prelude(guber_engine* e, const BatchView& B) {
     if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
     const int rc = maintain(e, B.n, B.now_ms);
     if (rc) return rc;
-    e->size_upper += B.n; e->rb_added += B.n; e->tags_upper += B.n;
-    e->touch = (e->touch + 1) & 0x7fffffffu;
+    note_enqueued(e, B.n);
+    take_stamps(e, B.n);
     e->batches++; e->small_batches++;
     return 0;
 }
@@ -863,7 +1124,7 @@ static int eval_host_once(guber_engine* e, const guber_batch_t* b, guber_result_
                     su8, sbeh, su8 + n, has_greg ? s64 + 5 * (size_t)n : nullptr, has_greg ? s64 + 6 * (size_t)n : nullptr, b->now_ms};
         ResultView R{o8, o64, o64 + n, o64 + 2 * (size_t)n, o8 + n};
         bool done = false;
-        if (n <= FT && !sev && !e->no_small && !e->careful) {
+        if (n <= FT && !sev && !e->no_small && !e->careful && !lru_may_bind(e, n)) {
             // one launch, one workgroup; completion = a sequence number in host memory, polled
             const uint32_t seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
             sout->done = 0;
@@ -1112,7 +1373,7 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     BatchView B{b.n, 0, b.key_bytes, b.key_off, b.hits, b.limit, b.duration, b.burst, b.created_at, b.algorithm, b.behavior, b.is_owner,
                 b.greg_expire, b.greg_duration, b.now_ms};
     ResultView R{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err};
-    if (b.n <= FT && !e->no_small) {
+    if (b.n <= FT && !e->no_small && !lru_may_bind(e, b.n)) {
         s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
         s->sout->done = 0;
         int rc = launch_small(e, B, R, s->sout, s->seq);
@@ -1545,7 +1806,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
             s->seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
             s->sout->done = 0;
             MS.sub[planned] = SmallArgs{e->T, B, ResultView{s->result.status, s->result.limit, s->result.remaining, s->result.reset_time, s->result.err},
-                                        s->sout, s->seq, e->touch};
+                                        s->sout, e->touch, s->seq};
             ++planned;
         }
         if (planned) {
@@ -1568,7 +1829,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         s->n = b.n; s->now_ms = b.now_ms; s->no_agg = true;
         if (b.n == 0) { s->mode = 0; ++enq; continue; }
         memset((uint8_t*)b.key_bytes + b.key_off[b.n], 0, 16);        // the kernels read keys as 8-byte words
-        const bool small = b.n <= FT && !e->no_small;
+        const bool small = b.n <= FT && !e->no_small && !lru_may_bind_unlocked(e, b.n);
         const bool fusable = !small && can_fuse(e, b.n);
         if (small) {
             if (sg && (sg == SMALL_MULTI_MAX || e->stream != sgrp[0]->e->stream || e->device != sgrp[0]->e->device)) rc = flush_small();
@@ -1704,7 +1965,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
         if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
         if (e->device != s->e->device || e->stream != s->e->stream) return fail(GUBER_E_INVALID_ARG, "the engines of a routed stage share device and stream");
         for (uint32_t q = 0; q < j; ++q) if (engines[q] == e) return fail(GUBER_E_INVALID_ARG, "an engine twice in one routed stage");
-        if (counts[j] && !can_fuse(e, counts[j])) return fail(GUBER_E_BATCH_TOO_LARGE, "an engine's share is larger than its two-launch pipeline takes");
+        if (counts[j] && !fits_fused(e, counts[j])) return fail(GUBER_E_BATCH_TOO_LARGE, "an engine's share is larger than its two-launch pipeline takes");
         own = own || e == s->e;
         total += counts[j];
     }
@@ -1723,7 +1984,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
         if (engines[j]->small_pending) { const int r2 = resolve_small_locked(engines[j]->small_pending, true, engines[j]); if (r2 < 0) return r2; }
     if (b.n <= FT) {                                                 // a handful of requests: ONE launch, a workgroup per share, in place
         bool small_ok = true;
-        for (uint32_t j = 0; j < n_engines; ++j) small_ok = small_ok && !engines[j]->no_small;
+        for (uint32_t j = 0; j < n_engines; ++j) small_ok = small_ok && !engines[j]->no_small && !(counts[j] && lru_may_bind(engines[j], counts[j]));
         if (small_ok) {
             MultiSmallRouted MS{};
             s->parts.clear();
@@ -1737,7 +1998,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
                 const uint32_t seq = ++e->small_seq ? e->small_seq : ++e->small_seq;
                 SmallOut* out = (SmallOut*)(s->h_parts_out + 64 * s->parts.size());
                 out->done = 0;
-                MS.sub[s->parts.size()] = SmallRoutedSub{e->T, out, seq, e->touch, counts[j], j};
+                MS.sub[s->parts.size()] = SmallRoutedSub{e->T, out, e->touch, seq, counts[j], j};
                 s->parts.push_back(guber_stage::RoutedPart{e, j, counts[j], seq, out, true, 0});
             }
             MS.nb = (uint32_t)s->parts.size(); MS.n_total = b.n; MS.dest = s->h_dest; MS.B = BH;
@@ -1776,6 +2037,11 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
     MultiArgsMem* HA = s->h_margs; MultiArgsMem* DA = (MultiArgsMem*)e0->d_margs.p;
     uint32_t tiles = 0, base = 0; int planned = 0;
     guber_engine* took[MULTI_MEM_MAX]; uint32_t took_n[MULTI_MEM_MAX];
+    // a share that may overflow its engine's cache needs the eviction pre-pass (launch_batch), which reads the share's keys: then the
+    // shares are brought to HBM first and evaluated engine by engine
+    bool exact = false;
+    for (uint32_t j = 0; j < n_engines; ++j) exact = exact || (counts[j] && lru_may_bind(engines[j], counts[j]));
+    BatchView XB[MULTI_MEM_MAX]; ResultView XR[MULTI_MEM_MAX];
     for (uint32_t j = 0; j < n_engines; ++j) {
         A.base[j] = base;
         const uint32_t nj = counts[j];
@@ -1784,6 +2050,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
         BatchView B{nj, 0, d_keys, A.d_key_off + base, A.d_hits + base, A.d_limit + base, A.d_duration + base, A.d_burst + base, A.d_created_at + base,
                     A.d_algorithm + base, A.d_behavior + base, A.d_is_owner + base, nullptr, nullptr, b.now_ms, 0, A.d_key_len + base};
         ResultView R{o_status + base, o_limit + base, o_remaining + base, o_reset + base, o_err + base};
+        if (exact) { XB[planned] = B; XR[planned] = R; took[planned] = e; took_n[planned] = nj; ++planned; base += nj; continue; }
         Work W; FastPlan FP;
         int rc = batch_prelude(e, B, W);
         if (!rc) rc = plan_fast(e, B, false, W, FP);
@@ -1805,6 +2072,15 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
     A.nb_arg = 4;
     hipStream_t st = e0->stream;
     hipLaunchKernelGGL(k_stage_in_routed, dim3(A.nb_req + A.nb_key + A.nb_arg), dim3(256), 0, st, A);
+    if (exact) {
+        for (int i = 0; i < planned; ++i) { const int rc = launch_batch(took[i], XB[i], XR[i]); if (rc) return rc; }
+        hipLaunchKernelGGL(k_stage_out_routed, dim3(A.nb_req), dim3(256), 0, st, O);
+        if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+        if (hipEventRecord(s->ev, st) != hipSuccess) return fail(GUBER_E_HIP, "hipEventRecord");
+        s->routed.assign(engines, engines + n_engines);
+        s->gev = nullptr; s->mode = 2;
+        return GUBER_OK;
+    }
     e0->span_begin(KT_FRONT_MULTI, n);
     hipLaunchKernelGGL(k_front_multi_mem, dim3(tiles), dim3(FT), 0, st, (const MultiFrontMem*)&DA->F);
     e0->span_end();
@@ -1907,7 +2183,7 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
         cleanup(); return fail(GUBER_E_HIP, "add_items H2D", he);
     }
     hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p);
-    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p, (e->touch = (e->touch + 1) & 0x7fffffffu));
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p, take_stamps(e, n));
     std::vector<uint8_t> res(n);
     if ((he = hipMemcpyAsync(res.data(), d_res.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipStreamSynchronize(st)) != hipSuccess) {
@@ -1935,7 +2211,7 @@ static int add_items_locked(guber_engine_t* e, const guber_item_t* items, uint32
         const int rc = maintain(e, n, e->clock_ms);
         if (rc) return rc;
     }
-    e->tags_upper += n; e->size_upper += n; e->rb_added += n;
+    note_enqueued(e, n);
     // LRUCache.Add is applied item by item (workers.go:566-581): with duplicates of a key in one call
     // the LAST one must win and the later ones report existed = 1.  Waves of distinct keys keep that.
     std::vector<uint8_t> res(n, 0);
@@ -1983,7 +2259,7 @@ static int item_lookup(guber_engine* e, const uint8_t* key, uint32_t key_len, in
     hipError_t he;
     if ((he = hipMemcpyAsync(d_key.p, kb.data(), kb.size(), hipMemcpyHostToDevice, st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup H2D", he); }
     if (mode == 0 && now_ms > e->clock_ms) e->clock_ms = now_ms;
-    hipLaunchKernelGGL(k_item_lookup, dim3(1), dim3(64), 0, st, e->T, d_key.p, key_len, now_ms, mode, d_rec.p, d_found.p, (e->touch = (e->touch + 1) & 0x7fffffffu));
+    hipLaunchKernelGGL(k_item_lookup, dim3(1), dim3(64), 0, st, e->T, d_key.p, key_len, now_ms, mode, d_rec.p, d_found.p, take_stamps(e, 1));
     if ((he = hipMemcpyAsync(&hfound, d_found.p, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipMemcpyAsync(&hrec, d_rec.p, sizeof(Rec), hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipStreamSynchronize(st)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "lookup D2H", he); }
@@ -2020,11 +2296,11 @@ extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to
         taken = true;
         rc = maintain(to, n, to->clock_ms);
         if (rc) break;
-        to->tags_upper += n; to->size_upper += n; to->rb_added += n;
+        note_enqueued(to, n);
         hipStream_t st = to->stream;
         hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, to->T, from->d_items.p, from->d_ikeys.p, n, to->d_islots.p, to->d_iflags.p);
         hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, to->T, from->d_items.p, from->d_ikeys.p, n, to->d_islots.p, to->d_iflags.p,
-                           to->d_ires.p, (to->touch = (to->touch + 1) & 0x7fffffffu));
+                           to->d_ires.p, take_stamps(to, n));
         if ((he = hipMemcpyAsync(res.data(), to->d_ires.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
         he = hipStreamSynchronize(st);
     } while (0);
@@ -2068,6 +2344,7 @@ extern "C" int guber_stats(guber_engine_t* e, guber_stats_t* out) {
     out->unexpired_evictions = c.evictions; out->cache_size = c.size; out->table_slots = e->slots;
     out->tags_used = c.tags_used; out->batches = e->batches; out->retries = c.retries; out->compactions = e->compactions;
     out->small_batches = e->small_batches; out->fused_batches = e->fused_batches;
+    out->eviction_passes = e->lru_applied; out->tail_rebuilds = e->lru_rebuilds; out->batch_cuts = e->lru_cuts;
     return GUBER_OK;
 }
 extern "C" int64_t guber_size(guber_engine_t* e) {
@@ -2242,14 +2519,14 @@ extern "C" int guber_add_items_dev(guber_engine_t* e, const guber_items_dev_t* i
         const int rc = maintain(e, n, e->clock_ms);
         if (rc) return rc;
     }
-    e->tags_upper += n; e->size_upper += n; e->rb_added += n;
+    note_enqueued(e, n);
     if (e->d_items.ensure(n) || e->d_islots.ensure(n) || e->d_iflags.ensure(n)) return GUBER_E_NOMEM;
     ItemsSoA S{it->key_off, it->algorithm, it->status, it->limit, it->duration, it->remaining, it->remaining_f, it->stamp, it->burst,
                it->expire_at, it->invalid_at};
     hipStream_t st = e->stream;
     hipLaunchKernelGGL(k_items_from_soa, dim3((n + 255) / 256), dim3(256), 0, st, S, n, e->d_items.p);
     hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p);
-    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p, result, (e->touch = (e->touch + 1) & 0x7fffffffu));
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, e->d_items.p, it->key_bytes, n, e->d_islots.p, e->d_iflags.p, result, take_stamps(e, n));
     HIPCHK(hipGetLastError());
     return GUBER_OK;
 }
@@ -2346,93 +2623,55 @@ static int compact_table(guber_engine* e, int64_t now_ms) {
     e->T.dir = e->dir.p; e->T.buckets = e->buckets.p; e->T.arena = e->arena.p;
     e->tags_upper = co.kept; e->size_upper = co.live;
     e->last_ctr.size = (long long)co.live; e->last_ctr.tags_used = co.kept;
-    e->rb_inflight = false; e->rb_added = 0;
+    rb_disarm_all(e);
+    e->lru_tail_ok = false;                                          // the tail list names slots of the old table
     e->compactions++;
     return 0;
 }
 
-// Evict the least recently used items until at most `target` are live (lrucache.go:98-100,138-149; order approximated by
-// the epoch of the last touch, expired items first).  The counters must be fresh (engine_refresh_counters).
-static int evict_to(guber_engine* e, uint64_t target, int64_t now_ms) {
-    const uint64_t live = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
-    if (live <= target) return 0;
-    const uint64_t need = live - target;
-    DevBuf<unsigned long long> d_hist, d_q;
-    if (d_hist.ensure(EV_BINS) || d_q.ensure(4)) { d_hist.release(); d_q.release(); return GUBER_E_NOMEM; }
-    auto cleanup = [&]() { d_hist.release(); d_q.release(); };
-    std::vector<unsigned long long> hist(EV_BINS);
-    hipError_t he;
-    const unsigned blocks = (unsigned)std::min<uint64_t>((e->slots + 255) / 256, 4096);
-    if ((he = hipMemsetAsync(d_hist.p, 0, EV_BINS * 8, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
-    hipLaunchKernelGGL(k_evict_hist, dim3(blocks), dim3(256), 0, e->stream, e->T, e->slots, now_ms, e->touch, d_hist.p);
-    if ((he = hipMemcpyAsync(hist.data(), d_hist.p, EV_BINS * 8, hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
-        (he = hipStreamSynchronize(e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
-    // exactly `need` items go: expired ones first (they are dead anyway and do not count), then whole age classes from
-    // the oldest down, then a quota of the class at the cut
-    const unsigned long long q_expired = std::min<unsigned long long>(need, hist[0]);
-    uint64_t left = need - q_expired;
-    uint32_t cut = EV_BINS;                       // classes > cut are dropped entirely
-    unsigned long long quota = 0;
-    for (uint32_t b = EV_BINS - 1; b >= 1 && left > 0; --b) {
-        if (hist[b] <= left) { left -= hist[b]; cut = b - 1; }
-        else { cut = b; quota = left; left = 0; }
-    }
-    unsigned long long q[4] = {quota, 0, 0, q_expired};
-    if ((he = hipMemcpyAsync(d_q.p, q, sizeof(q), hipMemcpyHostToDevice, e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
-    hipLaunchKernelGGL(k_evict_apply, dim3((unsigned)((e->slots + 255) / 256)), dim3(256), 0, e->stream, e->T, e->slots, now_ms, e->touch,
-                       cut, d_q.p);
-    if ((he = hipMemcpyAsync(q, d_q.p, sizeof(q), hipMemcpyDeviceToHost, e->stream)) != hipSuccess ||
-        (he = hipStreamSynchronize(e->stream)) != hipSuccess) { cleanup(); return fail(GUBER_E_HIP, "evict", he); }
-    cleanup();
-    // fold into the device counters (the kernels only cleared the buckets)
-    DevCounters c;
-    HIPCHK(hipMemcpy(&c, e->ctr.p, sizeof(c), hipMemcpyDeviceToHost));
-    c.size -= (long long)q[1]; c.evictions += q[2];
-    HIPCHK(hipMemcpy(e->ctr.p, &c, sizeof(c), hipMemcpyHostToDevice));
-    e->last_ctr.size -= (long long)q[1]; e->last_ctr.evictions += q[2];
-    e->size_upper = (uint64_t)std::max<long long>(e->last_ctr.size, 0);
-    e->evict_passes++;
-    return 0;
+// Bring the cache down to cache_size: the least recently used items go, in the list's exact order (lrucache.go:98-100,138-149).
+// Batches never leave the cache above its size (their pre-pass evicts as the reference does, in the middle of the batch); this is
+// what Add / UpdatePeerGlobals / Load need — adding n items and then dropping the oldest leaves exactly the items the reference's
+// item-by-item Add leaves — and the safety net behind everything else.
+static int evict_to_size(guber_engine* e, int64_t now_ms) {
+    uint32_t st = 0;
+    const LruKeys none{};
+    const int rc = lru_admit(e, none, 0, now_ms, &st);
+    if (!rc) e->evict_passes++;
+    return rc;
 }
 
 // Keep the cache within cache_size and the directory under its load limit before `incoming` more requests arrive.
-// The bounds are upper bounds (every request might create an item).  Crossing a SOFT limit only enqueues an asynchronous
-// read-back of the real counters, folded by a later call once its event has completed; the stream is drained only when
-// an eviction / rebuild is really due or a HARD limit (physical room) is at stake.
+// The bounds are upper bounds (every request in flight might create an item).  Near a limit, counter snapshots are kept on their
+// way (one riding on every batch) and folded as they complete; the stream is drained only when an eviction / rebuild is really
+// due or a HARD limit (physical room) is at stake.
 static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows) {
     const uint64_t tag_limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
     const uint64_t hard_size = e->cache_size + std::max<uint64_t>(e->cache_size / 2, 4ull * e->max_batch);
-    if (e->snap_pending && !batch_follows) {              // a read-back that was to ride on a batch that never came: launch it now
-        hipLaunchKernelGGL(k_ctr_snapshot, dim3(1), dim3(256), 0, e->stream, e->ctr.p, e->bctr.p, e->n_bctr, e->h_ctr.p, e->h_bctr.p, e->h_rb_seq.p, e->rb_seq);
-        e->snap_pending = false;
+    if (e->rb_ride >= 0 && !batch_follows) {              // a snapshot that was to ride on a batch that never came: launch it now
+        const uint32_t i = (uint32_t)e->rb_ride;
+        e->rb_ride = -1;
+        rb_launch(e, i);
     }
-    if (e->rb_inflight && !e->snap_pending && counter_readback_done(e)) {
-        const uint64_t added = e->rb_added;
-        fold_counters(e);                                 // exact as of the read-back; what was enqueued since is added back
-        e->size_upper += added; e->tags_upper += added;
-    }
-    const bool soft = e->size_upper > e->cache_size || e->tags_upper + incoming > tag_limit;
-    if (!soft) return 0;
-    const bool sure_over = (uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size && !e->rb_inflight;
-    const bool hard = incoming == 0 || e->size_upper > hard_size || e->tags_upper + incoming > tag_limit || sure_over;
+    if (rb_any_armed(e)) rb_fold_newest(e);                // exact as of the newest completed snapshot + what was enqueued since
+    // A call whose size bound reaches cache_size goes through the eviction pre-pass, which synchronises (lru_may_bind / lru_admit),
+    // so the bound is tightened EARLY: from 16 calls' worth of requests below a limit on, every batch carries a snapshot, and the
+    // bound a decision is taken on is the exact count a few batches ago plus what was enqueued since.
+    const uint64_t early = std::min<uint64_t>(16 * incoming, e->cache_size / 2);
+    const bool over = e->size_upper > e->cache_size, tags = e->tags_upper + incoming > tag_limit;
+    const bool near = e->size_upper + incoming + early > e->cache_size || e->tags_upper + incoming + early > tag_limit;
+    if (!over && !tags && !near) return 0;
+    const bool sure_over = (uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size && !rb_any_armed(e);
+    const bool hard = (incoming == 0 && (over || tags)) || e->size_upper > hard_size || tags || sure_over;
     if (!hard) {
-        if (!e->rb_inflight) {
-            if (batch_follows) {                              // no launch of its own: the batch's k_front carries it
-                if (e->h_rb_seq.ensure(1)) return GUBER_E_NOMEM;
-                ++e->rb_seq;
-                e->snap_pending = true;
-            } else {
-                int rc = enqueue_counter_readback(e);
-                if (rc) return rc;
-            }
-            e->rb_inflight = true; e->rb_added = 0;
-        }
+        if (batch_follows) (void)rb_arm(e, true);            // no launch of its own: the batch's first kernel carries it
+        else if (!rb_any_armed(e)) { (void)rb_arm(e, false); HIPCHK(hipGetLastError()); }
         return 0;
     }
     int rc = engine_refresh_counters(e);
     if (rc) return rc;
     if ((uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size) {
-        rc = evict_to(e, e->cache_size - e->cache_size / 64, now_ms);   // a little below the bound, so that a churning key set does not evict every batch
+        rc = evict_to_size(e, now_ms);
         if (rc) return rc;
     }
     if (e->tags_upper + incoming > tag_limit) {

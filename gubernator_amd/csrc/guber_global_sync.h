@@ -646,13 +646,13 @@ extern "C" int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_s
         st.bytes_moved += (uint64_t)n * gs_item_rb(c); r->last.bytes_moved += (uint64_t)n * gs_item_rb(c);
         if (!n) continue;
         rc = maintain(e, n, now_ms); if (rc) return rc;
-        e->tags_upper += n; e->size_upper += n; e->rb_added += n;
+        note_enqueued(e, n);
         if (r->item_in.ensure(n) || r->islots.ensure(n) || r->iflags.ensure(n) || r->ires.ensure(n)) return GUBER_E_NOMEM;
         HIPCHK(hipMemsetAsync(&r->ctr.p->bad, 0, sizeof(unsigned int), e->stream));
         hipLaunchKernelGGL(k_gs_item_in, dim3((n + 255) / 256), dim3(256), 0, e->stream, r->items_recv.p, c->stride, n, r->item_in.p);
         hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, r->item_in.p, r->items_recv.p, n, r->islots.p, r->iflags.p);
         hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->T, r->item_in.p, r->items_recv.p, n, r->islots.p, r->iflags.p, r->ires.p,
-                           (e->touch = (e->touch + 1) & 0x7fffffffu));
+                           take_stamps(e, n));
         hipLaunchKernelGGL(k_gs_count_bad, dim3((n + 255) / 256), dim3(256), 0, e->stream, r->ires.p, n, r->ctr.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(r->h_ctr.p, r->ctr.p, sizeof(GsCounters), hipMemcpyDeviceToHost, e->stream));

@@ -585,6 +585,7 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
                 else if (leaky_fast(s0, r, B.now_ms, rank, out, after, ev)) done = true;
             }
             const bool walk = !parallel && rank == 0;
+            uint32_t lastj = i;                                          // the run's last request (walk: the last one walked)
             if ((parallel && !done) || walk) {
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
@@ -617,6 +618,7 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
                             }
                         }
                         if (end) break;
+                        lastj = j;
                         cur = load_req(B, j);
                     }
                     const Rec before = after;
@@ -661,7 +663,7 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             }
             if ((parallel && rank == total - 1) || walk) {
-                after.pad = W.touch;                                  // last touch (approximate LRU order for eviction)
+                rec_set_stamp(after, W.touch + lastj);                // the key's place in the recency order: its last request (lrucache.go:111-128)
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);

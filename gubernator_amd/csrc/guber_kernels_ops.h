@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_items_probe(Table T, const ItemIn* item
 // phase B: verify tentative matches, publish READY, LRUCache.Add (lrucache.go:88-103): replace the
 // value when the key is resident (existed = 1), insert otherwise.  result: 0/1 existed, 0xFF retry, 0xFE error
 __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
-                                                      const uint32_t* slots, const uint8_t* flags, uint8_t* result, uint32_t touch) {
+                                                      const uint32_t* slots, const uint8_t* flags, uint8_t* result, uint64_t touch) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint8_t f = flags[i];
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* ite
     if ((f & RF_NEED_VERIFY) && !key_equal(T, slot, keys + items[i].key_off, items[i].key_len)) { result[i] = 0xFF; return; }
     const bool existed = rec_kind(T.buckets[slot].rec) != K_ABSENT;
     Rec nr = items[i].rec;
-    nr.pad = touch;                                   // LRUCache.Add pushes / moves the item to the front (lrucache.go:91,96)
+    rec_set_stamp(nr, touch + i);                     // LRUCache.Add pushes / moves the item to the front (lrucache.go:91,96); item i of the call after item i - 1
     T.buckets[slot].rec = nr;
     if (!existed) atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
     result[i] = existed ? 1 : 0;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void k_items_restore(Table T, const ItemIn* ite
 }
 
 // LRUCache.GetItem (lrucache.go:111-128) / Remove (:131-135) for one key. mode 0 = get, 1 = remove
-__global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found, uint32_t touch) {
+__global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t now, int mode, Rec* out, int* found, uint64_t touch) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     *found = 0;
     uint32_t slot;
@@ -112,7 +112,7 @@ __global__ void k_item_lookup(Table T, const uint8_t* key, uint32_t len, int64_t
         return;
     }
     if (mode == 0) atomicAdd(&T.ctr->hits, 1ull);
-    T.buckets[slot].rec.pad = touch;                  // GetItem moves the item to the front (lrucache.go:123)
+    rec_set_stamp(s, touch); T.buckets[slot].rec = s;   // GetItem moves the item to the front (lrucache.go:123)
     *out = s; *found = 1;
 }
 
@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void k_global_take(Table T, uint32_t n, uint32
     T.gpend[slot] = z;
 }
 
-// Table compaction: re-insert every LIVE bucket (present and not expired at `now`) of the old table into a fresh one.
-// Expired buckets are indistinguishable from absent ones for the algorithm (lrucache.go:115-119 removes them on access),
-// removed / evicted buckets (K_ABSENT) only kept their tag for probing; both are dropped, which frees their directory
-// entries.  A bucket with a pending GLOBAL record is kept whatever its state and the record moves with it (new dirty list);
+// Table compaction: re-insert every bucket that holds an item into a fresh table.  Removed / evicted buckets (K_ABSENT) only kept
+// their tag for probing and are dropped, which frees their directory entries.  An item that has expired is still an item of the
+// reference's list until somebody asks for it or it reaches the back (lrucache.go:115-119, :138-149) — it takes a place, so it
+// moves with the others (`live` = the items moved).  A bucket with a pending GLOBAL record is kept whatever its state and the record moves with it (new dirty list);
 // long keys are copied into a fresh arena, so the space of dropped keys is reclaimed.
 struct CompactOut { unsigned long long kept, live, arena_head; unsigned int gdirty_n; };
 __global__ __launch_bounds__(256) void k_compact(Table Old, uint64_t old_slots, Table New, int64_t now, CompactOut* out) {
@@ -191,9 +191,8 @@ __global__ __launch_bounds__(256) void k_compact(Table Old, uint64_t old_slots, 
     if (tag == 0ull) return;
     Bucket b = Old.buckets[s];
     const bool pending = Old.gpend && Old.gpend[s].queued != 0;
-    const bool dead = rec_kind(b.rec) == K_ABSENT || rec_expired(b.rec, now);
+    const bool dead = rec_kind(b.rec) == K_ABSENT;
     if (dead && !pending) return;
-    if (dead && rec_kind(b.rec) != K_ABSENT) rec_clear(b.rec);       // kept for its pending record only
     const uint32_t len = (uint32_t)(b.cell.w[7] >> 48);
     if (len > INLINE_KEY && len != 0xffffu) {
         const uint64_t need = ((uint64_t)len + 7) & ~7ull;
@@ -216,66 +215,6 @@ __global__ __launch_bounds__(256) void k_compact(Table Old, uint64_t old_slots, 
             return;
         }
     }
-}
-
-// Bounded cache (lrucache.go:98-100,138-149): when more than cache_size items are live, the least recently used go.  Every
-// bucket carries the engine's touch counter at its last touch (Rec.pad: written by the request that ends a key's run in a
-// batch, by Add and by GetItem; the counter advances with every call, so items touched by different calls are ordered
-// exactly and items touched by one batch share a stamp).  Pass 1 counts the live buckets per age class, the host picks
-// the cut, pass 2 drops every class older than the cut and `quota` buckets of the class at the cut.  Buckets that are
-// already expired go first and do not count as unexpired evictions (lrucache.go:142-146).  Age classes are exact for the
-// newest 1024 stamps and 1/64-octave wide beyond; order inside a class is arbitrary: an approximation of the
-// reference's exact list order.
-constexpr uint32_t EV_EXACT = 1024, EV_BINS = 1 + EV_EXACT + 22 * 64;      // hist[0] = expired; hist[1 + class(age)]
-__device__ __forceinline__ uint32_t evict_bin(const Rec& r, int64_t now, uint32_t cur) {
-    if (rec_expired(r, now)) return 0u;
-    const uint32_t age = (cur - r.pad) & 0x7fffffffu;
-    if (age < EV_EXACT) return 1u + age;
-    const uint32_t e = 31u - (uint32_t)__clz((int)age);              // 10 .. 30
-    return 1u + EV_EXACT + (e - 10u) * 64u + ((age >> (e - 6u)) & 63u);
-}
-__global__ __launch_bounds__(256) void k_evict_hist(Table T, uint64_t slots, int64_t now, uint32_t cur, unsigned long long* hist) {
-    __shared__ uint32_t lh[EV_BINS];                                 // per-workgroup histogram: one global add per non-empty class
-    for (uint32_t j = threadIdx.x; j < EV_BINS; j += 256) lh[j] = 0u;
-    __syncthreads();
-    for (uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * 256) {
-        if (T.dir[s].tag == 0ull) continue;
-        const Rec r = T.buckets[s].rec;
-        if (rec_kind(r) == K_ABSENT) continue;
-        if (T.gpend && T.gpend[s].queued != 0) continue;             // pending GLOBAL work: not evictable
-        atomicAdd(&lh[evict_bin(r, now, cur)], 1u);
-    }
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < EV_BINS; j += 256)
-        if (lh[j]) atomicAdd(&hist[j], (unsigned long long)lh[j]);
-}
-__device__ __forceinline__ bool take_quota(unsigned long long* q) {   // one unit, never below zero
-    unsigned long long v = ld_agent(q);
-    while (v > 0ull) {
-        const unsigned long long old = atomicCAS(q, v, v - 1ull);
-        if (old == v) return true;
-        v = old;
-    }
-    return false;
-}
-// drop classes > cut_bin entirely, quota[0] buckets of class == cut_bin and quota[3] of the expired ones
-__global__ __launch_bounds__(256) void k_evict_apply(Table T, uint64_t slots, int64_t now, uint32_t cur, uint32_t cut_bin,
-                                                     unsigned long long* quota /* [0] quota at the cut, [1] evicted, [2] unexpired, [3] quota of expired */) {
-    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= slots || T.dir[s].tag == 0ull) return;
-    const Rec r = T.buckets[s].rec;
-    if (rec_kind(r) == K_ABSENT) return;
-    if (T.gpend && T.gpend[s].queued != 0) return;
-    const uint32_t b = evict_bin(r, now, cur);
-    bool drop = false;
-    if (b == 0u) drop = take_quota(&quota[3]);
-    else if (b > cut_bin) drop = true;
-    else if (b == cut_bin) drop = take_quota(&quota[0]);
-    if (!drop) return;
-    Rec z; rec_clear(z);
-    T.buckets[s].rec = z;
-    atomicAdd(&quota[1], 1ull);
-    if (b != 0u) atomicAdd(&quota[2], 1ull);
 }
 
 // wrap of the 31-bit batch epoch: forget every dense-id claim

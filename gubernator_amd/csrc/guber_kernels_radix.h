@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
                 if (rank == last - first) {
-                    after.pad = W.touch;                          // last touch (approximate LRU order for eviction)
+                    rec_set_stamp(after, W.touch + i);            // the key's place in the recency order: its last request
                     T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                     if (out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     if (out.err == 0) queue_global(T, slot, rj, 1);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
-                s.pad = W.touch;
+                rec_set_stamp(s, W.touch + W.order[last]);
                 T.buckets[slot].rec = s;
                 c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
             }

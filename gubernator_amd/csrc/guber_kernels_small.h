@@ -30,7 +30,7 @@ struct SmallReqs {
 
 // map (LDS, or nullptr): request tid of this workgroup's batch is entry map[tid] of the arrays B and R point at — a share of a
 // routed stage, picked out of the stage's arrival order (k_small_routed)
-__device__ __forceinline__ void small_body(const Table& T, const BatchView& B, const ResultView& R, SmallOut* out, const uint32_t seq, const uint32_t touch,
+__device__ __forceinline__ void small_body(const Table& T, const BatchView& B, const ResultView& R, SmallOut* out, const uint32_t seq, const uint64_t touch,
                                            const uint32_t* map = nullptr) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
     __shared__ unsigned long long gkey[GT];
@@ -196,7 +196,7 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
             store_resp(R, at, o);
             c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             if (rank == total - 1) {
-                after.pad = touch;
+                rec_set_stamp(after, touch + tid);                          // the key's place in the recency order: its last request
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
                 if (o.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
@@ -222,12 +222,12 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
         __hip_atomic_store(&out->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-__global__ __launch_bounds__(FT) void k_small(Table T, BatchView B, ResultView R, SmallOut* out, uint32_t seq, uint32_t touch) { small_body(T, B, R, out, seq, touch); }
+__global__ __launch_bounds__(FT) void k_small(Table T, BatchView B, ResultView R, SmallOut* out, uint32_t seq, uint64_t touch) { small_body(T, B, R, out, seq, touch); }
 
 // the small batches of several engines (the logical shards of a GPU: one table each) in ONE launch, one workgroup per batch —
 // what a pool's dispatcher has when a handful of requests arrive spread over its shards (guber_stages_submit)
 constexpr int SMALL_MULTI_MAX = 8;
-struct SmallArgs { Table T; BatchView B; ResultView R; SmallOut* out; uint32_t seq, touch; };
+struct SmallArgs { Table T; BatchView B; ResultView R; SmallOut* out; uint64_t touch; uint32_t seq; };
 struct MultiSmall { uint32_t nb; SmallArgs sub[SMALL_MULTI_MAX]; };
 static_assert(sizeof(MultiSmall) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(FT) void k_small_multi(MultiSmall A) {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(FT) void k_small_multi(MultiSmall A) {
 // arrival order by the dest column (engine << 24 | rank: the rank is the request's place in the workgroup), then runs the
 // one-launch body on them in place.  Every share reports its own outcome (SmallOut): a share the fast path declines is re-run by
 // the host through the general pipeline, the others stand.
-struct SmallRoutedSub { Table T; SmallOut* out; uint32_t seq, touch, n, engine; };
+struct SmallRoutedSub { Table T; SmallOut* out; uint64_t touch; uint32_t seq, n, engine; };
 struct MultiSmallRouted { uint32_t nb, n_total; const uint32_t* dest; BatchView B; ResultView R; SmallRoutedSub sub[16]; };
 static_assert(sizeof(MultiSmallRouted) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(FT) void k_small_routed(MultiSmallRouted A) {

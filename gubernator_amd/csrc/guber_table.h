@@ -138,7 +138,7 @@ struct Work {
     uint32_t* hist;        // [MAX_PASSES][tiles][RADIX], raw per-tile digit counts
     uint32_t tiles;        // tiles of this batch
     uint32_t epoch;        // 1 .. 2^31-1
-    uint32_t touch;        // the engine's touch counter for this batch (Rec.pad of every bucket the batch writes: LRU order)
+    uint64_t touch;        // the recency stamp of this batch's request 0 (request i carries touch + i: rec_set_stamp by the request that ends a key's run)
     // tile-bitmap grouping (batches of <= FT_MAX_TILES tiles of FT requests): per segment a bitmap of the tiles holding its
     // requests and, per (segment, tile), the group's size and start inside the tile's sorted order.
     // seg_tilemask is double-buffered by batch parity: a batch's eval kernel clears, in the other copy, the words the

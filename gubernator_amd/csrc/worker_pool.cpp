@@ -104,7 +104,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     guber_config_t c = cfg;
     if (c.max_batch < stage_cap_) c.max_batch = stage_cap_;
     const uint32_t total = n_devices_ * shards;
-    const uint64_t per_shard = total > 1 ? cfg.cache_size / total + 1 : cfg.cache_size;   // workers.go:132 `CacheSize / Workers` per worker
+    const uint64_t per_shard = cfg.cache_size / total;   // workers.go:132 `CacheSize / Workers` per worker (0 -> the engine takes NewLRUCache's default of 50 000, lrucache.go:62)
     max_key_ = c.max_key_bytes ? c.max_key_bytes : 1024;
     // room for batch_limit keys of typical size; a batch whose keys do not fit is flushed early (never overrun)
     key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)stage_cap_ * std::min<uint32_t>(max_key_, 96u) + max_key_, (1u << 24) - 1);

@@ -180,6 +180,9 @@ typedef struct guber_stats {
     uint64_t compactions;     /* table rebuilds (guber_compact or automatic) */
     uint64_t small_batches;   /* batches of <= 256 requests answered by the one-launch path */
     uint64_t fused_batches;   /* batches that shared their two launches with other engines' batches (guber_eval_batches_routed_dev) */
+    uint64_t eviction_passes; /* eviction pre-passes that evicted (a call that would have overflowed the cache: "Bounded cache" below) */
+    uint64_t tail_rebuilds;   /* times the recency order of the live items was rebuilt from the table (one scan + one sort) */
+    uint64_t batch_cuts;      /* batches larger than the cache that were evaluated in pieces of cache_size requests */
 } guber_stats_t;
 
 /* ---- lifecycle: NewWorkerPool / WorkerPool.Close (workers.go:125,157) -------- */
@@ -337,22 +340,31 @@ typedef struct guber_store_events {
 int guber_probe_missing(guber_engine_t* e, const guber_batch_t* b, uint8_t* missing);
 int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r, guber_store_events_t* ev);
 
-/* ---- bounded cache: the reference keeps at most CacheSize items and evicts the least recently used when an Add makes it
- *      grow beyond that (lrucache.go:98-100,138-149), counting the evictions of items that had not expired yet
- *      (gubernator_unexpired_evictions_count, :142-146).  The engine does the same between batches: every bucket carries the
- *      batch epoch of its last touch; when more than cache_size items are live the oldest are dropped — already-expired
- *      ones first, which do not count — until cache_size (minus 1/64 of hysteresis) remain, and guber_result_t /
- *      guber_stats_t.unexpired_evictions report the rest.  Differences from the reference's exact list order (documented in
- *      DESIGN.md): order inside one batch epoch is arbitrary; a batch that brings more new keys than fit is evaluated first
- *      and trimmed afterwards (the table is sized for cache_size + max_batch items), so a key requested twice in such a batch
- *      is not evicted between its two requests; buckets holding pending GLOBAL work are never evicted.
- *      MEASURED (tests/test_gpu_parity.py test_evicted_keys_that_return_measure_the_lru_divergence): as long
- *      as evicted keys do not come back at once the answers equal a bounded LRU's; when they do — 2 600 keys cycling over a
- *      cache of 2 000 — 49.5 % of the answers of a cyclic scan and 18.9 % of a random walk are those of a bucket that lived
- *      longer or shorter than the reference's (fresh or old state, never wrong arithmetic).
- *      The directory entries of evicted / expired / removed keys are reclaimed by a rebuild of the table (guber_compact,
+/* ---- bounded cache: the reference keeps at most CacheSize items in a list ordered by last access (Add and GetItem move an
+ *      item to the front, lrucache.go:88-128) and removes the item at the back the moment an insert makes the list longer than
+ *      that (:98-100, :138-149) — in the middle of a stream of requests: a key evicted by request i is a new item for request
+ *      j > i — counting the evictions of items that had not expired yet (gubernator_unexpired_evictions_count, :142-146).
+ *      The engine keeps exactly that list: every bucket carries the sequence number of the last request that touched it (53
+ *      bits; request i of a batch after request i - 1, the items of an Add in their order), and a call that may overflow the
+ *      cache (live items + requests > cache_size) first goes through an eviction pre-pass that decides, from the order of the
+ *      batch's first accesses and the recency order of the resident items, which resident keys are gone before the batch first
+ *      asks for them (their buckets become absent: the batch sees a new key, as the reference does) and which untouched items
+ *      leave; a batch larger than cache_size is evaluated in pieces of cache_size requests (guber_stats_t.batch_cuts).
+ *      Expired items keep their place until somebody asks for them or they reach the back, as in the reference; items with
+ *      pending GLOBAL work are evicted like any other (the pending record stays queued, as the reference's queues do).
+ *      Every answer, LRUCache.Size() and the unexpired evictions equal the reference's on the same request sequence
+ *      (tests/test_gpu_parity.py test_evicted_keys_that_return_meet_the_reference_list,
+ *      test_a_batch_larger_than_the_cache_is_evaluated_in_pieces; tests/test_kernels_devsim.py on the CPU).  What is NOT
+ *      reproduced: a request with an invalid algorithm refreshes a resident key's recency (the reference rejects it before
+ *      the cache, workers.go:317-321); a key whose requests ALL fail inside the algorithm (an invalid Gregorian interval) is
+ *      counted as an insert when the pre-pass sizes the evictions; duplicates of one key inside one guber_add_items call are
+ *      applied in waves (last one wins, as in the reference, but the recency order among the call's keys follows the waves).
+ *      Cost: nothing while live items + requests <= cache_size (size the cache with a batch of headroom); beyond that one
+ *      pre-pass per batch (a dozen small launches and one stream synchronisation; the recency order of the live items comes
+ *      from one table scan + sort per ~live/(2 x batch) batches: guber_stats_t.tail_rebuilds).
+ *      The directory entries of evicted / removed keys are reclaimed by a rebuild of the table (guber_compact,
  *      also automatic when the directory passes 7/8 full; GLOBAL engines included, pending records move with their
- *      buckets; the long-key arena is rebuilt too).  Only when the LIVE set itself cannot be placed do new keys get
+ *      buckets; the long-key arena is rebuilt too).  Only when the items themselves cannot be placed do new keys get
  *      GUBER_ITEM_E_TABLE_FULL — per item; resident keys are always served.
  *      The engine has no clock: "now" arrives with every batch; maintenance between batches (eviction right after
  *      guber_add_items) classifies items as expired against the latest value seen, which guber_set_clock overrides

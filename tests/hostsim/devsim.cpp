@@ -10,6 +10,7 @@
 
 #define GUBER_KERNELS_PIPELINES_ONLY
 #include "../../gubernator_amd/csrc/guber_kernels.h"
+#include "../../gubernator_amd/csrc/guber_kernels_lru.h"
 #include "../../include/guber_gpu.h"
 
 // ---- the fiber runtime behind fakehip ------------------------------------------------------------------------------------
@@ -114,12 +115,82 @@ struct DevSim {
     std::vector<DirEntry> dir; std::vector<Bucket> buckets; std::vector<uint8_t> arena; DevCounters ctr{}; std::vector<BlockCounters> bctr;
     std::vector<uint32_t> u32; std::vector<uint8_t> rflags; std::vector<unsigned long long> tilemask, claims, segtiles; std::vector<SegRec> srec;
     std::vector<int64_t> sinv; std::vector<uint16_t> tilerow; std::vector<uint32_t> did2, did3, gse; std::vector<GMsg> gmsg; std::vector<GRec> grec;
-    uint32_t epoch16 = 0, fast_batches = 0, fast_prev_n = 0, touch = 0, claims_cells = 0;
+    uint32_t epoch16 = 0, fast_batches = 0, fast_prev_n = 0, claims_cells = 0;
+    uint64_t seq_next = 1;
+    // the bounded cache (guber_kernels_lru.h), driven as guber_engine.hip lru_admit / lru_rebuild drive it
+    uint64_t cache_size = 0; LruCtl ctl{}; std::vector<unsigned long long> tstamp; std::vector<uint32_t> tslot; bool tail_ok = true;
+    uint64_t admits = 0, applied = 0, rebuilds = 0, cuts = 0, passes = 0;
 };
+static long long ds_size(DevSim* d) { long long sz = d->ctr.size; for (auto& bc : d->bctr) sz += bc.size_delta; return sz; }
+static void ds_rebuild(DevSim* d) {
+    std::vector<unsigned long long> st(d->slots); std::vector<uint32_t> sl(d->slots);
+    unsigned long long cnt = 0;
+    fakehip::launch(dim3((unsigned)((d->slots + 255) / 256)), dim3(256), nullptr, [&] { k_lru_gather(d->T, d->slots, st.data(), sl.data(), d->slots, &cnt); });
+    std::vector<uint32_t> ord(cnt);
+    for (uint32_t i = 0; i < cnt; ++i) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return st[a] < st[b]; });
+    d->tstamp.assign(cnt + 16, 0); d->tslot.assign(cnt + 16, 0);
+    for (uint32_t i = 0; i < cnt; ++i) { d->tstamp[i] = st[ord[i]]; d->tslot[i] = sl[ord[i]]; }
+    d->ctl.cursor = 0; d->ctl.tail_n = cnt;
+    d->tail_ok = true; d->rebuilds++;
+}
+// the launch sequence of lru_admit (guber_engine.hip); returns the status
+static uint32_t ds_admit(DevSim* d, const LruKeys& K, uint32_t n, int64_t now) {
+    uint32_t cells = 1024; while (cells < 2 * (uint64_t)n) cells <<= 1;
+    d->admits++;
+    if (d->tstamp.empty()) { d->tstamp.assign(16, 0); d->tslot.assign(16, 0); }
+    uint64_t w_len = std::max<uint64_t>(2 * (uint64_t)n, 64);            // (small on purpose: the tests go through LRU_MORE)
+    for (int round = 0; round < 64; ++round) {
+        if (!d->tail_ok) ds_rebuild(d);
+        if (w_len > d->tstamp.size()) w_len = d->tstamp.size();
+        const uint32_t W = (uint32_t)w_len, wblocks = (W + 255) / 256;
+        const size_t nn = (size_t)n + 1;
+        std::vector<unsigned long long> gid(cells, ~0ull), rstamp(nn), zstamp(W + 1);
+        std::vector<uint32_t> gfirst(cells, 0xffffffffu), rfirst(nn), rslot(nn), zslot(W + 1), zwidx(W + 1), qfirst(nn), qrank(nn), qslot(nn), blockcnt(wblocks + 1),
+            new_before(nn), touched_before(W + 1);
+        std::vector<uint8_t> isnew_at(nn, 0), wflag(W + 1, 0), ztouched(W + 1, 0);
+        uint32_t n_risk = 0;
+        LruGroups G{gid.data(), gfirst.data(), cells - 1}; LruRes R{rfirst.data(), rslot.data(), rstamp.data()};
+        LruWin Z{zstamp.data(), zslot.data(), zwidx.data()}; LruRisk Q{qfirst.data(), qrank.data(), qslot.data()};
+        LruCtl* C = &d->ctl;
+        fakehip::launch(dim3(1), dim3(256), nullptr, [&] { k_lru_begin(d->T, C, (uint32_t)d->bctr.size()); });
+        if (n) {
+            fakehip::launch(dim3((n + 255) / 256), dim3(256), nullptr, [&] { k_lru_probe(d->T, K, n, G); });
+            fakehip::launch(dim3(cells / 256), dim3(256), nullptr, [&] { k_lru_keys(d->T, G, C, isnew_at.data(), R); });
+        }
+        if (W) {
+            fakehip::launch(dim3(wblocks), dim3(256), nullptr, [&] { k_lru_win_flag(d->T, d->tstamp.data(), d->tslot.data(), C, W, wflag.data(), blockcnt.data()); });
+            fakehip::launch(dim3(1), dim3(1024), nullptr, [&] { k_lru_scan_u32(blockcnt.data(), wblocks, &C->win_valid); });
+            fakehip::launch(dim3(wblocks), dim3(256), nullptr, [&] { k_lru_win_emit(d->tstamp.data(), d->tslot.data(), C, W, wflag.data(), blockcnt.data(), Z); });
+        }
+        fakehip::launch(dim3(1), dim3(1), nullptr, [&] { k_lru_check(C, W, n, d->cache_size); });
+        if (W) {
+            if (n) {
+                fakehip::launch(dim3((n + 255) / 256), dim3(256), nullptr, [&] { k_lru_risk(C, R, Z, ztouched.data(), Q, &n_risk); });
+                fakehip::launch(dim3(1), dim3(1024), nullptr, [&] { k_lru_scan_u8(isnew_at.data(), n, new_before.data()); });
+            }
+            fakehip::launch(dim3(1), dim3(1024), nullptr, [&] { k_lru_scan_u8(ztouched.data(), W, touched_before.data()); });
+            if (n) fakehip::launch(dim3((n + 255) / 256), dim3(256), nullptr, [&] { k_lru_decide(d->T, C, d->cache_size, Q, &n_risk, new_before.data(), now); });
+            fakehip::launch(dim3(wblocks), dim3(256), nullptr, [&] { k_lru_evict(d->T, C, Z, ztouched.data(), touched_before.data(), now); });
+            fakehip::launch(dim3(1), dim3(1), nullptr, [&] { k_lru_end(d->T, C, Z); });
+        }
+        d->passes++;
+        const uint32_t st = C->status;
+        if (st == LRU_NONE || st == LRU_APPLIED) { if (st == LRU_APPLIED) d->applied++; return st; }
+        if (st == LRU_CUT) { d->cuts++; return st; }
+        if (st == LRU_MORE) { w_len *= 4; continue; }
+        if (st == LRU_REBUILD) { d->tail_ok = false; w_len = std::max<uint64_t>(w_len, 2 * (uint64_t)n + C->zone); continue; }
+        return 0;
+    }
+    return 0;
+}
 
 extern "C" {
-void* ds_create(uint64_t slots, uint32_t max_batch, int weak_hash) {
+void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint64_t cache_size);
+void* ds_create(uint64_t slots, uint32_t max_batch, int weak_hash) { return ds_create_bounded(slots, max_batch, weak_hash, 0); }
+void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint64_t cache_size) {
     DevSim* d = new DevSim();
+    d->cache_size = cache_size;
     uint64_t s = 1024; while (s < slots) s <<= 1;
     d->slots = s; d->max_batch = max_batch; d->cap = (max_batch + 255u) & ~255u;
     d->dir.assign(s, DirEntry{0, 0}); d->buckets.resize(s); memset(d->buckets.data(), 0, s * sizeof(Bucket));
@@ -146,7 +217,10 @@ void* ds_create(uint64_t slots, uint32_t max_batch, int weak_hash) {
 void ds_destroy(void* h) { delete (DevSim*)h; }
 void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
 
-// pipeline 0: k_front + k_eval2 (careful = the retry round), 1: k_part + k_own + k_eval3
+static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int pipeline, int careful);
+// pipeline 0: k_front + k_eval2 (careful = the retry round), 1: k_part + k_own + k_eval3.  With a bounded cache (ds_create_bounded)
+// a batch that may overflow it goes through the eviction pre-pass and, when it is larger than the cache, in pieces — as
+// launch_batch (guber_engine.hip) does.
 int ds_eval(void* h, const guber_batch_t* b, guber_result_t* r, int pipeline, int careful) {
     DevSim* d = (DevSim*)h;
     const uint32_t n = b->n;
@@ -156,8 +230,39 @@ int ds_eval(void* h, const guber_batch_t* b, guber_result_t* r, int pipeline, in
                 b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
     B.key_stride = 0; B.key_len = nullptr;
     ResultView R{r->status, r->limit, r->remaining, r->reset_time, r->err};
+    if (!d->cache_size || (uint64_t)ds_size(d) + n <= d->cache_size) return ds_eval_piece(d, B, R, pipeline, careful);
+    for (uint32_t pos = 0; pos < n;) {
+        uint32_t len = n - pos;
+        auto slice = [&](uint32_t p, uint32_t l) {
+            BatchView S = B; S.n = l; S.key_off = B.key_off + p; S.hits = B.hits + p; S.limit = B.limit + p; S.duration = B.duration + p;
+            if (B.burst) S.burst = B.burst + p;
+            if (B.created_at) S.created_at = B.created_at + p;
+            if (B.algorithm) S.algorithm = B.algorithm + p;
+            if (B.behavior) S.behavior = B.behavior + p;
+            if (B.is_owner) S.is_owner = B.is_owner + p;
+            if (B.greg_expire) S.greg_expire = B.greg_expire + p;
+            if (B.greg_duration) S.greg_duration = B.greg_duration + p;
+            return S;
+        };
+        auto keys = [&](const BatchView& S) { LruKeys K{}; K.bytes = S.key_bytes; K.off_p = (const uint8_t*)S.key_off; K.off_stride = 4; K.algorithm = S.algorithm; return K; };
+        uint32_t st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms);
+        if (st == LRU_CUT) { len = (uint32_t)std::min<uint64_t>(len, d->cache_size); st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms); }
+        if (st != LRU_NONE && st != LRU_APPLIED) return -3;
+        const int rc = ds_eval_piece(d, slice(pos, len), ResultView{R.status + pos, R.limit + pos, R.remaining + pos, R.reset_time + pos, R.err + pos}, pipeline, careful);
+        if (rc) return rc;
+        pos += len;
+    }
+    return 0;
+}
+// admits, applied, rebuilds, cuts, passes, evicted unexpired (total)
+void ds_lru_stats(void* h, unsigned long long* out) {
+    DevSim* d = (DevSim*)h;
+    out[0] = d->admits; out[1] = d->applied; out[2] = d->rebuilds; out[3] = d->cuts; out[4] = d->passes; out[5] = d->ctr.evictions;
+}
+static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int pipeline, int careful) {
+    const uint32_t n = B.n;
     Work W = d->W;
-    W.touch = d->touch = (d->touch + 1) & 0x7fffffffu;
+    W.touch = d->seq_next; d->seq_next += n;
     const uint32_t tiles = (n + FT - 1) / FT;
     if (pipeline == 0) {
         W.careful = careful ? 1u : 0u;

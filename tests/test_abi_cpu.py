@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ga.GuberBatch) == 8 + 12 * 8 + 8
     assert C.sizeof(ga.GuberResult) == 5 * 8 + 5 * 8
     assert C.sizeof(ga.GuberItem) == 80
-    assert C.sizeof(ga.GuberStats) == 96
+    assert C.sizeof(ga.GuberStats) == 120
 
 
 def test_no_silent_cpu_fallback(L):

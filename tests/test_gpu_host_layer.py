@@ -245,6 +245,35 @@ def test_loader_round_trip_through_the_pool(shards):
     inst.close()
 
 
+@pytest.mark.parametrize("shards", [1, 4])
+def test_a_pool_whose_caches_bind_evicts_like_the_reference_workers(shards):
+    """workers.go:125-140: every worker has an LRUCache of CacheSize / workers items (lrucache.go:88-149).  A pool over a key
+    population larger than that, 1 000-item RPCs whose evicted keys come back at once: every answer equals the reference's worker
+    pool (the oracle with the same worker rule and per-worker bounded LRU) — through the pool's front stage, whose shares then go
+    through the engines' eviction pre-pass one engine at a time (guber_stage_submit_routed)."""
+    os.environ["GUBER_POOL_REBALANCE_MS"] = "0"          # the placement stays the reference's worker rule (no hot-key moves)
+    try:
+        inst = ga.V1Instance(cache_size=1200, batch_limit=1000, batch_wait_us=50, shards=shards)
+    finally:
+        del os.environ["GUBER_POOL_REBALANCE_MS"]
+    orc = support.Oracle(cache_size=1200, workers=shards)
+    rng = np.random.default_rng(21)
+    now = 1_700_000_000_000
+    for step in range(20):
+        inst.set_clock(now)
+        ids = rng.integers(0, 1700, 1000) if step % 3 else (step * 700 + np.arange(1000)) % 1700
+        reqs = [dict(name="lru", unique_key=f"k{int(i)}", hits=1, limit=1000, duration=3_600_000) for i in ids]
+        out = inst.GetRateLimits(reqs)
+        hb = support.HostBatch([f"lru_k{int(i)}" for i in ids], 1, 1000, 3_600_000, now, created_at=now)
+        want = orc.eval(hb)
+        got = np.array([o["remaining"] for o in out])
+        assert all(o["error"] == "" for o in out)
+        assert np.array_equal(got, np.asarray(want.remaining[:hb.n])), (step, np.nonzero(got != np.asarray(want.remaining[:hb.n]))[0][:10])
+        now += 100
+    assert inst.size() == orc.size()
+    inst.close()
+
+
 def test_pool_shards_follow_the_reference_worker_rule():
     """WorkerPool.getWorker (workers.go:153-155,180-184; workers_internal_test.go:51-54): shard = XXH64(key) >> 1 divided by
     2^63 / workers — the pool's key -> shard map must be exactly that, and every key must live in exactly one shard."""

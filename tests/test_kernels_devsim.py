@@ -25,13 +25,21 @@ def lib():
     L.ds_eval.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int, C.c_int]
     L.ds_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.ds_chaos.argtypes = [C.c_uint32]
+    L.ds_create_bounded.restype = C.c_void_p
+    L.ds_create_bounded.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
+    L.ds_lru_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     return L
 
 
 class Sim:
-    def __init__(self, lib, slots=4096, max_batch=4096, weak=0, pipeline=1):
+    def __init__(self, lib, slots=4096, max_batch=4096, weak=0, pipeline=1, cache_size=0):
         self.lib, self.pipeline = lib, pipeline
-        self.h = lib.ds_create(slots, max_batch, weak)
+        self.h = lib.ds_create_bounded(slots, max_batch, weak, cache_size)
+
+    def lru_stats(self):
+        out = (C.c_ulonglong * 6)()
+        self.lib.ds_lru_stats(self.h, out)
+        return dict(zip(("admits", "applied", "rebuilds", "cuts", "passes", "unexpired_evictions"), out))
 
     def eval(self, batch, careful=0):
         res = HostResult(batch.n)
@@ -202,3 +210,53 @@ def test_the_routing_kernels_agree_with_the_placement(lib):
             assert np.array_equal(dest[shard == e] & 0xffffff, np.arange(want_counts[e], dtype=np.uint32)), (rnd, e)   # arrival order
     lib.ds_chaos(0)
     pl.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+@pytest.mark.parametrize("pattern", ["cyclic", "random", "zipf", "expiring"])
+def test_bounded_cache_evicts_in_the_reference_order(lib, pipeline, pattern):
+    """lrucache.go:88-149 through the eviction pre-pass (guber_kernels_lru.h) + an unchanged pipeline: 2 600 keys over a cache of
+    2 000, batches of 1 500 in which evicted keys come back in the same and in the next batch — every answer, the size after every
+    batch and the count of unexpired evictions equal the bounded-LRU oracle.  cyclic = the classic worst case (every access of an
+    exact LRU misses), expiring = short durations with the clock moving (expired items still hold their place in the list)."""
+    cs, nkeys, bsz = 2000, 2600, 1500
+    sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
+    rng = np.random.default_rng(11)
+    z = streams.ZipfSampler(nkeys, seed=3)
+    now, pos = streams.NOW0, 0
+    for step in range(16):
+        if pattern == "cyclic":
+            ids = (pos + np.arange(bsz)) % nkeys
+            pos += bsz
+        elif pattern == "zipf":
+            ids = z.draw(bsz)
+        else:
+            ids = rng.integers(0, nkeys, bsz)
+        dur = 1500 if pattern == "expiring" else 3_600_000
+        b = HostBatch([f"lru_{int(i)}" for i in ids], 1, 1000, dur, now, algorithm=(ids & 1).astype(np.uint8))
+        want, got = orc.eval(b), sim.eval(b)
+        assert_results_equal(got, want, f"{pattern} step {step}")
+        assert sim.counters()[3] == orc.size() <= cs, step
+        now += 1000
+    st = sim.lru_stats()
+    assert st["unexpired_evictions"] == orc.counters()[3] and st["applied"] >= 1, st
+    assert sim.counters()[:3] == orc.counters()[:3]
+    sim.close()
+
+
+def test_batches_larger_than_the_cache_are_cut(lib):
+    """a cache of 300 items under batches of 1 000 requests over 500 keys: the batch is evaluated in pieces of cache_size requests,
+    a key evicted by request i is a new item for request j > i of the same batch (lrucache.go:98-100)"""
+    cs = 300
+    sim, orc = Sim(lib, slots=1 << 14, max_batch=4096, cache_size=cs), Oracle(cache_size=cs)
+    rng = np.random.default_rng(5)
+    now = streams.NOW0
+    for step in range(6):
+        ids = rng.integers(0, 500, 1000)
+        b = HostBatch([f"cut_{int(i)}" for i in ids], 1, 50, 3_600_000, now)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"step {step}")
+        assert sim.counters()[3] == orc.size() == cs
+        now += 10
+    st = sim.lru_stats()
+    assert st["cuts"] >= 5 and st["unexpired_evictions"] == orc.counters()[3], st
+    sim.close()
