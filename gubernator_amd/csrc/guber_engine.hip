@@ -346,7 +346,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (const char* v = getenv("GUBER_PIPELINE")) { if (!strcmp(v, "claims")) e->use_part = false; else if (!strcmp(v, "part")) e->part_single = true; }
     if (const char* v = getenv("GUBER_PART_MIN")) e->part_min = (uint32_t)std::max(257, atoi(v));
     if (e->force_part) e->part_min = 1;
-    rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure(e->cap256); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);
+    rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure((size_t)e->cap256 + e->cap256 / 2); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);   // (grec: 32-byte records first, then the 64-byte form)
     rc |= e->w_did3.ensure(e->cap256); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
@@ -398,7 +398,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
-    e->W.gmsg = e->w_gmsg.p; e->W.grec = e->w_grec.p; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
+    e->W.gmsg = e->w_gmsg.p; e->W.gshape = (GShape*)((char*)e->w_gmsg.p + (size_t)e->cap256 * 32);
+    e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
     { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096 + 3 * 2048);

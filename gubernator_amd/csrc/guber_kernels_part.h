@@ -41,7 +41,7 @@ struct alignas(64) GMsg {
     unsigned long long misc;             // gm_*: head thread 8 | members-1 8 | G_* 8 | key length 5 | behavior 6 | algorithm 2 | owner 1 | created_at: min 18 (ms from the batch clock, signed), span 8
 };
 static_assert(sizeof(GMsg) == 64, "one message = one 64-byte sector");
-enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_ODD = 16, G_LONG = 32 };
+enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_ODD = 16, G_LONG = 32, G_SHAPE0 = 64 };
 //   G_NONUNIFORM  members of the group differ in a request field other than created_at
 //   G_RETRY       members of the group differ in their key bytes (one hash, two keys)
 //   G_CREATED     members differ in created_at only (the range travels in misc)
@@ -49,6 +49,34 @@ enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_OD
 //   G_ODD         a request the packed shape cannot carry exactly (behavior bits above 5, an algorithm other than 0 / 1, calendar
 //                 values precomputed by the host): equal to nothing but the members of its own group
 //   G_LONG        key longer than 16 bytes: compared through the request's key bytes in memory
+//   G_SHAPE0      (compact messages only) hits / limit / duration / burst are those of the tile's request 0: gshape[tile * FT]
+//
+// GUBER_PART_COMPACT = 1: what travels between the three kernels is HALF the size — the pipeline's rate follows the number of
+// write transactions at the fabric (profiles/r03_*, r04_*: one 64-byte message and one 64-byte record per (key, tile) group are
+// 90 k of a batch's 142 k write requests), so
+//   * a message is 32 bytes {hash, key bytes, packed rest}: the four 64-bit request fields it used to carry are a SHAPE, written
+//     once per tile for the shape of the tile's request 0 (gshape[tile * FT]; a group whose requests have that shape says so:
+//     G_SHAPE0 — rate limits come in few shapes, a tile usually has one) and once per group that differs (gshape[tile * FT + head
+//     thread]).  The owner keeps the 256 tile shapes in LDS and rebuilds the 64-byte form in registers: everything behind the
+//     load is unchanged and as exact as before (a group with its own shape costs its owner one more dependent load);
+//   * a record is 32 bytes {remaining, stamp, expire_at, packed: slot 26 | total 16 | base 16 | burst is zero | algorithm | status
+//     | kind | 1} whenever the rest of the bucket is what the request itself says (stored limit / duration / burst equal to the
+//     request's — the steady state —, or the key is new), nothing is flagged, no error, no InvalidAt; every other group gets
+//     {.., 0} there and the 64-byte record beside it (grec[]).  Two 32-byte records of neighbouring groups — owners of one XCD
+//     are neighbours in a tile's region — share a sector in that XCD's L2 and leave it as one write.
+#ifndef GUBER_PART_COMPACT
+#define GUBER_PART_COMPACT 0
+#endif
+struct alignas(32) GMsgS { unsigned long long hash, key0, key1, misc; };
+struct alignas(32) GShape { long long hits, limit, duration, burst; };
+struct alignas(32) GRecS { int64_t remaining, stamp, expire_at; unsigned long long pk; };
+static_assert(sizeof(GMsgS) == 32 && sizeof(GShape) == 32 && sizeof(GRecS) == 32, "two per sector");
+enum : uint32_t { SM_COMPACT_OK = 1u << 24, SM_BURST_ZERO = 1u << 25 };      // GRec::smeta, k_own only: the group's record has the 32-byte form
+GB_HD unsigned long long grs_pack(uint32_t kind, uint32_t status, uint32_t algo, bool burst_zero, uint32_t base, uint32_t total, uint32_t slot) {
+    return 1ull | ((unsigned long long)(kind & 3u) << 1) | ((unsigned long long)(status & 1u) << 3) | ((unsigned long long)(algo & 1u) << 4) |
+           ((unsigned long long)(burst_zero ? 1u : 0u) << 5) | ((unsigned long long)(base & 0xffffu) << 6) |
+           ((unsigned long long)((total - 1u) & 0xffffu) << 22) | ((unsigned long long)slot << 38);
+}
 GB_HD uint32_t gm_head(unsigned long long m) { return (uint32_t)m & 0xffu; }
 GB_HD uint32_t gm_cnt(unsigned long long m) { return (((uint32_t)m >> 8) & 0xffu) + 1u; }
 GB_HD uint32_t gm_flags(unsigned long long m) { return ((uint32_t)m >> 16) & 0xffu; }
@@ -257,6 +285,17 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
             k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
             if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
         } else { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
+#if GUBER_PART_COMPACT
+        if (mine.hits == sreq.hits[0] && mine.limit == sreq.limit[0] && mine.duration == sreq.duration[0] && mine.burst == sreq.burst[0]) f |= G_SHAPE0;
+        else {
+            ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT + tid];
+            sq[0] = make_ulonglong2((unsigned long long)mine.hits, (unsigned long long)mine.limit);
+            sq[1] = make_ulonglong2((unsigned long long)mine.duration, (unsigned long long)mine.burst);
+        }
+        ulonglong2* mq = (ulonglong2*)((GMsgS*)W.gmsg + (size_t)tile * FT + j);
+        mq[0] = make_ulonglong2(gk, k0);
+        mq[1] = make_ulonglong2(k1, gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
+#else
         GMsg* m = &W.gmsg[(size_t)tile * FT + j];
         ulonglong2* mq = (ulonglong2*)m;
         mq[0] = make_ulonglong2(gk, k0);
@@ -264,7 +303,15 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         mq[2] = make_ulonglong2((unsigned long long)mine.limit, (unsigned long long)mine.duration);
         mq[3] = make_ulonglong2((unsigned long long)mine.burst,
                                 gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
+#endif
     }
+#if GUBER_PART_COMPACT
+    if (tid == 0) {                                                   // the tile's shape: its request 0's (a tile that exists has one)
+        ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT];
+        sq[0] = make_ulonglong2((unsigned long long)mine.hits, (unsigned long long)mine.limit);
+        sq[1] = make_ulonglong2((unsigned long long)mine.duration, (unsigned long long)mine.burst);
+    }
+#endif
     lds_barrier();
     if (valid) {
         if (errcode) W.did[g] = pd_pack(0, 0, errcode);
@@ -278,6 +325,9 @@ __global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
 #ifndef GUBER_OWN_DIR_EARLY
 #define GUBER_OWN_DIR_EARLY 0
+#endif
+#ifndef GUBER_ABLATE_TABLE
+#define GUBER_ABLATE_TABLE 0             // 1 = MEASUREMENT ONLY, WRONG ANSWERS: no bucket is read or written (what the table trips cost the pipeline)
 #endif
 #ifndef GUBER_OWN_EPT
 #define GUBER_OWN_EPT 3
@@ -320,6 +370,15 @@ __device__ __forceinline__ bool msg_same_request(const ulonglong2& a1, const ulo
     return a1.y == b1.y && a2.x == b2.x && a2.y == b2.y && a3.x == b3.x && gm_shape(a3.y) == gm_shape(b3.y);
 }
 
+// the hash of message i of the batch (either form)
+__device__ __forceinline__ unsigned long long msg_hash_at(const Work& W, size_t i) {
+#if GUBER_PART_COMPACT
+    return ((const GMsgS*)W.gmsg)[i].hash;
+#else
+    return W.gmsg[i].hash;
+#endif
+}
+
 __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, const Work& W, const uint32_t p, const uint32_t ntiles) {
     __shared__ unsigned long long ktab[OW_HT];          // the round's keys: hash (0 = free)
     __shared__ uint16_t kidOf[OW_HT];                   // table slot -> key id
@@ -336,9 +395,19 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ int sp;
     GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+#if GUBER_PART_COMPACT
+    __shared__ GShape tshape[256];                      // tile -> the shape of its request 0 (what a G_SHAPE0 message refers to)
+#endif
 
     uint32_t start = 0, c = 0;
-    if (t < ntiles) { const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16; }
+    if (t < ntiles) {
+        const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16;
+#if GUBER_PART_COMPACT
+        const ulonglong2* sq = (const ulonglong2*)&W.gshape[(size_t)t * FT];
+        const ulonglong2 s0 = sq[0], s1 = sq[1];
+        ulonglong2* lq = (ulonglong2*)&tshape[t]; lq[0] = s0; lq[1] = s1;
+#endif
+    }
     const size_t mbase = (size_t)t * FT + start;
     if (t == 0) { stk[0] = 0u; sp = 1; ins_n = 0u; }
     tstart[t] = (uint16_t)start;
@@ -354,7 +423,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2); j += 256) csum[j] = 0u;
         // my tile's messages of this round
         uint32_t cm = c;
-        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((W.gmsg[mbase + r].hash >> 7) & T.mask) & smask) == res ? 1u : 0u; }
+        if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((msg_hash_at(W, mbase + r) >> 7) & T.mask) & smask) == res ? 1u : 0u; }
         uint32_t M;
         {
             const uint32_t incl = wave_incl_scan_u32(cm);
@@ -391,14 +460,36 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                     if (lg) {                                         // a split round: the r-th message of the tile's run that belongs to this round
                         const uint32_t mb = lo * FT + tstart[lo];
                         uint32_t seen = 0, x = 0;
-                        for (;; ++x) { if (((uint32_t)((W.gmsg[mb + x].hash >> 7) & T.mask) & smask) == res) { if (seen == r) break; ++seen; } }
+                        for (;; ++x) { if (((uint32_t)((msg_hash_at(W, mb + x) >> 7) & T.mask) & smask) == res) { if (seen == r) break; ++seen; } }
                         mi = mb + x;
                     }
                     esrc[k] = mi;
+#if GUBER_PART_COMPACT
+                    const ulonglong2* mq = (const ulonglong2*)((const GMsgS*)W.gmsg + mi);
+                    m0[k] = mq[0]; m1[k] = mq[1];                     // {hash, key0} {key1, packed rest}
+#else
                     const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mi];
                     m0[k] = mq[0]; m1[k] = mq[1]; m2[k] = mq[2]; m3[k] = mq[3];
+#endif
                 }
             }
+#if GUBER_PART_COMPACT
+            // the 64-byte form of every message, rebuilt: its shape is its tile's (LDS) or its own (one more load, issued for all
+            // of the thread's messages together)
+#pragma unroll
+            for (int k = 0; k < OW_EPT; ++k) {
+                if (esrc[k] != 0xffffffffu) {
+                    const unsigned long long misc = m1[k].y;
+                    const uint32_t tl = esrc[k] >> 8;
+                    ulonglong2 s0, s1;
+                    if (gm_flags(misc) & G_SHAPE0) { const ulonglong2* lq = (const ulonglong2*)&tshape[tl]; s0 = lq[0]; s1 = lq[1]; }
+                    else { const ulonglong2* sq = (const ulonglong2*)&W.gshape[(size_t)tl * FT + gm_head(misc)]; s0 = sq[0]; s1 = sq[1]; }
+                    m1[k].y = s0.x;                                   // hits
+                    m2[k] = make_ulonglong2(s0.y, s1.x);              // limit, duration
+                    m3[k] = make_ulonglong2(s1.y, misc & ~((unsigned long long)G_SHAPE0 << 16));   // burst, packed rest
+                }
+            }
+#endif
             // ---- hash -> LDS table slot; the first message of a key installs it and leaves its content as the key's reference ----
 #pragma unroll
             for (int k = 0; k < OW_EPT; ++k) {
@@ -437,9 +528,11 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             } else {
                 // (more than OW_KCAP keys on one home position: cannot happen below 2^24 slots; answered RETRY, never evaluated)
                 for (uint32_t r = 0; r < c; ++r) {
-                    const GMsg* m = &W.gmsg[mbase + r];
-                    if (((uint32_t)((m->hash >> 7) & T.mask) & smask) != res) continue;
+                    if (((uint32_t)((msg_hash_at(W, mbase + r) >> 7) & T.mask) & smask) != res) continue;
                     GRec* o = &W.grec[mbase + r];
+#if GUBER_PART_COMPACT
+                    { ulonglong2* cs = (ulonglong2*)&W.grs[mbase + r]; cs[0] = make_ulonglong2(0ull, 0ull); cs[1] = make_ulonglong2(0ull, 0ull); }
+#endif
                     o->limit = o->duration = o->remaining = o->stamp = o->burst = o->expire_at = 0; o->smeta = 0; o->slot = 0;
                     o->tail = gr_tail(SEG_RETRY, 0, 0, 1, (uint32_t)(mbase + r));
                 }
@@ -459,9 +552,11 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         const bool haskey = t < nk;
         if (haskey) {
             kpos = (kref[t].hash >> 7) & T.mask;
+#if !GUBER_ABLATE_TABLE
             const Bucket* hb = &T.buckets[kpos];
             const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
             trec = hb->rec;
+#endif
 #if GUBER_OWN_DIR_EARLY
             // ... and the two directory entries a displaced key needs next (usually one 64-byte line more): a key one step from home
             // then costs two trips instead of three, at the price of a line that the keys at home (the majority) do not use
@@ -539,9 +634,11 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         for (uint32_t kid = t; kid < nk; kid += 256) {
             if (kid != t) {                                           // (more than 256 keys in a round: uniform keys)
                 kpos = (kref[kid].hash >> 7) & T.mask;
+#if !GUBER_ABLATE_TABLE
                 const Bucket* hb = &T.buckets[kpos];
                 const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
                 trec = hb->rec;
+#endif
 #if GUBER_OWN_DIR_EARLY
                 de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[(kpos + 1) & T.mask];
 #endif
@@ -556,8 +653,12 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             const uint8_t* lkey = nullptr; uint32_t llen = 0;
             if (klen == 31u) { lkey = B.key_bytes + (uint32_t)wm.key0; llen = (uint32_t)(wm.key0 >> 32); }
             // at home?  (keys of <= 16 bytes: the two key words and the length say it all; longer keys go through the directory)
+#if GUBER_ABLATE_TABLE
+            const bool at_home = true;
+#else
             const bool at_home = klen != 31u && (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 &&
                                  (tc3.w >> 16) == klen;
+#endif
             if (at_home) { slot = home; cand = true; }
 #if !GUBER_OWN_DIR_EARLY
             else {
@@ -625,6 +726,18 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             kr.limit = trec.limit; kr.duration = trec.duration; kr.remaining = trec.remaining; kr.stamp = trec.stamp; kr.burst = trec.burst;
             kr.expire_at = trec.expire_at;
             kr.smeta = pack_smeta(trec, 1); kr.slot = slot;
+#if GUBER_PART_COMPACT
+            {   // does the 32-byte record carry this key?  (nothing flagged, no error, and the rest of the bucket is what the request says)
+                const uint32_t kind = rec_kind(trec);
+                bool cok = sf == 0u && errcode == 0u && cand && trec.invalid_at == 0 && slot < (1u << 26) && (kfl[kid] & ~(uint32_t)G_LONG) == 0u;
+                if (kind == K_ABSENT)
+                    cok = cok && rec_meta(trec) == 0u && (trec.limit | trec.duration | trec.remaining | trec.stamp | trec.burst | trec.expire_at) == 0;
+                else
+                    cok = cok && kind != K_NIL && rec_algo(trec) <= 1u && trec.limit == wm.limit && trec.duration == wm.duration &&
+                          (trec.burst == 0 || trec.burst == wm.burst);
+                if (cok) kr.smeta |= SM_COMPACT_OK | (trec.burst == 0 ? SM_BURST_ZERO : 0u);
+            }
+#endif
             const uint32_t wl = kwin[kid];                             // the installing message: list index -> its place in gmsg
             uint32_t seg = 0;
             {   // (the installer's esrc lives in its thread's registers: recomputed from the list index as every thread did)
@@ -634,7 +747,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 if (lg) {
                     const uint32_t mb = lo * FT + tstart[lo];
                     uint32_t seen = 0, x = 0;
-                    for (;; ++x) { if (((uint32_t)((W.gmsg[mb + x].hash >> 7) & T.mask) & smask) == res) { if (seen == wl - tpos[lo]) break; ++seen; } }
+                    for (;; ++x) { if (((uint32_t)((msg_hash_at(W, mb + x) >> 7) & T.mask) & smask) == res) { if (seen == wl - tpos[lo]) break; ++seen; } }
                     seg = mb + x;
                 }
             }
@@ -652,8 +765,22 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 ulonglong2 q0 = kq[0], q1 = kq[1], q2 = kq[2], q3 = kq[3];
                 q3.y |= (unsigned long long)(ebase[k] & 0xffffu) << 16;
                 const uint32_t src = esrc[k];
+#if GUBER_PART_COMPACT
+                ulonglong2* cs = (ulonglong2*)&W.grs[src];
+                const uint32_t sm = (uint32_t)q3.x;
+                if (sm & SM_COMPACT_OK) {
+                    cs[0] = q1;                                       // remaining, stamp
+                    cs[1] = make_ulonglong2(q2.y, grs_pack(sm & 3u, (sm >> 2) & 1u, (sm >> 8) & 1u, (sm & SM_BURST_ZERO) != 0u, ebase[k],
+                                                           ((uint32_t)(q3.y >> 32) & 0xffffu) + 1u, (uint32_t)(q3.x >> 32)));
+                } else {
+                    cs[0] = make_ulonglong2(0ull, 0ull); cs[1] = make_ulonglong2(0ull, 0ull);        // "see grec[]"
+                    ulonglong2* o = (ulonglong2*)&W.grec[src];
+                    o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+                }
+#else
                 ulonglong2* o = (ulonglong2*)&W.grec[src];
                 o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
+#endif
                 if ((uint32_t)q3.y & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) {   // the walk's map: which tiles hold the segment, and as which group
                     const uint32_t seg = (uint32_t)(q3.y >> 48), tile = src >> 8;
                     atomicOr(&W.segtiles[(size_t)seg * 4 + (tile >> 6)], 1ull << (tile & 63));
@@ -685,7 +812,28 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
     rec_clear(s0);
     if (live) {
         r = load_req_nogreg(B, i);
+#if GUBER_PART_COMPACT
+        bool full = !derr;
         if (!derr) {
+            const ulonglong2* cq = (const ulonglong2*)&W.grs[(size_t)tile * 256 + gj];   // 32 bytes per (key, tile) group
+            const ulonglong2 c0 = cq[0], c1 = cq[1];
+            const unsigned long long pk = c1.y;
+            if (pk & 1ull) {                                          // the usual record: the rest of the bucket is what the request says
+                full = false;
+                const uint32_t kind = (uint32_t)(pk >> 1) & 3u;
+                if (kind != K_ABSENT) {
+                    s0.limit = r.limit; s0.duration = r.duration; s0.remaining = (int64_t)c0.x; s0.stamp = (int64_t)c0.y;
+                    s0.burst = ((pk >> 5) & 1ull) ? 0 : r.burst; s0.expire_at = (int64_t)c1.x;
+                    smeta = kind | (((uint32_t)(pk >> 3) & 1u) << 2) | (((uint32_t)(pk >> 4) & 1u) << 8);
+                    s0.meta = smeta_meta(smeta);
+                }
+                base = (uint32_t)(pk >> 6) & 0xffffu; total = ((uint32_t)(pk >> 22) & 0xffffu) + 1u; slot = (uint32_t)(pk >> 38);
+            }
+        }
+        if (full) {
+#else
+        if (!derr) {
+#endif
             const ulonglong2* q = (const ulonglong2*)&W.grec[(size_t)tile * 256 + gj];   // one 64-byte sector per (key, tile) group
             const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             s0.limit = (int64_t)q0.x; s0.duration = (int64_t)q0.y; s0.remaining = (int64_t)q1.x; s0.stamp = (int64_t)q1.y;
@@ -804,8 +952,10 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             }
             if ((parallel && rank == total - 1) || walk) {
                 rec_set_stamp(after, W.touch + lastj);                // the key's place in the recency order: its last request (lrucache.go:111-128)
+#if !GUBER_ABLATE_TABLE
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+#endif
                 if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
             }
         }

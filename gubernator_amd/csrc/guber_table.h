@@ -117,7 +117,7 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMP2(k) do {} while (0)
 #define GB_STAMPW(k) do {} while (0)
 #endif
-struct GMsg; struct GRec;
+struct GMsg; struct GRec; struct GShape; struct GRecS;
 struct Work {
     // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.
@@ -165,6 +165,11 @@ struct Work {
     GRec* grec;                         // [cap] the owner's answer to message i: bucket before the batch, slot, flags, rank base, total
     unsigned long long* segtiles;       // [cap][4] tiles holding a segment whose requests are walked serially (all zero between batches)
     uint32_t pshift;                    // owner of a key = its home position >> pshift
+    // the compact forms (GUBER_PART_COMPACT, guber_kernels_part.h): 32-byte messages live in the first half of gmsg[], the
+    // request shapes they refer to in the second half (gshape); 32-byte records in grs[], the 64-byte form (grec[]) only for
+    // the groups whose record does not fit
+    GShape* gshape;                     // [cap] tile t: gshape[t * FT + 0] = the shape of the tile's request 0, [t * FT + head] = a head's own
+    GRecS* grs;                         // [cap]
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -200,7 +200,7 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->sinv.assign(d->cap, 0); d->tilerow.assign((size_t)d->cap * FT_MAX_TILES, 0); d->did2.assign((size_t)2 * d->cap, 0); d->did3.assign(d->cap, 0);
     d->claims_cells = 1024; while (d->claims_cells < 4 * d->cap) d->claims_cells <<= 1;
     d->claims.assign(d->claims_cells, 0);
-    d->gmsg.resize(d->cap); d->grec.resize(d->cap); d->gse.assign((size_t)FT_MAX_TILES * PT_PARTS, 0); d->segtiles.assign((size_t)d->cap * 4, 0);
+    d->gmsg.resize(d->cap); d->grec.resize((size_t)d->cap + d->cap / 2); d->gse.assign((size_t)FT_MAX_TILES * PT_PARTS, 0); d->segtiles.assign((size_t)d->cap * 4, 0);
     memset(&d->T, 0, sizeof(Table)); memset(&d->W, 0, sizeof(Work));
     d->T.dir = d->dir.data(); d->T.buckets = d->buckets.data(); d->T.arena = d->arena.data(); d->T.mask = s - 1;
     d->T.arena_cap = d->arena.size() - 64; d->T.ctr = &d->ctr; d->T.bctr = d->bctr.data();
@@ -209,7 +209,8 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->W.slot = d->u32.data(); d->W.rflags = d->rflags.data();
     d->W.seg_tilemask = d->tilemask.data(); d->W.srec = d->srec.data(); d->W.sinv = d->sinv.data(); d->W.tilerow = d->tilerow.data();
     d->W.claims = d->claims.data();
-    d->W.gmsg = d->gmsg.data(); d->W.grec = d->grec.data(); d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
+    d->W.gmsg = d->gmsg.data(); d->W.gshape = (GShape*)((char*)d->gmsg.data() + (size_t)d->cap * 32);
+    d->W.grs = (GRecS*)d->grec.data(); d->W.grec = d->grec.data() + d->cap / 2; d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
     uint32_t lg = 0; while ((1ull << lg) < s) lg++;
     d->W.pshift = lg - 8;
     return d;
@@ -287,6 +288,24 @@ static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int
         for (auto v : d->segtiles) if (v) return -2;      // the walk's tile maps must be all zero between batches
     }
     return 0;
+}
+// the last owner-partitioned batch: (key, tile) groups, of which answered by a 32-byte record, of which sent with the tile's shape
+// (0, 0 in a build without GUBER_PART_COMPACT)
+void ds_part_forms(void* h, uint32_t n, unsigned long long* out) {
+    DevSim* d = (DevSim*)h;
+    out[0] = out[1] = out[2] = 0;
+    const uint32_t tiles = (n + FT - 1) / FT;
+    for (uint32_t t = 0; t < tiles; ++t) {
+        uint32_t groups = 0;
+        for (uint32_t p = 0; p < PT_PARTS; ++p) groups += d->gse[(size_t)t * PT_PARTS + p] >> 16;
+        out[0] += groups;
+#if GUBER_PART_COMPACT
+        for (uint32_t j = 0; j < groups; ++j) {
+            out[1] += d->W.grs[(size_t)t * FT + j].pk & 1ull;
+            out[2] += (gm_flags(((const GMsgS*)d->W.gmsg)[(size_t)t * FT + j].misc) & G_SHAPE0) ? 1 : 0;
+        }
+#endif
+    }
 }
 // over, hits, misses, size, retries, tags_used
 void ds_counters(void* h, long long* out) {

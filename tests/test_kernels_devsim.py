@@ -15,10 +15,12 @@ from support import ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle
 HS = os.path.join(ROOT, "tests", "hostsim")
 
 
-@pytest.fixture(scope="module")
-def lib():
+# both forms of what travels between k_part, k_own and k_eval3: 64-byte messages and records (GUBER_PART_COMPACT=0) and the 32-byte
+# ones (=1: shapes per tile, records that leave out what the request says)
+@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so"])
+def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
-    L = C.CDLL(os.path.join(HS, "libdevsim.so"))
+    L = C.CDLL(os.path.join(HS, request.param))
     L.ds_create.restype = C.c_void_p
     L.ds_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int]
     L.ds_destroy.argtypes = [C.c_void_p]
@@ -28,6 +30,8 @@ def lib():
     L.ds_create_bounded.restype = C.c_void_p
     L.ds_create_bounded.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
     L.ds_lru_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    L.ds_part_forms.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    L.compact = "compact" in request.param
     return L
 
 
@@ -46,6 +50,12 @@ class Sim:
         rc = self.lib.ds_eval(self.h, C.byref(batch.c), C.byref(res.c), self.pipeline, careful)
         assert rc == 0, rc
         return res
+
+    def part_forms(self, n):
+        """(key, tile) groups of the last owner-partitioned batch of n requests, 32-byte records among them, messages with the tile's shape"""
+        out = (C.c_ulonglong * 3)()
+        self.lib.ds_part_forms(self.h, n, out)
+        return tuple(out)
 
     def counters(self):
         out = (C.c_longlong * 6)()
@@ -92,6 +102,16 @@ def test_zipf_batches_with_hot_keys_spanning_every_tile(lib):
         ids = z.draw(5000)
         b = streams.bench_batch(table, ids, now, algorithm=k & 1, limit=40, duration=3000)
         assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
+        groups, short_recs, tile_shapes = sim.part_forms(5000)
+        if lib.compact:
+            # one request shape per batch: every message refers to its tile's shape.  The 32-byte record serves every key whose bucket
+            # holds what the request says (limit, duration, burst — or no burst) and every new key: all of batch 0 (new) and batch 1
+            # (leaky requests meeting token buckets of the same limit), most of the leaky batches after that; a token request that
+            # meets a leaky bucket (burst 40 stored, none asked for) gets the 64-byte form — both forms in one batch from batch 2 on
+            assert groups > 2000 and tile_shapes == groups, (k, groups, tile_shapes)
+            assert short_recs == groups if k < 2 else 0 < short_recs < groups, (k, groups, short_recs)
+        else:
+            assert short_recs == 0 and tile_shapes == 0
         now += [1, 700, 1, 3500, 2, 900, 1, 1][k]
     assert sim.counters()[:3] == orc.counters()[:3]
     sim.close()
