@@ -67,6 +67,12 @@ enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_OD
 #ifndef GUBER_PART_COMPACT
 #define GUBER_PART_COMPACT 0
 #endif
+#ifndef GUBER_PART_MSG32                  // (the two halves can be built apart for measurements)
+#define GUBER_PART_MSG32 GUBER_PART_COMPACT
+#endif
+#ifndef GUBER_PART_REC32
+#define GUBER_PART_REC32 GUBER_PART_COMPACT
+#endif
 struct alignas(32) GMsgS { unsigned long long hash, key0, key1, misc; };
 struct alignas(32) GShape { long long hits, limit, duration, burst; };
 struct alignas(32) GRecS { int64_t remaining, stamp, expire_at; unsigned long long pk; };
@@ -285,7 +291,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
             k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
             if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
         } else { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
         if (mine.hits == sreq.hits[0] && mine.limit == sreq.limit[0] && mine.duration == sreq.duration[0] && mine.burst == sreq.burst[0]) f |= G_SHAPE0;
         else {
             ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT + tid];
@@ -305,7 +311,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
                                 gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
 #endif
     }
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
     if (tid == 0) {                                                   // the tile's shape: its request 0's (a tile that exists has one)
         ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT];
         sq[0] = make_ulonglong2((unsigned long long)mine.hits, (unsigned long long)mine.limit);
@@ -372,7 +378,7 @@ __device__ __forceinline__ bool msg_same_request(const ulonglong2& a1, const ulo
 
 // the hash of message i of the batch (either form)
 __device__ __forceinline__ unsigned long long msg_hash_at(const Work& W, size_t i) {
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
     return ((const GMsgS*)W.gmsg)[i].hash;
 #else
     return W.gmsg[i].hash;
@@ -395,14 +401,14 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ int sp;
     GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
     __shared__ GShape tshape[256];                      // tile -> the shape of its request 0 (what a G_SHAPE0 message refers to)
 #endif
 
     uint32_t start = 0, c = 0;
     if (t < ntiles) {
         const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16;
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
         const ulonglong2* sq = (const ulonglong2*)&W.gshape[(size_t)t * FT];
         const ulonglong2 s0 = sq[0], s1 = sq[1];
         ulonglong2* lq = (ulonglong2*)&tshape[t]; lq[0] = s0; lq[1] = s1;
@@ -464,7 +470,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                         mi = mb + x;
                     }
                     esrc[k] = mi;
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
                     const ulonglong2* mq = (const ulonglong2*)((const GMsgS*)W.gmsg + mi);
                     m0[k] = mq[0]; m1[k] = mq[1];                     // {hash, key0} {key1, packed rest}
 #else
@@ -473,7 +479,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
 #endif
                 }
             }
-#if GUBER_PART_COMPACT
+#if GUBER_PART_MSG32
             // the 64-byte form of every message, rebuilt: its shape is its tile's (LDS) or its own (one more load, issued for all
             // of the thread's messages together)
 #pragma unroll
@@ -530,7 +536,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 for (uint32_t r = 0; r < c; ++r) {
                     if (((uint32_t)((msg_hash_at(W, mbase + r) >> 7) & T.mask) & smask) != res) continue;
                     GRec* o = &W.grec[mbase + r];
-#if GUBER_PART_COMPACT
+#if GUBER_PART_REC32
                     { ulonglong2* cs = (ulonglong2*)&W.grs[mbase + r]; cs[0] = make_ulonglong2(0ull, 0ull); cs[1] = make_ulonglong2(0ull, 0ull); }
 #endif
                     o->limit = o->duration = o->remaining = o->stamp = o->burst = o->expire_at = 0; o->smeta = 0; o->slot = 0;
@@ -726,7 +732,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             kr.limit = trec.limit; kr.duration = trec.duration; kr.remaining = trec.remaining; kr.stamp = trec.stamp; kr.burst = trec.burst;
             kr.expire_at = trec.expire_at;
             kr.smeta = pack_smeta(trec, 1); kr.slot = slot;
-#if GUBER_PART_COMPACT
+#if GUBER_PART_REC32
             {   // does the 32-byte record carry this key?  (nothing flagged, no error, and the rest of the bucket is what the request says)
                 const uint32_t kind = rec_kind(trec);
                 bool cok = sf == 0u && errcode == 0u && cand && trec.invalid_at == 0 && slot < (1u << 26) && (kfl[kid] & ~(uint32_t)G_LONG) == 0u;
@@ -765,7 +771,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 ulonglong2 q0 = kq[0], q1 = kq[1], q2 = kq[2], q3 = kq[3];
                 q3.y |= (unsigned long long)(ebase[k] & 0xffffu) << 16;
                 const uint32_t src = esrc[k];
-#if GUBER_PART_COMPACT
+#if GUBER_PART_REC32
                 ulonglong2* cs = (ulonglong2*)&W.grs[src];
                 const uint32_t sm = (uint32_t)q3.x;
                 if (sm & SM_COMPACT_OK) {
@@ -812,7 +818,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
     rec_clear(s0);
     if (live) {
         r = load_req_nogreg(B, i);
-#if GUBER_PART_COMPACT
+#if GUBER_PART_REC32
         bool full = !derr;
         if (!derr) {
             const ulonglong2* cq = (const ulonglong2*)&W.grs[(size_t)tile * 256 + gj];   // 32 bytes per (key, tile) group

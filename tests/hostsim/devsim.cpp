@@ -299,12 +299,14 @@ void ds_part_forms(void* h, uint32_t n, unsigned long long* out) {
         uint32_t groups = 0;
         for (uint32_t p = 0; p < PT_PARTS; ++p) groups += d->gse[(size_t)t * PT_PARTS + p] >> 16;
         out[0] += groups;
-#if GUBER_PART_COMPACT
         for (uint32_t j = 0; j < groups; ++j) {
+#if GUBER_PART_REC32
             out[1] += d->W.grs[(size_t)t * FT + j].pk & 1ull;
-            out[2] += (gm_flags(((const GMsgS*)d->W.gmsg)[(size_t)t * FT + j].misc) & G_SHAPE0) ? 1 : 0;
-        }
 #endif
+#if GUBER_PART_MSG32
+            out[2] += (gm_flags(((const GMsgS*)d->W.gmsg)[(size_t)t * FT + j].misc) & G_SHAPE0) ? 1 : 0;
+#endif
+        }
     }
 }
 // over, hits, misses, size, retries, tags_used
