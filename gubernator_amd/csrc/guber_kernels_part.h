@@ -51,27 +51,28 @@ enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_OD
 //   G_LONG        key longer than 16 bytes: compared through the request's key bytes in memory
 //   G_SHAPE0      (compact messages only) hits / limit / duration / burst are those of the tile's request 0: gshape[tile * FT]
 //
-// GUBER_PART_COMPACT = 1: what travels between the three kernels is HALF the size — the pipeline's rate follows the number of
-// write transactions at the fabric (profiles/r03_*, r04_*: one 64-byte message and one 64-byte record per (key, tile) group are
-// 90 k of a batch's 142 k write requests), so
-//   * a message is 32 bytes {hash, key bytes, packed rest}: the four 64-bit request fields it used to carry are a SHAPE, written
-//     once per tile for the shape of the tile's request 0 (gshape[tile * FT]; a group whose requests have that shape says so:
-//     G_SHAPE0 — rate limits come in few shapes, a tile usually has one) and once per group that differs (gshape[tile * FT + head
-//     thread]).  The owner keeps the 256 tile shapes in LDS and rebuilds the 64-byte form in registers: everything behind the
-//     load is unchanged and as exact as before (a group with its own shape costs its owner one more dependent load);
-//   * a record is 32 bytes {remaining, stamp, expire_at, packed: slot 26 | total 16 | base 16 | burst is zero | algorithm | status
-//     | kind | 1} whenever the rest of the bucket is what the request itself says (stored limit / duration / burst equal to the
-//     request's — the steady state —, or the key is new), nothing is flagged, no error, no InvalidAt; every other group gets
-//     {.., 0} there and the 64-byte record beside it (grec[]).  Two 32-byte records of neighbouring groups — owners of one XCD
-//     are neighbours in a tile's region — share a sector in that XCD's L2 and leave it as one write.
+// The 32-byte forms of what travels between the three kernels.  (Measured on one box, 12 shards fused, profiles/r04_w_*, r04_y_*:
+// 32-byte records +2.3 %, 32-byte messages +0.6 %, both +1.7 %: the records are the default, the messages a build option.)
+//   * GUBER_PART_REC32 (default 1): a record is 32 bytes {remaining, stamp, expire_at, packed: slot 26 | total 16 | base 16 | burst is
+//     zero | algorithm | status | kind | 1} whenever the rest of the bucket is what the request itself says (stored limit / duration
+//     / burst equal to the request's — the steady state —, or the key is new), nothing is flagged, no error, no InvalidAt; every
+//     other group gets {.., 0} there and the 64-byte record beside it (grec[]).  Two 32-byte records of neighbouring groups — owners
+//     of one XCD are neighbours in a tile's region — share a sector in that XCD's L2 and leave it as one write; k_eval3 reads half
+//     the bytes.
+//   * GUBER_PART_MSG32 (default 0; GUBER_PART_COMPACT=1 switches both on): a message is 32 bytes {hash, key bytes, packed rest}; the
+//     four 64-bit request fields it used to carry are a SHAPE, written once per tile for the shape of the tile's request 0
+//     (gshape[tile * FT]; a group whose requests have that shape says so: G_SHAPE0 — rate limits come in few shapes, a tile usually
+//     has one) and once per group that differs (gshape[tile * FT + head thread]).  The owner keeps the 256 tile shapes in LDS and
+//     rebuilds the 64-byte form in registers: everything behind the load is unchanged and as exact as before (a group with its own
+//     shape costs its owner one more dependent load; 8 KB more LDS and 7 more VGPRs in k_own — why it does not pay).
 #ifndef GUBER_PART_COMPACT
 #define GUBER_PART_COMPACT 0
 #endif
-#ifndef GUBER_PART_MSG32                  // (the two halves can be built apart for measurements)
+#ifndef GUBER_PART_MSG32
 #define GUBER_PART_MSG32 GUBER_PART_COMPACT
 #endif
 #ifndef GUBER_PART_REC32
-#define GUBER_PART_REC32 GUBER_PART_COMPACT
+#define GUBER_PART_REC32 1
 #endif
 struct alignas(32) GMsgS { unsigned long long hash, key0, key1, misc; };
 struct alignas(32) GShape { long long hits, limit, duration, burst; };
@@ -132,10 +133,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, const Work& W, const uint32_t tile) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
     __shared__ unsigned long long gkey[GT];
-    __shared__ unsigned long long gbits[FT / 64][GT];
+    // the per-wave member bitmaps are read once, right after the grouping; the tile's request fields are needed from then on (members
+    // against their head): one piece of LDS for both (27 KB per workgroup instead of 39: five workgroups per CU instead of four)
+    __shared__ union GbitsOrReqs { unsigned long long gbits[FT / 64][GT]; TileReqs sreq; } gu;
+    unsigned long long (&gbits)[FT / 64][GT] = gu.gbits;
+    TileReqs& sreq = gu.sreq;
     __shared__ uint32_t sd[FT];                                   // head -> G_* raised by the group's members, then the position of its group's message in the tile's region
     __shared__ uint32_t soff[FT], slen[FT];
-    __shared__ TileReqs sreq;
     __shared__ int gcmin[FT], gcmax[FT];                          // head -> created_at range of the group (ms from the batch clock, clamped to +-2^17)
     __shared__ uint32_t pc[PT_PARTS];                             // groups per owner (in owner_order), then where each owner's run starts
     __shared__ uint32_t wsum[FT / 64];
@@ -195,7 +199,6 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
             h = (spec ? xxhash64_words4(kw, len, 0) : xxhash64(key, len, 0)) & T.hash_mask;
             gk = h ? h : 1ull;
         }
-        tile_put(sreq, tid, mine);
     }
     soff[tid] = off; slen[tid] = len;
     GP_STAMPW(0, 1);
@@ -228,6 +231,8 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     }
     const bool khead = valid && gk != 0ull && eq_before == 0;
     const bool member = valid && gk != 0ull && eq_before != 0;
+    lds_barrier();                                                // every bitmap has been read: the requests' fields take their place
+    if (valid) tile_put(sreq, tid, mine);
     GP_STAMP(0, 2);
     // created_at as the messages carry it: milliseconds from the batch clock
     int cd = 0; bool cfar = false;
@@ -326,7 +331,10 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     GP_STAMPW(0, 5);
 }
 
-__global__ __launch_bounds__(FT, 4) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
+#ifndef GUBER_PART_WAVES
+#define GUBER_PART_WAVES 4               // waves per SIMD the register allocation of k_part must allow (LDS allows 6 workgroups per CU)
+#endif
+__global__ __launch_bounds__(FT, GUBER_PART_WAVES) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
 #ifndef GUBER_OWN_DIR_EARLY
@@ -996,7 +1004,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
 
 // ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
 // kernel arguments; k_own_multi: 256 owners per batch, so that an owner's XCD is the same in every batch) ----------------------
-__global__ __launch_bounds__(FT, 4) void k_part_multi(MultiFront A) {
+__global__ __launch_bounds__(FT, GUBER_PART_WAVES) void k_part_multi(MultiFront A) {
     uint32_t sb = 0, first = 0;
 #pragma unroll
     for (int k = 0; k < MULTI_MAX - 1; ++k)

@@ -15,9 +15,9 @@ from support import ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle
 HS = os.path.join(ROOT, "tests", "hostsim")
 
 
-# both forms of what travels between k_part, k_own and k_eval3: 64-byte messages and records (GUBER_PART_COMPACT=0) and the 32-byte
-# ones (=1: shapes per tile, records that leave out what the request says)
-@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so"])
+# every form of what travels between k_part, k_own and k_eval3: the product's default (64-byte messages, 32-byte records that leave out
+# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), and 64 bytes both ways
+@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so"])
 def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
     L = C.CDLL(os.path.join(HS, request.param))
@@ -31,8 +31,15 @@ def lib(request):
     L.ds_create_bounded.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
     L.ds_lru_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.ds_part_forms.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_ulonglong)]
-    L.compact = "compact" in request.param
+    L.short_recs, L.short_msgs = "wide" not in request.param, "compact" in request.param
+    L.product_form = request.param == "libdevsim.so"
     return L
+
+
+def only_where_the_form_matters(lib, pipeline=1):
+    """the other builds differ in k_part / k_own / k_eval3 only: what does not run them, or is about something else, runs once"""
+    if not lib.product_form and pipeline != 1:
+        pytest.skip("the two-launch pipeline is the same in every build")
 
 
 class Sim:
@@ -80,6 +87,7 @@ def sub_batch(b, idx):
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_adversarial_streams_through_the_kernel_source(lib, pipeline, seed):
     """every branch of algorithms.go, duplicate-heavy keys, mixed request shapes: element-wise equal to the oracle, counters too"""
+    only_where_the_form_matters(lib, pipeline)
     sim, orc = Sim(lib, pipeline=pipeline), Oracle()
     for k, b in enumerate(streams.adversarial_batches(seed, 10, 1500, greg_fn=gregorian)):
         want, got = orc.eval(b), sim.eval(b)
@@ -103,15 +111,19 @@ def test_zipf_batches_with_hot_keys_spanning_every_tile(lib):
         b = streams.bench_batch(table, ids, now, algorithm=k & 1, limit=40, duration=3000)
         assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
         groups, short_recs, tile_shapes = sim.part_forms(5000)
-        if lib.compact:
-            # one request shape per batch: every message refers to its tile's shape.  The 32-byte record serves every key whose bucket
+        if lib.short_msgs:
+            assert tile_shapes == groups, (k, groups, tile_shapes)     # one request shape per batch: every message refers to its tile's shape
+        else:
+            assert tile_shapes == 0
+        if lib.short_recs:
+            # The 32-byte record serves every key whose bucket
             # holds what the request says (limit, duration, burst — or no burst) and every new key: all of batch 0 (new) and batch 1
             # (leaky requests meeting token buckets of the same limit), most of the leaky batches after that; a token request that
             # meets a leaky bucket (burst 40 stored, none asked for) gets the 64-byte form — both forms in one batch from batch 2 on
-            assert groups > 2000 and tile_shapes == groups, (k, groups, tile_shapes)
+            assert groups > 2000
             assert short_recs == groups if k < 2 else 0 < short_recs < groups, (k, groups, short_recs)
         else:
-            assert short_recs == 0 and tile_shapes == 0
+            assert short_recs == 0
         now += [1, 700, 1, 3500, 2, 900, 1, 1][k]
     assert sim.counters()[:3] == orc.counters()[:3]
     sim.close()
@@ -144,6 +156,7 @@ def test_owner_rounds_split_when_a_round_does_not_fit(lib):
 def test_hash_collisions_are_reported_and_resolved_by_the_careful_round(lib, pipeline):
     """6 significant hash bits: distinct keys share hashes; the pipelines answer RETRY for those and nothing else, and the careful
     round of the two-launch pipeline (what the engine re-runs them through) gives the oracle's answers"""
+    only_where_the_form_matters(lib, pipeline)
     sim, fix, orc = Sim(lib, weak=1, pipeline=pipeline), None, Oracle()
     rng = np.random.default_rng(11)
     keys = [b"col_%d" % i for i in range(300)]
@@ -199,6 +212,7 @@ def test_the_routing_kernels_agree_with_the_placement(lib):
     shard = guber_placement_route_keys (workers.go:153-155, 180-184 generalised: slot table + hot-key list), GLOBAL requests go to
     the GLOBAL engine, ranks follow the arrival order, the shares' sizes add up — before and after a rebalance that pins hot
     keys; also with the workgroups in a shuffled order (the tile scan runs in whichever workgroup finishes last)."""
+    only_where_the_form_matters(lib, 0)
     import gubernator_amd as ga
     lib.ds_route.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64,
                              C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -239,6 +253,7 @@ def test_bounded_cache_evicts_in_the_reference_order(lib, pipeline, pattern):
     2 000, batches of 1 500 in which evicted keys come back in the same and in the next batch — every answer, the size after every
     batch and the count of unexpired evictions equal the bounded-LRU oracle.  cyclic = the classic worst case (every access of an
     exact LRU misses), expiring = short durations with the clock moving (expired items still hold their place in the list)."""
+    only_where_the_form_matters(lib, pipeline if pattern in ('cyclic', 'expiring') else 0)
     cs, nkeys, bsz = 2000, 2600, 1500
     sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
     rng = np.random.default_rng(11)
@@ -267,6 +282,7 @@ def test_bounded_cache_evicts_in_the_reference_order(lib, pipeline, pattern):
 def test_batches_larger_than_the_cache_are_cut(lib):
     """a cache of 300 items under batches of 1 000 requests over 500 keys: the batch is evaluated in pieces of cache_size requests,
     a key evicted by request i is a new item for request j > i of the same batch (lrucache.go:98-100)"""
+    only_where_the_form_matters(lib, 0)
     cs = 300
     sim, orc = Sim(lib, slots=1 << 14, max_batch=4096, cache_size=cs), Oracle(cache_size=cs)
     rng = np.random.default_rng(5)
