@@ -400,7 +400,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
     e->W.gmsg = e->w_gmsg.p; e->W.gshape = (GShape*)((char*)e->w_gmsg.p + (size_t)e->cap256 * 32);
     e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
-    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
+    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - PT_BITS; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096 + 3 * 2048);
 #endif

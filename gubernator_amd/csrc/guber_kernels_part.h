@@ -31,7 +31,15 @@
 
 namespace guber {
 
-constexpr int PT_PARTS = 256;            // owners per batch (= k_own workgroups)
+#ifndef GUBER_PT_BITS
+#define GUBER_PT_BITS 8
+#endif
+// log2(owners per batch).  8: 175 messages / 112 keys of a Zipf batch per owner — half of a k_own workgroup's lanes idle.  7 (fewer,
+// fuller workgroups) measured +8 % on the Zipf headline and -46 % on uniform keys (512 keys per owner: every round splits after
+// a wasted pass; profiles/r04_z_owners_ab.txt) — a build option, not the default
+constexpr int PT_BITS = GUBER_PT_BITS;
+constexpr int PT_PARTS = 1 << PT_BITS;   // owners per batch (= k_own workgroups)
+static_assert(PT_BITS >= 3 && PT_PARTS <= 256, "k_part sorts a tile's groups by owner with one thread per owner");
 
 // one (key, tile) group, tile -> owner
 struct alignas(64) GMsg {
@@ -119,8 +127,8 @@ GB_HD uint32_t pd_pack(uint32_t j, uint32_t rank, uint32_t err) { return (j & 0x
 __device__ __forceinline__ uint32_t owner_of(const Table& T, const Work& W, uint64_t h) { return (uint32_t)(((h >> 7) & T.mask) >> W.pshift) & (PT_PARTS - 1); }
 // launch order of the owners' workgroups is round-robin over the 8 XCDs: a tile writes the messages of the owners that share an
 // XCD next to each other, so that an L2 sees whole sectors of a tile's region
-GB_HD uint32_t owner_order(uint32_t p) { return ((p & 7u) << 5) | (p >> 3); }
-GB_HD uint32_t owner_from_order(uint32_t q) { return ((q & 31u) << 3) | (q >> 5); }
+GB_HD uint32_t owner_order(uint32_t p) { return ((p & 7u) << (PT_BITS - 3)) | (p >> 3); }
+GB_HD uint32_t owner_from_order(uint32_t q) { return ((q & ((1u << (PT_BITS - 3)) - 1u)) << 3) | (q >> (PT_BITS - 3)); }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     const uint32_t lane = threadIdx.x & 63;
@@ -141,7 +149,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     __shared__ uint32_t sd[FT];                                   // head -> G_* raised by the group's members, then the position of its group's message in the tile's region
     __shared__ uint32_t soff[FT], slen[FT];
     __shared__ int gcmin[FT], gcmax[FT];                          // head -> created_at range of the group (ms from the batch clock, clamped to +-2^17)
-    __shared__ uint32_t pc[PT_PARTS];                             // groups per owner (in owner_order), then where each owner's run starts
+    __shared__ uint32_t pc[FT];                                   // groups per owner (in owner_order), then where each owner's run starts
     __shared__ uint32_t wsum[FT / 64];
     uint32_t* const gfl = sd;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,7 +286,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         for (uint32_t w = 0; w < FT / 64; ++w) before += w < wave ? wsum[w] : 0u;
         const uint32_t start = before + incl - c;
         pc[tid] = start;
-        W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid)] = start | (c << 16);
+        if (tid < (uint32_t)PT_PARTS) W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid)] = start | (c << 16);
     }
     lds_barrier();
     GP_STAMP(0, 4);
@@ -511,7 +519,10 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                     const unsigned long long hh = m0[k].x;
                     uint32_t s = (uint32_t)((hh * 0x9E3779B97F4A7C15ull) >> 55) & (OW_HT - 1);
                     bool won = false;
-                    for (;;) {
+                    // (bounded: a round with more distinct keys than the table has cells — 513 .. OW_MCAP keys of one owner in one batch —
+                    // must come out of here and split, not probe a full table for ever; a key that found no cell raises nkeys past OW_KCAP)
+                    for (uint32_t probes = 0;; ++probes) {
+                        if (probes == (uint32_t)OW_HT) { atomicAdd(&nkeys, (uint32_t)OW_KCAP + 1u); s = 0; break; }
                         const unsigned long long old = atomicCAS(&ktab[s], 0ull, hh);
                         if (old == 0ull) { won = true; break; }
                         if (old == hh) break;

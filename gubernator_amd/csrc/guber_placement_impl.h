@@ -11,17 +11,24 @@
 
 namespace guber_placement_detail {
 constexpr uint32_t kMaxHot = 64, kExCells = 256, kSketchBits = 14, kSketchRows = 2;
+constexpr uint32_t kColdRounds = 3;        // online passes in a row a pinned key must be missing from the heavy hitters before its pin goes
+constexpr uint64_t kMinWindow = 4096;      // observations a pass must have seen before it lets pins age (an idle period forgets nothing)
+constexpr size_t kKeepRetired = 64;        // published snapshots kept alive for readers that loaded the pointer before a publish
 
 struct Exceptions {                     // open addressing on the key hash, immutable once published
     uint32_t n = 0;
     uint64_t h[kExCells] = {0};
     uint16_t s[kExCells] = {0};
+    uint8_t cold[kExCells] = {0};       // online passes in a row the key was not heavy (host only: the device sees h[] and s[])
     static uint32_t home(uint64_t x) { return (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 56); }
     void put(uint64_t key, uint16_t shard) {
         uint32_t i = home(key);
         while (h[i] != 0 && h[i] != key) i = (i + 1) & (kExCells - 1);
         if (h[i] == 0) n++;
-        h[i] = key; s[i] = shard;
+        h[i] = key; s[i] = shard; cold[i] = 0;
+    }
+    void set_cold(uint64_t key, uint8_t c) {
+        for (uint32_t i = home(key); h[i] != 0; i = (i + 1) & (kExCells - 1)) if (h[i] == key) { cold[i] = c; return; }
     }
     int get(uint64_t key) const {
         if (n == 0) return -1;
@@ -41,7 +48,7 @@ struct guber_placement {
     uint64_t inv_step = 0, inv_sub = 0;                     // floor(2^64 / step), floor(2^64 * per / step)
     std::unique_ptr<std::atomic<uint16_t>[]> table;        // slot -> shard
     std::atomic<const Exceptions*> ex{nullptr};
-    std::vector<std::unique_ptr<Exceptions>> retired;       // every snapshot ever published (a few hundred bytes each)
+    std::vector<std::unique_ptr<Exceptions>> retired;       // the last kKeepRetired snapshots published (2.8 KB each): a reader uses the pointer it loaded for a few instructions
     std::unique_ptr<std::atomic<uint64_t>[]> slot_w;        // requests observed per slot
     std::unique_ptr<Cell[]> sketch;                         // [rows][1 << bits]
     std::unique_ptr<Exceptions> pending;                    // guber_placement_plan's list, waiting for guber_placement_commit

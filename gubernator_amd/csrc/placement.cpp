@@ -90,8 +90,9 @@ extern "C" int guber_placement_observe_keys(guber_placement_t* p, const uint8_t*
 
 // Longest-processing-time-first over what was observed since the last call.  move_slots != 0: slots and hot keys are all
 // placed afresh (only legal while no key of this placement is resident anywhere: before the first request, or offline);
-// move_slots == 0: the slot table stays, only keys that became heavy are given a shard of their own choice (the least
-// loaded one) — those are the moves reported, for the caller to migrate.
+// move_slots == 0: the slot table stays, keys that became heavy are given a shard of their own choice (the least loaded one)
+// and pins of keys that stopped being heavy kColdRounds passes ago are taken back — those are the moves reported, for the
+// caller to migrate (at most `cap` of them per pass: what does not fit waits for the next).
 // plan (p->mu held): the new exception list (and, with move_slots, the new slot table written in place); nothing published
 static uint32_t plan_locked(guber_placement* p, double heavy_fraction, int move_slots, guber_placement_move_t* moves, uint32_t cap,
                             std::unique_ptr<Exceptions>& ne) {
@@ -142,10 +143,32 @@ static uint32_t plan_locked(guber_placement* p, double heavy_fraction, int move_
             } else p->table[it.id].store((uint16_t)j, std::memory_order_relaxed);
         }
     } else {
+        // pins AGE: a key that has not been heavy for kColdRounds passes in a row (each over a window that saw real traffic) follows
+        // its slot again — reported as a move back to the slot's shard, so that the caller migrates the bucket — and makes room for
+        // the keys that are heavy now (without this a drifting hot set ends in kMaxHot stale pins and no isolation for new ones)
+        const uint32_t room = moves ? cap : 0xffffffffu;                          // never more moves than the caller can take
+        *ne = Exceptions();
+        if (old) {
+            for (uint32_t i = 0; i < kExCells; ++i) {
+                const uint64_t h = old->h[i];
+                if (h == 0) continue;
+                bool heavy = false;
+                for (auto& x : hot) if (x.h == h) { heavy = true; break; }
+                const uint32_t c = heavy ? 0u : (total >= kMinWindow ? (uint32_t)old->cold[i] + 1u : (uint32_t)old->cold[i]);
+                const uint32_t slot_shard = p->table[p->slot_of(h)].load();
+                if (c >= kColdRounds && (slot_shard == old->s[i] || nm < room)) {
+                    if (slot_shard != old->s[i]) { if (moves && nm < cap) moves[nm] = guber_placement_move_t{h, old->s[i], slot_shard}; nm++; }
+                    continue;                                                      // the pin is gone
+                }
+                ne->put(h, old->s[i]);
+                ne->set_cold(h, (uint8_t)std::min(c, 255u));
+            }
+        }
         for (uint32_t s = 0; s < p->n_slots; ++s) load[p->table[s].load()] += sw[s];
         for (auto& x : hot) { const int s = ne->get(x.h); if (s >= 0) load[s] += x.w; }     // already isolated: stays where it is
         for (auto& x : hot) {
             if (ne->get(x.h) >= 0 || ne->n >= kMaxHot) continue;
+            if (nm >= room) break;
             const uint32_t from = p->table[p->slot_of(x.h)].load();
             const uint32_t j = least();
             load[j] += x.w;
@@ -163,6 +186,7 @@ static void publish_locked(guber_placement* p, std::unique_ptr<Exceptions>& ne) 
         p->retired.push_back(std::move(ne));
         p->ex.store(p->retired.back().get(), std::memory_order_release);
         p->version.fetch_add(1, std::memory_order_acq_rel);
+        if (p->retired.size() > kKeepRetired) p->retired.erase(p->retired.begin());   // (a reader holds a snapshot for a handful of instructions, not for 64 publishes)
     }
     for (uint32_t s = 0; s < p->n_slots; ++s) p->slot_w[s].store(0);
     for (size_t k = 0; k < ((size_t)kSketchRows << kSketchBits); ++k) { p->sketch[k].h.store(0); p->sketch[k].c.store(0); }
@@ -192,14 +216,19 @@ extern "C" int guber_placement_plan(guber_placement_t* p, double heavy_fraction,
     if (n_moves) *n_moves = nm;
     return (moves && nm > cap) ? GUBER_E_NOMEM : GUBER_OK;
 }
-// a planned move whose bucket could not be migrated: the key keeps following its slot (nothing a reader sees changes for it)
+// a planned move whose bucket could not be migrated: the key stays where the published placement has it — following its slot (a
+// new pin is dropped) or pinned (a pin that had aged out is kept) — nothing a reader sees changes for it
 extern "C" int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash) {
     if (!p) return GUBER_E_INVALID_ARG;
     std::lock_guard<std::mutex> lk(p->mu);
-    if (!p->pending || p->pending->get(key_hash) < 0) return GUBER_OK;
+    if (!p->pending) return GUBER_OK;
+    const Exceptions* pub = p->ex.load();
+    const int was = pub ? pub->get(key_hash) : -1;                              // where the published placement pins the key (-1: it follows its slot)
+    if (p->pending->get(key_hash) == was) return GUBER_OK;                      // nothing planned for this key
     std::unique_ptr<guber_placement::Exceptions> ne(new guber_placement::Exceptions());
     for (uint32_t i = 0; i < guber_placement_detail::kExCells; ++i)
-        if (p->pending->h[i] != 0 && p->pending->h[i] != key_hash) ne->put(p->pending->h[i], p->pending->s[i]);
+        if (p->pending->h[i] != 0 && p->pending->h[i] != key_hash) { ne->put(p->pending->h[i], p->pending->s[i]); ne->set_cold(p->pending->h[i], p->pending->cold[i]); }
+    if (was >= 0) ne->put(key_hash, (uint16_t)was);                              // a pin that was to go stays (its bucket could not be moved back)
     p->pending = std::move(ne);
     return GUBER_OK;
 }

@@ -535,8 +535,12 @@ int64_t guber_pool_size(guber_pool_t* p);
  *                                         move_slots = 1: slots and hot keys are placed afresh — only while no key of this
  *                                         placement is resident (before the first request, offline);
  *                                         move_slots = 0: the slot table stays; keys that became heavy get the least loaded
- *                                         shard.  moves[] lists the hot keys whose shard changed: the caller migrates their
- *                                         buckets (GPUWorkerPool does, at a batch boundary) before serving them there.
+ *                                         shard, and a key that has not been heavy for three passes in a row (each over at
+ *                                         least 4096 observations) loses its individual place and follows its slot again, so
+ *                                         that a drifting hot set never exhausts the 64 places.  moves[] lists the keys whose
+ *                                         shard changed, either way (at most cap per pass; the rest waits for the next): the
+ *                                         caller migrates their buckets (GPUWorkerPool does, at a batch boundary) before
+ *                                         serving them there.
  *      Readers are wait-free; guber_placement_version changes with every rebalance. */
 typedef struct guber_placement guber_placement_t;
 typedef struct guber_placement_move { uint64_t key_hash; uint32_t from, to; } guber_placement_move_t;
@@ -556,7 +560,8 @@ int guber_placement_info(const guber_placement_t* p, uint32_t* n_shards, uint32_
  * (version + 1) and starts a fresh observation round. */
 int guber_placement_plan(guber_placement_t* p, double heavy_fraction, guber_placement_move_t* moves, uint32_t cap, uint32_t* n_moves);
 int guber_placement_commit(guber_placement_t* p);
-/* between plan and commit: drop one planned move (its bucket could not be migrated): the key keeps following its slot */
+/* between plan and commit: drop one planned move (its bucket could not be migrated): the key stays where the published placement
+ * has it (following its slot, or at its individual place if that was to be taken back) */
 int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash);
 /* the published placement in the form guber_stage_route takes (global_engine = -1; the pointers stay valid until the placement is
  * destroyed: a commit publishes new snapshots and retires, never frees, the old ones — export again after every commit) */

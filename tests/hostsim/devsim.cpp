@@ -212,7 +212,7 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->W.gmsg = d->gmsg.data(); d->W.gshape = (GShape*)((char*)d->gmsg.data() + (size_t)d->cap * 32);
     d->W.grs = (GRecS*)d->grec.data(); d->W.grec = d->grec.data() + d->cap / 2; d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
     uint32_t lg = 0; while ((1ull << lg) < s) lg++;
-    d->W.pshift = lg - 8;
+    d->W.pshift = lg - PT_BITS;
     return d;
 }
 void ds_destroy(void* h) { delete (DevSim*)h; }

@@ -41,6 +41,28 @@ def test_get_peer_rate_limits_order_stable():
         e.close()
 
 
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("nkeys", [513, 700])
+def test_more_keys_of_one_owner_than_its_lds_table_has_cells(nkeys):
+    """the owner-partitioned pipeline, 513 / 700 DISTINCT keys that share ONE owner workgroup (the top 8 bits of the home position) in
+    one batch: one round's worth of messages, more keys than the round's LDS hash table has cells.  k_own's insert loop is bounded
+    and the round splits (it used to probe the full table for ever: tests/test_kernels_devsim.py has the CPU twin)"""
+    slots = 1 << 20
+    ol = support.oracle_lib()
+    keys, i = [], 0
+    while len(keys) < nkeys:
+        k = b"own_%d" % i
+        i += 1
+        if ((ol.oracle_xxhash64(k, len(k), 0) >> 7) & (slots - 1)) >> 12 == 0:
+            keys.append(k)
+    o, e = Oracle(cache_size=1 << 20), engine(cache_size=1 << 16, max_batch=4096, table_slots=slots, flags=ga.FLAG_TEST_FORCE_PART)
+    assert e.stats()["table_slots"] == slots
+    for rnd in range(2):
+        b = HostBatch(keys, 1, 5, 60000, streams.NOW0 + rnd)
+        support.assert_results_equal(e.eval(b), o.eval(b), f"round {rnd}")
+    e.close()
+
+
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
 # mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline;
 # 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path);

@@ -16,8 +16,9 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 
 
 # every form of what travels between k_part, k_own and k_eval3: the product's default (64-byte messages, 32-byte records that leave out
-# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), and 64 bytes both ways
-@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so"])
+# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), 64 bytes both ways, and the default form with
+# 128 owners per batch instead of 256 (GUBER_PT_BITS=7)
+@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so", "libdevsim_p7.so"])
 def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
     L = C.CDLL(os.path.join(HS, request.param))
@@ -149,6 +150,37 @@ def test_owner_rounds_split_when_a_round_does_not_fit(lib):
         rng.shuffle(ids)
         b = HostBatch([keys[j] for j in ids], 1, 5, 60000, now + rnd)
         assert_results_equal(sim.eval(b), orc.eval(b), f"round {rnd}")
+    sim.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nkeys", [513, 600, 768])
+def test_more_keys_of_one_owner_than_its_lds_table_has_cells(lib, nkeys):
+    """513 .. 768 DISTINCT keys of one owner in one batch: few enough messages for one round (<= OW_MCAP), more keys than the round's
+    LDS hash table has cells (OW_HT = 512).  The insert loop used to probe the full table for ever (a hang of k_own — found on the GPU
+    with 128 owners per batch and uniform keys, reachable with 256 by keys chosen to share an owner); it is bounded now and the round
+    splits"""
+    only_where_the_form_matters(lib, 1 if lib.product_form or "p7" in lib._name else 0)
+    from support import oracle_lib
+    ol = oracle_lib()
+    keys, i = [], 0
+    while len(keys) < nkeys:
+        k = b"own_%d" % i
+        i += 1
+        if ((ol.oracle_xxhash64(k, len(k), 0) >> 7) & ((1 << 20) - 1)) >> 12 == 0:
+            keys.append(k)
+    sim, orc = Sim(lib, slots=1 << 20, max_batch=2304), Oracle()
+    for rnd in range(2):
+        b = HostBatch(keys, 1, 5, 60000, streams.NOW0 + rnd)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"round {rnd}")
+    # ... and keys that come back in other tiles of the batch (several groups per key, rank bases across tiles) while the owner's
+    # round has to split: 450 of the keys, 750 requests in 3 tiles
+    rng = np.random.default_rng(nkeys)
+    for rnd in range(2):
+        ids = np.concatenate([np.arange(450), rng.integers(0, 450, 300)])
+        rng.shuffle(ids)
+        b = HostBatch([keys[j] for j in ids], 1, 5, 60000, streams.NOW0 + 10 + rnd, algorithm=(ids % 2).astype(np.uint8))
+        assert_results_equal(sim.eval(b), orc.eval(b), f"split round, round {rnd}")
     sim.close()
 
 

@@ -70,3 +70,47 @@ def test_online_pass_moves_only_hot_keys_and_reports_them():
     assert all(m[0] == int(hashes[4242]) for m in moves) and len(moves) <= 1
     assert pl.n_hot() == 1
     pl.close()
+
+
+def test_individual_places_age_out_when_the_hot_set_drifts():
+    """online passes (the slot table stays): a key that stopped being heavy three passes ago follows its slot again — reported as a move
+    back, so that its bucket can be migrated — and the 64 individual places never fill up with yesterday's hot keys (placement.cpp
+    plan_locked).  An idle pass (too few observations) forgets nothing."""
+    nk, S = 50_000, 8
+    pl = ga.Placement(S)
+    slot_shard, hashes = pl.route_keys(*_keys(nk))
+    slot_shard = slot_shard.copy()
+    rng = np.random.default_rng(5)
+
+    def window(hot_ids, n=200_000):
+        ids = np.concatenate([np.repeat(np.asarray(hot_ids), 12_000), rng.integers(0, nk, n)])
+        pl.observe_keys(*_keys(nk, ids))
+        return pl.rebalance(0.125, False)
+
+    first = [101, 202, 303]
+    moves = window(first)
+    assert pl.n_hot() == 3
+    pinned = {int(hashes[k]): pl.shard(int(hashes[k])) for k in first}
+    assert all(m[0] in pinned and m[2] == pinned[m[0]] for m in moves)
+    # an idle pass: a handful of requests says nothing about what is hot
+    pl.observe_keys(*_keys(nk, rng.integers(0, nk, 100)))
+    assert pl.rebalance(0.125, False) == [] and pl.n_hot() == 3
+    # the hot set drifts: other keys are heavy now; the old ones cool for three passes, then go
+    back = []
+    for rnd in range(4):
+        second = [4000 + rnd * 7 + j for j in range(3)]                          # (a new trio every pass: drift)
+        mv = window(second)
+        back += [m for m in mv if m[0] in pinned]
+        if rnd < 2:
+            assert all(pl.shard(h) == s for h, s in pinned.items()), rnd          # not yet: two cold passes are not three
+    assert all(pl.shard(int(hashes[k])) == slot_shard[k] for k in first)         # they follow their slots again
+    assert {m[0] for m in back} == {h for h, s in pinned.items() if s != slot_shard[[int(x) for x in hashes].index(h)]}
+    assert all(m[1] == pinned[m[0]] and m[2] == pl.shard(m[0]) for m in back)    # reported from the individual place back to the slot's shard
+    assert pl.n_hot() <= 3 * 3                                                    # only the recent trios hold places (each ages out in turn)
+    # many more drifting rounds never exhaust the 64 places
+    for rnd in range(40):
+        window([10_000 + rnd * 5 + j for j in range(4)])
+        assert pl.n_hot() <= 4 * 4, (rnd, pl.n_hot())
+    latest = [10_000 + 39 * 5 + j for j in range(4)]
+    assert all(pl.shard(int(hashes[k])) is not None for k in latest)
+    pl.close()
