@@ -8,9 +8,9 @@ TAG=${1:-r04_final2}
 cd $R
 O=gpurun_out/$TAG; mkdir -p $O
 (nproc; cat /sys/fs/cgroup/cpu.max; lscpu | grep -E "Model name|Socket|Core|Thread") > $O/host_cpus.txt 2>&1
-timeout 400 python -m pytest tests -m gpu -q -s > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|device wire decode|native global sync" $O/pytest_gpu.txt | cut -c1-300
+timeout 150 python -m pytest tests -m gpu -q -s > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|device wire decode|native global sync" $O/pytest_gpu.txt | cut -c1-300
 T0=$SECONDS
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$? wall $((SECONDS-T0)) s"
+timeout 220 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench(driver cmd) rc=$? wall $((SECONDS-T0)) s"
 python - <<PY
 import json
 d=json.load(open("$O/bench_driver_cmd.json"))
