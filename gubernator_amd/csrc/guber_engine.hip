@@ -106,7 +106,7 @@ struct guber_engine {
     DevBuf<uint32_t> w_did2;
     // owner-partitioned pipeline (guber_kernels_part.h): messages tile -> owner, records owner -> tile, runs per (tile, owner),
     // tile maps of walked segments, the per-request words.  cap256 = fast_cap rounded up to whole tiles.
-    DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3; DevBuf<unsigned long long> w_segtiles;
+    DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3, w_pmode; DevBuf<unsigned long long> w_segtiles;
     uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false; uint64_t part_batches = 0;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
@@ -347,7 +347,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (const char* v = getenv("GUBER_PART_MIN")) e->part_min = (uint32_t)std::max(257, atoi(v));
     if (e->force_part) e->part_min = 1;
     rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure((size_t)e->cap256 + e->cap256 / 2); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);   // (grec: 32-byte records first, then the 64-byte form)
-    rc |= e->w_did3.ensure(e->cap256); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4);
+    rc |= e->w_did3.ensure(e->cap256); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4); rc |= e->w_pmode.ensure(16);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
@@ -364,6 +364,10 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (!rc) memset(e->h_rb_seq.p, 0, (guber_engine::kRb + 1) * sizeof(uint32_t));
     if (rc) { guber_engine_destroy(e); return GUBER_E_NOMEM; }
     hipError_t he = hipSuccess;
+    // owners per batch of the owner-partitioned pipeline: starts at 128 and follows the traffic on the device (guber_kernels_part.h
+    // "HOW MANY OWNERS"); GUBER_PT_BITS=7|8 pins it (measurements, tests)
+    uint32_t pm0[4] = {7u, 0u, 0u, 0u};
+    if (const char* v = getenv("GUBER_PT_BITS")) { const int b = atoi(v); if (b == 7 || b == 8) { pm0[0] = (uint32_t)b; pm0[3] = 1u; } }
     if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->buckets.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
@@ -373,6 +377,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
         (he = hipMemsetAsync(e->w_did2.p, 0, (size_t)2 * e->fast_cap * 4, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_segtiles.p, 0, (size_t)e->cap256 * 4 * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_gse.p, 0, (size_t)FT_MAX_TILES * PT_PARTS * 4, e->stream)) != hipSuccess ||
+        (he = hipMemcpyAsync(e->w_pmode.p, pm0, sizeof(pm0), hipMemcpyHostToDevice, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_claims.p, 0, (size_t)e->claims_cells * 8, e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->w_u32.p, 0, (size_t)M * 14 * 4, e->stream)) != hipSuccess ||
         (e->gpend.p && (he = hipMemsetAsync(e->gpend.p, 0, e->slots * sizeof(GPend), e->stream)) != hipSuccess) ||
@@ -399,8 +404,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
     e->W.gmsg = e->w_gmsg.p; e->W.gshape = (GShape*)((char*)e->w_gmsg.p + (size_t)e->cap256 * 32);
-    e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p;
-    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - PT_BITS; }   // (slots >= 1024)
+    e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p; e->W.pmode = e->w_pmode.p;
+    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096 + 3 * 2048);
 #endif
@@ -453,7 +458,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     e->bctr.release(); e->h_bctr.release();
     e->w_tilemask.release(); e->w_srec.release(); e->w_sinv.release(); e->w_tilerow.release();
     e->w_did2.release();
-    e->w_gmsg.release(); e->w_grec.release(); e->w_gse.release(); e->w_did3.release(); e->w_segtiles.release();
+    e->w_gmsg.release(); e->w_grec.release(); e->w_gse.release(); e->w_did3.release(); e->w_pmode.release(); e->w_segtiles.release();
     e->d_keys.release(); e->d_off.release(); e->d_i64.release(); e->d_beh.release(); e->d_u8.release();
     e->d_out64.release(); e->d_out8.release(); e->h_stage.release(); e->h_ctr.release(); e->h_rb_seq.release(); e->z_stage.release();
     e->d_stash64.release(); e->d_stash32.release(); e->d_stash8.release();

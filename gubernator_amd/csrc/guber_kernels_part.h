@@ -31,15 +31,16 @@
 
 namespace guber {
 
-#ifndef GUBER_PT_BITS
-#define GUBER_PT_BITS 8
-#endif
-// log2(owners per batch).  8: 175 messages / 112 keys of a Zipf batch per owner — half of a k_own workgroup's lanes idle.  7 (fewer,
-// fuller workgroups) measured +8 % on the Zipf headline and -46 % on uniform keys (512 keys per owner: every round splits after
-// a wasted pass; profiles/r04_z_owners_ab.txt) — a build option, not the default
-constexpr int PT_BITS = GUBER_PT_BITS;
-constexpr int PT_PARTS = 1 << PT_BITS;   // owners per batch (= k_own workgroups)
-static_assert(PT_BITS >= 3 && PT_PARTS <= 256, "k_part sorts a tile's groups by owner with one thread per owner");
+constexpr int PT_PARTS = 256;            // k_own workgroups launched per batch = the largest number of owners
+// HOW MANY OWNERS a batch is split over follows the traffic, on the device, batch by batch (Work::pmode, four words per engine):
+// 128 (7 bits) or 256 (8 bits).  With 256 a Zipf batch gives a k_own workgroup 175 messages / 112 keys — half of its lanes idle for
+// the whole residency; with 128 it gets 350 / 225 and the pipeline is 8 % faster (profiles/r04_z_owners_ab.txt).  With 128 a batch
+// of uniform keys brings 512 keys per owner: every round splits after a wasted gather and the pipeline is 46 % slower.  So: k_own
+// counts the rounds that split for their number of keys (pmode[2]); the batch's k_eval3 — after every k_own workgroup, before the
+// next batch's k_part — moves to 8 bits for PM_HOLD batches when PM_SPLITS or more did, and back to 7 afterwards (a probe: one slower
+// batch in PM_HOLD + 1 if the traffic is still uniform).  pmode[3] != 0 pins the mode (GUBER_PT_BITS=7|8, tests).
+constexpr uint32_t PM_SPLITS = 8, PM_HOLD = 255;
+GB_HD uint32_t pm_bits(const uint32_t* pm) { return pm[0] == 7u ? 7u : 8u; }
 
 // one (key, tile) group, tile -> owner
 struct alignas(64) GMsg {
@@ -124,11 +125,12 @@ GB_HD unsigned long long gr_tail(uint32_t sf, uint32_t err, uint32_t base, uint3
 GB_HD uint32_t pd_pack(uint32_t j, uint32_t rank, uint32_t err) { return (j & 0xffu) | ((rank & 0xffu) << 8) | ((err & 0xffu) << 16) | 0x80000000u; }
 
 // owner of a key: the top PT_PARTS bits of its home position — an owner's keys live in one contiguous 1/256 of the table
-__device__ __forceinline__ uint32_t owner_of(const Table& T, const Work& W, uint64_t h) { return (uint32_t)(((h >> 7) & T.mask) >> W.pshift) & (PT_PARTS - 1); }
+// (W.pshift = log2(slots) - 8: the shift for 256 owners)
+__device__ __forceinline__ uint32_t owner_of(const Table& T, const Work& W, uint64_t h, uint32_t pbits) { return (uint32_t)(((h >> 7) & T.mask) >> (W.pshift + 8u - pbits)) & ((1u << pbits) - 1u); }
 // launch order of the owners' workgroups is round-robin over the 8 XCDs: a tile writes the messages of the owners that share an
 // XCD next to each other, so that an L2 sees whole sectors of a tile's region
-GB_HD uint32_t owner_order(uint32_t p) { return ((p & 7u) << (PT_BITS - 3)) | (p >> 3); }
-GB_HD uint32_t owner_from_order(uint32_t q) { return ((q & ((1u << (PT_BITS - 3)) - 1u)) << 3) | (q >> (PT_BITS - 3)); }
+GB_HD uint32_t owner_order(uint32_t p, uint32_t pbits) { return ((p & 7u) << (pbits - 3u)) | (p >> 3); }
+GB_HD uint32_t owner_from_order(uint32_t q, uint32_t pbits) { return ((q & ((1u << (pbits - 3u)) - 1u)) << 3) | (q >> (pbits - 3u)); }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     const uint32_t lane = threadIdx.x & 63;
@@ -155,6 +157,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
+    const uint32_t pbits = pm_bits(W.pmode);                      // owners of this batch: 1 << pbits
     GP_STAMP(0, 0);
 
     if (tile == 0 && W.snap_seq) {                                // a counter read-back rides on this launch (Work::snap_*)
@@ -257,7 +260,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         if (len > 16) f |= G_LONG;
         if (cfar) f |= G_CFAR;
         gfl[tid] = f; gcmin[tid] = cd; gcmax[tid] = cd;
-        q = owner_order(owner_of(T, W, h));
+        q = owner_order(owner_of(T, W, h, pbits), pbits);
         qr = atomicAdd(&pc[q], 1u);
     }
     lds_barrier();
@@ -286,7 +289,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         for (uint32_t w = 0; w < FT / 64; ++w) before += w < wave ? wsum[w] : 0u;
         const uint32_t start = before + incl - c;
         pc[tid] = start;
-        if (tid < (uint32_t)PT_PARTS) W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid)] = start | (c << 16);
+        if (tid < (1u << pbits)) W.gse[(size_t)tile * PT_PARTS + owner_from_order(tid, pbits)] = start | (c << 16);
     }
     lds_barrier();
     GP_STAMP(0, 4);
@@ -417,6 +420,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ int sp;
     GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (p >= (1u << pm_bits(W.pmode))) return;          // (256 workgroups are launched per batch whatever the batch's owner count)
 #if GUBER_PART_MSG32
     __shared__ GShape tshape[256];                      // tile -> the shape of its request 0 (what a G_SHAPE0 message refers to)
 #endif
@@ -544,6 +548,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             }
             lds_barrier();
             split = nkeys > OW_KCAP;
+            if (split && t == 0) atomicAdd(&W.pmode[2], 1u);          // a round that split for its number of keys: what the owner count follows
         }
         if (split) {
             // the round does not fit: two rounds on one more bit of the home position (nothing outside LDS was touched yet)
@@ -1004,6 +1009,17 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
         if (threadIdx.x == 0 && (cnt[0] | cnt[1] | cnt[2] | cnt[3])) {
             BlockCounters* bc = &T.bctr[tile];
             bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
+        }
+    }
+    // the owner count of the next batch (all of this batch's k_own workgroups are done, the next batch's k_part has not started)
+    if (tile == 0 && threadIdx.x == 0) {
+        uint32_t* pm = W.pmode;
+        const uint32_t splits = pm[2];
+        pm[2] = 0u;
+        if (pm[3] == 0u) {
+            if (pm[0] == 7u) { if (splits >= PM_SPLITS) { pm[0] = 8u; pm[1] = PM_HOLD; } }
+            else if (pm[1] > 1u) pm[1]--;
+            else { pm[0] = 7u; pm[1] = 0u; }
         }
     }
     GP_STAMPW(2, 3);

@@ -164,7 +164,8 @@ struct Work {
     uint32_t* gse;                      // [FT_MAX_TILES][PT_PARTS] start | count << 16
     GRec* grec;                         // [cap] the owner's answer to message i: bucket before the batch, slot, flags, rank base, total
     unsigned long long* segtiles;       // [cap][4] tiles holding a segment whose requests are walked serially (all zero between batches)
-    uint32_t pshift;                    // owner of a key = its home position >> pshift
+    uint32_t pshift;                    // owner of a key (256 owners) = its home position >> pshift
+    uint32_t* pmode;                    // [4] device words: owner bits of the next batch (7 | 8), batches left at 8, rounds that split in this batch, pinned
     // the compact forms (GUBER_PART_COMPACT, guber_kernels_part.h): 32-byte messages live in the first half of gmsg[], the
     // request shapes they refer to in the second half (gshape); 32-byte records in grs[], the 64-byte form (grec[]) only for
     // the groups whose record does not fit

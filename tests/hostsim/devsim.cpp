@@ -111,6 +111,7 @@ using namespace guber;
 // ---- a table and the per-batch work arrays in host memory, laid out as guber_engine_create does -----------------------------
 struct DevSim {
     uint64_t slots = 0; uint32_t max_batch = 0, cap = 0;
+    uint32_t pmode[4] = {7, 0, 0, 0};                              // Work::pmode: the owner count follows the traffic (guber_kernels_part.h)
     Table T{}; Work W{};
     std::vector<DirEntry> dir; std::vector<Bucket> buckets; std::vector<uint8_t> arena; DevCounters ctr{}; std::vector<BlockCounters> bctr;
     std::vector<uint32_t> u32; std::vector<uint8_t> rflags; std::vector<unsigned long long> tilemask, claims, segtiles; std::vector<SegRec> srec;
@@ -212,10 +213,16 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->W.gmsg = d->gmsg.data(); d->W.gshape = (GShape*)((char*)d->gmsg.data() + (size_t)d->cap * 32);
     d->W.grs = (GRecS*)d->grec.data(); d->W.grec = d->grec.data() + d->cap / 2; d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
     uint32_t lg = 0; while ((1ull << lg) < s) lg++;
-    d->W.pshift = lg - PT_BITS;
+    d->W.pshift = lg - 8;
+    d->pmode[0] = 7; d->pmode[1] = d->pmode[2] = d->pmode[3] = 0; d->W.pmode = d->pmode;
     return d;
 }
 void ds_destroy(void* h) { delete (DevSim*)h; }
+// owners per batch: bits = 7 | 8 pinned, 0 = follow the traffic (the default); ds_owner_bits: what the next batch will use
+void ds_pin_owner_bits(void* h, uint32_t bits) { DevSim* d = (DevSim*)h; d->pmode[3] = bits ? 1u : 0u; if (bits) d->pmode[0] = bits; d->pmode[1] = d->pmode[2] = 0; }
+uint32_t ds_owner_bits(void* h) { return ((DevSim*)h)->pmode[0]; }
+// batches left with 256 owners (pmode[1]): read, or shorten for a test (n != 0)
+uint32_t ds_owner_hold(void* h, uint32_t n) { DevSim* d = (DevSim*)h; if (n) d->pmode[1] = n; return d->pmode[1]; }
 void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
 
 static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int pipeline, int careful);

@@ -63,6 +63,27 @@ def test_more_keys_of_one_owner_than_its_lds_table_has_cells(nkeys):
     e.close()
 
 
+@pytest.mark.parametrize("bits", ["7", "8", ""])
+def test_owner_partitioned_pipeline_with_either_owner_count(bits, monkeypatch):
+    """the owner-partitioned pipeline splits a batch over 128 or 256 owner workgroups, following the traffic on the device
+    (guber_kernels_part.h "HOW MANY OWNERS"; GUBER_PT_BITS pins it): adversarial streams, then batches of 40 000 distinct keys
+    (312 / 156 per owner: with 128 owners some rounds split, the count moves to 256 by itself when it is free to) — equal to the oracle"""
+    if bits:
+        monkeypatch.setenv("GUBER_PT_BITS", bits)
+    else:
+        monkeypatch.delenv("GUBER_PT_BITS", raising=False)
+    o, e = Oracle(cache_size=1 << 20), engine(cache_size=1 << 18, flags=ga.FLAG_TEST_FORCE_PART)
+    for bi, b in enumerate(streams.adversarial_batches(5, 12, 3000, greg_fn=support.gregorian)):
+        support.assert_results_equal(e.eval(b), o.eval(b), f"bits {bits!r} batch {bi}")
+    table = streams.key_table(120_000)
+    rng = np.random.default_rng(17)
+    for rnd in range(4):
+        ids = rng.permutation(120_000)[:40_000]
+        b = streams.bench_batch(table, ids, streams.NOW0 + 100 + rnd, limit=20, duration=60_000)
+        support.assert_results_equal(e.eval(b), o.eval(b), f"bits {bits!r} distinct keys {rnd}")
+    e.close()
+
+
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
 # mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline;
 # 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path);

@@ -16,12 +16,14 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 
 
 # every form of what travels between k_part, k_own and k_eval3: the product's default (64-byte messages, 32-byte records that leave out
-# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), 64 bytes both ways, and the default form with
-# 128 owners per batch instead of 256 (GUBER_PT_BITS=7)
-@pytest.fixture(scope="module", params=["libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so", "libdevsim_p7.so"])
+# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), 64 bytes both ways; and the default form with
+# the owner count (128 or 256 per batch: Work::pmode) pinned either way instead of following the traffic
+@pytest.fixture(scope="module", params=[("libdevsim.so", 0), ("libdevsim_compact.so", 0), ("libdevsim_wide.so", 0), ("libdevsim.so", 7), ("libdevsim.so", 8)],
+                ids=lambda p: p[0][3:-3] + (f"-owners{1 << p[1]}" if p[1] else ""))
 def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
-    L = C.CDLL(os.path.join(HS, request.param))
+    request_param, owner_bits = request.param
+    L = C.CDLL(os.path.join(HS, request_param))
     L.ds_create.restype = C.c_void_p
     L.ds_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int]
     L.ds_destroy.argtypes = [C.c_void_p]
@@ -32,8 +34,14 @@ def lib(request):
     L.ds_create_bounded.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
     L.ds_lru_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     L.ds_part_forms.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_ulonglong)]
-    L.short_recs, L.short_msgs = "wide" not in request.param, "compact" in request.param
-    L.product_form = request.param == "libdevsim.so"
+    L.ds_pin_owner_bits.argtypes = [C.c_void_p, C.c_uint32]
+    L.ds_owner_bits.argtypes = [C.c_void_p]
+    L.ds_owner_bits.restype = C.c_uint32
+    L.ds_owner_hold.argtypes = [C.c_void_p, C.c_uint32]
+    L.ds_owner_hold.restype = C.c_uint32
+    L.short_recs, L.short_msgs = "wide" not in request_param, "compact" in request_param
+    L.owner_bits = owner_bits
+    L.product_form = request_param == "libdevsim.so" and owner_bits == 0
     return L
 
 
@@ -47,6 +55,11 @@ class Sim:
     def __init__(self, lib, slots=4096, max_batch=4096, weak=0, pipeline=1, cache_size=0):
         self.lib, self.pipeline = lib, pipeline
         self.h = lib.ds_create_bounded(slots, max_batch, weak, cache_size)
+        if lib.owner_bits:
+            lib.ds_pin_owner_bits(self.h, lib.owner_bits)
+
+    def owner_bits(self):
+        return self.lib.ds_owner_bits(self.h)
 
     def lru_stats(self):
         out = (C.c_ulonglong * 6)()
@@ -160,7 +173,7 @@ def test_more_keys_of_one_owner_than_its_lds_table_has_cells(lib, nkeys):
     LDS hash table has cells (OW_HT = 512).  The insert loop used to probe the full table for ever (a hang of k_own — found on the GPU
     with 128 owners per batch and uniform keys, reachable with 256 by keys chosen to share an owner); it is bounded now and the round
     splits"""
-    only_where_the_form_matters(lib, 1 if lib.product_form or "p7" in lib._name else 0)
+    only_where_the_form_matters(lib, 1 if lib.product_form or lib.owner_bits else 0)
     from support import oracle_lib
     ol = oracle_lib()
     keys, i = [], 0
@@ -181,6 +194,50 @@ def test_more_keys_of_one_owner_than_its_lds_table_has_cells(lib, nkeys):
         rng.shuffle(ids)
         b = HostBatch([keys[j] for j in ids], 1, 5, 60000, streams.NOW0 + 10 + rnd, algorithm=(ids % 2).astype(np.uint8))
         assert_results_equal(sim.eval(b), orc.eval(b), f"split round, round {rnd}")
+    sim.close()
+
+
+def test_the_owner_count_follows_the_traffic(lib):
+    """Work::pmode: a batch starts with 128 owners; when 8 or more of them split a round for their number of keys (uniform keys:
+    512 per owner), the batch's k_eval3 moves the next 255 batches to 256 owners, then probes 128 again — answers equal to the
+    oracle all the way (guber_kernels_part.h "HOW MANY OWNERS")"""
+    if lib.owner_bits or not lib.product_form:
+        pytest.skip("the traffic-following mode of the product's form")
+    sim, orc = Sim(lib, slots=1 << 20, max_batch=8192), Oracle(cache_size=1 << 20)
+    assert sim.owner_bits() == 7
+    table = streams.key_table(20_000)
+    now = streams.NOW0
+    # Zipf batches: nobody splits, the count stays at 128
+    z = streams.ZipfSampler(20_000, seed=11)
+    for k in range(2):
+        b = streams.bench_batch(table, z.draw(6_000), now + k, limit=50, duration=60_000)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"zipf {k}")
+        assert sim.owner_bits() == 7
+    # 400 distinct keys for each of 8 of the 128 owners (more than a round's 320): those eight split; the NEXT batch runs with 256 owners
+    from support import oracle_lib
+    ol = oracle_lib()
+    crowd, i = [], 0
+    per = [0] * 8
+    while min(per) < 400:
+        k = b"crowd_%d" % i
+        i += 1
+        o = ((ol.oracle_xxhash64(k, len(k), 0) >> 7) & ((1 << 20) - 1)) >> 13
+        if o < 8 and per[o] < 400:
+            per[o] += 1
+            crowd.append(k)
+    for rnd in range(2):
+        b = HostBatch(crowd, 1, 50, 60_000, now + 10 + rnd)
+        assert_results_equal(sim.eval(b), orc.eval(b), f"crowded owners {rnd}")
+        assert sim.owner_bits() == 8
+    # ... for 255 batches, then 128 again (the test shortens the wait: 254 left -> 4 left)
+    assert lib.ds_owner_hold(sim.h, 0) == 254
+    lib.ds_owner_hold(sim.h, 4)
+    small = streams.bench_batch(table, z.draw(300), now + 12, limit=50, duration=60_000)
+    for k in range(4):
+        assert_results_equal(sim.eval(small), orc.eval(small), f"hold {k}")
+        assert sim.owner_bits() == (8 if k < 3 else 7), k
+    assert_results_equal(sim.eval(small), orc.eval(small), "128 owners again")
+    assert sim.owner_bits() == 7
     sim.close()
 
 
