@@ -830,13 +830,24 @@ __global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own(Table T, BatchView
 // Request order, workgroup = tile.  As k_eval2 from the evaluation on; what differs is where a request learns its segment:
 // packed word -> its group's record (ONE sector: bucket, slot, flags, base, total), no bitmaps, no LDS pre-pass, no barrier
 // before the evaluation.  The serial walk of a heterogeneous segment follows the segment's tile map (Work::segtiles, tilerow).
+// MODE 0: everything in one launch.  GUBER_EVAL3_SPLIT=1 (engine): TWO launches — MODE 1, the closed forms only (58 VGPRs: eight waves
+// per SIMD instead of four; what it cannot answer — apply() for new / expired / odd buckets, the serial walk of a heterogeneous
+// segment — it marks: bit 30 of the request's word, one flag per tile in the tile's first gse cell, dead by now) and MODE 2, the
+// full body for the marked requests of the marked tiles (a workgroup of an unmarked tile returns at once).  The register file
+// holds twice the waiting waves of the launch every request goes through (registers x residency is the bound).
+constexpr uint32_t PD_SLOW = 0x40000000u;
+template <int MODE>
 __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t tile) {
     const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
     __shared__ unsigned long long cnt[4];
+    __shared__ uint32_t slow_any;
+    if (MODE == 2 && W.gse[(size_t)tile * PT_PARTS] == 0u) return;          // nothing of this tile was left for the second launch
     const uint32_t i = tile * 256 + threadIdx.x;
-    const bool live = i < B.n;
+    const uint32_t dl0 = i < B.n ? W.did[i] : 0u;
+    const bool live = i < B.n && (MODE != 2 || (dl0 & PD_SLOW) != 0u);
+    bool deferred = false;
     GP_STAMP(2, 0);
-    const uint32_t dl = live ? W.did[i] : 0u;
+    const uint32_t dl = live ? dl0 : 0u;
     const uint32_t gj = dl & 0xffu, lr = (dl >> 8) & 0xffu, derr = (dl >> 16) & 0xffu;
     uint32_t sf = 0, slot = 0, smeta = 0, base = 0, total = 1, d = 0, rerr = 0; Req r; Rec s0;
     rec_clear(s0);
@@ -875,6 +886,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
         }
     }
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
+    if (MODE == 1 && threadIdx.x == 0) slow_any = 0u;
     GP_STAMPW(2, 1);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (live) {
@@ -905,7 +917,8 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             }
             const bool walk = !parallel && rank == 0;
             uint32_t lastj = i;                                          // the run's last request (walk: the last one walked)
-            if ((parallel && !done) || walk) {
+            if (MODE == 1 && ((parallel && !done) || walk)) deferred = true;      // the second launch's
+            else if ((parallel && !done) || walk) {
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
                     if (B.greg_expire && B.greg_duration) { cur.greg_expire = B.greg_expire[i]; cur.greg_duration = B.greg_duration[i]; }
@@ -975,12 +988,12 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                     }
                 }
             }
-            if (parallel) {
+            if (parallel && !deferred) {
                 store_resp(R, i, out);
                 store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             }
-            if ((parallel && rank == total - 1) || walk) {
+            if (((parallel && rank == total - 1) || walk) && !deferred) {
                 rec_set_stamp(after, W.touch + lastj);                // the key's place in the recency order: its last request (lrucache.go:111-128)
 #if !GUBER_ABLATE_TABLE
                 T.buckets[slot].rec = after;
@@ -990,15 +1003,17 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             }
         }
         // the first request of a segment that carries a tile map clears it (walked or not): the map is all zero between batches
-        if (!derr && flagged && rank == 0) {
+        if (!derr && flagged && rank == 0 && !deferred) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) W.segtiles[(size_t)d * 4 + w] = 0ull;
         }
+        if (MODE == 1 && deferred) W.did[i] = dl | PD_SLOW;
     }
     GP_STAMP(2, 2);
     {
         const int w_over = wave_sum(c_over), w_hit = wave_sum(c_hit), w_miss = wave_sum(c_miss), w_size = wave_sum(c_size);
         lds_barrier();                                               // (cnt zeroed)
+        if (MODE == 1 && deferred) slow_any = 1u;
         if ((threadIdx.x & 63) == 0 && (w_over | w_hit | w_miss | w_size)) {
             if (w_over) atomicAdd(&cnt[0], (unsigned long long)w_over);
             if (w_hit) atomicAdd(&cnt[1], (unsigned long long)w_hit);
@@ -1011,8 +1026,9 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
         }
     }
+    if (MODE == 1 && threadIdx.x == 0) W.gse[(size_t)tile * PT_PARTS] = slow_any;      // (after the barriers above)
     // the owner count of the next batch (all of this batch's k_own workgroups are done, the next batch's k_part has not started)
-    if (tile == 0 && threadIdx.x == 0) {
+    if (MODE != 2 && tile == 0 && threadIdx.x == 0) {
         uint32_t* pm = W.pmode;
         const uint32_t splits = pm[2];
         pm[2] = 0u;
@@ -1026,7 +1042,15 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
 }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
     const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    eval3_body(*a, blockIdx.x);
+    eval3_body<0>(*a, blockIdx.x);
+}
+__global__ __launch_bounds__(256, 8) void k_eval3f(EvalArgs A) {
+    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    eval3_body<1>(*a, blockIdx.x);
+}
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s(EvalArgs A) {
+    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    eval3_body<2>(*a, blockIdx.x);
 }
 
 // ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
@@ -1046,13 +1070,17 @@ __global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own_multi(MultiFront A
     const FrontArgs* a = m->sub + sb;
     own_body(a->T, a->B, a->W, blockIdx.x % PT_PARTS, ntiles);
 }
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) {
+template <int MODE>
+__device__ __forceinline__ void eval3_multi_body(const MultiEval& A) {
     uint32_t sb = 0, first = 0;
 #pragma unroll
     for (int k = 0; k < MULTI_MAX - 1; ++k)
         if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
     const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
-    eval3_body(*a, blockIdx.x - first);
+    eval3_body<MODE>(*a, blockIdx.x - first);
 }
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) { eval3_multi_body<0>(A); }
+__global__ __launch_bounds__(256, 8) void k_eval3f_multi(MultiEval A) { eval3_multi_body<1>(A); }
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s_multi(MultiEval A) { eval3_multi_body<2>(A); }
 
 }  // namespace guber

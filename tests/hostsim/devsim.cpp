@@ -111,6 +111,7 @@ using namespace guber;
 // ---- a table and the per-batch work arrays in host memory, laid out as guber_engine_create does -----------------------------
 struct DevSim {
     uint64_t slots = 0; uint32_t max_batch = 0, cap = 0;
+    bool eval3_split = false;                                      // k_eval3 as two launches (GUBER_EVAL3_SPLIT)
     uint32_t pmode[4] = {7, 0, 0, 0};                              // Work::pmode: the owner count follows the traffic (guber_kernels_part.h)
     Table T{}; Work W{};
     std::vector<DirEntry> dir; std::vector<Bucket> buckets; std::vector<uint8_t> arena; DevCounters ctr{}; std::vector<BlockCounters> bctr;
@@ -221,6 +222,7 @@ void ds_destroy(void* h) { delete (DevSim*)h; }
 // owners per batch: bits = 7 | 8 pinned, 0 = follow the traffic (the default); ds_owner_bits: what the next batch will use
 void ds_pin_owner_bits(void* h, uint32_t bits) { DevSim* d = (DevSim*)h; d->pmode[3] = bits ? 1u : 0u; if (bits) d->pmode[0] = bits; d->pmode[1] = d->pmode[2] = 0; }
 uint32_t ds_owner_bits(void* h) { return ((DevSim*)h)->pmode[0]; }
+void ds_eval3_split(void* h, int on) { ((DevSim*)h)->eval3_split = on != 0; }
 // batches left with 256 owners (pmode[1]): read, or shorten for a test (n != 0)
 uint32_t ds_owner_hold(void* h, uint32_t n) { DevSim* d = (DevSim*)h; if (n) d->pmode[1] = n; return d->pmode[1]; }
 void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
@@ -291,7 +293,11 @@ static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int
         fakehip::launch(dim3(tiles), dim3(FT), nullptr, [&] { k_part(d->T, B, W); });
         fakehip::launch(dim3(PT_PARTS), dim3(256), nullptr, [&] { k_own(d->T, B, W, tiles); });
         EvalArgs A{d->T, B, R, W};
-        fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
+        if (d->eval3_split) {
+            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3f(A); });
+            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3s(A); });
+        } else
+            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
         for (auto v : d->segtiles) if (v) return -2;      // the walk's tile maps must be all zero between batches
     }
     return 0;

@@ -18,11 +18,13 @@ HS = os.path.join(ROOT, "tests", "hostsim")
 # every form of what travels between k_part, k_own and k_eval3: the product's default (64-byte messages, 32-byte records that leave out
 # what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), 64 bytes both ways; and the default form with
 # the owner count (128 or 256 per batch: Work::pmode) pinned either way instead of following the traffic
-@pytest.fixture(scope="module", params=[("libdevsim.so", 0), ("libdevsim_compact.so", 0), ("libdevsim_wide.so", 0), ("libdevsim.so", 7), ("libdevsim.so", 8)],
-                ids=lambda p: p[0][3:-3] + (f"-owners{1 << p[1]}" if p[1] else ""))
+# ... and with k_eval3 as two launches (GUBER_EVAL3_SPLIT: closed forms first, the rest second)
+@pytest.fixture(scope="module", params=[("libdevsim.so", 0, 0), ("libdevsim_compact.so", 0, 0), ("libdevsim_wide.so", 0, 0), ("libdevsim.so", 7, 0), ("libdevsim.so", 8, 0),
+                                        ("libdevsim.so", 0, 1), ("libdevsim_wide.so", 0, 1)],
+                ids=lambda p: p[0][3:-3] + (f"-owners{1 << p[1]}" if p[1] else "") + ("-eval3split" if p[2] else ""))
 def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
-    request_param, owner_bits = request.param
+    request_param, owner_bits, eval3_split = request.param
     L = C.CDLL(os.path.join(HS, request_param))
     L.ds_create.restype = C.c_void_p
     L.ds_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int]
@@ -40,8 +42,9 @@ def lib(request):
     L.ds_owner_hold.argtypes = [C.c_void_p, C.c_uint32]
     L.ds_owner_hold.restype = C.c_uint32
     L.short_recs, L.short_msgs = "wide" not in request_param, "compact" in request_param
-    L.owner_bits = owner_bits
-    L.product_form = request_param == "libdevsim.so" and owner_bits == 0
+    L.ds_eval3_split.argtypes = [C.c_void_p, C.c_int]
+    L.owner_bits, L.eval3_split = owner_bits, eval3_split
+    L.product_form = request_param == "libdevsim.so" and owner_bits == 0 and not eval3_split
     return L
 
 
@@ -57,6 +60,8 @@ class Sim:
         self.h = lib.ds_create_bounded(slots, max_batch, weak, cache_size)
         if lib.owner_bits:
             lib.ds_pin_owner_bits(self.h, lib.owner_bits)
+        if lib.eval3_split:
+            lib.ds_eval3_split(self.h, 1)
 
     def owner_bits(self):
         return self.lib.ds_owner_bits(self.h)
@@ -173,7 +178,7 @@ def test_more_keys_of_one_owner_than_its_lds_table_has_cells(lib, nkeys):
     LDS hash table has cells (OW_HT = 512).  The insert loop used to probe the full table for ever (a hang of k_own — found on the GPU
     with 128 owners per batch and uniform keys, reachable with 256 by keys chosen to share an owner); it is bounded now and the round
     splits"""
-    only_where_the_form_matters(lib, 1 if lib.product_form or lib.owner_bits else 0)
+    only_where_the_form_matters(lib, 1 if lib.product_form or lib.owner_bits or lib.eval3_split else 0)
     from support import oracle_lib
     ol = oracle_lib()
     keys, i = [], 0
