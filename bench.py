@@ -589,6 +589,26 @@ def oracle_populate(rig, orc, threads, now0):
                  threads=threads)
 
 
+def pipeline_traffic(tj, algo, kernels, launches, per_launch, B):
+    """HBM-side bytes per step from the PMC passes (profiles/roofline_traffic.json, written by tools/summarize_r04.py from separate
+    --pmc runs: bytes per 65536-request batch and kernel).  A batch goes through ONE pipeline — the two launches with claims or the
+    three owner-partitioned ones — so the step's traffic is the mix the profile segment ran: every kernel's bytes per batch weighted
+    by the batches it carried, over the batches that entered a pipeline (those of the first-stage kernels).  Fused launches use the
+    per-batch figures measured on fused launches where the file has them ("<algo>_fused"), the one-table figures otherwise."""
+    one, fused = tj.get(algo, {}), tj.get(algo + "_fused", {})
+    total = entered = 0.0
+    for k in kernels:
+        base = k.replace("_multi", "")
+        per_batch = (fused.get(base) if k.endswith("_multi") else None) or one.get(base)
+        if not per_batch:
+            return None
+        batches = launches.get(k, 0) * per_launch.get(k, B) / B
+        total += per_batch * batches
+        if base in ("k_front", "k_part"):
+            entered += batches
+    return int(total / entered * B / 65536) if entered else None
+
+
 def parity_over_timed_work(rig, orc, threads, now0, label):
     """The oracle is fed what the engine was fed — populate, warm-up, every timed batch, in order, with the same clocks — and
     the engine's kept answers (every 64th timed batch, the first 8, the last) must equal the oracle's element-wise.
@@ -755,13 +775,8 @@ def main():
             achieved = dom_bytes / (cand[dom] * 1e-3) / 1e9
             traffic = measured = None
             try:
-                # PMC bytes per 65536-request batch of every kernel of the pipeline (profiles/roofline_traffic.json, written by
-                # tools/summarize_r04.py from separate --pmc passes): summed = HBM bytes per step, like `achieved`
                 tj = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
-                names = sorted({k.replace("_multi", "") for k in cand})
-                per = [tj.get(args.algo, {}).get(k) for k in names]
-                if per and all(per):
-                    traffic = int(sum(per) * B / 65536)
+                traffic = pipeline_traffic(tj, args.algo, cand, launches, per_launch, B)
                 measured = tj.get("note")
             except Exception:   # noqa: BLE001
                 pass

@@ -136,7 +136,7 @@ for s in sorted(pm):
             lines.append(f"| {k} | {n} | " + " | ".join(f"{pm[s][k][c][0]:.1f}" if c in pm[s][k] else "" for c in ctrs) + " |")
     lines.append("")
     out["counters"][s] = {k: {c: v[0] for c, v in cs.items()} for k, cs in pm[s].items()}
-tr, tr_raw = {}, {}
+tr, tr_raw, trf, trf_raw = {}, {}, {}, {}
 lines += ["## HBM-side traffic per 65536-request batch", "", "| configuration | kernel | FETCH_SIZE KiB | WRITE_SIZE KiB | raw bytes | corrected bytes (2xFETCH+WRITE) | algorithmic bytes | raw / algorithmic | corrected / algorithmic |", "|---|---|---|---|---|---|---|---|---|"]
 per_launch_batches = {}
 try:
@@ -156,15 +156,17 @@ for s_, label, ks_ in (("s1", "one table, claims", ("k_front", "k_eval2")), ("s1
             base_k = k.replace("_multi", "")
             if s_ != "s12":
                 tr[base_k], tr_raw[base_k] = int(cor), int(raw)
+            else:
+                trf[base_k], trf_raw[base_k] = int(cor), int(raw)
             tot_raw += raw; tot_cor += cor; tot_alg += ALG[k] * 65536
             lines.append(f"| {label} | {k} | {f:.1f} | {w:.1f} | {raw:.0f} | {cor:.0f} | {ALG[k] * 65536} | {raw / (ALG[k] * 65536):.2f} | {cor / (ALG[k] * 65536):.2f} |")
     if tot_alg:
         lines.append(f"| {label} | **pipeline** | | | {tot_raw:.0f} | {tot_cor:.0f} | {tot_alg} | **{tot_raw / tot_alg:.2f}** | **{tot_cor / tot_alg:.2f}** |")
 lines.append("")
 if tr:
-    json.dump({"token": tr, "token_raw": tr_raw, "source": f"profiles/{tag}_rocprof_summary.md",
+    json.dump({"token": tr, "token_raw": tr_raw, "token_fused": trf, "token_fused_raw": trf_raw, "source": f"profiles/{tag}_rocprof_summary.md",
                "note": "PMC bytes per 65536-request batch and kernel on the non-replayed stream, one table: token = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, an "
-                       "upper bound for 64-byte requests), token_raw = (FETCH_SIZE + WRITE_SIZE)*1024; the bench line sums the kernels of its pipeline"},
+                       "upper bound for 64-byte requests), token_raw = (FETCH_SIZE + WRITE_SIZE)*1024; token_fused[_raw] = the same per batch of a fused launch (12 shards); the bench line weights every kernel by the batches it carried (bench.py pipeline_traffic)"},
               open(os.path.join(base, "roofline_traffic.json"), "w"), indent=1)
 if violations:
     lines += ["## CONSISTENCY VIOLATIONS (> 5 %)", ""] + [f"* {v}" for v in violations] + [""]
