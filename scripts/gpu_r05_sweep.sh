@@ -1,0 +1,23 @@
+#!/bin/bash
+# PREPARED FOR ROUND 5 (round 4 ran out of GPU time): batches in flight on the round-4 kernels — shards x streams (a launch carries the
+# next batch of up to GUBER_MULTI_MAX = 4 shards of a stream; more shards than streams x 4 = several launch groups per stream), and the
+# owner count pinned either way beside the traffic-following default.  One box; every run under its own short timeout.
+#   usage: gpu_r05_sweep.sh [tag]
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R; O=$R/gpurun_out/${1:-r05_sweep}; mkdir -p $O
+run() {  # name, bench args
+  local name=$1; shift
+  timeout 60 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 "$@" > $O/bench_$name.json 2> $O/bench_$name.err; echo "bench $name rc=$?"
+}
+NAMES=""
+for cfg in "12 3" "12 4" "16 4" "16 3" "18 3" "20 5" "24 4" "24 6" "8 2" "12 2"; do
+  set -- $cfg
+  run s$1_t$2 --shards $1 --streams $2; NAMES="$NAMES s$1_t$2"
+done
+python - <<PY
+import json
+for f in "$NAMES".split():
+    try: d = json.load(open("$O/bench_%s.json" % f))
+    except Exception as e: print(f, "unreadable", e); continue
+    print(f, "value", round(d["value"]/1e9, 3), "ms/step", d["ms_per_step"], {k: v for k, v in d["roofline"].get("kernel_avg_us", {}).items() if "multi" in k})
+PY
