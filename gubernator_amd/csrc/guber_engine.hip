@@ -795,11 +795,12 @@ static int launch_batch_inner(guber_engine* e, const BatchView& B, const ResultV
                 const unsigned long long* b = hb + kern * 2048;
                 const uint32_t wgs = kern == 1 ? (uint32_t)PT_PARTS : P.ftiles;
                 unsigned long long t0 = ~0ull;
-                for (uint32_t t = 0; t < wgs; ++t) t0 = b[t * 8] < t0 ? b[t * 8] : t0;
-                for (int k = 0; k < nst[kern]; ++k) {
+                uint32_t ran = 0;                                        // (k_own workgroups beyond the batch's owner count return at once and stamp 0)
+                for (uint32_t t = 0; t < wgs; ++t) if (b[t * 8]) { t0 = b[t * 8] < t0 ? b[t * 8] : t0; ran++; }
+                for (int k = 0; k < nst[kern] && ran; ++k) {
                     double sum = 0, mx = 0;
-                    for (uint32_t t = 0; t < wgs; ++t) { const double v = (double)(b[t * 8 + k] - t0) * 0.01; sum += v; mx = v > mx ? v : mx; }
-                    e->dbg_avg[2 + kern][k] += sum / wgs; e->dbg_max[2 + kern][k] += mx;
+                    for (uint32_t t = 0; t < wgs; ++t) { if (!b[t * 8]) continue; const double v = (double)(b[t * 8 + k] - t0) * 0.01; sum += v; mx = v > mx ? v : mx; }
+                    e->dbg_avg[2 + kern][k] += sum / ran; e->dbg_max[2 + kern][k] += mx;
                 }
             }
             e->dbg_pn++;

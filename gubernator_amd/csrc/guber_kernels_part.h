@@ -420,7 +420,12 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ int sp;
     GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (p >= (1u << pm_bits(W.pmode))) return;          // (256 workgroups are launched per batch whatever the batch's owner count)
+    if (p >= (1u << pm_bits(W.pmode))) {                // (256 workgroups are launched per batch whatever the batch's owner count)
+#ifdef GUBER_PHASE_TIMING
+        if (t == 0) W.dbg[4096 + 2048 + blockIdx.x * 8] = 0ull;       // "did not run": the fold of the stamps skips this workgroup
+#endif
+        return;
+    }
 #if GUBER_PART_MSG32
     __shared__ GShape tshape[256];                      // tile -> the shape of its request 0 (what a G_SHAPE0 message refers to)
 #endif
