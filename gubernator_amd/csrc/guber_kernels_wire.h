@@ -104,8 +104,15 @@ constexpr uint32_t WIRE_WIN = 8192;
 // walk runs on the scalar unit (uniform branches, no exec-mask bookkeeping).  The usual record — tag 0x0a, a one- or two-byte
 // length — is decided from four bytes; everything else (multi-byte tags, unknown fields, long lengths) goes through scan_one over
 // plain memory: the shared, fuzzed code.
-__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) {
+// TABLE (k_wire_scan_tab; GUBER_WIRE_TABLE=1 in guber_wire_dev.h — built and checked against the shared framing code on the CPU,
+// not yet measured on the GPU): what the chain needs from a position is decided for EVERY position of a freshly staged window at
+// once — sixteen positions per lane and 16-byte chunk, from registers: "a record of the usual form starts here: header 2 | 3 bytes,
+// body L" as one 16-bit word, 0 for everything else — so that a step of the walk is ONE dependent LDS read instead of two reads,
+// a funnel shift and the decode.  Same decisions: the word holds exactly what the serial decode computes from the same four bytes.
+template <bool TABLE>
+__device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScratch& sc) {
     __shared__ uint32_t win[WIRE_WIN / 4 + 8];
+    __shared__ uint16_t nx[TABLE ? WIRE_WIN : 16];                    // position -> ((L << 1 | header - 2) + 1), 0 = not the usual form
     const uint32_t r = blockIdx.x;
     const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
     const uint8_t* g = in.buf + off;
@@ -140,17 +147,46 @@ __global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) {
             for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) *(uint4*)((unsigned char*)win + (c * 64 + threadIdx.x) * 16) = v[c];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            if (TABLE) {
+#pragma unroll
+                for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) {
+                    const uint32_t ci = c * 64 + threadIdx.x;                  // my chunk: its 16 bytes are in v[c], the 3 after it in the next chunk's first word
+                    if (wbase + ci * 16 >= lim) continue;                     // (nothing of the payload in it: the walk never asks)
+                    const uint32_t w[5] = {v[c].x, v[c].y, v[c].z, v[c].w, win[ci * 4 + 4]};   // (the last chunk reads the pad behind the window: positions the walk never uses — pos + 4 <= wend)
+                    uint32_t e[16];
+#pragma unroll
+                    for (uint32_t j = 0; j < 16; ++j) {
+                        const uint32_t h = (uint32_t)((((unsigned long long)w[(j >> 2) + 1] << 32) | w[j >> 2]) >> ((j & 3u) * 8));
+                        uint32_t L = 0, hdr = 0;
+                        if ((h & 0xffu) == 0x0au) {
+                            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
+                            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+                        }
+                        e[j] = hdr ? (((L << 1) | (hdr - 2u)) + 1u) : 0u;
+                    }
+                    uint4* o = (uint4*)((unsigned char*)nx + ci * 32);
+                    o[0] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+                    o[1] = make_uint4(e[8] | e[9] << 16, e[10] | e[11] << 16, e[12] | e[13] << 16, e[14] | e[15] << 16);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+            }
         }
         const uint32_t o = pos - wbase;
-        const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
-        uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
-        h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
         const uint32_t avail = len - pos;
-        if (avail < 4) h &= (1u << (8 * avail)) - 1u;                 // zero beyond the payload
         uint32_t L = 0, hdr = 0;
-        if ((h & 0xffu) == 0x0au) {
-            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
-            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+        if (TABLE && avail >= 4) {                                    // (the last three bytes of a payload are decoded below, with the bytes beyond it zeroed)
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nx[o]);
+            if (e) { hdr = 2u + ((e - 1u) & 1u); L = (e - 1u) >> 1; }
+        } else {
+            const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
+            uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
+            h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+            if (avail < 4) h &= (1u << (8 * avail)) - 1u;             // zero beyond the payload
+            if ((h & 0xffu) == 0x0au) {
+                if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
+                else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+            }
         }
         if (hdr) {
             if (hdr > avail || L > avail - hdr) { st = WIRE_MALFORMED; break; }
@@ -171,6 +207,8 @@ __global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) {
     if (st == WIRE_OK && ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc)) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
     if (threadIdx.x == 0) { sc.count[r] = count; sc.status[r] = st; }
 }
+__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) { wire_scan_body<false>(in, sc); }
+__global__ __launch_bounds__(64) void k_wire_scan_tab(WireIn in, WireScratch sc) { wire_scan_body<true>(in, sc); }
 
 // first[r] = where RPC r's items start (RPCs that are not ok contribute nothing), first[nrpc] = the batch size; an RPC that would not
 // fit the arrays any more is turned away as too large
