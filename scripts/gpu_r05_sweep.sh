@@ -21,3 +21,8 @@ for f in "$NAMES".split():
     except Exception as e: print(f, "unreadable", e); continue
     print(f, "value", round(d["value"]/1e9, 3), "ms/step", d["ms_per_step"], {k: v for k, v in d["roofline"].get("kernel_avg_us", {}).items() if "multi" in k})
 PY
+# the device wire decoder's table walk against the serial one: parity (against the host transcoder) and the rates by RPC size
+for t in 0 1; do
+  GUBER_WIRE_TABLE=$t timeout 120 python -m pytest tests/test_gpu_wire_dev.py -m gpu -q -s > $O/pytest_wire_table$t.txt 2>&1; echo "wire decode, GUBER_WIRE_TABLE=$t rc=$?"
+  grep -E "device wire decode|passed|failed" $O/pytest_wire_table$t.txt | cut -c1-200
+done
