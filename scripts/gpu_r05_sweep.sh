@@ -21,6 +21,14 @@ for f in "$NAMES".split():
     except Exception as e: print(f, "unreadable", e); continue
     print(f, "value", round(d["value"]/1e9, 3), "ms/step", d["ms_per_step"], {k: v for k, v in d["roofline"].get("kernel_avg_us", {}).items() if "multi" in k})
 PY
+# six tables per launch instead of four (a build: make -C gubernator_amd/csrc variant VNAME=mm6 VFLAGS=-DGUBER_MULTI_MAX=6, BEFORE the call)
+if [ -f $R/gubernator_amd/libguber_hip_v_mm6.so ]; then
+  for cfg in "18 3" "12 2" "24 4" "12 3"; do
+    set -- $cfg
+    GUBER_HIP_LIB=$R/gubernator_amd/libguber_hip_v_mm6.so timeout 60 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 --shards $1 --streams $2 > $O/bench_mm6_s$1_t$2.json 2> $O/bench_mm6_s$1_t$2.err
+    python -c "import json; d=json.load(open('$O/bench_mm6_s$1_t$2.json')); print('mm6 s$1 t$2', round(d['value']/1e9,3), d['ms_per_step'])"
+  done
+fi
 # the device wire decoder's table walk against the serial one: parity (against the host transcoder) and the rates by RPC size
 for t in 0 1; do
   GUBER_WIRE_TABLE=$t timeout 120 python -m pytest tests/test_gpu_wire_dev.py -m gpu -q -s > $O/pytest_wire_table$t.txt 2>&1; echo "wire decode, GUBER_WIRE_TABLE=$t rc=$?"
