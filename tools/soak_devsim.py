@@ -1,0 +1,59 @@
+"""Randomised soak of the batch pipelines' kernel source on the CPU (tests/hostsim/libdevsim*.so: make -C tests/hostsim devsim_lib)
+against the oracle: per seed a table size, a key population, a batch size, an owner mode (following / 128 / 256), a record / message
+form and k_eval3 whole or split, adversarial streams through the owner-partitioned pipeline, every answer and the counters compared.
+Test infrastructure, not part of the suite:   python tools/soak_devsim.py <first seed> <last seed> <seconds>"""
+import sys, os, time, ctypes as C, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import numpy as np
+import streams
+from support import GuberBatch, GuberResult, HostBatch, HostResult, Oracle, assert_results_equal, gregorian
+
+HS = os.path.join(ROOT, "tests", "hostsim")
+def load(name):
+    L = C.CDLL(os.path.join(HS, name))
+    L.ds_create_bounded.restype = C.c_void_p; L.ds_create_bounded.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint64]
+    L.ds_destroy.argtypes = [C.c_void_p]
+    L.ds_eval.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int, C.c_int]
+    L.ds_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    L.ds_pin_owner_bits.argtypes = [C.c_void_p, C.c_uint32]
+    L.ds_eval3_split.argtypes = [C.c_void_p, C.c_int]
+    return L
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    libname = rng.choice(["libdevsim.so", "libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so"])
+    L = load(libname)
+    slots = int(rng.choice([4096, 16384, 1 << 17, 1 << 20]))
+    n_keys = int(rng.choice([50, 97, 400, 1000, 3000, 12000]))
+    n_keys = min(n_keys, slots // 8)
+    bs = int(rng.choice([300, 1500, 5000, 12000]))
+    obits = int(rng.choice([0, 0, 7, 8])); split = int(rng.random() < 0.4)
+    nb = int(rng.choice([4, 8, 14]))
+    h = L.ds_create_bounded(slots, 16384, 0, 0)
+    if obits: L.ds_pin_owner_bits(h, obits)
+    if split: L.ds_eval3_split(h, 1)
+    orc = Oracle(cache_size=1 << 20)
+    cfg = f"seed {seed} lib {libname} slots {slots} keys {n_keys} batch {bs} x{nb} owners {obits} split {split}"
+    try:
+        for k, b in enumerate(streams.adversarial_batches(seed, nb, bs, n_keys=n_keys, greg_fn=gregorian)):
+            res = HostResult(b.n)
+            rc = L.ds_eval(h, C.byref(b.c), C.byref(res.c), 1, 0)
+            assert rc == 0, f"rc {rc}"
+            assert_results_equal(res, orc.eval(b), f"{cfg} batch {k}")
+        out = (C.c_longlong * 6)(); L.ds_counters(h, out)
+        co = orc.counters()
+        assert (out[0], out[1], out[2]) == (co[0], co[1], co[2]) and out[3] == orc.size(), f"{cfg}: counters {tuple(out)} vs {co} size {orc.size()}"
+        assert out[4] == 0, f"{cfg}: retries {out[4]}"
+        return "ok " + cfg
+    except Exception as e:   # noqa
+        return "FAIL " + cfg + " :: " + str(e)[:400]
+    finally:
+        L.ds_destroy(h)
+
+if __name__ == "__main__":
+    lo, hi, budget = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+    t0 = time.time()
+    for seed in range(lo, hi):
+        if time.time() - t0 > budget: break
+        print(one(seed), flush=True)
