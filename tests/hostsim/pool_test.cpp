@@ -167,13 +167,22 @@ int main(int argc, char** argv) {
         GPUWorkerPool pool(cfg, 256, 150, 4);
         V1Instance inst(&pool);
         pool.SetClockMs(NOW0);
-        std::atomic<bool> stop{false};
-        std::thread kicker([&] { while (!stop.load()) { pool.RebalanceNow(); std::this_thread::sleep_for(std::chrono::milliseconds(3)); } });
+        std::atomic<bool> stop{false}, moved{false};
+        std::thread kicker([&] {
+            while (!stop.load()) {
+                pool.RebalanceNow();
+                guber_pool_metrics_t km{}; pool.Metrics(&km);            // (all atomics)
+                if (km.keys_moved) moved.store(true);
+                std::this_thread::sleep_for(std::chrono::milliseconds(3));
+            }
+        });
         std::vector<std::thread> th;
         for (int t = 0; t < 6; ++t) th.emplace_back([&, t] {
             Ref ref; std::mt19937 rng(500 + t);
             const std::string ns = "mv" + std::to_string(t);
-            for (int it = 0; it < 300 / scale; ++it) {
+            // (whether a pass finds a hot key worth moving depends on what its few milliseconds of traffic looked like: the callers go on —
+            // within reason — until one has been moved, so that what this block is about has happened at least once in every run)
+            for (int it = 0; it < 300 / scale || (!moved.load() && it < 6000 / scale); ++it) {
                 std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 25, 200);
                 for (size_t q = 0; q < reqs.size(); ++q)
                     if (rng() % 5 != 0) { reqs[q].unique_key = "hot"; reqs[q].algorithm = t % 2; reqs[q].hits = 1; reqs[q].limit = 1000000; reqs[q].duration = 3600000; reqs[q].behavior = 0; }
