@@ -787,6 +787,10 @@ def main():
                         "what": (f"{BYTES_PER_DECISION[args.algo]} algorithmic B per decision (SURVEY 8d) x {B} decisions per step / ms_per_step: every kernel of "
                                  "the pipeline, all shards overlapping, as the driver's clock sees it"),
                         "traffic": traffic, "traffic_note": measured,
+                        "limiter": ("not HBM bytes: same-box experiments (profiles/r04_w_*, r04_x_*, r04_y_*, r04_split_*; DESIGN.md section 4) — the pipeline without "
+                                    "any table access is not faster, 29 % fewer fabric transactions gave 6 %, more waves per SIMD 1-3.5 %; a launch's duration "
+                                    "under load is one workgroup's dependent chain on a chip shared by three streams, the rate = batches in flight / the sum of "
+                                    "those latencies"),
                         "kernel": dom,
                         "dominant_kernel_overlapped": {
                             "kernel": dom, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBPS, 6),
