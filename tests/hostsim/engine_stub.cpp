@@ -14,7 +14,9 @@
 #include "../../include/guber_gpu.h"
 #include "../../oracle/guber_oracle.h"
 
-struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; guber_route_rule_t rule{}; bool have_rule = false; };
+struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; guber_route_rule_t rule{}; bool have_rule = false;
+                      // the rule's arrays are COPIED at the call, as the engine uploads them (guber_engine.hip guber_stage_route): the caller's snapshot may be retired afterwards
+                      std::vector<uint16_t> rt_table, rt_exs; std::vector<uint64_t> rt_exh; };
 struct guber_stage {
     guber_engine* e; uint32_t max_n, key_cap;
     std::vector<uint32_t> off, beh; std::vector<int64_t> hits, limit, duration, burst, created, rl, rr, rs;
@@ -108,7 +110,17 @@ static uint32_t stub_route(const guber_route_rule_t& R, uint64_t h) {
 extern "C" int guber_stage_route(guber_stage_t* s, const guber_route_rule_t* rule, uint32_t n_engines) {
     static const long null_lat = getenv("GUBER_STUB_ROUTE_LAT_US") ? atol(getenv("GUBER_STUB_ROUTE_LAT_US")) : 0;
     if (!s || s->in_flight || n_engines == 0 || n_engines > 16) return GUBER_E_INVALID_ARG;
-    if (rule) { s->e->rule = *rule; s->e->have_rule = true; }
+    if (rule) {
+        guber_engine* e = s->e;
+        if (rule->n_shards == 0 || rule->per == 0 || !rule->table || (rule->ex_n && (!rule->ex_hash || !rule->ex_shard))) return GUBER_E_INVALID_ARG;
+        e->rule = *rule;
+        e->rt_table.assign(rule->table, rule->table + (size_t)rule->n_shards * rule->per); e->rule.table = e->rt_table.data();
+        if (rule->ex_n) {
+            e->rt_exh.assign(rule->ex_hash, rule->ex_hash + rule->ex_cells); e->rt_exs.assign(rule->ex_shard, rule->ex_shard + rule->ex_cells);
+            e->rule.ex_hash = e->rt_exh.data(); e->rule.ex_shard = e->rt_exs.data();
+        }
+        e->have_rule = true;
+    }
     if (!s->e->have_rule) return GUBER_E_INVALID_ARG;
     const guber_route_rule_t& R = s->e->rule;
     const uint32_t n = s->b.n;
