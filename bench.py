@@ -63,9 +63,11 @@ BYTES_PER_DECISION = {"token": 149, "leaky": 173}
 KERNEL_BYTES = {"token": {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73,
                           # owner-partitioned pipeline: k_part reads key_off 4 + key 16, k_own the table 56, k_eval3 the request fields 32,
                           # writes table 16 + response 25
-                          "k_part": 20, "k_own": 56, "k_eval3": 73, "k_part_multi": 20, "k_own_multi": 56, "k_eval3_multi": 73},
+                          "k_part": 20, "k_own": 56, "k_eval3": 73, "k_part_multi": 20, "k_own_multi": 56, "k_eval3_multi": 73,
+                          "k_evalpart_multi": 93},     # (GUBER_FUSE_EP: one batch's k_eval3 + the next one's k_part in one launch)
                 "leaky": {"k_front": 84, "k_eval2": 89, "k_front_multi": 84, "k_eval2_multi": 89,
-                          "k_part": 20, "k_own": 64, "k_eval3": 89, "k_part_multi": 20, "k_own_multi": 64, "k_eval3_multi": 89}}
+                          "k_part": 20, "k_own": 64, "k_eval3": 89, "k_part_multi": 20, "k_own_multi": 64, "k_eval3_multi": 89,
+                          "k_evalpart_multi": 109}}
 
 
 DIGEST_C = (-7046029254386353131, -4417276706812531889, 1609587929392839161, -8796714831421723037)   # odd 64-bit multipliers (int64 view)
@@ -599,12 +601,16 @@ def pipeline_traffic(tj, algo, kernels, launches, per_launch, B):
     total = entered = 0.0
     for k in kernels:
         base = k.replace("_multi", "")
-        per_batch = (fused.get(base) if k.endswith("_multi") else None) or one.get(base)
+        if base == "k_evalpart":          # GUBER_FUSE_EP: one batch's k_eval3 and the next one's k_part in one launch — priced as the two
+            parts = [fused.get(b) or one.get(b) for b in ("k_eval3", "k_part")]
+            per_batch = sum(parts) if all(parts) else None
+        else:
+            per_batch = (fused.get(base) if k.endswith("_multi") else None) or one.get(base)
         if not per_batch:
             return None
         batches = launches.get(k, 0) * per_launch.get(k, B) / B
         total += per_batch * batches
-        if base in ("k_front", "k_part"):
+        if base in ("k_front", "k_part", "k_evalpart"):
             entered += batches
     return int(total / entered * B / 65536) if entered else None
 

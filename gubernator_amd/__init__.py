@@ -414,11 +414,13 @@ class Engine:
 
     def profile_read(self):
         """{kernel name: (launches, total_ms)} since the last read."""
-        arr = (abi.GuberKernelTime * 16)()
+        cap = 32
+        arr = (abi.GuberKernelTime * cap)()
         n = C.c_uint32(0)
-        _check(lib().guber_profile_read(self.h, arr, 16, C.byref(n)))
-        self.last_profile_units = {arr[i].name.decode(): arr[i].units for i in range(n.value)}
-        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(n.value)}
+        _check(lib().guber_profile_read(self.h, arr, cap, C.byref(n)))
+        got = min(n.value, cap)                                       # (n = the kernels the library knows; it fills at most cap)
+        self.last_profile_units = {arr[i].name.decode(): arr[i].units for i in range(got)}
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(got)}
 
     def profile_passes(self):
         """after profile_read(): microseconds every pipeline pass (one batch, or one fused group) took from its first kernel's start

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -107,7 +108,7 @@ struct guber_engine {
     // owner-partitioned pipeline (guber_kernels_part.h): messages tile -> owner, records owner -> tile, runs per (tile, owner),
     // tile maps of walked segments, the per-request words.  cap256 = fast_cap rounded up to whole tiles.
     DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3, w_pmode; DevBuf<unsigned long long> w_segtiles;
-    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false, eval3_split = false; uint64_t part_batches = 0;
+    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false, eval3_split = false, fuse_ep = false; uint64_t part_batches = 0, ep_launches = 0;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -177,7 +178,7 @@ struct guber_engine {
     struct Span { int kernel; hipEvent_t a, b; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
-    double prof_ms[16] = {0}; uint64_t prof_n[16] = {0}, prof_units[16] = {0};
+    double prof_ms[24] = {0}; uint64_t prof_n[24] = {0}, prof_units[24] = {0};
     std::vector<float> group_us;   // per pipeline pass (the launches of one batch, or of one fused group): first kernel's start -> last kernel's end
 
     hipEvent_t get_event() {
@@ -191,11 +192,11 @@ struct guber_engine {
 };
 
 enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI,
-       KT_PART, KT_OWN, KT_EVAL3, KT_PART_MULTI, KT_OWN_MULTI, KT_EVAL3_MULTI, KT_COUNT };
-static_assert(KT_COUNT <= 16, "guber_engine::prof_* hold 16 kernels");
+       KT_PART, KT_OWN, KT_EVAL3, KT_PART_MULTI, KT_OWN_MULTI, KT_EVAL3_MULTI, KT_EVALPART_MULTI, KT_COUNT };
+static_assert(KT_COUNT <= 24, "guber_engine::prof_* hold 24 kernels");
 static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
                                                    "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi",
-                                                   "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi"};
+                                                   "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi", "k_evalpart_multi"};
 
 static uint64_t take_stamps(guber_engine* e, uint64_t n) {
     const uint64_t b = e->seq_next;
@@ -348,9 +349,14 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     // GUBER_EVAL3_SPLIT=1: the owner-partitioned pipeline's last kernel as two launches (closed forms at eight waves per SIMD; the rest:
     // guber_kernels_part.h eval3_body) — built and verified, off until it has been measured on the GPU
     if (const char* v = getenv("GUBER_EVAL3_SPLIT")) e->eval3_split = atoi(v) != 0;
+    // GUBER_FUSE_EP=1: inside one guber_eval_batches_routed_dev call, a group's k_eval3 shares a launch with the k_part of the same
+    // tables' next batches (k_evalpart_multi, guber_kernels_part.h: two launches per pass instead of three) — built and checked
+    // through the kernel source on the CPU, off until it has been measured on the GPU.  While such a call runs its engines belong
+    // to it: another thread's call on one of them could be enqueued between a k_own and the k_eval3 that is still held back.
+    if (const char* v = getenv("GUBER_FUSE_EP")) e->fuse_ep = atoi(v) != 0 && !e->eval3_split;
     if (e->force_part) e->part_min = 1;
     rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure((size_t)e->cap256 + e->cap256 / 2); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);   // (grec: 32-byte records first, then the 64-byte form)
-    rc |= e->w_did3.ensure(e->cap256); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4); rc |= e->w_pmode.ensure(16);
+    rc |= e->w_did3.ensure((size_t)e->cap256 * (e->fuse_ep ? 2 : 1)); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4); rc |= e->w_pmode.ensure(16);
     rc |= e->w_did2.ensure((size_t)2 * e->fast_cap);
     e->claims_cells = 1024;
     while (e->claims_cells < 4 * e->fast_cap) e->claims_cells <<= 1;   // load <= 0.25: short probe chains, 2 MB at 65 536
@@ -369,8 +375,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     hipError_t he = hipSuccess;
     // owners per batch of the owner-partitioned pipeline: starts at 128 and follows the traffic on the device (guber_kernels_part.h
     // "HOW MANY OWNERS"); GUBER_PT_BITS=7|8 pins it (measurements, tests)
-    uint32_t pm0[4] = {7u, 0u, 0u, 0u};
-    if (const char* v = getenv("GUBER_PT_BITS")) { const int b = atoi(v); if (b == 7 || b == 8) { pm0[0] = (uint32_t)b; pm0[3] = 1u; } }
+    uint32_t pm0[8] = {7u, 0u, 0u, 0u, 7u, 7u, 0u, 0u};              // ([4..5]: the bits per batch parity of a GUBER_FUSE_EP engine, Work::pmslot)
+    if (const char* v = getenv("GUBER_PT_BITS")) { const int b = atoi(v); if (b == 7 || b == 8) { pm0[0] = pm0[4] = pm0[5] = (uint32_t)b; pm0[3] = 1u; } }
     if ((he = hipMemsetAsync(e->dir.p, 0, e->slots * sizeof(DirEntry), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->buckets.p, 0, e->slots * sizeof(Bucket), e->stream)) != hipSuccess ||
         (he = hipMemsetAsync(e->ctr.p, 0, sizeof(DevCounters), e->stream)) != hipSuccess ||
@@ -408,7 +414,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
     e->W.gmsg = e->w_gmsg.p; e->W.gshape = (GShape*)((char*)e->w_gmsg.p + (size_t)e->cap256 * 32);
     e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p; e->W.pmode = e->w_pmode.p;
-    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; }   // (slots >= 1024)
+    { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; e->W.pmslot = 0; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
     (void)e->dbg.ensure(4096 + 3 * 2048);
 #endif
@@ -421,8 +427,8 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (getenv("GUBER_ENGINE_STATS"))
-        fprintf(stderr, "[engine %p] batches %llu (small %llu fused %llu part %llu) cache_size %llu size_upper %llu last size %lld | eviction pre-passes: calls %llu launches %llu applied %llu cuts %llu tail rebuilds %llu | waits for a snapshot %llu | compactions %llu\n",
-                (void*)e, (unsigned long long)e->batches, (unsigned long long)e->small_batches, (unsigned long long)e->fused_batches, (unsigned long long)e->part_batches,
+        fprintf(stderr, "[engine %p] batches %llu (small %llu fused %llu part %llu, k_evalpart launches %llu) cache_size %llu size_upper %llu last size %lld | eviction pre-passes: calls %llu launches %llu applied %llu cuts %llu tail rebuilds %llu | waits for a snapshot %llu | compactions %llu\n",
+                (void*)e, (unsigned long long)e->batches, (unsigned long long)e->small_batches, (unsigned long long)e->fused_batches, (unsigned long long)e->part_batches, (unsigned long long)e->ep_launches,
                 (unsigned long long)e->cache_size, (unsigned long long)e->size_upper, (long long)e->last_ctr.size, (unsigned long long)e->lru_admits, (unsigned long long)e->lru_passes,
                 (unsigned long long)e->lru_applied, (unsigned long long)e->lru_cuts, (unsigned long long)e->lru_rebuilds, (unsigned long long)e->settle_waits, (unsigned long long)e->compactions);
 #ifdef GUBER_PHASE_TIMING
@@ -700,7 +706,10 @@ static int plan_part(guber_engine* e, const BatchView& B, Work& W, FastPlan& P) 
     W.careful = 0u;
     W.snap_seq = 0;
     if (e->rb_ride >= 0) attach_counter_readback(e, W);
-    W.did = e->w_did3.p;
+    // (a GUBER_FUSE_EP engine: packed words and owner count per batch parity — this batch's k_part may run beside the previous
+    // batch's k_eval3, k_evalpart_multi)
+    W.did = e->w_did3.p + (e->fuse_ep ? (size_t)(e->part_batches & 1) * e->cap256 : 0);
+    W.pmslot = e->fuse_ep ? 1u + (uint32_t)(e->part_batches & 1) : 0u;
     W.st_hits = nullptr;
 #ifdef GUBER_PHASE_TIMING
     W.dbg = e->dbg.p;
@@ -939,8 +948,41 @@ static bool fits_fused(const guber_engine* e, uint32_t n) {
 // (a batch that may overflow the cache goes alone, through launch_batch and its eviction pre-pass)
 static bool can_fuse(guber_engine* e, uint32_t n) { return fits_fused(e, n) && !lru_may_bind_unlocked(e, n); }   // (takes the engine mutex for the look)
 
+// GUBER_FUSE_EP: a group's k_eval3_multi that has not been launched yet — held back until the same tables' next group comes (then
+// it shares that group's first launch: k_evalpart_multi) or until anything else is about to be enqueued on its stream / the call ends
+// (then it goes on its own).  Lives inside ONE guber_eval_batches_routed_dev call, one per stream the call uses.
+struct PendingEval {
+    bool valid = false; int n = 0; uint32_t tiles = 0; uint64_t units = 0;
+    guber_engine* eng[MULTI_MAX]; MultiEval ME;
+};
+static int flush_pending(PendingEval& p, bool engines_locked = false) {
+    if (!p.valid) return 0;
+    p.valid = false;
+    guber_engine* order[MULTI_MAX];
+    for (int i = 0; i < p.n; ++i) order[i] = p.eng[i];
+    std::sort(order, order + p.n);
+    if (!engines_locked) for (int i = 0; i < p.n; ++i) order[i]->mu.lock();
+    struct Unlock { guber_engine** o; int g; ~Unlock() { for (int i = g - 1; i >= 0; --i) o[i]->mu.unlock(); } } unlock{order, engines_locked ? 0 : p.n};
+    guber_engine* e0 = p.eng[0];
+    if (e0->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    e0->span_begin(KT_EVAL3_MULTI, p.units);
+    hipLaunchKernelGGL(k_eval3_multi, dim3(p.tiles), dim3(256), 0, e0->stream, p.ME);
+    e0->span_end();
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    return 0;
+}
+// Would this batch's prelude (batch_prelude: maintain, epochs) enqueue or read anything?  Then the k_eval3 held back on the stream has
+// to go first.  The same arithmetic as maintain()'s early return, plus the epoch's wrap and a counter read-back waiting for a ride.
+static bool prelude_is_quiet(const guber_engine* e, uint64_t n) {
+    if (e->rb_ride >= 0 || e->epoch + 1 >= 0x7fffffffu) return false;
+    const uint64_t tag_limit = e->slots - e->slots / 8;
+    const uint64_t early = std::min<uint64_t>(16 * n, e->cache_size / 2);
+    return !(e->size_upper > e->cache_size) && !(e->tags_upper + n > tag_limit) &&
+           !(e->size_upper + n + early > e->cache_size || e->tags_upper + n + early > tag_limit);
+}
+
 static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
-                        uint32_t* enqueued) {
+                        uint32_t* enqueued, PendingEval* pend = nullptr) {
     auto views = [&](int i, BatchView& B, ResultView& R) {
         const guber_batch_t* b = &batches[gk[i]]; guber_result_t* r = &results[gk[i]];
         B = BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
@@ -950,12 +992,26 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     };
     if (g == 1) {
         guber_engine* e = grp[0];
+        if (pend) { const int rc = flush_pending(*pend); if (rc) return rc; }
         std::lock_guard<std::mutex> lk(e->mu);
         if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
         BatchView B; ResultView R; views(0, B, R);
         const int rc = launch_batch(e, B, R);
         if (rc == 0) ++*enqueued;
         return rc;
+    }
+    // GUBER_FUSE_EP: the k_eval3 held back on this stream shares this group's first launch (k_evalpart_multi) if the group is the same
+    // tables again, in the same order, all taking the owner-partitioned pipeline, and no prelude has anything to enqueue; otherwise it
+    // goes first, on its own.  What needs no lock is decided here, before the group's locks are taken (flush_pending takes its own).
+    bool same_set = false;
+    if (pend) {
+        same_set = g <= EP_MAX;
+        for (int i = 0; i < g && same_set; ++i) same_set = grp[i]->fuse_ep && takes_part_path(grp[i], batches[gk[i]].n, false, true);
+        if (pend->valid) {
+            bool same = same_set && pend->n == g;
+            for (int i = 0; i < g && same; ++i) same = pend->eng[i] == grp[i];
+            if (!same) { const int rc0 = flush_pending(*pend); if (rc0) return rc0; }
+        }
     }
     // lock the group's engines in address order (any other caller holds at most one engine lock, or locks in this order)
     guber_engine* order[MULTI_MAX];
@@ -969,6 +1025,12 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     int planned = 0, rc = 0;
     bool part = true;                                              // the group takes the owner-partitioned pipeline if all its batches do
     for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false, true);
+    // GUBER_FUSE_EP: the k_eval3 held back on this stream shares this group's first launch if the group is the same tables again, in
+    // the same order, and no prelude has anything to enqueue; otherwise it goes first, on its own
+    const bool ep = pend && same_set && part;                     // (same_set: decided before the locks were taken, below the g == 1 case)
+    bool join = ep && pend->valid;
+    for (int i = 0; i < g && join; ++i) join = prelude_is_quiet(grp[i], batches[gk[i]].n);
+    if (pend && pend->valid && !join) { rc = flush_pending(*pend, true); if (rc) return rc; }   // (valid here => the same engines: locked)
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);
@@ -988,12 +1050,39 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         uint64_t units = 0;
         for (int i = 0; i < planned; ++i) units += ns[i];
         if (part) {
-            grp[0]->span_begin(KT_PART_MULTI, units);
-            hipLaunchKernelGGL(k_part_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
-            grp[0]->span_end();
+            // (a prelude that was not quiet after all — a counter read-back now rides on this k_part — or a group cut short by an
+            // error: the k_eval3 held back goes first)
+            bool joined = join && pend->valid && planned == g;
+            for (int i = 0; i < planned && joined; ++i) joined = MF.sub[i].W.snap_seq == 0 && MF.sub[i].T.buckets == pend->ME.sub[i].T.buckets;
+            if (pend && pend->valid && !joined) { const int rcf = flush_pending(*pend, true); if (rcf) return rcf; }
+            if (joined) {
+                // ONE launch: workgroups [0, pending tiles) are the held-back k_eval3, the rest this group's k_part
+                MultiEP EP{};
+                EP.nb = (uint32_t)planned;
+                for (int i = 0; i < planned; ++i) {
+                    EP.end_e[i] = pend->ME.end_tile[i]; EP.end_p[i] = MF.end_tile[i];
+                    EP.sub[i].E = pend->ME.sub[i]; EP.sub[i].Bp = MF.sub[i].B; EP.sub[i].did_p = MF.sub[i].W.did; EP.sub[i].pmslot_p = MF.sub[i].W.pmslot;
+                }
+                pend->valid = false;
+                grp[0]->span_begin(KT_EVALPART_MULTI, pend->units);
+                hipLaunchKernelGGL(k_evalpart_multi, dim3(pend->tiles + tiles), dim3(256), 0, grp[0]->stream, EP);
+                grp[0]->span_end();
+                grp[0]->ep_launches++;
+            } else {
+                grp[0]->span_begin(KT_PART_MULTI, units);
+                hipLaunchKernelGGL(k_part_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
+                grp[0]->span_end();
+            }
             grp[0]->span_begin(KT_OWN_MULTI, units);
             hipLaunchKernelGGL(k_own_multi, dim3((unsigned)planned * PT_PARTS), dim3(256), 0, grp[0]->stream, MF);
             grp[0]->span_end();
+            if (ep && planned == g) {                             // held back: the same tables' next group, or flush_pending, launches it
+                pend->valid = true; pend->n = planned; pend->tiles = tiles; pend->units = units; pend->ME = ME;
+                for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
+                *enqueued += (uint32_t)planned;
+                if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+                return rc;
+            }
             grp[0]->span_begin(KT_EVAL3_MULTI, units);
             if (grp[0]->eval3_split) {
                 hipLaunchKernelGGL(k_eval3f_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
@@ -1033,6 +1122,18 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
     std::vector<size_t> pos(n_engines, 0);
     uint32_t enqueued = 0, empty = 0;
     for (uint32_t k = 0; k < count; ++k) empty += batches[k].n == 0;
+    // GUBER_FUSE_EP engines: per stream of the call, the k_eval3 of the stream's last group, held back for the next one (launch_group)
+    struct StreamPend { hipStream_t stream; int device; PendingEval p; };
+    std::vector<std::unique_ptr<StreamPend>> pends;
+    bool any_ep = false;
+    for (uint32_t j = 0; j < n_engines; ++j) any_ep = any_ep || (engines[j] && engines[j]->fuse_ep);
+    auto pend_of = [&](guber_engine* e) -> PendingEval* {
+        if (!any_ep) return nullptr;
+        for (auto& sp : pends) if (sp->stream == e->stream && sp->device == e->device) return &sp->p;
+        pends.emplace_back(new StreamPend{e->stream, e->device, PendingEval{}});
+        return &pends.back()->p;
+    };
+    auto flush_all = [&]() -> int { int r = 0; for (auto& sp : pends) { const int q = flush_pending(sp->p); if (!r) r = q; } return r; };
     for (;;) {
         guber_engine* grp[MULTI_MAX]; uint32_t gk[MULTI_MAX]; int g = 0;
         bool any = false;
@@ -1045,17 +1146,21 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
             bool fits = can_fuse(e, batches[k].n);
             for (int i = 0; i < g && fits; ++i) fits = grp[i] != e;
             if (g && (!fits || g == MULTI_MAX || e->stream != grp[0]->stream || e->device != grp[0]->device)) {
-                rc = launch_group(grp, gk, g, batches, results, &enqueued);
+                rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0]));
                 g = 0;
                 if (rc) break;
             }
             grp[g] = e; gk[g] = k; ++g;
-            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued); g = 0; }
+            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0])); g = 0; }
         }
-        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued);
+        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0]));
         if (done) *done = enqueued;
-        if (rc) return rc;
+        if (rc) { (void)flush_all(); return rc; }                  // (what was enqueued is completed: its k_eval3 goes now)
         if (!any) break;
+    }
+    {
+        const int rc = flush_all();
+        if (rc) return rc;
     }
     if (done) *done = enqueued + empty;
     return GUBER_OK;
@@ -2729,13 +2834,16 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     HIPCHK(hipStreamSynchronize(e->stream));
     {   // one pipeline pass = the spans from a first-stage kernel up to the next first-stage kernel
-        auto first_stage = [](int k) { return k == KT_FRONT || k == KT_FRONT_MULTI || k == KT_PART || k == KT_PART_MULTI || k == KT_RESOLVE; };
+        // (k_evalpart_multi both ends a pass — the previous group's k_eval3 — and begins the next: a pass that is followed by one
+        // lasts until the end of that launch)
+        auto first_stage = [](int k) { return k == KT_FRONT || k == KT_FRONT_MULTI || k == KT_PART || k == KT_PART_MULTI || k == KT_RESOLVE || k == KT_EVALPART_MULTI; };
         size_t g0 = 0;
         for (size_t i = 0; i <= e->spans.size(); ++i) {
             if (i == e->spans.size() || (i > g0 && first_stage(e->spans[i].kernel))) {
                 if (i > g0 && first_stage(e->spans[g0].kernel)) {
                     float ms = 0.f;
-                    if (hipEventElapsedTime(&ms, e->spans[g0].a, e->spans[i - 1].b) == hipSuccess) e->group_us.push_back(ms * 1e3f);
+                    const size_t last = i < e->spans.size() && e->spans[i].kernel == KT_EVALPART_MULTI ? i : i - 1;
+                    if (hipEventElapsedTime(&ms, e->spans[g0].a, e->spans[last].b) == hipSuccess) e->group_us.push_back(ms * 1e3f);
                 }
                 g0 = i;
             }

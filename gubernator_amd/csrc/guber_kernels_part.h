@@ -41,6 +41,11 @@ constexpr int PT_PARTS = 256;            // k_own workgroups launched per batch 
 // batch in PM_HOLD + 1 if the traffic is still uniform).  pmode[3] != 0 pins the mode (GUBER_PT_BITS=7|8, tests).
 constexpr uint32_t PM_SPLITS = 8, PM_HOLD = 255;
 GB_HD uint32_t pm_bits(const uint32_t* pm) { return pm[0] == 7u ? 7u : 8u; }
+// GUBER_FUSE_EP (k_evalpart_multi below: batch b's k_eval3 and batch b + 1's k_part in ONE launch): the word k_eval3 decides in is
+// being written while the next batch's k_part runs, so a batch of such an engine reads its owner count from a slot of its own
+// parity instead (Work::pmslot = 1 + (batch & 1) -> pmode[3 + pmslot]; 0 = the word itself), and its k_eval3 leaves the decision
+// there for the batch after the next: the same rule, taking effect one batch later.
+GB_HD uint32_t pm_bits_of(const Work& W) { return (W.pmslot ? W.pmode[3u + W.pmslot] : W.pmode[0]) == 7u ? 7u : 8u; }
 
 // one (key, tile) group, tile -> owner
 struct alignas(64) GMsg {
@@ -157,7 +162,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t g = tile * FT + tid;
     const bool valid = g < B.n;
-    const uint32_t pbits = pm_bits(W.pmode);                      // owners of this batch: 1 << pbits
+    const uint32_t pbits = pm_bits_of(W);                         // owners of this batch: 1 << pbits
     GP_STAMP(0, 0);
 
     if (tile == 0 && W.snap_seq) {                                // a counter read-back rides on this launch (Work::snap_*)
@@ -420,7 +425,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
     __shared__ int sp;
     GRec* const krec = (GRec*)kref;
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (p >= (1u << pm_bits(W.pmode))) {                // (256 workgroups are launched per batch whatever the batch's owner count)
+    if (p >= (1u << pm_bits_of(W))) {                // (256 workgroups are launched per batch whatever the batch's owner count)
 #ifdef GUBER_PHASE_TIMING
         if (t == 0) W.dbg[4096 + 2048 + blockIdx.x * 8] = 0ull;       // "did not run": the fold of the stamps skips this workgroup
 #endif
@@ -1042,6 +1047,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             else if (pm[1] > 1u) pm[1]--;
             else { pm[0] = 7u; pm[1] = 0u; }
         }
+        if (W.pmslot) pm[3u + W.pmslot] = pm[0];                  // (the batch after the next reads it: pm_bits_of)
     }
     GP_STAMPW(2, 3);
 }
@@ -1087,5 +1093,36 @@ __device__ __forceinline__ void eval3_multi_body(const MultiEval& A) {
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) { eval3_multi_body<0>(A); }
 __global__ __launch_bounds__(256, 8) void k_eval3f_multi(MultiEval A) { eval3_multi_body<1>(A); }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s_multi(MultiEval A) { eval3_multi_body<2>(A); }
+
+// ---- batch b's k_eval3 and batch b + 1's k_part of the same tables in ONE launch (GUBER_FUSE_EP=1; built and checked through the
+// kernel source on the CPU, off until it has been measured on the GPU).  A stream's passes are k_part, k_own, k_eval3, k_part, ...:
+// k_part(b + 1) needs nothing k_eval3(b) produces — it hashes and groups the next batch's requests and reads no bucket — so the two
+// can share a launch and a pass is two launches long instead of three (what bounds the fused pipeline is the latency of the
+// launches' chains: DESIGN.md section 4).  What the two halves must not share, they do not: the packed words (Work::did) are
+// double-buffered by batch parity, the owner count of a batch comes from its parity's slot (pm_bits_of), messages / {start, count}
+// are dead once k_own(b) has run, k_eval3 reads records, k_part writes messages.  The engine only fuses what maintenance leaves
+// alone: same tables in the same order, no counter read-back riding on the k_part half (guber_engine.hip launch_group).
+// Workgroups [0, end_e[nb - 1]) are k_eval3's tiles, the rest k_part's.
+constexpr int EP_MAX = MULTI_MAX < 4 ? MULTI_MAX : 4;     // (four tables' arguments fit the 4 KB kernel-argument segment)
+struct EPSub { EvalArgs E; BatchView Bp; uint32_t* did_p; uint32_t pmslot_p; uint32_t pad_; };
+struct MultiEP { uint32_t nb; uint32_t end_e[EP_MAX]; uint32_t end_p[EP_MAX]; EPSub sub[EP_MAX]; };
+static_assert(sizeof(MultiEP) <= 4096, "kernel arguments are limited to 4 KB");
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_evalpart_multi(MultiEP A) {
+    static_assert(FT == 256, "k_eval3's workgroup is k_part's tile");
+    const uint32_t tiles_e = A.end_e[A.nb - 1];
+    const bool part = blockIdx.x >= tiles_e;
+    const uint32_t wg = part ? blockIdx.x - tiles_e : blockIdx.x;
+    uint32_t sb = 0, first = 0;
+#pragma unroll
+    for (int k = 0; k < EP_MAX - 1; ++k) {
+        const uint32_t end = part ? A.end_p[k] : A.end_e[k];
+        if (sb == (uint32_t)k && k + 1 < (int)A.nb && wg >= end) { first = end; sb = k + 1; }
+    }
+    const EPSub* a = (const EPSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEP, sub)) + sb;
+    if (!part) { eval3_body<0>(a->E, wg - first); return; }
+    Work W = a->E.W;                                       // the next batch's work arrays are this engine's, but for:
+    W.did = a->did_p; W.pmslot = a->pmslot_p; W.snap_seq = 0u;
+    part_body(a->E.T, a->Bp, W, wg - first);
+}
 
 }  // namespace guber

@@ -165,7 +165,8 @@ struct Work {
     GRec* grec;                         // [cap] the owner's answer to message i: bucket before the batch, slot, flags, rank base, total
     unsigned long long* segtiles;       // [cap][4] tiles holding a segment whose requests are walked serially (all zero between batches)
     uint32_t pshift;                    // owner of a key (256 owners) = its home position >> pshift
-    uint32_t* pmode;                    // [4] device words: owner bits of the next batch (7 | 8), batches left at 8, rounds that split in this batch, pinned
+    uint32_t pmslot;                    // 0: the batch's owner count is pmode[0]; 1 | 2: pmode[3 + pmslot] (GUBER_FUSE_EP: guber_kernels_part.h pm_bits_of)
+    uint32_t* pmode;                    // device words: [0..3] owner bits of the next batch (7 | 8), batches left at 8, rounds that split in this batch, pinned; [4..5] the bits per batch parity (pmslot)
     // the compact forms (GUBER_PART_COMPACT, guber_kernels_part.h): 32-byte messages live in the first half of gmsg[], the
     // request shapes they refer to in the second half (gshape); 32-byte records in grs[], the 64-byte form (grec[]) only for
     // the groups whose record does not fit

@@ -9,6 +9,20 @@ run() {  # name, bench args
   local name=$1; shift
   timeout 60 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 "$@" > $O/bench_$name.json 2> $O/bench_$name.err; echo "bench $name rc=$?"
 }
+# FIRST: GUBER_FUSE_EP (k_eval3 of a group + k_part of the same tables' next group in ONE launch: two launches per pass instead of three;
+# built at the end of round 4, checked through the kernel source on the CPU only) — parity on the GPU, then the headline with / without,
+# alternating on this box; the bench's own parity gate (2048 / 2048 batches by digest) runs in both
+GUBER_FUSE_EP=1 timeout 300 python scripts/r05_fuse_ep_check.py > $O/fuse_ep_check.txt 2>&1; echo "fuse_ep check rc=$?"; tail -4 $O/fuse_ep_check.txt
+if grep -q "FUSE_EP CHECK OK" $O/fuse_ep_check.txt; then
+  for rep in 1 2; do
+    for ep in 0 1; do
+      GUBER_FUSE_EP=$ep timeout 90 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 > $O/bench_ep${ep}_$rep.json 2> $O/bench_ep${ep}_$rep.err; echo "bench fuse_ep=$ep rep $rep rc=$?"
+      python -c "import json; d=json.load(open('$O/bench_ep${ep}_$rep.json')); print('fuse_ep=$ep', round(d['value']/1e9,3), d['ms_per_step'], d.get('parity'), {k: v for k, v in d['roofline'].get('kernel_avg_us', {}).items() if 'multi' in k})"
+    done
+  done
+  GUBER_FUSE_EP=1 timeout 90 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 --shards 12 --streams 2 > $O/bench_ep1_s12_t2.json 2> $O/bench_ep1_s12_t2.err
+  python -c "import json; d=json.load(open('$O/bench_ep1_s12_t2.json')); print('fuse_ep=1 12 shards 2 streams', round(d['value']/1e9,3), d['ms_per_step'])"
+fi
 NAMES=""
 for cfg in "12 3" "12 4" "16 4" "16 3" "18 3" "20 5" "24 4" "24 6" "8 2" "12 2"; do
   set -- $cfg

@@ -69,7 +69,15 @@ template <class F> void launch(dim3 grid, dim3 block, const void* kernarg, F bod
     g_body = body;
     S.gdim = grid; S.bdim = block; S.kernarg = kernarg;
     while (g_stacks.size() < block.x) g_stacks.push_back((char*)malloc(kStack));
-    for (uint32_t b = 0; b < grid.x; ++b) {
+    std::vector<uint32_t> order(grid.x);
+    for (uint32_t b = 0; b < grid.x; ++b) order[b] = S.block_order == 1 ? grid.x - 1 - b : b;
+    if (S.block_order == 2)
+        for (uint32_t b = grid.x; b > 1; --b) {
+            S.rng ^= S.rng << 13; S.rng ^= S.rng >> 7; S.rng ^= S.rng << 17;
+            std::swap(order[b - 1], order[S.rng % b]);
+        }
+    for (uint32_t bi = 0; bi < grid.x; ++bi) {
+        const uint32_t b = order[bi];
         S.bidx = dim3(b);
         S.fib.assign(block.x, Fiber{});
         S.bar_waiting = 0;
@@ -112,7 +120,8 @@ using namespace guber;
 struct DevSim {
     uint64_t slots = 0; uint32_t max_batch = 0, cap = 0;
     bool eval3_split = false;                                      // k_eval3 as two launches (GUBER_EVAL3_SPLIT)
-    uint32_t pmode[4] = {7, 0, 0, 0};                              // Work::pmode: the owner count follows the traffic (guber_kernels_part.h)
+    uint32_t pmode[8] = {7, 0, 0, 0, 7, 7, 0, 0};                  // Work::pmode: the owner count follows the traffic (guber_kernels_part.h); [4..5]: per batch parity (fuse_ep)
+    bool fuse_ep = false; uint64_t part_seq = 0;                   // GUBER_FUSE_EP: every owner-partitioned batch reads its parity's slot, did3 is double-buffered
     Table T{}; Work W{};
     std::vector<DirEntry> dir; std::vector<Bucket> buckets; std::vector<uint8_t> arena; DevCounters ctr{}; std::vector<BlockCounters> bctr;
     std::vector<uint32_t> u32; std::vector<uint8_t> rflags; std::vector<unsigned long long> tilemask, claims, segtiles; std::vector<SegRec> srec;
@@ -199,7 +208,7 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->arena.assign(std::max<uint64_t>(s * 16, 1 << 20) + 64, 0); d->bctr.assign((d->cap + 255) / 256, BlockCounters{0, 0, 0, 0});
     d->u32.assign((size_t)d->cap * 2, 0); d->rflags.assign(d->cap, 0);
     d->tilemask.assign((size_t)2 * d->cap * FT_WORDS, 0); d->srec.resize(d->cap); memset(d->srec.data(), 0, d->cap * sizeof(SegRec));
-    d->sinv.assign(d->cap, 0); d->tilerow.assign((size_t)d->cap * FT_MAX_TILES, 0); d->did2.assign((size_t)2 * d->cap, 0); d->did3.assign(d->cap, 0);
+    d->sinv.assign(d->cap, 0); d->tilerow.assign((size_t)d->cap * FT_MAX_TILES, 0); d->did2.assign((size_t)2 * d->cap, 0); d->did3.assign((size_t)2 * d->cap, 0);
     d->claims_cells = 1024; while (d->claims_cells < 4 * d->cap) d->claims_cells <<= 1;
     d->claims.assign(d->claims_cells, 0);
     d->gmsg.resize(d->cap); d->grec.resize((size_t)d->cap + d->cap / 2); d->gse.assign((size_t)FT_MAX_TILES * PT_PARTS, 0); d->segtiles.assign((size_t)d->cap * 4, 0);
@@ -215,17 +224,25 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->W.grs = (GRecS*)d->grec.data(); d->W.grec = d->grec.data() + d->cap / 2; d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
     uint32_t lg = 0; while ((1ull << lg) < s) lg++;
     d->W.pshift = lg - 8;
-    d->pmode[0] = 7; d->pmode[1] = d->pmode[2] = d->pmode[3] = 0; d->W.pmode = d->pmode;
+    d->pmode[0] = d->pmode[4] = d->pmode[5] = 7; d->pmode[1] = d->pmode[2] = d->pmode[3] = 0; d->W.pmode = d->pmode;
     return d;
 }
 void ds_destroy(void* h) { delete (DevSim*)h; }
 // owners per batch: bits = 7 | 8 pinned, 0 = follow the traffic (the default); ds_owner_bits: what the next batch will use
-void ds_pin_owner_bits(void* h, uint32_t bits) { DevSim* d = (DevSim*)h; d->pmode[3] = bits ? 1u : 0u; if (bits) d->pmode[0] = bits; d->pmode[1] = d->pmode[2] = 0; }
+void ds_pin_owner_bits(void* h, uint32_t bits) { DevSim* d = (DevSim*)h; d->pmode[3] = bits ? 1u : 0u; if (bits) d->pmode[0] = d->pmode[4] = d->pmode[5] = bits; d->pmode[1] = d->pmode[2] = 0; }
 uint32_t ds_owner_bits(void* h) { return ((DevSim*)h)->pmode[0]; }
 void ds_eval3_split(void* h, int on) { ((DevSim*)h)->eval3_split = on != 0; }
 // batches left with 256 owners (pmode[1]): read, or shorten for a test (n != 0)
 uint32_t ds_owner_hold(void* h, uint32_t n) { DevSim* d = (DevSim*)h; if (n) d->pmode[1] = n; return d->pmode[1]; }
 void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
+// the order a launch's workgroups run in (0 ascending, 1 descending, 2 a seeded shuffle): the two halves of k_evalpart_multi must
+// not care
+void ds_block_order(uint32_t order) { fakehip::S.block_order = order; }
+// GUBER_FUSE_EP: every owner-partitioned batch of this table reads its owner count from its parity's slot and has packed words
+// of its own parity (what guber_engine.hip plan_part does for such an engine)
+void ds_fuse_ep(void* h, int on) { DevSim* d = (DevSim*)h; d->fuse_ep = on != 0; d->pmode[4] = d->pmode[5] = d->pmode[0]; }
+// the owner bits the batch after the next will use (its parity's slot), for the tests of the mode's one-batch lag
+uint32_t ds_owner_slot(void* h, uint32_t parity) { return ((DevSim*)h)->pmode[4 + (parity & 1u)]; }
 
 static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int pipeline, int careful);
 // pipeline 0: k_front + k_eval2 (careful = the retry round), 1: k_part + k_own + k_eval3.  With a bounded cache (ds_create_bounded)
@@ -289,7 +306,9 @@ static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int
         fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval2(A); });
         d->fast_batches++; d->fast_prev_n = n;
     } else {
-        W.did = d->did3.data();
+        W.did = d->did3.data() + (d->fuse_ep ? (size_t)(d->part_seq & 1) * d->cap : 0);
+        W.pmslot = d->fuse_ep ? 1u + (uint32_t)(d->part_seq & 1) : 0u;
+        d->part_seq++;
         fakehip::launch(dim3(tiles), dim3(FT), nullptr, [&] { k_part(d->T, B, W); });
         fakehip::launch(dim3(PT_PARTS), dim3(256), nullptr, [&] { k_own(d->T, B, W, tiles); });
         EvalArgs A{d->T, B, R, W};
@@ -300,6 +319,54 @@ static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int
             fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
         for (auto v : d->segtiles) if (v) return -2;      // the walk's tile maps must be all zero between batches
     }
+    return 0;
+}
+// `rounds` batches for each of nh (<= EP_MAX) tables — batch r of table j is batches[r * nh + j] — through the owner-partitioned
+// pipeline as a GUBER_FUSE_EP stream enqueues them (guber_engine.hip launch_group): k_part_multi, k_own_multi, then per further round ONE
+// k_evalpart_multi (the previous round's k_eval3 + this round's k_part) and k_own_multi, and the last round's k_eval3_multi.
+int ds_eval_stream_ep(void* const* hs, uint32_t nh, const guber_batch_t* batches, guber_result_t* results, uint32_t rounds) {
+    if (nh == 0 || nh > (uint32_t)EP_MAX || rounds == 0) return -1;
+    struct Planned { BatchView B; ResultView R; Work W; uint32_t tiles; };
+    std::vector<Planned> prev, cur(nh);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        for (uint32_t j = 0; j < nh; ++j) {
+            DevSim* d = (DevSim*)hs[j];
+            const guber_batch_t* b = &batches[(size_t)r * nh + j]; guber_result_t* rs = &results[(size_t)r * nh + j];
+            if (!d->fuse_ep || d->cache_size || b->n == 0 || b->n > d->max_batch || b->n > 65536) return -1;
+            Planned& P = cur[j];
+            P.B = BatchView{b->n, d->cap, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                            b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
+            P.B.key_stride = 0; P.B.key_len = nullptr;
+            P.R = ResultView{rs->status, rs->limit, rs->remaining, rs->reset_time, rs->err};
+            P.W = d->W;
+            P.W.touch = d->seq_next; d->seq_next += b->n;
+            P.W.did = d->did3.data() + (size_t)(d->part_seq & 1) * d->cap;
+            P.W.pmslot = 1u + (uint32_t)(d->part_seq & 1);
+            d->part_seq++;
+            P.tiles = (b->n + FT - 1) / FT;
+        }
+        MultiFront MF{}; MF.nb = nh;
+        uint32_t tp = 0;
+        for (uint32_t j = 0; j < nh; ++j) { tp += cur[j].tiles; MF.end_tile[j] = tp; MF.sub[j] = FrontArgs{((DevSim*)hs[j])->T, cur[j].B, cur[j].W}; }
+        if (prev.empty())
+            fakehip::launch(dim3(tp), dim3(FT), &MF, [&] { k_part_multi(MF); });
+        else {
+            MultiEP A{}; A.nb = nh;
+            uint32_t te = 0;
+            for (uint32_t j = 0; j < nh; ++j) {
+                te += prev[j].tiles; A.end_e[j] = te; A.end_p[j] = MF.end_tile[j];
+                A.sub[j] = EPSub{EvalArgs{((DevSim*)hs[j])->T, prev[j].B, prev[j].R, prev[j].W}, cur[j].B, cur[j].W.did, cur[j].W.pmslot, 0u};
+            }
+            fakehip::launch(dim3(te + tp), dim3(256), &A, [&] { k_evalpart_multi(A); });
+        }
+        fakehip::launch(dim3(nh * PT_PARTS), dim3(256), &MF, [&] { k_own_multi(MF); });
+        prev = cur;
+    }
+    MultiEval ME{}; ME.nb = nh;
+    uint32_t te = 0;
+    for (uint32_t j = 0; j < nh; ++j) { te += prev[j].tiles; ME.end_tile[j] = te; ME.sub[j] = EvalArgs{((DevSim*)hs[j])->T, prev[j].B, prev[j].R, prev[j].W}; }
+    fakehip::launch(dim3(te), dim3(256), &ME, [&] { k_eval3_multi(ME); });
+    for (uint32_t j = 0; j < nh; ++j) for (auto v : ((DevSim*)hs[j])->segtiles) if (v) return -2;
     return 0;
 }
 // the last owner-partitioned batch: (key, tile) groups, of which answered by a 32-byte record, of which sent with the tile's shape

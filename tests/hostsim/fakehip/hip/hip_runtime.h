@@ -40,6 +40,7 @@ struct State {
     unsigned long long wx[16][2][kWave]; int warrived[16][2]; unsigned long long wgen[16]; unsigned long long lane_gen[1024];
     const void* kernarg = nullptr;
     uint32_t chaos = 0;   // != 0: yield inside atomics in a seeded pseudo-random pattern
+    uint32_t block_order = 0;   // the order a launch's workgroups run in: 0 ascending, 1 descending, 2 a seeded shuffle
     uint64_t rng = 88172645463325252ull;
     unsigned long long progress = 0;   // bumped whenever a fiber gets past a wait, ends, or yields voluntarily (deadlock detection)
 };

@@ -25,6 +25,9 @@ def test_roofline_traffic_is_the_mix_of_pipelines_the_profile_segment_ran():
     launches = {"k_front": 2, "k_eval2": 2, "k_part_multi": 3, "k_own_multi": 3, "k_eval3_multi": 3}
     per_launch = {k: 4 * B for k in ("k_part_multi", "k_own_multi", "k_eval3_multi")}
     assert b.pipeline_traffic(tj, "token", list(launches), launches, per_launch, B) == int((2 * 30 + 12 * 18) / 14)
+    # GUBER_FUSE_EP: k_part_multi once, then k_evalpart_multi (one group's k_eval3 + the next group's k_part) per round, k_eval3_multi last
+    launches = {"k_part_multi": 1, "k_own_multi": 3, "k_evalpart_multi": 2, "k_eval3_multi": 1}
+    assert b.pipeline_traffic(tj, "token", list(launches), launches, {k: 4 * B for k in launches}, B) == 18
     # a kernel the file does not know: no figure rather than a wrong one
     assert b.pipeline_traffic(tj, "token", ["k_front", "k_eval2", "k_other"], {"k_front": 1, "k_eval2": 1, "k_other": 1}, {}, B) is None
     # the committed file carries every kernel of both pipelines

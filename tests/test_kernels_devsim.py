@@ -392,3 +392,109 @@ def test_batches_larger_than_the_cache_are_cut(lib):
     st = sim.lru_stats()
     assert st["cuts"] >= 5 and st["unexpired_evictions"] == orc.counters()[3], st
     sim.close()
+
+
+# ---- GUBER_FUSE_EP: batch b's k_eval3 and batch b + 1's k_part of the same tables in ONE launch (k_evalpart_multi) --------------------
+def ep_lib(lib):
+    if not lib.product_form:
+        pytest.skip("the fused launch is built from the product's form")
+    lib.ds_fuse_ep.argtypes = [C.c_void_p, C.c_int]
+    lib.ds_block_order.argtypes = [C.c_uint32]
+    lib.ds_owner_slot.argtypes = [C.c_void_p, C.c_uint32]
+    lib.ds_owner_slot.restype = C.c_uint32
+    lib.ds_eval_stream_ep.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_uint32]
+    return lib
+
+
+def run_ep_stream(lib, sims, rounds):
+    """rounds[r][j] = the batch of table j in round r: through ds_eval_stream_ep (k_part_multi, k_own_multi, then per round ONE
+    k_evalpart_multi + k_own_multi, the last k_eval3_multi); the results, same shape"""
+    nh, nr = len(sims), len(rounds)
+    bs, rs = (GuberBatch * (nh * nr))(), (GuberResult * (nh * nr))()
+    res = [[HostResult(b.n) for b in rnd] for rnd in rounds]
+    for r in range(nr):
+        for j in range(nh):
+            bs[r * nh + j], rs[r * nh + j] = rounds[r][j].c, res[r][j].c
+    hs = (C.c_void_p * nh)(*[s.h for s in sims])
+    rc = lib.ds_eval_stream_ep(hs, nh, bs, rs, nr)
+    assert rc == 0, rc
+    return res
+
+
+@pytest.mark.parametrize("order,chaos", [(0, 0), (1, 0), (2, 1)], ids=["eval3_first", "part_first", "shuffled_chaos"])
+def test_eval3_and_the_next_batchs_part_in_one_launch(lib, order, chaos):
+    """three tables, six rounds of adversarial batches each (every branch of algorithms.go, hot keys, mixed shapes, 1 .. 7 tiles):
+    whichever half of the fused launch runs first — all of k_eval3(b) before k_part(b + 1), the reverse, or the workgroups
+    shuffled — every batch of every table equals its oracle, counters too (the halves share nothing: packed words per batch parity,
+    the owner count from the parity's slot)"""
+    L = ep_lib(lib)
+    sims, orcs = [Sim(L, slots=8192, max_batch=2048) for _ in range(3)], [Oracle() for _ in range(3)]
+    for s in sims:
+        L.ds_fuse_ep(s.h, 1)
+    gens = [streams.adversarial_batches(40 + j, 6, [1700, 600, 300][j], greg_fn=gregorian) for j in range(3)]
+    rounds = [[next(g) for g in gens] for _ in range(6)]
+    L.ds_block_order(order)
+    L.ds_chaos(chaos)
+    try:
+        res = run_ep_stream(L, sims, rounds)
+    finally:
+        L.ds_block_order(0)
+        L.ds_chaos(0)
+    for j in range(3):
+        for r in range(6):
+            assert_results_equal(res[r][j], orcs[j].eval(rounds[r][j]), f"table {j} round {r}")
+        o, hi, mi, sz, retries, _ = sims[j].counters()
+        co = orcs[j].counters()
+        assert retries == 0 and (o, hi, mi) == (co[0], co[1], co[2]) and sz == orcs[j].size()
+    for s in sims:
+        s.close()
+
+
+def test_a_fuse_ep_table_launched_batch_by_batch(lib):
+    """what guber_engine.hip does for such an engine when nothing can be fused (a lone batch, maintenance in between): the three
+    launches one after the other, the packed words and the owner count still per batch parity"""
+    L = ep_lib(lib)
+    sim, orc = Sim(L), Oracle()
+    L.ds_fuse_ep(sim.h, 1)
+    for k, b in enumerate(streams.adversarial_batches(3, 8, 1500, greg_fn=gregorian)):
+        assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
+    sim.close()
+
+
+def test_the_owner_count_of_a_fused_stream_follows_one_batch_later(lib):
+    """a batch whose k_eval3 shares a launch with the next batch's k_part cannot change THAT batch's owner count any more: it leaves
+    the decision in its parity's slot, for the batch after the next (pm_bits_of) — crowded owners in batch 1 move batch 3 to 256
+    owners, batch 2 still splits its rounds at 128; the answers equal the oracle's all the way, in either order of the halves"""
+    L = ep_lib(lib)
+    from support import oracle_lib
+    ol = oracle_lib()
+    crowd, i, per = [], 0, [0] * 8
+    while min(per) < 400:
+        k = b"crowd_%d" % i
+        i += 1
+        o = ((ol.oracle_xxhash64(k, len(k), 0) >> 7) & ((1 << 20) - 1)) >> 13
+        if o < 8 and per[o] < 400:
+            per[o] += 1
+            crowd.append(k)
+    table = streams.key_table(20_000)
+    z = streams.ZipfSampler(20_000, seed=11)
+    now = streams.NOW0
+    for order in (0, 1):
+        sim, orc = Sim(L, slots=1 << 20, max_batch=8192), Oracle(cache_size=1 << 20)
+        L.ds_fuse_ep(sim.h, 1)
+        rounds = [[streams.bench_batch(table, z.draw(3_000), now, limit=50, duration=60_000)],
+                  [HostBatch(crowd, 1, 50, 60_000, now + 1)],
+                  [HostBatch(crowd, 1, 50, 60_000, now + 2)],
+                  [HostBatch(crowd, 1, 50, 60_000, now + 3)],
+                  [streams.bench_batch(table, z.draw(3_000), now + 4, limit=50, duration=60_000)]]
+        L.ds_block_order(order)
+        try:
+            res = run_ep_stream(L, [sim], rounds[:2])          # batches 0 and 1: the second one crowds eight owners
+            assert (L.ds_owner_slot(sim.h, 0), L.ds_owner_slot(sim.h, 1)) == (7, 8)      # batch 2 (parity 0) stays at 128, batch 3 gets 256
+            res += run_ep_stream(L, [sim], rounds[2:])
+        finally:
+            L.ds_block_order(0)
+        assert (L.ds_owner_slot(sim.h, 0), L.ds_owner_slot(sim.h, 1)) == (8, 8)
+        for r, rnd in enumerate(rounds):
+            assert_results_equal(res[r][0], orc.eval(rnd[0]), f"order {order} batch {r}")
+        sim.close()
