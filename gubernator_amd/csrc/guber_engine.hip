@@ -971,6 +971,26 @@ static int flush_pending(PendingEval& p, bool engines_locked = false) {
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
     return 0;
 }
+// every k_eval3 a call is holding back: at most one per set of engines (sets are disjoint: one that overlaps a new group without
+// being it is launched before the group is)
+struct PendSet {
+    std::vector<std::unique_ptr<PendingEval>> items;
+    PendingEval* free_slot() {
+        for (auto& q : items) if (!q->valid) return q.get();
+        items.emplace_back(new PendingEval());
+        return items.back().get();
+    }
+    int flush_touching(guber_engine* const* grp, int g, const PendingEval* keep = nullptr) {
+        for (auto& q : items) {
+            if (!q->valid || q.get() == keep) continue;
+            bool overlap = false;
+            for (int i = 0; i < q->n && !overlap; ++i) for (int j = 0; j < g && !overlap; ++j) overlap = q->eng[i] == grp[j];
+            if (overlap) { const int rc = flush_pending(*q); if (rc) return rc; }
+        }
+        return 0;
+    }
+    int flush_all() { int r = 0; for (auto& q : items) { const int rc = flush_pending(*q); if (!r) r = rc; } return r; }
+};
 // Would this batch's prelude (batch_prelude: maintain, epochs) enqueue or read anything?  Then the k_eval3 held back on the stream has
 // to go first.  The same arithmetic as maintain()'s early return, plus the epoch's wrap and a counter read-back waiting for a ride.
 static bool prelude_is_quiet(const guber_engine* e, uint64_t n) {
@@ -982,7 +1002,7 @@ static bool prelude_is_quiet(const guber_engine* e, uint64_t n) {
 }
 
 static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
-                        uint32_t* enqueued, PendingEval* pend = nullptr) {
+                        uint32_t* enqueued, PendSet* ps = nullptr) {
     auto views = [&](int i, BatchView& B, ResultView& R) {
         const guber_batch_t* b = &batches[gk[i]]; guber_result_t* r = &results[gk[i]];
         B = BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
@@ -992,7 +1012,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     };
     if (g == 1) {
         guber_engine* e = grp[0];
-        if (pend) { const int rc = flush_pending(*pend); if (rc) return rc; }
+        if (ps) { const int rc = ps->flush_touching(grp, 1); if (rc) return rc; }
         std::lock_guard<std::mutex> lk(e->mu);
         if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
         BatchView B; ResultView R; views(0, B, R);
@@ -1004,14 +1024,18 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     // tables again, in the same order, all taking the owner-partitioned pipeline, and no prelude has anything to enqueue; otherwise it
     // goes first, on its own.  What needs no lock is decided here, before the group's locks are taken (flush_pending takes its own).
     bool same_set = false;
-    if (pend) {
+    PendingEval* pend = nullptr;                                   // the k_eval3 held back for exactly these tables, if there is one
+    if (ps) {
         same_set = g <= EP_MAX;
         for (int i = 0; i < g && same_set; ++i) same_set = grp[i]->fuse_ep && takes_part_path(grp[i], batches[gk[i]].n, false, true);
-        if (pend->valid) {
-            bool same = same_set && pend->n == g;
-            for (int i = 0; i < g && same; ++i) same = pend->eng[i] == grp[i];
-            if (!same) { const int rc0 = flush_pending(*pend); if (rc0) return rc0; }
+        for (auto& q : ps->items) {
+            if (!q->valid || !same_set || q->n != g) continue;
+            bool same = true;
+            for (int i = 0; i < g && same; ++i) same = q->eng[i] == grp[i];
+            if (same) { pend = q.get(); break; }
         }
+        const int rc0 = ps->flush_touching(grp, g, pend);         // (one that holds some of these engines in another combination: first)
+        if (rc0) return rc0;
     }
     // lock the group's engines in address order (any other caller holds at most one engine lock, or locks in this order)
     guber_engine* order[MULTI_MAX];
@@ -1027,10 +1051,10 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false, true);
     // GUBER_FUSE_EP: the k_eval3 held back on this stream shares this group's first launch if the group is the same tables again, in
     // the same order, and no prelude has anything to enqueue; otherwise it goes first, on its own
-    const bool ep = pend && same_set && part;                     // (same_set: decided before the locks were taken, below the g == 1 case)
-    bool join = ep && pend->valid;
+    const bool ep = ps && same_set && part;                       // (same_set, pend: decided before the locks were taken, below the g == 1 case)
+    bool join = ep && pend && pend->valid;
     for (int i = 0; i < g && join; ++i) join = prelude_is_quiet(grp[i], batches[gk[i]].n);
-    if (pend && pend->valid && !join) { rc = flush_pending(*pend, true); if (rc) return rc; }   // (valid here => the same engines: locked)
+    if (pend && pend->valid && !join) { rc = flush_pending(*pend, true); if (rc) return rc; }   // (pend => the same engines: locked)
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);
@@ -1077,6 +1101,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
             hipLaunchKernelGGL(k_own_multi, dim3((unsigned)planned * PT_PARTS), dim3(256), 0, grp[0]->stream, MF);
             grp[0]->span_end();
             if (ep && planned == g) {                             // held back: the same tables' next group, or flush_pending, launches it
+                if (!pend) pend = ps->free_slot();
                 pend->valid = true; pend->n = planned; pend->tiles = tiles; pend->units = units; pend->ME = ME;
                 for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
                 *enqueued += (uint32_t)planned;
@@ -1122,18 +1147,12 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
     std::vector<size_t> pos(n_engines, 0);
     uint32_t enqueued = 0, empty = 0;
     for (uint32_t k = 0; k < count; ++k) empty += batches[k].n == 0;
-    // GUBER_FUSE_EP engines: per stream of the call, the k_eval3 of the stream's last group, held back for the next one (launch_group)
-    struct StreamPend { hipStream_t stream; int device; PendingEval p; };
-    std::vector<std::unique_ptr<StreamPend>> pends;
+    // GUBER_FUSE_EP engines: the k_eval3 of a group of tables is held back for the same tables' next group (launch_group)
+    PendSet pendset;
     bool any_ep = false;
     for (uint32_t j = 0; j < n_engines; ++j) any_ep = any_ep || (engines[j] && engines[j]->fuse_ep);
-    auto pend_of = [&](guber_engine* e) -> PendingEval* {
-        if (!any_ep) return nullptr;
-        for (auto& sp : pends) if (sp->stream == e->stream && sp->device == e->device) return &sp->p;
-        pends.emplace_back(new StreamPend{e->stream, e->device, PendingEval{}});
-        return &pends.back()->p;
-    };
-    auto flush_all = [&]() -> int { int r = 0; for (auto& sp : pends) { const int q = flush_pending(sp->p); if (!r) r = q; } return r; };
+    PendSet* const ps = any_ep ? &pendset : nullptr;
+    auto flush_all = [&]() -> int { return pendset.flush_all(); };
     for (;;) {
         guber_engine* grp[MULTI_MAX]; uint32_t gk[MULTI_MAX]; int g = 0;
         bool any = false;
@@ -1146,14 +1165,14 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
             bool fits = can_fuse(e, batches[k].n);
             for (int i = 0; i < g && fits; ++i) fits = grp[i] != e;
             if (g && (!fits || g == MULTI_MAX || e->stream != grp[0]->stream || e->device != grp[0]->device)) {
-                rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0]));
+                rc = launch_group(grp, gk, g, batches, results, &enqueued, ps);
                 g = 0;
                 if (rc) break;
             }
             grp[g] = e; gk[g] = k; ++g;
-            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0])); g = 0; }
+            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued, ps); g = 0; }
         }
-        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued, pend_of(grp[0]));
+        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued, ps);
         if (done) *done = enqueued;
         if (rc) { (void)flush_all(); return rc; }                  // (what was enqueued is completed: its k_eval3 goes now)
         if (!any) break;

@@ -386,6 +386,7 @@ typedef struct guber_kernel_time {
     uint64_t units;      /* requests those launches processed (a fused launch carries several engines' batches) */
 } guber_kernel_time_t;
 int guber_profile_enable(guber_engine_t* e, int enable);
+/* *n_out = the kernels the library times (17 today; it grows with the library), of which the first min(cap, *n_out) are filled. */
 int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, uint32_t cap, uint32_t* n_out);
 /* After guber_profile_read(): the duration of every pipeline pass the profiled region made on this engine's stream — the launches
  * of one batch, or of one fused group of up to four tables' batches (recorded by the group's first engine) — from the first

@@ -20,8 +20,11 @@ if grep -q "FUSE_EP CHECK OK" $O/fuse_ep_check.txt; then
       python -c "import json; d=json.load(open('$O/bench_ep${ep}_$rep.json')); print('fuse_ep=$ep', round(d['value']/1e9,3), d['ms_per_step'], d.get('parity'), {k: v for k, v in d['roofline'].get('kernel_avg_us', {}).items() if 'multi' in k})"
     done
   done
-  GUBER_FUSE_EP=1 timeout 90 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 --shards 12 --streams 2 > $O/bench_ep1_s12_t2.json 2> $O/bench_ep1_s12_t2.err
-  python -c "import json; d=json.load(open('$O/bench_ep1_s12_t2.json')); print('fuse_ep=1 12 shards 2 streams', round(d['value']/1e9,3), d['ms_per_step'])"
+  for cfg in "12 2" "16 4" "24 4" "24 3"; do                 # (more than four shards per stream: several groups per stream and round, each with its own held-back k_eval3)
+    set -- $cfg
+    GUBER_FUSE_EP=1 timeout 90 python bench.py --no-cpu-baseline --extras "" --latency-steps 0 --shards $1 --streams $2 > $O/bench_ep1_s$1_t$2.json 2> $O/bench_ep1_s$1_t$2.err
+    python -c "import json; d=json.load(open('$O/bench_ep1_s$1_t$2.json')); print('fuse_ep=1 $1 shards $2 streams', round(d['value']/1e9,3), d['ms_per_step'])"
+  done
 fi
 NAMES=""
 for cfg in "12 3" "12 4" "16 4" "16 3" "18 3" "20 5" "24 4" "24 6" "8 2" "12 2"; do
