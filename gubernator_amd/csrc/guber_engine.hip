@@ -483,7 +483,7 @@ extern "C" void guber_engine_destroy(guber_engine_t* e) {
 
 // Enqueue the kernel sequence for one batch whose arrays are all in HBM.
 static int compact_table(guber_engine* e, int64_t now_ms);
-static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows = false);
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows = false, bool* defer_hard = nullptr);
 // What a batch needs before its kernels can be enqueued, shared by the single-engine and the fused multi-engine launch:
 // cache maintenance, the engine's epochs, and (two-launch pipeline) the views / work arrays of this batch.
 struct FastPlan { BatchView B2, B3; Work W; uint32_t ftiles; };
@@ -637,17 +637,19 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
     return fail(GUBER_E_HIP, "the eviction pre-pass did not converge");
 }
 
-static int batch_prelude(guber_engine* e, const BatchView& B, Work& W) {
+static int batch_prelude(guber_engine* e, const BatchView& B, Work& W, bool* defer_hard = nullptr) {
     const uint32_t n = B.n;
     if (n > e->max_batch) return fail(GUBER_E_BATCH_TOO_LARGE, "batch larger than guber_config_t.max_batch");
+    if (defer_hard && e->epoch + 1 >= 0x7fffffffu) { *defer_hard = true; return 0; }   // (the wrap below enqueues a launch)
     if (B.now_ms > e->clock_ms) e->clock_ms = B.now_ms;
     // Bounded cache and directory load.  size_upper / tags_upper are host-side upper bounds (every request might create a
     // new item); only when one crosses its limit are the real counters read back, the least recently used items evicted
     // (lrucache.go:98-100) and, if the directory is above its load limit, the table rebuilt without its dead entries.  A
     // batch that still finds no room gets per-item GUBER_ITEM_E_TABLE_FULL from the bounded probe, for NEW keys only.
     {
-        const int rc = maintain(e, n, B.now_ms, takes_fast_path(e, n));
+        const int rc = maintain(e, n, B.now_ms, takes_fast_path(e, n), defer_hard);
         if (rc) return rc;
+        if (defer_hard && *defer_hard) return 0;             // (nothing has been done: the caller comes back)
     }
     note_enqueued(e, n);
     if (++e->epoch >= 0x7fffffffu) {   // 31-bit epoch wrapped: drop all dense-id claims
@@ -991,16 +993,6 @@ struct PendSet {
     }
     int flush_all() { int r = 0; for (auto& q : items) { const int rc = flush_pending(*q); if (!r) r = rc; } return r; }
 };
-// Would this batch's prelude (batch_prelude: maintain, epochs) enqueue or read anything?  Then the k_eval3 held back on the stream has
-// to go first.  The same arithmetic as maintain()'s early return, plus the epoch's wrap and a counter read-back waiting for a ride.
-static bool prelude_is_quiet(const guber_engine* e, uint64_t n) {
-    if (e->rb_ride >= 0 || e->epoch + 1 >= 0x7fffffffu) return false;
-    const uint64_t tag_limit = e->slots - e->slots / 8;
-    const uint64_t early = std::min<uint64_t>(16 * n, e->cache_size / 2);
-    return !(e->size_upper > e->cache_size) && !(e->tags_upper + n > tag_limit) &&
-           !(e->size_upper + n + early > e->cache_size || e->tags_upper + n + early > tag_limit);
-}
-
 static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
                         uint32_t* enqueued, PendSet* ps = nullptr) {
     auto views = [&](int i, BatchView& B, ResultView& R) {
@@ -1053,13 +1045,18 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     // the same order, and no prelude has anything to enqueue; otherwise it goes first, on its own
     const bool ep = ps && same_set && part;                       // (same_set, pend: decided before the locks were taken, below the g == 1 case)
     bool join = ep && pend && pend->valid;
-    for (int i = 0; i < g && join; ++i) join = prelude_is_quiet(grp[i], batches[gk[i]].n);
     if (pend && pend->valid && !join) { rc = flush_pending(*pend, true); if (rc) return rc; }   // (pend => the same engines: locked)
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);
         Work W; FastPlan P;
-        rc = batch_prelude(e, B, W);
+        bool defer = false;
+        rc = batch_prelude(e, B, W, join ? &defer : nullptr);
+        if (!rc && defer) {                                       // this prelude has something to enqueue or to read: the k_eval3 held back goes first
+            join = false;
+            rc = flush_pending(*pend, true);
+            if (!rc) rc = batch_prelude(e, B, W);
+        }
         if (!rc) rc = part ? plan_part(e, B, W, P) : plan_fast(e, B, false, W, P);
         if (rc) break;                                            // enqueue what is planned, then report
         tiles += P.ftiles;
@@ -1077,8 +1074,15 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
             // (a prelude that was not quiet after all — a counter read-back now rides on this k_part — or a group cut short by an
             // error: the k_eval3 held back goes first)
             bool joined = join && pend->valid && planned == g;
-            for (int i = 0; i < planned && joined; ++i) joined = MF.sub[i].W.snap_seq == 0 && MF.sub[i].T.buckets == pend->ME.sub[i].T.buckets;
+            for (int i = 0; i < planned && joined; ++i) joined = MF.sub[i].T.buckets == pend->ME.sub[i].T.buckets;
             if (pend && pend->valid && !joined) { const int rcf = flush_pending(*pend, true); if (rcf) return rcf; }
+            // a counter read-back riding on this k_part runs beside the held-back k_eval3: what it reads lies between the counters
+            // before and after that batch, so the host counts that batch's requests among "enqueued since" as well (rb_fold_slot)
+            for (int i = 0; i < planned && joined; ++i) {
+                if (!MF.sub[i].W.snap_seq) continue;
+                for (auto& slot : grp[i]->rb)
+                    if (slot.armed && slot.seq == MF.sub[i].W.snap_seq) slot.mark -= std::min<uint64_t>(slot.mark, pend->ME.sub[i].B.n);
+            }
             if (joined) {
                 // ONE launch: workgroups [0, pending tiles) are the held-back k_eval3, the rest this group's k_part
                 MultiEP EP{};
@@ -1086,6 +1090,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                 for (int i = 0; i < planned; ++i) {
                     EP.end_e[i] = pend->ME.end_tile[i]; EP.end_p[i] = MF.end_tile[i];
                     EP.sub[i].E = pend->ME.sub[i]; EP.sub[i].Bp = MF.sub[i].B; EP.sub[i].did_p = MF.sub[i].W.did; EP.sub[i].pmslot_p = MF.sub[i].W.pmslot;
+                    const Work& Wp = MF.sub[i].W;
+                    EP.sub[i].snap_seq = Wp.snap_seq; EP.sub[i].snap_n = Wp.snap_n; EP.sub[i].snap_c = Wp.snap_c; EP.sub[i].snap_b = Wp.snap_b; EP.sub[i].snap_stamp = Wp.snap_stamp;
                 }
                 pend->valid = false;
                 grp[0]->span_begin(KT_EVALPART_MULTI, pend->units);
@@ -2787,10 +2793,13 @@ static int evict_to_size(guber_engine* e, int64_t now_ms) {
 // The bounds are upper bounds (every request in flight might create an item).  Near a limit, counter snapshots are kept on their
 // way (one riding on every batch) and folded as they complete; the stream is drained only when an eviction / rebuild is really
 // due or a HARD limit (physical room) is at stake.
-static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows) {
+// defer_hard (GUBER_FUSE_EP, launch_group): the caller is holding a k_eval3 back on this stream — anything that would enqueue, synchronise
+// or read the counters must wait until that has been launched: *defer_hard = true and NOTHING is done; the caller launches it and calls again
+static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool batch_follows, bool* defer_hard) {
     const uint64_t tag_limit = e->slots - e->slots / 8;   // keep >= 1/8 of the entries free
     const uint64_t hard_size = e->cache_size + std::max<uint64_t>(e->cache_size / 2, 4ull * e->max_batch);
     if (e->rb_ride >= 0 && !batch_follows) {              // a snapshot that was to ride on a batch that never came: launch it now
+        if (defer_hard) { *defer_hard = true; return 0; }
         const uint32_t i = (uint32_t)e->rb_ride;
         e->rb_ride = -1;
         rb_launch(e, i);
@@ -2807,9 +2816,11 @@ static int maintain(guber_engine* e, uint64_t incoming, int64_t now_ms, bool bat
     const bool hard = (incoming == 0 && (over || tags)) || e->size_upper > hard_size || tags || sure_over;
     if (!hard) {
         if (batch_follows) (void)rb_arm(e, true);            // no launch of its own: the batch's first kernel carries it
+        else if (defer_hard) { *defer_hard = true; return 0; }
         else if (!rb_any_armed(e)) { (void)rb_arm(e, false); HIPCHK(hipGetLastError()); }
         return 0;
     }
+    if (defer_hard) { *defer_hard = true; return 0; }
     int rc = engine_refresh_counters(e);
     if (rc) return rc;
     if ((uint64_t)std::max<long long>(e->last_ctr.size, 0) > e->cache_size) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void gs_copy_words(uint8_t* dst, const uint8_t* src, 
 __global__ __launch_bounds__(256) void k_gs_take(Table T, uint32_t role_mask, uint32_t* keep_list, GsCounters* C, uint8_t* rows, uint32_t stride,
                                                  uint32_t cap, uint32_t* owner, const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
                                                  int ring_kind, uint32_t world) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GUBER_DYN_LDS(smem);
     uint64_t* lh = (uint64_t*)smem;
     for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
     __syncthreads();

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_clear_claims(Table T, uint64_t slots) {
 __global__ __launch_bounds__(256) void k_route(const uint8_t* key_bytes, const uint32_t* key_off, uint32_t n,
                                                const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
                                                int kind, uint32_t* owner) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GUBER_DYN_LDS(smem);
     uint64_t* lh = (uint64_t*)smem;
     for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
     __syncthreads();
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void k_route(const uint8_t* key_bytes, const u
 __global__ __launch_bounds__(256) void k_route_rows(const uint8_t* key_rows, uint32_t stride, const uint32_t* key_len, uint32_t n,
                                                     const uint64_t* ring_hash, const uint32_t* ring_owner, uint32_t npts,
                                                     int kind, uint32_t* owner) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GUBER_DYN_LDS(smem);
     uint64_t* lh = (uint64_t*)smem;
     for (uint32_t j = threadIdx.x; j < npts; j += 256) lh[j] = ring_hash[j];
     __syncthreads();

@@ -1101,10 +1101,14 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s_multi(MultiEv
 // launches' chains: DESIGN.md section 4).  What the two halves must not share, they do not: the packed words (Work::did) are
 // double-buffered by batch parity, the owner count of a batch comes from its parity's slot (pm_bits_of), messages / {start, count}
 // are dead once k_own(b) has run, k_eval3 reads records, k_part writes messages.  The engine only fuses what maintenance leaves
-// alone: same tables in the same order, no counter read-back riding on the k_part half (guber_engine.hip launch_group).
+// alone: same tables in the same order, nothing to enqueue or to read first (guber_engine.hip launch_group).  A counter read-back
+// riding on the k_part half reads counters that k_eval3's tiles are adding to: the host counts that batch as still to come.
 // Workgroups [0, end_e[nb - 1]) are k_eval3's tiles, the rest k_part's.
 constexpr int EP_MAX = MULTI_MAX < 4 ? MULTI_MAX : 4;     // (four tables' arguments fit the 4 KB kernel-argument segment)
-struct EPSub { EvalArgs E; BatchView Bp; uint32_t* did_p; uint32_t pmslot_p; uint32_t pad_; };
+struct EPSub {
+    EvalArgs E; BatchView Bp; uint32_t* did_p; uint32_t pmslot_p;
+    uint32_t snap_seq, snap_n, pad_; DevCounters* snap_c; BlockCounters* snap_b; uint32_t* snap_stamp;     // a counter read-back riding on the k_part half (Work::snap_*)
+};
 struct MultiEP { uint32_t nb; uint32_t end_e[EP_MAX]; uint32_t end_p[EP_MAX]; EPSub sub[EP_MAX]; };
 static_assert(sizeof(MultiEP) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_evalpart_multi(MultiEP A) {
@@ -1121,7 +1125,8 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_evalpart_multi(Multi
     const EPSub* a = (const EPSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEP, sub)) + sb;
     if (!part) { eval3_body<0>(a->E, wg - first); return; }
     Work W = a->E.W;                                       // the next batch's work arrays are this engine's, but for:
-    W.did = a->did_p; W.pmslot = a->pmslot_p; W.snap_seq = 0u;
+    W.did = a->did_p; W.pmslot = a->pmslot_p;
+    W.snap_seq = a->snap_seq; W.snap_n = a->snap_n; W.snap_c = a->snap_c; W.snap_b = a->snap_b; W.snap_stamp = a->snap_stamp;
     part_body(a->E.T, a->Bp, W, wg - first);
 }
 

@@ -118,6 +118,11 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMPW(k) do {} while (0)
 #endif
 struct GMsg; struct GRec; struct GShape; struct GRecS;
+// the launch's dynamic LDS as a byte array (a macro so that the host emulation of the kernel source, tests/hostsim/fakehip, can give it storage)
+#ifndef GUBER_DYN_LDS
+#define GUBER_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+
 struct Work {
     // Store side channel (guber_eval_batch_store): per request, which Store callbacks the reference would issue
     // (EV_ONCHANGE | EV_REMOVE >> 3) and the bucket right after the request.  null = not requested.

@@ -1,0 +1,150 @@
+"""Cases of tests/test_enginesim_cpu.py, run in a process of their own with GUBER_HIP_LIB pointing at tests/hostsim/libenginesim.so —
+the engine's HOST code and kernels compiled for the CPU (tests/hostsim/enginesim.cpp: test infrastructure, not a fallback; the
+product library is hipcc's and needs a device).  "Device" pointers are numpy buffers here.
+    GUBER_HIP_LIB=tests/hostsim/libenginesim.so python tests/enginesim_cases.py <case>"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+import gubernator_amd as ga
+import streams
+import support
+
+assert "enginesim" in ga.LIB_PATH, "these cases are for the CPU build of the engine (GUBER_HIP_LIB)"
+
+
+def dev_batch(hb):
+    """a HostBatch's columns as the "device" arrays of a guber_batch_t + result arrays; returns (batch, result, keep-alive, result dict)"""
+    n = hb.n
+    cols = [np.ascontiguousarray(hb.key_bytes), np.ascontiguousarray(hb.key_off.view(np.int32)), np.ascontiguousarray(hb.hits), np.ascontiguousarray(hb.limit),
+            np.ascontiguousarray(hb.duration), np.ascontiguousarray(hb.algorithm), np.ascontiguousarray(hb.behavior.view(np.int32))]
+    p = [c.ctypes.data for c in cols]
+    r = dict(status=np.empty(n, np.uint8), err=np.empty(n, np.uint8), limit=np.empty(n, np.int64), remaining=np.empty(n, np.int64), reset_time=np.empty(n, np.int64))
+    b = ga.GuberBatch(n, 0, p[0], p[1], p[2], p[3], p[4], None, None, p[5], p[6], None, None, None, hb.now_ms)
+    res = ga.GuberResult(r["status"].ctypes.data, r["limit"].ctypes.data, r["remaining"].ctypes.data, r["reset_time"].ctypes.data, r["err"].ctypes.data, 0, 0, 0, 0, 0)
+    return b, res, cols, r
+
+
+def routed(n_engines, fuse_ep):
+    """guber_eval_batches_routed_dev over n_engines tables on ONE stream, 8 rounds in one call: Zipf batches with hot keys, both
+    algorithms, the clock stepping; a batch too small for the owner-partitioned pipeline in one round, a round without one table,
+    uniform keys in two rounds (owners split, the owner count moves).  Every batch equals its table's oracle, sizes and counters too.
+    With GUBER_FUSE_EP=1: k_evalpart_multi carried most passes; without: it never ran."""
+    K, B, rounds = 3000, 2048, 8
+    tab = streams.key_table(K * n_engines)
+    e0 = ga.Engine(cache_size=1 << 16, max_batch=4 * B)
+    engs = [e0] + [ga.Engine(cache_size=1 << 16, max_batch=4 * B, stream=e0.stream_handle()) for _ in range(n_engines - 1)]
+    orcs = [support.Oracle(cache_size=1 << 16) for _ in range(n_engines)]
+    zs = [streams.ZipfSampler(K, seed=300 + j) for j in range(n_engines)]
+    rng = np.random.default_rng(5)
+    for e in engs:
+        e.profile(True)
+    which, hbs, keep, cb, cr = [], [], [], [], []
+    for r in range(rounds):
+        for j in range(n_engines):
+            if r == 4 and j == 2:
+                continue
+            n = 300 if (r == 2 and j == 1) else [B, B, 1500, B, 2 * B][(r + j) % 5]
+            ids = rng.integers(0, K, n) if r in (5, 6) else zs[j].draw(n)
+            hb = streams.bench_batch(tab, j * K + ids, streams.NOW0 + r * 900, algorithm=(r + j) % 2, limit=30, duration=4000)
+            b, res, cols, rd = dev_batch(hb)
+            keep.append((cols, rd)); which.append(j); hbs.append(hb); cb.append(b); cr.append(res)
+    N = len(which)
+    ga.Engine.eval_routed_dev(engs, (C.c_uint32 * N)(*which), (ga.GuberBatch * N)(*cb), (ga.GuberResult * N)(*cr), N)
+    sums = [[0, 0, 0] for _ in range(n_engines)]
+    for s in range(N):
+        want = orcs[which[s]].eval(hbs[s])
+        got = ga.HostResult(hbs[s].n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = keep[s][1][name]
+        support.assert_results_equal(got, want, f"batch {s} of table {which[s]}")
+        for q in range(3):
+            sums[which[s]][q] += want.counters()[q]
+    launches = {}
+    for e in engs:
+        for k, v in e.profile_read().items():
+            launches[k] = launches.get(k, 0) + v[0]
+    print("launches", {k: v for k, v in launches.items() if v})
+    groups = (n_engines + 3) // 4
+    if fuse_ep:
+        assert launches.get("k_evalpart_multi", 0) >= (rounds - 4) * groups, launches
+        # every pass has ONE k_own_multi; its k_eval3 went with the next pass's k_part or, held back to the end / flushed, on its own
+        assert launches["k_own_multi"] == launches["k_evalpart_multi"] + launches["k_eval3_multi"], launches
+        assert launches["k_own_multi"] == launches["k_evalpart_multi"] + launches["k_part_multi"], launches
+    else:
+        assert launches.get("k_evalpart_multi", 0) == 0 and launches["k_part_multi"] == launches["k_own_multi"] == launches["k_eval3_multi"], launches
+    for j, (e, o) in enumerate(zip(engs, orcs)):
+        assert e.size() == o.size(), (j, e.size(), o.size())
+        assert list(e.counters()[:3]) == sums[j], (j, e.counters(), sums[j])
+        e.close()
+
+
+def routed_lru(fuse_ep):
+    """four tables whose caches come to BIND (6 000 items each, 7 000 keys in play, uniform draws: after a few rounds): batches that may overflow the cache leave the fused
+    groups and go through the eviction pre-pass on their own, the others share launches (and, with GUBER_FUSE_EP, hold their k_eval3
+    back) — every answer equals the bounded-LRU oracle's, evictions included"""
+    n_engines, K, rounds = 4, 7000, 8
+    tab = streams.key_table(K * n_engines)
+    e0 = ga.Engine(cache_size=6000, max_batch=4096)
+    engs = [e0] + [ga.Engine(cache_size=6000, max_batch=4096, stream=e0.stream_handle()) for _ in range(n_engines - 1)]
+    orcs = [support.Oracle(cache_size=6000) for _ in range(n_engines)]
+    rng = np.random.default_rng(9)
+    zs = [streams.ZipfSampler(K, seed=500 + j) for j in range(n_engines)]
+    for e in engs:
+        e.profile(True)
+    which, hbs, keep, cb, cr = [], [], [], [], []
+    for r in range(rounds):
+        for j in range(n_engines):
+            hb = streams.bench_batch(tab, j * K + (rng.integers(0, K, [1500, 2048, 1100][(r + j) % 3]) if r % 3 else zs[j].draw(1500)), streams.NOW0 + r * 50, algorithm=(r + j) % 2, limit=30, duration=60_000)
+            b, res, cols, rd = dev_batch(hb)
+            keep.append((cols, rd)); which.append(j); hbs.append(hb); cb.append(b); cr.append(res)
+    N = len(which)
+    ga.Engine.eval_routed_dev(engs, (C.c_uint32 * N)(*which), (ga.GuberBatch * N)(*cb), (ga.GuberResult * N)(*cr), N)
+    for s in range(N):
+        want = orcs[which[s]].eval(hbs[s])
+        got = ga.HostResult(hbs[s].n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = keep[s][1][name]
+        support.assert_results_equal(got, want, f"batch {s} of table {which[s]}")
+    launches = {}
+    for e in engs:
+        for k, v in e.profile_read().items():
+            launches[k] = launches.get(k, 0) + v[0]
+    print("launches", {k: v for k, v in launches.items() if v})
+    evicted = 0
+    for j, (e, o) in enumerate(zip(engs, orcs)):
+        assert e.size() == o.size() <= 6000, (j, e.size(), o.size())
+        evicted += e.stats()["unexpired_evictions"] if "unexpired_evictions" in e.stats() else 0
+        e.close()
+    assert launches.get("k_own_multi", 0) > 0, launches               # some groups did share launches
+    if fuse_ep:
+        assert launches.get("k_evalpart_multi", 0) > 0, launches
+
+
+def single(flags):
+    """adversarial batches through guber_eval_batch (host pointers: stage, copies, kernels, copies back) on one engine"""
+    eng, orc = ga.Engine(cache_size=4096, max_batch=4096, flags=flags), support.Oracle(cache_size=1 << 20)
+    for k, b in enumerate(streams.adversarial_batches(21, 8, 1500, greg_fn=support.gregorian)):
+        want, got = orc.eval(b), eng.eval(b)
+        support.assert_results_equal(got, want, f"batch {k}")
+        assert got.counters() == want.counters(), k
+    assert eng.size() == orc.size()
+    eng.close()
+
+
+CASES = {
+    "routed4": lambda: routed(4, os.environ.get("GUBER_FUSE_EP") == "1"),
+    "routed6": lambda: routed(6, os.environ.get("GUBER_FUSE_EP") == "1"),
+    "routed_lru": lambda: routed_lru(os.environ.get("GUBER_FUSE_EP") == "1"),
+    "single_default": lambda: single(0),
+    "single_part": lambda: single(ga.FLAG_TEST_FORCE_PART),
+}
+
+if __name__ == "__main__":
+    CASES[sys.argv[1]]()
+    print("ENGINESIM CASE OK", sys.argv[1])

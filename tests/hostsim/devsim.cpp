@@ -13,106 +13,7 @@
 #include "../../gubernator_amd/csrc/guber_kernels_lru.h"
 #include "../../include/guber_gpu.h"
 
-// ---- the fiber runtime behind fakehip ------------------------------------------------------------------------------------
-namespace fakehip {
-State S;
-static std::function<void()> g_body;
-static constexpr size_t kStack = 256 * 1024;
-static int g_readers[16][2];
-
-static int live_count() { int n = 0; for (auto& f : S.fib) n += f.done ? 0 : 1; return n; }
-static int live_in_wave(int w) {
-    int n = 0;
-    for (int l = 0; l < kWave; ++l) { const size_t i = (size_t)w * kWave + l; if (i < S.fib.size() && !S.fib[i].done) n++; }
-    return n;
-}
-void yield() { Fiber& f = S.fib[S.cur]; swapcontext(&f.ctx, &S.sched); }
-void barrier() {
-    const unsigned long long gen = S.bar_gen;
-    S.bar_waiting++;
-    for (;;) {
-        if (S.bar_gen != gen) break;
-        if (S.bar_waiting == live_count()) { S.bar_waiting = 0; S.bar_gen++; break; }
-        S.fib[S.cur].waiting = 1;
-        yield();
-    }
-    S.fib[S.cur].waiting = 0;
-    S.progress++;
-}
-unsigned long long wave_exchange(unsigned long long v, int, unsigned long long* all, unsigned long long* live_mask) {
-    const int tid = S.cur, w = tid / kWave, lane = tid % kWave;
-    const int buf = (int)(S.lane_gen[tid]++ & 1);
-    S.wx[w][buf][lane] = v;
-    S.warrived[w][buf]++;
-    while (S.warrived[w][buf] < live_in_wave(w)) { S.fib[tid].waiting = 2; yield(); }
-    S.fib[tid].waiting = 0;
-    S.progress++;
-    unsigned long long lm = 0;
-    for (int l = 0; l < kWave; ++l) {
-        const size_t i = (size_t)w * kWave + l;
-        if (i < S.fib.size() && !S.fib[i].done) lm |= 1ull << l;
-        if (all) all[l] = S.wx[w][buf][l];
-    }
-    if (live_mask) *live_mask = lm;
-    // the last reader re-arms the buffer (everybody has arrived, so nobody can be two operations ahead)
-    if (++g_readers[w][buf] == live_in_wave(w)) { g_readers[w][buf] = 0; S.warrived[w][buf] = 0; }
-    return 0;
-}
-static void trampoline() {
-    g_body();
-    S.fib[S.cur].done = true;
-    S.progress++;
-    swapcontext(&S.fib[S.cur].ctx, &S.sched);
-}
-static std::vector<char*> g_stacks;
-template <class F> void launch(dim3 grid, dim3 block, const void* kernarg, F body) {
-    g_body = body;
-    S.gdim = grid; S.bdim = block; S.kernarg = kernarg;
-    while (g_stacks.size() < block.x) g_stacks.push_back((char*)malloc(kStack));
-    std::vector<uint32_t> order(grid.x);
-    for (uint32_t b = 0; b < grid.x; ++b) order[b] = S.block_order == 1 ? grid.x - 1 - b : b;
-    if (S.block_order == 2)
-        for (uint32_t b = grid.x; b > 1; --b) {
-            S.rng ^= S.rng << 13; S.rng ^= S.rng >> 7; S.rng ^= S.rng << 17;
-            std::swap(order[b - 1], order[S.rng % b]);
-        }
-    for (uint32_t bi = 0; bi < grid.x; ++bi) {
-        const uint32_t b = order[bi];
-        S.bidx = dim3(b);
-        S.fib.assign(block.x, Fiber{});
-        S.bar_waiting = 0;
-        memset(S.warrived, 0, sizeof(S.warrived)); memset(S.lane_gen, 0, sizeof(S.lane_gen)); memset(g_readers, 0, sizeof(g_readers));
-        for (uint32_t t = 0; t < block.x; ++t) {
-            Fiber& f = S.fib[t];
-            getcontext(&f.ctx);
-            f.ctx.uc_stack.ss_sp = g_stacks[t]; f.ctx.uc_stack.ss_size = kStack; f.ctx.uc_link = &S.sched;
-            f.done = false; f.waiting = 0;
-            makecontext(&f.ctx, (void (*)())trampoline, 0);
-        }
-        // run-to-yield, round robin (S.chaos reverses the order of every other pass and yields inside atomics)
-        unsigned pass = 0;
-        for (;;) {
-            const unsigned long long before = S.progress;
-            bool any = false;
-            for (uint32_t k = 0; k < block.x; ++k) {
-                const uint32_t t = (S.chaos && (pass & 1)) ? block.x - 1 - k : k;
-                if (S.fib[t].done) continue;
-                any = true;
-                S.cur = (int)t; S.tidx = dim3(t);
-                swapcontext(&S.sched, &S.fib[t].ctx);
-            }
-            if (!any) break;
-            if (S.progress == before) {
-                fprintf(stderr, "[devsim] deadlock in workgroup %u: ", b);
-                for (uint32_t t = 0; t < block.x; ++t) if (!S.fib[t].done) fprintf(stderr, "%u:%d ", t, S.fib[t].waiting);
-                fprintf(stderr, "\n");
-                abort();
-            }
-            pass++;
-        }
-    }
-}
-}  // namespace fakehip
+#include "fakehip/fiber_runtime.h"   // the fiber runtime behind fakehip (definitions)
 
 using namespace guber;
 

@@ -19,6 +19,9 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+// a launch's dynamic LDS (gubernator_amd/csrc/guber_table.h GUBER_DYN_LDS): one workgroup runs at a time, so one static buffer serves
+namespace fakehip { inline unsigned char* dyn_lds() { alignas(16) static unsigned char buf[160 * 1024]; return buf; } }
+#define GUBER_DYN_LDS(name) unsigned char* const name = fakehip::dyn_lds()
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
@@ -31,7 +34,11 @@ struct dim3 { uint32_t x, y, z; dim3(uint32_t a = 1, uint32_t b = 1, uint32_t c 
 
 namespace fakehip {
 constexpr int kWave = 64;
+#if defined(__x86_64__)
+struct Fiber { void* sp; bool done; int waiting; /* 0 run, 1 barrier, 2 wave op */ };       // (fiber_runtime.h: fh_switch)
+#else
 struct Fiber { ucontext_t ctx; char* stack; bool done; int waiting; /* 0 run, 1 barrier, 2 wave op */ };
+#endif
 struct State {
     dim3 tidx, bidx, bdim, gdim;
     std::vector<Fiber> fib; int cur = -1; ucontext_t sched;
@@ -118,3 +125,7 @@ static inline unsigned long long __ballot(int pred) {
     unsigned long long m = 0; for (int i = 0; i < 64; ++i) if (((live >> i) & 1) && all[i]) m |= 1ull << i;
     return m;
 }
+
+#ifdef FAKEHIP_RUNTIME   // the runtime API as well (streams, events, memory, launches): the engine's host code on the CPU
+#include "hip_runtime_api_fake.h"
+#endif

@@ -1,0 +1,52 @@
+"""The ENGINE on a machine without a GPU: gubernator_amd/csrc/guber_engine.hip — host code and kernels — compiled for the host against
+tests/hostsim/fakehip (the kernel language as cooperative fibers, the HIP runtime API as a stand-in whose launches run at once:
+tests/hostsim/enginesim.cpp), driven through the C ABI exactly as the GPU suite drives the product library, against the oracle.
+What this covers that tests/test_kernels_devsim.py cannot: the engine's HOST logic — launch groups of several tables, preludes and
+maintenance, the eviction pre-pass around fused groups, and GUBER_FUSE_EP's held-back k_eval3 (launch_group / PendSet), which no GPU
+has run yet.  Test infrastructure only: the cases run in processes of their own with GUBER_HIP_LIB pointing at the test library; the
+product library is hipcc's, needs a device and has no CPU path (test_abi_cpu.py checks that it fails loudly without one)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from support import ROOT
+
+HS = os.path.join(ROOT, "tests", "hostsim")
+LIB = os.path.join(HS, "libenginesim.so")
+
+
+@pytest.fixture(scope="module")
+def enginesim():
+    subprocess.run(["make", "-s", "-C", HS, "enginesim_lib"], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    return LIB
+
+
+def run_case(lib, case, **env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "enginesim_cases.py"), case], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GUBER_HIP_LIB=lib, **env))
+    assert p.returncode == 0 and f"ENGINESIM CASE OK {case}" in p.stdout, (p.stdout + p.stderr)[-3000:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("case", ["single_default", "single_part"])
+def test_one_engine_through_the_host_pointer_entry(enginesim, case):
+    """guber_eval_batch: stage, copies, the pipeline's launches, copies back — adversarial batches, counters"""
+    run_case(enginesim, case)
+
+
+@pytest.mark.parametrize("case,fuse_ep", [("routed4", "0"), ("routed4", "1"), ("routed6", "1")], ids=["4_tables-three_launches", "4_tables-fuse_ep", "6_tables-fuse_ep"])
+def test_routed_batches_of_several_tables(enginesim, case, fuse_ep):
+    """guber_eval_batches_routed_dev on four tables (one group per round) and six (two groups per round) of one stream: the default three
+    launches per pass, and GUBER_FUSE_EP=1 — k_eval3 held back and launched with the same tables' next k_part (k_evalpart_multi), on
+    its own when a group changes, takes the other pipeline, or the call ends; the launch counts say which path ran"""
+    out = run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
+    assert ("k_evalpart_multi" in out) == (fuse_ep == "1"), out[-500:]
+
+
+@pytest.mark.parametrize("fuse_ep", ["0", "1"], ids=["three_launches", "fuse_ep"])
+def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
+    """batches that may overflow their table's cache leave the groups for the eviction pre-pass; answers equal the bounded-LRU oracle's"""
+    run_case(enginesim, "routed_lru", GUBER_FUSE_EP=fuse_ep)
