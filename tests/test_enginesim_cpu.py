@@ -4,7 +4,7 @@ tests/hostsim/enginesim.cpp), driven through the C ABI exactly as the GPU suite 
 What this covers that tests/test_kernels_devsim.py cannot: the engine's HOST logic — launch groups of several tables, preludes and
 maintenance, the eviction pre-pass around fused groups, and GUBER_FUSE_EP's held-back k_eval3 (launch_group / PendSet), which no GPU
 has run yet.  Test infrastructure only: the cases run in processes of their own with GUBER_HIP_LIB pointing at the test library; the
-product library is hipcc's, needs a device and has no CPU path (test_abi_cpu.py checks that it fails loudly without one)."""
+product library is hipcc's, needs a device and has no CPU path (test_abi_cpu.py checks that it fails loudly without one).  The test library runs under AddressSanitizer."""
 import os
 import subprocess
 import sys
@@ -14,19 +14,26 @@ import pytest
 from support import ROOT
 
 HS = os.path.join(ROOT, "tests", "hostsim")
-LIB = os.path.join(HS, "libenginesim.so")
+LIB = os.path.join(HS, "libenginesim_san.so")
 
 
 @pytest.fixture(scope="module")
 def enginesim():
-    subprocess.run(["make", "-s", "-C", HS, "enginesim_lib"], check=True)
+    """the library under AddressSanitizer (make enginesim_lib builds it without, for a debugger): every "device" buffer is a host
+    allocation here, so a KERNEL that reads or writes outside a table, a work array or a caller's column is reported, like the host code"""
+    subprocess.run(["make", "-s", "-C", HS, "enginesim_san_lib"], check=True)
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
     return LIB
 
 
+def _runtime(name):
+    return subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True, check=True).stdout.strip()
+
+
 def run_case(lib, case, **env):
+    san = dict(LD_PRELOAD=_runtime("libasan.so"), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "enginesim_cases.py"), case], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, GUBER_HIP_LIB=lib, **env))
+                       env=dict(os.environ, GUBER_HIP_LIB=lib, **san, **env))
     assert p.returncode == 0 and f"ENGINESIM CASE OK {case}" in p.stdout, (p.stdout + p.stderr)[-3000:]
     return p.stdout
 
@@ -50,3 +57,4 @@ def test_routed_batches_of_several_tables(enginesim, case, fuse_ep):
 def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
     """batches that may overflow their table's cache leave the groups for the eviction pre-pass; answers equal the bounded-LRU oracle's"""
     run_case(enginesim, "routed_lru", GUBER_FUSE_EP=fuse_ep)
+

@@ -29,11 +29,11 @@ ENVS = {"eager": {},                                                          # 
         "device_routes": {"GUBER_POOL_DEVROUTE": "1"}}                         # one front stage, the DEVICE hashes / looks up / ranks (guber_stage_route; default: the callers do)
 
 
-@pytest.mark.parametrize("tag,flags,scale,env,repeats", [("plain", [], 1, "eager", 5), ("plain", [], 2, "limit_or_wait", 2), ("plain", [], 2, "idle_flush", 2),
+@pytest.mark.parametrize("tag,flags,scale,env,repeats", [("plain", [], 1, "eager", 3), ("plain", [], 2, "limit_or_wait", 2), ("plain", [], 2, "idle_flush", 2),
                                                          ("plain", [], 2, "few_active", 2), ("plain", [], 2, "direct", 3), ("plain", [], 2, "per_shard_stages", 2), ("plain", [], 2, "device_routes", 2),
-                                                         ("tsan", ["-fsanitize=thread"], 4, "direct", 1), ("tsan", ["-fsanitize=thread"], 4, "per_shard_stages", 1), ("tsan", ["-fsanitize=thread"], 2, "device_routes", 1),
-                                                         ("tsan", ["-fsanitize=thread"], 2, "eager", 1), ("tsan", ["-fsanitize=thread"], 4, "idle_flush", 1),
-                                                         ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 2, "eager", 1)])
+                                                         ("tsan", ["-fsanitize=thread"], 4, "direct", 1), ("tsan", ["-fsanitize=thread"], 4, "per_shard_stages", 1), ("tsan", ["-fsanitize=thread"], 3, "device_routes", 1),
+                                                         ("tsan", ["-fsanitize=thread"], 3, "eager", 1), ("tsan", ["-fsanitize=thread"], 4, "idle_flush", 1),
+                                                         ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], 3, "eager", 1)])
 def test_pool_host_logic(tag, flags, scale, env, repeats):
     exe = build(tag, flags)
     for _ in range(repeats):                                         # (races show up in some runs only)
