@@ -58,3 +58,16 @@ def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
     """batches that may overflow their table's cache leave the groups for the eviction pre-pass; answers equal the bounded-LRU oracle's"""
     run_case(enginesim, "routed_lru", GUBER_FUSE_EP=fuse_ep)
 
+
+
+def test_the_gpu_suites_host_layer_and_wire_files_against_the_cpu_engine(enginesim):
+    """tests/test_gpu_host_layer.py and tests/test_gpu_wire_dev.py — the `-m gpu` tests of the pool on real engines (stages, routed stages,
+    placement passes moving buckets, Store / Loader, GLOBAL engines, zones), of the wire front end and of the device wire decoder — run
+    unchanged in a process of their own against the CPU build of the engine, under AddressSanitizer.  (The plain-C replica of the Go
+    binding links the product library itself and stays a GPU test.)"""
+    san = dict(LD_PRELOAD=_runtime("libasan.so"), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_layer.py"), os.path.join(ROOT, "tests", "test_gpu_wire_dev.py"),
+                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not plain_c"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                       env=dict(os.environ, GUBER_HIP_LIB=enginesim, **san))
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, tail
