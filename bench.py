@@ -863,6 +863,8 @@ def main():
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
                     "resident_items_by_rank": resident_by_rank, "ranks_seen_by_the_collective_backend": ranks_seen, "backend": args.backend if world > 1 else None,
                     "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
+                    # engine options taken from the environment (experiments; all unset in the driver's run)
+                    "engine_env": {k: os.environ[k] for k in ("GUBER_FUSE_EP", "GUBER_PIPELINE", "GUBER_PT_BITS", "GUBER_EVAL3_SPLIT", "GUBER_HIP_LIB") if k in os.environ},
                     "stream": {"replayed": False, "distinct_batches_total": len(rig.seq), "timed_batches": steps,
                                "distinct_keys_touched": touched, "table_bytes_touched": touched * 144, "table_bytes_touched_in_64B_sectors": touched * 192,
                                "now_ms": "advances 1 ms per batch",

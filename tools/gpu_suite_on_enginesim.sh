@@ -13,4 +13,6 @@ else
   make -s -C $R/tests/hostsim enginesim_lib || exit 1
   export GUBER_HIP_LIB=$R/tests/hostsim/libenginesim.so
 fi
-cd $R && exec python -m pytest ${@:-tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_wire_dev.py} -m gpu -q -p no:cacheprovider --timeout 300
+cd $R
+if [ $# -eq 0 ]; then set -- tests/test_gpu_parity.py tests/test_gpu_host_layer.py tests/test_gpu_wire_dev.py; fi
+exec python -m pytest "$@" -m gpu -q -p no:cacheprovider --timeout 300
