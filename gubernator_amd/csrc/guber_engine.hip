@@ -88,6 +88,8 @@ struct CohBuf {
 
 }  // namespace
 
+struct guber_engine;
+static void ep_flush_held(const guber_engine* e);
 struct guber_engine {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
@@ -188,7 +190,11 @@ struct guber_engine {
     void span_begin(int k, uint64_t units = 0) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); prof_units[k] += units; } }
     void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, stream); }
 
-    int set_device() const { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+    // GUBER_FUSE_EP: the k_eval3 a routed call is holding back for a group this engine belongs to (guarded by mu).  Whoever is about to
+    // enqueue on this engine, or to read what that launch writes, launches it first — every entry point comes through set_device()
+    // after taking the lock; entry points that lock several engines call ep_flush_held on each (guber_engine.hip "held back")
+    mutable struct PendingEval* held = nullptr;
+    int set_device() const { if (held) ep_flush_held(this); return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 };
 
 enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI,
@@ -351,8 +357,8 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     if (const char* v = getenv("GUBER_EVAL3_SPLIT")) e->eval3_split = atoi(v) != 0;
     // GUBER_FUSE_EP=1: inside one guber_eval_batches_routed_dev call, a group's k_eval3 shares a launch with the k_part of the same
     // tables' next batches (k_evalpart_multi, guber_kernels_part.h: two launches per pass instead of three) — built and checked
-    // through the kernel source on the CPU, off until it has been measured on the GPU.  While such a call runs its engines belong
-    // to it: another thread's call on one of them could be enqueued between a k_own and the k_eval3 that is still held back.
+    // through the kernel source and the engine's host code on the CPU, off until it has been measured on the GPU.  Another thread's
+    // call on one of the group's engines launches the held-back k_eval3 first (guber_engine::held).
     if (const char* v = getenv("GUBER_FUSE_EP")) e->fuse_ep = atoi(v) != 0 && !e->eval3_split;
     if (e->force_part) e->part_min = 1;
     rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure((size_t)e->cap256 + e->cap256 / 2); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);   // (grec: 32-byte records first, then the 64-byte form)
@@ -954,37 +960,63 @@ static bool can_fuse(guber_engine* e, uint32_t n) { return fits_fused(e, n) && !
 // it shares that group's first launch: k_evalpart_multi) or until anything else is about to be enqueued on its stream / the call ends
 // (then it goes on its own).  Lives inside ONE guber_eval_batches_routed_dev call, one per stream the call uses.
 struct PendingEval {
-    bool valid = false; int n = 0; uint32_t tiles = 0; uint64_t units = 0;
+    std::mutex pm;                                                 // two threads that each hold ONE of the group's engines may both come to launch it
+    std::atomic<bool> valid{false};                                // (written under pm; the dispatcher also looks before it has taken the engines' locks, and again after)
+    int n = 0; uint32_t tiles = 0; uint64_t units = 0;
     guber_engine* eng[MULTI_MAX]; MultiEval ME;
 };
-static int flush_pending(PendingEval& p, bool engines_locked = false) {
+static thread_local int tl_ep_dispatcher = 0;                      // this thread is inside a routed call that holds evaluations back: it launches them itself
+// launch it (if it has not been launched).  The caller holds the mutex of at least one of its engines: nothing can be enqueued on
+// any of them by the dispatcher meanwhile (it takes them all), and the launch lands on their stream before whatever the caller enqueues next.
+static int launch_held(PendingEval& p, bool spans) {
+    std::lock_guard<std::mutex> lk(p.pm);
     if (!p.valid) return 0;
     p.valid = false;
+    guber_engine* e0 = p.eng[0];
+    if (hipSetDevice(e0->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (spans) e0->span_begin(KT_EVAL3_MULTI, p.units);            // (per-kernel timing belongs to the group's first engine: only under its mutex)
+    hipLaunchKernelGGL(k_eval3_multi, dim3(p.tiles), dim3(256), 0, e0->stream, p.ME);
+    if (spans) e0->span_end();
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    return 0;
+}
+// an entry point other than the dispatcher that holds it back, with e's mutex held
+static void ep_flush_held(const guber_engine* e) {
+    if (!e->held || tl_ep_dispatcher) return;
+    (void)launch_held(*e->held, false);
+    e->held = nullptr;
+}
+// the dispatcher's own: with all of its engines locked (engines_locked) or locking them here
+static int flush_pending(PendingEval& p, bool engines_locked = false) {
     guber_engine* order[MULTI_MAX];
     for (int i = 0; i < p.n; ++i) order[i] = p.eng[i];
     std::sort(order, order + p.n);
     if (!engines_locked) for (int i = 0; i < p.n; ++i) order[i]->mu.lock();
     struct Unlock { guber_engine** o; int g; ~Unlock() { for (int i = g - 1; i >= 0; --i) o[i]->mu.unlock(); } } unlock{order, engines_locked ? 0 : p.n};
-    guber_engine* e0 = p.eng[0];
-    if (e0->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    e0->span_begin(KT_EVAL3_MULTI, p.units);
-    hipLaunchKernelGGL(k_eval3_multi, dim3(p.tiles), dim3(256), 0, e0->stream, p.ME);
-    e0->span_end();
-    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
-    return 0;
+    const int rc = launch_held(p, true);
+    for (int i = 0; i < p.n; ++i) if (p.eng[i]->held == &p) p.eng[i]->held = nullptr;
+    return rc;
 }
 // every k_eval3 a call is holding back: at most one per set of engines (sets are disjoint: one that overlaps a new group without
 // being it is launched before the group is)
 struct PendSet {
     std::vector<std::unique_ptr<PendingEval>> items;
-    PendingEval* free_slot() {
-        for (auto& q : items) if (!q->valid) return q.get();
+    // (a slot only ever serves ONE set of tables: an engine's `held` may outlive a foreign launch and must not come to mean another group)
+    PendingEval* slot_for(guber_engine* const* grp, int g) {
+        for (auto& q : items) {
+            if (q->valid || q->n != g) continue;
+            bool same = true;
+            for (int i = 0; i < g && same; ++i) same = q->eng[i] == grp[i];
+            if (same) return q.get();
+        }
         items.emplace_back(new PendingEval());
+        items.back()->n = g;
+        for (int i = 0; i < g; ++i) items.back()->eng[i] = grp[i];
         return items.back().get();
     }
     int flush_touching(guber_engine* const* grp, int g, const PendingEval* keep = nullptr) {
         for (auto& q : items) {
-            if (!q->valid || q.get() == keep) continue;
+            if (q.get() == keep) continue;                          // (also the ones a foreign thread launched: their engines' `held` is cleared here)
             bool overlap = false;
             for (int i = 0; i < q->n && !overlap; ++i) for (int j = 0; j < g && !overlap; ++j) overlap = q->eng[i] == grp[j];
             if (overlap) { const int rc = flush_pending(*q); if (rc) return rc; }
@@ -1006,6 +1038,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         guber_engine* e = grp[0];
         if (ps) { const int rc = ps->flush_touching(grp, 1); if (rc) return rc; }
         std::lock_guard<std::mutex> lk(e->mu);
+        if (e->held) { (void)launch_held(*e->held, false); e->held = nullptr; }      // (another call's)
         if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
         BatchView B; ResultView R; views(0, B, R);
         const int rc = launch_batch(e, B, R);
@@ -1035,6 +1068,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     std::sort(order, order + g);
     for (int i = 0; i < g; ++i) order[i]->mu.lock();
     struct Unlock { guber_engine** o; int g; ~Unlock() { for (int i = g - 1; i >= 0; --i) o[i]->mu.unlock(); } } unlock{order, g};
+    for (int i = 0; i < g; ++i)                                    // a k_eval3 ANOTHER call holds back for one of these tables goes first
+        if (grp[i]->held && grp[i]->held != pend) { (void)launch_held(*grp[i]->held, false); grp[i]->held = nullptr; }
     if (grp[0]->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     MultiFront MF{}; MultiEval ME{};
     uint32_t tiles = 0, ns[MULTI_MAX];
@@ -1093,7 +1128,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                     const Work& Wp = MF.sub[i].W;
                     EP.sub[i].snap_seq = Wp.snap_seq; EP.sub[i].snap_n = Wp.snap_n; EP.sub[i].snap_c = Wp.snap_c; EP.sub[i].snap_b = Wp.snap_b; EP.sub[i].snap_stamp = Wp.snap_stamp;
                 }
-                pend->valid = false;
+                { std::lock_guard<std::mutex> pl(pend->pm); pend->valid = false; }
+                for (int i = 0; i < planned; ++i) grp[i]->held = nullptr;
                 grp[0]->span_begin(KT_EVALPART_MULTI, pend->units);
                 hipLaunchKernelGGL(k_evalpart_multi, dim3(pend->tiles + tiles), dim3(256), 0, grp[0]->stream, EP);
                 grp[0]->span_end();
@@ -1107,9 +1143,12 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
             hipLaunchKernelGGL(k_own_multi, dim3((unsigned)planned * PT_PARTS), dim3(256), 0, grp[0]->stream, MF);
             grp[0]->span_end();
             if (ep && planned == g) {                             // held back: the same tables' next group, or flush_pending, launches it
-                if (!pend) pend = ps->free_slot();
-                pend->valid = true; pend->n = planned; pend->tiles = tiles; pend->units = units; pend->ME = ME;
-                for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
+                if (!pend) pend = ps->slot_for(grp, planned);
+                {
+                    std::lock_guard<std::mutex> pl(pend->pm);
+                    pend->valid = true; pend->n = planned; pend->tiles = tiles; pend->units = units; pend->ME = ME;
+                }
+                for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->held = pend; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
                 *enqueued += (uint32_t)planned;
                 if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
                 return rc;
@@ -1158,6 +1197,7 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
     bool any_ep = false;
     for (uint32_t j = 0; j < n_engines; ++j) any_ep = any_ep || (engines[j] && engines[j]->fuse_ep);
     PendSet* const ps = any_ep ? &pendset : nullptr;
+    struct Dispatching { bool on; Dispatching(bool o) : on(o) { if (on) ++tl_ep_dispatcher; } ~Dispatching() { if (on) --tl_ep_dispatcher; } } dispatching(any_ep);
     auto flush_all = [&]() -> int { return pendset.flush_all(); };
     for (;;) {
         guber_engine* grp[MULTI_MAX]; uint32_t gk[MULTI_MAX]; int g = 0;
@@ -1917,7 +1957,7 @@ extern "C" int guber_stages_submit(guber_stage_t* const* stages, uint32_t n, uin
         guber_engine* order[MULTI_MEM_MAX];
         for (int i = 0; i < g; ++i) order[i] = grp[i].s->e;
         std::sort(order, order + g);                               // engine locks in address order (launch_group's rule)
-        for (int i = 0; i < g; ++i) order[i]->mu.lock();
+        for (int i = 0; i < g; ++i) { order[i]->mu.lock(); ep_flush_held(order[i]); }
         int rc = 0;
         if (grp[0].s->e->set_device()) rc = fail(GUBER_E_HIP, "hipSetDevice");
         for (int i = 0; i < g && !rc; ++i) {
@@ -2124,7 +2164,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
     guber_engine* order[MULTI_MEM_MAX];
     for (uint32_t j = 0; j < n_engines; ++j) order[j] = engines[j];
     std::sort(order, order + n_engines);                             // engine locks in address order (launch_group's rule)
-    for (uint32_t j = 0; j < n_engines; ++j) order[j]->mu.lock();
+    for (uint32_t j = 0; j < n_engines; ++j) { order[j]->mu.lock(); ep_flush_held(order[j]); }
     struct Unlock { guber_engine** o; uint32_t n; ~Unlock() { for (uint32_t j = n; j-- > 0;) o[j]->mu.unlock(); } } unlock{order, n_engines};
     guber_engine* e0 = s->e;
     if (e0->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
@@ -2427,6 +2467,7 @@ extern "C" int guber_move_items_by_hash(guber_engine_t* from, guber_engine_t* to
     if (n == 0) return GUBER_OK;
     guber_engine* a = from < to ? from : to; guber_engine* b = from < to ? to : from;     // address order, as every multi-locker
     std::lock_guard<std::mutex> la(a->mu); std::lock_guard<std::mutex> lb(b->mu);
+    ep_flush_held(a); ep_flush_held(b);
     if (from->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     const uint32_t stride = (std::min(from->max_key, to->max_key) + 23u) & ~7u;
     DevBuf<uint64_t>& d_h = from->d_mvh;

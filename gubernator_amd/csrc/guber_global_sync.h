@@ -556,7 +556,7 @@ extern "C" int guber_global_sync(guber_comm_t* c, int64_t now_ms, guber_global_s
     std::vector<guber_engine*> held;
     for (GsRank* r : c->ranks) held.push_back(r->e);
     std::sort(held.begin(), held.end());
-    for (guber_engine* e : held) e->mu.lock();
+    for (guber_engine* e : held) { e->mu.lock(); ep_flush_held(e); }
     struct Unlock { std::vector<guber_engine*>& h; ~Unlock() { for (size_t i = h.size(); i-- > 0;) h[i]->mu.unlock(); } } unlock{held};
     const uint32_t W = c->world;
     int rc = 0;

@@ -84,6 +84,66 @@ def routed(n_engines, fuse_ep):
         e.close()
 
 
+def routed_with_a_second_thread(fuse_ep):
+    """while ONE guber_eval_batches_routed_dev call works through 10 rounds on four tables (holding k_eval3 launches back with
+    GUBER_FUSE_EP), another thread keeps calling entry points on two of the tables — guber_size, guber_get_item (read-only, so the
+    oracle comparison stays meaningful): whoever takes an engine's mutex launches the evaluation held back for it first
+    (guber_engine::held), so the reader never sees a table one batch behind its own stream, nothing deadlocks, and every answer of the
+    routed call still equals the oracle"""
+    import threading
+    n_engines, K, B, rounds = 4, 3000, 2048, 10
+    tab = streams.key_table(K * n_engines)
+    e0 = ga.Engine(cache_size=1 << 16, max_batch=4 * B)
+    engs = [e0] + [ga.Engine(cache_size=1 << 16, max_batch=4 * B, stream=e0.stream_handle()) for _ in range(n_engines - 1)]
+    orcs = [support.Oracle(cache_size=1 << 16) for _ in range(n_engines)]
+    zs = [streams.ZipfSampler(K, seed=700 + j) for j in range(n_engines)]
+    for e in engs:
+        e.profile(True)
+    which, hbs, keep, cb, cr = [], [], [], [], []
+    for r in range(rounds):
+        for j in range(n_engines):
+            hb = streams.bench_batch(tab, j * K + zs[j].draw(B), streams.NOW0 + r * 900, algorithm=(r + j) % 2, limit=30, duration=4000)
+            b, res, cols, rd = dev_batch(hb)
+            keep.append((cols, rd)); which.append(j); hbs.append(hb); cb.append(b); cr.append(res)
+    N = len(which)
+    stop, seen, errors = threading.Event(), [0], []
+    probe_key = bytes(tab[1 * K + 5])
+
+    def reader():
+        try:
+            while not stop.is_set():
+                engs[1].size()
+                engs[3].get_item(probe_key, streams.NOW0)
+                seen[0] += 1
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+
+    t = threading.Thread(target=reader)
+    t.start()
+    try:
+        ga.Engine.eval_routed_dev(engs, (C.c_uint32 * N)(*which), (ga.GuberBatch * N)(*cb), (ga.GuberResult * N)(*cr), N)
+    finally:
+        stop.set()
+        t.join()
+    assert not errors and seen[0] > 0, (errors, seen)
+    for s in range(N):
+        want = orcs[which[s]].eval(hbs[s])
+        got = ga.HostResult(hbs[s].n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = keep[s][1][name]
+        support.assert_results_equal(got, want, f"batch {s} of table {which[s]}")
+    launches = {}
+    for e in engs:
+        for k, v in e.profile_read().items():
+            launches[k] = launches.get(k, 0) + v[0]
+    print("launches", {k: v for k, v in launches.items() if v}, "reader calls", seen[0])
+    if fuse_ep:      # (evaluations launched by the reader's calls are not timed: only the dispatcher's own k_eval3_multi are counted)
+        assert launches.get("k_evalpart_multi", 0) + launches.get("k_eval3_multi", 0) <= launches["k_own_multi"] == rounds, launches
+    for j, (e, o) in enumerate(zip(engs, orcs)):
+        assert e.size() == o.size(), (j, e.size(), o.size())
+        e.close()
+
+
 def routed_lru(fuse_ep):
     """four tables whose caches come to BIND (6 000 items each, 7 000 keys in play, uniform draws: after a few rounds): batches that may overflow the cache leave the fused
     groups and go through the eviction pre-pass on their own, the others share launches (and, with GUBER_FUSE_EP, hold their k_eval3
@@ -140,6 +200,7 @@ def single(flags):
 CASES = {
     "routed4": lambda: routed(4, os.environ.get("GUBER_FUSE_EP") == "1"),
     "routed6": lambda: routed(6, os.environ.get("GUBER_FUSE_EP") == "1"),
+    "routed_threads": lambda: routed_with_a_second_thread(os.environ.get("GUBER_FUSE_EP") == "1"),
     "routed_lru": lambda: routed_lru(os.environ.get("GUBER_FUSE_EP") == "1"),
     "single_default": lambda: single(0),
     "single_part": lambda: single(ga.FLAG_TEST_FORCE_PART),

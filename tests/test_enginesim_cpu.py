@@ -60,6 +60,12 @@ def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
 
 
 
+def test_another_thread_on_tables_whose_evaluation_is_held_back(enginesim):
+    """GUBER_FUSE_EP: while one routed call holds k_eval3 launches back, a second thread calls guber_size / guber_get_item on two of its
+    tables — it launches what is held back for them before it looks (guber_engine::held), the call's answers stay the oracle's"""
+    run_case(enginesim, "routed_threads", GUBER_FUSE_EP="1")
+
+
 def test_the_gpu_suites_host_layer_and_wire_files_against_the_cpu_engine(enginesim):
     """tests/test_gpu_host_layer.py and tests/test_gpu_wire_dev.py — the `-m gpu` tests of the pool on real engines (stages, routed stages,
     placement passes moving buckets, Store / Loader, GLOBAL engines, zones), of the wire front end and of the device wire decoder — run
