@@ -709,8 +709,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked plainly (`python bench.py --gpus N`, the shape of the driver's 1-GPU command): become the launcher the contract
+        # names — one rank per GPU of this node under torch.distributed.run, rendezvous on 127.0.0.1
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or plainly: bench.py starts it)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     if args.one_device:
@@ -815,7 +826,31 @@ def main():
             latency = {"idle": latency, "under_load": rig.latency_under_load(),
                        "note": "the BASELINE metric pairs decisions/s with p99 batch latency: `under_load` is the latency in the regime `value` is measured in"}
 
-    # ---- parity over the timed work + CPU baseline (rank 0, N = 1 only) ---------------------------
+    # ---- parity over the timed work on EVERY rank (ranks own disjoint keys, replicated_hash.go:104-119: each checks its own timed
+    # stream against its own oracle) + the CPU baseline (rank 0; the W sweep at N = 1 only) ---------------------------
+    parity_by_rank = None
+    if world > 1 and not args.no_cpu_baseline:
+        import support
+        gate_w = min(os.cpu_count() or 1, 32)
+        th = max(1, min(gate_w, usable_cpus() // world))                     # (the ranks run their passes at the same time on one host)
+        orc = support.Oracle(cache_size=4 * K, workers=gate_w)
+        ok, compared, el = parity_over_timed_work(rig, orc, th if gate_w > 1 else 0, NOW0, f"rank {rank}")
+        orc.close()
+        ok = bool(ok and m["internal_retries"] == 0 and compared == steps)
+        oks = shard.gather_over_ranks(1 if ok else 0, device=red_dev)
+        cmp_by_rank = shard.gather_over_ranks(compared, device=red_dev)
+        if not all(oks):
+            raise SystemExit(f"parity gate failed on rank(s) {[r for r, o in enumerate(oks) if not o]}: refusing to report a number")
+        parity_by_rank = cmp_by_rank
+        parity = (f"{sum(oks)}/{world} ranks, {min(cmp_by_rank)}/{steps} timed batches each: bit-exact vs the rank's own oracle fed the rank's whole stream "
+                  f"(populate, warm-up, all timed batches in order) by a 64-bit digest of status|err, limit, remaining, reset_time computed on the device and on "
+                  f"the oracle's answers; internal retries in the timed region: 0 on every rank")
+        if rank == 0:
+            ucpu = usable_cpus()
+            cpu = {"value": round(steps * B / el, 1), "unit": "decisions/s", "cores": th, "kind": "port", "workers": gate_w,
+                   "host": {"cpus": os.cpu_count(), "usable": ucpu},
+                   "sample": f"rank 0's parity pass: all {steps} timed batches of {B} ({el:.1f} s), {K} resident keys, W = {gate_w} worker caches on {th} threads "
+                             f"while the other {world - 1} rank(s) ran theirs on the same host (the N = 1 line carries the thread sweep)"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import support
         ncpu = os.cpu_count() or 1
@@ -864,7 +899,7 @@ def main():
                     "resident_items_by_rank": resident_by_rank, "ranks_seen_by_the_collective_backend": ranks_seen, "backend": args.backend if world > 1 else None,
                     "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
                     # engine options taken from the environment (experiments; all unset in the driver's run)
-                    "engine_env": {k: os.environ[k] for k in ("GUBER_FUSE_EP", "GUBER_PIPELINE", "GUBER_PT_BITS", "GUBER_EVAL3_SPLIT", "GUBER_HIP_LIB") if k in os.environ},
+                    "engine_env": {k: os.environ[k] for k in ("GUBER_FUSE_EP", "GUBER_PIPELINE", "GUBER_PT_BITS", "GUBER_HIP_LIB") if k in os.environ},
                     "stream": {"replayed": False, "distinct_batches_total": len(rig.seq), "timed_batches": steps,
                                "distinct_keys_touched": touched, "table_bytes_touched": touched * 144, "table_bytes_touched_in_64B_sectors": touched * 192,
                                "now_ms": "advances 1 ms per batch",
@@ -886,7 +921,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)",
-            "value": round(m["value"], 1), "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "value": round(m["value"], 1), "unit": "decisions/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
             "warmup": args.warmup, "ms_per_step": round(m["ms_per_step"], 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
@@ -898,8 +933,10 @@ def main():
                              "enqueue": ("caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
                                          else f"one dispatcher for {S} shards over {args.streams} stream(s) (guber_eval_batches_routed_dev: batches of shards that share a stream share launches)"),
                              "shard_streams": m["shard_streams"]},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "batch_latency": latency,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "parity_batches_by_rank": parity_by_rank, "batch_latency": latency,
         }
+        if world > 1 and parity is None and not args.no_cpu_baseline:
+            raise SystemExit("no parity verdict for an N > 1 run: refusing to report a number")
         out.update(extras)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -1069,8 +1106,9 @@ def run_global(args, ctx, dist):
     from gubernator_amd import shard
     K, B, world, rank, dev = ctx.K, ctx.B, ctx.world, ctx.rank, ctx.dev
     GSYNC, NOW0 = args.global_sync, streams.NOW0
-    if world > 1 and args.one_device:
-        raise SystemExit("--global-sync with --one-device: RCCL refuses two ranks on one GPU; run ONE process with --logical-ranks R instead")
+    if world > 1 and args.one_device and not os.environ.get("GUBER_RCCL_LIB"):
+        raise SystemExit("--global-sync with --one-device: RCCL refuses two ranks on one GPU; run ONE process with --logical-ranks R instead "
+                         "(or rehearse the RCCL call sequence through the test-only librccl: GUBER_RCCL_LIB=tests/hostsim/libfake_rccl.so)")
     R = 1 if world > 1 else max(1, args.logical_ranks)          # ranks living in this process
     nranks = world if world > 1 else R
     ring = ga.Ring(shard.peer_names(nranks), 512, "fnv1")
@@ -1135,11 +1173,16 @@ def run_global(args, ctx, dist):
         reads.append(res.remaining.clone())
     converged = all(bool(torch.equal(reads[0], r)) for r in reads[1:])
     if world > 1:
-        ref = reads[0].clone()
+        on_host = args.backend != "nccl"                         # (gloo: host tensors)
+        mine = reads[0].cpu() if on_host else reads[0]
+        ref = mine.clone()
         dist.broadcast(ref, src=0)
-        flag = torch.tensor([1 if torch.equal(ref, reads[0]) else 0], device=dev)
+        flag = torch.tensor([1 if (converged and torch.equal(ref, mine)) else 0], device="cpu" if on_host else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         converged = bool(flag.item())
+    fallbacks = shard.sum_over_ranks(int(sum(x["fallbacks"] for x in sync_stats)), device=dev if args.backend == "nccl" else None)
+    if not converged:
+        raise SystemExit("GLOBAL leg: the replicas did not converge after the final ticks (functional_test.go:1815-1821): refusing to report a number")
     if rank == 0:
         timed = sync_stats[args.warmup // GSYNC:] or sync_stats
         avg = lambda k: sum(x[k] for x in timed) / max(len(timed), 1)   # noqa: E731
@@ -1150,8 +1193,10 @@ def run_global(args, ctx, dist):
                "config": {"workload": f"{K} keys replicated on every rank, {args.dist} stream (distinct batches, never replayed), batch={B}, {args.algo.upper()}_BUCKET, GLOBAL behaviour, "
                                       f"guber_global_sync every {GSYNC} batches, {world}xMI355X" + (f", {R} logical ranks on one GPU" if world == 1 else ""),
                           "keys_per_gpu": K, "batch": B, "resident_items_local": int(resident), "ranks": nranks},
+               "parity": (f"{nranks}/{nranks} ranks: after two final ticks every replica answers a hits=0 read of the last batch's {B} requests with the same remaining "
+                          f"(functional_test.go:1815-1821); host fallbacks over all ranks: {fallbacks}"),
                "global_sync": {"every_batches": GSYNC, "syncs": len(sync_stats), "implementation": "native: guber_comm_* + guber_global_sync (guber_global_sync.h)",
-                               "transport": "RCCL grouped send/recv (xGMI)" if world > 1 else "device copies between logical ranks of one GPU",
+                               "transport": (("the test-only librccl (GUBER_RCCL_LIB): ranks sharing one GPU" if os.environ.get("GUBER_RCCL_LIB") else "RCCL grouped send/recv (xGMI)") if world > 1 else "device copies between logical ranks of one GPU"),
                                "avg_ms": round(avg("ms"), 3), "avg_wall_ms": round(avg("wall_ms"), 3),
                                "avg_hits_rows_sent": int(avg("hits_rows_sent")), "avg_hits_rows_applied": int(avg("hits_rows_applied")),
                                "avg_update_rows": int(avg("update_rows")), "avg_items_installed": int(avg("items_installed")),

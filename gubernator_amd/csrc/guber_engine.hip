@@ -110,7 +110,7 @@ struct guber_engine {
     // owner-partitioned pipeline (guber_kernels_part.h): messages tile -> owner, records owner -> tile, runs per (tile, owner),
     // tile maps of walked segments, the per-request words.  cap256 = fast_cap rounded up to whole tiles.
     DevBuf<GMsg> w_gmsg; DevBuf<GRec> w_grec; DevBuf<uint32_t> w_gse, w_did3, w_pmode; DevBuf<unsigned long long> w_segtiles;
-    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false, eval3_split = false, fuse_ep = false; uint64_t part_batches = 0, ep_launches = 0;
+    uint32_t cap256 = 0, part_min = 1024; bool use_part = true, part_single = false, force_part = false, fuse_ep = true; uint64_t part_batches = 0, ep_launches = 0;
     uint32_t fast_cap = 0;      // entries of the arrays above
     uint32_t fast_batches = 0, fast_prev_n = 0;
     bool force_radix = false;
@@ -352,14 +352,11 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     // owner-partitioned pipeline when several tables share the launches (where it is faster: profiles/r04_*), claims otherwise
     if (const char* v = getenv("GUBER_PIPELINE")) { if (!strcmp(v, "claims")) e->use_part = false; else if (!strcmp(v, "part")) e->part_single = true; }
     if (const char* v = getenv("GUBER_PART_MIN")) e->part_min = (uint32_t)std::max(257, atoi(v));
-    // GUBER_EVAL3_SPLIT=1: the owner-partitioned pipeline's last kernel as two launches (closed forms at eight waves per SIMD; the rest:
-    // guber_kernels_part.h eval3_body) — built and verified, off until it has been measured on the GPU
-    if (const char* v = getenv("GUBER_EVAL3_SPLIT")) e->eval3_split = atoi(v) != 0;
-    // GUBER_FUSE_EP=1: inside one guber_eval_batches_routed_dev call, a group's k_eval3 shares a launch with the k_part of the same
-    // tables' next batches (k_evalpart_multi, guber_kernels_part.h: two launches per pass instead of three) — built and checked
-    // through the kernel source and the engine's host code on the CPU, off until it has been measured on the GPU.  Another thread's
-    // call on one of the group's engines launches the held-back k_eval3 first (guber_engine::held).
-    if (const char* v = getenv("GUBER_FUSE_EP")) e->fuse_ep = atoi(v) != 0 && !e->eval3_split;
+    // Inside one guber_eval_batches_routed_dev call a group's k_eval3 shares a launch with the k_part of the same tables' next batches
+    // (k_evalpart_multi, guber_kernels_part.h: two launches per pass instead of three; measured in round 5 on the headline, same box,
+    // alternating: 8.69 -> 8.99 G decisions/s, profiles/r05_a_fuse_ep_ab.txt).  Another thread's call on one of the group's engines
+    // launches the held-back k_eval3 first (guber_engine::held).  GUBER_FUSE_EP=0 is the switch for an A/B on another box.
+    if (const char* v = getenv("GUBER_FUSE_EP")) e->fuse_ep = atoi(v) != 0;
     if (e->force_part) e->part_min = 1;
     rc |= e->w_gmsg.ensure(e->cap256); rc |= e->w_grec.ensure((size_t)e->cap256 + e->cap256 / 2); rc |= e->w_gse.ensure((size_t)FT_MAX_TILES * PT_PARTS);   // (grec: 32-byte records first, then the 64-byte form)
     rc |= e->w_did3.ensure((size_t)e->cap256 * (e->fuse_ep ? 2 : 1)); rc |= e->w_segtiles.ensure((size_t)e->cap256 * 4); rc |= e->w_pmode.ensure(16);
@@ -418,7 +415,7 @@ extern "C" int guber_engine_create(const guber_config_t* cfg, guber_engine_t** o
     e->W.snap_seq = 0; e->W.snap_n = 0; e->W.snap_c = nullptr; e->W.snap_b = nullptr; e->W.snap_stamp = nullptr;
     e->W.parity = 0; e->W.clear_n = 0; e->W.store_flags = nullptr; e->W.store_after = nullptr;
     e->W.claims = e->w_claims.p; e->W.cmask = e->claims_cells - 1; e->W.epoch16 = 0;
-    e->W.gmsg = e->w_gmsg.p; e->W.gshape = (GShape*)((char*)e->w_gmsg.p + (size_t)e->cap256 * 32);
+    e->W.gmsg = e->w_gmsg.p;
     e->W.grs = (GRecS*)e->w_grec.p; e->W.grec = e->w_grec.p + e->cap256 / 2; e->W.gse = e->w_gse.p; e->W.segtiles = e->w_segtiles.p; e->W.pmode = e->w_pmode.p;
     { uint32_t lg = 0; while ((1ull << lg) < e->slots) ++lg; e->W.pshift = lg - 8; e->W.pmslot = 0; }   // (slots >= 1024)
 #ifdef GUBER_PHASE_TIMING
@@ -795,11 +792,7 @@ static int launch_batch_inner(guber_engine* e, const BatchView& B, const ResultV
         hipLaunchKernelGGL(k_own, dim3(PT_PARTS), dim3(256), 0, e->stream, e->T, P.B2, P.W, P.ftiles);
         e->span_end();
         e->span_begin(KT_EVAL3, n);
-        if (e->eval3_split) {
-            hipLaunchKernelGGL(k_eval3f, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
-            hipLaunchKernelGGL(k_eval3s, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
-        } else
-            hipLaunchKernelGGL(k_eval3, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
+        hipLaunchKernelGGL(k_eval3, dim3(P.ftiles), dim3(256), 0, e->stream, EvalArgs{e->T, P.B3, R, P.W});
         e->span_end();
         HIPCHK(hipGetLastError());
 #ifdef GUBER_PHASE_TIMING
@@ -1154,11 +1147,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                 return rc;
             }
             grp[0]->span_begin(KT_EVAL3_MULTI, units);
-            if (grp[0]->eval3_split) {
-                hipLaunchKernelGGL(k_eval3f_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
-                hipLaunchKernelGGL(k_eval3s_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
-            } else
-                hipLaunchKernelGGL(k_eval3_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
+            hipLaunchKernelGGL(k_eval3_multi, dim3(tiles), dim3(256), 0, grp[0]->stream, ME);
             grp[0]->span_end();
             for (int i = 0; i < planned; ++i) { grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
             *enqueued += (uint32_t)planned;

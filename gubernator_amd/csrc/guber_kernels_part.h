@@ -55,7 +55,7 @@ struct alignas(64) GMsg {
     unsigned long long misc;             // gm_*: head thread 8 | members-1 8 | G_* 8 | key length 5 | behavior 6 | algorithm 2 | owner 1 | created_at: min 18 (ms from the batch clock, signed), span 8
 };
 static_assert(sizeof(GMsg) == 64, "one message = one 64-byte sector");
-enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_ODD = 16, G_LONG = 32, G_SHAPE0 = 64 };
+enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_ODD = 16, G_LONG = 32 };
 //   G_NONUNIFORM  members of the group differ in a request field other than created_at
 //   G_RETRY       members of the group differ in their key bytes (one hash, two keys)
 //   G_CREATED     members differ in created_at only (the range travels in misc)
@@ -63,35 +63,15 @@ enum : uint32_t { G_NONUNIFORM = 1, G_RETRY = 2, G_CREATED = 4, G_CFAR = 8, G_OD
 //   G_ODD         a request the packed shape cannot carry exactly (behavior bits above 5, an algorithm other than 0 / 1, calendar
 //                 values precomputed by the host): equal to nothing but the members of its own group
 //   G_LONG        key longer than 16 bytes: compared through the request's key bytes in memory
-//   G_SHAPE0      (compact messages only) hits / limit / duration / burst are those of the tile's request 0: gshape[tile * FT]
 //
-// The 32-byte forms of what travels between the three kernels.  (Measured on one box, 12 shards fused, profiles/r04_w_*, r04_y_*:
-// 32-byte records +2.3 %, 32-byte messages +0.6 %, both +1.7 %: the records are the default, the messages a build option.)
-//   * GUBER_PART_REC32 (default 1): a record is 32 bytes {remaining, stamp, expire_at, packed: slot 26 | total 16 | base 16 | burst is
-//     zero | algorithm | status | kind | 1} whenever the rest of the bucket is what the request itself says (stored limit / duration
-//     / burst equal to the request's — the steady state —, or the key is new), nothing is flagged, no error, no InvalidAt; every
-//     other group gets {.., 0} there and the 64-byte record beside it (grec[]).  Two 32-byte records of neighbouring groups — owners
-//     of one XCD are neighbours in a tile's region — share a sector in that XCD's L2 and leave it as one write; k_eval3 reads half
-//     the bytes.
-//   * GUBER_PART_MSG32 (default 0; GUBER_PART_COMPACT=1 switches both on): a message is 32 bytes {hash, key bytes, packed rest}; the
-//     four 64-bit request fields it used to carry are a SHAPE, written once per tile for the shape of the tile's request 0
-//     (gshape[tile * FT]; a group whose requests have that shape says so: G_SHAPE0 — rate limits come in few shapes, a tile usually
-//     has one) and once per group that differs (gshape[tile * FT + head thread]).  The owner keeps the 256 tile shapes in LDS and
-//     rebuilds the 64-byte form in registers: everything behind the load is unchanged and as exact as before (a group with its own
-//     shape costs its owner one more dependent load; 8 KB more LDS and 7 more VGPRs in k_own — why it does not pay).
-#ifndef GUBER_PART_COMPACT
-#define GUBER_PART_COMPACT 0
-#endif
-#ifndef GUBER_PART_MSG32
-#define GUBER_PART_MSG32 GUBER_PART_COMPACT
-#endif
-#ifndef GUBER_PART_REC32
-#define GUBER_PART_REC32 1
-#endif
-struct alignas(32) GMsgS { unsigned long long hash, key0, key1, misc; };
-struct alignas(32) GShape { long long hits, limit, duration, burst; };
+// The record of a group is 32 bytes {remaining, stamp, expire_at, packed: slot 26 | total 16 | base 16 | burst is zero | algorithm |
+// status | kind | 1} whenever the rest of the bucket is what the request itself says (stored limit / duration / burst equal to the
+// request's — the steady state —, or the key is new), nothing is flagged, no error, no InvalidAt; every other group gets {.., 0}
+// there and the 64-byte record beside it (grec[]).  Two 32-byte records of neighbouring groups — owners of one XCD are neighbours
+// in a tile's region — share a sector in that XCD's L2 and leave it as one write; k_eval3 reads half the bytes (+2.3 % on one box,
+// profiles/r04_w_forms_ab.txt; 32-byte MESSAGES were measured too: +0.6 %, not kept).
 struct alignas(32) GRecS { int64_t remaining, stamp, expire_at; unsigned long long pk; };
-static_assert(sizeof(GMsgS) == 32 && sizeof(GShape) == 32 && sizeof(GRecS) == 32, "two per sector");
+static_assert(sizeof(GRecS) == 32, "two per sector");
 enum : uint32_t { SM_COMPACT_OK = 1u << 24, SM_BURST_ZERO = 1u << 25 };      // GRec::smeta, k_own only: the group's record has the 32-byte form
 GB_HD unsigned long long grs_pack(uint32_t kind, uint32_t status, uint32_t algo, bool burst_zero, uint32_t base, uint32_t total, uint32_t slot) {
     return 1ull | ((unsigned long long)(kind & 3u) << 1) | ((unsigned long long)(status & 1u) << 3) | ((unsigned long long)(algo & 1u) << 4) |
@@ -312,17 +292,6 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
             k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
             if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
         } else { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
-#if GUBER_PART_MSG32
-        if (mine.hits == sreq.hits[0] && mine.limit == sreq.limit[0] && mine.duration == sreq.duration[0] && mine.burst == sreq.burst[0]) f |= G_SHAPE0;
-        else {
-            ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT + tid];
-            sq[0] = make_ulonglong2((unsigned long long)mine.hits, (unsigned long long)mine.limit);
-            sq[1] = make_ulonglong2((unsigned long long)mine.duration, (unsigned long long)mine.burst);
-        }
-        ulonglong2* mq = (ulonglong2*)((GMsgS*)W.gmsg + (size_t)tile * FT + j);
-        mq[0] = make_ulonglong2(gk, k0);
-        mq[1] = make_ulonglong2(k1, gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
-#else
         GMsg* m = &W.gmsg[(size_t)tile * FT + j];
         ulonglong2* mq = (ulonglong2*)m;
         mq[0] = make_ulonglong2(gk, k0);
@@ -330,15 +299,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         mq[2] = make_ulonglong2((unsigned long long)mine.limit, (unsigned long long)mine.duration);
         mq[3] = make_ulonglong2((unsigned long long)mine.burst,
                                 gm_pack(tid, eq_total, f, len <= 16 ? len : 31u, shape, (f & G_CFAR) ? 0 : (int64_t)dmin, (f & G_CFAR) ? 0u : span));
-#endif
     }
-#if GUBER_PART_MSG32
-    if (tid == 0) {                                                   // the tile's shape: its request 0's (a tile that exists has one)
-        ulonglong2* sq = (ulonglong2*)&W.gshape[(size_t)tile * FT];
-        sq[0] = make_ulonglong2((unsigned long long)mine.hits, (unsigned long long)mine.limit);
-        sq[1] = make_ulonglong2((unsigned long long)mine.duration, (unsigned long long)mine.burst);
-    }
-#endif
     lds_barrier();
     if (valid) {
         if (errcode) W.did[g] = pd_pack(0, 0, errcode);
@@ -353,12 +314,6 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
 __global__ __launch_bounds__(FT, GUBER_PART_WAVES) void k_part(Table T, BatchView B, Work W) { part_body(T, B, W, blockIdx.x); }
 
 // ---- k_own ----------------------------------------------------------------------------------------------------------------
-#ifndef GUBER_OWN_DIR_EARLY
-#define GUBER_OWN_DIR_EARLY 0
-#endif
-#ifndef GUBER_ABLATE_TABLE
-#define GUBER_ABLATE_TABLE 0             // 1 = MEASUREMENT ONLY, WRONG ANSWERS: no bucket is read or written (what the table trips cost the pipeline)
-#endif
 #ifndef GUBER_OWN_EPT
 #define GUBER_OWN_EPT 3
 #endif
@@ -402,11 +357,7 @@ __device__ __forceinline__ bool msg_same_request(const ulonglong2& a1, const ulo
 
 // the hash of message i of the batch (either form)
 __device__ __forceinline__ unsigned long long msg_hash_at(const Work& W, size_t i) {
-#if GUBER_PART_MSG32
-    return ((const GMsgS*)W.gmsg)[i].hash;
-#else
     return W.gmsg[i].hash;
-#endif
 }
 
 __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, const Work& W, const uint32_t p, const uint32_t ntiles) {
@@ -431,18 +382,10 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
 #endif
         return;
     }
-#if GUBER_PART_MSG32
-    __shared__ GShape tshape[256];                      // tile -> the shape of its request 0 (what a G_SHAPE0 message refers to)
-#endif
 
     uint32_t start = 0, c = 0;
     if (t < ntiles) {
         const uint32_t se = W.gse[(size_t)t * PT_PARTS + p]; start = se & 0xffffu; c = se >> 16;
-#if GUBER_PART_MSG32
-        const ulonglong2* sq = (const ulonglong2*)&W.gshape[(size_t)t * FT];
-        const ulonglong2 s0 = sq[0], s1 = sq[1];
-        ulonglong2* lq = (ulonglong2*)&tshape[t]; lq[0] = s0; lq[1] = s1;
-#endif
     }
     const size_t mbase = (size_t)t * FT + start;
     if (t == 0) { stk[0] = 0u; sp = 1; ins_n = 0u; }
@@ -500,32 +443,10 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                         mi = mb + x;
                     }
                     esrc[k] = mi;
-#if GUBER_PART_MSG32
-                    const ulonglong2* mq = (const ulonglong2*)((const GMsgS*)W.gmsg + mi);
-                    m0[k] = mq[0]; m1[k] = mq[1];                     // {hash, key0} {key1, packed rest}
-#else
                     const ulonglong2* mq = (const ulonglong2*)&W.gmsg[mi];
                     m0[k] = mq[0]; m1[k] = mq[1]; m2[k] = mq[2]; m3[k] = mq[3];
-#endif
                 }
             }
-#if GUBER_PART_MSG32
-            // the 64-byte form of every message, rebuilt: its shape is its tile's (LDS) or its own (one more load, issued for all
-            // of the thread's messages together)
-#pragma unroll
-            for (int k = 0; k < OW_EPT; ++k) {
-                if (esrc[k] != 0xffffffffu) {
-                    const unsigned long long misc = m1[k].y;
-                    const uint32_t tl = esrc[k] >> 8;
-                    ulonglong2 s0, s1;
-                    if (gm_flags(misc) & G_SHAPE0) { const ulonglong2* lq = (const ulonglong2*)&tshape[tl]; s0 = lq[0]; s1 = lq[1]; }
-                    else { const ulonglong2* sq = (const ulonglong2*)&W.gshape[(size_t)tl * FT + gm_head(misc)]; s0 = sq[0]; s1 = sq[1]; }
-                    m1[k].y = s0.x;                                   // hits
-                    m2[k] = make_ulonglong2(s0.y, s1.x);              // limit, duration
-                    m3[k] = make_ulonglong2(s1.y, misc & ~((unsigned long long)G_SHAPE0 << 16));   // burst, packed rest
-                }
-            }
-#endif
             // ---- hash -> LDS table slot; the first message of a key installs it and leaves its content as the key's reference ----
 #pragma unroll
             for (int k = 0; k < OW_EPT; ++k) {
@@ -570,9 +491,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 for (uint32_t r = 0; r < c; ++r) {
                     if (((uint32_t)((msg_hash_at(W, mbase + r) >> 7) & T.mask) & smask) != res) continue;
                     GRec* o = &W.grec[mbase + r];
-#if GUBER_PART_REC32
                     { ulonglong2* cs = (ulonglong2*)&W.grs[mbase + r]; cs[0] = make_ulonglong2(0ull, 0ull); cs[1] = make_ulonglong2(0ull, 0ull); }
-#endif
                     o->limit = o->duration = o->remaining = o->stamp = o->burst = o->expire_at = 0; o->smeta = 0; o->slot = 0;
                     o->tail = gr_tail(SEG_RETRY, 0, 0, 1, (uint32_t)(mbase + r));
                 }
@@ -592,16 +511,9 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         const bool haskey = t < nk;
         if (haskey) {
             kpos = (kref[t].hash >> 7) & T.mask;
-#if !GUBER_ABLATE_TABLE
             const Bucket* hb = &T.buckets[kpos];
             const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
             trec = hb->rec;
-#endif
-#if GUBER_OWN_DIR_EARLY
-            // ... and the two directory entries a displaced key needs next (usually one 64-byte line more): a key one step from home
-            // then costs two trips instead of three, at the price of a line that the keys at home (the majority) do not use
-            de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[(kpos + 1) & T.mask];
-#endif
         }
         GP_STAMP(1, 3);
         // ---- every message against its key's reference: exact key bytes, exact request shape; the key's totals ----
@@ -674,14 +586,9 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         for (uint32_t kid = t; kid < nk; kid += 256) {
             if (kid != t) {                                           // (more than 256 keys in a round: uniform keys)
                 kpos = (kref[kid].hash >> 7) & T.mask;
-#if !GUBER_ABLATE_TABLE
                 const Bucket* hb = &T.buckets[kpos];
                 const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
                 trec = hb->rec;
-#endif
-#if GUBER_OWN_DIR_EARLY
-                de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[(kpos + 1) & T.mask];
-#endif
             }
             const GMsg wm = kref[kid];
             const unsigned long long tag = wm.hash;
@@ -693,20 +600,14 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             const uint8_t* lkey = nullptr; uint32_t llen = 0;
             if (klen == 31u) { lkey = B.key_bytes + (uint32_t)wm.key0; llen = (uint32_t)(wm.key0 >> 32); }
             // at home?  (keys of <= 16 bytes: the two key words and the length say it all; longer keys go through the directory)
-#if GUBER_ABLATE_TABLE
-            const bool at_home = true;
-#else
             const bool at_home = klen != 31u && (((uint64_t)tc0.y << 32) | tc0.x) == wm.key0 && (((uint64_t)tc0.w << 32) | tc0.z) == wm.key1 &&
                                  (tc3.w >> 16) == klen;
-#endif
             if (at_home) { slot = home; cand = true; }
-#if !GUBER_OWN_DIR_EARLY
             else {
                 // not there: the directory entries of the home position and of the next one, and the next bucket, in one trip
                 const uint64_t npos = (kpos + 1) & T.mask;
                 de0 = *(const ulonglong2*)&T.dir[kpos]; de1 = *(const ulonglong2*)&T.dir[npos];
             }
-#endif
             for (uint32_t step = 0; !at_home && step < T.max_probe; ++step, ppos = (ppos + 1) & T.mask) {
                 ulonglong2 de = step == 0 ? de0 : de1;
                 if (step >= 1) {
@@ -766,7 +667,6 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             kr.limit = trec.limit; kr.duration = trec.duration; kr.remaining = trec.remaining; kr.stamp = trec.stamp; kr.burst = trec.burst;
             kr.expire_at = trec.expire_at;
             kr.smeta = pack_smeta(trec, 1); kr.slot = slot;
-#if GUBER_PART_REC32
             {   // does the 32-byte record carry this key?  (nothing flagged, no error, and the rest of the bucket is what the request says)
                 const uint32_t kind = rec_kind(trec);
                 bool cok = sf == 0u && errcode == 0u && cand && trec.invalid_at == 0 && slot < (1u << 26) && (kfl[kid] & ~(uint32_t)G_LONG) == 0u;
@@ -777,7 +677,6 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                           (trec.burst == 0 || trec.burst == wm.burst);
                 if (cok) kr.smeta |= SM_COMPACT_OK | (trec.burst == 0 ? SM_BURST_ZERO : 0u);
             }
-#endif
             const uint32_t wl = kwin[kid];                             // the installing message: list index -> its place in gmsg
             uint32_t seg = 0;
             {   // (the installer's esrc lives in its thread's registers: recomputed from the list index as every thread did)
@@ -805,7 +704,6 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                 ulonglong2 q0 = kq[0], q1 = kq[1], q2 = kq[2], q3 = kq[3];
                 q3.y |= (unsigned long long)(ebase[k] & 0xffffu) << 16;
                 const uint32_t src = esrc[k];
-#if GUBER_PART_REC32
                 ulonglong2* cs = (ulonglong2*)&W.grs[src];
                 const uint32_t sm = (uint32_t)q3.x;
                 if (sm & SM_COMPACT_OK) {
@@ -817,10 +715,6 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
                     ulonglong2* o = (ulonglong2*)&W.grec[src];
                     o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
                 }
-#else
-                ulonglong2* o = (ulonglong2*)&W.grec[src];
-                o[0] = q0; o[1] = q1; o[2] = q2; o[3] = q3;
-#endif
                 if ((uint32_t)q3.y & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) {   // the walk's map: which tiles hold the segment, and as which group
                     const uint32_t seg = (uint32_t)(q3.y >> 48), tile = src >> 8;
                     atomicOr(&W.segtiles[(size_t)seg * 4 + (tile >> 6)], 1ull << (tile & 63));
@@ -840,30 +734,20 @@ __global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own(Table T, BatchView
 // Request order, workgroup = tile.  As k_eval2 from the evaluation on; what differs is where a request learns its segment:
 // packed word -> its group's record (ONE sector: bucket, slot, flags, base, total), no bitmaps, no LDS pre-pass, no barrier
 // before the evaluation.  The serial walk of a heterogeneous segment follows the segment's tile map (Work::segtiles, tilerow).
-// MODE 0: everything in one launch.  GUBER_EVAL3_SPLIT=1 (engine): TWO launches — MODE 1, the closed forms only (58 VGPRs: eight waves
-// per SIMD instead of four; what it cannot answer — apply() for new / expired / odd buckets, the serial walk of a heterogeneous
-// segment — it marks: bit 30 of the request's word, one flag per tile in the tile's first gse cell, dead by now) and MODE 2, the
-// full body for the marked requests of the marked tiles (a workgroup of an unmarked tile returns at once).  The register file
-// holds twice the waiting waves of the launch every request goes through (registers x residency is the bound).
-constexpr uint32_t PD_SLOW = 0x40000000u;
-template <int MODE>
+// (Measured and not kept, round 4: the closed forms and the rest as two launches — the first at eight waves per SIMD: +1 % / -7 %,
+// profiles/r04_split_eval3_ab.txt.)
 __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t tile) {
     const Table& T = A.T; const BatchView& B = A.B; const ResultView& R = A.R; const Work& W = A.W;
     __shared__ unsigned long long cnt[4];
-    __shared__ uint32_t slow_any;
-    if (MODE == 2 && W.gse[(size_t)tile * PT_PARTS] == 0u) return;          // nothing of this tile was left for the second launch
     const uint32_t i = tile * 256 + threadIdx.x;
-    const uint32_t dl0 = i < B.n ? W.did[i] : 0u;
-    const bool live = i < B.n && (MODE != 2 || (dl0 & PD_SLOW) != 0u);
-    bool deferred = false;
+    const bool live = i < B.n;
     GP_STAMP(2, 0);
-    const uint32_t dl = live ? dl0 : 0u;
+    const uint32_t dl = live ? W.did[i] : 0u;
     const uint32_t gj = dl & 0xffu, lr = (dl >> 8) & 0xffu, derr = (dl >> 16) & 0xffu;
     uint32_t sf = 0, slot = 0, smeta = 0, base = 0, total = 1, d = 0, rerr = 0; Req r; Rec s0;
     rec_clear(s0);
     if (live) {
         r = load_req_nogreg(B, i);
-#if GUBER_PART_REC32
         bool full = !derr;
         if (!derr) {
             const ulonglong2* cq = (const ulonglong2*)&W.grs[(size_t)tile * 256 + gj];   // 32 bytes per (key, tile) group
@@ -882,9 +766,6 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             }
         }
         if (full) {
-#else
-        if (!derr) {
-#endif
             const ulonglong2* q = (const ulonglong2*)&W.grec[(size_t)tile * 256 + gj];   // one 64-byte sector per (key, tile) group
             const ulonglong2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
             s0.limit = (int64_t)q0.x; s0.duration = (int64_t)q0.y; s0.remaining = (int64_t)q1.x; s0.stamp = (int64_t)q1.y;
@@ -896,7 +777,6 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
         }
     }
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
-    if (MODE == 1 && threadIdx.x == 0) slow_any = 0u;
     GP_STAMPW(2, 1);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
     if (live) {
@@ -927,8 +807,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             }
             const bool walk = !parallel && rank == 0;
             uint32_t lastj = i;                                          // the run's last request (walk: the last one walked)
-            if (MODE == 1 && ((parallel && !done) || walk)) deferred = true;      // the second launch's
-            else if ((parallel && !done) || walk) {
+            if ((parallel && !done) || walk) {
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
                     if (B.greg_expire && B.greg_duration) { cur.greg_expire = B.greg_expire[i]; cur.greg_duration = B.greg_duration[i]; }
@@ -998,32 +877,28 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                     }
                 }
             }
-            if (parallel && !deferred) {
+            if (parallel) {
                 store_resp(R, i, out);
                 store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             }
-            if (((parallel && rank == total - 1) || walk) && !deferred) {
+            if ((parallel && rank == total - 1) || walk) {
                 rec_set_stamp(after, W.touch + lastj);                // the key's place in the recency order: its last request (lrucache.go:111-128)
-#if !GUBER_ABLATE_TABLE
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
-#endif
                 if (parallel && out.err == 0) queue_global(T, slot, r, (uint64_t)rank + 1);
             }
         }
         // the first request of a segment that carries a tile map clears it (walked or not): the map is all zero between batches
-        if (!derr && flagged && rank == 0 && !deferred) {
+        if (!derr && flagged && rank == 0) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) W.segtiles[(size_t)d * 4 + w] = 0ull;
         }
-        if (MODE == 1 && deferred) W.did[i] = dl | PD_SLOW;
     }
     GP_STAMP(2, 2);
     {
         const int w_over = wave_sum(c_over), w_hit = wave_sum(c_hit), w_miss = wave_sum(c_miss), w_size = wave_sum(c_size);
         lds_barrier();                                               // (cnt zeroed)
-        if (MODE == 1 && deferred) slow_any = 1u;
         if ((threadIdx.x & 63) == 0 && (w_over | w_hit | w_miss | w_size)) {
             if (w_over) atomicAdd(&cnt[0], (unsigned long long)w_over);
             if (w_hit) atomicAdd(&cnt[1], (unsigned long long)w_hit);
@@ -1036,9 +911,8 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
             bc->over += cnt[0]; bc->hits += cnt[1]; bc->misses += cnt[2]; bc->size_delta += (long long)cnt[3];
         }
     }
-    if (MODE == 1 && threadIdx.x == 0) W.gse[(size_t)tile * PT_PARTS] = slow_any;      // (after the barriers above)
     // the owner count of the next batch (all of this batch's k_own workgroups are done, the next batch's k_part has not started)
-    if (MODE != 2 && tile == 0 && threadIdx.x == 0) {
+    if (tile == 0 && threadIdx.x == 0) {
         uint32_t* pm = W.pmode;
         const uint32_t splits = pm[2];
         pm[2] = 0u;
@@ -1053,15 +927,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
 }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
     const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    eval3_body<0>(*a, blockIdx.x);
-}
-__global__ __launch_bounds__(256, 8) void k_eval3f(EvalArgs A) {
-    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    eval3_body<1>(*a, blockIdx.x);
-}
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s(EvalArgs A) {
-    const EvalArgs* a = (const EvalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    eval3_body<2>(*a, blockIdx.x);
+    eval3_body(*a, blockIdx.x);
 }
 
 // ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
@@ -1081,18 +947,14 @@ __global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own_multi(MultiFront A
     const FrontArgs* a = m->sub + sb;
     own_body(a->T, a->B, a->W, blockIdx.x % PT_PARTS, ntiles);
 }
-template <int MODE>
-__device__ __forceinline__ void eval3_multi_body(const MultiEval& A) {
+__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) {
     uint32_t sb = 0, first = 0;
 #pragma unroll
     for (int k = 0; k < MULTI_MAX - 1; ++k)
         if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
     const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
-    eval3_body<MODE>(*a, blockIdx.x - first);
+    eval3_body(*a, blockIdx.x - first);
 }
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) { eval3_multi_body<0>(A); }
-__global__ __launch_bounds__(256, 8) void k_eval3f_multi(MultiEval A) { eval3_multi_body<1>(A); }
-__global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3s_multi(MultiEval A) { eval3_multi_body<2>(A); }
 
 // ---- batch b's k_eval3 and batch b + 1's k_part of the same tables in ONE launch (GUBER_FUSE_EP=1; built and checked through the
 // kernel source on the CPU, off until it has been measured on the GPU).  A stream's passes are k_part, k_own, k_eval3, k_part, ...:
@@ -1123,7 +985,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_evalpart_multi(Multi
         if (sb == (uint32_t)k && k + 1 < (int)A.nb && wg >= end) { first = end; sb = k + 1; }
     }
     const EPSub* a = (const EPSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEP, sub)) + sb;
-    if (!part) { eval3_body<0>(a->E, wg - first); return; }
+    if (!part) { eval3_body(a->E, wg - first); return; }
     Work W = a->E.W;                                       // the next batch's work arrays are this engine's, but for:
     W.did = a->did_p; W.pmslot = a->pmslot_p;
     W.snap_seq = a->snap_seq; W.snap_n = a->snap_n; W.snap_c = a->snap_c; W.snap_b = a->snap_b; W.snap_stamp = a->snap_stamp;

@@ -117,7 +117,7 @@ enum : uint32_t { SEG_NONUNIFORM = 1, SEG_RETRY = 2, SEG_ERR = 4 /* code in bits
 #define GB_STAMP2(k) do {} while (0)
 #define GB_STAMPW(k) do {} while (0)
 #endif
-struct GMsg; struct GRec; struct GShape; struct GRecS;
+struct GMsg; struct GRec; struct GRecS;
 // the launch's dynamic LDS as a byte array (a macro so that the host emulation of the kernel source, tests/hostsim/fakehip, can give it storage)
 #ifndef GUBER_DYN_LDS
 #define GUBER_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
@@ -172,10 +172,8 @@ struct Work {
     uint32_t pshift;                    // owner of a key (256 owners) = its home position >> pshift
     uint32_t pmslot;                    // 0: the batch's owner count is pmode[0]; 1 | 2: pmode[3 + pmslot] (GUBER_FUSE_EP: guber_kernels_part.h pm_bits_of)
     uint32_t* pmode;                    // device words: [0..3] owner bits of the next batch (7 | 8), batches left at 8, rounds that split in this batch, pinned; [4..5] the bits per batch parity (pmslot)
-    // the compact forms (GUBER_PART_COMPACT, guber_kernels_part.h): 32-byte messages live in the first half of gmsg[], the
-    // request shapes they refer to in the second half (gshape); 32-byte records in grs[], the 64-byte form (grec[]) only for
+    // 32-byte records in grs[] (guber_kernels_part.h), the 64-byte form (grec[]) only for
     // the groups whose record does not fit
-    GShape* gshape;                     // [cap] tile t: gshape[t * FT + 0] = the shape of the tile's request 0, [t * FT + head] = a head's own
     GRecS* grs;                         // [cap]
 };
 

@@ -17,6 +17,23 @@
 #include "guber_algo.h"
 #include "guber_placement_impl.h"
 
+// -DGUBER_POOL_TRACE (test builds only: tests/hostsim/engine_stub.cpp keeps the ring and prints it on a mismatch): who reserved,
+// sealed, submitted, moved what, in which order.  Nothing in the product build.
+#ifdef GUBER_POOL_TRACE
+extern "C" void guber_pool_trace(const char* what, const void* obj, uint64_t a, uint64_t b, uint64_t c);
+#define PT(what, obj, a, b, c) guber_pool_trace(what, (const void*)(obj), (uint64_t)(a), (uint64_t)(b), (uint64_t)(c))
+#else
+#define PT(what, obj, a, b, c) do {} while (0)
+#endif
+// -DGUBER_POOL_TEST_HOOKS (tests/hostsim/pool_test.cpp): the test is told where a caller is, so that it can make a placement pass
+// happen exactly there (in the middle of a routing round) instead of waiting for the scheduler to arrange it
+#ifdef GUBER_POOL_TEST_HOOKS
+extern "C" void guber_pool_test_hook(int where, uint32_t i, uint32_t n);
+#define HOOK(where, i, n) guber_pool_test_hook(where, i, n)
+#else
+#define HOOK(where, i, n) do {} while (0)
+#endif
+
 namespace gubernator {
 
 // Callers wait for their generation — and the dispatcher for work — on plain futex words: an announcement wakes exactly the
@@ -367,6 +384,7 @@ struct GPUWorkerPool::Call {
         while (!S.todo.empty()) {
             S.vers.assign(P.n_devices_, 0xffffffffu);
             S.count.assign(n_shards + 1, 0);
+            [[maybe_unused]] uint32_t routed_so_far = 0;
             for (uint32_t i : S.todo) {
                 const uint32_t dv = S.dev[i];
                 Device& d = *P.devs_[dv];
@@ -375,6 +393,7 @@ struct GPUWorkerPool::Call {
                 const uint32_t j = P.routed_ ? dv : dv * P.shards_per_device_ + e;
                 S.shard[i] = j; S.eng[i] = (uint8_t)e;
                 S.count[j + 1]++;
+                HOOK(1, routed_so_far++, (uint32_t)S.todo.size());
             }
             for (uint32_t j = 0; j < n_shards; ++j) S.count[j + 1] += S.count[j];
             const uint32_t base = (uint32_t)S.order.size();
@@ -419,6 +438,13 @@ struct GPUWorkerPool::Call {
             }
             PH(2);
             S.todo.swap(S.next);
+            // What was refused goes into the next round IN THE CALL'S ORDER.  The lists above are per shard, and a round that was
+            // routing while a placement pass published (the version it holds is the old one: everything it reserves from here on is
+            // refused) may have put the earlier requests of a moving key on the old shard's list and the later ones on the new
+            // shard's; taken list by list, the later ones would come first in the next round and be evaluated first.  (Found under
+            // ThreadSanitizer's timing with stages per shard, GUBER_POOL_ROUTED=0: the answers of one RPC's hot key came out
+            // permuted, the totals right.  With one front stage per device a device has ONE list, in arrival order.)
+            if (S.todo.size() > 1 && n_shards > 1) std::sort(S.todo.begin(), S.todo.end());
             if (closed) { for (uint32_t i : S.todo) sink.closed(i); S.todo.clear(); }
         }
         P.leave();                                                   // (waiting for the answers needs no CPU)
@@ -563,12 +589,12 @@ struct GPUWorkerPool::Call {
             const uint32_t seq = sh.open_seq.load(std::memory_order_acquire);
             const uint32_t k = sh.open.load(std::memory_order_acquire);
             if (k == kOpenDead) return 0;
-            if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver) return -1;
+            if ((d.ver.load(std::memory_order_acquire) & 0x7fu) != ver) { PT("refused", &sh, ver, d.ver.load(), count); return -1; }
             if (k < kStages) {
                 Stage& s = sh.st[k];
                 uint64_t w = s.word.load(std::memory_order_acquire);
                 while (!(w & kClosed)) {
-                    if (word_ver(w) != ver) return -1;
+                    if (word_ver(w) != ver) { PT("refused_word", &s, ver, word_ver(w), count); return -1; }
                     const uint32_t cnt = word_count(w), kbytes = word_bytes(w);
                     const uint32_t room = P.stage_cap_ - cnt;
                     uint32_t take = std::min(room, count); uint64_t bytes = 0;
@@ -591,6 +617,7 @@ struct GPUWorkerPool::Call {
                     }
                     if (s.word.compare_exchange_weak(w, w + take + (bytes << 32), std::memory_order_acq_rel, std::memory_order_acquire)) {
                         *out = Ticket2{&s, s.gen.load(std::memory_order_relaxed), cnt, take, pos, kbytes, false};
+                        PT("reserve", &s, out->gen, (uint64_t)cnt << 32 | take, (uint64_t)ver << 32 | S.order[pos]);
                         const bool first = cnt == 0, full = cnt + take >= P.stage_cap_;
                         const int64_t now = mono_us();
                         if (first) s.first_us.store(now, std::memory_order_release);
@@ -841,6 +868,7 @@ void GPUWorkerPool::open_stage(Shard& sh, uint32_t k, uint32_t ver) {
     if (sh.front) for (auto& c : s.eng_n) c.store(0, std::memory_order_relaxed);
     s.gen.store(s.gen.load() + 1);
     s.state = Stage::kOpen;
+    PT("open", &s, s.gen.load(), ver, k);
     s.word.store((uint64_t)(ver & 0x7fu) << 56, std::memory_order_release);
     sh.cur = k;
     sh.open.store(k, std::memory_order_release);
@@ -862,6 +890,7 @@ int GPUWorkerPool::find_free(Shard& sh) {
 void GPUWorkerPool::seal(Shard& sh, Stage& s, std::vector<Stage*>& due) {
     const uint64_t w = s.word.fetch_or(kClosed, std::memory_order_acq_rel);
     s.n = word_count(w);
+    PT("seal", &s, s.gen.load(), s.n, word_ver(w));
     if (s.n == 0) { s.state = Stage::kFree; return; }
     ((uint32_t*)s.b->key_off)[s.n] = word_bytes(w);
     s.state = Stage::kSealed;
@@ -938,7 +967,9 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
         for (Stage* s : due) {
             int rc;
             const int64_t ts = mono_us();
-            if (dev_route_ && s->n <= 256) {                         // a handful of requests: routed here (one launch then, no round trip for the sizes)
+            if (dev_route_ && s->n <= 256 && d.routing_q.empty()) {  // a handful of requests: routed here (one launch then, no round trip for the sizes)
+                // (only while no earlier generation is still waiting for its shares' sizes: that one's batch is enqueued when they are
+                // back, and a generation submitted here meanwhile would be evaluated BEFORE it — the second half of an RPC ahead of the first)
                 route_on_host(d, *s);
                 uint32_t counts[kMaxEngines];
                 for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_relaxed);
@@ -954,7 +985,7 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
                     rule.global_engine = has_global_ ? (int32_t)d.n_plain : -1;
                 }
                 rc = guber_stage_route(s->stage, d.rule_dirty ? &rule : nullptr, ne);
-                if (rc == GUBER_OK) { d.rule_dirty = false; s->routing = true; }
+                if (rc == GUBER_OK) { d.rule_dirty = false; s->routing = true; d.routing_q.push_back(s); }
             } else {
                 uint32_t counts[kMaxEngines];
                 for (uint32_t j = 0; j < ne; ++j) counts[j] = s->eng_n[j].load(std::memory_order_acquire);
@@ -976,6 +1007,7 @@ void GPUWorkerPool::submit_due(Device& d, std::vector<Stage*>& due, std::vector<
         for (uint32_t q = 0; q < m; ++q) arr[q] = due[lo + q]->stage;
         uint32_t done = 0;
         const int64_t ts = mono_us();
+        for (uint32_t q = 0; q < m; ++q) PT("submit", due[lo + q], due[lo + q]->gen.load(), due[lo + q]->n, q);
         const int rc = guber_stages_submit(arr, m, GUBER_STAGES_NO_AGGREGATES, &done);
         d.submit_us.fetch_add((uint64_t)(mono_us() - ts), std::memory_order_relaxed); d.submits.fetch_add(1, std::memory_order_relaxed);
         for (uint32_t q = 0; q < m; ++q) {
@@ -996,6 +1028,7 @@ bool GPUWorkerPool::submit_routed_now(Device& d, Stage& s, const uint32_t* count
     guber_engine_t* eng[kMaxEngines];
     const uint32_t ne = (uint32_t)d.shards.size();
     for (uint32_t j = 0; j < ne; ++j) eng[j] = d.shards[j]->engine;
+    PT("submit_routed", &s, s.gen.load(), s.n, 0);
     const int rc = guber_stage_submit_routed(s.stage, eng, ne, counts);
     s.submitted = rc == GUBER_OK;
     if (rc != GUBER_OK) s.rc = rc;
@@ -1011,20 +1044,30 @@ void GPUWorkerPool::finish(Stage& s) {
 // look at the stages in flight; announce the ones whose responses are there.  Returns whether any finished.
 bool GPUWorkerPool::poll(std::vector<Stage*>& inflight) {
     bool any = false;
-    for (size_t q = 0; q < inflight.size();) {
-        Stage* s = inflight[q];
-        if (s->routing) {                                            // the device is deciding the shards: sizes back -> the batch itself goes
+    // generations whose shards the device is deciding (guber_stage_route): the sizes are back -> the batch itself goes.  Strictly in
+    // the order they were sealed: the batches are evaluated in the order they are enqueued HERE, and the halves of an RPC that spans
+    // two generations must be evaluated in that order (round 4 looked at them in the order of `inflight`, which swap-removes, and let a
+    // small generation that is routed on the host overtake: the answers of such an RPC came out permuted — found under ThreadSanitizer's
+    // timing)
+    if (!inflight.empty()) {
+        Device& d = *inflight[0]->shard->dev;
+        while (!d.routing_q.empty()) {
+            Stage* s = d.routing_q.front();
             uint32_t counts[kMaxEngines] = {0};
             const int r = guber_stage_route_poll(s->stage, counts);
-            if (r == 0) { ++q; continue; }
+            if (r == 0) break;
+            d.routing_q.pop_front();
             s->routing = false;
             any = true;
-            if (r > 0 && submit_routed_now(*s->shard->dev, *s, counts)) { ++q; continue; }
+            if (r > 0 && submit_routed_now(d, *s, counts)) continue;
             if (r < 0) s->rc = r;
             finish(*s);
-            inflight[q] = inflight.back(); inflight.pop_back();
-            continue;
+            for (size_t q = 0; q < inflight.size(); ++q) if (inflight[q] == s) { inflight[q] = inflight.back(); inflight.pop_back(); break; }
         }
+    }
+    for (size_t q = 0; q < inflight.size();) {
+        Stage* s = inflight[q];
+        if (s->routing) { ++q; continue; }                           // (its turn comes above)
         const int r = guber_stage_poll(s->stage);
         if (r == 0) { ++q; continue; }
         s->rc = r < 0 ? r : guber_stage_wait(s->stage);              // (already complete: resolves the rare internal retry)
@@ -1041,6 +1084,7 @@ void GPUWorkerPool::announce(Shard& sh, Stage& s) {
     sh.send_us_sum += us;
     if (us > sh.send_us_max.load(std::memory_order_relaxed)) sh.send_us_max.store(us, std::memory_order_relaxed);
     sh.flushed++; sh.in_flight--;
+    PT("announce", &s, s.gen.load(), s.n, s.rc);
     s.state = Stage::kDraining;
     s.done_gen.store((uint32_t)s.gen.load(), std::memory_order_seq_cst);
     if (s.sleepers.load(std::memory_order_seq_cst) > 0) futex_wake_n(&s.done_gen, 2);
@@ -1060,10 +1104,11 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
     if (!d.place || d.n_plain < 2) return;
     guber_placement_move_t moves[64];
     uint32_t nm = 0;
-    if (guber_placement_plan(d.place, 0.125, moves, 64, &nm) != GUBER_OK) { (void)guber_placement_commit(d.place); return; }
+    if (guber_placement_plan(d.place, 0.125, moves, 64, &nm) != GUBER_OK) return;   // (nothing published: the next pass plans afresh)
     d.rebalances++;
     if (nm == 0) { (void)guber_placement_commit(d.place); return; }  // (keys pinned where they are change nothing a caller can see)
     std::vector<Stage*> due;
+    PT("rebalance", &d, nm, d.ver.load(), inflight.size());
     for (Shard* sh : d.staging) {
         if (sh->open.load(std::memory_order_relaxed) == kOpenNone) continue;
         sh->open.store(kOpenNone, std::memory_order_release);
@@ -1078,6 +1123,7 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
             if (moves[q].from >= d.n_plain || moves[q].to >= d.n_plain) continue;
             uint32_t moved = 0;
             const int mrc = guber_move_items_by_hash(d.shards[moves[q].from]->engine, d.shards[moves[q].to]->engine, &moves[q].key_hash, 1, &moved);
+            PT("move", moves[q].key_hash, moves[q].from, moves[q].to, moved);
             // a bucket that did not arrive (an error, a full or colliding destination) went back to its table: its key must keep
             // following its slot, or its requests would start a fresh bucket elsewhere.  (moved == 0 with no error also means
             // "the hash named no live bucket" — nothing to lose, the new placement may stand.)
@@ -1089,6 +1135,7 @@ void GPUWorkerPool::rebalance(Device& d, std::vector<Stage*>& inflight) {
         d.ver.fetch_add(1, std::memory_order_acq_rel);
     }
     const uint32_t ver = d.ver.load();
+    PT("rebalanced", &d, ver, 0, 0);
     for (Shard* sh : d.staging) {
         const int k = find_free(*sh);
         if (k >= 0) open_stage(*sh, (uint32_t)k, ver);               // (none free: seal_if_due opens one as soon as its callers have read it out)

@@ -40,6 +40,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -188,6 +189,7 @@ class GPUWorkerPool {
         std::atomic<uint64_t> rebalances{0}, moves{0}, submit_us{0}, submits{0};
         uint32_t gen_seq = 0, gen_left[8] = {0}, gens_in_flight = 0;   // dispatcher: submissions whose batches are not all back
         bool rule_dirty = true;                           // dispatcher: the device has not seen the current placement yet (guber_stage_route)
+        std::deque<Stage*> routing_q;                     // dispatcher: generations waiting for their shares' sizes (guber_stage_route), oldest first
     };
     struct Ticket2 { Stage* st; uint64_t gen; uint32_t first_slot, count, list_begin, key_base; bool consumed; };
     struct Scratch;                                       // per-thread buffers of a call

@@ -20,7 +20,6 @@ using namespace guber;
 // ---- a table and the per-batch work arrays in host memory, laid out as guber_engine_create does -----------------------------
 struct DevSim {
     uint64_t slots = 0; uint32_t max_batch = 0, cap = 0;
-    bool eval3_split = false;                                      // k_eval3 as two launches (GUBER_EVAL3_SPLIT)
     uint32_t pmode[8] = {7, 0, 0, 0, 7, 7, 0, 0};                  // Work::pmode: the owner count follows the traffic (guber_kernels_part.h); [4..5]: per batch parity (fuse_ep)
     bool fuse_ep = false; uint64_t part_seq = 0;                   // GUBER_FUSE_EP: every owner-partitioned batch reads its parity's slot, did3 is double-buffered
     Table T{}; Work W{};
@@ -121,7 +120,7 @@ void* ds_create_bounded(uint64_t slots, uint32_t max_batch, int weak_hash, uint6
     d->W.slot = d->u32.data(); d->W.rflags = d->rflags.data();
     d->W.seg_tilemask = d->tilemask.data(); d->W.srec = d->srec.data(); d->W.sinv = d->sinv.data(); d->W.tilerow = d->tilerow.data();
     d->W.claims = d->claims.data();
-    d->W.gmsg = d->gmsg.data(); d->W.gshape = (GShape*)((char*)d->gmsg.data() + (size_t)d->cap * 32);
+    d->W.gmsg = d->gmsg.data();
     d->W.grs = (GRecS*)d->grec.data(); d->W.grec = d->grec.data() + d->cap / 2; d->W.gse = d->gse.data(); d->W.segtiles = d->segtiles.data();
     uint32_t lg = 0; while ((1ull << lg) < s) lg++;
     d->W.pshift = lg - 8;
@@ -132,7 +131,6 @@ void ds_destroy(void* h) { delete (DevSim*)h; }
 // owners per batch: bits = 7 | 8 pinned, 0 = follow the traffic (the default); ds_owner_bits: what the next batch will use
 void ds_pin_owner_bits(void* h, uint32_t bits) { DevSim* d = (DevSim*)h; d->pmode[3] = bits ? 1u : 0u; if (bits) d->pmode[0] = d->pmode[4] = d->pmode[5] = bits; d->pmode[1] = d->pmode[2] = 0; }
 uint32_t ds_owner_bits(void* h) { return ((DevSim*)h)->pmode[0]; }
-void ds_eval3_split(void* h, int on) { ((DevSim*)h)->eval3_split = on != 0; }
 // batches left with 256 owners (pmode[1]): read, or shorten for a test (n != 0)
 uint32_t ds_owner_hold(void* h, uint32_t n) { DevSim* d = (DevSim*)h; if (n) d->pmode[1] = n; return d->pmode[1]; }
 void ds_chaos(uint32_t on) { fakehip::S.chaos = on; }
@@ -213,11 +211,7 @@ static int ds_eval_piece(DevSim* d, const BatchView& B, const ResultView& R, int
         fakehip::launch(dim3(tiles), dim3(FT), nullptr, [&] { k_part(d->T, B, W); });
         fakehip::launch(dim3(PT_PARTS), dim3(256), nullptr, [&] { k_own(d->T, B, W, tiles); });
         EvalArgs A{d->T, B, R, W};
-        if (d->eval3_split) {
-            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3f(A); });
-            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3s(A); });
-        } else
-            fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
+        fakehip::launch(dim3(tiles), dim3(256), &A, [&] { k_eval3(A); });
         for (auto v : d->segtiles) if (v) return -2;      // the walk's tile maps must be all zero between batches
     }
     return 0;
@@ -270,8 +264,7 @@ int ds_eval_stream_ep(void* const* hs, uint32_t nh, const guber_batch_t* batches
     for (uint32_t j = 0; j < nh; ++j) for (auto v : ((DevSim*)hs[j])->segtiles) if (v) return -2;
     return 0;
 }
-// the last owner-partitioned batch: (key, tile) groups, of which answered by a 32-byte record, of which sent with the tile's shape
-// (0, 0 in a build without GUBER_PART_COMPACT)
+// the last owner-partitioned batch: (key, tile) groups, of which answered by a 32-byte record (out[2]: unused)
 void ds_part_forms(void* h, uint32_t n, unsigned long long* out) {
     DevSim* d = (DevSim*)h;
     out[0] = out[1] = out[2] = 0;
@@ -281,12 +274,7 @@ void ds_part_forms(void* h, uint32_t n, unsigned long long* out) {
         for (uint32_t p = 0; p < PT_PARTS; ++p) groups += d->gse[(size_t)t * PT_PARTS + p] >> 16;
         out[0] += groups;
         for (uint32_t j = 0; j < groups; ++j) {
-#if GUBER_PART_REC32
             out[1] += d->W.grs[(size_t)t * FT + j].pk & 1ull;
-#endif
-#if GUBER_PART_MSG32
-            out[2] += (gm_flags(((const GMsgS*)d->W.gmsg)[(size_t)t * FT + j].misc) & G_SHAPE0) ? 1 : 0;
-#endif
         }
     }
 }

@@ -14,6 +14,46 @@
 #include "../../include/guber_gpu.h"
 #include "../../oracle/guber_oracle.h"
 
+// ---- trace ring (builds with -DGUBER_POOL_TRACE: the pool reports reservations / seals / submissions / moves through guber_pool_trace,
+// the stub adds what each engine evaluated; pool_test.cpp prints the ring on the first mismatch) ----
+#include <atomic>
+#include <string>
+struct TraceEv { int64_t us; uint64_t tid; const char* what; const void* obj; uint64_t a, b, c; };
+static TraceEv g_ring[1 << 15];
+static std::atomic<uint64_t> g_ring_n{0};
+extern "C" void guber_pool_trace(const char* what, const void* obj, uint64_t a, uint64_t b, uint64_t c) {
+    const uint64_t k = g_ring_n.fetch_add(1);
+    TraceEv& e = g_ring[k & ((1u << 15) - 1)];
+    e.us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    e.tid = (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) & 0xffff; e.what = what; e.obj = obj; e.a = a; e.b = b; e.c = c;
+}
+extern "C" void guber_pool_trace_dump(uint32_t last) {
+    const uint64_t n = g_ring_n.load();
+    const uint64_t lo = n > last ? n - last : 0;
+    for (uint64_t k = lo; k < n; ++k) {
+        const TraceEv& e = g_ring[k & ((1u << 15) - 1)];
+        fprintf(stderr, "TRACE %lld t%04llx %-14s %p %llx %llx %llx\n", (long long)e.us, (unsigned long long)e.tid, e.what, e.obj, (unsigned long long)e.a, (unsigned long long)e.b, (unsigned long long)e.c);
+    }
+}
+#ifdef GUBER_POOL_TRACE
+// what an engine evaluated: per batch, for every "*_hot" key the number of its requests and the first one's answer
+static void trace_eval(const void* eng, const void* stage, const guber_batch_t* b, const guber_result_t* r) {
+    struct K { uint64_t h; uint32_t n; int64_t first; };
+    std::vector<K> ks;
+    for (uint32_t i = 0; i < b->n; ++i) {
+        const uint32_t off = b->key_off[i], len = b->key_off[i + 1] - off;
+        if (len < 4 || memcmp(b->key_bytes + off + len - 4, "_hot", 4) != 0) continue;
+        const uint64_t h = guber_xxhash64(b->key_bytes + off, len, 0);
+        bool seen = false;
+        for (auto& k : ks) if (k.h == h) { k.n++; seen = true; break; }
+        if (!seen) ks.push_back({h, 1, r->remaining[i]});
+    }
+    for (auto& k : ks) { guber_pool_trace("eval", eng, k.h, k.n, (uint64_t)k.first); guber_pool_trace("  in stage", stage, b->n, 0, 0); }
+}
+#else
+static void trace_eval(const void*, const void*, const guber_batch_t*, const guber_result_t*) {}
+#endif
+
 struct guber_engine { oracle_t* o; std::mutex mu; uint32_t max_batch; uint64_t cache_size; guber_route_rule_t rule{}; bool have_rule = false;
                       // the rule's arrays are COPIED at the call, as the engine uploads them (guber_engine.hip guber_stage_route): the caller's snapshot may be retired afterwards
                       std::vector<uint16_t> rt_table, rt_exs; std::vector<uint64_t> rt_exh; };
@@ -61,7 +101,7 @@ extern "C" int guber_stage_submit(guber_stage_t* s) {
     {   // evaluation order = submission order, like the engine stream
         std::lock_guard<std::mutex> lk(s->e->mu);
         static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;   // measure the pool alone (tools/bench_pool.cpp on a CPU box)
-        if (s->b.n && !null_engine) oracle_eval_batch(s->e->o, &s->b, &s->r);
+        if (s->b.n && !null_engine) { oracle_eval_batch(s->e->o, &s->b, &s->r); trace_eval(s->e, s, &s->b, &s->r); }
         if (null_engine) memset(s->err.data(), 0, s->b.n);
     }
     s->in_flight = true;
@@ -189,6 +229,7 @@ extern "C" int guber_stage_submit_routed(guber_stage_t* s, guber_engine_t* const
         {
             std::lock_guard<std::mutex> lk(engines[j]->mu);
             oracle_eval_batch(engines[j]->o, &b, &res);
+            trace_eval(engines[j], s, &b, &res);
         }
         for (uint32_t r = 0; r < nj; ++r) {
             const uint32_t i = at[r];
@@ -230,7 +271,7 @@ extern "C" int guber_global_sync(guber_comm_t*, int64_t, guber_global_sync_stats
 extern "C" int guber_eval_batch(guber_engine_t* e, const guber_batch_t* b, guber_result_t* r) {
     std::lock_guard<std::mutex> lk(e->mu);
     static const bool null_engine = getenv("GUBER_STUB_NULL") != nullptr;
-    if (b->n && !null_engine) oracle_eval_batch(e->o, b, r);
+    if (b->n && !null_engine) { oracle_eval_batch(e->o, b, r); trace_eval(e, nullptr, b, r); }
     if (null_engine) memset(r->err, 0, b->n);
     else { static thread_local std::mt19937 rng{99}; std::this_thread::sleep_for(std::chrono::microseconds(rng() % 40)); }   // the launch + the GPU take a while
     return GUBER_OK;

@@ -3,6 +3,7 @@
 // order — across shard routing, partial reservations (RPCs larger than what a stage still takes), stage rotation, many
 // concurrent callers and shutdown under load.  Built plain and with -fsanitize=thread by tests/test_pool_cpu.py.
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +18,8 @@
 using namespace gubernator;
 static const int64_t NOW0 = 1700000000000ll;
 static int failures = 0;
-#define CHECK(c, ...) do { if (!(c)) { if (++failures < 20) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } } while (0)
+extern "C" void guber_pool_trace_dump(uint32_t last);      // engine_stub.cpp: the trace ring (events only in -DGUBER_POOL_TRACE builds)
+#define CHECK(c, ...) do { if (!(c)) { if (++failures < 20) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } if (failures == 1) guber_pool_trace_dump(6000); } } while (0)
 
 // the oracle on a list of requests, in order (keys = HashKey)
 struct Ref {
@@ -70,11 +72,35 @@ static void compare(const std::vector<RateLimitReq>& reqs, const std::vector<Rat
     }
 }
 
+// the pool tells where a caller is (worker_pool.cpp HOOK, test builds): a thread that armed the hook gets a placement pass in the
+// MIDDLE of its routing round — the requests routed before it see the old placement, the ones after it the new one, and everything
+// the round reserves afterwards is refused (its version is the old one) and goes into the next round
+static GPUWorkerPool* g_hook_pool = nullptr;
+static thread_local bool g_hook_armed = false;
+static std::atomic<long> g_hook_passes{0};
+extern "C" void guber_pool_test_hook(int where, uint32_t i, uint32_t n) {
+    if (where != 1 || !g_hook_armed || !g_hook_pool || n < 8 || i != n / 2) return;
+    guber_pool_metrics_t m0{}; g_hook_pool->Metrics(&m0);
+    g_hook_pool->RebalanceNow();
+    for (int spin = 0; spin < 2000; ++spin) {                   // (until the pass has run: <= 100 ms)
+        guber_pool_metrics_t m{}; g_hook_pool->Metrics(&m);
+        if (m.rebalances != m0.rebalances) { g_hook_passes++; break; }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
 int main(int argc, char** argv) {
     const int scale = argc > 1 ? atoi(argv[1]) : 1;       // 1 = full, larger = shorter runs (sanitizer builds)
     guber_config_t cfg{};
     cfg.cache_size = 600000; cfg.max_batch = 64;
-    {   // 1. one caller, three shards, tiny stages: RPCs span several stages and generations, order per key is kept
+    // GUBER_POOL_TEST_ONLY=5,9: only these blocks (chasing a rare failure of one of them); unset = all
+    auto on = [](int block) {
+        const char* v = getenv("GUBER_POOL_TEST_ONLY");
+        if (!v || !*v) return true;
+        for (const char* p = v; *p;) { if (atoi(p) == block) return true; while (*p && *p != ',') ++p; if (*p) ++p; }
+        return false;
+    };
+    if (on(1)) {   // 1. one caller, three shards, tiny stages: RPCs span several stages and generations, order per key is kept
         GPUWorkerPool pool(cfg, 64, 100, 3);
         V1Instance inst(&pool);
         Ref ref;
@@ -94,7 +120,7 @@ int main(int argc, char** argv) {
               (unsigned long long)m.batch_size_max, m.shards);
         printf("single caller: %llu batches, %llu requests, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests, failures);
     }
-    {   // 2. many callers: each thread owns its keys (exact comparison with its own oracle) and all hammer one shared key
+    if (on(2)) {   // 2. many callers: each thread owns its keys (exact comparison with its own oracle) and all hammer one shared key
         GPUWorkerPool pool(cfg, 512, 200, 4);
         V1Instance inst(&pool);
         pool.SetClockMs(NOW0);
@@ -122,7 +148,7 @@ int main(int argc, char** argv) {
         printf("concurrent callers: %llu batches, %llu requests (max batch %llu), shared key %ld/%ld under, failures so far %d\n",
                (unsigned long long)m.batches, (unsigned long long)m.requests, (unsigned long long)m.batch_size_max, shared_under.load(), shared_total.load(), failures);
     }
-    {   // 3. per-item errors that never reach (or come back from) the device
+    if (on(3)) {   // 3. per-item errors that never reach (or come back from) the device
         guber_config_t c2 = cfg; c2.max_key_bytes = 64;
         GPUWorkerPool pool(c2, 64, 100, 2);
         V1Instance inst(&pool);
@@ -139,7 +165,7 @@ int main(int argc, char** argv) {
         guber_pool_metrics_t m{}; pool.Metrics(&m);
         CHECK(m.key_too_long == 1, "key_too_long %llu", (unsigned long long)m.key_too_long);
     }
-    {   // 4. Close() under load: every call returns, with answers or with the pool's closed error
+    if (on(4)) {   // 4. Close() under load: every call returns, with answers or with the pool's closed error
         GPUWorkerPool pool(cfg, 256, 100, 3);
         V1Instance inst(&pool);
         std::atomic<bool> stop{false}; std::atomic<long> ok{0}, closed{0}, other{0};
@@ -161,7 +187,7 @@ int main(int argc, char** argv) {
         CHECK(ok.load() > 0 && closed.load() > 0 && other.load() == 0, "close under load: ok %ld closed %ld other %ld", ok.load(), closed.load(), other.load());
         printf("close under load: %ld answered, %ld refused, failures so far %d\n", ok.load(), closed.load(), failures);
     }
-    {   // 5. placement passes under load: every thread hammers a key of its own (exact comparison with its own oracle) while the
+    if (on(5)) {   // 5. placement passes under load: every thread hammers a key of its own (exact comparison with its own oracle) while the
         //    dispatcher is asked for a rebalance every few milliseconds — hot keys move to other shards WITH their buckets, at
         //    batch boundaries, and no request of a key is evaluated out of order or against a stale bucket
         GPUWorkerPool pool(cfg, 256, 150, 4);
@@ -198,7 +224,7 @@ int main(int argc, char** argv) {
         printf("placement passes: %llu passes, %llu hot keys moved, %llu batches, failures so far %d\n", (unsigned long long)m.rebalances,
                (unsigned long long)m.keys_moved, (unsigned long long)m.batches, failures);
     }
-    {   // 6. the C entry point a binding calls (structure-of-arrays in and out, V1Instance front end folded in) against the same oracle
+    if (on(6)) {   // 6. the C entry point a binding calls (structure-of-arrays in and out, V1Instance front end folded in) against the same oracle
         guber_pool_t* cp = nullptr;
         CHECK(guber_pool_create_sharded(&cfg, 3, 128, 100, &cp) == GUBER_OK, "pool create");
         guber_pool_set_clock(cp, NOW0);
@@ -236,7 +262,7 @@ int main(int argc, char** argv) {
         guber_pool_destroy(cp);
         printf("C entry point: failures so far %d\n", failures);
     }
-    {   // 7. RPCs of a handful of requests: the caller evaluates them itself when nobody else is at the shard, otherwise they travel in
+    if (on(7)) {   // 7. RPCs of a handful of requests: the caller evaluates them itself when nobody else is at the shard, otherwise they travel in
         //    stages — both ways while placement passes move the hot keys; exact per thread, the shared key exact in total
         GPUWorkerPool pool(cfg, 256, 150, 4);
         V1Instance inst(&pool);
@@ -273,7 +299,7 @@ int main(int argc, char** argv) {
         printf("small RPCs: %llu batches of which %llu evaluated by their callers, %llu hot keys moved, failures so far %d\n", (unsigned long long)m.batches,
                (unsigned long long)m.direct_batches, (unsigned long long)m.keys_moved, failures);
     }
-    {   // 8. ONE shard on one device (the reference's Workers = 1): the callers reserve first and touch every request once (no hash on
+    if (on(8)) {   // 8. ONE shard on one device (the reference's Workers = 1): the callers reserve first and touch every request once (no hash on
         //    the host); tiny stages, so RPCs span stages and generations; over-long keys and empty fields answered in between
         guber_config_t c8 = cfg; c8.max_key_bytes = 64;
         GPUWorkerPool pool(c8, 96, 100, 1);
@@ -307,7 +333,7 @@ int main(int argc, char** argv) {
         CHECK(m.batch_size_max <= 96 && m.shards == 1 && m.key_too_long > 0, "metrics: max %llu shards %u too long %llu", (unsigned long long)m.batch_size_max, m.shards, (unsigned long long)m.key_too_long);
         printf("one shard: %llu batches, %llu requests, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests, failures);
     }
-    {   // 9. three devices x two shards (logical devices: the ring decides, replicated_hash.go:104-119): every device has a front stage
+    if (on(9)) {   // 9. three devices x two shards (logical devices: the ring decides, replicated_hash.go:104-119): every device has a front stage
         //    of its own, an RPC is split by owner and answered in place, placement passes run on every device
         GPUWorkerPool pool(cfg, 128, 100, 2, std::vector<int32_t>{0, 0, 0});
         V1Instance inst(&pool);
@@ -340,6 +366,40 @@ int main(int argc, char** argv) {
         CHECK(m.devices == 3 && m.shards == 6 && m.in_flight == 0, "metrics: %u devices %u shards", m.devices, m.shards);
         printf("several devices: %llu batches, %llu requests, %llu placement passes, failures so far %d\n", (unsigned long long)m.batches, (unsigned long long)m.requests,
                (unsigned long long)m.rebalances, failures);
+    }
+    if (on(10)) {   // 10. a placement pass in the MIDDLE of a routing round (the hook above), RPC after RPC: hot keys move between the requests
+        //     a caller has routed and the ones it has not; what the round reserves afterwards is refused and routed again.  Every key's
+        //     requests must still be answered in the caller's order.  (Round 4's pool re-queued the refused requests shard list by
+        //     shard list: with stages per shard the later requests of a moving key came first — the answers of one RPC permuted.)
+        GPUWorkerPool pool(cfg, 256, 150, 4);
+        V1Instance inst(&pool);
+        pool.SetClockMs(NOW0);
+        g_hook_pool = &pool; g_hook_passes = 0;
+        std::vector<std::thread> th;
+        for (int t = 0; t < 4; ++t) th.emplace_back([&, t] {
+            Ref ref; std::mt19937 rng(1500 + t);
+            const std::string ns = "hk" + std::to_string(t);
+            for (int it = 0; it < 240 / scale; ++it) {
+                std::vector<RateLimitReq> reqs = random_rpc(rng, ns, 25, 200);
+                // two hot keys per thread taking turns (a key that stays hot is pinned once and never moves again; one that cools down
+                // for a few passes loses its pin and is moved back, then forth again)
+                const std::string hot = (it / 12) % 2 ? "hotA" : "hotB";
+                for (size_t q = 0; q < reqs.size(); ++q)
+                    if (rng() % 4 != 0) { reqs[q].unique_key = hot; reqs[q].algorithm = t % 2; reqs[q].hits = 1; reqs[q].limit = 1000000; reqs[q].duration = 3600000; reqs[q].behavior = 0; }
+                std::vector<RateLimitResp> resps; std::string err;
+                g_hook_armed = true;
+                const bool okc = inst.GetRateLimits(reqs, &resps, &err);
+                g_hook_armed = false;
+                CHECK(okc, "rpc failed: %s", err.c_str());
+                compare(reqs, resps, ref, NOW0, "pass inside a routing round");
+            }
+        });
+        for (auto& x : th) x.join();
+        g_hook_pool = nullptr;
+        guber_pool_metrics_t m{}; pool.Metrics(&m);
+        const bool device_routes = getenv("GUBER_POOL_DEVROUTE") && atoi(getenv("GUBER_POOL_DEVROUTE"));   // (its callers do not route: no rounds to be inside of)
+        CHECK(device_routes || (g_hook_passes.load() > 20 && m.keys_moved > 0), "passes inside routing rounds %ld, keys moved %llu", g_hook_passes.load(), (unsigned long long)m.keys_moved);
+        printf("pass inside a routing round: %ld such passes, %llu hot keys moved, failures so far %d\n", g_hook_passes.load(), (unsigned long long)m.keys_moved, failures);
     }
     printf(failures ? "POOL TEST FAILED (%d)\n" : "POOL TEST OK\n", failures);
     return failures ? 1 : 0;

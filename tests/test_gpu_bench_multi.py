@@ -1,0 +1,63 @@
+"""bench.py's N > 1 path, rehearsed on a box with ONE GPU (the driver's SCALE run is the first time it sees 2, 4, 8):
+
+  * `python bench.py --gpus 2 ...` invoked PLAINLY (no WORLD_SIZE: the shape of the driver's 1-GPU command) re-executes itself under
+    torch.distributed.run, one rank per "GPU" (--one-device: both ranks on GPU 0, --backend gloo for the timing collectives);
+  * every rank digest-checks its own timed stream against its own oracle — the ranks own disjoint keys on the reference's ring
+    (replicated_hash.go:104-119) — and rank 0 prints `parity: "2/2 ranks, K/K timed batches each"`, a cpu_baseline and the roofline
+    object; a line without a parity verdict is refused;
+  * the aggregate of two ranks that SHARE one GPU is compared with the N = 1 run of the same flags (they time-slice one device: the
+    aggregate is about the N = 1 value, never a multiple of it);
+  * --global-sync (BASELINE config 5) with two PROCESSES: guber_comm_create_rank + the product's ncclSend / ncclRecv sequence through
+    the test-only librccl for ranks that share a GPU (tests/hostsim/fake_rccl.cpp), replicas converged or no line.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FAKE = os.path.join(HERE, "hostsim", "libfake_rccl.so")
+COMMON = ["--keys", "2000000", "--min-batches", "256", "--steps", "256", "--warmup", "8", "--extras", "", "--latency-steps", "0", "--profile-steps", "32",
+          "--cpu-threads", "8", "--cpu-seconds", "1"]
+
+
+def _bench(extra, env=None, timeout=900):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_device_are_parity_gated_and_agree_with_one_rank():
+    one = _bench(["--gpus", "1"] + COMMON)
+    assert one["n_gpus"] == 1 and one["parity"] and one["parity"] != "FAILED" and one["steps"] == 256 and one["steps_requested"] == 256
+    two = _bench(["--gpus", "2", "--one-device", "--backend", "gloo"] + COMMON)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["parity"].startswith("2/2 ranks, 256/256 timed batches each"), two["parity"]
+    assert two["parity_batches_by_rank"] == [256, 256]
+    assert two["cpu_baseline"] and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["kind"] == "port"
+    assert two["roofline"] and two["roofline"]["bound"] == "hbm" and 0 < two["roofline"]["frac"] < 1
+    assert two["config"]["ranks_seen_by_the_collective_backend"] == 2
+    res = two["config"]["resident_items_by_rank"]
+    assert len(res) == 2 and all(r == 2_000_000 for r in res), res          # (--keys is per GPU: weak scaling)
+    ratio = two["value"] / one["value"]
+    print(f"bench.py --gpus 2 on ONE device: {two['value'] / 1e9:.2f} G/s against {one['value'] / 1e9:.2f} G/s for --gpus 1 (ratio {ratio:.2f})")
+    # two processes time-slicing one GPU: the aggregate stays in the neighbourhood of one process's rate (a multiple would mean the
+    # ranks' work or the clock is counted wrongly; a collapse, that the ranks serialise on something that is not the GPU)
+    assert 0.5 < ratio < 1.4, ratio
+
+
+def test_global_leg_with_two_processes_through_the_rccl_call_sequence():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "hostsim"), "fake_rccl"], check=True)
+    out = _bench(["--gpus", "2", "--one-device", "--backend", "gloo", "--global-sync", "8", "--keys", "200000", "--steps", "32", "--warmup", "8"],
+                 env={"GUBER_RCCL_LIB": FAKE})
+    assert out["n_gpus"] == 2 and out["global_sync"]["replicas_converged"] is True and out["global_sync"]["host_fallbacks"] == 0
+    assert out["parity"].startswith("2/2 ranks"), out["parity"]
+    assert out["global_sync"]["syncs"] >= 4 and out["global_sync"]["avg_hits_rows_sent"] > 0 and out["value"] > 0

@@ -84,19 +84,6 @@ def test_owner_partitioned_pipeline_with_either_owner_count(bits, monkeypatch):
     e.close()
 
 
-def test_owner_partitioned_pipeline_with_k_eval3_as_two_launches(monkeypatch):
-    """GUBER_EVAL3_SPLIT=1 (a build-time experiment kept as an option: the closed forms in a first launch at eight waves per SIMD, apply()
-    and the serial walk in a second one for the requests the first marks — guber_kernels_part.h eval3_body): adversarial streams (every
-    branch of algorithms.go, heterogeneous segments that are walked) and renewals, equal to the oracle incl. the counters"""
-    monkeypatch.setenv("GUBER_EVAL3_SPLIT", "1")
-    o, e = Oracle(cache_size=1 << 20), engine(flags=ga.FLAG_TEST_FORCE_PART)
-    for bi, b in enumerate(streams.adversarial_batches(9, 24, 3000, greg_fn=support.gregorian)):
-        want, got = o.eval(b), e.eval(b)
-        support.assert_results_equal(got, want, f"split batch {bi}")
-        assert got.counters() == want.counters(), f"counters batch {bi}"
-    e.close()
-
-
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
 # mode (verify first, claims keyed by the bucket slot: the retry round's code path); 2 = force the large-batch radix pipeline;
 # 32 = batches of <= 256 requests through the two-launch pipeline as well (with 0 they take the one-launch small path);

@@ -15,16 +15,13 @@ from support import ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle
 HS = os.path.join(ROOT, "tests", "hostsim")
 
 
-# every form of what travels between k_part, k_own and k_eval3: the product's default (64-byte messages, 32-byte records that leave out
-# what the request says), 32-byte messages as well (GUBER_PART_COMPACT=1: shapes per tile), 64 bytes both ways; and the default form with
-# the owner count (128 or 256 per batch: Work::pmode) pinned either way instead of following the traffic
-# ... and with k_eval3 as two launches (GUBER_EVAL3_SPLIT: closed forms first, the rest second)
-@pytest.fixture(scope="module", params=[("libdevsim.so", 0, 0), ("libdevsim_compact.so", 0, 0), ("libdevsim_wide.so", 0, 0), ("libdevsim.so", 7, 0), ("libdevsim.so", 8, 0),
-                                        ("libdevsim.so", 0, 1)],
-                ids=lambda p: p[0][3:-3] + (f"-owners{1 << p[1]}" if p[1] else "") + ("-eval3split" if p[2] else ""))
+# the kernels as the product builds them (64-byte messages, 32-byte records that leave out what the request says), with the owner count
+# (128 or 256 per batch: Work::pmode) following the traffic and pinned either way
+@pytest.fixture(scope="module", params=[("libdevsim.so", 0), ("libdevsim.so", 7), ("libdevsim.so", 8)],
+                ids=lambda p: p[0][3:-3] + (f"-owners{1 << p[1]}" if p[1] else ""))
 def lib(request):
     subprocess.run(["make", "-s", "-C", HS, "devsim_lib"], check=True)
-    request_param, owner_bits, eval3_split = request.param
+    request_param, owner_bits = request.param
     L = C.CDLL(os.path.join(HS, request_param))
     L.ds_create.restype = C.c_void_p
     L.ds_create.argtypes = [C.c_uint64, C.c_uint32, C.c_int]
@@ -41,10 +38,8 @@ def lib(request):
     L.ds_owner_bits.restype = C.c_uint32
     L.ds_owner_hold.argtypes = [C.c_void_p, C.c_uint32]
     L.ds_owner_hold.restype = C.c_uint32
-    L.short_recs, L.short_msgs = "wide" not in request_param, "compact" in request_param
-    L.ds_eval3_split.argtypes = [C.c_void_p, C.c_int]
-    L.owner_bits, L.eval3_split = owner_bits, eval3_split
-    L.product_form = request_param == "libdevsim.so" and owner_bits == 0 and not eval3_split
+    L.owner_bits = owner_bits
+    L.product_form = owner_bits == 0
     return L
 
 
@@ -60,8 +55,6 @@ class Sim:
         self.h = lib.ds_create_bounded(slots, max_batch, weak, cache_size)
         if lib.owner_bits:
             lib.ds_pin_owner_bits(self.h, lib.owner_bits)
-        if lib.eval3_split:
-            lib.ds_eval3_split(self.h, 1)
 
     def owner_bits(self):
         return self.lib.ds_owner_bits(self.h)
@@ -131,20 +124,13 @@ def test_zipf_batches_with_hot_keys_spanning_every_tile(lib):
         ids = z.draw(5000)
         b = streams.bench_batch(table, ids, now, algorithm=k & 1, limit=40, duration=3000)
         assert_results_equal(sim.eval(b), orc.eval(b), f"batch {k}")
-        groups, short_recs, tile_shapes = sim.part_forms(5000)
-        if lib.short_msgs:
-            assert tile_shapes == groups, (k, groups, tile_shapes)     # one request shape per batch: every message refers to its tile's shape
-        else:
-            assert tile_shapes == 0
-        if lib.short_recs:
-            # The 32-byte record serves every key whose bucket
-            # holds what the request says (limit, duration, burst — or no burst) and every new key: all of batch 0 (new) and batch 1
-            # (leaky requests meeting token buckets of the same limit), most of the leaky batches after that; a token request that
-            # meets a leaky bucket (burst 40 stored, none asked for) gets the 64-byte form — both forms in one batch from batch 2 on
-            assert groups > 2000
-            assert short_recs == groups if k < 2 else 0 < short_recs < groups, (k, groups, short_recs)
-        else:
-            assert short_recs == 0
+        groups, short_recs, _ = sim.part_forms(5000)
+        # The 32-byte record serves every key whose bucket
+        # holds what the request says (limit, duration, burst — or no burst) and every new key: all of batch 0 (new) and batch 1
+        # (leaky requests meeting token buckets of the same limit), most of the leaky batches after that; a token request that
+        # meets a leaky bucket (burst 40 stored, none asked for) gets the 64-byte form — both forms in one batch from batch 2 on
+        assert groups > 2000
+        assert short_recs == groups if k < 2 else 0 < short_recs < groups, (k, groups, short_recs)
         now += [1, 700, 1, 3500, 2, 900, 1, 1][k]
     assert sim.counters()[:3] == orc.counters()[:3]
     sim.close()
@@ -180,7 +166,7 @@ def test_more_keys_of_one_owner_than_its_lds_table_has_cells(lib, nkeys):
     LDS hash table has cells (OW_HT = 512).  The insert loop used to probe the full table for ever (a hang of k_own — found on the GPU
     with 128 owners per batch and uniform keys, reachable with 256 by keys chosen to share an owner); it is bounded now and the round
     splits"""
-    only_where_the_form_matters(lib, 1 if lib.product_form or lib.owner_bits or lib.eval3_split else 0)
+    only_where_the_form_matters(lib, 1 if lib.product_form or lib.owner_bits else 0)
     from support import oracle_lib
     ol = oracle_lib()
     keys, i = [], 0
@@ -349,7 +335,7 @@ def test_bounded_cache_evicts_in_the_reference_order(lib, pipeline, pattern):
     2 000, batches of 1 500 in which evicted keys come back in the same and in the next batch — every answer, the size after every
     batch and the count of unexpired evictions equal the bounded-LRU oracle.  cyclic = the classic worst case (every access of an
     exact LRU misses), expiring = short durations with the clock moving (expired items still hold their place in the list)."""
-    only_where_the_form_matters(lib, pipeline if pattern == 'cyclic' and lib.eval3_split else 0)          # (the pre-pass does not depend on the batch pipeline's form: one extra run, with k_eval3 split)
+    only_where_the_form_matters(lib, 0)          # (the pre-pass does not depend on the owner count)
     cs, nkeys, bsz = 2000, 2600, 1500
     sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
     rng = np.random.default_rng(11)

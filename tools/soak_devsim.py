@@ -19,7 +19,6 @@ def load(name):
     L.ds_eval.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_int, C.c_int]
     L.ds_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     L.ds_pin_owner_bits.argtypes = [C.c_void_p, C.c_uint32]
-    L.ds_eval3_split.argtypes = [C.c_void_p, C.c_int]
     L.ds_fuse_ep.argtypes = [C.c_void_p, C.c_int]
     L.ds_block_order.argtypes = [C.c_uint32]
     L.ds_chaos.argtypes = [C.c_uint32]
@@ -72,17 +71,16 @@ def one_ep(seed):
 
 def one(seed):
     rng = np.random.default_rng(seed)
-    libname = rng.choice(["libdevsim.so", "libdevsim.so", "libdevsim_compact.so", "libdevsim_wide.so"])
+    libname = "libdevsim.so"
     L = load(libname)
     slots = int(rng.choice([4096, 16384, 1 << 17, 1 << 20]))
     n_keys = int(rng.choice([50, 97, 400, 1000, 3000, 12000]))
     n_keys = min(n_keys, slots // 8)
     bs = int(rng.choice([300, 1500, 5000, 12000]))
-    obits = int(rng.choice([0, 0, 7, 8])); split = int(rng.random() < 0.4)
+    obits = int(rng.choice([0, 0, 7, 8])); split = 0
     nb = int(rng.choice([4, 8, 14]))
     h = L.ds_create_bounded(slots, 16384, 0, 0)
     if obits: L.ds_pin_owner_bits(h, obits)
-    if split: L.ds_eval3_split(h, 1)
     orc = Oracle(cache_size=1 << 20)
     cfg = f"seed {seed} lib {libname} slots {slots} keys {n_keys} batch {bs} x{nb} owners {obits} split {split}"
     try:
