@@ -465,6 +465,7 @@ class Rig:
             for j in range(self.S):
                 ev0[j].record(self.sstreams[j])
         t0 = time.perf_counter()
+        c0 = time.thread_time()                                       # CPU time of THIS thread (the dispatcher's call runs on it)
         if one:
             self.ga.Engine.eval_routed_dev(self.engines, wa, ba1, ra1, cnt1)
         elif self.workers is not None:
@@ -474,6 +475,7 @@ class Rig:
                 if f:
                     f()
         t_enq = time.perf_counter()
+        self.last_enqueue_busy_s = time.thread_time() - c0
         if timed:
             for j in range(self.S):
                 ev1[j].record(self.sstreams[j])
@@ -503,7 +505,7 @@ class Rig:
         self.retries = sum(e.stats()["retries"] for e in self.engines) - retries0
         B = ctx.B
         return {"value": steps * B * ctx.world / wall, "ms_per_step": wall / steps * 1e3, "timed_batches": steps,
-                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / steps, "enqueue_ms": self.last_enqueue_s * 1e3,
+                "timed_ms": wall * 1e3, "ms_per_step_events": ev_ms / steps, "enqueue_ms": self.last_enqueue_s * 1e3, "enqueue_busy_ms": self.last_enqueue_busy_s * 1e3,
                 "distinct_keys_in_stream": self.distinct_keys,
                 "internal_retries": int(self.retries),
                 "shard_streams": [{"batches": b, "stream_ms": round(m, 3), "us_per_batch": round(m * 1e3 / max(b, 1), 2)}
@@ -929,7 +931,8 @@ def main():
             "timed_region": {"distinct_batches": steps, "replays": 0, "ms": round(m["timed_ms"], 3),
                              "note": (f"--steps {args.steps} was raised to {steps}: the timed region is never shorter than {args.min_batches} distinct batches"
                                       if steps != args.steps else "every timed batch is a distinct part of the stream"),
-                             "ms_per_step_hip_events": round(m["ms_per_step_events"], 5), "host_enqueue_ms": round(m["enqueue_ms"], 3),
+                             "ms_per_step_hip_events": round(m["ms_per_step_events"], 5), "host_enqueue_ms": round(m["enqueue_ms"], 3), "host_enqueue_busy_ms": round(m["enqueue_busy_ms"], 3),
+                             "host_enqueue_note": "wall time of the ONE dispatcher call that enqueues the whole timed region, and the CPU time its thread burnt in it (busy << wall: it waits for queue room, the GPU is the bound; busy ~ wall: the host is)",
                              "enqueue": ("caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
                                          else f"one dispatcher for {S} shards over {args.streams} stream(s) (guber_eval_batches_routed_dev: batches of shards that share a stream share launches)"),
                              "shard_streams": m["shard_streams"]},
@@ -1162,10 +1165,17 @@ def run_global(args, ctx, dist):
     # same remaining for the keys of the last batch (hits = 0 reads)
     comm.sync(NOW0 + 1 + total_steps)
     comm.sync(NOW0 + 2 + total_steps)
-    probe = rigs[0].batches[total_steps - 1]
+    # (every replica is asked for the SAME keys: rank 0's last batch — each rank of an N > 1 run draws a stream of its own)
+    L = rigs[0].L
+    probe_keys = rigs[0].d_keys[(total_steps - 1) * B * L:(total_steps - 1) * B * L + B * L + 8].clone()
+    if world > 1:
+        pk = probe_keys.cpu() if args.backend != "nccl" else probe_keys
+        dist.broadcast(pk, src=0)
+        probe_keys = pk.to(dev)
+        torch.cuda.synchronize(dev)
     reads = []
     for rig in rigs:
-        b = rig.batch_struct(probe.key_bytes, B, NOW0 + 3 + total_steps, hits=0)
+        b = rig.batch_struct(probe_keys.data_ptr(), B, NOW0 + 3 + total_steps, hits=0)
         res = rig.DevResult(rig, B)
         torch.cuda.synchronize(dev)
         rig.engines[0].eval_dev(b, res.c)

@@ -1018,8 +1018,16 @@ struct PendSet {
     }
     int flush_all() { int r = 0; for (auto& q : items) { const int rc = flush_pending(*q); if (!r) r = rc; } return r; }
 };
+// GUBER_DISPATCH_PROFILE=1: where the dispatcher's time goes (printed at the end of every guber_eval_batches_routed_dev call):
+// [0] waiting for the GPU's progress before a batch may be enqueued (can_fuse -> lru_may_bind), [1] locks + held-back launches,
+// [2] preludes + plans, [3] argument blocks, [4] inside hipLaunchKernelGGL, [5] groups, [6] batches
+static const bool g_dprof = getenv("GUBER_DISPATCH_PROFILE") != nullptr;
+static thread_local uint64_t tl_dp[8];
+static inline uint64_t dp_now() { return g_dprof ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0; }
+struct DpSpan { int k; uint64_t t0; explicit DpSpan(int kk) : k(kk), t0(dp_now()) {} ~DpSpan() { if (g_dprof) tl_dp[k] += dp_now() - t0; } };
 static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
                         uint32_t* enqueued, PendSet* ps = nullptr) {
+    if (g_dprof) { tl_dp[5]++; tl_dp[6] += (uint64_t)g; }
     auto views = [&](int i, BatchView& B, ResultView& R) {
         const guber_batch_t* b = &batches[gk[i]]; guber_result_t* r = &results[gk[i]];
         B = BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
@@ -1057,6 +1065,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     }
     // lock the group's engines in address order (any other caller holds at most one engine lock, or locks in this order)
     guber_engine* order[MULTI_MAX];
+    uint64_t dp_t = dp_now();
+    auto dp_lap = [&](int k) { if (g_dprof) { const uint64_t t = dp_now(); tl_dp[k] += t - dp_t; dp_t = t; } };
     for (int i = 0; i < g; ++i) order[i] = grp[i];
     std::sort(order, order + g);
     for (int i = 0; i < g; ++i) order[i]->mu.lock();
@@ -1074,6 +1084,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     const bool ep = ps && same_set && part;                       // (same_set, pend: decided before the locks were taken, below the g == 1 case)
     bool join = ep && pend && pend->valid;
     if (pend && pend->valid && !join) { rc = flush_pending(*pend, true); if (rc) return rc; }   // (pend => the same engines: locked)
+    dp_lap(1);
     for (int i = 0; i < g; ++i) {
         guber_engine* e = grp[i];
         BatchView B; ResultView R; views(i, B, R);
@@ -1093,6 +1104,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         ME.sub[planned] = EvalArgs{e->T, P.B3, R, P.W};
         ns[planned++] = B.n;
     }
+    dp_lap(2);
     if (planned) {
         static_assert(FT == 256, "k_eval2's workgroup is k_front's tile");
         MF.nb = ME.nb = (uint32_t)planned;
@@ -1123,11 +1135,13 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                 }
                 { std::lock_guard<std::mutex> pl(pend->pm); pend->valid = false; }
                 for (int i = 0; i < planned; ++i) grp[i]->held = nullptr;
+                dp_lap(3);
                 grp[0]->span_begin(KT_EVALPART_MULTI, pend->units);
                 hipLaunchKernelGGL(k_evalpart_multi, dim3(pend->tiles + tiles), dim3(256), 0, grp[0]->stream, EP);
                 grp[0]->span_end();
                 grp[0]->ep_launches++;
             } else {
+                dp_lap(3);
                 grp[0]->span_begin(KT_PART_MULTI, units);
                 hipLaunchKernelGGL(k_part_multi, dim3(tiles), dim3(FT), 0, grp[0]->stream, MF);
                 grp[0]->span_end();
@@ -1135,6 +1149,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
             grp[0]->span_begin(KT_OWN_MULTI, units);
             hipLaunchKernelGGL(k_own_multi, dim3((unsigned)planned * PT_PARTS), dim3(256), 0, grp[0]->stream, MF);
             grp[0]->span_end();
+            dp_lap(4);
             if (ep && planned == g) {                             // held back: the same tables' next group, or flush_pending, launches it
                 if (!pend) pend = ps->slot_for(grp, planned);
                 {
@@ -1144,6 +1159,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                 for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->held = pend; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
                 *enqueued += (uint32_t)planned;
                 if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+                dp_lap(3);
                 return rc;
             }
             grp[0]->span_begin(KT_EVAL3_MULTI, units);
@@ -1197,7 +1213,8 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
             any = true;
             guber_engine* e = engines[j];
             const uint32_t k = fifo[j][pos[j]++];
-            bool fits = can_fuse(e, batches[k].n);
+            bool fits;
+            { DpSpan sp(0); fits = can_fuse(e, batches[k].n); }
             for (int i = 0; i < g && fits; ++i) fits = grp[i] != e;
             if (g && (!fits || g == MULTI_MAX || e->stream != grp[0]->stream || e->device != grp[0]->device)) {
                 rc = launch_group(grp, gk, g, batches, results, &enqueued, ps);
@@ -1215,6 +1232,12 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
     {
         const int rc = flush_all();
         if (rc) return rc;
+    }
+    if (g_dprof && tl_dp[6]) {
+        fprintf(stderr, "[dispatch] %llu batches in %llu groups; per batch: wait-for-progress %.2f us, locks %.2f, preludes+plans %.2f, argument blocks %.2f, launches %.2f\n",
+                (unsigned long long)tl_dp[6], (unsigned long long)tl_dp[5], tl_dp[0] / 1e3 / tl_dp[6], tl_dp[1] / 1e3 / tl_dp[6], tl_dp[2] / 1e3 / tl_dp[6],
+                tl_dp[3] / 1e3 / tl_dp[6], tl_dp[4] / 1e3 / tl_dp[6]);
+        for (auto& v : tl_dp) v = 0;
     }
     if (done) *done = enqueued + empty;
     return GUBER_OK;

@@ -708,25 +708,46 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2(EvalArgs A) {
 #endif
 constexpr int MULTI_MAX = GUBER_MULTI_MAX;
 struct FrontArgs { Table T; BatchView B; Work W; };
-struct MultiFront { uint32_t nb; uint32_t end_tile[MULTI_MAX]; FrontArgs sub[MULTI_MAX]; };
-struct MultiEval { uint32_t nb; uint32_t end_tile[MULTI_MAX]; EvalArgs sub[MULTI_MAX]; };
+// (end_tile[k] = where batch k's workgroups end; entries past the last batch stay at UINT32_MAX — what multi_batch_of relies on)
+struct MultiFront {
+    uint32_t nb; uint32_t end_tile[MULTI_MAX]; FrontArgs sub[MULTI_MAX];
+    MultiFront() { memset((void*)this, 0, sizeof *this); for (int k = 0; k < MULTI_MAX; ++k) end_tile[k] = 0xffffffffu; }
+};
+struct MultiEval {
+    uint32_t nb; uint32_t end_tile[MULTI_MAX]; EvalArgs sub[MULTI_MAX];
+    MultiEval() { memset((void*)this, 0, sizeof *this); for (int k = 0; k < MULTI_MAX; ++k) end_tile[k] = 0xffffffffu; }
+};
 static_assert(sizeof(MultiFront) <= 4096 && sizeof(MultiEval) <= 4096, "kernel arguments are limited to 4 KB");
 
-__global__ __launch_bounds__(FT) void k_front_multi(MultiFront A) {
-    uint32_t sb = 0, first = 0;
+// which batch of a fused launch a workgroup belongs to: the number of batches that end at or before it (the ends ascend; unused
+// entries are UINT32_MAX), without a branch — `ends` is read through the kernel-argument pointer: one wide scalar load and a dozen
+// scalar instructions (the chain of conditional updates it replaces was 25-30 with three branches, in every wave of every fused launch)
+template <int N>
+__device__ __forceinline__ uint32_t multi_batch_of(const uint32_t* ends, uint32_t wg, uint32_t& first) {
+    uint32_t e[N];
 #pragma unroll
-    for (int k = 0; k < MULTI_MAX - 1; ++k)
-        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    for (int k = 0; k < N - 1; ++k) e[k] = ends[k];
+    uint32_t sb = 0;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) sb += wg >= e[k] ? 1u : 0u;
+    first = 0u;
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) first = sb == (uint32_t)(k + 1) ? e[k] : first;
+    return sb;
+}
+__global__ __launch_bounds__(FT) void k_front_multi(MultiFront A) {
+    const MultiFront* m = (const MultiFront*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t first;
+    const uint32_t sb = multi_batch_of<MULTI_MAX>(m->end_tile, blockIdx.x, first);
     const FrontArgs* a = (const FrontArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiFront, sub)) + sb;
     front_body(a->T, a->B, a->W, blockIdx.x - first);
 }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi(MultiEval A) {
-    uint32_t sb = 0, first = 0;
-#pragma unroll
-    for (int k = 0; k < MULTI_MAX - 1; ++k)
-        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const MultiEval* m = (const MultiEval*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t first;
+    const uint32_t sb = multi_batch_of<MULTI_MAX>(m->end_tile, blockIdx.x, first);
     const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
-    eval2_body(*a, blockIdx.x - first, A.end_tile[sb] - first);
+    eval2_body(*a, blockIdx.x - first, m->end_tile[sb] - first);
 }
 
 

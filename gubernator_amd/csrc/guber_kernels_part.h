@@ -117,17 +117,14 @@ __device__ __forceinline__ uint32_t owner_of(const Table& T, const Work& W, uint
 GB_HD uint32_t owner_order(uint32_t p, uint32_t pbits) { return ((p & 7u) << (pbits - 3u)) | (p >> 3); }
 GB_HD uint32_t owner_from_order(uint32_t q, uint32_t pbits) { return ((q & ((1u << (pbits - 3u)) - 1u)) << 3) | (q >> (pbits - 3u)); }
 
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    const uint32_t lane = threadIdx.x & 63;
-#pragma unroll
-    for (uint32_t o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(v, o, 64); if (lane >= o) v += t; }
-    return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) { return (uint32_t)wave_incl_scan_i32((int)v); }   // (guber_table.h: DPP)
 
 // ---- k_part ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, const Work& W, const uint32_t tile) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;
-    __shared__ unsigned long long gkey[GT];
+    __shared__ alignas(16) unsigned long long gkey[GT];       // the grouping's hash table; afterwards (same bytes) the heads' key words
+    ulonglong2* const hkw = (ulonglong2*)gkey;                    // head thread -> {key bytes 0..7, 8..15} of a key of <= 16 bytes, zero padded
+    static_assert(GT * 8 >= FT * 16, "the heads' key words fit where the hash table was");
     // the per-wave member bitmaps are read once, right after the grouping; the tile's request fields are needed from then on (members
     // against their head): one piece of LDS for both (27 KB per workgroup instead of 39: five workgroups per CU instead of four)
     __shared__ union GbitsOrReqs { unsigned long long gbits[FT / 64][GT]; TileReqs sreq; } gu;
@@ -229,6 +226,11 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
     const bool member = valid && gk != 0ull && eq_before != 0;
     lds_barrier();                                                // every bitmap has been read: the requests' fields take their place
     if (valid) tile_put(sreq, tid, mine);
+    // the key's bytes as the message carries them (<= 16 bytes: two zero-padded words).  A head leaves them where the hash table was:
+    // its members compare their own words with them — two LDS words instead of walking both keys' bytes in memory
+    unsigned long long k0 = kw[0], k1 = len > 8 ? kw[1] : 0ull;
+    if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
+    if (khead && len <= 16) hkw[tid] = make_ulonglong2(k0, k1);
     GP_STAMP(0, 2);
     // created_at as the messages carry it: milliseconds from the batch clock
     int cd = 0; bool cfar = false;
@@ -259,7 +261,12 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
             f |= G_CREATED | (cfar ? G_CFAR : 0u);
             atomicMin(&gcmin[head_tid], cd); atomicMax(&gcmax[head_tid], cd);
         }
-        if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) f |= G_RETRY;
+        bool keq;
+        if (len <= 16) {
+            keq = slen[head_tid] == len;
+            if (keq) { const ulonglong2 hk = hkw[head_tid]; keq = hk.x == k0 && hk.y == k1; }
+        } else keq = req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid]);
+        if (!keq) f |= G_RETRY;
         if (f) atomicOr(&gfl[head_tid], f);
     }
     GP_STAMPW(0, 3);
@@ -287,11 +294,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         const uint32_t span = (uint32_t)(gcmax[tid] - dmin);
         if (span > 255u) f |= G_CFAR;
         const uint32_t shape = (mine.behavior & 63u) | ((mine.algorithm > 1u ? 2u : (uint32_t)mine.algorithm) << 6) | ((mine.is_owner ? 1u : 0u) << 8);
-        unsigned long long k0, k1;
-        if (len <= 16) {
-            k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
-            if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
-        } else { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
+        if (len > 16) { k0 = (unsigned long long)off | ((unsigned long long)len << 32); k1 = 0ull; }
         GMsg* m = &W.gmsg[(size_t)tile * FT + j];
         ulonglong2* mq = (ulonglong2*)m;
         mq[0] = make_ulonglong2(gk, k0);
@@ -361,9 +364,10 @@ __device__ __forceinline__ unsigned long long msg_hash_at(const Work& W, size_t 
 }
 
 __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, const Work& W, const uint32_t p, const uint32_t ntiles) {
-    __shared__ unsigned long long ktab[OW_HT];          // the round's keys: hash (0 = free)
+    __shared__ alignas(16) unsigned long long ktab[OW_HT];          // the round's keys: hash (0 = free)
     __shared__ uint16_t kidOf[OW_HT];                   // table slot -> key id
-    __shared__ uint32_t csum[OW_CH * (OW_KCAP / 2)];    // requests per (64-message chunk, key), two u16 per word
+    __shared__ alignas(16) uint32_t csum[OW_CH * (OW_KCAP / 2)];    // requests per (64-message chunk, key), two u16 per word
+    __shared__ uint8_t etile[OW_MCAP];                  // position in the owner's list -> the tile the message comes from
     __shared__ GMsg kref[OW_KCAP];                      // key id -> the message that installed the key; then (same thread) the key's record
     __shared__ uint16_t kwin[OW_KCAP];                  // key id -> list index of that message
     __shared__ uint32_t kfl[OW_KCAP];                   // G_* over the key's groups
@@ -398,8 +402,9 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         const uint32_t lg = cur >> 24, res = cur & 0xffffffu, smask = (1u << lg) - 1u;
         lds_barrier();
         if (t == 0) { sp--; nkeys = 0u; }
-        for (uint32_t j = t; j < OW_HT; j += 256) ktab[j] = 0ull;
-        for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2); j += 256) csum[j] = 0u;
+        static_assert(OW_HT % 2 == 0 && (OW_CH * (OW_KCAP / 2)) % 4 == 0, "cleared sixteen bytes at a time");
+        for (uint32_t j = t; j < OW_HT / 2; j += 256) ((uint4*)ktab)[j] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t j = t; j < OW_CH * (OW_KCAP / 2) / 4; j += 256) ((uint4*)csum)[j] = make_uint4(0u, 0u, 0u, 0u);
         // my tile's messages of this round
         uint32_t cm = c;
         if (lg) { cm = 0; for (uint32_t r = 0; r < c; ++r) cm += ((uint32_t)((msg_hash_at(W, mbase + r) >> 7) & T.mask) & smask) == res ? 1u : 0u; }
@@ -427,13 +432,19 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
 #pragma unroll
         for (int k = 0; k < OW_EPT; ++k) { esrc[k] = 0xffffffffu; eslot[k] = 0; m0[k] = m1[k] = m2[k] = m3[k] = make_ulonglong2(0ull, 0ull); }
         if (!split) {
-            lds_barrier();                                            // tpos complete
+            // which tile a position of the list belongs to: every tile's thread says so for its own run (one or two messages as a
+            // rule) — a message then finds its tile with ONE read (round 4: a binary search over the tiles' list positions, eight
+            // dependent reads per message)
+            {
+                const uint32_t pos = tpos[t];
+                for (uint32_t r = 0; r < cm; ++r) etile[pos + r] = (uint8_t)t;
+            }
+            lds_barrier();                                            // tpos, etile complete
 #pragma unroll
             for (int k = 0; k < OW_EPT; ++k) {
                 const uint32_t e = (uint32_t)k * 256 + t;
                 if (e < M) {
-                    uint32_t lo = 0, hi = 256;                        // the last tile whose run starts at or before e and is not empty there
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpos[mid] <= e) lo = mid; else hi = mid; }
+                    const uint32_t lo = etile[e];                     // the tile whose run holds position e
                     uint32_t r = e - tpos[lo];
                     uint32_t mi = lo * FT + tstart[lo] + r;
                     if (lg) {                                         // a split round: the r-th message of the tile's run that belongs to this round
@@ -680,8 +691,7 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
             const uint32_t wl = kwin[kid];                             // the installing message: list index -> its place in gmsg
             uint32_t seg = 0;
             {   // (the installer's esrc lives in its thread's registers: recomputed from the list index as every thread did)
-                uint32_t lo = 0, hi = 256;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpos[mid] <= wl) lo = mid; else hi = mid; }
+                const uint32_t lo = etile[wl];
                 seg = lo * FT + tstart[lo] + (wl - tpos[lo]);
                 if (lg) {
                     const uint32_t mb = lo * FT + tstart[lo];
@@ -933,10 +943,9 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3(EvalArgs A) {
 // ---- several engines in one launch (as k_front_multi / k_eval2_multi: workgroup -> (batch, tile) by the prefix table in the
 // kernel arguments; k_own_multi: 256 owners per batch, so that an owner's XCD is the same in every batch) ----------------------
 __global__ __launch_bounds__(FT, GUBER_PART_WAVES) void k_part_multi(MultiFront A) {
-    uint32_t sb = 0, first = 0;
-#pragma unroll
-    for (int k = 0; k < MULTI_MAX - 1; ++k)
-        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const MultiFront* m = (const MultiFront*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t first;
+    const uint32_t sb = multi_batch_of<MULTI_MAX>(m->end_tile, blockIdx.x, first);
     const FrontArgs* a = (const FrontArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiFront, sub)) + sb;
     part_body(a->T, a->B, a->W, blockIdx.x - first);
 }
@@ -948,10 +957,9 @@ __global__ __launch_bounds__(256, GUBER_OWN_WAVES) void k_own_multi(MultiFront A
     own_body(a->T, a->B, a->W, blockIdx.x % PT_PARTS, ntiles);
 }
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval3_multi(MultiEval A) {
-    uint32_t sb = 0, first = 0;
-#pragma unroll
-    for (int k = 0; k < MULTI_MAX - 1; ++k)
-        if (sb == (uint32_t)k && k + 1 < (int)A.nb && blockIdx.x >= A.end_tile[k]) { first = A.end_tile[k]; sb = k + 1; }
+    const MultiEval* m = (const MultiEval*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t first;
+    const uint32_t sb = multi_batch_of<MULTI_MAX>(m->end_tile, blockIdx.x, first);
     const EvalArgs* a = (const EvalArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEval, sub)) + sb;
     eval3_body(*a, blockIdx.x - first);
 }
@@ -971,19 +979,19 @@ struct EPSub {
     EvalArgs E; BatchView Bp; uint32_t* did_p; uint32_t pmslot_p;
     uint32_t snap_seq, snap_n, pad_; DevCounters* snap_c; BlockCounters* snap_b; uint32_t* snap_stamp;     // a counter read-back riding on the k_part half (Work::snap_*)
 };
-struct MultiEP { uint32_t nb; uint32_t end_e[EP_MAX]; uint32_t end_p[EP_MAX]; EPSub sub[EP_MAX]; };
+struct MultiEP {
+    uint32_t nb; uint32_t end_e[EP_MAX]; uint32_t end_p[EP_MAX]; EPSub sub[EP_MAX];
+    MultiEP() { memset((void*)this, 0, sizeof *this); for (int k = 0; k < EP_MAX; ++k) end_e[k] = end_p[k] = 0xffffffffu; }
+};
 static_assert(sizeof(MultiEP) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_evalpart_multi(MultiEP A) {
     static_assert(FT == 256, "k_eval3's workgroup is k_part's tile");
-    const uint32_t tiles_e = A.end_e[A.nb - 1];
+    const MultiEP* m = (const MultiEP*)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t tiles_e = m->end_e[m->nb - 1];
     const bool part = blockIdx.x >= tiles_e;
     const uint32_t wg = part ? blockIdx.x - tiles_e : blockIdx.x;
-    uint32_t sb = 0, first = 0;
-#pragma unroll
-    for (int k = 0; k < EP_MAX - 1; ++k) {
-        const uint32_t end = part ? A.end_p[k] : A.end_e[k];
-        if (sb == (uint32_t)k && k + 1 < (int)A.nb && wg >= end) { first = end; sb = k + 1; }
-    }
+    uint32_t first;
+    const uint32_t sb = multi_batch_of<EP_MAX>(part ? m->end_p : m->end_e, wg, first);
     const EPSub* a = (const EPSub*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MultiEP, sub)) + sb;
     if (!part) { eval3_body(a->E, wg - first); return; }
     Work W = a->E.W;                                       // the next batch's work arrays are this engine's, but for:

@@ -345,10 +345,32 @@ __device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, ui
     return (uint32_t)r;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave, ALL of them active.  On the device: six DPP adds (row_shr 1 / 2 / 4 / 8 inside the
+// rows of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 — the gfx9 scan) instead of six
+// ds_bpermute round trips with their index arithmetic (round 5's instruction diet: a scan was ~36 instructions, now 6 + hazards).
+// The host build of the kernel source (tests/hostsim/fakehip) takes the shuffle form.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 (lane 15 of the row before -> rows 1, 3)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 (lane 31 -> rows 2, 3)
+    return v;
+#else
+    const int lane = (int)(threadIdx.x & 63);
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, (unsigned)o, 64); if (lane >= o) v += t; }
+    return v;
+#endif
+}
 __device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63);
+#else
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#endif
 }
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global
 // load, store and atomic of the wave (s_waitcnt vmcnt(0)); k_front / k_eval2 exchange data between threads

@@ -12,7 +12,7 @@ run() {  # name, bench args
 # FIRST: GUBER_FUSE_EP (k_eval3 of a group + k_part of the same tables' next group in ONE launch: two launches per pass instead of three;
 # built at the end of round 4, checked through the kernel source on the CPU only) — parity on the GPU, then the headline with / without,
 # alternating on this box; the bench's own parity gate (2048 / 2048 batches by digest) runs in both
-GUBER_FUSE_EP=1 timeout 300 python scripts/r05_fuse_ep_check.py > $O/fuse_ep_check.txt 2>&1; echo "fuse_ep check rc=$?"; tail -4 $O/fuse_ep_check.txt
+GUBER_FUSE_EP=1 timeout 300 python tests/fuse_ep_check.py > $O/fuse_ep_check.txt 2>&1; echo "fuse_ep check rc=$?"; tail -4 $O/fuse_ep_check.txt
 if grep -q "FUSE_EP CHECK OK" $O/fuse_ep_check.txt; then
   for rep in 1 2; do
     for ep in 0 1; do

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""PREPARED FOR ROUND 5's FIRST GPU CALL (round 4 had no GPU time left when GUBER_FUSE_EP was built): the fused launch
-k_evalpart_multi — one group's k_eval3 + the same tables' next k_part (gubernator_amd/csrc/guber_kernels_part.h, launch_group in
-guber_engine.hip) — on the GPU against the oracle.  Not collected by pytest: the mode joins the `-m gpu` suite once it has passed here.
-  GUBER_FUSE_EP=1 python scripts/r05_fuse_ep_check.py        (the variable is set below if it is not)
+"""The fused launch k_evalpart_multi — one group's k_eval3 + the same tables' next k_part (gubernator_amd/csrc/guber_kernels_part.h,
+launch_group in guber_engine.hip; the engine's default since round 5's first GPU call measured it: +3.5 % on the headline) — on the GPU
+against the oracle.  Run by tests/test_gpu_parity.py::test_k_eval3_and_the_next_k_part_share_a_launch in a process of its own, or by hand:
+  python tests/fuse_ep_check.py
 Four tables on one stream (then six: two groups per round), 30 rounds of one batch each through ONE guber_eval_batches_routed_dev call: adversarial Zipf batches with
 hot keys, both algorithms, the clock stepping so that buckets expire and renew; in between a batch too small for the owner-partitioned
 pipeline (the held-back k_eval3 must go first), a round in which one table has no batch (another group: flush), uniform keys that make
@@ -13,9 +13,10 @@ import os
 import sys
 
 os.environ.setdefault("GUBER_FUSE_EP", "1")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 import numpy as np
 import torch
 
@@ -81,7 +82,7 @@ def main(NE=4):
             print("SIZE", j, e.size(), o.size())
         e.close()
     fused = prof.get("k_evalpart_multi", (0, 0))[0]
-    if os.environ.get("GUBER_FUSE_EP") == "1" and fused < (rounds // 2) * ((NE + 3) // 4):
+    if os.environ.get("GUBER_FUSE_EP", "1") == "1" and fused < (rounds // 2) * ((NE + 3) // 4):
         bad += 1
         print("k_evalpart_multi was launched", fused, "times only")
     print(f"{NE} tables on one stream:", "ok" if not bad else f"FAILED ({bad})")

@@ -29,7 +29,9 @@ def _bench(extra, env=None, timeout=900):
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    if p.returncode != 0:
+        print(p.stdout[-3000:]); print(p.stderr[-8000:])
+    assert p.returncode == 0, "bench.py failed (its output is printed above)"
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     return json.loads(lines[0])
@@ -46,7 +48,8 @@ def test_two_ranks_on_one_device_are_parity_gated_and_agree_with_one_rank():
     assert two["roofline"] and two["roofline"]["bound"] == "hbm" and 0 < two["roofline"]["frac"] < 1
     assert two["config"]["ranks_seen_by_the_collective_backend"] == 2
     res = two["config"]["resident_items_by_rank"]
-    assert len(res) == 2 and all(r == 2_000_000 for r in res), res          # (--keys is per GPU: weak scaling)
+    # (--keys is per GPU — weak scaling — and the ring splits the 2 x K keys nearly evenly: replicated_hash.go:78-119, 512 vnodes per peer)
+    assert len(res) == 2 and sum(res) == 4_000_000 and all(abs(r - 2_000_000) < 150_000 for r in res), res
     ratio = two["value"] / one["value"]
     print(f"bench.py --gpus 2 on ONE device: {two['value'] / 1e9:.2f} G/s against {one['value'] / 1e9:.2f} G/s for --gpus 1 (ratio {ratio:.2f})")
     # two processes time-slicing one GPU: the aggregate stays in the neighbourhood of one process's rate (a multiple would mean the

@@ -2,6 +2,8 @@
 CPU oracle on the same seeded inputs — bit-exact on status / limit / remaining / reset_time / err,
 for token AND leaky buckets (the leaky float64 math is IEEE division, add, subtract and conversions
 only, so the tolerance is 0)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -82,6 +84,18 @@ def test_owner_partitioned_pipeline_with_either_owner_count(bits, monkeypatch):
         b = streams.bench_batch(table, ids, streams.NOW0 + 100 + rnd, limit=20, duration=60_000)
         support.assert_results_equal(e.eval(b), o.eval(b), f"bits {bits!r} distinct keys {rnd}")
     e.close()
+
+
+def test_k_eval3_and_the_next_k_part_share_a_launch():
+    """the engine's default for routed calls (k_evalpart_multi: two launches per pass instead of three): four and six tables on one
+    stream, 30 rounds of adversarial Zipf batches incl. a batch too small for the pipeline, a round without one table, uniform keys
+    that move the owner count — every batch equal to its table's oracle, sizes too, and the fused launch really carried the passes
+    (tests/fuse_ep_check.py, in a process of its own: the engines read GUBER_FUSE_EP once)"""
+    import subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k != "GUBER_FUSE_EP"}
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuse_ep_check.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "FUSE_EP CHECK OK" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])
+    assert "k_evalpart_multi" in p.stdout
 
 
 # flags 0 = two-launch tile-bitmap pipeline (batches <= 65536), claims in the engine's claim table; 4 = the same in careful
