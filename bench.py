@@ -110,8 +110,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU baseline AND the oracle parity pass")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU time budget per thread count of the baseline")
     ap.add_argument("--cpu-threads", default="1,8,16,64,all", help="worker shards / threads of the CPU baseline (comma list, 'all' = every host core)")
-    ap.add_argument("--profile-steps", type=int, default=128, help="distinct batches run once more with HIP events around every launch")
-    ap.add_argument("--latency-steps", type=int, default=128, help="distinct batches run one at a time for the single-batch latency")
+    ap.add_argument("--profile-steps", type=int, default=4096,
+                    help="further distinct batches run once more, dispatched like the timed region, with HIP events around every launch: the per-kernel "
+                         "durations and the batch latency under load (4096 batches = >= 1000 pipeline passes of up to four tables)")
+    ap.add_argument("--latency-steps", type=int, default=1024, help="distinct batches run one at a time for the single-batch latency")
     ap.add_argument("--shards", type=int, default=12, metavar="S",
                     help="logical key-space shards per GPU (the reference's Config.Workers sharding, workers.go:19-25): S "
                          "engines with their own tables, the stream routed to them key by key")
@@ -688,12 +690,12 @@ def finish_distributed(dist):
 
 
 def rocprof_reference(algo):
-    """the committed rocprofv3 summary of this command (profiles/r04_rocprof_summary.json), if any: the same formula on its
+    """the committed rocprofv3 summary of this command (profiles/r05_rocprof_summary.json), if any: the same formula on its
     average kernel duration, so that the line and the file can be checked against each other"""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r04_rocprof_summary.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r05_rocprof_summary.json")))
         k = j["dominant_kernel"]
-        return {"file": "profiles/r04_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "requests_per_launch": k["requests_per_launch"],
+        return {"file": "profiles/r05_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "requests_per_launch": k["requests_per_launch"],
                 "achieved": k["achieved_GBps"], "frac": k["frac"], "command": j.get("command")}
     except Exception:   # noqa: BLE001
         return None
@@ -799,6 +801,20 @@ def main():
                 measured = tj.get("note")
             except Exception:   # noqa: BLE001
                 pass
+            # the issue side: what the SIMDs spend issuing the three kernels' instructions for one batch (SQ counter passes, committed as
+            # profiles/roofline_issue.json by tools/summarize_r05.py) over the step the driver's clock sees
+            issue = None
+            try:
+                ij = json.load(open(os.path.join(ROOT, "profiles", "roofline_issue.json")))
+                iu = float(ij["issue_us_per_batch"]) * B / 65536
+                issue = {"issue_us_per_step": round(iu, 4), "step_us": round(m["ms_per_step"] * 1e3, 4), "frac": round(iu / (m["ms_per_step"] * 1e3), 4),
+                         "insts_per_wave": {k: v["insts_per_wave_all"] for k, v in ij["kernels"].items()},
+                         "what": ("SQ_ACTIVE_INST_ANY of k_part + k_own + k_eval3 per 65536-request batch (quad-cycles a SIMD spent issuing, summed over the chip) x 4 cycles / "
+                                  "(1024 SIMDs x 2.4 GHz) over the step time: the share of the step in which EVERY SIMD of the chip would have to be issuing — the resource "
+                                  "this pipeline is closest to filling (round 5: fewer instructions per request moved the rate almost one for one, DESIGN.md section 4)"),
+                         "source": ij.get("source"), "counters_from": "a separate rocprofv3 --pmc run of this command (committed), not this run"}
+            except Exception:   # noqa: BLE001
+                pass
             pipe = BYTES_PER_DECISION[args.algo] * B / (m["ms_per_step"] * 1e-3) / 1e9
             # the line's roofline: the WHOLE pipeline's algorithmic bytes over the driver-visible step time — reproducible from
             # `ms_per_step` alone.  The per-kernel figure of a fused run is a diagnostic: the streams' kernels overlap in time.
@@ -806,10 +822,11 @@ def main():
                         "what": (f"{BYTES_PER_DECISION[args.algo]} algorithmic B per decision (SURVEY 8d) x {B} decisions per step / ms_per_step: every kernel of "
                                  "the pipeline, all shards overlapping, as the driver's clock sees it"),
                         "traffic": traffic, "traffic_note": measured,
-                        "limiter": ("not HBM bytes: same-box experiments (profiles/r04_w_*, r04_x_*, r04_y_*, r04_split_*; DESIGN.md section 4) — the pipeline without "
-                                    "any table access is not faster, 29 % fewer fabric transactions gave 6 %, more waves per SIMD 1-3.5 %; a launch's duration "
-                                    "under load is one workgroup's dependent chain on a chip shared by three streams, the rate = batches in flight / the sum of "
-                                    "those latencies"),
+                        "issue": issue,
+                        "limiter": ("instruction issue, not HBM bytes: the pipeline without any table access is not faster and fewer fabric transactions barely moved it "
+                                    "(round 4: profiles/r04_w_*, r04_x_*), while round 5's instruction diet — 15 % fewer instructions per request in the three kernels — "
+                                    "gave 12.5 % on one box (profiles/r05_d_*, r05_e_*); `issue.frac` is how full the SIMDs' issue slots are on average, the rest is "
+                                    "imbalance between owners, kernel tails on three streams and waves parked at s_waitcnt"),
                         "kernel": dom,
                         "dominant_kernel_overlapped": {
                             "kernel": dom, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBPS, 6),

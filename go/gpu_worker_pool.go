@@ -141,11 +141,63 @@ func NewGPUWorkerPool(conf *Config, devices []int, shards int, batchLimit int, b
 		return nil, errors.Errorf("guber_pool_create_multi: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
 	}
 	p.bufs.New = func() any { return newRPCBuf(kMaxBatch, kMaxBatch*96) }
+	// DURATION_IS_GREGORIAN intervals are computed on the device from the batch clock; interval.go:97-142 builds its civil dates in
+	// now.Location(), so the engine gets the daemon's zone: the offset in effect now and the coming transitions (UTC: nothing to say)
+	if err := setEngineTimezone(time.Local, time.Now(), 7); err != nil {
+		C.guber_pool_destroy(p.pool)
+		return nil, err
+	}
 	if conf.Store != nil {
 		p.handle = cgo.NewHandle(p)
 		C.guber_go_set_store(p.pool, unsafe.Pointer(uintptr(p.handle)))
 	}
 	return p, nil
+}
+
+// setEngineTimezone hands guber_set_timezone the zone as Go's time.Location holds it: the UTC offset at `from` and the transitions of the
+// next `years` years as (UTC second, offset from then on).  Go exports no transition table, so the offsets are sampled hourly and every
+// change is bisected to the second (a zone with daylight saving time has two per year; the engine's table takes 16).  Call it again once
+// a year (the daemon's restart cadence in practice), or with another Location for tests.
+func setEngineTimezone(loc *time.Location, from time.Time, years int) error {
+	offAt := func(u int64) int { _, off := time.Unix(u, 0).In(loc).Zone(); return off }
+	t := from.Unix() - from.Unix()%3600
+	end := from.AddDate(years, 0, 0).Unix()
+	off0 := offAt(t)
+	cur := off0
+	var when []int64
+	var offs []int32
+	for ; t < end && len(when) < 16; t += 3600 {
+		if offAt(t+3600) == cur {
+			continue
+		}
+		lo, hi := t, t+3600
+		for hi-lo > 1 {
+			if mid := (lo + hi) / 2; offAt(mid) == cur {
+				lo = mid
+			} else {
+				hi = mid
+			}
+		}
+		cur = offAt(hi)
+		when = append(when, hi)
+		offs = append(offs, int32(cur))
+	}
+	if off0 == 0 && len(when) == 0 {
+		return nil // UTC: the engine's default
+	}
+	tz := C.guber_tz_t{n: C.uint32_t(len(when)), offset0_s: C.int32_t(off0)}
+	if n := len(when); n > 0 { // the two arrays in C memory: the struct handed to C must not point into the Go heap
+		tz.when_s = (*C.int64_t)(C.malloc(C.size_t(8 * n)))
+		tz.offset_s = (*C.int32_t)(C.malloc(C.size_t(4 * n)))
+		defer C.free(unsafe.Pointer(tz.when_s))
+		defer C.free(unsafe.Pointer(tz.offset_s))
+		copy(unsafe.Slice((*int64)(unsafe.Pointer(tz.when_s)), n), when)
+		copy(unsafe.Slice((*int32)(unsafe.Pointer(tz.offset_s)), n), offs)
+	}
+	if rc := C.guber_set_timezone(&tz); rc != C.GUBER_OK {
+		return errors.Errorf("guber_set_timezone: %s (%s)", C.GoString(C.guber_strerror(rc)), C.GoString(C.guber_last_error()))
+	}
+	return nil
 }
 
 const kMaxBatch = 1000 // gubernator.go:40 maxBatchSize

@@ -662,6 +662,9 @@ def zone_transitions(name, year_from, year_to):
             cur = off_at(hi)
             out.append((hi, cur))
         t += step
+    if len(out) > 16:                                             # (guber_tz_t holds 16: a zone with DST has two per year)
+        raise ValueError(f"{name} has {len(out)} transitions between {year_from} and {year_to}: guber_set_timezone takes at most 16 — narrow the window "
+                         f"(the daemon needs the years its clock can reach, not history)")
     return off0, out
 
 

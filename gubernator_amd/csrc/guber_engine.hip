@@ -14,6 +14,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -513,7 +514,10 @@ static bool lru_may_bind(guber_engine* e, uint64_t n) {
         if (rb_fold_newest(e) && e->size_upper + n <= e->cache_size) { e->settle_waits += waited; return false; }
         if (!rb_any_launched(e)) break;
         waited = true;
-        if ((spins & 0xff) == 0xff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        if ((spins & 0xff) == 0xff) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            std::this_thread::yield();                           // (the engine mutex is held: whoever else needs this CPU gets it)
+        }
         __builtin_ia32_pause();
     }
     e->settle_waits += waited;
@@ -1074,6 +1078,21 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     for (int i = 0; i < g; ++i)                                    // a k_eval3 ANOTHER call holds back for one of these tables goes first
         if (grp[i]->held && grp[i]->held != pend) { (void)launch_held(*grp[i]->held, false); grp[i]->held = nullptr; }
     if (grp[0]->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    {   // can_fuse() looked at the cache bound BEFORE these locks were taken (it takes and drops each engine's mutex): another thread's
+        // AddCacheItem / eval on one of the tables may have used the headroom since.  Looked at again here, under the locks, with the
+        // cheap form of the bound; a table that is tight now leaves the group and goes through launch_batch and its eviction pre-pass,
+        // one by one — the cache never grows past cache_size and the victims stay lrucache.go's
+        bool tight = false;
+        for (int i = 0; i < g; ++i) tight = tight || grp[i]->size_upper + batches[gk[i]].n > grp[i]->cache_size;
+        if (tight) {
+            if (pend && pend->valid) { const int rcf = flush_pending(*pend, true); if (rcf) return rcf; }
+            for (int i = g - 1; i >= 0; --i) order[i]->mu.unlock();
+            unlock.g = 0;
+            int rc1 = 0;
+            for (int i = 0; i < g && !rc1; ++i) rc1 = launch_group(&grp[i], &gk[i], 1, batches, results, enqueued, ps);
+            return rc1;
+        }
+    }
     MultiFront MF{}; MultiEval ME{};
     uint32_t tiles = 0, ns[MULTI_MAX];
     int planned = 0, rc = 0;
@@ -2355,7 +2374,7 @@ static void item_from_rec(const Rec& s, guber_item_t* out) {
     }
 }
 
-static int add_items_once(guber_engine* e, const guber_item_t* items, const std::vector<uint32_t>& sel, uint8_t* res_out) {
+static int add_items_once(guber_engine* e, const guber_item_t* items, const std::vector<uint32_t>& sel, uint8_t* res_out, uint64_t stamp0) {
     const uint32_t n = (uint32_t)sel.size();
     size_t kbytes = 0;
     for (uint32_t j : sel) kbytes += items[j].key_len;
@@ -2365,6 +2384,7 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
     for (uint32_t j = 0; j < n; ++j) {
         const guber_item_t& it = items[sel[j]];
         host[j].rec = rec_from_item(it);
+        rec_set_stamp(host[j].rec, stamp0 + sel[j]);             // the item's place in the CALL (lrucache.go:91,96: Add moves to the front, item by item)
         host[j].key_off = (uint32_t)off; host[j].key_len = it.key_len;
         if (it.key_len) memcpy(keys.data() + off, it.key, it.key_len);
         off += it.key_len;
@@ -2383,7 +2403,7 @@ static int add_items_once(guber_engine* e, const guber_item_t* items, const std:
         cleanup(); return fail(GUBER_E_HIP, "add_items H2D", he);
     }
     hipLaunchKernelGGL(k_items_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p);
-    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p, take_stamps(e, n));
+    hipLaunchKernelGGL(k_items_commit, dim3((n + 255) / 256), dim3(256), 0, st, e->T, d_items.p, d_keys.p, n, d_slots.p, d_flags.p, d_res.p, ITEMS_KEEP_STAMP);
     std::vector<uint8_t> res(n);
     if ((he = hipMemcpyAsync(res.data(), d_res.p, n, hipMemcpyDeviceToHost, st)) != hipSuccess ||
         (he = hipStreamSynchronize(st)) != hipSuccess) {
@@ -2413,7 +2433,10 @@ static int add_items_locked(guber_engine_t* e, const guber_item_t* items, uint32
     }
     note_enqueued(e, n);
     // LRUCache.Add is applied item by item (workers.go:566-581): with duplicates of a key in one call
-    // the LAST one must win and the later ones report existed = 1.  Waves of distinct keys keep that.
+    // the LAST one must win and the later ones report existed = 1.  Waves of distinct keys keep that; every item carries the
+    // recency number of its place in the call, so the order among the call's keys is the reference's too (round 4 numbered the
+    // items wave by wave: [A, A, D] left A in front of D).
+    const uint64_t stamp0 = take_stamps(e, n);
     std::vector<uint8_t> res(n, 0);
     std::vector<uint32_t> pending(n);
     for (uint32_t i = 0; i < n; ++i) pending[i] = i;
@@ -2426,7 +2449,7 @@ static int add_items_locked(guber_engine_t* e, const guber_item_t* items, uint32
             std::string k((const char*)items[i].key, items[i].key_len);
             if (seen.emplace(std::move(k), 1).second) wave.push_back(i); else later.push_back(i);
         }
-        int rc = add_items_once(e, items, wave, res.data());
+        int rc = add_items_once(e, items, wave, res.data(), stamp0);
         if (rc) return rc;
         std::vector<uint32_t> next;
         for (uint32_t i : wave) {
@@ -2950,17 +2973,23 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
 
 // the process's zone: the host helpers' copy and, on every visible device, the kernels' (guber_table.h g_tz)
 extern "C" int guber_set_timezone(const guber_tz_t* tz) {
-    const int rc = guber_host_set_tz(tz);
+    // validate first; then every device; the host helpers' copy LAST, and only when every device has the zone — a failure part of the
+    // way leaves the devices that were reached in the new zone and says so, the host (and with it guber_gregorian_*) in the old one
+    // never ahead of them; the caller's current device is restored on every path
+    guber::TzTable t{};
+    const int rc = guber_host_build_tz(tz, &t);
     if (rc != GUBER_OK) return fail(rc, "time zone: at most 16 transitions, ascending");
     int ndev = 0, cur = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GUBER_OK;          // (no device: the helpers still follow the zone)
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { guber_host_publish_tz(t); return GUBER_OK; }   // (no device: the helpers still follow the zone)
     (void)hipGetDevice(&cur);
-    for (int d = 0; d < ndev; ++d) {
+    int failed = -1;
+    for (int d = 0; d < ndev && failed < 0; ++d) {
         if (hipSetDevice(d) != hipSuccess) continue;
-        HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(guber::g_tz), guber_host_tz_table(), sizeof(guber::TzTable)));
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(guber::g_tz), &t, sizeof(guber::TzTable)) != hipSuccess) failed = d;
     }
     (void)hipSetDevice(cur);
+    if (failed >= 0) { (void)hipGetLastError(); return fail(GUBER_E_HIP, "time zone: a device did not take the table (the host helpers keep the zone they had)"); }
+    guber_host_publish_tz(t);
     return GUBER_OK;
 }
 

@@ -131,7 +131,8 @@ extern "C" int guber_ring_route(const guber_ring_t* r, const uint8_t* key_bytes,
 static guber::TzTable g_host_tz{};                                   // the process's zone (guber_set_timezone); all zero = UTC
 static const guber::TzTable* host_tz() { return (g_host_tz.n || g_host_tz.offset0_s) ? &g_host_tz : nullptr; }
 const guber::TzTable* guber_host_tz_table() { return &g_host_tz; }
-int guber_host_set_tz(const guber_tz_t* tz) {
+// validate a zone and build its table; nothing is published (guber_set_timezone publishes to the devices first, to the host last)
+int guber_host_build_tz(const guber_tz_t* tz, guber::TzTable* out) {
     guber::TzTable t{};
     if (tz) {
         if (tz->n > (uint32_t)guber::TZ_MAX || (tz->n && (!tz->when_s || !tz->offset_s))) return GUBER_E_INVALID_ARG;
@@ -141,8 +142,15 @@ int guber_host_set_tz(const guber_tz_t* tz) {
             t.when_s[k] = tz->when_s[k]; t.offset_s[k] = tz->offset_s[k];
         }
     }
-    g_host_tz = t;
+    *out = t;
     return GUBER_OK;
+}
+void guber_host_publish_tz(const guber::TzTable& t) { g_host_tz = t; }
+int guber_host_set_tz(const guber_tz_t* tz) {
+    guber::TzTable t{};
+    const int rc = guber_host_build_tz(tz, &t);
+    if (rc == GUBER_OK) g_host_tz = t;
+    return rc;
 }
 extern "C" int guber_gregorian_expiration(int64_t now_ns, int64_t d, int64_t* expire_ms) {
     if (!expire_ms) return GUBER_E_INVALID_ARG;

@@ -10,3 +10,5 @@ extern "C" uint64_t guber_ring_id(const guber_ring_t* r);   // unique per guber_
 namespace guber { struct TzTable; }
 int guber_host_set_tz(const guber_tz_t* tz);                 // validates and stores the process's zone (host helpers); guber_set_timezone adds the devices
 const guber::TzTable* guber_host_tz_table();
+int guber_host_build_tz(const guber_tz_t* tz, guber::TzTable* out);   // validate + build, nothing published
+void guber_host_publish_tz(const guber::TzTable& t);                   // the host helpers' copy (guber_set_timezone: after every device has it)

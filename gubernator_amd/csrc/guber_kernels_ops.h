@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_items_probe(Table T, const ItemIn* item
 }
 // phase B: verify tentative matches, publish READY, LRUCache.Add (lrucache.go:88-103): replace the
 // value when the key is resident (existed = 1), insert otherwise.  result: 0/1 existed, 0xFF retry, 0xFE error
+constexpr uint64_t ITEMS_KEEP_STAMP = ~0ull;
 __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* items, const uint8_t* keys, uint32_t n,
                                                       const uint32_t* slots, const uint8_t* flags, uint8_t* result, uint64_t touch) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -41,7 +42,10 @@ __global__ __launch_bounds__(256) void k_items_commit(Table T, const ItemIn* ite
     if ((f & RF_NEED_VERIFY) && !key_equal(T, slot, keys + items[i].key_off, items[i].key_len)) { result[i] = 0xFF; return; }
     const bool existed = rec_kind(T.buckets[slot].rec) != K_ABSENT;
     Rec nr = items[i].rec;
-    rec_set_stamp(nr, touch + i);                     // LRUCache.Add pushes / moves the item to the front (lrucache.go:91,96); item i of the call after item i - 1
+    // LRUCache.Add pushes / moves the item to the front (lrucache.go:91,96); item i of the call after item i - 1.  ITEMS_KEEP_STAMP: the
+    // host has numbered the items itself (guber_add_items applies a call with duplicate keys in several launches: the numbers follow
+    // the items' places in the CALL, so the recency order among the call's keys is the reference's whatever the launches were)
+    if (touch != ITEMS_KEEP_STAMP) rec_set_stamp(nr, touch + i);
     T.buckets[slot].rec = nr;
     if (!existed) atomicAdd((unsigned long long*)&T.ctr->size, 1ull);
     result[i] = existed ? 1 : 0;

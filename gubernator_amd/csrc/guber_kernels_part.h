@@ -816,7 +816,7 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                 else if (leaky_fast(s0, r, B.now_ms, rank, out, after, ev)) done = true;
             }
             const bool walk = !parallel && rank == 0;
-            uint32_t lastj = i;                                          // the run's last request (walk: the last one walked)
+            uint32_t lastj = walk ? 0xffffffffu : i;                     // the run's last request (walk: the last one walked that reached the cache)
             if ((parallel && !done) || walk) {
                 Req cur = r;
                 if (parallel) {                                          // the calendar values are loaded only here
@@ -848,8 +848,8 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                             }
                         }
                         if (end) break;
-                        lastj = j;
                         cur = load_req(B, j);
+                        if (cur.algorithm <= ALGO_LEAKY) lastj = j;
                     }
                     const Rec before = after;
                     const uint32_t e1 = apply(after, cur, B.now_ms, out);
@@ -892,7 +892,10 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
                 store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
             }
-            if ((parallel && rank == total - 1) || walk) {
+            // (a request with an invalid algorithm never reaches the cache — workers.go:317-321 rejects it before tokenBucket / leakyBucket call
+            // GetItem — so it does not move its key in the recency order: a run of such requests writes nothing, a walked segment is
+            // stamped with its last request that did reach the cache)
+            if ((parallel && rank == total - 1 && r.algorithm <= ALGO_LEAKY) || (walk && lastj != 0xffffffffu)) {
                 rec_set_stamp(after, W.touch + lastj);                // the key's place in the recency order: its last request (lrucache.go:111-128)
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                 store_resp(R, i, out);
                 store_events(W, i, ev, after);
                 c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
-                if (rank == last - first) {
+                if (rank == last - first && r.algorithm <= ALGO_LEAKY) {   // (an invalid algorithm never reaches the cache: workers.go:317-321)
                     rec_set_stamp(after, W.touch + i);            // the key's place in the recency order: its last request
                     T.buckets[slot].rec = after;
                     c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
@@ -218,9 +218,11 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
             } else if (rank == 0) {
                 // requests to this key differ: apply them one by one in request order
                 Rec s = s0;
+                uint32_t lastj = 0xffffffffu;                      // the last request of the segment that reached the cache
                 for (uint32_t q = first; q <= last; ++q) {
                     const uint32_t j = W.order[q];
                     const Req rj = load_req(B, j);
+                    if (rj.algorithm <= ALGO_LEAKY) lastj = j;
                     Resp out;
                     const uint32_t ev = apply(s, rj, B.now_ms, out);
                     store_resp(R, j, out);
@@ -228,9 +230,11 @@ __global__ __launch_bounds__(256) void k_eval(Table T, BatchView B, ResultView R
                     if (out.err == 0) queue_global(T, slot, rj, 1);
                     c_over += (ev & EV_OVER) ? 1 : 0; c_hit += (ev & EV_HIT) ? 1 : 0; c_miss += (ev & EV_MISS) ? 1 : 0;
                 }
-                rec_set_stamp(s, W.touch + W.order[last]);
-                T.buckets[slot].rec = s;
-                c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                if (lastj != 0xffffffffu) {
+                    rec_set_stamp(s, W.touch + lastj);
+                    T.buckets[slot].rec = s;
+                    c_size = (int)(rec_kind(s) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+                }
             }
         }
     }

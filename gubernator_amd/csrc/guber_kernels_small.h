@@ -195,7 +195,7 @@ __device__ __forceinline__ void small_body(const Table& T, const BatchView& B, c
             if (!done) ev = eval_uniform_rank_1x(s0, r, B.now_ms, rank, o, after);
             store_resp(R, at, o);
             c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
-            if (rank == total - 1) {
+            if (rank == total - 1 && r.algorithm <= ALGO_LEAKY) {      // (an invalid algorithm never reaches the cache: workers.go:317-321)
                 rec_set_stamp(after, touch + tid);                          // the key's place in the recency order: its last request
                 T.buckets[slot].rec = after;
                 c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);

@@ -1343,6 +1343,18 @@ int GPUWorkerPool::store_eval(guber_engine_t* engine_, const guber_batch_t& B, g
 // shard its hash selects.  The reference has one cache per worker, so its AddCacheItem / GetCacheItem need no such distinction;
 // here the caller says which (behavior: the RateLimitReq behaviour the item belongs to — UpdatePeerGlobals, gubernator.go:425-459,
 // installs GLOBAL state), or leaves it open (behavior < 0): then the item goes where the key already is, the GLOBAL engine first.
+// "does this engine hold the key?" without the side effects of a cache access: guber_probe_missing only reads (k_probe_missing) — no
+// hit / miss counted, no move to the front of the recency order.  (The reference has ONE cache per worker, so its AddCacheItem /
+// GetCacheItem never have to ask where a key lives; a probe that counted would skew a GLOBAL pool's metrics and LRU order: ADVICE r04.)
+static int peek_resident(guber_engine_t* e, const uint8_t* key, uint32_t key_len, int64_t now_ms, bool* resident) {
+    const uint32_t off[2] = {0, key_len};
+    guber_batch_t b{};
+    b.n = 1; b.key_bytes = key; b.key_off = off; b.now_ms = now_ms;
+    uint8_t missing = 1;
+    const int rc = guber_probe_missing(e, &b, &missing);
+    *resident = rc == GUBER_OK && missing == 0;
+    return rc;
+}
 int GPUWorkerPool::AddCacheItem(const guber_item_t& item, int behavior) {
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
     const uint32_t dv = DeviceOf(item.key, item.key_len);
@@ -1352,10 +1364,8 @@ int GPUWorkerPool::AddCacheItem(const guber_item_t& item, int behavior) {
         guber_engine_t* ge = d.shards[d.n_plain]->engine;
         bool global = behavior >= 0 && (behavior & 2);
         if (behavior < 0) {
-            guber_item_t tmp; int f = 0;
-            const int rc = guber_get_item(ge, item.key, item.key_len, NowMs(), &tmp, &f);
+            const int rc = peek_resident(ge, item.key, item.key_len, NowMs(), &global);
             if (rc != GUBER_OK) return rc;
-            global = f != 0;
         }
         if (global) return guber_add_items(ge, &item, 1, nullptr);
     }
@@ -1366,10 +1376,15 @@ int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool*
     if (shards_.empty()) return GUBER_E_INVALID_ARG;
     Device& d = *devs_[DeviceOf((const uint8_t*)key.data(), (uint32_t)key.size())];
     std::shared_lock<std::shared_mutex> lk(d.place_mu);
-    if (has_global_) {                                                                 // the GLOBAL engine first (see AddCacheItem)
-        const int rc = guber_get_item(d.shards[d.n_plain]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
+    if (has_global_) {                                                                 // the GLOBAL engine first (see AddCacheItem): a look without side effects,
+        bool there = false;                                                            // then ONE counted access where the key lives, as the reference's one cache has
+        const int rc = peek_resident(d.shards[d.n_plain]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), &there);
         if (rc != GUBER_OK) return rc;
-        if (f) { *found = true; return GUBER_OK; }
+        if (there) {
+            const int rc2 = guber_get_item(d.shards[d.n_plain]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
+            *found = f != 0;
+            return rc2;
+        }
     }
     const int rc = guber_get_item(shards_[ShardOf(key)]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
     *found = f != 0;

@@ -354,11 +354,16 @@ int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_resu
  *      pending GLOBAL work are evicted like any other (the pending record stays queued, as the reference's queues do).
  *      Every answer, LRUCache.Size() and the unexpired evictions equal the reference's on the same request sequence
  *      (tests/test_gpu_parity.py test_evicted_keys_that_return_meet_the_reference_list,
- *      test_a_batch_larger_than_the_cache_is_evaluated_in_pieces; tests/test_kernels_devsim.py on the CPU).  What is NOT
- *      reproduced: a request with an invalid algorithm refreshes a resident key's recency (the reference rejects it before
- *      the cache, workers.go:317-321); a key whose requests ALL fail inside the algorithm (an invalid Gregorian interval) is
- *      counted as an insert when the pre-pass sizes the evictions; duplicates of one key inside one guber_add_items call are
- *      applied in waves (last one wins, as in the reference, but the recency order among the call's keys follows the waves).
+ *      test_a_batch_larger_than_the_cache_is_evaluated_in_pieces; tests/test_kernels_devsim.py on the CPU).  A request with an
+ *      invalid algorithm never reaches the cache (workers.go:317-321): it counts no access and leaves its key's place in the list
+ *      alone (test_an_invalid_algorithm_request_does_not_refresh_recency); duplicates of one key inside one guber_add_items
+ *      call leave the keys in the order of their LAST places in the call (test_duplicates_inside_one_add_keep_the_calls_order)
+ *      — both closed in round 5.  What is NOT reproduced (one case): a NEW key whose requests in a batch ALL fail inside the
+ *      algorithm — DURATION_IS_GREGORIAN with a duration that is no interval constant (interval.go:93,107) — is counted as an
+ *      insert when the eviction pre-pass sizes a batch's evictions: the reference calls GetItem (a miss) and returns the error
+ *      before Add, so it evicts one item fewer.  It takes a binding cache AND a client that sends an invalid interval constant
+ *      for a key that is not resident; answers of the batch itself are unaffected, the cache holds one live item fewer than
+ *      the reference until the next insert.
  *      Cost: nothing while live items + requests <= cache_size (size the cache with a batch of headroom); beyond that one
  *      pre-pass per batch (a dozen small launches and one stream synchronisation; the recency order of the live items comes
  *      from one table scan + sort per ~live/(2 x batch) batches: guber_stats_t.tail_rebuilds).
@@ -564,8 +569,12 @@ int guber_placement_commit(guber_placement_t* p);
 /* between plan and commit: drop one planned move (its bucket could not be migrated): the key stays where the published placement
  * has it (following its slot, or at its individual place if that was to be taken back) */
 int guber_placement_cancel(guber_placement_t* p, uint64_t key_hash);
-/* the published placement in the form guber_stage_route takes (global_engine = -1; the pointers stay valid until the placement is
- * destroyed: a commit publishes new snapshots and retires, never frees, the old ones — export again after every commit) */
+/* the published placement in the form guber_stage_route takes (global_engine = -1).  out->table points into the placement (valid
+ * until it is destroyed; its entries are atomics that a rebalance with move_slots rewrites in place); out->ex_hash / ex_shard point
+ * into the snapshot published by the LAST commit / rebalance and are valid only until the NEXT one on this placement — use the rule
+ * at once (guber_stage_route copies it to the device before it returns) or copy the arrays; export again after every commit.
+ * (Retired snapshots are kept alive for wait-free readers that loaded the pointer a few instructions before a publish — the last
+ * 64 of them — not for holders of an exported rule.) */
 int guber_placement_export(const guber_placement_t* p, struct guber_route_rule* out);
 /* The buckets of the keys with these XXH64 hashes leave `from`'s table and enter `to`'s (two logical shards of ONE GPU), on
  * the device.  The caller guarantees that neither engine has a batch with those keys being formed or in flight.  *moved

@@ -45,6 +45,15 @@ static int call_sequence(int really) {
         return rc;
     }
     if (!really) return 0;
+    {   /* setEngineTimezone: the daemon's zone (here: UTC+1 until a transition to UTC+2, then back), and UTC again for what follows */
+        const int64_t when_s[2] = {1900000000, 1915000000};
+        const int32_t offset_s[2] = {7200, 3600};
+        guber_tz_t tz;
+        tz.n = 2; tz.offset0_s = 3600; tz.when_s = when_s; tz.offset_s = offset_s;
+        rc = guber_set_timezone(&tz);
+        if (rc == GUBER_OK) rc = guber_set_timezone(NULL);
+        if (rc != GUBER_OK) { printf("set_timezone: %s (%s)\n", guber_strerror(rc), guber_last_error()); guber_pool_destroy(pool); return rc; }
+    }
     {
         enum { N = 2, STRIDE = 200 };
         const char names[] = "ab", ukeys[] = "xy";

@@ -951,6 +951,63 @@ def test_a_batch_larger_than_the_cache_is_evaluated_in_pieces():
     e.close()
 
 
+@pytest.mark.parametrize("flags", [0, 2, 64])
+def test_an_invalid_algorithm_request_does_not_refresh_recency(flags):
+    """workers.go:317-321 rejects a request with an unknown algorithm BEFORE tokenBucket / leakyBucket call cache.GetItem: it neither
+    counts as a cache access nor moves its key to the front of the list (lrucache.go:111-128).  Over a binding cache the difference
+    shows as WHO is evicted next: keys that were only "touched" by invalid requests are the oldest and go first.  (Round 4 stamped the
+    bucket with the run's last request whatever it was.)  Uniform runs of invalid requests, a segment that mixes valid and invalid ones
+    (walked: stamped with its last VALID request), keys that are not resident at all — element-wise equal to the bounded-LRU oracle,
+    sizes and counters too, on every batch pipeline."""
+    cs = 600
+    o, e = Oracle(cache_size=cs), engine(cache_size=cs, max_batch=2048, flags=flags)
+    rng = np.random.default_rng(21)
+    now = streams.NOW0
+    for step in range(20):
+        ids = rng.integers(0, 900, 700)
+        algo = (ids & 1).astype(np.uint8)
+        bad = rng.random(700) < 0.3                                   # a third of the requests carry an algorithm the reference rejects
+        if step % 4 == 1:
+            bad |= ids % 3 == 0                                       # ... whole keys' runs among them
+        algo[bad] = 7
+        b = HostBatch([f"inv_{int(i)}" for i in ids], 1, 40, 3_600_000, now, algorithm=algo)
+        got, want = e.eval(b), o.eval(b)
+        support.assert_results_equal(got, want, f"step {step}")
+        assert got.counters() == want.counters(), (step, got.counters(), want.counters())
+        now += 500
+    assert e.stats()["unexpired_evictions"] == o.counters()[3] and e.size() == o.size()
+    e.close()
+
+
+def test_duplicates_inside_one_add_keep_the_calls_order():
+    """LRUCache.Add item by item (lrucache.go:88-103, workers.go:566-581): with [A, B, A', C, B', A'', D, E] in one call the last
+    value of a key wins and the recency order is that of the keys' LAST places in the call.  guber_add_items applies duplicates in
+    several launches; every item carries the recency number of its place in the CALL, so the next evictions take the reference's
+    victims (round 4 numbered the items launch by launch: the re-added keys ended up in front of D and E)."""
+    cs = 8
+    now = streams.NOW0
+    mk = lambda k, rem: support.make_item(k, 0, limit=10, duration=3_600_000, remaining=rem, stamp=now, expire_at=now + 3_600_000)
+    o, e = Oracle(cache_size=cs), engine(cache_size=cs, max_batch=1024)
+    call = [mk("d_A", 9), mk("d_B", 8), mk("d_A", 7), mk("d_C", 6), mk("d_B", 5), mk("d_A", 4), mk("d_D", 3), mk("d_E", 2)]
+    e.add_item(mk("d_seed", 1), now); o.add_item(mk("d_seed", 1), now)        # (also sets the engine's clock)
+    for it in call:
+        o.add_item(it, now)
+    e.add_items(call)
+    assert e.size() == o.size() == 6
+    # oldest -> newest: seed, C (place 3), B (4), A (5), D (6), E (7).  Five new keys over a cache of 8 holding 6: seed, C and B go
+    b = HostBatch([f"d_new{i}" for i in range(5)], 1, 10, 3_600_000, now + 1)
+    support.assert_results_equal(e.eval(b), o.eval(b), "new keys")
+    assert e.size() == o.size() == cs
+    left = {}
+    for k in ("d_seed", "d_C", "d_B", "d_A", "d_D", "d_E"):
+        a, g = o.get_item(k, now + 2), e.get_item(k, now + 2)
+        assert (a is None) == (g is None), (k, a, g)
+        left[k] = None if a is None else a["remaining"]
+        assert a is None or a["remaining"] == g["remaining"], (k, a, g)
+    assert left == {"d_seed": None, "d_C": None, "d_B": None, "d_A": 4, "d_D": 3, "d_E": 2}, left
+    e.close()
+
+
 def test_global_engine_keeps_serving_across_rebuilds():
     """An engine created with GUBER_FLAG_GLOBAL whose directory fills with the entries of expired keys: the table is rebuilt
     (pending GLOBAL records move with their buckets) instead of rejecting the batch, and what was queued before the rebuild

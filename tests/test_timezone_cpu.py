@@ -127,3 +127,13 @@ def test_utc_is_the_default_and_a_bad_table_is_refused():
     with pytest.raises(ga.GuberError):
         ga.set_timezone(0, [(k, 0) for k in range(17)])              # more than 16
     assert helper(now_ns, 2)[0] == 1_546_387_199_999                  # (refused tables change nothing)
+
+
+def test_more_transitions_than_the_table_holds_is_a_clear_error():
+    """guber_tz_t takes 16 transitions: a zone with daylight saving time over more than eight years does not fit, and the helper says so
+    instead of handing guber_set_timezone a list it rejects with INVALID_ARG"""
+    import pytest
+    with pytest.raises(ValueError, match="at most 16"):
+        ga.zone_transitions("America/New_York", 2000, 2020)
+    off0, tr = ga.zone_transitions("America/New_York", 2018, 2025)
+    assert len(tr) == 16 and off0 == -5 * 3600

@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 outputs of scripts/gpu_profile_r04.sh (gpurun_out/<tag>/) into <tag>_rocprof_summary.{md,json}
-and roofline_traffic.json (copied to profiles/ by hand).  Exits 1 when the bench line of the traced run and the trace disagree
+"""Condense the rocprofv3 outputs of scripts/gpu_profile_r05.sh (gpurun_out/<tag>/) into <tag>_rocprof_summary.{md,json},
+roofline_traffic.json and roofline_issue.json (copied to profiles/ by hand).  Exits 1 when the bench line of the traced run and the trace disagree
 by more than 5 % on the dominant kernel's average duration (the line's HIP events against rocprofv3's timestamps).  Kernel durations: End - Start timestamps of the kernel trace.
 `dominant_kernel` = the kernel with the largest summed duration among the batch kernels; its roofline line uses the formula
 of bench.py: bytes per request x average requests per launch / average duration / 8000 GB/s.  Only the dispatches of the
 non-replayed stream count (for one table: the last N launches of k_front / k_eval2 — the earlier ones are the residency pass).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM
 section): raw = FETCH + WRITE, corrected = 2 x FETCH + WRITE (an upper bound for this mix of 16..64-byte random reads).
-usage: summarize_r04.py <tag> [pmc_batches]"""
+roofline_issue.json (round 5): from the SQ counter passes (sq_counters.json, GUBER_FUSE_EP=0 so that the three kernels are counted one
+by one): per kernel and 65536-request batch the instructions issued by kind and the quad-cycles in which a SIMD was issuing
+(SQ_ACTIVE_INST_ANY); bench.py turns their sum into roofline.issue = issue time / step time over 1024 SIMDs at 2.4 GHz.
+usage: summarize_r05.py <tag> [pmc_batches]"""
 import collections, csv, glob, json, os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 base = os.path.join(ROOT, "gpurun_out", tag)
 ALG = {"k_front": 76, "k_eval2": 73, "k_front_multi": 76, "k_eval2_multi": 73,
-       "k_part": 20, "k_own": 56, "k_eval3": 73, "k_part_multi": 20, "k_own_multi": 56, "k_eval3_multi": 73}
+       "k_part": 20, "k_own": 56, "k_eval3": 73, "k_part_multi": 20, "k_own_multi": 56, "k_eval3_multi": 73, "k_evalpart_multi": 93}
 SINGLE = ("k_front", "k_eval2", "k_part", "k_own", "k_eval3")
 violations = []
 notes = []
@@ -168,6 +171,37 @@ if tr:
                "note": "PMC bytes per 65536-request batch and kernel on the non-replayed stream, one table: token = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 correction, an "
                        "upper bound for 64-byte requests), token_raw = (FETCH_SIZE + WRITE_SIZE)*1024; token_fused[_raw] = the same per batch of a fused launch (12 shards); the bench line weights every kernel by the batches it carried (bench.py pipeline_traffic)"},
               open(os.path.join(base, "roofline_traffic.json"), "w"), indent=1)
+# ---- the issue side (SQ counters): instructions per wave and SIMD-issue time per batch ----
+try:
+    sq = json.load(open(os.path.join(base, "sq_counters.json")))
+    issue = {"clock_GHz": 2.4, "simds": 1024, "kernels": {}, "source": f"profiles/{tag}_sq_counters.txt",
+             "note": ("SQ counter passes (rocprofv3 --pmc, one group per pass) over the headline configuration with GUBER_FUSE_EP=0: per launch of a fused kernel "
+                      "(~3.9 batches) SQ_WAVES, SQ_INSTS_* and SQ_ACTIVE_INST_ANY (quad-cycles a SIMD spent issuing, summed over the chip); per batch = per launch x 1024 waves / SQ_WAVES. "
+                      "issue_us_per_batch = SQ_ACTIVE_INST_ANY x 4 cycles / (1024 SIMDs x 2.4 GHz)")}
+    lines += ["## instruction issue (SQ counters, GUBER_FUSE_EP=0: the three kernels counted one by one)", "",
+              "| kernel | waves per launch | VALU / wave | SALU / wave | LDS / wave | VMEM / wave | SMEM / wave | branch / wave | all / wave | issuing quad-cycles per batch | issue us per batch (1024 SIMDs, 2.4 GHz) |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+    tot_us = 0.0
+    for k in ("k_part_multi", "k_own_multi", "k_eval3_multi"):
+        c = {n: v["avg_per_launch"] for n, v in sq.get(k, {}).items()}
+        w = c.get("SQ_WAVES")
+        if not w:
+            continue
+        per = {n[9:].lower(): c[n] / w for n in c if n.startswith("SQ_INSTS_")}
+        allw = sum(per.values())
+        batches = w / 1024.0
+        anyq = c.get("SQ_ACTIVE_INST_ANY", 0.0) / batches
+        us = anyq * 4 / (1024 * 2.4e3)
+        tot_us += us
+        issue["kernels"][k.replace("_multi", "")] = {"insts_per_wave": {a: round(b, 1) for a, b in per.items()}, "insts_per_wave_all": round(allw, 1), "waves_per_batch": 1024,
+                                                     "active_inst_any_quad_cycles_per_batch": round(anyq, 1), "issue_us_per_batch": round(us, 4)}
+        lines.append(f"| {k} | {w:.0f} | {per.get('valu', 0):.0f} | {per.get('salu', 0):.0f} | {per.get('lds', 0):.0f} | {per.get('vmem_rd', 0) + per.get('vmem_wr', 0):.0f} | {per.get('smem', 0):.0f} | "
+                     f"{per.get('branch', 0):.0f} | {allw:.0f} | {anyq:.0f} | {us:.3f} |")
+    issue["issue_us_per_batch"] = round(tot_us, 4)
+    lines += ["", f"**issue time of one 65536-request batch: {tot_us:.3f} us** (the three kernels; what the chip's 1024 SIMDs would need if every one of them issued all the time)", ""]
+    json.dump(issue, open(os.path.join(base, "roofline_issue.json"), "w"), indent=1)
+    out["issue"] = issue
+except Exception as ex:   # noqa: BLE001
+    notes.append(f"no SQ counters for the issue roofline: {ex!r}")
 if violations:
     lines += ["## CONSISTENCY VIOLATIONS (> 5 %)", ""] + [f"* {v}" for v in violations] + [""]
 if notes:
