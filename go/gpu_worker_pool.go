@@ -63,8 +63,9 @@ import (
 // GPUWorkerPool satisfies the call surface of *WorkerPool.  devices[i] is the HIP ordinal of peer "gpu<i>" on the reference's
 // replicated consistent hash (a node's GPUs are peers of a ring inside the process); inside a device the key space is split
 // over `shards` logical shards — engines with their own HBM table — whose initial key -> shard map IS the reference's worker
-// rule (workers.go:153-155,180-184).  shards <= 0 picks 8 (conf.Workers defaults to NumCPU, which is a statement about
-// goroutines, not about tables on a GPU; GUBER_GPU_SHARDS overrides).
+// rule (workers.go:153-155,180-184).  shards <= 0 picks ONE table per device (conf.Workers defaults to NumCPU, which is a statement
+// about goroutines, not about tables on a GPU; the pool's callers are its bound, and they are fastest on one table: see below;
+// GUBER_GPU_SHARDS overrides).
 type GPUWorkerPool struct {
 	conf   *Config
 	pool   *C.guber_pool_t
@@ -119,7 +120,10 @@ func at8(p *C.uint8_t, i int) *C.uint8_t    { return (*C.uint8_t)(unsafe.Add(uns
 // batcher's BatchLimit / BatchWait do (peer_client.go:284-337); below them a batch goes as soon as the device has room.
 func NewGPUWorkerPool(conf *Config, devices []int, shards int, batchLimit int, batchWait time.Duration) (*GPUWorkerPool, error) {
 	if shards <= 0 {
-		shards = 8
+		// ONE table per device is the fastest arrangement of the pool: its callers — the host's CPUs — are the bound (16 usable CPUs:
+		// 323 M decisions/s on one table against 222 on eight shards, profiles/r04_final2_bench_driver_cmd.json), and one table alone
+		// evaluates 2.4 G/s.  Several shards per device pay where batches arrive already in HBM (guber_eval_batches_routed_dev: 10 G/s).
+		shards = 1
 	}
 	cfg := C.guber_config_t{}
 	cfg.struct_size = C.uint32_t(unsafe.Sizeof(cfg))

@@ -1039,6 +1039,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         R = ResultView{r->status, r->limit, r->remaining, r->reset_time, r->err};
         r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
     };
+    // (one batch: launch_batch.  Measured in round 5 and not kept: a sequence of ONE table's batches through these fused launches —
+    // 1.50 against 2.40 G decisions/s: 128 k_own workgroups for the whole chip take 36 us, profiles/r05_g_one_table_fused.txt)
     if (g == 1) {
         guber_engine* e = grp[0];
         if (ps) { const int rc = ps->flush_touching(grp, 1); if (rc) return rc; }

@@ -181,7 +181,9 @@ __device__ __forceinline__ Req tile_get(const TileReqs& t, uint32_t i) {
 
 __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, const Work& W, const uint32_t tile) {
     constexpr int GT_BITS = 9, GT = 1 << GT_BITS;                 // grouping table: 2 x FT entries
-    __shared__ unsigned long long gkey[GT];                       // grouping key (0 = free)
+    __shared__ alignas(16) unsigned long long gkey[GT];           // grouping key (0 = free); after the grouping (same bytes): the heads' key words
+    ulonglong2* const hkw = (ulonglong2*)gkey;                    // head thread -> {key bytes 0..7, 8..15} of a key of <= 16 bytes, zero padded
+    static_assert(GT * 8 >= FT * 16, "the heads' key words fit where the hash table was");
     __shared__ unsigned long long gbits[FT / 64][GT];             // per wave: lanes holding the entry's key
     __shared__ uint32_t sd[FT];                                   // head -> segment id
     __shared__ uint32_t sslot[FT];                                // head -> bucket slot (for the rare member that needs the bucket)
@@ -220,6 +222,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     unsigned long long gk = 0ull;
     uint64_t h = 0;
     Rec rec; rec_clear(rec);
+    unsigned long long k0 = 0ull, k1 = 0ull;                       // a key of <= 16 bytes as two zero-padded words (members against their head, through LDS)
     if (valid) {
         // Fixed-width keys (every front end that formats its keys does): the key's words are requested at the offset the first
         // two keys suggest, together with the request's own offsets instead of after them — one dependent trip less.  The words
@@ -244,7 +247,15 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
         else if (len > T.max_key) errcode = 7;
         GB_STAMPW(6);
         if (!errcode) {
-            h = (spec && off == off_g && len == len_g ? xxhash64_words4(kw, len, 0) : xxhash64(key, len, 0)) & T.hash_mask;
+            if (!(spec && off == off_g && len == len_g)) {
+                spec = false;
+                if (len <= 16) { kw[0] = ld_key_word(key); kw[1] = len > 8 ? ld_key_word(key + 8) : 0ull; }
+            }
+            h = (spec ? xxhash64_words4(kw, len, 0) : xxhash64(key, len, 0)) & T.hash_mask;
+            if (len <= 16) {
+                k0 = kw[0]; k1 = len > 8 ? kw[1] : 0ull;
+                if (len < 8) k0 &= tail_mask(len); else if (len > 8 && len < 16) k1 &= tail_mask(len - 8);
+            }
             if (W.careful) {
                 // retry round: every request finds its bucket with a full, verifying probe BEFORE anything is claimed
                 uint32_t cslot = 0;
@@ -296,6 +307,7 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     const bool head = valid && eq_before == 0;
     const bool khead = head && gk != 0ull;                           // heads that have a key to resolve
     const bool member = valid && gk != 0ull && eq_before != 0;
+    if (khead && len <= 16) hkw[tid] = make_ulonglong2(k0, k1);    // (the hash table is done with: every probe ended before the barrier above)
     GB_STAMP(1);
 
     // ---- stage 2 (heads): claim the key's cell and fetch directory entry + home bucket in the SAME round trip (most resident
@@ -345,7 +357,12 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
     // ---- stage 3: exact key comparison (member: its head's key, same tile; head: the claimer's key), and the head's
     // request against the claimer's ----
     if (member) {
-        if (!req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid])) my_flags |= SEG_RETRY;   // two keys under one hash: careful round
+        bool keq;                                                  // (two LDS words instead of walking both keys' bytes in memory)
+        if (len <= 16) {
+            keq = slen[head_tid] == len;
+            if (keq) { const ulonglong2 hk = hkw[head_tid]; keq = hk.x == k0 && hk.y == k1; }
+        } else keq = req_key_equal_at(B, off, len, soff[head_tid], slen[head_tid]);
+        if (!keq) my_flags |= SEG_RETRY;                           // two keys under one hash: careful round
     } else if (khead && d != g) {
         const uint32_t c_off = key_off_of(B, d), c_len = key_len_of(B, d, c_off);
         const Req cq = load_req_nogreg(B, d);

@@ -2,7 +2,6 @@
 #include "worker_pool.h"
 
 #include <linux/futex.h>
-#include <semaphore.h>
 #include <sys/syscall.h>
 #include <time.h>
 #include <unistd.h>
@@ -83,7 +82,11 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
         max_active_ = env_u32("GUBER_POOL_MAX_ACTIVE", cpus > 4 ? cpus - 2 - cpus / 8 : cpus);
         limit_active_ = max_active_ != 0;
         max_spinners_ = std::max(1u, std::min(cpus / 2, 16u));
-        if (limit_active_) sem_init(&active_sem_, 0, max_active_);
+        if (limit_active_) {
+            turn_.reset(new std::atomic<uint32_t>[kTurns]);
+            for (uint32_t k = 0; k < kTurns; ++k) turn_[k].store(0, std::memory_order_relaxed);
+            granted_.store(max_active_, std::memory_order_relaxed);                 // the first max_active_ tickets walk in
+        }
     }
     rebalance_ms_ = env_u32("GUBER_POOL_REBALANCE_MS", 250);         // 0 = placement stays the reference's worker rule
     if (shards == 0) shards = 1;
@@ -201,13 +204,28 @@ GPUWorkerPool::~GPUWorkerPool() {
     Close();
     for (auto& d : devs_) if (d->place) { guber_placement_destroy(d->place); d->place = nullptr; }
     if (ring_) guber_ring_destroy(ring_);
-    if (limit_active_) sem_destroy(&active_sem_);
 }
 
 // at most max_active_ callers are in the CPU part of a call at a time; the others wait their turn asleep (a counting semaphore:
 // one sleeper is woken per slot that frees up — no herd)
-void GPUWorkerPool::enter() { if (limit_active_) while (sem_wait(&active_sem_) != 0) {} }
-void GPUWorkerPool::leave() { if (limit_active_) sem_post(&active_sem_); }
+void GPUWorkerPool::enter() {
+    if (!limit_active_) return;
+    const uint64_t t = next_ticket_.fetch_add(1, std::memory_order_seq_cst);
+    std::atomic<uint32_t>* w = &turn_[t % kTurns];            // the word this ticket sleeps on: it changes whenever a ticket that maps to it is granted
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t v = w->load(std::memory_order_seq_cst);
+        if (t < granted_.load(std::memory_order_seq_cst)) return;
+        if (spins < 64) { cpu_relax(); continue; }
+        futex_wait(w, v, 2000);                               // (woken by the grant — the word has changed by then, or changes before the sleep starts; the bound is a belt)
+    }
+}
+void GPUWorkerPool::leave() {
+    if (!limit_active_) return;
+    const uint64_t t = granted_.fetch_add(1, std::memory_order_seq_cst);       // the ticket that may enter now
+    std::atomic<uint32_t>* w = &turn_[t % kTurns];
+    w->store((uint32_t)(t + 1), std::memory_order_seq_cst);
+    if (t < next_ticket_.load(std::memory_order_seq_cst)) futex_wake_all(w);    // (its holder is waiting or about to look; tickets kTurns apart share the word and look again)
+}
 
 void GPUWorkerPool::wake(Device& d) {
     d.wake.fetch_add(1, std::memory_order_seq_cst);

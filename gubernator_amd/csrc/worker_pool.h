@@ -36,7 +36,6 @@
 // reserve in them (the version is part of the word its compare-and-swap expects) and routes again.  Per-key request order
 // is therefore kept across a move.
 #pragma once
-#include <semaphore.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -232,7 +231,13 @@ class GPUWorkerPool {
     uint32_t direct_max_ = 4, direct_callers_ = 0;
     std::atomic<uint32_t> in_calls_{0};                   // calls in progress
     std::atomic<uint32_t> spinners_{0}; uint32_t max_spinners_ = 4;   // callers looking at a word instead of sleeping on it
-    sem_t active_sem_; bool limit_active_ = false;        // callers in the CPU part of a call (bounded by max_active_)
+    // callers in the CPU part of a call, bounded by max_active_ and admitted FIRST COME, FIRST SERVED: a caller takes a ticket and sleeps
+    // on the turn word of its ticket; whoever leaves grants the next ticket and wakes exactly that sleeper.  (A counting semaphore woke
+    // an arbitrary waiter: with 256 callers on 12 slots some waited for many rounds — the p99 of an RPC was 8.8 ms against a p50 of 1 ms.)
+    static constexpr uint32_t kTurns = 1024;              // more callers than this in the queue at a time: the late ones spin on a word that is not theirs yet
+    bool limit_active_ = false;
+    std::atomic<uint64_t> next_ticket_{0}, granted_{0};   // tickets handed out / tickets allowed in (ticket t may enter once t < granted_)
+    std::unique_ptr<std::atomic<uint32_t>[]> turn_;       // turn_[t % kTurns] = (uint32_t)(t + 1) once ticket t has been granted (futex word)
     mutable std::atomic<uint64_t> d_dbg_[6] = {};         // GUBER_POOL_DEBUG: where a batch's time goes
     std::atomic<bool> closed_{false};
     std::atomic<int64_t> frozen_ms_{0};
