@@ -104,15 +104,9 @@ constexpr uint32_t WIRE_WIN = 8192;
 // walk runs on the scalar unit (uniform branches, no exec-mask bookkeeping).  The usual record — tag 0x0a, a one- or two-byte
 // length — is decided from four bytes; everything else (multi-byte tags, unknown fields, long lengths) goes through scan_one over
 // plain memory: the shared, fuzzed code.
-// TABLE (k_wire_scan_tab; GUBER_WIRE_TABLE=1 in guber_wire_dev.h — built and checked against the shared framing code on the CPU,
-// not yet measured on the GPU): what the chain needs from a position is decided for EVERY position of a freshly staged window at
-// once — sixteen positions per lane and 16-byte chunk, from registers: "a record of the usual form starts here: header 2 | 3 bytes,
-// body L" as one 16-bit word, 0 for everything else — so that a step of the walk is ONE dependent LDS read instead of two reads,
-// a funnel shift and the decode.  Same decisions: the word holds exactly what the serial decode computes from the same four bytes.
-template <bool TABLE>
-__device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScratch& sc) {
+__device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScratch& sc, uint32_t only_flagged) {
+    if (only_flagged && sc.status[blockIdx.x] != 1 /* WIRE_SERIAL: k_wire_scan_par left this payload to the serial walk */) return;
     __shared__ uint32_t win[WIRE_WIN / 4 + 8];
-    __shared__ uint16_t nx[TABLE ? WIRE_WIN : 16];                    // position -> ((L << 1 | header - 2) + 1), 0 = not the usual form
     const uint32_t r = blockIdx.x;
     const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
     const uint8_t* g = in.buf + off;
@@ -147,38 +141,11 @@ __device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScrat
             for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) *(uint4*)((unsigned char*)win + (c * 64 + threadIdx.x) * 16) = v[c];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            if (TABLE) {
-#pragma unroll
-                for (uint32_t c = 0; c < WIRE_WIN / (64 * 16); ++c) {
-                    const uint32_t ci = c * 64 + threadIdx.x;                  // my chunk: its 16 bytes are in v[c], the 3 after it in the next chunk's first word
-                    if (wbase + ci * 16 >= lim) continue;                     // (nothing of the payload in it: the walk never asks)
-                    const uint32_t w[5] = {v[c].x, v[c].y, v[c].z, v[c].w, win[ci * 4 + 4]};   // (the last chunk reads the pad behind the window: positions the walk never uses — pos + 4 <= wend)
-                    uint32_t e[16];
-#pragma unroll
-                    for (uint32_t j = 0; j < 16; ++j) {
-                        const uint32_t h = (uint32_t)((((unsigned long long)w[(j >> 2) + 1] << 32) | w[j >> 2]) >> ((j & 3u) * 8));
-                        uint32_t L = 0, hdr = 0;
-                        if ((h & 0xffu) == 0x0au) {
-                            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
-                            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
-                        }
-                        e[j] = hdr ? (((L << 1) | (hdr - 2u)) + 1u) : 0u;
-                    }
-                    uint4* o = (uint4*)((unsigned char*)nx + ci * 32);
-                    o[0] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
-                    o[1] = make_uint4(e[8] | e[9] << 16, e[10] | e[11] << 16, e[12] | e[13] << 16, e[14] | e[15] << 16);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            }
         }
         const uint32_t o = pos - wbase;
         const uint32_t avail = len - pos;
         uint32_t L = 0, hdr = 0;
-        if (TABLE && avail >= 4) {                                    // (the last three bytes of a payload are decoded below, with the bytes beyond it zeroed)
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nx[o]);
-            if (e) { hdr = 2u + ((e - 1u) & 1u); L = (e - 1u) >> 1; }
-        } else {
+        {
             const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
             uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
             h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
@@ -207,8 +174,149 @@ __device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScrat
     if (st == WIRE_OK && ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc)) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
     if (threadIdx.x == 0) { sc.count[r] = count; sc.status[r] = st; }
 }
-__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc) { wire_scan_body<false>(in, sc); }
-__global__ __launch_bounds__(64) void k_wire_scan_tab(WireIn in, WireScratch sc) { wire_scan_body<true>(in, sc); }
+// only_flagged: behind k_wire_scan_par — only the payloads it left (status WIRE_SERIAL); 0 = every payload
+__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc, uint32_t only_flagged) { wire_scan_body(in, sc, only_flagged); }
+
+// ---- the chain of a payload found IN PARALLEL (round 5) ---------------------------------------------------------------------------
+// The serial walk above costs one dependent LDS read per record: 255 ns each with 64 waves on the chip, 255 us for a batch of 64
+// RPCs of 1 000 items (the reference's maximum, gubernator.go:40) — 230 M items/s where the kernels behind it take billions.  Here one
+// WORKGROUP takes a payload, 8 KB at a time:
+//   * every position of the window decides what the chain would do IF it came by ("a record of the usual form starts here: header
+//     2 | 3 bytes, body L", from the same four bytes the serial walk looks at) — up to 8 192 positions at once;
+//   * next[o] = where the chain goes from o; the positions the chain really visits — those reachable from the window's first
+//     position — are found by pointer doubling: in round k every visited position marks the one 2^k steps on and every position's
+//     pointer is squared (next = next o next); a window of 1 000-item RPCs (~290 records) is done in nine rounds of 32 LDS steps per
+//     thread instead of 290 dependent ones;
+//   * the visited positions in ascending order ARE the records in order: a popcount prefix over the 128 words of the bitmap numbers them.
+// Anything that is not the usual form where the chain really passes — a multi-byte tag, an unknown field, a length of three or more
+// bytes, a record that overruns the payload, the last three bytes of a payload — leaves the WHOLE payload to the serial walk
+// (status WIRE_SERIAL; k_wire_scan runs behind this kernel for exactly those): one source of truth for every verdict that is not
+// "ok" and for every unusual construct (scan_one, shared with the host transcoder and its fuzz).
+constexpr int32_t WIRE_SERIAL = 1;
+constexpr uint32_t WP_WIN = 8192;
+constexpr uint32_t WP_T = 1024;                                    // threads per payload: sixteen waves, four per SIMD — the rounds are chains of dependent LDS reads, other waves fill the waits
+__global__ __launch_bounds__(WP_T) void k_wire_scan_par(WireIn in, WireScratch sc) {
+    __shared__ alignas(16) uint32_t win[WP_WIN / 4 + 8];
+    __shared__ uint16_t J[2][WP_WIN];                             // position -> the position 2^k steps on (a terminal points at itself)
+    __shared__ unsigned long long reach[WP_WIN / 64];             // the positions the chain visits
+    __shared__ uint32_t wsum[WP_T / 64], s_more[3], s_bad, s_next;
+    static_assert(WP_T >= WP_WIN / 16 && WP_T >= WP_WIN / 64 && WP_WIN % WP_T == 0, "a thread per 16-byte chunk and per bitmap word");
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t r = blockIdx.x;
+    const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
+    const uint8_t* g = in.buf + off;
+    const uint32_t lim = (len + 15u) & ~15u;
+    uint32_t* ro = sc.rec_off + (size_t)r * in.cap_per_rpc; uint32_t* rl = sc.rec_len + (size_t)r * in.cap_per_rpc;
+    uint32_t pos = 0, count = 0;
+    bool serial = false;
+    auto barrier = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); };
+    enum : uint32_t { N_REC_NEXT = 0, N_REC_EXIT = 1, N_CONT = 2, N_END = 3, N_BAD = 4 };
+    while (pos < len) {
+        const uint32_t wbase = pos & ~15u;
+        const uint32_t wlen = len - wbase < WP_WIN ? len - wbase : WP_WIN;      // payload bytes in this window
+        const uint32_t nb = (wlen + WP_T) / WP_T < WP_WIN / WP_T ? (wlen + WP_T) / WP_T : WP_WIN / WP_T;   // positions 0 .. wlen, in rows of WP_T
+        // what position o is to the chain: a record followed by a position of this window / a record that leaves the window / too
+        // close to the window's end to be decided here (the next window starts with it) / the payload's end / anything else.  The
+        // usual form is decided from the four bytes at o exactly as the serial walk decides it.
+        auto node = [&](uint32_t o, uint32_t& hdr, uint32_t& L, uint32_t& nxt) -> uint32_t {
+            hdr = L = 0; nxt = o;
+            if (o >= wlen) return o == wlen ? N_END : N_BAD;
+            if (o + 4 > WP_WIN) return N_CONT;
+            if (wlen - o < 4) return N_BAD;                        // (only in a payload's last window: its last three bytes)
+            const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
+            const uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
+            if ((h & 0xffu) != 0x0au) return N_BAD;
+            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
+            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+            else return N_BAD;
+            if (hdr + L > len - (wbase + o)) return N_BAD;          // overruns the payload: the serial walk says malformed
+            nxt = o + hdr + L;
+            return nxt < WP_WIN ? N_REC_NEXT : N_REC_EXIT;
+        };
+        barrier();                                                   // (the window before this one has been read out)
+        {
+            if (t < WP_WIN / 16) {
+                const uint32_t o = t * 16;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (o < wlen + 16u && wbase + o < lim) v = *(const uint4*)(g + wbase + o);
+                *(uint4*)((unsigned char*)win + o) = v;
+            }
+            if (t < 8) win[WP_WIN / 4 + t] = 0u;
+            if (t < WP_WIN / 64) reach[t] = 0ull;
+            if (t == 0) { s_more[0] = 0u; s_bad = 0u; s_next = 0u; }
+            barrier();
+        }
+        for (uint32_t b = 0; b < nb; ++b) {                          // where the chain goes from every position (terminals: themselves)
+            const uint32_t o = b * WP_T + t;
+            uint32_t hdr, L, nxt;
+            const uint32_t k = node(o, hdr, L, nxt);
+            J[0][o] = (uint16_t)(k == N_REC_NEXT ? nxt : o);
+        }
+        if (t == 0) { const uint32_t o0 = pos - wbase; reach[o0 >> 6] = 1ull << (o0 & 63u); }
+        barrier();
+        uint32_t cur = 0;
+        for (uint32_t round = 0;; ++round) {                         // pointer doubling: after round k the chain's first 2^(k+1) positions are marked
+            if (t == 0) s_more[(round + 1) % 3] = 0u;
+            bool more = false;
+            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {                // (four rows at a time: the dependent reads of a row overlap the next rows')
+                uint32_t j[4], j2[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) j[u] = b0 + u < nb ? J[cur][(b0 + u) * WP_T + t] : 0u;
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) j2[u] = J[cur][j[u]];
+#pragma unroll
+                for (uint32_t u = 0; u < 4; ++u) {
+                    if (b0 + u >= nb) continue;                      // (uniform)
+                    J[cur ^ 1][(b0 + u) * WP_T + t] = (uint16_t)j2[u];
+                    const unsigned long long mine = reach[(b0 + u) * (WP_T / 64) + wave];   // (the word of this wave's 64 positions: a broadcast read)
+                    if ((mine >> lane) & 1ull) {
+                        if (!((reach[j[u] >> 6] >> (j[u] & 63u)) & 1ull)) { atomicOr(&reach[j[u] >> 6], 1ull << (j[u] & 63u)); more = true; }
+                    }
+                }
+            }
+            if (more) s_more[round % 3] = 1u;
+            barrier();
+            cur ^= 1;
+            if (!s_more[round % 3]) break;                           // (uniform: read after the barrier; the flag is reused three rounds later)
+        }
+        // the visited positions, in order: records (numbered by a prefix over the bitmap's words), and the one terminal
+        uint32_t mine_n = 0;
+        const unsigned long long word = t < WP_WIN / 64 ? reach[t] : 0ull;
+        for (unsigned long long m = word; m; m &= m - 1ull) {
+            const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+            uint32_t hdr, L, nxt;
+            const uint32_t k = node(o, hdr, L, nxt);
+            if (k == N_BAD) s_bad = 1u;
+            else if (k == N_REC_NEXT) mine_n++;
+            else if (k == N_REC_EXIT) { mine_n++; s_next = nxt; }
+            else s_next = o;                                         // N_CONT: the next window starts here; N_END: the payload's end
+        }
+        const uint32_t incl = wave_incl_scan_u32(mine_n);
+        if (lane == 63) wsum[wave] = incl;
+        barrier();
+        if (s_bad) { serial = true; break; }                         // (uniform)
+        uint32_t before = 0, total = 0;
+        for (uint32_t w = 0; w < WP_WIN / 64 / 64; ++w) { before += w < wave ? wsum[w] : 0u; total += wsum[w]; }   // (the bitmap's words live in the first two waves)
+        uint32_t k = count + before + incl - mine_n;
+        for (unsigned long long m = word; m; m &= m - 1ull) {
+            const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+            uint32_t hdr, L, nxt;
+            const uint32_t kind = node(o, hdr, L, nxt);
+            if (kind == N_REC_NEXT || kind == N_REC_EXIT) {
+                if (k < in.cap_per_rpc) { ro[k] = off + wbase + o + hdr; rl[k] = L; }
+                ++k;
+            }
+        }
+        count += total;
+        pos = wbase + s_next;                                        // (> the window's first position: the chain moved on, or this was its end)
+    }
+    if (t == 0) {
+        int32_t st = WIRE_OK;
+        if (serial) st = WIRE_SERIAL;
+        else if ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
+        sc.count[r] = count; sc.status[r] = st;
+    }
+}
 
 // first[r] = where RPC r's items start (RPCs that are not ok contribute nothing), first[nrpc] = the batch size; an RPC that would not
 // fit the arrays any more is turned away as too large

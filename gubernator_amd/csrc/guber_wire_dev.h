@@ -85,11 +85,11 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
     if (is_owner) HIPCHK(hipMemcpyAsync(d->d_owner.p, is_owner, nrpc, hipMemcpyHostToDevice, st));
     else HIPCHK(hipMemsetAsync(d->d_owner.p, 1, nrpc, st));
     d->in.nrpc = nrpc; d->in.max_per_rpc = max_per_rpc; d->out.now_ms = now_ms;
-    // GUBER_WIRE_TABLE=1: the walk over a per-window table of decoded positions (guber_kernels_wire.h "TABLE"; same verdicts, checked on
-    // the CPU in tests/test_wire_scan_devsim.py) — off until it has been measured on the GPU
-    static const bool wire_table = [] { const char* v = getenv("GUBER_WIRE_TABLE"); return v && atoi(v) != 0; }();
-    if (wire_table) hipLaunchKernelGGL(guber::k_wire_scan_tab, dim3(nrpc), dim3(64), 0, st, d->in, d->sc);
-    else hipLaunchKernelGGL(guber::k_wire_scan, dim3(nrpc), dim3(64), 0, st, d->in, d->sc);
+    // the chain of every payload: in parallel (k_wire_scan_par: a workgroup per payload, pointer doubling over 8 KB windows), then the
+    // serial walk for the payloads that hold anything but plain records (GUBER_WIRE_SERIAL=1: the serial walk for all, for A/B runs)
+    static const bool wire_serial = [] { const char* v = getenv("GUBER_WIRE_SERIAL"); return v && atoi(v) != 0; }();
+    if (!wire_serial) hipLaunchKernelGGL(guber::k_wire_scan_par, dim3(nrpc), dim3(guber::WP_T), 0, st, d->in, d->sc);
+    hipLaunchKernelGGL(guber::k_wire_scan, dim3(nrpc), dim3(64), 0, st, d->in, d->sc, wire_serial ? 0u : 1u);
     hipLaunchKernelGGL(guber::k_wire_prefix, dim3(1), dim3(256), 0, st, d->in, d->sc);
     const unsigned blocks = (d->max_items + 255) / 256;
     hipLaunchKernelGGL(guber::k_wire_fill, dim3(blocks), dim3(256), 0, st, d->in, d->sc, d->out);

@@ -1,8 +1,11 @@
-"""The device wire decoder's chain walk — k_wire_scan and its table variant k_wire_scan_tab (guber_kernels_wire.h: GUBER_WIRE_TABLE) —
-compiled for the host (tests/hostsim/wiresim.cpp: fakehip, one wave at a time) against the framing code they share with the host
+"""The device wire decoder's chain walks — the serial k_wire_scan, and the parallel k_wire_scan_par (a workgroup per payload: pointer
+doubling over 8 KB windows) with the serial walk behind it for what it leaves (guber_kernels_wire.h) —
+compiled for the host (tests/hostsim/wiresim.cpp: fakehip) against the framing code they share with the host
 transcoder and its AddressSanitizer fuzz (scan_toplevel over plain memory): generated and mutated payloads (bodies full of bytes that
 look like tags, 1- / 2- / 3-byte and non-minimal lengths, unknown fields of every wire type, multi-byte and over-long tags,
-truncations, flipped bytes) — item counts, verdicts and every record's offset and length agree.  The GPU twin is
+truncations, flipped bytes; and payloads of nothing but plain records: thousands of them over several windows, records across and
+longer than a window, empty records, ends on a window's edge) — item counts, verdicts and every record's offset and length agree, and
+the parallel walk really finishes the plain payloads on its own.  The GPU twin is
 tests/test_gpu_wire_dev.py (against the host transcoder)."""
 import ctypes as C
 import os
@@ -20,18 +23,19 @@ def lib():
     subprocess.run(["make", "-s", "-C", HS, "wiresim_lib"], check=True)
     L = C.CDLL(os.path.join(HS, "libwiresim.so"))
     L.ws_fuzz.restype = C.c_uint64
-    L.ws_fuzz.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_ulonglong)]
+    L.ws_fuzz.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_ulonglong)]      # (.., mode, max_per_rpc, stats[4])
     return L
 
 
-@pytest.mark.parametrize("table", [0, 1])
+@pytest.mark.parametrize("table", [0, 1], ids=["serial", "parallel_then_serial"])
 @pytest.mark.parametrize("max_per_rpc", [0, 1000])
 def test_chain_walk_agrees_with_the_shared_framing_code(lib, table, max_per_rpc):
     total = 0
     for seed in range(4):
-        st = (C.c_ulonglong * 3)()
+        st = (C.c_ulonglong * 4)()
         bad = lib.ws_fuzz(300, 1000 + seed, table, max_per_rpc, st)
         assert bad == 0, (seed, bad)
         assert st[0] > 700 and st[2] > 25           # payloads, of which malformed / too large
+        assert not table or st[3] > 300, st[3]      # payloads the parallel walk finished without the serial one
         total += st[1]
     assert total > 300_000                           # records walked
