@@ -789,7 +789,27 @@ __device__ __forceinline__ void eval3_body(const EvalArgs& A, const uint32_t til
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0ull;
     GP_STAMPW(2, 1);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
-    if (live) {
+    // The wave in which EVERY request is the common case — a live token bucket met by a request that does not reconfigure it, nothing
+    // flagged, no Store side channel, no GLOBAL bookkeeping — runs straight through the closed form: one ballot instead of the general
+    // path's cascade of divergent branches (error codes, flags, the leaky form, the serial walk, events, queues), each of which costs
+    // every wave its exec-mask bookkeeping whether a lane takes it or not.  Exactly the general path's own steps for such a request
+    // (token_fast_ok -> token_fast -> store -> the run's last request writes the bucket), so the results are the same by construction.
+    const bool plain = !live || (!derr && sf == 0u && !(smeta & SM_HAS_INVALID) && token_fast_ok(s0, r, B.now_ms));
+    const bool plain_wave = !W.store_flags && !T.gpend && __ballot(!plain) == 0ull;
+    if (plain_wave) {
+        if (live) {
+            const uint32_t rank = base + lr;
+            Rec after; Resp out;
+            const uint32_t ev = token_fast(s0, r, rank, out, after);
+            store_resp(R, i, out);
+            c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+            if (rank == total - 1) {
+                rec_set_stamp(after, W.touch + i);                    // the key's place in the recency order: its last request (lrucache.go:111-128)
+                T.buckets[slot].rec = after;
+                c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+            }
+        }
+    } else if (live) {
         const uint32_t rank = base + lr;
         const bool flagged = (sf & (SEG_NONUNIFORM | SEG_CREATED_DIFFERS)) != 0u;
         if (derr) {

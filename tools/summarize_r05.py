@@ -41,8 +41,8 @@ def bench_line(log):
 
 
 for key, d, lastn, title in (("fused", "trace_fused", None, "the default bench command (12 logical shards, one dispatcher, 3 streams): up to four tables per launch, owner-partitioned pipeline"),
-                             ("shards_1", "trace_s1", 1024 + 16 + 128 + 128, "one table (--shards 1, 1024 timed batches), default policy: the two-launch pipeline with claims, one batch in flight"),
-                             ("shards_1_part", "trace_s1_part", 1024 + 16 + 128 + 128, "one table, GUBER_PIPELINE=part: the owner-partitioned pipeline, one batch in flight")):
+                             ("shards_1", "trace_s1", 1024 + 16 + 4096 + 1024, "one table (--shards 1, 1024 timed batches), default policy: the two-launch pipeline with claims, one batch in flight"),
+                             ("shards_1_part", "trace_s1_part", 1024 + 16 + 4096 + 1024, "one table, GUBER_PIPELINE=part: the owner-partitioned pipeline, one batch in flight")):
     path = find(d, "*kernel_trace.csv")
     if not path:
         continue
