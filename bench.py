@@ -1021,7 +1021,8 @@ def run_pool(args):
     except Exception:   # noqa: BLE001
         pass
     cases = {"rpc_1000": (64, 8, 1000, args.keys, 2.0), "rpc_1000_256_callers": (256, 8, 1000, args.keys, 2.0), "rpc_1000_12_shards": (64, 12, 1000, args.keys, 2.0),
-             "rpc_1000_one_table": (64, 1, 1000, args.keys, 2.0), "rpc_1": (16, 8, 1, args.keys, 1.0), "rpc_1_one_caller": (1, 8, 1, args.keys, 1.0)}
+             "rpc_1000_one_table": (64, 1, 1000, args.keys, 2.0), "rpc_1000_one_table_128_callers": (128, 1, 1000, args.keys, 2.0),
+             "rpc_1": (16, 8, 1, args.keys, 1.0), "rpc_1_one_caller": (1, 8, 1, args.keys, 1.0)}
     for label, (T, S, items, keys, secs) in cases.items():
         p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs)], capture_output=True, text=True, timeout=300)
         mm = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)(?:, rpc latency p50 ([0-9.]+) us p99 ([0-9.]+) us)?", p.stdout)
