@@ -194,6 +194,23 @@ __global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc, uin
 // "ok" and for every unusual construct (scan_one, shared with the host transcoder and its fuzz).
 constexpr int32_t WIRE_SERIAL = 1;
 constexpr uint32_t WP_WIN = 8192;
+// inclusive prefix sum over a wave's 64 lanes, all active (this header stands alone — the host transcoder's fuzz compiles it without
+// the batch kernels' headers — so it carries its own copy of guber_table.h's wave_incl_scan_i32: DPP on the device, shuffles elsewhere)
+__device__ __forceinline__ uint32_t wire_wave_incl_scan(uint32_t x) {
+    int v = (int)x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+#else
+    const int lane = (int)(threadIdx.x & 63);
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, (unsigned)o, 64); if (lane >= o) v += t; }
+#endif
+    return (uint32_t)v;
+}
 constexpr uint32_t WP_T = 1024;                                    // threads per payload: sixteen waves, four per SIMD — the rounds are chains of dependent LDS reads, other waves fill the waits
 __global__ __launch_bounds__(WP_T) void k_wire_scan_par(WireIn in, WireScratch sc) {
     __shared__ alignas(16) uint32_t win[WP_WIN / 4 + 8];
@@ -291,7 +308,7 @@ __global__ __launch_bounds__(WP_T) void k_wire_scan_par(WireIn in, WireScratch s
             else if (k == N_REC_EXIT) { mine_n++; s_next = nxt; }
             else s_next = o;                                         // N_CONT: the next window starts here; N_END: the payload's end
         }
-        const uint32_t incl = wave_incl_scan_u32(mine_n);
+        const uint32_t incl = wire_wave_incl_scan(mine_n);
         if (lane == 63) wsum[wave] = incl;
         barrier();
         if (s_bad) { serial = true; break; }                         // (uniform)

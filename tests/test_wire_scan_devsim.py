@@ -31,11 +31,12 @@ def lib():
 @pytest.mark.parametrize("max_per_rpc", [0, 1000])
 def test_chain_walk_agrees_with_the_shared_framing_code(lib, table, max_per_rpc):
     total = 0
+    iters = 100 if table else 300                    # (the parallel walk is 1 024 fibers per payload on the CPU: fewer rounds of it)
     for seed in range(4):
         st = (C.c_ulonglong * 4)()
-        bad = lib.ws_fuzz(300, 1000 + seed, table, max_per_rpc, st)
+        bad = lib.ws_fuzz(iters, 1000 + seed, table, max_per_rpc, st)
         assert bad == 0, (seed, bad)
-        assert st[0] > 700 and st[2] > 25           # payloads, of which malformed / too large
-        assert not table or st[3] > 300, st[3]      # payloads the parallel walk finished without the serial one
+        assert st[0] > 2 * iters and st[2] > iters // 15          # payloads, of which malformed / too large
+        assert not table or st[3] > iters, st[3]                  # payloads the parallel walk finished without the serial one
         total += st[1]
-    assert total > 300_000                           # records walked
+    assert total > 1000 * iters                                   # records walked
