@@ -7,7 +7,8 @@
 //   k_wire_scan   one wave per RPC payload walks that chain — headers only (tag + length, 2-3 bytes per record), read from a window
 //                 of the payload staged in LDS, every lane computing the same thing (broadcast reads, no divergence) — and leaves
 //                 every record's offset and length, the RPC's item count and its status (ok / malformed / too many items);
-//   k_wire_prefix one workgroup: where each RPC's items start in the batch (exclusive scan of the counts of the RPCs that are ok);
+//                 (the usual payload — nothing but plain records — has its chain found in parallel first: k_wire_win_a / k_wire_win_b below);
+//                 the launch's last workgroup: where each RPC's items start in the batch (exclusive scan of the counts of the RPCs that are ok);
 //   k_wire_fill   one thread per item: the record body through guber::wire::parse_req — the SAME source the host transcoder and its
 //                 AddressSanitizer fuzz compile (guber_wire_parse.h: every read bounded by the record) — into the arrays: HashKey
 //                 bytes `name + "_" + unique_key` (client.go:39-41) as one row per item, the CreatedAt default, the algorithm code,
@@ -91,7 +92,12 @@ struct WireIn {
     uint32_t max_per_rpc;           // 0 = no cap (gubernator.go:40 passes 1000)
     uint32_t cap_items;             // items the output arrays hold
 };
-struct WireScratch { uint32_t* rec_off; uint32_t* rec_len; uint32_t* count; int32_t* status; uint32_t* first; };
+struct WireScratch {
+    uint32_t* rec_off; uint32_t* rec_len; uint32_t* count; int32_t* status; uint32_t* first;
+    const uint32_t* wfirst;         // [nrpc + 1] the windows of the payloads, numbered through the batch (k_wire_win_*): where each payload's start
+    uint2* went;                    // [windows][WP_ENT] k_wire_win_a -> k_wire_win_b
+    uint32_t* done;                 // workgroups of k_wire_scan that have finished (zero between launches)
+};
 struct WireOut {
     uint8_t* key_rows; uint32_t key_stride; uint32_t* key_len;
     int64_t *hits, *limit, *duration, *burst, *created_at; uint32_t* behavior; int32_t* algo_raw;
@@ -104,8 +110,7 @@ constexpr uint32_t WIRE_WIN = 8192;
 // walk runs on the scalar unit (uniform branches, no exec-mask bookkeeping).  The usual record — tag 0x0a, a one- or two-byte
 // length — is decided from four bytes; everything else (multi-byte tags, unknown fields, long lengths) goes through scan_one over
 // plain memory: the shared, fuzzed code.
-__device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScratch& sc, uint32_t only_flagged) {
-    if (only_flagged && sc.status[blockIdx.x] != 1 /* WIRE_SERIAL: k_wire_scan_par left this payload to the serial walk */) return;
+__device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScratch& sc) {
     __shared__ uint32_t win[WIRE_WIN / 4 + 8];
     const uint32_t r = blockIdx.x;
     const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
@@ -174,26 +179,40 @@ __device__ __forceinline__ void wire_scan_body(const WireIn& in, const WireScrat
     if (st == WIRE_OK && ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc)) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
     if (threadIdx.x == 0) { sc.count[r] = count; sc.status[r] = st; }
 }
-// only_flagged: behind k_wire_scan_par — only the payloads it left (status WIRE_SERIAL); 0 = every payload
-__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc, uint32_t only_flagged) { wire_scan_body(in, sc, only_flagged); }
+// (the kernel: k_wire_scan below — it also numbers the batch)
 
 // ---- the chain of a payload found IN PARALLEL (round 5) ---------------------------------------------------------------------------
 // The serial walk above costs one dependent LDS read per record: 255 ns each with 64 waves on the chip, 255 us for a batch of 64
-// RPCs of 1 000 items (the reference's maximum, gubernator.go:40) — 230 M items/s where the kernels behind it take billions.  Here one
-// WORKGROUP takes a payload, 8 KB at a time:
+// RPCs of 1 000 items (the reference's maximum, gubernator.go:40) — 230 M items/s where the kernels behind it take billions.  Here a
+// payload is cut into WINDOWS of 8 KB at fixed positions and every window gets a WORKGROUP:
 //   * every position of the window decides what the chain would do IF it came by ("a record of the usual form starts here: header
-//     2 | 3 bytes, body L", from the same four bytes the serial walk looks at) — up to 8 192 positions at once;
-//   * next[o] = where the chain goes from o; the positions the chain really visits — those reachable from the window's first
-//     position — are found by pointer doubling: in round k every visited position marks the one 2^k steps on and every position's
-//     pointer is squared (next = next o next); a window of 1 000-item RPCs (~290 records) is done in nine rounds of 32 LDS steps per
-//     thread instead of 290 dependent ones;
+//     2 | 3 bytes, body L", from the same four bytes the serial walk looks at) — 8 192 positions at once;
+//   * next[o] = where the chain goes from o; the positions the chain really visits — those reachable from the position the chain
+//     ENTERS the window at — are found by pointer doubling: in round k every visited position marks the one 2^k steps on and every
+//     position's pointer is squared (next = next o next); a window of 1 000-item RPCs (~290 records) is done in nine rounds of 32 LDS
+//     steps per thread instead of 290 dependent ones;
 //   * the visited positions in ascending order ARE the records in order: a popcount prefix over the 128 words of the bitmap numbers them.
+// Where the chain enters a window, and how many records came before, is what the window before it knows.  So that the windows of a
+// payload need not wait for each other, a first launch (k_wire_win_a) answers that question for EVERY position a chain could enter
+// at: the same pointer doubling without the marks, with the number of records riding on the pointers ({where, how many} composed:
+// exact whatever order the words are updated in, so it runs in place), leaves for each of a window's first WP_ENT positions where a
+// chain entering THERE leaves the window and how many records it passes.  The second launch (k_wire_win_b: a workgroup per window
+// again) follows those answers from position 0 of the payload through the windows before its own — one thread, one dependent load per
+// window, beside the loads of its window — and then marks, numbers and writes its own records: four windows of a 1 000-item payload
+// run side by side instead of one after the other.
 // Anything that is not the usual form where the chain really passes — a multi-byte tag, an unknown field, a length of three or more
-// bytes, a record that overruns the payload, the last three bytes of a payload — leaves the WHOLE payload to the serial walk
-// (status WIRE_SERIAL; k_wire_scan runs behind this kernel for exactly those): one source of truth for every verdict that is not
-// "ok" and for every unusual construct (scan_one, shared with the host transcoder and its fuzz).
+// bytes, a record that overruns the payload, the last three bytes of a payload, a record of more than WP_ENT bytes across a window's
+// edge — leaves the WHOLE payload to the serial walk (status WIRE_SERIAL, set by the workgroup of the payload's last window, which
+// sees every window's answer; k_wire_scan runs behind this kernel for exactly those): one source of truth for every verdict that is
+// not "ok" and for every unusual construct (scan_one, shared with the host transcoder and its fuzz).  The windows in front of such a
+// place have written their records by then: the same values the serial walk writes again.
 constexpr int32_t WIRE_SERIAL = 1;
-constexpr uint32_t WP_WIN = 8192;
+constexpr uint32_t WP_WIN = 8192;                                  // bytes per window (the window's workgroup also reads the 16 bytes behind it)
+constexpr uint32_t WP_ENT = 1024;                                  // positions of a window a chain may enter at (= the longest record across an edge)
+constexpr uint32_t WP_T = 1024;                                    // threads per window: sixteen waves, four per SIMD — the rounds are chains of dependent LDS reads, other waves fill the waits
+constexpr uint32_t WP_NONE = 0xffffffffu, WP_SKIP = 0xfffffffeu;
+constexpr uint32_t WP_MIN = 1024;                                  // a payload shorter than this (three dozen records) is the serial walk's from the start: a wave is enough for it
+GW_HD uint32_t wire_windows_of(uint32_t len) { return len < WP_MIN ? 0u : len / WP_WIN + 1u; }     // (position `len`, the chain's end, lies in the last window)
 // inclusive prefix sum over a wave's 64 lanes, all active (this header stands alone — the host transcoder's fuzz compiles it without
 // the batch kernels' headers — so it carries its own copy of guber_table.h's wave_incl_scan_i32: DPP on the device, shuffles elsewhere)
 __device__ __forceinline__ uint32_t wire_wave_incl_scan(uint32_t x) {
@@ -211,160 +230,267 @@ __device__ __forceinline__ uint32_t wire_wave_incl_scan(uint32_t x) {
 #endif
     return (uint32_t)v;
 }
-constexpr uint32_t WP_T = 1024;                                    // threads per payload: sixteen waves, four per SIMD — the rounds are chains of dependent LDS reads, other waves fill the waits
-__global__ __launch_bounds__(WP_T) void k_wire_scan_par(WireIn in, WireScratch sc) {
+__device__ __forceinline__ void wire_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// the workgroup's window: blockIdx -> (payload, window) through wfirst[] (where each payload's windows start: the host knows the lengths)
+struct WireWindow {
+    uint32_t r, w, nwin, off, len, wbase, rest;                    // rest = payload bytes from the window's first position on
+    const uint8_t* g;
+};
+__device__ __forceinline__ WireWindow wire_window(const WireIn& in, const WireScratch& sc) {
+    uint32_t lo = 0, hi = in.nrpc;                                   // the last payload whose first window is <= blockIdx: it has windows, the next one's start behind blockIdx
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sc.wfirst[mid] <= blockIdx.x) lo = mid; else hi = mid; }
+    WireWindow W;
+    W.r = lo; W.w = blockIdx.x - sc.wfirst[lo];
+    W.off = in.rpc_off[lo]; W.len = in.rpc_len[lo];
+    W.nwin = W.len / WP_WIN + 1u;
+    W.wbase = W.w * WP_WIN; W.rest = W.len - W.wbase;
+    W.g = in.buf + W.off;
+    return W;
+}
+// the window's bytes + the 16 behind them (a position decides from its four bytes) -> LDS; zero beyond the payload's 16-byte chunks
+__device__ __forceinline__ void wire_window_load(const WireWindow& W, uint32_t* win) {
+    const uint32_t t = threadIdx.x, lim = (W.len + 15u) & ~15u;
+    if (t <= WP_WIN / 16) {
+        const uint32_t o = t * 16;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (o < W.rest + 16u && W.wbase + o < lim) v = *(const uint4*)(W.g + W.wbase + o);
+        *(uint4*)((unsigned char*)win + o) = v;
+    }
+    if (t < 4) win[WP_WIN / 4 + 4 + t] = 0u;
+}
+// what position o is to the chain: a record followed by a position of this window / a record that leaves the window / the payload's
+// end / anything else.  The usual form is decided from the four bytes at o exactly as the serial walk decides it.
+enum : uint32_t { N_REC_NEXT = 0, N_REC_EXIT = 1, N_END = 3, N_BAD = 4 };
+__device__ __forceinline__ uint32_t wire_node(const WireWindow& W, const uint32_t* win, uint32_t o, uint32_t& hdr, uint32_t& L, uint32_t& nxt) {
+    hdr = L = 0; nxt = o;
+    if (o >= W.rest) return o == W.rest ? N_END : N_BAD;
+    if (W.rest - o < 4) return N_BAD;                              // (a payload's last three bytes: the serial walk's)
+    const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
+    const uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
+    if ((h & 0xffu) != 0x0au) return N_BAD;
+    if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
+    else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
+    else return N_BAD;
+    if (hdr + L > W.rest - o) return N_BAD;                        // overruns the payload: the serial walk says malformed
+    nxt = o + hdr + L;
+    return nxt < WP_WIN ? N_REC_NEXT : N_REC_EXIT;
+}
+
+// first launch: for every window but a payload's last, went[window][p] = {where a chain that enters at p leaves (a position of the
+// payload; WP_NONE: it meets something the serial walk must see), records it passes}, p < WP_ENT
+__global__ __launch_bounds__(WP_T) void k_wire_win_a(WireIn in, WireScratch sc) {
+    __shared__ alignas(16) uint32_t win[WP_WIN / 4 + 8];
+    __shared__ uint32_t JC[WP_WIN];                                 // position -> where 2^k or more steps on (a terminal: itself) | records passed << 16
+    __shared__ uint32_t s_more[3];
+    static_assert(WP_T > WP_WIN / 16 && WP_WIN % WP_T == 0 && WP_ENT == WP_T, "a thread per 16-byte chunk, per entry");
+    const WireWindow W = wire_window(in, sc);
+    if (W.w + 1u >= W.nwin) return;                                  // nothing comes after a payload's last window
+    const uint32_t t = threadIdx.x;
+    constexpr uint32_t NB = WP_WIN / WP_T;
+    wire_window_load(W, win);
+    if (t == 0) s_more[0] = 0u;
+    wire_barrier();
+#pragma unroll
+    for (uint32_t b = 0; b < NB; ++b) {
+        const uint32_t o = b * WP_T + t;
+        uint32_t hdr, L, nxt;
+        JC[o] = wire_node(W, win, o, hdr, L, nxt) == N_REC_NEXT ? (nxt | (1u << 16)) : o;
+    }
+    wire_barrier();
+    for (uint32_t round = 0;; ++round) {
+        if (t == 0) s_more[(round + 1) % 3] = 0u;
+        bool more = false;
+#pragma unroll
+        for (uint32_t b0 = 0; b0 < NB; b0 += 4) {
+            uint32_t a[4], c[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) a[u] = JC[(b0 + u) * WP_T + t];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) c[u] = JC[a[u] & 0xffffu];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) {
+                const uint32_t nv = (c[u] & 0xffffu) | ((a[u] & 0xffff0000u) + (c[u] & 0xffff0000u));
+                if (nv != a[u]) { JC[(b0 + u) * WP_T + t] = nv; if (b0 + u == 0) more = true; }   // (done when the ENTRIES stand still: each is at a terminal then)
+            }
+        }
+        if (more) s_more[round % 3] = 1u;
+        wire_barrier();
+        if (!s_more[round % 3]) break;                               // (uniform: read after the barrier; the flag is reused three rounds later)
+    }
+    {
+        const uint32_t v = JC[t], tn = v & 0xffffu;
+        uint32_t hdr, L, nxt;
+        uint2 e = make_uint2(WP_NONE, 0u);
+        if (wire_node(W, win, tn, hdr, L, nxt) == N_REC_EXIT) e = make_uint2(W.wbase + nxt, (v >> 16) + 1u);
+        sc.went[(size_t)blockIdx.x * WP_ENT + t] = e;
+    }
+}
+
+// second launch: the window's records
+__global__ __launch_bounds__(WP_T) void k_wire_win_b(WireIn in, WireScratch sc) {
     __shared__ alignas(16) uint32_t win[WP_WIN / 4 + 8];
     __shared__ uint16_t J[2][WP_WIN];                             // position -> the position 2^k steps on (a terminal points at itself)
     __shared__ unsigned long long reach[WP_WIN / 64];             // the positions the chain visits
-    __shared__ uint32_t wsum[WP_T / 64], s_more[3], s_bad, s_next;
-    static_assert(WP_T >= WP_WIN / 16 && WP_T >= WP_WIN / 64 && WP_WIN % WP_T == 0, "a thread per 16-byte chunk and per bitmap word");
+    __shared__ uint32_t wsum[WP_T / 64], s_more[3], s_bad, s_entry, s_base;
+    static_assert(WP_T >= WP_WIN / 64, "a thread per bitmap word");
+    const WireWindow W = wire_window(in, sc);
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t r = blockIdx.x;
-    const uint32_t off = in.rpc_off[r], len = in.rpc_len[r];
-    const uint8_t* g = in.buf + off;
-    const uint32_t lim = (len + 15u) & ~15u;
-    uint32_t* ro = sc.rec_off + (size_t)r * in.cap_per_rpc; uint32_t* rl = sc.rec_len + (size_t)r * in.cap_per_rpc;
-    uint32_t pos = 0, count = 0;
-    bool serial = false;
-    auto barrier = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); };
-    enum : uint32_t { N_REC_NEXT = 0, N_REC_EXIT = 1, N_CONT = 2, N_END = 3, N_BAD = 4 };
-    while (pos < len) {
-        const uint32_t wbase = pos & ~15u;
-        const uint32_t wlen = len - wbase < WP_WIN ? len - wbase : WP_WIN;      // payload bytes in this window
-        const uint32_t nb = (wlen + WP_T) / WP_T < WP_WIN / WP_T ? (wlen + WP_T) / WP_T : WP_WIN / WP_T;   // positions 0 .. wlen, in rows of WP_T
-        // what position o is to the chain: a record followed by a position of this window / a record that leaves the window / too
-        // close to the window's end to be decided here (the next window starts with it) / the payload's end / anything else.  The
-        // usual form is decided from the four bytes at o exactly as the serial walk decides it.
-        auto node = [&](uint32_t o, uint32_t& hdr, uint32_t& L, uint32_t& nxt) -> uint32_t {
-            hdr = L = 0; nxt = o;
-            if (o >= wlen) return o == wlen ? N_END : N_BAD;
-            if (o + 4 > WP_WIN) return N_CONT;
-            if (wlen - o < 4) return N_BAD;                        // (only in a payload's last window: its last three bytes)
-            const uint32_t w0 = win[o >> 2], w1 = win[(o >> 2) + 1];
-            const uint32_t h = (uint32_t)((((unsigned long long)w1 << 32) | w0) >> ((o & 3u) * 8));
-            if ((h & 0xffu) != 0x0au) return N_BAD;
-            if (!(h & 0x8000u)) { L = (h >> 8) & 0x7fu; hdr = 2; }
-            else if (!(h & 0x800000u)) { L = ((h >> 8) & 0x7fu) | ((h >> 9) & 0x3f80u); hdr = 3; }
-            else return N_BAD;
-            if (hdr + L > len - (wbase + o)) return N_BAD;          // overruns the payload: the serial walk says malformed
-            nxt = o + hdr + L;
-            return nxt < WP_WIN ? N_REC_NEXT : N_REC_EXIT;
-        };
-        barrier();                                                   // (the window before this one has been read out)
-        {
-            if (t < WP_WIN / 16) {
-                const uint32_t o = t * 16;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (o < wlen + 16u && wbase + o < lim) v = *(const uint4*)(g + wbase + o);
-                *(uint4*)((unsigned char*)win + o) = v;
-            }
-            if (t < 8) win[WP_WIN / 4 + t] = 0u;
-            if (t < WP_WIN / 64) reach[t] = 0ull;
-            if (t == 0) { s_more[0] = 0u; s_bad = 0u; s_next = 0u; }
-            barrier();
+    const bool last = W.w + 1u == W.nwin;
+    uint32_t* ro = sc.rec_off + (size_t)W.r * in.cap_per_rpc; uint32_t* rl = sc.rec_len + (size_t)W.r * in.cap_per_rpc;
+    const uint32_t wlen = W.rest < WP_WIN ? W.rest : WP_WIN;
+    const uint32_t nb = (wlen + WP_T) / WP_T < WP_WIN / WP_T ? (wlen + WP_T) / WP_T : WP_WIN / WP_T;   // positions 0 .. wlen, in rows of WP_T
+    wire_window_load(W, win);
+    if (t < WP_WIN / 64) reach[t] = 0ull;
+    if (t == 0) { s_more[0] = 0u; s_bad = 0u; }
+    if (t == WP_T - 1u) {                                            // where the chain enters this window, and the records before it
+        uint32_t pos = 0, cnt = 0, wc = 0;
+        bool bad = false;
+        while (wc < W.w) {
+            const uint32_t o = pos - wc * WP_WIN;
+            if (o >= WP_ENT) { bad = true; break; }
+            const uint2 e = sc.went[(size_t)(blockIdx.x - W.w + wc) * WP_ENT + o];
+            if (e.x == WP_NONE) { bad = true; break; }
+            cnt += e.y; pos = e.x; wc = pos / WP_WIN;
         }
-        for (uint32_t b = 0; b < nb; ++b) {                          // where the chain goes from every position (terminals: themselves)
-            const uint32_t o = b * WP_T + t;
-            uint32_t hdr, L, nxt;
-            const uint32_t k = node(o, hdr, L, nxt);
-            J[0][o] = (uint16_t)(k == N_REC_NEXT ? nxt : o);
-        }
-        if (t == 0) { const uint32_t o0 = pos - wbase; reach[o0 >> 6] = 1ull << (o0 & 63u); }
-        barrier();
-        uint32_t cur = 0;
-        for (uint32_t round = 0;; ++round) {                         // pointer doubling: after round k the chain's first 2^(k+1) positions are marked
-            if (t == 0) s_more[(round + 1) % 3] = 0u;
-            bool more = false;
-            for (uint32_t b0 = 0; b0 < nb; b0 += 4) {                // (four rows at a time: the dependent reads of a row overlap the next rows')
-                uint32_t j[4], j2[4];
+        s_entry = bad ? WP_NONE : wc > W.w ? WP_SKIP : pos - W.wbase;
+        s_base = cnt;
+    }
+    wire_barrier();
+    const uint32_t entry = s_entry, base = s_base;
+    if (entry == WP_NONE) { if (last && t == 0) { sc.count[W.r] = 0u; sc.status[W.r] = WIRE_SERIAL; } return; }
+    if (entry == WP_SKIP) return;                                    // a record longer than a window passes over this one (never the last)
+    for (uint32_t b = 0; b < nb; ++b) {                              // where the chain goes from every position (terminals: themselves)
+        const uint32_t o = b * WP_T + t;
+        uint32_t hdr, L, nxt;
+        const uint32_t k = wire_node(W, win, o, hdr, L, nxt);
+        J[0][o] = (uint16_t)(k == N_REC_NEXT ? nxt : o);
+    }
+    if (t == 0) reach[entry >> 6] = 1ull << (entry & 63u);
+    wire_barrier();
+    uint32_t cur = 0;
+    for (uint32_t round = 0;; ++round) {                             // pointer doubling: after round k the chain's first 2^(k+1) positions are marked
+        if (t == 0) s_more[(round + 1) % 3] = 0u;
+        bool more = false;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 4) {                    // (four rows at a time: the dependent reads of a row overlap the next rows')
+            uint32_t j[4], j2[4];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) j[u] = b0 + u < nb ? J[cur][(b0 + u) * WP_T + t] : 0u;
+            for (uint32_t u = 0; u < 4; ++u) j[u] = b0 + u < nb ? J[cur][(b0 + u) * WP_T + t] : 0u;
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) j2[u] = J[cur][j[u]];
+            for (uint32_t u = 0; u < 4; ++u) j2[u] = J[cur][j[u]];
 #pragma unroll
-                for (uint32_t u = 0; u < 4; ++u) {
-                    if (b0 + u >= nb) continue;                      // (uniform)
-                    J[cur ^ 1][(b0 + u) * WP_T + t] = (uint16_t)j2[u];
-                    const unsigned long long mine = reach[(b0 + u) * (WP_T / 64) + wave];   // (the word of this wave's 64 positions: a broadcast read)
-                    if ((mine >> lane) & 1ull) {
-                        if (!((reach[j[u] >> 6] >> (j[u] & 63u)) & 1ull)) { atomicOr(&reach[j[u] >> 6], 1ull << (j[u] & 63u)); more = true; }
-                    }
+            for (uint32_t u = 0; u < 4; ++u) {
+                if (b0 + u >= nb) continue;                          // (uniform)
+                J[cur ^ 1][(b0 + u) * WP_T + t] = (uint16_t)j2[u];
+                const unsigned long long mine = reach[(b0 + u) * (WP_T / 64) + wave];   // (the word of this wave's 64 positions: a broadcast read)
+                if ((mine >> lane) & 1ull) {
+                    if (!((reach[j[u] >> 6] >> (j[u] & 63u)) & 1ull)) { atomicOr(&reach[j[u] >> 6], 1ull << (j[u] & 63u)); more = true; }
                 }
             }
-            if (more) s_more[round % 3] = 1u;
-            barrier();
-            cur ^= 1;
-            if (!s_more[round % 3]) break;                           // (uniform: read after the barrier; the flag is reused three rounds later)
         }
-        // the visited positions, in order: records (numbered by a prefix over the bitmap's words), and the one terminal
-        uint32_t mine_n = 0;
-        const unsigned long long word = t < WP_WIN / 64 ? reach[t] : 0ull;
-        for (unsigned long long m = word; m; m &= m - 1ull) {
-            const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
-            uint32_t hdr, L, nxt;
-            const uint32_t k = node(o, hdr, L, nxt);
-            if (k == N_BAD) s_bad = 1u;
-            else if (k == N_REC_NEXT) mine_n++;
-            else if (k == N_REC_EXIT) { mine_n++; s_next = nxt; }
-            else s_next = o;                                         // N_CONT: the next window starts here; N_END: the payload's end
+        if (more) s_more[round % 3] = 1u;
+        wire_barrier();
+        cur ^= 1;
+        if (!s_more[round % 3]) break;                               // (uniform: read after the barrier; the flag is reused three rounds later)
+    }
+    // the visited positions, in order: records (numbered by a prefix over the bitmap's words), and the one terminal
+    uint32_t mine_n = 0;
+    const unsigned long long word = t < WP_WIN / 64 ? reach[t] : 0ull;
+    for (unsigned long long m = word; m; m &= m - 1ull) {
+        const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        uint32_t hdr, L, nxt;
+        const uint32_t k = wire_node(W, win, o, hdr, L, nxt);
+        if (k == N_BAD) s_bad = 1u;
+        else if (k != N_END) mine_n++;
+    }
+    const uint32_t incl = wire_wave_incl_scan(mine_n);
+    if (lane == 63) wsum[wave] = incl;
+    wire_barrier();
+    if (s_bad) { if (last && t == 0) { sc.count[W.r] = 0u; sc.status[W.r] = WIRE_SERIAL; } return; }   // (uniform; a window in front of the last: the last one sees it in went[])
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < WP_WIN / 64 / 64; ++w) { before += w < wave ? wsum[w] : 0u; total += wsum[w]; }   // (the bitmap's words live in the first two waves)
+    uint32_t k = base + before + incl - mine_n;
+    for (unsigned long long m = word; m; m &= m - 1ull) {
+        const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        uint32_t hdr, L, nxt;
+        const uint32_t kind = wire_node(W, win, o, hdr, L, nxt);
+        if (kind == N_REC_NEXT || kind == N_REC_EXIT) {
+            if (k < in.cap_per_rpc) { ro[k] = W.off + W.wbase + o + hdr; rl[k] = L; }
+            ++k;
         }
-        const uint32_t incl = wire_wave_incl_scan(mine_n);
-        if (lane == 63) wsum[wave] = incl;
-        barrier();
-        if (s_bad) { serial = true; break; }                         // (uniform)
-        uint32_t before = 0, total = 0;
-        for (uint32_t w = 0; w < WP_WIN / 64 / 64; ++w) { before += w < wave ? wsum[w] : 0u; total += wsum[w]; }   // (the bitmap's words live in the first two waves)
-        uint32_t k = count + before + incl - mine_n;
-        for (unsigned long long m = word; m; m &= m - 1ull) {
-            const uint32_t o = t * 64 + (uint32_t)__ffsll((unsigned long long)m) - 1u;
-            uint32_t hdr, L, nxt;
-            const uint32_t kind = node(o, hdr, L, nxt);
-            if (kind == N_REC_NEXT || kind == N_REC_EXIT) {
-                if (k < in.cap_per_rpc) { ro[k] = off + wbase + o + hdr; rl[k] = L; }
-                ++k;
+    }
+    if (last && t == 0) {
+        const uint32_t count = base + total;
+        sc.count[W.r] = count;
+        sc.status[W.r] = ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc) ? WIRE_TOO_LARGE : WIRE_OK;   // gubernator.go:189-193
+    }
+}
+
+// The numbering of the batch: first[r] = where RPC r's items start (RPCs that are not ok contribute nothing), first[nrpc] = the batch
+// size; an RPC that would not fit the arrays any more is turned away as too large.  By one workgroup of WAVES waves; the loads of
+// several rows of payloads are in flight together (a row at a time: 2 us of latency per row).
+template <uint32_t WAVES>
+__device__ __forceinline__ void wire_number_batch(const WireIn& in, const WireScratch& sc) {
+    __shared__ uint32_t wtot[WAVES];
+    constexpr uint32_t U = WAVES == 1 ? 16 : 2, ROW = 64 * WAVES;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < in.nrpc; base += ROW * U) {
+        int32_t st[U]; uint32_t cn[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t r = base + u * ROW + t;
+            st[u] = r < in.nrpc ? sc.status[r] : WIRE_MALFORMED;
+            cn[u] = r < in.nrpc ? sc.count[r] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) {
+            const uint32_t r = base + u * ROW + t;
+            const uint32_t c = st[u] == WIRE_OK ? cn[u] : 0u;        // (rows behind the last payload: zeros)
+            const uint32_t incl = wire_wave_incl_scan(c);
+            uint32_t before = 0, tot = (uint32_t)__shfl((int)incl, 63, 64);
+            if (WAVES > 1) {
+                if (lane == 63u) wtot[wave] = incl;
+                wire_barrier();
+                tot = 0;
+                for (uint32_t w = 0; w < WAVES; ++w) { before += w < wave ? wtot[w] : 0u; tot += wtot[w]; }
+                wire_barrier();
             }
+            const uint32_t excl = carry + before + incl - c;
+            if (r < in.nrpc) {
+                if (c && excl + c > in.cap_items) sc.status[r] = WIRE_TOO_LARGE;   // (rare: flagged; its slots stay unused — see k_wire_fill)
+                sc.first[r] = excl;
+            }
+            carry += tot;
         }
-        count += total;
-        pos = wbase + s_next;                                        // (> the window's first position: the chain moved on, or this was its end)
     }
-    if (t == 0) {
-        int32_t st = WIRE_OK;
-        if (serial) st = WIRE_SERIAL;
-        else if ((in.max_per_rpc && count > in.max_per_rpc) || count > in.cap_per_rpc) st = WIRE_TOO_LARGE;   // gubernator.go:189-193
-        sc.count[r] = count; sc.status[r] = st;
-    }
+    if (t == 0) sc.first[in.nrpc] = carry < in.cap_items ? carry : in.cap_items;
 }
-
-// first[r] = where RPC r's items start (RPCs that are not ok contribute nothing), first[nrpc] = the batch size; an RPC that would not
-// fit the arrays any more is turned away as too large
-__global__ __launch_bounds__(256) void k_wire_prefix(WireIn in, WireScratch sc) {
-    __shared__ uint32_t part[256];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < in.nrpc; base += 256) {
-        const uint32_t r = base + threadIdx.x;
-        uint32_t c = (r < in.nrpc && sc.status[r] == WIRE_OK) ? sc.count[r] : 0u;
-        part[threadIdx.x] = c;
-        __syncthreads();
-        for (uint32_t o = 1; o < 256; o <<= 1) {                     // Hillis-Steele inclusive scan
-            const uint32_t v = threadIdx.x >= o ? part[threadIdx.x - o] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
-        }
-        const uint32_t excl = carry + part[threadIdx.x] - c;
-        if (r < in.nrpc) {
-            if (c && excl + c > in.cap_items) { sc.status[r] = WIRE_TOO_LARGE; }   // (rare: flagged; its slots stay unused — see k_wire_fill)
-            sc.first[r] = excl;
-        }
-        __syncthreads();
-        if (threadIdx.x == 255) carry += part[255];
-        __syncthreads();
+// The serial walk — only_flagged: behind k_wire_win_b, only the payloads it left (status WIRE_SERIAL, or shorter than WP_MIN: no windows);
+// 0 = every payload — and, with `number`, the numbering of the batch by the LAST workgroup of the launch to finish (a launch of its own
+// costs 5 us where the whole decode of 64 RPCs takes 60; every workgroup's ticket is a device-scope atomic on one word, 20-25 ns each
+// one after the other — 100 us for 4 000 payloads —, so batches of more than WIRE_NUMBER_FUSED payloads get k_wire_prefix instead).
+constexpr uint32_t WIRE_NUMBER_FUSED = 256;
+__global__ __launch_bounds__(64) void k_wire_scan(WireIn in, WireScratch sc, uint32_t only_flagged, uint32_t number) {
+    if (!only_flagged || in.rpc_len[blockIdx.x] < WP_MIN || sc.status[blockIdx.x] == WIRE_SERIAL) wire_scan_body(in, sc);
+    if (!number) return;
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+        __threadfence();                                             // this payload's count and status before the ticket
+        s_last = atomicAdd(sc.done, 1u) == gridDim.x - 1u ? 1u : 0u;
     }
-    if (threadIdx.x == 0) sc.first[in.nrpc] = carry < in.cap_items ? carry : in.cap_items;
+    wire_barrier();
+    if (!s_last) return;
+    __threadfence();                                                 // (what the other workgroups wrote before their tickets is visible from here)
+    wire_number_batch<1>(in, sc);
+    if (threadIdx.x == 0) *sc.done = 0u;
 }
+__global__ __launch_bounds__(1024) void k_wire_prefix(WireIn in, WireScratch sc) { wire_number_batch<16>(in, sc); }
 
+// One thread per item.  (Measured in round 5, profiles/r05_m_*: of its 16 us for 64 000 items 6 are parse_req, the rest is the chain of
+// dependent first-touch loads first[] -> status / record -> bytes at ~1.5 us each; parsing from a copy of the records in LDS, the search
+// of first[] in LDS and 8-byte row stores changed nothing and were taken out again.)
 __global__ __launch_bounds__(256) void k_wire_fill(WireIn in, WireScratch sc, WireOut out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t total = sc.first[in.nrpc];

@@ -10,6 +10,7 @@ struct guber_wire_dev {
     PinBuf<uint8_t> h_buf; PinBuf<uint32_t> h_u32; PinBuf<int32_t> h_status;           // staging: payload bytes; off | len | first | count; status
     DevBuf<uint8_t> d_buf, d_owner, d_rows, d_u8; DevBuf<uint32_t> d_u32, d_rec; DevBuf<int32_t> d_status, d_algo; DevBuf<int64_t> d_i64;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
+    DevBuf<uint2> d_went; uint32_t max_windows = 0;                                        // k_wire_win_a -> k_wire_win_b (8 KB per window of 8 KB)
     PinBuf<uint8_t> h_cols;                                                              // read-back of the decoded columns (tests, response encoding)
     uint32_t nrpc = 0, n_items = 0; int64_t now_ms = 0;
     guber::WireIn in{}; guber::WireScratch sc{}; guber::WireOut out{};
@@ -27,13 +28,17 @@ extern "C" int guber_wire_dev_create(guber_engine_t* e, uint32_t max_items, uint
     d->cap_per_rpc = std::min<uint32_t>(max_items, 4096);
     d->stride = ((e->max_key + 7u) & ~7u) + 8u;
     const size_t M = max_items, R = max_rpcs;
-    int rc = d->h_buf.ensure(d->max_bytes) | d->h_u32.ensure(4 * R + 4) | d->h_status.ensure(R) | d->d_buf.ensure(d->max_bytes) | d->d_owner.ensure(R) |
-             d->d_u32.ensure(2 * R + R + (R + 1) + M + M + M) | d->d_rec.ensure(2 * R * d->cap_per_rpc) | d->d_status.ensure(R) | d->d_algo.ensure(M) |
-             d->d_i64.ensure(5 * M) | d->d_rows.ensure(M * d->stride + 64) | d->d_u8.ensure(3 * M) | d->d_out64.ensure(3 * M) | d->d_out8.ensure(2 * M);
+    d->max_windows = d->max_bytes / guber::WP_WIN + max_rpcs;                            // (a payload of len bytes: len / 8 KB + 1 windows)
+    int rc = d->h_buf.ensure(d->max_bytes) | d->h_u32.ensure(5 * R + 8) | d->h_status.ensure(R) | d->d_buf.ensure(d->max_bytes) | d->d_owner.ensure(R) |
+             d->d_u32.ensure(2 * R + R + (R + 1) + (R + 1) + 1 + M + M + M) | d->d_rec.ensure(2 * R * d->cap_per_rpc) | d->d_status.ensure(R) | d->d_algo.ensure(M) |
+             d->d_i64.ensure(5 * M) | d->d_rows.ensure(M * d->stride + 64) | d->d_u8.ensure(3 * M) | d->d_out64.ensure(3 * M) | d->d_out8.ensure(2 * M) |
+             d->d_went.ensure((size_t)d->max_windows * guber::WP_ENT);
     if (rc) { guber_wire_dev_destroy(d); return GUBER_E_NOMEM; }
     uint32_t* u = d->d_u32.p;
     d->in.buf = d->d_buf.p; d->in.rpc_off = u; u += R; d->in.rpc_len = u; u += R;
     d->sc.count = u; u += R; d->sc.first = u; u += R + 1;
+    d->sc.wfirst = u; u += R + 1; d->sc.done = u; u += 1; d->sc.went = d->d_went.p;
+    if (hipMemset(d->sc.done, 0, 4) != hipSuccess) { guber_wire_dev_destroy(d); return fail(GUBER_E_HIP, "hipMemset"); }
     d->out.key_len = u; u += M; d->out.behavior = u; u += M; d->out.item_rpc = u; u += M;
     d->in.rpc_owner = d->d_owner.p; d->in.cap_per_rpc = d->cap_per_rpc; d->in.cap_items = max_items;
     d->sc.rec_off = d->d_rec.p; d->sc.rec_len = d->d_rec.p + (size_t)R * d->cap_per_rpc; d->sc.status = d->d_status.p;
@@ -50,7 +55,7 @@ extern "C" void guber_wire_dev_destroy(guber_wire_dev_t* d) {
     if (!d) return;
     if (d->e) { (void)hipSetDevice(d->e->device); (void)hipStreamSynchronize(d->e->stream); }
     d->h_buf.release(); d->h_u32.release(); d->h_status.release(); d->d_buf.release(); d->d_owner.release(); d->d_rows.release(); d->d_u8.release();
-    d->d_u32.release(); d->d_rec.release(); d->d_status.release(); d->d_algo.release(); d->d_i64.release(); d->d_out64.release(); d->d_out8.release();
+    d->d_u32.release(); d->d_went.release(); d->d_rec.release(); d->d_status.release(); d->d_algo.release(); d->d_i64.release(); d->d_out64.release(); d->d_out8.release();
     d->h_cols.release();
     delete d;
 }
@@ -67,9 +72,13 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
     if (!nrpc) return GUBER_OK;
-    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs;
+    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 4 * (size_t)d->max_rpcs + 4;
     size_t pos = 0;
+    uint32_t windows = 0;
+    bool multi = false;                                                                    // a payload of more than one window: k_wire_win_a has something to say
     for (uint32_t r = 0; r < nrpc; ++r) {
+        const uint32_t nw = guber::wire_windows_of(lens[r]);
+        h_wfirst[r] = windows; windows += nw; multi = multi || nw > 1;
         pos = (pos + 15) & ~(size_t)15;
         if (pos + lens[r] + 16 > d->max_bytes) return fail(GUBER_E_WIRE_FULL, "payload bytes exceed the decoder's buffer");
         if (lens[r] && !msgs[r]) return fail(GUBER_E_INVALID_ARG, "null payload");
@@ -77,6 +86,7 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
         h_off[r] = (uint32_t)pos; h_len[r] = lens[r];
         pos += lens[r];
     }
+    h_wfirst[nrpc] = windows;                                                              // (<= max_windows: the bytes fit)
     memset(d->h_buf.p + pos, 0, 16);
     hipStream_t st = e->stream;
     HIPCHK(hipMemcpyAsync(d->d_buf.p, d->h_buf.p, pos + 16, hipMemcpyHostToDevice, st));
@@ -85,12 +95,21 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
     if (is_owner) HIPCHK(hipMemcpyAsync(d->d_owner.p, is_owner, nrpc, hipMemcpyHostToDevice, st));
     else HIPCHK(hipMemsetAsync(d->d_owner.p, 1, nrpc, st));
     d->in.nrpc = nrpc; d->in.max_per_rpc = max_per_rpc; d->out.now_ms = now_ms;
-    // the chain of every payload: in parallel (k_wire_scan_par: a workgroup per payload, pointer doubling over 8 KB windows), then the
-    // serial walk for the payloads that hold anything but plain records (GUBER_WIRE_SERIAL=1: the serial walk for all, for A/B runs)
+    // the chain of every payload: in parallel (a workgroup per 8 KB window, pointer doubling: k_wire_win_a — only when a payload has
+    // more than one window — says where the chain enters each window, k_wire_win_b finds the records), then the serial walk for the
+    // payloads that hold anything but plain records, and the numbering of the batch (by that launch's last workgroup; a launch of its
+    // own for batches of many payloads)
+    // (payloads of less than 1 KB have no windows: a wave walks three dozen records sooner than a workgroup sets up; GUBER_WIRE_SERIAL=1: the
+    // serial walk for all, for A/B runs)
     static const bool wire_serial = [] { const char* v = getenv("GUBER_WIRE_SERIAL"); return v && atoi(v) != 0; }();
-    if (!wire_serial) hipLaunchKernelGGL(guber::k_wire_scan_par, dim3(nrpc), dim3(guber::WP_T), 0, st, d->in, d->sc);
-    hipLaunchKernelGGL(guber::k_wire_scan, dim3(nrpc), dim3(64), 0, st, d->in, d->sc, wire_serial ? 0u : 1u);
-    hipLaunchKernelGGL(guber::k_wire_prefix, dim3(1), dim3(256), 0, st, d->in, d->sc);
+    if (!wire_serial) {
+        HIPCHK(hipMemcpyAsync((void*)d->sc.wfirst, h_wfirst, (size_t)(nrpc + 1) * 4, hipMemcpyHostToDevice, st));
+        if (multi) hipLaunchKernelGGL(guber::k_wire_win_a, dim3(windows), dim3(guber::WP_T), 0, st, d->in, d->sc);
+        if (windows) hipLaunchKernelGGL(guber::k_wire_win_b, dim3(windows), dim3(guber::WP_T), 0, st, d->in, d->sc);
+    }
+    const bool fused_numbering = nrpc <= guber::WIRE_NUMBER_FUSED;
+    hipLaunchKernelGGL(guber::k_wire_scan, dim3(nrpc), dim3(64), 0, st, d->in, d->sc, wire_serial ? 0u : 1u, fused_numbering ? 1u : 0u);
+    if (!fused_numbering) hipLaunchKernelGGL(guber::k_wire_prefix, dim3(1), dim3(1024), 0, st, d->in, d->sc);
     const unsigned blocks = (d->max_items + 255) / 256;
     hipLaunchKernelGGL(guber::k_wire_fill, dim3(blocks), dim3(256), 0, st, d->in, d->sc, d->out);
     hipLaunchKernelGGL(guber::k_wire_kill, dim3(blocks), dim3(256), 0, st, d->in, d->sc, d->out);

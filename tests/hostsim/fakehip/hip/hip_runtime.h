@@ -26,6 +26,8 @@ namespace fakehip { inline unsigned char* dyn_lds() { alignas(16) static unsigne
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __HIP_MEMORY_SCOPE_WORKGROUP 0
 
+struct alignas(8) uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 struct uint4 { uint32_t x, y, z, w; };
 struct ulonglong2 { unsigned long long x, y; };
 static inline ulonglong2 make_ulonglong2(unsigned long long a, unsigned long long b) { return ulonglong2{a, b}; }

@@ -1,5 +1,5 @@
 // wiresim.cpp — TEST INFRASTRUCTURE: the device wire decoder's chain walks (guber_kernels_wire.h: the serial k_wire_scan and the
-// parallel k_wire_scan_par with the serial walk behind it) compiled for the host against fakehip/ and run against the SAME framing code over plain memory
+// parallel k_wire_win_a / k_wire_win_b with the serial walk behind them) compiled for the host against fakehip/ and run against the SAME framing code over plain memory
 // (scan_toplevel<MemReader>: what the host transcoder's fuzz runs) on generated and mutated payloads: item counts, verdicts and every
 // record's offset and length must agree.  Built as its own library (tests/test_wire_scan_devsim.py); nothing in the product includes it.
 #include "devsim.cpp"
@@ -15,6 +15,7 @@ std::vector<uint8_t> make_payload(Rng& g) {
     std::vector<uint8_t> p;
     const uint32_t shape = g.below(8);
     const bool plain = g.below(2) == 0;
+    const bool small = g.below(3) != 0;                                 // (plain payloads: few records of kilobytes — a chain enters a window within its first WP_ENT positions or the payload is the serial walk's)
     const uint32_t n = shape == 0 ? 0 : shape < 5 ? g.below(40) : shape < 7 ? 200 + g.below(1300) : g.below(6);
     for (uint32_t i = 0; i < n; ++i) {
         const uint32_t k = plain ? 6 + g.below(58) : g.below(64);
@@ -25,8 +26,8 @@ std::vector<uint8_t> make_payload(Rng& g) {
         if (k == 4) { p.push_back(0x8a); p.push_back(0x01); const uint32_t L = g.below(10); put_varint(p, L); for (uint32_t b = 0; b < L; ++b) p.push_back(0x41); continue; }   // field 17, two-byte tag
         if (k == 5) { p.push_back(0x8a); p.push_back(0x80); p.push_back(0x00); const uint32_t L = g.below(5); put_varint(p, L); for (uint32_t b = 0; b < L; ++b) p.push_back(0x42); continue; }   // field 1, over-long tag
         uint32_t L = g.below(60);
-        const uint32_t big = plain ? 1 + g.below(199) : g.below(200);
-        if (plain && g.below(400) == 0) L = 9000 + g.below(7000);                                       // a record longer than a window (two-byte length)
+        const uint32_t big = plain ? 1 + g.below(small ? 3999 : 199) : g.below(200);
+        if (plain && g.below(small ? 20000 : 400) == 0) L = 9000 + g.below(7000);                                       // a record longer than a window (two-byte length)
         if (plain && g.below(40) == 0) L = 0;
         if (big == 0) L = 16384 + g.below(300);                                                        // three-byte length
         else if (big < 12) L = 128 + g.below(3000);                                                    // two-byte length
@@ -44,13 +45,13 @@ std::vector<uint8_t> make_payload(Rng& g) {
 }  // namespace
 
 extern "C" {
-// runs `iters` rounds of 1 .. 6 payloads through k_wire_scan (mode 0) or k_wire_scan_par + k_wire_scan for what it leaves (mode 1);
+// runs `iters` rounds of 1 .. 6 payloads through k_wire_scan (mode 0) or k_wire_win_a + k_wire_win_b + k_wire_scan for what they leave (mode 1);
 // returns the number of payloads that disagree with scan_toplevel<MemReader>; stats: payloads, records, payloads with a verdict other
-// than ok, payloads the parallel walk finished on its own
+// than ok, payloads the parallel walk finished on its own, those of them with more than one window
 uint64_t ws_fuzz(uint32_t iters, uint64_t seed, int table, uint32_t max_per_rpc, unsigned long long* stats) {
     Rng g{seed * 0x9E3779B97F4A7C15ull + 12345};
     uint64_t bad = 0;
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    stats[0] = stats[1] = stats[2] = stats[3] = stats[4] = 0;
     for (uint32_t it = 0; it < iters; ++it) {
         const uint32_t nrpc = 1 + g.below(6), cap = 1600;
         std::vector<std::vector<uint8_t>> pl(nrpc);
@@ -66,12 +67,30 @@ uint64_t ws_fuzz(uint32_t iters, uint64_t seed, int table, uint32_t max_per_rpc,
         std::vector<int32_t> st(nrpc, 12345);
         guber::WireIn in{}; in.buf = buf.data(); in.rpc_off = off.data(); in.rpc_len = len.data(); in.rpc_owner = nullptr;
         in.nrpc = nrpc; in.cap_per_rpc = cap; in.max_per_rpc = max_per_rpc; in.cap_items = nrpc * cap;
-        guber::WireScratch sc{ro.data(), rl.data(), cnt.data(), st.data(), first.data()};
+        std::vector<uint32_t> wfirst(nrpc + 1, 0);
+        for (uint32_t r = 0; r < nrpc; ++r) wfirst[r + 1] = wfirst[r] + guber::wire_windows_of(len[r]);
+        const uint32_t windows = wfirst[nrpc];
+        std::vector<uint2> went((size_t)windows * guber::WP_ENT, make_uint2(0xabababab, 0xabababab));
+        uint32_t done = 0;
+        guber::WireScratch sc{ro.data(), rl.data(), cnt.data(), st.data(), first.data(), wfirst.data(), went.data(), &done};
+        const bool fused = (it & 1u) == 0;                               // the numbering: by k_wire_scan's last workgroup / by k_wire_prefix
         if (table) {
-            fakehip::launch(dim3(nrpc), dim3(guber::WP_T), nullptr, [&] { guber::k_wire_scan_par(in, sc); });
-            for (uint32_t r = 0; r < nrpc; ++r) stats[3] += st[r] != guber::WIRE_SERIAL;
-            fakehip::launch(dim3(nrpc), dim3(64), nullptr, [&] { guber::k_wire_scan(in, sc, 1u); });
-        } else fakehip::launch(dim3(nrpc), dim3(64), nullptr, [&] { guber::k_wire_scan(in, sc, 0u); });
+            bool multi = false;
+            for (uint32_t r = 0; r < nrpc; ++r) multi = multi || wfirst[r + 1] - wfirst[r] > 1;
+            if (multi) fakehip::launch(dim3(windows), dim3(guber::WP_T), nullptr, [&] { guber::k_wire_win_a(in, sc); });
+            if (windows) fakehip::launch(dim3(windows), dim3(guber::WP_T), nullptr, [&] { guber::k_wire_win_b(in, sc); });
+            for (uint32_t r = 0; r < nrpc; ++r) { stats[3] += wfirst[r + 1] > wfirst[r] && st[r] != guber::WIRE_SERIAL; stats[4] += wfirst[r + 1] - wfirst[r] > 1 && st[r] != guber::WIRE_SERIAL; }
+            fakehip::launch(dim3(nrpc), dim3(64), nullptr, [&] { guber::k_wire_scan(in, sc, 1u, fused ? 1u : 0u); });
+        } else fakehip::launch(dim3(nrpc), dim3(64), nullptr, [&] { guber::k_wire_scan(in, sc, 0u, fused ? 1u : 0u); });
+        if (!fused) fakehip::launch(dim3(1), dim3(1024), nullptr, [&] { guber::k_wire_prefix(in, sc); });
+        // the numbering of the batch by the launch's last workgroup: the exclusive scan of the counts of the payloads that are ok
+        {
+            uint32_t run = 0;
+            bool okp = done == 0;
+            for (uint32_t r = 0; r < nrpc; ++r) { okp = okp && first[r] == run; if (st[r] == guber::WIRE_OK) run += cnt[r]; }
+            okp = okp && first[nrpc] == run;
+            if (!okp) { if (bad < 5) fprintf(stderr, "[wiresim] seed %llu it %u: the batch's numbering is off\n", (unsigned long long)seed, it); bad++; }
+        }
         for (uint32_t r = 0; r < nrpc; ++r) {
             std::vector<uint32_t> wo, wl;
             guber::MemReader rd{pl[r].data(), len[r]};

@@ -1,5 +1,5 @@
 """The protobuf wire format decoded ON THE DEVICE (include/guber_wire.h guber_wire_dev_*, kernels guber_kernels_wire.h): payloads
-serialized by the protobuf runtime on the reference's schema -> k_wire_scan / k_wire_prefix / k_wire_fill -> the batch the engine
+serialized by the protobuf runtime on the reference's schema -> k_wire_win_a / k_wire_win_b / k_wire_scan / k_wire_fill -> the batch the engine
 evaluates.  Checked against what the requests say (as tests/test_wire_cpu.py checks the host transcoder), against the host
 transcoder itself on fuzzed payloads (per RPC: the same verdict, the same items), and end to end against the oracle."""
 import time
@@ -107,7 +107,7 @@ def test_device_decoded_batches_evaluate_like_the_oracle_and_report_throughput()
         support.assert_results_equal(got, want, f"round {rnd}")
         now += 700
     # throughput, decode only (host copy into the pinned buffer + 5 launches + the read-back of the per-RPC verdicts): a workgroup per
-    # payload finds its record chain by pointer doubling (k_wire_scan_par), the serial walk takes what it leaves
+    # 8 KB window of a payload finds its part of the record chain by pointer doubling (k_wire_win_a, k_wire_win_b), the serial walk takes what they leave
     import ctypes
     import os
     on_cpu_engine = "enginesim" in os.environ.get("GUBER_HIP_LIB", "")     # (the kernel source on the CPU, tests/test_enginesim_cpu.py: the calls, not the rates)

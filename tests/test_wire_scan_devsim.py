@@ -1,5 +1,6 @@
-"""The device wire decoder's chain walks — the serial k_wire_scan, and the parallel k_wire_scan_par (a workgroup per payload: pointer
-doubling over 8 KB windows) with the serial walk behind it for what it leaves (guber_kernels_wire.h) —
+"""The device wire decoder's chain walks — the serial k_wire_scan, and the parallel k_wire_win_a / k_wire_win_b (a workgroup per 8 KB
+window of a payload: pointer doubling; the first launch says where the chain enters every window, the second finds the records) with
+the serial walk — and the numbering of the batch by its launch's last workgroup — behind them (guber_kernels_wire.h) —
 compiled for the host (tests/hostsim/wiresim.cpp: fakehip) against the framing code they share with the host
 transcoder and its AddressSanitizer fuzz (scan_toplevel over plain memory): generated and mutated payloads (bodies full of bytes that
 look like tags, 1- / 2- / 3-byte and non-minimal lengths, unknown fields of every wire type, multi-byte and over-long tags,
@@ -23,7 +24,7 @@ def lib():
     subprocess.run(["make", "-s", "-C", HS, "wiresim_lib"], check=True)
     L = C.CDLL(os.path.join(HS, "libwiresim.so"))
     L.ws_fuzz.restype = C.c_uint64
-    L.ws_fuzz.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_ulonglong)]      # (.., mode, max_per_rpc, stats[4])
+    L.ws_fuzz.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_uint32, C.POINTER(C.c_ulonglong)]      # (.., mode, max_per_rpc, stats[5])
     return L
 
 
@@ -33,10 +34,11 @@ def test_chain_walk_agrees_with_the_shared_framing_code(lib, table, max_per_rpc)
     total = 0
     iters = 100 if table else 300                    # (the parallel walk is 1 024 fibers per payload on the CPU: fewer rounds of it)
     for seed in range(4):
-        st = (C.c_ulonglong * 4)()
+        st = (C.c_ulonglong * 5)()
         bad = lib.ws_fuzz(iters, 1000 + seed, table, max_per_rpc, st)
         assert bad == 0, (seed, bad)
         assert st[0] > 2 * iters and st[2] > iters // 15          # payloads, of which malformed / too large
-        assert not table or st[3] > iters, st[3]                  # payloads the parallel walk finished without the serial one
+        assert not table or st[3] > iters // 3, st[3]             # payloads (of 1 KB and more) the parallel walk finished without the serial one
+        assert not table or st[4] > iters // 12, st[4]            # ... of more than one window (the chain handed from window to window)
         total += st[1]
     assert total > 1000 * iters                                   # records walked
