@@ -109,8 +109,8 @@ int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off,
 
 /* ---- the same decode ON THE DEVICE (gubernator_amd/csrc/guber_kernels_wire.h): the serialized payloads of many RPCs -> one batch in
  *      HBM, evaluated where it is.  The reference unmarshals every RateLimitReq into a heap object on the CPU (generated code of
- *      gubernator.proto:137-182) and validates it there (gubernator.go:189-220); here a wave per payload walks the record chain,
- *      a thread per item parses its record (the same source as guber_wire_decode_requests) and the items land in the structure of
+ *      gubernator.proto:137-182) and validates it there (gubernator.go:189-220); here a workgroup per 8 KB window of a payload finds its part of
+ *      the record chain (a wave per payload walks it where it holds anything but plain records), a thread per item parses its record (the same source as guber_wire_decode_requests) and the items land in the structure of
  *      arrays the engine's kernels read.
  *   guber_wire_dev_create   a decoder bound to an engine: at most max_items items, max_payload_bytes payload bytes and max_rpcs
  *                           payloads per decode (max_items <= the engine's max_batch; an RPC holds at most min(max_items, 4096) items)
