@@ -61,7 +61,7 @@ extern "C" void guber_wire_dev_destroy(guber_wire_dev_t* d) {
 }
 
 // Decode nrpc serialized GetRateLimitsReq / GetPeerRateLimitsReq payloads into ONE device batch.  The payload bytes are copied into
-// the decoder's pinned buffer (a receive path that reads its sockets straight into guber_wire_dev_buffer() skips that copy).
+// the decoder's pinned buffer (this copy and the H2D transfer are what the C call's rate is made of: DESIGN.md 5b).
 extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* msgs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
                                      uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items) {
     if (!d || (nrpc && (!msgs || !lens)) || !n_items) return fail(GUBER_E_INVALID_ARG, "null argument");
