@@ -595,7 +595,8 @@ __device__ __forceinline__ void own_body(const Table& T, const BatchView& B, con
         // comparison against references happened before the barrier above)
         int inserted = 0;
         for (uint32_t kid = t; kid < nk; kid += 256) {
-            if (kid != t) {                                           // (more than 256 keys in a round: uniform keys)
+            if (kid != t) {                                           // (more than 256 keys in a round: uniform keys.  Touching this bucket beside the first
+                                                                      // key's, so that the second pass finds it in the L2: 6.35 -> 6.30 G/s, profiles/r05_n_*)
                 kpos = (kref[kid].hash >> 7) & T.mask;
                 const Bucket* hb = &T.buckets[kpos];
                 const uint4* cw = (const uint4*)&hb->cell; tc0 = cw[0]; tc3 = cw[3];
