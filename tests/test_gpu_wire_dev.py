@@ -91,6 +91,65 @@ def test_fuzzed_payloads_same_verdict_and_items_as_the_host_transcoder():
     dec.close(); e.close()
 
 
+def _same_as_the_host_transcoder(dec, payloads, max_key):
+    status, first, count, n = dec.decode(payloads, NOW, max_per_rpc=0)
+    cols = dec.columns()
+    for k, p in enumerate(payloads):
+        wb = gw.WireBatch(max_items=4096, max_key_bytes=1 << 21)
+        wb.reset(NOW)
+        f0, c0 = wb.decode(p, max_per_rpc=0)
+        host = wb.arrays()
+        assert status[k] == 0 and count[k] == c0, (k, status[k], count[k], c0)
+        for j in range(c0):
+            i = int(first[k]) + j
+            assert cols["keys"][i] == host["keys"][j] or (len(host["keys"][j]) > max_key and cols["key_len"][i] == len(host["keys"][j])), (k, j)
+            for name in ("hits", "limit", "duration", "burst", "created_at", "algorithm", "behavior"):
+                assert cols[name][i] == host[name][j], (name, k, j)
+        wb.close()
+    return int(n)
+
+
+def test_payloads_of_many_windows_and_records_across_their_edges():
+    """the parallel chain walk hands a payload's chain from 8 KB window to window (k_wire_win_a says where it enters each): payloads of
+    up to sixteen windows whose records (1 .. 300 bytes) cross every edge at another place, a payload that ends exactly on an edge
+    and one byte to either side of it, records of about a kilobyte (the longest a chain may enter a window with: beyond, the payload is
+    the serial walk's), one record longer than a window — all of them the host transcoder's items, RPC by RPC"""
+    rng = np.random.default_rng(23)
+    e = ga.Engine(cache_size=1 << 16, max_batch=32768, max_key_bytes=512)
+    dec = gw.DevWireDecoder(e, max_items=32768, max_payload_bytes=8 << 20, max_rpcs=64)
+
+    def req(i, klen):
+        return dict(name="n", unique_key=("k%d_" % i) + "x" * klen, hits=int(rng.integers(0, 3)), limit=10, duration=60_000, algorithm=int(rng.integers(0, 2)),
+                    behavior=0, burst=0, created_at=0)
+    total = 0
+    for rnd in range(3):
+        payloads = []
+        for _ in range(6):                                         # many windows, records of every length across the edges
+            payloads.append(wire_replay.pb_request([req(i, int(rng.integers(0, 280))) for i in range(int(rng.integers(300, 1000)))]))
+        for target in (8192, 8191, 8193, 16384, 24576 + 1):        # the payload's end on / beside a window's edge
+            reqs, size = [], 0
+            while True:
+                r = req(len(reqs), int(rng.integers(0, 40)))
+                sz = len(wire_replay.pb_request([r]))
+                if size + sz > target - 60:
+                    break
+                reqs.append(r); size += sz
+            pad = target - size                                     # the last record brings the payload to the byte
+            for klen in range(0, 200):
+                r = req(len(reqs), klen)
+                if len(wire_replay.pb_request([r])) == pad:
+                    reqs.append(r); size += pad
+                    break
+            payloads.append(wire_replay.pb_request(reqs))
+            assert len(payloads[-1]) == size
+        payloads.append(wire_replay.pb_request([req(i, int(rng.integers(900, 1015))) for i in range(60)]))     # about a kilobyte each
+        payloads.append(wire_replay.pb_request([req(i, int(rng.integers(1015, 1300))) for i in range(40)]))    # more: somewhere the serial walk's
+        payloads.append(wire_replay.pb_request([req(0, 5), req(1, 9000), req(2, 7)] + [req(3 + i, 20) for i in range(400)]))   # one record longer than a window
+        total += _same_as_the_host_transcoder(dec, payloads, 512)
+    assert total > 10_000
+    dec.close(); e.close()
+
+
 def test_device_decoded_batches_evaluate_like_the_oracle_and_report_throughput():
     rng = np.random.default_rng(3)
     e, o = ga.Engine(cache_size=1 << 18, max_batch=65536, max_key_bytes=64), support.Oracle(cache_size=1 << 20)
