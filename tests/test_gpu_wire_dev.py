@@ -2,6 +2,7 @@
 serialized by the protobuf runtime on the reference's schema -> k_wire_win_a / k_wire_win_b / k_wire_scan / k_wire_fill -> the batch the engine
 evaluates.  Checked against what the requests say (as tests/test_wire_cpu.py checks the host transcoder), against the host
 transcoder itself on fuzzed payloads (per RPC: the same verdict, the same items), and end to end against the oracle."""
+import os
 import time
 
 import numpy as np
@@ -59,7 +60,7 @@ def _mutate(rng, p):
 def test_fuzzed_payloads_same_verdict_and_items_as_the_host_transcoder():
     """mutated payloads (bit flips, insertions, truncations — also right at the window boundaries of the scan): per RPC the device
     decoder rejects exactly what the host transcoder rejects, and accepts with the same items"""
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(int(os.environ.get("GUBER_WIRE_FUZZ_SEED", "11")))      # (scripts/gpu_r05_p.sh: a soak over seeds)
     e = ga.Engine(cache_size=1 << 16, max_batch=32768, max_key_bytes=512)
     dec = gw.DevWireDecoder(e, max_items=32768, max_payload_bytes=8 << 20, max_rpcs=512)
     accepted = rejected = 0
@@ -114,7 +115,7 @@ def test_payloads_of_many_windows_and_records_across_their_edges():
     up to sixteen windows whose records (1 .. 300 bytes) cross every edge at another place, a payload that ends exactly on an edge
     and one byte to either side of it, records of about a kilobyte (the longest a chain may enter a window with: beyond, the payload is
     the serial walk's), one record longer than a window — all of them the host transcoder's items, RPC by RPC"""
-    rng = np.random.default_rng(23)
+    rng = np.random.default_rng(int(os.environ.get("GUBER_WIRE_FUZZ_SEED", "23")))
     e = ga.Engine(cache_size=1 << 16, max_batch=32768, max_key_bytes=512)
     dec = gw.DevWireDecoder(e, max_items=32768, max_payload_bytes=8 << 20, max_rpcs=64)
 
