@@ -405,7 +405,11 @@ __device__ __forceinline__ void front_body(const Table& T, const BatchView& B, c
                                       ((uint64_t)c3.y << 32) | c3.x, ((uint64_t)c3.w << 32) | c3.z};
             bool eq = (uint32_t)(cell[7] >> 48) == len;
             if (eq) {
-                if (len <= INLINE_KEY) {
+                if (len <= 16) {
+                    // the key's two zero-padded words are in registers since the hash (cells are stored zero-padded: key_store):
+                    // no second trip to the key bytes
+                    eq = cell[0] == k0 && cell[1] == k1;
+                } else if (len <= INLINE_KEY) {
                     const uint32_t nw = (len + 7) >> 3;
 #pragma unroll
                     for (uint32_t w = 0; w < 8; ++w) {
@@ -565,7 +569,24 @@ __device__ __forceinline__ void eval2_body(const EvalArgs& A, const uint32_t til
     lds_barrier();
     GB_STAMP2(2);
     int c_over = 0, c_hit = 0, c_miss = 0, c_size = 0;
-    if (live) {
+    // the wave in which every request is the common case runs straight through the closed form (as k_eval3's does,
+    // guber_kernels_part.h: one ballot instead of the general path's cascade of divergent sections; the same steps, so the same results)
+    const bool plain = !live || (!(rf & RF_INSERTED) && sf == 0u && !(smeta & SM_HAS_INVALID) && token_fast_ok(s0, r, B.now_ms));
+    const bool plain_wave = !W.store_flags && !T.gpend && __ballot(!plain) == 0ull;
+    if (plain_wave) {
+        if (live) {
+            const uint32_t total = stotal[lr >> 8], rank = sbase[lr >> 8] + (lr & 0xffu);
+            Rec after; Resp out;
+            const uint32_t ev = token_fast(s0, r, rank, out, after);
+            store_resp(R, i, out);
+            c_over = (ev & EV_OVER) ? 1 : 0; c_hit = (ev & EV_HIT) ? 1 : 0; c_miss = (ev & EV_MISS) ? 1 : 0;
+            if (rank == total - 1) {
+                rec_set_stamp(after, W.touch + i);                    // the key's place in the recency order: its last request (lrucache.go:111-128)
+                T.buckets[slot].rec = after;
+                c_size = (int)(rec_kind(after) != K_ABSENT) - (int)(rec_kind(s0) != K_ABSENT);
+            }
+        }
+    } else if (live) {
         if (rf & RF_INSERTED) atomicOr(&T.dir[W.slot[i]].meta, META_READY);   // publish this batch's inserts
         if (sf & SEG_ERR) {
             store_err(R, i, (uint8_t)(sf >> 8));
