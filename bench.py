@@ -753,6 +753,7 @@ def main():
     def route_on_device(eng, ring, kb, ko):       # ReplicatedConsistentHash.Get for a chunk of keys (k_route)
         d_kb, d_ko = torch.from_numpy(kb).to(dev), torch.from_numpy(ko.view(np.int32)).to(dev)
         d_owner = torch.empty(len(ko) - 1, dtype=torch.int32, device=dev)
+        torch.cuda.current_stream(dev).synchronize()                  # (the copies are torch's stream's, the router kernel the engine's)
         eng.route_dev(ring, d_kb.data_ptr(), d_ko.data_ptr(), len(ko) - 1, d_owner.data_ptr())
         return d_owner.cpu().numpy()
     ctx.route_on_device = route_on_device
@@ -1151,10 +1152,13 @@ def run_global(args, ctx, dist):
         rig.warmup, rig.steps, rig.profile_steps, rig.latency_steps = args.warmup, args.steps, 0, 0
         rig.build_stream(total_steps, NOW0, 1234 + my_rank * 64)
         rig.kept = {}
-        for s, b in enumerate(rig.batches):                     # is_owner[i] = (ring owner of key i == this rank), on device
-            d_owner = torch.empty(B, dtype=torch.int32, device=dev)
-            rig.engines[0].route_dev(ring, b.key_bytes, b.key_off, B, d_owner.data_ptr())
+        d_owner = torch.empty(B, dtype=torch.int32, device=dev)   # ONE buffer, reused only after torch's stream has read it: a buffer per
+        for s, b in enumerate(rig.batches):                     # batch went back to torch's allocator while the comparison below was still queued on
+            # torch's stream, and the ENGINE's stream (which the allocator knows nothing about) wrote the next batch's owners into it — with two
+            # processes sharing a GPU that race was lost in 4 runs of 10: a few hundred wrong is_owner flags, replicas that never converge
+            rig.engines[0].route_dev(ring, b.key_bytes, b.key_off, B, d_owner.data_ptr())   # is_owner[i] = (ring owner of key i == this rank), on device
             t = (d_owner == my_rank).to(torch.uint8)
+            torch.cuda.current_stream(dev).synchronize()
             owners.append(t)
             b.is_owner = t.data_ptr()
     torch.cuda.synchronize(dev)                                 # the owner flags are produced on torch's stream
@@ -1207,11 +1211,20 @@ def run_global(args, ctx, dist):
         rig.engines[0].synchronize()
         reads.append(res.remaining.clone())
     converged = all(bool(torch.equal(reads[0], r)) for r in reads[1:])
+    if os.environ.get("GUBER_BENCH_GLOBAL_SUMS"):                # (diagnostics: the probe's answers as sums, per local replica)
+        print(f"[global leg] rank {rank}: stream checksums {[int(r_.h_ids.astype(np.int64).sum()) for r_ in rigs]}, owner flags set {int(sum(int(t.sum()) for t in owners))}, "
+              f"per sync (hits rows sent, applied, update rows, items installed): {[(x['hits_rows_sent'], x['hits_rows_applied'], x['update_rows'], x['items_installed']) for x in sync_stats]}",
+              file=sys.stderr, flush=True)
+        print(f"[global leg] rank {rank}: sums of the probe's remaining per local replica: {[int(r.sum()) for r in reads]}", file=sys.stderr, flush=True)
     if world > 1:
         on_host = args.backend != "nccl"                         # (gloo: host tensors)
         mine = reads[0].cpu() if on_host else reads[0]
         ref = mine.clone()
         dist.broadcast(ref, src=0)
+        if not torch.equal(ref, mine):                            # what differs, for whoever reads the failure
+            bad = (ref != mine).nonzero().flatten()
+            print(f"[global leg] rank {rank}: {bad.numel()} of {B} reads differ from rank 0's; first: "
+                  f"{[(int(i), int(mine[i]), int(ref[i])) for i in bad[:8]]}", file=sys.stderr, flush=True)
         flag = torch.tensor([1 if (converged and torch.equal(ref, mine)) else 0], device="cpu" if on_host else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         converged = bool(flag.item())
@@ -1236,7 +1249,10 @@ def run_global(args, ctx, dist):
                                "avg_hits_rows_sent": int(avg("hits_rows_sent")), "avg_hits_rows_applied": int(avg("hits_rows_applied")),
                                "avg_update_rows": int(avg("update_rows")), "avg_items_installed": int(avg("items_installed")),
                                "avg_bytes_moved": int(avg("bytes_moved")), "host_fallbacks": int(sum(x["fallbacks"] for x in sync_stats)),
-                               "replicas_converged": converged}}
+                               "replicas_converged": converged,
+                               # the answers themselves, as one number: the streams are seeded, so every run of the same flags — as two
+                               # processes or as two logical ranks of one — must say the same (tests/test_gpu_bench_multi.py)
+                               "probe_remaining_sum": int(reads[0].sum())}}
         print(json.dumps(out), flush=True)
     comm.close()
     for rig in rigs:

@@ -64,3 +64,9 @@ def test_global_leg_with_two_processes_through_the_rccl_call_sequence():
     assert out["n_gpus"] == 2 and out["global_sync"]["replicas_converged"] is True and out["global_sync"]["host_fallbacks"] == 0
     assert out["parity"].startswith("2/2 ranks"), out["parity"]
     assert out["global_sync"]["syncs"] >= 4 and out["global_sync"]["avg_hits_rows_sent"] > 0 and out["value"] > 0
+    # the same flags as two logical ranks of ONE process (device copies instead of the RCCL calls): the streams are seeded, so the replicas
+    # end in the same state — the probe's answers add up to the same number.  (Converging is not enough: with wrong is_owner flags — a
+    # race in bench.py's setup that two processes sharing a GPU lost in 4 runs of 10 — the replicas sometimes agreed on a wrong state.)
+    one = _bench(["--gpus", "1", "--global-sync", "8", "--keys", "200000", "--steps", "32", "--warmup", "8"])
+    assert one["global_sync"]["replicas_converged"] is True
+    assert out["global_sync"]["probe_remaining_sum"] == one["global_sync"]["probe_remaining_sum"], (out["global_sync"], one["global_sync"])
