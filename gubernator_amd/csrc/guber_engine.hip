@@ -527,6 +527,7 @@ static bool lru_may_bind_unlocked(guber_engine* e, uint64_t n) { std::lock_guard
 static LruKeys lru_keys_of(const BatchView& B) {
     LruKeys K{};
     K.bytes = B.key_bytes; K.algorithm = B.algorithm; K.key_stride = B.key_stride;
+    K.behavior = B.behavior; K.duration = B.duration; K.greg_duration = (B.greg_expire && B.greg_duration) ? B.greg_duration : nullptr;
     if (!B.key_stride) { K.off_p = (const uint8_t*)B.key_off; K.off_stride = 4; }
     if (B.key_stride || B.key_len) { K.len_p = (const uint8_t*)B.key_len; K.len_stride = 4; }
     return K;
@@ -580,13 +581,13 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
         const uint64_t live_cap = e->lru_tstamp.cap;
         if (w_len > live_cap) w_len = live_cap;
         const uint32_t W = (uint32_t)std::min<uint64_t>(w_len, 1u << 30), wblocks = (W + 255) / 256;
-        // scratch: u64 [cells gid | n rstamp | W zstamp], u32 [cells gfirst | n rfirst | n rslot | W zslot | W zwidx | n qfirst | n qrank | n qslot |
+        // scratch: u64 [cells gid | n rstamp | W zstamp], u32 [cells gfirst | cells gfirst_ok | n rfirst | n rslot | W zslot | W zwidx | n qfirst | n qrank | n qslot |
         //               wblocks + 1 blockcnt | n + 1 new_before | W + 1 touched_before | 4 n_risk], u8 [n + 1 isnew_at | W wflag | W ztouched]
         const size_t nn = (size_t)n + 1;
-        if (e->lru_u64.ensure((size_t)cells + nn + W + 8) || e->lru_u32.ensure((size_t)cells + 6 * nn + 3 * ((size_t)W + 1) + wblocks + 16) ||
+        if (e->lru_u64.ensure((size_t)cells + nn + W + 8) || e->lru_u32.ensure(2 * (size_t)cells + 6 * nn + 3 * ((size_t)W + 1) + wblocks + 16) ||
             e->lru_u8.ensure(nn + 2 * ((size_t)W + 1) + 64)) return GUBER_E_NOMEM;
         unsigned long long* p64 = e->lru_u64.p; uint32_t* p32 = e->lru_u32.p; uint8_t* p8 = e->lru_u8.p;
-        LruGroups G{p64, p32, cells - 1}; p64 += cells; p32 += cells;
+        LruGroups G{p64, p32, p32 + cells, cells - 1}; p64 += cells; p32 += 2 * (size_t)cells;
         LruRes R{p32, p32 + nn, p64}; p32 += 2 * nn; p64 += nn;
         LruWin Z{p64, p32, p32 + W + 1}; p64 += W; p32 += 2 * ((size_t)W + 1);
         LruRisk Q{p32, p32 + nn, p32 + 2 * nn}; p32 += 3 * nn;
@@ -599,7 +600,7 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
         hipLaunchKernelGGL(k_lru_begin, dim3(1), dim3(256), 0, st, e->T, C, e->n_bctr);
         if (n) {
             HIPCHK(hipMemsetAsync(G.id, 0xff, (size_t)cells * 8, st));
-            HIPCHK(hipMemsetAsync(G.first, 0xff, (size_t)cells * 4, st));
+            HIPCHK(hipMemsetAsync(G.first, 0xff, (size_t)cells * 8, st));                   // (first and first_ok)
             HIPCHK(hipMemsetAsync(isnew_at, 0, nn, st));
             hipLaunchKernelGGL(k_lru_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, K, n, G);
             hipLaunchKernelGGL(k_lru_keys, dim3(cells / 256), dim3(256), 0, st, e->T, G, C, isnew_at, R);

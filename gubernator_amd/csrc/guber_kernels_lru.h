@@ -53,13 +53,24 @@ struct LruKeys {
     const uint8_t* len_p; uint32_t len_stride;     // u32 length likewise (null: off[i + 1] - off[i])
     uint32_t key_stride;
     const uint8_t* algorithm;                      // requests only: an invalid algorithm never reaches the cache (workers.go:317-321)
+    // requests only: DURATION_IS_GREGORIAN with a duration that is no interval constant fails in tokenBucketNewItem / leakyBucketNewItem
+    // BEFORE c.Add (algorithms.go; interval.go:93,107,125,148): for a key that is not in the cache such a request is a GetItem miss and
+    // nothing else — it inserts nothing (for a resident key it is an access like any other: GetItem has moved the item to the front)
+    const uint32_t* behavior; const int64_t* duration; const int64_t* greg_duration;   // (greg_duration: host-precomputed, < 0 = the error)
 };
+__device__ __forceinline__ bool lru_cannot_insert(const LruKeys& K, uint32_t i) {
+    if (!K.behavior || !(K.behavior[i] & BH_GREGORIAN)) return false;
+    if (K.greg_duration) return K.greg_duration[i] < 0;
+    const int64_t d = K.duration ? K.duration[i] : 0;
+    return d < 0 || d > 5 || d == 3;                 // GregorianWeeks: "not supported" (interval.go:97,130)
+}
 __device__ __forceinline__ uint32_t lru_u32(const uint8_t* p, uint32_t stride, uint32_t i) { return *(const uint32_t*)(p + (size_t)i * stride); }
 
 // the keys of the batch, grouped: an insert-only hash table id -> first request index (cells = pow2 >= 2 n, all bits set = empty).
 // id: bit 63 set = the key has a directory entry (slot in the low 32 bits; bit 62 = its bucket is live), else 63 bits of a
 // second, independent hash of the key bytes (a key the table has never seen)
-struct LruGroups { unsigned long long* id; uint32_t* first; uint32_t mask; };
+// first = the key's first request, first_ok = its first request that can insert it (all bits set: none — see lru_cannot_insert)
+struct LruGroups { unsigned long long* id; uint32_t* first; uint32_t* first_ok; uint32_t mask; };
 struct LruRes { uint32_t* first; uint32_t* slot; unsigned long long* stamp; };           // resident keys of the batch
 struct LruWin { unsigned long long* stamp; uint32_t* slot; uint32_t* widx; };             // the window's valid entries, oldest first
 struct LruRisk { uint32_t* first; uint32_t* rank; uint32_t* slot; };                     // resident keys inside the zone
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(256) void k_lru_probe(Table T, LruKeys K, uint32_t 
     for (;;) {
         unsigned long long cur = G.id[c];
         if (cur == ~0ull) { const unsigned long long old = atomicCAS(&G.id[c], ~0ull, id); cur = old == ~0ull ? id : old; }
-        if (cur == id) { atomicMin(&G.first[c], i); return; }
+        if (cur == id) { atomicMin(&G.first[c], i); if (!lru_cannot_insert(K, i)) atomicMin(&G.first_ok[c], i); return; }
         c = (c + 1) & G.mask;
     }
 }
@@ -119,8 +130,10 @@ __global__ __launch_bounds__(256) void k_lru_keys(Table T, LruGroups G, LruCtl* 
         const uint32_t k = atomicAdd(&C->m_res, 1u);
         R.first[k] = f; R.slot[k] = slot; R.stamp[k] = rec_stamp(T.buckets[slot].rec);
     } else {
+        const uint32_t fo = G.first_ok[c];               // a new key is inserted by its first request that gets as far as c.Add
+        if (fo == 0xffffffffu) return;                   // (none does: the key never enters the list)
         atomicAdd(&C->m_new, 1u);
-        isnew_at[f] = 1;
+        isnew_at[fo] = 1;
     }
 }
 

@@ -358,12 +358,15 @@ int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_resu
  *      invalid algorithm never reaches the cache (workers.go:317-321): it counts no access and leaves its key's place in the list
  *      alone (test_an_invalid_algorithm_request_does_not_refresh_recency); duplicates of one key inside one guber_add_items
  *      call leave the keys in the order of their LAST places in the call (test_duplicates_inside_one_add_keep_the_calls_order)
- *      — both closed in round 5.  What is NOT reproduced (one case): a NEW key whose requests in a batch ALL fail inside the
- *      algorithm — DURATION_IS_GREGORIAN with a duration that is no interval constant (interval.go:93,107) — is counted as an
- *      insert when the eviction pre-pass sizes a batch's evictions: the reference calls GetItem (a miss) and returns the error
- *      before Add, so it evicts one item fewer.  It takes a binding cache AND a client that sends an invalid interval constant
- *      for a key that is not resident; answers of the batch itself are unaffected, the cache holds one live item fewer than
- *      the reference until the next insert.
+ *      — both closed in round 5 —; and a request that fails inside the algorithm BEFORE c.Add — DURATION_IS_GREGORIAN with a
+ *      duration that is no interval constant, or GregorianWeeks (interval.go:93,97,107,125,130,148) — inserts nothing: a key that
+ *      is not resident and whose requests in the batch all fail that way never enters the list, a key with a failing request
+ *      first and a good one later is inserted by the good one (test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert;
+ *      closed at the end of round 5).  What is NOT reproduced (one case left): a RESIDENT key near the back of the list that the
+ *      batch pushes out before the batch first asks for it, when that first request is such a failing one: the pre-pass sizes the
+ *      evictions as if the request re-inserted the key (the reference re-inserts it at the key's first good request, or not at
+ *      all), so it can evict one item more.  It takes a binding cache, a key inside the few hundred oldest items, and a client
+ *      that sends an invalid interval constant for exactly that key; the answers of the batch itself are unaffected.
  *      Cost: nothing while live items + requests <= cache_size (size the cache with a batch of headroom); beyond that one
  *      pre-pass per batch (a dozen small launches and one stream synchronisation; the recency order of the live items comes
  *      from one table scan + sort per ~live/(2 x batch) batches: guber_stats_t.tail_rebuilds).

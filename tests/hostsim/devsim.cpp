@@ -57,11 +57,11 @@ static uint32_t ds_admit(DevSim* d, const LruKeys& K, uint32_t n, int64_t now) {
         const uint32_t W = (uint32_t)w_len, wblocks = (W + 255) / 256;
         const size_t nn = (size_t)n + 1;
         std::vector<unsigned long long> gid(cells, ~0ull), rstamp(nn), zstamp(W + 1);
-        std::vector<uint32_t> gfirst(cells, 0xffffffffu), rfirst(nn), rslot(nn), zslot(W + 1), zwidx(W + 1), qfirst(nn), qrank(nn), qslot(nn), blockcnt(wblocks + 1),
+        std::vector<uint32_t> gfirst(cells, 0xffffffffu), gfirst_ok(cells, 0xffffffffu), rfirst(nn), rslot(nn), zslot(W + 1), zwidx(W + 1), qfirst(nn), qrank(nn), qslot(nn), blockcnt(wblocks + 1),
             new_before(nn), touched_before(W + 1);
         std::vector<uint8_t> isnew_at(nn, 0), wflag(W + 1, 0), ztouched(W + 1, 0);
         uint32_t n_risk = 0;
-        LruGroups G{gid.data(), gfirst.data(), cells - 1}; LruRes R{rfirst.data(), rslot.data(), rstamp.data()};
+        LruGroups G{gid.data(), gfirst.data(), gfirst_ok.data(), cells - 1}; LruRes R{rfirst.data(), rslot.data(), rstamp.data()};
         LruWin Z{zstamp.data(), zslot.data(), zwidx.data()}; LruRisk Q{qfirst.data(), qrank.data(), qslot.data()};
         LruCtl* C = &d->ctl;
         fakehip::launch(dim3(1), dim3(256), nullptr, [&] { k_lru_begin(d->T, C, (uint32_t)d->bctr.size()); });
@@ -170,7 +170,8 @@ int ds_eval(void* h, const guber_batch_t* b, guber_result_t* r, int pipeline, in
             if (B.greg_duration) S.greg_duration = B.greg_duration + p;
             return S;
         };
-        auto keys = [&](const BatchView& S) { LruKeys K{}; K.bytes = S.key_bytes; K.off_p = (const uint8_t*)S.key_off; K.off_stride = 4; K.algorithm = S.algorithm; return K; };
+        auto keys = [&](const BatchView& S) { LruKeys K{}; K.bytes = S.key_bytes; K.off_p = (const uint8_t*)S.key_off; K.off_stride = 4; K.algorithm = S.algorithm;
+                                             K.behavior = S.behavior; K.duration = S.duration; K.greg_duration = (S.greg_expire && S.greg_duration) ? S.greg_duration : nullptr; return K; };
         uint32_t st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms);
         if (st == LRU_CUT) { len = (uint32_t)std::min<uint64_t>(len, d->cache_size); st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms); }
         if (st != LRU_NONE && st != LRU_APPLIED) return -3;

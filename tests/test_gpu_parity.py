@@ -922,6 +922,48 @@ def test_evicted_keys_that_return_meet_the_reference_list(flags):
         e.close()
 
 
+@pytest.mark.parametrize("flags", [0, 64])
+@pytest.mark.parametrize("precomputed", [True, False], ids=["host_calendar_values", "calendar_on_the_device"])
+def test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert(flags, precomputed):
+    """A request with DURATION_IS_GREGORIAN and a duration that is no interval constant (or GregorianWeeks: not supported) fails in
+    tokenBucketNewItem / leakyBucketNewItem BEFORE c.Add (algorithms.go; interval.go:93,97,107,125,130,148): for a key that is not in
+    the cache it is a GetItem miss and nothing else — no insert, nobody leaves the list for it (lrucache.go:98-100); a key with a
+    failing request first and a good one later in the batch is inserted by the good one.  Under a binding cache every answer, the
+    counters and the size after every batch equal the bounded-LRU oracle (round 5: the eviction pre-pass counted such keys as inserts
+    and evicted one item too many for each — this test fails without lru_cannot_insert, guber_kernels_lru.h)."""
+    cs, nkeys, bsz = 2000, 2600, 1500
+    rng = np.random.default_rng(17)
+    o, e = Oracle(cache_size=cs), engine(cache_size=cs, max_batch=2048, flags=flags)
+    now = streams.NOW0
+    for step in range(16):
+        ids = rng.integers(0, nkeys, bsz)
+        keys = [f"lru_{int(i)}" for i in ids]
+        beh = np.zeros(bsz, np.uint32); dur = np.full(bsz, 3_600_000, np.int64)
+        bad = rng.choice(bsz, 120, replace=False)
+        for q, i in enumerate(bad):                              # keys nobody else asks for: all their requests fail
+            keys[i] = f"never_{step}_{q % 40}"
+            beh[i] = support.GREGORIAN; dur[i] = 3 if q % 2 else 99
+        late = rng.choice(np.setdiff1d(np.arange(bsz), bad), 60, replace=False)
+        for q, i in enumerate(sorted(late)):                     # a failing request first, a good one for the same key later
+            keys[i] = f"late_{step}_{q // 2}"
+            if q % 2 == 0:
+                beh[i] = support.GREGORIAN; dur[i] = 77
+        ge, gd = np.zeros(bsz, np.int64), np.zeros(bsz, np.int64)
+        for i in np.nonzero(beh & support.GREGORIAN)[0]:
+            ge[i], gd[i] = support.gregorian(now, int(dur[i]))
+        algo = (ids & 1).astype(np.uint8)
+        want = o.eval(HostBatch(keys, 1, 1000, dur, now, algorithm=algo, behavior=beh, greg_expire=ge, greg_duration=gd))
+        got = e.eval(HostBatch(keys, 1, 1000, dur, now, algorithm=algo, behavior=beh, greg_expire=ge, greg_duration=gd) if precomputed
+                     else HostBatch(keys, 1, 1000, dur, now, algorithm=algo, behavior=beh))
+        support.assert_results_equal(got, want, f"step {step}")
+        assert (got.err[bad] != 0).all()
+        assert got.counters() == want.counters() and want.counters()[4] <= cs, (step, got.counters(), want.counters())
+        now += 1000
+    st = e.stats()
+    assert st["unexpired_evictions"] == o.counters()[3] and st["cache_size"] == o.size() and st["eviction_passes"] >= 1, st
+    e.close()
+
+
 def test_a_batch_larger_than_the_cache_is_evaluated_in_pieces():
     """cache_size 300 under batches of 1 000 requests over 500 keys (and one of 70 000 through the radix pipeline's size class): the
     engine cuts the batch into pieces of cache_size requests, each with its own eviction pre-pass — a key evicted by request i is a

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import streams
-from support import ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle, assert_results_equal, gregorian
+from support import GREGORIAN, ROOT, GuberBatch, GuberResult, HostBatch, HostResult, Oracle, assert_results_equal, gregorian
 
 HS = os.path.join(ROOT, "tests", "hostsim")
 
@@ -358,6 +358,44 @@ def test_bounded_cache_evicts_in_the_reference_order(lib, pipeline, pattern):
     st = sim.lru_stats()
     assert st["unexpired_evictions"] == orc.counters()[3] and st["applied"] >= 1, st
     assert sim.counters()[:3] == orc.counters()[:3]
+    sim.close()
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert(lib, pipeline):
+    """algorithms.go: a request with DURATION_IS_GREGORIAN and a duration that is no interval constant (interval.go:93,107,125,148) fails
+    in tokenBucketNewItem / leakyBucketNewItem BEFORE c.Add: for a key that is not resident it is a GetItem miss and nothing else — no
+    insert, nobody leaves the list for it (lrucache.go:98-100).  A key with a failing request first and a good one later is inserted
+    by the good one.  Under a binding cache every answer, the size after every batch and the unexpired evictions equal the oracle's."""
+    only_where_the_form_matters(lib, 0)
+    cs, nkeys, bsz = 2000, 2600, 1500
+    sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
+    rng = np.random.default_rng(17)
+    now = streams.NOW0
+    for step in range(12):
+        ids = rng.integers(0, nkeys, bsz)
+        keys = [f"lru_{int(i)}" for i in ids]
+        beh = np.zeros(bsz, np.uint32); dur = np.full(bsz, 3_600_000, np.int64)
+        bad = rng.choice(bsz, 120, replace=False)
+        for q, i in enumerate(bad):                              # keys nobody else asks for: all their requests fail
+            keys[i] = f"never_{step}_{q % 40}"                   # (some of them three times in the batch)
+            beh[i] = GREGORIAN; dur[i] = 3 if q % 2 else 99      # weeks (not supported) / no interval constant
+        late = rng.choice(np.setdiff1d(np.arange(bsz), bad), 60, replace=False)
+        for q, i in enumerate(sorted(late)):                     # a failing request first, a good one for the same key later in the batch
+            keys[i] = f"late_{step}_{q // 2}"
+            if q % 2 == 0:
+                beh[i] = GREGORIAN; dur[i] = 77
+        ge, gd = np.zeros(bsz, np.int64), np.zeros(bsz, np.int64)
+        for i in np.nonzero(beh & GREGORIAN)[0]:                 # (as the host layer precomputes them: a negative greg_duration carries the error)
+            ge[i], gd[i] = gregorian(now, int(dur[i]))
+        b = HostBatch(keys, 1, 1000, dur, now, algorithm=(ids & 1).astype(np.uint8), behavior=beh, greg_expire=ge, greg_duration=gd)
+        want, got = orc.eval(b), sim.eval(b)
+        assert_results_equal(got, want, f"step {step}")
+        assert (got.err[bad] != 0).all()
+        assert sim.counters()[3] == orc.size() <= cs, (step, sim.counters()[3], orc.size())
+        now += 1000
+    st = sim.lru_stats()
+    assert st["unexpired_evictions"] == orc.counters()[3] and st["applied"] >= 1, (st, orc.counters())
     sim.close()
 
 
