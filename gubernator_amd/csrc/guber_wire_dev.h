@@ -60,36 +60,14 @@ extern "C" void guber_wire_dev_destroy(guber_wire_dev_t* d) {
     delete d;
 }
 
-// Decode nrpc serialized GetRateLimitsReq / GetPeerRateLimitsReq payloads into ONE device batch.  The payload bytes are copied into
-// the decoder's pinned buffer (this copy and the H2D transfer are what the C call's rate is made of: DESIGN.md 5b).
-extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* msgs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
-                                     uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items) {
-    if (!d || (nrpc && (!msgs || !lens)) || !n_items) return fail(GUBER_E_INVALID_ARG, "null argument");
-    *n_items = 0;
-    if (nrpc > d->max_rpcs) return fail(GUBER_E_BATCH_TOO_LARGE, "more RPCs than the decoder was created for");
+// The payloads lie in the decoder's pinned buffer (h_buf) at h_off[] (16-byte aligned): copy [lo, hi) to the device and decode.
+// Engine mutex held, device set.
+static int wire_dev_decode_staged_locked(guber_wire_dev* d, uint32_t nrpc, size_t lo, size_t hi, uint32_t windows, bool multi, const uint8_t* is_owner,
+                                         uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items) {
     guber_engine* e = d->e;
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
-    d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
-    if (!nrpc) return GUBER_OK;
     uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 4 * (size_t)d->max_rpcs + 4;
-    size_t pos = 0;
-    uint32_t windows = 0;
-    bool multi = false;                                                                    // a payload of more than one window: k_wire_win_a has something to say
-    for (uint32_t r = 0; r < nrpc; ++r) {
-        const uint32_t nw = guber::wire_windows_of(lens[r]);
-        h_wfirst[r] = windows; windows += nw; multi = multi || nw > 1;
-        pos = (pos + 15) & ~(size_t)15;
-        if (pos + lens[r] + 16 > d->max_bytes) return fail(GUBER_E_WIRE_FULL, "payload bytes exceed the decoder's buffer");
-        if (lens[r] && !msgs[r]) return fail(GUBER_E_INVALID_ARG, "null payload");
-        memcpy(d->h_buf.p + pos, msgs[r], lens[r]);
-        h_off[r] = (uint32_t)pos; h_len[r] = lens[r];
-        pos += lens[r];
-    }
-    h_wfirst[nrpc] = windows;                                                              // (<= max_windows: the bytes fit)
-    memset(d->h_buf.p + pos, 0, 16);
     hipStream_t st = e->stream;
-    HIPCHK(hipMemcpyAsync(d->d_buf.p, d->h_buf.p, pos + 16, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d->d_buf.p + lo, d->h_buf.p + lo, hi - lo, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync((void*)d->in.rpc_off, h_off, (size_t)nrpc * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync((void*)d->in.rpc_len, h_len, (size_t)nrpc * 4, hipMemcpyHostToDevice, st));
     if (is_owner) HIPCHK(hipMemcpyAsync(d->d_owner.p, is_owner, nrpc, hipMemcpyHostToDevice, st));
@@ -127,6 +105,73 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
         if (count) count[r] = d->h_status.p[r] == GUBER_OK ? h_count[r] : (d->h_status.p[r] == GUBER_E_WIRE_TOO_LARGE ? h_count[r] : 0);
     }
     return GUBER_OK;
+}
+
+// Decode nrpc serialized GetRateLimitsReq / GetPeerRateLimitsReq payloads into ONE device batch.  The payload bytes are copied into
+// the decoder's pinned buffer (this copy and the H2D transfer are what the C call's rate is made of: DESIGN.md 5b; a receive path
+// that reads its sockets straight into guber_wire_dev_buffer() and calls guber_wire_dev_decode_staged skips the copy).
+extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* msgs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
+                                     uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items) {
+    if (!d || (nrpc && (!msgs || !lens)) || !n_items) return fail(GUBER_E_INVALID_ARG, "null argument");
+    *n_items = 0;
+    if (nrpc > d->max_rpcs) return fail(GUBER_E_BATCH_TOO_LARGE, "more RPCs than the decoder was created for");
+    guber_engine* e = d->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
+    if (!nrpc) return GUBER_OK;
+    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 4 * (size_t)d->max_rpcs + 4;
+    size_t pos = 0;
+    uint32_t windows = 0;
+    bool multi = false;                                                                    // a payload of more than one window: k_wire_win_a has something to say
+    for (uint32_t r = 0; r < nrpc; ++r) {
+        const uint32_t nw = guber::wire_windows_of(lens[r]);
+        h_wfirst[r] = windows; windows += nw; multi = multi || nw > 1;
+        pos = (pos + 15) & ~(size_t)15;
+        if (pos + lens[r] + 16 > d->max_bytes) return fail(GUBER_E_WIRE_FULL, "payload bytes exceed the decoder's buffer");
+        if (lens[r] && !msgs[r]) return fail(GUBER_E_INVALID_ARG, "null payload");
+        memcpy(d->h_buf.p + pos, msgs[r], lens[r]);
+        h_off[r] = (uint32_t)pos; h_len[r] = lens[r];
+        pos += lens[r];
+    }
+    h_wfirst[nrpc] = windows;                                                              // (<= max_windows: the bytes fit)
+    memset(d->h_buf.p + pos, 0, 16);
+    return wire_dev_decode_staged_locked(d, nrpc, 0, pos + 16, windows, multi, is_owner, max_per_rpc, now_ms, status, first, count, n_items);
+}
+
+// The decoder's pinned staging buffer, and the decode of payloads that already lie in it: offs[r] 16-byte aligned, ascending, the
+// payloads not overlapping, 16 bytes of room behind the last one (the kernels read whole 16-byte pieces: what lies there is never
+// interpreted).  Everything else as guber_wire_dev_decode.
+extern "C" int guber_wire_dev_buffer(guber_wire_dev_t* d, uint8_t** buf, size_t* cap) {
+    if (!d || !buf || !cap) return fail(GUBER_E_INVALID_ARG, "null argument");
+    *buf = d->h_buf.p; *cap = d->max_bytes;
+    return GUBER_OK;
+}
+extern "C" int guber_wire_dev_decode_staged(guber_wire_dev_t* d, const uint32_t* offs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
+                                            uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items) {
+    if (!d || (nrpc && (!offs || !lens)) || !n_items) return fail(GUBER_E_INVALID_ARG, "null argument");
+    *n_items = 0;
+    if (nrpc > d->max_rpcs) return fail(GUBER_E_BATCH_TOO_LARGE, "more RPCs than the decoder was created for");
+    guber_engine* e = d->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
+    if (!nrpc) return GUBER_OK;
+    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 4 * (size_t)d->max_rpcs + 4;
+    uint32_t windows = 0;
+    bool multi = false;
+    size_t end = 0;
+    for (uint32_t r = 0; r < nrpc; ++r) {
+        if ((offs[r] & 15u) || (size_t)offs[r] < end || (size_t)offs[r] + lens[r] + 16 > d->max_bytes)
+            return fail(GUBER_E_INVALID_ARG, "staged payloads: offsets 16-byte aligned, ascending, not overlapping, 16 bytes of room behind the last");
+        const uint32_t nw = guber::wire_windows_of(lens[r]);
+        h_wfirst[r] = windows; windows += nw; multi = multi || nw > 1;
+        h_off[r] = offs[r]; h_len[r] = lens[r];
+        end = (size_t)offs[r] + lens[r];
+    }
+    h_wfirst[nrpc] = windows;
+    if (windows > d->max_windows) return fail(GUBER_E_WIRE_FULL, "staged payloads: more 8 KB windows than the decoder was created for");
+    return wire_dev_decode_staged_locked(d, nrpc, offs[0], end + 16, windows, multi, is_owner, max_per_rpc, now_ms, status, first, count, n_items);
 }
 
 // The decoded batch through the engine's pipelines; results to host arrays of n_items entries.

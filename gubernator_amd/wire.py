@@ -195,6 +195,9 @@ class DevWireDecoder:
         L.guber_wire_dev_destroy.restype = None
         L.guber_wire_dev_decode.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int64,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.guber_wire_dev_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.guber_wire_dev_decode_staged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int64,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.guber_wire_dev_eval.argtypes = [C.c_void_p, C.POINTER(GuberResult)]
         L.guber_wire_dev_columns.argtypes = [C.c_void_p, C.POINTER(_Columns)]
         self.engine = engine
@@ -213,6 +216,28 @@ class DevWireDecoder:
         items = C.c_uint32(0)
         rc = self.L.guber_wire_dev_decode(self.h, msgs, lens.ctypes.data, n, own.ctypes.data if own is not None else None, max_per_rpc, now_ms,
                                           status.ctypes.data, first.ctypes.data, count.ctypes.data, C.byref(items))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        self.n = items.value
+        return status[:n], first[:n], count[:n], items.value
+
+    def buffer(self):
+        """the decoder's pinned staging buffer as a writable numpy view (guber_wire_dev_buffer): what a receive path reads its sockets into"""
+        p, cap = C.c_void_p(), C.c_size_t()
+        rc = self.L.guber_wire_dev_buffer(self.h, C.byref(p), C.byref(cap))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (cap.value,))
+
+    def decode_staged(self, offs, lens, now_ms, is_owner=None, max_per_rpc=1000):
+        """payloads that already lie in buffer() at offs[] (16-byte aligned, ascending) -> (status[nrpc], first[nrpc], count[nrpc], n_items)"""
+        offs, lens = np.ascontiguousarray(offs, np.uint32), np.ascontiguousarray(lens, np.uint32)
+        n = len(offs)
+        own = None if is_owner is None else np.asarray(is_owner, np.uint8)
+        status, first, count = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32)
+        items = C.c_uint32(0)
+        rc = self.L.guber_wire_dev_decode_staged(self.h, offs.ctypes.data, lens.ctypes.data, n, own.ctypes.data if own is not None else None, max_per_rpc,
+                                                 now_ms, status.ctypes.data, first.ctypes.data, count.ctypes.data, C.byref(items))
         if rc:
             raise GuberError(rc, lib().guber_last_error().decode())
         self.n = items.value

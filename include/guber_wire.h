@@ -119,6 +119,9 @@ int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off,
  *                           GUBER_E_WIRE_TOO_LARGE), first[r], count[r] = the slice of the batch its items occupy (responses are
  *                           positionally aligned); *n_items = the batch size.  Items of a rejected RPC that were already placed stay
  *                           as dead slots (pre_err GUBER_WIRE_PRE_DEAD, empty key): they never reach a bucket.
+ *   guber_wire_dev_buffer / guber_wire_dev_decode_staged   the decoder's own pinned staging buffer, and the decode of payloads that
+ *                           already lie in it (offs[r] 16-byte aligned, ascending, not overlapping, 16 bytes of room behind the
+ *                           last): a receive path that reads its sockets straight into the buffer skips guber_wire_dev_decode's copy
  *   guber_wire_dev_eval     the batch through the engine (as guber_eval_batch_dev), results to host arrays of n_items entries
  *   guber_wire_dev_columns  the decoded columns copied to host memory (keys as rows of key_stride bytes + key_len): what
  *                           guber_wire_encode_responses-style code and the tests read */
@@ -135,6 +138,9 @@ int guber_wire_dev_create(guber_engine_t* e, uint32_t max_items, uint32_t max_pa
 void guber_wire_dev_destroy(guber_wire_dev_t* d);
 int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* msgs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
                           uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items);
+int guber_wire_dev_buffer(guber_wire_dev_t* d, uint8_t** buf, size_t* cap);
+int guber_wire_dev_decode_staged(guber_wire_dev_t* d, const uint32_t* offs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
+                                 uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items);
 int guber_wire_dev_eval(guber_wire_dev_t* d, guber_result_t* r);
 int guber_wire_dev_columns(guber_wire_dev_t* d, guber_wire_columns_t* c);
 

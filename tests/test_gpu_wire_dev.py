@@ -182,5 +182,26 @@ def test_device_decoded_batches_evaluate_like_the_oracle_and_report_throughput()
             _, _, _, n = dec2.decode(payloads, now)
         dt = (time.perf_counter() - t0) / reps
         print(f"device wire decode: {nrpc} payloads x {per_rpc} items = {n} items, {sum(map(len, payloads))} bytes in {dt * 1e6:.0f} us = {n / dt / 1e6:.0f} M items/s")
+        # the same payloads already in the decoder's pinned buffer (a receive path that reads its sockets into guber_wire_dev_buffer):
+        # no host copy — and the same batch, column by column
+        ref = dec2.columns()
+        buf = dec2.buffer()
+        offs, pos = [], 0
+        for p in payloads:
+            pos = (pos + 15) & ~15
+            buf[pos:pos + len(p)] = np.frombuffer(p, np.uint8)
+            offs.append(pos); pos += len(p)
+        lens = [len(p) for p in payloads]
+        st2, first2, count2, n2 = dec2.decode_staged(offs, lens, now)
+        assert n2 == n and (st2 == 0).all()
+        got = dec2.columns()
+        assert got["keys"] == ref["keys"] and all(np.array_equal(got[k], ref[k]) for k in ref if k != "keys")
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dec2.decode_staged(offs, lens, now)
+        dt = (time.perf_counter() - t0) / reps
+        print(f"device wire decode, payloads in the pinned buffer: {nrpc} payloads x {per_rpc} items in {dt * 1e6:.0f} us = {n / dt / 1e6:.0f} M items/s")
+        with pytest.raises(ga.GuberError):
+            dec2.decode_staged([8], [16], now)                   # (an offset that is not 16-byte aligned)
         dec2.close()
     dec.close(); e.close(); o.close()
