@@ -14,7 +14,8 @@ WIRE_SYMBOLS = [
     "guber_wire_decode_requests", "guber_wire_batch_view", "guber_wire_batch_result", "guber_wire_batch_pre_errors",
     "guber_wire_eval", "guber_wire_encode_bound", "guber_wire_encode_responses",
     "guber_wire_items_create", "guber_wire_items_destroy", "guber_wire_decode_globals", "guber_wire_encode_globals",
-    "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_eval", "guber_wire_dev_columns",
+    "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_buffer", "guber_wire_dev_decode_staged",
+    "guber_wire_dev_eval", "guber_wire_dev_columns",
 ]
 _bound = False
 
