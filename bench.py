@@ -97,7 +97,8 @@ def parse():
     ap.add_argument("--duration-ms", type=int, default=60_000, help="RateLimitReq.duration of the stream")
     ap.add_argument("--min-batches", type=int, default=MIN_TIMED_BATCHES, help="lower bound of the timed region in distinct batches (measurement scripts may lower it)")
     ap.add_argument("--min-ms", type=float, default=0.0, help="accepted and ignored (the timed region is a fixed number of distinct batches, never a replay)")
-    ap.add_argument("--extras", default="leaky,expiring,shards_1,uniform,end_to_end,pool",
+    ap.add_argument("--gen-batches", type=int, default=8, help="`routed`: batches of --batch requests per generation handed to the device-side front (guber_front_*)")
+    ap.add_argument("--extras", default="routed,leaky,expiring,shards_1,uniform,end_to_end,pool",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--extra-batches", type=int, default=1024, help="timed distinct batches of the extra configurations")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
@@ -588,6 +589,138 @@ class Rig:
         self.kept = {}
 
 
+class RoutedRig(Rig):
+    """The all-inclusive arrangement (guber_front_*, include/guber_gpu.h): ONE raw request stream in HBM, never split on the host.  A
+    generation = `gen_batches` consecutive batches of B requests in ARRIVAL order (what a batcher has collected while the previous
+    generation ran: peer_client.go:284-337) -> on the device: XXH64 of every HashKey + the placement's rule -> shard (workers.go:261-289,
+    getWorker :180-184), every shard's share contiguous and in arrival order -> the S tables through the fused launches -> the answers
+    back in ARRIVAL order (gubernator.proto:51-54) — all inside the clock.  Units: `steps` / `warmup` / seq / kept / host_batch are in
+    batches of B (slices of a generation), so the parity and CPU-baseline passes are the headline's, fed in request order."""
+
+    def __init__(self, ctx, algo, dist_kind, S, gen_batches, duration_ms=60_000):
+        super().__init__(ctx, algo, dist_kind, S, duration_ms=duration_ms)
+        self.GB = int(gen_batches)
+        self.G = self.GB * ctx.B
+        self.front = self.ga.Front(self.engines, self.place, max_n=self.G, depth=4)
+
+    def gen_now(self, g, now0):
+        return now0 + 1 + g * self.GB                               # (the clock advances 1 ms per batch of B on average)
+
+    def build_stream(self, total, now0, seed):
+        """total = batches of B (a multiple of GB): ONE stream in arrival order, generation g = requests [g*G, (g+1)*G)"""
+        torch, B, L, dev, G, GB = self.torch, self.ctx.B, self.L, self.ctx.dev, self.G, self.GB
+        assert total % GB == 0
+        ngen = total // GB
+        nk = len(self.ctx.my_ids)
+        n = total * B
+        if self.dist_kind == "zipf":
+            d_ids = ZipfRanker(torch, dev, nk, s=1.1, seed=seed, perm_seed=99).draw_dev(n)
+        else:
+            d_ids = torch.from_numpy(np.random.default_rng(seed).integers(0, nk, n, dtype=np.int32)).to(dev)
+        self.seq = [(0, self.gen_now(s // GB, now0)) for s in range(total)]
+        self.h_ids = d_ids.view(total, B).cpu().numpy()
+        d_keys = torch.empty(n * L + 16, dtype=torch.uint8, device=dev)
+        d_keys[-16:] = 0
+        step = 256
+        for lo in range(0, total, step):
+            hi = min(total, lo + step)
+            d_keys[lo * B * L:hi * B * L] = self.d_keytab.index_select(0, d_ids[lo * B:hi * B]).reshape(-1)
+        self.d_keys = d_keys
+        self.distinct_keys = int(torch.unique(d_ids).numel())
+        del d_ids
+        t_offG = torch.from_numpy((np.arange(G + 1, dtype=np.int64) * L).astype(np.int32)).to(dev)
+        self.cols = {"off": t_offG.repeat(ngen), "hits": torch.full((n,), 1, dtype=torch.int64, device=dev),
+                     "limit": torch.full((n,), 100, dtype=torch.int64, device=dev),
+                     "duration": torch.full((n,), self.duration_ms, dtype=torch.int64, device=dev),
+                     "algorithm": torch.full((n,), self.algo_id, dtype=torch.uint8, device=dev),
+                     "behavior": torch.zeros((n,), dtype=torch.int32, device=dev)}
+        c, ga = self.cols, self.ga
+        self.gens = [ga.GuberBatch(G, 0, d_keys.data_ptr() + g * G * L, c["off"].data_ptr() + g * (G + 1) * 4, c["hits"].data_ptr() + g * G * 8,
+                                   c["limit"].data_ptr() + g * G * 8, c["duration"].data_ptr() + g * G * 8, None, None, c["algorithm"].data_ptr() + g * G,
+                                   c["behavior"].data_ptr() + g * G * 4, None, None, None, int(self.gen_now(g, now0))) for g in range(ngen)]
+        # every generation writes its own answer arrays (request order); every timed slice of B is digest-checked afterwards
+        self.res_all = {"status": torch.empty(n, dtype=torch.uint8, device=dev), "err": torch.empty(n, dtype=torch.uint8, device=dev),
+                        "limit": torch.empty(n, dtype=torch.int64, device=dev), "remaining": torch.empty(n, dtype=torch.int64, device=dev),
+                        "reset_time": torch.empty(n, dtype=torch.int64, device=dev)}
+        r = self.res_all
+        self.gres = [ga.GuberResult(r["status"].data_ptr() + g * G, r["limit"].data_ptr() + g * G * 8, r["remaining"].data_ptr() + g * G * 8,
+                                    r["reset_time"].data_ptr() + g * G * 8, r["err"].data_ptr() + g * G, 0, 0, 0, 0, 0) for g in range(ngen)]
+        torch.cuda.synchronize(dev)
+
+    def keep_results(self, which):
+        """the timed slices' answers ARE slices of the generations' answer arrays (request order)"""
+        which = list(which)
+        B = self.ctx.B
+        lo = which[0]
+        assert which == list(range(lo, lo + len(which)))
+        self.res_cols = {k: v[lo * B:(lo + len(which)) * B] for k, v in self.res_all.items()}
+        self.kept = {s: self.SliceResult(self, k) for k, s in enumerate(which)}
+
+    def run(self, lo, hi, timed=False):
+        torch, GB = self.torch, self.GB
+        assert lo % GB == 0 and hi % GB == 0
+        g0, g1 = lo // GB, hi // GB
+        N = g1 - g0
+        ba = (self.ga.GuberBatch * max(N, 1))(*self.gens[g0:g1])
+        ra = (self.ga.GuberResult * max(N, 1))(*self.gres[g0:g1])
+        if timed:
+            torch.cuda.synchronize(self.ctx.dev)
+            self.ctx.barrier()
+        t0 = time.perf_counter()
+        c0 = time.thread_time()
+        done = self.front.eval_dev(ba, ra, N)
+        t_enq = time.perf_counter()
+        self.last_enqueue_busy_s = time.thread_time() - c0
+        self.front.synchronize()
+        torch.cuda.synchronize(self.ctx.dev)
+        t1 = time.perf_counter()
+        assert done == N, (done, N)
+        if timed:
+            self.ctx.barrier()
+            self.last_stream_ms, self.last_stream_batches = [(t1 - t0) * 1e3], [hi - lo]
+            self.last_enqueue_s = t_enq - t0
+            return t1 - t0, (t1 - t0) * 1e3
+        return t1 - t0, None
+
+    def kernel_profile(self):
+        out = super().kernel_profile()
+        self.gen_us = self.front.latencies()
+        return out
+
+    def latency_under_load(self):
+        lat = sorted(getattr(self, "gen_us", []))
+        if not lat:
+            return None
+        return {"unit": "us", "p50": round(percentile(lat, 0.5), 2), "p99": round(percentile(lat, 0.99), 2), "min": round(lat[0], 2), "max": round(lat[-1], 2),
+                "n": len(lat), "what": (f"per generation of {self.G} requests: first routing kernel's start -> the end of the answers' last hop (HIP events on the routing "
+                                        "stream), the whole profile segment enqueued at once like the timed region: the routing runs two generations ahead of the "
+                                        "evaluation, so a generation's way includes the two before it (open loop)")}
+
+    def latency(self):
+        """one generation at a time, nothing else in flight: the call -> the answers in HBM (host clock: enqueue included)"""
+        GB = self.GB
+        lo = (self.warmup + self.steps + self.profile_steps) // GB
+        hi = lo + self.latency_steps // GB
+        lat = []
+        for g in range(lo, hi):
+            ba, ra = (self.ga.GuberBatch * 1)(self.gens[g]), (self.ga.GuberResult * 1)(self.gres[g])
+            t0 = time.perf_counter()
+            self.front.eval_dev(ba, ra, 1)
+            self.front.synchronize()
+            lat.append((time.perf_counter() - t0) * 1e6)
+        if not lat:
+            return None
+        lat.sort()
+        return {"unit": "us", "p50": round(percentile(lat, 0.5), 2), "p99": round(percentile(lat, 0.99), 2), "min": round(lat[0], 2), "n": len(lat),
+                "what": f"one generation of {self.G} requests (each a fresh part of the stream), host clock around guber_front_eval_dev + guber_front_synchronize, nothing else in flight"}
+
+    def close(self):
+        self.front_stats = self.front.stats()
+        self.front.close()
+        self.gens, self.gres, self.res_all, self.res_cols = [], [], None, None
+        super().close()
+
+
 def oracle_populate(rig, orc, threads, now0):
     ctx = rig.ctx
     for lo in range(0, len(ctx.my_ids), 1 << 18):
@@ -976,6 +1109,8 @@ def run_extra(name, args, ctx, NOW0, seed):
     K, B = ctx.K, ctx.B
     steps = max(64, args.extra_batches)
     warmup = max(4, min(args.warmup, 16))                        # (raised to four batches per shard below)
+    if name == "routed":
+        return run_routed(args, ctx, NOW0, seed, steps)
     if name == "end_to_end":
         return run_end_to_end(args, ctx, NOW0, seed)
     if name == "pool":
@@ -1011,6 +1146,50 @@ def run_extra(name, args, ctx, NOW0, seed):
         if not ok:
             out.pop("value")
     rig.close()
+    return out
+
+
+def run_routed(args, ctx, NOW0, seed, steps, algo=None, dist_kind=None):
+    """the all-inclusive arrangement (RoutedRig): one raw stream -> device route -> S tables -> answers in request order, all inside the
+    clock; parity against the oracle fed the same stream in request order, every timed batch by digest"""
+    import support
+    K, B = ctx.K, ctx.B
+    algo, dist_kind = algo or args.algo, dist_kind or args.dist
+    S, GB = max(1, args.shards), max(1, args.gen_batches)
+    steps = -(-steps // GB) * GB
+    rig = RoutedRig(ctx, algo, dist_kind, S, GB, duration_ms=args.duration_ms)
+    rig.populate(NOW0)
+    m = rig.measure(steps, 4 * GB, NOW0, seed, profile_steps=32 * GB, latency_steps=16 * GB)
+    pipe = BYTES_PER_DECISION[algo] * B / (m["ms_per_step"] * 1e-3) / 1e9
+    out = {"value": round(m["value"], 1), "unit": "decisions/s", "ms_per_step": round(m["ms_per_step"], 5), "timed_batches": steps, "replays": 0,
+           "generation_requests": rig.G, "generations_timed": steps // GB, "distinct_keys_touched": m["distinct_keys_in_stream"],
+           "dtype": "int64" if algo == "token" else "f64",
+           "roofline": {"bound": "hbm", "achieved": round(pipe, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBPS, 6),
+                        "what": f"{BYTES_PER_DECISION[algo]} algorithmic B per decision x {B} / ms_per_step; the routing's copies (request columns into the shares, answers "
+                                "back into arrival order) are coordination, not algorithmic bytes: they show in the time, not in the numerator"},
+           "host_enqueue_ms": round(m["enqueue_ms"], 3), "host_enqueue_busy_ms": round(m["enqueue_busy_ms"], 3), "timed_ms": round(m["timed_ms"], 3),
+           "workload": (f"{K} keys, ONE {dist_kind} request stream in arrival order, never split on the host, {algo.upper()}_BUCKET, generations of {GB} x {B} requests "
+                        f"(one now_ms each, +{GB} ms per generation) -> guber_front_eval_dev: k_fr_count (XXH64 of every HashKey + the placement's rule -> shard, "
+                        f"workers.go:180-184) + k_fr_scatter (shares contiguous, arrival order kept) on a routing stream two generations ahead -> the {S} tables "
+                        f"through the fused launches on {args.streams} streams -> k_fr_out (answers in request order, gubernator.proto:51-54); {steps} distinct batches "
+                        f"= {steps // GB} generations inside the clock, one call"),
+           "placement": rig.placement}
+    km, per_launch, launches = rig.kernel_profile()
+    out["kernel_avg_us"] = {k: round(v * 1e3, 2) for k, v in km.items() if v > 0}
+    out["requests_per_launch"] = {k: round(per_launch.get(k, 0), 1) for k, v in km.items() if v > 0}
+    out["batch_latency"] = {"idle": rig.latency(), "under_load": rig.latency_under_load()}
+    if not args.no_cpu_baseline:
+        w = min(os.cpu_count() or 1, 32)
+        orc = support.Oracle(cache_size=4 * K, workers=w)
+        ok, compared, _ = parity_over_timed_work(rig, orc, min(w, usable_cpus()) if w > 1 else 0, NOW0, "routed")
+        orc.close()
+        ok = ok and m["internal_retries"] == 0 and compared == steps
+        out["parity"] = (f"bit-exact vs ONE oracle fed the whole stream in request order (populate, warm-up, every timed generation): {compared}/{steps} timed batches "
+                         f"by digest of the answers in REQUEST order (tolerance 0), internal retries {m['internal_retries']}" if ok else "FAILED")
+        if not ok:
+            out.pop("value")
+    rig.close()
+    out["front"] = rig.front_stats
     return out
 
 

@@ -461,6 +461,71 @@ class Engine:
         _check(lib().guber_ring_route_dev(self.h, ring.h, key_bytes_ptr, key_off_ptr, n, owner_ptr))
 
 
+class FrontStats(C.Structure):
+    _fields_ = [("generations", C.c_uint64), ("forced_flushes", C.c_uint64), ("host_waits", C.c_uint64), ("host_wait_us", C.c_uint64)]
+
+
+class Front:
+    """guber_front_t (include/guber_gpu.h): generations of requests in ARRIVAL order, resident in HBM -> routed to the engines on the
+    device (XXH64 + the placement's rule: WorkerPool.getWorker, workers.go:180-184) -> evaluated -> answered in ARRIVAL order
+    (gubernator.proto:51-54)."""
+
+    def __init__(self, engines, placement=None, max_n=65536, depth=0):
+        L = lib()
+        L.guber_front_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.guber_front_destroy.argtypes = [C.c_void_p]
+        L.guber_front_destroy.restype = None
+        L.guber_front_eval_dev.argtypes = [C.c_void_p, C.POINTER(GuberBatch), C.POINTER(GuberResult), C.c_uint32, C.POINTER(C.c_uint32)]
+        L.guber_front_synchronize.argtypes = [C.c_void_p]
+        L.guber_front_set_rule.argtypes = [C.c_void_p, C.c_void_p]
+        L.guber_front_stats.argtypes = [C.c_void_p, C.POINTER(FrontStats)]
+        L.guber_front_stream.argtypes = [C.c_void_p]
+        L.guber_front_stream.restype = C.c_void_p
+        self.engines = list(engines)
+        self.placement = placement
+        hs = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        self.h = C.c_void_p()
+        rule = placement.export() if placement is not None else None
+        _check(L.guber_front_create(hs, len(self.engines), C.byref(rule) if rule is not None else None, max_n, depth, C.byref(self.h)))
+
+    def eval_dev(self, gen_array, result_array, count):
+        """ctypes arrays of GuberBatch / GuberResult (device pointers, arrival order); asynchronous"""
+        done = C.c_uint32(0)
+        _check(lib().guber_front_eval_dev(self.h, gen_array, result_array, count, C.byref(done)))
+        return done.value
+
+    def synchronize(self):
+        _check(lib().guber_front_synchronize(self.h))
+
+    def stream_handle(self):
+        return lib().guber_front_stream(self.h)
+
+    def latencies(self):
+        """microseconds per generation since the last call (profiling on the first engine)"""
+        L = lib()
+        L.guber_front_latencies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        buf = np.zeros(1 << 16, np.float32)
+        n = C.c_uint32(0)
+        _check(L.guber_front_latencies(self.h, buf.ctypes.data, len(buf), C.byref(n)))
+        return buf[:min(n.value, len(buf))].tolist()
+
+    def stats(self):
+        st = FrontStats()
+        _check(lib().guber_front_stats(self.h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in FrontStats._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().guber_front_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Stage:
     """guber_stage_t: one batch's request / response arrays in device-visible host memory, filled in place (numpy views),
     submitted asynchronously.  Two stages per engine = the overlapped end-to-end path."""

@@ -178,7 +178,7 @@ struct guber_engine {
     std::mutex mu;
     // optional per-kernel timing (guber_profile_*)
     bool profiling = false;
-    struct Span { int kernel; hipEvent_t a, b; };
+    struct Span { int kernel; hipEvent_t a, b; hipStream_t st; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> event_pool;
     double prof_ms[24] = {0}; uint64_t prof_n[24] = {0}, prof_units[24] = {0};
@@ -188,8 +188,9 @@ struct guber_engine {
         if (!event_pool.empty()) { hipEvent_t ev = event_pool.back(); event_pool.pop_back(); return ev; }
         hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); return ev;
     }
-    void span_begin(int k, uint64_t units = 0) { if (profiling) { Span s{k, get_event(), get_event()}; (void)hipEventRecord(s.a, stream); spans.push_back(s); prof_units[k] += units; } }
-    void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, stream); }
+    // (st: the stream the launch goes to when it is not the engine's own — the front's routing stream, guber_front.h)
+    void span_begin(int k, uint64_t units = 0, hipStream_t st = nullptr) { if (profiling) { Span s{k, get_event(), get_event(), st ? st : stream}; (void)hipEventRecord(s.a, s.st); spans.push_back(s); prof_units[k] += units; } }
+    void span_end() { if (profiling) (void)hipEventRecord(spans.back().b, spans.back().st); }
 
     // GUBER_FUSE_EP: the k_eval3 a routed call is holding back for a group this engine belongs to (guarded by mu).  Whoever is about to
     // enqueue on this engine, or to read what that launch writes, launches it first — every entry point comes through set_device()
@@ -199,11 +200,12 @@ struct guber_engine {
 };
 
 enum { KT_FRONT = 0, KT_EVAL2, KT_RESOLVE, KT_HIST, KT_SCATTER0, KT_SCATTER, KT_HEADS, KT_EVAL, KT_FRONT_MULTI, KT_EVAL2_MULTI,
-       KT_PART, KT_OWN, KT_EVAL3, KT_PART_MULTI, KT_OWN_MULTI, KT_EVAL3_MULTI, KT_EVALPART_MULTI, KT_COUNT };
+       KT_PART, KT_OWN, KT_EVAL3, KT_PART_MULTI, KT_OWN_MULTI, KT_EVAL3_MULTI, KT_EVALPART_MULTI, KT_FR_COUNT, KT_FR_SCAN, KT_FR_SCATTER, KT_FR_OUT, KT_COUNT };
 static_assert(KT_COUNT <= 24, "guber_engine::prof_* hold 24 kernels");
 static const char* const kKernelNames[KT_COUNT] = {"k_front", "k_eval2", "k_resolve", "k_hist", "k_scatter(first)",
                                                    "k_scatter", "k_heads", "k_eval", "k_front_multi", "k_eval2_multi",
-                                                   "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi", "k_evalpart_multi"};
+                                                   "k_part", "k_own", "k_eval3", "k_part_multi", "k_own_multi", "k_eval3_multi", "k_evalpart_multi",
+                                                   "k_fr_count", "k_fr_scan", "k_fr_scatter", "k_fr_out"};
 
 static uint64_t take_stamps(guber_engine* e, uint64_t n) {
     const uint64_t b = e->seq_next;
@@ -957,8 +959,17 @@ static bool can_fuse(guber_engine* e, uint32_t n) { return fits_fused(e, n) && !
 // GUBER_FUSE_EP: a group's k_eval3_multi that has not been launched yet — held back until the same tables' next group comes (then
 // it shares that group's first launch: k_evalpart_multi) or until anything else is about to be enqueued on its stream / the call ends
 // (then it goes on its own).  Lives inside ONE guber_eval_batches_routed_dev call, one per stream the call uses.
+// guber_front: "every evaluation of generation g on this stream has been launched" as an event the answers' way home waits for.
+// A held-back evaluation carries the hook of its generation; whoever launches it — the dispatcher's next group (k_evalpart_multi), a
+// flush, another thread's entry point — counts it off, and the last one records the event behind the launch.
+struct EvalHook {
+    hipEvent_t ev = nullptr; hipStream_t st = nullptr;
+    std::atomic<int> outstanding{0}; std::atomic<bool> recorded{false};
+    void launched() { if (outstanding.fetch_sub(1) == 1) { (void)hipEventRecord(ev, st); recorded.store(true, std::memory_order_release); } }
+};
 struct PendingEval {
     std::mutex pm;                                                 // two threads that each hold ONE of the group's engines may both come to launch it
+    EvalHook* hook = nullptr;                                      // (written under pm)
     std::atomic<bool> valid{false};                                // (written under pm; the dispatcher also looks before it has taken the engines' locks, and again after)
     int n = 0; uint32_t tiles = 0; uint64_t units = 0;
     guber_engine* eng[MULTI_MAX]; MultiEval ME;
@@ -975,6 +986,7 @@ static int launch_held(PendingEval& p, bool spans) {
     if (spans) e0->span_begin(KT_EVAL3_MULTI, p.units);            // (per-kernel timing belongs to the group's first engine: only under its mutex)
     hipLaunchKernelGGL(k_eval3_multi, dim3(p.tiles), dim3(256), 0, e0->stream, p.ME);
     if (spans) e0->span_end();
+    if (p.hook) { p.hook->launched(); p.hook = nullptr; }
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
     return 0;
 }
@@ -1030,16 +1042,12 @@ static const bool g_dprof = getenv("GUBER_DISPATCH_PROFILE") != nullptr;
 static thread_local uint64_t tl_dp[8];
 static inline uint64_t dp_now() { return g_dprof ? (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0; }
 struct DpSpan { int k; uint64_t t0; explicit DpSpan(int kk) : k(kk), t0(dp_now()) {} ~DpSpan() { if (g_dprof) tl_dp[k] += dp_now() - t0; } };
-static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, const guber_batch_t* batches, guber_result_t* results,
-                        uint32_t* enqueued, PendSet* ps = nullptr) {
+// (the batches as views: a caller's guber_batch_t, or an engine's share of a front's generation — guber_front.h; hook: the front's
+// "this generation's evaluations on this stream have all been launched" — a held-back evaluation takes it along)
+struct GroupItem { BatchView B; ResultView R; };
+static int launch_group(guber_engine* const* grp, const GroupItem* it, int g, uint32_t* enqueued, PendSet* ps = nullptr, EvalHook* hook = nullptr) {
     if (g_dprof) { tl_dp[5]++; tl_dp[6] += (uint64_t)g; }
-    auto views = [&](int i, BatchView& B, ResultView& R) {
-        const guber_batch_t* b = &batches[gk[i]]; guber_result_t* r = &results[gk[i]];
-        B = BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
-                      b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms};
-        R = ResultView{r->status, r->limit, r->remaining, r->reset_time, r->err};
-        r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
-    };
+    auto views = [&](int i, BatchView& B, ResultView& R) { B = it[i].B; R = it[i].R; };
     // (one batch: launch_batch.  Measured in round 5 and not kept: a sequence of ONE table's batches through these fused launches —
     // 1.50 against 2.40 G decisions/s: 128 k_own workgroups for the whole chip take 36 us, profiles/r05_g_one_table_fused.txt)
     if (g == 1) {
@@ -1060,7 +1068,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     PendingEval* pend = nullptr;                                   // the k_eval3 held back for exactly these tables, if there is one
     if (ps) {
         same_set = g <= EP_MAX;
-        for (int i = 0; i < g && same_set; ++i) same_set = grp[i]->fuse_ep && takes_part_path(grp[i], batches[gk[i]].n, false, true);
+        for (int i = 0; i < g && same_set; ++i) same_set = grp[i]->fuse_ep && takes_part_path(grp[i], it[i].B.n, false, true);
         for (auto& q : ps->items) {
             if (!q->valid || !same_set || q->n != g) continue;
             bool same = true;
@@ -1086,13 +1094,13 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
         // cheap form of the bound; a table that is tight now leaves the group and goes through launch_batch and its eviction pre-pass,
         // one by one — the cache never grows past cache_size and the victims stay lrucache.go's
         bool tight = false;
-        for (int i = 0; i < g; ++i) tight = tight || grp[i]->size_upper + batches[gk[i]].n > grp[i]->cache_size;
+        for (int i = 0; i < g; ++i) tight = tight || grp[i]->size_upper + it[i].B.n > grp[i]->cache_size;
         if (tight) {
             if (pend && pend->valid) { const int rcf = flush_pending(*pend, true); if (rcf) return rcf; }
             for (int i = g - 1; i >= 0; --i) order[i]->mu.unlock();
             unlock.g = 0;
             int rc1 = 0;
-            for (int i = 0; i < g && !rc1; ++i) rc1 = launch_group(&grp[i], &gk[i], 1, batches, results, enqueued, ps);
+            for (int i = 0; i < g && !rc1; ++i) rc1 = launch_group(&grp[i], &it[i], 1, enqueued, ps, hook);
             return rc1;
         }
     }
@@ -1100,7 +1108,7 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     uint32_t tiles = 0, ns[MULTI_MAX];
     int planned = 0, rc = 0;
     bool part = true;                                              // the group takes the owner-partitioned pipeline if all its batches do
-    for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], batches[gk[i]].n, false, true);
+    for (int i = 0; i < g; ++i) part = part && takes_part_path(grp[i], it[i].B.n, false, true);
     // GUBER_FUSE_EP: the k_eval3 held back on this stream shares this group's first launch if the group is the same tables again, in
     // the same order, and no prelude has anything to enqueue; otherwise it goes first, on its own
     const bool ep = ps && same_set && part;                       // (same_set, pend: decided before the locks were taken, below the g == 1 case)
@@ -1155,12 +1163,14 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                     const Work& Wp = MF.sub[i].W;
                     EP.sub[i].snap_seq = Wp.snap_seq; EP.sub[i].snap_n = Wp.snap_n; EP.sub[i].snap_c = Wp.snap_c; EP.sub[i].snap_b = Wp.snap_b; EP.sub[i].snap_stamp = Wp.snap_stamp;
                 }
-                { std::lock_guard<std::mutex> pl(pend->pm); pend->valid = false; }
+                EvalHook* joined_hook;
+                { std::lock_guard<std::mutex> pl(pend->pm); pend->valid = false; joined_hook = pend->hook; pend->hook = nullptr; }
                 for (int i = 0; i < planned; ++i) grp[i]->held = nullptr;
                 dp_lap(3);
                 grp[0]->span_begin(KT_EVALPART_MULTI, pend->units);
                 hipLaunchKernelGGL(k_evalpart_multi, dim3(pend->tiles + tiles), dim3(256), 0, grp[0]->stream, EP);
                 grp[0]->span_end();
+                if (joined_hook) joined_hook->launched();
                 grp[0]->ep_launches++;
             } else {
                 dp_lap(3);
@@ -1177,6 +1187,8 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
                 {
                     std::lock_guard<std::mutex> pl(pend->pm);
                     pend->valid = true; pend->n = planned; pend->tiles = tiles; pend->units = units; pend->ME = ME;
+                    pend->hook = hook;
+                    if (hook) hook->outstanding.fetch_add(1);
                 }
                 for (int i = 0; i < planned; ++i) { pend->eng[i] = grp[i]; grp[i]->held = pend; grp[i]->batches++; grp[i]->part_batches++; grp[i]->fused_batches++; }
                 *enqueued += (uint32_t)planned;
@@ -1205,56 +1217,69 @@ static int launch_group(guber_engine* const* grp, const uint32_t* gk, int g, con
     return rc;
 }
 
-extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* which,
-                                             const guber_batch_t* batches, guber_result_t* results, uint32_t count, uint32_t* done) {
-    if (done) *done = 0;
-    if (!engines || !n_engines || (count && (!which || !batches || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
-    std::vector<std::vector<uint32_t>> fifo(n_engines);
-    for (uint32_t k = 0; k < count; ++k) {
-        if (which[k] >= n_engines || !engines[which[k]]) return fail(GUBER_E_INVALID_ARG, "which[k] names no engine");
-        const int rc = check_batch_args(&batches[k], &results[k]);
-        if (rc) return rc;
-        if (batches[k].n) fifo[which[k]].push_back(k);
-    }
+// One round after the other: the next item of every engine that has one; engines that share device and stream share launches.
+// fifo[j] = the items of engines[j] in their order.  *enqueued counts items.  The caller owns `ps` (and flushes it).
+static int dispatch_rounds(guber_engine_t* const* engines, uint32_t n_engines, const std::vector<std::vector<GroupItem>>& fifo, PendSet* ps,
+                           uint32_t* enqueued, EvalHook* const* hook_of_engine = nullptr) {
     std::vector<size_t> pos(n_engines, 0);
-    uint32_t enqueued = 0, empty = 0;
-    for (uint32_t k = 0; k < count; ++k) empty += batches[k].n == 0;
-    // GUBER_FUSE_EP engines: the k_eval3 of a group of tables is held back for the same tables' next group (launch_group)
-    PendSet pendset;
-    bool any_ep = false;
-    for (uint32_t j = 0; j < n_engines; ++j) any_ep = any_ep || (engines[j] && engines[j]->fuse_ep);
-    PendSet* const ps = any_ep ? &pendset : nullptr;
-    struct Dispatching { bool on; Dispatching(bool o) : on(o) { if (on) ++tl_ep_dispatcher; } ~Dispatching() { if (on) --tl_ep_dispatcher; } } dispatching(any_ep);
-    auto flush_all = [&]() -> int { return pendset.flush_all(); };
     for (;;) {
-        guber_engine* grp[MULTI_MAX]; uint32_t gk[MULTI_MAX]; int g = 0;
+        guber_engine* grp[MULTI_MAX]; GroupItem git[MULTI_MAX]; int g = 0;
+        EvalHook* hk = nullptr;
         bool any = false;
         int rc = 0;
         for (uint32_t j = 0; j < n_engines && !rc; ++j) {
             if (pos[j] >= fifo[j].size()) continue;
             any = true;
             guber_engine* e = engines[j];
-            const uint32_t k = fifo[j][pos[j]++];
+            const GroupItem& item = fifo[j][pos[j]++];
             bool fits;
-            { DpSpan sp(0); fits = can_fuse(e, batches[k].n); }
+            { DpSpan sp(0); fits = can_fuse(e, item.B.n); }
             for (int i = 0; i < g && fits; ++i) fits = grp[i] != e;
             if (g && (!fits || g == MULTI_MAX || e->stream != grp[0]->stream || e->device != grp[0]->device)) {
-                rc = launch_group(grp, gk, g, batches, results, &enqueued, ps);
+                rc = launch_group(grp, git, g, enqueued, ps, hk);
                 g = 0;
                 if (rc) break;
             }
-            grp[g] = e; gk[g] = k; ++g;
-            if (!fits) { rc = launch_group(grp, gk, g, batches, results, &enqueued, ps); g = 0; }
+            grp[g] = e; git[g] = item; ++g;
+            hk = hook_of_engine ? hook_of_engine[j] : nullptr;      // (engines of one stream share their generation's hook)
+            if (!fits) { rc = launch_group(grp, git, g, enqueued, ps, hk); g = 0; }
         }
-        if (!rc && g) rc = launch_group(grp, gk, g, batches, results, &enqueued, ps);
-        if (done) *done = enqueued;
-        if (rc) { (void)flush_all(); return rc; }                  // (what was enqueued is completed: its k_eval3 goes now)
+        if (!rc && g) rc = launch_group(grp, git, g, enqueued, ps, hk);
+        if (rc) return rc;
         if (!any) break;
     }
-    {
-        const int rc = flush_all();
+    return 0;
+}
+
+extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* which,
+                                             const guber_batch_t* batches, guber_result_t* results, uint32_t count, uint32_t* done) {
+    if (done) *done = 0;
+    if (!engines || !n_engines || (count && (!which || !batches || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::vector<std::vector<GroupItem>> fifo(n_engines);
+    uint32_t empty = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (which[k] >= n_engines || !engines[which[k]]) return fail(GUBER_E_INVALID_ARG, "which[k] names no engine");
+        const int rc = check_batch_args(&batches[k], &results[k]);
         if (rc) return rc;
+        const guber_batch_t* b = &batches[k]; guber_result_t* r = &results[k];
+        r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+        if (!b->n) { ++empty; continue; }
+        fifo[which[k]].push_back(GroupItem{BatchView{b->n, 0, b->key_bytes, b->key_off, b->hits, b->limit, b->duration, b->burst, b->created_at,
+                                                     b->algorithm, b->behavior, b->is_owner, b->greg_expire, b->greg_duration, b->now_ms},
+                                           ResultView{r->status, r->limit, r->remaining, r->reset_time, r->err}});
     }
+    uint32_t enqueued = 0;
+    // GUBER_FUSE_EP engines: the k_eval3 of a group of tables is held back for the same tables' next group (launch_group)
+    PendSet pendset;
+    bool any_ep = false;
+    for (uint32_t j = 0; j < n_engines; ++j) any_ep = any_ep || (engines[j] && engines[j]->fuse_ep);
+    PendSet* const ps = any_ep ? &pendset : nullptr;
+    struct Dispatching { bool on; Dispatching(bool o) : on(o) { if (on) ++tl_ep_dispatcher; } ~Dispatching() { if (on) --tl_ep_dispatcher; } } dispatching(any_ep);
+    const int rc = dispatch_rounds(engines, n_engines, fifo, ps, &enqueued);
+    const int rcf = pendset.flush_all();                            // (what was enqueued is completed: its k_eval3 goes now)
+    if (done) *done = enqueued;
+    if (rc) return rc;
+    if (rcf) return rcf;
     if (g_dprof && tl_dp[6]) {
         fprintf(stderr, "[dispatch] %llu batches in %llu groups; per batch: wait-for-progress %.2f us, locks %.2f, preludes+plans %.2f, argument blocks %.2f, launches %.2f\n",
                 (unsigned long long)tl_dp[6], (unsigned long long)tl_dp[5], tl_dp[0] / 1e3 / tl_dp[6], tl_dp[1] / 1e3 / tl_dp[6], tl_dp[2] / 1e3 / tl_dp[6],
@@ -1264,6 +1289,8 @@ extern "C" int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uin
     if (done) *done = enqueued + empty;
     return GUBER_OK;
 }
+
+#include "guber_front.h"
 
 // Host-pointer evaluation: stage -> H2D -> kernels -> D2H.  `idx` (optional) selects a subset of
 // the caller's batch (used to re-submit GUBER_ITEM_E_RETRY items).
@@ -2946,13 +2973,16 @@ extern "C" int guber_profile_read(guber_engine_t* e, guber_kernel_time_t* out, u
         // (k_evalpart_multi both ends a pass — the previous group's k_eval3 — and begins the next: a pass that is followed by one
         // lasts until the end of that launch)
         auto first_stage = [](int k) { return k == KT_FRONT || k == KT_FRONT_MULTI || k == KT_PART || k == KT_PART_MULTI || k == KT_RESOLVE || k == KT_EVALPART_MULTI; };
+        // (a front's routing kernels run on a stream of their own and belong to no pass: guber_front_latencies times a generation's way)
+        std::vector<const guber_engine::Span*> sp;
+        for (auto& x : e->spans) if (x.kernel < KT_FR_COUNT || x.kernel > KT_FR_OUT) sp.push_back(&x);
         size_t g0 = 0;
-        for (size_t i = 0; i <= e->spans.size(); ++i) {
-            if (i == e->spans.size() || (i > g0 && first_stage(e->spans[i].kernel))) {
-                if (i > g0 && first_stage(e->spans[g0].kernel)) {
+        for (size_t i = 0; i <= sp.size(); ++i) {
+            if (i == sp.size() || (i > g0 && first_stage(sp[i]->kernel))) {
+                if (i > g0 && first_stage(sp[g0]->kernel)) {
                     float ms = 0.f;
-                    const size_t last = i < e->spans.size() && e->spans[i].kernel == KT_EVALPART_MULTI ? i : i - 1;
-                    if (hipEventElapsedTime(&ms, e->spans[g0].a, e->spans[last].b) == hipSuccess) e->group_us.push_back(ms * 1e3f);
+                    const size_t last = i < sp.size() && sp[i]->kernel == KT_EVALPART_MULTI ? i : i - 1;
+                    if (hipEventElapsedTime(&ms, sp[g0]->a, sp[last]->b) == hipSuccess) e->group_us.push_back(ms * 1e3f);
                 }
                 g0 = i;
             }

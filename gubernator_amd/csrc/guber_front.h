@@ -1,0 +1,367 @@
+// guber_front.h — guber_front_*: a generation of requests in ARRIVAL order, resident in HBM -> routed to the GPU's logical shards on
+// the device -> evaluated by the fused pipelines -> answered in ARRIVAL order.  Part of guber_engine.hip's translation unit (it uses
+// the dispatcher's internals: launch_group, PendSet, the engines' locks).
+//
+// Reference: WorkerPool.GetRateLimit picks a request's worker from the XXH64 of its HashKey (workers.go:261-289, getWorker :180-184)
+// and V1Instance.GetRateLimits answers in request order (gubernator.go:203-300, gubernator.proto:51-54).  guber_eval_batches_routed_dev
+// takes batches that somebody has already split by shard and leaves the answers in the shards' order; this is the whole of it.
+//
+// One generation g (slot = g mod depth):
+//   routing stream   k_fr_count(g)  k_fr_scan(g)  k_fr_scatter(g)  [event in(g)]                                   ... k_fr_out(g)
+//   engine streams                                    wait in(g) | the shares as batches of the fused pipelines | [event done(g, s)]
+// The routing runs ahead of the evaluation (two generations), so the shares' sizes — which the host needs to size the launches and to
+// keep the bounded caches' admission exact — are in pinned memory by the time the host asks: it never waits for the GPU in steady state.
+#pragma once
+
+struct guber_front {
+    std::mutex mu;
+    int device = 0;
+    std::vector<guber_engine*> eng;
+    std::vector<hipStream_t> streams;                 // the engines' distinct streams
+    std::vector<int> stream_of;                       // engine -> index into streams
+    hipStream_t rs = nullptr;                         // the routing stream (k_fr_count, k_fr_scatter, k_fr_out)
+    uint32_t cap = 0, depth = 0, max_key = 0;
+    uint32_t seq = 0;
+    DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
+    struct Slot {
+        DevBuf<uint8_t> mem; CohBuf<FrontHost> host;
+        FrIn in{}; FrOut out{};
+        uint8_t *o_status = nullptr, *o_err = nullptr; int64_t *o_limit = nullptr, *o_remaining = nullptr, *o_reset = nullptr;
+        hipEvent_t ev_in = nullptr, ev_a = nullptr;
+        std::vector<std::unique_ptr<EvalHook>> hooks;   // one per engine stream
+        uint32_t seq = 0, n = 0;
+        int64_t gen = -1;                               // the generation the slot holds (-1: free)
+        bool routed = false, dispatched = false, out_done = true;
+    };
+    std::vector<Slot> slots;
+    uint64_t generations = 0, forced_flushes = 0, host_waits = 0; double host_wait_ms = 0;
+    // with the first engine's per-kernel timing on (guber_profile_enable): every generation's way through the GPU, first routing kernel's
+    // start -> the answers' last hop's end (guber_front_latencies)
+    struct GenSpan { hipEvent_t a, b; };
+    std::vector<GenSpan> gen_spans;
+};
+
+static size_t front_col(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
+
+extern "C" void guber_front_destroy(guber_front_t* f) {
+    if (!f) return;
+    (void)hipSetDevice(f->device);
+    if (f->rs) { (void)hipStreamSynchronize(f->rs); }
+    for (auto st : f->streams) (void)hipStreamSynchronize(st);
+    for (auto& s : f->slots) {
+        s.mem.release(); s.host.release();
+        if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        for (auto& h : s.hooks) if (h && h->ev) (void)hipEventDestroy(h->ev);
+    }
+    f->rt_table.release(); f->rt_exs.release(); f->rt_exh.release();
+    if (f->rs) (void)hipStreamDestroy(f->rs);
+    delete f;
+}
+
+static int front_set_rule(guber_front* f, const guber_route_rule_t* rule) {
+    if (rule->n_shards == 0 || rule->per == 0 || !rule->table || rule->n_shards > 4096 || (rule->ex_cells & (rule->ex_cells - 1)) ||
+        (rule->ex_n && (!rule->ex_hash || !rule->ex_shard || rule->ex_n >= rule->ex_cells)))
+        return fail(GUBER_E_INVALID_ARG, "malformed route rule");
+    const size_t slots = (size_t)rule->n_shards * rule->per, cells = rule->ex_cells ? rule->ex_cells : 1;
+    if (f->rt_table.ensure(slots) || f->rt_exh.ensure(cells) || f->rt_exs.ensure(cells)) return GUBER_E_NOMEM;
+    hipError_t he = hipStreamSynchronize(f->rs);                     // (launches still reading the previous rule)
+    if (he == hipSuccess) he = hipMemcpy(f->rt_table.p, rule->table, slots * 2, hipMemcpyHostToDevice);
+    if (he == hipSuccess && rule->ex_n) he = hipMemcpy(f->rt_exh.p, rule->ex_hash, cells * 8, hipMemcpyHostToDevice);
+    if (he == hipSuccess && rule->ex_n) he = hipMemcpy(f->rt_exs.p, rule->ex_shard, cells * 2, hipMemcpyHostToDevice);
+    if (he != hipSuccess) { f->have_rule = false; return fail(GUBER_E_HIP, "guber_front: rule upload", he); }
+    f->rule = RouteRule{rule->n_shards, rule->per, rule->ex_cells, rule->ex_n, rule->global_engine, rule->step, rule->inv_step, rule->inv_sub,
+                        f->rt_table.p, (const unsigned long long*)f->rt_exh.p, f->rt_exs.p};
+    f->have_rule = true;
+    return 0;
+}
+
+extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_engines, const guber_route_rule_t* rule, uint32_t max_n,
+                                  uint32_t depth, guber_front_t** out) {
+    if (!engines || !out || !n_engines || n_engines > (uint32_t)MULTI_MEM_MAX) return fail(GUBER_E_INVALID_ARG, "1 .. 16 engines per front");
+    if (n_engines > 1 && !rule) return fail(GUBER_E_INVALID_ARG, "a front over several engines needs the placement's rule");
+    if (max_n == 0 || max_n > FR_MAX_N) return fail(GUBER_E_BATCH_TOO_LARGE, "a generation holds at most 4 194 304 requests");
+    if (depth == 0) depth = 4;
+    if (depth < 3 || depth > 16) return fail(GUBER_E_INVALID_ARG, "3 .. 16 generations in flight");
+    std::unique_ptr<guber_front, void (*)(guber_front*)> f(new guber_front(), [](guber_front* p) { guber_front_destroy(p); });
+    for (uint32_t j = 0; j < n_engines; ++j) {
+        guber_engine* e = engines[j];
+        if (!e) return fail(GUBER_E_INVALID_ARG, "null engine");
+        if (e->device != engines[0]->device) return fail(GUBER_E_INVALID_ARG, "the engines of a front live on one device");
+        for (uint32_t q = 0; q < j; ++q) if (engines[q] == e) return fail(GUBER_E_INVALID_ARG, "an engine twice in one front");
+        f->eng.push_back(e);
+        int si = -1;
+        for (size_t q = 0; q < f->streams.size(); ++q) if (f->streams[q] == e->stream) si = (int)q;
+        if (si < 0) { si = (int)f->streams.size(); f->streams.push_back(e->stream); }
+        f->stream_of.push_back(si);
+        f->max_key = j == 0 ? e->max_key : std::min(f->max_key, e->max_key);
+    }
+    f->device = engines[0]->device; f->cap = max_n; f->depth = depth;
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    HIPCHK(hipStreamCreateWithFlags(&f->rs, hipStreamNonBlocking));
+    if (rule) { const int rc = front_set_rule(f.get(), rule); if (rc) return rc; }
+    else f->rule = RouteRule{1, 1, 0, 0, -1, 0, 0, 0, nullptr, nullptr, nullptr};      // one engine: everything is its share
+    const size_t cap = max_n, tiles = (cap + 255) / 256;
+    f->slots.resize(depth);
+    for (auto& s : f->slots) {
+        // the mirror: request columns, where each request went, the answers in the shares' order, the keys (<= FR_KEY_COPY_MAX bytes each
+        // when they travel), then the routing's scratch
+        const size_t bytes = 3 * front_col(cap * 4 + 4) + 5 * front_col(cap * 8) + front_col(cap * 4) + 2 * front_col(cap) +   // requests
+                             3 * front_col(cap * 8) + 2 * front_col(cap) +                                                  // answers
+                             front_col(cap * FR_KEY_COPY_MAX + 64) +                                                         // keys
+                             front_col(cap * 2) + 2 * front_col(tiles * MULTI_MEM_MAX * 4) + front_col(sizeof(FrontCtl));
+        if (s.mem.ensure(bytes) || s.host.ensure(1)) return GUBER_E_NOMEM;
+        uint8_t* p = s.mem.p;
+        FrIn& A = s.in;
+        A.d_key_off = (uint32_t*)p; p += front_col(cap * 4 + 4); A.d_key_len = (uint32_t*)p; p += front_col(cap * 4 + 4); A.d_fwd = (uint32_t*)p; p += front_col(cap * 4 + 4);
+        A.d_hits = (int64_t*)p; p += front_col(cap * 8); A.d_limit = (int64_t*)p; p += front_col(cap * 8); A.d_duration = (int64_t*)p; p += front_col(cap * 8);
+        A.d_burst = (int64_t*)p; p += front_col(cap * 8); A.d_created_at = (int64_t*)p; p += front_col(cap * 8);
+        A.d_behavior = (uint32_t*)p; p += front_col(cap * 4); A.d_algorithm = p; p += front_col(cap); A.d_is_owner = p; p += front_col(cap);
+        s.o_limit = (int64_t*)p; p += front_col(cap * 8); s.o_remaining = (int64_t*)p; p += front_col(cap * 8); s.o_reset = (int64_t*)p; p += front_col(cap * 8);
+        s.o_status = p; p += front_col(cap); s.o_err = p; p += front_col(cap);
+        A.d_keys = p; p += front_col(cap * FR_KEY_COPY_MAX + 64);
+        A.er = (uint16_t*)p; p += front_col(cap * 2);
+        A.tile_cnt = (uint32_t*)p; p += front_col(tiles * MULTI_MEM_MAX * 4); A.tile_base = (uint32_t*)p; p += front_col(tiles * MULTI_MEM_MAX * 4);
+        A.ctl = (FrontCtl*)p; p += front_col(sizeof(FrontCtl));
+        A.host = s.host.p;
+        memset((void*)s.host.p, 0, sizeof(FrontHost));
+        HIPCHK(hipMemsetAsync(A.ctl, 0, sizeof(FrontCtl), f->rs));
+        HIPCHK(hipMemsetAsync(A.d_keys, 0, front_col(cap * FR_KEY_COPY_MAX + 64), f->rs));   // (the kernels read keys as 8-byte words: the bytes behind the last key are defined)
+        HIPCHK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        for (size_t q = 0; q < f->streams.size(); ++q) {
+            s.hooks.emplace_back(new EvalHook());
+            HIPCHK(hipEventCreateWithFlags(&s.hooks.back()->ev, hipEventDisableTiming));
+            s.hooks.back()->st = f->streams[q];
+        }
+    }
+    HIPCHK(hipStreamSynchronize(f->rs));
+    *out = f.release();
+    return GUBER_OK;
+}
+
+extern "C" int guber_front_set_rule(guber_front_t* f, const guber_route_rule_t* rule) {
+    if (!f || !rule) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    return front_set_rule(f, rule);
+}
+
+// k_fr_count, k_fr_scan and k_fr_scatter of generation g on the routing stream
+static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t* b, int64_t gen) {
+    s.gen = gen; s.n = b->n; s.routed = true; s.dispatched = false; s.out_done = false;
+    s.seq = ++f->seq ? f->seq : ++f->seq;
+    for (auto& h : s.hooks) { h->outstanding.store(1); h->recorded.store(false); }      // (1: the dispatcher's own hold until the generation's groups are out)
+    if (b->n == 0) return 0;
+    FrIn& A = s.in;
+    A.n = b->n; A.n_engines = (uint32_t)f->eng.size(); A.max_key = f->max_key; A.seq = s.seq;
+    A.key_bytes = b->key_bytes; A.key_off = b->key_off; A.hits = b->hits; A.limit = b->limit; A.duration = b->duration;
+    A.burst = b->burst; A.created_at = b->created_at; A.behavior = b->behavior; A.algorithm = b->algorithm; A.is_owner = b->is_owner;
+    A.R = f->rule;
+    const uint32_t tiles = (b->n + 255u) / 256u;
+    guber_engine* e0 = f->eng[0];
+    std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);       // (the per-kernel timing's spans and events belong to the first engine)
+    if (e0->profiling) pl.lock();
+    s.ev_a = nullptr;
+    if (e0->profiling) { s.ev_a = e0->get_event(); (void)hipEventRecord(s.ev_a, f->rs); }
+    e0->span_begin(KT_FR_COUNT, b->n, f->rs);
+    hipLaunchKernelGGL(k_fr_count, dim3(tiles), dim3(256), 0, f->rs, A);
+    e0->span_end();
+    e0->span_begin(KT_FR_SCAN, b->n, f->rs);
+    hipLaunchKernelGGL(k_fr_scan, dim3(MULTI_MEM_MAX / 4), dim3(FR_SCAN_T), 0, f->rs, A, tiles, (tiles + FR_SCAN_T - 1) / FR_SCAN_T);
+    e0->span_end();
+    e0->span_begin(KT_FR_SCATTER, b->n, f->rs);
+    hipLaunchKernelGGL(k_fr_scatter, dim3(tiles), dim3(256), 0, f->rs, A);
+    e0->span_end();
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    HIPCHK(hipEventRecord(s.ev_in, f->rs));
+    return 0;
+}
+
+// the answers of the slot's generation home, in arrival order (every evaluation of the generation has been launched)
+static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
+    s.out_done = true;
+    if (s.n == 0) return 0;
+    for (auto& h : s.hooks) HIPCHK(hipStreamWaitEvent(f->rs, h->ev, 0));
+    FrOut O{};
+    O.n = s.n; O.fwd = s.in.d_fwd;
+    O.d_status = s.o_status; O.d_err = s.o_err; O.d_limit = s.o_limit; O.d_remaining = s.o_remaining; O.d_reset_time = s.o_reset;
+    O.status = r->status; O.err = r->err; O.limit = r->limit; O.remaining = r->remaining; O.reset_time = r->reset_time;
+    guber_engine* e0 = f->eng[0];
+    std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);
+    if (e0->profiling) pl.lock();
+    e0->span_begin(KT_FR_OUT, s.n, f->rs);
+    hipLaunchKernelGGL(k_fr_out, dim3((s.n + 255u) / 256u), dim3(256), 0, f->rs, O);
+    e0->span_end();
+    if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, f->rs); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }
+    if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    return 0;
+}
+
+static bool front_evals_launched(const guber_front::Slot& s) {
+    for (auto& h : s.hooks) if (!h->recorded.load(std::memory_order_acquire)) return false;
+    return true;
+}
+
+// gens[k] -> results[k], k = 0 .. count-1: every pointer inside is a DEVICE pointer, requests in arrival order, answers in arrival
+// order.  Asynchronous: returns when everything is enqueued (guber_front_synchronize waits).  The caller's arrays must stay valid and
+// their contents ready (produced before the call, on any stream the caller has synchronised with) until then.
+extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens, guber_result_t* results, uint32_t count, uint32_t* done) {
+    if (done) *done = 0;
+    if (!f || (count && (!gens || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    for (uint32_t k = 0; k < count; ++k) {
+        const int rc = check_batch_args(&gens[k], &results[k]);
+        if (rc) return rc;
+        if (gens[k].n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "generation larger than the front was created for");
+        if (gens[k].greg_expire || gens[k].greg_duration) return fail(GUBER_E_INVALID_ARG, "a front takes its calendar intervals from the device");
+        guber_result_t* r = &results[k];
+        r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+    }
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    const uint32_t ne = (uint32_t)f->eng.size(), D = f->depth, ahead = D - 2;
+    PendSet pendset;
+    bool any_ep = false;
+    for (auto* e : f->eng) any_ep = any_ep || e->fuse_ep;
+    PendSet* const ps = any_ep ? &pendset : nullptr;
+    struct Dispatching { bool on; Dispatching(bool o) : on(o) { if (on) ++tl_ep_dispatcher; } ~Dispatching() { if (on) --tl_ep_dispatcher; } } dispatching(any_ep);
+    uint32_t next_route = 0, next_out = 0, enq = 0;
+    int rc = 0;
+    auto slot_of = [&](uint32_t k) -> guber_front::Slot& { return f->slots[k % D]; };
+    // the answers of every generation whose evaluations have all been launched go home, oldest first
+    auto drain_outs = [&](uint32_t upto, bool force) -> int {
+        while (next_out < upto) {
+            guber_front::Slot& s = slot_of(next_out);
+            if (!s.dispatched) break;
+            if (s.n && !front_evals_launched(s)) {
+                if (!force) break;
+                f->forced_flushes++;
+                const int r2 = pendset.flush_all();
+                if (r2) return r2;
+                if (!front_evals_launched(s)) return fail(GUBER_E_HIP, "guber_front: an evaluation was not launched");
+            }
+            const int r3 = front_out(f, s, &results[next_out]);
+            if (r3) return r3;
+            ++next_out;
+            if (done) *done = next_out;
+        }
+        return 0;
+    };
+    std::vector<std::vector<GroupItem>> fifo(ne);
+    std::vector<EvalHook*> hook_of(ne, nullptr);
+    for (uint32_t k = 0; k < count && !rc; ++k) {
+        // the routing runs ahead; a slot is routed into again only after its previous generation's answers have left it
+        while (next_route < count && next_route <= k + ahead && !rc) {
+            if (next_route >= D) { rc = drain_outs(next_route - D + 1, true); if (rc) break; }
+            rc = front_route(f, slot_of(next_route), &gens[next_route], (int64_t)f->generations + next_route);
+            ++next_route;
+        }
+        if (rc) break;
+        guber_front::Slot& s = slot_of(k);
+        const guber_batch_t* b = &gens[k];
+        if (s.n) {
+            // the shares' sizes (in pinned memory since k_fr_scan: normally long there)
+            auto reported = [&]() {
+                for (int q = 0; q <= MULTI_MEM_MAX; ++q)
+                    if ((uint32_t)(__atomic_load_n((volatile unsigned long long*)&s.host.p->w[q], __ATOMIC_ACQUIRE) >> 32) != s.seq) return false;
+                return true;
+            };
+            if (!reported()) {
+                const auto t0 = std::chrono::steady_clock::now();
+                f->host_waits++;
+                uint32_t spins = 0;
+                while (!reported()) {
+                    if (++spins > 2000) {
+                        std::this_thread::yield();
+                        if ((spins & 0x3ffu) == 0 && hipStreamQuery(f->rs) != hipErrorNotReady && !reported()) {
+                            rc = fail(GUBER_E_HIP, "guber_front: the routing of a generation did not report"); break;
+                        }
+                    }
+                }
+                f->host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (rc) break;
+            }
+            uint32_t counts[MULTI_MEM_MAX];
+            for (int q = 0; q < MULTI_MEM_MAX; ++q) counts[q] = (uint32_t)s.host.p->w[q];
+            const bool packed = !((uint32_t)s.host.p->w[MULTI_MEM_MAX] >> 8 & 1u);
+            for (auto st : f->streams) { if (hipStreamWaitEvent(st, s.ev_in, 0) != hipSuccess) { rc = fail(GUBER_E_HIP, "hipStreamWaitEvent"); break; } }
+            if (rc) break;
+            uint32_t base = 0, total = 0;
+            for (uint32_t j = 0; j < ne; ++j) {
+                fifo[j].clear();
+                hook_of[j] = s.hooks[f->stream_of[j]].get();
+                const uint32_t nj = counts[j];
+                total += nj;
+                guber_engine* e = f->eng[j];
+                const uint32_t piece = std::max<uint32_t>(1u, std::min<uint32_t>(e->fast_cap ? e->fast_cap : e->max_batch, e->max_batch));
+                for (uint32_t pos = 0; pos < nj; pos += piece) {
+                    const uint32_t len = std::min(piece, nj - pos), d0 = base + pos;
+                    const FrIn& A = s.in;
+                    BatchView B{len, 0, packed ? A.d_keys : b->key_bytes, A.d_key_off + d0, A.d_hits + d0, A.d_limit + d0, A.d_duration + d0,
+                                b->burst ? A.d_burst + d0 : nullptr, b->created_at ? A.d_created_at + d0 : nullptr,
+                                A.d_algorithm + d0, A.d_behavior + d0, b->is_owner ? A.d_is_owner + d0 : nullptr, nullptr, nullptr, b->now_ms,
+                                0, packed ? nullptr : A.d_key_len + d0};
+                    fifo[j].push_back(GroupItem{B, ResultView{s.o_status + d0, s.o_limit + d0, s.o_remaining + d0, s.o_reset + d0, s.o_err + d0}});
+                }
+                base += nj;
+            }
+            if (total != s.n) { rc = fail(GUBER_E_HIP, "guber_front: the shares do not add up to the generation"); break; }
+            rc = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data());
+        }
+        s.dispatched = true;
+        for (auto& h : s.hooks) h->launched();                      // the dispatcher's hold: the event is recorded once nothing of the generation is held back
+        if (rc) break;
+        rc = drain_outs(k + 1, false);
+    }
+    // (what was routed or enqueued is completed, also after an error: its evaluations go now, its answers go home)
+    {
+        for (uint32_t k = 0; k < next_route; ++k) {
+            guber_front::Slot& s = slot_of(k);
+            if (k >= next_out && !s.dispatched) { s.dispatched = true; s.n = 0; for (auto& h : s.hooks) h->launched(); }   // (routed, never evaluated: an error above)
+        }
+        const int rcf = pendset.flush_all();
+        if (!rc) rc = rcf;
+        const int rco = drain_outs(next_route, true);
+        if (!rc) rc = rco;
+    }
+    f->generations += next_out;
+    return rc;
+}
+
+extern "C" int guber_front_synchronize(guber_front_t* f) {
+    if (!f) return fail(GUBER_E_INVALID_ARG, "null front");
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    for (auto st : f->streams) HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(f->rs));
+    return GUBER_OK;
+}
+
+// microseconds per generation since the last call (needs guber_profile_enable on the front's FIRST engine while the generations ran);
+// waits for the routing stream
+extern "C" int guber_front_latencies(guber_front_t* f, float* us, uint32_t cap, uint32_t* n_out) {
+    if (!f || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(f->rs));
+    uint32_t n = 0;
+    guber_engine* e0 = f->eng[0];
+    std::lock_guard<std::mutex> lk2(e0->mu);
+    for (auto& g : f->gen_spans) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g.a, g.b) == hipSuccess && us && n < cap) us[n] = ms * 1e3f;
+        ++n;
+        e0->event_pool.push_back(g.a); e0->event_pool.push_back(g.b);
+    }
+    f->gen_spans.clear();
+    *n_out = n;
+    return GUBER_OK;
+}
+
+extern "C" void* guber_front_stream(guber_front_t* f) { return f ? (void*)f->rs : nullptr; }
+
+extern "C" int guber_front_stats(guber_front_t* f, guber_front_stats_t* out) {
+    if (!f || !out) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(f->mu);
+    out->generations = f->generations; out->forced_flushes = f->forced_flushes; out->host_waits = f->host_waits;
+    out->host_wait_us = (uint64_t)(f->host_wait_ms * 1e3);
+    return GUBER_OK;
+}

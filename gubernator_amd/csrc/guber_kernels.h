@@ -825,6 +825,7 @@ __global__ __launch_bounds__(256, GUBER_EVAL2_WAVES) void k_eval2_multi_mem(cons
 
 #include "guber_kernels_part.h"
 #include "guber_kernels_route.h"
+#include "guber_kernels_front.h"
 #ifndef GUBER_KERNELS_PIPELINES_ONLY   // (the host emulation of the batch pipelines, tests/hostsim/devsim.cpp, stops here)
 #include "guber_kernels_ops.h"
 #include "guber_kernels_small.h"

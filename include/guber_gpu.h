@@ -293,6 +293,40 @@ int guber_eval_batches_dev(guber_engine_t* e, const guber_batch_t* batches, gube
 int guber_eval_batches_routed_dev(guber_engine_t* const* engines, uint32_t n_engines, const uint32_t* which,
                                   const guber_batch_t* batches, guber_result_t* results, uint32_t count, uint32_t* done);
 
+/* ---- the front of a GPU's logical shards, on the device: WorkerPool.GetRateLimit's choice of the worker (workers.go:261-289,
+ *      getWorker :180-184: XXH64 of the HashKey -> worker) and GetRateLimits' answers in request order (gubernator.go:203-300,
+ *      gubernator.proto:51-54), for requests that already lie in HBM.  guber_eval_batches_routed_dev takes batches somebody has
+ *      split by shard and leaves the answers in the shards' order; a front takes ONE stream of requests in ARRIVAL order:
+ *        gens[k]     a generation: up to max_n requests (what a batcher has collected; all columns DEVICE pointers, no host-computed
+ *                    calendar columns), one now_ms
+ *        on the GPU  XXH64 of every key + the placement's rule (guber_placement_export; NULL with one engine) -> engine; every engine's
+ *                    share contiguous and in arrival order (a key's requests keep their order); the shares run through the engines'
+ *                    pipelines, engines that share a stream sharing launches, generation after generation; the answers return to
+ *                    results[k]'s arrays in arrival order.  The routing runs two generations ahead on a stream of its own, the host
+ *                    reads the shares' sizes from pinned memory and never waits for the GPU in steady state.
+ *      Results are those of evaluating the generation's requests one by one in arrival order (what gubernator.go:203 does).  depth =
+ *      generations in flight (0 = 4).  Asynchronous like guber_eval_batch_dev; guber_front_synchronize waits for the engines' streams
+ *      and the routing stream.  On failure *done counts the generations whose answers are on their way. */
+typedef struct guber_front guber_front_t;
+typedef struct guber_front_stats {
+    uint64_t generations;      /* evaluated */
+    uint64_t forced_flushes;   /* times a slot was needed before its generation's held-back evaluation had been launched */
+    uint64_t host_waits;       /* times the host found a generation's share sizes not yet reported ... */
+    uint64_t host_wait_us;     /* ... and how long it waited in total */
+} guber_front_stats_t;
+int guber_front_create(guber_engine_t* const* engines, uint32_t n_engines, const struct guber_route_rule* rule, uint32_t max_n,
+                       uint32_t depth, guber_front_t** out);
+void guber_front_destroy(guber_front_t* f);
+int guber_front_set_rule(guber_front_t* f, const struct guber_route_rule* rule);   /* after a placement commit (waits for the routing stream) */
+int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens, guber_result_t* results, uint32_t count, uint32_t* done);
+int guber_front_synchronize(guber_front_t* f);
+void* guber_front_stream(guber_front_t* f);                                        /* the routing stream (hipStream_t): the answers' last hop runs on it */
+int guber_front_stats(guber_front_t* f, guber_front_stats_t* out);
+/* With guber_profile_enable on the front's FIRST engine while generations ran: per generation the time from its first routing kernel's
+ * start to the end of its answers' last hop, in microseconds, since the last call (us may be NULL, *n_out = how many there were).
+ * The routing kernels appear in that engine's guber_profile_read as k_fr_count / k_fr_scatter / k_fr_out.  Waits for the routing stream. */
+int guber_front_latencies(guber_front_t* f, float* us, uint32_t cap, uint32_t* n_out);
+
 /* ---- WorkerPool.AddCacheItem (workers.go:537; callers gubernator.go:452 UpdatePeerGlobals,
  *      workers.go:329 Load).  Add semantics = LRUCache.Add (lrucache.go:88): replace if present.
  *      existed[i] (optional) receives Add's return value. */

@@ -197,7 +197,102 @@ def single(flags):
     eng.close()
 
 
+def dev_gen(hb, full):
+    """a generation for guber_front_eval_dev: every column a "device" array (full: burst / created_at / is_owner too)"""
+    n = hb.n
+    cols = dict(key_bytes=np.ascontiguousarray(np.concatenate([hb.key_bytes, np.zeros(16, np.uint8)])), key_off=np.ascontiguousarray(hb.key_off.view(np.int32)),
+                hits=np.ascontiguousarray(hb.hits), limit=np.ascontiguousarray(hb.limit), duration=np.ascontiguousarray(hb.duration),
+                algorithm=np.ascontiguousarray(hb.algorithm), behavior=np.ascontiguousarray(hb.behavior.view(np.int32)),
+                burst=np.ascontiguousarray(hb.burst) if full else None, created_at=np.ascontiguousarray(hb.created_at) if full else None,
+                is_owner=np.ascontiguousarray(hb.is_owner) if full else None)
+    p = {k: (v.ctypes.data if v is not None else None) for k, v in cols.items()}
+    r = dict(status=np.full(n, 99, np.uint8), err=np.full(n, 99, np.uint8), limit=np.full(n, -7, np.int64), remaining=np.full(n, -7, np.int64), reset_time=np.full(n, -7, np.int64))
+    b = ga.GuberBatch(n, 0, p["key_bytes"], p["key_off"], p["hits"], p["limit"], p["duration"], p["burst"] if full else None, p["created_at"] if full else None,
+                      p["algorithm"], p["behavior"], p["is_owner"] if full else None, None, None, hb.now_ms)
+    res = ga.GuberResult(r["status"].ctypes.data, r["limit"].ctypes.data, r["remaining"].ctypes.data, r["reset_time"].ctypes.data, r["err"].ctypes.data, 0, 0, 0, 0, 0)
+    return b, res, cols, r
+
+
+def front(n_engines, n_streams, fuse_ep, max_batch=4096):
+    """guber_front_eval_dev: ONE stream of requests in arrival order over ONE key space -> k_fr_count / k_fr_scatter hand every request to
+    the engine the placement names (hot keys placed individually) -> the engines' shares through the fused launches (shares larger than an
+    engine's max_batch in pieces) -> k_fr_out brings the answers back in arrival order.  Twelve generations in two calls: fixed-width keys
+    (they travel with their requests) and ragged ones (they stay where they are), every request column or only the mandatory ones, an
+    empty generation, a generation of three requests, uniform keys.  Every generation equals ONE oracle fed the generations in order."""
+    K, G = 9000, 8192
+    tab = streams.key_table(K)
+    place = ga.Placement(n_engines)
+    place.observe_keys(*streams.keys_for_ids(tab, streams.ZipfSampler(K, seed=77).draw(1 << 15)))
+    place.rebalance(0.125, True)
+    engs = []                                                       # engines of one stream are neighbours (the dispatcher groups neighbours)
+    for j in range(n_engines):
+        sj = j * n_streams // n_engines
+        first = next((q for q in range(j) if q * n_streams // n_engines == sj), None)
+        engs.append(ga.Engine(cache_size=1 << 16, max_batch=max_batch, stream=None if first is None else engs[first].stream_handle()))
+    for e in engs:
+        e.profile(True)
+    fr = ga.Front(engs, place, max_n=G, depth=4)
+    orc = support.Oracle(cache_size=1 << 20)
+    zs = streams.ZipfSampler(K, seed=31)
+    rng = np.random.default_rng(8)
+    adv = streams.adversarial_batches(44, 6, 3000, greg_fn=support.gregorian)
+    gens = []
+    for g in range(12):
+        now = streams.NOW0 + g * 700
+        if g in (3, 7, 10):
+            hb = next(adv)                                          # ragged keys, every column, every behaviour but host-computed calendars
+            hb.behavior[:] = hb.behavior & ~np.uint32(4)
+            hb.duration[:] = np.where(hb.duration < 8, 50, hb.duration)
+            hb.greg_expire[:] = 0
+            hb.greg_duration[:] = 0
+            gens.append((hb, True))
+            continue
+        n = [G, 5000, 0, G, 3, G, 7777, 6000, G, 1, G, 300][g]
+        ids = rng.integers(0, K, n) if g in (5, 8) else zs.draw(n)
+        hb = streams.bench_batch(tab, ids, now, algorithm=g % 2, limit=30, duration=4000)
+        if n:
+            hb.algorithm[:] = (np.arange(n) // 97 + g) % 2           # both algorithms inside one generation
+        gens.append((hb, False))
+    done = 0
+    for lo, hi in ((0, 5), (5, 12)):
+        part = [dev_gen(hb, full) for hb, full in gens[lo:hi]]
+        N = hi - lo
+        got_done = fr.eval_dev((ga.GuberBatch * N)(*[x[0] for x in part]), (ga.GuberResult * N)(*[x[1] for x in part]), N)
+        fr.synchronize()
+        assert got_done == N, (got_done, N)
+        for k, (hb, full) in enumerate(gens[lo:hi]):
+            want = orc.eval(hb)
+            got = ga.HostResult(hb.n)
+            for name in ("status", "limit", "remaining", "reset_time", "err"):
+                getattr(got, name)[:hb.n] = part[k][3][name]
+            if hb.n:
+                support.assert_results_equal(got, want, f"generation {lo + k}")
+        done += N
+    launches = {}
+    for e in engs:
+        for k, v in e.profile_read().items():
+            launches[k] = launches.get(k, 0) + v[0]
+    print("launches", {k: v for k, v in launches.items() if v}, "front", fr.stats())
+    assert launches.get("k_fr_count", 0) == launches.get("k_fr_scatter", 0) == launches.get("k_fr_out", 0) == launches.get("k_fr_scan", 0) == 11, launches   # (the empty generation launches nothing)
+    if n_engines > 1:
+        assert launches.get("k_own_multi", 0) > 0, launches
+        if fuse_ep and max_batch >= 4096:
+            assert launches.get("k_evalpart_multi", 0) > 0, launches
+    assert fr.stats()["generations"] == 12
+    assert sum(e.size() for e in engs) == orc.size(), ([e.size() for e in engs], orc.size())
+    sizes = [e.size() for e in engs]
+    assert min(sizes) > 0, sizes                                    # every engine holds a part of the key space
+    fr.close()
+    for e in engs:
+        e.close()
+    place.close()
+
+
 CASES = {
+    "front4": lambda: front(4, 1, os.environ.get("GUBER_FUSE_EP") == "1"),
+    "front6x2": lambda: front(6, 2, os.environ.get("GUBER_FUSE_EP") == "1"),
+    "front6x3_pieces": lambda: front(6, 3, os.environ.get("GUBER_FUSE_EP") == "1", max_batch=1024),
+    "front1": lambda: front(1, 1, os.environ.get("GUBER_FUSE_EP") == "1"),
     "routed4": lambda: routed(4, os.environ.get("GUBER_FUSE_EP") == "1"),
     "routed6": lambda: routed(6, os.environ.get("GUBER_FUSE_EP") == "1"),
     "routed_threads": lambda: routed_with_a_second_thread(os.environ.get("GUBER_FUSE_EP") == "1"),

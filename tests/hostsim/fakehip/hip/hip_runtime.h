@@ -89,6 +89,7 @@ static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long 
 static inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { return fh_add(p, v); }
 static inline int atomicAdd(int* p, int v) { return fh_add(p, v); }
 static inline int atomicExch(int* p, int v) { fakehip::maybe_chaos(); auto o = *p; *p = v; return o; }
+static inline unsigned int atomicExch(unsigned int* p, unsigned int v) { fakehip::maybe_chaos(); auto o = *p; *p = v; return o; }
 static inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { fakehip::maybe_chaos(); auto o = *p; *p = o | v; return o; }
 static inline unsigned int atomicOr(unsigned int* p, unsigned int v) { fakehip::maybe_chaos(); auto o = *p; *p = o | v; return o; }
 static inline long long atomicMin(long long* p, long long v) { fakehip::maybe_chaos(); auto o = *p; if (v < o) *p = v; return o; }

@@ -59,6 +59,7 @@ static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuc
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { if (e) e->t_ms = fakehip::now_ms(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 
 // hipLaunchKernelGGL(kernel, grid, block, dynamic LDS, stream, args...): the arguments are converted to the kernel's parameter

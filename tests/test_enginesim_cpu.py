@@ -60,6 +60,16 @@ def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
 
 
 
+@pytest.mark.parametrize("case,fuse_ep", [("front4", "1"), ("front4", "0"), ("front6x2", "1"), ("front6x3_pieces", "1"), ("front1", "1")])
+def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(enginesim, case, fuse_ep):
+    """guber_front_eval_dev (guber_front.h, guber_kernels_front.h): ONE stream of requests in arrival order -> k_fr_count / k_fr_scatter
+    (XXH64 + the placement's rule, workers.go:180-184) -> the engines' shares through the fused launches, on one, two and three streams,
+    shares larger than an engine's max_batch in pieces, the k_eval3 of a generation held back for the next one's k_part (and the event the
+    answers' way home waits for recorded behind whoever launches it) -> k_fr_out: every generation equals ONE oracle fed the generations
+    in order (gubernator.go:203: a serial loop in request order), keys of one width and ragged ones, empty and tiny generations"""
+    run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
+
+
 def test_another_thread_on_tables_whose_evaluation_is_held_back(enginesim):
     """GUBER_FUSE_EP: while one routed call holds k_eval3 launches back, a second thread calls guber_size / guber_get_item on two of its
     tables — it launches what is held back for them before it looks (guber_engine::held), the call's answers stay the oracle's"""
