@@ -97,8 +97,11 @@ def parse():
     ap.add_argument("--duration-ms", type=int, default=60_000, help="RateLimitReq.duration of the stream")
     ap.add_argument("--min-batches", type=int, default=MIN_TIMED_BATCHES, help="lower bound of the timed region in distinct batches (measurement scripts may lower it)")
     ap.add_argument("--min-ms", type=float, default=0.0, help="accepted and ignored (the timed region is a fixed number of distinct batches, never a replay)")
-    ap.add_argument("--gen-batches", type=int, default=8, help="`routed`: batches of --batch requests per generation handed to the device-side front (guber_front_*)")
-    ap.add_argument("--extras", default="routed,leaky,expiring,shards_1,uniform,end_to_end,pool",
+    ap.add_argument("--gen-batches", type=int, default=16, help="routed: batches of --batch requests per generation handed to the device-side front (guber_front_*)")
+    ap.add_argument("--headline", choices=["routed", "presplit"], default="routed",
+                    help="routed (the all-inclusive arrangement): ONE raw request stream in arrival order -> routed to the shards on the device -> answers in request "
+                         "order, inside the clock; presplit: rounds 2-5's headline (per-shard batches split outside the clock, answers left in shard order)")
+    ap.add_argument("--extras", default="presplit,leaky,expiring,shards_1,uniform,end_to_end,pool",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--extra-batches", type=int, default=1024, help="timed distinct batches of the extra configurations")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
@@ -371,6 +374,9 @@ class Rig:
             d_keys[lo * B * L:hi * B * L] = self.d_keytab.index_select(0, d_bids[lo:hi].reshape(-1)).reshape(-1)
         self.d_keys = d_keys
         self.distinct_keys = int(torch.unique(d_bids).numel())
+        # table accesses per decision: a batch touches the table once per DISTINCT key (sampled over 16 batches)
+        samp = list(range(0, total, max(1, total // 16)))[:16]
+        self.access_frac = float(np.mean([int(torch.unique(d_bids[r]).numel()) for r in samp])) / B
         del d_bids
         # every batch reads its OWN request columns (key offsets, hits, limit, duration, behavior, algorithm: 36 B per request with the
         # offset), as it reads its own keys: nothing of a request is served from a cache line an earlier batch left behind
@@ -601,7 +607,7 @@ class RoutedRig(Rig):
         super().__init__(ctx, algo, dist_kind, S, duration_ms=duration_ms)
         self.GB = int(gen_batches)
         self.G = self.GB * ctx.B
-        self.front = self.ga.Front(self.engines, self.place, max_n=self.G, depth=4)
+        self.front = self.ga.Front(self.engines, self.place, max_n=self.G, depth=int(os.environ.get("GUBER_BENCH_FRONT_DEPTH", "8")))
 
     def gen_now(self, g, now0):
         return now0 + 1 + g * self.GB                               # (the clock advances 1 ms per batch of B on average)
@@ -627,6 +633,8 @@ class RoutedRig(Rig):
             d_keys[lo * B * L:hi * B * L] = self.d_keytab.index_select(0, d_ids[lo * B:hi * B]).reshape(-1)
         self.d_keys = d_keys
         self.distinct_keys = int(torch.unique(d_ids).numel())
+        samp = list(range(0, ngen, max(1, ngen // 16)))[:16]            # (a generation touches the tables once per distinct key: its shares have disjoint keys)
+        self.access_frac = float(np.mean([int(torch.unique(d_ids[g * G:(g + 1) * G]).numel()) for g in samp])) / G
         del d_ids
         t_offG = torch.from_numpy((np.arange(G + 1, dtype=np.int64) * L).astype(np.int32)).to(dev)
         self.cols = {"off": t_offG.repeat(ngen), "hits": torch.full((n,), 1, dtype=torch.int64, device=dev),
@@ -778,6 +786,38 @@ def parity_over_timed_work(rig, orc, threads, now0, label):
     return ok, compared, el
 
 
+def measure_ceilings(keys):
+    """what THIS box sustains, measured before anything else is on the GPU (tools/random_access quick, about a second): independent random
+    accesses of the engine's shape (128-byte bucket read, its 64-byte record written back) over a table of the tables' size, and a streaming copy"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "random_access")
+    if not os.path.exists(exe):
+        return None
+    try:
+        gb = max(0.25, 4.5 * keys / 10_000_000)                      # 2^25 slots x 144 B for 10 M keys (DESIGN.md section 3)
+        p = subprocess.run([exe, "quick", f"{gb:.2f}"], capture_output=True, text=True, timeout=120)
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def against_ceilings(ceil, value, access_frac, bytes_per_decision):
+    """a rate next to the box's measured ceilings: the table accesses it implies (one per distinct key of a batch) over the measured rate of
+    independent random bucket accesses, and its algorithmic bytes over the measured streaming copy"""
+    if not ceil or "error" in ceil or not value:
+        return None
+    acc = value * access_frac
+    return {"table_accesses_per_decision": round(access_frac, 4), "table_accesses_per_s": round(acc, 1),
+            "random_r128_w64_ceiling_per_s": round(ceil["random_r128_w64_Gbuckets_s"] * 1e9, 1),
+            "frac_of_measured_random_rw": round(acc / (ceil["random_r128_w64_Gbuckets_s"] * 1e9), 4),
+            "stream_copy_ceiling_GBps": ceil["stream_copy_GBps"],
+            "frac_of_measured_stream": round(value * bytes_per_decision / 1e9 / ceil["stream_copy_GBps"], 4),
+            "table_gb": ceil["table_gb"],
+            "what": ("measured on this box at the start of this run (tools/random_access quick): INDEPENDENT random accesses of a 128-byte bucket read + its 64-byte record "
+                     "written back over a table of the tables' size — what the table phase could do if nothing depended on anything — and a streaming copy (read + write) in "
+                     "place of the 8 TB/s spec figure")}
+
+
 def usable_cpus():
     """CPUs this process may really use: the affinity mask, capped by a cgroup CPU quota (cpu.max)"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -906,8 +946,12 @@ def main():
 
     S = max(1, args.shards)
     seed = 1234 + rank * 64
-    steps = max(args.steps, args.min_batches)
-    rig = Rig(ctx, args.algo, args.dist, S, duration_ms=args.duration_ms)
+    ctx.ceil = measure_ceilings(K) if (rank == 0 and world == 1) else None
+    routed = args.headline == "routed"
+    GB = max(1, args.gen_batches) if routed else 1
+    up = lambda v: -(-int(v) // GB) * GB                              # noqa: E731  (whole generations)
+    steps = up(max(args.steps, args.min_batches))
+    rig = RoutedRig(ctx, args.algo, args.dist, S, GB, duration_ms=args.duration_ms) if routed else Rig(ctx, args.algo, args.dist, S, duration_ms=args.duration_ms)
     resident = rig.populate(NOW0)
     # what every rank holds, and how many ranks the collective backend (nccl = RCCL for N > 1) really sees
     resident_by_rank = shard.gather_over_ranks(resident, device=red_dev)
@@ -915,8 +959,8 @@ def main():
     # --warmup W is honoured as a LOWER bound: the driver's command passes 5, and five batches do not reach every one of the S shards
     # (nor every stream with every kernel) before the clock starts — the first process on a fresh box then pays first-use costs inside
     # the timed region (measured: 9.4-9.6 instead of 10.0-10.2 G/s, profiles/r05_t_*).  At least four batches per shard run untimed.
-    warm = max(args.warmup, 4 * S)
-    m = rig.measure(steps, warm, NOW0, seed, profile_steps=max(0, args.profile_steps), latency_steps=max(0, args.latency_steps))
+    warm = up(max(args.warmup, 4 * S))
+    m = rig.measure(steps, warm, NOW0, seed, profile_steps=up(max(0, args.profile_steps)), latency_steps=up(max(0, args.latency_steps)))
 
     roofline = latency = cpu = parity = None
     extras = {}
@@ -959,6 +1003,7 @@ def main():
             roofline = {"bound": "hbm", "achieved": round(pipe, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(pipe / HBM_PEAK_GBPS, 6),
                         "what": (f"{BYTES_PER_DECISION[args.algo]} algorithmic B per decision (SURVEY 8d) x {B} decisions per step / ms_per_step: every kernel of "
                                  "the pipeline, all shards overlapping, as the driver's clock sees it"),
+                        "measured": against_ceilings(ctx.ceil, m["value"], rig.access_frac, BYTES_PER_DECISION[args.algo]),
                         "traffic": traffic, "traffic_note": measured,
                         "issue": issue,
                         "limiter": ("instruction issue, not HBM bytes: the pipeline without any table access is not faster and fewer fabric transactions barely moved it "
@@ -1045,13 +1090,23 @@ def main():
                "by_threads": {str(w): {"value": round(v[0], 1), "batches": v[1], "seconds": round(v[2], 2)} for w, v in sorted(res.items())}}
 
     touched = m["distinct_keys_in_stream"]
-    headline_cfg = {"workload": f"{K} resident keys per GPU, one {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") +
-                                f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration={args.duration_ms}ms, {world}xMI355X"
-                                + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
-                                + ((f", {S} logical shards per GPU (own table each; the stream is split key by key by the placement, a shard flushes a batch "
-                                    f"when {B} requests are waiting), " +
-                                    ("own stream + batcher thread each" if args.dispatch == "threads" else
-                                     f"one dispatcher, shards spread over {args.streams} stream(s): the next batch of up to four shards of a stream per pair of launches")) if S > 1 else ", one table"),
+    if routed:
+        wl = (f"{K} resident keys per GPU, ONE {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") + f" over them in ARRIVAL order, never split on the host, "
+              f"batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration={args.duration_ms}ms, {world}xMI355X"
+              + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
+              + f"; generations of {GB} batches (what a batcher has collected while the previous generation ran, peer_client.go:284-337; one now_ms each) go through "
+                f"guber_front_eval_dev, everything inside the clock: XXH64 of every HashKey + the placement's rule -> one of {S} logical shards (workers.go:261-289, getWorker "
+                f":180-184), shares contiguous and in arrival order, the {S} tables through the fused launches on {args.streams} streams, answers back in REQUEST order "
+                f"(gubernator.proto:51-54)")
+    else:
+        wl = (f"{K} resident keys per GPU, one {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") +
+              f" over them, batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration={args.duration_ms}ms, {world}xMI355X"
+              + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
+              + ((f", {S} logical shards per GPU (own table each; the stream is split key by key by the placement OUTSIDE the clock, a shard flushes a batch "
+                  f"when {B} requests are waiting; answers stay in the shards' order), " +
+                  ("own stream + batcher thread each" if args.dispatch == "threads" else
+                   f"one dispatcher, shards spread over {args.streams} stream(s): the next batch of up to four shards of a stream per pair of launches")) if S > 1 else ", one table"))
+    headline_cfg = {"workload": wl, "arrangement": args.headline, "generation_requests": (GB * B) if routed else None,
                     "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
                     "resident_items_by_rank": resident_by_rank, "ranks_seen_by_the_collective_backend": ranks_seen, "backend": args.backend if world > 1 else None,
                     "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
@@ -1059,9 +1114,13 @@ def main():
                     "engine_env": {k: os.environ[k] for k in ("GUBER_FUSE_EP", "GUBER_PIPELINE", "GUBER_PT_BITS", "GUBER_HIP_LIB") if k in os.environ},
                     "stream": {"replayed": False, "distinct_batches_total": len(rig.seq), "timed_batches": steps,
                                "distinct_keys_touched": touched, "table_bytes_touched": touched * 144, "table_bytes_touched_in_64B_sectors": touched * 192,
-                               "now_ms": "advances 1 ms per batch",
-                               "routing": "per-request routing to the shards is outside the clock (the front end's work: see `pool`); `shards_1` needs none"}}
+                               "now_ms": "advances 1 ms per batch" if not routed else f"one per generation, advancing {GB} ms per generation",
+                               "routing": ("per request ON THE DEVICE, inside the clock (guber_front_*): hash, placement, shares, answers back in request order" if routed else
+                                           "per-request routing to the shards is outside the clock (the front end's work: see `pool`); `shards_1` needs none")}}
+    front_stats = None
     rig.close()
+    if routed:
+        front_stats = rig.front_stats
     del rig
     torch.cuda.empty_cache()
 
@@ -1090,7 +1149,10 @@ def main():
                                       if steps != args.steps else "every timed batch is a distinct part of the stream"),
                              "ms_per_step_hip_events": round(m["ms_per_step_events"], 5), "host_enqueue_ms": round(m["enqueue_ms"], 3), "host_enqueue_busy_ms": round(m["enqueue_busy_ms"], 3),
                              "host_enqueue_note": "wall time of the ONE dispatcher call that enqueues the whole timed region, and the CPU time its thread burnt in it (busy << wall: it waits for queue room, the GPU is the bound; busy ~ wall: the host is)",
-                             "enqueue": ("caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
+                             "front": front_stats,
+                             "enqueue": ("ONE guber_front_eval_dev call for the whole timed region: routing launches ahead of the evaluation, the shares' sizes read from pinned memory, "
+                                         f"one dispatcher for {S} shards over {args.streams} stream(s)") if routed else (
+                                         "caller thread" if S == 1 else f"{S} pre-started batcher threads behind a barrier" if args.dispatch == "threads"
                                          else f"one dispatcher for {S} shards over {args.streams} stream(s) (guber_eval_batches_routed_dev: batches of shards that share a stream share launches)"),
                              "shard_streams": m["shard_streams"]},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "parity_batches_by_rank": parity_by_rank, "batch_latency": latency,
@@ -1116,12 +1178,13 @@ def run_extra(name, args, ctx, NOW0, seed):
     if name == "pool":
         return run_pool(args)
     algo, dist_kind, S, dur = {"leaky": ("leaky", "zipf", max(1, args.shards), 60_000), "shards_1": (args.algo, args.dist, 1, args.duration_ms),
+                               "presplit": (args.algo, args.dist, max(1, args.shards), args.duration_ms),
                                "uniform": (args.algo, "uniform", max(1, args.shards), args.duration_ms),
                                "expiring": (args.algo, "zipf", max(1, args.shards), 500)}[name]
     rig = Rig(ctx, algo, dist_kind, S, duration_ms=dur)
     rig.populate(NOW0)
-    prof = 64 if name in ("leaky", "shards_1") else 0
-    lat = 64 if name in ("leaky", "shards_1") else 0
+    prof = 64 if name in ("leaky", "shards_1", "presplit") else 0
+    lat = 64 if name in ("leaky", "shards_1", "presplit") else 0
     warmup = max(warmup, 4 * S)
     m = rig.measure(steps, warmup, NOW0, seed, profile_steps=prof, latency_steps=lat)
     out = {"value": round(m["value"], 1), "unit": "decisions/s", "ms_per_step": round(m["ms_per_step"], 5), "timed_batches": steps, "replays": 0,
@@ -1133,7 +1196,11 @@ def run_extra(name, args, ctx, NOW0, seed):
         kb = KERNEL_BYTES[algo]
         out["roofline_frac"] = {k: round(kb[k] * per_launch.get(k, B) / (v * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5) for k, v in km.items() if v > 0 and k in kb}
         out["batch_latency"] = {"idle": rig.latency(), "under_load": rig.latency_under_load()}
-    if name in ("leaky", "expiring") and not args.no_cpu_baseline:
+    out["measured"] = against_ceilings(getattr(ctx, "ceil", None), m["value"], rig.access_frac, BYTES_PER_DECISION[algo])
+    if name == "presplit":
+        out["excludes"] = ("the per-request routing to the shards (the stream is split by the placement before the clock starts) and the answers' way back into request "
+                           "order (they stay in the shards' order): rounds 2-5's headline, kept as the kernel pipelines' own rate; the line's `value` includes both")
+    if not args.no_cpu_baseline:                                    # every printed number is gated on ITS OWN timed work
         w = min(os.cpu_count() or 1, 32)
         orc = support.Oracle(cache_size=4 * K, workers=w)
         ok, compared, _ = parity_over_timed_work(rig, orc, min(w, usable_cpus()) if w > 1 else 0, NOW0, name)
@@ -1213,6 +1280,7 @@ def run_pool(args):
     for label, (T, S, items, keys, secs) in cases.items():
         p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs)], capture_output=True, text=True, timeout=300)
         mm = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)(?:, rpc latency p50 ([0-9.]+) us p99 ([0-9.]+) us)?", p.stdout)
+        cons = re.search(r"conservation: (\d+) keys (\d+) decisions (\d+) violations", p.stdout)
         if not mm:
             out[label] = {"error": (p.stdout + p.stderr)[-400:]}
             continue
@@ -1220,6 +1288,14 @@ def run_pool(args):
                       "errors": int(mm.group(4)), "caller_threads": T, "shards": S, "items_per_rpc": items, "keys": keys}
         if mm.group(5):
             out[label]["rpc_latency_us"] = {"p50": float(mm.group(5)), "p99": float(mm.group(6))}
+        # the gate of a number whose callers run concurrently (no serial order to replay): per-key conservation over every answer the pool gave
+        if cons and int(cons.group(3)) == 0 and int(mm.group(4)) == 0:
+            out[label]["parity"] = (f"per-key conservation over all {int(cons.group(2))} decisions on {int(cons.group(1))} keys since the pool's creation: admitted <= limit, the admitted "
+                                    "hits' `remaining` are exactly {limit-1 .. limit-admitted} (count and sum), refused => remaining 0 and the window's tokens gone, limit echoed, "
+                                    "no item error: 0 violations (tools/bench_pool.cpp)")
+        else:
+            out[label]["parity"] = "FAILED" if cons else "not checked"
+            out[label].pop("value", None)
     head = out.get("rpc_1000", {})
     res = {"value": head.get("value"), "unit": "decisions/s"}
     res.update(out)
@@ -1283,16 +1359,36 @@ def run_end_to_end(args, ctx, NOW0, seed):
         return ss
     few = make(depth + 1)
     with_fill = pump(few, NB, [rig.host_batch(i) for i in range(NB)])          # also warms the path up
+    got = {}                                                         # batch -> digest of the answers as they lie in the stage's HOST arrays
+    for j in range(NB - (depth + 1), NB):                            # (the stages of this run are refilled under the clock: the last answers are still there)
+        got[j] = host_digest(few[j % (depth + 1)].result())
     for st in few:
         st.close()
     many = make(NP)
     for k, st in enumerate(many):
         st.fill(rig.host_batch(NB + k))
     best = pump(many, NP, None)
+    for k, st in enumerate(many):                                    # every batch of the headline run keeps its stage: all of them are checked
+        got[NB + k] = host_digest(st.result())
     for st in many:
         st.close()
+    parity = None
+    if not args.no_cpu_baseline:
+        import support
+        w = min(os.cpu_count() or 1, 32)
+        th = min(w, usable_cpus()) if w > 1 else 0
+        orc = support.Oracle(cache_size=4 * K, workers=w)
+        oracle_populate(rig, orc, th, NOW0)
+        bad = [s for s in range(NB + NP) if (lambda want: s in got and host_digest(want) != got[s])(orc.eval(rig.host_batch(s), threads=th))]
+        orc.close()
+        parity = (f"bit-exact vs the oracle fed the whole sequence (populate, the {NB} batches of `with_host_fill`, the {NP} of the headline run, in order): {len(got)} batches by "
+                  f"digest of the stages' HOST result arrays — all {NP} of the headline run, the last {depth + 1} of `with_host_fill` (its stages are refilled under the clock)"
+                  if not bad else "FAILED")
+        if bad:
+            print(f"PARITY FAILURE: end_to_end batches {bad[:8]}", file=sys.stderr)
+            best["value"] = None
     rig.close()
-    return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NP, "replays": 0,
+    return {"value": best["value"], "unit": "decisions/s", "ms_per_step": best["ms_per_step"], "steps": NP, "replays": 0, "parity": parity,
             "latency_us": best["latency_us"], "pcie_GBps": best["pcie_GBps"], "host_us_per_batch": best["host_us_per_batch"],
             "with_host_fill": with_fill,
             "workload": f"{K} keys, {args.dist}, {args.algo.upper()}_BUCKET, batch {B}, one table, guber_stage_submit / guber_stage_wait from one host thread: request "

@@ -7,8 +7,9 @@
 // takes batches that somebody has already split by shard and leaves the answers in the shards' order; this is the whole of it.
 //
 // One generation g (slot = g mod depth):
-//   routing stream   k_fr_count(g)  k_fr_scan(g)  k_fr_scatter(g)  [event in(g)]                                   ... k_fr_out(g)
-//   engine streams                                    wait in(g) | the shares as batches of the fused pipelines | [event done(g, s)]
+//   routing stream g mod 2   k_fr_count(g)  k_fr_scan(g)  k_fr_scatter(g)  [event in(g)]
+//   engine streams                                             wait in(g) | the shares as batches of the fused pipelines | [event done(g, s)]
+//   answers' stream                                                                                              wait done(g, *) | k_fr_out(g) [event out(g)]
 // The routing runs ahead of the evaluation (two generations), so the shares' sizes — which the host needs to size the launches and to
 // keep the bounded caches' admission exact — are in pinned memory by the time the host asks: it never waits for the GPU in steady state.
 #pragma once
@@ -19,7 +20,10 @@ struct guber_front {
     std::vector<guber_engine*> eng;
     std::vector<hipStream_t> streams;                 // the engines' distinct streams
     std::vector<int> stream_of;                       // engine -> index into streams
-    hipStream_t rs = nullptr;                         // the routing stream (k_fr_count, k_fr_scatter, k_fr_out)
+    // Two routing streams, generations alternating (k_fr_count, k_fr_scan, k_fr_scatter: four dependent trips each, one round of
+    // workgroups — latency, not work: one stream carried 60 of a generation's 95 us and the host waited for it), and one for the answers'
+    // way home (k_fr_out).  rs = routing stream of even generations (and of rule uploads)
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr; int n_own_streams = 1;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -27,7 +31,7 @@ struct guber_front {
         DevBuf<uint8_t> mem; CohBuf<FrontHost> host;
         FrIn in{}; FrOut out{};
         uint8_t *o_status = nullptr, *o_err = nullptr; int64_t *o_limit = nullptr, *o_remaining = nullptr, *o_reset = nullptr;
-        hipEvent_t ev_in = nullptr, ev_a = nullptr;
+        hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_a = nullptr; bool out_recorded = false;
         std::vector<std::unique_ptr<EvalHook>> hooks;   // one per engine stream
         uint32_t seq = 0, n = 0;
         int64_t gen = -1;                               // the generation the slot holds (-1: free)
@@ -46,14 +50,17 @@ static size_t front_col(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
 extern "C" void guber_front_destroy(guber_front_t* f) {
     if (!f) return;
     (void)hipSetDevice(f->device);
-    if (f->rs) { (void)hipStreamSynchronize(f->rs); }
+    for (hipStream_t st : {f->rs, f->rs2, f->os}) if (st) (void)hipStreamSynchronize(st);
     for (auto st : f->streams) (void)hipStreamSynchronize(st);
     for (auto& s : f->slots) {
         s.mem.release(); s.host.release();
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
+        if (s.ev_out) (void)hipEventDestroy(s.ev_out);
         for (auto& h : s.hooks) if (h && h->ev) (void)hipEventDestroy(h->ev);
     }
     f->rt_table.release(); f->rt_exs.release(); f->rt_exh.release();
+    if (f->rs2 && f->rs2 != f->rs) (void)hipStreamDestroy(f->rs2);
+    if (f->os && f->os != f->rs) (void)hipStreamDestroy(f->os);
     if (f->rs) (void)hipStreamDestroy(f->rs);
     delete f;
 }
@@ -65,6 +72,7 @@ static int front_set_rule(guber_front* f, const guber_route_rule_t* rule) {
     const size_t slots = (size_t)rule->n_shards * rule->per, cells = rule->ex_cells ? rule->ex_cells : 1;
     if (f->rt_table.ensure(slots) || f->rt_exh.ensure(cells) || f->rt_exs.ensure(cells)) return GUBER_E_NOMEM;
     hipError_t he = hipStreamSynchronize(f->rs);                     // (launches still reading the previous rule)
+    if (he == hipSuccess && f->rs2) he = hipStreamSynchronize(f->rs2);
     if (he == hipSuccess) he = hipMemcpy(f->rt_table.p, rule->table, slots * 2, hipMemcpyHostToDevice);
     if (he == hipSuccess && rule->ex_n) he = hipMemcpy(f->rt_exh.p, rule->ex_hash, cells * 8, hipMemcpyHostToDevice);
     if (he == hipSuccess && rule->ex_n) he = hipMemcpy(f->rt_exs.p, rule->ex_shard, cells * 2, hipMemcpyHostToDevice);
@@ -98,6 +106,13 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     f->device = engines[0]->device; f->cap = max_n; f->depth = depth;
     if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
     HIPCHK(hipStreamCreateWithFlags(&f->rs, hipStreamNonBlocking));
+    f->n_own_streams = 1;
+#ifdef GUBER_LAB
+    if (const char* v = getenv("GUBER_FRONT_STREAMS")) f->n_own_streams = std::max(1, std::min(3, atoi(v)));
+#endif
+    f->rs2 = f->os = f->rs;
+    if (f->n_own_streams >= 2) HIPCHK(hipStreamCreateWithFlags(&f->os, hipStreamNonBlocking));
+    if (f->n_own_streams >= 3) HIPCHK(hipStreamCreateWithFlags(&f->rs2, hipStreamNonBlocking));
     if (rule) { const int rc = front_set_rule(f.get(), rule); if (rc) return rc; }
     else f->rule = RouteRule{1, 1, 0, 0, -1, 0, 0, 0, nullptr, nullptr, nullptr};      // one engine: everything is its share
     const size_t cap = max_n, tiles = (cap + 255) / 256;
@@ -127,6 +142,7 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
         HIPCHK(hipMemsetAsync(A.ctl, 0, sizeof(FrontCtl), f->rs));
         HIPCHK(hipMemsetAsync(A.d_keys, 0, front_col(cap * FR_KEY_COPY_MAX + 64), f->rs));   // (the kernels read keys as 8-byte words: the bytes behind the last key are defined)
         HIPCHK(hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
         for (size_t q = 0; q < f->streams.size(); ++q) {
             s.hooks.emplace_back(new EvalHook());
             HIPCHK(hipEventCreateWithFlags(&s.hooks.back()->ev, hipEventDisableTiming));
@@ -145,8 +161,11 @@ extern "C" int guber_front_set_rule(guber_front_t* f, const guber_route_rule_t* 
     return front_set_rule(f, rule);
 }
 
-// k_fr_count, k_fr_scan and k_fr_scatter of generation g on the routing stream
+// k_fr_count, k_fr_scan and k_fr_scatter of generation g on its routing stream
 static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t* b, int64_t gen) {
+    hipStream_t rs = (gen & 1) ? f->rs2 : f->rs;
+    // the slot's previous generation has left it: its answers' way home read what this routing writes
+    if (s.out_recorded) { if (rs != f->os) HIPCHK(hipStreamWaitEvent(rs, s.ev_out, 0)); s.out_recorded = false; }
     s.gen = gen; s.n = b->n; s.routed = true; s.dispatched = false; s.out_done = false;
     s.seq = ++f->seq ? f->seq : ++f->seq;
     for (auto& h : s.hooks) { h->outstanding.store(1); h->recorded.store(false); }      // (1: the dispatcher's own hold until the generation's groups are out)
@@ -161,18 +180,18 @@ static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t
     std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);       // (the per-kernel timing's spans and events belong to the first engine)
     if (e0->profiling) pl.lock();
     s.ev_a = nullptr;
-    if (e0->profiling) { s.ev_a = e0->get_event(); (void)hipEventRecord(s.ev_a, f->rs); }
-    e0->span_begin(KT_FR_COUNT, b->n, f->rs);
-    hipLaunchKernelGGL(k_fr_count, dim3(tiles), dim3(256), 0, f->rs, A);
+    if (e0->profiling) { s.ev_a = e0->get_event(); (void)hipEventRecord(s.ev_a, rs); }
+    e0->span_begin(KT_FR_COUNT, b->n, rs);
+    hipLaunchKernelGGL(k_fr_count, dim3(tiles), dim3(256), 0, rs, A);
     e0->span_end();
-    e0->span_begin(KT_FR_SCAN, b->n, f->rs);
-    hipLaunchKernelGGL(k_fr_scan, dim3(MULTI_MEM_MAX / 4), dim3(FR_SCAN_T), 0, f->rs, A, tiles, (tiles + FR_SCAN_T - 1) / FR_SCAN_T);
+    e0->span_begin(KT_FR_SCAN, b->n, rs);
+    hipLaunchKernelGGL(k_fr_scan, dim3(MULTI_MEM_MAX / 4), dim3(FR_SCAN_T), 0, rs, A, tiles, (tiles + FR_SCAN_T - 1) / FR_SCAN_T);
     e0->span_end();
-    e0->span_begin(KT_FR_SCATTER, b->n, f->rs);
-    hipLaunchKernelGGL(k_fr_scatter, dim3(tiles), dim3(256), 0, f->rs, A);
+    e0->span_begin(KT_FR_SCATTER, b->n, rs);
+    hipLaunchKernelGGL(k_fr_scatter, dim3(tiles), dim3(256), 0, rs, A);
     e0->span_end();
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
-    HIPCHK(hipEventRecord(s.ev_in, f->rs));
+    HIPCHK(hipEventRecord(s.ev_in, rs));
     return 0;
 }
 
@@ -180,7 +199,7 @@ static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t
 static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     s.out_done = true;
     if (s.n == 0) return 0;
-    for (auto& h : s.hooks) HIPCHK(hipStreamWaitEvent(f->rs, h->ev, 0));
+    for (auto& h : s.hooks) HIPCHK(hipStreamWaitEvent(f->os, h->ev, 0));
     FrOut O{};
     O.n = s.n; O.fwd = s.in.d_fwd;
     O.d_status = s.o_status; O.d_err = s.o_err; O.d_limit = s.o_limit; O.d_remaining = s.o_remaining; O.d_reset_time = s.o_reset;
@@ -188,11 +207,12 @@ static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     guber_engine* e0 = f->eng[0];
     std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);
     if (e0->profiling) pl.lock();
-    e0->span_begin(KT_FR_OUT, s.n, f->rs);
-    hipLaunchKernelGGL(k_fr_out, dim3((s.n + 255u) / 256u), dim3(256), 0, f->rs, O);
+    e0->span_begin(KT_FR_OUT, s.n, f->os);
+    hipLaunchKernelGGL(k_fr_out, dim3((s.n + 255u) / 256u), dim3(256), 0, f->os, O);
     e0->span_end();
-    if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, f->rs); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }
+    if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, f->os); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    if (f->n_own_streams > 1) { HIPCHK(hipEventRecord(s.ev_out, f->os)); s.out_recorded = true; }
     return 0;
 }
 
@@ -225,6 +245,8 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
     struct Dispatching { bool on; Dispatching(bool o) : on(o) { if (on) ++tl_ep_dispatcher; } ~Dispatching() { if (on) --tl_ep_dispatcher; } } dispatching(any_ep);
     uint32_t next_route = 0, next_out = 0, enq = 0;
     int rc = 0;
+    uint64_t fp[4] = {0, 0, 0, 0};                                  // GUBER_DISPATCH_PROFILE: ns spent enqueueing the routing, waiting for the shares' sizes, dispatching, on the answers
+    struct FpSpan { uint64_t* a; uint64_t t0; explicit FpSpan(uint64_t* x) : a(x), t0(dp_now()) {} ~FpSpan() { if (g_dprof) *a += dp_now() - t0; } };
     auto slot_of = [&](uint32_t k) -> guber_front::Slot& { return f->slots[k % D]; };
     // the answers of every generation whose evaluations have all been launched go home, oldest first
     auto drain_outs = [&](uint32_t upto, bool force) -> int {
@@ -251,7 +273,7 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
         // the routing runs ahead; a slot is routed into again only after its previous generation's answers have left it
         while (next_route < count && next_route <= k + ahead && !rc) {
             if (next_route >= D) { rc = drain_outs(next_route - D + 1, true); if (rc) break; }
-            rc = front_route(f, slot_of(next_route), &gens[next_route], (int64_t)f->generations + next_route);
+            { FpSpan sp(&fp[0]); rc = front_route(f, slot_of(next_route), &gens[next_route], (int64_t)f->generations + next_route); }
             ++next_route;
         }
         if (rc) break;
@@ -265,13 +287,14 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
                 return true;
             };
             if (!reported()) {
+                FpSpan sp(&fp[1]);
                 const auto t0 = std::chrono::steady_clock::now();
                 f->host_waits++;
                 uint32_t spins = 0;
                 while (!reported()) {
                     if (++spins > 2000) {
                         std::this_thread::yield();
-                        if ((spins & 0x3ffu) == 0 && hipStreamQuery(f->rs) != hipErrorNotReady && !reported()) {
+                        if ((spins & 0x3ffu) == 0 && hipStreamQuery((s.gen & 1) ? f->rs2 : f->rs) != hipErrorNotReady && !reported()) {
                             rc = fail(GUBER_E_HIP, "guber_front: the routing of a generation did not report"); break;
                         }
                     }
@@ -291,7 +314,12 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
                 const uint32_t nj = counts[j];
                 total += nj;
                 guber_engine* e = f->eng[j];
-                const uint32_t piece = std::max<uint32_t>(1u, std::min<uint32_t>(e->fast_cap ? e->fast_cap : e->max_batch, e->max_batch));
+                // a share larger than the engine's pipelines take goes in pieces of EQUAL size (whole tiles): the rounds of a generation then
+                // carry the same load (65 536 + a rest would make the second round a third of the first)
+                const uint32_t cap_e = std::max<uint32_t>(1u, std::min<uint32_t>(e->fast_cap ? e->fast_cap : e->max_batch, e->max_batch));
+                const uint32_t np = (nj + cap_e - 1) / cap_e;
+                uint32_t piece = np > 1 ? ((nj + np - 1) / np + 255u) & ~255u : cap_e;
+                if (piece > cap_e) piece = cap_e;
                 for (uint32_t pos = 0; pos < nj; pos += piece) {
                     const uint32_t len = std::min(piece, nj - pos), d0 = base + pos;
                     const FrIn& A = s.in;
@@ -304,12 +332,12 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
                 base += nj;
             }
             if (total != s.n) { rc = fail(GUBER_E_HIP, "guber_front: the shares do not add up to the generation"); break; }
-            rc = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data());
+            { FpSpan sp(&fp[2]); rc = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data()); }
         }
         s.dispatched = true;
         for (auto& h : s.hooks) h->launched();                      // the dispatcher's hold: the event is recorded once nothing of the generation is held back
         if (rc) break;
-        rc = drain_outs(k + 1, false);
+        { FpSpan sp(&fp[3]); rc = drain_outs(k + 1, false); }
     }
     // (what was routed or enqueued is completed, also after an error: its evaluations go now, its answers go home)
     {
@@ -323,6 +351,14 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
         if (!rc) rc = rco;
     }
     f->generations += next_out;
+    if (g_dprof && next_out) {
+        fprintf(stderr, "[front] %u generations; per generation: routing enqueue %.2f us, waiting for the shares' sizes %.2f, dispatch %.2f, answers %.2f\n", next_out,
+                fp[0] / 1e3 / next_out, fp[1] / 1e3 / next_out, fp[2] / 1e3 / next_out, fp[3] / 1e3 / next_out);
+        if (tl_dp[6]) fprintf(stderr, "[front dispatch] %llu batches in %llu groups; per batch: wait-for-progress %.2f us, locks %.2f, preludes+plans %.2f, argument blocks %.2f, launches %.2f\n",
+                (unsigned long long)tl_dp[6], (unsigned long long)tl_dp[5], tl_dp[0] / 1e3 / tl_dp[6], tl_dp[1] / 1e3 / tl_dp[6], tl_dp[2] / 1e3 / tl_dp[6],
+                tl_dp[3] / 1e3 / tl_dp[6], tl_dp[4] / 1e3 / tl_dp[6]);
+        for (auto& v : tl_dp) v = 0;
+    }
     return rc;
 }
 
@@ -331,7 +367,7 @@ extern "C" int guber_front_synchronize(guber_front_t* f) {
     std::lock_guard<std::mutex> lk(f->mu);
     if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
     for (auto st : f->streams) HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipStreamSynchronize(f->rs));
+    for (hipStream_t st : {f->rs, f->rs2, f->os}) HIPCHK(hipStreamSynchronize(st));
     return GUBER_OK;
 }
 
@@ -341,7 +377,7 @@ extern "C" int guber_front_latencies(guber_front_t* f, float* us, uint32_t cap, 
     if (!f || !n_out) return fail(GUBER_E_INVALID_ARG, "null argument");
     std::lock_guard<std::mutex> lk(f->mu);
     if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
-    HIPCHK(hipStreamSynchronize(f->rs));
+    HIPCHK(hipStreamSynchronize(f->os));
     uint32_t n = 0;
     guber_engine* e0 = f->eng[0];
     std::lock_guard<std::mutex> lk2(e0->mu);
@@ -356,7 +392,7 @@ extern "C" int guber_front_latencies(guber_front_t* f, float* us, uint32_t cap, 
     return GUBER_OK;
 }
 
-extern "C" void* guber_front_stream(guber_front_t* f) { return f ? (void*)f->rs : nullptr; }
+extern "C" void* guber_front_stream(guber_front_t* f) { return f ? (void*)f->os : nullptr; }
 
 extern "C" int guber_front_stats(guber_front_t* f, guber_front_stats_t* out) {
     if (!f || !out) return fail(GUBER_E_INVALID_ARG, "null argument");

@@ -274,7 +274,7 @@ def front(n_engines, n_streams, fuse_ep, max_batch=4096):
             launches[k] = launches.get(k, 0) + v[0]
     print("launches", {k: v for k, v in launches.items() if v}, "front", fr.stats())
     assert launches.get("k_fr_count", 0) == launches.get("k_fr_scatter", 0) == launches.get("k_fr_out", 0) == launches.get("k_fr_scan", 0) == 11, launches   # (the empty generation launches nothing)
-    if n_engines > 1:
+    if n_engines > 1 and max_batch >= 4096:
         assert launches.get("k_own_multi", 0) > 0, launches
         if fuse_ep and max_batch >= 4096:
             assert launches.get("k_evalpart_multi", 0) > 0, launches

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 template <int CHUNKS, bool WRITE>   // CHUNKS x 64 bytes read per bucket
@@ -57,7 +59,51 @@ static void run(uint4* d, size_t bytes, uint32_t bucket_bytes, uint32_t* out) {
     hipEventDestroy(a); hipEventDestroy(b);
 }
 
-int main() {
+// what a streaming copy sustains (read + write, 16 bytes per thread and step): the measured counterpart of the 8 TB/s spec figure
+__global__ __launch_bounds__(256) void stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) dst[i] = src[i];
+}
+// `random_access quick <table GB>`: ONE table size, the engine's access shape (a 128-byte bucket read, its 64-byte record written back) and
+// the 64-byte read + write, plus the streaming copy — one JSON line for bench.py's roofline.measured (about a second)
+static double run_quiet(int chunks, uint4* d, size_t bytes, uint32_t bucket_bytes, uint32_t* out) {
+    const unsigned long long n_buckets = bytes / bucket_bytes;
+    const uint32_t wgs = 256 * 16, rounds = 8;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    auto launch = [&](uint32_t seed) {
+        if (chunks == 1) hipLaunchKernelGGL((touch<1, true>), dim3(wgs), dim3(256), 0, 0, d, n_buckets, bucket_bytes / 16, seed, rounds, out);
+        else hipLaunchKernelGGL((touch<2, true>), dim3(wgs), dim3(256), 0, 0, d, n_buckets, bucket_bytes / 16, seed, rounds, out);
+    };
+    launch(1u);
+    hipDeviceSynchronize();
+    hipEventRecord(a, 0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) launch(2u + i);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a); hipEventDestroy(b);
+    return (double)reps * wgs * 256 * rounds * 4 / ms / 1e6;          // G buckets/s
+}
+static int quick(double gb) {
+    uint32_t* out; hipMalloc(&out, 256 * 16 * 256 * 4);
+    const size_t bytes = (size_t)(gb * (1ull << 30));
+    uint4* d = nullptr;
+    if (hipMalloc(&d, bytes + 4096) != hipSuccess) { printf("{\"error\": \"alloc failed\"}\n"); return 1; }
+    hipMemset(d, 1, bytes);
+    const double r128w64 = run_quiet(2, d, bytes, 128, out), r64w64 = run_quiet(1, d, bytes, 64, out);
+    const size_t half16 = bytes / 32;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(stream_copy, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)d, d + half16, half16);
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(stream_copy, dim3(256 * 32), dim3(256), 0, 0, (const uint4*)d, d + half16, half16);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    const double copy_gbps = 4.0 * (double)half16 * 32.0 / ms / 1e6;   // read + written bytes
+    printf("{\"table_gb\": %.2f, \"random_r128_w64_Gbuckets_s\": %.3f, \"random_r64_w64_Gbuckets_s\": %.3f, \"stream_copy_GBps\": %.1f}\n", gb, r128w64, r64w64, copy_gbps);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "quick") return quick(argc > 2 ? atof(argv[2]) : 4.5);
     uint32_t* out; hipMalloc(&out, 256 * 16 * 256 * 4);
     for (double gb : {0.5, 4.0, 16.0}) {
         const size_t bytes = (size_t)(gb * (1ull << 30));
