@@ -953,6 +953,10 @@ def main():
     steps = up(max(args.steps, args.min_batches))
     rig = RoutedRig(ctx, args.algo, args.dist, S, GB, duration_ms=args.duration_ms) if routed else Rig(ctx, args.algo, args.dist, S, duration_ms=args.duration_ms)
     resident = rig.populate(NOW0)
+    if os.environ.get("GUBER_BENCH_EXIT_AFTER_SETUP"):              # scripts/gpu_r06_fault.sh: many fresh starts of the set-up phase
+        torch.cuda.synchronize(dev)
+        print(json.dumps({"setup_only": True, "resident": int(resident)}), flush=True)
+        os._exit(0)
     # what every rank holds, and how many ranks the collective backend (nccl = RCCL for N > 1) really sees
     resident_by_rank = shard.gather_over_ranks(resident, device=red_dev)
     ranks_seen = shard.sum_over_ranks(1, device=red_dev)

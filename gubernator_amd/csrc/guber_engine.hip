@@ -163,7 +163,7 @@ struct guber_engine {
     DevBuf<unsigned long long> lru_tstamp, lru_tstamp_in, lru_cnt; DevBuf<uint32_t> lru_tslot, lru_tslot_in; DevBuf<uint8_t> lru_sort_tmp;
     DevBuf<unsigned long long> lru_u64; DevBuf<uint32_t> lru_u32; DevBuf<uint8_t> lru_u8;
     bool lru_tail_ok = false;  // false: the slots' numbering or the table changed under the list (rebuild before use)
-    uint64_t lru_admits = 0, lru_applied = 0, lru_rebuilds = 0, lru_cuts = 0, lru_passes = 0;
+    uint64_t lru_admits = 0, lru_applied = 0, lru_rebuilds = 0, lru_cuts = 0, lru_passes = 0; uint32_t lru_split_at = 0;
     uint64_t touch = 0;        // first stamp of the call in progress (take_stamps)
     // asynchronous counter read-back (maintain): enqueued when an upper bound crosses its soft limit, folded when its event
     // has completed — the hot path never waits for it
@@ -583,13 +583,13 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
         const uint64_t live_cap = e->lru_tstamp.cap;
         if (w_len > live_cap) w_len = live_cap;
         const uint32_t W = (uint32_t)std::min<uint64_t>(w_len, 1u << 30), wblocks = (W + 255) / 256;
-        // scratch: u64 [cells gid | n rstamp | W zstamp], u32 [cells gfirst | cells gfirst_ok | n rfirst | n rslot | W zslot | W zwidx | n qfirst | n qrank | n qslot |
+        // scratch: u64 [cells gid | n rstamp | W zstamp], u32 [cells gfirst | cells gfirst_ok | cells gfirst_reset | n rfirst | n rslot | W zslot | W zwidx | n qfirst | n qrank | n qslot |
         //               wblocks + 1 blockcnt | n + 1 new_before | W + 1 touched_before | 4 n_risk], u8 [n + 1 isnew_at | W wflag | W ztouched]
         const size_t nn = (size_t)n + 1;
-        if (e->lru_u64.ensure((size_t)cells + nn + W + 8) || e->lru_u32.ensure(2 * (size_t)cells + 6 * nn + 3 * ((size_t)W + 1) + wblocks + 16) ||
+        if (e->lru_u64.ensure((size_t)cells + nn + W + 8) || e->lru_u32.ensure(3 * (size_t)cells + 6 * nn + 3 * ((size_t)W + 1) + wblocks + 16) ||
             e->lru_u8.ensure(nn + 2 * ((size_t)W + 1) + 64)) return GUBER_E_NOMEM;
         unsigned long long* p64 = e->lru_u64.p; uint32_t* p32 = e->lru_u32.p; uint8_t* p8 = e->lru_u8.p;
-        LruGroups G{p64, p32, p32 + cells, cells - 1}; p64 += cells; p32 += 2 * (size_t)cells;
+        LruGroups G{p64, p32, p32 + cells, p32 + 2 * (size_t)cells, cells - 1}; p64 += cells; p32 += 3 * (size_t)cells;
         LruRes R{p32, p32 + nn, p64}; p32 += 2 * nn; p64 += nn;
         LruWin Z{p64, p32, p32 + W + 1}; p64 += W; p32 += 2 * ((size_t)W + 1);
         LruRisk Q{p32, p32 + nn, p32 + 2 * nn}; p32 += 3 * nn;
@@ -602,7 +602,7 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
         hipLaunchKernelGGL(k_lru_begin, dim3(1), dim3(256), 0, st, e->T, C, e->n_bctr);
         if (n) {
             HIPCHK(hipMemsetAsync(G.id, 0xff, (size_t)cells * 8, st));
-            HIPCHK(hipMemsetAsync(G.first, 0xff, (size_t)cells * 8, st));                   // (first and first_ok)
+            HIPCHK(hipMemsetAsync(G.first, 0xff, (size_t)cells * 12, st));                  // (first, first_ok and first_reset)
             HIPCHK(hipMemsetAsync(isnew_at, 0, nn, st));
             hipLaunchKernelGGL(k_lru_probe, dim3((n + 255) / 256), dim3(256), 0, st, e->T, K, n, G);
             hipLaunchKernelGGL(k_lru_keys, dim3(cells / 256), dim3(256), 0, st, e->T, G, C, isnew_at, R);
@@ -640,6 +640,7 @@ static int lru_admit(guber_engine* e, const LruKeys& K, uint32_t n, int64_t now_
             return 0;
         }
         if (c.status == LRU_CUT) { e->lru_cuts++; *status = LRU_CUT; return 0; }
+        if (c.status == LRU_SPLIT) { e->lru_cuts++; e->lru_split_at = c.split_at; *status = LRU_SPLIT; return 0; }
         if (c.status == LRU_MORE) { w_len *= 4; continue; }
         if (c.status == LRU_REBUILD) { e->lru_tail_ok = false; w_len = std::max<uint64_t>(w_len, 2 * (uint64_t)n + c.zone); continue; }
         return fail(GUBER_E_HIP, "the eviction pre-pass left no verdict");
@@ -768,6 +769,12 @@ static int launch_batch(guber_engine* e, const BatchView& B, const ResultView& R
         if (!rc && st == LRU_CUT) {
             len = (uint32_t)std::min<uint64_t>(len, std::max<uint64_t>(e->cache_size, 1));
             rc = lru_admit(e, lru_keys_of(batch_slice(B, pos, len)), len, B.now_ms, &st);
+        }
+        // a resident key whose first request cannot insert (guber_kernels_lru.h "ISOLATED"): the requests before it, then it alone, then the rest
+        if (!rc && st == LRU_SPLIT) {
+            len = e->lru_split_at ? std::min(len, e->lru_split_at) : 1u;
+            rc = lru_admit(e, lru_keys_of(batch_slice(B, pos, len)), len, B.now_ms, &st);
+            if (!rc && st != LRU_NONE && st != LRU_APPLIED) rc = fail(GUBER_E_HIP, "the eviction pre-pass split a piece twice");
         }
         if (rc) break;
         if (sf0) { e->W.store_flags = sf0 + pos; e->W.store_after = sa0 + pos; }

@@ -15,6 +15,21 @@
 //   * after its first access a key is at the front and cannot be evicted again within n <= cacheSize requests;
 //   * the items the batch never touches leave from the back: the oldest len0 + (new keys) - cacheSize of them.
 //
+// Two kinds of request do not fit these rules, because they change the list's LENGTH where the rules only move keys to the front:
+//   * a TOKEN_BUCKET request with RESET_REMAINING for a key that is in the cache REMOVES the item (algorithms.go:78-90) and inserts
+//     nothing: the list is one shorter until the key's next request, or for good — one eviction less for whoever inserts next, and
+//     everything behind the key has moved up one place;
+//   * the FIRST request of a resident key that fails inside the algorithm before c.Add (DURATION_IS_GREGORIAN with a duration that is
+//     no interval constant: lru_cannot_insert) is no arrival at the front if the key had been pushed out before (GetItem misses,
+//     nothing is inserted: the key re-enters at its first good request, or never) or if its item had expired (GetItem removes it,
+//     cache.go:43-57 / lrucache.go:111-128, and nothing takes its place).
+// Both are rare (a client resetting a limit; a client's invalid constant), so they are not modelled, they are ISOLATED: the pre-pass
+// reports the first such request (LruCtl::split_at, status LRU_SPLIT) and the host evaluates the requests before it as a batch of
+// their own — for which the rules hold as they stand —, then that request alone (a batch of one: its key is first, nothing precedes
+// it, and one request cannot overflow a cache that was not over its size), then the rest, each with its own pre-pass.  Exact by
+// construction, at the price of a pre-pass per such request while the cache binds.  (Round 5 documented the second kind as not
+// reproduced and had not noticed the first.)
+//
 // So before a batch that may overflow the cache (host: live + n > cacheSize) a PRE-PASS decides which resident keys are evicted
 // before their first access (their buckets become absent: the batch's pipeline — any of them — then sees a new key, as the
 // reference does) and which untouched items go; the pipeline itself is unchanged.  Only the items near the back matter: the
@@ -37,13 +52,14 @@ enum : uint32_t { LRU_NONE = 1,      // the batch cannot overflow the cache: not
                   LRU_APPLIED = 2,   // evictions decided and applied
                   LRU_MORE = 3,      // the window holds too few valid entries and the tail list goes on: look at a longer window
                   LRU_REBUILD = 4,   // the tail list is used up: build a new one
-                  LRU_CUT = 5 };     // evictions are due and the batch is larger than the cache: evaluate it in pieces
+                  LRU_CUT = 5,       // evictions are due and the batch is larger than the cache: evaluate it in pieces
+                  LRU_SPLIT = 6 };   // evictions are due and a RESIDENT key's first request cannot insert (LruCtl::split_at): that request is evaluated on its own
 
 struct LruCtl {
     unsigned long long cursor, tail_n;             // the tail list: first entry that may still be valid, entries (persistent)
     long long len0;                                // items in the cache before the batch
     unsigned long long evicted, unexpired;         // this call: buckets made absent, of which not yet expired (lrucache.go:142-146)
-    uint32_t m_new, m_res, n_risk, win_len, win_valid, zone, evict_untouched, first_left, status, pad;
+    uint32_t m_new, m_res, n_risk, win_len, win_valid, zone, evict_untouched, first_left, status, split_at;
 };
 
 // where the keys of the requests (or of the items of an Add) are
@@ -70,7 +86,8 @@ __device__ __forceinline__ uint32_t lru_u32(const uint8_t* p, uint32_t stride, u
 // id: bit 63 set = the key has a directory entry (slot in the low 32 bits; bit 62 = its bucket is live), else 63 bits of a
 // second, independent hash of the key bytes (a key the table has never seen)
 // first = the key's first request, first_ok = its first request that can insert it (all bits set: none — see lru_cannot_insert)
-struct LruGroups { unsigned long long* id; uint32_t* first; uint32_t* first_ok; uint32_t mask; };
+// first_reset = its first TOKEN_BUCKET request with RESET_REMAINING (all bits set: none)
+struct LruGroups { unsigned long long* id; uint32_t* first; uint32_t* first_ok; uint32_t* first_reset; uint32_t mask; };
 struct LruRes { uint32_t* first; uint32_t* slot; unsigned long long* stamp; };           // resident keys of the batch
 struct LruWin { unsigned long long* stamp; uint32_t* slot; uint32_t* widx; };             // the window's valid entries, oldest first
 struct LruRisk { uint32_t* first; uint32_t* rank; uint32_t* slot; };                     // resident keys inside the zone
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void k_lru_begin(Table T, LruCtl* C, uint32_t 
         C->len0 = t < 0 ? 0 : t;
         C->evicted = C->unexpired = 0ull;
         C->m_new = C->m_res = C->n_risk = C->win_len = C->win_valid = C->zone = C->evict_untouched = 0u;
-        C->first_left = 0xffffffffu; C->status = 0u;
+        C->first_left = 0xffffffffu; C->status = 0u; C->split_at = 0xffffffffu;
     }
 }
 
@@ -113,7 +130,12 @@ __global__ __launch_bounds__(256) void k_lru_probe(Table T, LruKeys K, uint32_t 
     for (;;) {
         unsigned long long cur = G.id[c];
         if (cur == ~0ull) { const unsigned long long old = atomicCAS(&G.id[c], ~0ull, id); cur = old == ~0ull ? id : old; }
-        if (cur == id) { atomicMin(&G.first[c], i); if (!lru_cannot_insert(K, i)) atomicMin(&G.first_ok[c], i); return; }
+        if (cur == id) {
+            atomicMin(&G.first[c], i);
+            if (!lru_cannot_insert(K, i)) atomicMin(&G.first_ok[c], i);
+            if (K.behavior && (K.behavior[i] & BH_RESET_REMAINING) && (!K.algorithm || K.algorithm[i] == ALGO_TOKEN)) atomicMin(&G.first_reset[c], i);
+            return;
+        }
         c = (c + 1) & G.mask;
     }
 }
@@ -125,10 +147,15 @@ __global__ __launch_bounds__(256) void k_lru_keys(Table T, LruGroups G, LruCtl* 
     const unsigned long long id = G.id[c];
     if (id == ~0ull) return;
     const uint32_t f = G.first[c];
+    // requests that change the list's length are evaluated on their own (file header): a token RESET of a key that is in the cache by then
+    // (resident, or inserted by an earlier request of this batch; a RESET that is a new key's first request is an insert like any other —
+    // it goes alone all the same, so that the key's next RESET finds it resident), and a resident key's first request that cannot insert
+    if (G.first_reset[c] != 0xffffffffu) atomicMin(&C->split_at, G.first_reset[c]);
     if ((id >> 62) == 3ull) {
         const uint32_t slot = (uint32_t)id;
         const uint32_t k = atomicAdd(&C->m_res, 1u);
         R.first[k] = f; R.slot[k] = slot; R.stamp[k] = rec_stamp(T.buckets[slot].rec);
+        if (G.first_ok[c] != f) atomicMin(&C->split_at, f);
     } else {
         const uint32_t fo = G.first_ok[c];               // a new key is inserted by its first request that gets as far as c.Add
         if (fo == 0xffffffffu) return;                   // (none does: the key never enters the list)
@@ -212,6 +239,7 @@ __global__ void k_lru_check(LruCtl* C, uint32_t w_len, uint32_t n, uint64_t cach
     C->win_len = (uint32_t)((C->cursor + w_len <= C->tail_n) ? w_len : (C->tail_n > C->cursor ? C->tail_n - C->cursor : 0ull));
     if (len0 + m_new <= N) { C->status = LRU_NONE; return; }
     if ((long long)n > N) { C->status = LRU_CUT; return; }
+    if (C->split_at != 0xffffffffu && n > 1) { C->status = LRU_SPLIT; return; }
     long long zone = len0 + m - N;                       // <= len0 because m <= n <= N
     if (zone > len0) zone = len0;
     C->zone = (uint32_t)zone;

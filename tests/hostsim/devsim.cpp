@@ -30,7 +30,7 @@ struct DevSim {
     uint64_t seq_next = 1;
     // the bounded cache (guber_kernels_lru.h), driven as guber_engine.hip lru_admit / lru_rebuild drive it
     uint64_t cache_size = 0; LruCtl ctl{}; std::vector<unsigned long long> tstamp; std::vector<uint32_t> tslot; bool tail_ok = true;
-    uint64_t admits = 0, applied = 0, rebuilds = 0, cuts = 0, passes = 0;
+    uint64_t admits = 0, applied = 0, rebuilds = 0, cuts = 0, passes = 0; uint32_t split_at = 0;
 };
 static long long ds_size(DevSim* d) { long long sz = d->ctr.size; for (auto& bc : d->bctr) sz += bc.size_delta; return sz; }
 static void ds_rebuild(DevSim* d) {
@@ -57,11 +57,11 @@ static uint32_t ds_admit(DevSim* d, const LruKeys& K, uint32_t n, int64_t now) {
         const uint32_t W = (uint32_t)w_len, wblocks = (W + 255) / 256;
         const size_t nn = (size_t)n + 1;
         std::vector<unsigned long long> gid(cells, ~0ull), rstamp(nn), zstamp(W + 1);
-        std::vector<uint32_t> gfirst(cells, 0xffffffffu), gfirst_ok(cells, 0xffffffffu), rfirst(nn), rslot(nn), zslot(W + 1), zwidx(W + 1), qfirst(nn), qrank(nn), qslot(nn), blockcnt(wblocks + 1),
+        std::vector<uint32_t> gfirst(cells, 0xffffffffu), gfirst_ok(cells, 0xffffffffu), gfirst_reset(cells, 0xffffffffu), rfirst(nn), rslot(nn), zslot(W + 1), zwidx(W + 1), qfirst(nn), qrank(nn), qslot(nn), blockcnt(wblocks + 1),
             new_before(nn), touched_before(W + 1);
         std::vector<uint8_t> isnew_at(nn, 0), wflag(W + 1, 0), ztouched(W + 1, 0);
         uint32_t n_risk = 0;
-        LruGroups G{gid.data(), gfirst.data(), gfirst_ok.data(), cells - 1}; LruRes R{rfirst.data(), rslot.data(), rstamp.data()};
+        LruGroups G{gid.data(), gfirst.data(), gfirst_ok.data(), gfirst_reset.data(), cells - 1}; LruRes R{rfirst.data(), rslot.data(), rstamp.data()};
         LruWin Z{zstamp.data(), zslot.data(), zwidx.data()}; LruRisk Q{qfirst.data(), qrank.data(), qslot.data()};
         LruCtl* C = &d->ctl;
         fakehip::launch(dim3(1), dim3(256), nullptr, [&] { k_lru_begin(d->T, C, (uint32_t)d->bctr.size()); });
@@ -89,6 +89,7 @@ static uint32_t ds_admit(DevSim* d, const LruKeys& K, uint32_t n, int64_t now) {
         const uint32_t st = C->status;
         if (st == LRU_NONE || st == LRU_APPLIED) { if (st == LRU_APPLIED) d->applied++; return st; }
         if (st == LRU_CUT) { d->cuts++; return st; }
+        if (st == LRU_SPLIT) { d->cuts++; d->split_at = C->split_at; return st; }
         if (st == LRU_MORE) { w_len *= 4; continue; }
         if (st == LRU_REBUILD) { d->tail_ok = false; w_len = std::max<uint64_t>(w_len, 2 * (uint64_t)n + C->zone); continue; }
         return 0;
@@ -174,6 +175,7 @@ int ds_eval(void* h, const guber_batch_t* b, guber_result_t* r, int pipeline, in
                                              K.behavior = S.behavior; K.duration = S.duration; K.greg_duration = (S.greg_expire && S.greg_duration) ? S.greg_duration : nullptr; return K; };
         uint32_t st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms);
         if (st == LRU_CUT) { len = (uint32_t)std::min<uint64_t>(len, d->cache_size); st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms); }
+        if (st == LRU_SPLIT) { len = d->split_at ? std::min(len, d->split_at) : 1u; st = ds_admit(d, keys(slice(pos, len)), len, b->now_ms); }   // (launch_batch, guber_engine.hip)
         if (st != LRU_NONE && st != LRU_APPLIED) return -3;
         const int rc = ds_eval_piece(d, slice(pos, len), ResultView{R.status + pos, R.limit + pos, R.remaining + pos, R.reset_time + pos, R.err + pos}, pipeline, careful);
         if (rc) return rc;

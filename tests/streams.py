@@ -102,3 +102,37 @@ def adversarial_batches(seed, n_batches, batch_size, n_keys=97, greg_fn=None):
         yield HostBatch(keys, hits, limit, duration, now, burst=burst, created_at=created, algorithm=algorithm,
                         behavior=beh, is_owner=is_owner, greg_expire=ge, greg_duration=gd)
         now += int(rng.choice([0, 1, 1, 3, 10, 60, 1000, 61000]))
+
+
+def length_changing_batches(seed, steps, nkeys, bsz, kinds, greg_fn):
+    """batches over `nkeys` keys in which some requests change the LENGTH of the reference's list instead of moving a key to its front
+    (guber_kernels_lru.h "ISOLATED"): kinds has "reset" — TOKEN_BUCKET requests with RESET_REMAINING on keys of the population (resident or
+    not, as a key's first, middle and last request of the batch) — and / or "greg" — requests with DURATION_IS_GREGORIAN and no interval
+    constant as the FIRST request of keys of the population, many of them among the oldest of a binding cache; a third of the keys have a
+    duration short enough to have expired when they are asked for again.  -> HostBatch per step (calendar values precomputed)"""
+    rng = np.random.default_rng(seed)
+    now = NOW0
+    for step in range(steps):
+        ids = rng.integers(0, nkeys, bsz)
+        beh = np.zeros(bsz, np.uint32)
+        dur = np.where(ids % 3 == 0, 1500, 3_600_000).astype(np.int64)
+        algo = (ids & 1).astype(np.uint8)
+        if "reset" in kinds:
+            for i in rng.choice(bsz, 40, replace=False):
+                beh[i] |= 8                                          # Behavior_RESET_REMAINING
+                algo[i] = 0 if rng.random() < 0.8 else algo[i]       # (a leaky request's RESET refills the bucket and removes nothing)
+            hot = int(ids[0])                                        # one key with several requests around its RESETs
+            for i in rng.choice(bsz, 12, replace=False):
+                ids[i] = hot; algo[i] = 0; dur[i] = 3_600_000 if hot % 3 else 1500
+        if "greg" in kinds:
+            seen = set()
+            for i in range(bsz):                                     # the FIRST request of some keys of the population cannot insert
+                k = int(ids[i])
+                if k not in seen and rng.random() < 0.06:
+                    beh[i] |= 4; dur[i] = 77 if rng.random() < 0.5 else 3
+                seen.add(k)
+        ge, gd = np.zeros(bsz, np.int64), np.zeros(bsz, np.int64)
+        for i in np.nonzero(beh & 4)[0]:
+            ge[i], gd[i] = greg_fn(now, int(dur[i]))
+        yield HostBatch([f"lru_{int(i)}" for i in ids], 1, 1000, dur, now, algorithm=algo, behavior=beh, greg_expire=ge, greg_duration=gd)
+        now += 1000

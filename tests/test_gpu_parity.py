@@ -964,6 +964,29 @@ def test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert(flags, 
     e.close()
 
 
+@pytest.mark.parametrize("flags", [0, 64])
+@pytest.mark.parametrize("kinds", ["greg", "reset", "reset+greg"])
+def test_requests_that_change_the_lists_length_are_evaluated_on_their_own(flags, kinds):
+    """VERDICT r05 item 3 (row A8).  Under a binding cache the eviction pre-pass models every access as "the key is at the front now"
+    (guber_kernels_lru.h).  Two kinds of request are not that: a TOKEN_BUCKET RESET_REMAINING of a key in the cache removes the item and
+    inserts nothing (algorithms.go:78-90), and a resident key's FIRST request that fails before c.Add (DURATION_IS_GREGORIAN with no
+    interval constant) is no arrival at the front if the key had been pushed out before it (round 5's documented divergence: the key
+    among the oldest, evicted by the batch's earlier inserts, GetItem misses, nothing is inserted) or had expired (lrucache.go:111-128
+    removes it).  The pre-pass reports the first such request (LRU_SPLIT) and the engine evaluates the requests before it, it alone,
+    and the rest as batches of their own.  Every answer, the counters and the size after EVERY batch — i.e. which item the next batch
+    finds evicted — equal the bounded-LRU oracle's; all six cases fail without the split (checked on the kernel source on the CPU,
+    tests/test_kernels_devsim.py)."""
+    cs, nkeys, bsz = 2000, 2600, 1500
+    o, e = Oracle(cache_size=cs), engine(cache_size=cs, max_batch=2048, flags=flags)
+    for step, b in enumerate(streams.length_changing_batches(23, 12, nkeys, bsz, kinds, support.gregorian)):
+        want, got = o.eval(b), e.eval(b)
+        support.assert_results_equal(got, want, f"{kinds} step {step}")
+        assert got.counters() == want.counters() and want.counters()[4] <= cs, (step, got.counters(), want.counters())
+    st = e.stats()
+    assert st["unexpired_evictions"] == o.counters()[3] and st["cache_size"] == o.size() and st["eviction_passes"] >= 1 and st["batch_cuts"] >= 1, st
+    e.close()
+
+
 def test_a_batch_larger_than_the_cache_is_evaluated_in_pieces():
     """cache_size 300 under batches of 1 000 requests over 500 keys (and one of 70 000 through the radix pipeline's size class): the
     engine cuts the batch into pieces of cache_size requests, each with its own eviction pre-pass — a key evicted by request i is a

@@ -399,6 +399,27 @@ def test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert(lib, pi
     sim.close()
 
 
+@pytest.mark.parametrize("pipeline,kinds", [(1, "reset+greg"), (0, "greg"), (0, "reset")])
+def test_requests_that_change_the_lists_length_are_evaluated_on_their_own(lib, pipeline, kinds):
+    """Under a binding cache the eviction pre-pass models every access as "the key is at the front now".  Two kinds of request are not
+    that: a TOKEN_BUCKET RESET_REMAINING of a key in the cache removes the item and inserts nothing (algorithms.go:78-90), and a resident
+    key's first request that fails before c.Add (an invalid Gregorian constant) is no arrival at the front if the key had been pushed out
+    before it, or had expired (lrucache.go:111-128).  The pre-pass reports the first such request (LRU_SPLIT) and the host evaluates the
+    requests before it, it alone, and the rest as batches of their own: every answer, the size after every batch and the unexpired
+    evictions equal the bounded-LRU oracle's (the second kind was round 5's documented divergence; the first was found
+    writing this test — both fail without the split)."""
+    only_where_the_form_matters(lib, 0)
+    cs, nkeys, bsz = 2000, 2600, 1500
+    sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
+    for step, b in enumerate(streams.length_changing_batches(23, 5, nkeys, bsz, kinds, gregorian)):
+        want, got = orc.eval(b), sim.eval(b)
+        assert_results_equal(got, want, f"{kinds} step {step}")
+        assert sim.counters()[3] == orc.size() <= cs, (step, sim.counters()[3], orc.size())
+    st = sim.lru_stats()
+    assert st["unexpired_evictions"] == orc.counters()[3] and st["applied"] >= 1 and st["cuts"] >= 1, (st, orc.counters())
+    sim.close()
+
+
 def test_batches_larger_than_the_cache_are_cut(lib):
     """a cache of 300 items under batches of 1 000 requests over 500 keys: the batch is evaluated in pieces of cache_size requests,
     a key evicted by request i is a new item for request j > i of the same batch (lrucache.go:98-100)"""
