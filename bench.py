@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--headline", choices=["routed", "presplit"], default="routed",
                     help="routed (the all-inclusive arrangement): ONE raw request stream in arrival order -> routed to the shards on the device -> answers in request "
                          "order, inside the clock; presplit: rounds 2-5's headline (per-shard batches split outside the clock, answers left in shard order)")
-    ap.add_argument("--extras", default="presplit,leaky,expiring,shards_1,uniform,end_to_end,pool",
+    ap.add_argument("--extras", default="presplit,leaky,expiring,shards_1,uniform,end_to_end,pool,global_sync,two_ranks",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--extra-batches", type=int, default=1024, help="timed distinct batches of the extra configurations")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
@@ -126,6 +126,9 @@ def parse():
                          "and every K steps the ranks run guber_global_sync (0 = off)")
     ap.add_argument("--logical-ranks", type=int, default=2, help="with --global-sync on ONE process: logical ranks sharing the GPU (device-copy transport)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
+    ap.add_argument("--ring-peers", type=int, default=0,
+                    help="N > 1: peers on the consistent-hash ring (default = --gpus).  More peers than ranks = BASELINE config 4's shape rehearsed with fewer "
+                         "GPUs: the key space is ring-peers x --keys, rank r owns what the ring gives gpu<r>")
     ap.add_argument("--one-device", action="store_true",
                     help="debug: all ranks share GPU 0 (single-GPU box; use with --backend gloo)")
     return ap.parse_args()
@@ -932,13 +935,14 @@ def main():
     ctx.route_on_device = route_on_device
 
     # ---- key ownership: ids of the global key space (world x K) this rank owns on the ring ------
-    total_keys = K if GSYNC else K * world      # GLOBAL: one key space, replicated on every GPU
+    peers = max(world, args.ring_peers or world)
+    total_keys = K if GSYNC else K * peers      # GLOBAL: one key space, replicated on every GPU
     ctx.table = streams.key_table(total_keys)
-    if GSYNC or world == 1:
+    if GSYNC or peers == 1:
         ctx.my_ids = np.arange(total_keys, dtype=np.int64)
     else:
         tmp = ga.Engine(cache_size=1024, device=local_rank, max_batch=1024)
-        ctx.my_ids = shard.owned_key_ids(ctx.table, world, rank, route=lambda ring, kb, ko: route_on_device(tmp, ring, kb, ko), chunk=4_000_000)
+        ctx.my_ids = shard.owned_key_ids(ctx.table, peers, rank, route=lambda ring, kb, ko: route_on_device(tmp, ring, kb, ko), chunk=4_000_000)
         tmp.close()
 
     if GSYNC:
@@ -966,6 +970,9 @@ def main():
     warm = up(max(args.warmup, 4 * S))
     m = rig.measure(steps, warm, NOW0, seed, profile_steps=up(max(0, args.profile_steps)), latency_steps=up(max(0, args.latency_steps)))
 
+    if os.environ.get("GUBER_BENCH_EXIT_AFTER_TIMED"):              # scripts/gpu_r06_fault.sh: many fresh starts up to the end of the timed region
+        print(json.dumps({"timed_only": True, "value": m["value"]}), flush=True)
+        os._exit(0)
     roofline = latency = cpu = parity = None
     extras = {}
     if rank == 0:
@@ -1097,7 +1104,7 @@ def main():
     if routed:
         wl = (f"{K} resident keys per GPU, ONE {args.dist} request stream" + (" s=1.1" if args.dist == "zipf" else "") + f" over them in ARRIVAL order, never split on the host, "
               f"batch={B}, {args.algo.upper()}_BUCKET, hits=1 limit=100 duration={args.duration_ms}ms, {world}xMI355X"
-              + (", keys sharded by replicated consistent hash (512 vnodes, fnv1)" if world > 1 else "")
+              + (f", keys sharded by replicated consistent hash (512 vnodes, fnv1, {peers} peers)" if peers > 1 else "")
               + f"; generations of {GB} batches (what a batcher has collected while the previous generation ran, peer_client.go:284-337; one now_ms each) go through "
                 f"guber_front_eval_dev, everything inside the clock: XXH64 of every HashKey + the placement's rule -> one of {S} logical shards (workers.go:261-289, getWorker "
                 f":180-184), shares contiguous and in arrival order, the {S} tables through the fused launches on {args.streams} streams, answers back in REQUEST order "
@@ -1111,7 +1118,7 @@ def main():
                   ("own stream + batcher thread each" if args.dispatch == "threads" else
                    f"one dispatcher, shards spread over {args.streams} stream(s): the next batch of up to four shards of a stream per pair of launches")) if S > 1 else ", one table"))
     headline_cfg = {"workload": wl, "arrangement": args.headline, "generation_requests": (GB * B) if routed else None,
-                    "keys_per_gpu": K, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
+                    "keys_per_gpu": K, "ring_peers": peers, "batch": B, "algorithm": args.algo, "resident_items_rank0": int(resident),
                     "resident_items_by_rank": resident_by_rank, "ranks_seen_by_the_collective_backend": ranks_seen, "backend": args.backend if world > 1 else None,
                     "logical_shards_per_gpu": S, "dispatch": args.dispatch if S > 1 else "caller thread", "placement": rig.placement, "host_cores": os.cpu_count(),
                     # engine options taken from the environment (experiments; all unset in the driver's run)
@@ -1142,7 +1149,7 @@ def main():
         out = {
             "metric": "rate-limit decisions/sec (kernel path, inputs resident in HBM)",
             "value": round(m["value"], 1), "unit": "decisions/s", "n_gpus": world, "steps": steps, "steps_requested": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(m["ms_per_step"], 5), "higher_is_better": True,
+            "warmup": warm, "warmup_requested": args.warmup, "ms_per_step": round(m["ms_per_step"], 5), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "int64" if args.algo == "token" else "f64", "data": "synthetic",
             "config": headline_cfg,
@@ -1177,6 +1184,8 @@ def run_extra(name, args, ctx, NOW0, seed):
     warmup = max(4, min(args.warmup, 16))                        # (raised to four batches per shard below)
     if name == "routed":
         return run_routed(args, ctx, NOW0, seed, steps)
+    if name in ("global_sync", "two_ranks"):
+        return run_rehearsal(name, args)
     if name == "end_to_end":
         return run_end_to_end(args, ctx, NOW0, seed)
     if name == "pool":
@@ -1261,6 +1270,39 @@ def run_routed(args, ctx, NOW0, seed, steps, algo=None, dist_kind=None):
             out.pop("value")
     rig.close()
     out["front"] = rig.front_stats
+    return out
+
+
+def run_rehearsal(name, args):
+    """N > 1 readiness on a box with ONE GPU (no multi-GPU hardware has run this code): further bench.py processes of
+    their own, parity-gated like any run.
+      global_sync: BASELINE config 5 — every request GLOBAL, two logical ranks on this GPU, guber_global_sync every 8 batches on the native
+                   exchange (device copies between the ranks: RCCL refuses two ranks on one device), replicas converged or no number
+      two_ranks:   BASELINE config 4's shape — a ring of 8 peers over 8 x keys, TWO of them as processes sharing this GPU (gloo for the
+                   timing collectives), each owning what the ring gives gpu<rank> (~ keys each), each gated against its own oracle
+    Real RCCL between GPUs has never executed; what these legs pin is that the N > 1 code paths run and answer like the reference."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GUBER_BENCH_EXIT_AFTER_SETUP", "GUBER_BENCH_EXIT_AFTER_TIMED")}
+    if name == "global_sync":
+        cmd = ["--gpus", "1", "--global-sync", "8", "--logical-ranks", "2", "--keys", str(args.keys), "--steps", "64", "--warmup", "8"]
+    else:
+        cmd = ["--gpus", "2", "--one-device", "--backend", "gloo", "--ring-peers", "8", "--keys", str(args.keys), "--steps", "256", "--min-batches", "256", "--warmup", "8",
+               "--extras", "", "--profile-steps", "0", "--latency-steps", "0", "--cpu-threads", "16", "--cpu-seconds", "1"]
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"error": (p.stdout + p.stderr)[-600:], "command": "bench.py " + " ".join(cmd)}
+    j = json.loads(lines[0])
+    out = {"value": j["value"], "unit": "decisions/s", "ms_per_step": j["ms_per_step"], "n_gpus": j["n_gpus"], "parity": j["parity"], "command": "bench.py " + " ".join(cmd),
+           "hardware": "ONE GPU: " + ("two logical ranks of one process, device copies between them" if name == "global_sync" else
+                                      "two processes (two of the ring's eight peers) time-slicing it; gloo carries the timing collectives") +
+                       " — a rehearsal of the N > 1 code paths, not a scaling number; RCCL between GPUs has not executed on any hardware yet"}
+    if name == "global_sync":
+        out["global_sync"] = j.get("global_sync")
+    else:
+        c = j["config"]
+        out.update({"resident_items_by_rank": c.get("resident_items_by_rank"), "ranks_seen_by_the_collective_backend": c.get("ranks_seen_by_the_collective_backend"),
+                    "ring_peers": c.get("ring_peers"), "parity_batches_by_rank": j.get("parity_batches_by_rank")})
     return out
 
 

@@ -58,6 +58,7 @@ import (
 	"unsafe"
 
 	"github.com/pkg/errors"
+	"github.com/sirupsen/logrus"
 )
 
 // GPUWorkerPool satisfies the call surface of *WorkerPool.  devices[i] is the HIP ordinal of peer "gpu<i>" on the reference's
@@ -147,7 +148,9 @@ func NewGPUWorkerPool(conf *Config, devices []int, shards int, batchLimit int, b
 	p.bufs.New = func() any { return newRPCBuf(kMaxBatch, kMaxBatch*96) }
 	// DURATION_IS_GREGORIAN intervals are computed on the device from the batch clock; interval.go:97-142 builds its civil dates in
 	// now.Location(), so the engine gets the daemon's zone: the offset in effect now and the coming transitions (UTC: nothing to say)
-	if err := setEngineTimezone(time.Local, time.Now(), 7); err != nil {
+	// (guber_set_timezone is process-wide and waits for every device: ONCE per process, before the first batch — a second pool must not
+	// stall the first one's kernels —, and again from a timer well before the table of 16 transitions runs out: ADVICE r05)
+	if err := ensureEngineTimezone(); err != nil {
 		C.guber_pool_destroy(p.pool)
 		return nil, err
 	}
@@ -158,10 +161,35 @@ func NewGPUWorkerPool(conf *Config, devices []int, shards int, batchLimit int, b
 	return p, nil
 }
 
+var (
+	tzOnce sync.Once
+	tzErr  error
+)
+
+// ensureEngineTimezone publishes the daemon's zone once per process and keeps it fresh: the table holds 16 transitions — eight years
+// of two changes, four of a zone with four per year —, so it is rebuilt every 180 days, from "now", for as long as the process lives.
+// A refresh swaps the table between batches (guber_set_timezone synchronises every device it touches; at two calls a year that is noise).
+func ensureEngineTimezone() error {
+	tzOnce.Do(func() {
+		tzErr = setEngineTimezone(time.Local, time.Now(), 7)
+		if tzErr != nil {
+			return
+		}
+		go func() {
+			for range time.Tick(180 * 24 * time.Hour) {
+				if err := setEngineTimezone(time.Local, time.Now(), 7); err != nil {
+					logrus.WithError(err).Error("gubernator: refreshing the engine's time zone table failed; the previous table stays in effect")
+				}
+			}
+		}()
+	})
+	return tzErr
+}
+
 // setEngineTimezone hands guber_set_timezone the zone as Go's time.Location holds it: the UTC offset at `from` and the transitions of the
 // next `years` years as (UTC second, offset from then on).  Go exports no transition table, so the offsets are sampled hourly and every
-// change is bisected to the second (a zone with daylight saving time has two per year; the engine's table takes 16).  Call it again once
-// a year (the daemon's restart cadence in practice), or with another Location for tests.
+// change is bisected to the second (a zone with daylight saving time has two per year; the engine's table takes 16).  ensureEngineTimezone
+// calls it at start-up and every 180 days; tests call it with another Location.
 func setEngineTimezone(loc *time.Location, from time.Time, years int) error {
 	offAt := func(u int64) int { _, off := time.Unix(u, 0).In(loc).Zone(); return off }
 	t := from.Unix() - from.Unix()%3600

@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "guber_last_error", "guber_version", "guber_profile_enable", "guber_profile_read", "guber_profile_passes", "guber_set_timezone", "guber_global_take",
     "guber_pool_create", "guber_pool_destroy", "guber_pool_set_clock", "guber_pool_engine", "guber_pool_batches",
     "guber_pool_get_rate_limits", "guber_compact", "guber_probe_missing", "guber_eval_batch_store",
-    "guber_eval_batches_dev", "guber_eval_batches_routed_dev", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
+    "guber_eval_batches_dev", "guber_eval_batches_routed_dev", "guber_front_create", "guber_front_destroy", "guber_front_set_rule", "guber_front_eval_dev",
+               "guber_front_synchronize", "guber_front_stream", "guber_front_stats", "guber_front_latencies", "guber_set_clock", "guber_comm_create_local", "guber_comm_unique_id", "guber_comm_create_rank",
     "guber_comm_destroy", "guber_global_sync", "guber_comm_last_stats", "guber_stage_create", "guber_stage_destroy",
     "guber_stage_batch", "guber_stage_result", "guber_stage_capacity", "guber_stage_submit", "guber_stage_wait", "guber_pool_create_multi",
     "guber_pool_shards", "guber_pool_device_of", "guber_pool_engine_at", "guber_pool_metrics", "guber_pool_set_store", "guber_pool_create_sharded", "guber_pool_shard_of", "guber_pool_load", "guber_pool_store", "guber_global_pending", "guber_global_take_dev", "guber_ring_route_rows_dev", "guber_add_items_dev",

@@ -107,9 +107,7 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
     HIPCHK(hipStreamCreateWithFlags(&f->rs, hipStreamNonBlocking));
     f->n_own_streams = 1;
-#ifdef GUBER_LAB
-    if (const char* v = getenv("GUBER_FRONT_STREAMS")) f->n_own_streams = std::max(1, std::min(3, atoi(v)));
-#endif
+    if (const char* v = guber_lab_env("GUBER_FRONT_STREAMS")) f->n_own_streams = std::max(1, std::min(3, atoi(v)));
     f->rs2 = f->os = f->rs;
     if (f->n_own_streams >= 2) HIPCHK(hipStreamCreateWithFlags(&f->os, hipStreamNonBlocking));
     if (f->n_own_streams >= 3) HIPCHK(hipStreamCreateWithFlags(&f->rs2, hipStreamNonBlocking));

@@ -12,3 +12,14 @@ int guber_host_set_tz(const guber_tz_t* tz);                 // validates and st
 const guber::TzTable* guber_host_tz_table();
 int guber_host_build_tz(const guber_tz_t* tz, guber::TzTable* out);   // validate + build, nothing published
 void guber_host_publish_tz(const guber::TzTable& t);                   // the host helpers' copy (guber_set_timezone: after every device has it)
+
+// The product library reads a handful of documented environment variables (INTEGRATION.md "Runtime knobs"); everything else a
+// measurement ever switched — pipelines, owner counts, fusion, stage copies, pool policies — is read only by builds with -DGUBER_LAB
+// (make -C gubernator_amd/csrc lab; the tests' CPU builds of the engine and the pool).  In the product the names are not even in the
+// binary (tests/test_abi_cpu.py looks).
+#ifdef GUBER_LAB
+#include <cstdlib>
+#define guber_lab_env(name) getenv(name)
+#else
+#define guber_lab_env(name) ((const char*)nullptr)
+#endif

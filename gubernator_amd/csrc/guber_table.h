@@ -345,6 +345,11 @@ __device__ __forceinline__ uint32_t probe(const Table& T, const uint8_t* key, ui
     return (uint32_t)r;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave, ALL of them active: the DPP forms read neighbouring lanes' registers whether those
+// lanes are enabled or not, so a partial EXEC mask would drop partial sums silently and readlane(63) would return a stale value.  Every
+// caller is at a workgroup-uniform point of a kernel whose workgroup is a multiple of 64 threads (block_sum / block_sum_lds, the scans of
+// k_part / k_own / k_eval3 / k_fr_scan / the wire decoder): keep it that way — a divergent caller must take its own shuffle loop.
+// row_bcast exists on gfx9 (gfx90a / gfx94x / gfx950) only; this library is built for gfx950 alone.
 // Inclusive prefix sum over the 64 lanes of a wave, ALL of them active.  On the device: six DPP adds (row_shr 1 / 2 / 4 / 8 inside the
 // rows of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 — the gfx9 scan) instead of six
 // ds_bpermute round trips with their index arithmetic (round 5's instruction diet: a scan was ~36 instructions, now 6 + hazards).

@@ -73,13 +73,16 @@ static int wire_dev_decode_staged_locked(guber_wire_dev* d, uint32_t nrpc, size_
     if (is_owner) HIPCHK(hipMemcpyAsync(d->d_owner.p, is_owner, nrpc, hipMemcpyHostToDevice, st));
     else HIPCHK(hipMemsetAsync(d->d_owner.p, 1, nrpc, st));
     d->in.nrpc = nrpc; d->in.max_per_rpc = max_per_rpc; d->out.now_ms = now_ms;
+    // (the serial walk's last workgroup numbers the batch and resets this counter; a decode that failed or faulted part of the way would
+    //  leave it raised and every later batch unnumbered, silently: four bytes a decode — ADVICE r05)
+    HIPCHK(hipMemsetAsync(d->sc.done, 0, 4, st));
     // the chain of every payload: in parallel (a workgroup per 8 KB window, pointer doubling: k_wire_win_a — only when a payload has
     // more than one window — says where the chain enters each window, k_wire_win_b finds the records), then the serial walk for the
     // payloads that hold anything but plain records, and the numbering of the batch (by that launch's last workgroup; a launch of its
     // own for batches of many payloads)
     // (payloads of less than 1 KB have no windows: a wave walks three dozen records sooner than a workgroup sets up; GUBER_WIRE_SERIAL=1: the
     // serial walk for all, for A/B runs)
-    static const bool wire_serial = [] { const char* v = getenv("GUBER_WIRE_SERIAL"); return v && atoi(v) != 0; }();
+    static const bool wire_serial = [] { const char* v = guber_lab_env("GUBER_WIRE_SERIAL"); return v && atoi(v) != 0; }();
     if (!wire_serial) {
         HIPCHK(hipMemcpyAsync((void*)d->sc.wfirst, h_wfirst, (size_t)(nrpc + 1) * 4, hipMemcpyHostToDevice, st));
         if (multi) hipLaunchKernelGGL(guber::k_wire_win_a, dim3(windows), dim3(guber::WP_T), 0, st, d->in, d->sc);

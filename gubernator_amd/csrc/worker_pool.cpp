@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "guber_algo.h"
+#include "guber_host.h"
 #include "guber_placement_impl.h"
 
 // -DGUBER_POOL_TRACE (test builds only: tests/hostsim/engine_stub.cpp keeps the ring and prints it on a mismatch): who reserved,
@@ -55,18 +56,20 @@ static inline void cpu_relax() {
 #endif
 }
 static uint32_t env_u32(const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; }
+// (the experiments' knobs: read by -DGUBER_LAB builds only, guber_host.h)
+#define lab_u32(name, dflt) ([&]() -> uint32_t { const char* v_ = guber_lab_env(name); return v_ ? (uint32_t)strtoul(v_, nullptr, 10) : (uint32_t)(dflt); }())
 
 GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, uint32_t batch_wait_us, uint32_t shards,
                              const std::vector<int32_t>& devices)
     : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
-    idle_us_ = env_u32("GUBER_POOL_IDLE_US", 0);                     // optional extra trigger: nobody reserved for this long and all slots written
+    idle_us_ = lab_u32("GUBER_POOL_IDLE_US", 0);                     // optional extra trigger: nobody reserved for this long and all slots written
     depth_ = std::max(1u, std::min(env_u32("GUBER_POOL_DEPTH", 2), kStages - 2));   // batches of one shard on the GPU at a time
-    eager_ = env_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
-    eager_min_ = env_u32("GUBER_POOL_EAGER_MIN", 4096);
+    eager_ = lab_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
+    eager_min_ = lab_u32("GUBER_POOL_EAGER_MIN", 4096);
     direct_max_ = env_u32("GUBER_POOL_DIRECT_MAX", 4);               // RPCs of at most this many requests may be evaluated by their caller (0 = never)
-    direct_callers_ = env_u32("GUBER_POOL_DIRECT_CALLERS", 0);       // ... while at most this many calls are in progress (0 = half the shards, at least 2)
-    one_pass_ = env_u32("GUBER_POOL_ONE_PASS", 1) != 0;              // one shard on one device: reserve first, then touch every request once
-    nt_stores_ = env_u32("GUBER_POOL_NT_STORES", 1) != 0;            // the 8-byte request columns go into the stage with non-temporal stores
+    direct_callers_ = lab_u32("GUBER_POOL_DIRECT_CALLERS", 0);       // ... while at most this many calls are in progress (0 = half the shards, at least 2)
+    one_pass_ = lab_u32("GUBER_POOL_ONE_PASS", 1) != 0;              // one shard on one device: reserve first, then touch every request once
+    nt_stores_ = lab_u32("GUBER_POOL_NT_STORES", 1) != 0;            // the 8-byte request columns go into the stage with non-temporal stores
     spin_us_ = env_u32("GUBER_POOL_SPIN_US", 40);                    // how long a waiting caller looks before it sleeps
     {   // callers allowed in the CPU part of a call at a time: the CPUs this process may really use (a cgroup CPU quota counts),
         // minus one for the dispatcher.  More runnable callers than CPUs only get the whole group throttled.
@@ -108,7 +111,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     // (guber_stage_submit_routed).  What a caller pays per RPC — one compare-and-swap, contiguous writes, one sleep — then
     // does not grow with the number of shards.  GUBER_POOL_ROUTED=0: every shard has stages of its own and the callers sort
     // their requests by shard (the arrangement this replaced; also what a build without the routed entry point would do).
-    routed_ = env_u32("GUBER_POOL_ROUTED", 1) != 0 && shards_per_device_ >= 2 && shards_per_device_ <= kMaxEngines;
+    routed_ = lab_u32("GUBER_POOL_ROUTED", 1) != 0 && shards_per_device_ >= 2 && shards_per_device_ <= kMaxEngines;
     stage_cap_ = routed_ ? (uint32_t)std::min<uint64_t>((uint64_t)batch_limit_ * shards, 65536) : batch_limit_;
     if (routed_ && batch_limit_ > 65536) { routed_ = false; stage_cap_ = batch_limit_; }     // (a share may be the whole stage: the two-launch pipeline takes 65 536)
     // a second generation behind the one in flight: per-shard stages pay a set of launches per group of four shards, so it waits
@@ -119,8 +122,8 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     // a flag over PCIe, then the submission: +45 us on a 2 000-request batch, +70..90 us on a 20 000-request one on MI355X) costs a
     // closed loop of callers more than their CPUs gain (64 x 1000-item RPCs, 8 shards: 218 instead of 236 M decisions/s).  It pays
     // where the callers' CPUs are the scarce resource and latency is not.
-    dev_route_ = routed_ && env_u32("GUBER_POOL_DEVROUTE", 0) != 0;
-    if (!getenv("GUBER_POOL_EAGER_MIN")) eager_min_ = routed_ ? 16 : 4096;
+    dev_route_ = routed_ && lab_u32("GUBER_POOL_DEVROUTE", 0) != 0;
+    if (!guber_lab_env("GUBER_POOL_EAGER_MIN")) eager_min_ = routed_ ? 16 : 4096;
     guber_config_t c = cfg;
     if (c.max_batch < stage_cap_) c.max_batch = stage_cap_;
     const uint32_t total = n_devices_ * shards;
@@ -129,7 +132,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     // room for batch_limit keys of typical size; a batch whose keys do not fit is flushed early (never overrun)
     key_cap_ = (uint32_t)std::min<uint64_t>((uint64_t)stage_cap_ * std::min<uint32_t>(max_key_, 96u) + max_key_, (1u << 24) - 1);
     // the shards of a device are spread over a few streams; shards that share one share their launches (guber_stages_submit)
-    uint32_t n_streams = env_u32("GUBER_POOL_STREAMS", 0);
+    uint32_t n_streams = lab_u32("GUBER_POOL_STREAMS", 0);
     if (n_streams == 0) n_streams = (shards + 3) / 4;                // a fused launch carries the batches of up to four shards
     n_streams = std::max(1u, std::min(n_streams, shards));
     if (routed_) n_streams = 1;                                      // (the shares of a front stage travel in one pair of launches)
@@ -286,7 +289,7 @@ void GPUWorkerPool::Metrics(guber_pool_metrics_t* out) const {
     for (const Shard* sh : counted) out->direct_batches += sh->direct.load();
     for (auto& d : devs_) { out->rebalances += d->rebalances.load(); out->keys_moved += d->moves.load(); out->submit_us_sum += d->submit_us.load(); out->submits += d->submits.load(); }
     out->shards = (uint32_t)shards_.size(); out->devices = n_devices_;
-    if (getenv("GUBER_POOL_DEBUG") && d_dbg_[3].load())
+    if (guber_lab_env("GUBER_POOL_DEBUG") && d_dbg_[3].load())
         fprintf(stderr, "[pool] per batch: wait for writers %.1f us, submit %.1f us, on the GPU until seen %.1f us (%llu batches); dispatcher loops %llu, polls %llu\n",
                 (double)d_dbg_[0] / d_dbg_[3], (double)d_dbg_[1] / d_dbg_[3], (double)d_dbg_[2] / d_dbg_[3], (unsigned long long)d_dbg_[3].load(),
                 (unsigned long long)d_dbg_[4].load(), (unsigned long long)d_dbg_[5].load());
@@ -1400,8 +1403,10 @@ int GPUWorkerPool::GetCacheItem(const std::string& key, guber_item_t* out, bool*
         if (rc != GUBER_OK) return rc;
         if (there) {
             const int rc2 = guber_get_item(d.shards[d.n_plain]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);
-            *found = f != 0;
-            return rc2;
+            if (rc2 != GUBER_OK || f) { *found = f != 0; return rc2; }
+            // (gone between the look and the access — evicted, or expired by now: the key's plain shard is asked like any other key's.
+            //  An expired item of the GLOBAL engine that nobody asks for by a GLOBAL request keeps its place until it reaches the back
+            //  of the list, as every expired item does: lrucache.go:111-128 reaps on access, :138-149 at the back)
         }
     }
     const int rc = guber_get_item(shards_[ShardOf(key)]->engine, (const uint8_t*)key.data(), (uint32_t)key.size(), NowMs(), out, &f);

@@ -78,17 +78,10 @@ typedef struct guber_engine guber_engine_t;
 
 /* guber_config_t.flags */
 #define GUBER_FLAG_GLOBAL 8u          /* keep per-bucket pending GLOBAL hits / updates (guber_global_take) */
-#define GUBER_FLAG_DIR_CLAIMS 16u     /* accepted and ignored (round-1 tuning knob: per-batch claims in the directory entries) */
-#define GUBER_FLAG_TEST_NO_SMALL 32u   /* tests only: batches of <= 256 requests take the two-launch pipeline too (not the one-launch small path) */
-#define GUBER_FLAG_TEST_CAREFUL 4u    /* tests only: never claim speculatively (the retry-round code path) */
-#define GUBER_FLAG_TEST_FORCE_RADIX 2u /* tests only: evaluate small batches with the large-batch (global radix
-                                          sort) kernel sequence as well */
-#define GUBER_FLAG_TEST_FORCE_PART 64u /* tests only: every batch (also <= 256 requests, also host-resident ones) takes the
-                                          owner-partitioned three-launch pipeline (guber_kernels_part.h) */
 #define GUBER_FLAG_NO_PART 128u        /* never take the owner-partitioned pipeline: batches of 257 .. 65 536 requests run the
                                           two-launch pipeline with per-batch claims (round 3's; kept as the retry round) */
-#define GUBER_FLAG_TEST_WEAK_HASH 1u /* tests only: keep 6 bits of the key hash so distinct keys collide and
-                                        the exact-key verification / retry path is exercised */
+/* (bits 1, 2, 4, 32 and 64 select code paths for the test suite — gubernator_amd/csrc/guber_test_flags.h —, bit 16 is accepted and
+ *  ignored: a binding passes none of them) */
 
 /* Engine configuration.  Replaces Config.{CacheSize,Workers,CacheFactory}
  * (reference config.go:73-123, workers.go:125-147). */
@@ -182,7 +175,7 @@ typedef struct guber_stats {
     uint64_t fused_batches;   /* batches that shared their two launches with other engines' batches (guber_eval_batches_routed_dev) */
     uint64_t eviction_passes; /* eviction pre-passes that evicted (a call that would have overflowed the cache: "Bounded cache" below) */
     uint64_t tail_rebuilds;   /* times the recency order of the live items was rebuilt from the table (one scan + one sort) */
-    uint64_t batch_cuts;      /* batches larger than the cache that were evaluated in pieces of cache_size requests */
+    uint64_t batch_cuts;      /* batches evaluated in pieces: larger than the cache (pieces of cache_size requests), or holding a request that changes the list's length ("bounded cache" below) */
 } guber_stats_t;
 
 /* ---- lifecycle: NewWorkerPool / WorkerPool.Close (workers.go:125,157) -------- */
@@ -396,11 +389,14 @@ int guber_eval_batch_store(guber_engine_t* e, const guber_batch_t* b, guber_resu
  *      duration that is no interval constant, or GregorianWeeks (interval.go:93,97,107,125,130,148) — inserts nothing: a key that
  *      is not resident and whose requests in the batch all fail that way never enters the list, a key with a failing request
  *      first and a good one later is inserted by the good one (test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert;
- *      closed at the end of round 5).  What is NOT reproduced (one case left): a RESIDENT key near the back of the list that the
- *      batch pushes out before the batch first asks for it, when that first request is such a failing one: the pre-pass sizes the
- *      evictions as if the request re-inserted the key (the reference re-inserts it at the key's first good request, or not at
- *      all), so it can evict one item more.  It takes a binding cache, a key inside the few hundred oldest items, and a client
- *      that sends an invalid interval constant for exactly that key; the answers of the batch itself are unaffected.
+ *      closed at the end of round 5).  Two kinds of request change the LENGTH of the reference's list instead of moving a key to its
+ *      front — a TOKEN_BUCKET request with RESET_REMAINING for a key that is in the cache (algorithms.go:78-90: the item is removed,
+ *      nothing is inserted) and a resident key's FIRST request that fails before c.Add (above) when the key had been pushed out before
+ *      that request or had expired (lrucache.go:111-128: GetItem misses / removes, nothing takes the place) —; while the cache binds the
+ *      pre-pass reports the first such request of a batch and the engine evaluates the requests before it, that request alone, and the
+ *      rest as batches of their own (guber_stats_t.batch_cuts counts them): exact by construction
+ *      (test_requests_that_change_the_lists_length_are_evaluated_on_their_own; round 5 had documented the second kind as not
+ *      reproduced).  Nothing of lrucache.go:88-171 is left unreproduced.
  *      Cost: nothing while live items + requests <= cache_size (size the cache with a batch of headroom); beyond that one
  *      pre-pass per batch (a dozen small launches and one stream synchronisation; the recency order of the live items comes
  *      from one table scan + sort per ~live/(2 x batch) batches: guber_stats_t.tail_rebuilds).

@@ -127,3 +127,21 @@ def test_headers_are_plain_c99_and_the_go_call_sequence_links(L, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert "no HIP device" in r.stdout or "no CPU fallback" in r.stdout, r.stdout
+
+
+def test_the_product_library_reads_only_the_documented_environment_variables():
+    """the experiments' knobs (pipelines, owner counts, fusion, pool policies ...) are read by -DGUBER_LAB builds only
+    (gubernator_amd/csrc/guber_host.h guber_lab_env; `make -C gubernator_amd/csrc lab`, the tests' CPU builds).  In the product library
+    the names are not even in the binary: every GUBER_* name it contains is one of the runtime knobs INTEGRATION.md documents."""
+    import subprocess
+    documented = {"GUBER_RCCL_LIB", "GUBER_POOL_MAX_ACTIVE", "GUBER_POOL_REBALANCE_MS", "GUBER_POOL_SPIN_US", "GUBER_POOL_DEPTH", "GUBER_POOL_DIRECT_MAX"}
+    out = subprocess.run(["strings", "-n", "8", ga.LIB_PATH if "enginesim" not in ga.LIB_PATH else os.path.join(support.ROOT, "gubernator_amd", "libguber_hip.so")],
+                         capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r"^(GUBER_[A-Z0-9_]+)$", out, re.M))
+    assert names <= documented, names - documented
+    assert len(documented) <= 8
+    text = open(os.path.join(support.ROOT, "INTEGRATION.md")).read()
+    for n in documented:
+        assert n in text, f"{n} is read by the product but INTEGRATION.md does not say what it does"
+    hdr = open(os.path.join(support.ROOT, "include", "guber_gpu.h")).read()
+    assert "FLAG_TEST" not in hdr                                     # (the test suite's flag bits live in gubernator_amd/csrc/guber_test_flags.h)

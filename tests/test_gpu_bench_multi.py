@@ -57,6 +57,18 @@ def test_two_ranks_on_one_device_are_parity_gated_and_agree_with_one_rank():
     assert 0.5 < ratio < 1.4, ratio
 
 
+def test_two_of_eight_ring_peers_share_the_device():
+    """BASELINE config 4's shape with the hardware at hand (bench.py's default `two_ranks` extra): a ring of EIGHT peers over 8 x keys,
+    two of them as processes on this GPU — each owns what the ring gives gpu<rank> (about --keys each: replicated_hash.go:78-119), is
+    gated against its own oracle, and the line says what every rank held and how many ranks the backend saw"""
+    out = _bench(["--gpus", "2", "--one-device", "--backend", "gloo", "--ring-peers", "8"] + [("500000" if a == "2000000" else a) for a in COMMON])
+    assert out["n_gpus"] == 2 and out["config"]["ring_peers"] == 8
+    assert out["parity"].startswith("2/2 ranks, 256/256 timed batches each"), out["parity"]
+    assert out["config"]["ranks_seen_by_the_collective_backend"] == 2
+    res = out["config"]["resident_items_by_rank"]
+    assert len(res) == 2 and all(abs(r - 500_000) < 75_000 for r in res), res      # (two eighths of 4 M keys, +- the ring's imbalance)
+
+
 def test_global_leg_with_two_processes_through_the_rccl_call_sequence():
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "hostsim"), "fake_rccl"], check=True)
     out = _bench(["--gpus", "2", "--one-device", "--backend", "gloo", "--global-sync", "8", "--keys", "200000", "--steps", "32", "--warmup", "8"],

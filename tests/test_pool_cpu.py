@@ -17,7 +17,7 @@ def build(tag, flags):
     obj = f"/tmp/guber_pool_oracle_{tag}.o"
     subprocess.run(["gcc", "-O1", "-g", *flags, "-c", "oracle/guber_oracle.c", "-o", obj], cwd=ROOT, check=True)
     # -DGUBER_POOL_TEST_HOOKS: the pool tells pool_test.cpp where a caller is (a placement pass in the middle of a routing round: block 10)
-    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-DGUBER_POOL_TEST_HOOKS", *flags, *SRC, obj, "-o", out, "-lpthread"], cwd=ROOT, check=True)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-DGUBER_POOL_TEST_HOOKS", "-DGUBER_LAB", *flags, *SRC, obj, "-o", out, "-lpthread"], cwd=ROOT, check=True)
     return out
 
 
