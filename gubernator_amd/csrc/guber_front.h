@@ -20,10 +20,13 @@ struct guber_front {
     std::vector<guber_engine*> eng;
     std::vector<hipStream_t> streams;                 // the engines' distinct streams
     std::vector<int> stream_of;                       // engine -> index into streams
-    // Two routing streams, generations alternating (k_fr_count, k_fr_scan, k_fr_scatter: four dependent trips each, one round of
-    // workgroups — latency, not work: one stream carried 60 of a generation's 95 us and the host waited for it), and one for the answers'
-    // way home (k_fr_out).  rs = routing stream of even generations (and of rule uploads)
-    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr; int n_own_streams = 1;
+    // ONE stream of the front's own: the routing (k_fr_count, k_fr_scan, k_fr_scatter).  The answers' last hop (k_fr_out) rides on the
+    // engines' streams, generation by generation in turn: measured on one box (profiles/r06_front_streams.txt), with it behind the routing
+    // on the same stream the routing stream was the pipeline's bottleneck (it also stalled on every generation's evaluation) and the
+    // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
+    // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
+    // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr; int n_own_streams = 1; bool out_on_eval = false;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -108,12 +111,14 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     HIPCHK(hipStreamCreateWithFlags(&f->rs, hipStreamNonBlocking));
     f->n_own_streams = 1;
     if (const char* v = guber_lab_env("GUBER_FRONT_STREAMS")) f->n_own_streams = std::max(1, std::min(3, atoi(v)));
+    f->out_on_eval = true;
+    if (const char* v = guber_lab_env("GUBER_FRONT_OUT_ON_EVAL")) f->out_on_eval = atoi(v) != 0;
     f->rs2 = f->os = f->rs;
     if (f->n_own_streams >= 2) HIPCHK(hipStreamCreateWithFlags(&f->os, hipStreamNonBlocking));
     if (f->n_own_streams >= 3) HIPCHK(hipStreamCreateWithFlags(&f->rs2, hipStreamNonBlocking));
     if (rule) { const int rc = front_set_rule(f.get(), rule); if (rc) return rc; }
     else f->rule = RouteRule{1, 1, 0, 0, -1, 0, 0, 0, nullptr, nullptr, nullptr};      // one engine: everything is its share
-    const size_t cap = max_n, tiles = (cap + 255) / 256;
+    const size_t cap = max_n, tiles = (cap + FR_TILE - 1) / FR_TILE;
     f->slots.resize(depth);
     for (auto& s : f->slots) {
         // the mirror: request columns, where each request went, the answers in the shares' order, the keys (<= FR_KEY_COPY_MAX bytes each
@@ -163,7 +168,7 @@ extern "C" int guber_front_set_rule(guber_front_t* f, const guber_route_rule_t* 
 static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t* b, int64_t gen) {
     hipStream_t rs = (gen & 1) ? f->rs2 : f->rs;
     // the slot's previous generation has left it: its answers' way home read what this routing writes
-    if (s.out_recorded) { if (rs != f->os) HIPCHK(hipStreamWaitEvent(rs, s.ev_out, 0)); s.out_recorded = false; }
+    if (s.out_recorded) { HIPCHK(hipStreamWaitEvent(rs, s.ev_out, 0)); s.out_recorded = false; }
     s.gen = gen; s.n = b->n; s.routed = true; s.dispatched = false; s.out_done = false;
     s.seq = ++f->seq ? f->seq : ++f->seq;
     for (auto& h : s.hooks) { h->outstanding.store(1); h->recorded.store(false); }      // (1: the dispatcher's own hold until the generation's groups are out)
@@ -173,14 +178,14 @@ static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t
     A.key_bytes = b->key_bytes; A.key_off = b->key_off; A.hits = b->hits; A.limit = b->limit; A.duration = b->duration;
     A.burst = b->burst; A.created_at = b->created_at; A.behavior = b->behavior; A.algorithm = b->algorithm; A.is_owner = b->is_owner;
     A.R = f->rule;
-    const uint32_t tiles = (b->n + 255u) / 256u;
+    const uint32_t tiles = (b->n + FR_TILE - 1u) / FR_TILE;
     guber_engine* e0 = f->eng[0];
     std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);       // (the per-kernel timing's spans and events belong to the first engine)
     if (e0->profiling) pl.lock();
     s.ev_a = nullptr;
     if (e0->profiling) { s.ev_a = e0->get_event(); (void)hipEventRecord(s.ev_a, rs); }
     e0->span_begin(KT_FR_COUNT, b->n, rs);
-    hipLaunchKernelGGL(k_fr_count, dim3(tiles), dim3(256), 0, rs, A);
+    hipLaunchKernelGGL(k_fr_count, dim3(tiles), dim3(FR_TILE), 0, rs, A);
     e0->span_end();
     e0->span_begin(KT_FR_SCAN, b->n, rs);
     hipLaunchKernelGGL(k_fr_scan, dim3(MULTI_MEM_MAX / 4), dim3(FR_SCAN_T), 0, rs, A, tiles, (tiles + FR_SCAN_T - 1) / FR_SCAN_T);
@@ -197,7 +202,10 @@ static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t
 static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     s.out_done = true;
     if (s.n == 0) return 0;
-    for (auto& h : s.hooks) HIPCHK(hipStreamWaitEvent(f->os, h->ev, 0));
+    // (out_on_eval: the answers' last hop rides on one of the engines' streams, generation by generation in turn — those are idle two fifths
+    //  of the time, the routing stream is the pipeline's bottleneck)
+    hipStream_t os = f->out_on_eval ? f->streams[(size_t)s.gen % f->streams.size()] : f->os;
+    for (auto& h : s.hooks) if (h->st != os) HIPCHK(hipStreamWaitEvent(os, h->ev, 0));
     FrOut O{};
     O.n = s.n; O.fwd = s.in.d_fwd;
     O.d_status = s.o_status; O.d_err = s.o_err; O.d_limit = s.o_limit; O.d_remaining = s.o_remaining; O.d_reset_time = s.o_reset;
@@ -205,12 +213,12 @@ static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     guber_engine* e0 = f->eng[0];
     std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);
     if (e0->profiling) pl.lock();
-    e0->span_begin(KT_FR_OUT, s.n, f->os);
-    hipLaunchKernelGGL(k_fr_out, dim3((s.n + 255u) / 256u), dim3(256), 0, f->os, O);
+    e0->span_begin(KT_FR_OUT, s.n, os);
+    hipLaunchKernelGGL(k_fr_out, dim3((s.n + FR_TILE - 1u) / FR_TILE), dim3(256), 0, os, O);
     e0->span_end();
-    if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, f->os); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }
+    if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, os); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }
     if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
-    if (f->n_own_streams > 1) { HIPCHK(hipEventRecord(s.ev_out, f->os)); s.out_recorded = true; }
+    if (os != f->rs) { HIPCHK(hipEventRecord(s.ev_out, os)); s.out_recorded = true; }
     return 0;
 }
 

@@ -9,7 +9,7 @@ namespace guber {
 // getWorker :180-184) and GetRateLimits answers in request order (gubernator.proto:51-54, gubernator.go:203-300) — done for a whole
 // generation of requests that already lie in HBM:
 //   k_fr_count    per request: XXH64 of the key, the placement's rule -> engine, its rank among the tile's requests of that engine
-//                 (stable: arrival order); per tile of 256 requests the requests per engine
+//                 (stable: arrival order); per tile of 1 024 requests the requests per engine
 //   k_fr_scan     one workgroup: where every tile's part of every share starts; places the shares (base[engine]), hands the shares'
 //                 sizes to the host and releases the flag it polls
 //   k_fr_scatter  request i -> place d = base[engine] + tile_base + rank of the mirror: every engine's share is
@@ -18,11 +18,13 @@ namespace guber {
 //                 their requests — share j's keys are packed, key_off[d] = d x width, so k_part's speculative key fetch applies —
 //                 other keys stay where they are and the share carries offset + length (BatchView.key_len)
 //   k_fr_out      answer i = share answer fwd[i]: coalesced writes in arrival order
-// A tile of 256 consecutive requests holds ~256 / n_engines requests of each engine, consecutive in the share: the scattered side of
-// both copy kernels moves runs of ~20 elements, so sectors are used almost fully.
-constexpr uint32_t FR_SCAN_T = 1024;               // threads of k_fr_scan's one workgroup
-constexpr uint32_t FR_SCAN_PER = 16;               // tiles per thread, at most
-constexpr uint32_t FR_MAX_N = FR_SCAN_T * FR_SCAN_PER * 256u;   // 4 194 304 requests per generation
+constexpr uint32_t FR_PER = 4;                     // requests per thread of the copy kernels
+constexpr uint32_t FR_TILE = 256 * FR_PER;         // requests per tile
+constexpr uint32_t FR_RANK_BITS = 10;              // er[i] = engine << 10 | rank among the tile's requests of that engine
+static_assert((1u << FR_RANK_BITS) >= FR_TILE && (MULTI_MEM_MAX << FR_RANK_BITS) <= 65536, "engine and rank share sixteen bits");
+constexpr uint32_t FR_SCAN_T = 1024;               // threads of k_fr_scan's workgroups
+constexpr uint32_t FR_SCAN_PER = 4;                // tiles per thread, at most
+constexpr uint32_t FR_MAX_N = FR_SCAN_T * FR_SCAN_PER * FR_TILE;   // 4 194 304 requests per generation
 constexpr uint32_t FR_KEY_COPY_MAX = 32;           // keys of one width up to this many bytes are copied into the shares
 
 struct FrontCtl {                                   // per slot, device memory, zeroed once
@@ -54,10 +56,16 @@ static_assert(sizeof(FrIn) <= 4096, "kernel arguments are limited to 4 KB");
 // No workgroup waits for another and none takes a ticket: the order between the three steps is the stream's (a device-scope ticket per
 // workgroup was 25 ns each, one after the other: 50 us for a generation of 2 048 tiles, and the scans ran behind it — round 6's first form
 // took 157 us for 524 288 requests with nothing else on the GPU).
-__global__ __launch_bounds__(256) void k_fr_count(FrIn A) {
-    __shared__ uint32_t wtot[4][MULTI_MEM_MAX];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, i = blockIdx.x * 256u + tid;
-    if (tid < 4 * MULTI_MEM_MAX) wtot[tid / MULTI_MEM_MAX][tid % MULTI_MEM_MAX] = 0u;
+// A tile is FR_TILE = 1 024 requests (round 6's second form; the first had 256): a generation has a quarter of the tiles and scan
+// steps, and the runs the copy kernels move (a tile's requests of one engine, consecutive in the share) are four times as long — about
+// 85 elements with twelve engines: sectors are used almost fully.  k_fr_scatter / k_fr_out take four requests per thread (request k of
+// thread t: tile x 1024 + k x 256 + t — coalesced, every load before the first store).
+__global__ __launch_bounds__(FR_TILE) void k_fr_count(FrIn A) {
+    // one request per thread, 1 024 threads: the chain offsets -> key -> hot-key list -> slot table is four dependent trips, and what hides
+    // them is waves in flight (four requests per thread, a quarter of the waves: 24 us instead of 20 for a million requests)
+    __shared__ uint32_t wtot[FR_TILE / 64][MULTI_MEM_MAX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, i = blockIdx.x * FR_TILE + tid;
+    if (tid < (FR_TILE / 64) * MULTI_MEM_MAX) (&wtot[0][0])[tid] = 0u;
     uint32_t e = 0xffu;
     if (i < A.n) {
         // keys of one width: the key's words are requested at the place the first two offsets suggest, together with the request's own
@@ -87,9 +95,13 @@ __global__ __launch_bounds__(256) void k_fr_count(FrIn A) {
     __syncthreads();
     if (i < A.n) {
         for (uint32_t w = 0; w < wave; ++w) rank += wtot[w][e];
-        A.er[i] = (uint16_t)(e << 8 | rank);
+        A.er[i] = (uint16_t)(e << FR_RANK_BITS | rank);
     }
-    if (tid < MULTI_MEM_MAX) A.tile_cnt[blockIdx.x * MULTI_MEM_MAX + tid] = wtot[0][tid] + wtot[1][tid] + wtot[2][tid] + wtot[3][tid];
+    if (tid < MULTI_MEM_MAX) {
+        uint32_t c = 0;
+        for (uint32_t w = 0; w < FR_TILE / 64; ++w) c += wtot[w][tid];
+        A.tile_cnt[blockIdx.x * MULTI_MEM_MAX + tid] = c;
+    }
 }
 
 // FOUR workgroups, one per four engines (one 16-byte word of a tile's counts): the exclusive scan of the tiles' counts (thread t takes
@@ -131,41 +143,51 @@ __global__ __launch_bounds__(FR_SCAN_T) void k_fr_scan(FrIn A, uint32_t nt, uint
 
 __global__ __launch_bounds__(256) void k_fr_scatter(FrIn A) {
     __shared__ uint32_t sbase[MULTI_MEM_MAX];                        // where each engine's share starts: the prefix over the shares' sizes
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (threadIdx.x < MULTI_MEM_MAX) {
         uint32_t b = 0;
         for (uint32_t k = 0; k < threadIdx.x; ++k) b += A.ctl->tot[k];
         sbase[threadIdx.x] = b;
     }
     __syncthreads();
-    if (i >= A.n) return;
-    const uint32_t er = A.er[i], e = er >> 8, rank = er & 255u, tile = blockIdx.x;
-    const uint32_t o0 = A.key_off[i], o1 = A.key_off[i + 1];
-    const int64_t hits = A.hits[i], limit = A.limit[i], duration = A.duration[i];
-    const uint32_t beh = A.behavior ? A.behavior[i] : 0u; const uint8_t algo = A.algorithm ? A.algorithm[i] : (uint8_t)0;
-    const uint32_t d = sbase[e] + A.tile_base[tile * MULTI_MEM_MAX + e] + rank;
+    const uint32_t tile = blockIdx.x, i0 = tile * FR_TILE + threadIdx.x;
     const bool packed = A.ctl->ragged_seq != A.seq;                   // keys of one width: they travel with their requests
-    A.d_fwd[i] = d < A.n ? d : 0u;
-    if (d >= A.n) return;                                            // (cannot happen: the ranks are a permutation; nothing is written out of bounds)
-    A.d_hits[d] = hits; A.d_limit[d] = limit; A.d_duration[d] = duration; A.d_behavior[d] = beh; A.d_algorithm[d] = algo;
-    if (A.burst) A.d_burst[d] = A.burst[i];
-    if (A.created_at) A.d_created_at[d] = A.created_at[i];
-    if (A.is_owner) A.d_is_owner[d] = A.is_owner[i];
-    if (packed) {
-        const uint32_t len = o1 - o0;
-        const uint8_t* src = A.key_bytes + o0; uint8_t* dst = A.d_keys + (size_t)d * len;
-        if (len >= 8) {                                              // whole words, the last one overlapping the one before: nothing is written behind the
-            uint32_t b = 0;                                          // key, whose neighbour's first bytes are another thread's
-            for (; b + 8 <= len; b += 8) { const uint64_t w = ld_key_word(src + b); __builtin_memcpy(dst + b, &w, 8); }
-            if (b < len) { const uint64_t w = ld_key_word(src + len - 8); __builtin_memcpy(dst + len - 8, &w, 8); }
+    uint32_t er[FR_PER], o0[FR_PER], o1[FR_PER], beh[FR_PER]; int64_t hits[FR_PER], limit[FR_PER], duration[FR_PER]; uint8_t algo[FR_PER];
+#pragma unroll
+    for (int k = 0; k < FR_PER; ++k) {                               // every load of the thread's four requests before the first store
+        const uint32_t i = i0 + k * 256u;
+        if (i >= A.n) { er[k] = 0xffffffffu; continue; }
+        er[k] = A.er[i]; o0[k] = A.key_off[i]; o1[k] = A.key_off[i + 1];
+        hits[k] = A.hits[i]; limit[k] = A.limit[i]; duration[k] = A.duration[i];
+        beh[k] = A.behavior ? A.behavior[i] : 0u; algo[k] = A.algorithm ? A.algorithm[i] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < FR_PER; ++k) {
+        const uint32_t i = i0 + k * 256u;
+        if (er[k] == 0xffffffffu) continue;
+        const uint32_t e = er[k] >> FR_RANK_BITS, rank = er[k] & ((1u << FR_RANK_BITS) - 1u);
+        const uint32_t d = sbase[e] + A.tile_base[tile * MULTI_MEM_MAX + e] + rank;
+        A.d_fwd[i] = d < A.n ? d : 0u;
+        if (d >= A.n) continue;                                      // (cannot happen: the ranks are a permutation; nothing is written out of bounds)
+        A.d_hits[d] = hits[k]; A.d_limit[d] = limit[k]; A.d_duration[d] = duration[k]; A.d_behavior[d] = beh[k]; A.d_algorithm[d] = algo[k];
+        if (A.burst) A.d_burst[d] = A.burst[i];
+        if (A.created_at) A.d_created_at[d] = A.created_at[i];
+        if (A.is_owner) A.d_is_owner[d] = A.is_owner[i];
+        if (packed) {
+            const uint32_t len = o1[k] - o0[k];
+            const uint8_t* src = A.key_bytes + o0[k]; uint8_t* dst = A.d_keys + (size_t)d * len;
+            if (len >= 8) {                                          // whole words, the last one overlapping the one before: nothing is written behind the
+                uint32_t b = 0;                                      // key, whose neighbour's first bytes are another thread's
+                for (; b + 8 <= len; b += 8) { const uint64_t w = ld_key_word(src + b); __builtin_memcpy(dst + b, &w, 8); }
+                if (b < len) { const uint64_t w = ld_key_word(src + len - 8); __builtin_memcpy(dst + len - 8, &w, 8); }
+            } else {
+                const uint64_t w = ld_key_word(src);                 // (a key buffer is readable 8 bytes past its last key)
+                for (uint32_t q = 0; q < len; ++q) dst[q] = (uint8_t)(w >> (8 * q));
+            }
+            A.d_key_off[d] = d * len;
+            if (d == A.n - 1) A.d_key_off[A.n] = A.n * len;
         } else {
-            const uint64_t w = ld_key_word(src);                     // (a key buffer is readable 8 bytes past its last key)
-            for (uint32_t k = 0; k < len; ++k) dst[k] = (uint8_t)(w >> (8 * k));
+            A.d_key_off[d] = o0[k]; A.d_key_len[d] = o1[k] - o0[k];
         }
-        A.d_key_off[d] = d * len;
-        if (d == A.n - 1) A.d_key_off[A.n] = A.n * len;
-    } else {
-        A.d_key_off[d] = o0; A.d_key_len[d] = o1 - o0;
     }
 }
 
@@ -175,12 +197,21 @@ struct FrOut {
     uint8_t *status, *err; int64_t *limit, *remaining, *reset_time;                           // the caller's result arrays, arrival order
 };
 __global__ __launch_bounds__(256) void k_fr_out(FrOut A) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= A.n) return;
-    const uint32_t d = A.fwd[i];
-    const uint8_t st = A.d_status[d], er = A.d_err[d];
-    const int64_t l = A.d_limit[d], r = A.d_remaining[d], t = A.d_reset_time[d];
-    A.limit[i] = l; A.remaining[i] = r; A.reset_time[i] = t; A.status[i] = st; A.err[i] = er;
+    const uint32_t i0 = blockIdx.x * FR_TILE + threadIdx.x;
+    uint32_t d[FR_PER]; uint8_t st[FR_PER], er[FR_PER]; int64_t l[FR_PER], r[FR_PER], t[FR_PER];
+#pragma unroll
+    for (int k = 0; k < FR_PER; ++k) d[k] = i0 + k * 256u < A.n ? A.fwd[i0 + k * 256u] : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < FR_PER; ++k) {
+        if (d[k] == 0xffffffffu) continue;
+        st[k] = A.d_status[d[k]]; er[k] = A.d_err[d[k]]; l[k] = A.d_limit[d[k]]; r[k] = A.d_remaining[d[k]]; t[k] = A.d_reset_time[d[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < FR_PER; ++k) {
+        if (d[k] == 0xffffffffu) continue;
+        const uint32_t i = i0 + k * 256u;
+        A.limit[i] = l[k]; A.remaining[i] = r[k]; A.reset_time[i] = t[k]; A.status[i] = st[k]; A.err[i] = er[k];
+    }
 }
 
 }  // namespace guber
