@@ -866,13 +866,14 @@ def finish_distributed(dist):
 
 
 def rocprof_reference(algo):
-    """the committed rocprofv3 summary of this command (profiles/r05_rocprof_summary.json), if any: the same formula on its
-    average kernel duration, so that the line and the file can be checked against each other"""
+    """the committed rocprofv3 summary of this command (profiles/r06_rocprof_summary.json), if any: the kernel the GPU spends most time in
+    with its average launch duration from the trace, so that the line and the file can be checked against each other"""
     try:
-        j = json.load(open(os.path.join(ROOT, "profiles", "r05_rocprof_summary.json")))
+        j = json.load(open(os.path.join(ROOT, "profiles", "r06_rocprof_summary.json")))
         k = j["dominant_kernel"]
-        return {"file": "profiles/r05_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "requests_per_launch": k["requests_per_launch"],
-                "achieved": k["achieved_GBps"], "frac": k["frac"], "command": j.get("command")}
+        return {"file": "profiles/r06_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "max_us": k.get("max_us"), "launches": k.get("launches"),
+                "requests_per_launch": k.get("requests_per_launch"), "achieved": k.get("achieved_GBps"), "frac": k.get("frac"), "command": j.get("command"),
+                "bench_line_of_traced_run": (j.get("bench_lines") or {}).get("routed")}
     except Exception:   # noqa: BLE001
         return None
 
@@ -990,7 +991,10 @@ def main():
             traffic = measured = None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
-                traffic = pipeline_traffic(tj, args.algo, cand, launches, per_launch, B)
+                if routed:                                           # every kernel of the routed pipeline incl. the front's copies, per 65536-request batch
+                    traffic = int(tj["routed"]["corrected_per_batch"] * B / 65536) if args.algo == "token" else None
+                else:
+                    traffic = pipeline_traffic(tj, args.algo, cand, launches, per_launch, B)
                 measured = tj.get("note")
             except Exception:   # noqa: BLE001
                 pass
@@ -999,10 +1003,12 @@ def main():
             issue = None
             try:
                 ij = json.load(open(os.path.join(ROOT, "profiles", "roofline_issue.json")))
+                if ij.get("arrangement", "presplit") != args.headline:
+                    raise KeyError("the committed SQ passes are of the other arrangement")
                 iu = float(ij["issue_us_per_batch"]) * B / 65536
                 issue = {"issue_us_per_step": round(iu, 4), "step_us": round(m["ms_per_step"] * 1e3, 4), "frac": round(iu / (m["ms_per_step"] * 1e3), 4),
                          "insts_per_wave": {k: v["insts_per_wave_all"] for k, v in ij["kernels"].items()},
-                         "what": ("SQ_ACTIVE_INST_ANY of k_part + k_own + k_eval3 per 65536-request batch (quad-cycles a SIMD spent issuing, summed over the chip) x 4 cycles / "
+                         "what": ("SQ_ACTIVE_INST_ANY of every kernel of the pipeline (the front's copies included) per 65536-request batch (quad-cycles a SIMD spent issuing, summed over the chip) x 4 cycles / "
                                   "(1024 SIMDs x 2.4 GHz) over the step time: the share of the step in which EVERY SIMD of the chip would have to be issuing — the resource "
                                   "this pipeline is closest to filling (round 5: fewer instructions per request moved the rate almost one for one, DESIGN.md section 4)"),
                          "source": ij.get("source"), "counters_from": "a separate rocprofv3 --pmc run of this command (committed), not this run"}
@@ -1017,10 +1023,14 @@ def main():
                         "measured": against_ceilings(ctx.ceil, m["value"], rig.access_frac, BYTES_PER_DECISION[args.algo]),
                         "traffic": traffic, "traffic_note": measured,
                         "issue": issue,
-                        "limiter": ("instruction issue, not HBM bytes: the pipeline without any table access is not faster and fewer fabric transactions barely moved it "
-                                    "(round 4: profiles/r04_w_*, r04_x_*), while round 5's instruction diet — 15 % fewer instructions per request in the three kernels — "
-                                    "gave 12.5 % on one box (profiles/r05_d_*, r05_e_*); `issue.frac` is how full the SIMDs' issue slots are on average, the rest is "
-                                    "imbalance between owners, kernel tails on three streams and waves parked at s_waitcnt"),
+                        "limiter": (("the dependencies between the four in-order queues (the HIP runtime gives a process four hardware queues: one routing stream + three for the "
+                                     "tables): every queue is busy ~60 % of the stretch, 2.3 kernels run at a time (profiles/r06_front_timeline.txt); the routed pipeline does the "
+                                     "pre-split one's work plus the front's copies (`traffic` counts them), and the pre-split one is bound by instruction issue (`presplit`, DESIGN.md section 4)")
+                                    if routed else
+                                    ("instruction issue, not HBM bytes: the pipeline without any table access is not faster and fewer fabric transactions barely moved it "
+                                     "(round 4: profiles/r04_w_*, r04_x_*), while round 5's instruction diet — 15 % fewer instructions per request in the three kernels — "
+                                     "gave 12.5 % on one box (profiles/r05_d_*, r05_e_*); `issue.frac` is how full the SIMDs' issue slots are on average, the rest is "
+                                     "imbalance between owners, kernel tails on three streams and waves parked at s_waitcnt")),
                         "kernel": dom,
                         "dominant_kernel_overlapped": {
                             "kernel": dom, "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBPS, 6),

@@ -64,7 +64,7 @@ GPUWorkerPool::GPUWorkerPool(const guber_config_t& cfg, uint32_t batch_limit, ui
     : batch_limit_(batch_limit ? batch_limit : 1000), batch_wait_us_(batch_wait_us ? batch_wait_us : 500) {
     idle_us_ = lab_u32("GUBER_POOL_IDLE_US", 0);                     // optional extra trigger: nobody reserved for this long and all slots written
     depth_ = std::max(1u, std::min(env_u32("GUBER_POOL_DEPTH", 2), kStages - 2));   // batches of one shard on the GPU at a time
-    eager_ = lab_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
+    eager_ = env_u32("GUBER_POOL_EAGER", 1) != 0;                    // 0 = the reference's peer batcher policy alone: limit or wait
     eager_min_ = lab_u32("GUBER_POOL_EAGER_MIN", 4096);
     direct_max_ = env_u32("GUBER_POOL_DIRECT_MAX", 4);               // RPCs of at most this many requests may be evaluated by their caller (0 = never)
     direct_callers_ = lab_u32("GUBER_POOL_DIRECT_CALLERS", 0);       // ... while at most this many calls are in progress (0 = half the shards, at least 2)

@@ -134,7 +134,7 @@ def test_the_product_library_reads_only_the_documented_environment_variables():
     (gubernator_amd/csrc/guber_host.h guber_lab_env; `make -C gubernator_amd/csrc lab`, the tests' CPU builds).  In the product library
     the names are not even in the binary: every GUBER_* name it contains is one of the runtime knobs INTEGRATION.md documents."""
     import subprocess
-    documented = {"GUBER_RCCL_LIB", "GUBER_POOL_MAX_ACTIVE", "GUBER_POOL_REBALANCE_MS", "GUBER_POOL_SPIN_US", "GUBER_POOL_DEPTH", "GUBER_POOL_DIRECT_MAX"}
+    documented = {"GUBER_RCCL_LIB", "GUBER_POOL_MAX_ACTIVE", "GUBER_POOL_REBALANCE_MS", "GUBER_POOL_SPIN_US", "GUBER_POOL_DEPTH", "GUBER_POOL_DIRECT_MAX", "GUBER_POOL_EAGER"}
     out = subprocess.run(["strings", "-n", "8", ga.LIB_PATH if "enginesim" not in ga.LIB_PATH else os.path.join(support.ROOT, "gubernator_amd", "libguber_hip.so")],
                          capture_output=True, text=True, check=True).stdout
     names = set(re.findall(r"^(GUBER_[A-Z0-9_]+)$", out, re.M))

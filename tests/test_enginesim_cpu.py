@@ -60,7 +60,7 @@ def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
 
 
 
-@pytest.mark.parametrize("case,fuse_ep", [("front4", "1"), ("front6x2", "0"), ("front6x3_pieces", "1"), ("front1", "1")])
+@pytest.mark.parametrize("case,fuse_ep", [("front4", "1"), ("front6x3_pieces", "0"), ("front1", "1")])
 def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(enginesim, case, fuse_ep):
     """guber_front_eval_dev (guber_front.h, guber_kernels_front.h): ONE stream of requests in arrival order -> k_fr_count / k_fr_scatter
     (XXH64 + the placement's rule, workers.go:180-184) -> the engines' shares through the fused launches, on one, two and three streams,

@@ -399,7 +399,7 @@ def test_a_new_key_whose_requests_all_fail_in_the_algorithm_is_no_insert(lib, pi
     sim.close()
 
 
-@pytest.mark.parametrize("pipeline,kinds", [(1, "reset+greg"), (0, "greg"), (0, "reset")])
+@pytest.mark.parametrize("pipeline,kinds", [(1, "reset+greg"), (0, "greg")])
 def test_requests_that_change_the_lists_length_are_evaluated_on_their_own(lib, pipeline, kinds):
     """Under a binding cache the eviction pre-pass models every access as "the key is at the front now".  Two kinds of request are not
     that: a TOKEN_BUCKET RESET_REMAINING of a key in the cache removes the item and inserts nothing (algorithms.go:78-90), and a resident
@@ -411,7 +411,7 @@ def test_requests_that_change_the_lists_length_are_evaluated_on_their_own(lib, p
     only_where_the_form_matters(lib, 0)
     cs, nkeys, bsz = 2000, 2600, 1500
     sim, orc = Sim(lib, slots=1 << 15, max_batch=4096, pipeline=pipeline, cache_size=cs), Oracle(cache_size=cs)
-    for step, b in enumerate(streams.length_changing_batches(23, 5, nkeys, bsz, kinds, gregorian)):
+    for step, b in enumerate(streams.length_changing_batches(23, 4, nkeys, bsz, kinds, gregorian)):
         want, got = orc.eval(b), sim.eval(b)
         assert_results_equal(got, want, f"{kinds} step {step}")
         assert sim.counters()[3] == orc.size() <= cs, (step, sim.counters()[3], orc.size())
