@@ -610,7 +610,7 @@ class RoutedRig(Rig):
         super().__init__(ctx, algo, dist_kind, S, duration_ms=duration_ms)
         self.GB = int(gen_batches)
         self.G = self.GB * ctx.B
-        self.front = self.ga.Front(self.engines, self.place, max_n=self.G, depth=int(os.environ.get("GUBER_BENCH_FRONT_DEPTH", "8")))
+        self.front = self.ga.Front(self.engines, self.place, max_n=self.G, depth=int(os.environ.get("GUBER_BENCH_FRONT_DEPTH", "4")))
 
     def gen_now(self, g, now0):
         return now0 + 1 + g * self.GB                               # (the clock advances 1 ms per batch of B on average)

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(FR_TILE) void k_fr_count(FrIn A) {
         if (spec) { const uint8_t* kp = A.key_bytes + off_g; kw[0] = ld_key_word(kp); kw[1] = ld_key_word(kp + 8); kw[2] = ld_key_word(kp + 16); kw[3] = ld_key_word(kp + 24); }
         const uint32_t off = A.key_off[i], len = A.key_off[i + 1] - off;
         e = 0;
+        // (the hash is not handed on to k_part: a column for it costs the copy kernels 32 B per request, measured -2 % on the routed rate with
+        //  k_part hashing less — the pipeline is closer to its transactions than to its instructions: profiles/r06_pass_hash_ab.txt)
         if (A.R.global_engine >= 0 && A.behavior && (A.behavior[i] & 2u)) e = (uint32_t)A.R.global_engine;      // Behavior_GLOBAL: the device's GLOBAL engine
         else if (len != 0 && len <= A.max_key && A.R.n_shards > 1)
             e = route_engine(A.R, (spec && off == off_g && len == len0) ? xxhash64_words4(kw, len, 0) : xxhash64(A.key_bytes + off, len, 0));
@@ -86,12 +88,14 @@ __global__ __launch_bounds__(FR_TILE) void k_fr_count(FrIn A) {
         }
     }
     __syncthreads();
-    uint32_t rank = 0;
-    for (uint32_t k = 0; k < A.n_engines; ++k) {                     // stable: the rank follows the arrival order
-        const unsigned long long m = __ballot(e == k);
-        if (e == k) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wtot[wave][k] = (uint32_t)__popcll(m);
-    }
+    // the lanes of the wave that go to the same engine: four ballots (one per bit of the engine's number) instead of one per engine;
+    // a lane's rank among them follows the arrival order (stable), the group's first lane leaves the group's size
+    unsigned long long same = __ballot(true);
+#pragma unroll
+    for (uint32_t b = 0; b < 4; ++b) { const unsigned long long m = __ballot((e >> b) & 1u); same &= ((e >> b) & 1u) ? m : ~m; }
+    if (e > 15u) same = 0ull;                                        // (lanes behind the generation's end)
+    uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    if (same && rank == 0) wtot[wave][e] = (uint32_t)__popcll(same);
     __syncthreads();
     if (i < A.n) {
         for (uint32_t w = 0; w < wave; ++w) rank += wtot[w][e];
