@@ -288,7 +288,79 @@ def front(n_engines, n_streams, fuse_ep, max_batch=4096):
     place.close()
 
 
+def bench_sequence():
+    """bench.py's own sequence in small, on the CPU build of the engine under AddressSanitizer: twelve engines over three
+    streams with the product's placement; the residency pass (hits = 0, a batch per engine at a time through guber_eval_batch_dev); a
+    pre-split stretch (guber_eval_batches_routed_dev: the stream split by the placement, a shard flushing whenever B of its requests wait);
+    then the routed arrangement (guber_front_eval_dev over generations of four batches, warm-up and timed calls) — every "device" buffer a
+    host allocation, so a kernel or a copy that reads or writes outside one is a report; answers equal ONE oracle fed the same requests"""
+    S, K, B = 12, 60_000, 4096
+    tab = streams.key_table(K)
+    place = ga.Placement(S)
+    place.observe_keys(*streams.keys_for_ids(tab, streams.ZipfSampler(K, seed=990_001).draw(1 << 16)))
+    place.rebalance(0.125, True)
+    sown, _ = place.route_keys(*streams.keys_for_ids(tab, np.arange(K)))
+    heads = {}
+    engs = []
+    for j in range(S):
+        sj = j * 3 // S
+        engs.append(ga.Engine(cache_size=2 * int((sown == j).sum()) + 8 * B + 1024, max_batch=B, stream=heads[sj].stream_handle() if sj in heads else None))
+        heads.setdefault(sj, engs[-1])
+    orc = support.Oracle(cache_size=4 * K)
+    now = streams.NOW0
+    keep = []
+    for j in range(S):                                               # residency pass
+        loc = np.nonzero(sown == j)[0]
+        for lo in range(0, len(loc), B):
+            hb = streams.bench_batch(tab, loc[lo:lo + B], now, hits=0)
+            b, res, cols, rd = dev_batch(hb)
+            engs[j].eval_dev(b, res)
+            engs[j].synchronize()
+            orc.eval(hb)
+    assert sum(e.size() for e in engs) == orc.size() == K
+    zs = streams.ZipfSampler(K, seed=1234)
+    ids = zs.draw(40 * B)
+    # pre-split: per shard the stream's requests in order, flushed B at a time, in flush order
+    which, hbs, cb, cr = [], [], [], []
+    per = [np.nonzero(sown[ids] == j)[0] for j in range(S)]
+    flush = sorted((int(per[j][(q + 1) * B - 1]), j, q) for j in range(S) for q in range(len(per[j]) // B))
+    for step, (_, j, q) in enumerate(flush):
+        hb = streams.bench_batch(tab, ids[per[j][q * B:(q + 1) * B]], now + 1 + step)
+        b, res, cols, rd = dev_batch(hb)
+        keep.append((cols, rd)); which.append(j); hbs.append(hb); cb.append(b); cr.append(res)
+    N = len(which)
+    ga.Engine.eval_routed_dev(engs, (C.c_uint32 * N)(*which), (ga.GuberBatch * N)(*cb), (ga.GuberResult * N)(*cr), N)
+    for s in range(N):
+        want = orc.eval(hbs[s])
+        got = ga.HostResult(hbs[s].n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = keep[s][1][name]
+        support.assert_results_equal(got, want, f"pre-split batch {s} of table {which[s]}")
+    # routed: generations of four batches, a warm-up call and a timed one
+    fr = ga.Front(engs, place, max_n=4 * B, depth=4)
+    ids2 = zs.draw(12 * 4 * B).reshape(12, 4 * B)
+    gens = [streams.bench_batch(tab, ids2[g], now + 1000 + 4 * g) for g in range(12)]
+    for lo, hi in ((0, 4), (4, 12)):
+        part = [dev_gen(hb, False) for hb in gens[lo:hi]]
+        n = hi - lo
+        assert fr.eval_dev((ga.GuberBatch * n)(*[x[0] for x in part]), (ga.GuberResult * n)(*[x[1] for x in part]), n) == n
+        fr.synchronize()
+        for k, hb in enumerate(gens[lo:hi]):
+            want = orc.eval(hb)
+            got = ga.HostResult(hb.n)
+            for name in ("status", "limit", "remaining", "reset_time", "err"):
+                getattr(got, name)[:] = part[k][3][name]
+            support.assert_results_equal(got, want, f"generation {lo + k}")
+    assert fr.stats()["forced_flushes"] == 0 and sum(e.stats()["retries"] for e in engs) == 0
+    assert sum(e.size() for e in engs) == orc.size()
+    fr.close()
+    for e in engs:
+        e.close()
+    place.close()
+
+
 CASES = {
+    "bench_sequence": bench_sequence,
     "front4": lambda: front(4, 1, os.environ.get("GUBER_FUSE_EP") == "1"),
     "front6x2": lambda: front(6, 2, os.environ.get("GUBER_FUSE_EP") == "1"),
     "front6x3_pieces": lambda: front(6, 3, os.environ.get("GUBER_FUSE_EP") == "1", max_batch=1024),

@@ -70,6 +70,13 @@ def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(e
     run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
 
 
+def test_the_benchs_own_sequence_under_the_address_sanitizer(enginesim):
+    """bench.py in small on the CPU engine: residency pass, a pre-split stretch through guber_eval_batches_routed_dev, then the routed
+    headline's guber_front_eval_dev calls, twelve engines over three streams — AddressSanitizer watches every kernel and copy (VERDICT r05
+    item 2: the one GPU memory access fault of round 5 was never reproduced; this is the sequence it happened in)"""
+    run_case(enginesim, "bench_sequence", GUBER_FUSE_EP="1")
+
+
 def test_another_thread_on_tables_whose_evaluation_is_held_back(enginesim):
     """GUBER_FUSE_EP: while one routed call holds k_eval3 launches back, a second thread calls guber_size / guber_get_item on two of its
     tables — it launches what is held back for them before it looks (guber_engine::held), the call's answers stay the oracle's"""
