@@ -147,7 +147,7 @@ __device__ __forceinline__ void part_body(const Table& T, const BatchView& B, co
         if (tid == 0) *W.snap_c = *T.ctr;
         __syncthreads();
         if (tid == 0) {
-            __threadfence_system();
+            __threadfence_system();                                  // (measured in round 6: a relaxed stamp instead changes nothing, profiles/r06_snapshot_release_ab.txt)
             __hip_atomic_store(W.snap_stamp, W.snap_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
