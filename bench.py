@@ -101,7 +101,7 @@ def parse():
     ap.add_argument("--headline", choices=["routed", "presplit"], default="routed",
                     help="routed (the all-inclusive arrangement): ONE raw request stream in arrival order -> routed to the shards on the device -> answers in request "
                          "order, inside the clock; presplit: rounds 2-5's headline (per-shard batches split outside the clock, answers left in shard order)")
-    ap.add_argument("--extras", default="presplit,leaky,expiring,shards_1,uniform,end_to_end,pool,global_sync,two_ranks",
+    ap.add_argument("--extras", default="presplit,routed_leaky,leaky,expiring,shards_1,uniform,end_to_end,pool,global_sync,two_ranks",
                     help="comma list of extra configurations measured after the headline one (N = 1 only); '' = none")
     ap.add_argument("--extra-batches", type=int, default=1024, help="timed distinct batches of the extra configurations")
     ap.add_argument("--dispatch", choices=["threads", "one"], default="one",
@@ -1194,6 +1194,8 @@ def run_extra(name, args, ctx, NOW0, seed):
     warmup = max(4, min(args.warmup, 16))                        # (raised to four batches per shard below)
     if name == "routed":
         return run_routed(args, ctx, NOW0, seed, steps)
+    if name == "routed_leaky":                                      # BASELINE configs[2] in the all-inclusive arrangement
+        return run_routed(args, ctx, NOW0, seed, steps, algo="leaky", dist_kind="zipf")
     if name in ("global_sync", "two_ranks"):
         return run_rehearsal(name, args)
     if name == "end_to_end":

@@ -203,12 +203,13 @@ def dev_gen(hb, full):
     cols = dict(key_bytes=np.ascontiguousarray(np.concatenate([hb.key_bytes, np.zeros(16, np.uint8)])), key_off=np.ascontiguousarray(hb.key_off.view(np.int32)),
                 hits=np.ascontiguousarray(hb.hits), limit=np.ascontiguousarray(hb.limit), duration=np.ascontiguousarray(hb.duration),
                 algorithm=np.ascontiguousarray(hb.algorithm), behavior=np.ascontiguousarray(hb.behavior.view(np.int32)),
-                burst=np.ascontiguousarray(hb.burst) if full else None, created_at=np.ascontiguousarray(hb.created_at) if full else None,
-                is_owner=np.ascontiguousarray(hb.is_owner) if full else None)
+                burst=np.ascontiguousarray(hb.burst) if (full and hb.burst is not None) else None,
+                created_at=np.ascontiguousarray(hb.created_at) if (full and hb.created_at is not None) else None,
+                is_owner=np.ascontiguousarray(hb.is_owner) if (full and hb.is_owner is not None) else None)
     p = {k: (v.ctypes.data if v is not None else None) for k, v in cols.items()}
     r = dict(status=np.full(n, 99, np.uint8), err=np.full(n, 99, np.uint8), limit=np.full(n, -7, np.int64), remaining=np.full(n, -7, np.int64), reset_time=np.full(n, -7, np.int64))
-    b = ga.GuberBatch(n, 0, p["key_bytes"], p["key_off"], p["hits"], p["limit"], p["duration"], p["burst"] if full else None, p["created_at"] if full else None,
-                      p["algorithm"], p["behavior"], p["is_owner"] if full else None, None, None, hb.now_ms)
+    b = ga.GuberBatch(n, 0, p["key_bytes"], p["key_off"], p["hits"], p["limit"], p["duration"], p["burst"], p["created_at"],
+                      p["algorithm"], p["behavior"], p["is_owner"], None, None, hb.now_ms)
     res = ga.GuberResult(r["status"].ctypes.data, r["limit"].ctypes.data, r["remaining"].ctypes.data, r["reset_time"].ctypes.data, r["err"].ctypes.data, 0, 0, 0, 0, 0)
     return b, res, cols, r
 
@@ -359,7 +360,34 @@ def bench_sequence():
     place.close()
 
 
+def front_lru(workers):
+    """tests/test_gpu_front.py test_the_front_over_binding_caches_is_the_references_worker_pool on the CPU build of the engine"""
+    cs, nkeys, G = 2000, 2600, 4096
+    place = ga.Placement(workers)
+    e0 = ga.Engine(cache_size=cs // workers, max_batch=4096)
+    engs = [e0] + [ga.Engine(cache_size=cs // workers, max_batch=4096, stream=e0.stream_handle()) for _ in range(workers - 1)]
+    fr = ga.Front(engs, place, max_n=G, depth=4)
+    orc = support.Oracle(cache_size=cs, workers=workers)
+    for step, hb in enumerate(streams.length_changing_batches(29, 6, nkeys, 3000, "reset+greg", support.gregorian)):
+        hb.greg_expire[:] = 0
+        want = orc.eval(hb)
+        b, res, cols, rd = dev_gen(hb, True)
+        assert fr.eval_dev((ga.GuberBatch * 1)(b), (ga.GuberResult * 1)(res), 1) == 1
+        fr.synchronize()
+        got = ga.HostResult(hb.n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:hb.n] = rd[name]
+        support.assert_results_equal(got, want, f"generation {step}")
+        assert sum(e.size() for e in engs) == orc.size(), (step, [e.size() for e in engs], orc.size())
+    assert sum(e.stats()["unexpired_evictions"] for e in engs) == orc.counters()[3]
+    fr.close()
+    for e in engs:
+        e.close()
+    place.close()
+
+
 CASES = {
+    "front_lru3": lambda: front_lru(3),
     "bench_sequence": bench_sequence,
     "front4": lambda: front(4, 1, os.environ.get("GUBER_FUSE_EP") == "1"),
     "front6x2": lambda: front(6, 2, os.environ.get("GUBER_FUSE_EP") == "1"),

@@ -70,6 +70,12 @@ def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(e
     run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
 
 
+def test_the_front_over_binding_caches_is_the_references_worker_pool(enginesim):
+    """three engines with CacheSize / 3 items each behind a front whose placement is the untouched worker rule == the oracle with three
+    workers (workers.go:125-151,180-184): device routing, per-table eviction pre-passes, requests that change a list's length"""
+    run_case(enginesim, "front_lru3", GUBER_FUSE_EP="1")
+
+
 def test_the_benchs_own_sequence_under_the_address_sanitizer(enginesim):
     """bench.py in small on the CPU engine: residency pass, a pre-split stretch through guber_eval_batches_routed_dev, then the routed
     headline's guber_front_eval_dev calls, twelve engines over three streams — AddressSanitizer watches every kernel and copy (VERDICT r05

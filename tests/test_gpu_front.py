@@ -19,7 +19,7 @@ def dev_gen(torch, dev, hb, full):
     n = hb.n
     cols = dict(key_bytes=np.concatenate([hb.key_bytes, np.zeros(16, np.uint8)]), key_off=hb.key_off.view(np.int32), hits=hb.hits, limit=hb.limit,
                 duration=hb.duration, algorithm=hb.algorithm, behavior=hb.behavior.view(np.int32),
-                burst=hb.burst if full else None, created_at=hb.created_at if full else None, is_owner=hb.is_owner if full else None)
+                burst=hb.burst if full else None, created_at=hb.created_at if full else None, is_owner=hb.is_owner if full else None)   # (None: the column is absent)
     t = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if v is not None else None) for k, v in cols.items()}
     p = {k: (v.data_ptr() if v is not None else None) for k, v in t.items()}
     r = dict(status=torch.full((max(n, 1),), 99, dtype=torch.uint8, device=dev), err=torch.full((max(n, 1),), 99, dtype=torch.uint8, device=dev),
@@ -128,3 +128,38 @@ def test_a_long_stream_of_generations_keeps_every_keys_order():
     for e in engs:
         e.close()
     place.close()
+
+
+@pytest.mark.parametrize("workers", [4, 3])
+def test_the_front_over_binding_caches_is_the_references_worker_pool(workers):
+    """The reference shards its cache over Config.Workers goroutines by the XXH64 of the HashKey (workers.go:125-151: CacheSize / Workers
+    items each; getWorker :180-184) and every worker evicts in its own list's order (lrucache.go:88-149).  A front over `workers` engines
+    whose placement is untouched (its initial table IS getWorker, also for worker counts that do not divide 2^63) with cache_size / workers
+    items each must therefore answer a stream in arrival order exactly like the oracle with that many workers — through device routing,
+    shares, eviction pre-passes per table (the caches bind: 2 600 keys over 2 000 items), requests that change a list's length, and the
+    answers' way home; sizes and unexpired evictions included."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cs, nkeys, G = 2000, 2600, 4096
+    place = ga.Placement(workers) if workers > 1 else None
+    stream = torch.cuda.Stream(device=dev)
+    engs = [ga.Engine(cache_size=cs // workers, max_batch=4096, stream=stream.cuda_stream) for _ in range(workers)]
+    fr = ga.Front(engs, place, max_n=G, depth=4)
+    orc = Oracle(cache_size=cs, workers=workers)
+    gens = list(streams.length_changing_batches(29, 10, nkeys, 3000, "reset+greg", support.gregorian))
+    for step, hb in enumerate(gens):
+        hb.greg_expire[:] = 0                                   # (a front takes its calendar intervals from the device: the engines compute them in UTC,
+        want = orc.eval(hb)                                      #  as support.gregorian does; invalid constants fail on either side)
+        b, res, t, r = dev_gen(torch, dev, hb, True)
+        torch.cuda.synchronize(dev)
+        assert fr.eval_dev((ga.GuberBatch * 1)(b), (ga.GuberResult * 1)(res), 1) == 1
+        fr.synchronize()
+        check(hb, r, want, f"generation {step}")
+        assert sum(e.size() for e in engs) == orc.size(), (step, [e.size() for e in engs], orc.size())
+    assert sum(e.stats()["unexpired_evictions"] for e in engs) == orc.counters()[3]
+    assert sum(e.stats()["eviction_passes"] for e in engs) >= 1
+    fr.close()
+    for e in engs:
+        e.close()
+    if place is not None:
+        place.close()
