@@ -471,7 +471,7 @@ class Front:
     device (XXH64 + the placement's rule: WorkerPool.getWorker, workers.go:180-184) -> evaluated -> answered in ARRIVAL order
     (gubernator.proto:51-54)."""
 
-    def __init__(self, engines, placement=None, max_n=65536, depth=0):
+    def __init__(self, engines, placement=None, max_n=65536, depth=0, global_engine=-1):
         L = lib()
         L.guber_front_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.guber_front_destroy.argtypes = [C.c_void_p]
@@ -486,7 +486,7 @@ class Front:
         self.placement = placement
         hs = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
         self.h = C.c_void_p()
-        rule = placement.export() if placement is not None else None
+        rule = placement.export(global_engine=global_engine) if placement is not None else None   # (global_engine: index of the engine that takes Behavior_GLOBAL requests)
         _check(L.guber_front_create(hs, len(self.engines), C.byref(rule) if rule is not None else None, max_n, depth, C.byref(self.h)))
 
     def eval_dev(self, gen_array, result_array, count):

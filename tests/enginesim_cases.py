@@ -386,7 +386,41 @@ def front_lru(workers):
     place.close()
 
 
+def front_global():
+    """the rule's global_engine: requests that carry Behavior_GLOBAL go to the device's GLOBAL engine whatever their key hashes to (as the
+    pool's routing does: a device keeps the keys of GLOBAL requests in an engine of its own), the others by the placement.  Keys are either
+    always GLOBAL or never in this stream, so ONE oracle sees the same sequence per key; the GLOBAL engine ends up with exactly those keys."""
+    K, G = 3000, 4096
+    tab = streams.key_table(K)
+    place = ga.Placement(2)
+    e0 = ga.Engine(cache_size=1 << 15, max_batch=4096)
+    engs = [e0, ga.Engine(cache_size=1 << 15, max_batch=4096, stream=e0.stream_handle()), ga.Engine(cache_size=1 << 15, max_batch=4096, stream=e0.stream_handle())]
+    fr = ga.Front(engs, place, max_n=G, depth=4, global_engine=2)
+    orc = support.Oracle(cache_size=1 << 20)
+    zs = streams.ZipfSampler(K, seed=41)
+    for g in range(5):
+        ids = zs.draw(G)
+        hb = streams.bench_batch(tab, ids, streams.NOW0 + g * 500, algorithm=g % 2, limit=40, duration=5000)
+        hb.behavior[:] = np.where(ids % 3 == 0, 2, 0).astype(np.uint32)
+        b, res, cols, rd = dev_gen(hb, False)
+        assert fr.eval_dev((ga.GuberBatch * 1)(b), (ga.GuberResult * 1)(res), 1) == 1
+        fr.synchronize()
+        want = orc.eval(hb)
+        got = ga.HostResult(hb.n)
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(got, name)[:] = rd[name]
+        support.assert_results_equal(got, want, f"generation {g}")
+    seen = np.unique(np.concatenate([streams.ZipfSampler(K, seed=41).draw(5 * G)]))
+    assert engs[2].size() == int((seen % 3 == 0).sum()), (engs[2].size(), int((seen % 3 == 0).sum()))
+    assert engs[0].size() + engs[1].size() == int((seen % 3 != 0).sum()) and min(engs[0].size(), engs[1].size()) > 0
+    fr.close()
+    for e in engs:
+        e.close()
+    place.close()
+
+
 CASES = {
+    "front_global": front_global,
     "front_lru3": lambda: front_lru(3),
     "bench_sequence": bench_sequence,
     "front4": lambda: front(4, 1, os.environ.get("GUBER_FUSE_EP") == "1"),

@@ -70,6 +70,11 @@ def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(e
     run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
 
 
+def test_a_front_sends_global_requests_to_the_global_engine(enginesim):
+    """guber_route_rule_t.global_engine: Behavior_GLOBAL requests go to the device's GLOBAL engine, the rest by the placement"""
+    run_case(enginesim, "front_global")
+
+
 def test_the_front_over_binding_caches_is_the_references_worker_pool(enginesim):
     """three engines with CacheSize / 3 items each behind a front whose placement is the untouched worker rule == the oracle with three
     workers (workers.go:125-151,180-184): device routing, per-table eviction pre-passes, requests that change a list's length"""

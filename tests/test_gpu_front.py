@@ -163,3 +163,37 @@ def test_the_front_over_binding_caches_is_the_references_worker_pool(workers):
         e.close()
     if place is not None:
         place.close()
+
+
+def test_global_requests_go_to_the_global_engine():
+    """guber_route_rule_t.global_engine (the pool keeps a device's GLOBAL keys in an engine of its own): requests that carry
+    Behavior_GLOBAL land there whatever their key hashes to, the others follow the placement; answers equal ONE oracle (a key is either always
+    GLOBAL or never in this stream)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    K, G = 30_000, 32768
+    tab = streams.key_table(K)
+    place = ga.Placement(2)
+    stream = torch.cuda.Stream(device=dev)
+    engs = [ga.Engine(cache_size=1 << 17, max_batch=32768, stream=stream.cuda_stream) for _ in range(3)]
+    fr = ga.Front(engs, place, max_n=G, depth=4, global_engine=2)
+    orc = Oracle(cache_size=1 << 20)
+    zs = streams.ZipfSampler(K, seed=41)
+    seen = []
+    for g in range(5):
+        ids = zs.draw(G)
+        seen.append(ids)
+        hb = streams.bench_batch(tab, ids, streams.NOW0 + g * 500, algorithm=g % 2, limit=40, duration=5000)
+        hb.behavior[:] = np.where(ids % 3 == 0, 2, 0).astype(np.uint32)
+        b, res, t, r = dev_gen(torch, dev, hb, False)
+        torch.cuda.synchronize(dev)
+        assert fr.eval_dev((ga.GuberBatch * 1)(b), (ga.GuberResult * 1)(res), 1) == 1
+        fr.synchronize()
+        check(hb, r, orc.eval(hb), f"generation {g}")
+    u = np.unique(np.concatenate(seen))
+    assert engs[2].size() == int((u % 3 == 0).sum())
+    assert engs[0].size() + engs[1].size() == int((u % 3 != 0).sum()) and min(engs[0].size(), engs[1].size()) > 0
+    fr.close()
+    for e in engs:
+        e.close()
+    place.close()
