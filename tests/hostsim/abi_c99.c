@@ -85,8 +85,67 @@ static int call_sequence(int really) {
     return rc;
 }
 
+/* the front of a GPU's shards from C — two engines on one stream, the placement's rule exported, one generation of
+ * requests in arrival order in device-visible memory (guber_alloc_pinned: what a binding without a HIP allocator of its own has), the
+ * answers in arrival order.  Two requests of one key must be answered in their order whatever engine the key lives on. */
+static int front_sequence(void) {
+    enum { N = 6, L = 4 };
+    guber_config_t cfg;
+    guber_engine_t* eng[2] = {NULL, NULL};
+    guber_placement_t* place = NULL;
+    guber_front_t* front = NULL;
+    guber_front_stats_t fst;
+    struct guber_route_rule rule;
+    guber_batch_t gen;
+    guber_result_t res;
+    uint8_t* mem;
+    int rc, i;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (uint32_t)sizeof cfg; cfg.cache_size = 1000; cfg.max_batch = 1024;
+    rc = guber_engine_create(&cfg, &eng[0]);
+    if (rc != GUBER_OK) return rc;
+    cfg.stream = guber_engine_stream(eng[0]);
+    rc = guber_engine_create(&cfg, &eng[1]);
+    if (rc == GUBER_OK) rc = guber_placement_create(2, 0, &place);
+    if (rc == GUBER_OK) rc = guber_placement_export(place, &rule);
+    if (rc == GUBER_OK) { rule.global_engine = -1; rc = guber_front_create(eng, 2, &rule, 1024, 0, &front); }
+    mem = (uint8_t*)guber_alloc_pinned(4096);
+    if (rc == GUBER_OK && mem) {
+        uint8_t* keys = mem; uint32_t* off = (uint32_t*)(mem + 256);
+        int64_t* hits = (int64_t*)(mem + 512); int64_t* limit = hits + N; int64_t* duration = limit + N;
+        uint32_t* beh = (uint32_t*)(mem + 1024); uint8_t* algo = mem + 1280;
+        int64_t* o_limit = (int64_t*)(mem + 2048); int64_t* o_rem = o_limit + N; int64_t* o_reset = o_rem + N;
+        uint8_t* o_status = mem + 3072; uint8_t* o_err = mem + 3200;
+        memset(mem, 0, 4096);
+        memcpy(keys, "k_aak_bbk_aak_cck_bbk_aa", N * L);                   /* a b a c b a */
+        for (i = 0; i <= N; ++i) off[i] = (uint32_t)(i * L);
+        for (i = 0; i < N; ++i) { hits[i] = 1; limit[i] = 2; duration[i] = 60000; }
+        memset(&gen, 0, sizeof gen); memset(&res, 0, sizeof res);
+        gen.n = N; gen.key_bytes = keys; gen.key_off = off; gen.hits = hits; gen.limit = limit; gen.duration = duration;
+        gen.behavior = beh; gen.algorithm = algo; gen.now_ms = 1700000000000LL;
+        res.status = o_status; res.limit = o_limit; res.remaining = o_rem; res.reset_time = o_reset; res.err = o_err;
+        rc = guber_front_eval_dev(front, &gen, &res, 1, NULL);
+        if (rc == GUBER_OK) rc = guber_front_synchronize(front);
+        if (rc == GUBER_OK) rc = guber_front_stats(front, &fst);
+        /* key a: 1, 0 left, then refused; b: 1, 0; c: 1 — in request order */
+        if (rc == GUBER_OK && !(o_rem[0] == 1 && o_rem[2] == 0 && o_status[5] == GUBER_STATUS_OVER_LIMIT && o_rem[1] == 1 && o_rem[4] == 0 && o_rem[3] == 1 &&
+                                o_status[0] == GUBER_STATUS_UNDER_LIMIT && fst.generations == 1)) {
+            printf("front: answers out of order: %lld %lld %lld %lld %lld status[5] %d\n", (long long)o_rem[0], (long long)o_rem[1], (long long)o_rem[2], (long long)o_rem[3], (long long)o_rem[4], o_status[5]);
+            rc = GUBER_E_INVALID_ARG;
+        }
+    }
+    if (rc != GUBER_OK) printf("front: %s (%s)\n", guber_strerror(rc), guber_last_error());
+    guber_front_destroy(front);
+    guber_free_pinned(mem);
+    guber_placement_destroy(place);
+    if (eng[1]) guber_engine_destroy(eng[1]);
+    if (eng[0]) guber_engine_destroy(eng[0]);
+    return rc;
+}
+
 int main(int argc, char** argv) {
-    const int rc = call_sequence(argc > 1 && !strcmp(argv[1], "--gpu"));
+    int rc = call_sequence(argc > 1 && !strcmp(argv[1], "--gpu"));
+    if (rc == GUBER_OK && argc > 1 && !strcmp(argv[1], "--gpu")) rc = front_sequence();
     (void)argv;
     if (argc > 1) return rc == GUBER_OK ? 0 : 1;
     return rc == GUBER_E_NO_DEVICE ? 0 : 2;       /* no GPU: the product fails loudly, it has no CPU path */
