@@ -865,15 +865,20 @@ def finish_distributed(dist):
     os._exit(0)
 
 
-def rocprof_reference(algo):
-    """the committed rocprofv3 summary of this command (profiles/r06_rocprof_summary.json), if any: the kernel the GPU spends most time in
-    with its average launch duration from the trace, so that the line and the file can be checked against each other"""
+def rocprof_reference(kernel):
+    """the committed rocprofv3 summary of this command (profiles/r06_rocprof_summary.json), if any: the average launch duration of `kernel`
+    (the one the line's `roofline.kernel` names) from the trace, beside the kernel the trace's GPU spent most time in — so that the line and
+    the file can be checked against each other.  (The traced run is slower than an untraced one — the profiler's interception costs the host
+    that enqueues ~25 launches per generation —, so its kernels see less contention: its averages are a few microseconds below the line's.)"""
     try:
         j = json.load(open(os.path.join(ROOT, "profiles", "r06_rocprof_summary.json")))
-        k = j["dominant_kernel"]
-        return {"file": "profiles/r06_rocprof_summary.json", "kernel": k["name"], "avg_us": k["avg_us"], "max_us": k.get("max_us"), "launches": k.get("launches"),
-                "requests_per_launch": k.get("requests_per_launch"), "achieved": k.get("achieved_GBps"), "frac": k.get("frac"), "command": j.get("command"),
-                "bench_line_of_traced_run": (j.get("bench_lines") or {}).get("routed")}
+        ks = (j.get("kernels") or {}).get("routed") or {}
+        k = ks.get(kernel)
+        dom = j.get("dominant_kernel") or {}
+        return {"file": "profiles/r06_rocprof_summary.json", "kernel": kernel,
+                "avg_us": round(k["avg_us"], 3) if k else None, "max_us": round(k["max_us"], 3) if k else None, "launches": k["launches"] if k else None,
+                "trace_dominant_kernel": {"name": dom.get("name"), "avg_us": dom.get("avg_us"), "max_us": dom.get("max_us"), "launches": dom.get("launches")},
+                "command": j.get("command"), "bench_line_of_traced_run": (j.get("bench_lines") or {}).get("routed")}
     except Exception:   # noqa: BLE001
         return None
 
@@ -1044,7 +1049,7 @@ def main():
                         "kernel_timing": (f"HIP events around every launch of {args.profile_steps} further distinct batches dispatched exactly like the timed "
                                           "region (all shards' streams overlapping; a launch carries the next batch of up to four shards)") if fused
                         else f"HIP events around every launch of {args.profile_steps} further distinct batches on the engine stream, one batch in flight",
-                        "rocprof": rocprof_reference(args.algo)}
+                        "rocprof": rocprof_reference(dom) if routed else None}
         if latency is not None:
             latency = {"idle": latency, "under_load": rig.latency_under_load(),
                        "note": "the BASELINE metric pairs decisions/s with p99 batch latency: `under_load` is the latency in the regime `value` is measured in"}
