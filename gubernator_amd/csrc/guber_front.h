@@ -49,6 +49,8 @@ struct guber_front {
 };
 
 static size_t front_col(size_t bytes) { return (bytes + 63) & ~(size_t)63; }
+// a generation as the front's internals see it: the caller's guber_batch_t, or columns whose keys are rows (the device wire decoder's output)
+struct FrontGen { guber_batch_t b; uint32_t key_stride = 0; const uint32_t* key_len = nullptr; };
 
 extern "C" void guber_front_destroy(guber_front_t* f) {
     if (!f) return;
@@ -165,7 +167,8 @@ extern "C" int guber_front_set_rule(guber_front_t* f, const guber_route_rule_t* 
 }
 
 // k_fr_count, k_fr_scan and k_fr_scatter of generation g on its routing stream
-static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t* b, int64_t gen) {
+static int front_route(guber_front* f, guber_front::Slot& s, const FrontGen* fg, int64_t gen) {
+    const guber_batch_t* b = &fg->b;
     hipStream_t rs = (gen & 1) ? f->rs2 : f->rs;
     // the slot's previous generation has left it: its answers' way home read what this routing writes
     if (s.out_recorded) { HIPCHK(hipStreamWaitEvent(rs, s.ev_out, 0)); s.out_recorded = false; }
@@ -175,7 +178,7 @@ static int front_route(guber_front* f, guber_front::Slot& s, const guber_batch_t
     if (b->n == 0) return 0;
     FrIn& A = s.in;
     A.n = b->n; A.n_engines = (uint32_t)f->eng.size(); A.max_key = f->max_key; A.seq = s.seq;
-    A.key_bytes = b->key_bytes; A.key_off = b->key_off; A.hits = b->hits; A.limit = b->limit; A.duration = b->duration;
+    A.key_bytes = b->key_bytes; A.key_off = b->key_off; A.key_stride = fg->key_stride; A.key_len = fg->key_len; A.hits = b->hits; A.limit = b->limit; A.duration = b->duration;
     A.burst = b->burst; A.created_at = b->created_at; A.behavior = b->behavior; A.algorithm = b->algorithm; A.is_owner = b->is_owner;
     A.R = f->rule;
     const uint32_t tiles = (b->n + FR_TILE - 1u) / FR_TILE;
@@ -230,14 +233,24 @@ static bool front_evals_launched(const guber_front::Slot& s) {
 // gens[k] -> results[k], k = 0 .. count-1: every pointer inside is a DEVICE pointer, requests in arrival order, answers in arrival
 // order.  Asynchronous: returns when everything is enqueued (guber_front_synchronize waits).  The caller's arrays must stay valid and
 // their contents ready (produced before the call, on any stream the caller has synchronised with) until then.
+static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done);
 extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens, guber_result_t* results, uint32_t count, uint32_t* done) {
     if (done) *done = 0;
     if (!f || (count && (!gens || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
+    std::vector<FrontGen> g(count);
     for (uint32_t k = 0; k < count; ++k) {
         const int rc = check_batch_args(&gens[k], &results[k]);
         if (rc) return rc;
-        if (gens[k].n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "generation larger than the front was created for");
-        if (gens[k].greg_expire || gens[k].greg_duration) return fail(GUBER_E_INVALID_ARG, "a front takes its calendar intervals from the device");
+        g[k].b = gens[k];
+    }
+    return front_eval(f, g.data(), results, count, done);
+}
+static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done) {
+    if (done) *done = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        if (gens[k].b.n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "generation larger than the front was created for");
+        if (gens[k].b.greg_expire || gens[k].b.greg_duration) return fail(GUBER_E_INVALID_ARG, "a front takes its calendar intervals from the device");
+        if (gens[k].key_stride & 7u) return fail(GUBER_E_INVALID_ARG, "key rows are a multiple of 8 bytes apart");
         guber_result_t* r = &results[k];
         r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
     }
@@ -284,7 +297,7 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
         }
         if (rc) break;
         guber_front::Slot& s = slot_of(k);
-        const guber_batch_t* b = &gens[k];
+        const guber_batch_t* b = &gens[k].b;
         if (s.n) {
             // the shares' sizes (in pinned memory since k_fr_scan: normally long there)
             auto reported = [&]() {

@@ -43,6 +43,8 @@ struct FrIn {
     uint32_t n, n_engines, max_key, seq;
     // the generation as the caller holds it (HBM, arrival order); burst / created_at / is_owner may be null
     const uint8_t* key_bytes; const uint32_t* key_off;
+    // keys as rows instead (the device wire decoder's output): key i = key_bytes + i * key_stride, key_len[i] bytes; key_stride a multiple of 8
+    uint32_t key_stride; const uint32_t* key_len;
     const int64_t *hits, *limit, *duration, *burst, *created_at; const uint32_t* behavior; const uint8_t *algorithm, *is_owner;
     // scratch of the slot
     uint16_t* er; uint32_t* tile_cnt; uint32_t* tile_base; FrontCtl* ctl; FrontHost* host;
@@ -52,6 +54,10 @@ struct FrIn {
     RouteRule R;
 };
 static_assert(sizeof(FrIn) <= 4096, "kernel arguments are limited to 4 KB");
+__device__ __forceinline__ uint32_t fr_key_off(const FrIn& A, uint32_t i) { return A.key_stride ? i * A.key_stride : A.key_off[i]; }
+__device__ __forceinline__ uint32_t fr_key_len(const FrIn& A, uint32_t i, uint32_t off) { return A.key_stride ? A.key_len[i] : A.key_off[i + 1] - off; }
+// the width the generation's keys have if they all have one (the first key's), and where its keys end
+__device__ __forceinline__ uint32_t fr_len0(const FrIn& A) { return A.key_stride ? A.key_len[0] : A.key_off[1] - A.key_off[0]; }
 
 // No workgroup waits for another and none takes a ticket: the order between the three steps is the stream's (a device-scope ticket per
 // workgroup was 25 ns each, one after the other: 50 us for a generation of 2 048 tiles, and the scans ran behind it — round 6's first form
@@ -70,12 +76,14 @@ __global__ __launch_bounds__(FR_TILE) void k_fr_count(FrIn A) {
     if (i < A.n) {
         // keys of one width: the key's words are requested at the place the first two offsets suggest, together with the request's own
         // offsets, and used if those confirm the guess (as k_part does: one dependent trip less)
-        const uint32_t o0 = A.key_off[0], len0 = A.key_off[1] - o0, oend = A.key_off[A.n];
-        const uint32_t off_g = o0 + i * len0;
+        // (keys as rows: a row's place is known, its length is the guess; 32 bytes of the row are readable when the rows are that long)
+        const uint32_t len0 = fr_len0(A);
+        const uint32_t o0 = A.key_stride ? 0u : A.key_off[0], oend = A.key_stride ? A.n * A.key_stride : A.key_off[A.n];
+        const uint32_t off_g = A.key_stride ? i * A.key_stride : o0 + i * len0;
         uint64_t kw[4] = {0, 0, 0, 0};
-        const bool spec = len0 != 0 && len0 < 32 && (uint64_t)off_g + 32 <= (uint64_t)oend + 8;    // (the buffer is readable 8 bytes past the last key)
+        const bool spec = len0 != 0 && len0 < 32 && (A.key_stride ? A.key_stride >= 32u : (uint64_t)off_g + 32 <= (uint64_t)oend + 8);    // (a packed buffer is readable 8 bytes past the last key)
         if (spec) { const uint8_t* kp = A.key_bytes + off_g; kw[0] = ld_key_word(kp); kw[1] = ld_key_word(kp + 8); kw[2] = ld_key_word(kp + 16); kw[3] = ld_key_word(kp + 24); }
-        const uint32_t off = A.key_off[i], len = A.key_off[i + 1] - off;
+        const uint32_t off = fr_key_off(A, i), len = fr_key_len(A, i, off);
         e = 0;
         // (the hash is not handed on to k_part: a column for it costs the copy kernels 32 B per request, measured -2 % on the routed rate with
         //  k_part hashing less — the pipeline is closer to its transactions than to its instructions: profiles/r06_pass_hash_ab.txt)
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(FR_SCAN_T) void k_fr_scan(FrIn A, uint32_t nt, uint
     }
     if (q == 0 && tid == 0) {
         const uint32_t ragged = __hip_atomic_load(&A.ctl->ragged_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == A.seq ? 1u : 0u;
-        const uint32_t len0 = A.key_off[1] - A.key_off[0];
+        const uint32_t len0 = fr_len0(A);
         __hip_atomic_store(&A.host->w[MULTI_MEM_MAX], (unsigned long long)A.seq << 32 | ragged << 8 | (len0 < 255u ? len0 : 255u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void k_fr_scatter(FrIn A) {
     for (int k = 0; k < FR_PER; ++k) {                               // every load of the thread's four requests before the first store
         const uint32_t i = i0 + k * 256u;
         if (i >= A.n) { er[k] = 0xffffffffu; continue; }
-        er[k] = A.er[i]; o0[k] = A.key_off[i]; o1[k] = A.key_off[i + 1];
+        er[k] = A.er[i]; o0[k] = fr_key_off(A, i); o1[k] = o0[k] + fr_key_len(A, i, o0[k]);
         hits[k] = A.hits[i]; limit[k] = A.limit[i]; duration[k] = A.duration[i];
         beh[k] = A.behavior ? A.behavior[i] : 0u; algo[k] = A.algorithm ? A.algorithm[i] : (uint8_t)0;
     }

@@ -210,6 +210,47 @@ extern "C" int guber_wire_dev_eval(guber_wire_dev_t* d, guber_result_t* r) {
     return GUBER_OK;
 }
 
+// The decoded batch through a FRONT (guber_front.h) instead of the decoder's own engine: the items — in the order of their RPCs, i.e. in
+// arrival order — are routed to the front's engines on the device, evaluated there and answered in arrival order; results to host arrays
+// of n_items entries.  Decode (k_wire_*), routing (k_fr_*), evaluation and the answers' order all happen in HBM: what the pool's callers
+// do per request on the host today (hash, placement, copy: DESIGN.md 5b) has a device counterpart for every step.  The decoder's engine
+// only lends its stream to the decode; it need not be one of the front's.
+extern "C" int guber_wire_dev_eval_front(guber_wire_dev_t* d, guber_front_t* f, guber_result_t* r) {
+    if (!d || !f || !r) return fail(GUBER_E_INVALID_ARG, "null argument");
+    const uint32_t n = d->n_items;
+    r->over_limit_count = r->cache_hits = r->cache_misses = r->unexpired_evictions = 0; r->cache_size = 0;
+    if (!n) return GUBER_OK;
+    if (!r->status || !r->limit || !r->remaining || !r->reset_time || !r->err) return fail(GUBER_E_INVALID_ARG, "result is missing an array");
+    if (n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "more items than the front's generations hold");
+    const size_t M = d->max_items;
+    FrontGen g;
+    memset(&g.b, 0, sizeof g.b);
+    g.b.n = n; g.b.key_bytes = d->out.key_rows; g.b.hits = d->out.hits; g.b.limit = d->out.limit; g.b.duration = d->out.duration; g.b.burst = d->out.burst;
+    g.b.created_at = d->out.created_at; g.b.algorithm = d->out.algorithm; g.b.behavior = d->out.behavior; g.b.is_owner = d->out.is_owner; g.b.now_ms = d->now_ms;
+    g.key_stride = d->stride; g.key_len = d->out.key_len;
+    guber_result_t dr{};
+    dr.status = d->d_out8.p; dr.err = d->d_out8.p + M; dr.limit = d->d_out64.p; dr.remaining = d->d_out64.p + M; dr.reset_time = d->d_out64.p + 2 * M;
+    {   // (the decode ran on the decoder's engine's stream and was synchronised there: guber_wire_dev_decode* read its verdicts back)
+        const int rc = front_eval(f, &g, &dr, 1, nullptr);
+        if (rc) return rc;
+    }
+    {
+        const int rc = guber_front_synchronize(f);
+        if (rc) return rc;
+    }
+    guber_engine* e = d->e;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    hipStream_t st = e->stream;
+    HIPCHK(hipMemcpyAsync(r->status, d->d_out8.p, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->err, d->d_out8.p + M, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->limit, d->d_out64.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->remaining, d->d_out64.p + M, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r->reset_time, d->d_out64.p + 2 * M, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return GUBER_OK;
+}
+
 // The decoded columns on the host (for response encoding and for tests): pointers into the decoder's own pinned memory, valid until
 // the next decode.
 extern "C" int guber_wire_dev_columns(guber_wire_dev_t* d, guber_wire_columns_t* c) {

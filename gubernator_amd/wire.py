@@ -15,7 +15,7 @@ WIRE_SYMBOLS = [
     "guber_wire_eval", "guber_wire_encode_bound", "guber_wire_encode_responses",
     "guber_wire_items_create", "guber_wire_items_destroy", "guber_wire_decode_globals", "guber_wire_encode_globals",
     "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_buffer", "guber_wire_dev_decode_staged",
-    "guber_wire_dev_eval", "guber_wire_dev_columns",
+    "guber_wire_dev_eval", "guber_wire_dev_eval_front", "guber_wire_dev_columns",
 ]
 _bound = False
 
@@ -248,6 +248,16 @@ class DevWireDecoder:
         from .abi import HostResult
         res = HostResult(max(self.n, 1))
         rc = self.L.guber_wire_dev_eval(self.h, C.byref(res.c))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        return res
+
+    def eval_front(self, front):
+        """the decoded batch through a front (guber_front_*): routed to the front's engines on the device, answered in the items' order"""
+        from .abi import HostResult
+        self.L.guber_wire_dev_eval_front.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(GuberResult)]
+        res = HostResult(max(self.n, 1))
+        rc = self.L.guber_wire_dev_eval_front(self.h, front.h, C.byref(res.c))
         if rc:
             raise GuberError(rc, lib().guber_last_error().decode())
         return res

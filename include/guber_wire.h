@@ -123,6 +123,7 @@ int guber_wire_encode_globals(const uint8_t* key_bytes, const uint32_t* key_off,
  *                           already lie in it (offs[r] 16-byte aligned, ascending, not overlapping, 16 bytes of room behind the
  *                           last): a receive path that reads its sockets straight into the buffer skips guber_wire_dev_decode's copy
  *   guber_wire_dev_eval     the batch through the engine (as guber_eval_batch_dev), results to host arrays of n_items entries
+ *   guber_wire_dev_eval_front  the batch through a front over several engines: decode, routing, evaluation and the answers' order in HBM
  *   guber_wire_dev_columns  the decoded columns copied to host memory (keys as rows of key_stride bytes + key_len): what
  *                           guber_wire_encode_responses-style code and the tests read */
 #define GUBER_WIRE_PRE_DEAD 255
@@ -142,6 +143,9 @@ int guber_wire_dev_buffer(guber_wire_dev_t* d, uint8_t** buf, size_t* cap);
 int guber_wire_dev_decode_staged(guber_wire_dev_t* d, const uint32_t* offs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
                                  uint32_t max_per_rpc, int64_t now_ms, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items);
 int guber_wire_dev_eval(guber_wire_dev_t* d, guber_result_t* r);
+/* the decoded batch through a front (include/guber_gpu.h guber_front_*) instead: routed to the front's engines on the device, evaluated there,
+ * answered in the order of the RPCs' items; results to host arrays of n_items entries (n_items <= the front's max_n) */
+int guber_wire_dev_eval_front(guber_wire_dev_t* d, guber_front_t* f, guber_result_t* r);
 int guber_wire_dev_columns(guber_wire_dev_t* d, guber_wire_columns_t* c);
 
 #ifdef __cplusplus

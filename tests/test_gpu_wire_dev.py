@@ -205,3 +205,46 @@ def test_device_decoded_batches_evaluate_like_the_oracle_and_report_throughput()
             dec2.decode_staged([8], [16], now)                   # (an offset that is not 16-byte aligned)
         dec2.close()
     dec.close(); e.close(); o.close()
+
+
+@pytest.mark.parametrize("fixed_width", [False, True], ids=["ragged_keys", "keys_of_one_width"])
+def test_device_decoded_batches_through_a_front_over_four_tables(fixed_width):
+    """guber_wire_dev_eval_front: serialized RPC payloads -> decoded on the device (items in the order of their RPCs: arrival order, keys as
+    rows) -> routed to four tables by the front (XXH64 + the placement's rule) -> evaluated -> answered in the items' order: equal to ONE
+    oracle fed the flat item list.  Keys of one width travel with their requests into the shares (packed), ragged ones stay in the decoder's
+    rows; items the decoder pre-rejected (an empty unique_key: an empty key row) keep their place and are answered with the item error."""
+    rng = np.random.default_rng(5)
+    place = ga.Placement(4)
+    e0 = ga.Engine(cache_size=1 << 16, max_batch=16384, max_key_bytes=64)
+    engs = [e0] + [ga.Engine(cache_size=1 << 16, max_batch=16384, max_key_bytes=64, stream=e0.stream_handle()) for _ in range(3)]
+    fr = ga.Front(engs, place, max_n=16384, depth=4)
+    dec = gw.DevWireDecoder(e0, max_items=16384, max_payload_bytes=2 << 20, max_rpcs=256)
+    o = support.Oracle(cache_size=1 << 20)
+    now = NOW
+    for rnd in range(4):
+        def ukey():
+            k = int(rng.integers(0, 2000))
+            return ("acct:%06d" % k) if fixed_width else ("acct:%d" % k) + "x" * int(k % 5)
+        rpcs = [[dict(name="ns_1" if fixed_width else "ns_%d" % rng.integers(0, 12), unique_key=ukey(), hits=1, limit=20, duration=60_000, algorithm=int(rng.integers(0, 2)),
+                      behavior=0, burst=0, created_at=0) for _ in range(int(rng.integers(1, 600)))] for _ in range(12)]
+        if not fixed_width:
+            rpcs[3][0]["unique_key"] = ""                          # gubernator.go:208-211: answered in place with the reference's error
+        payloads = [wire_replay.pb_request(r) for r in rpcs]
+        status, first, count, n = dec.decode(payloads, now)
+        assert (status == 0).all()
+        got = dec.eval_front(fr)
+        flat = [r for reqs in rpcs for r in reqs]
+        ok = np.array([bool(r["unique_key"]) for r in flat])
+        good = [r for r in flat if r["unique_key"]]
+        want = o.eval(support.HostBatch([expected_key(r) for r in good], 1, 20, 60_000, now, algorithm=np.array([r["algorithm"] for r in good], np.uint8)))
+        assert (got.err[:n][~ok] == 4).all()                       # GUBER_ITEM_E_EMPTY_KEY: never reached a bucket
+        sel = ga.HostResult(len(good))
+        for name in ("status", "limit", "remaining", "reset_time", "err"):
+            getattr(sel, name)[:] = getattr(got, name)[:n][ok]
+        support.assert_results_equal(sel, want, f"round {rnd}")
+        now += 700
+    assert sum(e.size() for e in engs) == o.size() and min(e.size() for e in engs) > 0
+    dec.close(); fr.close()
+    for e in engs:
+        e.close()
+    place.close(); o.close()
