@@ -32,13 +32,13 @@ struct guber_front {
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
     struct Slot {
         DevBuf<uint8_t> mem; CohBuf<FrontHost> host;
-        FrIn in{}; FrOut out{};
+        FrIn in{};
         uint8_t *o_status = nullptr, *o_err = nullptr; int64_t *o_limit = nullptr, *o_remaining = nullptr, *o_reset = nullptr;
         hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_a = nullptr; bool out_recorded = false;
         std::vector<std::unique_ptr<EvalHook>> hooks;   // one per engine stream
         uint32_t seq = 0, n = 0;
         int64_t gen = -1;                               // the generation the slot holds (-1: free)
-        bool routed = false, dispatched = false, out_done = true;
+        bool dispatched = false;
     };
     std::vector<Slot> slots;
     uint64_t generations = 0, forced_flushes = 0, host_waits = 0; double host_wait_ms = 0;
@@ -172,7 +172,7 @@ static int front_route(guber_front* f, guber_front::Slot& s, const FrontGen* fg,
     hipStream_t rs = (gen & 1) ? f->rs2 : f->rs;
     // the slot's previous generation has left it: its answers' way home read what this routing writes
     if (s.out_recorded) { HIPCHK(hipStreamWaitEvent(rs, s.ev_out, 0)); s.out_recorded = false; }
-    s.gen = gen; s.n = b->n; s.routed = true; s.dispatched = false; s.out_done = false;
+    s.gen = gen; s.n = b->n; s.dispatched = false;
     s.seq = ++f->seq ? f->seq : ++f->seq;
     for (auto& h : s.hooks) { h->outstanding.store(1); h->recorded.store(false); }      // (1: the dispatcher's own hold until the generation's groups are out)
     if (b->n == 0) return 0;
@@ -203,7 +203,6 @@ static int front_route(guber_front* f, guber_front::Slot& s, const FrontGen* fg,
 
 // the answers of the slot's generation home, in arrival order (every evaluation of the generation has been launched)
 static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
-    s.out_done = true;
     if (s.n == 0) return 0;
     // (out_on_eval: the answers' last hop rides on one of the engines' streams, generation by generation in turn — those are idle two fifths
     //  of the time, the routing stream is the pipeline's bottleneck)
