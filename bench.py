@@ -1186,6 +1186,9 @@ def main():
         if world > 1 and parity is None and not args.no_cpu_baseline:
             raise SystemExit("no parity verdict for an N > 1 run: refusing to report a number")
         out.update(extras)
+        if routed and isinstance(extras.get("presplit"), dict) and extras["presplit"].get("value"):
+            # what the per-request routing on the device and the answers' way back into request order cost
+            out["routed_over_presplit"] = round(out["value"] / extras["presplit"]["value"], 4)
         print(json.dumps(out), flush=True)
     if world > 1:
         finish_distributed(dist)
