@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised soak of guber_front_* on the CPU build of the engine (tests/hostsim/libenginesim.so: host code + kernels compiled for the host)
-against the oracle: engines x streams x max_batch x generation size x key population x key form x which columns are present x binding caches.
-CPU only; test infrastructure (the product library needs a device).
+"""Randomised soak of guber_front_* against the oracle — on the CPU build of the engine (tests/hostsim/libenginesim.so: host code + kernels compiled
+for the host) or, without GUBER_HIP_LIB, on the GPU through the product library: engines x streams x max_batch x generation size x key population x key form x which columns are present x binding caches.
+Test infrastructure.
     GUBER_HIP_LIB=tests/hostsim/libenginesim.so python tools/soak_front.py [seconds] [seed]"""
 import ctypes as C
 import os
@@ -17,11 +17,21 @@ import gubernator_amd as ga
 import streams
 import support
 
-assert "enginesim" in ga.LIB_PATH, "run with GUBER_HIP_LIB=tests/hostsim/libenginesim.so"
+ON_GPU = "enginesim" not in ga.LIB_PATH                             # (the product library: real streams and events — what the CPU build cannot show)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from enginesim_cases import dev_gen   # noqa: E402
+if ON_GPU:
+    import torch
+    from test_gpu_front import dev_gen as _dev_gen_gpu
+    _dev = torch.device("cuda", 0)
+
+    def dev_gen(hb, full):
+        b, res, t, r = _dev_gen_gpu(torch, _dev, hb, full)
+        return b, res, t, r
+else:
+    os.environ.setdefault("GUBER_HIP_LIB", ga.LIB_PATH)
+    from enginesim_cases import dev_gen   # noqa: E402
 
 t_end, it = time.time() + budget, 0
 while time.time() < t_end:
@@ -64,6 +74,8 @@ while time.time() < t_end:
             gens.append(hb)
             now += int(rng.choice([0, 1, 400, 1200]))
         parts = [dev_gen(hb, full) for hb in gens]
+        if ON_GPU:
+            torch.cuda.synchronize(_dev)
         N = len(gens)
         # in one call or one by one
         if rng.random() < 0.5:
@@ -72,6 +84,8 @@ while time.time() < t_end:
             for x in parts:
                 assert fr.eval_dev((ga.GuberBatch * 1)(x[0]), (ga.GuberResult * 1)(x[1]), 1) == 1
         fr.synchronize()
+        if ON_GPU:
+            parts = [(x[0], x[1], x[2], {kk: vv.cpu().numpy()[:gens[q].n] for kk, vv in x[3].items()}) for q, x in enumerate(parts)]
         for k, hb in enumerate(gens):
             want = orc.eval(hb)
             if hb.n:
