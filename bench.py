@@ -1342,16 +1342,27 @@ def run_pool(args):
         pass
     cases = {"rpc_1000": (64, 8, 1000, args.keys, 2.0), "rpc_1000_256_callers": (256, 8, 1000, args.keys, 2.0), "rpc_1000_12_shards": (64, 12, 1000, args.keys, 2.0),
              "rpc_1000_one_table": (64, 1, 1000, args.keys, 2.0), "rpc_1000_one_table_128_callers": (128, 1, 1000, args.keys, 2.0),
-             "rpc_1": (16, 8, 1, args.keys, 1.0), "rpc_1_one_caller": (1, 8, 1, args.keys, 1.0)}
-    for label, (T, S, items, keys, secs) in cases.items():
-        p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs)], capture_output=True, text=True, timeout=300)
+             "rpc_1": (16, 8, 1, args.keys, 1.0), "rpc_1_one_caller": (1, 8, 1, args.keys, 1.0),
+             # the payload stage (guber_wire_pool_*): the callers hand over SERIALIZED GetRateLimitsReq messages and get serialized responses back
+             "wire_rpc_1000": (64, 8, 1000, args.keys, 2.0, "wire"), "wire_rpc_1000_128_callers": (128, 8, 1000, args.keys, 2.0, "wire"),
+             "wire_rpc_1000_256_callers": (256, 8, 1000, args.keys, 2.0, "wire"), "wire_rpc_1000_one_table_256_callers": (256, 1, 1000, args.keys, 2.0, "wire"),
+             "wire_rpc_1_one_caller": (1, 8, 1, args.keys, 1.0, "wire")}
+    for label, case in cases.items():
+        T, S, items, keys, secs = case[:5]
+        api = case[5] if len(case) > 5 else "c"
+        p = subprocess.run([exe, str(T), str(S), str(items), str(keys), str(secs), "200", api], capture_output=True, text=True, timeout=300)
         mm = re.search(r"([0-9.]+) M decisions/s,\s+([0-9.]+) batches/s, avg batch\s+([0-9.]+) requests, errors (\d+)(?:, rpc latency p50 ([0-9.]+) us p99 ([0-9.]+) us)?", p.stdout)
         cons = re.search(r"conservation: (\d+) keys (\d+) decisions (\d+) violations", p.stdout)
         if not mm:
             out[label] = {"error": (p.stdout + p.stderr)[-400:]}
             continue
         out[label] = {"value": float(mm.group(1)) * 1e6, "unit": "decisions/s", "batches_per_s": float(mm.group(2)), "avg_batch": float(mm.group(3)),
-                      "errors": int(mm.group(4)), "caller_threads": T, "shards": S, "items_per_rpc": items, "keys": keys}
+                      "errors": int(mm.group(4)), "caller_threads": T, "shards": S, "items_per_rpc": items, "keys": keys, "api": api}
+        wm = re.search(r"wire pool: (\d+) stages .*?per stage: first payload -> sealed ([0-9.]+) us, sealed -> decoded ([0-9.]+) us, decoded -> answers in host memory ([0-9.]+) us, "
+                       r"([0-9.]+) items, ([0-9.]+) RPCs; the pool threads' own time per stage: decode enqueue ([0-9.]+) us, routing enqueue ([0-9.]+) us, evaluation enqueue ([0-9.]+) us", p.stdout)
+        if wm:
+            out[label]["per_stage"] = {"items": float(wm.group(5)), "rpcs": float(wm.group(6)), "fill_us": float(wm.group(2)), "decode_us": float(wm.group(3)),
+                                       "evaluate_us": float(wm.group(4)), "host_enqueue_us": {"decode": float(wm.group(7)), "routing": float(wm.group(8)), "evaluation": float(wm.group(9))}}
         if mm.group(5):
             out[label]["rpc_latency_us"] = {"p50": float(mm.group(5)), "p99": float(mm.group(6))}
         # the gate of a number whose callers run concurrently (no serial order to replay): per-key conservation over every answer the pool gave
@@ -1366,6 +1377,9 @@ def run_pool(args):
     res = {"value": head.get("value"), "unit": "decisions/s"}
     res.update(out)
     res["host_cpus_usable"] = quota if quota else os.cpu_count()
+    res["wire"] = ("wire_*: caller threads x SERIALIZED GetRateLimitsReq messages through guber_wire_pool_get_rate_limits (include/guber_wire.h): per RPC the host does one "
+                   "compare-and-swap, one memcpy and the response's varints; decode (k_wire_*), HashKey, XXH64, placement, evaluation and the answers' order on the device "
+                   "(guber_front); the callers parse the response bytes inside the clock (that is what the conservation gate reads)")
     res["workload"] = ("caller threads x RPCs through guber_pool_get_rate_limits (the C ABI a binding calls: structure-of-arrays in and out) -> GPUWorkerPool: "
                        "one dispatcher per device, fused launches over the shards' stages, placement on key hashes with online hot-key isolation, Zipf-1.1, "
                        "closed loop: front-end checks, HashKey, XXH64, placement, slot reservation, in-place stage filling, completion and response fan-out "

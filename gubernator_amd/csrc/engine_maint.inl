@@ -213,3 +213,4 @@ extern "C" const char* guber_last_error(void) { return g_last_error.c_str(); }
 
 #include "guber_global_sync.h"
 #include "guber_wire_dev.h"
+#include "guber_wire_pool.h"    // guber_wire_pool_*: the payload stage (caller threads hand over serialized RPCs)

@@ -26,7 +26,7 @@ struct guber_front {
     // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
     // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
     // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
-    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr; int n_own_streams = 1; bool out_on_eval = false;
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -42,6 +42,7 @@ struct guber_front {
     };
     std::vector<Slot> slots;
     uint64_t generations = 0, forced_flushes = 0, host_waits = 0; double host_wait_ms = 0;
+    bool pre_routed = false;                          // front_route_ahead has routed the next call's first generation already
     // with the first engine's per-kernel timing on (guber_profile_enable): every generation's way through the GPU, first routing kernel's
     // start -> the answers' last hop's end (guber_front_latencies)
     struct GenSpan { hipEvent_t a, b; };
@@ -207,6 +208,7 @@ static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     // (out_on_eval: the answers' last hop rides on one of the engines' streams, generation by generation in turn — those are idle two fifths
     //  of the time, the routing stream is the pipeline's bottleneck)
     hipStream_t os = f->out_on_eval ? f->streams[(size_t)s.gen % f->streams.size()] : f->os;
+    f->last_os = os;
     for (auto& h : s.hooks) if (h->st != os) HIPCHK(hipStreamWaitEvent(os, h->ev, 0));
     FrOut O{};
     O.n = s.n; O.fwd = s.in.d_fwd;
@@ -232,7 +234,7 @@ static bool front_evals_launched(const guber_front::Slot& s) {
 // gens[k] -> results[k], k = 0 .. count-1: every pointer inside is a DEVICE pointer, requests in arrival order, answers in arrival
 // order.  Asynchronous: returns when everything is enqueued (guber_front_synchronize waits).  The caller's arrays must stay valid and
 // their contents ready (produced before the call, on any stream the caller has synchronised with) until then.
-static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done);
+static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done, hipEvent_t after = nullptr);
 extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens, guber_result_t* results, uint32_t count, uint32_t* done) {
     if (done) *done = 0;
     if (!f || (count && (!gens || !results))) return fail(GUBER_E_INVALID_ARG, "null argument");
@@ -244,7 +246,8 @@ extern "C" int guber_front_eval_dev(guber_front_t* f, const guber_batch_t* gens,
     }
     return front_eval(f, g.data(), results, count, done);
 }
-static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done) {
+// `after`: recorded behind the last generation's answers (on the stream their last hop ran on: the answers of a call leave in order)
+static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* results, uint32_t count, uint32_t* done, hipEvent_t after) {
     if (done) *done = 0;
     for (uint32_t k = 0; k < count; ++k) {
         if (gens[k].b.n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "generation larger than the front was created for");
@@ -265,7 +268,10 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
     int rc = 0;
     uint64_t fp[4] = {0, 0, 0, 0};                                  // GUBER_DISPATCH_PROFILE: ns spent enqueueing the routing, waiting for the shares' sizes, dispatching, on the answers
     struct FpSpan { uint64_t* a; uint64_t t0; explicit FpSpan(uint64_t* x) : a(x), t0(dp_now()) {} ~FpSpan() { if (g_dprof) *a += dp_now() - t0; } };
-    auto slot_of = [&](uint32_t k) -> guber_front::Slot& { return f->slots[k % D]; };
+    // (the slots go round across calls: a caller that hands over one generation per call — the payload stage — gets the routing of its next
+    //  generation beside the evaluation of the last one, as a caller that hands over sixteen at once does)
+    const uint64_t g0 = f->generations;
+    auto slot_of = [&](uint32_t k) -> guber_front::Slot& { return f->slots[(g0 + k) % D]; };
     // the answers of every generation whose evaluations have all been launched go home, oldest first
     auto drain_outs = [&](uint32_t upto, bool force) -> int {
         while (next_out < upto) {
@@ -291,7 +297,8 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
         // the routing runs ahead; a slot is routed into again only after its previous generation's answers have left it
         while (next_route < count && next_route <= k + ahead && !rc) {
             if (next_route >= D) { rc = drain_outs(next_route - D + 1, true); if (rc) break; }
-            { FpSpan sp(&fp[0]); rc = front_route(f, slot_of(next_route), &gens[next_route], (int64_t)f->generations + next_route); }
+            if (next_route == 0 && f->pre_routed) f->pre_routed = false;          // (front_route_ahead did it: same slot, same generation number)
+            else { FpSpan sp(&fp[0]); rc = front_route(f, slot_of(next_route), &gens[next_route], (int64_t)f->generations + next_route); }
             ++next_route;
         }
         if (rc) break;
@@ -369,6 +376,7 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
         if (!rc) rc = rco;
     }
     f->generations += next_out;
+    if (after && !rc && hipEventRecord(after, f->last_os ? f->last_os : f->rs) != hipSuccess) rc = fail(GUBER_E_HIP, "hipEventRecord");
     if (g_dprof && next_out) {
         fprintf(stderr, "[front] %u generations; per generation: routing enqueue %.2f us, waiting for the shares' sizes %.2f, dispatch %.2f, answers %.2f\n", next_out,
                 fp[0] / 1e3 / next_out, fp[1] / 1e3 / next_out, fp[2] / 1e3 / next_out, fp[3] / 1e3 / next_out);
@@ -378,6 +386,30 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
         for (auto& v : tl_dp) v = 0;
     }
     return rc;
+}
+
+// The routing of the NEXT call's first generation, enqueued now (the payload stage: its flusher never waits for the GPU, so it routes as
+// soon as a stage is decoded and comes back for the evaluation when the shares' sizes are in host memory).  The next front_eval call must
+// hand over the same generation first.
+static int front_route_ahead(guber_front* f, const FrontGen* g) {
+    if (g->b.n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "generation larger than the front was created for");
+    if (g->key_stride & 7u) return fail(GUBER_E_INVALID_ARG, "key rows are a multiple of 8 bytes apart");
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (f->pre_routed) return fail(GUBER_E_INVALID_ARG, "guber_front: a generation is routed ahead already");
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    const int rc = front_route(f, f->slots[f->generations % f->depth], g, (int64_t)f->generations);
+    if (!rc) f->pre_routed = true;
+    return rc;
+}
+// have the shares' sizes of the generation routed ahead reached host memory?
+static bool front_routed_ahead_ready(guber_front* f) {
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (!f->pre_routed) return true;
+    guber_front::Slot& s = f->slots[f->generations % f->depth];
+    if (s.n == 0) return true;
+    for (int q = 0; q <= MULTI_MEM_MAX; ++q)
+        if ((uint32_t)(__atomic_load_n((volatile unsigned long long*)&s.host.p->w[q], __ATOMIC_ACQUIRE) >> 32) != s.seq) return false;
+    return true;
 }
 
 extern "C" int guber_front_synchronize(guber_front_t* f) {

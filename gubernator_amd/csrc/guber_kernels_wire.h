@@ -103,6 +103,8 @@ struct WireOut {
     int64_t *hits, *limit, *duration, *burst, *created_at; uint32_t* behavior; int32_t* algo_raw;
     uint8_t *algorithm, *is_owner, *pre_err; uint32_t* item_rpc;
     int64_t now_ms;
+    // the verdicts in DEVICE-VISIBLE HOST memory, written by the decode's last kernel (no copies behind it): first[nrpc + 1] | count[nrpc] | status[nrpc]
+    uint32_t* rep_first; uint32_t* rep_count; int32_t* rep_status;
 };
 
 constexpr uint32_t WIRE_WIN = 8192;
@@ -534,8 +536,18 @@ __global__ __launch_bounds__(256) void k_wire_fill(WireIn in, WireScratch sc, Wi
 }
 
 // items of an RPC that a later record showed to be malformed (or that did not fit): dead slots — an empty key never reaches a bucket
+// ... and the decode's report: the verdicts per payload go to host memory from here (three copy commands less behind the decode; k_wire_fill
+// may still have turned a payload away, so this is the first kernel that can), and the numbering's ticket counter is left at zero whatever
+// happened before (a memset command per decode did that)
 __global__ __launch_bounds__(256) void k_wire_kill(WireIn in, WireScratch sc, WireOut out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (out.rep_first) {
+        for (uint32_t r = i; r <= in.nrpc; r += gridDim.x * 256u) {
+            out.rep_first[r] = sc.first[r];
+            if (r < in.nrpc) { out.rep_count[r] = sc.count[r]; out.rep_status[r] = sc.status[r]; }
+        }
+    }
+    if (i == 0) *sc.done = 0u;
     if (i >= sc.first[in.nrpc]) return;
     if (sc.status[out.item_rpc[i]] != WIRE_OK) { out.key_len[i] = 0; out.pre_err[i] = WIRE_PRE_DEAD; }
 }

@@ -16,6 +16,10 @@ WIRE_SYMBOLS = [
     "guber_wire_items_create", "guber_wire_items_destroy", "guber_wire_decode_globals", "guber_wire_encode_globals",
     "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_buffer", "guber_wire_dev_decode_staged",
     "guber_wire_dev_eval", "guber_wire_dev_eval_front", "guber_wire_dev_columns",
+    "guber_wire_dev_set_stream", "guber_wire_dev_decode_staged_async", "guber_wire_dev_decode_collect", "guber_wire_dev_eval_front_async",
+    "guber_wire_dev_eval_collect",
+    "guber_wire_pool_create", "guber_wire_pool_destroy", "guber_wire_pool_get_rate_limits", "guber_wire_pool_response_bound",
+    "guber_wire_pool_set_clock", "guber_wire_pool_stats",
 ]
 _bound = False
 
@@ -282,3 +286,68 @@ class DevWireDecoder:
         if getattr(self, "h", None):
             self.L.guber_wire_dev_destroy(self.h)
             self.h = None
+
+
+class WirePoolConfig(C.Structure):
+    _fields_ = [("stages", C.c_uint32), ("max_items", C.c_uint32), ("max_payload_bytes", C.c_uint32), ("max_rpcs", C.c_uint32),
+                ("batch_wait_us", C.c_uint32), ("max_per_rpc", C.c_uint32), ("spin_us", C.c_uint32), ("decodes_queued", C.c_uint32)]
+
+
+class WirePoolStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("rpcs", "items", "stages", "sealed_full", "sealed_wait", "sealed_idle", "open_waits",
+                                           "fill_us_sum", "decode_us_sum", "eval_us_sum", "host_decode_ns", "host_route_ns", "host_eval_ns")]
+
+
+class WirePool:
+    """guber_wire_pool_* (include/guber_wire.h): the payload stage — V1Instance.GetRateLimits on the SERIALIZED messages
+    (gubernator.go:183-306).  get_rate_limits() is what one gRPC handler thread calls; it may be called from many threads at once
+    (the call releases the GIL)."""
+
+    def __init__(self, engines, placement=None, **cfg):
+        L = self.L = _lib()
+        L.guber_wire_pool_create.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_void_p, C.POINTER(WirePoolConfig), C.POINTER(C.c_void_p)]
+        L.guber_wire_pool_destroy.argtypes = [C.c_void_p]
+        L.guber_wire_pool_destroy.restype = None
+        L.guber_wire_pool_get_rate_limits.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.guber_wire_pool_response_bound.argtypes = [C.c_char_p, C.c_size_t]
+        L.guber_wire_pool_response_bound.restype = C.c_size_t
+        L.guber_wire_pool_set_clock.argtypes = [C.c_void_p, C.c_int64]
+        L.guber_wire_pool_stats.argtypes = [C.c_void_p, C.POINTER(WirePoolStats)]
+        self.engines = list(engines)
+        self.placement = placement
+        hs = (C.c_void_p * len(self.engines))(*[e.h for e in self.engines])
+        rule = placement.export() if placement is not None else None
+        c = WirePoolConfig(**cfg)
+        self.h = C.c_void_p()
+        rc = L.guber_wire_pool_create(hs, len(self.engines), C.byref(rule) if rule is not None else None, C.byref(c), C.byref(self.h))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+
+    def set_clock(self, now_ms):
+        self.L.guber_wire_pool_set_clock(self.h, now_ms)
+
+    def get_rate_limits(self, payload, is_owner=True, wrap_errors=True, cap=None):
+        """serialized GetRateLimitsReq -> serialized GetRateLimitsResp (GuberError for a message that is turned away whole)"""
+        cap = self.L.guber_wire_pool_response_bound(payload, len(payload)) if cap is None else cap
+        buf = C.create_string_buffer(max(cap, 1))
+        n = C.c_size_t(0)
+        rc = self.L.guber_wire_pool_get_rate_limits(self.h, payload, len(payload), 1 if is_owner else 0, 1 if wrap_errors else 0, buf, cap, C.byref(n))
+        if rc:
+            raise GuberError(rc, lib().guber_last_error().decode())
+        return buf.raw[:n.value]
+
+    def stats(self):
+        st = WirePoolStats()
+        self.L.guber_wire_pool_stats(self.h, C.byref(st))
+        return {k: int(getattr(st, k)) for k, _ in WirePoolStats._fields_}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.guber_wire_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

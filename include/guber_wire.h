@@ -38,6 +38,8 @@ extern "C" {
 #define GUBER_E_WIRE_MALFORMED (-20)   /* truncated / invalid protobuf; nothing was appended */
 #define GUBER_E_WIRE_TOO_LARGE (-21)   /* more than max_per_rpc items: gubernator.go:189-193 (codes.OutOfRange) */
 #define GUBER_E_WIRE_FULL (-22)        /* the batch has no room for this payload; nothing was appended: flush, reset, retry */
+#define GUBER_E_WIRE_CLOSED (-23)      /* guber_wire_pool: the pool is being destroyed */
+#define GUBER_PENDING 1                /* guber_wire_dev_*_collect(wait = 0): the GPU is still at it */
 
 #define GUBER_WIRE_PINNED 1u           /* allocate the SoA with guber_alloc_pinned (needs a HIP device) */
 
@@ -147,6 +149,70 @@ int guber_wire_dev_eval(guber_wire_dev_t* d, guber_result_t* r);
  * answered in the order of the RPCs' items; results to host arrays of n_items entries (n_items <= the front's max_n) */
 int guber_wire_dev_eval_front(guber_wire_dev_t* d, guber_front_t* f, guber_result_t* r);
 int guber_wire_dev_columns(guber_wire_dev_t* d, guber_wire_columns_t* c);
+/* The same in two halves each, for a caller that keeps several decoders busy and never blocks on the GPU (the payload stage below):
+ *   guber_wire_dev_set_stream           the decode's copies and kernels go to `stream` (hipStream_t) instead of the engine's stream
+ *   guber_wire_dev_decode_staged_async  guber_wire_dev_decode_staged up to its last enqueue (is_owner stays valid until collected)
+ *   guber_wire_dev_decode_collect       wait = 0: GUBER_PENDING while the GPU is at it; GUBER_OK: the verdicts, as guber_wire_dev_decode_staged
+ *   guber_wire_dev_eval_front_async     guber_wire_dev_eval_front, enqueued only; r's arrays are DEVICE-VISIBLE (HBM, or pinned host memory the
+ *                                       answers' last hop writes in place over PCIe): no copy follows
+ *   guber_wire_dev_eval_collect         wait = 0: GUBER_PENDING while the answers are on their way
+ *   guber_wire_dev_route_front_async    optional, before guber_wire_dev_eval_front_async: only the front's routing of the decoded batch, enqueued;
+ *   guber_wire_dev_route_ready          GUBER_PENDING until the shares' sizes are in host memory (the evaluation's enqueue then waits for nothing).
+ *                                       Nothing else may go through the front between the two calls. */
+int guber_wire_dev_set_stream(guber_wire_dev_t* d, void* stream);
+int guber_wire_dev_decode_staged_async(guber_wire_dev_t* d, const uint32_t* offs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
+                                       uint32_t max_per_rpc, int64_t now_ms);
+int guber_wire_dev_decode_collect(guber_wire_dev_t* d, int wait, int32_t* status, uint32_t* first, uint32_t* count, uint32_t* n_items);
+int guber_wire_dev_eval_front_async(guber_wire_dev_t* d, guber_front_t* f, guber_result_t* r);
+int guber_wire_dev_eval_collect(guber_wire_dev_t* d, int wait);
+int guber_wire_dev_route_front_async(guber_wire_dev_t* d, guber_front_t* f);
+int guber_wire_dev_route_ready(guber_wire_dev_t* d, guber_front_t* f);
+
+/* ---- the payload stage: V1Instance.GetRateLimits / GetPeerRateLimits on the SERIALIZED messages (gubernator.go:183-306, :470-520; the batching
+ *      shape is peer_client.go:284-337's: a queue that leaves when it is full or BatchWait after its first entry — here RPCs are the entries).
+ *      Caller threads (the gRPC handlers: a codec that hands the handler the raw bytes) call guber_wire_pool_get_rate_limits concurrently; per RPC the
+ *      host does one compare-and-swap (a place in the open stage), one memcpy (the payload into pinned memory) and the response's varints.
+ *      Unmarshalling, validation, the CreatedAt default, HashKey, the worker's choice by XXH64 (workers.go:180-184), the evaluation and the
+ *      answers' order all happen on the device: k_wire_* -> guber_front -> the answers written in place into host memory.
+ *   guber_wire_pool_create            over the engines of ONE device and the placement's rule (as guber_front_create; rule NULL with one engine);
+ *                                     cfg NULL or zero fields = defaults.  Two threads per pool (intake, front); neither ever blocks on the GPU.
+ *   guber_wire_pool_get_rate_limits   req/len: one serialized GetRateLimitsReq (= GetPeerRateLimitsReq); is_owner: RateLimitReqState.IsOwner of its
+ *                                     items; wrap_errors as guber_wire_encode_responses.  Blocks until the stage the payload joined has been
+ *                                     through the GPU.  resp/cap: at least guber_wire_pool_response_bound(req, len) bytes — a smaller buffer is
+ *                                     refused before anything is evaluated when it cannot even hold error-free answers; when it turns out too small
+ *                                     for the error texts the call returns GUBER_E_NOMEM AFTER the decisions have been applied.
+ *                                     GUBER_E_WIRE_MALFORMED / GUBER_E_WIRE_TOO_LARGE: the message is turned away whole (nothing of it evaluated),
+ *                                     as the protobuf runtime / gubernator.go:189-193 do.  The bytes equal guber_wire_encode_responses' (and the
+ *                                     protobuf runtimes').
+ *   guber_wire_pool_set_clock         0 = the wall clock (clock.Now(): a stage's items share the instant it was sealed); otherwise a frozen clock
+ *                                     in ms, as the reference's tests use clock.Freeze */
+typedef struct guber_wire_pool guber_wire_pool_t;
+typedef struct guber_wire_pool_config {
+    uint32_t stages;             /* payload stages in rotation (one fills while the others are on the GPU); 0 = 6, 2 .. 12 */
+    uint32_t max_items;          /* items a stage holds; 0 = 131 072 (<= 1 048 575) */
+    uint32_t max_payload_bytes;  /* payload bytes a stage holds; 0 = 8 MiB (<= 16 MiB) */
+    uint32_t max_rpcs;           /* RPCs a stage holds; 0 = 1024 (<= 4095) */
+    uint32_t batch_wait_us;      /* a stage leaves at the latest this long after its first payload; 0 = 500 (BatchWait, config.go:131) */
+    uint32_t max_per_rpc;        /* 0 = 1000 (gubernator.go:40); 0xffffffff = no cap */
+    uint32_t spin_us;            /* how long a waiting caller looks before it sleeps — when there are CPUs to look with: callers beyond half of them sleep at once; 0 = 150 */
+    uint32_t decodes_queued;     /* a stage leaves early — before it is full or BatchWait is over — while fewer than this many stages are waiting for or
+                                  * in their decode: 1 = one decode at a time (smallest latency under light load), 0 = 2 (the decoder's stream never idles) */
+} guber_wire_pool_config_t;
+typedef struct guber_wire_pool_stats {
+    uint64_t rpcs, items, stages;                       /* answered so far */
+    uint64_t sealed_full, sealed_wait, sealed_idle;     /* why stages left: full / BatchWait / the decoder was idle */
+    uint64_t open_waits;                                /* callers that slept because every stage was on the GPU */
+    uint64_t fill_us_sum, decode_us_sum, eval_us_sum;   /* per stage: first payload -> sealed; sealed -> decoded; decoded -> answers in host memory */
+    uint64_t host_decode_ns, host_route_ns, host_eval_ns; /* the pool's threads' own time inside the three enqueueing calls */
+} guber_wire_pool_stats_t;
+int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n_engines, const struct guber_route_rule* rule, const guber_wire_pool_config_t* cfg,
+                           guber_wire_pool_t** out);
+void guber_wire_pool_destroy(guber_wire_pool_t* p);     /* no call may be in flight or arrive any more */
+int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8_t* req, size_t len, int is_owner, int wrap_errors, uint8_t* resp, size_t cap,
+                                    size_t* resp_len);
+size_t guber_wire_pool_response_bound(const uint8_t* req, size_t len);
+int guber_wire_pool_set_clock(guber_wire_pool_t* p, int64_t now_ms);
+int guber_wire_pool_stats(guber_wire_pool_t* p, guber_wire_pool_stats_t* out);
 
 #ifdef __cplusplus
 }
