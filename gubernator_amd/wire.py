@@ -17,7 +17,7 @@ WIRE_SYMBOLS = [
     "guber_wire_dev_create", "guber_wire_dev_destroy", "guber_wire_dev_decode", "guber_wire_dev_buffer", "guber_wire_dev_decode_staged",
     "guber_wire_dev_eval", "guber_wire_dev_eval_front", "guber_wire_dev_columns",
     "guber_wire_dev_set_stream", "guber_wire_dev_decode_staged_async", "guber_wire_dev_decode_collect", "guber_wire_dev_eval_front_async",
-    "guber_wire_dev_eval_collect",
+    "guber_wire_dev_eval_collect", "guber_wire_dev_route_front_async", "guber_wire_dev_route_ready",
     "guber_wire_pool_create", "guber_wire_pool_destroy", "guber_wire_pool_get_rate_limits", "guber_wire_pool_response_bound",
     "guber_wire_pool_set_clock", "guber_wire_pool_stats",
 ]

@@ -95,13 +95,14 @@ def test_another_thread_on_tables_whose_evaluation_is_held_back(enginesim):
 
 
 def test_the_gpu_suites_host_layer_and_wire_files_against_the_cpu_engine(enginesim):
-    """tests/test_gpu_host_layer.py and tests/test_gpu_wire_dev.py — the `-m gpu` tests of the pool on real engines (stages, routed stages,
-    placement passes moving buckets, Store / Loader, GLOBAL engines, zones), of the wire front end and of the device wire decoder — run
-    unchanged in a process of their own against the CPU build of the engine, under AddressSanitizer.  (The plain-C replica of the Go
+    """tests/test_gpu_host_layer.py, tests/test_gpu_wire_dev.py and tests/test_gpu_wire_pool.py — the `-m gpu` tests of the pool on real
+    engines (stages, routed stages, placement passes moving buckets, Store / Loader, GLOBAL engines, zones), of the wire front end, of the
+    device wire decoder and of the payload stage (caller threads, the pool's two threads, the front) — run unchanged in a process of their
+    own against the CPU build of the engine, under AddressSanitizer.  (The plain-C replica of the Go
     binding links the product library itself and stays a GPU test.)"""
     san = dict(LD_PRELOAD=_runtime("libasan.so"), ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_host_layer.py"), os.path.join(ROOT, "tests", "test_gpu_wire_dev.py"),
-                        "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not plain_c"], capture_output=True, text=True, timeout=1500, cwd=ROOT,
+                        os.path.join(ROOT, "tests", "test_gpu_wire_pool.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k", "not plain_c"], capture_output=True, text=True, timeout=2400, cwd=ROOT,
                        env=dict(os.environ, GUBER_HIP_LIB=enginesim, **san))
     tail = (p.stdout + p.stderr)[-3000:]
     assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, tail

@@ -53,3 +53,18 @@ def test_pool_host_logic(tag, flags, scale, env, repeats):
         tail = (p.stdout + p.stderr)[-3000:]
         assert p.returncode == 0 and "POOL TEST OK" in p.stdout, tail
         assert "ThreadSanitizer" not in p.stderr and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, tail
+
+
+@pytest.mark.parametrize("callers,rpcs,items", [(12, 40, 60), (32, 40, 40), (48, 20, 200)])
+def test_the_payload_stages_host_protocol_under_thread_sanitizer(callers, rpcs, items):
+    """gubernator_amd/csrc/guber_wire_pool.h (guber_wire_pool_*: the callers' reservation word, the intake and front threads, the hand-over
+    ring, the wake-ups, shutdown) compiled on its own against stand-ins for the device decoder and the front (the host transcoder and the
+    oracle, completing after a few polls): tests/hostsim/wire_pool_tsan.cpp.  Three arrangements per run (four stages / two stages and one
+    decode at a time / three RPCs per stage so that callers close full stages), per-key conservation over all answers, a pool destroyed
+    without ever seeing a caller.  (The real decoder and front run under AddressSanitizer: tests/test_enginesim_cpu.py.)"""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostsim"), "wire_pool_tsan"], check=True)
+    for _ in range(2):
+        p = subprocess.run(["/tmp/guber_wire_pool_tsan", str(callers), str(rpcs), str(items)], capture_output=True, text=True, timeout=900)
+        tail = (p.stdout + p.stderr)[-3000:]
+        assert p.returncode == 0 and "WIRE POOL TSAN OK" in p.stdout, tail
+        assert "ThreadSanitizer" not in p.stderr, tail
