@@ -26,7 +26,7 @@ struct guber_front {
     // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
     // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
     // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
-    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false;
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -116,6 +116,7 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     if (const char* v = guber_lab_env("GUBER_FRONT_STREAMS")) f->n_own_streams = std::max(1, std::min(3, atoi(v)));
     f->out_on_eval = true;
     if (const char* v = guber_lab_env("GUBER_FRONT_OUT_ON_EVAL")) f->out_on_eval = atoi(v) != 0;
+    if (const char* v = guber_lab_env("GUBER_FRONT_OUT_DELAY")) f->out_delay = (uint32_t)std::max(0, std::min(2, atoi(v)));
     f->rs2 = f->os = f->rs;
     if (f->n_own_streams >= 2) HIPCHK(hipStreamCreateWithFlags(&f->os, hipStreamNonBlocking));
     if (f->n_own_streams >= 3) HIPCHK(hipStreamCreateWithFlags(&f->rs2, hipStreamNonBlocking));
@@ -362,7 +363,7 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
         s.dispatched = true;
         for (auto& h : s.hooks) h->launched();                      // the dispatcher's hold: the event is recorded once nothing of the generation is held back
         if (rc) break;
-        { FpSpan sp(&fp[3]); rc = drain_outs(k + 1, false); }
+        { FpSpan sp(&fp[3]); rc = drain_outs(k + 1 > f->out_delay ? k + 1 - f->out_delay : 0, false); }
     }
     // (what was routed or enqueued is completed, also after an error: its evaluations go now, its answers go home)
     {

@@ -143,9 +143,64 @@ static int front_sequence(void) {
     return rc;
 }
 
+/* go/wire_server.go's calls: the payload stage over two tables; one GetRateLimitsReq of three requests (a, b, a: limit 2) handed over as bytes, the
+ * GetRateLimitsResp bytes checked field by field */
+static int wire_pool_sequence(void) {
+    /* RateLimitReq{name "n", unique_key "a"|"b", hits 1, limit 2, duration 60000}: 0a <len> { 0a 01 6e  12 01 61  18 01  20 02  28 e0 d4 03 } */
+    static const uint8_t req[] = {0x0a, 14, 0x0a, 1, 'n', 0x12, 1, 'a', 0x18, 1, 0x20, 2, 0x28, 0xe0, 0xd4, 0x03,
+                                  0x0a, 14, 0x0a, 1, 'n', 0x12, 1, 'b', 0x18, 1, 0x20, 2, 0x28, 0xe0, 0xd4, 0x03,
+                                  0x0a, 14, 0x0a, 1, 'n', 0x12, 1, 'a', 0x18, 1, 0x20, 2, 0x28, 0xe0, 0xd4, 0x03};
+    guber_config_t cfg;
+    guber_engine_t* eng[2] = {NULL, NULL};
+    guber_placement_t* place = NULL;
+    guber_wire_pool_t* pool = NULL;
+    guber_wire_pool_config_t wc;
+    guber_wire_pool_stats_t st;
+    struct guber_route_rule rule;
+    uint8_t resp[2048];
+    size_t n = 0, bound;
+    int rc;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = (uint32_t)sizeof cfg; cfg.cache_size = 1000; cfg.max_batch = 1024;
+    rc = guber_engine_create(&cfg, &eng[0]);
+    if (rc != GUBER_OK) return rc;
+    cfg.stream = guber_engine_stream(eng[0]);
+    rc = guber_engine_create(&cfg, &eng[1]);
+    if (rc == GUBER_OK) rc = guber_placement_create(2, 0, &place);
+    if (rc == GUBER_OK) rc = guber_placement_export(place, &rule);
+    memset(&wc, 0, sizeof wc);
+    wc.stages = 2; wc.max_items = 1024; wc.max_payload_bytes = 1u << 16; wc.max_rpcs = 8;
+    if (rc == GUBER_OK) { rule.global_engine = -1; rc = guber_wire_pool_create(eng, 2, &rule, &wc, &pool); }
+    if (rc == GUBER_OK) rc = guber_wire_pool_set_clock(pool, 1700000000000LL);
+    bound = guber_wire_pool_response_bound(req, sizeof req);
+    if (rc == GUBER_OK && bound > sizeof resp) rc = GUBER_E_NOMEM;
+    if (rc == GUBER_OK) rc = guber_wire_pool_get_rate_limits(pool, req, sizeof req, 1, 1, resp, sizeof resp, &n);
+    if (rc == GUBER_OK) rc = guber_wire_pool_stats(pool, &st);
+    if (rc == GUBER_OK) {
+        /* a: limit 2, remaining 1 | b: limit 2, remaining 1 | a: limit 2 (remaining 0 is not written): reset_time 1700000060000 = e0 a4 99 ff bc 31 */
+        static const uint8_t want[] = {0x0a, 11, 0x10, 2, 0x18, 1, 0x20, 0xe0, 0xa4, 0x99, 0xff, 0xbc, 0x31,
+                                       0x0a, 11, 0x10, 2, 0x18, 1, 0x20, 0xe0, 0xa4, 0x99, 0xff, 0xbc, 0x31,
+                                       0x0a, 9, 0x10, 2, 0x20, 0xe0, 0xa4, 0x99, 0xff, 0xbc, 0x31};
+        if (n != sizeof want || memcmp(resp, want, n) != 0 || st.rpcs != 1 || st.items != 3) {
+            size_t i;
+            printf("wire pool: unexpected response (%u bytes, rpcs %llu items %llu):", (unsigned)n, (unsigned long long)st.rpcs, (unsigned long long)st.items);
+            for (i = 0; i < n; ++i) printf(" %02x", resp[i]);
+            printf("\n");
+            rc = GUBER_E_INVALID_ARG;
+        }
+    }
+    if (rc != GUBER_OK) printf("wire pool: %s (%s)\n", guber_strerror(rc), guber_last_error());
+    guber_wire_pool_destroy(pool);
+    guber_placement_destroy(place);
+    if (eng[1]) guber_engine_destroy(eng[1]);
+    if (eng[0]) guber_engine_destroy(eng[0]);
+    return rc;
+}
+
 int main(int argc, char** argv) {
     int rc = call_sequence(argc > 1 && !strcmp(argv[1], "--gpu"));
     if (rc == GUBER_OK && argc > 1 && !strcmp(argv[1], "--gpu")) rc = front_sequence();
+    if (rc == GUBER_OK && argc > 1 && !strcmp(argv[1], "--gpu")) rc = wire_pool_sequence();
     (void)argv;
     if (argc > 1) return rc == GUBER_OK ? 0 : 1;
     return rc == GUBER_E_NO_DEVICE ? 0 : 2;       /* no GPU: the product fails loudly, it has no CPU path */

@@ -416,7 +416,8 @@ def test_pool_global_engine_and_hot_key_migration():
 
 def test_the_go_bindings_call_sequence_in_plain_c(tmp_path):
     """tests/hostsim/abi_c99.c — the cgo preamble and the calls go/gpu_worker_pool.go makes, compiled as C99 — against the real
-    library on the GPU: create, GetRateLimits with owner flags, AddCacheItem (GLOBAL), GetCacheItem, Load, Store, GlobalSync, Close."""
+    library on the GPU: create, GetRateLimits with owner flags, AddCacheItem (GLOBAL), GetCacheItem, Load, Store, GlobalSync, Close; then
+    the front over two tables, and go/wire_server.go's calls: a serialized GetRateLimitsReq through the payload stage, the response bytes checked."""
     import subprocess
     exe = str(tmp_path / "abi_c99")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
