@@ -1345,6 +1345,7 @@ def run_pool(args):
              "rpc_1": (16, 8, 1, args.keys, 1.0), "rpc_1_one_caller": (1, 8, 1, args.keys, 1.0),
              # the payload stage (guber_wire_pool_*): the callers hand over SERIALIZED GetRateLimitsReq messages and get serialized responses back
              "wire_rpc_1000": (64, 8, 1000, args.keys, 2.0, "wire"), "wire_rpc_1000_128_callers": (128, 8, 1000, args.keys, 2.0, "wire"),
+             "wire_rpc_1000_192_callers": (192, 8, 1000, args.keys, 2.0, "wire"),
              "wire_rpc_1000_256_callers": (256, 8, 1000, args.keys, 2.0, "wire"), "wire_rpc_1000_one_table_256_callers": (256, 1, 1000, args.keys, 2.0, "wire"),
              "wire_rpc_1_one_caller": (1, 8, 1, args.keys, 1.0, "wire")}
     for label, case in cases.items():

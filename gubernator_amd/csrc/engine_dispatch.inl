@@ -277,6 +277,56 @@ static int launch_group(guber_engine* const* grp, const GroupItem* it, int g, ui
     return rc;
 }
 
+// Up to 16 tables of ONE device and stream in ONE pair of launches (k_front_multi_mem / k_eval2_multi_mem: the argument blocks travel through
+// device memory, one copy command ahead of the pair): what a payload stage's generation is — a few thousand requests per table, where the
+// owner-partitioned pipeline's three launches per group of four would be six or nine launches for eight or twelve tables.  The caller has
+// checked that every share fits the two-launch pipeline and cannot make its cache bind (can_fuse) and that nothing is held back on these
+// tables by its own call.  HA: device-visible host memory that stays untouched until the copy has run; DA: its place in HBM.
+// Returns 1 when a table turned out tight under the locks (nothing was enqueued: the caller takes the ordinary way), 0 / < 0 otherwise.
+static int launch_group_mem(guber_engine* const* grp, const GroupItem* it, int g, uint32_t* enqueued, MultiArgsMem* HA, MultiArgsMem* DA) {
+    guber_engine* order[MULTI_MEM_MAX];
+    for (int i = 0; i < g; ++i) order[i] = grp[i];
+    std::sort(order, order + g);
+    for (int i = 0; i < g; ++i) order[i]->mu.lock();
+    struct Unlock { guber_engine** o; int g; ~Unlock() { for (int i = g - 1; i >= 0; --i) o[i]->mu.unlock(); } } unlock{order, g};
+    for (int i = 0; i < g; ++i)                                    // a k_eval3 ANOTHER call holds back for one of these tables goes first
+        if (grp[i]->held) { (void)launch_held(*grp[i]->held, false); grp[i]->held = nullptr; }
+    if (grp[0]->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
+    for (int i = 0; i < g; ++i)
+        if (grp[i]->size_upper + it[i].B.n > grp[i]->cache_size || grp[i]->small_pending) return 1;
+    uint32_t tiles = 0, ns[MULTI_MEM_MAX];
+    int planned = 0, rc = 0;
+    for (int i = 0; i < g; ++i) {
+        guber_engine* e = grp[i];
+        Work W; FastPlan P;
+        rc = batch_prelude(e, it[i].B, W);
+        if (!rc) rc = plan_fast(e, it[i].B, false, W, P);
+        if (rc) break;                                            // enqueue what is planned, then report
+        tiles += P.ftiles;
+        HA->F.end_tile[planned] = HA->E.end_tile[planned] = tiles;
+        HA->F.sub[planned] = FrontArgs{e->T, P.B2, P.W};
+        HA->E.sub[planned] = EvalArgs{e->T, P.B3, it[i].R, P.W};
+        ns[planned++] = it[i].B.n;
+    }
+    if (planned) {
+        HA->F.nb = HA->E.nb = (uint32_t)planned;
+        uint64_t units = 0;
+        for (int i = 0; i < planned; ++i) units += ns[i];
+        hipStream_t st = grp[0]->stream;
+        if (hipMemcpyAsync(DA, HA, sizeof(MultiArgsMem), hipMemcpyHostToDevice, st) != hipSuccess) return fail(GUBER_E_HIP, "hipMemcpyAsync");
+        grp[0]->span_begin(KT_FRONT_MULTI, units);
+        hipLaunchKernelGGL(k_front_multi_mem, dim3(tiles), dim3(FT), 0, st, (const MultiFrontMem*)&DA->F);
+        grp[0]->span_end();
+        grp[0]->span_begin(KT_EVAL2_MULTI, units);
+        hipLaunchKernelGGL(k_eval2_multi_mem, dim3(tiles), dim3(256), 0, st, (const MultiEvalMem*)&DA->E);
+        grp[0]->span_end();
+        for (int i = 0; i < planned; ++i) { finish_fast(grp[i], ns[i]); grp[i]->fused_batches++; }
+        *enqueued += (uint32_t)planned;
+        if (hipGetLastError() != hipSuccess) return fail(GUBER_E_HIP, "kernel launch");
+    }
+    return rc;
+}
+
 // One round after the other: the next item of every engine that has one; engines that share device and stream share launches.
 // fifo[j] = the items of engines[j] in their order.  *enqueued counts items.  The caller owns `ps` (and flushes it).
 static int dispatch_rounds(guber_engine_t* const* engines, uint32_t n_engines, const std::vector<std::vector<GroupItem>>& fifo, PendSet* ps,

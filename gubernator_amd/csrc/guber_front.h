@@ -14,6 +14,11 @@
 // keep the bounded caches' admission exact — are in pinned memory by the time the host asks: it never waits for the GPU in steady state.
 #pragma once
 
+// generations of at most this many requests whose tables share ONE stream go as one pair of launches for all tables (launch_group_mem);
+// larger ones keep the owner-partitioned pipeline in groups of four tables, whose advantage grows with the share.
+// Measured on the payload stage, eight tables, alternating on one box (profiles/r06_wire_pool.txt): generations of 28 000 requests +16 %,
+// of 40 000 +5 ... +10 %, of 57 000 -8 %.
+constexpr uint32_t FRONT_ONE_PAIR_MAX = 49152;
 struct guber_front {
     std::mutex mu;
     int device = 0;
@@ -26,7 +31,7 @@ struct guber_front {
     // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
     // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
     // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
-    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0;
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0, one_pair_max = FRONT_ONE_PAIR_MAX;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -36,6 +41,7 @@ struct guber_front {
         uint8_t *o_status = nullptr, *o_err = nullptr; int64_t *o_limit = nullptr, *o_remaining = nullptr, *o_reset = nullptr;
         hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_a = nullptr; bool out_recorded = false;
         std::vector<std::unique_ptr<EvalHook>> hooks;   // one per engine stream
+        CohBuf<uint8_t> h_margs; DevBuf<uint8_t> d_margs; // the argument blocks of a generation that goes as ONE pair of launches (launch_group_mem)
         uint32_t seq = 0, n = 0;
         int64_t gen = -1;                               // the generation the slot holds (-1: free)
         bool dispatched = false;
@@ -59,7 +65,7 @@ extern "C" void guber_front_destroy(guber_front_t* f) {
     for (hipStream_t st : {f->rs, f->rs2, f->os}) if (st) (void)hipStreamSynchronize(st);
     for (auto st : f->streams) (void)hipStreamSynchronize(st);
     for (auto& s : f->slots) {
-        s.mem.release(); s.host.release();
+        s.mem.release(); s.host.release(); s.h_margs.release(); s.d_margs.release();
         if (s.ev_in) (void)hipEventDestroy(s.ev_in);
         if (s.ev_out) (void)hipEventDestroy(s.ev_out);
         for (auto& h : s.hooks) if (h && h->ev) (void)hipEventDestroy(h->ev);
@@ -117,6 +123,7 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     f->out_on_eval = true;
     if (const char* v = guber_lab_env("GUBER_FRONT_OUT_ON_EVAL")) f->out_on_eval = atoi(v) != 0;
     if (const char* v = guber_lab_env("GUBER_FRONT_OUT_DELAY")) f->out_delay = (uint32_t)std::max(0, std::min(2, atoi(v)));
+    if (const char* v = guber_lab_env("GUBER_FRONT_ONE_PAIR_MAX")) f->one_pair_max = (uint32_t)strtoul(v, nullptr, 10);
     f->rs2 = f->os = f->rs;
     if (f->n_own_streams >= 2) HIPCHK(hipStreamCreateWithFlags(&f->os, hipStreamNonBlocking));
     if (f->n_own_streams >= 3) HIPCHK(hipStreamCreateWithFlags(&f->rs2, hipStreamNonBlocking));
@@ -132,6 +139,7 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
                              front_col(cap * FR_KEY_COPY_MAX + 64) +                                                         // keys
                              front_col(cap * 2) + 2 * front_col(tiles * MULTI_MEM_MAX * 4) + front_col(sizeof(FrontCtl));
         if (s.mem.ensure(bytes) || s.host.ensure(1)) return GUBER_E_NOMEM;
+        if (f->streams.size() == 1 && n_engines > 1 && (s.h_margs.ensure(sizeof(MultiArgsMem)) || s.d_margs.ensure(sizeof(MultiArgsMem)))) return GUBER_E_NOMEM;
         uint8_t* p = s.mem.p;
         FrIn& A = s.in;
         A.d_key_off = (uint32_t*)p; p += front_col(cap * 4 + 4); A.d_key_len = (uint32_t*)p; p += front_col(cap * 4 + 4); A.d_fwd = (uint32_t*)p; p += front_col(cap * 4 + 4);
@@ -358,7 +366,21 @@ static int front_eval(guber_front* f, const FrontGen* gens, guber_result_t* resu
                 base += nj;
             }
             if (total != s.n) { rc = fail(GUBER_E_HIP, "guber_front: the shares do not add up to the generation"); break; }
-            { FpSpan sp(&fp[2]); rc = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data()); }
+            // a generation of small shares on ONE stream (the payload stage's): all its tables in one pair of launches
+            bool one_pair = f->streams.size() == 1 && ne > 1 && s.h_margs.p && s.n <= f->one_pair_max;
+            guber_engine* og[MULTI_MEM_MAX]; GroupItem oi[MULTI_MEM_MAX]; int on = 0;
+            for (uint32_t j = 0; j < ne && one_pair; ++j) {
+                if (fifo[j].empty()) continue;
+                one_pair = fifo[j].size() == 1 && can_fuse(f->eng[j], fifo[j][0].B.n);
+                og[on] = f->eng[j]; oi[on] = fifo[j][0]; ++on;
+            }
+            if (one_pair && on > 1) {
+                FpSpan sp(&fp[2]);
+                rc = pendset.flush_all();                                   // (what an earlier generation of this call holds back on these tables goes first)
+                int r1 = rc ? rc : launch_group_mem(og, oi, on, &enq, (MultiArgsMem*)s.h_margs.p, (MultiArgsMem*)s.d_margs.p);
+                if (r1 == 1) r1 = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data());   // (a table turned out tight: the ordinary way)
+                rc = r1;
+            } else { FpSpan sp(&fp[2]); rc = dispatch_rounds(f->eng.data(), ne, fifo, ps, &enq, hook_of.data()); }
         }
         s.dispatched = true;
         for (auto& h : s.hooks) h->launched();                      // the dispatcher's hold: the event is recorded once nothing of the generation is held back

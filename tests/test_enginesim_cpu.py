@@ -60,14 +60,21 @@ def test_fused_groups_around_a_cache_that_binds(enginesim, fuse_ep):
 
 
 
-@pytest.mark.parametrize("case,fuse_ep", [("front4", "1"), ("front6x3_pieces", "0"), ("front1", "1")])
-def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(enginesim, case, fuse_ep):
+@pytest.mark.parametrize("case,fuse_ep,one_pair", [("front4", "1", "0"), ("front4", "1", None), ("front6x3_pieces", "0", None), ("front1", "1", None)],
+                         ids=["front4-owner_partitioned", "front4-one_pair_of_launches", "front6x3_pieces", "front1"])
+def test_a_front_routes_generations_on_the_device_and_answers_in_arrival_order(enginesim, case, fuse_ep, one_pair):
     """guber_front_eval_dev (guber_front.h, guber_kernels_front.h): ONE stream of requests in arrival order -> k_fr_count / k_fr_scatter
     (XXH64 + the placement's rule, workers.go:180-184) -> the engines' shares through the fused launches, on one, two and three streams,
     shares larger than an engine's max_batch in pieces, the k_eval3 of a generation held back for the next one's k_part (and the event the
     answers' way home waits for recorded behind whoever launches it) -> k_fr_out: every generation equals ONE oracle fed the generations
-    in order (gubernator.go:203: a serial loop in request order), keys of one width and ragged ones, empty and tiny generations"""
-    run_case(enginesim, case, GUBER_FUSE_EP=fuse_ep)
+    in order (gubernator.go:203: a serial loop in request order), keys of one width and ragged ones, empty and tiny generations.
+    Four tables of ONE stream twice: through the owner-partitioned pipeline in one group (the laboratory knob GUBER_FRONT_ONE_PAIR_MAX=0) and
+    the way the product takes generations of that size — all tables in ONE pair of launches (launch_group_mem: k_front_multi_mem /
+    k_eval2_multi_mem, the argument blocks through device memory)"""
+    env = dict(GUBER_FUSE_EP=fuse_ep)
+    if one_pair is not None:
+        env["GUBER_FRONT_ONE_PAIR_MAX"] = one_pair
+    run_case(enginesim, case, **env)
 
 
 def test_a_front_sends_global_requests_to_the_global_engine(enginesim):
