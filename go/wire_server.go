@@ -38,7 +38,7 @@ type WireServer struct {
 }
 
 // NewWireServer: the engines of the device (GPUWorkerPool's shards), the placement's rule (nil with one table), the defaults of
-// guber_wire_pool_config_t (six stages of 131 072 items, BatchWait 500 us, 1000 requests per RPC).
+// guber_wire_pool_config_t (twelve stages of 49 152 items, BatchWait 500 us, 1000 requests per RPC).
 func NewWireServer(engines []*C.guber_engine_t, rule *C.struct_guber_route_rule) (*WireServer, error) {
 	s := &WireServer{}
 	if rc := C.guber_wire_pool_create(&engines[0], C.uint32_t(len(engines)), rule, nil, &s.pool); rc != C.GUBER_OK {

@@ -384,8 +384,11 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
     *out = nullptr;
     guber_wire_pool_config_t c{};
     if (cfg) c = *cfg;
-    if (!c.stages) c.stages = 6;
-    if (!c.max_items) c.max_items = 131072;
+    // (stages no larger than what the front evaluates as ONE pair of launches for all tables, FRONT_ONE_PAIR_MAX, and enough of them in rotation
+    //  for a few hundred callers: measured against six stages of 131 072 items — 192 callers 258-363 -> 398-413 M/s, 256 callers 301-311 ->
+    //  375-382, 384 callers 247-259 -> 370-373: profiles/r06_wire_pool.txt)
+    if (!c.stages) c.stages = 12;
+    if (!c.max_items) c.max_items = 49152;
     if (!c.max_payload_bytes) c.max_payload_bytes = 8u << 20;
     if (!c.max_rpcs) c.max_rpcs = 1024;
     if (!c.batch_wait_us) c.batch_wait_us = 500;                       // config.go:131 BatchWait

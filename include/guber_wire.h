@@ -188,8 +188,8 @@ int guber_wire_dev_route_ready(guber_wire_dev_t* d, guber_front_t* f);
  *                                     in ms, as the reference's tests use clock.Freeze */
 typedef struct guber_wire_pool guber_wire_pool_t;
 typedef struct guber_wire_pool_config {
-    uint32_t stages;             /* payload stages in rotation (one fills while the others are on the GPU); 0 = 6, 2 .. 12 */
-    uint32_t max_items;          /* items a stage holds; 0 = 131 072 (<= 1 048 575) */
+    uint32_t stages;             /* payload stages in rotation (one fills while the others are on the GPU); 0 = 12, 2 .. 12 */
+    uint32_t max_items;          /* items a stage holds; 0 = 49 152 — what the front evaluates as one pair of launches for all tables (<= 1 048 575) */
     uint32_t max_payload_bytes;  /* payload bytes a stage holds; 0 = 8 MiB (<= 16 MiB) */
     uint32_t max_rpcs;           /* RPCs a stage holds; 0 = 1024 (<= 4095) */
     uint32_t batch_wait_us;      /* a stage leaves at the latest this long after its first payload; 0 = 500 (BatchWait, config.go:131) */
