@@ -1377,6 +1377,10 @@ def run_pool(args):
     head = out.get("rpc_1000", {})
     res = {"value": head.get("value"), "unit": "decisions/s"}
     res.update(out)
+    gated = {k: v["value"] for k, v in out.items() if isinstance(v, dict) and v.get("value") and str(v.get("parity", "")).startswith("per-key conservation")}
+    if gated:
+        best = max(gated, key=gated.get)
+        res["best"] = {"case": best, "value": gated[best], "unit": "decisions/s", "note": "the largest gated rate among the cases above (`value` stays rpc_1000 through guber_pool_get_rate_limits, as in earlier rounds)"}
     res["host_cpus_usable"] = quota if quota else os.cpu_count()
     res["wire"] = ("wire_*: caller threads x SERIALIZED GetRateLimitsReq messages through guber_wire_pool_get_rate_limits (include/guber_wire.h): per RPC the host does one "
                    "compare-and-swap, one memcpy and the response's varints; decode (k_wire_*), HashKey, XXH64, placement, evaluation and the answers' order on the device "

@@ -168,11 +168,33 @@ def test_concurrent_callers_share_stages_and_every_hit_is_applied_exactly_once(c
         except Exception as e:  # noqa: BLE001
             failures.append((t, repr(e)))
 
-    th = [threading.Thread(target=caller, args=(t,)) for t in range(callers)]
+    # two more callers whose messages are turned away whole, into the same stages: a truncated message and one of 1001 requests in turn (its keys are
+    # the others' keys with a limit of 1: had any of it been evaluated, conservation below would not hold)
+    rng_bad = np.random.default_rng(7)
+    too_many = wire_replay.pb_request([dict(name="conc", unique_key="k%04d" % k, hits=1, limit=1, duration=3_600_000, algorithm=0, behavior=0)
+                                       for k in rng_bad.integers(0, KEYS, 1001)])
+    truncated = plans[0][0][2][:-5]
+    turned_away = []
+
+    def bad_caller(t):
+        try:
+            start.wait()
+            for q in range(RPCS):
+                try:
+                    pool.get_rate_limits(too_many if (q + t) & 1 else truncated)
+                    failures.append((t, "a message that must be turned away was answered"))
+                except ga.GuberError as e:
+                    turned_away.append(e.code)
+        except Exception as e:  # noqa: BLE001
+            failures.append((t, repr(e)))
+
+    start = threading.Barrier(callers + 2)
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(callers)] + [threading.Thread(target=bad_caller, args=(t,)) for t in (0, 1)]
     for x in th:
         x.start()
     for x in th:
         x.join()
+    assert sorted(set(turned_away)) == [-21, -20] and len(turned_away) == 2 * RPCS, turned_away[:8]
     assert not failures, failures[:3]
     admitted = np.zeros(KEYS, np.int64); refused = np.zeros(KEYS, np.int64); sum_rem = np.zeros(KEYS, np.int64)
     for t in range(callers):
@@ -197,7 +219,8 @@ def test_concurrent_callers_share_stages_and_every_hit_is_applied_exactly_once(c
     assert (admitted[refused > 0] == LIMIT).all()
     assert refused.sum() > 0 and (admitted < LIMIT).any()
     st = pool.stats()
-    assert st["rpcs"] == callers * RPCS and st["stages"] < st["rpcs"]                # RPCs shared stages
+    assert st["rpcs"] == (callers + 2) * RPCS and st["stages"] < st["rpcs"]          # RPCs shared stages (the messages turned away count as RPCs, not as items)
+    assert st["items"] == callers * RPCS * ITEMS
     pool.close()
     for e in reversed(engs):
         e.close()
