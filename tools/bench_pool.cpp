@@ -30,6 +30,14 @@
 
 #include "../gubernator_amd/csrc/worker_pool.h"
 #include "../include/guber_wire.h"
+#ifdef GUBER_BENCH_NO_WIRE   // the build against the oracle-backed engine stub (tests/hostsim: no device decoder, no front): api = wire is not available there
+extern "C" int guber_wire_pool_create(guber_engine_t* const*, uint32_t, const struct guber_route_rule*, const guber_wire_pool_config_t*, guber_wire_pool_t**) { return GUBER_E_NO_DEVICE; }
+extern "C" void guber_wire_pool_destroy(guber_wire_pool_t*) {}
+extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t*, const uint8_t*, size_t, int, int, uint8_t*, size_t, size_t*) { return GUBER_E_NO_DEVICE; }
+extern "C" size_t guber_wire_pool_response_bound(const uint8_t*, size_t) { return 0; }
+extern "C" int guber_wire_pool_stats(guber_wire_pool_t*, guber_wire_pool_stats_t*) { return GUBER_E_NO_DEVICE; }
+#define guber_last_error() "api = wire needs the product library"
+#endif
 
 using namespace gubernator;
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
