@@ -30,6 +30,9 @@
 #include <sys/resource.h>
 #include <climits>
 
+#ifndef GUBER_WPL_WALK_MAX
+#define GUBER_WPL_WALK_MAX 8192       // payloads shorter than this have their records counted; longer ones are bounded by the cap
+#endif
 namespace {
 constexpr uint64_t WPL_CLOSED = 1ull << 63;
 constexpr uint32_t WPL_MAX_RPCS = 4095, WPL_MAX_ITEMS = (1u << 20) - 1, WPL_MAX_B16 = (1u << 20) - 1, WPL_NONE = 15, WPL_MAX_STAGES = 12;
@@ -51,10 +54,12 @@ inline void wpl_relax() {
     __builtin_ia32_pause();
 #endif
 }
-// how many RateLimitReq records a payload can hold at most: the top-level chain walked for short payloads (exact when well-formed), the
-// cap for long ones (an RPC with more than the cap is turned away whole and takes no place: gubernator.go:189-193)
+// how many RateLimitReq records a payload can hold at most: the top-level chain walked for short payloads (exact when well-formed), the cap for
+// long ones (an RPC with more than the cap is turned away whole and takes no place: gubernator.go:189-193).  Counting the records of EVERY
+// payload (a tag, a length and a skip per record: ~3 us for 1000) would keep stages full when long RPCs hold few, long requests, and was
+// measured on full ones: -3 ... -4 % at every caller count (profiles/r06_wire_pool.txt) — the bound of a long payload stays the cap.
 inline uint32_t wpl_item_bound(const uint8_t* p, size_t len, uint32_t cap) {
-    if (len >= 8192) return (uint32_t)std::min<size_t>(cap, len / 2);
+    if (len >= GUBER_WPL_WALK_MAX) return (uint32_t)std::min<size_t>(cap, len / 2);
     const uint8_t* end = p + len;
     uint32_t n = 0;
     while (p < end) {
@@ -512,16 +517,13 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
         uint32_t v;
         const int64_t t0 = may_spin ? wpl_mono_us() : 0;
         uint32_t spins = 0;
-        bool slept = false;
         while ((v = s.done_gen.load(std::memory_order_acquire)) != gen) {
             if (may_spin && (++spins & 63u || wpl_mono_us() - t0 < (int64_t)p->spin_us)) { wpl_relax(); continue; }
             s.sleepers.fetch_add(1, std::memory_order_seq_cst);
             while ((v = s.done_gen.load(std::memory_order_seq_cst)) != gen) wpl_futex_wait(&s.done_gen, v, -1);
-            slept = true;
             if (s.sleepers.fetch_sub(1, std::memory_order_seq_cst) > 1) wpl_futex_wake(&s.done_gen, 2);
             break;
         }
-        (void)slept;
     }
     // ---- my slice of the answers -> GetRateLimitsResp
     int rc = s.rc;
