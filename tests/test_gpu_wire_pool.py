@@ -225,3 +225,42 @@ def test_concurrent_callers_share_stages_and_every_hit_is_applied_exactly_once(c
     for e in reversed(engs):
         e.close()
     place.close()
+
+
+def test_fuzzed_payloads_get_the_host_transcoders_verdict_and_bytes():
+    """mutated payloads (bit flips, insertions, deletions, truncations, inserted garbage: tests/test_gpu_wire_dev.py's mutator) one after the other through
+    the stage: what the host transcoder turns away (csrc/wire.cpp, itself pinned on the protobuf runtime's verdicts by tests/test_wire_cpu.py) the stage
+    turns away with the same code and evaluates nothing of; what it accepts the stage answers with the same BYTES as the host transcoder around the
+    oracle — whatever the mutation made of the requests (huge hits, negative limits, unknown algorithms and behaviours, empty names)"""
+    from test_gpu_wire_dev import _mutate
+    rng = np.random.default_rng(23)
+    engs = _engines(3, cache_size=1 << 16, max_batch=8192, max_key_bytes=512)
+    place = ga.Placement(3)
+    pool = gw.WirePool(engs, place, stages=3, max_items=8192, max_payload_bytes=1 << 20, max_rpcs=64)
+    o = support.Oracle(cache_size=1 << 20)
+    wb = gw.WireBatch(8192, 4 << 20)
+    base = [wire_replay.pb_request(rand_reqs(rng, int(rng.integers(1, 300)))) for _ in range(30)]
+    now = NOW
+    accepted = rejected = 0
+    for k in range(400):
+        payload = _mutate(rng, base[int(rng.integers(0, len(base)))])
+        pool.set_clock(now)
+        wb.reset(now)
+        try:
+            first, count = wb.decode(payload, max_per_rpc=1000)
+        except ga.GuberError as e:
+            with pytest.raises(ga.GuberError) as ei:
+                pool.get_rate_limits(payload)
+            assert ei.value.code == e.code, (k, e.code, ei.value.code)
+            rejected += 1
+            continue
+        o.lib.oracle_eval_batch(o.h, C.byref(wb.view()), C.byref(wb.result()))
+        assert pool.get_rate_limits(payload) == wb.encode(first, count), f"payload {k}"
+        accepted += 1
+        now += int(rng.integers(0, 50))
+    assert accepted > 100 and rejected > 50, (accepted, rejected)
+    pool.close()
+    for e in reversed(engs):
+        e.close()
+    place.close()
+    o.close(); wb.close()
