@@ -7,7 +7,11 @@
 struct guber_wire_dev {
     guber_engine* e = nullptr;
     uint32_t max_items = 0, max_bytes = 0, max_rpcs = 0, cap_per_rpc = 0, stride = 0;
-    PinBuf<uint8_t> h_buf; PinBuf<uint32_t> h_u32;                                       // staging: payload bytes; the decode's arguments off[R] | len[R] | wfirst[R + 1] | owner bytes[R] (ONE copy)
+    // staging, host and device alike: the decode's arguments off[R] | len[R] | wfirst[R + 1] | owner bytes[R] (meta_bytes, a multiple of 64), then the
+    // payload bytes — ONE copy command brings both to HBM
+    PinBuf<uint8_t> h_buf; size_t meta_bytes = 0;
+    uint32_t* h_meta() const { return (uint32_t*)h_buf.p; }
+    uint8_t* h_pay() const { return h_buf.p + meta_bytes; }
     CohBuf<uint32_t> h_rep;                                                              // the verdicts, written by k_wire_kill: first[R + 1] | count[R] | status[R]
     DevBuf<uint8_t> d_buf, d_rows, d_u8; DevBuf<uint32_t> d_u32, d_rec; DevBuf<int32_t> d_status, d_algo; DevBuf<int64_t> d_i64;
     DevBuf<int64_t> d_out64; DevBuf<uint8_t> d_out8;
@@ -36,15 +40,16 @@ extern "C" int guber_wire_dev_create(guber_engine_t* e, uint32_t max_items, uint
     d->stride = ((e->max_key + 7u) & ~7u) + 8u;
     const size_t M = max_items, R = max_rpcs;
     d->max_windows = d->max_bytes / guber::WP_WIN + max_rpcs;                            // (a payload of len bytes: len / 8 KB + 1 windows)
-    const size_t meta = 3 * R + 1 + (R + 3) / 4;                                         // u32 words of the arguments' block
-    int rc = d->h_buf.ensure(d->max_bytes) | d->h_u32.ensure(meta + 8) | d->h_rep.ensure(3 * R + 8) | d->d_buf.ensure(d->max_bytes) |
-             d->d_u32.ensure(meta + R + (R + 1) + 1 + M + M + M) | d->d_rec.ensure(2 * R * d->cap_per_rpc) | d->d_status.ensure(R) | d->d_algo.ensure(M) |
+    d->meta_bytes = (((3 * R + 1) * 4 + R) + 63) & ~(size_t)63;                          // the arguments' block in front of the payload bytes
+    int rc = d->h_buf.ensure(d->meta_bytes + d->max_bytes) | d->h_rep.ensure(3 * R + 8) | d->d_buf.ensure(d->meta_bytes + d->max_bytes) |
+             d->d_u32.ensure(R + (R + 1) + 1 + M + M + M) | d->d_rec.ensure(2 * R * d->cap_per_rpc) | d->d_status.ensure(R) | d->d_algo.ensure(M) |
              d->d_i64.ensure(5 * M) | d->d_rows.ensure(M * d->stride + 64) | d->d_u8.ensure(3 * M) | d->d_out64.ensure(3 * M) | d->d_out8.ensure(2 * M) |
              d->d_went.ensure((size_t)d->max_windows * guber::WP_ENT);
     if (rc) { guber_wire_dev_destroy(d); return GUBER_E_NOMEM; }
+    uint32_t* a = (uint32_t*)d->d_buf.p;                                                 // (the block the host's arguments are copied over, with the payload, in one piece)
+    d->in.rpc_off = a; a += R; d->in.rpc_len = a; a += R; d->sc.wfirst = a; a += R + 1; d->in.rpc_owner = (const uint8_t*)a;
+    d->in.buf = d->d_buf.p + d->meta_bytes;
     uint32_t* u = d->d_u32.p;
-    d->in.buf = d->d_buf.p; d->in.rpc_off = u; u += R; d->in.rpc_len = u; u += R;
-    d->sc.wfirst = u; u += R + 1; d->in.rpc_owner = (const uint8_t*)u; u += (R + 3) / 4;      // (the block the host's arguments are copied over, in one piece)
     d->sc.count = u; u += R; d->sc.first = u; u += R + 1;
     d->sc.done = u; u += 1; d->sc.went = d->d_went.p;
     if (hipMemset(d->sc.done, 0, 4) != hipSuccess) { guber_wire_dev_destroy(d); return fail(GUBER_E_HIP, "hipMemset"); }
@@ -66,7 +71,7 @@ extern "C" void guber_wire_dev_destroy(guber_wire_dev_t* d) {
     if (d->e) { (void)hipSetDevice(d->e->device); (void)hipStreamSynchronize(d->stream()); }
     if (d->ev_dec) (void)hipEventDestroy(d->ev_dec);
     if (d->ev_eval) (void)hipEventDestroy(d->ev_eval);
-    d->h_buf.release(); d->h_u32.release(); d->h_rep.release(); d->d_buf.release(); d->d_rows.release(); d->d_u8.release();
+    d->h_buf.release(); d->h_rep.release(); d->d_buf.release(); d->d_rows.release(); d->d_u8.release();
     d->d_u32.release(); d->d_went.release(); d->d_rec.release(); d->d_status.release(); d->d_algo.release(); d->d_i64.release(); d->d_out64.release(); d->d_out8.release();
     d->h_cols.release();
     delete d;
@@ -77,14 +82,15 @@ extern "C" void guber_wire_dev_destroy(guber_wire_dev_t* d) {
 static int wire_dev_decode_enqueue(guber_wire_dev* d, uint32_t nrpc, size_t lo, size_t hi, uint32_t windows, bool multi, const uint8_t* is_owner,
                                    uint32_t max_per_rpc, int64_t now_ms) {
     const size_t R = d->max_rpcs;
-    uint32_t* h_off = d->h_u32.p;
+    uint32_t* h_off = d->h_meta();
     uint8_t* h_owner = (uint8_t*)(h_off + 3 * R + 1);
     hipStream_t st = d->stream();
     if (is_owner) memcpy(h_owner, is_owner, nrpc); else memset(h_owner, 1, nrpc);
-    // two copies — the payload bytes, and the decode's arguments in one piece (off | len | wfirst | owner) — then the kernels; the verdicts
-    // come back through k_wire_kill's stores into host memory: no copy, no memset behind or between (every command costs the stream ~5 us)
-    HIPCHK(hipMemcpyAsync(d->d_buf.p + lo, d->h_buf.p + lo, hi - lo, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync((void*)d->in.rpc_off, h_off, (3 * R + 1) * 4 + nrpc, hipMemcpyHostToDevice, st));
+    // ONE copy — the decode's arguments (off | len | wfirst | owner) and, behind them, the payload bytes up to the last payload's end — then the
+    // kernels; the verdicts come back through k_wire_kill's stores into host memory: no copy, no memset behind or between (every command costs
+    // the stream ~5 us; what lies between the arguments and the first payload of a caller that staged at an offset travels along unread)
+    (void)lo;
+    HIPCHK(hipMemcpyAsync(d->d_buf.p, d->h_buf.p, d->meta_bytes + hi, hipMemcpyHostToDevice, st));
     d->in.nrpc = nrpc; d->in.max_per_rpc = max_per_rpc; d->out.now_ms = now_ms;
     // the chain of every payload: in parallel (a workgroup per 8 KB window, pointer doubling: k_wire_win_a — only when a payload has
     // more than one window — says where the chain enters each window, k_wire_win_b finds the records), then the serial walk for the
@@ -141,7 +147,7 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
     if (e->set_device()) return fail(GUBER_E_HIP, "hipSetDevice");
     d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
     if (!nrpc) return GUBER_OK;
-    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 2 * (size_t)d->max_rpcs;
+    uint32_t* h_off = d->h_meta(); uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 2 * (size_t)d->max_rpcs;
     size_t pos = 0;
     uint32_t windows = 0;
     bool multi = false;                                                                    // a payload of more than one window: k_wire_win_a has something to say
@@ -151,12 +157,12 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
         pos = (pos + 15) & ~(size_t)15;
         if (pos + lens[r] + 16 > d->max_bytes) return fail(GUBER_E_WIRE_FULL, "payload bytes exceed the decoder's buffer");
         if (lens[r] && !msgs[r]) return fail(GUBER_E_INVALID_ARG, "null payload");
-        memcpy(d->h_buf.p + pos, msgs[r], lens[r]);
+        memcpy(d->h_pay() + pos, msgs[r], lens[r]);
         h_off[r] = (uint32_t)pos; h_len[r] = lens[r];
         pos += lens[r];
     }
     h_wfirst[nrpc] = windows;                                                              // (<= max_windows: the bytes fit)
-    memset(d->h_buf.p + pos, 0, 16);
+    memset(d->h_pay() + pos, 0, 16);
     return wire_dev_decode_staged_locked(d, nrpc, 0, pos + 16, windows, multi, is_owner, max_per_rpc, now_ms, status, first, count, n_items);
 }
 
@@ -165,7 +171,7 @@ extern "C" int guber_wire_dev_decode(guber_wire_dev_t* d, const uint8_t* const* 
 // interpreted).  Everything else as guber_wire_dev_decode.
 extern "C" int guber_wire_dev_buffer(guber_wire_dev_t* d, uint8_t** buf, size_t* cap) {
     if (!d || !buf || !cap) return fail(GUBER_E_INVALID_ARG, "null argument");
-    *buf = d->h_buf.p; *cap = d->max_bytes;
+    *buf = d->h_pay(); *cap = d->max_bytes;
     return GUBER_OK;
 }
 static int wire_dev_decode_staged_any(guber_wire_dev_t* d, const uint32_t* offs, const uint32_t* lens, uint32_t nrpc, const uint8_t* is_owner,
@@ -182,7 +188,7 @@ static int wire_dev_decode_staged_any(guber_wire_dev_t* d, const uint32_t* offs,
     if (d->own ? hipSetDevice(e->device) != hipSuccess : e->set_device() != 0) return fail(GUBER_E_HIP, "hipSetDevice");
     d->nrpc = nrpc; d->n_items = 0; d->now_ms = now_ms;
     if (!nrpc) return GUBER_OK;
-    uint32_t* h_off = d->h_u32.p; uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 2 * (size_t)d->max_rpcs;
+    uint32_t* h_off = d->h_meta(); uint32_t* h_len = h_off + d->max_rpcs; uint32_t* h_wfirst = h_off + 2 * (size_t)d->max_rpcs;
     uint32_t windows = 0;
     bool multi = false;
     size_t end = 0;
