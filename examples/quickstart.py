@@ -6,6 +6,8 @@ of include/guber_gpu.h, so the same calls map one-to-one to cgo / JNI / N-API).
   2. a batch of RateLimitReq-shaped rows (structure of arrays), evaluated in request order like gubernator's
      V1.GetRateLimits -> WorkerPool.GetRateLimit
   3. the same through the protobuf wire format (what a daemon would hand over from the socket)
+  4. the payload stage: what a gRPC handler thread calls with the raw bytes of its RPC — decode, routing to the GPU's tables, evaluation and the
+     answers' order all on the device (guber_wire_pool_*)
 """
 import os
 import sys
@@ -46,3 +48,16 @@ first, count = wb.decode(payload, max_per_rpc=1000)
 wb.eval(engine)
 print("GetRateLimitsResp bytes:", wb.encode(first, count).hex())
 engine.close()
+
+# the payload stage over four tables of one GPU: serialized GetRateLimitsReq in, serialized GetRateLimitsResp out; thread-safe, one call per RPC
+place = ga.Placement(4)                                        # key -> table: the reference's worker rule (workers.go:180-184), hot keys isolated online
+first_table = ga.Engine(cache_size=100_000, max_batch=8192)
+tables = [first_table] + [ga.Engine(cache_size=100_000, max_batch=8192, stream=first_table.stream_handle()) for _ in range(3)]
+pool = wire.WirePool(tables, place)                            # defaults: twelve stages of 49 152 items, BatchWait 500 us, 1000 requests per RPC
+payload = req(b"requests_per_sec", b"account:7", 1, 2, 9_000) * 3 + req(b"mails_per_hour", b"account:7", 1, 100, 3_600_000)
+print("payload stage:", pool.get_rate_limits(payload).hex())
+print("stages so far:", pool.stats()["stages"])
+pool.close()
+for t in reversed(tables):
+    t.close()
+place.close()

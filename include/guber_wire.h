@@ -185,7 +185,12 @@ int guber_wire_dev_route_ready(guber_wire_dev_t* d, guber_front_t* f);
  *                                     as the protobuf runtime / gubernator.go:189-193 do.  The bytes equal guber_wire_encode_responses' (and the
  *                                     protobuf runtimes').
  *   guber_wire_pool_set_clock         0 = the wall clock (clock.Now(): a stage's items share the instant it was sealed); otherwise a frozen clock
- *                                     in ms, as the reference's tests use clock.Freeze */
+ *                                     in ms, as the reference's tests use clock.Freeze
+ *   What this surface does NOT do: the Store's write-through callbacks (store.go:49-65: guber_pool_set_store / guber_eval_batch_store — a daemon
+ *   with conf.Store keeps the per-request pool), metadata propagation (RateLimitReq.metadata is skipped), and the decision WHERE a payload goes
+ *   (forwarding to the owning peer, gubernator.go:236-283: the Go front end hands over only what this instance evaluates).  Behavior_GLOBAL items
+ *   are evaluated on their table and queued for the GLOBAL exchange by the engine as on every other entry point (guber_global_take / _sync);
+ *   a rule whose global_engine is set sends them to the device's GLOBAL engine. */
 typedef struct guber_wire_pool guber_wire_pool_t;
 typedef struct guber_wire_pool_config {
     uint32_t stages;             /* payload stages in rotation (one fills while the others are on the GPU); 0 = 12, 2 .. 12 */
