@@ -31,7 +31,7 @@ struct guber_front {
     // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
     // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
     // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
-    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0, one_pair_max = FRONT_ONE_PAIR_MAX;
+    hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0, one_pair_max = FRONT_ONE_PAIR_MAX; bool rs_borrowed = false;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
     DevBuf<uint16_t> rt_table, rt_exs; DevBuf<uint64_t> rt_exh; RouteRule rule{}; bool have_rule = false;
@@ -73,7 +73,7 @@ extern "C" void guber_front_destroy(guber_front_t* f) {
     f->rt_table.release(); f->rt_exs.release(); f->rt_exh.release();
     if (f->rs2 && f->rs2 != f->rs) (void)hipStreamDestroy(f->rs2);
     if (f->os && f->os != f->rs) (void)hipStreamDestroy(f->os);
-    if (f->rs) (void)hipStreamDestroy(f->rs);
+    if (f->rs && !f->rs_borrowed) (void)hipStreamDestroy(f->rs);
     delete f;
 }
 
@@ -167,6 +167,19 @@ extern "C" int guber_front_create(guber_engine_t* const* engines, uint32_t n_eng
     HIPCHK(hipStreamSynchronize(f->rs));
     *out = f.release();
     return GUBER_OK;
+}
+
+// The routing on a stream of the caller's choice — the engines' own, when they share one — instead of the front's (before the front's first
+// generation).  For a caller that needs the hardware queue the routing stream would take: the runtime has four that run at full speed
+// (profiles/r06_wire_pool_hw_queues.txt: a fifth quarters the payload stage's rate), and a payload stage wants two for its decodes.
+static int front_route_on(guber_front* f, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(f->mu);
+    if (f->generations || f->pre_routed || f->n_own_streams != 1) return fail(GUBER_E_INVALID_ARG, "guber_front: the routing stream is chosen before the first generation");
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    HIPCHK(hipStreamSynchronize(f->rs));
+    HIPCHK(hipStreamDestroy(f->rs));
+    f->rs = f->rs2 = f->os = st; f->rs_borrowed = true;
+    return 0;
 }
 
 extern "C" int guber_front_set_rule(guber_front_t* f, const guber_route_rule_t* rule) {

@@ -414,7 +414,18 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
         if (rc) return rc;
     }
     if (hipSetDevice(p->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+#ifdef GUBER_LAB
+    {   // (laboratory knob: the front's routing on the engines' one stream, which frees a hardware queue for the second decode stream:
+        //  profiles/r06_wire_pool_hw_queues.txt — faster with 256 callers, slower with fewer)
+        const char* v = guber_lab_env("GUBER_WIRE_ROUTE_ON_ENGINES");
+        bool one = true;
+        for (uint32_t j = 1; j < n_engines; ++j) one = one && engines[j]->stream == engines[0]->stream;
+        if (v && atoi(v) != 0 && one) { const int rc = front_route_on(p->front, engines[0]->stream); if (rc) return rc; }
+    }
+#endif
     HIPCHK(hipStreamCreateWithFlags(&p->ws[0], hipStreamNonBlocking));
+    // (both decode streams land on ONE of the runtime's hardware queues, ~75 % busy at 400 M/s; a second one at another priority or GPU_MAX_HW_QUEUES > 4
+    //  gives it a queue of its own — a FIFTH queue, and the rate falls to a quarter: profiles/r06_wire_pool_hw_queues.txt)
     if (c.decodes_queued > 1) HIPCHK(hipStreamCreateWithFlags(&p->ws[1], hipStreamNonBlocking));
     p->stages.reset(new guber_wire_pool::Stage[c.stages]);
     const size_t M = c.max_items, R = c.max_rpcs;
