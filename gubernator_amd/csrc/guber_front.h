@@ -13,6 +13,7 @@
 // The routing runs ahead of the evaluation (two generations), so the shares' sizes — which the host needs to size the launches and to
 // keep the bounded caches' admission exact — are in pinned memory by the time the host asks: it never waits for the GPU in steady state.
 #pragma once
+#include "guber_kernels_wire.h"    // guber::WireEnc / k_wire_enc: the payload stage's form of the answers' last hop (front_out)
 
 // generations of at most this many requests whose tables share ONE stream go as one pair of launches for all tables (launch_group_mem);
 // larger ones keep the owner-partitioned pipeline in groups of four tables, whose advantage grows with the share.
@@ -31,6 +32,7 @@ struct guber_front {
     // engines' streams idled two fifths of the time: 4.36 -> 5.7 G decisions/s at 8 batches per generation, 5.93 -> 6.2 at 16.  More
     // streams of its own (answers, a second routing stream: GUBER_FRONT_STREAMS=2|3 in the laboratory build) lose 5 - 10 %: the HIP
     // runtime maps streams onto four hardware queues, a fifth stream shares one (and GPU_MAX_HW_QUEUES=8 halves the rate).
+    const guber::WireEnc* enc_hook = nullptr;         // set around a front_eval call by the payload stage: k_wire_enc in k_fr_out's place (front_out)
     hipStream_t rs = nullptr, rs2 = nullptr, os = nullptr, last_os = nullptr; int n_own_streams = 1; bool out_on_eval = false; uint32_t out_delay = 0, one_pair_max = FRONT_ONE_PAIR_MAX; bool rs_borrowed = false;
     uint32_t cap = 0, depth = 0, max_key = 0;
     uint32_t seq = 0;
@@ -240,6 +242,12 @@ static int front_out(guber_front* f, guber_front::Slot& s, guber_result_t* r) {
     std::unique_lock<std::mutex> pl(e0->mu, std::defer_lock);
     if (e0->profiling) pl.lock();
     e0->span_begin(KT_FR_OUT, s.n, os);
+    if (f->enc_hook) {
+        // the payload stage (guber_wire_pool.h): the answers' last hop is the encoder — every RPC's GetRateLimitsResp bytes from the shares, through fwd
+        guber::WireEnc E = *f->enc_hook;
+        E.fwd = O.fwd; E.d_status = O.d_status; E.d_err = O.d_err; E.d_limit = O.d_limit; E.d_remaining = O.d_remaining; E.d_reset = O.d_reset_time;
+        hipLaunchKernelGGL(guber::k_wire_enc, dim3(E.nrpc), dim3(guber::WE_T), 0, os, E);
+    } else
     hipLaunchKernelGGL(k_fr_out, dim3((s.n + FR_TILE - 1u) / FR_TILE), dim3(256), 0, os, O);
     e0->span_end();
     if (s.ev_a) { hipEvent_t evb = e0->get_event(); (void)hipEventRecord(evb, os); f->gen_spans.push_back({s.ev_a, evb}); s.ev_a = nullptr; }

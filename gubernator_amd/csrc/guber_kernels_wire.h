@@ -552,4 +552,123 @@ __global__ __launch_bounds__(256) void k_wire_kill(WireIn in, WireScratch sc, Wi
     if (sc.status[out.item_rpc[i]] != WIRE_OK) { out.key_len[i] = 0; out.pre_err[i] = WIRE_PRE_DEAD; }
 }
 
+// ---- the answers as GetRateLimitsResp bytes, encoded where they are -----------------------------------------------------------------
+// gubernator.proto:184-203: GetRateLimitsResp = repeated RateLimitResp responses = 1; RateLimitResp = status 1, limit 2, remaining 3,
+// reset_time 4 (varints, zero fields not written), error 5, metadata 6.  One workgroup per RPC turns its slice of the answers (arrival
+// order, HBM) into the bytes the runtimes write for it — `0x0a len body` per item, at most 37 bytes — and leaves them in DEVICE-VISIBLE
+// HOST memory at wire_enc_off(first, r), their number in enc_len[r]: all that is left for the RPC's caller thread is one memcpy.  An
+// RPC with an item error (the text needs the item's key and raw algorithm: the host transcoder writes it) is not encoded: its raw answers
+// go to the host arrays instead and enc_len[r] = WIRE_ENC_RAW.  Byte-for-byte the host transcoder's output (csrc/wire.cpp), which is
+// checked against the protobuf runtime.
+constexpr uint32_t WIRE_ENC_ITEM_MAX = 37;                           // 0x0a, one length byte, status (2), three int64 fields (11 each)
+constexpr uint32_t WIRE_ENC_RAW = 0xffffffffu;
+constexpr uint32_t WE_T = 256, WE_PER = 4, WE_CH = WE_T * WE_PER;  // a workgroup encodes its RPC in pieces of 1 024 items
+// where RPC r's bytes start: 16-byte aligned, and the regions of two RPCs never meet (count x 37 + 17 bytes apart at least, the last
+// piece is written in whole 16-byte words)
+GW_HD size_t wire_enc_off(uint32_t first, uint32_t r) { return ((size_t)first * WIRE_ENC_ITEM_MAX + (size_t)r * 32u) & ~(size_t)15; }
+GW_HD size_t wire_enc_bytes(uint32_t max_items, uint32_t max_rpcs) { return (size_t)max_items * WIRE_ENC_ITEM_MAX + (size_t)max_rpcs * 32u + 64u; }
+struct WireEnc {
+    uint32_t nrpc;
+    const uint32_t *first, *count; const int32_t* status;            // the decode's verdicts (HBM)
+    // the answers (HBM): item i's are at fwd[i] — the front's shares, as the engines left them: this kernel IS the answers' last hop
+    // (k_fr_out's place, guber_front.h front_out) — or, fwd null, at i
+    const uint32_t* fwd;
+    const uint8_t *d_status, *d_err; const int64_t *d_limit, *d_remaining, *d_reset;
+    uint8_t* enc; uint32_t* enc_len;                                 // host memory the device writes in place
+    uint8_t *h_status, *h_err; int64_t *h_limit, *h_remaining, *h_reset;               // host: the raw answers of the RPCs that are not encoded
+};
+__device__ __forceinline__ uint32_t wire_varint_len(uint64_t v) {
+    uint32_t n = 1;
+    while (v >= 0x80ull) { v >>= 7; ++n; }
+    return n;
+}
+__device__ __forceinline__ uint32_t wire_put_field(uint8_t* p, uint8_t tag, uint64_t v) {   // a varint field that is not zero
+    uint32_t n = 0;
+    p[n++] = tag;
+    while (v >= 0x80ull) { p[n++] = (uint8_t)(v | 0x80ull); v >>= 7; }
+    p[n++] = (uint8_t)v;
+    return n;
+}
+__global__ __launch_bounds__(WE_T) void k_wire_enc(WireEnc E) {
+    __shared__ alignas(16) uint8_t stage[WE_CH * WIRE_ENC_ITEM_MAX + 32];
+    __shared__ uint32_t wsum[WE_T / 64];
+    __shared__ uint32_t s_bad;
+    const uint32_t r = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t first = E.first[r];
+    const uint32_t count = E.status[r] == WIRE_OK ? E.count[r] : 0u;  // (a message turned away whole has no answers: its caller gets the verdict)
+    if (count == 0u) { if (tid == 0) E.enc_len[r] = 0u; return; }
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    // an item error anywhere in the RPC?  An RPC of one piece (the usual one: at most 1 000 items, gubernator.go:40) finds out from the loads it
+    // encodes from; a longer one looks first
+    const bool one_piece = count <= WE_CH;
+    if (!one_piece) {
+        uint32_t bad = 0;
+        for (uint32_t k = tid; k < count; k += WE_T) { const uint32_t i = first + k; bad |= E.d_err[E.fwd ? E.fwd[i] : i] != 0 ? 1u : 0u; }
+        if (bad) s_bad = 1u;
+        __syncthreads();
+    }
+    auto raw = [&]() {                                                 // the host transcoder's: the raw answers, as they are, in arrival order
+        for (uint32_t k = tid; k < count; k += WE_T) {
+            const uint32_t i = first + k, j = E.fwd ? E.fwd[i] : i;
+            E.h_status[i] = E.d_status[j]; E.h_err[i] = E.d_err[j]; E.h_limit[i] = E.d_limit[j]; E.h_remaining[i] = E.d_remaining[j]; E.h_reset[i] = E.d_reset[j];
+        }
+        if (tid == 0) E.enc_len[r] = WIRE_ENC_RAW;
+    };
+    if (!one_piece && s_bad) { raw(); return; }
+    uint8_t* const dst = E.enc + wire_enc_off(first, r);
+    uint32_t carry = 0, flushed = 0;                                   // bytes at the front of `stage` that wait for a whole word; bytes that have left
+    for (uint32_t c0 = 0; c0 < count; c0 += WE_CH) {
+        // thread t: items c0 + 4 t .. c0 + 4 t + 3 (neighbours in the output: one offset per thread)
+        const uint32_t i0 = c0 + tid * WE_PER;
+        uint32_t st[WE_PER]; uint64_t lim[WE_PER], rem[WE_PER], rst[WE_PER];
+        uint32_t mine = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < WE_PER; ++k) {
+            st[k] = 0; lim[k] = 0; rem[k] = 0; rst[k] = 0;
+            if (i0 + k < count) {
+                const uint32_t i = E.fwd ? E.fwd[first + i0 + k] : first + i0 + k;
+                st[k] = E.d_status[i]; lim[k] = (uint64_t)E.d_limit[i]; rem[k] = (uint64_t)E.d_remaining[i]; rst[k] = (uint64_t)E.d_reset[i];
+                if (one_piece && E.d_err[i] != 0) s_bad = 1u;
+                mine += 2u + (st[k] ? 1u + wire_varint_len(st[k]) : 0u) + (lim[k] ? 1u + wire_varint_len(lim[k]) : 0u) +
+                        (rem[k] ? 1u + wire_varint_len(rem[k]) : 0u) + (rst[k] ? 1u + wire_varint_len(rst[k]) : 0u);
+            }
+        }
+        const uint32_t incl = wire_wave_incl_scan(mine);
+        if (lane == 63u) wsum[wave] = incl;
+        __syncthreads();
+        if (one_piece && s_bad) { raw(); return; }
+        uint32_t base = carry + incl - mine, chunk = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < WE_T / 64; ++w) { const uint32_t s = wsum[w]; if (w < wave) base += s; chunk += s; }
+        uint8_t* o = stage + base;
+#pragma unroll
+        for (uint32_t k = 0; k < WE_PER; ++k) {
+            if (i0 + k < count) {
+                uint8_t* body = o + 2;
+                uint32_t b = 0;
+                if (st[k]) b += wire_put_field(body + b, 0x08, st[k]);
+                if (lim[k]) b += wire_put_field(body + b, 0x10, lim[k]);
+                if (rem[k]) b += wire_put_field(body + b, 0x18, rem[k]);
+                if (rst[k]) b += wire_put_field(body + b, 0x20, rst[k]);
+                o[0] = 0x0a; o[1] = (uint8_t)b;                        // (a body is at most 35 bytes: its length is one byte)
+                o += 2 + b;
+            }
+        }
+        const uint32_t total = carry + chunk;
+        const bool last = c0 + WE_CH >= count;
+        const uint32_t full = last ? (total + 15u) & ~15u : total & ~15u;
+        if (last && tid < full - total) stage[total + tid] = 0;       // (the last word's padding: never read as part of the response)
+        __syncthreads();
+        for (uint32_t q = tid * 16u; q < full; q += WE_T * 16u) *(uint4*)(dst + flushed + q) = *(const uint4*)(stage + q);
+        if (last) { if (tid == 0) E.enc_len[r] = flushed + total; return; }
+        uint8_t keep = 0;
+        if (tid < total - full) keep = stage[full + tid];
+        __syncthreads();
+        if (tid < total - full) stage[tid] = keep;
+        carry = total - full; flushed += full;
+        __syncthreads();
+    }
+}
+
 }  // namespace guber

@@ -369,6 +369,41 @@ extern "C" int guber_wire_dev_eval_front_async(guber_wire_dev_t* d, guber_front_
     d->eval_pending = true;
     return GUBER_OK;
 }
+// wire_dev_eval_front_enc_async     the payload stage's form of guber_wire_dev_eval_front_async: k_wire_enc IS the answers' last hop (front_out
+//                                   launches it in k_fr_out's place) — it reads the shares' answers through the routing's fwd[] and leaves every
+//                                   RPC's GetRateLimitsResp bytes in `enc` (DEVICE-VISIBLE HOST memory of wire_enc_bytes(max_items, max_rpcs)
+//                                   bytes; RPC r's at wire_enc_off(first[r], r), enc_len[r] of them).  An RPC with an item error is not encoded:
+//                                   enc_len[r] = WIRE_ENC_RAW and its raw answers are in `raw`'s (device-visible host) arrays, in arrival order,
+//                                   for the host transcoder.
+static int wire_dev_eval_front_enc_async(guber_wire_dev* d, guber_front* f, uint8_t* enc, uint32_t* enc_len, guber_result_t* raw) {
+    if (!d || !f || !enc || !enc_len || !raw) return fail(GUBER_E_INVALID_ARG, "null argument");
+    if (d->dec_pending || d->eval_pending) return fail(GUBER_E_INVALID_ARG, "the decoder's previous asynchronous call has not been collected");
+    const uint32_t n = d->n_items;
+    raw->over_limit_count = raw->cache_hits = raw->cache_misses = raw->unexpired_evictions = 0; raw->cache_size = 0;
+    if (!n) return GUBER_OK;
+    if (!raw->status || !raw->limit || !raw->remaining || !raw->reset_time || !raw->err) return fail(GUBER_E_INVALID_ARG, "result is missing an array");
+    if (n > f->cap) return fail(GUBER_E_BATCH_TOO_LARGE, "more items than the front's generations hold");
+    if (hipSetDevice(f->device) != hipSuccess) return fail(GUBER_E_HIP, "hipSetDevice");
+    if (!d->ev_eval) HIPCHK(hipEventCreateWithFlags(&d->ev_eval, hipEventDisableTiming));
+    const size_t M = d->max_items;
+    FrontGen g;
+    wire_dev_front_gen(d, g);
+    guber_result_t dr{};
+    dr.status = d->d_out8.p; dr.err = d->d_out8.p + M; dr.limit = d->d_out64.p; dr.remaining = d->d_out64.p + M; dr.reset_time = d->d_out64.p + 2 * M;
+    d->routed = false;
+    // (the encoder takes the place of the answers' last hop, front_out: it reads the shares' answers through the routing's fwd[] — one launch
+    //  and one pass over the answers less than k_fr_out into HBM + an encoder behind it, which measured -10 % with 64 - 128 callers)
+    guber::WireEnc E{};
+    E.nrpc = d->nrpc; E.first = d->sc.first; E.count = d->sc.count; E.status = d->sc.status;
+    E.enc = enc; E.enc_len = enc_len;
+    E.h_status = raw->status; E.h_err = raw->err; E.h_limit = raw->limit; E.h_remaining = raw->remaining; E.h_reset = raw->reset_time;
+    f->enc_hook = &E;
+    const int rc = front_eval(f, &g, &dr, 1, nullptr, d->ev_eval);
+    f->enc_hook = nullptr;
+    if (rc) return rc;
+    d->eval_pending = true;
+    return GUBER_OK;
+}
 extern "C" int guber_wire_dev_eval_collect(guber_wire_dev_t* d, int wait) {
     if (!d) return fail(GUBER_E_INVALID_ARG, "null argument");
     if (!d->eval_pending) return GUBER_OK;

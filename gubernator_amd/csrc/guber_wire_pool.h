@@ -1,10 +1,11 @@
 // guber_wire_pool.h — guber_wire_pool_*: the payload stage.  Caller threads (the gRPC handlers of a daemon) hand over the SERIALIZED
 // GetRateLimitsReq / GetPeerRateLimitsReq of their RPC and get the serialized response back; per RPC the host does one compare-and-swap
-// (a place in the open stage), one memcpy (the payload into pinned memory) and the response's varints.  Everything the reference does per
+// (a place in the open stage) and two memcpys (the payload into pinned memory, the response out of it).  Everything the reference does per
 // REQUEST on the CPU — unmarshalling into heap objects (generated code of gubernator.proto:137-182), validation and the CreatedAt default
 // (gubernator.go:189-220), HashKey (client.go:39-41), the worker's choice by XXH64 (workers.go:180-184, :261-289), the evaluation
-// (algorithms.go), the answers' order (gubernator.proto:51-54) — happens on the device: k_wire_* (decode) -> guber_front (k_fr_*: routing,
-// the engines' fused pipelines, the answers in arrival order, written in place into host memory over PCIe).
+// (algorithms.go), the answers' order (gubernator.proto:51-54), marshalling the response (gubernator.proto:184-203) — happens on the device:
+// k_wire_* (decode) -> guber_front (k_fr_*: routing, the engines' fused pipelines, the answers in arrival order) -> k_wire_enc (every RPC's
+// GetRateLimitsResp bytes, written in place into host memory over PCIe; an RPC with an item error: its raw answers, for the host transcoder).
 // The batching shape is the reference's own (peer_client.go:284-337: a queue that is sent when it is full or BatchWait after its first
 // entry), turned around: RPCs are the entries, a stage is the queue.
 //
@@ -103,7 +104,8 @@ struct guber_wire_pool {
         uint8_t* buf = nullptr;
         PinBuf<uint32_t> meta; PinBuf<uint8_t> owner;                     // offs[R] | lens[R]; is_owner[R] — written by the callers at their index
         std::vector<int32_t> status; std::vector<uint32_t> first, count;  // per RPC, after the decode
-        CohBuf<uint8_t> res; guber_result_t r{};                          // the answers in arrival order: written by the device, read by the callers
+        CohBuf<uint8_t> res; guber_result_t r{};                          // the raw answers in arrival order (host memory the device writes in place): of the RPCs the device does not encode
+        CohBuf<uint8_t> enc; CohBuf<uint32_t> enc_len;                    // every RPC's GetRateLimitsResp bytes (k_wire_enc): at wire_enc_off(first, idx), enc_len[idx] of them
         alignas(64) std::atomic<uint64_t> word{WPL_CLOSED};
         alignas(64) std::atomic<uint32_t> filled{0}; std::atomic<int64_t> t_first_us{0};
         alignas(64) std::atomic<uint32_t> done_gen{0xffffffffu}; std::atomic<uint32_t> sleepers{0};
@@ -117,6 +119,7 @@ struct guber_wire_pool {
     hipStream_t ws[2] = {nullptr, nullptr};            // the decodes' streams: consecutive stages alternate, so one stage's copy and latency-bound kernels run beside the other's
     uint32_t next_open = 0;
     uint32_t n_stages = 0, max_items = 0, max_b16 = 0, max_rpcs = 0, wait_us = 0, max_per_rpc = 0, item_cap = 0, spin_us = 0, decodes = 2;
+    bool host_encode = false;                           // laboratory build only: the callers write the responses' varints themselves (round 6's first form, for A/B runs)
     std::unique_ptr<Stage[]> stages;
     alignas(64) std::atomic<uint32_t> open_word{WPL_NONE};               // (sequence << 4) | stage index (15: none): futex word of callers waiting for a stage
     std::atomic<uint32_t> open_waiters{0};
@@ -327,7 +330,8 @@ static void wpl_front(guber_wire_pool* p) {
             int st = s.state.load(std::memory_order_relaxed);
             if (st == WP::ROUTING && guber_wire_dev_route_ready(s.dec, p->front) != GUBER_PENDING) {
                 const auto h0 = std::chrono::steady_clock::now();
-                const int rc = guber_wire_dev_eval_front_async(s.dec, p->front, &s.r);
+                const int rc = p->host_encode ? guber_wire_dev_eval_front_async(s.dec, p->front, &s.r)
+                                              : wire_dev_eval_front_enc_async(s.dec, p->front, s.enc.p, s.enc_len.p, &s.r);
                 p->st_host_eval_ns.fetch_add(wpl_ns_since(h0), std::memory_order_relaxed);
                 p->evals_started.fetch_add(1, std::memory_order_release);       // (also after a failure: the routing was consumed or given up)
                 if (rc) { wpl_publish(p, s, rc); st = WP::ANSWERED; }
@@ -376,7 +380,7 @@ extern "C" void guber_wire_pool_destroy(guber_wire_pool_t* p) {
     if (p->stages) for (uint32_t k = 0; k < p->n_stages; ++k) {
         guber_wire_pool::Stage& s = p->stages[k];
         if (s.dec) guber_wire_dev_destroy(s.dec);
-        s.meta.release(); s.owner.release(); s.res.release();
+        s.meta.release(); s.owner.release(); s.res.release(); s.enc.release(); s.enc_len.release();
     }
     if (p->front) guber_front_destroy(p->front);
     for (hipStream_t st : p->ws) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
@@ -417,6 +421,8 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
 #ifdef GUBER_LAB
     {   // (laboratory knob: the front's routing on the engines' one stream, which frees a hardware queue for the second decode stream:
         //  profiles/r06_wire_pool_hw_queues.txt — faster with 256 callers, slower with fewer)
+        const char* he = guber_lab_env("GUBER_WIRE_HOST_ENCODE");
+        p->host_encode = he && atoi(he) != 0;
         const char* v = guber_lab_env("GUBER_WIRE_ROUTE_ON_ENGINES");
         bool one = true;
         for (uint32_t j = 1; j < n_engines; ++j) one = one && engines[j]->stream == engines[0]->stream;
@@ -439,7 +445,8 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
         rc = guber_wire_dev_buffer(s.dec, &s.buf, &cap);
         if (rc) return rc;
         const size_t col8 = (M + 63) & ~(size_t)63;
-        if (s.meta.ensure(2 * R) || s.owner.ensure(R) || s.res.ensure(2 * col8 + 3 * 8 * M + 64)) return GUBER_E_NOMEM;
+        if (s.meta.ensure(2 * R) || s.owner.ensure(R) || s.res.ensure(2 * col8 + 3 * 8 * M + 64) || s.enc.ensure(guber::wire_enc_bytes(c.max_items, c.max_rpcs)) || s.enc_len.ensure(R))
+            return GUBER_E_NOMEM;
         s.status.resize(R); s.first.resize(R); s.count.resize(R);
         uint8_t* q = s.res.p;
         s.r = guber_result_t{};
@@ -544,10 +551,15 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
         if (st != GUBER_OK) rc = st;                                   // GUBER_E_WIRE_MALFORMED / GUBER_E_WIRE_TOO_LARGE: the whole message is turned away
         else {
             const uint32_t first = s.first[idx], count = s.count[idx];
-            const uint8_t* e8 = s.r.err + first;
-            bool any_err = false;
-            for (uint32_t i = 0; i < count; ++i) any_err = any_err || e8[i] != GUBER_ITEM_OK;
-            if (!any_err && cap >= (size_t)count * 37) {
+            const uint32_t el = p->host_encode ? guber::WIRE_ENC_RAW : s.enc_len.p[idx];
+            bool any_err = !p->host_encode;                            // (not encoded on the device: an item carries an error, the raw answers are in s.r)
+            if (p->host_encode) { const uint8_t* e8 = s.r.err + first; for (uint32_t i = 0; i < count; ++i) any_err = any_err || e8[i] != GUBER_ITEM_OK; }
+            if (el != guber::WIRE_ENC_RAW) {
+                // the device has written this RPC's GetRateLimitsResp (k_wire_enc): one memcpy.  (cap >= el: the check at the door — the
+                // response bound, or 37 bytes per item, which is the most an item without an error takes)
+                if (cap < el) rc = fail(GUBER_E_NOMEM, "response buffer too small (the decisions HAVE been applied): guber_wire_pool_response_bound()");
+                else { memcpy(resp, s.enc.p + guber::wire_enc_off(first, idx), el); used = el; }
+            } else if (!any_err && cap >= (size_t)count * 37) {     // (laboratory build, GUBER_WIRE_HOST_ENCODE=1: the caller writes the varints)
                 const uint8_t* st8 = s.r.status + first; const int64_t* lim = s.r.limit + first; const int64_t* rem = s.r.remaining + first; const int64_t* rst = s.r.reset_time + first;
                 uint8_t* o = resp;
                 for (uint32_t i = 0; i < count; ++i) {

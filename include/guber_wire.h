@@ -171,9 +171,11 @@ int guber_wire_dev_route_ready(guber_wire_dev_t* d, guber_front_t* f);
 /* ---- the payload stage: V1Instance.GetRateLimits / GetPeerRateLimits on the SERIALIZED messages (gubernator.go:183-306, :470-520; the batching
  *      shape is peer_client.go:284-337's: a queue that leaves when it is full or BatchWait after its first entry — here RPCs are the entries).
  *      Caller threads (the gRPC handlers: a codec that hands the handler the raw bytes) call guber_wire_pool_get_rate_limits concurrently; per RPC the
- *      host does one compare-and-swap (a place in the open stage), one memcpy (the payload into pinned memory) and the response's varints.
- *      Unmarshalling, validation, the CreatedAt default, HashKey, the worker's choice by XXH64 (workers.go:180-184), the evaluation and the
- *      answers' order all happen on the device: k_wire_* -> guber_front -> the answers written in place into host memory.
+ *      host does one compare-and-swap (a place in the open stage) and two memcpys (the payload into pinned memory, the response out of it).
+ *      Unmarshalling, validation, the CreatedAt default, HashKey, the worker's choice by XXH64 (workers.go:180-184), the evaluation, the
+ *      answers' order and the marshalling of GetRateLimitsResp (gubernator.proto:184-203) all happen on the device: k_wire_* -> guber_front ->
+ *      k_wire_enc, which writes every RPC's response bytes in place into host memory.  (An RPC with an item error is marshalled by the host
+ *      transcoder from the raw answers: the error's text needs the item's key.)
  *   guber_wire_pool_create            over the engines of ONE device and the placement's rule (as guber_front_create; rule NULL with one engine);
  *                                     cfg NULL or zero fields = defaults.  Two threads per pool (intake, front); neither ever blocks on the GPU.
  *   guber_wire_pool_get_rate_limits   req/len: one serialized GetRateLimitsReq (= GetPeerRateLimitsReq); is_owner: RateLimitReqState.IsOwner of its

@@ -55,6 +55,7 @@ struct guber_wire_dev {
     std::vector<int32_t> status; std::vector<uint32_t> first, count;
     uint32_t nrpc = 0, n_items = 0; int polls = 0; bool dec_pending = false, eval_pending = false, routed = false;
     guber_result_t* dst = nullptr;
+    uint8_t* enc = nullptr; uint32_t* enc_len = nullptr;
 };
 extern "C" int guber_front_create(guber_engine_t* const*, uint32_t, const guber_route_rule_t*, uint32_t, uint32_t, guber_front_t** out) { *out = new guber_front(); return 0; }
 extern "C" void guber_front_destroy(guber_front_t* f) { delete f; }
@@ -110,6 +111,16 @@ extern "C" int guber_wire_dev_eval_front_async(guber_wire_dev_t* d, guber_front_
     d->dst = r; d->eval_pending = true; d->polls = 3;
     return 0;
 }
+// (k_wire_enc's stand-in: the host transcoder writes every RPC's bytes where the kernel would — or, for an RPC with an item error, nothing but the mark)
+namespace guber {
+constexpr uint32_t WIRE_ENC_ITEM_MAX = 37, WIRE_ENC_RAW = 0xffffffffu;
+static size_t wire_enc_off(uint32_t first, uint32_t r) { return ((size_t)first * WIRE_ENC_ITEM_MAX + (size_t)r * 32u) & ~(size_t)15; }
+static size_t wire_enc_bytes(uint32_t max_items, uint32_t max_rpcs) { return (size_t)max_items * WIRE_ENC_ITEM_MAX + (size_t)max_rpcs * 32u + 64u; }
+}
+static int wire_dev_eval_front_enc_async(guber_wire_dev* d, guber_front* f, uint8_t* enc, uint32_t* enc_len, guber_result_t* raw) {
+    d->enc = enc; d->enc_len = enc_len;
+    return guber_wire_dev_eval_front_async(d, f, raw);
+}
 extern "C" int guber_wire_dev_eval_collect(guber_wire_dev_t* d, int) {
     if (!d->eval_pending) return 0;
     if (d->polls-- > 0) return GUBER_PENDING;
@@ -118,6 +129,16 @@ extern "C" int guber_wire_dev_eval_collect(guber_wire_dev_t* d, int) {
     const size_t n = d->n_items;
     memcpy(d->dst->status, s->status, n); memcpy(d->dst->err, s->err, n);
     memcpy(d->dst->limit, s->limit, n * 8); memcpy(d->dst->remaining, s->remaining, n * 8); memcpy(d->dst->reset_time, s->reset_time, n * 8);
+    if (d->enc) for (uint32_t r = 0; r < d->nrpc; ++r) {
+        const uint32_t first = d->first[r], count = d->status[r] ? 0 : d->count[r];
+        bool bad = false;
+        for (uint32_t i = 0; i < count; ++i) bad = bad || s->err[first + i] != 0;
+        size_t used = 0;
+        if (bad) d->enc_len[r] = guber::WIRE_ENC_RAW;
+        else if (count == 0) d->enc_len[r] = 0;
+        else if (guber_wire_encode_responses(d->wb, first, count, 1, d->enc + guber::wire_enc_off(first, r), (size_t)count * guber::WIRE_ENC_ITEM_MAX, &used)) return GUBER_E_HIP;
+        else d->enc_len[r] = (uint32_t)used;
+    }
     return 0;
 }
 

@@ -72,6 +72,43 @@ def test_one_caller_gets_the_host_transcoders_bytes_around_the_oracle(n_engines)
     o.close(); wb.close()
 
 
+def test_long_rpcs_are_encoded_on_the_device_in_pieces():
+    """k_wire_enc (csrc/guber_kernels_wire.h) writes an RPC's GetRateLimitsResp in pieces of 1 024 items, the bytes that do not fill a
+    16-byte word carried into the next piece: RPCs of 1 .. 4 096 items (the 1000-item cap lifted), among them exactly 1 024, 1 025, 2 048
+    and 4 096, without item errors (the device's encoding) and with (the host transcoder's, from the raw answers) — the host transcoder's
+    bytes around the oracle, byte for byte; buckets run empty on the way (status and remaining change the items' widths)."""
+    rng = np.random.default_rng(77)
+    engs = _engines(2, cache_size=1 << 16, max_batch=8192, max_key_bytes=256)
+    place = ga.Placement(2)
+    pool = gw.WirePool(engs, place, stages=3, max_items=8192, max_payload_bytes=2 << 20, max_rpcs=64, max_per_rpc=0xffffffff)
+    o = support.Oracle(cache_size=1 << 20)
+    wb = gw.WireBatch(4096, 2 << 20)
+    now = NOW
+    sizes = [1, 2, 15, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 4095, 4096] + [int(x) for x in rng.integers(1025, 4097, 6)]
+    for k, n in enumerate(sizes):
+        with_errors = k % 5 == 4
+        reqs = rand_reqs(rng, n, bad=with_errors)
+        if not with_errors:                                      # (rand_reqs' DURATION_IS_GREGORIAN requests carry durations that are no interval: item errors)
+            for r in reqs:
+                r["behavior"] = int(rng.choice([0, 0, 2, 8, 32, 34, 1]))
+        payload = wire_replay.pb_request(reqs)
+        pool.set_clock(now)
+        wb.reset(now)
+        first, count = wb.decode(payload, max_per_rpc=0)
+        assert count == n
+        o.lib.oracle_eval_batch(o.h, C.byref(wb.view()), C.byref(wb.result()))
+        want = wb.encode(first, count, wrap_errors=True)
+        got = pool.get_rate_limits(payload)
+        assert got == want, f"RPC {k}: {n} requests"
+        assert with_errors == any(row[4] for row in wire_replay.rows_of(got))   # (which of the two encoders this RPC went through)
+        now += int(rng.integers(0, 2000))
+    pool.close()
+    for e in reversed(engs):
+        e.close()
+    place.close()
+    o.close(); wb.close()
+
+
 def test_messages_that_are_turned_away_whole():
     """a truncated message (the protobuf runtime's error), more than 1000 requests (gubernator.go:189-193): the call says so, nothing of the
     message is evaluated, and the RPCs that shared its stage are answered as if it had not been there"""
