@@ -1383,8 +1383,9 @@ def run_pool(args):
         res["best"] = {"case": best, "value": gated[best], "unit": "decisions/s", "note": "the largest gated rate among the cases above (`value` stays rpc_1000 through guber_pool_get_rate_limits, as in earlier rounds)"}
     res["host_cpus_usable"] = quota if quota else os.cpu_count()
     res["wire"] = ("wire_*: caller threads x SERIALIZED GetRateLimitsReq messages through guber_wire_pool_get_rate_limits (include/guber_wire.h): per RPC the host does one "
-                   "compare-and-swap, one memcpy and the response's varints; decode (k_wire_*), HashKey, XXH64, placement, evaluation and the answers' order on the device "
-                   "(guber_front); the callers parse the response bytes inside the clock (that is what the conservation gate reads)")
+                   "compare-and-swap and two memcpys (payload in, response out); decode (k_wire_*), HashKey, XXH64, placement, evaluation, the answers' order (guber_front) "
+                   "and the marshalling of GetRateLimitsResp (k_wire_enc) on the device; the callers parse the response bytes inside the clock (that is what the "
+                   "conservation gate reads)")
     res["workload"] = ("caller threads x RPCs through guber_pool_get_rate_limits (the C ABI a binding calls: structure-of-arrays in and out) -> GPUWorkerPool: "
                        "one dispatcher per device, fused launches over the shards' stages, placement on key hashes with online hot-key isolation, Zipf-1.1, "
                        "closed loop: front-end checks, HashKey, XXH64, placement, slot reservation, in-place stage filling, completion and response fan-out "
