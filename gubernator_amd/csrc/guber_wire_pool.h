@@ -551,7 +551,8 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
         if (st != GUBER_OK) rc = st;                                   // GUBER_E_WIRE_MALFORMED / GUBER_E_WIRE_TOO_LARGE: the whole message is turned away
         else {
             const uint32_t first = s.first[idx], count = s.count[idx];
-            const uint32_t el = p->host_encode ? guber::WIRE_ENC_RAW : s.enc_len.p[idx];
+            // (a message without a single RateLimitReq — unknown fields only — has no answers; when nothing of its stage had any, no kernel wrote enc_len)
+            const uint32_t el = p->host_encode ? guber::WIRE_ENC_RAW : count ? s.enc_len.p[idx] : 0u;
             bool any_err = !p->host_encode;                            // (not encoded on the device: an item carries an error, the raw answers are in s.r)
             if (p->host_encode) { const uint8_t* e8 = s.r.err + first; for (uint32_t i = 0; i < count; ++i) any_err = any_err || e8[i] != GUBER_ITEM_OK; }
             if (el != guber::WIRE_ENC_RAW) {

@@ -102,6 +102,10 @@ def test_long_rpcs_are_encoded_on_the_device_in_pieces():
         assert got == want, f"RPC {k}: {n} requests"
         assert with_errors == any(row[4] for row in wire_replay.rows_of(got))   # (which of the two encoders this RPC went through)
         now += int(rng.integers(0, 2000))
+    # a message that holds no RateLimitReq at all (an unknown varint field): alone in its stage nothing is evaluated and no kernel runs — an
+    # empty response, not what an earlier RPC left at that place of the stage
+    for _ in range(4):
+        assert pool.get_rate_limits(b"\x78\x01") == b""
     pool.close()
     for e in reversed(engs):
         e.close()
