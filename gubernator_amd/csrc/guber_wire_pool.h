@@ -119,6 +119,10 @@ struct guber_wire_pool {
     hipStream_t ws[2] = {nullptr, nullptr};            // the decodes' streams: consecutive stages alternate, so one stage's copy and latency-bound kernels run beside the other's
     uint32_t next_open = 0;
     uint32_t n_stages = 0, max_items = 0, max_b16 = 0, max_rpcs = 0, wait_us = 0, max_per_rpc = 0, item_cap = 0, spin_us = 0, decodes = 2;
+    // the direct path of a lone one-request RPC (wpl_direct): the placement's rule as the HOST applies it
+    struct HostRule { uint32_t n_shards = 1, per = 1, ex_cells = 0, ex_n = 0; int32_t global_engine = -1; uint64_t step = 0, inv_step = 0, inv_sub = 0;
+                      std::vector<uint16_t> table, ex_shard; std::vector<uint64_t> ex_hash; } hrule;
+    bool direct = true;
     bool host_encode = false;                           // laboratory build only: the callers write the responses' varints themselves (round 6's first form, for A/B runs)
     std::unique_ptr<Stage[]> stages;
     alignas(64) std::atomic<uint32_t> open_word{WPL_NONE};               // (sequence << 4) | stage index (15: none): futex word of callers waiting for a stage
@@ -412,6 +416,15 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
     p->n_stages = c.stages; p->max_items = c.max_items; p->max_b16 = c.max_payload_bytes / 16; p->max_rpcs = c.max_rpcs; p->wait_us = c.batch_wait_us;
     p->max_per_rpc = c.max_per_rpc == 0xffffffffu ? 0 : c.max_per_rpc; p->spin_us = c.spin_us; p->decodes = c.decodes_queued;
     p->cpus = wpl_usable_cpus();
+    if (rule && n_engines > 1) {
+        if (rule->n_shards == 0 || rule->per == 0 || !rule->table || (rule->ex_cells & (rule->ex_cells - 1)) || (rule->ex_n && (!rule->ex_hash || !rule->ex_shard || rule->ex_n >= rule->ex_cells)))
+            return fail(GUBER_E_INVALID_ARG, "malformed route rule");
+        guber_wire_pool::HostRule& H = p->hrule;
+        H.n_shards = rule->n_shards; H.per = rule->per; H.ex_cells = rule->ex_cells; H.ex_n = rule->ex_n; H.global_engine = rule->global_engine;
+        H.step = rule->step; H.inv_step = rule->inv_step; H.inv_sub = rule->inv_sub;
+        H.table.assign(rule->table, rule->table + (size_t)rule->n_shards * rule->per);
+        if (rule->ex_n) { H.ex_hash.assign(rule->ex_hash, rule->ex_hash + rule->ex_cells); H.ex_shard.assign(rule->ex_shard, rule->ex_shard + rule->ex_cells); }
+    }
     p->item_cap = std::min<uint32_t>(std::min<uint32_t>(c.max_items, 4096u), p->max_per_rpc ? p->max_per_rpc : 4096u);   // (an RPC holds at most min(max_items, 4096) items: guber_wire_dev_create)
     {
         const int rc = guber_front_create(engines, n_engines, rule, c.max_items, 4, &p->front);
@@ -421,6 +434,7 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
 #ifdef GUBER_LAB
     {   // (laboratory knob: the front's routing on the engines' one stream, which frees a hardware queue for the second decode stream:
         //  profiles/r06_wire_pool_hw_queues.txt — faster with 256 callers, slower with fewer)
+        if (const char* dv = guber_lab_env("GUBER_WIRE_DIRECT")) p->direct = atoi(dv) != 0;
         const char* he = guber_lab_env("GUBER_WIRE_HOST_ENCODE");
         p->host_encode = he && atoi(he) != 0;
         const char* v = guber_lab_env("GUBER_WIRE_ROUTE_ON_ENGINES");
@@ -466,6 +480,69 @@ extern "C" int guber_wire_pool_set_clock(guber_wire_pool_t* p, int64_t now_ms) {
     return GUBER_OK;
 }
 
+// ---- a lone RPC of ONE request (the reference's BenchmarkServer shape, benchmark_test.go:63-84; a lightly loaded daemon's usual call): nobody to share a
+// stage with, and a stage's way through the GPU is a dozen launches (~90 us).  While no other call is inside the pool the caller evaluates it itself: the host
+// transcoder (wire.cpp) parses the payload into a batch of the thread's own (pinned), the placement's rule picks the table exactly as k_fr_count does — XXH64 of
+// the HashKey, individually placed keys first, then slot -> shard; Behavior_GLOBAL to the GLOBAL engine —, guber_eval_batch takes the engine's one-launch
+// path in place (k_small: ~12 us), the host transcoder writes the response.  Same bytes (tests/test_gpu_wire_pool.py), no stage, no pool thread involved.
+// The moment a second caller is inside, everybody goes through the stages again and shares launches.
+static uint32_t wpl_route_host(const guber_wire_pool::HostRule& R, uint64_t h) {   // = route_engine (guber_kernels_route.h), on the host
+    if (R.ex_n) {
+        for (uint32_t i = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 56) & (R.ex_cells - 1);; i = (i + 1) & (R.ex_cells - 1)) {
+            const uint64_t x = R.ex_hash[i];
+            if (x == h) return R.ex_shard[i];
+            if (x == 0ull) break;
+        }
+    }
+    auto mulhi = [](uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); };
+    const uint64_t h63 = h >> 1;
+    uint64_t w = mulhi(h63, R.inv_step);
+    if ((w + 1) * R.step <= h63) ++w;
+    if (w >= R.n_shards) w = R.n_shards - 1;
+    uint64_t sub = mulhi(h63 - w * R.step, R.inv_sub);
+    if (sub >= R.per) sub = R.per - 1;
+    return R.table[(size_t)(w * R.per + sub)];
+}
+namespace {
+struct WplThreadBatch { guber_wire_batch_t* wb = nullptr; bool failed = false; ~WplThreadBatch() { if (wb) guber_wire_batch_destroy(wb); } };
+constexpr size_t WPL_DIRECT_MAX_BYTES = 2048;
+}
+// returns true when the call has been answered (rc, used); false: not for this path, nothing has happened
+static bool wpl_direct(guber_wire_pool* p, const uint8_t* req, size_t len, int is_owner, int wrap_errors, uint8_t* resp, size_t cap, size_t* used, int* rc_out) {
+    thread_local WplThreadBatch tl;
+    if (tl.failed) return false;
+    if (!tl.wb) {
+        (void)hipSetDevice(p->device);
+        if (guber_wire_batch_create(4, (uint32_t)(2 * WPL_DIRECT_MAX_BYTES), GUBER_WIRE_PINNED, &tl.wb) != GUBER_OK) { tl.wb = nullptr; tl.failed = true; return false; }
+    }
+    guber_wire_batch_reset(tl.wb, wpl_now_ms(p));
+    uint32_t f0 = 0, c0 = 0;
+    int rc = guber_wire_decode_requests(tl.wb, req, len, p->max_per_rpc, is_owner ? 1 : 0, &f0, &c0);
+    if (rc == GUBER_E_WIRE_FULL || (rc == GUBER_OK && c0 > 1)) return false;                  // (not what the bound promised: the stages take it)
+    *used = 0;
+    if (rc == GUBER_OK && c0 == 1) {
+        const guber_batch_t* v = guber_wire_batch_view(tl.wb);
+        uint32_t e = 0;
+        const uint32_t ne = (uint32_t)p->eng.size();
+        if (ne > 1) {
+            const uint32_t klen = v->key_off[1] - v->key_off[0];
+            if (p->hrule.global_engine >= 0 && v->behavior && (v->behavior[0] & 2u)) e = (uint32_t)p->hrule.global_engine;
+            else if (klen != 0 && p->hrule.n_shards > 1) e = wpl_route_host(p->hrule, guber_xxhash64(v->key_bytes + v->key_off[0], klen, 0));
+            if (e >= ne) e = 0;
+        }
+        rc = guber_eval_batch(p->eng[e], v, guber_wire_batch_result(tl.wb));
+        if (rc == GUBER_OK) {
+            rc = guber_wire_encode_responses(tl.wb, 0, 1, wrap_errors, resp, cap, used);
+            if (rc == GUBER_E_NOMEM) fail(GUBER_E_NOMEM, "response buffer too small (the decisions HAVE been applied): guber_wire_pool_response_bound()");
+        }
+        p->st_items.fetch_add(1, std::memory_order_relaxed);
+    } else if (rc != GUBER_OK) fail(rc, "guber_wire_pool: the message is turned away whole");
+    // (a batch of its own: counted among the stages that left because nothing else was there)
+    p->st_rpcs.fetch_add(1, std::memory_order_relaxed); p->st_stages.fetch_add(1, std::memory_order_relaxed); p->st_eager.fetch_add(1, std::memory_order_relaxed);
+    *rc_out = rc;
+    return true;
+}
+
 extern "C" size_t guber_wire_pool_response_bound(const uint8_t* req, size_t len) {
     // per item: tag + length + four varint fields (37 bytes), or an error: wrapper text + message (<= 310 bytes) + its key (the keys of a payload: <= len + one '_' each)
     const size_t items = req ? wpl_item_bound(req, len, 4096) : 0;
@@ -493,6 +570,10 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
     const uint32_t bound = std::max(1u, wpl_item_bound(req, len, p->item_cap));
     if (cap < (size_t)bound * 37 && cap < guber_wire_pool_response_bound(req, len)) { *resp_len = guber_wire_pool_response_bound(req, len); return fail(GUBER_E_NOMEM, "response buffer below guber_wire_pool_response_bound()"); }
     struct Inside { std::atomic<uint32_t>& c; uint32_t n; explicit Inside(std::atomic<uint32_t>& x) : c(x), n(x.fetch_add(1, std::memory_order_relaxed) + 1) {} ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); } } inside(p->inside);
+    if (bound == 1 && inside.n == 1 && p->direct && len <= WPL_DIRECT_MAX_BYTES && !p->closed.load(std::memory_order_acquire)) {
+        size_t used = 0; int rc = GUBER_OK;
+        if (wpl_direct(p, req, len, is_owner, wrap_errors, resp, cap, &used, &rc)) { *resp_len = used; return rc; }
+    }
     // looking (spinning) is for callers that have a CPU to themselves: the pool's two threads need theirs, the others sleep at once
     const bool may_spin = p->spin_us && inside.n + 1 <= p->cpus / 2;
     // ---- a place in the open stage

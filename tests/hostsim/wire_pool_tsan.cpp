@@ -42,11 +42,15 @@ template <typename T> struct CohBuf : PinBuf<T> {};
 struct guber_engine { int device = 0; };
 extern "C" void* guber_alloc_pinned(size_t n) { return calloc(1, n ? n : 1); }     // (wire.cpp's GUBER_WIRE_PINNED batches: not used here)
 extern "C" void guber_free_pinned(void* p) { free(p); }
-extern "C" int guber_eval_batch(guber_engine_t*, const guber_batch_t*, guber_result_t*) { return GUBER_E_NO_DEVICE; }   // (wire.cpp's guber_wire_eval: not used here)
-
-// the stand-in decoder: payloads -> ONE host batch (wire.cpp), "decoded" after a few polls; evaluated by the oracle, "answered" after a few more
 static oracle_t* g_oracle;
 static std::mutex g_oracle_mu;
+extern "C" int guber_eval_batch(guber_engine_t*, const guber_batch_t* b, guber_result_t* r) {   // (the pool's direct path of a lone one-request RPC)
+    std::lock_guard<std::mutex> lk(g_oracle_mu);
+    oracle_eval_batch(g_oracle, b, r);
+    return GUBER_OK;
+}
+
+// the stand-in decoder: payloads -> ONE host batch (wire.cpp), "decoded" after a few polls; evaluated by the oracle, "answered" after a few more
 struct guber_front { int dummy = 0; bool pre_routed = false; };
 struct guber_wire_dev {
     uint32_t max_items, max_bytes, max_rpcs;

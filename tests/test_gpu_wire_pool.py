@@ -72,6 +72,50 @@ def test_one_caller_gets_the_host_transcoders_bytes_around_the_oracle(n_engines)
     o.close(); wb.close()
 
 
+@pytest.mark.parametrize("n_engines", [1, 4])
+def test_a_lone_one_request_rpc_is_evaluated_by_its_caller(n_engines):
+    """guber_wire_pool.h wpl_direct: while nobody else is inside the pool an RPC of ONE request skips the stages — host transcoder, the
+    placement's rule on the host (the table k_fr_count would pick: the buckets are shared with the stages), the engine's one-launch path,
+    host transcoder.  One-request RPCs (every kind of request, errors included) between RPCs of several requests that go through the
+    stages, on the same keys: every response equals the host transcoder's around ONE oracle fed the same sequence."""
+    rng = np.random.default_rng(91 + n_engines)
+    engs = _engines(n_engines, cache_size=1 << 16, max_batch=8192, max_key_bytes=256)
+    place = ga.Placement(n_engines) if n_engines > 1 else None
+    pool = gw.WirePool(engs, place, **SMALL)
+    o = support.Oracle(cache_size=1 << 20)
+    wb = gw.WireBatch(4096, 1 << 20)
+    now = NOW
+    singles = 0
+    for k in range(240):
+        n = 1 if k % 4 != 3 else int(rng.integers(2, 40))
+        reqs = rand_reqs(rng, n, bad=(k % 3 == 0))
+        for r in reqs:                                           # few keys: the two paths meet on the same buckets all the time
+            if r["unique_key"].startswith("acct:"):
+                r["unique_key"] = "acct:%d" % rng.integers(0, 12)
+        payload = wire_replay.pb_request(reqs, peer=bool(k & 1))
+        pool.set_clock(now)
+        got = pool.get_rate_limits(payload, wrap_errors=not (k & 2))
+        want = _expected(o, wb, payload, now, wrap=not (k & 2))
+        assert got == want, f"RPC {k}: {n} request(s) {reqs[:1]}"
+        singles += n == 1
+        now += int(rng.integers(0, 400))
+        if k == 2:                                               # three one-request RPCs so far: no stage has been through the decoder
+            st = pool.stats()
+            assert st["rpcs"] == 3 and st["host_decode_ns"] == 0 and st["decode_us_sum"] == 0
+    st = pool.stats()
+    assert st["host_decode_ns"] > 0                              # (the RPCs of several requests went through the stages)
+    assert st["rpcs"] == 240 and st["stages"] == 240 and singles == 180   # (an RPC evaluated by its caller counts as a batch of its own)
+    with pytest.raises(ga.GuberError) as ei:                     # a truncated one-request message: the runtimes' verdict, from this path too
+        pool.get_rate_limits(wire_replay.pb_request(rand_reqs(rng, 1, bad=False))[:-2])
+    assert ei.value.code == -20
+    pool.close()
+    for e in reversed(engs):
+        e.close()
+    if place:
+        place.close()
+    o.close(); wb.close()
+
+
 def test_long_rpcs_are_encoded_on_the_device_in_pieces():
     """k_wire_enc (csrc/guber_kernels_wire.h) writes an RPC's GetRateLimitsResp in pieces of 1 024 items, the bytes that do not fill a
     16-byte word carried into the next piece: RPCs of 1 .. 4 096 items (the 1000-item cap lifted), among them exactly 1 024, 1 025, 2 048
