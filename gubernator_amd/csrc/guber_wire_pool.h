@@ -122,7 +122,11 @@ struct guber_wire_pool {
     // the direct path of a lone one-request RPC (wpl_direct): the placement's rule as the HOST applies it
     struct HostRule { uint32_t n_shards = 1, per = 1, ex_cells = 0, ex_n = 0; int32_t global_engine = -1; uint64_t step = 0, inv_step = 0, inv_sub = 0;
                       std::vector<uint16_t> table, ex_shard; std::vector<uint64_t> ex_hash; } hrule;
-    bool direct = true;
+    // callers inside the pool up to which a one-request RPC is evaluated by its caller (0: never).  Measured (profiles/r06_wire_direct.txt, 8 tables, p50 of a
+    // 1-item RPC): 1 / 2 / 4 / 8 callers 12 / 15 / 23 / 38 us against 86 / 105 / 139 / 212 us through the stages, 0.13 against 0.04 M/s; from 16 callers on the
+    // launches of many threads queue up in the runtime and on the engines' locks (p99 0.8 ms with 16, 2 ms with 32) while the stages' shared launches keep
+    // p99 under 0.45 ms and overtake in throughput near 48 callers — so: up to 8
+    uint32_t direct_max = 8;
     bool host_encode = false;                           // laboratory build only: the callers write the responses' varints themselves (round 6's first form, for A/B runs)
     std::unique_ptr<Stage[]> stages;
     alignas(64) std::atomic<uint32_t> open_word{WPL_NONE};               // (sequence << 4) | stage index (15: none): futex word of callers waiting for a stage
@@ -434,7 +438,7 @@ extern "C" int guber_wire_pool_create(guber_engine_t* const* engines, uint32_t n
 #ifdef GUBER_LAB
     {   // (laboratory knob: the front's routing on the engines' one stream, which frees a hardware queue for the second decode stream:
         //  profiles/r06_wire_pool_hw_queues.txt — faster with 256 callers, slower with fewer)
-        if (const char* dv = guber_lab_env("GUBER_WIRE_DIRECT")) p->direct = atoi(dv) != 0;
+        if (const char* dv = guber_lab_env("GUBER_WIRE_DIRECT")) p->direct_max = (uint32_t)atoi(dv);
         const char* he = guber_lab_env("GUBER_WIRE_HOST_ENCODE");
         p->host_encode = he && atoi(he) != 0;
         const char* v = guber_lab_env("GUBER_WIRE_ROUTE_ON_ENGINES");
@@ -480,12 +484,13 @@ extern "C" int guber_wire_pool_set_clock(guber_wire_pool_t* p, int64_t now_ms) {
     return GUBER_OK;
 }
 
-// ---- a lone RPC of ONE request (the reference's BenchmarkServer shape, benchmark_test.go:63-84; a lightly loaded daemon's usual call): nobody to share a
-// stage with, and a stage's way through the GPU is a dozen launches (~90 us).  While no other call is inside the pool the caller evaluates it itself: the host
+// ---- an RPC of ONE request while the pool is nearly idle (the reference's BenchmarkServer shape, benchmark_test.go:63-84; a lightly loaded daemon's usual call):
+// hardly anybody to share a stage with, and a stage's way through the GPU is a dozen launches (~90 us).  While at most direct_max calls are inside the pool the
+// caller evaluates it itself: the host
 // transcoder (wire.cpp) parses the payload into a batch of the thread's own (pinned), the placement's rule picks the table exactly as k_fr_count does — XXH64 of
 // the HashKey, individually placed keys first, then slot -> shard; Behavior_GLOBAL to the GLOBAL engine —, guber_eval_batch takes the engine's one-launch
 // path in place (k_small: ~12 us), the host transcoder writes the response.  Same bytes (tests/test_gpu_wire_pool.py), no stage, no pool thread involved.
-// The moment a second caller is inside, everybody goes through the stages again and shares launches.
+// With more than direct_max callers inside, everybody goes through the stages again and shares launches.
 static uint32_t wpl_route_host(const guber_wire_pool::HostRule& R, uint64_t h) {   // = route_engine (guber_kernels_route.h), on the host
     if (R.ex_n) {
         for (uint32_t i = (uint32_t)((h * 0x9E3779B97F4A7C15ull) >> 56) & (R.ex_cells - 1);; i = (i + 1) & (R.ex_cells - 1)) {
@@ -570,7 +575,7 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
     const uint32_t bound = std::max(1u, wpl_item_bound(req, len, p->item_cap));
     if (cap < (size_t)bound * 37 && cap < guber_wire_pool_response_bound(req, len)) { *resp_len = guber_wire_pool_response_bound(req, len); return fail(GUBER_E_NOMEM, "response buffer below guber_wire_pool_response_bound()"); }
     struct Inside { std::atomic<uint32_t>& c; uint32_t n; explicit Inside(std::atomic<uint32_t>& x) : c(x), n(x.fetch_add(1, std::memory_order_relaxed) + 1) {} ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); } } inside(p->inside);
-    if (bound == 1 && inside.n == 1 && p->direct && len <= WPL_DIRECT_MAX_BYTES && !p->closed.load(std::memory_order_acquire)) {
+    if (bound == 1 && inside.n <= p->direct_max && len <= WPL_DIRECT_MAX_BYTES && !p->closed.load(std::memory_order_acquire)) {
         size_t used = 0; int rc = GUBER_OK;
         if (wpl_direct(p, req, len, is_owner, wrap_errors, resp, cap, &used, &rc)) { *resp_len = used; return rc; }
     }
