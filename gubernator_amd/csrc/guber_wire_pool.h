@@ -484,7 +484,7 @@ extern "C" int guber_wire_pool_set_clock(guber_wire_pool_t* p, int64_t now_ms) {
     return GUBER_OK;
 }
 
-// ---- an RPC of ONE request while the pool is nearly idle (the reference's BenchmarkServer shape, benchmark_test.go:63-84; a lightly loaded daemon's usual call):
+// ---- an RPC of at most WPL_DIRECT_ITEMS (four) requests while the pool is nearly idle (the reference's BenchmarkServer shape, benchmark_test.go:63-84; a lightly loaded daemon's usual call):
 // hardly anybody to share a stage with, and a stage's way through the GPU is a dozen launches (~90 us).  While at most direct_max calls are inside the pool the
 // caller evaluates it itself: the host
 // transcoder (wire.cpp) parses the payload into a batch of the thread's own (pinned), the placement's rule picks the table exactly as k_fr_count does — XXH64 of
@@ -511,6 +511,7 @@ static uint32_t wpl_route_host(const guber_wire_pool::HostRule& R, uint64_t h) {
 namespace {
 struct WplThreadBatch { guber_wire_batch_t* wb = nullptr; bool failed = false; ~WplThreadBatch() { if (wb) guber_wire_batch_destroy(wb); } };
 constexpr size_t WPL_DIRECT_MAX_BYTES = 2048;
+constexpr uint32_t WPL_DIRECT_ITEMS = 4;      // requests an RPC may hold to be evaluated by its caller (the per-request pool's GUBER_POOL_DIRECT_MAX)
 }
 // returns true when the call has been answered (rc, used); false: not for this path, nothing has happened
 static bool wpl_direct(guber_wire_pool* p, const uint8_t* req, size_t len, int is_owner, int wrap_errors, uint8_t* resp, size_t cap, size_t* used, int* rc_out) {
@@ -523,24 +524,46 @@ static bool wpl_direct(guber_wire_pool* p, const uint8_t* req, size_t len, int i
     guber_wire_batch_reset(tl.wb, wpl_now_ms(p));
     uint32_t f0 = 0, c0 = 0;
     int rc = guber_wire_decode_requests(tl.wb, req, len, p->max_per_rpc, is_owner ? 1 : 0, &f0, &c0);
-    if (rc == GUBER_E_WIRE_FULL || (rc == GUBER_OK && c0 > 1)) return false;                  // (not what the bound promised: the stages take it)
+    if (rc == GUBER_E_WIRE_FULL || (rc == GUBER_OK && c0 > WPL_DIRECT_ITEMS)) return false;                  // (not what the bound promised: the stages take it)
     *used = 0;
-    if (rc == GUBER_OK && c0 == 1) {
+    if (rc == GUBER_OK && c0 >= 1) {
         const guber_batch_t* v = guber_wire_batch_view(tl.wb);
-        uint32_t e = 0;
+        guber_result_t* r = guber_wire_batch_result(tl.wb);
         const uint32_t ne = (uint32_t)p->eng.size();
+        uint32_t eng[WPL_DIRECT_ITEMS] = {0, 0, 0, 0};
+        bool same = true;
         if (ne > 1) {
-            const uint32_t klen = v->key_off[1] - v->key_off[0];
-            if (p->hrule.global_engine >= 0 && v->behavior && (v->behavior[0] & 2u)) e = (uint32_t)p->hrule.global_engine;
-            else if (klen != 0 && p->hrule.n_shards > 1) e = wpl_route_host(p->hrule, guber_xxhash64(v->key_bytes + v->key_off[0], klen, 0));
-            if (e >= ne) e = 0;
+            for (uint32_t i = 0; i < c0; ++i) {
+                const uint32_t klen = v->key_off[i + 1] - v->key_off[i];
+                uint32_t e = i ? eng[i - 1] : 0u;                     // (an item without a key never reaches a bucket: it goes along with its neighbour)
+                if (klen != 0) {
+                    if (p->hrule.global_engine >= 0 && v->behavior && (v->behavior[i] & 2u)) e = (uint32_t)p->hrule.global_engine;
+                    else if (p->hrule.n_shards > 1) e = wpl_route_host(p->hrule, guber_xxhash64(v->key_bytes + v->key_off[i], klen, 0));
+                    else e = 0;
+                    if (e >= ne) e = 0;
+                }
+                eng[i] = e;
+                same = same && e == eng[0];
+            }
         }
-        rc = guber_eval_batch(p->eng[e], v, guber_wire_batch_result(tl.wb));
+        if (same) rc = guber_eval_batch(p->eng[eng[0]], v, r);         // one launch for the RPC
+        else for (uint32_t i = 0; i < c0 && rc == GUBER_OK; ++i) {      // its requests live on several tables: one after the other, in the RPC's order
+            guber_batch_t sv = *v; guber_result_t sr = *r;
+            sv.n = 1; sv.key_off = v->key_off + i; sv.hits = v->hits + i; sv.limit = v->limit + i; sv.duration = v->duration + i;
+            if (v->burst) sv.burst = v->burst + i;
+            if (v->created_at) sv.created_at = v->created_at + i;
+            sv.algorithm = v->algorithm + i; sv.behavior = v->behavior + i;
+            if (v->is_owner) sv.is_owner = v->is_owner + i;
+            if (v->greg_expire) sv.greg_expire = v->greg_expire + i;
+            if (v->greg_duration) sv.greg_duration = v->greg_duration + i;
+            sr.status = r->status + i; sr.limit = r->limit + i; sr.remaining = r->remaining + i; sr.reset_time = r->reset_time + i; sr.err = r->err + i;
+            rc = guber_eval_batch(p->eng[eng[i]], &sv, &sr);
+        }
         if (rc == GUBER_OK) {
-            rc = guber_wire_encode_responses(tl.wb, 0, 1, wrap_errors, resp, cap, used);
+            rc = guber_wire_encode_responses(tl.wb, 0, c0, wrap_errors, resp, cap, used);
             if (rc == GUBER_E_NOMEM) fail(GUBER_E_NOMEM, "response buffer too small (the decisions HAVE been applied): guber_wire_pool_response_bound()");
         }
-        p->st_items.fetch_add(1, std::memory_order_relaxed);
+        p->st_items.fetch_add(c0, std::memory_order_relaxed);
     } else if (rc != GUBER_OK) fail(rc, "guber_wire_pool: the message is turned away whole");
     // (a batch of its own: counted among the stages that left because nothing else was there)
     p->st_rpcs.fetch_add(1, std::memory_order_relaxed); p->st_stages.fetch_add(1, std::memory_order_relaxed); p->st_eager.fetch_add(1, std::memory_order_relaxed);
@@ -575,7 +598,7 @@ extern "C" int guber_wire_pool_get_rate_limits(guber_wire_pool_t* p, const uint8
     const uint32_t bound = std::max(1u, wpl_item_bound(req, len, p->item_cap));
     if (cap < (size_t)bound * 37 && cap < guber_wire_pool_response_bound(req, len)) { *resp_len = guber_wire_pool_response_bound(req, len); return fail(GUBER_E_NOMEM, "response buffer below guber_wire_pool_response_bound()"); }
     struct Inside { std::atomic<uint32_t>& c; uint32_t n; explicit Inside(std::atomic<uint32_t>& x) : c(x), n(x.fetch_add(1, std::memory_order_relaxed) + 1) {} ~Inside() { c.fetch_sub(1, std::memory_order_relaxed); } } inside(p->inside);
-    if (bound == 1 && inside.n <= p->direct_max && len <= WPL_DIRECT_MAX_BYTES && !p->closed.load(std::memory_order_acquire)) {
+    if (bound <= WPL_DIRECT_ITEMS && inside.n <= p->direct_max && len <= WPL_DIRECT_MAX_BYTES && !p->closed.load(std::memory_order_acquire)) {
         size_t used = 0; int rc = GUBER_OK;
         if (wpl_direct(p, req, len, is_owner, wrap_errors, resp, cap, &used, &rc)) { *resp_len = used; return rc; }
     }

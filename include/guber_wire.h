@@ -175,7 +175,7 @@ int guber_wire_dev_route_ready(guber_wire_dev_t* d, guber_front_t* f);
  *      Unmarshalling, validation, the CreatedAt default, HashKey, the worker's choice by XXH64 (workers.go:180-184), the evaluation, the
  *      answers' order and the marshalling of GetRateLimitsResp (gubernator.proto:184-203) all happen on the device: k_wire_* -> guber_front ->
  *      k_wire_enc, which writes every RPC's response bytes in place into host memory.  (An RPC with an item error is marshalled by the host
- *      transcoder from the raw answers: the error's text needs the item's key.)  An RPC of ONE request that finds at most eight calls inside the
+ *      transcoder from the raw answers: the error's text needs the item's key.)  An RPC of at most FOUR requests that finds at most eight calls inside the
  *      pool skips the stages: its caller evaluates it through the engine's one-launch path (host transcoder, the placement's rule on the host,
  *      guber_eval_batch) — 12 us instead of a stage's 90; same bytes.
  *   guber_wire_pool_create            over the engines of ONE device and the placement's rule (as guber_front_create; rule NULL with one engine);

@@ -73,11 +73,12 @@ def test_one_caller_gets_the_host_transcoders_bytes_around_the_oracle(n_engines)
 
 
 @pytest.mark.parametrize("n_engines", [1, 4])
-def test_a_lone_one_request_rpc_is_evaluated_by_its_caller(n_engines):
-    """guber_wire_pool.h wpl_direct: while nobody else is inside the pool an RPC of ONE request skips the stages — host transcoder, the
-    placement's rule on the host (the table k_fr_count would pick: the buckets are shared with the stages), the engine's one-launch path,
-    host transcoder.  One-request RPCs (every kind of request, errors included) between RPCs of several requests that go through the
-    stages, on the same keys: every response equals the host transcoder's around ONE oracle fed the same sequence."""
+def test_a_small_rpc_in_an_idle_pool_is_evaluated_by_its_caller(n_engines):
+    """guber_wire_pool.h wpl_direct: while (almost) nobody else is inside the pool an RPC of at most FOUR requests skips the stages — host
+    transcoder, the placement's rule on the host (the table k_fr_count would pick: the buckets are shared with the stages), the engine's
+    one-launch path (request by request when the RPC's requests live on several tables), host transcoder.  RPCs of 1 .. 4 requests (every
+    kind of request, errors included) between RPCs of 5 .. 39 that go through the stages, on the same keys: every response equals the
+    host transcoder's around ONE oracle fed the same sequence."""
     rng = np.random.default_rng(91 + n_engines)
     engs = _engines(n_engines, cache_size=1 << 16, max_batch=8192, max_key_bytes=256)
     place = ga.Placement(n_engines) if n_engines > 1 else None
@@ -87,7 +88,7 @@ def test_a_lone_one_request_rpc_is_evaluated_by_its_caller(n_engines):
     now = NOW
     singles = 0
     for k in range(240):
-        n = 1 if k % 4 != 3 else int(rng.integers(2, 40))
+        n = (1 if k < 3 else int(rng.integers(1, 5))) if k % 4 != 3 else int(rng.integers(5, 40))   # (up to four requests: the caller's own)
         reqs = rand_reqs(rng, n, bad=(k % 3 == 0))
         for r in reqs:                                           # few keys: the two paths meet on the same buckets all the time
             if r["unique_key"].startswith("acct:"):
@@ -97,7 +98,7 @@ def test_a_lone_one_request_rpc_is_evaluated_by_its_caller(n_engines):
         got = pool.get_rate_limits(payload, wrap_errors=not (k & 2))
         want = _expected(o, wb, payload, now, wrap=not (k & 2))
         assert got == want, f"RPC {k}: {n} request(s) {reqs[:1]}"
-        singles += n == 1
+        singles += n <= 4
         now += int(rng.integers(0, 400))
         if k == 2:                                               # three one-request RPCs so far: no stage has been through the decoder
             st = pool.stats()
