@@ -295,7 +295,10 @@ int main(int argc, char** argv) {
         // (with GUBER_POOL_MAX_ACTIVE the dispatcher keeps so little in flight that whether a caller ever finds the device idle is a
         // matter of scheduling: seen 0 of 2541 on a loaded 8-core host; the direct path has its own configuration in tests/test_pool_cpu.py)
         const bool few_active = getenv("GUBER_POOL_MAX_ACTIVE") != nullptr;
-        CHECK((m.direct_batches > 0 || !eager || few_active) && m.batches >= m.direct_batches, "direct %llu of %llu batches", (unsigned long long)m.direct_batches, (unsigned long long)m.batches);
+        // (the same with the laboratory's device routing, whose generations wait GUBER_STUB_ROUTE_LAT_US for their shares' sizes: ten callers in a closed loop
+        // then hardly ever find at most shards / 2 calls in progress — seen 0 of 2161 on this 8-core host under load at the end of round 6, once in ~90 runs)
+        const bool dev_routes = getenv("GUBER_POOL_DEVROUTE") && atoi(getenv("GUBER_POOL_DEVROUTE")) != 0;
+        CHECK((m.direct_batches > 0 || !eager || few_active || dev_routes) && m.batches >= m.direct_batches, "direct %llu of %llu batches", (unsigned long long)m.direct_batches, (unsigned long long)m.batches);
         printf("small RPCs: %llu batches of which %llu evaluated by their callers, %llu hot keys moved, failures so far %d\n", (unsigned long long)m.batches,
                (unsigned long long)m.direct_batches, (unsigned long long)m.keys_moved, failures);
     }
